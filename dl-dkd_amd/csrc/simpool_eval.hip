@@ -1,0 +1,357 @@
+// simpool (eval): all-pairs  score[q, v] = max_{l < len_v} < q_hat[q], g_hat[v, l] >  for 1-2 branches
+// and their weighted fusion.  Replaces DLDKD.get_sim_scores (reference method/model.py:307-329) as
+// driven by compute_query2ctx_info (method/eval.py:200-208) and the fusion at method/eval.py:254.
+//
+// MI355X design (DESIGN.md section "K1"):
+//   * The contraction is [clips x 384] . [384 x queries] on bf16 MFMA 32x32x16 with CLIPS as the MFMA
+//     row index and QUERIES on the lanes, so the 32x32 fp32 result has one query per lane and the
+//     clip rows in the 16 accumulator registers: the key-clip max-pool is in-register v_max3 plus one
+//     cross-half exchange.  The (Nq, L, Nv) clip tensor of the reference is never materialised.
+//   * GALLERY-STATIONARY IN REGISTERS: a wave owns one (video, branch): all 128 clips x 384 dims
+//     (96 KiB) live in 384 of the wave's 512 registers for the wave's whole life; one wave per SIMD,
+//     4 videos per CU.  The gallery is read from HBM exactly once.
+//   * The queries are pre-packed into MFMA B-fragment order and streamed L2 -> LDS by LDS-DMA in 24 KiB
+//     tiles (32 queries) shared by the workgroup's 4 waves, double-buffered, one barrier per tile.
+//     Each B fragment read from LDS feeds up to 4 MFMAs (0.25 KiB of LDS read per MFMA).
+//   * ragged videos: only ceil(len/32) row tiles are computed (wave-uniform template dispatch); videos
+//     are visited in a caller-given order (descending length balances the 4 waves of a workgroup).
+#include "common.hpp"
+
+namespace dldkd {
+
+constexpr int kKSteps = kHidden / 16;          // 24 MFMA k-steps
+constexpr int kQTile = 32;                     // queries per B fragment / per LDS tile
+constexpr int kQTileBytes = kKSteps * 1024;    // 24 KiB: [24 k-steps][64 lanes][8 bf16]
+constexpr int kRowBf16x8 = kHidden / 8;        // 48 16-byte chunks per gallery row
+
+__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ----------------------------------------------------------------------------------------------
+// packers (fp32 -> normalised bf16).  Tiny, bandwidth-bound, vectorised 16-byte stores.
+// ----------------------------------------------------------------------------------------------
+// Packed query layout: [tile = q/32][k-step ks][lane = 32*h + (q%32)][8 bf16 = k 16ks + 8h ..+8]
+// = the B operand of mfma_f32_32x32x16_bf16 (cdna_hip_programming.md section 3 lane maps).
+__global__ __launch_bounds__(256) void pack_queries_kernel(const float* __restrict__ q, int nq, int nq_pad,
+                                                           int normalize, bf16x8* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq_pad) return;
+    float v[8];
+    float ss = 0.f;
+    const bool act = lane < kRowBf16x8 && qi < nq;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (act) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(q + (size_t)qi * kHidden + lane * 8);
+        f32x4 a = src[0], b = src[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+    }
+    float scale = 1.f;
+    if (normalize) {
+        ss = wave_sum(ss);
+        scale = 1.f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize eps, model.py:318
+    }
+    if (lane < kRowBf16x8) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (short)f32_to_bf16_bits(v[j] * scale);
+        const int ks = lane >> 1, h = lane & 1;
+        out[((size_t)(qi >> 5) * kKSteps + ks) * 64 + h * 32 + (qi & 31)] = o;
+    }
+}
+
+// Gallery blob: row-major bf16 [nv][Lp][384], Lp = round_up(L, 32); rows l >= len_v are zero.
+__global__ __launch_bounds__(256) void pack_gallery_kernel(const float* __restrict__ g, const float* __restrict__ mask,
+                                                           int nv, int L, int Lp, int normalize,
+                                                           bf16x8* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)nv * Lp) return;
+    const int v = (int)(row / Lp), l = (int)(row % Lp);
+    const bool valid = l < L && (mask == nullptr || mask[(size_t)v * L + l] > 0.f);
+    float x[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = 0.f;
+    if (valid && lane < kRowBf16x8) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(g + ((size_t)v * L + l) * kHidden + lane * 8);
+        f32x4 a = src[0], b = src[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[j] = a[j]; x[4 + j] = b[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+    }
+    float scale = 1.f;
+    if (normalize) {
+        ss = wave_sum(ss);
+        scale = 1.f / fmaxf(sqrtf(ss), 1e-12f);   // model.py:319
+    }
+    if (lane < kRowBf16x8) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (short)f32_to_bf16_bits(x[j] * scale);
+        out[(size_t)row * kRowBf16x8 + lane] = o;
+    }
+}
+
+// lens[v] = number of mask entries > 0 (compute_kl_loss counts them the same way, model.py:192;
+// masks are prefix masks, data_provider.py:81-84).
+__global__ __launch_bounds__(256) void mask_lens_kernel(const float* __restrict__ mask, int nv, int L,
+                                                        int32_t* __restrict__ lens) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= nv) return;
+    float c = 0.f;
+    for (int l = lane; l < L; l += 64) c += (mask == nullptr || mask[(size_t)v * L + l] > 0.f) ? 1.f : 0.f;
+    c = wave_sum(c);
+    if (lane == 0) lens[v] = (int32_t)c;
+}
+
+// ----------------------------------------------------------------------------------------------
+// the scorer
+// ----------------------------------------------------------------------------------------------
+struct SimpoolEvalArgs {
+    const bf16x8* q[2];      // packed queries per branch
+    const bf16x8* g[2];      // gallery blobs per branch
+    const int32_t* lens;     // [nv]
+    const int32_t* order;    // [nv] visiting order (sorted position -> video id)
+    float* part;             // [n_branches][nv (sorted position)][nq_pad] partial pooled scores
+    int nq_pad, nv, Lp, n_qtiles, n_groups;
+};
+
+// Row r of a 32x32 accumulator register set lives at clip (r&3) + 8*(r>>2) + 4*(lane>>5) of the row tile
+// (cdna_hip_programming.md section 3).
+__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
+
+template <int NRT>
+__device__ __forceinline__ void score_stream(const bf16x8 (&a)[4][kKSteps], const SimpoolEvalArgs& p, int branch,
+                                             int vs, int len, char* smem) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const char* qsrc = reinterpret_cast<const char*>(p.q[branch]);
+    // clips of the LAST row tile at or beyond `lim` (in this lane's half) are padding
+    const int lim = len - 32 * (NRT - 1) - 4 * (lane >> 5);
+    float* outp = (NRT > 0) ? p.part + ((size_t)branch * p.nv + vs) * p.nq_pad + (lane & 31) : nullptr;
+
+    auto stage = [&](int t) {
+        char* dst = smem + (t & 1) * kQTileBytes;
+        const char* src = qsrc + (size_t)t * kQTileBytes;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int piece = wave * 6 + i;
+            glds16(src + piece * 1024 + lane * 16, dst + piece * 1024);
+        }
+    };
+
+    stage(0);
+    float pending = 0.f;   // result of tile t-1, stored one tile late so its write latency is hidden
+    for (int t = 0; t < p.n_qtiles; ++t) {
+        __syncthreads();   // tile t has landed (each wave drained its DMA); everyone is done with tile t-1
+        if (t + 1 < p.n_qtiles) stage(t + 1);
+        if constexpr (NRT > 0) {
+            if (t > 0 && lane < 32) outp[(size_t)(t - 1) * kQTile] = pending;
+            const char* bsrc = smem + (t & 1) * kQTileBytes + lane * 16;
+            f32x16 acc[NRT];
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(bsrc + ks * 1024);
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) {
+                    if (ks == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][ks], b, z, 0, 0, 0);
+                    } else {
+                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][ks], b, acc[rt], 0, 0, 0);
+                    }
+                }
+            }
+            // key-clip max-pool in registers
+            float m = -3.0e38f;
+#pragma unroll
+            for (int rt = 0; rt < NRT - 1; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[rt][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, acc_row(r) < lim ? acc[NRT - 1][r] : -3.0e38f);
+            pending = fmaxf(m, __shfl_xor(m, 32));
+        }
+    }
+    if constexpr (NRT > 0) {
+        if (lane < 32) outp[(size_t)(p.n_qtiles - 1) * kQTile] = pending;
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void simpool_eval_kernel(const SimpoolEvalArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int branch = blockIdx.x / p.n_groups;
+    const int vs = (blockIdx.x % p.n_groups) * 4 + wave;
+    int len = 0, v = 0;
+    if (vs < p.nv) {
+        v = p.order[vs];
+        len = p.lens[v];
+    }
+    len = __builtin_amdgcn_readfirstlane(len);
+    const int nrt = (len + 31) >> 5;
+
+    // stationary operand: A fragments of the whole video, lane l holds clip (32rt + l%32), k 16ks+8(l/32)..+8
+    bf16x8 a[4][kKSteps];
+    const bf16x8* gv = p.g[branch] + (size_t)v * p.Lp * kRowBf16x8 + (lane & 31) * kRowBf16x8 + (lane >> 5);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        if (rt < nrt) {
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) a[rt][ks] = gv[(size_t)rt * 32 * kRowBf16x8 + ks * 2];
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) a[rt][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    // Pin register classes: 64 fragments in the accumulator half of the unified file, 32 in arch VGPRs.
+    // Without this hipcc allocates all of them as VGPR-class values, "spills" the overflow to AGPRs and
+    // copies each back before its MFMA (160 v_accvgpr_mov per 96 MFMAs).  The file is built with
+    // -mllvm -amdgpu-mfma-vgpr-form=1 so the MFMA results stay in arch VGPRs, where the max-pool VALU
+    // reads them directly (AGPR-form results cost one v_accvgpr_read per value).
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) {
+            if (rt * kKSteps + ks < 64) asm volatile("" : "+a"(a[rt][ks]));
+            else asm volatile("" : "+v"(a[rt][ks]));
+        }
+
+    switch (nrt) {
+        case 4: score_stream<4>(a, p, branch, vs, len, smem); break;
+        case 3: score_stream<3>(a, p, branch, vs, len, smem); break;
+        case 2: score_stream<2>(a, p, branch, vs, len, smem); break;
+        case 1: score_stream<1>(a, p, branch, vs, len, smem); break;
+        default: score_stream<0>(a, p, branch, vs, len, smem); break;   // padding wave: barriers + staging only
+    }
+}
+
+// fused[q, v] = w0 * part[0][pos(v)][q] + w1 * part[1][pos(v)][q]  (eval.py:254), plus per-branch copies.
+// 32x32 tile transpose through LDS: reads coalesced along q, writes coalesced along v.
+__global__ __launch_bounds__(256) void simpool_finish_kernel(const float* __restrict__ part, const int32_t* __restrict__ inv,
+                                                             int nq, int nq_pad, int nv, int n_branches, float w0, float w1,
+                                                             float* __restrict__ fused, float* __restrict__ s0,
+                                                             float* __restrict__ s1) {
+    __shared__ float t0[32][33];
+    __shared__ float t1[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int q0 = blockIdx.x * 32, v0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int vv = v0 + ty + 8 * i;
+        float a = 0.f, b = 0.f;
+        if (vv < nv) {
+            const size_t row = (size_t)inv[vv] * nq_pad + q0 + tx;   // q0+tx < nq_pad always
+            a = part[row];
+            if (n_branches > 1) b = part[(size_t)nv * nq_pad + row];
+        }
+        t0[ty + 8 * i][tx] = a;
+        t1[ty + 8 * i][tx] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int qq = q0 + ty + 8 * i, vv = v0 + tx;
+        if (qq < nq && vv < nv) {
+            const float a = t0[tx][ty + 8 * i], b = t1[tx][ty + 8 * i];
+            const size_t o = (size_t)qq * nv + vv;
+            if (fused) fused[o] = n_branches > 1 ? w0 * a + w1 * b : a;
+            if (s0) s0[o] = a;
+            if (s1) s1[o] = b;
+        }
+    }
+}
+
+}  // namespace dldkd
+
+using namespace dldkd;
+
+extern "C" {
+
+size_t dldkd_packed_queries_bytes(int nq) {
+    return (size_t)round_up(nq < 1 ? 1 : nq, kQTile) * kHidden * 2;
+}
+size_t dldkd_packed_gallery_bytes(int nv, int L) {
+    return (size_t)(nv < 1 ? 1 : nv) * round_up(L < 1 ? 1 : L, 32) * kHidden * 2;
+}
+size_t dldkd_simpool_eval_workspace_bytes(int nq, int nv, int n_branches) {
+    return (size_t)n_branches * (nv < 1 ? 1 : nv) * round_up(nq < 1 ? 1 : nq, kQTile) * sizeof(float);
+}
+
+int dldkd_pack_queries_bf16(const float* q, int nq, int normalize, void* q_packed, void* stream) {
+    if (nq < 0 || (nq > 0 && (!q || !q_packed))) { set_error("pack_queries: bad arguments"); return DLDKD_EINVAL; }
+    if (nq == 0) return DLDKD_OK;
+    const int nq_pad = round_up(nq, kQTile);
+    hipLaunchKernelGGL(pack_queries_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, nq, nq_pad,
+                       normalize, (bf16x8*)q_packed);
+    return check_launch("pack_queries");
+}
+
+int dldkd_pack_gallery_bf16(const float* g, const float* mask, int nv, int L, int normalize, void* g_packed,
+                            int32_t* lens, void* stream) {
+    if (nv < 0 || L < 1 || L > DLDKD_MAX_CLIPS || (nv > 0 && (!g || !g_packed || !lens))) {
+        set_error("pack_gallery: bad arguments (nv=%d L=%d, L must be 1..%d)", nv, L, DLDKD_MAX_CLIPS);
+        return DLDKD_EINVAL;
+    }
+    if (nv == 0) return DLDKD_OK;
+    const int Lp = round_up(L, 32);
+    const long rows = (long)nv * Lp;
+    hipLaunchKernelGGL(pack_gallery_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, mask,
+                       nv, L, Lp, normalize, (bf16x8*)g_packed);
+    hipLaunchKernelGGL(mask_lens_kernel, dim3((nv + 3) / 4), dim3(256), 0, (hipStream_t)stream, mask, nv, L, lens);
+    return check_launch("pack_gallery");
+}
+
+int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_packed, const int32_t* lens,
+                            const int32_t* order, int nq, int nv, int L, int n_branches, void* workspace,
+                            void* stream) {
+    if (nq < 0 || nv < 0 || L < 1 || L > DLDKD_MAX_CLIPS || n_branches < 1 || n_branches > 2) {
+        set_error("simpool_eval: bad sizes nq=%d nv=%d L=%d branches=%d", nq, nv, L, n_branches);
+        return DLDKD_EINVAL;
+    }
+    if (nq == 0 || nv == 0) return DLDKD_OK;
+    if (!q_packed || !g_packed || !lens || !order || !workspace || !q_packed[0] || !g_packed[0] ||
+        (n_branches == 2 && (!q_packed[1] || !g_packed[1]))) {
+        set_error("simpool_eval: null pointer");
+        return DLDKD_EINVAL;
+    }
+    SimpoolEvalArgs p;
+    for (int b = 0; b < 2; ++b) {
+        p.q[b] = (const bf16x8*)q_packed[b < n_branches ? b : 0];
+        p.g[b] = (const bf16x8*)g_packed[b < n_branches ? b : 0];
+    }
+    p.lens = lens;
+    p.order = order;
+    p.part = (float*)workspace;
+    p.nq_pad = round_up(nq, kQTile);
+    p.nv = nv;
+    p.Lp = round_up(L, 32);
+    p.n_qtiles = p.nq_pad / kQTile;
+    p.n_groups = (nv + 3) / 4;
+    hipLaunchKernelGGL(simpool_eval_kernel, dim3(p.n_groups * n_branches), dim3(256), 2 * kQTileBytes,
+                       (hipStream_t)stream, p);
+    return check_launch("simpool_eval");
+}
+
+int dldkd_simpool_finish(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches, float w0,
+                         float w1, float* fused, float* s0, float* s1, void* stream) {
+    if (nq < 0 || nv < 0 || n_branches < 1 || n_branches > 2) {
+        set_error("simpool_finish: bad sizes nq=%d nv=%d branches=%d", nq, nv, n_branches);
+        return DLDKD_EINVAL;
+    }
+    if (nq == 0 || nv == 0 || (!fused && !s0 && !s1)) return DLDKD_OK;
+    if (!workspace || !inv_order) { set_error("simpool_finish: null pointer"); return DLDKD_EINVAL; }
+    const int nq_pad = round_up(nq, kQTile);
+    hipLaunchKernelGGL(simpool_finish_kernel, dim3(nq_pad / 32, (nv + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, inv_order, nq, nq_pad, nv, n_branches, w0, w1, fused, s0, s1);
+    return check_launch("simpool_finish");
+}
+
+}  // extern "C"

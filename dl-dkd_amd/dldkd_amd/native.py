@@ -1,0 +1,83 @@
+"""ctypes binding of libdldkd_hip.so (C ABI: include/dldkd_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, this raises.  torch is used only
+for device memory (tensor.data_ptr()) and the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdldkd_hip.so")
+ABI_VERSION = 1
+
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_c_void_p = ctypes.c_void_p
+_c_size_t = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/dldkd_hip.h declares
+SIGNATURES = {
+    "dldkd_abi_version": (_c_int, []),
+    "dldkd_last_error": (ctypes.c_char_p, []),
+    "dldkd_packed_queries_bytes": (_c_size_t, [_c_int]),
+    "dldkd_packed_gallery_bytes": (_c_size_t, [_c_int, _c_int]),
+    "dldkd_simpool_eval_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "dldkd_pack_queries_bf16": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "dldkd_pack_gallery_bf16": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_simpool_eval_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                                          _c_void_p, _c_void_p]),
+    "dldkd_simpool_finish": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p,
+                                       _c_void_p, _c_void_p, _c_void_p]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise NativeError if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} not found: build it with `make -C dl-dkd_amd/csrc` (or __graft_entry__.build()). "
+                "dldkd_amd has no CPU/eager fallback by design.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)      # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if h.dldkd_abi_version() != ABI_VERSION:
+            raise NativeError(f"libdldkd_hip.so ABI {h.dldkd_abi_version()} != expected {ABI_VERSION}")
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NativeError(f"{what} failed (rc={rc}): {lib().dldkd_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NativeError("dldkd_amd kernels need tensors on the GPU (no CPU path)")
+    if not t.is_contiguous():
+        raise NativeError("non-contiguous tensor passed to a dldkd_amd kernel")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr

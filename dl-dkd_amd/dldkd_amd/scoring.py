@@ -1,0 +1,120 @@
+"""Host side of the scoring path (K1 `simpool`): packing and launching.
+
+Mirrors what DLDKD.get_sim_scores + compute_query2ctx_info + eval_epoch's fusion do in the reference
+(method/model.py:307-329, method/eval.py:200-208,254) but keeps the gallery resident in a packed bf16
+layout and never builds the (Nq, L, Nv) clip tensor.
+"""
+import torch
+
+from . import native
+
+HIDDEN = 384
+MAX_CLIPS = 128
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class PackedQueries:
+    """bf16 queries in MFMA B-fragment order, one blob per branch."""
+
+    def __init__(self, blobs, nq):
+        self.blobs = blobs
+        self.nq = nq
+
+
+class PackedGallery:
+    """Resident bf16 gallery: one blob per branch + lens + a visiting order (descending length)."""
+
+    def __init__(self, blobs, lens, order, inv_order, nv, L):
+        self.blobs, self.lens, self.order, self.inv_order, self.nv, self.L = blobs, lens, order, inv_order, nv, L
+
+    @property
+    def n_branches(self):
+        return len(self.blobs)
+
+
+def pack_queries(qs, normalize=True):
+    """qs: list (one per branch) of (Nq, 384) tensors on the GPU."""
+    L = native.lib()
+    nq = qs[0].shape[0]
+    blobs = []
+    for q in qs:
+        if q.dim() != 2 or q.shape[1] != HIDDEN or q.shape[0] != nq:
+            raise native.NativeError(f"queries must be (Nq, {HIDDEN}); got {tuple(q.shape)}")
+        q = _f32c(q)
+        blob = torch.empty(L.dldkd_packed_queries_bytes(nq), dtype=torch.uint8, device=q.device)
+        native.check(L.dldkd_pack_queries_bf16(native.ptr(q), nq, int(normalize), native.ptr(blob), native.stream()),
+                     "pack_queries")
+        blobs.append(blob)
+    return PackedQueries(blobs, nq)
+
+
+def pack_gallery(gs, mask=None, normalize=True):
+    """gs: list (one per branch) of (Nv, L, 384) GPU tensors; mask (Nv, L) 0/1 prefix mask or None."""
+    L_ = native.lib()
+    nv, L = gs[0].shape[0], gs[0].shape[1]
+    if L > MAX_CLIPS:
+        raise native.NativeError(f"at most {MAX_CLIPS} clips per video (config max_ctx_l); got {L}")
+    dev = gs[0].device
+    lens = torch.empty(max(nv, 1), dtype=torch.int32, device=dev)
+    m = None if mask is None else _f32c(mask)
+    blobs = []
+    for g in gs:
+        if g.dim() != 3 or g.shape[2] != HIDDEN or g.shape[0] != nv or g.shape[1] != L:
+            raise native.NativeError(f"gallery must be (Nv, L, {HIDDEN}); got {tuple(g.shape)}")
+        g = _f32c(g)
+        blob = torch.empty(L_.dldkd_packed_gallery_bytes(nv, L), dtype=torch.uint8, device=dev)
+        native.check(L_.dldkd_pack_gallery_bf16(native.ptr(g), native.ptr(m), nv, L, int(normalize), native.ptr(blob),
+                                                native.ptr(lens), native.stream()), "pack_gallery")
+        blobs.append(blob)
+    lens = lens[:nv]
+    # longest first: the 4 waves of a workgroup get similar lengths and the tail of the grid is light
+    order = torch.argsort(lens, descending=True, stable=True).to(torch.int32)
+    inv = torch.empty_like(order)
+    inv[order.long()] = torch.arange(nv, dtype=torch.int32, device=dev)
+    return PackedGallery(blobs, lens, order, inv, nv, L)
+
+
+def simpool_partials(pq, pg, workspace=None):
+    """Stage 1 (the dominant kernel): per-branch pooled scores into the workspace, transposed and in
+    visiting order.  Returns the workspace tensor."""
+    L_ = native.lib()
+    nb = pg.n_branches
+    if len(pq.blobs) != nb:
+        raise native.NativeError("query / gallery branch count mismatch")
+    need = L_.dldkd_simpool_eval_workspace_bytes(pq.nq, pg.nv, nb)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=pg.lens.device)
+    if pq.nq and pg.nv:
+        native.check(L_.dldkd_simpool_eval_bf16(native.ptr_array(pq.blobs), native.ptr_array(pg.blobs), native.ptr(pg.lens),
+                                                native.ptr(pg.order), pq.nq, pg.nv, pg.L, nb, native.ptr(workspace),
+                                                native.stream()), "simpool_eval")
+    return workspace
+
+
+def simpool_finish(workspace, pq, pg, w=(0.7, 0.3), want_fused=True, want_branches=False):
+    """Stage 2: (Nq, Nv) outputs.  Returns (fused, s0, s1), each fp32 (Nq, Nv) or None."""
+    L_ = native.lib()
+    nb, nq, nv, dev = pg.n_branches, pq.nq, pg.nv, pg.lens.device
+    fused = torch.empty(nq, nv, dtype=torch.float32, device=dev) if want_fused else None
+    s0 = torch.empty(nq, nv, dtype=torch.float32, device=dev) if want_branches else None
+    s1 = torch.empty(nq, nv, dtype=torch.float32, device=dev) if (want_branches and nb == 2) else None
+    if nq and nv:
+        native.check(L_.dldkd_simpool_finish(native.ptr(workspace), native.ptr(pg.inv_order), nq, nv, nb, float(w[0]),
+                                             float(w[1]), native.ptr(fused), native.ptr(s0), native.ptr(s1),
+                                             native.stream()), "simpool_finish")
+    return fused, s0, s1
+
+
+def simpool_eval(pq, pg, w=(0.7, 0.3), want_fused=True, want_branches=False, workspace=None):
+    """Pooled cosine/dot scores of every query against every video.
+
+    Returns (fused, s0, s1): (Nq, Nv) fp32 tensors or None.  fused = w[0]*s0 + w[1]*s1 (eval.py:254),
+    or s0 alone for a single-branch model.
+    """
+    ws = simpool_partials(pq, pg, workspace)
+    return simpool_finish(ws, pq, pg, w, want_fused, want_branches)

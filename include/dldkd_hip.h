@@ -1,0 +1,81 @@
+/*
+ * dldkd_hip.h - C ABI of libdldkd_hip.so: the MI355X (gfx950) kernels under the DL-DKD scoring +
+ * distillation hot path.
+ *
+ * The upstream reference (HuiGuanLab/DL-DKD) has no FFI: its boundary for this path is the Python
+ * class method.model.DLDKD and the module functions of method/eval.py.  This
+ * header is the boundary one level down: what a maintainer of the reference would bind (ctypes, see
+ * INTEGRATION.md) to run those functions on an MI355X.  Every entry point names the reference code it
+ * replaces.
+ *
+ * Conventions
+ *   - plain C: pointers are DEVICE pointers unless the name says host_; sizes are ints; `stream` is a
+ *     hipStream_t passed as void* (NULL = the default stream).  No torch / C++ types.
+ *   - every function only ENQUEUES work on `stream` (no allocation, no host sync: safe to capture in a
+ *     hipGraph) and returns DLDKD_OK or a negative DLDKD_E* code; dldkd_last_error() gives the text.
+ *   - float tensors are row-major fp32 unless stated; "bf16" buffers are opaque device blobs whose size
+ *     comes from the matching *_bytes() function.
+ */
+#ifndef DLDKD_HIP_H
+#define DLDKD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLDKD_OK 0
+#define DLDKD_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define DLDKD_ELAUNCH (-2)  /* HIP launch error */
+
+#define DLDKD_HIDDEN 384    /* config.py:70-71 hidden size the kernels are specialised for */
+#define DLDKD_MAX_CLIPS 128 /* config.py:60 max_ctx_l */
+
+int dldkd_abi_version(void);
+const char* dldkd_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scoring: query x video x clip similarity with key-clip max-pool.
+ * Replaces DLDKD.get_sim_scores (method/model.py:307-329) / get_unnormalized_sim_scores (:331-350) as
+ * they are used by compute_query2ctx_info (method/eval.py:200-208) and eval_epoch's 0.7/0.3 fusion
+ * (method/eval.py:254).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Bytes of the packed bf16 query blob for nq queries of dimension DLDKD_HIDDEN. */
+size_t dldkd_packed_queries_bytes(int nq);
+/* Bytes of the packed bf16 gallery blob for nv videos padded to L clips (L <= DLDKD_MAX_CLIPS). */
+size_t dldkd_packed_gallery_bytes(int nv, int L);
+/* Bytes of scratch the eval scorer needs (per-branch transposed partial scores). */
+size_t dldkd_simpool_eval_workspace_bytes(int nq, int nv, int n_branches);
+
+/* q (nq, 384) fp32 -> packed bf16 MFMA-fragment order; normalize != 0 applies F.normalize (eps 1e-12,
+ * model.py:318) in fp32 before rounding. */
+int dldkd_pack_queries_bf16(const float* q, int nq, int normalize, void* q_packed, void* stream);
+
+/* g (nv, L, 384) fp32 + mask (nv, L) fp32 0/1 prefix masks (NULL = all valid) -> bf16 gallery blob,
+ * lens[nv] int32 (number of valid clips, data_provider.py:81-84).  normalize as above (model.py:319). */
+int dldkd_pack_gallery_bf16(const float* g, const float* mask, int nv, int L, int normalize,
+                            void* g_packed, int32_t* lens, void* stream);
+
+/* All-pairs pooled scores, stage 1 (the dominant kernel).  For each branch b < n_branches (1 or 2):
+ *     part_b[pos(v), q] = max_{l < lens[v]} < q_packed[b][q], g_packed[b][v, l] >   (model.py:321-327)
+ * written to `workspace` as [n_branches][nv][round_up(nq,32)] fp32, videos in `order` (order[pos] = v;
+ * any permutation is valid; descending-length order balances the workgroups).  bf16 operands, fp32
+ * accumulation; the (nq, L, nv) clip tensor of the reference is never formed. */
+int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_packed, const int32_t* lens,
+                            const int32_t* order, int nq, int nv, int L, int n_branches, void* workspace,
+                            void* stream);
+
+/* Stage 2: (nq, nv) row-major outputs from the workspace.  inv_order[v] = pos(v).
+ *     s_b[q, v]   = part_b[pos(v), q]                  what get_sim_scores returns, model.py:327-329
+ *     fused[q, v] = w0 * s_0 + w1 * s_1                eval.py:254   (= s_0 when n_branches == 1)
+ * fused / s0 / s1 may each be NULL. */
+int dldkd_simpool_finish(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches,
+                         float w0, float w1, float* fused, float* s0, float* s1, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLDKD_HIP_H */

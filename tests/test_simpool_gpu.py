@@ -1,0 +1,140 @@
+"""GPU parity: HIP simpool (bf16 MFMA) against the oracle and the committed golden vectors.
+
+Two yardsticks per case:
+  * "exact-input": the oracle in fp64 on the SAME bf16-rounded normalised operands the kernel sees
+    -> only fp32 accumulation order (and an occasional 1-ulp bf16 flip from the normalisation being
+    summed in a different order on CPU and GPU) differs -> tolerance 1e-4.  Catches layout / mask / max bugs.
+  * "reference": the oracle in fp32 on the original fp32 inputs (what the reference computes)
+    -> adds bf16 operand rounding -> tolerance 6e-3 absolute on cosine scores in [-1, 1].
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import dldkd_oracle as orc
+import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_EXACT = 1e-4
+TOL_BF16 = 6e-3
+
+
+def _bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+def _run(q_list, g_list, mask, normalize=True, w=(0.7, 0.3)):
+    from dldkd_amd import scoring
+    dev = "cuda:0"
+    pq = scoring.pack_queries([q.to(dev) for q in q_list], normalize=normalize)
+    pg = scoring.pack_gallery([g.to(dev) for g in g_list], None if mask is None else mask.to(dev), normalize=normalize)
+    fused, s0, s1 = scoring.simpool_eval(pq, pg, w=w, want_fused=True, want_branches=True)
+    torch.cuda.synchronize()
+    return fused.cpu(), s0.cpu(), None if s1 is None else s1.cpu(), pg
+
+
+def _oracle_exact(q, g, mask, normalize):
+    if normalize:
+        q = F.normalize(q.float(), dim=-1)
+        g = F.normalize(g.float(), dim=-1)
+    return orc.unnormalized_sim_scores(_bf16_round(q), _bf16_round(g), None if mask is None else mask.double())
+
+
+def _check(q_list, g_list, mask, normalize=True, tol_ref=TOL_BF16):
+    fused, s0, s1, pg = _run(q_list, g_list, mask, normalize)
+    outs = [s0, s1]
+    for b, (q, g) in enumerate(zip(q_list, g_list)):
+        exact = _oracle_exact(q, g, mask, normalize)
+        assert (outs[b].double() - exact).abs().max().item() <= TOL_EXACT * max(1.0, exact.abs().max().item()), f"branch {b} exact-input"
+        ref = orc.sim_scores(q, g, mask)[0] if normalize else orc.unnormalized_sim_scores(q, g, mask)
+        scale = 1.0 if normalize else float(ref.abs().max())
+        assert (outs[b] - ref).abs().max().item() <= tol_ref * scale, f"branch {b} vs fp32 reference"
+    if len(q_list) == 2:
+        assert (fused - (0.7 * s0 + 0.3 * s1)).abs().max().item() <= 1e-6
+    else:
+        assert (fused - s0).abs().max().item() == 0
+    if mask is not None:
+        assert (pg.lens.cpu() == (mask > 0).sum(1).int()).all()
+    return fused
+
+
+def test_g1_golden(golden_dir):
+    g = np.load(f"{golden_dir}/g1_simpool.npz")
+    rs = np.random.RandomState(11)
+    q = torch.from_numpy(rs.standard_normal((7, 384)).astype(np.float32))
+    ctx = torch.from_numpy(rs.standard_normal((5, 9, 384)).astype(np.float32))
+    mask = torch.from_numpy((np.arange(9)[None] < g["lens"][:, None]).astype(np.float32))
+    ctx = ctx * mask.unsqueeze(-1)
+    _, s0, _, _ = _run([q], [ctx], mask, True)
+    assert np.abs(s0.numpy() - g["pooled"]).max() <= TOL_BF16
+    _, r0, _, _ = _run([q], [ctx], mask, False)
+    assert np.abs(r0.numpy() - g["raw"]).max() <= TOL_BF16 * np.abs(g["raw"]).max()
+    _, n0, _, _ = _run([q], [ctx], None, True)
+    assert np.abs(n0.numpy() - g["pooled_nomask"]).max() <= TOL_BF16
+
+
+@pytest.mark.parametrize("nq,nv,L,len_lo", [(64, 64, 16, 4), (1, 1, 1, 1), (33, 5, 128, 1), (200, 131, 128, 24),
+                                            (97, 66, 40, 33), (31, 7, 96, 65), (5, 4, 128, 128)])
+def test_vs_oracle_two_branches(nq, nv, L, len_lo):
+    d0 = synth.make_gallery(100 + nq, nq, nv, L, len_lo, sigma=0.5)
+    d1 = synth.make_gallery(200 + nq, nq, nv, L, len_lo, sigma=1.0)
+    _check([d0["q"], d1["q"]], [d0["g"], d1["g"] * d0["mask"].unsqueeze(-1)], d0["mask"])
+
+
+def test_single_branch_and_raw_mode():
+    d = synth.make_gallery(7, 50, 37, 64, 3, sigma=0.3)
+    _check([d["q"]], [d["g"]], d["mask"], normalize=True)
+    _check([d["q"]], [d["g"]], d["mask"], normalize=False)
+
+
+def test_all_negative_scores_not_beaten_by_padding():
+    """Padded clips give dot = 0; a video whose valid clips all score < 0 must keep its negative max
+    (the reference masks padding to -1e10, model.py:444-445)."""
+    d = synth.make_gallery(9, 40, 9, 64, 5, sigma=0.0)
+    g, mask = d["g"].clone(), d["mask"].clone()
+    for v, n in ((2, 1), (5, 33), (7, 31)):          # every valid clip of these videos is anti-aligned with query v
+        mask[v] = (torch.arange(64) < n).float()
+        g[v] = (-d["q"][v].unsqueeze(0) + 0.05 * torch.randn(64, 384)) * mask[v].unsqueeze(-1)
+    fused = _check([d["q"]], [g], mask)
+    for v in (2, 5, 7):
+        assert fused[v, v] < -0.9
+
+
+def test_mask_none_equals_full_mask():
+    d = synth.make_gallery(3, 20, 6, 32, 32, sigma=0.2)
+    a = _run([d["q"]], [d["g"]], None)[1]
+    b = _run([d["q"]], [d["g"]], torch.ones(6, 32))[1]
+    assert torch.equal(a, b)
+
+
+def test_empty_inputs():
+    from dldkd_amd import scoring
+    dev = "cuda:0"
+    pq = scoring.pack_queries([torch.zeros(0, 384, device=dev)])
+    pg = scoring.pack_gallery([torch.randn(3, 8, 384, device=dev)])
+    fused, _, _ = scoring.simpool_eval(pq, pg)
+    assert fused.shape == (0, 3)
+
+
+def test_rank_parity_planted_gallery():
+    """R@1/5/10/100 of HIP scores vs fp32-oracle scores on a planted-signal gallery agree within 0.1
+    (BASELINE.json north_star gate), at a size the oracle finishes in seconds."""
+    nq, nv = 2000, 1500
+    d0 = synth.make_gallery(42, nq, nv, 128, 24, sigma=5.0)
+    d1 = synth.make_gallery(43, nq, nv, 128, 24, sigma=6.0)
+    g1 = d1["g"] * d0["mask"].unsqueeze(-1)
+    fused, _, _, _ = _run([d0["q"], d1["q"]], [d0["g"], g1], d0["mask"])
+    oi, oe = orc.eval_scores(d0["q"], d1["q"], d0["g"], g1, d0["mask"], chunk=50)
+    of = orc.fuse_scores(oi, oe)
+    gt = d0["gt"]
+
+    def recalls(s):
+        gts = s[torch.arange(nq), gt]
+        rank = 1 + (s > gts.unsqueeze(1)).sum(1)
+        return [100.0 * (rank <= k).float().mean().item() for k in (1, 5, 10, 100)]
+    rh, ro = recalls(fused), recalls(of)
+    assert 5.0 < ro[0] < 95.0, f"planted signal should give a non-trivial R@1, got {ro}"
+    for a, b in zip(rh, ro):
+        assert abs(a - b) <= 0.1, (rh, ro)
