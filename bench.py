@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark: query x video pairs scored / s on the TVR full gallery (BASELINE.json).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the scoring hot path over the whole synthetic TVR-shaped workload (config C2,
+SURVEY.md 8d): normalise + pack the 10,895 x 2 query vectors, score them against the resident bf16
+gallery of 21,793 videos x <=128 clips x 384 dims x 2 branches (key-clip max-pool in registers), fuse the
+branches 0.7/0.3 into the (Nq, Nv) fp32 score matrix.  The gallery is resident in HBM in its packed
+bf16 form before the timed region (it is the output format of the gallery encoder).  N > 1: the gallery
+is sharded by video across ranks, every rank scores all queries against its shard, and the step ends
+with one RCCL all-gather of the score blocks (strong scaling: total work fixed).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "dl-dkd_amd"))
+
+import torch  # noqa: E402
+
+NQ, NV, L, LEN_LO, D, NB = 10895, 21793, 128, 24, 384, 2
+SIGMA = (5.5, 6.5)        # planted-signal noise (per branch) -> TVR-like R@1
+W_FUSE = (0.7, 0.3)       # eval.py:254
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def synth_shard(dev, v_lo, v_hi, seed=2):
+    """Encoded-gallery shard [v_lo, v_hi) for both branches + planted queries (same on every rank)."""
+    lens_all = torch.randint(LEN_LO, L + 1, (NV,), generator=torch.Generator().manual_seed(seed)).to(dev)
+    n_loc = v_hi - v_lo
+    gs = []
+    for b in range(NB):
+        gen = torch.Generator(device=dev).manual_seed(1000 * seed + 10 * v_lo + b)
+        gs.append(torch.randn(n_loc, L, D, generator=gen, device=dev))
+    lens = lens_all[v_lo:v_hi]
+    mask = (torch.arange(L, device=dev).unsqueeze(0) < lens.unsqueeze(1)).float()
+    # queries: planted on a valid clip of video (q mod NV) when that video is local, plain noise otherwise
+    qgen = torch.Generator(device=dev).manual_seed(seed + 7)
+    gt = torch.arange(NQ, device=dev) % NV
+    lstar = (torch.rand(NQ, generator=qgen, device=dev) * lens_all[gt].float()).long().clamp(max=L - 1)
+    qs = []
+    for b in range(NB):
+        noise = torch.randn(NQ, D, generator=qgen, device=dev)
+        local = (gt >= v_lo) & (gt < v_hi)
+        base = torch.zeros(NQ, D, device=dev)
+        base[local] = gs[b][(gt[local] - v_lo), lstar[local]]
+        qs.append(base + SIGMA[b] * noise)
+    return gs, mask, lens, qs, gt
+
+
+def recalls(scores, gt):
+    g = scores.gather(1, gt.unsqueeze(1))
+    rank = 1 + (scores > g).sum(1)
+    return [round(100.0 * (rank <= k).float().mean().item(), 3) for k in (1, 5, 10, 100)]
+
+
+def cpu_baseline(gs, mask, qs, fused_gpu, nq_s=200, nv_s=4359):
+    """The oracle (CPU restatement of eval.py:188-208 + :254, fp32, 50-query chunks) timed on this
+    box's host cores on a bounded sample of the same workload; doubles as a parity check."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dldkd_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g0, g1 = gs[0][:nv_s].cpu(), gs[1][:nv_s].cpu()
+    m = mask[:nv_s].cpu()
+    g0, g1 = g0 * m.unsqueeze(-1), g1 * m.unsqueeze(-1)
+    q0, q1 = qs[0][:nq_s].cpu(), qs[1][:nq_s].cpu()
+    orc.eval_scores(q0[:50], q1[:50], g0[:256], g1[:256], m[:256])      # warm-up
+    t0 = time.perf_counter()
+    oi, oe = orc.eval_scores(q0, q1, g0, g1, m, chunk=50)
+    ref = orc.fuse_scores(oi, oe)
+    dt = time.perf_counter() - t0
+    err = (fused_gpu[:nq_s, :nv_s].cpu() - ref).abs().max().item()
+    return dict(value=nq_s * nv_s / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{nq_s} queries x {nv_s} videos (first 1/5 of the C2 gallery), both branches + fusion, "
+                       f"fp32, 50-query chunks like eval.py:188-208; {dt:.1f} s"), err
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N (one rank per GPU)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dldkd_amd import native, scoring
+    native.lib()   # fail loudly before anything else if the HIP library is missing
+
+    shard = (NV + world - 1) // world
+    v_lo, v_hi = min(rank * shard, NV), min((rank + 1) * shard, NV)
+    gs, mask, lens, qs, gt = synth_shard(dev, v_lo, v_hi)
+    n_loc = v_hi - v_lo
+    if n_loc < shard:   # pad the last shard with 1-clip zero videos so all_gather blocks are equal
+        pad = shard - n_loc
+        gs = [torch.cat([g, torch.zeros(pad, L, D, device=dev)]) for g in gs]
+        mask = torch.cat([mask, torch.zeros(pad, L, device=dev)])
+        mask[n_loc:, 0] = 1.0
+    t0 = time.perf_counter()
+    pg = scoring.pack_gallery(gs, mask)            # resident bf16 gallery (outside the timed region)
+    torch.cuda.synchronize()
+    pack_gallery_ms = (time.perf_counter() - t0) * 1e3
+    keep_fp32 = (world == 1 and not a.no_cpu_baseline)
+    if not keep_fp32:
+        del gs
+    ws = torch.empty(native.lib().dldkd_simpool_eval_workspace_bytes(NQ, shard, NB), dtype=torch.uint8, device=dev)
+    gathered = torch.empty(world, NQ, shard, dtype=torch.float32, device=dev) if world > 1 else None
+    flops_launch = 2.0 * D * NB * NQ * float(lens.sum().item())   # algorithmic: valid clips only
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def step(i=None):
+        pq = scoring.pack_queries(qs)                                  # F.normalize + bf16 (model.py:318)
+        if i is not None:
+            ev[i][0].record()
+        scoring.simpool_partials(pq, pg, ws)                           # the dominant kernel
+        if i is not None:
+            ev[i][1].record()
+        fused, _, _ = scoring.simpool_finish(ws, pq, pg, W_FUSE)       # (NQ, shard) fp32
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, fused)               # RCCL over xGMI
+        return fused
+
+    for _ in range(a.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        fused = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(a.steps, 1)
+
+    out = None
+    if rank == 0:
+        metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        achieved = flops_launch / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": metric, "value": NQ * NV * a.steps / dt, "unit": "pairs/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "C2: TVR full eval gallery text->video scoring (configs[1])",
+                       "n_queries": NQ, "n_videos": NV, "max_clips": L, "clip_len": f"U{{{LEN_LO}..{L}}}",
+                       "hidden": D, "branches": NB, "fusion": list(W_FUSE),
+                       "parallelism": "1 GPU" if world == 1 else f"gallery sharded x{world} + all_gather",
+                       "step": "pack queries + simpool (sim + key-clip max-pool) + 0.7/0.3 fusion"
+                               + (" + all_gather" if world > 1 else ""),
+                       "gallery_pack_ms_untimed": round(pack_gallery_ms, 2)},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "simpool_eval_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_flops_per_launch": flops_launch},
+        }
+        if world == 1:
+            out["recall_hip"] = dict(zip(("R@1", "R@5", "R@10", "R@100"), recalls(fused, gt)))
+        if keep_fp32:
+            cb, err = cpu_baseline(gs, mask, qs, fused)
+            out["cpu_baseline"] = cb
+            out["parity_max_abs_err_vs_oracle_sample"] = err
+            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
