@@ -15,6 +15,10 @@
 //     Each B fragment read from LDS feeds up to 4 MFMAs (0.25 KiB of LDS read per MFMA).
 //   * ragged videos: only ceil(len/32) row tiles are computed (wave-uniform template dispatch); videos
 //     are visited in a caller-given order (descending length balances the 4 waves of a workgroup).
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace dldkd {
@@ -31,8 +35,10 @@ __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m *
 // ----------------------------------------------------------------------------------------------
 // Packed query layout: [tile = q/32][k-step ks][lane = 32*h + (q%32)][8 bf16 = k 16ks + 8h ..+8]
 // = the B operand of mfma_f32_32x32x16_bf16 (cdna_hip_programming.md section 3 lane maps).
+// layout 1 (scorer v2, mfma_f32_16x16x32_bf16): [tile = q/32][sub = (q%32)/16][k-step ks of 32][lane = 16*kg + q%16]
+// [8 bf16 = k 32ks + 8kg ..+8].
 __global__ __launch_bounds__(256) void pack_queries_kernel(const float* __restrict__ q, int nq, int nq_pad,
-                                                           int normalize, bf16x8* __restrict__ out) {
+                                                           int normalize, int layout, bf16x8* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= nq_pad) return;
@@ -58,8 +64,13 @@ __global__ __launch_bounds__(256) void pack_queries_kernel(const float* __restri
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (short)f32_to_bf16_bits(v[j] * scale);
-        const int ks = lane >> 1, h = lane & 1;
-        out[((size_t)(qi >> 5) * kKSteps + ks) * 64 + h * 32 + (qi & 31)] = o;
+        if (layout == 0) {
+            const int ks = lane >> 1, h = lane & 1;
+            out[((size_t)(qi >> 5) * kKSteps + ks) * 64 + h * 32 + (qi & 31)] = o;
+        } else {
+            const int ks = lane >> 2, kg = lane & 3, sub = (qi >> 4) & 1;
+            out[(((size_t)(qi >> 5) * 2 + sub) * (kKSteps / 2) + ks) * 64 + kg * 16 + (qi & 15)] = o;
+        }
     }
 }
 
@@ -155,18 +166,27 @@ __device__ __forceinline__ void score_stream(const bf16x8 (&a)[4][kKSteps], cons
             if (t > 0 && lane < 32) outp[(size_t)(t - 1) * kQTile] = pending;
             const char* bsrc = smem + (t & 1) * kQTileBytes + lane * 16;
             f32x16 acc[NRT];
+            // B fragments run kPF k-steps ahead of the MFMAs that consume them (a ring of kPF registers
+            // sets), so an LDS round trip never sits between two MFMAs.
+            constexpr int kPF = 4;
+            bf16x8 b[kPF];
+#pragma unroll
+            for (int i = 0; i < kPF; ++i) b[i] = *reinterpret_cast<const bf16x8*>(bsrc + i * 1024);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < kKSteps; ++ks) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(bsrc + ks * 1024);
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt) {
                     if (ks == 0) {
                         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][ks], b, z, 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][ks], b[ks % kPF], z, 0, 0, 0);
                     } else {
-                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][ks], b, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][ks], b[ks % kPF], acc[rt], 0, 0, 0);
                     }
                 }
+                if (ks + kPF < kKSteps) b[ks % kPF] = *reinterpret_cast<const bf16x8*>(bsrc + (ks + kPF) * 1024);
+                // hipcc otherwise sinks the reads back next to their use ({2 reads, lgkmcnt(0), 8 MFMA})
+                __builtin_amdgcn_sched_barrier(0);
             }
             // key-clip max-pool in registers
             float m = -3.0e38f;
@@ -233,6 +253,202 @@ __global__ __launch_bounds__(256, 1) void simpool_eval_kernel(const SimpoolEvalA
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// scorer v2: mfma_f32_16x16x32_bf16.  Same gallery-stationary structure as v1, but
+//   * 16-clip row tiles: ragged videos waste < 16 padded rows instead of < 32;
+//   * a 16-query sub-tile needs only 4 accumulator registers per row tile, so TWO accumulator sets fit:
+//     the max-pool VALU of sub-tile i is issued in slices between the MFMAs of sub-tile i+1;
+//   * 3-slot LDS ring: tile t+1 is already visible while tile t is computed, so the B-fragment
+//     prefetch ring runs across tile boundaries and the only per-tile cost left is the barrier itself.
+// ----------------------------------------------------------------------------------------------
+constexpr int kKSteps16 = kHidden / 32;   // 12
+constexpr int kRing = 3;
+
+__device__ __forceinline__ float xor16_max(float m) {
+    const unsigned u = __builtin_bit_cast(unsigned, m);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // rows 1<->0', 3<->2'
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float xor32_max(float m) {
+    const unsigned u = __builtin_bit_cast(unsigned, m);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // upper half <-> lower half'
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+
+template <int NRT>
+__device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], const SimpoolEvalArgs& p, int branch,
+                                               int vs, int len, char* smem) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const char* qsrc = reinterpret_cast<const char*>(p.q[branch]);
+    const int T = p.n_qtiles;
+
+    auto stage = [&](int t, int slot) {
+        char* dst = smem + slot * kQTileBytes;
+        const char* src = qsrc + (size_t)t * kQTileBytes;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int piece = wave * 6 + i;
+            glds16(src + piece * 1024 + lane * 16, dst + piece * 1024);
+        }
+    };
+
+    stage(0, 0);
+    if (T > 1) stage(1, 1);
+
+    if constexpr (NRT == 0) {   // padding wave: staging + barriers only
+        int slot2 = 2;
+        for (int t = 0; t < T; ++t) {
+            __syncthreads();
+            if (t + 2 < T) stage(t + 2, slot2);
+            slot2 = slot2 == kRing - 1 ? 0 : slot2 + 1;
+        }
+    } else {
+        // rows of the LAST row tile at or beyond `lim` (relative to this lane's 4-row group) are padding
+        const int lim = len - 16 * (NRT - 1) - 4 * (lane >> 4);
+        const bool ok0 = 0 < lim, ok1 = 1 < lim, ok2 = 2 < lim, ok3 = 3 < lim;
+        float* outp = p.part + ((size_t)branch * p.nv + vs) * p.nq_pad + (lane & 15);
+        constexpr int V = NRT * 4;              // accumulator values per lane per sub-tile
+        constexpr int kFoldSteps = 9;           // k-steps 0..8 fold the values, 9/10 cross lanes, 11 stores
+        constexpr int kPer = (V + kFoldSteps - 1) / kFoldSteps;
+        constexpr int kPF = 4;                  // B-fragment ring depth (divides 12)
+
+        f32x4 accA[NRT], accB[NRT];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) accB[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 b[kPF];
+        float m = 0.f;
+
+        // one 16-query sub-tile: MFMAs into `cur`, max-pool of `prev` sliced between the k-steps
+        auto subtile = [&](auto sub_c, f32x4 (&cur)[NRT], const f32x4 (&prev)[NRT], const char* cbase, const char* nbase,
+                           float* prev_out) {
+            constexpr int S = decltype(sub_c)::value;
+#pragma unroll
+            for (int ks = 0; ks < kKSteps16; ++ks) {
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) {
+                    if (ks == 0) {
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        cur[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][ks], b[ks % kPF], z, 0, 0, 0);
+                    } else {
+                        cur[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][ks], b[ks % kPF], cur[rt], 0, 0, 0);
+                    }
+                }
+                // keep the B ring kPF k-steps ahead, across the sub-tile and the tile boundary
+                constexpr int kIdxBase = S * kKSteps16 + kPF;
+                const int idx = kIdxBase + ks;
+                if (idx < 2 * kKSteps16) {
+                    b[ks % kPF] = *reinterpret_cast<const bf16x8*>(cbase + idx * 1024);
+                } else {   // past the last tile this reads a stale ring slot: harmless, never consumed
+                    b[ks % kPF] = *reinterpret_cast<const bf16x8*>(nbase + (idx - 2 * kKSteps16) * 1024);
+                }
+                // slice of the previous sub-tile's key-clip max-pool
+                if (ks < kFoldSteps) {
+                    if (ks == 0) m = -3.0e38f;
+#pragma unroll
+                    for (int i = ks * kPer; i < (ks + 1) * kPer && i < V; ++i) {
+                        float x = prev[i >> 2][i & 3];
+                        if ((i >> 2) == NRT - 1) {
+                            const bool ok = (i & 3) == 0 ? ok0 : (i & 3) == 1 ? ok1 : (i & 3) == 2 ? ok2 : ok3;
+                            x = ok ? x : -3.0e38f;
+                        }
+                        m = fmaxf(m, x);
+                    }
+                } else if (ks == 9) {
+                    m = xor16_max(m);
+                } else if (ks == 10) {
+                    m = xor32_max(m);
+                } else {
+                    if (lane < 16) *prev_out = m;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        int slot = 0, slot2 = 2;
+        for (int t = 0; t < T; ++t) {
+            __syncthreads();   // tile t+1 (and t) landed and visible; every wave is done with tile t-1
+            if (t + 2 < T) stage(t + 2, slot2);
+            const int nslot = slot == kRing - 1 ? 0 : slot + 1;
+            const char* cbase = smem + slot * kQTileBytes + lane * 16;
+            const char* nbase = smem + nslot * kQTileBytes + lane * 16;
+            if (t == 0) {
+#pragma unroll
+                for (int i = 0; i < kPF; ++i) b[i] = *reinterpret_cast<const bf16x8*>(cbase + i * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // t == 0: there is no previous sub-tile; its (garbage) result goes to queries 0..15, which the
+            // next sub-tile's store - later in program order, same lanes, same addresses - overwrites.
+            subtile(std::integral_constant<int, 0>{}, accA, accB, cbase, nbase, outp + (t > 0 ? (size_t)t * kQTile - 16 : 0));
+            subtile(std::integral_constant<int, 1>{}, accB, accA, cbase, nbase, outp + (size_t)t * kQTile);
+            slot = nslot;
+            slot2 = slot2 == kRing - 1 ? 0 : slot2 + 1;
+        }
+        // drain: max-pool of the very last sub-tile
+        m = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float x = accB[i >> 2][i & 3];
+            if ((i >> 2) == NRT - 1) {
+                const bool ok = (i & 3) == 0 ? ok0 : (i & 3) == 1 ? ok1 : (i & 3) == 2 ? ok2 : ok3;
+                x = ok ? x : -3.0e38f;
+            }
+            m = fmaxf(m, x);
+        }
+        m = xor32_max(xor16_max(m));
+        if (lane < 16) outp[(size_t)(T - 1) * kQTile + 16] = m;
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void simpool_eval16_kernel(const SimpoolEvalArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int branch = blockIdx.x / p.n_groups;
+    const int vs = (blockIdx.x % p.n_groups) * 4 + wave;
+    int len = 0, v = 0;
+    if (vs < p.nv) {
+        v = p.order[vs];
+        len = p.lens[v];
+    }
+    len = __builtin_amdgcn_readfirstlane(len);
+    const int nrt = (len + 15) >> 4;
+
+    // stationary operand: lane l holds clip (16rt + l%16), k 32ks + 8(l/16) ..+8
+    bf16x8 a[8][kKSteps16];
+    const bf16x8* gv = p.g[branch] + (size_t)v * p.Lp * kRowBf16x8 + (lane & 15) * kRowBf16x8 + (lane >> 4);
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+        if (rt < nrt) {
+#pragma unroll
+            for (int ks = 0; ks < kKSteps16; ++ks) a[rt][ks] = gv[(size_t)rt * 16 * kRowBf16x8 + ks * 4];
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < kKSteps16; ++ks) a[rt][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < kKSteps16; ++ks) {
+            if (rt * kKSteps16 + ks < 64) asm volatile("" : "+a"(a[rt][ks]));
+            else asm volatile("" : "+v"(a[rt][ks]));
+        }
+
+    switch (nrt) {
+        case 8: score_stream16<8>(a, p, branch, vs, len, smem); break;
+        case 7: score_stream16<7>(a, p, branch, vs, len, smem); break;
+        case 6: score_stream16<6>(a, p, branch, vs, len, smem); break;
+        case 5: score_stream16<5>(a, p, branch, vs, len, smem); break;
+        case 4: score_stream16<4>(a, p, branch, vs, len, smem); break;
+        case 3: score_stream16<3>(a, p, branch, vs, len, smem); break;
+        case 2: score_stream16<2>(a, p, branch, vs, len, smem); break;
+        case 1: score_stream16<1>(a, p, branch, vs, len, smem); break;
+        default: score_stream16<0>(a, p, branch, vs, len, smem); break;
+    }
+}
+
 // fused[q, v] = w0 * part[0][pos(v)][q] + w1 * part[1][pos(v)][q]  (eval.py:254), plus per-branch copies.
 // 32x32 tile transpose through LDS: reads coalesced along q, writes coalesced along v.
 __global__ __launch_bounds__(256) void simpool_finish_kernel(const float* __restrict__ part, const int32_t* __restrict__ inv,
@@ -273,6 +489,16 @@ __global__ __launch_bounds__(256) void simpool_finish_kernel(const float* __rest
 
 using namespace dldkd;
 
+// DLDKD_SIMPOOL_VARIANT=1 selects the 32x32x16 scorer (v1); default is the 16x16x32 scorer (v2).  The
+// packed-query layout follows the variant, so it is read once per process.
+static int simpool_variant() {
+    static const int v = [] {
+        const char* e = getenv("DLDKD_SIMPOOL_VARIANT");
+        return (e && e[0] == '1') ? 1 : 2;
+    }();
+    return v;
+}
+
 extern "C" {
 
 size_t dldkd_packed_queries_bytes(int nq) {
@@ -290,7 +516,7 @@ int dldkd_pack_queries_bf16(const float* q, int nq, int normalize, void* q_packe
     if (nq == 0) return DLDKD_OK;
     const int nq_pad = round_up(nq, kQTile);
     hipLaunchKernelGGL(pack_queries_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, nq, nq_pad,
-                       normalize, (bf16x8*)q_packed);
+                       normalize, simpool_variant() == 1 ? 0 : 1, (bf16x8*)q_packed);
     return check_launch("pack_queries");
 }
 
@@ -335,8 +561,18 @@ int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_pa
     p.Lp = round_up(L, 32);
     p.n_qtiles = p.nq_pad / kQTile;
     p.n_groups = (nv + 3) / 4;
-    hipLaunchKernelGGL(simpool_eval_kernel, dim3(p.n_groups * n_branches), dim3(256), 2 * kQTileBytes,
-                       (hipStream_t)stream, p);
+    if (simpool_variant() == 1) {
+        hipLaunchKernelGGL(simpool_eval_kernel, dim3(p.n_groups * n_branches), dim3(256), 2 * kQTileBytes,
+                           (hipStream_t)stream, p);
+    } else {
+        static const bool attr_ok = [] {
+            return hipFuncSetAttribute((const void*)simpool_eval16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kRing * kQTileBytes) == hipSuccess;
+        }();
+        (void)attr_ok;
+        hipLaunchKernelGGL(simpool_eval16_kernel, dim3(p.n_groups * n_branches), dim3(256), kRing * kQTileBytes,
+                           (hipStream_t)stream, p);
+    }
     return check_launch("simpool_eval");
 }
 
