@@ -1,0 +1,296 @@
+// Encoder-tower forward kernels, fp32 (parity grade).  Together with gemm_f32 they implement
+// DLDKD.encode_input / encode_context / encode_query (reference method/model.py:199-258) without any
+// library call:
+//   layernorm_f32      LayerNorm(x [+ add]) : LinearLayer.LayerNorm (model_components.py:308), the
+//                      "+ position rows, LayerNorm" of TrainablePositionalEncoding (:277-284) and the
+//                      "+ residual, LayerNorm" of BertSelfOutput (:446-450)
+//   attention_fwd_f32  BertSelfAttention.forward (:398-436): softmax(QK^T/sqrt(96) + (1-mask)*-1e4) V,
+//                      4 heads x 96, whole sequence (L <= 128) resident in LDS, no L x L matrix in HBM
+//   modpool_fwd_f32    get_modularized_queries (model.py:245-258)
+#include "common.hpp"
+
+namespace dldkd {
+
+// ----------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (eps inside the sqrt, biased variance: nn.LayerNorm).  One wave per row;
+// the row is cached in registers (two-pass mean / variance like ATen, not E[x^2]-mean^2).
+// add_mod == 0: add[row]; add_mod > 0: add[row % add_mod] (position table); add == NULL: none.
+// ----------------------------------------------------------------------------------------------
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                        int add_mod, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ out, long M,
+                                                        int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
+    const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (add_mod > 0 ? row % add_mod : row) * D) : nullptr;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            v[i] = xr[c];
+            if (ar) { const f32x4 a = ar[c]; v[i] += a; }
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    f32x4* orow = reinterpret_cast<f32x4*>(out + row * D);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const f32x4 g = g4[c], b = b4[c];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            orow[c] = o;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Fused self-attention, one workgroup (4 waves) per (sequence, head); wave w owns queries 32w..32w+31.
+// Computed "swapped" (S^T = K Q^T) so that keys sit on MFMA rows = accumulator registers and queries on
+// lanes: the softmax over keys is in-register (+ one permlane32 swap) and the probabilities are already
+// the B operand of the second product O^T = V^T P^T (cdna_hip_programming.md section 3, "An accumulator
+// tile as the next MFMA's operand"; T12).  fp32-input MFMA 32x32x2.
+// ----------------------------------------------------------------------------------------------
+constexpr int kHeads = 4, kDh = 96, kLmax = 128;
+constexpr int kLdQK = kDh + 1;   // [row][d] pitch: 32 consecutive rows at one d hit 32 banks
+
+__device__ __forceinline__ float half_swap_max(float m) {
+    const unsigned u = __builtin_bit_cast(unsigned, m);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float half_swap_sum(float m) {
+    const unsigned u = __builtin_bit_cast(unsigned, m);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+template <int NKT>   // key tiles of 32 (ceil(L/32))
+__device__ __forceinline__ void attention_body(const float* __restrict__ qkv, const float* __restrict__ mask,
+                                               float* __restrict__ out, int L, float* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x / kHeads, head = blockIdx.x % kHeads;
+    float* Qs = smem;                              // [NKT*32][97]
+    float* Ks = Qs + NKT * 32 * kLdQK;             // [NKT*32][97]
+    float* Vs = Ks + NKT * 32 * kLdQK;             // [NKT*32][96]
+    float* Ms = Vs + NKT * 32 * kDh;               // [NKT*32] additive key mask
+    constexpr int LP = NKT * 32;
+    const float* base = qkv + (size_t)n * L * (3 * kHidden) + head * kDh;
+    // stage Q, K, V rows (zero beyond L): 24 float4 per row per matrix
+    for (int i = tid; i < LP * 24; i += 256) {
+        const int row = i / 24, c = i % 24;
+        f32x4 q = {0.f, 0.f, 0.f, 0.f}, k = q, v = q;
+        if (row < L) {
+            const float* r = base + (size_t)row * (3 * kHidden) + c * 4;
+            q = *reinterpret_cast<const f32x4*>(r);
+            k = *reinterpret_cast<const f32x4*>(r + kHidden);
+            v = *reinterpret_cast<const f32x4*>(r + 2 * kHidden);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Qs[row * kLdQK + c * 4 + e] = q[e];
+            Ks[row * kLdQK + c * 4 + e] = k[e];
+        }
+        *reinterpret_cast<f32x4*>(Vs + row * kDh + c * 4) = v;
+    }
+    for (int i = tid; i < LP; i += 256) {
+        // keys >= L do not exist; masked keys get the reference's additive -10000 (model_components.py:422)
+        Ms[i] = i < L ? (mask ? (1.f - mask[(size_t)n * L + i]) * -10000.f : 0.f) : -INFINITY;
+    }
+    __syncthreads();
+
+    const int q0 = wave * 32;
+    if (q0 < L) {
+        // S^T[key][query] = sum_d K[key][d] Q[query][d]
+        f32x16 s[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+        const float* qrow = Qs + (q0 + (lane & 31)) * kLdQK + (lane >> 5);
+        const float* krow = Ks + (lane & 31) * kLdQK + (lane >> 5);
+#pragma unroll 4
+        for (int d = 0; d < kDh; d += 2) {
+            const float b = qrow[d];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[kt * 32 * kLdQK + d], b, s[kt], 0, 0, 0);
+        }
+        // softmax over keys: registers, then the other lane half
+        const float scale = 0.10206207261596577f;   // 1/sqrt(96), model_components.py:419
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                s[kt][r] = s[kt][r] * scale + Ms[key];
+                mx = fmaxf(mx, s[kt][r]);
+            }
+        mx = half_swap_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[kt][r] = expf(s[kt][r] - mx);
+                sum += s[kt][r];
+            }
+        sum = half_swap_sum(sum);
+        const float inv = 1.f / sum;
+        // O^T[d][query] = sum_key V[key][d] P[key][query]; register r of key tile kt holds keys
+        // (kr, kr+4) on the two lane halves = one k-step of the 32x32x2 MFMA
+        f32x16 o[3];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float* vrow = Vs + key * kDh + (lane & 31);
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[dt * 32], s[kt][r], o[dt], 0, 0, 0);
+            }
+        // write the context rows: out[n, q, head*96 + d]; lane = query, registers = d
+        const int q = q0 + (lane & 31);
+        if (q < L) {
+            float* orow = out + ((size_t)n * L + q) * kHidden + head * kDh;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = o[dt][r4 * 4 + e] * inv;
+                    // registers 4*r4..4*r4+3 are 4 consecutive d: d = dt*32 + 8*r4 + 4*(lane>>5) + e
+                    *reinterpret_cast<f32x4*>(orow + dt * 32 + 8 * r4 + 4 * (lane >> 5)) = v;
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
+                                                            float* __restrict__ out, int L) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int nkt = (L + 31) >> 5;
+    switch (nkt) {
+        case 1: attention_body<1>(qkv, mask, out, L, smem_f); break;
+        case 2: attention_body<2>(qkv, mask, out, L, smem_f); break;
+        case 3: attention_body<3>(qkv, mask, out, L, smem_f); break;
+        default: attention_body<4>(qkv, mask, out, L, smem_f); break;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Modular query pooling: logits_l = h_l . w, masked words -> exactly -1e10 (mask_logits, model.py:444),
+// softmax over words, out = sum_l a_l h_l.  One wave per query (L <= 64 words; config max_desc_l = 30).
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void modpool_fwd_kernel(const float* __restrict__ h, const float* __restrict__ mask,
+                                                          const float* __restrict__ w, float* __restrict__ out,
+                                                          float* __restrict__ attn, int N, int L) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* hn = h + (size_t)n * L * kHidden;
+    float wv[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) wv[j] = w[lane + 64 * j];
+    float my_logit = -INFINITY;   // lane l keeps word l's logit
+    for (int l = 0; l < L; ++l) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d += hn[(size_t)l * kHidden + lane + 64 * j] * wv[j];
+        d = wave_sum(d);
+        const float m = mask[(size_t)n * L + l];
+        d = d * m + (1.f - m) * -1e10f;
+        if (lane == l) my_logit = d;
+    }
+    const float mx = wave_max(my_logit);
+    const float e = lane < L ? expf(my_logit - mx) : 0.f;
+    const float a = e / wave_sum(e);
+    if (attn && lane < L) attn[(size_t)n * L + lane] = a;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < L; ++l) {
+        const float al = __shfl(a, l);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[j] += al * hn[(size_t)l * kHidden + lane + 64 * j];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) out[(size_t)n * kHidden + lane + 64 * j] = acc[j];
+}
+
+}  // namespace dldkd
+
+using namespace dldkd;
+
+extern "C" {
+
+int dldkd_layernorm_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out,
+                        long M, int D, float eps, void* stream) {
+    if (M < 0 || D < 4 || (D & 3) || D > 4096 || add_mod < 0) {
+        set_error("layernorm: bad sizes M=%ld D=%d (D must be a multiple of 4, <= 4096)", M, D);
+        return DLDKD_EINVAL;
+    }
+    if (M == 0) return DLDKD_OK;
+    if (!x || !gamma || !beta || !out) { set_error("layernorm: null pointer"); return DLDKD_EINVAL; }
+    const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int nv = (D / 4 + 63) / 64;
+    if (nv <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
+    else if (nv <= 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
+    else if (nv <= 8) hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
+    return check_launch("layernorm");
+}
+
+int dldkd_attention_fwd_f32(const float* qkv, const float* mask, float* out, int N, int L, void* stream) {
+    if (N < 0 || L < 1 || L > kLmax) { set_error("attention: bad sizes N=%d L=%d (L <= %d)", N, L, kLmax); return DLDKD_EINVAL; }
+    if (N == 0) return DLDKD_OK;
+    if (!qkv || !out) { set_error("attention: null pointer"); return DLDKD_EINVAL; }
+    const int LP = ((L + 31) / 32) * 32;
+    const size_t lds = (size_t)(2 * LP * kLdQK + LP * kDh + LP) * sizeof(float);
+    static const bool attr_ok = [] {
+        return hipFuncSetAttribute((const void*)attention_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (2 * kLmax * kLdQK + kLmax * kDh + kLmax) * (int)sizeof(float)) == hipSuccess;
+    }();
+    (void)attr_ok;
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(N * kHeads), dim3(256), lds, (hipStream_t)stream, qkv, mask, out, L);
+    return check_launch("attention_fwd");
+}
+
+int dldkd_modpool_fwd_f32(const float* h, const float* mask, const float* w, float* out, float* attn, int N, int L,
+                          void* stream) {
+    if (N < 0 || L < 1 || L > 64) { set_error("modpool: bad sizes N=%d L=%d (L <= 64)", N, L); return DLDKD_EINVAL; }
+    if (N == 0) return DLDKD_OK;
+    if (!h || !mask || !w || !out) { set_error("modpool: null pointer"); return DLDKD_EINVAL; }
+    hipLaunchKernelGGL(modpool_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, mask, w, out, attn, N, L);
+    return check_launch("modpool_fwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+"""Eval driver: encode the gallery, score every query against every video, rank, R@K.
+
+Same function names, arguments and return values as reference method/eval.py:43-263 for the part that
+is on the hot path.  Differences in HOW (not in what is returned):
+  * the gallery is packed once into the resident bf16 layout (the reference re-normalises it for every
+    50-query chunk, model.py:319) and all queries are scored in ONE launch of the MFMA scorer;
+  * ranks are counted on the GPU (rank = 1 + #scores above the best ground-truth video) instead of
+    np.argsort per query + a pure-Python AP loop (eval.py:69-83,97-111).
+"""
+import logging
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from . import native, scoring
+from .data import collate_frame_val, collate_text_val
+
+logger = logging.getLogger(__name__)
+
+
+def get_gt(video_metas, query_metas):
+    """cap_id 'vid#...' is a caption of video 'vid' (eval.py:43-57).  Returns (v2t_gt, t2v_gt)."""
+    pos = {}
+    for i, v in enumerate(video_metas):
+        pos.setdefault(v, []).append(i)
+    v2t_gt = [[] for _ in video_metas]
+    for qi, cap in enumerate(query_metas):
+        for vi in pos.get(cap.split("#", 1)[0], ()):
+            v2t_gt[vi].append(qi)
+    t2v_gt = {}
+    for vi, qs in enumerate(v2t_gt):
+        for qi in qs:
+            t2v_gt.setdefault(qi, []).append(vi)
+    return v2t_gt, t2v_gt
+
+
+def _gt_csr(t2v_gt, n_q, device):
+    ptr = np.zeros(n_q + 1, np.int32)
+    idx = []
+    for q in range(n_q):
+        g = t2v_gt.get(q, []) if isinstance(t2v_gt, dict) else t2v_gt[q]
+        idx.extend(g)
+        ptr[q + 1] = len(idx)
+    idx = np.asarray(idx if idx else [0], np.int32)
+    return torch.from_numpy(ptr).to(device), torch.from_numpy(idx).to(device)
+
+
+def gt_ranks_gpu(scores, t2v_gt):
+    """scores: (Nq, Nv) fp32 GPU similarity (higher = better).  Returns (rank_best, rank_first) int32 GPU."""
+    L = native.lib()
+    scores = scores.contiguous()
+    nq, nv = scores.shape
+    ptr, idx = _gt_csr(t2v_gt, nq, scores.device)
+    rb = torch.empty(nq, dtype=torch.int32, device=scores.device)
+    rf = torch.empty(nq, dtype=torch.int32, device=scores.device)
+    native.check(L.dldkd_rank_gt(native.ptr(scores), nq, nv, native.ptr(ptr), native.ptr(idx), native.ptr(rb),
+                                 native.ptr(rf), native.stream()), "rank_gt")
+    return rb, rf
+
+
+def _recalls(ranks, n_q):
+    r = ranks.astype(np.int64)
+    out = [100.0 * int((r <= k).sum()) / n_q for k in (1, 5, 10, 100)]
+    return (out[0], out[1], out[2], out[3], float(np.median(r)), float(r.mean()))
+
+
+def eval_q2m(scores, q2m_gts):
+    """(r1, r5, r10, r100, medr, meanr) as eval.py:59-94.  `scores` is an ERROR matrix (lower = better,
+    the reference passes -1 * similarity); numpy or torch, any device - it is ranked on the GPU."""
+    t = torch.as_tensor(scores)
+    if not t.is_cuda:
+        t = t.cuda()
+    rb, _ = gt_ranks_gpu(-t.float(), q2m_gts)
+    return _recalls(rb.cpu().numpy(), t.shape[0])
+
+
+def t2v_map(c2i, t2v_gts):
+    """mean AP over queries using the first GT video only (eval.py:97-111)."""
+    t = torch.as_tensor(c2i)
+    if not t.is_cuda:
+        t = t.cuda()
+    _, rf = gt_ranks_gpu(-t.float(), t2v_gts)
+    return float((1.0 / rf.cpu().numpy().astype(np.float64)).mean())
+
+
+def cal_perf(t2v_all_errors, t2v_gt, test=False):
+    """eval.py:223-234: logs and returns (r1, r5, r10, r100, medr, meanr, mAP)."""
+    t = torch.as_tensor(t2v_all_errors)
+    if not t.is_cuda:
+        t = t.cuda()
+    rb, rf = gt_ranks_gpu(-t.float(), t2v_gt)
+    r1, r5, r10, r100, medr, meanr = _recalls(rb.cpu().numpy(), t.shape[0])
+    m = float((1.0 / rf.cpu().numpy().astype(np.float64)).mean())
+    logging.info(" * Text to Video:")
+    logging.info(" * r_1_5_10_100: {}".format([round(r1, 1), round(r5, 1), round(r10, 1), round(r100, 1)]))
+    logging.info(" * recall sum: {}".format(round(r1 + r5 + r10 + r100, 1)))
+    logging.info(" * mAP: {}".format(round(m, 4)))
+    logging.info(" * " + "-" * 10)
+    return (r1, r5, r10, r100, medr, meanr, m)
+
+
+def compute_context_info(model, eval_dataset, opt):
+    """Encode the gallery in batches of eval_context_bsz, zero-pad to the global max length, concatenate
+    (eval.py:114-175).  Adds `_packed`: the resident bf16 gallery the scorer consumes."""
+    model.eval()
+    loader = DataLoader(eval_dataset, collate_fn=collate_frame_val, batch_size=opt.eval_context_bsz,
+                        num_workers=opt.num_workers, shuffle=False, pin_memory=opt.pin_memory)
+    metas, inh, exp, masks = [], [], [], []
+    with torch.no_grad():
+        for batch in loader:
+            metas.extend(batch[-1])
+            feat = batch[0].to(opt.device, non_blocking=True)
+            mask = batch[1].to(opt.device, non_blocking=True)
+            gi, ge = model.encode_context(feat, mask)
+            inh.append(gi)
+            exp.append(ge)
+            masks.append(mask)
+
+    def cat(tensors):
+        lmax = max(t.shape[1] for t in tensors)
+        out = tensors[0].new_zeros((sum(t.shape[0] for t in tensors), lmax) + tuple(tensors[0].shape[2:]))
+        o = 0
+        for t in tensors:
+            out[o:o + t.shape[0], :t.shape[1]] = t
+            o += t.shape[0]
+        return out
+
+    info = dict(video_metas=metas, inher_frame_feat=cat(inh),
+                explore_frame_feat=cat(exp) if model.double_branch else None,
+                teacher_frame_feat=None, video_mask=cat(masks))
+    gs = [info["inher_frame_feat"]] + ([info["explore_frame_feat"]] if model.double_branch else [])
+    info["_packed"] = scoring.pack_gallery(gs, info["video_mask"])
+    return info
+
+
+def _encode_all_queries(model, eval_dataset, opt):
+    loader = DataLoader(eval_dataset, collate_fn=collate_text_val, batch_size=opt.eval_query_bsz,
+                        num_workers=opt.num_workers, shuffle=False, pin_memory=opt.pin_memory)
+    metas, qi, qe = [], [], []
+    with torch.no_grad():
+        for batch in loader:
+            metas.extend(batch[-1])
+            feat = batch[0].to(opt.device, non_blocking=True)
+            mask = batch[1].to(opt.device, non_blocking=True)
+            a, b = model.encode_query(feat, mask)
+            qi.append(a)
+            qe.append(b)
+    qs = [torch.cat(qi, 0)] + ([torch.cat(qe, 0)] if model.double_branch else [])
+    return metas, qs
+
+
+def score_queries(model, eval_dataset, opt, ctx_info):
+    """GPU-resident form of compute_query2ctx_info: (fused, inher, explore, query_metas), tensors on the GPU."""
+    model.eval()
+    metas, qs = _encode_all_queries(model, eval_dataset, opt)
+    fused, s0, s1 = model.pooled_scores(qs, ctx_info["_packed"], want_branches=True)
+    return fused, s0, s1, metas
+
+
+def compute_query2ctx_info(model, eval_dataset, opt, ctx_info):
+    """(inher_scores, explore_scores, None, query_metas) with numpy (Nq, Nv) fp32 matrices, rows in
+    query_metas order = per-batch length-sorted order (eval.py:177-219)."""
+    _, s0, s1, metas = score_queries(model, eval_dataset, opt, ctx_info)
+    return s0.cpu().numpy().copy(), (s1.cpu().numpy().copy() if s1 is not None else None), None, metas
+
+
+def eval_epoch(model, val_video_dataset, val_text_dataset, opt, test=False):
+    """SumR (R@1 + R@5 + R@10 + R@100) of the fused scores; logs the three rankings (eval.py:237-263)."""
+    model.eval()
+    logger.info("Computing scores")
+    context_info = compute_context_info(model, val_video_dataset, opt)
+    fused, s0, s1, query_metas = score_queries(model, val_text_dataset, opt, context_info)
+    _, t2v_gt = get_gt(context_info["video_metas"], query_metas)
+    if opt.double_branch:
+        logging.info("inher_scores:")
+        cal_perf(-1 * s0, t2v_gt, test)
+        logging.info("explore_scores:")
+        cal_perf(-1 * s1, t2v_gt, test)
+        logging.info("score_sum:")
+        r1, r5, r10, r100, _, _, _ = cal_perf(-1 * fused, t2v_gt, test)
+    else:
+        r1, r5, r10, r100, _, _, _ = cal_perf(-1 * s0, t2v_gt, test)
+    return r1 + r5 + r10 + r100

@@ -1,0 +1,110 @@
+"""Parameter containers for the encoder towers.
+
+Module / parameter names reproduce the reference's state dict (method/model_components.py:269-312,
+339-353,379-450) so its checkpoints load unchanged; the forward passes call the HIP kernels in
+libdldkd_hip.so through `ops` instead of ATen.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class TrainablePositionalEncoding(nn.Module):
+    """Learned position rows + LayerNorm (+ dropout in training).  Keys: position_embeddings.weight,
+    LayerNorm.{weight,bias} (model_components.py:269-284)."""
+
+    def __init__(self, max_position_embeddings, hidden_size, dropout=0.1):
+        super().__init__()
+        self.position_embeddings = nn.Embedding(max_position_embeddings, hidden_size)
+        self.LayerNorm = nn.LayerNorm(hidden_size)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, input_feat):
+        L = input_feat.shape[1]
+        if L > self.position_embeddings.num_embeddings:
+            raise IndexError(f"sequence length {L} exceeds {self.position_embeddings.num_embeddings} positions")
+        pos = self.position_embeddings.weight[:L].contiguous()
+        out = ops.layernorm(input_feat, self.LayerNorm.weight, self.LayerNorm.bias, add=pos, add_mod=L)
+        return self.dropout(out)
+
+
+class LinearLayer(nn.Module):
+    """LayerNorm -> Dropout -> Linear -> ReLU.  Keys: LayerNorm.*, net.1.* (model_components.py:294-312)."""
+
+    def __init__(self, in_hsz, out_hsz, layer_norm=True, dropout=0.1, relu=True):
+        super().__init__()
+        self.relu = relu
+        self.layer_norm = layer_norm
+        if layer_norm:
+            self.LayerNorm = nn.LayerNorm(in_hsz)
+        self.net = nn.Sequential(nn.Dropout(dropout), nn.Linear(in_hsz, out_hsz))
+
+    def forward(self, x):
+        if self.layer_norm:
+            x = ops.layernorm(x, self.LayerNorm.weight, self.LayerNorm.bias)
+        x = self.net[0](x)
+        lin = self.net[1]
+        return ops.linear(x, lin.weight, lin.bias, relu=self.relu)
+
+
+class BertSelfAttention(nn.Module):
+    """Keys: query/key/value.{weight,bias} (model_components.py:379-391)."""
+
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)" % (
+                config.hidden_size, config.num_attention_heads))
+        if config.hidden_size != ops.HIDDEN or config.num_attention_heads != 4:
+            raise ValueError("the gfx950 attention kernel is specialised for hidden 384 = 4 heads x 96")
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = config.hidden_size // config.num_attention_heads
+        self.all_head_size = config.hidden_size
+        self.query = nn.Linear(config.hidden_size, self.all_head_size)
+        self.key = nn.Linear(config.hidden_size, self.all_head_size)
+        self.value = nn.Linear(config.hidden_size, self.all_head_size)
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+
+    def fused_qkv(self):
+        w = torch.cat([self.query.weight, self.key.weight, self.value.weight], 0).contiguous()
+        b = torch.cat([self.query.bias, self.key.bias, self.value.bias], 0).contiguous()
+        return w, b
+
+    def forward(self, query_states, key_states, value_states, attention_mask=None):
+        if not (query_states is key_states and key_states is value_states):
+            raise NotImplementedError("only self-attention is on the DL-DKD path (BertAttention.forward, :351)")
+        w, b = self.fused_qkv()
+        qkv = ops.linear(query_states, w, b)                      # one GEMM for the three projections
+        mask = None
+        if attention_mask is not None:                            # (N, 1, L) as encode_input passes it (model.py:242)
+            mask = attention_mask.reshape(attention_mask.shape[0], -1).contiguous()
+        return ops.attention(qkv, mask)
+
+
+class BertSelfOutput(nn.Module):
+    """Keys: dense.*, LayerNorm.* (model_components.py:439-450)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, hidden_states, input_tensor):
+        h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
+        h = self.dropout(h)
+        return ops.layernorm(h, self.LayerNorm.weight, self.LayerNorm.bias, add=input_tensor.contiguous(), add_mod=0)
+
+
+class BertAttention(nn.Module):
+    """self-attention sub-layer with post-LN, no FFN (model_components.py:339-353)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertSelfAttention(config)
+        self.output = BertSelfOutput(config)
+
+    def forward(self, input_tensor, attention_mask=None):
+        ctx = self.self(input_tensor, input_tensor, input_tensor, attention_mask)
+        return self.output(ctx, input_tensor)

@@ -30,6 +30,13 @@ SIGNATURES = {
                                           _c_void_p, _c_void_p]),
     "dldkd_simpool_finish": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p,
                                        _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_gemm_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                 _c_int, _c_int, _c_int, _c_void_p]),
+    "dldkd_layernorm_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, ctypes.c_long, _c_int,
+                                      _c_float, _c_void_p]),
+    "dldkd_attention_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
+    "dldkd_modpool_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
+    "dldkd_rank_gt": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
 }
 
 _lib = None

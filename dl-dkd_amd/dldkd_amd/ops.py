@@ -1,0 +1,72 @@
+"""Thin tensor-level wrappers over the C ABI (one function per kernel).  No math happens here."""
+import torch
+
+from . import native
+
+HIDDEN = 384
+LN_EPS = 1e-5   # nn.LayerNorm default (model_components.py:274,301,443)
+
+
+def _chk(t, name):
+    if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
+        raise native.NativeError(f"{name}: need a contiguous fp32 GPU tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return t
+
+
+def linear(x, weight, bias=None, relu=False):
+    """y = act(x @ weight.T + bias); x (..., K), weight (N, K)."""
+    L = native.lib()
+    K = x.shape[-1]
+    x2 = _chk(x.reshape(-1, K), "linear.x")
+    _chk(weight, "linear.weight"); _chk(bias, "linear.bias")
+    M, N = x2.shape[0], weight.shape[0]
+    if weight.shape[1] != K:
+        raise native.NativeError(f"linear: x has {K} features, weight expects {weight.shape[1]}")
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    native.check(L.dldkd_gemm_f32(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
+                                  0, 0, int(relu), native.stream()), "gemm_f32")
+    return y.view(*x.shape[:-1], N)
+
+
+def gemm(a, b, a_kmajor, b_kmajor, M, N, K):
+    """C[M,N] = sum_k A(m,k) B(n,k) with explicit operand layouts (used by the backward passes)."""
+    L = native.lib()
+    _chk(a, "gemm.a"); _chk(b, "gemm.b")
+    c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    native.check(L.dldkd_gemm_f32(native.ptr(a), native.ptr(b), None, native.ptr(c), M, N, K, a.shape[-1], b.shape[-1], N,
+                                  int(a_kmajor), int(b_kmajor), 0, native.stream()), "gemm_f32")
+    return c
+
+
+def layernorm(x, gamma, beta, add=None, add_mod=0):
+    L = native.lib()
+    D = x.shape[-1]
+    x2 = _chk(x.reshape(-1, D), "layernorm.x")
+    _chk(gamma, "layernorm.gamma"); _chk(beta, "layernorm.beta"); _chk(add, "layernorm.add")
+    out = torch.empty_like(x2)
+    native.check(L.dldkd_layernorm_f32(native.ptr(x2), native.ptr(add), int(add_mod), native.ptr(gamma), native.ptr(beta),
+                                       native.ptr(out), x2.shape[0], D, LN_EPS, native.stream()), "layernorm")
+    return out.view(x.shape)
+
+
+def attention(qkv, mask):
+    """qkv (N, L, 1152), mask (N, L) or None -> context (N, L, 384)."""
+    L = native.lib()
+    _chk(qkv, "attention.qkv"); _chk(mask, "attention.mask")
+    N, Lq = qkv.shape[0], qkv.shape[1]
+    out = torch.empty(N, Lq, HIDDEN, dtype=torch.float32, device=qkv.device)
+    native.check(L.dldkd_attention_fwd_f32(native.ptr(qkv), native.ptr(mask), native.ptr(out), N, Lq, native.stream()),
+                 "attention_fwd")
+    return out
+
+
+def modpool(h, mask, w, want_attn=False):
+    """h (N, L, 384), mask (N, L), w (384,) -> (N, 384) [, attn (N, L)]."""
+    L = native.lib()
+    _chk(h, "modpool.h"); _chk(mask, "modpool.mask"); _chk(w, "modpool.w")
+    N, Lw = h.shape[0], h.shape[1]
+    out = torch.empty(N, HIDDEN, dtype=torch.float32, device=h.device)
+    attn = torch.empty(N, Lw, dtype=torch.float32, device=h.device) if want_attn else None
+    native.check(L.dldkd_modpool_fwd_f32(native.ptr(h), native.ptr(mask), native.ptr(w), native.ptr(out), native.ptr(attn),
+                                         N, Lw, native.stream()), "modpool_fwd")
+    return (out, attn) if want_attn else out

@@ -75,6 +75,47 @@ int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_pa
 int dldkd_simpool_finish(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches,
                          float w0, float w1, float* fused, float* s0, float* s1, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Encoder towers, fp32 parity-grade forward (fp32-input MFMA: exact fp32 products and sums).
+ * Together these replace DLDKD.encode_input / encode_context / encode_query (method/model.py:199-258).
+ * ------------------------------------------------------------------------------------------- */
+
+/* C[M,N] = act(sum_k A(m,k) * B(n,k) + bias[n]);  a_kmajor / b_kmajor = 1 when the contraction index is
+ * the row index of that operand in memory.  (0,0): nn.Linear forward Y = X W^T + b
+ * (model_components.py:302,388-390,442; model.py:39);  (0,1): dX = dY W;  (1,1): dW = dY^T X.
+ * relu != 0 applies max(.,0) (LinearLayer, model_components.py:310-311).  bias may be NULL.
+ * float4 loads are used when an operand is 16-byte aligned with a leading dimension divisible by 4. */
+int dldkd_gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda,
+                   int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* stream);
+
+/* out[row] = LayerNorm(x[row] + add[..]) * gamma + beta over the last dim D (nn.LayerNorm, eps inside the
+ * sqrt).  add == NULL: plain LayerNorm (LinearLayer.LayerNorm, model_components.py:308); add_mod == L > 0:
+ * add[row % L] = position rows (TrainablePositionalEncoding.forward :277-284); add_mod == 0: add[row] =
+ * residual (BertSelfOutput.forward :446-450). */
+int dldkd_layernorm_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta,
+                        float* out, long M, int D, float eps, void* stream);
+
+/* BertSelfAttention.forward (model_components.py:398-436) for N sequences of L <= 128 tokens, 4 heads x 96:
+ * qkv (N, L, 1152) = [query | key | value] projections, mask (N, L) 0/1 or NULL, out (N, L, 384) context
+ * layer.  softmax(QK^T / sqrt(96) + (1 - mask) * -10000) V; the L x L probabilities never leave the CU. */
+int dldkd_attention_fwd_f32(const float* qkv, const float* mask, float* out, int N, int L, void* stream);
+
+/* get_modularized_queries (model.py:245-258): h (N, L, 384), mask (N, L), w (384) -> out (N, 384);
+ * attn (N, L) optional (softmax weights, kept for the backward pass).  L <= 64. */
+int dldkd_modpool_fwd_f32(const float* h, const float* mask, const float* w, float* out, float* attn, int N,
+                          int L, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Ranking (the step after scoring).  Replaces the np.argsort loop of eval_q2m (method/eval.py:69-83) and
+ * the Python list walk of t2v_map (method/eval.py:97-111).
+ * scores (nq, nv) fp32 similarity (higher = better; the reference ranks -scores ascending, eval.py:250);
+ * GT videos of query q are gt_idx[gt_ptr[q] .. gt_ptr[q+1]) (CSR, built from get_gt, eval.py:43-57).
+ * rank_best[q]  = 1 + #(scores[q,:] > best GT score)   -> gt_ranks of eval_q2m (min over GT videos);
+ * rank_first[q] = 1 + #(scores[q,:] > first GT score)  -> AP = 1/rank for t2v_map (may be NULL).
+ * Queries without GT get nv + 1 (eval.py:76). */
+int dldkd_rank_gt(const float* scores, int nq, int nv, const int32_t* gt_ptr, const int32_t* gt_idx,
+                  int32_t* rank_best, int32_t* rank_first, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,86 @@
+"""GPU: the eval driver end to end (encode gallery -> score -> rank) against the reference's own
+eval_epoch outputs (golden G5) and the oracle."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import dldkd_oracle as orc
+import synth
+from test_encoder_gpu import _model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _opt():
+    return types.SimpleNamespace(eval_context_bsz=25, eval_query_bsz=50, num_workers=0, pin_memory=False,
+                                 device=torch.device(DEV), double_branch=True)
+
+
+def test_rank_kernel_vs_oracle():
+    from dldkd_amd import eval as ev
+    g = torch.Generator().manual_seed(5)
+    for nq, nv in ((1, 1), (37, 5), (64, 1001), (50, 21793)):
+        s = torch.randn(nq, nv, generator=g)
+        gts = {q: sorted(set(torch.randint(0, nv, (1 + q % 3,), generator=g).tolist())) for q in range(nq)}
+        rb, rf = ev.gt_ranks_gpu(s.to(DEV), gts)
+        ref = orc.gt_ranks(-s.numpy(), gts)
+        assert (rb.cpu().numpy() == ref).all()
+        first = np.array([1 + int((s[q] > s[q, gts[q][0]]).sum()) for q in range(nq)])
+        assert (rf.cpu().numpy() == first).all()
+        assert ev.eval_q2m(-s.numpy(), gts) == pytest.approx(orc.eval_q2m(-s.numpy(), gts))
+        assert ev.t2v_map(-s.numpy(), gts) == pytest.approx(orc.t2v_map(-s.numpy(), gts))
+
+
+def test_get_gt_matches_oracle():
+    from dldkd_amd import eval as ev
+    vm = [f"v{i}" for i in range(7)]
+    qm = ["v3#a", "v0#b#c", "zz#q", "v3#d", "v6#e"]
+    assert ev.get_gt(vm, qm) == orc.get_gt(vm, qm)
+
+
+def test_eval_epoch_vs_golden_g5(golden_dir):
+    from dldkd_amd import eval as ev
+    g = np.load(f"{golden_dir}/g5_eval_epoch.npz")
+    m = _model(3072, 768, synth.make_params(51, 3072, 768))
+    vids, txts = synth.make_eval_sets(5, nv=64, caps=3, dv=3072, dq=768)
+    opt = _opt()
+    with torch.no_grad():
+        ctx = ev.compute_context_info(m, synth.ListDataset(list(vids)), opt)
+        inh, exp, _, qmetas = ev.compute_query2ctx_info(m, synth.ListDataset(list(txts)), opt, ctx)
+        sumr = ev.eval_epoch(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), opt)
+    assert list(qmetas) == list(g["query_metas"])                 # per-batch length-sorted row order
+    assert list(ctx["video_metas"]) == list(g["video_metas"])
+    assert (ctx["video_mask"].cpu().numpy() == g["video_mask"]).all()
+    samp = ctx["inher_frame_feat"][::7, ::3, ::16].cpu().numpy()
+    assert np.abs(samp - g["gallery_inh_sample"]).max() < 3e-5     # fp32 towers
+    assert np.abs(inh - g["inh"]).max() < 6e-3 and np.abs(exp - g["exp"]).max() < 6e-3   # bf16 scorer
+    # R@K of the reference on these inputs; random-init weights give near-ties, so allow one query (of 192)
+    # to move across a cut: 100/192 = 0.52
+    _, t2v = ev.get_gt(ctx["video_metas"], qmetas)
+    fused = 0.7 * inh + 0.3 * exp
+    ours = ev.eval_q2m(-fused, t2v)
+    for a, b in zip(ours[:4], g["perf_fused"][:4]):
+        assert abs(a - b) <= 0.53, (ours, g["perf_fused"])
+    assert abs(sumr - float(g["sumr"])) <= 1.6
+    # and exactly equal to ranking OUR scores with the oracle's ranking code
+    assert ours == pytest.approx(orc.eval_q2m(-fused, t2v))
+
+
+def test_get_pred_from_raw_query():
+    from dldkd_amd import eval as ev
+    from dldkd_amd.data import collate_text_val
+    m = _model(1024, 1024, synth.make_params(9, 1024, 1024))
+    vids, txts = synth.make_eval_sets(6, nv=10, caps=2, dv=1024, dq=1024)
+    opt = _opt()
+    with torch.no_grad():
+        ctx = ev.compute_context_info(m, synth.ListDataset(list(vids)), opt)
+        words, mask, _, _ = collate_text_val(list(txts))
+        s0, s1 = m.get_pred_from_raw_query(words.to(DEV), mask.to(DEV), ctx)
+    p = {k: v.cpu() for k, v in m.state_dict().items()}
+    qi, qe = orc.encode_query(p, words, mask)
+    ref0 = orc.sim_scores(qi, ctx["inher_frame_feat"].cpu(), ctx["video_mask"].cpu())[0]
+    ref1 = orc.sim_scores(qe, ctx["explore_frame_feat"].cpu(), ctx["video_mask"].cpu())[0]
+    assert (s0.cpu() - ref0).abs().max() < 6e-3 and (s1.cpu() - ref1).abs().max() < 6e-3
