@@ -31,6 +31,10 @@ struct GemmArgs {
     float* C;
     int M, N, K, lda, ldb, ldc, relu;
     int a_vec, b_vec;   // operand is 16-byte aligned with a leading dimension divisible by 4 -> float4 loads
+    // strided batch: blockIdx.z = zo * batch_inner + zi; operand offset = zo * s?o + zi * s?i (elements)
+    int batch_inner;
+    long sAo, sAi, sBo, sBi, sCo, sCi;
+    float alpha;
 };
 
 // One operand tile (128 rows x 16 k) per k-tile; each thread moves 8 floats as two float4.
@@ -100,7 +104,13 @@ struct TileIO {
 };
 
 template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+    {
+        const int zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
+        p.A += zo * p.sAo + zi * p.sAi;
+        p.B += zo * p.sBo + zi * p.sBi;
+        p.C += zo * p.sCo + zi * p.sCi;
+    }
     __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_WORDS];   // [buffer][A|B]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
-                    float v = acc[i][j][r] + bias;
+                    float v = acc[i][j][r] * p.alpha + bias;
                     if (p.relu) v = fmaxf(v, 0.f);
                     p.C[(size_t)m * p.ldc + n] = v;
                 }
@@ -177,6 +187,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 
 using namespace dldkd;
 
+static int launch_gemm(GemmArgs p, int batch, int a_kmajor, int b_kmajor, void* stream) {
+    const dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p);
+    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p);
+    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, p);
+    return check_launch("gemm_f32");
+}
+
 extern "C" int dldkd_gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda,
                               int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* stream) {
     if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < N) {
@@ -186,12 +206,23 @@ extern "C" int dldkd_gemm_f32(const float* A, const float* B, const float* bias,
     if (M == 0 || N == 0) return DLDKD_OK;
     if (!A || !B || !C) { set_error("gemm_f32: null pointer"); return DLDKD_EINVAL; }
     const int a_vec = !(lda & 3) && !((uintptr_t)A & 15), b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
-    GemmArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec};
-    const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p);
-    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p);
-    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, p);
-    return check_launch("gemm_f32");
+    GemmArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f};
+    return launch_gemm(p, 1, a_kmajor, b_kmajor, stream);
+}
+
+extern "C" int dldkd_gemm_f32_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                                      int ldc, int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo,
+                                      long sAi, long sBo, long sBi, long sCo, long sCi, float alpha, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < 1 || batch_outer < 0 || batch_inner < 1) {
+        set_error("gemm_f32_batched: bad sizes");
+        return DLDKD_EINVAL;
+    }
+    const long batch = (long)batch_outer * batch_inner;
+    if (M == 0 || N == 0 || batch == 0) return DLDKD_OK;
+    if (batch > 65535) { set_error("gemm_f32_batched: batch %ld > 65535", batch); return DLDKD_EINVAL; }
+    if (!A || !B || !C) { set_error("gemm_f32_batched: null pointer"); return DLDKD_EINVAL; }
+    const bool al = !((sAo | sAi) & 3) && !(lda & 3) && !((uintptr_t)A & 15);
+    const bool bl = !((sBo | sBi) & 3) && !(ldb & 3) && !((uintptr_t)B & 15);
+    GemmArgs p{A, B, nullptr, C, M, N, K, lda, ldb, ldc, 0, al, bl, batch_inner, sAo, sAi, sBo, sBi, sCo, sCi, alpha};
+    return launch_gemm(p, (int)batch, a_kmajor, b_kmajor, stream);
 }

@@ -1,0 +1,356 @@
+// Loss kernels of DLDKD.forward (reference method/model.py:131-158), fp32, forward values and gradients.
+// Latency-bound: the matrices are (Nq, Nv) <= ~1024 x 1024 and (Nq, L <= 128); each replaces a Python
+// loop of the reference (640 host syncs + ~7k launches per step at the TVR batch).
+//   kl_frame      compute_kl_loss(mode='frame_score')        model.py:183-197
+//   nce_rows/cols clip_nce_soft.forward / clip_nce.forward   model_components.py:126-199 / :216-234
+//   trip_t2v/v2t  get_clip_triplet_loss                      model.py:353-387
+#include "common.hpp"
+
+namespace dldkd {
+
+// ---------------------------------------------------------------------------------------------
+// KL( softmax(t/temp) || softmax(p/temp) ) over the first len clips of the query's own video, per query.
+// Sp / St: (Nq, Nv, L) clip scores (student cosine / teacher cosine).  One wave per query, L <= 128.
+// dSp (optional): += g * (softmax(p/temp) - softmax(t/temp)) / temp at [q, label_q, l < len].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kl_frame_kernel(const float* __restrict__ Sp, const float* __restrict__ St,
+                                                       const int32_t* __restrict__ labels, const int32_t* __restrict__ lens,
+                                                       float temp, int nq, int nv, int L, float* __restrict__ out,
+                                                       float* __restrict__ dSp, float g) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int v = labels[q];
+    const int n = lens[v];
+    const size_t base = ((size_t)q * nv + v) * L;
+    float p[2], t[2];
+    float mp = -INFINITY, mt = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = lane + 64 * i;
+        p[i] = c < n ? Sp[base + c] / temp : -INFINITY;
+        t[i] = c < n ? St[base + c] / temp : -INFINITY;
+        mp = fmaxf(mp, p[i]);
+        mt = fmaxf(mt, t[i]);
+    }
+    mp = wave_max(mp);
+    mt = wave_max(mt);
+    float sp = 0.f, st = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (lane + 64 * i < n) { sp += expf(p[i] - mp); st += expf(t[i] - mt); }
+    }
+    const float lsp = mp + logf(wave_sum(sp)), lst = mt + logf(wave_sum(st));
+    float kl = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = lane + 64 * i;
+        if (c < n) {
+            const float logp = p[i] - lsp, logt = t[i] - lst, tt = expf(logt);
+            if (tt > 0.f) kl += tt * (logt - logp);          // xlogy: 0 where the target is 0
+            if (dSp) dSp[base + c] += g * (expf(logp) - tt) / temp;
+        }
+    }
+    kl = wave_sum(kl);
+    if (lane == 0 && out) out[q] = kl;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Symmetric InfoNCE, row pass (text -> video).  One wave per query row.
+//   IQ[q,:] = onehot(label_q)                                            (hard rows / clip_nce)
+//           = (1-beta) * softmax(T[q,:]) + beta * onehot                 (soft rows: q >= hardQ)
+//   term[q] = cq[q] * sum_v IQ[q,v] * (LSE(S[q,:]) - S[q,v])
+//   dS[q,v]  = g*cq[q] * (sum(IQ) * softmax(S[q,:])[v] - IQ[q,v])
+//   dT[q,u]  = g*cq[q] * (1-beta) * smT[u] * (c[u] - sum_v smT[v] c[v]),  c[v] = LSE - S[q,v]   (soft rows)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nce_rows_kernel(const float* __restrict__ S, const float* __restrict__ T,
+                                                       const int32_t* __restrict__ labels, const float* __restrict__ cq,
+                                                       int hardQ, float beta, int nq, int nv, float* __restrict__ terms,
+                                                       float* __restrict__ dS, float* __restrict__ dT, float g) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float* s = S + (size_t)q * nv;
+    const bool soft = T != nullptr && q >= hardQ;
+    const float* t = soft ? T + (size_t)q * nv : nullptr;
+    const int lab = labels[q];
+    float ms = -INFINITY, mt = -INFINITY;
+    for (int v = lane; v < nv; v += 64) { ms = fmaxf(ms, s[v]); if (soft) mt = fmaxf(mt, t[v]); }
+    ms = wave_max(ms);
+    if (soft) mt = wave_max(mt);
+    float zs = 0.f, zt = 0.f;
+    for (int v = lane; v < nv; v += 64) { zs += expf(s[v] - ms); if (soft) zt += expf(t[v] - mt); }
+    const float lse = ms + logf(wave_sum(zs));
+    const float izt = soft ? 1.f / wave_sum(zt) : 0.f;
+    float acc = 0.f, sumiq = 0.f, cbar = 0.f;
+    for (int v = lane; v < nv; v += 64) {
+        const float oh = v == lab ? 1.f : 0.f;
+        const float sm = soft ? expf(t[v] - mt) * izt : 0.f;
+        const float iq = soft ? fmaxf((1.f - beta) * sm + beta * oh, 0.f) : oh;
+        const float c = lse - s[v];
+        acc += iq * c;
+        sumiq += iq;
+        cbar += sm * c;
+    }
+    acc = wave_sum(acc);
+    sumiq = wave_sum(sumiq);
+    cbar = wave_sum(cbar);
+    const float coef = cq[q];
+    if (lane == 0 && terms) terms[q] = coef * acc;
+    if (dS) {
+        for (int v = lane; v < nv; v += 64) {
+            const float oh = v == lab ? 1.f : 0.f;
+            const float sm = soft ? expf(t[v] - mt) * izt : 0.f;
+            const float iq = soft ? fmaxf((1.f - beta) * sm + beta * oh, 0.f) : oh;
+            dS[(size_t)q * nv + v] = g * coef * (sumiq * expf(s[v] - lse) - iq);
+            if (dT) dT[(size_t)q * nv + v] = soft ? g * coef * (1.f - beta) * sm * ((lse - s[v]) - cbar) : 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column pass (video -> text).  One wave per video column; videos without a query contribute nothing.
+//   IV[q] = onehot                                                       (hard columns / clip_nce)
+//         = (1-beta) * softmax_q(T[:,v]) + beta * onehot                 (soft columns: v >= hardV)
+//   term[v] = cv[v] * ( LSE_q S[q,v] - LSE_q( log(IV[q] + eps) + S[q,v] ) )
+//   dS[q,v] += g*cv * (softmax_q(S[:,v])[q] - w[q]),  w = softmax_q(log(IV+eps) + S)
+//   dT[u,v] += g*cv * (1-beta) * smT[u] * (-r[u] + sum_q smT[q] r[q]),  r = w / (IV + eps)       (soft columns)
+// eps = 1e-12 for the soft loss (model_components.py:171), 0 for clip_nce (LSE over the positives only).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nce_cols_kernel(const float* __restrict__ S, const float* __restrict__ T,
+                                                       const int32_t* __restrict__ labels, const float* __restrict__ cv,
+                                                       int hardV, float beta, float eps, int nq, int nv,
+                                                       float* __restrict__ terms, float* __restrict__ dS,
+                                                       float* __restrict__ dT, float g) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= nv) return;
+    const bool soft = T != nullptr && v >= hardV;
+    float ms = -INFINITY, mt = -INFINITY;
+    int cnt = 0;
+    for (int q = lane; q < nq; q += 64) {
+        ms = fmaxf(ms, S[(size_t)q * nv + v]);
+        if (soft) mt = fmaxf(mt, T[(size_t)q * nv + v]);
+        cnt += labels[q] == v;
+    }
+    ms = wave_max(ms);
+    if (soft) mt = wave_max(mt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (cnt == 0) {   // label_dict has no entry for this video (model_components.py:169-180)
+        if (lane == 0 && terms) terms[v] = 0.f;
+        return;
+    }
+    float zs = 0.f, zt = 0.f;
+    for (int q = lane; q < nq; q += 64) {
+        zs += expf(S[(size_t)q * nv + v] - ms);
+        if (soft) zt += expf(T[(size_t)q * nv + v] - mt);
+    }
+    const float lse = ms + logf(wave_sum(zs));
+    const float izt = soft ? 1.f / wave_sum(zt) : 0.f;
+    // nominator LSE: max first
+    float mn = -INFINITY;
+    for (int q = lane; q < nq; q += 64) {
+        const float oh = labels[q] == v ? 1.f : 0.f;
+        const float sm = soft ? expf(T[(size_t)q * nv + v] - mt) * izt : 0.f;
+        const float iv = soft ? fmaxf((1.f - beta) * sm + beta * oh, 0.f) : oh;
+        const float a = iv + eps;
+        if (a > 0.f) mn = fmaxf(mn, logf(a) + S[(size_t)q * nv + v]);
+    }
+    mn = wave_max(mn);
+    float zn = 0.f;
+    for (int q = lane; q < nq; q += 64) {
+        const float oh = labels[q] == v ? 1.f : 0.f;
+        const float sm = soft ? expf(T[(size_t)q * nv + v] - mt) * izt : 0.f;
+        const float iv = soft ? fmaxf((1.f - beta) * sm + beta * oh, 0.f) : oh;
+        const float a = iv + eps;
+        if (a > 0.f) zn += expf(logf(a) + S[(size_t)q * nv + v] - mn);
+    }
+    const float nom = mn + logf(wave_sum(zn));
+    const float coef = cv[v];
+    if (lane == 0 && terms) terms[v] = coef * (lse - nom);
+    if (dS) {
+        float rbar = 0.f;
+        if (soft && dT) {
+            for (int q = lane; q < nq; q += 64) {
+                const float oh = labels[q] == v ? 1.f : 0.f;
+                const float sm = expf(T[(size_t)q * nv + v] - mt) * izt;
+                const float a = fmaxf((1.f - beta) * sm + beta * oh, 0.f) + eps;
+                const float w = expf(logf(a) + S[(size_t)q * nv + v] - nom);
+                rbar += sm * (w / a);
+            }
+            rbar = wave_sum(rbar);
+        }
+        for (int q = lane; q < nq; q += 64) {
+            const size_t i = (size_t)q * nv + v;
+            const float oh = labels[q] == v ? 1.f : 0.f;
+            const float sm = soft ? expf(T[i] - mt) * izt : 0.f;
+            const float iv = soft ? fmaxf((1.f - beta) * sm + beta * oh, 0.f) : oh;
+            const float a = iv + eps;
+            const float w = a > 0.f ? expf(logf(a) + S[i] - nom) : 0.f;
+            dS[i] += g * coef * (expf(S[i] - lse) - w);
+            if (soft && dT) dT[i] += g * coef * (1.f - beta) * sm * (-(w / a) + rbar);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Triplet, text -> video (model.py:372-385).  One wave per query: positive C[q,label]; negative = the
+// r-th largest (1-based r = rsel[q]) of the OTHER entries of the row (the reference forces the positive
+// to rank 0 with 999 and indexes the sorted row at r).  Selection by rank counting, no sort.
+// term[q] = max(0, margin + neg - pos) * scale;  dC[q,neg] += g*scale, dC[q,label] -= g*scale when active.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trip_t2v_kernel(const float* __restrict__ C, const int32_t* __restrict__ labels,
+                                                       const int32_t* __restrict__ rsel, float margin, float scale, int nq,
+                                                       int nv, float* __restrict__ terms, float* __restrict__ dC, float g) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    float* row = sm + (size_t)wave * nv;
+    if (q < nq) for (int v = lane; v < nv; v += 64) row[v] = C[(size_t)q * nv + v];
+    __syncthreads();
+    if (q >= nq) return;
+    const int lab = labels[q];
+    const int want = rsel[q] - 1;               // 0-based rank among the others
+    int found = -1;
+    for (int v = lane; v < nv; v += 64) {
+        if (v == lab) continue;
+        const float x = row[v];
+        int rank = 0;
+        for (int u = 0; u < nv; ++u) {
+            if (u == lab) continue;
+            const float y = row[u];
+            rank += (y > x) || (y == x && u < v);
+        }
+        if (rank == want) found = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) found = max(found, __shfl_xor(found, o));
+    if (lane == 0) {
+        const float loss = found >= 0 ? margin + row[found] - row[lab] : 0.f;
+        const bool act = loss > 0.f;
+        if (terms) terms[q] = act ? loss * scale : 0.f;
+        if (dC && act) {
+            atomicAdd(dC + (size_t)q * nv + found, g * scale);
+            atomicAdd(dC + (size_t)q * nv + lab, -g * scale);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Triplet, video -> text (model.py:360-369).  One workgroup per video i: positive = mean of C[q in i, i];
+// negative = max (hard) or the rsel[i]-th largest (0-based) of C[q not in i, i].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trip_v2t_kernel(const float* __restrict__ C, const int32_t* __restrict__ labels,
+                                                       const int32_t* __restrict__ rsel, int hard, float margin, float scale,
+                                                       int nq, int nv, float* __restrict__ terms, float* __restrict__ dC,
+                                                       float g) {
+    extern __shared__ float sm[];
+    __shared__ float red_s[4];
+    __shared__ int red_i[4];
+    __shared__ int sel;
+    float* col = sm;
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int q = tid; q < nq; q += 256) col[q] = C[(size_t)q * nv + i];
+    if (tid == 0) sel = -1;
+    __syncthreads();
+    float ps = 0.f;
+    int pc = 0;
+    for (int q = tid; q < nq; q += 256) if (labels[q] == i) { ps += col[q]; ++pc; }
+    ps = wave_sum(ps);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pc += __shfl_xor(pc, o);
+    if (lane == 0) { red_s[wave] = ps; red_i[wave] = pc; }
+    __syncthreads();
+    const float psum = red_s[0] + red_s[1] + red_s[2] + red_s[3];
+    const int pcnt = red_i[0] + red_i[1] + red_i[2] + red_i[3];
+    const int want = hard ? 0 : rsel[i];
+    for (int q = tid; q < nq; q += 256) {
+        if (labels[q] == i) continue;
+        const float x = col[q];
+        int rank = 0;
+        for (int u = 0; u < nq; ++u) {
+            if (labels[u] == i) continue;
+            const float y = col[u];
+            rank += (y > x) || (y == x && u < q);
+        }
+        if (rank == want) sel = q;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int n = sel;
+        const float pos = psum / (float)pcnt;       // NaN when the video has no caption, like torch.mean([])
+        const float loss = n >= 0 ? margin + col[n] - pos : 0.f;
+        const bool act = loss > 0.f;
+        if (terms) terms[i] = act ? loss * scale : (loss != loss ? loss : 0.f);
+        if (dC && act) atomicAdd(dC + (size_t)n * nv + i, g * scale);
+        red_i[0] = act ? 1 : 0;
+    }
+    __syncthreads();
+    if (dC && red_i[0]) {
+        for (int q = tid; q < nq; q += 256)
+            if (labels[q] == i) atomicAdd(dC + (size_t)q * nv + i, -g * scale / (float)pcnt);
+    }
+}
+
+// out[0] = sum x[0..n)   (single workgroup, deterministic order)
+__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+}  // namespace dldkd
+
+using namespace dldkd;
+
+extern "C" {
+
+int dldkd_kl_frame_f32(const float* Sp, const float* St, const int32_t* labels, const int32_t* lens, float temp, int nq,
+                       int nv, int L, float* out, float* dSp, float g, void* stream) {
+    if (nq < 0 || nv < 1 || L < 1 || L > 128 || temp <= 0.f) { set_error("kl_frame: bad sizes"); return DLDKD_EINVAL; }
+    if (nq == 0) return DLDKD_OK;
+    if (!Sp || !St || !labels || !lens) { set_error("kl_frame: null pointer"); return DLDKD_EINVAL; }
+    hipLaunchKernelGGL(kl_frame_kernel, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, Sp, St, labels, lens, temp, nq,
+                       nv, L, out, dSp, g);
+    return check_launch("kl_frame");
+}
+
+int dldkd_nce_f32(const float* S, const float* T, const int32_t* labels, const float* cq, const float* cv, int hardQ,
+                  int hardV, float beta, float eps, int nq, int nv, float* terms, float* dS, float* dT, float g,
+                  void* stream) {
+    if (nq < 1 || nv < 1) { set_error("nce: bad sizes"); return DLDKD_EINVAL; }
+    if (!S || !labels || !cq || !cv) { set_error("nce: null pointer"); return DLDKD_EINVAL; }
+    hipLaunchKernelGGL(nce_rows_kernel, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, T, labels, cq, hardQ, beta, nq,
+                       nv, terms, dS, dT, g);
+    hipLaunchKernelGGL(nce_cols_kernel, dim3((nv + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, T, labels, cv, hardV, beta, eps,
+                       nq, nv, terms ? terms + nq : nullptr, dS, dT, g);
+    return check_launch("nce");
+}
+
+int dldkd_triplet_f32(const float* C, const int32_t* labels, const int32_t* r_t2v, const int32_t* r_v2t, int hard,
+                      float margin, int nq, int nv, float* terms, float* dC, float g, void* stream) {
+    if (nq < 1 || nv < 1) { set_error("triplet: bad sizes"); return DLDKD_EINVAL; }
+    if (!C || !labels || !r_t2v || (!hard && !r_v2t)) { set_error("triplet: null pointer"); return DLDKD_EINVAL; }
+    if ((size_t)nv * 4 * sizeof(float) > 64 * 1024 || (size_t)nq * sizeof(float) > 64 * 1024) {
+        set_error("triplet: batch too large for the LDS row/column buffers");
+        return DLDKD_EINVAL;
+    }
+    hipLaunchKernelGGL(trip_t2v_kernel, dim3((nq + 3) / 4), dim3(256), (size_t)nv * 4 * sizeof(float), (hipStream_t)stream, C,
+                       labels, r_t2v, margin, 1.f / nq, nq, nv, terms, dC, g);
+    hipLaunchKernelGGL(trip_v2t_kernel, dim3(nv), dim3(256), (size_t)nq * sizeof(float), (hipStream_t)stream, C, labels, r_v2t,
+                       hard, margin, 1.f / nv, nq, nv, terms ? terms + nq : nullptr, dC, g);
+    return check_launch("triplet");
+}
+
+int dldkd_sum_f32(const float* x, long n, float* out, void* stream) {
+    if (n < 0 || !out) { set_error("sum: bad arguments"); return DLDKD_EINVAL; }
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    return check_launch("sum");
+}
+
+}  // extern "C"

@@ -1,0 +1,378 @@
+// fp32 training-side kernels of the encoder towers and the clip max-pool (forward pieces that must keep
+// intermediates, and every backward piece).  The heavy contractions go through gemm_f32 (plain and
+// strided-batched); what is here is bandwidth / latency bound row-wise work, one wave per row.
+//   softmax_rows_{fwd,bwd}   attention probabilities, BertSelfAttention.forward model_components.py:417-426
+//   layernorm_bwd            nn.LayerNorm backward (input grad + gamma/beta grads)
+//   colsum                   bias / position-table gradients (sum over rows)
+//   relu_bwd, axpy, mul      LinearLayer ReLU (:310-311), residual adds, dropout masks
+//   normalize_rows_{fwd,bwd} F.normalize of get_sim_scores (model.py:318-319)
+//   clip_pool_{fwd,bwd}      mask_logits + torch.max over clips (model.py:325-327,347-349)
+//   modpool_bwd              get_modularized_queries backward (model.py:245-258)
+#include "common.hpp"
+
+namespace dldkd {
+
+// ---------------------------------------------------------------- softmax over the last dim (<= 128)
+// rows = N*H*Lq; row r belongs to sequence r / (H*Lq); P = softmax(S*scale + (1-keymask)*-1e4), in place.
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float* __restrict__ S, const float* __restrict__ keymask,
+                                                               long rows, int L, int rows_per_seq, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float* row = S + r * L;
+    const float* km = keymask ? keymask + (r / rows_per_seq) * L : nullptr;
+    float v[2];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = -INFINITY;
+        if (c < L) {
+            v[i] = row[c] * scale + (km ? (1.f - km[c]) * -10000.f : 0.f);
+            mx = fmaxf(mx, v[i]);
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { v[i] = (lane + 64 * i < L) ? expf(v[i] - mx) : 0.f; sum += v[i]; }
+    const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) if (lane + 64 * i < L) row[lane + 64 * i] = v[i] * inv;
+}
+
+// dS = scale * P * (dP - sum(dP * P)), written over dP
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, long rows,
+                                                               int L, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* p = P + r * L;
+    float* d = dP + r * L;
+    float pv[2], dv[2], dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = lane + 64 * i;
+        pv[i] = c < L ? p[c] : 0.f;
+        dv[i] = c < L ? d[c] : 0.f;
+        dot += pv[i] * dv[i];
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) if (lane + 64 * i < L) d[lane + 64 * i] = scale * pv[i] * (dv[i] - dot);
+}
+
+// ---------------------------------------------------------------- LayerNorm backward
+// y = (x+add - mean) * rstd * gamma + beta.  dx (optional) = rstd * (g - mean(g) - xhat * mean(g * xhat)),
+// g = dy * gamma; dgamma += dy * xhat, dbeta += dy (atomics, one per column per workgroup).
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                            int add_mod, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dy, float* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, long M,
+                                                            int D, float eps, int rows_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int nv = D >> 2;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+    f32x4 ag[MAXV], ab[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; }
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rows_per_wave;
+    for (long row = row0; row < row0 + rows_per_wave && row < M; ++row) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
+        const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (add_mod > 0 ? row % add_mod : row) * D) : nullptr;
+        const f32x4* dyr = reinterpret_cast<const f32x4*>(dy + row * D);
+        f32x4 v[MAXV], d[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            d[i] = v[i];
+            if (c < nv) {
+                v[i] = xr[c];
+                if (ar) { const f32x4 a = ar[c]; v[i] += a; }
+                d[i] = dyr[c];
+                s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            }
+        }
+        const float mean = wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (lane + 64 * i < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float t = v[i][e] - mean; q += t * t; }
+            }
+        const float rstd = rsqrtf(wave_sum(q) / D + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const f32x4 g = g4[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (v[i][e] - mean) * rstd;
+                    v[i][e] = xh;
+                    ag[i][e] += d[i][e] * xh;
+                    ab[i][e] += d[i][e];
+                    d[i][e] *= g[e];
+                    sg += d[i][e];
+                    sgx += d[i][e] * xh;
+                }
+            }
+        }
+        if (dx) {
+            const float mg = wave_sum(sg) / D, mgx = wave_sum(sgx) / D;
+            f32x4* dxr = reinterpret_cast<f32x4*>(dx + row * D);
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nv) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rstd * (d[i][e] - mg - v[i][e] * mgx);
+                    dxr[c] = o;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(dgamma + c * 4 + e, ag[i][e]);
+                atomicAdd(dbeta + c * 4 + e, ab[i][e]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- column sums: out[c] += sum_r x[r, c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long M, long N,
+                                                     int rows_per_block) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    float s = 0.f;
+    for (long r = r0; r < r0 + rows_per_block && r < M; ++r) s += x[r * N + c];
+    atomicAdd(out + c, s);
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && !(y[i] > 0.f)) dy[i] = 0.f;
+}
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ a, const float* __restrict__ b, float alpha, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) a[i] += alpha * b[i];
+}
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ m, float scale,
+                                                  float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] * m[i] * scale;
+}
+
+// ---------------------------------------------------------------- F.normalize rows (eps 1e-12)
+__global__ __launch_bounds__(256) void normalize_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 float* __restrict__ inv, long M, int D) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    float ss = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = x[r * D + c]; ss += v * v; }
+    const float s = 1.f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+    for (int c = lane; c < D; c += 64) y[r * D + c] = x[r * D + c] * s;
+    if (lane == 0) inv[r] = s;
+}
+// dx = inv * (dy - y * <y, dy>)   (norm > eps; rows of zeros have y = 0 -> dx = inv * dy like ATen's clamp path)
+__global__ __launch_bounds__(256) void normalize_rows_bwd_kernel(const float* __restrict__ y, const float* __restrict__ inv,
+                                                                 const float* __restrict__ dy, float* __restrict__ dx,
+                                                                 long M, int D) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    float dot = 0.f;
+    for (int c = lane; c < D; c += 64) dot += y[r * D + c] * dy[r * D + c];
+    dot = wave_sum(dot);
+    const float s = inv[r];
+    for (int c = lane; c < D; c += 64) dx[r * D + c] = s * (dy[r * D + c] - y[r * D + c] * dot);
+}
+
+// ---------------------------------------------------------------- clip max-pool over (Nq, Nv, L) scores
+// S[q, v, l] for l >= lens[v] becomes exactly -1e10 (mask_logits, model.py:444-445); pooled = max_l, arg = first
+// index of the max.  One wave per (q, v).
+__global__ __launch_bounds__(256) void clip_pool_fwd_kernel(float* __restrict__ S, const int32_t* __restrict__ lens,
+                                                            float* __restrict__ pooled, int32_t* __restrict__ arg, long pairs,
+                                                            int nv, int L) {
+    const int lane = threadIdx.x & 63;
+    const long pr = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pr >= pairs) return;
+    const int len = lens[pr % nv];
+    float* row = S + pr * L;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < L; c += 64) {
+        float v = row[c];
+        if (c >= len) { v = -1e10f; row[c] = v; }
+        if (v > best) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { pooled[pr] = best; arg[pr] = bi; }
+}
+// dS[q, v, arg] += dpooled[q, v]   (valid clips only: the mask multiply zeroes the gradient of padding)
+__global__ __launch_bounds__(256) void clip_pool_bwd_kernel(const float* __restrict__ dpooled, const int32_t* __restrict__ arg,
+                                                            const int32_t* __restrict__ lens, float* __restrict__ dS,
+                                                            long pairs, int nv, int L) {
+    const long pr = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pr >= pairs) return;
+    const int a = arg[pr];
+    if (a < lens[pr % nv]) dS[pr * L + a] += dpooled[pr];
+}
+
+// ---------------------------------------------------------------- modular pooling backward
+// out = sum_l a_l h_l, a = softmax(logit), logit_l = m_l * (h_l . w) + (1 - m_l) * -1e10
+__global__ __launch_bounds__(256) void modpool_bwd_kernel(const float* __restrict__ h, const float* __restrict__ mask,
+                                                          const float* __restrict__ w, const float* __restrict__ attn,
+                                                          const float* __restrict__ dout, float* __restrict__ dh,
+                                                          float* __restrict__ dw, int N, int L) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    float wacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        const float* hn = h + (size_t)n * L * kHidden;
+        float* dhn = dh + (size_t)n * L * kHidden;
+        float wv[6], dv[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { wv[j] = w[lane + 64 * j]; dv[j] = dout[(size_t)n * kHidden + lane + 64 * j]; }
+        const float a = lane < L ? attn[(size_t)n * L + lane] : 0.f;
+        float my_da = 0.f;   // lane l keeps da_l = dout . h_l
+        for (int l = 0; l < L; ++l) {
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) d += hn[(size_t)l * kHidden + lane + 64 * j] * dv[j];
+            d = wave_sum(d);
+            if (lane == l) my_da = d;
+        }
+        const float dot = wave_sum(a * my_da);
+        const float dlogit = a * (my_da - dot) * (lane < L ? mask[(size_t)n * L + lane] : 0.f);
+        for (int l = 0; l < L; ++l) {
+            const float al = __shfl(a, l), dl = __shfl(dlogit, l);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float hv = hn[(size_t)l * kHidden + lane + 64 * j];
+                dhn[(size_t)l * kHidden + lane + 64 * j] = al * dv[j] + dl * wv[j];
+                wacc[j] += dl * hv;
+            }
+        }
+    }
+    if (n < N) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) atomicAdd(dw + lane + 64 * j, wacc[j]);
+    }
+}
+
+}  // namespace dldkd
+
+using namespace dldkd;
+
+#define LAUNCH1D(kernel, n, per_block, ...) \
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(((n) + (per_block) - 1) / (per_block))), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
+
+extern "C" {
+
+int dldkd_softmax_rows_fwd_f32(float* S, const float* keymask, long rows, int L, int rows_per_seq, float scale, void* stream) {
+    if (rows < 0 || L < 1 || L > 128 || rows_per_seq < 1) { set_error("softmax_rows_fwd: bad sizes"); return DLDKD_EINVAL; }
+    if (rows == 0) return DLDKD_OK;
+    LAUNCH1D(softmax_rows_fwd_kernel, rows, 4, S, keymask, rows, L, rows_per_seq, scale);
+    return check_launch("softmax_rows_fwd");
+}
+int dldkd_softmax_rows_bwd_f32(const float* P, float* dP, long rows, int L, float scale, void* stream) {
+    if (rows < 0 || L < 1 || L > 128) { set_error("softmax_rows_bwd: bad sizes"); return DLDKD_EINVAL; }
+    if (rows == 0) return DLDKD_OK;
+    LAUNCH1D(softmax_rows_bwd_kernel, rows, 4, P, dP, rows, L, scale);
+    return check_launch("softmax_rows_bwd");
+}
+int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* dy, float* dx,
+                            float* dgamma, float* dbeta, long M, int D, float eps, void* stream) {
+    if (M < 0 || D < 4 || (D & 3) || D > 4096) { set_error("layernorm_bwd: bad sizes"); return DLDKD_EINVAL; }
+    if (M == 0) return DLDKD_OK;
+    if (!x || !gamma || !dy || !dgamma || !dbeta) { set_error("layernorm_bwd: null pointer"); return DLDKD_EINVAL; }
+    const int rpw = 8;   // rows per wave -> one atomic per column per 32 rows
+    const long waves = (M + rpw - 1) / rpw;
+    const int nv = (D / 4 + 63) / 64;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (nv <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    else if (nv <= 4) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    else if (nv <= 8) hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    return check_launch("layernorm_bwd");
+}
+int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream) {
+    if (M < 0 || N < 0) { set_error("colsum: bad sizes"); return DLDKD_EINVAL; }
+    if (M == 0 || N == 0) return DLDKD_OK;
+    const int rpb = 64;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((M + rpb - 1) / rpb)), dim3(256), 0,
+                       (hipStream_t)stream, x, out, M, N, rpb);
+    return check_launch("colsum");
+}
+int dldkd_relu_bwd_f32(float* dy, const float* y, long n, void* stream) {
+    if (n <= 0) return n < 0 ? DLDKD_EINVAL : DLDKD_OK;
+    LAUNCH1D(relu_bwd_kernel, n, 256, dy, y, n);
+    return check_launch("relu_bwd");
+}
+int dldkd_axpy_f32(float* a, const float* b, float alpha, long n, void* stream) {
+    if (n <= 0) return n < 0 ? DLDKD_EINVAL : DLDKD_OK;
+    LAUNCH1D(axpy_kernel, n, 256, a, b, alpha, n);
+    return check_launch("axpy");
+}
+int dldkd_mul_f32(const float* a, const float* m, float scale, float* out, long n, void* stream) {
+    if (n <= 0) return n < 0 ? DLDKD_EINVAL : DLDKD_OK;
+    LAUNCH1D(mul_kernel, n, 256, a, m, scale, out, n);
+    return check_launch("mul");
+}
+int dldkd_normalize_rows_fwd_f32(const float* x, float* y, float* inv, long M, int D, void* stream) {
+    if (M < 0 || D < 1) { set_error("normalize_rows_fwd: bad sizes"); return DLDKD_EINVAL; }
+    if (M == 0) return DLDKD_OK;
+    LAUNCH1D(normalize_rows_fwd_kernel, M, 4, x, y, inv, M, D);
+    return check_launch("normalize_rows_fwd");
+}
+int dldkd_normalize_rows_bwd_f32(const float* y, const float* inv, const float* dy, float* dx, long M, int D, void* stream) {
+    if (M < 0 || D < 1) { set_error("normalize_rows_bwd: bad sizes"); return DLDKD_EINVAL; }
+    if (M == 0) return DLDKD_OK;
+    LAUNCH1D(normalize_rows_bwd_kernel, M, 4, y, inv, dy, dx, M, D);
+    return check_launch("normalize_rows_bwd");
+}
+int dldkd_clip_pool_fwd_f32(float* S, const int32_t* lens, float* pooled, int32_t* arg, int nq, int nv, int L, void* stream) {
+    if (nq < 0 || nv < 0 || L < 1) { set_error("clip_pool_fwd: bad sizes"); return DLDKD_EINVAL; }
+    const long pairs = (long)nq * nv;
+    if (pairs == 0) return DLDKD_OK;
+    LAUNCH1D(clip_pool_fwd_kernel, pairs, 4, S, lens, pooled, arg, pairs, nv, L);
+    return check_launch("clip_pool_fwd");
+}
+int dldkd_clip_pool_bwd_f32(const float* dpooled, const int32_t* arg, const int32_t* lens, float* dS, int nq, int nv, int L,
+                            void* stream) {
+    if (nq < 0 || nv < 0 || L < 1) { set_error("clip_pool_bwd: bad sizes"); return DLDKD_EINVAL; }
+    const long pairs = (long)nq * nv;
+    if (pairs == 0) return DLDKD_OK;
+    LAUNCH1D(clip_pool_bwd_kernel, pairs, 256, dpooled, arg, lens, dS, pairs, nv, L);
+    return check_launch("clip_pool_bwd");
+}
+int dldkd_modpool_bwd_f32(const float* h, const float* mask, const float* w, const float* attn, const float* dout, float* dh,
+                          float* dw, int N, int L, void* stream) {
+    if (N < 0 || L < 1 || L > 64) { set_error("modpool_bwd: bad sizes"); return DLDKD_EINVAL; }
+    if (N == 0) return DLDKD_OK;
+    LAUNCH1D(modpool_bwd_kernel, N, 4, h, mask, w, attn, dout, dh, dw, N, L);
+    return check_launch("modpool_bwd");
+}
+
+}  // extern "C"

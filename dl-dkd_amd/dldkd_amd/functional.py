@@ -1,0 +1,430 @@
+"""Differentiable ops: torch.autograd.Function shells whose forward AND backward are HIP kernels.
+
+torch supplies tensors, the tape and the stream; every number is produced by libdldkd_hip.so.  Under
+torch.no_grad() the same entry points run the fused inference kernels (ops.attention etc.).
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import native, ops
+
+HIDDEN, HEADS, DH = 384, 4, 96
+_L = native.lib
+_p, _s = native.ptr, native.stream
+
+
+def _f32(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def _colsum(x2d, n_out):
+    out = torch.zeros(n_out, dtype=torch.float32, device=x2d.device)
+    native.check(_L().dldkd_colsum_f32(_p(x2d), _p(out), x2d.shape[0], x2d.shape[1], _s()), "colsum")
+    return out
+
+
+def _axpy(a, b, alpha=1.0):
+    native.check(_L().dldkd_axpy_f32(_p(a), _p(b), float(alpha), a.numel(), _s()), "axpy")
+    return a
+
+
+# ------------------------------------------------------------------------------------------ linear
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        y = ops.linear(x, weight, bias, relu=relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        K, N = w.shape[1], w.shape[0]
+        dy2 = _f32(dy).reshape(-1, N)
+        if ctx.relu:
+            dy2 = dy2.clone()
+            native.check(_L().dldkd_relu_bwd_f32(_p(dy2), _p(y.reshape(-1, N)), dy2.numel(), _s()), "relu_bwd")
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        dx = ops.gemm(dy2, w, False, True, M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = ops.gemm(dy2, x2, True, True, N, K, M) if ctx.needs_input_grad[1] else None
+        db = _colsum(dy2, N) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, relu=False):
+    x = _f32(x)
+    if _needs_grad(x, weight, bias):
+        return _Linear.apply(x, weight, bias, relu)
+    return ops.linear(x, weight, bias, relu=relu)
+
+
+# ------------------------------------------------------------------------------------------ layernorm
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, add, add_mod):
+        ctx.save_for_backward(x, gamma, add)
+        ctx.add_mod = add_mod
+        return ops.layernorm(x, gamma, beta, add=add, add_mod=add_mod)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, add = ctx.saved_tensors
+        D = x.shape[-1]
+        dy = _f32(dy)
+        need_dx = ctx.needs_input_grad[0] or (add is not None and ctx.needs_input_grad[3])
+        dx = torch.empty_like(x) if need_dx else None
+        dg = torch.zeros(D, dtype=torch.float32, device=x.device)
+        db = torch.zeros(D, dtype=torch.float32, device=x.device)
+        native.check(_L().dldkd_layernorm_bwd_f32(_p(x.reshape(-1, D)), _p(add), ctx.add_mod, _p(gamma), _p(dy.reshape(-1, D)),
+                                                  _p(dx), _p(dg), _p(db), x.numel() // D, D, ops.LN_EPS, _s()), "layernorm_bwd")
+        dadd = None
+        if add is not None and ctx.needs_input_grad[3]:
+            if ctx.add_mod > 0:       # position table (L, D): sum over the batch
+                rows = ctx.add_mod * D
+                dadd = _colsum(dx.reshape(-1, rows), rows).view(ctx.add_mod, D)
+            else:                     # residual: same gradient
+                dadd = dx
+        return (dx if ctx.needs_input_grad[0] else None), dg, db, dadd, None
+
+
+def layernorm(x, gamma, beta, add=None, add_mod=0):
+    x = _f32(x)
+    add = _f32(add) if add is not None else None
+    if _needs_grad(x, gamma, beta, add):
+        return _LayerNorm.apply(x, gamma, beta, add, add_mod)
+    return ops.layernorm(x, gamma, beta, add=add, add_mod=add_mod)
+
+
+# ------------------------------------------------------------------------------------------ dropout
+class _Mul(Function):
+    @staticmethod
+    def forward(ctx, x, mask, scale):
+        ctx.save_for_backward(mask)
+        ctx.scale = scale
+        out = torch.empty_like(x)
+        native.check(_L().dldkd_mul_f32(_p(x), _p(mask), scale, _p(out), x.numel(), _s()), "mul")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = _f32(dy)
+        out = torch.empty_like(dy)
+        native.check(_L().dldkd_mul_f32(_p(dy), _p(mask), ctx.scale, _p(out), dy.numel(), _s()), "mul")
+        return out, None, None
+
+
+def dropout(x, p, training):
+    """Inverted dropout; the Bernoulli mask comes from torch's generator, the multiply is ours."""
+    if not training or p <= 0.0:
+        return x
+    x = _f32(x)
+    mask = (torch.rand_like(x) >= p).float()
+    return _Mul.apply(x, mask, 1.0 / (1.0 - p))
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _bgemm(A, B, C, M, N, K, lda, ldb, ldc, ak, bk, n_seq, sA, sB, sC, alpha=1.0):
+    """per-(sequence, head) product; s? = (outer stride, inner stride) in elements."""
+    native.check(_L().dldkd_gemm_f32_batched(A, B, C, M, N, K, lda, ldb, ldc, int(ak), int(bk), n_seq, HEADS,
+                                             sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], float(alpha), _s()), "gemm_f32_batched")
+
+
+def _off(t, elems):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + 4 * elems)
+
+
+class _AttentionTrain(Function):
+    """Training form of BertSelfAttention (model_components.py:398-436): batched GEMMs + row softmax, keeping
+    the probabilities for the backward pass.  qkv (N, L, 1152); returns the context layer (N, L, 384)."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask, drop_mask, drop_scale):
+        N, L = qkv.shape[0], qkv.shape[1]
+        P = torch.empty(N, HEADS, L, L, dtype=torch.float32, device=qkv.device)
+        sq = (L * 3 * HIDDEN, DH)
+        # S[q, key] = Q[q,:] . K[key,:]
+        _bgemm(_off(qkv, 0), _off(qkv, HIDDEN), _p(P), L, L, DH, 3 * HIDDEN, 3 * HIDDEN, L, 0, 0, N, sq, sq, (HEADS * L * L, L * L))
+        native.check(_L().dldkd_softmax_rows_fwd_f32(_p(P), _p(mask), N * HEADS * L, L, HEADS * L, 1.0 / math.sqrt(DH), _s()),
+                     "softmax_rows_fwd")
+        Pd = P
+        if drop_mask is not None:
+            Pd = torch.empty_like(P)
+            native.check(_L().dldkd_mul_f32(_p(P), _p(drop_mask), drop_scale, _p(Pd), P.numel(), _s()), "mul")
+        out = torch.empty(N, L, HIDDEN, dtype=torch.float32, device=qkv.device)
+        # ctx[q, d] = sum_key Pd[q,key] V[key,d]
+        _bgemm(_p(Pd), _off(qkv, 2 * HIDDEN), _p(out), L, DH, L, L, 3 * HIDDEN, HIDDEN, 0, 1, N, (HEADS * L * L, L * L), sq, (L * HIDDEN, DH))
+        ctx.save_for_backward(qkv, P, Pd if drop_mask is not None else None, drop_mask)
+        ctx.drop_scale = drop_scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, P, Pd, drop_mask = ctx.saved_tensors
+        N, L = qkv.shape[0], qkv.shape[1]
+        dout = _f32(dout)
+        dqkv = torch.empty_like(qkv)
+        sq, sp, so = (L * 3 * HIDDEN, DH), (HEADS * L * L, L * L), (L * HIDDEN, DH)
+        Puse = Pd if Pd is not None else P
+        # dV[key, d] = sum_q Pd[q,key] dout[q,d]
+        _bgemm(_p(Puse), _p(dout), _off(dqkv, 2 * HIDDEN), L, DH, L, L, HIDDEN, 3 * HIDDEN, 1, 1, N, sp, so, sq)
+        # dPd[q, key] = sum_d dout[q,d] V[key,d]
+        dP = torch.empty_like(P)
+        _bgemm(_p(dout), _off(qkv, 2 * HIDDEN), _p(dP), L, L, DH, HIDDEN, 3 * HIDDEN, L, 0, 0, N, so, sq, sp)
+        if drop_mask is not None:
+            native.check(_L().dldkd_mul_f32(_p(dP), _p(drop_mask), ctx.drop_scale, _p(dP), dP.numel(), _s()), "mul")
+        scale = 1.0 / math.sqrt(DH)
+        native.check(_L().dldkd_softmax_rows_bwd_f32(_p(P), _p(dP), N * HEADS * L, L, scale, _s()), "softmax_rows_bwd")
+        # dQ[q, d] = sum_key dS[q,key] K[key,d] ;  dK[key, d] = sum_q dS[q,key] Q[q,d]
+        _bgemm(_p(dP), _off(qkv, HIDDEN), _off(dqkv, 0), L, DH, L, L, 3 * HIDDEN, 3 * HIDDEN, 0, 1, N, sp, sq, sq)
+        _bgemm(_p(dP), _off(qkv, 0), _off(dqkv, HIDDEN), L, DH, L, L, 3 * HIDDEN, 3 * HIDDEN, 1, 1, N, sp, sq, sq)
+        return dqkv, None, None, None
+
+
+def attention(qkv, mask, p_drop=0.0, training=False):
+    qkv = _f32(qkv)
+    mask = _f32(mask) if mask is not None else None
+    if _needs_grad(qkv) or (training and p_drop > 0.0):
+        N, L = qkv.shape[0], qkv.shape[1]
+        if N * HEADS > 65535:
+            raise native.NativeError("training attention: at most 16383 sequences per call")
+        drop_mask = None
+        scale = 1.0
+        if training and p_drop > 0.0:
+            drop_mask = (torch.rand(N, HEADS, L, L, device=qkv.device) >= p_drop).float()
+            scale = 1.0 / (1.0 - p_drop)
+        return _AttentionTrain.apply(qkv, mask, drop_mask, scale)
+    return ops.attention(qkv, mask)
+
+
+# ------------------------------------------------------------------------------------------ modular pooling
+class _ModPool(Function):
+    @staticmethod
+    def forward(ctx, h, mask, w):
+        out, attn = ops.modpool(h, mask, w, want_attn=True)
+        ctx.save_for_backward(h, mask, w, attn)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, mask, w, attn = ctx.saved_tensors
+        dout = _f32(dout)
+        dh = torch.empty_like(h)
+        dw = torch.zeros_like(w)
+        native.check(_L().dldkd_modpool_bwd_f32(_p(h), _p(mask), _p(w), _p(attn), _p(dout), _p(dh), _p(dw), h.shape[0],
+                                                h.shape[1], _s()), "modpool_bwd")
+        return dh, None, dw
+
+
+def modpool(h, mask, w):
+    h, mask, w = _f32(h), _f32(mask), _f32(w)
+    if _needs_grad(h, w):
+        return _ModPool.apply(h, mask, w)
+    return ops.modpool(h, mask, w)
+
+
+# ------------------------------------------------------------------------------------------ scoring (training form)
+class _Normalize(Function):
+    @staticmethod
+    def forward(ctx, x):
+        D = x.shape[-1]
+        y = torch.empty_like(x)
+        inv = torch.empty(x.numel() // D, dtype=torch.float32, device=x.device)
+        native.check(_L().dldkd_normalize_rows_fwd_f32(_p(x), _p(y), _p(inv), x.numel() // D, D, _s()), "normalize_rows_fwd")
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        D = y.shape[-1]
+        dy = _f32(dy)
+        dx = torch.empty_like(y)
+        native.check(_L().dldkd_normalize_rows_bwd_f32(_p(y), _p(inv), _p(dy), _p(dx), y.numel() // D, D, _s()),
+                     "normalize_rows_bwd")
+        return dx
+
+
+def normalize(x):
+    return _Normalize.apply(_f32(x))
+
+
+class _ClipScores(Function):
+    """S[q, v, l] = <q_q, g_{v,l}> as one fp32-MFMA GEMM: (Nq, D) x (Nv*L, D)^T (model.py:321,344)."""
+
+    @staticmethod
+    def forward(ctx, q, g):
+        Nv, L, D = g.shape
+        ctx.save_for_backward(q, g)
+        return ops.linear(q, g.reshape(Nv * L, D)).view(q.shape[0], Nv, L)
+
+    @staticmethod
+    def backward(ctx, dS):
+        q, g = ctx.saved_tensors
+        Nv, L, D = g.shape
+        Nq = q.shape[0]
+        dS2 = _f32(dS).reshape(Nq, Nv * L)
+        dq = ops.gemm(dS2, g.reshape(Nv * L, D), False, True, Nq, D, Nv * L) if ctx.needs_input_grad[0] else None
+        dg = ops.gemm(dS2, q, True, True, Nv * L, D, Nq).view(Nv, L, D) if ctx.needs_input_grad[1] else None
+        return dq, dg
+
+
+def clip_scores(q, g):
+    return _ClipScores.apply(_f32(q), _f32(g))
+
+
+class _ClipPool(Function):
+    """mask_logits + max over clips.  Returns (pooled (Nq, Nv), masked clip scores (Nq, Nv, L))."""
+
+    @staticmethod
+    def forward(ctx, S, lens):
+        Nq, Nv, L = S.shape
+        Sm = S.clone()
+        pooled = torch.empty(Nq, Nv, dtype=torch.float32, device=S.device)
+        arg = torch.empty(Nq, Nv, dtype=torch.int32, device=S.device)
+        native.check(_L().dldkd_clip_pool_fwd_f32(_p(Sm), _p(lens), _p(pooled), _p(arg), Nq, Nv, L, _s()), "clip_pool_fwd")
+        ctx.save_for_backward(arg, lens)
+        ctx.shape = (Nq, Nv, L)
+        ctx.mark_non_differentiable(arg)
+        return pooled, Sm, arg
+
+    @staticmethod
+    def backward(ctx, dpooled, dSm, _darg):
+        arg, lens = ctx.saved_tensors
+        Nq, Nv, L = ctx.shape
+        dS = _f32(dSm).clone() if dSm is not None else torch.zeros(Nq, Nv, L, dtype=torch.float32, device=arg.device)
+        if dpooled is not None:
+            native.check(_L().dldkd_clip_pool_bwd_f32(_p(_f32(dpooled)), _p(arg), _p(lens), _p(dS), Nq, Nv, L, _s()),
+                         "clip_pool_bwd")
+        return dS, None
+
+
+def clip_pool(S, lens):
+    return _ClipPool.apply(_f32(S), lens)
+
+
+# ------------------------------------------------------------------------------------------ losses
+def _sum(x):
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    native.check(_L().dldkd_sum_f32(_p(x), x.numel(), _p(out), _s()), "sum")
+    return out.reshape(())
+
+
+class _KLFrame(Function):
+    @staticmethod
+    def forward(ctx, Sp, St, labels, lens, temp):
+        Nq, Nv, L = Sp.shape
+        out = torch.empty(Nq, dtype=torch.float32, device=Sp.device)
+        native.check(_L().dldkd_kl_frame_f32(_p(Sp), _p(St), _p(labels), _p(lens), temp, Nq, Nv, L, _p(out), None, 0.0, _s()),
+                     "kl_frame")
+        ctx.save_for_backward(Sp, St, labels, lens)
+        ctx.temp = temp
+        return _sum(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        Sp, St, labels, lens = ctx.saved_tensors
+        Nq, Nv, L = Sp.shape
+        dSp = torch.zeros_like(Sp)
+        native.check(_L().dldkd_kl_frame_f32(_p(Sp), _p(St), _p(labels), _p(lens), ctx.temp, Nq, Nv, L, None, _p(dSp),
+                                             float(g), _s()), "kl_frame")
+        return dSp, None, None, None, None
+
+
+def kl_frame(Sp, St, labels, lens, temp=0.2):
+    """sum_q KL(softmax(St[q, label_q, :len]/temp) || softmax(Sp[...]/temp)) (model.py:183-197)."""
+    return _KLFrame.apply(_f32(Sp), _f32(St).detach(), labels, lens, float(temp))
+
+
+class _NCE(Function):
+    @staticmethod
+    def forward(ctx, S, T, labels, cq, cv, hardQ, hardV, beta, eps, t_is_s):
+        Nq, Nv = S.shape
+        terms = torch.empty(Nq + Nv, dtype=torch.float32, device=S.device)
+        native.check(_L().dldkd_nce_f32(_p(S), _p(T), _p(labels), _p(cq), _p(cv), hardQ, hardV, beta, eps, Nq, Nv, _p(terms),
+                                        None, None, 0.0, _s()), "nce")
+        ctx.save_for_backward(S, T, labels, cq, cv)
+        ctx.cfg = (hardQ, hardV, beta, eps, t_is_s)
+        return _sum(terms)
+
+    @staticmethod
+    def backward(ctx, g):
+        S, T, labels, cq, cv = ctx.saved_tensors
+        hardQ, hardV, beta, eps, t_is_s = ctx.cfg
+        Nq, Nv = S.shape
+        dS = torch.empty_like(S)
+        dT = torch.empty_like(S) if (T is not None and t_is_s) else None
+        native.check(_L().dldkd_nce_f32(_p(S), _p(T), _p(labels), _p(cq), _p(cv), hardQ, hardV, beta, eps, Nq, Nv, None, _p(dS),
+                                        _p(dT), float(g), _s()), "nce")
+        if dT is not None:          # the exploration branch's soft labels are its own scores (model.py:149-150)
+            _axpy(dS, dT)
+        return dS, None, None, None, None, None, None, None, None, None
+
+
+def _part_coefs(n, hard_n, w_hard, w_soft, device):
+    c = torch.empty(n, dtype=torch.float32)
+    c[:hard_n] = w_hard
+    c[hard_n:] = w_soft
+    return c.to(device)
+
+
+def nce_soft(labels, S, T, alpha, beta):
+    """clip_nce_soft.forward (model_components.py:126-199).  T may be S itself (gradient then also flows
+    through the soft targets) or a tensor without gradient (teacher scores)."""
+    S = _f32(S)
+    Nq, Nv = S.shape
+    hardQ, hardV = math.floor(alpha * Nq), math.floor(alpha * Nv)
+    softQ, softV = Nq - hardQ, Nv - hardV
+    use_hard = hardQ != 0 and hardV != 0
+    use_soft = softQ != 0 and softV != 0
+    cq = _part_coefs(Nq, hardQ, alpha / hardQ if use_hard else 0.0, (1 - alpha) / softQ if use_soft else 0.0, S.device)
+    cv = _part_coefs(Nv, hardV, alpha / hardV if use_hard else 0.0, (1 - alpha) / softV if use_soft else 0.0, S.device)
+    t_is_s = T is S
+    Tt = S.detach() if t_is_s else _f32(T).detach()
+    return _NCE.apply(S, Tt, labels, cq, cv, hardQ, hardV, float(beta), 1e-12, t_is_s)
+
+
+def nce_hard(labels, S):
+    """clip_nce.forward (model_components.py:216-234)."""
+    S = _f32(S)
+    Nq, Nv = S.shape
+    cq = torch.full((Nq,), 1.0 / Nq, dtype=torch.float32, device=S.device)
+    cv = torch.full((Nv,), 1.0 / Nv, dtype=torch.float32, device=S.device)
+    return _NCE.apply(S, None, labels, cq, cv, Nq, Nv, 0.0, 0.0, False)
+
+
+class _Triplet(Function):
+    @staticmethod
+    def forward(ctx, C, labels, r_t2v, r_v2t, hard, margin):
+        Nq, Nv = C.shape
+        terms = torch.empty(Nq + Nv, dtype=torch.float32, device=C.device)
+        native.check(_L().dldkd_triplet_f32(_p(C), _p(labels), _p(r_t2v), _p(r_v2t), int(hard), margin, Nq, Nv, _p(terms),
+                                            None, 0.0, _s()), "triplet")
+        ctx.save_for_backward(C, labels, r_t2v, r_v2t)
+        ctx.cfg = (hard, margin)
+        return _sum(terms)
+
+    @staticmethod
+    def backward(ctx, g):
+        C, labels, r_t2v, r_v2t = ctx.saved_tensors
+        hard, margin = ctx.cfg
+        Nq, Nv = C.shape
+        dC = torch.zeros_like(C)
+        native.check(_L().dldkd_triplet_f32(_p(C), _p(labels), _p(r_t2v), _p(r_v2t), int(hard), margin, Nq, Nv, None, _p(dC),
+                                            float(g), _s()), "triplet")
+        return dC, None, None, None, None, None
+
+
+def triplet(C, labels, r_t2v, r_v2t, hard, margin):
+    """get_clip_triplet_loss (model.py:353-387) with the reference's random draws passed in."""
+    return _Triplet.apply(_f32(C), labels, r_t2v, r_v2t, bool(hard), float(margin))

@@ -4,12 +4,13 @@ Same constructor `(config, opt)`, same 74 state-dict keys, same public methods a
 reference method/model.py:13-387, so checkpoints and calling code carry over; every tensor op below the
 method boundary is a HIP kernel from libdldkd_hip.so (no ATen math on the path, no CPU fallback).
 """
-import copy
 import types
 
+import numpy as np
 import torch
 import torch.nn as nn
 
+from . import functional as F_
 from . import native, ops, scoring
 from .model_components import BertAttention, LinearLayer, TrainablePositionalEncoding
 
@@ -98,12 +99,12 @@ class DLDKD(nn.Module):
             h = self.encode_input(frame_video_feat, video_mask, getattr(self, pre + "visual_input_proj"),
                                   getattr(self, pre + "visual_encoder"), getattr(self, pre + "visual_pos_embed"))
             lin = getattr(self, pre + "out_mapping_linear")
-            out.append(ops.linear(h, lin.weight, lin.bias))
+            out.append(F_.linear(h, lin.weight, lin.bias))
         return (out[0], out[1]) if self.double_branch else (out[0], None)
 
     def get_modularized_queries(self, encoded_query, query_mask, inheritance=False):
         w = (self.modular_vector_mapping if inheritance else self.exp_modular_vector_mapping).weight
-        return ops.modpool(encoded_query.contiguous(), query_mask.float().contiguous(), w.reshape(-1).contiguous())
+        return F_.modpool(encoded_query, query_mask, w.reshape(-1))
 
     def encode_query(self, query_feat, query_mask):
         if query_feat.dim() == 2:            # the reference's collate .squeeze() drops a batch of one
@@ -137,3 +138,108 @@ class DLDKD(nn.Module):
         qs = [q_inh] + ([q_exp] if self.double_branch else [])
         _, s0, s1 = self.pooled_scores(qs, pg, want_branches=True)
         return s0, s1
+
+    # ------------------------------------------------------------------ fp32 scoring with clip-level output
+    @staticmethod
+    def _lens(mask, nv, L, device):
+        if mask is None:
+            return torch.full((nv,), L, dtype=torch.int32, device=device)
+        return (mask > 0).sum(1).to(torch.int32)
+
+    @staticmethod
+    def _clip_level(q, ctx, mask, normalize):
+        """fp32 (parity-grade) pooled + clip-level scores: returns (pooled (Nq,Nv), clip (Nq,Nv,L) masked)."""
+        q = q.float()
+        if q.dim() == 1:
+            q = q.unsqueeze(0)
+        ctx = ctx.float()
+        lens = DLDKD._lens(mask, ctx.shape[0], ctx.shape[1], ctx.device)
+        if normalize:
+            q, ctx = F_.normalize(q), F_.normalize(ctx)
+        pooled, clip, _ = F_.clip_pool(F_.clip_scores(q, ctx), lens)
+        return pooled, clip
+
+    @staticmethod
+    def get_sim_scores(modularied_query, context_feat, mask=None):
+        """Cosine scores: (pooled (Nq, Nv), clip-level (Nq, L, Nv)) as model.py:307-329; masked clips are
+        exactly -1e10.  fp32-MFMA path (differentiable); the clip-level tensor is a permuted view of the
+        (Nq, Nv, L) buffer the kernels use."""
+        pooled, clip = DLDKD._clip_level(modularied_query, context_feat, mask, True)
+        return pooled, clip.permute(0, 2, 1)
+
+    @staticmethod
+    def get_unnormalized_sim_scores(modularied_query, context_feat, mask=None):
+        """Raw dot-product twin (model.py:331-350): pooled (Nq, Nv)."""
+        return DLDKD._clip_level(modularied_query, context_feat, mask, False)[0]
+
+    # ------------------------------------------------------------------ losses (model.py:166-197, 353-387)
+    def compute_kl_loss(self, predict, target, cnn_mask, temp, mode="batch_score", query_labels=None):
+        if mode != "frame_score":
+            raise NotImplementedError("only mode='frame_score' is on the DL-DKD++ path (model.py:154-155)")
+        # predict / target arrive as (Nq, L, Nv) like the reference's; the kernels use (Nq, Nv, L)
+        Sp = predict.permute(0, 2, 1).contiguous()
+        St = target.permute(0, 2, 1).contiguous()
+        labels = torch.as_tensor(np.asarray(query_labels), dtype=torch.int32, device=Sp.device)
+        return F_.kl_frame(Sp, St, labels, self._lens(cnn_mask, Sp.shape[1], Sp.shape[2], Sp.device), temp)
+
+    def _draw_triplet(self, labels_np, nv):
+        """The reference's CPU torch.randint calls, same order and arguments (model.py:366-368,377-380)."""
+        hard = bool(_cfg_get(self.config, "use_hard_negative"))
+        r_v2t = None
+        if not hard:
+            r = [int(torch.randint(0, int((labels_np != i).sum()), size=(1,))) for i in range(nv)]
+            r_v2t = torch.tensor(r, dtype=torch.int32)
+        hi = min(1 + _cfg_get(self.config, "hard_pool_size"), nv) if hard else nv
+        r_t2v = torch.randint(1, hi, size=(len(labels_np),)).to(torch.int32)
+        return hard, r_t2v, r_v2t
+
+    def get_clip_triplet_loss(self, query_context_scores, labels):
+        labels_np = np.asarray(labels)
+        dev = query_context_scores.device
+        hard, r_t2v, r_v2t = self._draw_triplet(labels_np, query_context_scores.shape[1])
+        lab = torch.as_tensor(labels_np, dtype=torch.int32, device=dev)
+        return F_.triplet(query_context_scores, lab, r_t2v.to(dev), None if r_v2t is None else r_v2t.to(dev), hard,
+                          _cfg_get(self.config, "margin"))
+
+    # ------------------------------------------------------------------ training forward (model.py:100-163)
+    def forward(self, batch):
+        labels = batch["text_labels"]
+        mask = batch["student_videos_mask"].float()
+        dev = mask.device
+        lab = torch.as_tensor(np.asarray(labels), dtype=torch.int32, device=dev)
+        nv, L = mask.shape
+        lens = self._lens(mask, nv, L, dev)
+
+        g_inh, g_exp = self.encode_context(batch["student_videos"], mask)
+        q_inh, q_exp = self.encode_query(batch["student_text"], batch["student_text_mask"])
+        t_text = batch["teacher_text"].float().reshape(len(labels), -1)          # .squeeze() of model.py:114
+        t_vid = batch["teacher_videos"].float()
+
+        def both(q, g, want_clip):
+            pooled_cos, clip_cos, _ = F_.clip_pool(F_.clip_scores(F_.normalize(q), F_.normalize(g)), lens)
+            pooled_raw, _, _ = F_.clip_pool(F_.clip_scores(q, g), lens)
+            return pooled_cos, pooled_raw, (clip_cos if want_clip else None)
+
+        with torch.no_grad():
+            _, t_raw, t_clip = both(t_text, t_vid, True)
+        i_cos, i_raw, i_clip = both(q_inh, g_inh, True)
+
+        inher_trip = self.get_clip_triplet_loss(i_cos, labels)
+        soft = self.label_style == "soft"
+        if soft:
+            inher_nce = self.inher_nce_weight * F_.nce_soft(lab, i_raw, t_raw, self.alpha, self.belta)
+        else:
+            inher_nce = self.inher_nce_weight * F_.nce_hard(lab, i_raw)
+        explore_trip, explore_nce = 0, 0
+        if self.double_branch:
+            e_cos, e_raw, _ = both(q_exp, g_exp, False)
+            explore_trip = self.get_clip_triplet_loss(e_cos, labels)
+            if soft:
+                explore_nce = self.explore_nce_weight * F_.nce_soft(lab, e_raw, e_raw, self.alpha, self.belta)
+            else:
+                explore_nce = self.explore_nce_weight * F_.nce_hard(lab, e_raw)
+        kl_intra = self.kl_intra_weight * self.weight * F_.kl_frame(i_clip, t_clip, lab, lens, 0.2)
+        kl = kl_intra
+        loss = inher_trip + inher_nce + kl + explore_trip + explore_nce
+        return loss, {"loss_overall": float(loss), "inher_trip": inher_trip, "inher_nce": inher_nce,
+                      "explore_trip": explore_trip, "explore_nce": explore_nce, "kl": kl, "kl_intra": kl_intra}

@@ -7,6 +7,7 @@ libdldkd_hip.so through `ops` instead of ATen.
 import torch
 import torch.nn as nn
 
+from . import functional as F_
 from . import ops
 
 
@@ -24,9 +25,9 @@ class TrainablePositionalEncoding(nn.Module):
         L = input_feat.shape[1]
         if L > self.position_embeddings.num_embeddings:
             raise IndexError(f"sequence length {L} exceeds {self.position_embeddings.num_embeddings} positions")
-        pos = self.position_embeddings.weight[:L].contiguous()
-        out = ops.layernorm(input_feat, self.LayerNorm.weight, self.LayerNorm.bias, add=pos, add_mod=L)
-        return self.dropout(out)
+        pos = self.position_embeddings.weight[:L]
+        out = F_.layernorm(input_feat, self.LayerNorm.weight, self.LayerNorm.bias, add=pos, add_mod=L)
+        return F_.dropout(out, self.dropout.p, self.training)
 
 
 class LinearLayer(nn.Module):
@@ -42,10 +43,10 @@ class LinearLayer(nn.Module):
 
     def forward(self, x):
         if self.layer_norm:
-            x = ops.layernorm(x, self.LayerNorm.weight, self.LayerNorm.bias)
-        x = self.net[0](x)
+            x = F_.layernorm(x, self.LayerNorm.weight, self.LayerNorm.bias)
+        x = F_.dropout(x, self.net[0].p, self.training)
         lin = self.net[1]
-        return ops.linear(x, lin.weight, lin.bias, relu=self.relu)
+        return F_.linear(x, lin.weight, lin.bias, relu=self.relu)
 
 
 class BertSelfAttention(nn.Module):
@@ -75,11 +76,11 @@ class BertSelfAttention(nn.Module):
         if not (query_states is key_states and key_states is value_states):
             raise NotImplementedError("only self-attention is on the DL-DKD path (BertAttention.forward, :351)")
         w, b = self.fused_qkv()
-        qkv = ops.linear(query_states, w, b)                      # one GEMM for the three projections
+        qkv = F_.linear(query_states, w, b)                       # one GEMM for the three projections
         mask = None
         if attention_mask is not None:                            # (N, 1, L) as encode_input passes it (model.py:242)
             mask = attention_mask.reshape(attention_mask.shape[0], -1).contiguous()
-        return ops.attention(qkv, mask)
+        return F_.attention(qkv, mask, self.dropout.p, self.training)
 
 
 class BertSelfOutput(nn.Module):
@@ -92,9 +93,9 @@ class BertSelfOutput(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, hidden_states, input_tensor):
-        h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
-        h = self.dropout(h)
-        return ops.layernorm(h, self.LayerNorm.weight, self.LayerNorm.bias, add=input_tensor.contiguous(), add_mod=0)
+        h = F_.linear(hidden_states, self.dense.weight, self.dense.bias)
+        h = F_.dropout(h, self.dropout.p, self.training)
+        return F_.layernorm(h, self.LayerNorm.weight, self.LayerNorm.bias, add=input_tensor, add_mod=0)
 
 
 class BertAttention(nn.Module):

@@ -16,6 +16,7 @@ _c_int = ctypes.c_int
 _c_float = ctypes.c_float
 _c_void_p = ctypes.c_void_p
 _c_size_t = ctypes.c_size_t
+_c_long = ctypes.c_long
 
 # name -> (restype, argtypes); must list every symbol include/dldkd_hip.h declares
 SIGNATURES = {
@@ -32,11 +33,35 @@ SIGNATURES = {
                                        _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_gemm_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                  _c_int, _c_int, _c_int, _c_void_p]),
-    "dldkd_layernorm_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, ctypes.c_long, _c_int,
+    "dldkd_layernorm_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
                                       _c_float, _c_void_p]),
     "dldkd_attention_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
     "dldkd_modpool_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
     "dldkd_rank_gt": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_gemm_f32_batched": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                         _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_float,
+                                         _c_void_p]),
+    "dldkd_softmax_rows_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_float, _c_void_p]),
+    "dldkd_softmax_rows_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_float, _c_void_p]),
+    "dldkd_layernorm_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                          _c_long, _c_int, _c_float, _c_void_p]),
+    "dldkd_colsum_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_long, _c_void_p]),
+    "dldkd_relu_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p]),
+    "dldkd_axpy_f32": (_c_int, [_c_void_p, _c_void_p, _c_float, _c_long, _c_void_p]),
+    "dldkd_mul_f32": (_c_int, [_c_void_p, _c_void_p, _c_float, _c_void_p, _c_long, _c_void_p]),
+    "dldkd_normalize_rows_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
+    "dldkd_normalize_rows_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
+    "dldkd_clip_pool_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
+    "dldkd_clip_pool_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
+    "dldkd_modpool_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
+                                        _c_void_p]),
+    "dldkd_kl_frame_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_int, _c_int, _c_int, _c_void_p,
+                                     _c_void_p, _c_float, _c_void_p]),
+    "dldkd_nce_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_float, _c_int,
+                                _c_int, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_void_p]),
+    "dldkd_triplet_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_float, _c_int, _c_int, _c_void_p,
+                                    _c_void_p, _c_float, _c_void_p]),
+    "dldkd_sum_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p]),
 }
 
 _lib = None

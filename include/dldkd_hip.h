@@ -106,6 +106,83 @@ int dldkd_modpool_fwd_f32(const float* h, const float* mask, const float* w, flo
                           int L, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Training path, fp32 (DLDKD.forward + backward, method/model.py:100-197,353-387;
+ * method/model_components.py:106-234).  Heavy contractions = dldkd_gemm_f32{,_batched}; the rest is
+ * row-wise.  "d*" pointers are gradients; functions documented "+=" accumulate into zero-initialised or
+ * partially filled buffers.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Strided-batched form of dldkd_gemm_f32 (no bias/relu): for z = zo * batch_inner + zi,
+ * C_z = alpha * A_z B_z^T-style product with operand offsets zo * s?o + zi * s?i (elements).  Used for the
+ * per-(sequence, head) products of attention forward/backward (model_components.py:417,432). */
+int dldkd_gemm_f32_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                           int ldc, int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo,
+                           long sAi, long sBo, long sBi, long sCo, long sCi, float alpha, void* stream);
+
+/* P = softmax(S * scale + (1 - keymask) * -10000) over the last dim L <= 128, in place; row r uses
+ * keymask[r / rows_per_seq] (model_components.py:419-426).  keymask may be NULL. */
+int dldkd_softmax_rows_fwd_f32(float* S, const float* keymask, long rows, int L, int rows_per_seq, float scale,
+                               void* stream);
+/* dS = scale * P * (dP - sum(dP * P)), written over dP. */
+int dldkd_softmax_rows_bwd_f32(const float* P, float* dP, long rows, int L, float scale, void* stream);
+
+/* Backward of dldkd_layernorm_f32: dx (may be NULL) for the summed input; dgamma += , dbeta += . */
+int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* dy,
+                            float* dx, float* dgamma, float* dbeta, long M, int D, float eps, void* stream);
+
+/* out[c] += sum_r x[r, c]  (bias gradients; position-table gradient with x viewed as (batch, L*D)). */
+int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream);
+/* dy[i] = 0 where y[i] <= 0 (ReLU backward, in place). */
+int dldkd_relu_bwd_f32(float* dy, const float* y, long n, void* stream);
+/* a += alpha * b. */
+int dldkd_axpy_f32(float* a, const float* b, float alpha, long n, void* stream);
+/* out = a * m * scale  (dropout masks, forward and backward). */
+int dldkd_mul_f32(const float* a, const float* m, float scale, float* out, long n, void* stream);
+
+/* F.normalize(x, dim=-1) (eps 1e-12, model.py:318-319): y, inv (1/norm per row); and its backward. */
+int dldkd_normalize_rows_fwd_f32(const float* x, float* y, float* inv, long M, int D, void* stream);
+int dldkd_normalize_rows_bwd_f32(const float* y, const float* inv, const float* dy, float* dx, long M, int D,
+                                 void* stream);
+
+/* mask_logits + max over clips (model.py:325-327,347-349) on S (nq, nv, L): entries l >= lens[v] are set to
+ * exactly -1e10 in place; pooled (nq, nv) = max_l, arg = its first index.  Backward: dS[q,v,arg] += dpooled. */
+int dldkd_clip_pool_fwd_f32(float* S, const int32_t* lens, float* pooled, int32_t* arg, int nq, int nv, int L,
+                            void* stream);
+int dldkd_clip_pool_bwd_f32(const float* dpooled, const int32_t* arg, const int32_t* lens, float* dS, int nq,
+                            int nv, int L, void* stream);
+
+/* Backward of dldkd_modpool_fwd_f32: dh (N, L, 384) written, dw (384) += . */
+int dldkd_modpool_bwd_f32(const float* h, const float* mask, const float* w, const float* attn, const float* dout,
+                          float* dh, float* dw, int N, int L, void* stream);
+
+/* compute_kl_loss(mode='frame_score') (model.py:183-197): out[q] (may be NULL) = KL(softmax(St/temp) ||
+ * softmax(Sp/temp)) over the first lens[label_q] clips of Sp/St[q, label_q, :] ((nq, nv, L) clip scores);
+ * dSp (may be NULL) += g * d out[q] / d Sp. */
+int dldkd_kl_frame_f32(const float* Sp, const float* St, const int32_t* labels, const int32_t* lens, float temp,
+                       int nq, int nv, int L, float* out, float* dSp, float g, void* stream);
+
+/* Symmetric InfoNCE on raw pooled scores S (nq, nv) (clip_nce_soft / clip_nce, model_components.py:126-234).
+ * T = soft-label source scores or NULL (hard labels); rows q >= hardQ / columns v >= hardV use
+ * (1-beta) * softmax(T) + beta * onehot; cq[nq], cv[nv] = per-row / per-column weights (alpha, 1/count
+ * folded in by the host); eps = 1e-12 (soft) or 0 (clip_nce).  terms (nq + nv, may be NULL) = weighted
+ * row and column terms (their sum is the loss); dS (may be NULL) = g * dloss/dS (written);
+ * dT (may be NULL) = g * dloss/dT through the soft targets (written). */
+int dldkd_nce_f32(const float* S, const float* T, const int32_t* labels, const float* cq, const float* cv,
+                  int hardQ, int hardV, float beta, float eps, int nq, int nv, float* terms, float* dS, float* dT,
+                  float g, void* stream);
+
+/* get_clip_triplet_loss (model.py:353-387) on pooled cosine scores C (nq, nv): r_t2v[q] in [1, nv) = the
+ * reference's torch.randint draw (rank of the sampled negative in the row sorted descending with the
+ * positive first); r_v2t[v] = 0-based rank among the other queries' scores (ignored when hard != 0: the
+ * hardest negative).  terms (nq + nv) = per-query / per-video hinge terms already divided by nq / nv;
+ * dC (may be NULL) += g * dloss/dC. */
+int dldkd_triplet_f32(const float* C, const int32_t* labels, const int32_t* r_t2v, const int32_t* r_v2t, int hard,
+                      float margin, int nq, int nv, float* terms, float* dC, float g, void* stream);
+
+/* out[0] = sum of x[0..n) in a fixed order (single workgroup). */
+int dldkd_sum_f32(const float* x, long n, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Ranking (the step after scoring).  Replaces the np.argsort loop of eval_q2m (method/eval.py:69-83) and
  * the Python list walk of t2v_map (method/eval.py:97-111).
  * scores (nq, nv) fp32 similarity (higher = better; the reference ranks -scores ascending, eval.py:250);

@@ -1,0 +1,237 @@
+"""GPU parity of the training path: loss kernels vs the reference's golden values (G3) and the oracle's
+autograd gradients; encoder backward kernels vs torch autograd of the oracle; the whole
+DLDKD.forward + backward vs the reference's losses and 74 gradients (G4).
+
+Tolerances: losses 1e-4 relative (BASELINE.json north_star); gradients are compared with the oracle in
+fp64 at 2e-3 of each tensor's scale (fp32 kernels; the reference's own fp32 gradients differ from fp64 by
+1.3e-4, make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+import dldkd_oracle as orc
+import synth
+from test_encoder_gpu import _model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _g3(golden_dir):
+    g = np.load(f"{golden_dir}/g3_losses.npz")
+    counts = list(g["counts"])
+    labels = [i for i, c in enumerate(counts) for _ in range(c)]
+    L = g["predict"].shape[1]
+    mask = torch.from_numpy((np.arange(L)[None] < g["lens"][:, None]).astype(np.float32))
+    return g, labels, mask
+
+
+def _lab(labels):
+    return torch.tensor(labels, dtype=torch.int32, device=DEV)
+
+
+def _close(a, b, tol=1e-4):
+    a, b = float(a), float(b)
+    assert abs(a - b) <= tol * max(1.0, abs(b)), (a, b)
+
+
+def _gclose(got, ref, tol=2e-3):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    scale = ref.abs().max().clamp_min(1e-12)
+    assert ((got - ref).abs().max() / scale).item() <= tol, ((got - ref).abs().max().item(), scale.item())
+
+
+def test_kl_vs_golden_and_grad(golden_dir):
+    from dldkd_amd import functional as F_
+    g, labels, mask = _g3(golden_dir)
+    p = torch.from_numpy(g["predict"]).permute(0, 2, 1).contiguous().to(DEV).requires_grad_(True)   # (Nq, Nv, L)
+    t = torch.from_numpy(g["target"]).permute(0, 2, 1).contiguous().to(DEV)
+    lens = torch.from_numpy(g["lens"]).int().to(DEV)
+    kl = F_.kl_frame(p, t, _lab(labels), lens, 0.2)
+    _close(kl, g["kl"])
+    kl.backward()
+    po = torch.from_numpy(g["predict"]).double().requires_grad_(True)
+    orc.kl_frame_score(po, torch.from_numpy(g["target"]).double(), mask.double(), labels).backward()
+    _gclose(p.grad.permute(0, 2, 1), po.grad)
+
+
+@pytest.mark.parametrize("alpha", [0.0, 0.3, 0.8, 1.0])
+@pytest.mark.parametrize("beta", [0.5, 0.8])
+def test_nce_soft_vs_golden_and_grad(golden_dir, alpha, beta):
+    from dldkd_amd import functional as F_
+    g, labels, _ = _g3(golden_dir)
+    lab = _lab(labels)
+    raw, sims = torch.from_numpy(g["raw"]), torch.from_numpy(g["sims"])
+    S = raw.to(DEV).requires_grad_(True)
+    v = F_.nce_soft(lab, S, sims.to(DEV), alpha, beta)                 # teacher-style soft labels (no grad to T)
+    _close(v, g[f"nce_soft_a{alpha}_b{beta}"])
+    v.backward()
+    So = raw.double().requires_grad_(True)
+    orc.nce_soft(labels, So, sims.double(), alpha, beta).backward()
+    _gclose(S.grad, So.grad)
+    S2 = raw.to(DEV).requires_grad_(True)
+    v2 = F_.nce_soft(lab, S2, S2, alpha, beta)                          # exploration style: T is S (grad through targets)
+    _close(v2, g[f"nce_self_a{alpha}_b{beta}"])
+    v2.backward()
+    So2 = raw.double().requires_grad_(True)
+    orc.nce_soft(labels, So2, So2, alpha, beta).backward()
+    _gclose(S2.grad, So2.grad)
+
+
+def test_nce_hard_vs_golden_and_grad(golden_dir):
+    from dldkd_amd import functional as F_
+    g, labels, _ = _g3(golden_dir)
+    raw = torch.from_numpy(g["raw"])
+    S = raw.to(DEV).requires_grad_(True)
+    v = F_.nce_hard(_lab(labels), S)
+    _close(v, g["nce_hard"])
+    v.backward()
+    So = raw.double().requires_grad_(True)
+    orc.nce_hard(labels, So).backward()
+    _gclose(S.grad, So.grad)
+
+
+@pytest.mark.parametrize("hard", [0, 1])
+def test_triplet_vs_golden_and_grad(golden_dir, hard):
+    from dldkd_amd import functional as F_
+    g, labels, _ = _g3(golden_dir)
+    cos = torch.from_numpy(g["cos"])
+    r_t2v = torch.from_numpy(g[f"trip_hard{hard}_r_t2v"])
+    r_v2t = torch.from_numpy(g["trip_hard0_r_v2t"]) if not hard else None
+    C = cos.to(DEV).requires_grad_(True)
+    v = F_.triplet(C, _lab(labels), r_t2v.int().to(DEV), None if r_v2t is None else r_v2t.int().to(DEV), bool(hard), 0.1)
+    _close(v, g[f"trip_hard{hard}"])
+    v.backward()
+    Co = cos.double().requires_grad_(True)
+    orc.clip_triplet_loss(Co, labels, 0.1, bool(hard), r_v2t, r_t2v).backward()
+    _gclose(C.grad, Co.grad)
+
+
+def test_triplet_method_consumes_rng_like_reference(golden_dir):
+    """DLDKD.get_clip_triplet_loss draws from torch's CPU generator exactly as model.py:366-380 does."""
+    g, labels, _ = _g3(golden_dir)
+    m = _model(1024, 1024, synth.make_params(2, 1024, 1024))
+    for hard in (False, True):
+        m.set_hard_negative(hard, 5)
+        torch.manual_seed(77)
+        v = m.get_clip_triplet_loss(torch.from_numpy(g["cos"]).to(DEV), labels)
+        _close(v, g[f"trip_hard{int(hard)}"])
+
+
+def test_encoder_backward_ops_vs_autograd():
+    from dldkd_amd import functional as F_
+    gen = torch.Generator().manual_seed(11)
+    N, L, Din = 3, 13, 64
+    x = torch.randn(N, L, Din, generator=gen)
+    lens = torch.tensor([13, 4, 9])
+    mask = (torch.arange(L).unsqueeze(0) < lens.unsqueeze(1)).float()
+    p = {}
+    def mk(name, *shape, s=0.1):
+        p[name] = (torch.randn(*shape, generator=gen) * s)
+    mk("proj.LayerNorm.weight", Din, s=0.3); p["proj.LayerNorm.weight"] += 1
+    mk("proj.LayerNorm.bias", Din); mk("proj.net.1.weight", 384, Din); mk("proj.net.1.bias", 384)
+    mk("pos.position_embeddings.weight", 20, 384); mk("pos.LayerNorm.weight", 384, s=0.3); p["pos.LayerNorm.weight"] += 1
+    mk("pos.LayerNorm.bias", 384)
+    for n_ in ("query", "key", "value"):
+        mk(f"enc.self.{n_}.weight", 384, 384, s=0.05); mk(f"enc.self.{n_}.bias", 384)
+    mk("enc.output.dense.weight", 384, 384, s=0.05); mk("enc.output.dense.bias", 384)
+    mk("enc.output.LayerNorm.weight", 384, s=0.3); p["enc.output.LayerNorm.weight"] += 1; mk("enc.output.LayerNorm.bias", 384)
+    mk("w", 1, 384)
+    # oracle (fp64 autograd)
+    po = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    xo = x.double().requires_grad_(True)
+    ho = orc.encode_input(xo, mask.double(), po, "proj", "enc", "pos", 4)
+    out_o = orc.modular_pool(ho, mask.double(), po["w"])
+    cot = torch.randn(N, 384, generator=gen)
+    (out_o * cot.double()).sum().backward()
+    # HIP
+    pg = {k: v.to(DEV).requires_grad_(True) for k, v in p.items()}
+    xg = x.to(DEV).requires_grad_(True)
+    mg = mask.to(DEV)
+    h = F_.layernorm(xg, pg["proj.LayerNorm.weight"], pg["proj.LayerNorm.bias"])
+    h = F_.linear(h, pg["proj.net.1.weight"], pg["proj.net.1.bias"], relu=True)
+    h = F_.layernorm(h, pg["pos.LayerNorm.weight"], pg["pos.LayerNorm.bias"], add=pg["pos.position_embeddings.weight"][:L], add_mod=L)
+    w = torch.cat([pg[f"enc.self.{n_}.weight"] for n_ in ("query", "key", "value")], 0)
+    b = torch.cat([pg[f"enc.self.{n_}.bias"] for n_ in ("query", "key", "value")], 0)
+    ctxl = F_.attention(F_.linear(h, w, b), mg)
+    h2 = F_.layernorm(F_.linear(ctxl, pg["enc.output.dense.weight"], pg["enc.output.dense.bias"]),
+                      pg["enc.output.LayerNorm.weight"], pg["enc.output.LayerNorm.bias"], add=h, add_mod=0)
+    out = F_.modpool(h2, mg, pg["w"].reshape(-1))
+    assert (out.double().cpu() - out_o.detach()).abs().max() < 5e-5
+    (out * cot.to(DEV)).sum().backward()
+    _gclose(xg.grad, xo.grad)
+    gmax = max(v.grad.abs().max().item() for v in po.values())
+    for k in p:
+        ref = po[k].grad
+        got = pg[k].grad.double().cpu()
+        assert (got - ref).abs().max().item() <= 2e-3 * max(ref.abs().max().item(), 1e-4 * gmax), k   # key bias: exactly-zero gradient, fp32 noise
+
+
+def test_get_sim_scores_api_shapes_and_values(golden_dir):
+    """The drop-in static methods: (pooled, clip_level (Nq, L, Nv)) with -1e10 on padded clips."""
+    from dldkd_amd.model import DLDKD
+    g = np.load(f"{golden_dir}/g1_simpool.npz")
+    rs = np.random.RandomState(11)
+    q = torch.from_numpy(rs.standard_normal((7, 384)).astype(np.float32))
+    ctx = torch.from_numpy(rs.standard_normal((5, 9, 384)).astype(np.float32))
+    mask = torch.from_numpy((np.arange(9)[None] < g["lens"][:, None]).astype(np.float32))
+    ctx = ctx * mask.unsqueeze(-1)
+    pooled, clip = DLDKD.get_sim_scores(q.to(DEV), ctx.to(DEV), mask.to(DEV))
+    assert clip.shape == (7, 9, 5)
+    assert np.abs(pooled.cpu().numpy() - g["pooled"]).max() < 2e-6
+    assert np.abs(clip.cpu().numpy() - g["clip"]).max() < 2e-6 * 1e10 and (clip.cpu().numpy()[:, 3:, 1] == -1e10).all()
+    valid = g["clip"] > -1e9
+    assert np.abs(clip.cpu().numpy()[valid] - g["clip"][valid]).max() < 2e-6
+    raw = DLDKD.get_unnormalized_sim_scores(q.to(DEV), ctx.to(DEV), mask.to(DEV))
+    assert np.abs(raw.cpu().numpy() - g["raw"]).max() < 2e-5 * np.abs(g["raw"]).max()
+    pooled_nm, _ = DLDKD.get_sim_scores(q.to(DEV), ctx.to(DEV))
+    assert np.abs(pooled_nm.cpu().numpy() - g["pooled_nomask"]).max() < 2e-6
+
+
+@pytest.mark.parametrize("tag,label_style,hard,caps", [("soft_rand", "soft", False, 1), ("soft_hard", "soft", True, 3),
+                                                       ("hard_hard", "hard", True, 1)])
+def test_forward_backward_vs_golden_g4(golden_dir, tag, label_style, hard, caps):
+    g = np.load(f"{golden_dir}/g4_forward.npz")
+    m = _model(3072, 768, synth.make_params(41, 3072, 768))
+    m.label_style = label_style
+    m.set_hard_negative(hard, 20)
+    m.weight = 0.95 ** 2
+    batch = synth.make_train_batch(1, nv=64, caps=caps, L=16, dv=3072, dq=768)
+    batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    torch.manual_seed(4242)                               # same CPU RNG state the reference had
+    loss, d = m(batch)
+    for k in ("inher_trip", "inher_nce", "explore_trip", "explore_nce", "kl_intra"):
+        _close(d[k], g[f"{tag}_{k}"])                     # 1e-4 relative
+    _close(loss, g[f"{tag}_loss"])
+    assert isinstance(d["loss_overall"], float)
+    m.zero_grad()
+    loss.backward()
+    names = [n for n, _ in m.named_parameters()]
+    assert len(names) == 74
+    # A pre-activation within fp32 rounding of zero can land on the other side of the ReLU than in the
+    # reference (measured: 1 of 393,216 at |pre| = 4.9e-7 in one configuration).  That is a discontinuity of
+    # the function, not an error of the kernels: find such flips against the fp64 oracle and relax ONLY the
+    # gradients of that tower's input projection (the flip changes one row's contribution to its
+    # weight / bias / LayerNorm gradients by ~1e-2).
+    p64 = {k: v.double() for k, v in synth.make_params(41, 3072, 768).items()}
+    flipped = set()
+    for pre, key in (("", "student_videos"), ("exp_", "student_videos"), ("", "student_text"), ("exp_", "student_text")):
+        tower = pre + ("visual" if key == "student_videos" else "query") + "_input_proj"
+        x = batch[key].cpu().double()
+        ref_pre = orc._ln(x, p64[tower + ".LayerNorm.weight"], p64[tower + ".LayerNorm.bias"]) @ p64[tower + ".net.1.weight"].t() \
+            + p64[tower + ".net.1.bias"]
+        with torch.no_grad():
+            ours = getattr(m, tower)(batch[key]).cpu()
+        if bool(((ours > 0) != (ref_pre > 0)).any()):
+            flipped.add(tower)
+    gmax = max(float(np.abs(g[f"{tag}_grad/{n}/sample"]).max()) for n in names)
+    nmax = max(float(g[f"{tag}_grad/{n}/norm"]) for n in names)
+    for n, prm in m.named_parameters():
+        tol = 5e-2 if any(n.startswith(t + ".") for t in flipped) else 3e-3
+        gr = prm.grad.detach().reshape(-1).cpu()
+        idx = np.unique(np.linspace(0, gr.numel() - 1, min(48, gr.numel())).astype(np.int64))
+        ref = g[f"{tag}_grad/{n}/sample"].astype(np.float64)
+        scale = max(np.abs(ref).max(), 1e-4 * gmax)       # key biases: exactly-zero gradient, fp32 noise
+        assert np.abs(gr[idx].double().numpy() - ref).max() <= tol * scale, n
+        rn = float(g[f"{tag}_grad/{n}/norm"])
+        assert abs(float(gr.double().norm()) - rn) <= tol * max(rn, 1e-4 * nmax), n
