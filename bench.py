@@ -125,7 +125,7 @@ def main():
     if not keep_fp32:
         del gs
     ws = torch.empty(native.lib().dldkd_simpool_eval_workspace_bytes(NQ, shard, NB), dtype=torch.uint8, device=dev)
-    gathered = torch.empty(world, NQ, shard, dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty(world * NQ, shard, dtype=torch.float32, device=dev) if world > 1 else None
     flops_launch = 2.0 * D * NB * NQ * float(lens.sum().item())   # algorithmic: valid clips only
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]

@@ -1,0 +1,100 @@
+// Fused multi-tensor BertAdam step (reference method/optimization.py:278-343) and the threshold count used
+// by gather-free sharded ranking.  Both are bandwidth-bound elementwise / reduction kernels.
+//
+// BertAdam semantics kept exactly: per-TENSOR gradient clip to max_grad_norm (torch clip_grad_norm_:
+// coef = min(1, max_norm / (norm + 1e-6))), moments without bias correction, decoupled weight decay
+// added to the update, lr already multiplied by the schedule on the host (0 at step 0 for warmup_linear).
+// Layout: all parameters of the model live in ONE flat fp32 buffer (and so do grads and both moments);
+// tensor t occupies [start[t], start[t] + numel[t]) with start[t] a multiple of 256, so a 256-element chunk
+// never straddles two tensors and chunk_tensor[chunk] names its tensor.
+#include "common.hpp"
+
+namespace dldkd {
+
+__global__ __launch_bounds__(256) void adam_sumsq_kernel(const float* __restrict__ g, const int32_t* __restrict__ chunk_tensor,
+                                                         const int32_t* __restrict__ t_start, const int32_t* __restrict__ t_numel,
+                                                         float* __restrict__ norm2) {
+    __shared__ float red[4];
+    const int t = chunk_tensor[blockIdx.x];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    if (i < (long)t_start[t] + t_numel[t]) { v = g[i]; v *= v; }
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(norm2 + t, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, const int32_t* __restrict__ chunk_tensor,
+                                                          const int32_t* __restrict__ t_start, const int32_t* __restrict__ t_numel,
+                                                          const float* __restrict__ norm2, const float* __restrict__ t_wd,
+                                                          const float* __restrict__ t_lr, float b1, float b2, float eps,
+                                                          float max_norm) {
+    const int t = chunk_tensor[blockIdx.x];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)t_start[t] + t_numel[t]) return;
+    float coef = 1.f;
+    if (max_norm > 0.f) coef = fminf(max_norm / (sqrtf(norm2[t]) + 1e-6f), 1.f);
+    const float gr = g[i] * coef;
+    const float mi = m[i] * b1 + (1.f - b1) * gr;
+    const float vi = v[i] * b2 + (1.f - b2) * gr * gr;
+    float upd = mi / (sqrtf(vi) + eps);
+    const float wd = t_wd[t];
+    if (wd > 0.f) upd += wd * p[i];
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= t_lr[t] * upd;
+}
+
+// counts[q] = #{ v < nv : scores[q, v] > thr[q] }   (one workgroup per query row)
+__global__ __launch_bounds__(256) void count_above_kernel(const float* __restrict__ scores, const float* __restrict__ thr,
+                                                          int nv, int ld, int32_t* __restrict__ counts) {
+    __shared__ int red[4];
+    const int q = blockIdx.x;
+    const float* row = scores + (size_t)q * ld;
+    const float t = thr[q];
+    int c = 0;
+    for (int i = threadIdx.x; i < nv; i += 256) c += row[i] > t;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[q] = red[0] + red[1] + red[2] + red[3];
+}
+
+}  // namespace dldkd
+
+using namespace dldkd;
+
+extern "C" {
+
+int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const int32_t* chunk_tensor, int n_chunks,
+                             const int32_t* t_start, const int32_t* t_numel, int n_tensors, float* norm2_scratch,
+                             const float* t_wd, const float* t_lr, float b1, float b2, float eps, float max_grad_norm,
+                             void* stream) {
+    if (n_chunks < 0 || n_tensors < 0) { set_error("bert_adam: bad sizes"); return DLDKD_EINVAL; }
+    if (n_chunks == 0) return DLDKD_OK;
+    if (!p || !g || !m || !v || !chunk_tensor || !t_start || !t_numel || !norm2_scratch || !t_wd || !t_lr) {
+        set_error("bert_adam: null pointer");
+        return DLDKD_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (max_grad_norm > 0.f) {
+        if (hipMemsetAsync(norm2_scratch, 0, sizeof(float) * n_tensors, s) != hipSuccess) return check_launch("bert_adam memset");
+        hipLaunchKernelGGL(adam_sumsq_kernel, dim3(n_chunks), dim3(256), 0, s, g, chunk_tensor, t_start, t_numel, norm2_scratch);
+    }
+    hipLaunchKernelGGL(adam_update_kernel, dim3(n_chunks), dim3(256), 0, s, p, g, m, v, chunk_tensor, t_start, t_numel,
+                       norm2_scratch, t_wd, t_lr, b1, b2, eps, max_grad_norm);
+    return check_launch("bert_adam");
+}
+
+int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv, int ld, int32_t* counts, void* stream) {
+    if (nq < 0 || nv < 0 || ld < nv) { set_error("count_above: bad sizes"); return DLDKD_EINVAL; }
+    if (nq == 0) return DLDKD_OK;
+    if (!scores || !thr || !counts) { set_error("count_above: null pointer"); return DLDKD_EINVAL; }
+    hipLaunchKernelGGL(count_above_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, scores, thr, nv, ld, counts);
+    return check_launch("count_above");
+}
+
+}  // extern "C"

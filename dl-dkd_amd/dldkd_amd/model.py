@@ -241,5 +241,5 @@ class DLDKD(nn.Module):
         kl_intra = self.kl_intra_weight * self.weight * F_.kl_frame(i_clip, t_clip, lab, lens, 0.2)
         kl = kl_intra
         loss = inher_trip + inher_nce + kl + explore_trip + explore_nce
-        return loss, {"loss_overall": float(loss), "inher_trip": inher_trip, "inher_nce": inher_nce,
+        return loss, {"loss_overall": float(loss.detach()), "inher_trip": inher_trip, "inher_nce": inher_nce,
                       "explore_trip": explore_trip, "explore_nce": explore_nce, "kl": kl, "kl_intra": kl_intra}

@@ -62,6 +62,10 @@ SIGNATURES = {
     "dldkd_triplet_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_float, _c_int, _c_int, _c_void_p,
                                     _c_void_p, _c_float, _c_void_p]),
     "dldkd_sum_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p]),
+    "dldkd_bert_adam_step_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p,
+                                           _c_int, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_float, _c_float, _c_float,
+                                           _c_void_p]),
+    "dldkd_count_above_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
 }
 
 _lib = None

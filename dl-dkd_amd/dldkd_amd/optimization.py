@@ -1,0 +1,137 @@
+"""BertAdam with the reference's constructor and update rule (method/optimization.py:223-343), executed as
+ONE fused multi-tensor HIP step over a flat parameter buffer instead of ~10 elementwise launches per tensor.
+
+At construction the parameters (and their .grad) are re-pointed into flat fp32 buffers (tensor starts aligned
+to 256 elements), which is also what the data-parallel gradient all-reduce uses (dist.FlatGradBucket)."""
+import math
+
+import torch
+
+from . import native
+
+CHUNK = 256
+
+
+def warmup_linear(progress, warmup):
+    if progress < warmup:
+        return progress / warmup
+    return max((progress - 1.0) / (warmup - 1.0), 0.0)
+
+
+def warmup_constant(progress, warmup):
+    return progress / warmup if progress < warmup else 1.0
+
+
+def warmup_cosine(progress, warmup, cycles=0.5):
+    if progress < warmup:
+        return progress / warmup
+    progress = (progress - warmup) / (1 - warmup)
+    return 0.5 * (1.0 + math.cos(math.pi * cycles * 2 * progress))
+
+
+SCHEDULES = {None: None, "none": None, "warmup_linear": warmup_linear, "warmup_constant": warmup_constant,
+             "warmup_cosine": warmup_cosine}
+
+
+class FlatParams:
+    """Owns flat (param, grad) buffers and re-points every parameter's storage into them."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        dev = self.params[0].device
+        starts, numels, off = [], [], 0
+        for p in self.params:
+            starts.append(off)
+            numels.append(p.numel())
+            off += (p.numel() + CHUNK - 1) // CHUNK * CHUNK
+        self.total = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, s, n in zip(self.params, starts, numels):
+            self.flat[s:s + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[s:s + n].view(p.shape)
+            p.grad = self.grad[s:s + n].view(p.shape)
+        chunk_tensor = []
+        for t, (s, n) in enumerate(zip(starts, numels)):
+            chunk_tensor += [t] * ((n + CHUNK - 1) // CHUNK)
+        self.n_chunks = len(chunk_tensor)
+        self.chunk_tensor = torch.tensor(chunk_tensor, dtype=torch.int32, device=dev)
+        self.t_start = torch.tensor(starts, dtype=torch.int32, device=dev)
+        self.t_numel = torch.tensor(numels, dtype=torch.int32, device=dev)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p in self.params:           # autograd may have replaced .grad; point it back at the flat buffer
+            pass
+
+    def rebind_grads(self):
+        """If autograd replaced p.grad by a fresh tensor, copy it into the flat buffer and re-point."""
+        for p, s, n in zip(self.params, self.t_start.tolist(), self.t_numel.tolist()):
+            view = self.grad[s:s + n].view(p.shape)
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+            p.grad = view
+
+
+class BertAdam(torch.optim.Optimizer):
+    """Same arguments as the reference's BertAdam; `params` may be parameter groups with their own
+    weight_decay (train.py:203-213)."""
+
+    def __init__(self, params, lr, warmup=-1, t_total=-1, schedule="warmup_linear", b1=0.9, b2=0.999, e=1e-6,
+                 weight_decay=0.01, max_grad_norm=1.0, **kwargs):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if schedule not in SCHEDULES:
+            raise ValueError("Invalid schedule parameter: {}".format(schedule))
+        if not 0.0 <= b1 < 1.0 or not 0.0 <= b2 < 1.0 or not e >= 0.0:
+            raise ValueError("Invalid b1 / b2 / e")
+        defaults = dict(lr=lr, schedule=schedule, warmup=warmup, t_total=t_total, b1=b1, b2=b2, e=e,
+                        weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        super().__init__(params, defaults)
+        plist, wd, lrs = [], [], []
+        for grp in self.param_groups:
+            for p in grp["params"]:
+                plist.append(p)
+                wd.append(grp["weight_decay"])
+                lrs.append(grp["lr"])
+        self.fp = FlatParams(plist)
+        dev = self.fp.flat.device
+        self.m = torch.zeros_like(self.fp.flat)
+        self.v = torch.zeros_like(self.fp.flat)
+        self.t_wd = torch.tensor(wd, dtype=torch.float32, device=dev)
+        self._base_lr = lrs
+        self.t_lr = torch.zeros(len(plist), dtype=torch.float32, device=dev)
+        self.norm2 = torch.zeros(len(plist), dtype=torch.float32, device=dev)
+        self.step_count = 0
+
+    def schedule_multiplier(self):
+        g = self.param_groups[0]
+        fn = SCHEDULES[g["schedule"]]
+        if fn is None or g["t_total"] < 0:
+            return 1.0
+        return fn(float(self.step_count) / g["t_total"], g["warmup"])
+
+    def get_lr(self):
+        return [lr * self.schedule_multiplier() for lr in self._base_lr]
+
+    def zero_grad(self, set_to_none=False):
+        self.fp.grad.zero_()
+        self.fp.rebind_grads()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self.fp.rebind_grads()
+        g = self.param_groups[0]
+        mult = self.schedule_multiplier()
+        self.t_lr.copy_(torch.tensor([lr * mult for lr in self._base_lr], dtype=torch.float32))
+        L = native.lib()
+        native.check(L.dldkd_bert_adam_step_f32(native.ptr(self.fp.flat), native.ptr(self.fp.grad), native.ptr(self.m),
+                                                native.ptr(self.v), native.ptr(self.fp.chunk_tensor), self.fp.n_chunks,
+                                                native.ptr(self.fp.t_start), native.ptr(self.fp.t_numel), len(self.fp.params),
+                                                native.ptr(self.norm2), native.ptr(self.t_wd), native.ptr(self.t_lr),
+                                                g["b1"], g["b2"], g["e"], g["max_grad_norm"], native.stream()), "bert_adam_step")
+        self.step_count += 1
+        return loss

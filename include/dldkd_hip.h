@@ -193,6 +193,24 @@ int dldkd_sum_f32(const float* x, long n, float* out, void* stream);
 int dldkd_rank_gt(const float* scores, int nq, int nv, const int32_t* gt_ptr, const int32_t* gt_idx,
                   int32_t* rank_best, int32_t* rank_first, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser step and sharded-ranking helper.
+ * ------------------------------------------------------------------------------------------- */
+
+/* One BertAdam step (method/optimization.py:278-343) over ALL tensors of a flat parameter buffer in two
+ * launches.  p/g/m/v: flat fp32 buffers; tensor t = [t_start[t], t_start[t]+t_numel[t]), t_start multiples of
+ * 256; chunk_tensor[c] = tensor of 256-element chunk c.  Per-tensor clip to max_grad_norm (coef =
+ * min(1, max/(norm+1e-6)), optimization.py:311-312), no bias correction, update += wd_t * p, p -= lr_t * update;
+ * t_lr[t] = group lr x schedule multiplier (host).  norm2_scratch: n_tensors floats. */
+int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const int32_t* chunk_tensor, int n_chunks,
+                             const int32_t* t_start, const int32_t* t_numel, int n_tensors, float* norm2_scratch,
+                             const float* t_wd, const float* t_lr, float b1, float b2, float eps, float max_grad_norm,
+                             void* stream);
+
+/* counts[q] = #{v < nv : scores[q*ld + v] > thr[q]}: the local half of gather-free sharded ranking (each rank
+ * counts the videos of its shard that beat the query's ground-truth score; the counts are all-reduced). */
+int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv, int ld, int32_t* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
