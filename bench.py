@@ -167,6 +167,15 @@ def main():
     if rank == 0:
         metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         achieved = flops_launch / (kern_ms * 1e-3) / 1e12
+        # HBM bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
+        # KiB units; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md section HBM) from the committed
+        # profile of this same workload.  Not re-measured live (PMC needs the profiler), so N>1 reports null.
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_simpool_v2", "summary.json")
+        if world == 1 and os.path.exists(pmc):
+            d = json.load(open(pmc))
+            traffic = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+            traffic_src = "profiles/r01/pmc_simpool_v2/summary.json (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
         out = {
             "metric": metric, "value": NQ * NV * a.steps / dt, "unit": "pairs/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
@@ -179,8 +188,9 @@ def main():
                                + (" + all_gather" if world > 1 else ""),
                        "gallery_pack_ms_untimed": round(pack_gallery_ms, 2)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
-                         "kernel": "simpool_eval_kernel", "kernel_ms": kern_ms,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
+                         "kernel": "simpool_eval16_kernel", "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": flops_launch},
         }
         if world == 1:

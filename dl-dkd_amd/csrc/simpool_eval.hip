@@ -276,6 +276,19 @@ __device__ __forceinline__ float xor32_max(float m) {
     return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
 }
 
+// LDS fragment read the compiler does not track (cdna_hip_programming.md 5.7 form (iii)): hipcc turned the
+// 4-deep B ring into {issue read, s_waitcnt lgkmcnt(0)} pairs, i.e. a full LDS round trip every few k-steps
+// (22 % of wave cycles parked, PMC SQ_WAIT_ANY).  With the reads in asm the waits are hand-counted: exactly
+// one read is issued per k-step, so "all but the 3 newest" = the fragment this k-step consumes.
+__device__ __forceinline__ void lds_read_frag(bf16x8& dst, uint32_t lds_addr, int byte_off) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(0) : "memory");
+    (void)byte_off;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_frag_off(bf16x8& dst, uint32_t lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF) : "memory");
+}
+
 template <int NRT>
 __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], const SimpoolEvalArgs& p, int branch,
                                                int vs, int len, char* smem) {
@@ -312,7 +325,7 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
         constexpr int V = NRT * 4;              // accumulator values per lane per sub-tile
         constexpr int kFoldSteps = 9;           // k-steps 0..8 fold the values, 9/10 cross lanes, 11 stores
         constexpr int kPer = (V + kFoldSteps - 1) / kFoldSteps;
-        constexpr int kPF = 4;                  // B-fragment ring depth (divides 12)
+        constexpr int kPF = 4;                  // B-fragment ring depth (divides 12); lgkmcnt(3) below = kPF - 1
 
         f32x4 accA[NRT], accB[NRT];
 #pragma unroll
@@ -321,11 +334,14 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
         float m = 0.f;
 
         // one 16-query sub-tile: MFMAs into `cur`, max-pool of `prev` sliced between the k-steps
-        auto subtile = [&](auto sub_c, f32x4 (&cur)[NRT], const f32x4 (&prev)[NRT], const char* cbase, const char* nbase,
+        auto subtile = [&](auto sub_c, f32x4 (&cur)[NRT], const f32x4 (&prev)[NRT], uint32_t cbase, uint32_t nbase,
                            float* prev_out) {
             constexpr int S = decltype(sub_c)::value;
-#pragma unroll
-            for (int ks = 0; ks < kKSteps16; ++ks) {
+            auto step = [&](auto ks_c) {
+                constexpr int ks = decltype(ks_c)::value;
+                // the ring holds kPF reads in flight, issued one per k-step: all but the 3 newest have landed
+                asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt) {
                     if (ks == 0) {
@@ -335,16 +351,14 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
                         cur[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][ks], b[ks % kPF], cur[rt], 0, 0, 0);
                     }
                 }
-                // keep the B ring kPF k-steps ahead, across the sub-tile and the tile boundary
-                constexpr int kIdxBase = S * kKSteps16 + kPF;
-                const int idx = kIdxBase + ks;
-                if (idx < 2 * kKSteps16) {
-                    b[ks % kPF] = *reinterpret_cast<const bf16x8*>(cbase + idx * 1024);
-                } else {   // past the last tile this reads a stale ring slot: harmless, never consumed
-                    b[ks % kPF] = *reinterpret_cast<const bf16x8*>(nbase + (idx - 2 * kKSteps16) * 1024);
-                }
+                __builtin_amdgcn_sched_barrier(0);
+                // keep the B ring kPF k-steps ahead, across the sub-tile and the tile boundary (past the last
+                // tile this reads a stale ring slot: harmless, never consumed)
+                constexpr int idx = S * kKSteps16 + kPF + ks;
+                if constexpr (idx < 2 * kKSteps16) lds_read_frag_off<idx * 1024>(b[ks % kPF], cbase);
+                else lds_read_frag_off<(idx - 2 * kKSteps16) * 1024>(b[ks % kPF], nbase);
                 // slice of the previous sub-tile's key-clip max-pool
-                if (ks < kFoldSteps) {
+                if constexpr (ks < kFoldSteps) {
                     if (ks == 0) m = -3.0e38f;
 #pragma unroll
                     for (int i = ks * kPer; i < (ks + 1) * kPer && i < V; ++i) {
@@ -355,27 +369,44 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
                         }
                         m = fmaxf(m, x);
                     }
-                } else if (ks == 9) {
+                } else if constexpr (ks == 9) {
                     m = xor16_max(m);
-                } else if (ks == 10) {
+                } else if constexpr (ks == 10) {
                     m = xor32_max(m);
                 } else {
                     if (lane < 16) *prev_out = m;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            };
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+            step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 9>{});
+            step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
         };
 
         int slot = 0, slot2 = 2;
         for (int t = 0; t < T; ++t) {
-            __syncthreads();   // tile t+1 (and t) landed and visible; every wave is done with tile t-1
+            // Tile t+1 (and t) must have landed before the barrier; every wave is then done with tile t-1.
+            // VMEM ops retire in order: at t >= 1 the only ops younger than tile t+1's DMA are this wave's two
+            // result stores of iteration t-1, so vmcnt(2) waits for the DMA but not for the stores (a plain
+            // __syncthreads() = vmcnt(0) lgkmcnt(0) also waits for those stores and drains the B-fragment ring).
+            // Measured alternatives that did NOT help (kept out): staging the tile through registers
+            // (global_load + ds_write spread over k-steps) instead of LDS-DMA: 21.1 ms vs 20.4 ms at C2.
+            if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             if (t + 2 < T) stage(t + 2, slot2);
             const int nslot = slot == kRing - 1 ? 0 : slot + 1;
-            const char* cbase = smem + slot * kQTileBytes + lane * 16;
-            const char* nbase = smem + nslot * kQTileBytes + lane * 16;
+            const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
+            const uint32_t cbase = smem_lds + slot * kQTileBytes + lane * 16;
+            const uint32_t nbase = smem_lds + nslot * kQTileBytes + lane * 16;
             if (t == 0) {
-#pragma unroll
-                for (int i = 0; i < kPF; ++i) b[i] = *reinterpret_cast<const bf16x8*>(cbase + i * 1024);
+                lds_read_frag_off<0>(b[0], cbase);
+                lds_read_frag_off<1024>(b[1], cbase);
+                lds_read_frag_off<2048>(b[2], cbase);
+                lds_read_frag_off<3072>(b[3], cbase);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // t == 0: there is no previous sub-tile; its (garbage) result goes to queries 0..15, which the
@@ -385,6 +416,7 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
             slot = nslot;
             slot2 = slot2 == kRing - 1 ? 0 : slot2 + 1;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // retire the (unused) tail of the ring
         // drain: max-pool of the very last sub-tile
         m = -3.0e38f;
 #pragma unroll
