@@ -35,6 +35,10 @@ struct GemmArgs {
     int batch_inner;
     long sAo, sAi, sBo, sBi, sCo, sCi;
     float alpha;
+    // split-K (unbatched launches only): blockIdx.z owns k-tiles [z * k_tiles_per_split, ...) and adds its
+    // partial product into a zero-initialised C with fp32 atomics.  For dW-shaped problems (384 x 384 outputs,
+    // K = 16k rows) the plain grid has 9 workgroups on a 256-CU chip.
+    int split_k, k_tiles_per_split;
 };
 
 // One operand tile (128 rows x 16 k) per k-tile; each thread moves 8 floats as two float4.
@@ -105,7 +109,7 @@ struct TileIO {
 
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
-    {
+    if (p.split_k <= 1) {
         const int zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
         p.A += zo * p.sAo + zi * p.sAi;
         p.B += zo * p.sBo + zi * p.sBi;
@@ -116,7 +120,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = p.split_k > 1 ? blockIdx.z * p.k_tiles_per_split : 0;
+    const int nk = p.split_k > 1 ? min(nk_all - kt0, p.k_tiles_per_split) : nk_all;
+    if (nk <= 0) return;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -127,8 +134,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[2], rb[2];
-    TileIO<A_KMAJOR>::load(p.A, p.lda, m0, p.M, 0, p.K, tid, p.a_vec, ra);
-    TileIO<B_KMAJOR>::load(p.B, p.ldb, n0, p.N, 0, p.K, tid, p.b_vec, rb);
+    TileIO<A_KMAJOR>::load(p.A, p.lda, m0, p.M, kt0 * BK, p.K, tid, p.a_vec, ra);
+    TileIO<B_KMAJOR>::load(p.B, p.ldb, n0, p.N, kt0 * BK, p.K, tid, p.b_vec, rb);
     TileIO<A_KMAJOR>::store(lds[0][0], tid, ra);
     TileIO<B_KMAJOR>::store(lds[0][1], tid, rb);
     __syncthreads();
@@ -136,8 +143,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {   // next tile's global loads fly under this tile's MFMAs
-            TileIO<A_KMAJOR>::load(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid, p.a_vec, ra);
-            TileIO<B_KMAJOR>::load(p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid, p.b_vec, rb);
+            TileIO<A_KMAJOR>::load(p.A, p.lda, m0, p.M, (kt0 + kt + 1) * BK, p.K, tid, p.a_vec, ra);
+            TileIO<B_KMAJOR>::load(p.B, p.ldb, n0, p.N, (kt0 + kt + 1) * BK, p.K, tid, p.b_vec, rb);
         }
         const float* As = lds[cur][0];
         const float* Bs = lds[cur][1];
@@ -176,7 +183,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
                 if (m < p.M) {
                     float v = acc[i][j][r] * p.alpha + bias;
                     if (p.relu) v = fmaxf(v, 0.f);
-                    p.C[(size_t)m * p.ldc + n] = v;
+                    if (p.split_k > 1) atomicAdd(p.C + (size_t)m * p.ldc + n, v);
+                    else p.C[(size_t)m * p.ldc + n] = v;
                 }
             }
         }
@@ -206,7 +214,21 @@ extern "C" int dldkd_gemm_f32(const float* A, const float* B, const float* bias,
     if (M == 0 || N == 0) return DLDKD_OK;
     if (!A || !B || !C) { set_error("gemm_f32: null pointer"); return DLDKD_EINVAL; }
     const int a_vec = !(lda & 3) && !((uintptr_t)A & 15), b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
-    GemmArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f};
+    GemmArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+    // split-K when the output grid cannot fill the chip and K is long (weight gradients, dq of the clip scores)
+    const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
+    const int nk = (K + BK - 1) / BK;
+    if (!bias && !relu && ldc == N && tiles < 128 && nk >= 32) {
+        int split = (512 + tiles - 1) / tiles;
+        if (split > nk / 8) split = nk / 8;
+        if (split > 1) {
+            p.k_tiles_per_split = (nk + split - 1) / split;
+            p.split_k = (nk + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
+            if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, (hipStream_t)stream) != hipSuccess)
+                return check_launch("gemm_f32 memset");
+            return launch_gemm(p, p.split_k, a_kmajor, b_kmajor, stream);
+        }
+    }
     return launch_gemm(p, 1, a_kmajor, b_kmajor, stream);
 }
 
@@ -223,6 +245,6 @@ extern "C" int dldkd_gemm_f32_batched(const float* A, const float* B, float* C, 
     if (!A || !B || !C) { set_error("gemm_f32_batched: null pointer"); return DLDKD_EINVAL; }
     const bool al = !((sAo | sAi) & 3) && !(lda & 3) && !((uintptr_t)A & 15);
     const bool bl = !((sBo | sBi) & 3) && !(ldb & 3) && !((uintptr_t)B & 15);
-    GemmArgs p{A, B, nullptr, C, M, N, K, lda, ldb, ldc, 0, al, bl, batch_inner, sAo, sAi, sBo, sBi, sCo, sCi, alpha};
+    GemmArgs p{A, B, nullptr, C, M, N, K, lda, ldb, ldc, 0, al, bl, batch_inner, sAo, sAi, sBo, sBi, sCo, sCi, alpha, 1, 0};
     return launch_gemm(p, (int)batch, a_kmajor, b_kmajor, stream);
 }
