@@ -83,12 +83,70 @@ def cpu_baseline(gs, mask, qs, fused_gpu, nq_s=200, nv_s=4359):
                        f"fp32, 50-query chunks like eval.py:188-208; {dt:.1f} s"), err
 
 
+def extras(dev):
+    """Secondary measurements the survey asks to report beside the headline: C3 training step and the
+    gallery-encode rate.  Never allowed to break the headline line: failures are reported as strings."""
+    import types
+    out = {}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import synth
+        from dldkd_amd.model import DLDKD
+        from dldkd_amd.optimization import BertAdam
+        cfg = types.SimpleNamespace(visual_input_size=3072, query_input_size=768, inheritance_hidden=384,
+                                    exploration_hidden=384, max_ctx_l=128, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4,
+                                    initializer_range=0.02, margin=0.1, use_hard_negative=True, hard_pool_size=20,
+                                    label_style="soft")
+        opt_ = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04,
+                                     explore_nce_weight=0.04, collection="tvr", alpha=0.8, belta=0.8)
+        torch.manual_seed(0)
+        m = DLDKD(cfg, opt_).to(dev).train()
+        opt = BertAdam([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=3e-4, warmup=0.01, t_total=1000)
+        batch = synth.make_train_batch(3, nv=128, caps=5, L=128, len_lo=24, dv=3072, dq=768)
+        batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+        def step():
+            opt.zero_grad()
+            loss, _ = m(batch)
+            loss.backward()
+            opt.step()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        out["c3_train_step_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+        out["c3_train_step_config"] = "TVR: 128 videos / 640 queries, L<=128, label_style=soft, hard negatives, dropout 0.2, " \
+                                      "forward+backward+fused BertAdam, fp32-input MFMA path (parity grade)"
+        m.eval()
+        B, Lc = 200, 128
+        feats = torch.nn.functional.normalize(torch.randn(B, Lc, 3072, device=dev), dim=-1)
+        mask = torch.ones(B, Lc, device=dev)
+        with torch.no_grad():
+            m.encode_context(feats, mask)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                m.encode_context(feats, mask)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        out["gallery_encode_videos_per_s"] = B / dt
+        out["gallery_encode_raw_feature_GBps"] = B * Lc * 3072 * 4 / dt / 1e9
+        out["gallery_encode_config"] = "200 x 128 clips x 3072-d fp32 features, both branches, fp32-input MFMA towers"
+    except Exception as e:   # noqa: BLE001
+        out["error"] = repr(e)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,7 +181,7 @@ def main():
     pack_gallery_ms = (time.perf_counter() - t0) * 1e3
     keep_fp32 = (world == 1 and not a.no_cpu_baseline)
     if not keep_fp32:
-        del gs
+        gs = None
     ws = torch.empty(native.lib().dldkd_simpool_eval_workspace_bytes(NQ, shard, NB), dtype=torch.uint8, device=dev)
     gathered = torch.empty(world * NQ, shard, dtype=torch.float32, device=dev) if world > 1 else None
     flops_launch = 2.0 * D * NB * NQ * float(lens.sum().item())   # algorithmic: valid clips only
@@ -202,6 +260,10 @@ def main():
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not a.no_extras:
+            del gs, fused
+            torch.cuda.empty_cache()
+            out["extras"] = extras(dev)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -131,6 +131,7 @@ struct SimpoolEvalArgs {
     const int32_t* order;    // [nv] visiting order (sorted position -> video id)
     float* part;             // [n_branches][nv (sorted position)][nq_pad] partial pooled scores
     int nq_pad, nv, Lp, n_qtiles, n_groups;
+    int ablate;   // diagnostic only
 };
 
 // Row r of a 32x32 accumulator register set lives at clip (r&3) + 8*(r>>2) + 4*(lane>>5) of the row tile
@@ -289,7 +290,10 @@ __device__ __forceinline__ void lds_read_frag_off(bf16x8& dst, uint32_t lds_addr
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF) : "memory");
 }
 
-template <int NRT>
+// ABL (diagnostic builds only, DLDKD_SIMPOOL_ABLATE): 1 = no max-pool / stores, 2 = no in-loop LDS-DMA staging,
+// 4 = no per-tile barrier, 8 = no B-fragment LDS reads (ring registers reused).  Results are wrong by design;
+// only the timing matters (cdna_hip_programming.md section 7, "Ablate").
+template <int NRT, int ABL = 0>
 __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], const SimpoolEvalArgs& p, int branch,
                                                int vs, int len, char* smem) {
     const int lane = threadIdx.x & 63;
@@ -340,7 +344,7 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
             auto step = [&](auto ks_c) {
                 constexpr int ks = decltype(ks_c)::value;
                 // the ring holds kPF reads in flight, issued one per k-step: all but the 3 newest have landed
-                asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                if constexpr (!(ABL & 8)) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt) {
@@ -355,10 +359,16 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
                 // keep the B ring kPF k-steps ahead, across the sub-tile and the tile boundary (past the last
                 // tile this reads a stale ring slot: harmless, never consumed)
                 constexpr int idx = S * kKSteps16 + kPF + ks;
-                if constexpr (idx < 2 * kKSteps16) lds_read_frag_off<idx * 1024>(b[ks % kPF], cbase);
+                if constexpr (ABL & 8) { asm volatile("" : "+v"(b[ks % kPF])); }
+                else if constexpr (idx < 2 * kKSteps16) lds_read_frag_off<idx * 1024>(b[ks % kPF], cbase);
                 else lds_read_frag_off<(idx - 2 * kKSteps16) * 1024>(b[ks % kPF], nbase);
                 // slice of the previous sub-tile's key-clip max-pool
-                if constexpr (ks < kFoldSteps) {
+                if constexpr (ABL & 1) {
+                    if constexpr (ks == 11) {   // keep every accumulator (hence every MFMA) live: rule 17
+#pragma unroll
+                        for (int rt = 0; rt < NRT; ++rt) asm volatile("" :: "v"(prev[rt]));
+                    }
+                } else if constexpr (ks < kFoldSteps) {
                     if (ks == 0) m = -3.0e38f;
 #pragma unroll
                     for (int i = ks * kPer; i < (ks + 1) * kPer && i < V; ++i) {
@@ -395,9 +405,10 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
             // Measured alternatives that did NOT help (kept out): staging the tile through registers
             // (global_load + ds_write spread over k-steps) instead of LDS-DMA: 21.1 ms vs 20.4 ms at C2.
             if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t + 2 < T) stage(t + 2, slot2);
+            else if constexpr (!(ABL & 3)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t == 0 || !(ABL & 4)) __builtin_amdgcn_s_barrier();
+            if constexpr (!(ABL & 2)) { if (t + 2 < T) stage(t + 2, slot2); }
             const int nslot = slot == kRing - 1 ? 0 : slot + 1;
             const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
             const uint32_t cbase = smem_lds + slot * kQTileBytes + lane * 16;
@@ -468,6 +479,18 @@ __global__ __launch_bounds__(256, 1) void simpool_eval16_kernel(const SimpoolEva
             else asm volatile("" : "+v"(a[rt][ks]));
         }
 
+#ifdef DLDKD_DIAG_ABLATE   // `make DIAG=1`: co-compiled variants perturb the shipped one's codegen (rule 19)
+    if (p.ablate && nrt == 8) {   // diagnostic timing builds, full-length videos only
+        switch (p.ablate) {
+            case 1: score_stream16<8, 1>(a, p, branch, vs, len, smem); return;
+            case 2: score_stream16<8, 2>(a, p, branch, vs, len, smem); return;
+            case 4: score_stream16<8, 4>(a, p, branch, vs, len, smem); return;
+            case 8: score_stream16<8, 8>(a, p, branch, vs, len, smem); return;
+            case 15: score_stream16<8, 15>(a, p, branch, vs, len, smem); return;
+            default: break;
+        }
+    }
+#endif
     switch (nrt) {
         case 8: score_stream16<8>(a, p, branch, vs, len, smem); break;
         case 7: score_stream16<7>(a, p, branch, vs, len, smem); break;
@@ -593,6 +616,10 @@ int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_pa
     p.Lp = round_up(L, 32);
     p.n_qtiles = p.nq_pad / kQTile;
     p.n_groups = (nv + 3) / 4;
+    {
+        const char* e = getenv("DLDKD_SIMPOOL_ABLATE");
+        p.ablate = e ? atoi(e) : 0;
+    }
     if (simpool_variant() == 1) {
         hipLaunchKernelGGL(simpool_eval_kernel, dim3(p.n_groups * n_branches), dim3(256), 2 * kQTileBytes,
                            (hipStream_t)stream, p);
