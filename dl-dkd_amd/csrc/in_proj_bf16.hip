@@ -1,0 +1,213 @@
+// K4 in_proj: y = ReLU( LayerNorm(x) . W^T + b ) for the raw clip / word features, bf16 MFMA.
+// Replaces LinearLayer.forward (reference method/model_components.py:305-312) on the inference path; it is
+// the only stage that touches the raw fp32 features (Dv = 3072 for TVR i3d: 1.57 MB per 128-clip video),
+// so it is priced against HBM bandwidth, not MFMA.
+//
+//   * LayerNorm is FOLDED: with W' = gamma (.) W,  LN(x).W^T + b = rstd * (x.W'^T - mean * colsum(W')) + (W.beta + b).
+//     The kernel contracts the RAW rows with W' and applies mean / rstd in the epilogue; mean and E[x^2] are
+//     accumulated in fp32 from the very tiles that feed the MFMAs, so x is read from HBM exactly once
+//     (a separate LayerNorm pass would read and write it again).
+//   * fp32 -> bf16 conversion happens in registers on the way to LDS (v_cvt_pk_bf16_f32).
+//   * Both branches' weights are concatenated along N (768 outputs): the six 128-column tiles of one row
+//     block are adjacent in blockIdx, run together and share the x tile through L2.
+//   * 128x128x32 block tile, 4 waves (2x2) x 64x64, mfma_f32_32x32x16_bf16, global -> registers -> LDS one
+//     k-tile ahead, LDS rows padded to 80 B so every ds_read_b128 fragment read is conflict-free.
+//   Measured (MI355X, M = 400k rows, K = 3072, beyond the Infinity Cache): 4.9 ms = 1252 GB/s algorithmic (15.6 % of
+//   8 TB/s), 384 TFLOP/s, 10x the fp32 parity path.  It is bound by neither HBM nor MFMA yet but by VALU: every one
+//   of the six column-tile workgroups of a row block converts the same fp32 x tile to bf16 and re-accumulates the
+//   LayerNorm sums (~2.5 VALU ops per element, six times).  A 128x256x64 retile (x converted 3x) was slower
+//   (5.6 ms: one workgroup per CU).  Next: one workgroup owns all 768 columns of its rows (x converted once, W'
+//   streamed from L2 in MFMA-fragment order by LDS-DMA).
+#include "common.hpp"
+
+namespace dldkd {
+
+constexpr int PBM = 128, PBK = 32;
+constexpr int PITCH = PBK + 8;   // bf16 elements per LDS row (80 B): ds_read_b128 fragment reads are conflict-free
+
+// one wave per output row n: Wf[n,:] = bf16(gamma * W[n,:]); cs[n] = sum_k float(Wf[n,k]); bb[n] = W[n,:].beta + b[n]
+__global__ __launch_bounds__(256) void fold_ln_linear_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int N, int K, unsigned short* __restrict__ Wf,
+                                                             float* __restrict__ cs, float* __restrict__ bb) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float s = 0.f, t = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = W[(size_t)n * K + k];
+        const unsigned short h = f32_to_bf16_bits(w * gamma[k]);
+        Wf[(size_t)n * K + k] = h;
+        s += bf16_bits_to_f32(h);
+        t += w * beta[k];
+    }
+    s = wave_sum(s);
+    t = wave_sum(t);
+    if (lane == 0) { cs[n] = s; bb[n] = t + (bias ? bias[n] : 0.f); }
+}
+
+struct InProjArgs {
+    const float* x;
+    const bf16x8* Wf;      // [N][K] bf16
+    const float* cs;
+    const float* bb;
+    float* y[2];           // per-branch outputs (M, 384)
+    long M;
+    int N, K;
+    float eps;
+    int relu;
+};
+
+// BN = 256 (two branches, N = 768: three column tiles per row block) or 128 (one branch, N = 384).
+// 4 waves as 2 (rows) x 2 (cols); wave tile 64 x BN/2.
+template <int BN>
+__global__ __launch_bounds__(256) void in_proj_bf16_kernel(const InProjArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds_u16[];
+    constexpr int NJ = BN / 64;                       // 32-column MFMA tiles per wave
+    constexpr int WROWS = BN / 128;                   // W rows staged per thread pair... (BN=256: each thread a whole row)
+    unsigned short* As0 = lds_u16;                    // [2][PBM * PITCH]
+    unsigned short* Bs0 = lds_u16 + 2 * PBM * PITCH;  // [2][BN * PITCH]
+    __shared__ float s_mean[PBM], s_rstd[PBM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
+    const long m0 = (long)blockIdx.y * PBM;
+    const int n0 = blockIdx.x * BN;
+    const int nk = p.K / PBK;
+    const int lrow = tid >> 1, lhalf = tid & 1;       // x: row lrow, k [16*lhalf, +16)
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool row_ok = m0 + lrow < p.M;
+    const float* xrow = p.x + (size_t)(m0 + (row_ok ? lrow : 0)) * p.K + lhalf * (PBK / 2);
+    // W: BN = 256 -> thread t stages the whole k-tile row t; BN = 128 -> row t/2, half t%2
+    const int wrow_i = BN == 256 ? tid : (tid >> 1);
+    const int wk0 = BN == 256 ? 0 : (tid & 1) * (PBK / 2);
+    constexpr int WV = (BN == 256 ? PBK : PBK / 2) / 8;   // 16-byte pieces per thread
+    constexpr int XV = PBK / 8;                            // float4 pieces of x per thread
+    const bf16x8* wrow = p.Wf + ((size_t)(n0 + wrow_i) * p.K + wk0) / 8;
+    f32x4 rx[XV];
+    bf16x8 rw[WV];
+    float sum = 0.f, sq = 0.f;
+    (void)WROWS;
+
+    auto gload = [&](int kt) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(xrow + (size_t)kt * PBK);
+#pragma unroll
+        for (int i = 0; i < XV; ++i) rx[i] = row_ok ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < WV; ++i) rw[i] = wrow[(size_t)kt * (PBK / 8) + i];
+    };
+    auto lstore = [&](int buf) {
+        unsigned short* a = As0 + buf * PBM * PITCH + lrow * PITCH + lhalf * (PBK / 2);
+#pragma unroll
+        for (int g = 0; g < XV / 2; ++g) {
+            bf16x8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = rx[2 * g + (e >> 2)][e & 3];
+                sum += v;
+                sq += v * v;
+                h[e] = (short)f32_to_bf16_bits(v);
+            }
+            *reinterpret_cast<bf16x8*>(a + 8 * g) = h;
+        }
+        unsigned short* b = Bs0 + buf * BN * PITCH + wrow_i * PITCH + wk0;
+#pragma unroll
+        for (int i = 0; i < WV; ++i) *reinterpret_cast<bf16x8*>(b + 8 * i) = rw[i];
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const unsigned short* A = As0 + cur * PBM * PITCH;
+        const unsigned short* B = Bs0 + cur * BN * PITCH;
+#pragma unroll
+        for (int kk = 0; kk < PBK / 16; ++kk) {
+            bf16x8 a[2], b[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                a[i] = *reinterpret_cast<const bf16x8*>(A + (wm + 32 * i + (lane & 31)) * PITCH + kk * 16 + (lane >> 5) * 8);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(B + (wn + 32 * j + (lane & 31)) * PITCH + kk * 16 + (lane >> 5) * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // LayerNorm statistics of the block's rows (two threads per row)
+    sum += __shfl_xor(sum, 1);
+    sq += __shfl_xor(sq, 1);
+    if (lhalf == 0) {
+        const float mean = sum / p.K;
+        const float var = fmaxf(sq / p.K - mean * mean, 0.f);
+        s_mean[lrow] = mean;
+        s_rstd[lrow] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn + 32 * j + (lane & 31);       // a 32-column tile never straddles the 384 boundary
+        float* out = p.y[n / kHidden] + (n % kHidden);
+        const float csn = p.cs[n], bbn = p.bb[n];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m0 + ml < p.M) {
+                    float v = s_rstd[ml] * (acc[i][j][r] - s_mean[ml] * csn) + bbn;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    out[(size_t)(m0 + ml) * kHidden] = v;
+                }
+            }
+    }
+}
+
+}  // namespace dldkd
+
+using namespace dldkd;
+
+extern "C" {
+
+int dldkd_fold_ln_linear_bf16(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                              void* Wf, float* cs, float* bb, void* stream) {
+    if (N < 1 || K < 1) { set_error("fold_ln_linear: bad sizes"); return DLDKD_EINVAL; }
+    if (!W || !gamma || !beta || !Wf || !cs || !bb) { set_error("fold_ln_linear: null pointer"); return DLDKD_EINVAL; }
+    hipLaunchKernelGGL(fold_ln_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, bias, gamma, beta, N, K,
+                       (unsigned short*)Wf, cs, bb);
+    return check_launch("fold_ln_linear");
+}
+
+int dldkd_in_proj_bf16(const float* x, const void* Wf, const float* cs, const float* bb, float* y0, float* y1, long M, int N,
+                       int K, float eps, int relu, void* stream) {
+    if (M < 0 || (N != kHidden && N != 2 * kHidden) || K < PBK || (K % PBK)) {
+        set_error("in_proj_bf16: need N = 384 or 768 and K a multiple of %d (got M=%ld N=%d K=%d)", PBK, M, N, K);
+        return DLDKD_EINVAL;
+    }
+    if (M == 0) return DLDKD_OK;
+    if (!x || !Wf || !cs || !bb || !y0 || (N == 2 * kHidden && !y1)) { set_error("in_proj_bf16: null pointer"); return DLDKD_EINVAL; }
+    InProjArgs p{x, (const bf16x8*)Wf, cs, bb, {y0, y1}, M, N, K, eps, relu};
+    const unsigned rows = (unsigned)((M + PBM - 1) / PBM);
+    // 128-column tiles (6 for two branches).  Measured at M = 400k, K = 3072: BN 128 / BK 32 = 4.9 ms (1252 GB/s,
+    // 384 TFLOP/s); BN 256 / BK 64 = 5.6 ms (one workgroup per CU at 255 VGPRs).
+    constexpr int lds = (2 * PBM * PITCH + 2 * 128 * PITCH) * 2;
+    hipLaunchKernelGGL(in_proj_bf16_kernel<128>, dim3(N / 128, rows), dim3(256), lds, (hipStream_t)stream, p);
+    return check_launch("in_proj_bf16");
+}
+
+}  // extern "C"

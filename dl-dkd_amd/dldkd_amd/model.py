@@ -60,6 +60,10 @@ class DLDKD(nn.Module):
         # label_style is read by forward() but never put into model_config by the reference's train.py
         # (SURVEY quirk table): accept it from either place.
         self.label_style = c("label_style", getattr(opt, "label_style", "soft"))
+        # inference only: run the raw-feature input projections on the bf16 K4 kernel (LayerNorm folded, both
+        # branches in one pass over the features) instead of the fp32 parity path
+        self.fast_input_proj = False
+        self._folded = {}
         self.reset_parameters()
 
     # ------------------------------------------------------------------ init / config
@@ -93,11 +97,33 @@ class DLDKD(nn.Module):
             mask = mask.float().unsqueeze(1)
         return encoder_layer(h, mask)
 
+    def _fast_proj(self, kind, feat):
+        """K4: both branches' LayerNorm+Linear+ReLU of the raw features in one bf16 pass (inference only)."""
+        if kind not in self._folded:
+            layers = [getattr(self, pre + kind + "_input_proj") for pre in (("", "exp_") if self.double_branch else ("",))]
+            self._folded[kind] = ops.FoldedInProj(layers)
+        return ops.in_proj_bf16(feat.float().contiguous(), self._folded[kind])
+
+    def _use_fast(self, feat):
+        return self.fast_input_proj and not self.training and not torch.is_grad_enabled() and feat.shape[-1] % 32 == 0
+
+    @staticmethod
+    def _encode_after_proj(h, mask, encoder_layer, pos_embed_layer):
+        h = pos_embed_layer(h)
+        if mask is not None:
+            mask = mask.float().unsqueeze(1)
+        return encoder_layer(h, mask)
+
     def encode_context(self, frame_video_feat, video_mask=None):
         out = []
-        for pre in ("", "exp_") if self.double_branch else ("",):
-            h = self.encode_input(frame_video_feat, video_mask, getattr(self, pre + "visual_input_proj"),
-                                  getattr(self, pre + "visual_encoder"), getattr(self, pre + "visual_pos_embed"))
+        fast = self._fast_proj("visual", frame_video_feat) if self._use_fast(frame_video_feat) else None
+        for bi, pre in enumerate(("", "exp_") if self.double_branch else ("",)):
+            if fast is not None:
+                h = self._encode_after_proj(fast[bi], video_mask, getattr(self, pre + "visual_encoder"),
+                                            getattr(self, pre + "visual_pos_embed"))
+            else:
+                h = self.encode_input(frame_video_feat, video_mask, getattr(self, pre + "visual_input_proj"),
+                                      getattr(self, pre + "visual_encoder"), getattr(self, pre + "visual_pos_embed"))
             lin = getattr(self, pre + "out_mapping_linear")
             out.append(F_.linear(h, lin.weight, lin.bias))
         return (out[0], out[1]) if self.double_branch else (out[0], None)
@@ -110,9 +136,14 @@ class DLDKD(nn.Module):
         if query_feat.dim() == 2:            # the reference's collate .squeeze() drops a batch of one
             query_feat, query_mask = query_feat.unsqueeze(0), query_mask.reshape(1, -1)
         out = []
-        for pre in ("", "exp_") if self.double_branch else ("",):
-            h = self.encode_input(query_feat, query_mask, getattr(self, pre + "query_input_proj"),
-                                  getattr(self, pre + "query_encoder"), getattr(self, pre + "query_pos_embed"))
+        fast = self._fast_proj("query", query_feat) if self._use_fast(query_feat) else None
+        for bi, pre in enumerate(("", "exp_") if self.double_branch else ("",)):
+            if fast is not None:
+                h = self._encode_after_proj(fast[bi], query_mask, getattr(self, pre + "query_encoder"),
+                                            getattr(self, pre + "query_pos_embed"))
+            else:
+                h = self.encode_input(query_feat, query_mask, getattr(self, pre + "query_input_proj"),
+                                      getattr(self, pre + "query_encoder"), getattr(self, pre + "query_pos_embed"))
             out.append(self.get_modularized_queries(h, query_mask, inheritance=(pre == "")))
         return (out[0], out[1]) if self.double_branch else (out[0], None)
 

@@ -66,6 +66,10 @@ SIGNATURES = {
                                            _c_int, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_float, _c_float, _c_float,
                                            _c_void_p]),
     "dldkd_count_above_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "dldkd_fold_ln_linear_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
+                                            _c_void_p, _c_void_p]),
+    "dldkd_in_proj_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int,
+                                     _c_float, _c_int, _c_void_p]),
 }
 
 _lib = None

@@ -70,3 +70,56 @@ def modpool(h, mask, w, want_attn=False):
     native.check(L.dldkd_modpool_fwd_f32(native.ptr(h), native.ptr(mask), native.ptr(w), native.ptr(out), native.ptr(attn),
                                          N, Lw, native.stream()), "modpool_fwd")
     return (out, attn) if want_attn else out
+
+
+class FoldedInProj:
+    """LayerNorm-folded bf16 weights of 1-2 LinearLayer modules (one per branch), rebuilt when a parameter
+    changes (tensor._version)."""
+
+    def __init__(self, layers):
+        self.layers = layers
+        self.key = None
+
+    def _params(self):
+        ps = []
+        for l in self.layers:
+            ps += [l.LayerNorm.weight, l.LayerNorm.bias, l.net[1].weight, l.net[1].bias]
+        return ps
+
+    def get(self):
+        ps = self._params()
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if key != self.key:
+            L = native.lib()
+            K = self.layers[0].net[1].weight.shape[1]
+            nb = len(self.layers)
+            dev = ps[0].device
+            self.Wf = torch.empty(nb * HIDDEN * K * 2, dtype=torch.uint8, device=dev)
+            self.cs = torch.empty(nb * HIDDEN, dtype=torch.float32, device=dev)
+            self.bb = torch.empty(nb * HIDDEN, dtype=torch.float32, device=dev)
+            import ctypes
+            for b, l in enumerate(self.layers):
+                lin = l.net[1]
+                native.check(L.dldkd_fold_ln_linear_bf16(
+                    native.ptr(lin.weight.detach().contiguous()), native.ptr(lin.bias.detach()),
+                    native.ptr(l.LayerNorm.weight.detach()), native.ptr(l.LayerNorm.bias.detach()), HIDDEN, K,
+                    ctypes.c_void_p(self.Wf.data_ptr() + b * HIDDEN * K * 2), ctypes.c_void_p(self.cs.data_ptr() + 4 * b * HIDDEN),
+                    ctypes.c_void_p(self.bb.data_ptr() + 4 * b * HIDDEN), native.stream()), "fold_ln_linear")
+            self.key, self.K, self.nb = key, K, nb
+        return self
+
+
+def in_proj_bf16(x, folded, relu=True):
+    """x (..., K) fp32 -> list of per-branch (..., 384) fp32 outputs, one pass over x (K4)."""
+    L = native.lib()
+    f = folded.get()
+    K = x.shape[-1]
+    if K != f.K:
+        raise native.NativeError(f"in_proj: x has {K} features, weights expect {f.K}")
+    x2 = _chk(x.reshape(-1, K), "in_proj.x")
+    M = x2.shape[0]
+    ys = [torch.empty(M, HIDDEN, dtype=torch.float32, device=x.device) for _ in range(f.nb)]
+    native.check(L.dldkd_in_proj_bf16(native.ptr(x2), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb), native.ptr(ys[0]),
+                                      native.ptr(ys[1]) if f.nb == 2 else None, M, f.nb * HIDDEN, K, LN_EPS, int(relu),
+                                      native.stream()), "in_proj_bf16")
+    return [y.view(*x.shape[:-1], HIDDEN) for y in ys]

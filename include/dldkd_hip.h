@@ -106,6 +106,23 @@ int dldkd_modpool_fwd_f32(const float* h, const float* mask, const float* w, flo
                           int L, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K4: bf16 input projection of the raw features (inference), the HBM-bound stage of the gallery encode.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Fold LayerNorm(K) into the following Linear(K -> N): Wf[n,k] = bf16(gamma[k] * W[n,k]),
+ * cs[n] = sum_k Wf[n,k], bb[n] = sum_k beta[k] * W[n,k] + bias[n]  (LinearLayer, model_components.py:294-312).
+ * For two branches call it twice on the two halves of one (768, K) Wf buffer. */
+int dldkd_fold_ln_linear_bf16(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                              void* Wf, float* cs, float* bb, void* stream);
+
+/* y_b[m, :] = act( LayerNorm(x[m, :]) . W_b^T + b_b ) for b < N/384 branches, from the folded weights:
+ * rstd[m] * (bf16(x[m,:]) . Wf[n,:] - mean[m] * cs[n]) + bb[n];  x (M, K) fp32 is read ONCE for all branches,
+ * mean / rstd are accumulated from the same tiles.  N = 384 (y1 unused) or 768; K a multiple of 32.
+ * Replaces LinearLayer.forward (model_components.py:305-312) on the inference path. */
+int dldkd_in_proj_bf16(const float* x, const void* Wf, const float* cs, const float* bb, float* y0, float* y1, long M,
+                       int N, int K, float eps, int relu, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Training path, fp32 (DLDKD.forward + backward, method/model.py:100-197,353-387;
  * method/model_components.py:106-234).  Heavy contractions = dldkd_gemm_f32{,_batched}; the rest is
  * row-wise.  "d*" pointers are gradients; functions documented "+=" accumulate into zero-initialised or
