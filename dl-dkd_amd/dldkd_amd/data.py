@@ -30,3 +30,26 @@ def collate_text_val(data):
     feats, idxs, caps = zip(*data)
     words, mask = _pad(feats)
     return words, mask, idxs, caps
+
+
+def collate_train(data):
+    """Training batch assembly (data_provider.py:111-136): items are
+    (student clip feats (len_v, Dv), [caption word feats (len_q, Dq), ...], teacher clip feats (len_v, 512),
+     [teacher caption feats (1, 512), ...], idx, cap_ids, video_id).
+    Videos are sorted by their number of captions, most first (:116-117: clip_nce_soft splits hard/soft parts by
+    row position); text_labels[q] = index of the query's video in the batch."""
+    data = sorted(data, key=lambda x: len(x[1]), reverse=True)
+    s_vid, caps, t_vid, t_caps, _idxs, _cap_ids, _vids = zip(*data)
+    student_videos, student_mask = _pad(s_vid)
+    teacher_videos, _ = _pad(t_vid)
+    words, labels, t_words = [], [], []
+    for vi, (cs, tcs) in enumerate(zip(caps, t_caps)):
+        for c, tc in zip(cs, tcs):
+            words.append(c)
+            t_words.append(tc)
+            labels.append(vi)
+    student_text, student_text_mask = _pad(words)
+    teacher_text, _ = _pad(t_words)
+    return dict(student_videos=student_videos, teacher_videos=teacher_videos, student_videos_mask=student_mask,
+                student_text=student_text, student_text_mask=student_text_mask, teacher_text=teacher_text,
+                text_labels=labels)
