@@ -1,0 +1,53 @@
+// Feature ingest on the GPU: temporal down-sampling of raw frame features to at most
+// max_ctx_l clips by segment means + per-clip L2 normalisation + zero padding, i.e. what
+// VisDataSet4DLDKD.__getitem__ -> uniform_feature_sampling -> l2_normalize_np_array -> cat_videos do on the CPU
+// one clip at a time (reference method/data_provider.py:52-86,283-309).  HBM-bound: every frame row is read once,
+// one wave per output clip, 16-byte accesses.
+#include "common.hpp"
+
+namespace dldkd {
+
+// out row r (of n_rows = B * Lmax): seg_start[r] < 0 -> padding (zeros); seg_start < seg_end -> mean of frames
+// [seg_start, seg_end); seg_start == seg_end -> frame seg_start.  Then x / (||x|| + eps).
+__global__ __launch_bounds__(256) void segment_mean_l2norm_kernel(const float* __restrict__ frames,
+                                                                  const int32_t* __restrict__ seg_start,
+                                                                  const int32_t* __restrict__ seg_end,
+                                                                  float* __restrict__ out, long n_rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int nv = D >> 2;
+    f32x4* o = reinterpret_cast<f32x4*>(out + r * D);
+    const int s = seg_start[r];
+    if (s < 0) {
+        for (int c = lane; c < nv; c += 64) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    int e = seg_end[r];
+    if (e <= s) e = s + 1;
+    const float inv_n = 1.f / (float)(e - s);
+    float ss = 0.f;
+    for (int c = lane; c < nv; c += 64) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int f = s; f < e; ++f) acc += reinterpret_cast<const f32x4*>(frames + (size_t)f * D)[c];
+        acc *= inv_n;
+        o[c] = acc;
+        ss += acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2] + acc[3] * acc[3];
+    }
+    const float scale = 1.f / (sqrtf(wave_sum(ss)) + eps);
+    for (int c = lane; c < nv; c += 64) { f32x4 v = o[c]; v *= scale; o[c] = v; }
+}
+
+}  // namespace dldkd
+
+using namespace dldkd;
+
+extern "C" int dldkd_segment_mean_l2norm_f32(const float* frames, const int32_t* seg_start, const int32_t* seg_end, float* out,
+                                             long n_rows, int D, float eps, void* stream) {
+    if (n_rows < 0 || D < 4 || (D & 3)) { set_error("segment_mean_l2norm: bad sizes (D must be a multiple of 4)"); return DLDKD_EINVAL; }
+    if (n_rows == 0) return DLDKD_OK;
+    if (!frames || !seg_start || !seg_end || !out) { set_error("segment_mean_l2norm: null pointer"); return DLDKD_EINVAL; }
+    hipLaunchKernelGGL(segment_mean_l2norm_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, frames,
+                       seg_start, seg_end, out, n_rows, D, eps);
+    return check_launch("segment_mean_l2norm");
+}

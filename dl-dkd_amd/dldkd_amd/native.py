@@ -70,6 +70,7 @@ SIGNATURES = {
                                             _c_void_p, _c_void_p]),
     "dldkd_in_proj_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int,
                                      _c_float, _c_int, _c_void_p]),
+    "dldkd_segment_mean_l2norm_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_float, _c_void_p]),
 }
 
 _lib = None

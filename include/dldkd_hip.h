@@ -228,6 +228,15 @@ int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const
  * counts the videos of its shard that beat the query's ground-truth score; the counts are all-reduced). */
 int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv, int ld, int32_t* counts, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Feature ingest: temporal down-sampling + L2 normalisation + padding of raw frame features on the GPU.
+ * Replaces uniform_feature_sampling / l2_normalize_np_array / cat_videos (method/data_provider.py:52-86).
+ * frames (n_frames, D) fp32; output row r (n_rows = batch * Lmax, D): padding when seg_start[r] < 0, else the
+ * mean of frames [seg_start[r], seg_end[r]) (the single frame seg_start[r] when the range is empty), divided by
+ * (its L2 norm + eps) - eps is ADDED to the norm (data_provider.py:71-73). */
+int dldkd_segment_mean_l2norm_f32(const float* frames, const int32_t* seg_start, const int32_t* seg_end, float* out,
+                                  long n_rows, int D, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -455,3 +455,33 @@ def bert_adam_step(param, grad, m, v, step, lr, weight_decay, t_total, warmup,
         update = update + weight_decay * param
     lr_t = lr * warmup_linear(step, t_total, warmup)
     return param - lr_t * update, m, v
+
+
+# --------------------------------------------------------------------------------------
+# feature ingest (next-row f3)
+# --------------------------------------------------------------------------------------
+def sampling_bounds(num_clips, max_len):
+    """Segment bounds of uniform_feature_sampling (data_provider.py:52-68): idxs = round(arange(max_len+1) /
+    max_len * num_clips) with numpy's round-half-to-even, clipped to num_clips-1.  Returns (start, end) int arrays
+    of length max_len; segment i is the mean of rows [start, end) when start < end, else the single row start."""
+    idxs = np.arange(0, max_len + 1, 1.0) / max_len * num_clips
+    idxs = np.round(idxs).astype(np.int32)
+    idxs[idxs > num_clips - 1] = num_clips - 1
+    return idxs[:-1].copy(), idxs[1:].copy()
+
+
+def uniform_feature_sampling(features, max_len):
+    """Temporal down-sampling to at most max_len clips by segment means (data_provider.py:52-68)."""
+    n = features.shape[0]
+    if max_len is None or n <= max_len:
+        return features
+    s, e = sampling_bounds(n, max_len)
+    out = np.empty((max_len, features.shape[1]), features.dtype)
+    for i in range(max_len):
+        out[i] = features[s[i]:e[i]].mean(0) if s[i] < e[i] else features[s[i]]
+    return out
+
+
+def l2_normalize_rows(a, eps=1e-5):
+    """x / (||x|| + eps) (data_provider.py:71-73: eps is ADDED to the norm)."""
+    return a / (np.linalg.norm(a, axis=-1, keepdims=True) + eps)

@@ -256,10 +256,40 @@ def g6_bert_adam():
     np.savez(os.path.join(HERE, "g6_bert_adam.npz"), **out)
 
 
+def g7_ingest():
+    """uniform_feature_sampling + l2_normalize_np_array (data_provider.py:52-73) and BigFile.read_one on a tiny
+    on-disk feature file written here (utils/basic_utils.py:9-68)."""
+    import tempfile
+    from utils.basic_utils import BigFile
+    rs = np.random.RandomState(71)
+    out = {}
+    for n, max_len in ((5, 8), (8, 8), (9, 8), (13, 8), (100, 16), (129, 128), (300, 128), (777, 128), (3, 1)):
+        f = rs.standard_normal((n, 12)).astype(np.float32)
+        ref = R.data.l2_normalize_np_array(R.data.uniform_feature_sampling(f, max_len))
+        mine = orc.l2_normalize_rows(orc.uniform_feature_sampling(f, max_len))
+        close(mine, ref, 1e-6, f"ingest n={n} max_len={max_len}")
+        out[f"n{n}_L{max_len}"] = ref.astype(np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        rows = rs.standard_normal((7, 6)).astype(np.float32)
+        ids = [f"vid{i}_f{i*3}" for i in range(7)]
+        rows.tofile(os.path.join(d, "feature.bin"))
+        open(os.path.join(d, "id.txt"), "w").write(" ".join(ids))
+        open(os.path.join(d, "shape.txt"), "w").write("7 6")
+        bf = BigFile(d)
+        got = np.array([bf.read_one(i) for i in (ids[4], ids[0], ids[6])], dtype=np.float32)
+        close(got, rows[[4, 0, 6]], 0, "bigfile read_one")
+        names, vecs = bf.read([ids[5], ids[1], "missing"])
+        assert names == [ids[1], ids[5]]
+        out["bigfile_rows"] = rows
+        out["bigfile_read_names"] = np.array(names)
+        out["bigfile_read_vecs"] = np.array(vecs, dtype=np.float32)
+    np.savez(os.path.join(HERE, "g7_ingest.npz"), **out)
+
+
 if __name__ == "__main__":
     import warnings
     warnings.filterwarnings("ignore")
-    for fn in (g1_simpool, g2_encoders, g3_losses, g4_forward, g5_eval_epoch, g6_bert_adam):
+    for fn in (g1_simpool, g2_encoders, g3_losses, g4_forward, g5_eval_epoch, g6_bert_adam, g7_ingest):
         print(fn.__name__)
         fn()
     print("golden vectors written to", HERE)
