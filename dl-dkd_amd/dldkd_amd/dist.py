@@ -89,3 +89,36 @@ def all_reduce_flat(flat, group=None):
     """Mean all-reduce of an existing flat gradient buffer (BertAdam's FlatParams.grad)."""
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(dist.get_world_size(group))
+
+
+class OverlappedShardScorer:
+    """Score all queries against this rank's gallery shard in `n_chunks` query chunks and all-gather each chunk's
+    (nq_c, S) block asynchronously while the next chunk is being scored (the collective runs on RCCL's own stream;
+    xGMI is point-to-point, so the 7 peer transfers of one all-gather proceed in parallel and hide under compute).
+
+    score_chunk(lo, hi, out): writes the (hi - lo, S) fp32 block of queries [lo, hi) into `out`.
+    After step(): self.blocks[c] is (world * nq_c, S) rank-major; assemble() builds (Nq, n_videos)."""
+
+    def __init__(self, score_chunk, nq, shard, n_chunks, device, group=None):
+        self.score_chunk, self.nq, self.shard, self.group = score_chunk, nq, shard, group
+        self.world = dist.get_world_size(group)
+        n_chunks = max(1, min(n_chunks, nq))
+        step = (nq + n_chunks - 1) // n_chunks
+        self.bounds = [(lo, min(lo + step, nq)) for lo in range(0, nq, step)]
+        self.local = [torch.empty(hi - lo, shard, dtype=torch.float32, device=device) for lo, hi in self.bounds]
+        self.blocks = [torch.empty(self.world * (hi - lo), shard, dtype=torch.float32, device=device) for lo, hi in self.bounds]
+
+    def step(self):
+        works = []
+        for (lo, hi), loc, blk in zip(self.bounds, self.local, self.blocks):
+            self.score_chunk(lo, hi, loc)
+            works.append(dist.all_gather_into_tensor(blk, loc, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+
+    def assemble(self, n_videos):
+        rows = []
+        for (lo, hi), blk in zip(self.bounds, self.blocks):
+            n = hi - lo
+            rows.append(blk.view(self.world, n, self.shard).permute(1, 0, 2).reshape(n, self.world * self.shard))
+        return torch.cat(rows, 0)[:, :n_videos].contiguous()

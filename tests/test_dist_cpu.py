@@ -36,6 +36,13 @@ def _worker(rank, world, port, nv, nq, ret):
     local = orc.sim_scores(d["q"], g, mask)[0]        # (Nq, S): the injected scorer
     full = ddist.gather_scores(local, nv)
     ranks = ddist.sharded_gt_ranks(local, d["gt"], nv, count_fn=lambda sc, thr, n: (sc[:, :n] > thr[:, None]).sum(1).int())
+    # chunked, overlapped all-gather (what bench.py --gpus N runs)
+    def score_chunk(lo, hi, out):
+        out.copy_(orc.sim_scores(d["q"][lo:hi], g, mask)[0])
+    ov = ddist.OverlappedShardScorer(score_chunk, nq, s, 3, "cpu")
+    ov.step()
+    ov.step()                                            # buffers are reusable across steps
+    full_ov = ov.assemble(nv)
     # gradient bucket
     torch.manual_seed(rank)
     ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
@@ -45,6 +52,7 @@ def _worker(rank, world, port, nv, nq, ret):
     b.all_reduce_mean()
     if rank == 0:
         ret["full"], ret["ranks"], ret["grad"] = full.numpy(), ranks.numpy(), [p.grad.clone().numpy() for p in ps]
+        ret["full_ov"] = full_ov.numpy()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,6 +65,7 @@ def test_sharded_eval_two_ranks(nv, nq):
     d = synth.make_gallery(77, nq, nv, 16, 3, sigma=3.0)
     ref = orc.sim_scores(d["q"], d["g"], d["mask"])[0].numpy()
     np.testing.assert_allclose(ret["full"], ref, rtol=0, atol=1e-6)           # sharded == unsharded
+    np.testing.assert_allclose(ret["full_ov"], ref, rtol=0, atol=1e-6)        # chunked + overlapped gather too
     gts = {q: [int(d["gt"][q])] for q in range(nq)}
     assert (ret["ranks"] == orc.gt_ranks(-ref, gts)).all()                    # gather-free ranks are exact
     for gr in ret["grad"]:

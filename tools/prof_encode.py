@@ -1,0 +1,21 @@
+import os, sys, time, types
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dl-dkd_amd"))
+import torch
+from dldkd_amd.model import DLDKD
+DEV = "cuda:0"
+cfg = types.SimpleNamespace(visual_input_size=3072, query_input_size=768, inheritance_hidden=384, exploration_hidden=384,
+                            max_ctx_l=128, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4, initializer_range=0.02,
+                            margin=0.1, use_hard_negative=True, hard_pool_size=20, label_style="soft")
+opt_ = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                             collection="tvr", alpha=0.8, belta=0.8)
+m = DLDKD(cfg, opt_).to(DEV).eval()
+m.fast_input_proj = len(sys.argv) > 1 and sys.argv[1] == "fast"
+feats = torch.nn.functional.normalize(torch.randn(200, 128, 3072, device=DEV), dim=-1)
+mask = torch.ones(200, 128, device=DEV)
+with torch.no_grad():
+    for _ in range(3): m.encode_context(feats, mask)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): m.encode_context(feats, mask)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+print(f"encode_context 200x128x3072 fast={m.fast_input_proj}: {dt*1e3:.2f} ms = {200/dt:.0f} videos/s")
