@@ -71,6 +71,11 @@ SIGNATURES = {
     "dldkd_in_proj_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int,
                                      _c_float, _c_int, _c_void_p]),
     "dldkd_segment_mean_l2norm_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_float, _c_void_p]),
+    "dldkd_simpool_units_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "dldkd_simpool_eval_units_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                                                _c_int, _c_void_p, _c_void_p]),
+    "dldkd_simpool_finish_units": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
+                                             _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
 }
 
 _lib = None

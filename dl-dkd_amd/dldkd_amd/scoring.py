@@ -79,6 +79,34 @@ def pack_gallery(gs, mask=None, normalize=True):
     return PackedGallery(blobs, lens, order, inv, nv, L)
 
 
+def _variant():
+    import os
+    return os.environ.get("DLDKD_SIMPOOL_VARIANT", "2")
+
+
+def _units(pg):
+    """Half-video units of scorer v3, built once per gallery: (unit_video, unit_row0, unit_rows, video_unit0,
+    video_unit1, n_units).  Units are visited in descending ceil(rows/16) order."""
+    if getattr(pg, "_units", None) is None:
+        lens = pg.lens.long()
+        dev = lens.device
+        vid = torch.arange(pg.nv, device=dev)
+        two = lens > 64
+        uv = torch.cat([vid, vid[two]])
+        row0 = torch.cat([torch.zeros(pg.nv, dtype=torch.long, device=dev), torch.full((int(two.sum()),), 64, device=dev)])
+        rows = torch.cat([torch.clamp(lens, max=64), lens[two] - 64])
+        order = torch.argsort((rows + 15) // 16, descending=True, stable=True)
+        uv, row0, rows = uv[order], row0[order], rows[order]
+        n_units = uv.numel()
+        pos = torch.empty(n_units, dtype=torch.long, device=dev)
+        pos[order] = torch.arange(n_units, device=dev)
+        u0 = pos[:pg.nv]
+        u1 = torch.full((pg.nv,), -1, dtype=torch.long, device=dev)
+        u1[two] = pos[pg.nv:]
+        pg._units = tuple(t.to(torch.int32).contiguous() for t in (uv, row0, rows, u0, u1)) + (n_units,)
+    return pg._units
+
+
 def simpool_partials(pq, pg, workspace=None):
     """Stage 1 (the dominant kernel): per-branch pooled scores into the workspace, transposed and in
     visiting order.  Returns the workspace tensor."""
@@ -86,6 +114,16 @@ def simpool_partials(pq, pg, workspace=None):
     nb = pg.n_branches
     if len(pq.blobs) != nb:
         raise native.NativeError("query / gallery branch count mismatch")
+    if _variant() == "3":
+        uv, row0, rows, _, _, n_units = _units(pg)
+        need = L_.dldkd_simpool_units_workspace_bytes(pq.nq, n_units, nb)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, dtype=torch.uint8, device=pg.lens.device)
+        if pq.nq and pg.nv:
+            native.check(L_.dldkd_simpool_eval_units_bf16(native.ptr_array(pq.blobs), native.ptr_array(pg.blobs), native.ptr(uv),
+                                                          native.ptr(row0), native.ptr(rows), pq.nq, n_units, pg.L, nb,
+                                                          native.ptr(workspace), native.stream()), "simpool_eval_units")
+        return workspace
     need = L_.dldkd_simpool_eval_workspace_bytes(pq.nq, pg.nv, nb)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=pg.lens.device)
@@ -103,7 +141,12 @@ def simpool_finish(workspace, pq, pg, w=(0.7, 0.3), want_fused=True, want_branch
     fused = torch.empty(nq, nv, dtype=torch.float32, device=dev) if want_fused else None
     s0 = torch.empty(nq, nv, dtype=torch.float32, device=dev) if want_branches else None
     s1 = torch.empty(nq, nv, dtype=torch.float32, device=dev) if (want_branches and nb == 2) else None
-    if nq and nv:
+    if nq and nv and _variant() == "3":
+        _, _, _, u0, u1, n_units = _units(pg)
+        native.check(L_.dldkd_simpool_finish_units(native.ptr(workspace), native.ptr(u0), native.ptr(u1), nq, nv, n_units, nb,
+                                                   float(w[0]), float(w[1]), native.ptr(fused), native.ptr(s0), native.ptr(s1),
+                                                   native.stream()), "simpool_finish_units")
+    elif nq and nv:
         native.check(L_.dldkd_simpool_finish(native.ptr(workspace), native.ptr(pg.inv_order), nq, nv, nb, float(w[0]),
                                              float(w[1]), native.ptr(fused), native.ptr(s0), native.ptr(s1),
                                              native.stream()), "simpool_finish")

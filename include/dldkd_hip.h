@@ -75,6 +75,19 @@ int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_pa
 int dldkd_simpool_finish(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches,
                          float w0, float w1, float* fused, float* s0, float* s1, void* stream);
 
+/* Scorer v3 ("half-video units", two waves per SIMD).  The gallery is cut into units of <= 64 consecutive clips of
+ * one video (unit_video / unit_row0 in {0, 64} / unit_rows in 1..64; any order - descending ceil(rows/16) balances
+ * the 8 units of a workgroup); stage 1 writes part[b][unit][q]; stage 2 takes the max over the 1-2 units of every
+ * video (video_unit0[v], video_unit1[v] or -1) and fuses the branches.  Same results as dldkd_simpool_eval_bf16 +
+ * dldkd_simpool_finish, same packed operands. */
+size_t dldkd_simpool_units_workspace_bytes(int nq, int n_units, int n_branches);
+int dldkd_simpool_eval_units_bf16(const void* const* q_packed, const void* const* g_packed, const int32_t* unit_video,
+                                  const int32_t* unit_row0, const int32_t* unit_rows, int nq, int n_units, int L,
+                                  int n_branches, void* workspace, void* stream);
+int dldkd_simpool_finish_units(const void* workspace, const int32_t* video_unit0, const int32_t* video_unit1, int nq,
+                               int nv, int n_units, int n_branches, float w0, float w1, float* fused, float* s0,
+                               float* s1, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Encoder towers, fp32 parity-grade forward (fp32-input MFMA: exact fp32 products and sums).
  * Together these replace DLDKD.encode_input / encode_context / encode_query (method/model.py:199-258).
