@@ -178,6 +178,150 @@ __global__ __launch_bounds__(256) void in_proj_bf16_kernel(const InProjArgs p) {
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Full-row variant (two branches, N = 768): one 8-wave workgroup owns ALL output columns of its 128 rows.
+//   * x is converted to bf16 and its LayerNorm sums are accumulated ONCE per row (the column-tiled kernel above
+//     repeats both in each of its six column-tile workgroups and is VALU-bound by it);
+//   * the folded weights are stored in MFMA B-fragment order ([k-tile][32-col tile][kk][lane][8]) so a k-tile of
+//     W' (48 KiB) is 48 linear 1-KiB LDS-DMA pieces (6 per wave) and every fragment read is base + lane*16;
+//   * wave w computes rows 0..127 x columns [96w, 96w+96): 4x3 MFMA tiles, 192 accumulator registers, two waves
+//     per SIMD; per k-tile 24 MFMAs against 14 fragment reads.
+// ----------------------------------------------------------------------------------------------
+constexpr int FBM = 128, FBK = 32, FN = 768;
+constexpr int FPITCH = FBK + 8;                 // x image: 80-byte rows
+constexpr int FW_TILE_BYTES = FN * FBK * 2;     // 48 KiB of W' per k-tile
+
+__global__ __launch_bounds__(256) void fold_ln_linear_frag_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  int N, int K, int n_offset, unsigned short* __restrict__ Wfrag,
+                                                                  float* __restrict__ cs, float* __restrict__ bb) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int ng = n_offset + n, ct = ng >> 5, col = ng & 31;
+    float s = 0.f, t = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = W[(size_t)n * K + k];
+        const unsigned short h = f32_to_bf16_bits(w * gamma[k]);
+        const int kt = k >> 5, kk = (k >> 4) & 1, half = (k >> 3) & 1, j = k & 7;
+        Wfrag[((((size_t)kt * (FN / 32) + ct) * 2 + kk) * 64 + half * 32 + col) * 8 + j] = h;
+        s += bf16_bits_to_f32(h);
+        t += w * beta[k];
+    }
+    s = wave_sum(s);
+    t = wave_sum(t);
+    if (lane == 0) { cs[ng] = s; bb[ng] = t + (bias ? bias[n] : 0.f); }
+}
+
+__global__ __launch_bounds__(512, 2) void in_proj_bf16_full_kernel(const InProjArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds_full[];
+    char* Wl = lds_full;                                            // [2][48 KiB]
+    unsigned short* Al = reinterpret_cast<unsigned short*>(lds_full + 2 * FW_TILE_BYTES);   // [2][128 * FPITCH]
+    float* s_mean = reinterpret_cast<float*>(lds_full + 2 * FW_TILE_BYTES + 2 * FBM * FPITCH * 2);
+    float* s_rstd = s_mean + FBM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long m0 = (long)blockIdx.x * FBM;
+    const int nk = p.K / FBK;
+    const int xrow = tid >> 2, xq = tid & 3;                        // x: row xrow, floats [8*xq, 8*xq + 8) of the k-tile
+    const bool row_ok = m0 + xrow < p.M;
+    const float* xsrc = p.x + (size_t)(m0 + (row_ok ? xrow : 0)) * p.K + xq * 8;
+    const char* wsrc = reinterpret_cast<const char*>(p.Wf);
+
+    f32x16 acc[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 rx[2];
+    float sum = 0.f, sq = 0.f;
+    auto wstage = [&](int kt, int buf) {                            // 48 pieces, 6 per wave
+        const char* src = wsrc + (size_t)kt * FW_TILE_BYTES;
+        char* dst = Wl + buf * FW_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int piece = wave * 6 + i;
+            glds16(src + piece * 1024 + lane * 16, dst + piece * 1024);
+        }
+    };
+    auto xload = [&](int kt) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(xsrc + (size_t)kt * FBK);
+        rx[0] = row_ok ? src[0] : f32x4{0.f, 0.f, 0.f, 0.f};
+        rx[1] = row_ok ? src[1] : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto xstore = [&](int buf) {
+        bf16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = rx[e >> 2][e & 3];
+            sum += v;
+            sq += v * v;
+            h[e] = (short)f32_to_bf16_bits(v);
+        }
+        *reinterpret_cast<bf16x8*>(Al + buf * FBM * FPITCH + xrow * FPITCH + xq * 8) = h;
+    };
+
+    wstage(0, 0);
+    xload(0);
+    xstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) { wstage(kt + 1, cur ^ 1); xload(kt + 1); }
+        const unsigned short* A = Al + cur * FBM * FPITCH;
+        const char* B = Wl + cur * FW_TILE_BYTES + lane * 16;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(B + ((wave * 3 + j) * 2 + kk) * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // one A fragment live at a time: 192 accumulators leave little room
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (32 * i + (lane & 31)) * FPITCH + kk * 16 + (lane >> 5) * 8);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) xstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    sum += __shfl_xor(sum, 1);
+    sq += __shfl_xor(sq, 1);
+    sum += __shfl_xor(sum, 2);
+    sq += __shfl_xor(sq, 2);
+    if (xq == 0) {
+        const float mean = sum / p.K;
+        const float var = fmaxf(sq / p.K - mean * mean, 0.f);
+        s_mean[xrow] = mean;
+        s_rstd[xrow] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int n = wave * 96 + 32 * j + (lane & 31);
+        float* out = p.y[n / kHidden] + (n % kHidden);
+        const float csn = p.cs[n], bbn = p.bb[n];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m0 + ml < p.M) {
+                    float v = s_rstd[ml] * (acc[i][j][r] - s_mean[ml] * csn) + bbn;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    out[(size_t)(m0 + ml) * kHidden] = v;
+                }
+            }
+    }
+}
+
 }  // namespace dldkd
 
 using namespace dldkd;
@@ -208,6 +352,33 @@ int dldkd_in_proj_bf16(const float* x, const void* Wf, const float* cs, const fl
     constexpr int lds = (2 * PBM * PITCH + 2 * 128 * PITCH) * 2;
     hipLaunchKernelGGL(in_proj_bf16_kernel<128>, dim3(N / 128, rows), dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("in_proj_bf16");
+}
+
+
+int dldkd_fold_ln_linear_bf16_frag(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                                   int n_offset, void* Wfrag, float* cs, float* bb, void* stream) {
+    if (N < 1 || K < FBK || (K % FBK) || n_offset < 0 || n_offset + N > FN || (n_offset % 32)) {
+        set_error("fold_ln_linear_frag: need K a multiple of %d and columns inside [0, %d)", FBK, FN);
+        return DLDKD_EINVAL;
+    }
+    if (!W || !gamma || !beta || !Wfrag || !cs || !bb) { set_error("fold_ln_linear_frag: null pointer"); return DLDKD_EINVAL; }
+    hipLaunchKernelGGL(fold_ln_linear_frag_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, bias, gamma, beta, N,
+                       K, n_offset, (unsigned short*)Wfrag, cs, bb);
+    return check_launch("fold_ln_linear_frag");
+}
+
+int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1, long M,
+                            int K, float eps, int relu, void* stream) {
+    if (M < 0 || K < FBK || (K % FBK)) { set_error("in_proj_bf16_full: K must be a multiple of %d", FBK); return DLDKD_EINVAL; }
+    if (M == 0) return DLDKD_OK;
+    if (!x || !Wfrag || !cs || !bb || !y0 || !y1) { set_error("in_proj_bf16_full: null pointer"); return DLDKD_EINVAL; }
+    InProjArgs p{x, (const bf16x8*)Wfrag, cs, bb, {y0, y1}, M, FN, K, eps, relu};
+    constexpr int lds = 2 * FW_TILE_BYTES + 2 * FBM * FPITCH * 2 + 2 * FBM * 4;
+    static const bool ok = [] { return hipFuncSetAttribute((const void*)in_proj_bf16_full_kernel,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess; }();
+    (void)ok;
+    hipLaunchKernelGGL(in_proj_bf16_full_kernel, dim3((unsigned)((M + FBM - 1) / FBM)), dim3(512), lds, (hipStream_t)stream, p);
+    return check_launch("in_proj_bf16_full");
 }
 
 }  // extern "C"

@@ -76,6 +76,10 @@ SIGNATURES = {
                                                 _c_int, _c_void_p, _c_void_p]),
     "dldkd_simpool_finish_units": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
                                              _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_fold_ln_linear_bf16_frag": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
+                                                 _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_in_proj_bf16_full": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
+                                          _c_float, _c_int, _c_void_p]),
 }
 
 _lib = None

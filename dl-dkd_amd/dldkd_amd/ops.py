@@ -76,9 +76,13 @@ class FoldedInProj:
     """LayerNorm-folded bf16 weights of 1-2 LinearLayer modules (one per branch), rebuilt when a parameter
     changes (tensor._version)."""
 
-    def __init__(self, layers):
+    def __init__(self, layers, full_row=None):
         self.layers = layers
         self.key = None
+        # two branches: the full-row kernel (weights in MFMA fragment order); DLDKD_INPROJ_VARIANT=tiled forces the
+        # column-tiled kernel for A/B runs
+        import os
+        self.full_row = (len(layers) == 2 and os.environ.get("DLDKD_INPROJ_VARIANT", "full") != "tiled") if full_row is None else full_row
 
     def _params(self):
         ps = []
@@ -100,6 +104,12 @@ class FoldedInProj:
             import ctypes
             for b, l in enumerate(self.layers):
                 lin = l.net[1]
+                if self.full_row:
+                    native.check(L.dldkd_fold_ln_linear_bf16_frag(
+                        native.ptr(lin.weight.detach().contiguous()), native.ptr(lin.bias.detach()),
+                        native.ptr(l.LayerNorm.weight.detach()), native.ptr(l.LayerNorm.bias.detach()), HIDDEN, K, b * HIDDEN,
+                        native.ptr(self.Wf), native.ptr(self.cs), native.ptr(self.bb), native.stream()), "fold_ln_linear_frag")
+                    continue
                 native.check(L.dldkd_fold_ln_linear_bf16(
                     native.ptr(lin.weight.detach().contiguous()), native.ptr(lin.bias.detach()),
                     native.ptr(l.LayerNorm.weight.detach()), native.ptr(l.LayerNorm.bias.detach()), HIDDEN, K,
@@ -119,6 +129,10 @@ def in_proj_bf16(x, folded, relu=True):
     x2 = _chk(x.reshape(-1, K), "in_proj.x")
     M = x2.shape[0]
     ys = [torch.empty(M, HIDDEN, dtype=torch.float32, device=x.device) for _ in range(f.nb)]
+    if f.full_row:
+        native.check(L.dldkd_in_proj_bf16_full(native.ptr(x2), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb), native.ptr(ys[0]),
+                                               native.ptr(ys[1]), M, K, LN_EPS, int(relu), native.stream()), "in_proj_bf16_full")
+        return [y.view(*x.shape[:-1], HIDDEN) for y in ys]
     native.check(L.dldkd_in_proj_bf16(native.ptr(x2), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb), native.ptr(ys[0]),
                                       native.ptr(ys[1]) if f.nb == 2 else None, M, f.nb * HIDDEN, K, LN_EPS, int(relu),
                                       native.stream()), "in_proj_bf16")

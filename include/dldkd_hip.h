@@ -135,6 +135,15 @@ int dldkd_fold_ln_linear_bf16(const float* W, const float* bias, const float* ga
 int dldkd_in_proj_bf16(const float* x, const void* Wf, const float* cs, const float* bb, float* y0, float* y1, long M,
                        int N, int K, float eps, int relu, void* stream);
 
+/* Full-row variant for two branches (N = 768): Wfrag holds the folded weights in MFMA B-fragment order
+ * [k-tile of 32][32-column tile (24)][kk (2)][lane (64)][8 bf16]; fold each branch with n_offset = 0 / 384 into
+ * the same Wfrag / cs / bb buffers.  One workgroup computes all 768 columns of its 128 rows, so x is converted to
+ * bf16 and its LayerNorm sums are taken once.  Same result as dldkd_in_proj_bf16 with N = 768. */
+int dldkd_fold_ln_linear_bf16_frag(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                                   int n_offset, void* Wfrag, float* cs, float* bb, void* stream);
+int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
+                            long M, int K, float eps, int relu, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Training path, fp32 (DLDKD.forward + backward, method/model.py:100-197,353-387;
  * method/model_components.py:106-234).  Heavy contractions = dldkd_gemm_f32{,_batched}; the rest is
