@@ -165,6 +165,52 @@ def compute_query2ctx_info(model, eval_dataset, opt, ctx_info):
     return s0.cpu().numpy().copy(), (s1.cpu().numpy().copy() if s1 is not None else None), None, metas
 
 
+def _dist_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=False):
+    """eval_epoch with the gallery sharded by video over the ranks of the default process group (config C4).
+
+    Rank r encodes and keeps videos [r*S, (r+1)*S) only, every rank encodes all queries, scores them against its
+    shard, and the ranks come from dist.sharded_gt_ranks: all-reduce(MAX) of each query's ground-truth score, a local
+    count of shard videos above it, all-reduce(SUM) - no (Nq, Nv) matrix is ever exchanged or assembled, and R@K is
+    exactly that of the unsharded evaluation.  Returns SumR of the fused scores on every rank."""
+    from torch.utils.data import Subset
+    from . import dist as ddist
+    import torch.distributed as tdist
+    rank, world = _dist_world()
+    use_collectives = tdist.is_available() and tdist.is_initialized()
+    model.eval()
+    n_videos = len(val_video_dataset)
+    lo, hi, _ = ddist.shard_range(n_videos, rank, world)
+    # video ids of the WHOLE gallery are needed for the ground truth; only the ids, not the features
+    all_ids = [val_video_dataset[i][2] for i in range(n_videos)] if world > 1 else None
+    ctx = compute_context_info(model, Subset(val_video_dataset, range(lo, hi)), opt)
+    fused, s0, s1, query_metas = score_queries(model, val_text_dataset, opt, ctx)
+    video_metas = all_ids if all_ids is not None else ctx["video_metas"]
+    _, t2v_gt = get_gt(video_metas, query_metas)
+    nq = len(query_metas)
+    out = {}
+    for name, sc in (("inher", s0), ("explore", s1), ("fused", fused if s1 is not None else s0)):
+        if sc is None:
+            continue
+        # best GT per query = the GT video with the highest score; with one GT per query (TVR, ActivityNet,
+        # Charades captions) that is simply t2v_gt[q][0]
+        ranks = None
+        for k in range(max(len(v) for v in t2v_gt.values())):
+            gt_k = torch.tensor([t2v_gt[q][min(k, len(t2v_gt[q]) - 1)] for q in range(nq)], dtype=torch.long)
+            r = ddist.sharded_gt_ranks(sc, gt_k, n_videos) if use_collectives else gt_ranks_gpu(sc, {q: [int(gt_k[q])] for q in range(nq)})[0].long()
+            ranks = r if ranks is None else torch.minimum(ranks, r)
+        out[name] = _recalls(ranks.cpu().numpy(), nq)
+        logging.info(" * %s r_1_5_10_100: %s", name, [round(x, 1) for x in out[name][:4]])
+    r1, r5, r10, r100 = out["fused"][:4]
+    return r1 + r5 + r10 + r100
+
+
 def eval_epoch(model, val_video_dataset, val_text_dataset, opt, test=False):
     """SumR (R@1 + R@5 + R@10 + R@100) of the fused scores; logs the three rankings (eval.py:237-263)."""
     model.eval()

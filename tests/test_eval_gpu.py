@@ -84,3 +84,24 @@ def test_get_pred_from_raw_query():
     ref0 = orc.sim_scores(qi, ctx["inher_frame_feat"].cpu(), ctx["video_mask"].cpu())[0]
     ref1 = orc.sim_scores(qe, ctx["explore_frame_feat"].cpu(), ctx["video_mask"].cpu())[0]
     assert (s0.cpu() - ref0).abs().max() < 6e-3 and (s1.cpu() - ref1).abs().max() < 6e-3
+
+
+def test_eval_epoch_sharded_equals_unsharded():
+    """One-rank RCCL group: the sharded driver (gather-free ranking) returns the unsharded SumR."""
+    import os
+    import torch.distributed as dist
+    from dldkd_amd import eval as ev
+    m = _model(1024, 1024, synth.make_params(13, 1024, 1024))
+    vids, txts = synth.make_eval_sets(8, nv=37, caps=2, dv=1024, dq=1024)
+    opt = _opt()
+    with torch.no_grad():
+        ref = ev.eval_epoch(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), opt)
+        a = ev.eval_epoch_sharded(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), opt)   # no group
+        assert a == pytest.approx(ref)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("nccl", device_id=torch.device(DEV))
+        try:
+            b = ev.eval_epoch_sharded(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), opt)
+        finally:
+            dist.destroy_process_group()
+    assert b == pytest.approx(ref)
