@@ -264,17 +264,42 @@ __global__ __launch_bounds__(256) void trip_v2t_kernel(const float* __restrict__
     __syncthreads();
     const float psum = red_s[0] + red_s[1] + red_s[2] + red_s[3];
     const int pcnt = red_i[0] + red_i[1] + red_i[2] + red_i[3];
-    const int want = hard ? 0 : rsel[i];
-    for (int q = tid; q < nq; q += 256) {
-        if (labels[q] == i) continue;
-        const float x = col[q];
-        int rank = 0;
-        for (int u = 0; u < nq; ++u) {
-            if (labels[u] == i) continue;
-            const float y = col[u];
-            rank += (y > x) || (y == x && u < q);
+    if (hard) {
+        // hardest negative = plain arg-max over the other queries' scores (ties: lowest index, like the rank rule)
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int q = tid; q < nq; q += 256) {
+            if (labels[q] == i) continue;
+            const float x = col[q];
+            if (x > best || (x == best && q < bi)) { best = x; bi = q; }
         }
-        if (rank == want) sel = q;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        __syncthreads();                       // red_s / red_i were read above by every thread
+        if (lane == 0) { red_s[wave] = best; red_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float b = red_s[0]; int k = red_i[0];
+            for (int w = 1; w < 4; ++w) if (red_s[w] > b || (red_s[w] == b && red_i[w] < k)) { b = red_s[w]; k = red_i[w]; }
+            sel = k == 0x7fffffff ? -1 : k;
+        }
+    } else {
+        const int want = rsel[i];
+        for (int q = tid; q < nq; q += 256) {
+            if (labels[q] == i) continue;
+            const float x = col[q];
+            int rank = 0;
+            for (int u = 0; u < nq; ++u) {
+                if (labels[u] == i) continue;
+                const float y = col[u];
+                rank += (y > x) || (y == x && u < q);
+            }
+            if (rank == want) sel = q;
+        }
     }
     __syncthreads();
     if (tid == 0) {

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     f32x4 ag[MAXV], ab[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; }
-    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rows_per_wave;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rows_per_wave;   // may be >= M: the wave then only joins the reduction
     for (long row = row0; row < row0 + rows_per_wave && row < M; ++row) {
         const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
         const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (add_mod > 0 ? row % add_mod : row) * D) : nullptr;
@@ -138,16 +138,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
+    // dgamma / dbeta: combine the block's 4 waves in LDS, then ONE atomic per column per block (per-wave atomics
+    // were 1.5M same-address adds per call: the contended case MI355X_MICROARCH.md measures at 14x slower).
+    extern __shared__ float ln_red[];            // [4 waves][2][D]
+    float* mine = ln_red + (size_t)(threadIdx.x >> 6) * 2 * D;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(dgamma + c * 4 + e, ag[i][e]);
-                atomicAdd(dbeta + c * 4 + e, ab[i][e]);
-            }
+            *reinterpret_cast<f32x4*>(mine + c * 4) = ag[i];
+            *reinterpret_cast<f32x4*>(mine + D + c * 4) = ab[i];
         }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        const float v = ln_red[c] + ln_red[2 * D + c] + ln_red[4 * D + c] + ln_red[6 * D + c];
+        atomicAdd((c < D ? dgamma : dbeta - D) + c, v);
     }
 }
 
@@ -306,15 +312,21 @@ int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const
     if (M < 0 || D < 4 || (D & 3) || D > 4096) { set_error("layernorm_bwd: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0) return DLDKD_OK;
     if (!x || !gamma || !dy || !dgamma || !dbeta) { set_error("layernorm_bwd: null pointer"); return DLDKD_EINVAL; }
-    const int rpw = 8;   // rows per wave -> one atomic per column per 32 rows
+    const int rpw = 16;  // rows per wave -> one atomic per column per 64 rows (after the in-block LDS combine)
     const long waves = (M + rpw - 1) / rpw;
     const int nv = (D / 4 + 63) / 64;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    if (nv <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
-    else if (nv <= 4) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
-    else if (nv <= 8) hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    const size_t lds = (size_t)8 * D * sizeof(float);
+    static const bool attr_ok = [] {
+        return hipFuncSetAttribute((const void*)layernorm_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4096 * 4) == hipSuccess &&
+               hipFuncSetAttribute((const void*)layernorm_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2048 * 4) == hipSuccess;
+    }();
+    (void)attr_ok;
+    if (nv <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    else if (nv <= 4) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    else if (nv <= 8) hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
     return check_launch("layernorm_bwd");
 }
 int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream) {
