@@ -1,0 +1,242 @@
+// gemm_bf16: C[M,N] = act(alpha * sum_k A(m,k) * B(n,k) + bias[n]) with fp32 operands in memory, bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16) and fp32 accumulation: the throughput-mode twin of gemm_f32 (same argument
+// meaning, same three operand layouts for Linear forward / dX / dW, same strided batching and split-K).
+// Operands are converted fp32 -> bf16 in registers on the way to LDS; the LDS image is always [row][k]
+// (80-byte rows: conflict-free ds_read_b128 fragments), so an operand whose contraction index is its row
+// index in memory ("k-major": dX's W, both operands of dW) is transposed by its LDS write.
+#include "common.hpp"
+
+namespace dldkd {
+
+constexpr int HBM_ = 128, HBN_ = 128, HBK_ = 32;
+constexpr int HPITCH = HBK_ + 8;
+
+struct GemmHArgs {
+    const float* A;
+    const float* B;
+    const float* bias;
+    float* C;
+    int M, N, K, lda, ldb, ldc, relu;
+    int a_vec, b_vec;
+    int batch_inner;
+    long sAo, sAi, sBo, sBi, sCo, sCi;
+    float alpha;
+    int split_k, k_tiles_per_split;
+};
+
+// One operand tile: 128 rows x 32 k, 16 floats per thread.
+//   k-minor memory [row][k]: 4 float4 loads (8 threads cover a row's 128 B), packed 8-byte LDS writes.
+//   k-major memory [k][row]: the thread owns ONE row and 16 consecutive k (dword loads, coalesced across the wave
+//     along the row index), so the transposed LDS write is two 16-byte stores - no 2-byte scatter, no conflicts.
+template <bool KMAJOR>
+struct TileH {
+    static __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int K,
+                                                int tid, bool vec, float (&r)[16]) {
+        if constexpr (!KMAJOR) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = row0 + (tid >> 3) + 32 * j;
+                const int k = k0 + (tid & 7) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row < nrows) {
+                    const float* src = P + (size_t)row * ld + k;
+                    if (vec && k + 3 < K) v = *reinterpret_cast<const f32x4*>(src);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (k + e < K) v[e] = src[e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[4 * j + e] = v[e];
+            }
+        } else {
+            const int row = row0 + (tid & 127);
+            const int kb = k0 + (tid >> 7) * 16;
+            const float* src = P + (size_t)kb * ld + row;
+            const bool rok = row < nrows;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r[i] = (rok && kb + i < K) ? src[(size_t)i * ld] : 0.f;
+        }
+    }
+    // Interior tile (all 32 k in range, 16-byte aligned rows): branch-free.  Rows past the end are CLAMPED to the
+    // last row instead of zeroed - they only feed accumulator rows/columns that are never stored.
+    static __device__ __forceinline__ void load_fast(const float* __restrict__ P, int ld, int row0, int nrows, int k0,
+                                                     int tid, float (&r)[16]) {
+        if constexpr (!KMAJOR) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = min(row0 + (tid >> 3) + 32 * j, nrows - 1);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(P + (size_t)row * ld + k0 + (tid & 7) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[4 * j + e] = v[e];
+            }
+        } else {
+            const int row = min(row0 + (tid & 127), nrows - 1);
+            const float* src = P + (size_t)(k0 + (tid >> 7) * 16) * ld + row;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r[i] = src[(size_t)i * ld];
+        }
+    }
+    static __device__ __forceinline__ void store(unsigned short* __restrict__ S, int tid, const float (&r)[16]) {
+        if constexpr (!KMAJOR) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned short* dst = S + ((tid >> 3) + 32 * j) * HPITCH + (tid & 7) * 4;
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16_bits(r[4 * j]) | ((unsigned)f32_to_bf16_bits(r[4 * j + 1]) << 16);
+                pk.y = (unsigned)f32_to_bf16_bits(r[4 * j + 2]) | ((unsigned)f32_to_bf16_bits(r[4 * j + 3]) << 16);
+                *reinterpret_cast<uint2*>(dst) = pk;
+            }
+        } else {
+            unsigned short* dst = S + (tid & 127) * HPITCH + (tid >> 7) * 16;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint4 pk;
+                pk.x = (unsigned)f32_to_bf16_bits(r[8 * h + 0]) | ((unsigned)f32_to_bf16_bits(r[8 * h + 1]) << 16);
+                pk.y = (unsigned)f32_to_bf16_bits(r[8 * h + 2]) | ((unsigned)f32_to_bf16_bits(r[8 * h + 3]) << 16);
+                pk.z = (unsigned)f32_to_bf16_bits(r[8 * h + 4]) | ((unsigned)f32_to_bf16_bits(r[8 * h + 5]) << 16);
+                pk.w = (unsigned)f32_to_bf16_bits(r[8 * h + 6]) | ((unsigned)f32_to_bf16_bits(r[8 * h + 7]) << 16);
+                *reinterpret_cast<uint4*>(dst + 8 * h) = pk;
+            }
+        }
+    }
+};
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmHArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][HBM_ * HPITCH];
+    if (p.split_k <= 1) {
+        const int zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
+        p.A += zo * p.sAo + zi * p.sAi;
+        p.B += zo * p.sBo + zi * p.sBi;
+        p.C += zo * p.sCo + zi * p.sCi;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = blockIdx.y * HBM_, n0 = blockIdx.x * HBN_;
+    const int nk_all = (p.K + HBK_ - 1) / HBK_;
+    const int kt0 = p.split_k > 1 ? blockIdx.z * p.k_tiles_per_split : 0;
+    const int nk = p.split_k > 1 ? min(nk_all - kt0, p.k_tiles_per_split) : nk_all;
+    if (nk <= 0) return;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[16], rb[16];
+    // k-minor operands need 16-byte aligned rows for the fast path; k-major ones use dword loads (always fine)
+    const bool fa = A_KMAJOR || p.a_vec, fb = B_KMAJOR || p.b_vec;
+    auto load_tiles = [&](int k0) {
+        if (k0 + HBK_ <= p.K && fa && fb) {
+            TileH<A_KMAJOR>::load_fast(p.A, p.lda, m0, p.M, k0, tid, ra);
+            TileH<B_KMAJOR>::load_fast(p.B, p.ldb, n0, p.N, k0, tid, rb);
+        } else {
+            TileH<A_KMAJOR>::load(p.A, p.lda, m0, p.M, k0, p.K, tid, p.a_vec, ra);
+            TileH<B_KMAJOR>::load(p.B, p.ldb, n0, p.N, k0, p.K, tid, p.b_vec, rb);
+        }
+    };
+    load_tiles(kt0 * HBK_);
+    TileH<A_KMAJOR>::store(lds[0][0], tid, ra);
+    TileH<B_KMAJOR>::store(lds[0][1], tid, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt0 + kt + 1) * HBK_);
+        const unsigned short* As = lds[cur][0];
+        const unsigned short* Bs = lds[cur][1];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                a[i] = *reinterpret_cast<const bf16x8*>(As + (wm + 32 * i + (lane & 31)) * HPITCH + kk * 16 + (lane >> 5) * 8);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn + 32 * j + (lane & 31)) * HPITCH + kk * 16 + (lane >> 5) * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            TileH<A_KMAJOR>::store(lds[cur ^ 1][0], tid, ra);
+            TileH<B_KMAJOR>::store(lds[cur ^ 1][1], tid, rb);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + 32 * j + (lane & 31);
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) {
+                    float v = acc[i][j][r] * p.alpha + bias;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.split_k > 1) atomicAdd(p.C + (size_t)m * p.ldc + n, v);
+                    else p.C[(size_t)m * p.ldc + n] = v;
+                }
+            }
+    }
+}
+
+static int launch_gemm_h(GemmHArgs p, int batch, int a_kmajor, int b_kmajor, void* stream) {
+    const dim3 grid((p.N + HBN_ - 1) / HBN_, (p.M + HBM_ - 1) / HBM_, batch), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, p);
+    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, p);
+    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, p);
+    return check_launch("gemm_bf16");
+}
+
+}  // namespace dldkd
+
+using namespace dldkd;
+
+extern "C" int dldkd_gemm_bf16(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda,
+                               int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < N) { set_error("gemm_bf16: bad sizes"); return DLDKD_EINVAL; }
+    if (M == 0 || N == 0) return DLDKD_OK;
+    if (!A || !B || !C) { set_error("gemm_bf16: null pointer"); return DLDKD_EINVAL; }
+    const int a_vec = !(lda & 3) && !((uintptr_t)A & 15), b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
+    GemmHArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+    const int tiles = ((N + HBN_ - 1) / HBN_) * ((M + HBM_ - 1) / HBM_);
+    const int nk = (K + HBK_ - 1) / HBK_;
+    if (!bias && !relu && ldc == N && tiles < 128 && nk >= 16) {
+        int split = (256 + tiles - 1) / tiles;   // one block per CU: more splits only add atomics (measured)
+        if (split > nk / 4) split = nk / 4;
+        if (split > 1) {
+            p.k_tiles_per_split = (nk + split - 1) / split;
+            p.split_k = (nk + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
+            if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, (hipStream_t)stream) != hipSuccess) return check_launch("gemm_bf16 memset");
+            return launch_gemm_h(p, p.split_k, a_kmajor, b_kmajor, stream);
+        }
+    }
+    return launch_gemm_h(p, 1, a_kmajor, b_kmajor, stream);
+}
+
+extern "C" int dldkd_gemm_bf16_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                       int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo, long sAi,
+                                       long sBo, long sBi, long sCo, long sCi, float alpha, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < 1 || batch_outer < 0 || batch_inner < 1) {
+        set_error("gemm_bf16_batched: bad sizes");
+        return DLDKD_EINVAL;
+    }
+    const long batch = (long)batch_outer * batch_inner;
+    if (M == 0 || N == 0 || batch == 0) return DLDKD_OK;
+    if (batch > 65535) { set_error("gemm_bf16_batched: batch %ld > 65535", batch); return DLDKD_EINVAL; }
+    if (!A || !B || !C) { set_error("gemm_bf16_batched: null pointer"); return DLDKD_EINVAL; }
+    const bool al = !((sAo | sAi) & 3) && !(lda & 3) && !((uintptr_t)A & 15);
+    const bool bl = !((sBo | sBi) & 3) && !(ldb & 3) && !((uintptr_t)B & 15);
+    GemmHArgs p{A, B, nullptr, C, M, N, K, lda, ldb, ldc, 0, al, bl, batch_inner, sAo, sAi, sBo, sBi, sCo, sCi, alpha, 1, 0};
+    return launch_gemm_h(p, (int)batch, a_kmajor, b_kmajor, stream);
+}

@@ -83,6 +83,23 @@ struct TileIO {
             }
         }
     }
+    // Interior tile (all 16 k in range, 16-byte aligned): branch-free.  k-minor: rows past the end are clamped to
+    // the last row (they only feed accumulator rows that are never stored); k-major: the caller guarantees that
+    // all 128 rows of the tile exist.
+    static __device__ __forceinline__ void load_fast(const float* __restrict__ P, int ld, int row0, int nrows, int k0,
+                                                     int tid, f32x4 (&r)[2]) {
+        if constexpr (!KMAJOR) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = min(row0 + (tid >> 2) + 64 * j, nrows - 1);
+                r[j] = *reinterpret_cast<const f32x4*>(P + (size_t)row * ld + k0 + (tid & 3) * 4);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                r[j] = *reinterpret_cast<const f32x4*>(P + (size_t)(k0 + (tid >> 5) + 8 * j) * ld + row0 + (tid & 31) * 4);
+        }
+    }
     // registers -> LDS
     static __device__ __forceinline__ void store(float* __restrict__ S, int tid, const f32x4 (&r)[2]) {
         if constexpr (!KMAJOR) {
@@ -134,18 +151,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[2], rb[2];
-    TileIO<A_KMAJOR>::load(p.A, p.lda, m0, p.M, kt0 * BK, p.K, tid, p.a_vec, ra);
-    TileIO<B_KMAJOR>::load(p.B, p.ldb, n0, p.N, kt0 * BK, p.K, tid, p.b_vec, rb);
+    const bool fast = p.a_vec && p.b_vec && (!A_KMAJOR || m0 + BM <= p.M) && (!B_KMAJOR || n0 + BN <= p.N);
+    auto load_tiles = [&](int k0) {
+        if (fast && k0 + BK <= p.K) {
+            TileIO<A_KMAJOR>::load_fast(p.A, p.lda, m0, p.M, k0, tid, ra);
+            TileIO<B_KMAJOR>::load_fast(p.B, p.ldb, n0, p.N, k0, tid, rb);
+        } else {
+            TileIO<A_KMAJOR>::load(p.A, p.lda, m0, p.M, k0, p.K, tid, p.a_vec, ra);
+            TileIO<B_KMAJOR>::load(p.B, p.ldb, n0, p.N, k0, p.K, tid, p.b_vec, rb);
+        }
+    };
+    load_tiles(kt0 * BK);
     TileIO<A_KMAJOR>::store(lds[0][0], tid, ra);
     TileIO<B_KMAJOR>::store(lds[0][1], tid, rb);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {   // next tile's global loads fly under this tile's MFMAs
-            TileIO<A_KMAJOR>::load(p.A, p.lda, m0, p.M, (kt0 + kt + 1) * BK, p.K, tid, p.a_vec, ra);
-            TileIO<B_KMAJOR>::load(p.B, p.ldb, n0, p.N, (kt0 + kt + 1) * BK, p.K, tid, p.b_vec, rb);
-        }
+        if (kt + 1 < nk) load_tiles((kt0 + kt + 1) * BK);   // next tile's global loads fly under this tile's MFMAs
         const float* As = lds[cur][0];
         const float* Bs = lds[cur][1];
 #pragma unroll

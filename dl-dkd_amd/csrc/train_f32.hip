@@ -182,6 +182,63 @@ __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, c
     if (i < n) out[i] = a[i] * m[i] * scale;
 }
 
+// ---------------------------------------------------------------- dropout: counter-based RNG + mask + scale in one pass
+// Philox4x32-10 (Salmon et al., SC'11) keyed by `seed`, counter = (offset + i/4): four 32-bit draws per call, one
+// per element of a float4.  keep[i] = u32 >= p * 2^32;  out = keep ? x * scale : 0.  The byte mask is what the
+// backward pass re-reads (1 B/element instead of a 4 B float mask + a separate multiply kernel).
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          unsigned char* __restrict__ keep, long n, unsigned thresh, float scale,
+                                                          unsigned long long seed, unsigned long long offset) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;      // group of 4 elements
+    const long i = q * 4;
+    if (i >= n) return;
+    unsigned rnd[4];
+    const unsigned long long ctr = offset + (unsigned long long)q;
+    philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), rnd);
+    if (i + 3 < n) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+        f32x4 o;
+        uchar4 k;
+        k.x = rnd[0] >= thresh; k.y = rnd[1] >= thresh; k.z = rnd[2] >= thresh; k.w = rnd[3] >= thresh;
+        o[0] = k.x ? v[0] * scale : 0.f; o[1] = k.y ? v[1] * scale : 0.f;
+        o[2] = k.z ? v[2] * scale : 0.f; o[3] = k.w ? v[3] * scale : 0.f;
+        *reinterpret_cast<f32x4*>(out + i) = o;
+        *reinterpret_cast<uchar4*>(keep + i) = k;
+    } else {
+        for (int e = 0; i + e < n; ++e) {
+            const unsigned char k = rnd[e] >= thresh;
+            keep[i + e] = k;
+            out[i + e] = k ? x[i + e] * scale : 0.f;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void mask_scale_kernel(const float* __restrict__ a, const unsigned char* __restrict__ keep,
+                                                         float scale, float* __restrict__ out, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a + i);
+        const uchar4 k = *reinterpret_cast<const uchar4*>(keep + i);
+        f32x4 o;
+        o[0] = k.x ? v[0] * scale : 0.f; o[1] = k.y ? v[1] * scale : 0.f;
+        o[2] = k.z ? v[2] * scale : 0.f; o[3] = k.w ? v[3] * scale : 0.f;
+        *reinterpret_cast<f32x4*>(out + i) = o;
+    } else {
+        for (int e = 0; i + e < n; ++e) out[i + e] = keep[i + e] ? a[i + e] * scale : 0.f;
+    }
+}
+
 // ---------------------------------------------------------------- F.normalize rows (eps 1e-12)
 __global__ __launch_bounds__(256) void normalize_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                  float* __restrict__ inv, long M, int D) {
@@ -351,6 +408,24 @@ int dldkd_mul_f32(const float* a, const float* m, float scale, float* out, long 
     if (n <= 0) return n < 0 ? DLDKD_EINVAL : DLDKD_OK;
     LAUNCH1D(mul_kernel, n, 256, a, m, scale, out, n);
     return check_launch("mul");
+}
+int dldkd_dropout_fwd_f32(const float* x, float* out, unsigned char* keep, long n, float p, unsigned long long seed,
+                          unsigned long long offset, void* stream) {
+    if (n < 0 || !(p >= 0.f && p < 1.f)) { set_error("dropout_fwd: bad n=%ld or p=%f", n, (double)p); return DLDKD_EINVAL; }
+    if (n == 0) return DLDKD_OK;
+    if (!x || !out || !keep) { set_error("dropout_fwd: null pointer"); return DLDKD_EINVAL; }
+    if (((uintptr_t)x | (uintptr_t)out) & 15 || ((uintptr_t)keep & 3)) { set_error("dropout_fwd: unaligned buffer"); return DLDKD_EINVAL; }
+    const double t = (double)p * 4294967296.0;
+    const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    LAUNCH1D(dropout_fwd_kernel, (n + 3) / 4, 256, x, out, keep, n, thresh, 1.0f / (1.0f - p), seed, offset);
+    return check_launch("dropout_fwd");
+}
+int dldkd_mask_scale_f32(const float* a, const unsigned char* keep, float scale, float* out, long n, void* stream) {
+    if (n <= 0) return n < 0 ? DLDKD_EINVAL : DLDKD_OK;
+    if (!a || !out || !keep) { set_error("mask_scale: null pointer"); return DLDKD_EINVAL; }
+    if (((uintptr_t)a | (uintptr_t)out) & 15 || ((uintptr_t)keep & 3)) { set_error("mask_scale: unaligned buffer"); return DLDKD_EINVAL; }
+    LAUNCH1D(mask_scale_kernel, (n + 3) / 4, 256, a, keep, scale, out, n);
+    return check_launch("mask_scale");
 }
 int dldkd_normalize_rows_fwd_f32(const float* x, float* y, float* inv, long M, int D, void* stream) {
     if (M < 0 || D < 1) { set_error("normalize_rows_fwd: bad sizes"); return DLDKD_EINVAL; }

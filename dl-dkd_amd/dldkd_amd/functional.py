@@ -105,38 +105,53 @@ def layernorm(x, gamma, beta, add=None, add_mod=0):
 
 
 # ------------------------------------------------------------------------------------------ dropout
-class _Mul(Function):
+def _philox_slot(device, n):
+    """(seed, offset) for n elements from torch's CUDA generator; advances it like a torch op that draws n
+    numbers would, so torch.manual_seed / get_rng_state / set_rng_state govern our masks too."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    off = gen.get_offset()
+    gen.set_offset(off + 4 * ((n + 3) // 4))          # torch offsets move in multiples of 4
+    return gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, off
+
+
+def _dropout_fwd(x, p):
+    out = torch.empty_like(x)
+    keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    seed, off = _philox_slot(x.device, x.numel())
+    native.check(_L().dldkd_dropout_fwd_f32(_p(x), _p(out), _p(keep), x.numel(), float(p), seed, off, _s()), "dropout_fwd")
+    return out, keep
+
+
+class _Dropout(Function):
     @staticmethod
-    def forward(ctx, x, mask, scale):
-        ctx.save_for_backward(mask)
-        ctx.scale = scale
-        out = torch.empty_like(x)
-        native.check(_L().dldkd_mul_f32(_p(x), _p(mask), scale, _p(out), x.numel(), _s()), "mul")
+    def forward(ctx, x, p):
+        out, keep = _dropout_fwd(x, p)
+        ctx.save_for_backward(keep)
+        ctx.scale = 1.0 / (1.0 - p)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        (mask,) = ctx.saved_tensors
+        (keep,) = ctx.saved_tensors
         dy = _f32(dy)
         out = torch.empty_like(dy)
-        native.check(_L().dldkd_mul_f32(_p(dy), _p(mask), ctx.scale, _p(out), dy.numel(), _s()), "mul")
-        return out, None, None
+        native.check(_L().dldkd_mask_scale_f32(_p(dy), _p(keep), ctx.scale, _p(out), dy.numel(), _s()), "mask_scale")
+        return out, None
 
 
 def dropout(x, p, training):
-    """Inverted dropout; the Bernoulli mask comes from torch's generator, the multiply is ours."""
+    """Inverted dropout: Philox mask + scale in one kernel (seed/offset from torch's CUDA generator)."""
     if not training or p <= 0.0:
         return x
-    x = _f32(x)
-    mask = (torch.rand_like(x) >= p).float()
-    return _Mul.apply(x, mask, 1.0 / (1.0 - p))
+    return _Dropout.apply(_f32(x), float(p))
 
 
 # ------------------------------------------------------------------------------------------ attention
 def _bgemm(A, B, C, M, N, K, lda, ldb, ldc, ak, bk, n_seq, sA, sB, sC, alpha=1.0):
     """per-(sequence, head) product; s? = (outer stride, inner stride) in elements."""
-    native.check(_L().dldkd_gemm_f32_batched(A, B, C, M, N, K, lda, ldb, ldc, int(ak), int(bk), n_seq, HEADS,
-                                             sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], float(alpha), _s()), "gemm_f32_batched")
+    fn = _L().dldkd_gemm_bf16_batched if ops.gemm_precision() == "bf16" else _L().dldkd_gemm_f32_batched
+    native.check(fn(A, B, C, M, N, K, lda, ldb, ldc, int(ak), int(bk), n_seq, HEADS,
+                    sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], float(alpha), _s()), "gemm_batched")
 
 
 def _off(t, elems):
@@ -149,7 +164,7 @@ class _AttentionTrain(Function):
     the probabilities for the backward pass.  qkv (N, L, 1152); returns the context layer (N, L, 384)."""
 
     @staticmethod
-    def forward(ctx, qkv, mask, drop_mask, drop_scale):
+    def forward(ctx, qkv, mask, p_drop):
         N, L = qkv.shape[0], qkv.shape[1]
         P = torch.empty(N, HEADS, L, L, dtype=torch.float32, device=qkv.device)
         sq = (L * 3 * HIDDEN, DH)
@@ -157,20 +172,19 @@ class _AttentionTrain(Function):
         _bgemm(_off(qkv, 0), _off(qkv, HIDDEN), _p(P), L, L, DH, 3 * HIDDEN, 3 * HIDDEN, L, 0, 0, N, sq, sq, (HEADS * L * L, L * L))
         native.check(_L().dldkd_softmax_rows_fwd_f32(_p(P), _p(mask), N * HEADS * L, L, HEADS * L, 1.0 / math.sqrt(DH), _s()),
                      "softmax_rows_fwd")
-        Pd = P
-        if drop_mask is not None:
-            Pd = torch.empty_like(P)
-            native.check(_L().dldkd_mul_f32(_p(P), _p(drop_mask), drop_scale, _p(Pd), P.numel(), _s()), "mul")
+        Pd, keep = P, None
+        if p_drop > 0.0:
+            Pd, keep = _dropout_fwd(P, p_drop)
         out = torch.empty(N, L, HIDDEN, dtype=torch.float32, device=qkv.device)
         # ctx[q, d] = sum_key Pd[q,key] V[key,d]
         _bgemm(_p(Pd), _off(qkv, 2 * HIDDEN), _p(out), L, DH, L, L, 3 * HIDDEN, HIDDEN, 0, 1, N, (HEADS * L * L, L * L), sq, (L * HIDDEN, DH))
-        ctx.save_for_backward(qkv, P, Pd if drop_mask is not None else None, drop_mask)
-        ctx.drop_scale = drop_scale
+        ctx.save_for_backward(qkv, P, Pd if keep is not None else None, keep)
+        ctx.drop_scale = 1.0 / (1.0 - p_drop)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, P, Pd, drop_mask = ctx.saved_tensors
+        qkv, P, Pd, keep = ctx.saved_tensors
         N, L = qkv.shape[0], qkv.shape[1]
         dout = _f32(dout)
         dqkv = torch.empty_like(qkv)
@@ -181,14 +195,14 @@ class _AttentionTrain(Function):
         # dPd[q, key] = sum_d dout[q,d] V[key,d]
         dP = torch.empty_like(P)
         _bgemm(_p(dout), _off(qkv, 2 * HIDDEN), _p(dP), L, L, DH, HIDDEN, 3 * HIDDEN, L, 0, 0, N, so, sq, sp)
-        if drop_mask is not None:
-            native.check(_L().dldkd_mul_f32(_p(dP), _p(drop_mask), ctx.drop_scale, _p(dP), dP.numel(), _s()), "mul")
+        if keep is not None:
+            native.check(_L().dldkd_mask_scale_f32(_p(dP), _p(keep), ctx.drop_scale, _p(dP), dP.numel(), _s()), "mask_scale")
         scale = 1.0 / math.sqrt(DH)
         native.check(_L().dldkd_softmax_rows_bwd_f32(_p(P), _p(dP), N * HEADS * L, L, scale, _s()), "softmax_rows_bwd")
         # dQ[q, d] = sum_key dS[q,key] K[key,d] ;  dK[key, d] = sum_q dS[q,key] Q[q,d]
         _bgemm(_p(dP), _off(qkv, HIDDEN), _off(dqkv, 0), L, DH, L, L, 3 * HIDDEN, 3 * HIDDEN, 0, 1, N, sp, sq, sq)
         _bgemm(_p(dP), _off(qkv, 0), _off(dqkv, HIDDEN), L, DH, L, L, 3 * HIDDEN, 3 * HIDDEN, 1, 1, N, sp, sq, sq)
-        return dqkv, None, None, None
+        return dqkv, None, None
 
 
 def attention(qkv, mask, p_drop=0.0, training=False):
@@ -198,12 +212,7 @@ def attention(qkv, mask, p_drop=0.0, training=False):
         N, L = qkv.shape[0], qkv.shape[1]
         if N * HEADS > 65535:
             raise native.NativeError("training attention: at most 16383 sequences per call")
-        drop_mask = None
-        scale = 1.0
-        if training and p_drop > 0.0:
-            drop_mask = (torch.rand(N, HEADS, L, L, device=qkv.device) >= p_drop).float()
-            scale = 1.0 / (1.0 - p_drop)
-        return _AttentionTrain.apply(qkv, mask, drop_mask, scale)
+        return _AttentionTrain.apply(qkv, mask, float(p_drop) if training else 0.0)
     return ops.attention(qkv, mask)
 
 

@@ -7,6 +7,23 @@ HIDDEN = 384
 LN_EPS = 1e-5   # nn.LayerNorm default (model_components.py:274,301,443)
 
 
+_PRECISION = "fp32"
+
+
+def set_gemm_precision(precision):
+    """"fp32": fp32-input MFMA everywhere (parity grade, the default).  "bf16": the GEMMs of `linear` / `gemm` (and the
+    batched attention products in functional.py) run on bf16 MFMA with fp32 accumulation - the throughput mode of
+    the training step (BASELINE.json configs[2])."""
+    global _PRECISION
+    if precision not in ("fp32", "bf16"):
+        raise ValueError(precision)
+    _PRECISION = precision
+
+
+def gemm_precision():
+    return _PRECISION
+
+
 def _chk(t, name):
     if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
         raise native.NativeError(f"{name}: need a contiguous fp32 GPU tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
@@ -23,8 +40,9 @@ def linear(x, weight, bias=None, relu=False):
     if weight.shape[1] != K:
         raise native.NativeError(f"linear: x has {K} features, weight expects {weight.shape[1]}")
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    native.check(L.dldkd_gemm_f32(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
-                                  0, 0, int(relu), native.stream()), "gemm_f32")
+    fn = L.dldkd_gemm_bf16 if _PRECISION == "bf16" else L.dldkd_gemm_f32
+    native.check(fn(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
+                    0, 0, int(relu), native.stream()), "gemm")
     return y.view(*x.shape[:-1], N)
 
 
@@ -33,8 +51,9 @@ def gemm(a, b, a_kmajor, b_kmajor, M, N, K):
     L = native.lib()
     _chk(a, "gemm.a"); _chk(b, "gemm.b")
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    native.check(L.dldkd_gemm_f32(native.ptr(a), native.ptr(b), None, native.ptr(c), M, N, K, a.shape[-1], b.shape[-1], N,
-                                  int(a_kmajor), int(b_kmajor), 0, native.stream()), "gemm_f32")
+    fn = L.dldkd_gemm_bf16 if _PRECISION == "bf16" else L.dldkd_gemm_f32
+    native.check(fn(native.ptr(a), native.ptr(b), None, native.ptr(c), M, N, K, a.shape[-1], b.shape[-1], N,
+                    int(a_kmajor), int(b_kmajor), 0, native.stream()), "gemm")
     return c
 
 

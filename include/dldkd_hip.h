@@ -158,6 +158,15 @@ int dldkd_gemm_f32_batched(const float* A, const float* B, float* C, int M, int 
                            int ldc, int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo,
                            long sAi, long sBo, long sBi, long sCo, long sCi, float alpha, void* stream);
 
+/* Throughput-mode twins of dldkd_gemm_f32 / dldkd_gemm_f32_batched: same arguments and operand layouts, fp32
+ * operands in memory converted to bf16 on the way to LDS, bf16 MFMA with fp32 accumulation.  Used by the training
+ * step when the precision is set to "bf16" (BASELINE.json configs[2]); the fp32 entry points remain the parity path. */
+int dldkd_gemm_bf16(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
+                    int ldc, int a_kmajor, int b_kmajor, int relu, void* stream);
+int dldkd_gemm_bf16_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                            int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo, long sAi, long sBo,
+                            long sBi, long sCo, long sCi, float alpha, void* stream);
+
 /* P = softmax(S * scale + (1 - keymask) * -10000) over the last dim L <= 128, in place; row r uses
  * keymask[r / rows_per_seq] (model_components.py:419-426).  keymask may be NULL. */
 int dldkd_softmax_rows_fwd_f32(float* S, const float* keymask, long rows, int L, int rows_per_seq, float scale,
@@ -177,6 +186,15 @@ int dldkd_relu_bwd_f32(float* dy, const float* y, long n, void* stream);
 int dldkd_axpy_f32(float* a, const float* b, float alpha, long n, void* stream);
 /* out = a * m * scale  (dropout masks, forward and backward). */
 int dldkd_mul_f32(const float* a, const float* m, float scale, float* out, long n, void* stream);
+
+/* Inverted dropout in one pass (reference: nn.Dropout in model_components.py / model.py input_drop, drop).
+ * keep[i] = Philox4x32-10(key = seed, counter = offset + i/4)[i%4] >= p * 2^32;  out = keep ? x / (1-p) : 0.
+ * The caller advances `offset` by ceil(n/4) per call (the host side draws seed/offset from torch's CUDA generator,
+ * so torch.manual_seed makes a run reproducible).  dldkd_mask_scale_f32 is the backward: out = keep ? a*scale : 0
+ * (out may alias a).  Buffers 16-byte aligned, keep 4-byte aligned. */
+int dldkd_dropout_fwd_f32(const float* x, float* out, unsigned char* keep, long n, float p, unsigned long long seed,
+                          unsigned long long offset, void* stream);
+int dldkd_mask_scale_f32(const float* a, const unsigned char* keep, float scale, float* out, long n, void* stream);
 
 /* F.normalize(x, dim=-1) (eps 1e-12, model.py:318-319): y, inv (1/norm per row); and its backward. */
 int dldkd_normalize_rows_fwd_f32(const float* x, float* y, float* inv, long M, int D, void* stream);

@@ -1,0 +1,108 @@
+"""Throughput mode of the training step: the GEMMs on bf16 MFMA (fp32 accumulate), everything else as in fp32.
+
+The bf16 GEMM is checked exactly (against fp64 products of the bf16-rounded operands: only accumulation order
+differs) in every operand layout the training step uses; the whole forward+backward is then checked against the
+reference's golden losses/gradients (G4) at bf16-grade tolerance.  fp32 remains the parity mode (test_train_gpu)."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from test_encoder_gpu import _model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture
+def bf16_mode():
+    from dldkd_amd import ops
+    ops.set_gemm_precision("bf16")
+    yield
+    ops.set_gemm_precision("fp32")
+
+
+def _r(t):
+    return t.bfloat16().double()
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 4), (130, 70, 20), (257, 384, 3072), (1000, 1152, 384), (64, 384, 770)])
+def test_gemm_bf16_linear(bf16_mode, M, N, K):
+    from dldkd_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=True)
+    assert _rel(y, torch.relu(_r(x) @ _r(w).t() + b.double())) < 3e-6
+    assert _rel(y, torch.relu(x.double() @ w.double().t() + b.double())) < 2e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(96, 50, 36), (300, 384, 384), (640, 384, 16384), (129, 3072, 385)])
+def test_gemm_bf16_backward_layouts(bf16_mode, M, N, K):
+    from dldkd_amd import ops
+    g = torch.Generator().manual_seed(7)
+    dy, w, x = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g), torch.randn(M, N, generator=g)
+    dx = ops.gemm(dy.to(DEV), w.to(DEV), False, True, M, N, K)
+    assert _rel(dx, _r(dy) @ _r(w)) < 3e-6 * max(1.0, (K / 512) ** 0.5)
+    Kc = 128 if K > 128 else K
+    dyc = dy[:, :Kc].contiguous()
+    dw = ops.gemm(dyc.to(DEV), x.to(DEV), True, True, Kc, N, M)
+    assert _rel(dw, _r(dyc).t() @ _r(x)) < 3e-6
+
+
+def test_attention_train_bf16_matches_fp32(bf16_mode):
+    """batched per-head products of the training attention, bf16 vs the fp32 kernels."""
+    from dldkd_amd import functional as F_, ops
+    g = torch.Generator().manual_seed(3)
+    qkv = (torch.randn(6, 40, 1152, generator=g) * 0.5).to(DEV)
+    mask = torch.ones(6, 40)
+    mask[2, 25:] = 0
+    mask = mask.to(DEV)
+    outs = {}
+    for prec in ("bf16", "fp32"):
+        ops.set_gemm_precision(prec)
+        a = qkv.clone().requires_grad_(True)
+        o = F_._AttentionTrain.apply(a, mask, 0.0)
+        o.square().sum().backward()
+        outs[prec] = (o.detach(), a.grad.detach())
+    ops.set_gemm_precision("bf16")
+    assert _rel(outs["bf16"][0], outs["fp32"][0]) < 2e-2
+    assert _rel(outs["bf16"][1], outs["fp32"][1]) < 3e-2
+
+
+def test_forward_backward_bf16_vs_golden_g4(bf16_mode, golden_dir):
+    g = np.load(f"{golden_dir}/g4_forward.npz")
+    tag = "soft_rand"
+    m = _model(3072, 768, synth.make_params(41, 3072, 768))
+    m.label_style = "soft"
+    m.set_hard_negative(False, 20)
+    m.weight = 0.95 ** 2
+    batch = synth.make_train_batch(1, nv=64, caps=1, L=16, dv=3072, dq=768)
+    batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    torch.manual_seed(4242)
+    loss, d = m(batch)
+    for k in ("inher_trip", "inher_nce", "explore_trip", "explore_nce", "kl_intra"):
+        ref = float(g[f"{tag}_{k}"])
+        assert abs(float(d[k]) - ref) <= 2e-2 * max(1.0, abs(ref)), (k, float(d[k]), ref)
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) <= 2e-2 * max(1.0, abs(float(g[f"{tag}_loss"])))
+    m.zero_grad()
+    loss.backward()
+    # direction and size of the whole gradient: cosine over the sampled entries, norms per tensor
+    got, ref, bad = [], [], []
+    nmax = max(float(g[f"{tag}_grad/{n}/norm"]) for n, _ in m.named_parameters())
+    for n, prm in m.named_parameters():
+        gr = prm.grad.detach().reshape(-1).cpu()
+        idx = np.unique(np.linspace(0, gr.numel() - 1, min(48, gr.numel())).astype(np.int64))
+        got.append(gr[idx].double().numpy())
+        ref.append(g[f"{tag}_grad/{n}/sample"].astype(np.float64))
+        rn = float(g[f"{tag}_grad/{n}/norm"])
+        if abs(float(gr.double().norm()) - rn) > 0.1 * max(rn, 1e-3 * nmax):
+            bad.append((n, float(gr.double().norm()), rn))
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref)))
+    assert cos > 0.97, cos          # measured 0.987: bf16 operand rounding through 8 stacked GEMMs + hinge/ReLU boundaries
+    assert not bad, bad

@@ -235,3 +235,31 @@ def test_forward_backward_vs_golden_g4(golden_dir, tag, label_style, hard, caps)
         assert np.abs(gr[idx].double().numpy() - ref).max() <= tol * scale, n
         rn = float(g[f"{tag}_grad/{n}/norm"])
         assert abs(float(gr.double().norm()) - rn) <= tol * max(rn, 1e-4 * nmax), n
+
+
+@pytest.mark.parametrize("n,p", [(1, 0.5), (1027, 0.1), (4 * 128 * 128 * 16, 0.2)])
+def test_fused_dropout_mask_scale_and_rng(n, p):
+    """nn.Dropout semantics from one kernel: keep-rate 1-p, kept values scaled by 1/(1-p), the backward pass
+    re-uses the same mask, and torch's CUDA generator governs the stream (manual_seed reproduces, calls differ)."""
+    from dldkd_amd import functional as F_
+    x = torch.randn(n, device=DEV).abs() + 0.5
+    torch.manual_seed(11)
+    a = x.clone().requires_grad_(True)
+    y1 = F_.dropout(a, p, True)
+    y2 = F_.dropout(x, p, True)                      # next slot of the generator: different mask
+    torch.manual_seed(11)
+    y3 = F_.dropout(x, p, True)
+    assert torch.equal(y1.detach(), y3)
+    kept = y1.detach() != 0
+    assert torch.allclose(y1.detach()[kept], (x / (1 - p))[kept], rtol=1e-6)
+    if n > 1000:
+        assert not torch.equal(y1.detach(), y2)
+        rate = kept.float().mean().item()
+        assert abs(rate - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-3, rate
+        # no short-period structure: keep flags of neighbouring elements are uncorrelated
+        k = kept.float() - (1 - p)
+        assert abs((k[1:] * k[:-1]).mean().item()) < 5 * p * (1 - p) / n ** 0.5 + 1e-3
+    y1.backward(torch.ones_like(y1))
+    assert torch.equal(a.grad != 0, kept)
+    assert torch.allclose(a.grad[kept], torch.full_like(a.grad[kept], 1 / (1 - p)))
+    assert F_.dropout(x, p, False) is x and F_.dropout(x, 0.0, True) is x

@@ -8,6 +8,9 @@ from dldkd_amd.model import DLDKD
 from dldkd_amd.optimization import BertAdam
 DEV = "cuda:0"
 drop = float(sys.argv[1]) if len(sys.argv) > 1 else 0.2
+prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+from dldkd_amd import ops
+ops.set_gemm_precision(prec)
 cfg = types.SimpleNamespace(visual_input_size=3072, query_input_size=768, inheritance_hidden=384, exploration_hidden=384,
                             max_ctx_l=128, max_desc_l=30, input_drop=drop, drop=drop, n_heads=4, initializer_range=0.02,
                             margin=0.1, use_hard_negative=True, hard_pool_size=20, label_style="soft")
@@ -24,4 +27,4 @@ for _ in range(3): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-print(f"C3 train step (fp32-MFMA path, dropout {drop}): {dt*1e3:.2f} ms/step  loss {float(l):.4f}")
+print(f"C3 train step ({prec} GEMMs, dropout {drop}): {dt*1e3:.2f} ms/step  loss {float(l):.4f}")
