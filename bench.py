@@ -120,6 +120,21 @@ def extras(dev):
         out["c3_train_step_ms"] = (time.perf_counter() - t0) / 10 * 1e3
         out["c3_train_step_config"] = "TVR: 128 videos / 640 queries, L<=128, label_style=soft, hard negatives, dropout 0.2, " \
                                       "forward+backward+fused BertAdam, fp32-input MFMA path (parity grade)"
+        from dldkd_amd import ops
+        ops.set_gemm_precision("bf16")    # throughput mode: the configuration BASELINE.json configs[2] names (bf16)
+        try:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            out["c3_train_step_ms_bf16"] = (time.perf_counter() - t0) / 10 * 1e3
+            out["c3_train_step_bf16_config"] = "same step, every GEMM on bf16 MFMA with fp32 accumulation (fp32 master " \
+                                               "weights, fp32 activations in HBM, losses/normalisations/optimizer fp32)"
+        finally:
+            ops.set_gemm_precision("fp32")
         m.eval()
         B, Lc = 200, 128
         feats = torch.nn.functional.normalize(torch.randn(B, Lc, 3072, device=dev), dim=-1)
@@ -145,7 +160,18 @@ def extras(dev):
             torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
         out["gallery_encode_videos_per_s_k4_bf16"] = B / dt
-        from dldkd_amd import ops
+        ops.set_gemm_precision("bf16")    # + every remaining tower GEMM on bf16 MFMA
+        try:
+            with torch.no_grad():
+                m.encode_context(feats, mask)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    m.encode_context(feats, mask)
+                torch.cuda.synchronize()
+            out["gallery_encode_videos_per_s_all_bf16"] = B / ((time.perf_counter() - t0) / 5)
+        finally:
+            ops.set_gemm_precision("fp32")
         xk = torch.nn.functional.normalize(torch.randn(400000, 3072, device=dev), dim=-1)      # 4.9 GB: beyond the L3
         fold = ops.FoldedInProj([m.visual_input_proj, m.exp_visual_input_proj])
         ops.in_proj_bf16(xk, fold)
