@@ -172,6 +172,17 @@ def extras(dev):
             out["gallery_encode_videos_per_s_all_bf16"] = B / ((time.perf_counter() - t0) / 5)
         finally:
             ops.set_gemm_precision("fp32")
+        del m, opt, batch
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from bench_eval_e2e import stage_times
+        # GPU work of one eval_epoch at C2 from RAW features (encode gallery + queries, score, rank); SURVEY 8d
+        out["eval_epoch_gpu_stages_fp32"] = stage_times(NV, NQ, "fp32", str(dev))
+        out["eval_epoch_gpu_stages_fast"] = stage_times(NV, NQ, "fast", str(dev))
+        import types as _t
+        cfg2 = cfg
+        torch.manual_seed(0)
+        m = DLDKD(cfg2, opt_).to(dev).eval()
         xk = torch.nn.functional.normalize(torch.randn(400000, 3072, device=dev), dim=-1)      # 4.9 GB: beyond the L3
         fold = ops.FoldedInProj([m.visual_input_proj, m.exp_visual_input_proj])
         ops.in_proj_bf16(xk, fold)

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void pack_queries_kernel(const float* __restri
 }
 
 // Gallery blob: row-major bf16 [nv][Lp][384], Lp = round_up(L, 32); rows l >= len_v are zero.
+// `out` points at the first video of this call; L is the row count of the SOURCE (g, mask), Lp the destination's.
 __global__ __launch_bounds__(256) void pack_gallery_kernel(const float* __restrict__ g, const float* __restrict__ mask,
                                                            int nv, int L, int Lp, int normalize,
                                                            bf16x8* __restrict__ out) {
@@ -588,6 +589,25 @@ int dldkd_pack_gallery_bf16(const float* g, const float* mask, int nv, int L, in
                        nv, L, Lp, normalize, (bf16x8*)g_packed);
     hipLaunchKernelGGL(mask_lens_kernel, dim3((nv + 3) / 4), dim3(256), 0, (hipStream_t)stream, mask, nv, L, lens);
     return check_launch("pack_gallery");
+}
+
+int dldkd_pack_gallery_chunk_bf16(const float* g, const float* mask, int nv_chunk, int L_chunk, int normalize,
+                                  void* g_packed, int32_t* lens, int v0, int nv_total, int L_total, void* stream) {
+    if (nv_chunk < 0 || v0 < 0 || nv_total < 0 || (long)v0 + nv_chunk > nv_total || L_chunk < 1 || L_total < L_chunk ||
+        L_total > DLDKD_MAX_CLIPS || (nv_chunk > 0 && (!g || !g_packed || !lens))) {
+        set_error("pack_gallery_chunk: bad arguments (chunk %d videos x %d clips at %d into %d x %d, max %d clips)", nv_chunk,
+                  L_chunk, v0, nv_total, L_total, DLDKD_MAX_CLIPS);
+        return DLDKD_EINVAL;
+    }
+    if (nv_chunk == 0) return DLDKD_OK;
+    const int Lp = round_up(L_total, 32);
+    const long rows = (long)nv_chunk * Lp;
+    bf16x8* dst = (bf16x8*)g_packed + (size_t)v0 * Lp * kRowBf16x8;
+    hipLaunchKernelGGL(pack_gallery_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, mask,
+                       nv_chunk, L_chunk, Lp, normalize, dst);
+    hipLaunchKernelGGL(mask_lens_kernel, dim3((nv_chunk + 3) / 4), dim3(256), 0, (hipStream_t)stream, mask, nv_chunk, L_chunk,
+                       lens + v0);
+    return check_launch("pack_gallery_chunk");
 }
 
 int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_packed, const int32_t* lens,

@@ -100,21 +100,33 @@ def cal_perf(t2v_all_errors, t2v_gt, test=False):
     return (r1, r5, r10, r100, medr, meanr, m)
 
 
-def compute_context_info(model, eval_dataset, opt):
+def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
     """Encode the gallery in batches of eval_context_bsz, zero-pad to the global max length, concatenate
-    (eval.py:114-175).  Adds `_packed`: the resident bf16 gallery the scorer consumes."""
+    (eval.py:114-175).  Adds `_packed`: the resident bf16 gallery the scorer consumes.
+
+    keep_frame_feats=False (what eval_epoch uses): every encoded batch is packed straight into the resident bf16
+    gallery and dropped - the fp32 (Nv, Lmax, 384) tensors of the reference's dict (2 x 4.3 GB at TVR scale) are
+    never formed and `inher_frame_feat` / `explore_frame_feat` are None."""
+    from .model import _cfg_get
     model.eval()
     loader = DataLoader(eval_dataset, collate_fn=collate_frame_val, batch_size=opt.eval_context_bsz,
                         num_workers=opt.num_workers, shuffle=False, pin_memory=opt.pin_memory)
     metas, inh, exp, masks = [], [], [], []
+    packer = None
     with torch.no_grad():
         for batch in loader:
             metas.extend(batch[-1])
             feat = batch[0].to(opt.device, non_blocking=True)
             mask = batch[1].to(opt.device, non_blocking=True)
             gi, ge = model.encode_context(feat, mask)
-            inh.append(gi)
-            exp.append(ge)
+            if keep_frame_feats:
+                inh.append(gi)
+                exp.append(ge)
+            else:
+                if packer is None:
+                    packer = scoring.GalleryPacker(len(eval_dataset), int(_cfg_get(model.config, "max_ctx_l")),
+                                                   2 if model.double_branch else 1, gi.device)
+                packer.add([gi, ge] if model.double_branch else [gi], mask)
             masks.append(mask)
 
     def cat(tensors):
@@ -126,6 +138,9 @@ def compute_context_info(model, eval_dataset, opt):
             o += t.shape[0]
         return out
 
+    if not keep_frame_feats:
+        return dict(video_metas=metas, inher_frame_feat=None, explore_frame_feat=None, teacher_frame_feat=None,
+                    video_mask=cat(masks), _packed=packer.finish())
     info = dict(video_metas=metas, inher_frame_feat=cat(inh),
                 explore_frame_feat=cat(exp) if model.double_branch else None,
                 teacher_frame_feat=None, video_mask=cat(masks))
@@ -134,18 +149,47 @@ def compute_context_info(model, eval_dataset, opt):
     return info
 
 
+QUERY_SUPER_BATCH = 2048
+
+
 def _encode_all_queries(model, eval_dataset, opt):
+    """Encode every query; rows come out in query_metas order (per-loader-batch length-sorted, data_provider.py:153).
+    Loader batches (eval_query_bsz = 50 in the reference's scripts) are grouped into super-batches of up to
+    QUERY_SUPER_BATCH rows, zero-padded to a common word count, and encoded in ONE pass: padded words are masked out
+    of attention and pooling exactly (exp(-10000) and exp(-1e10) are 0 in fp32), so the vectors are those of the
+    per-batch calls while the launch count drops ~40x."""
     loader = DataLoader(eval_dataset, collate_fn=collate_text_val, batch_size=opt.eval_query_bsz,
                         num_workers=opt.num_workers, shuffle=False, pin_memory=opt.pin_memory)
     metas, qi, qe = [], [], []
+    pend_f, pend_m, pend_n = [], [], 0
+
+    def flush():
+        nonlocal pend_f, pend_m, pend_n
+        if not pend_f:
+            return
+        lw = max(f.shape[1] for f in pend_f)
+        feat = pend_f[0].new_zeros(pend_n, lw, pend_f[0].shape[2])
+        mask = pend_m[0].new_zeros(pend_n, lw)
+        o = 0
+        for f, m_ in zip(pend_f, pend_m):
+            feat[o:o + f.shape[0], :f.shape[1]] = f
+            mask[o:o + f.shape[0], :f.shape[1]] = m_
+            o += f.shape[0]
+        a, b = model.encode_query(feat, mask)
+        qi.append(a.reshape(pend_n, -1))
+        if b is not None:
+            qe.append(b.reshape(pend_n, -1))
+        pend_f, pend_m, pend_n = [], [], 0
+
     with torch.no_grad():
         for batch in loader:
             metas.extend(batch[-1])
-            feat = batch[0].to(opt.device, non_blocking=True)
-            mask = batch[1].to(opt.device, non_blocking=True)
-            a, b = model.encode_query(feat, mask)
-            qi.append(a)
-            qe.append(b)
+            pend_f.append(batch[0].to(opt.device, non_blocking=True))
+            pend_m.append(batch[1].to(opt.device, non_blocking=True))
+            pend_n += batch[0].shape[0]
+            if pend_n >= QUERY_SUPER_BATCH:
+                flush()
+        flush()
     qs = [torch.cat(qi, 0)] + ([torch.cat(qe, 0)] if model.double_branch else [])
     return metas, qs
 
@@ -189,7 +233,7 @@ def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=Fal
     lo, hi, _ = ddist.shard_range(n_videos, rank, world)
     # video ids of the WHOLE gallery are needed for the ground truth; only the ids, not the features
     all_ids = [val_video_dataset[i][2] for i in range(n_videos)] if world > 1 else None
-    ctx = compute_context_info(model, Subset(val_video_dataset, range(lo, hi)), opt)
+    ctx = compute_context_info(model, Subset(val_video_dataset, range(lo, hi)), opt, keep_frame_feats=False)
     fused, s0, s1, query_metas = score_queries(model, val_text_dataset, opt, ctx)
     video_metas = all_ids if all_ids is not None else ctx["video_metas"]
     _, t2v_gt = get_gt(video_metas, query_metas)
@@ -215,7 +259,7 @@ def eval_epoch(model, val_video_dataset, val_text_dataset, opt, test=False):
     """SumR (R@1 + R@5 + R@10 + R@100) of the fused scores; logs the three rankings (eval.py:237-263)."""
     model.eval()
     logger.info("Computing scores")
-    context_info = compute_context_info(model, val_video_dataset, opt)
+    context_info = compute_context_info(model, val_video_dataset, opt, keep_frame_feats=False)
     fused, s0, s1, query_metas = score_queries(model, val_text_dataset, opt, context_info)
     _, t2v_gt = get_gt(context_info["video_metas"], query_metas)
     if opt.double_branch:

@@ -79,6 +79,43 @@ def pack_gallery(gs, mask=None, normalize=True):
     return PackedGallery(blobs, lens, order, inv, nv, L)
 
 
+class GalleryPacker:
+    """Streaming pack_gallery: the eval driver hands over one encoded batch at a time and the fp32 (Nv, L, 384)
+    gallery of the reference (eval.py:139-175, 2 x 4.3 GB at TVR scale) never exists.  add() packs videos
+    [v0, v0 + n) of every branch; finish() computes the visiting order and returns the PackedGallery."""
+
+    def __init__(self, nv, L, n_branches, device, normalize=True):
+        if L > MAX_CLIPS:
+            raise native.NativeError(f"at most {MAX_CLIPS} clips per video (config max_ctx_l); got {L}")
+        L_ = native.lib()
+        self.nv, self.L, self.normalize, self.filled = nv, L, normalize, 0
+        self.blobs = [torch.empty(L_.dldkd_packed_gallery_bytes(nv, L), dtype=torch.uint8, device=device)
+                      for _ in range(n_branches)]
+        self.lens = torch.zeros(max(nv, 1), dtype=torch.int32, device=device)
+
+    def add(self, gs, mask):
+        n, lc = gs[0].shape[0], gs[0].shape[1]
+        if len(gs) != len(self.blobs) or self.filled + n > self.nv or lc > self.L:
+            raise native.NativeError(f"GalleryPacker.add: batch of {n} x {lc} does not fit ({self.filled}/{self.nv} x {self.L})")
+        m = None if mask is None else _f32c(mask)
+        for g, blob in zip(gs, self.blobs):
+            if g.dim() != 3 or g.shape[2] != HIDDEN or g.shape[0] != n or g.shape[1] != lc:
+                raise native.NativeError(f"gallery batch must be (n, L, {HIDDEN}); got {tuple(g.shape)}")
+            native.check(native.lib().dldkd_pack_gallery_chunk_bf16(native.ptr(_f32c(g)), native.ptr(m), n, lc, int(self.normalize),
+                                                                    native.ptr(blob), native.ptr(self.lens), self.filled, self.nv,
+                                                                    self.L, native.stream()), "pack_gallery_chunk")
+        self.filled += n
+
+    def finish(self):
+        if self.filled != self.nv:
+            raise native.NativeError(f"GalleryPacker.finish: {self.filled} of {self.nv} videos packed")
+        lens = self.lens[:self.nv]
+        order = torch.argsort(lens, descending=True, stable=True).to(torch.int32)
+        inv = torch.empty_like(order)
+        inv[order.long()] = torch.arange(self.nv, dtype=torch.int32, device=lens.device)
+        return PackedGallery(self.blobs, lens, order, inv, self.nv, self.L)
+
+
 def _variant():
     import os
     return os.environ.get("DLDKD_SIMPOOL_VARIANT", "2")

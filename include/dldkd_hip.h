@@ -59,6 +59,13 @@ int dldkd_pack_queries_bf16(const float* q, int nq, int normalize, void* q_packe
 int dldkd_pack_gallery_bf16(const float* g, const float* mask, int nv, int L, int normalize,
                             void* g_packed, int32_t* lens, void* stream);
 
+/* Streaming form of dldkd_pack_gallery_bf16 for the eval driver (compute_context_info, eval.py:114-175, encodes the
+ * gallery in batches of eval_context_bsz and zero-pads to the global max length, eval.py:139-155): packs one encoded
+ * batch (nv_chunk, L_chunk, 384) + its mask into videos [v0, v0 + nv_chunk) of a blob sized for (nv_total, L_total);
+ * clips l >= L_chunk are zero rows.  lens points at the lens array of the WHOLE gallery. */
+int dldkd_pack_gallery_chunk_bf16(const float* g, const float* mask, int nv_chunk, int L_chunk, int normalize,
+                                  void* g_packed, int32_t* lens, int v0, int nv_total, int L_total, void* stream);
+
 /* All-pairs pooled scores, stage 1 (the dominant kernel).  For each branch b < n_branches (1 or 2):
  *     part_b[pos(v), q] = max_{l < lens[v]} < q_packed[b][q], g_packed[b][v, l] >   (model.py:321-327)
  * written to `workspace` as [n_branches][nv][round_up(nq,32)] fp32, videos in `order` (order[pos] = v;

@@ -105,3 +105,53 @@ def test_eval_epoch_sharded_equals_unsharded():
         finally:
             dist.destroy_process_group()
     assert b == pytest.approx(ref)
+
+
+def test_gallery_packer_streaming_equals_one_shot():
+    """Chunks with their own (shorter) padded length land in the blob exactly as the one-shot packer puts them."""
+    from dldkd_amd import scoring
+    g = torch.Generator().manual_seed(21)
+    nv, L = 23, 50
+    lens = torch.randint(1, L + 1, (nv,), generator=g)
+    lens[4] = L
+    mask = (torch.arange(L)[None] < lens[:, None]).float()
+    gs = [(torch.randn(nv, L, 384, generator=g) * mask[..., None]).to(DEV) for _ in range(2)]
+    one = scoring.pack_gallery(gs, mask.to(DEV))
+    pk = scoring.GalleryPacker(nv, L, 2, torch.device(DEV))
+    for lo, hi in ((0, 7), (7, 8), (8, 23)):
+        lc = int(lens[lo:hi].max())                              # collate pads each batch to ITS max length
+        pk.add([x[lo:hi, :lc].contiguous() for x in gs], mask[lo:hi, :lc].contiguous().to(DEV))
+    st = pk.finish()
+    assert torch.equal(st.lens, one.lens) and torch.equal(st.order, one.order) and torch.equal(st.inv_order, one.inv_order)
+    for a, b in zip(st.blobs, one.blobs):
+        assert torch.equal(a, b)
+    with pytest.raises(Exception):
+        scoring.GalleryPacker(3, L, 1, torch.device(DEV)).finish()          # nothing packed yet
+    with pytest.raises(Exception):
+        scoring.GalleryPacker(3, 129, 1, torch.device(DEV))
+
+
+def test_streaming_context_and_query_super_batches_equal_per_batch_path():
+    from dldkd_amd import eval as ev
+    m = _model(1024, 1024, synth.make_params(17, 1024, 1024))
+    vids, txts = synth.make_eval_sets(9, nv=41, caps=3, dv=1024, dq=1024)
+    opt = _opt()
+    opt.eval_query_bsz = 7
+    with torch.no_grad():
+        full = ev.compute_context_info(m, synth.ListDataset(list(vids)), opt)
+        stream = ev.compute_context_info(m, synth.ListDataset(list(vids)), opt, keep_frame_feats=False)
+        assert stream["inher_frame_feat"] is None and torch.equal(stream["video_mask"], full["video_mask"])
+        assert torch.equal(stream["_packed"].lens, full["_packed"].lens)
+        f1, a1, b1, metas1 = ev.score_queries(m, synth.ListDataset(list(txts)), opt, full)
+        f2, a2, b2, metas2 = ev.score_queries(m, synth.ListDataset(list(txts)), opt, stream)
+        assert metas1 == metas2
+        assert torch.equal(f1, f2) and torch.equal(a1, a2) and torch.equal(b1, b2)
+        # super-batched query encoding (here: all 123 queries in one pass) vs one encode per loader batch
+        old, ev.QUERY_SUPER_BATCH = ev.QUERY_SUPER_BATCH, 1
+        try:
+            _, qs_small = ev._encode_all_queries(m, synth.ListDataset(list(txts)), opt)
+        finally:
+            ev.QUERY_SUPER_BATCH = old
+        _, qs_big = ev._encode_all_queries(m, synth.ListDataset(list(txts)), opt)
+        for x, y in zip(qs_small, qs_big):
+            assert x.shape == y.shape and (x - y).abs().max().item() < 2e-6

@@ -10,7 +10,10 @@ cfg = types.SimpleNamespace(visual_input_size=3072, query_input_size=768, inheri
 opt_ = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
                              collection="tvr", alpha=0.8, belta=0.8)
 m = DLDKD(cfg, opt_).to(DEV).eval()
-m.fast_input_proj = len(sys.argv) > 1 and sys.argv[1] == "fast"
+m.fast_input_proj = len(sys.argv) > 1 and sys.argv[1] in ("fast", "allbf16")
+if len(sys.argv) > 1 and sys.argv[1] == "allbf16":
+    from dldkd_amd import ops
+    ops.set_gemm_precision("bf16")
 feats = torch.nn.functional.normalize(torch.randn(200, 128, 3072, device=DEV), dim=-1)
 mask = torch.ones(200, 128, device=DEV)
 with torch.no_grad():
