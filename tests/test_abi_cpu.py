@@ -58,3 +58,11 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "dldkd_oracle" not in src and "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S), f
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: the header must compile as C99 (no C++-only constructs outside extern "C" guards)."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "dldkd_hip.h")
+    r = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
