@@ -78,9 +78,67 @@ def cpu_baseline(gs, mask, qs, fused_gpu, nq_s=200, nv_s=4359):
     ref = orc.fuse_scores(oi, oe)
     dt = time.perf_counter() - t0
     err = (fused_gpu[:nq_s, :nv_s].cpu() - ref).abs().max().item()
-    return dict(value=nq_s * nv_s / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{nq_s} queries x {nv_s} videos (first 1/5 of the C2 gallery), both branches + fusion, "
-                       f"fp32, 50-query chunks like eval.py:188-208; {dt:.1f} s"), err
+    out = dict(value=nq_s * nv_s / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+               sample=f"{nq_s} queries x {nv_s} videos (first 1/5 of the C2 gallery), both branches + fusion, "
+                      f"fp32, 50-query chunks like eval.py:188-208; {dt:.1f} s")
+    try:
+        out["c1"] = c1_cpu_vs_gpu(orc, fused_gpu.device)
+    except Exception as e:   # noqa: BLE001
+        out["c1"] = repr(e)
+    return out, err
+
+
+def c1_cpu_vs_gpu(orc, dev):
+    """BASELINE configs[0]: 64 queries x 64 videos x 16 clips of raw i3d/CLIP-dim features through the WHOLE eval
+    path (both towers + scoring + fusion), oracle on the host cores vs the HIP path, same weights and inputs."""
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import synth
+    from dldkd_amd.model import DLDKD
+    params = synth.make_params(41, 3072, 768)
+    b = synth.make_train_batch(1, nv=64, caps=1, L=16, dv=3072, dq=768)
+    v, vm, t, tm = b["student_videos"], b["student_videos_mask"], b["student_text"], b["student_text_mask"]
+
+    def cpu():
+        gi, ge = orc.encode_context(params, v, vm)
+        qi, qe = orc.encode_query(params, t, tm)
+        oi, oe = orc.eval_scores(qi, qe, gi, ge, vm)
+        return orc.fuse_scores(oi, oe)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(nthr, 8))      # 64-row tensors: more threads only add fork/join time (256 threads: 31 s)
+    try:
+        cpu()
+        t0 = time.perf_counter()
+        ref = cpu()
+        cpu_s = time.perf_counter() - t0
+        c1_threads = torch.get_num_threads()
+    finally:
+        torch.set_num_threads(nthr)
+    cfg = types.SimpleNamespace(visual_input_size=3072, query_input_size=768, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=128, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4, initializer_range=0.02,
+                                margin=0.1, use_hard_negative=False, hard_pool_size=20, label_style="soft")
+    opt_ = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                 collection="tvr", alpha=0.8, belta=0.8)
+    m = DLDKD(cfg, opt_)
+    m.load_state_dict(params, strict=True)
+    m = m.to(dev).eval()
+    dv, dvm, dt_, dtm = v.to(dev), vm.to(dev), t.to(dev), tm.to(dev)
+
+    def gpu():
+        with torch.no_grad():
+            gi, ge = m.encode_context(dv, dvm)
+            qi, qe = m.encode_query(dt_, dtm)
+            return m.pooled_scores([qi, qe], [gi, ge], dvm, want_branches=False)[0]
+    gpu()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        fused = gpu()
+    torch.cuda.synchronize()
+    gpu_s = (time.perf_counter() - t0) / 10
+    return {"config": "C1 (configs[0]): 64 q x 64 v x 16 clips, raw 3072/768-d features -> towers -> scores -> fusion",
+            "cpu_oracle_s": cpu_s, "cpu_threads": c1_threads, "hip_s": gpu_s, "pairs_per_s_cpu": 4096 / cpu_s, "pairs_per_s_hip": 4096 / gpu_s,
+            "max_abs_err": (fused.cpu() - ref).abs().max().item()}
 
 
 def extras(dev):
@@ -172,7 +230,57 @@ def extras(dev):
             out["gallery_encode_videos_per_s_all_bf16"] = B / ((time.perf_counter() - t0) / 5)
         finally:
             ops.set_gemm_precision("fp32")
-        del m, opt, batch
+        # C5 (configs[4], one rank of the DDP job): Charades, 1024-d features, captions [3,2,2,...], dropout 0.15
+        cfg5 = types.SimpleNamespace(**{**vars(cfg), "visual_input_size": 1024, "query_input_size": 1024, "input_drop": 0.15,
+                                        "drop": 0.15})
+        torch.manual_seed(5)
+        m5 = DLDKD(cfg5, opt_).to(dev).train()
+        opt5 = BertAdam([{"params": list(m5.parameters()), "weight_decay": 0.01}], lr=2.4e-4, warmup=0.01, t_total=1000)
+        caps5 = sorted([3] + [2] * 127, reverse=True)
+        b5 = synth.make_train_batch(5, nv=128, caps=caps5, L=64, len_lo=8, dv=1024, dq=1024)
+        b5 = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b5.items()}
+
+        def step5():
+            opt5.zero_grad()
+            loss, _ = m5(b5)
+            loss.backward()
+            opt5.step()
+        for prec in ("fp32", "bf16"):
+            ops.set_gemm_precision(prec)
+            try:
+                for _ in range(3):
+                    step5()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    step5()
+                torch.cuda.synchronize()
+                out["c5_train_step_ms_" + prec] = (time.perf_counter() - t0) / 10 * 1e3
+            finally:
+                ops.set_gemm_precision("fp32")
+        out["c5_train_step_config"] = "Charades rank-local step: 128 videos / 257 queries, L<=64, Dv=Dq=1024, dropout 0.15 " \
+                                      "(the gradient all-reduce of the 17.5 MB flat bucket is not part of a 1-GPU run)"
+        del m, opt, batch, m5, opt5, b5
+        torch.cuda.empty_cache()
+        # C4 (configs[3]) on ONE GPU: ActivityNet gallery 4917 videos x 128 clips (all valid) x 17505 queries
+        from dldkd_amd import scoring
+        g4 = torch.Generator(device=dev).manual_seed(4)
+        gal4 = [torch.randn(4917, 128, 384, generator=g4, device=dev) for _ in range(2)]
+        q4 = [torch.randn(17505, 384, generator=g4, device=dev) for _ in range(2)]
+        pg4 = scoring.pack_gallery(gal4, None)
+        del gal4
+        for _ in range(2):
+            scoring.simpool_eval(scoring.pack_queries(q4), pg4, want_branches=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            scoring.simpool_eval(scoring.pack_queries(q4), pg4, want_branches=False)
+        torch.cuda.synchronize()
+        dt4 = (time.perf_counter() - t0) / 10
+        out["c4_activitynet_1gpu"] = {"ms_per_step": dt4 * 1e3, "pairs_per_s": 17505 * 4917 / dt4,
+                                      "algorithmic_TFLOPs": 2.0 * 384 * 2 * 17505 * 4917 * 128 / dt4 / 1e12,
+                                      "config": "4917 videos x 128 clips (all valid) x 17505 queries, 2 branches + fusion, 1 GPU"}
+        del pg4, q4
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from bench_eval_e2e import stage_times
