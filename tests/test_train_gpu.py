@@ -263,3 +263,30 @@ def test_fused_dropout_mask_scale_and_rng(n, p):
     assert torch.equal(a.grad != 0, kept)
     assert torch.allclose(a.grad[kept], torch.full_like(a.grad[kept], 1 / (1 - p)))
     assert F_.dropout(x, p, False) is x and F_.dropout(x, 0.0, True) is x
+
+
+def test_forward_at_c3_size_vs_oracle():
+    """BASELINE configs[2] size (128 videos x 5 captions = 640 queries, <=128 clips, 3072/768-d features, soft
+    labels, hard negatives): the 7 losses of DLDKD.forward against the fp32 oracle on the same tensors and the same
+    CPU random draws, 1e-4 relative (north_star).  Dropout off (model.eval()), like golden G4."""
+    m = _model(3072, 768, synth.make_params(43, 3072, 768))
+    m.label_style = "soft"
+    m.set_hard_negative(True, 20)
+    m.weight = 0.1 * 0.95 ** 0 / 0.1                      # train.py:76-80 at epoch 0
+    batch = synth.make_train_batch(3, nv=128, caps=5, L=128, len_lo=24, dv=3072, dq=768)
+    labels = batch["text_labels"]
+    torch.manual_seed(99)
+    rnd = [orc.draw_triplet_randoms(labels, 128, True, 20) for _ in range(2)]
+    p = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    cfg = dict(n_heads=4, margin=0.1, use_hard_negative=True, label_style="soft", kl_intra_weight=0.1, weight=m.weight,
+               inher_nce_weight=0.04, explore_nce_weight=0.04, alpha=0.8, belta=0.8)
+    with torch.no_grad():
+        ref = orc.forward_losses(p, batch, cfg, rnd)
+    dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    torch.manual_seed(99)
+    loss, d = m(dbatch)
+    for k in ("inher_trip", "inher_nce", "explore_trip", "explore_nce", "kl_intra"):
+        _close(d[k], ref[k])
+    _close(loss, ref["loss"])
+    loss.backward()
+    assert all(prm.grad is not None and torch.isfinite(prm.grad).all() for prm in m.parameters())
