@@ -8,7 +8,15 @@
 
 namespace dldkd {
 
-constexpr int HBM_ = 128, HBN_ = 128, HBK_ = 32;
+#ifndef DLDKD_GEMM_BF16_BK
+#define DLDKD_GEMM_BF16_BK 64
+#endif
+constexpr int HBM_ = 128, HBN_ = 128, HBK_ = DLDKD_GEMM_BF16_BK;
+constexpr int KV_ = HBK_ / 4;            // float4 per tile row
+constexpr int RPP_ = 256 / KV_;          // rows per pass of the k-minor loader
+constexpr int NPASS_ = HBM_ / RPP_;      // passes
+constexpr int NREG_ = NPASS_ * 4;        // staging floats per thread per operand (= HBM_ * HBK_ / 256)
+constexpr int KPT_ = HBK_ / 2;           // k per thread of the k-major loader (one row, KPT_ consecutive k)
 constexpr int HPITCH = HBK_ + 8;
 
 struct GemmHArgs {
@@ -31,12 +39,12 @@ struct GemmHArgs {
 template <bool KMAJOR>
 struct TileH {
     static __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int K,
-                                                int tid, bool vec, float (&r)[16]) {
+                                                int tid, bool vec, float (&r)[NREG_]) {
         if constexpr (!KMAJOR) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = row0 + (tid >> 3) + 32 * j;
-                const int k = k0 + (tid & 7) * 4;
+            for (int j = 0; j < NPASS_; ++j) {
+                const int row = row0 + tid / KV_ + RPP_ * j;
+                const int k = k0 + (tid % KV_) * 4;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (row < nrows) {
                     const float* src = P + (size_t)row * ld + k;
@@ -51,46 +59,46 @@ struct TileH {
             }
         } else {
             const int row = row0 + (tid & 127);
-            const int kb = k0 + (tid >> 7) * 16;
+            const int kb = k0 + (tid >> 7) * KPT_;
             const float* src = P + (size_t)kb * ld + row;
             const bool rok = row < nrows;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) r[i] = (rok && kb + i < K) ? src[(size_t)i * ld] : 0.f;
+            for (int i = 0; i < KPT_; ++i) r[i] = (rok && kb + i < K) ? src[(size_t)i * ld] : 0.f;
         }
     }
-    // Interior tile (all 32 k in range, 16-byte aligned rows): branch-free.  Rows past the end are CLAMPED to the
+    // Interior tile (all k in range, 16-byte aligned rows): branch-free.  Rows past the end are CLAMPED to the
     // last row instead of zeroed - they only feed accumulator rows/columns that are never stored.
     static __device__ __forceinline__ void load_fast(const float* __restrict__ P, int ld, int row0, int nrows, int k0,
-                                                     int tid, float (&r)[16]) {
+                                                     int tid, float (&r)[NREG_]) {
         if constexpr (!KMAJOR) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = min(row0 + (tid >> 3) + 32 * j, nrows - 1);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(P + (size_t)row * ld + k0 + (tid & 7) * 4);
+            for (int j = 0; j < NPASS_; ++j) {
+                const int row = min(row0 + tid / KV_ + RPP_ * j, nrows - 1);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(P + (size_t)row * ld + k0 + (tid % KV_) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) r[4 * j + e] = v[e];
             }
         } else {
             const int row = min(row0 + (tid & 127), nrows - 1);
-            const float* src = P + (size_t)(k0 + (tid >> 7) * 16) * ld + row;
+            const float* src = P + (size_t)(k0 + (tid >> 7) * KPT_) * ld + row;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) r[i] = src[(size_t)i * ld];
+            for (int i = 0; i < KPT_; ++i) r[i] = src[(size_t)i * ld];
         }
     }
-    static __device__ __forceinline__ void store(unsigned short* __restrict__ S, int tid, const float (&r)[16]) {
+    static __device__ __forceinline__ void store(unsigned short* __restrict__ S, int tid, const float (&r)[NREG_]) {
         if constexpr (!KMAJOR) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                unsigned short* dst = S + ((tid >> 3) + 32 * j) * HPITCH + (tid & 7) * 4;
+            for (int j = 0; j < NPASS_; ++j) {
+                unsigned short* dst = S + (tid / KV_ + RPP_ * j) * HPITCH + (tid % KV_) * 4;
                 uint2 pk;
                 pk.x = (unsigned)f32_to_bf16_bits(r[4 * j]) | ((unsigned)f32_to_bf16_bits(r[4 * j + 1]) << 16);
                 pk.y = (unsigned)f32_to_bf16_bits(r[4 * j + 2]) | ((unsigned)f32_to_bf16_bits(r[4 * j + 3]) << 16);
                 *reinterpret_cast<uint2*>(dst) = pk;
             }
         } else {
-            unsigned short* dst = S + (tid & 127) * HPITCH + (tid >> 7) * 16;
+            unsigned short* dst = S + (tid & 127) * HPITCH + (tid >> 7) * KPT_;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < KPT_ / 8; ++h) {
                 uint4 pk;
                 pk.x = (unsigned)f32_to_bf16_bits(r[8 * h + 0]) | ((unsigned)f32_to_bf16_bits(r[8 * h + 1]) << 16);
                 pk.y = (unsigned)f32_to_bf16_bits(r[8 * h + 2]) | ((unsigned)f32_to_bf16_bits(r[8 * h + 3]) << 16);
@@ -104,7 +112,8 @@ struct TileH {
 
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmHArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][HBM_ * HPITCH];
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds_raw[];
+    unsigned short (*lds)[2][HBM_ * HPITCH] = reinterpret_cast<unsigned short (*)[2][HBM_ * HPITCH]>(lds_raw);
     if (p.split_k <= 1) {
         const int zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
         p.A += zo * p.sAo + zi * p.sAi;
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmHArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float ra[16], rb[16];
+    float ra[NREG_], rb[NREG_];
     // k-minor operands need 16-byte aligned rows for the fast path; k-major ones use dword loads (always fine)
     const bool fa = A_KMAJOR || p.a_vec, fb = B_KMAJOR || p.b_vec;
     auto load_tiles = [&](int k0) {
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmHArgs p) {
         const unsigned short* As = lds[cur][0];
         const unsigned short* Bs = lds[cur][1];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < HBK_ / 16; ++kk) {
             bf16x8 a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -191,10 +200,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmHArgs p) {
 static int launch_gemm_h(GemmHArgs p, int batch, int a_kmajor, int b_kmajor, void* stream) {
     const dim3 grid((p.N + HBN_ - 1) / HBN_, (p.M + HBM_ - 1) / HBM_, batch), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, p);
-    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, p);
-    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, p);
+    constexpr size_t lds = sizeof(unsigned short) * 2 * 2 * HBM_ * HPITCH;
+    static const bool attr_ok = [] {
+        bool ok = true;
+        ok &= hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        return ok;
+    }();
+    (void)attr_ok;
+    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, lds, s, p);
+    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, lds, s, p);
+    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, lds, s, p);
     return check_launch("gemm_bf16");
 }
 

@@ -51,11 +51,12 @@ struct InProjArgs {
     const bf16x8* Wf;      // [N][K] bf16
     const float* cs;
     const float* bb;
-    float* y[2];           // per-branch outputs (M, 384)
+    float* y[2];           // outputs: columns [0,384) -> y[0], [384,768) -> y[1]
     long M;
     int N, K;
     float eps;
     int relu;
+    int ldy;               // row stride of y[*] in floats (full-row kernels; the tiled kernel writes 384-wide rows)
 };
 
 // BN = 256 (two branches, N = 768: three column tiles per row block) or 128 (one branch, N = 384).
@@ -197,7 +198,7 @@ constexpr int FW_TILE_BYTES = FN * FBK * 2;     // 48 KiB of W' per k-tile
 
 __global__ __launch_bounds__(256) void fold_ln_linear_frag_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                  int N, int K, int n_offset, unsigned short* __restrict__ Wfrag,
+                                                                  int N, int K, int n_offset, int fn, unsigned short* __restrict__ Wfrag,
                                                                   float* __restrict__ cs, float* __restrict__ bb) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -206,25 +207,35 @@ __global__ __launch_bounds__(256) void fold_ln_linear_frag_kernel(const float* _
     float s = 0.f, t = 0.f;
     for (int k = lane; k < K; k += 64) {
         const float w = W[(size_t)n * K + k];
-        const unsigned short h = f32_to_bf16_bits(w * gamma[k]);
+        const unsigned short h = f32_to_bf16_bits(gamma ? w * gamma[k] : w);
         const int kt = k >> 5, kk = (k >> 4) & 1, half = (k >> 3) & 1, j = k & 7;
-        Wfrag[((((size_t)kt * (FN / 32) + ct) * 2 + kk) * 64 + half * 32 + col) * 8 + j] = h;
+        Wfrag[((((size_t)kt * (fn / 32) + ct) * 2 + kk) * 64 + half * 32 + col) * 8 + j] = h;
         s += bf16_bits_to_f32(h);
-        t += w * beta[k];
+        if (beta) t += w * beta[k];
     }
     s = wave_sum(s);
     t = wave_sum(t);
-    if (lane == 0) { cs[ng] = s; bb[ng] = t + (bias ? bias[n] : 0.f); }
+    if (lane == 0) { if (cs) cs[ng] = s; bb[ng] = t + (bias ? bias[n] : 0.f); }
 }
 
-__global__ __launch_bounds__(512, 2) void in_proj_bf16_full_kernel(const InProjArgs p) {
+// WR = 1: wave w owns rows 0..127 x columns [96w, 96w + 96) of N = 768 (the two-branch input projection).
+// WR = 2: waves are 2 row groups x 4 column groups of N = 384 (64 rows x 96 columns each): the 384-wide linears of the
+//         towers.  LNFOLD = false: plain y = x W^T + b (no LayerNorm statistics), bb = bias.
+template <int WR, bool LNFOLD>
+__global__ __launch_bounds__(512, 2) void rows_linear_bf16_kernel(const InProjArgs p) {
+    constexpr int WCN = 8 / WR;                      // column groups
+    constexpr int FN_ = 96 * WCN;                    // 768 or 384
+    constexpr int W_TILE = FN_ * FBK * 2;            // bytes of W' per k-tile
+    constexpr int PIECES = W_TILE / 1024 / 8;        // 1-KiB LDS-DMA pieces per wave
+    constexpr int RT = 4 / WR;                       // 32-row tiles per wave
     extern __shared__ __attribute__((aligned(16))) char lds_full[];
-    char* Wl = lds_full;                                            // [2][48 KiB]
-    unsigned short* Al = reinterpret_cast<unsigned short*>(lds_full + 2 * FW_TILE_BYTES);   // [2][128 * FPITCH]
-    float* s_mean = reinterpret_cast<float*>(lds_full + 2 * FW_TILE_BYTES + 2 * FBM * FPITCH * 2);
+    char* Wl = lds_full;                                            // [2][W_TILE]
+    unsigned short* Al = reinterpret_cast<unsigned short*>(lds_full + 2 * W_TILE);   // [2][128 * FPITCH]
+    float* s_mean = reinterpret_cast<float*>(lds_full + 2 * W_TILE + 2 * FBM * FPITCH * 2);
     float* s_rstd = s_mean + FBM;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WCN, wc = wave % WCN;
     const long m0 = (long)blockIdx.x * FBM;
     const int nk = p.K / FBK;
     const int xrow = tid >> 2, xq = tid & 3;                        // x: row xrow, floats [8*xq, 8*xq + 8) of the k-tile
@@ -232,9 +243,9 @@ __global__ __launch_bounds__(512, 2) void in_proj_bf16_full_kernel(const InProjA
     const float* xsrc = p.x + (size_t)(m0 + (row_ok ? xrow : 0)) * p.K + xq * 8;
     const char* wsrc = reinterpret_cast<const char*>(p.Wf);
 
-    f32x16 acc[4][3];
+    f32x16 acc[RT][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -242,12 +253,12 @@ __global__ __launch_bounds__(512, 2) void in_proj_bf16_full_kernel(const InProjA
 
     f32x4 rx[2];
     float sum = 0.f, sq = 0.f;
-    auto wstage = [&](int kt, int buf) {                            // 48 pieces, 6 per wave
-        const char* src = wsrc + (size_t)kt * FW_TILE_BYTES;
-        char* dst = Wl + buf * FW_TILE_BYTES;
+    auto wstage = [&](int kt, int buf) {                            // W_TILE / 1 KiB pieces, PIECES per wave
+        const char* src = wsrc + (size_t)kt * W_TILE;
+        char* dst = Wl + buf * W_TILE;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int piece = wave * 6 + i;
+        for (int i = 0; i < PIECES; ++i) {
+            const int piece = wave * PIECES + i;
             glds16(src + piece * 1024 + lane * 16, dst + piece * 1024);
         }
     };
@@ -261,8 +272,10 @@ __global__ __launch_bounds__(512, 2) void in_proj_bf16_full_kernel(const InProjA
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float v = rx[e >> 2][e & 3];
-            sum += v;
-            sq += v * v;
+            if constexpr (LNFOLD) {
+                sum += v;
+                sq += v * v;
+            }
             h[e] = (short)f32_to_bf16_bits(v);
         }
         *reinterpret_cast<bf16x8*>(Al + buf * FBM * FPITCH + xrow * FPITCH + xq * 8) = h;
@@ -275,16 +288,16 @@ __global__ __launch_bounds__(512, 2) void in_proj_bf16_full_kernel(const InProjA
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) { wstage(kt + 1, cur ^ 1); xload(kt + 1); }
-        const unsigned short* A = Al + cur * FBM * FPITCH;
-        const char* B = Wl + cur * FW_TILE_BYTES + lane * 16;
+        const unsigned short* A = Al + cur * FBM * FPITCH + wr * (FBM / WR) * FPITCH;
+        const char* B = Wl + cur * W_TILE + lane * 16;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 b[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                b[j] = *reinterpret_cast<const bf16x8*>(B + ((wave * 3 + j) * 2 + kk) * 1024);
+                b[j] = *reinterpret_cast<const bf16x8*>(B + ((wc * 3 + j) * 2 + kk) * 1024);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {   // one A fragment live at a time: 192 accumulators leave little room
+            for (int i = 0; i < RT; ++i) {   // one A fragment live at a time: 192 accumulators leave little room
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (32 * i + (lane & 31)) * FPITCH + kk * 16 + (lane >> 5) * 8);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[i][j], 0, 0, 0);
@@ -294,32 +307,36 @@ __global__ __launch_bounds__(512, 2) void in_proj_bf16_full_kernel(const InProjA
         __syncthreads();
     }
 
-    sum += __shfl_xor(sum, 1);
-    sq += __shfl_xor(sq, 1);
-    sum += __shfl_xor(sum, 2);
-    sq += __shfl_xor(sq, 2);
-    if (xq == 0) {
-        const float mean = sum / p.K;
-        const float var = fmaxf(sq / p.K - mean * mean, 0.f);
-        s_mean[xrow] = mean;
-        s_rstd[xrow] = rsqrtf(var + p.eps);
+    if constexpr (LNFOLD) {
+        sum += __shfl_xor(sum, 1);
+        sq += __shfl_xor(sq, 1);
+        sum += __shfl_xor(sum, 2);
+        sq += __shfl_xor(sq, 2);
+        if (xq == 0) {
+            const float mean = sum / p.K;
+            const float var = fmaxf(sq / p.K - mean * mean, 0.f);
+            s_mean[xrow] = mean;
+            s_rstd[xrow] = rsqrtf(var + p.eps);
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int n = wave * 96 + 32 * j + (lane & 31);
+        const int n = wc * 96 + 32 * j + (lane & 31);
         float* out = p.y[n / kHidden] + (n % kHidden);
-        const float csn = p.cs[n], bbn = p.bb[n];
+        const float csn = LNFOLD ? p.cs[n] : 0.f, bbn = p.bb[n];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ml = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int ml = wr * (FBM / WR) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m0 + ml < p.M) {
-                    float v = s_rstd[ml] * (acc[i][j][r] - s_mean[ml] * csn) + bbn;
+                    float v;
+                    if constexpr (LNFOLD) v = s_rstd[ml] * (acc[i][j][r] - s_mean[ml] * csn) + bbn;
+                    else v = acc[i][j][r] + bbn;
                     if (p.relu) v = fmaxf(v, 0.f);
-                    out[(size_t)(m0 + ml) * kHidden] = v;
+                    out[(size_t)(m0 + ml) * p.ldy] = v;
                 }
             }
     }
@@ -348,7 +365,7 @@ int dldkd_in_proj_bf16(const float* x, const void* Wf, const float* cs, const fl
     }
     if (M == 0) return DLDKD_OK;
     if (!x || !Wf || !cs || !bb || !y0 || (N == 2 * kHidden && !y1)) { set_error("in_proj_bf16: null pointer"); return DLDKD_EINVAL; }
-    InProjArgs p{x, (const bf16x8*)Wf, cs, bb, {y0, y1}, M, N, K, eps, relu};
+    InProjArgs p{x, (const bf16x8*)Wf, cs, bb, {y0, y1}, M, N, K, eps, relu, kHidden};
     const unsigned rows = (unsigned)((M + PBM - 1) / PBM);
     // 128-column tiles (6 for two branches).  Measured at M = 400k, K = 3072: BN 128 / BK 32 = 4.9 ms (1252 GB/s,
     // 384 TFLOP/s); BN 256 / BK 64 = 5.6 ms (one workgroup per CU at 255 VGPRs).
@@ -366,8 +383,49 @@ int dldkd_fold_ln_linear_bf16_frag(const float* W, const float* bias, const floa
     }
     if (!W || !gamma || !beta || !Wfrag || !cs || !bb) { set_error("fold_ln_linear_frag: null pointer"); return DLDKD_EINVAL; }
     hipLaunchKernelGGL(fold_ln_linear_frag_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, bias, gamma, beta, N,
-                       K, n_offset, (unsigned short*)Wfrag, cs, bb);
+                       K, n_offset, FN, (unsigned short*)Wfrag, cs, bb);
     return check_launch("fold_ln_linear_frag");
+}
+
+int dldkd_pack_linear_bf16_frag(const float* W, const float* bias, int N, int K, int n_offset, int n_total, void* Wfrag, float* bb,
+                                void* stream) {
+    if (N < 1 || K < FBK || (K % FBK) || (n_total != 384 && n_total != 768) || n_offset < 0 || n_offset + N > n_total ||
+        (n_offset % 32)) {
+        set_error("pack_linear_frag: need K a multiple of %d, n_total 384 or 768 and columns inside it (N=%d K=%d off=%d)", FBK, N, K,
+                  n_offset);
+        return DLDKD_EINVAL;
+    }
+    if (!W || !Wfrag || !bb) { set_error("pack_linear_frag: null pointer"); return DLDKD_EINVAL; }
+    hipLaunchKernelGGL(fold_ln_linear_frag_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, bias,
+                       (const float*)nullptr, (const float*)nullptr, N, K, n_offset, n_total, (unsigned short*)Wfrag,
+                       (float*)nullptr, bb);
+    return check_launch("pack_linear_frag");
+}
+
+int dldkd_linear_rows_bf16(const float* x, const void* Wfrag, const float* bb, float* y0, float* y1, int ldy, long M, int N, int K,
+                           int relu, void* stream) {
+    if (M < 0 || (N != 384 && N != 768) || K < FBK || (K % FBK) || ldy < 384) {
+        set_error("linear_rows_bf16: need N = 384 or 768, K a multiple of %d, ldy >= 384 (M=%ld N=%d K=%d ldy=%d)", FBK, M, N, K, ldy);
+        return DLDKD_EINVAL;
+    }
+    if (M == 0) return DLDKD_OK;
+    if (!x || !Wfrag || !bb || !y0 || (N == 768 && !y1)) { set_error("linear_rows_bf16: null pointer"); return DLDKD_EINVAL; }
+    InProjArgs p{x, (const bf16x8*)Wfrag, nullptr, bb, {y0, y1}, M, N, K, 0.f, relu, ldy};
+    const dim3 grid((unsigned)((M + FBM - 1) / FBM));
+    if (N == 768) {
+        constexpr int lds = 2 * FW_TILE_BYTES + 2 * FBM * FPITCH * 2 + 2 * FBM * 4;
+        static const bool ok = [] { return hipFuncSetAttribute((const void*)rows_linear_bf16_kernel<1, false>,
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess; }();
+        (void)ok;
+        hipLaunchKernelGGL((rows_linear_bf16_kernel<1, false>), grid, dim3(512), lds, (hipStream_t)stream, p);
+    } else {
+        constexpr int lds = FW_TILE_BYTES + 2 * FBM * FPITCH * 2 + 2 * FBM * 4;
+        static const bool ok = [] { return hipFuncSetAttribute((const void*)rows_linear_bf16_kernel<2, false>,
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess; }();
+        (void)ok;
+        hipLaunchKernelGGL((rows_linear_bf16_kernel<2, false>), grid, dim3(512), lds, (hipStream_t)stream, p);
+    }
+    return check_launch("linear_rows_bf16");
 }
 
 int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1, long M,
@@ -375,12 +433,12 @@ int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, 
     if (M < 0 || K < FBK || (K % FBK)) { set_error("in_proj_bf16_full: K must be a multiple of %d", FBK); return DLDKD_EINVAL; }
     if (M == 0) return DLDKD_OK;
     if (!x || !Wfrag || !cs || !bb || !y0 || !y1) { set_error("in_proj_bf16_full: null pointer"); return DLDKD_EINVAL; }
-    InProjArgs p{x, (const bf16x8*)Wfrag, cs, bb, {y0, y1}, M, FN, K, eps, relu};
+    InProjArgs p{x, (const bf16x8*)Wfrag, cs, bb, {y0, y1}, M, FN, K, eps, relu, kHidden};
     constexpr int lds = 2 * FW_TILE_BYTES + 2 * FBM * FPITCH * 2 + 2 * FBM * 4;
-    static const bool ok = [] { return hipFuncSetAttribute((const void*)in_proj_bf16_full_kernel,
+    static const bool ok = [] { return hipFuncSetAttribute((const void*)rows_linear_bf16_kernel<1, true>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess; }();
     (void)ok;
-    hipLaunchKernelGGL(in_proj_bf16_full_kernel, dim3((unsigned)((M + FBM - 1) / FBM)), dim3(512), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((rows_linear_bf16_kernel<1, true>), dim3((unsigned)((M + FBM - 1) / FBM)), dim3(512), lds, (hipStream_t)stream, p);
     return check_launch("in_proj_bf16_full");
 }
 

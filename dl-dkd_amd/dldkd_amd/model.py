@@ -125,7 +125,12 @@ class DLDKD(nn.Module):
                 h = self.encode_input(frame_video_feat, video_mask, getattr(self, pre + "visual_input_proj"),
                                       getattr(self, pre + "visual_encoder"), getattr(self, pre + "visual_pos_embed"))
             lin = getattr(self, pre + "out_mapping_linear")
-            out.append(F_.linear(h, lin.weight, lin.bias))
+            if ops.rows_kernel_ok(h):
+                if pre + "out_map" not in self._folded:
+                    self._folded[pre + "out_map"] = ops.PackedLinear([lin])
+                out.append(ops.linear_rows(h, self._folded[pre + "out_map"]))
+            else:
+                out.append(F_.linear(h, lin.weight, lin.bias))
         return (out[0], out[1]) if self.double_branch else (out[0], None)
 
     def get_modularized_queries(self, encoded_query, query_mask, inheritance=False):

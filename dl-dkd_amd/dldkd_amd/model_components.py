@@ -75,8 +75,13 @@ class BertSelfAttention(nn.Module):
     def forward(self, query_states, key_states, value_states, attention_mask=None):
         if not (query_states is key_states and key_states is value_states):
             raise NotImplementedError("only self-attention is on the DL-DKD path (BertAttention.forward, :351)")
-        w, b = self.fused_qkv()
-        qkv = F_.linear(query_states, w, b)                       # one GEMM for the three projections
+        if ops.rows_kernel_ok(query_states):                      # inference, throughput mode: full-row bf16 kernel
+            if getattr(self, "_packed_qkv", None) is None:
+                self._packed_qkv = ops.PackedLinear([self.query, self.key, self.value])
+            qkv = ops.linear_rows(query_states.float(), self._packed_qkv)
+        else:
+            w, b = self.fused_qkv()
+            qkv = F_.linear(query_states, w, b)                   # one GEMM for the three projections
         mask = None
         if attention_mask is not None:                            # (N, 1, L) as encode_input passes it (model.py:242)
             mask = attention_mask.reshape(attention_mask.shape[0], -1).contiguous()
@@ -93,7 +98,12 @@ class BertSelfOutput(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, hidden_states, input_tensor):
-        h = F_.linear(hidden_states, self.dense.weight, self.dense.bias)
+        if ops.rows_kernel_ok(hidden_states):
+            if getattr(self, "_packed_dense", None) is None:
+                self._packed_dense = ops.PackedLinear([self.dense])
+            h = ops.linear_rows(hidden_states.float(), self._packed_dense)
+        else:
+            h = F_.linear(hidden_states, self.dense.weight, self.dense.bias)
         h = F_.dropout(h, self.dropout.p, self.training)
         return F_.layernorm(h, self.LayerNorm.weight, self.LayerNorm.bias, add=input_tensor, add_mod=0)
 

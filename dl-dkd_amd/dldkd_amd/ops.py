@@ -138,6 +138,66 @@ class FoldedInProj:
         return self
 
 
+class PackedLinear:
+    """bf16 MFMA-fragment-order copy of 1-3 nn.Linear modules with the same in_features and 384 outputs each (one
+    q|k|v block, or a single dense layer) for `linear_rows`; rebuilt when a parameter changes (tensor._version)."""
+
+    def __init__(self, linears):
+        self.linears = list(linears)
+        if not 1 <= len(self.linears) <= 3 or any(l.weight.shape[0] != HIDDEN for l in self.linears):
+            raise native.NativeError("PackedLinear: 1-3 linears with 384 outputs each")
+        self.key = None
+
+    def get(self):
+        ps = [t for l in self.linears for t in (l.weight, l.bias)]
+        key = tuple((t.data_ptr(), t._version) for t in ps)
+        if key != self.key:
+            L = native.lib()
+            K = self.linears[0].weight.shape[1]
+            dev = ps[0].device
+            # launches: the first two linears share one N = 768 pass, a third gets its own N = 384 pass
+            groups = [self.linears[:2]] + ([self.linears[2:]] if len(self.linears) == 3 else [])
+            self.groups = []
+            for g in groups:
+                n_total = HIDDEN * len(g)
+                wf = torch.empty(n_total * K * 2, dtype=torch.uint8, device=dev)
+                bb = torch.empty(n_total, dtype=torch.float32, device=dev)
+                for i, l in enumerate(g):
+                    native.check(L.dldkd_pack_linear_bf16_frag(native.ptr(l.weight.detach().contiguous()), native.ptr(l.bias.detach()),
+                                                               HIDDEN, K, i * HIDDEN, n_total, native.ptr(wf), native.ptr(bb),
+                                                               native.stream()), "pack_linear_frag")
+                self.groups.append((wf, bb, n_total))
+            self.key, self.K = key, K
+        return self
+
+
+def rows_kernel_ok(x):
+    """The full-row bf16 kernel serves inference in throughput mode: no autograd, in_features a multiple of 32."""
+    return _PRECISION == "bf16" and not torch.is_grad_enabled() and x.shape[-1] % 32 == 0
+
+
+def linear_rows(x, packed, relu=False):
+    """x (..., K) fp32 -> (..., 384 * n_linears) fp32: y = act(x W^T + b) for the packed linears side by side."""
+    import ctypes
+    L = native.lib()
+    f = packed.get()
+    K = x.shape[-1]
+    if K != f.K:
+        raise native.NativeError(f"linear_rows: x has {K} features, weights expect {f.K}")
+    x2 = _chk(x.reshape(-1, K), "linear_rows.x")
+    M = x2.shape[0]
+    n_out = HIDDEN * len(f.linears)
+    y = torch.empty(M, n_out, dtype=torch.float32, device=x.device)
+    col = 0
+    for wf, bb, n_total in f.groups:
+        y0 = ctypes.c_void_p(y.data_ptr() + 4 * col)
+        y1 = ctypes.c_void_p(y.data_ptr() + 4 * (col + HIDDEN)) if n_total == 2 * HIDDEN else None
+        native.check(L.dldkd_linear_rows_bf16(native.ptr(x2), native.ptr(wf), native.ptr(bb), y0, y1, n_out, M, n_total, K, int(relu),
+                                              native.stream()), "linear_rows_bf16")
+        col += n_total
+    return y.view(*x.shape[:-1], n_out)
+
+
 def in_proj_bf16(x, folded, relu=True):
     """x (..., K) fp32 -> list of per-branch (..., 384) fp32 outputs, one pass over x (K4)."""
     L = native.lib()

