@@ -74,8 +74,8 @@ def attention(qkv, mask):
     _chk(qkv, "attention.qkv"); _chk(mask, "attention.mask")
     N, Lq = qkv.shape[0], qkv.shape[1]
     out = torch.empty(N, Lq, HIDDEN, dtype=torch.float32, device=qkv.device)
-    native.check(L.dldkd_attention_fwd_f32(native.ptr(qkv), native.ptr(mask), native.ptr(out), N, Lq, native.stream()),
-                 "attention_fwd")
+    fn = L.dldkd_attention_fwd_bf16 if _PRECISION == "bf16" else L.dldkd_attention_fwd_f32
+    native.check(fn(native.ptr(qkv), native.ptr(mask), native.ptr(out), N, Lq, native.stream()), "attention_fwd")
     return out
 
 

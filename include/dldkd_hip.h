@@ -119,6 +119,9 @@ int dldkd_layernorm_f32(const float* x, const float* add, int add_mod, const flo
  * qkv (N, L, 1152) = [query | key | value] projections, mask (N, L) 0/1 or NULL, out (N, L, 384) context
  * layer.  softmax(QK^T / sqrt(96) + (1 - mask) * -10000) V; the L x L probabilities never leave the CU. */
 int dldkd_attention_fwd_f32(const float* qkv, const float* mask, float* out, int N, int L, void* stream);
+/* Same contract on bf16 MFMA (Q, K, V and the probabilities rounded to bf16; softmax statistics and output fp32):
+ * the throughput-mode attention of the towers. */
+int dldkd_attention_fwd_bf16(const float* qkv, const float* mask, float* out, int N, int L, void* stream);
 
 /* get_modularized_queries (model.py:245-258): h (N, L, 384), mask (N, L), w (384) -> out (N, 384);
  * attn (N, L) optional (softmax weights, kept for the backward pass).  L <= 64. */

@@ -147,3 +147,27 @@ def test_towers_throughput_mode_close_to_parity_mode(bf16_mode):
     for a, r in zip(got, ref):
         assert a.shape == r.shape
         assert _rel(a, r) < 3e-2
+
+
+@pytest.mark.parametrize("N,L", [(3, 128), (2, 1), (5, 33), (4, 100), (7, 30)])
+def test_attention_bf16_vs_reference_math(bf16_mode, N, L):
+    """bf16-MFMA fused attention against fp64 softmax(QK^T/sqrt(96) + (1-mask)*-1e4) V on the bf16-rounded q|k|v
+    (the probabilities are additionally rounded to bf16 inside the kernel: 2^-9 relative)."""
+    from dldkd_amd import ops
+    g = torch.Generator().manual_seed(N * 131 + L)
+    qkv = torch.randn(N, L, 1152, generator=g)
+    lens = torch.randint(1, L + 1, (N,), generator=g)
+    lens[0] = L
+    mask = (torch.arange(L)[None] < lens[:, None]).float()
+    with torch.no_grad():
+        out = ops.attention(qkv.to(DEV), mask.to(DEV)).cpu().double()
+        assert ops.gemm_precision() == "bf16"
+    x = _r(qkv).view(N, L, 3, 4, 96)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)     # (N, 4, L, 96)
+    s = q @ k.transpose(-1, -2) / 96 ** 0.5 + (1.0 - mask.double())[:, None, None, :] * -10000.0
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(N, L, 384)
+    assert (out - ref).abs().max().item() < 6e-3 * ref.abs().max().item() + 1e-6
+    none = ops.attention(qkv.to(DEV), None).cpu().double()
+    s2 = q @ k.transpose(-1, -2) / 96 ** 0.5
+    ref2 = (torch.softmax(s2, -1) @ v).transpose(1, 2).reshape(N, L, 384)
+    assert (none - ref2).abs().max().item() < 6e-3 * ref2.abs().max().item() + 1e-6

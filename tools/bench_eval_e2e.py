@@ -34,8 +34,12 @@ def stage_times(nv=21793, nq=10895, mode="fp32", dev="cuda:0"):
             lens = torch.randint(24, L + 1, (B,), generator=gen, device=dev)
             mask = (torch.arange(L, device=dev).unsqueeze(0) < lens.unsqueeze(1)).float()
             feats = feats * mask.unsqueeze(-1)
-            for _ in range(2):
-                m.encode_context(feats, mask)
+            for _ in range(2):                                   # warm-up: kernel modules, allocator pools, torch's lazy sort
+                gi, ge = m.encode_context(feats, mask)
+                wpk = scoring.GalleryPacker(B, L, 2, torch.device(dev))
+                wpk.add([gi, ge], mask)
+                wpk.finish()
+            del wpk
             pk = scoring.GalleryPacker(nv, L, 2, torch.device(dev))   # 2 x 2.1 GB: first-touch hipMalloc is not GPU work
             t0 = sync()
             done = 0
