@@ -541,6 +541,51 @@ __global__ __launch_bounds__(256) void simpool_finish_kernel(const float* __rest
     }
 }
 
+// 64 x 64 tiles: every gathered part row is read as 256 contiguous bytes (float4 per lane) and every output row
+// segment is written as 256 contiguous bytes; 32 x 32 tiles (above, kept for the v1 layout checks) move 128-byte
+// segments and reach 3.0 TB/s, this form is measured in DESIGN.md.
+__global__ __launch_bounds__(256) void simpool_finish64_kernel(const float* __restrict__ part, const int32_t* __restrict__ inv,
+                                                               int nq, int nq_pad, int nv, int n_branches, float w0, float w1,
+                                                               float* __restrict__ fused, float* __restrict__ s0,
+                                                               float* __restrict__ s1) {
+    __shared__ float t0[64][65];
+    __shared__ float t1[64][65];
+    const int q0 = blockIdx.x * 64, v0 = blockIdx.y * 64;
+    {
+        const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 float4 along q x 16 video rows per pass
+        const int q = q0 + 4 * tx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vl = ty + 16 * i, vv = v0 + vl;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+            if (vv < nv && q < nq_pad) {
+                const size_t row = (size_t)inv[vv] * nq_pad + q;
+                a = *reinterpret_cast<const f32x4*>(part + row);
+                if (n_branches > 1) b = *reinterpret_cast<const f32x4*>(part + (size_t)nv * nq_pad + row);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                t0[vl][4 * tx + e] = a[e];
+                t1[vl][4 * tx + e] = b[e];
+            }
+        }
+    }
+    __syncthreads();
+    const int vl = threadIdx.x & 63, vv = v0 + vl;
+    if (vv >= nv) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ql = (threadIdx.x >> 6) + 4 * i, qq = q0 + ql;
+        if (qq < nq) {
+            const float a = t0[vl][ql], b = t1[vl][ql];
+            const size_t o = (size_t)qq * nv + vv;
+            if (fused) fused[o] = n_branches > 1 ? w0 * a + w1 * b : a;
+            if (s0) s0[o] = a;
+            if (s1) s1[o] = b;
+        }
+    }
+}
+
 }  // namespace dldkd
 
 using namespace dldkd;
@@ -664,8 +709,13 @@ int dldkd_simpool_finish(const void* workspace, const int32_t* inv_order, int nq
     if (nq == 0 || nv == 0 || (!fused && !s0 && !s1)) return DLDKD_OK;
     if (!workspace || !inv_order) { set_error("simpool_finish: null pointer"); return DLDKD_EINVAL; }
     const int nq_pad = round_up(nq, kQTile);
-    hipLaunchKernelGGL(simpool_finish_kernel, dim3(nq_pad / 32, (nv + 31) / 32), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)workspace, inv_order, nq, nq_pad, nv, n_branches, w0, w1, fused, s0, s1);
+    static const bool old = getenv("DLDKD_FINISH32") != nullptr;   // A/B switch
+    if (old)
+        hipLaunchKernelGGL(simpool_finish_kernel, dim3(nq_pad / 32, (nv + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)workspace, inv_order, nq, nq_pad, nv, n_branches, w0, w1, fused, s0, s1);
+    else
+        hipLaunchKernelGGL(simpool_finish64_kernel, dim3((nq_pad + 63) / 64, (nv + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)workspace, inv_order, nq, nq_pad, nv, n_branches, w0, w1, fused, s0, s1);
     return check_launch("simpool_finish");
 }
 
