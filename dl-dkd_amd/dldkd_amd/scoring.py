@@ -144,6 +144,32 @@ def _units(pg):
     return pg._units
 
 
+def _stream_plan(pg):
+    """Row-stream plan of scorer v4, built once per gallery on the host (dldkd_simpool_plan_stream) and kept on the
+    device: (rowsrc, tile_end, tile_unit, tail_unit, video_unit0, video_unit1, n_waves, n_units)."""
+    if getattr(pg, "_stream", None) is None:
+        import ctypes
+        import numpy as np
+        lens = np.ascontiguousarray(pg.lens.cpu().numpy().astype(np.int32))
+        lp = (pg.L + 31) // 32 * 32
+        max_waves = int((int(lens.sum()) + 15 * pg.nv) // 128 + 2)
+        rowsrc = np.empty(max_waves * 128, np.int32)
+        te, tu = np.empty(max_waves * 8, np.int32), np.empty(max_waves * 8, np.int32)
+        tail = np.empty(max_waves, np.int32)
+        u0, u1 = np.empty(max(pg.nv, 1), np.int32), np.empty(max(pg.nv, 1), np.int32)
+        nw, nu = ctypes.c_int(0), ctypes.c_int(0)
+        hp = lambda a: ctypes.c_void_p(a.ctypes.data)   # noqa: E731
+        native.check(native.lib().dldkd_simpool_plan_stream(hp(lens), pg.nv, lp, max_waves, hp(rowsrc), hp(te), hp(tu), hp(tail),
+                                                            hp(u0), hp(u1), ctypes.cast(ctypes.byref(nw), ctypes.c_void_p),
+                                                            ctypes.cast(ctypes.byref(nu), ctypes.c_void_p)), "simpool_plan_stream")
+        nw, nu = nw.value, nu.value
+        dev = pg.lens.device
+        up = lambda a: torch.from_numpy(a).to(dev)      # noqa: E731
+        pg._stream = (up(rowsrc[:max(nw, 1) * 128]), up(te[:max(nw, 1) * 8]), up(tu[:max(nw, 1) * 8]), up(tail[:max(nw, 1)]),
+                      up(u0), up(u1), nw, nu)
+    return pg._stream
+
+
 def simpool_partials(pq, pg, workspace=None):
     """Stage 1 (the dominant kernel): per-branch pooled scores into the workspace, transposed and in
     visiting order.  Returns the workspace tensor."""
@@ -151,6 +177,16 @@ def simpool_partials(pq, pg, workspace=None):
     nb = pg.n_branches
     if len(pq.blobs) != nb:
         raise native.NativeError("query / gallery branch count mismatch")
+    if _variant() == "4":
+        rowsrc, te, tu, tail, _, _, n_waves, n_units = _stream_plan(pg)
+        need = L_.dldkd_simpool_units_workspace_bytes(pq.nq, n_units, nb)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, dtype=torch.uint8, device=pg.lens.device)
+        if pq.nq and pg.nv:
+            native.check(L_.dldkd_simpool_eval_stream_bf16(native.ptr_array(pq.blobs), native.ptr_array(pg.blobs), native.ptr(rowsrc),
+                                                           native.ptr(te), native.ptr(tu), native.ptr(tail), pq.nq, n_waves, n_units,
+                                                           nb, native.ptr(workspace), native.stream()), "simpool_eval_stream")
+        return workspace
     if _variant() == "3":
         uv, row0, rows, _, _, n_units = _units(pg)
         need = L_.dldkd_simpool_units_workspace_bytes(pq.nq, n_units, nb)
@@ -178,8 +214,11 @@ def simpool_finish(workspace, pq, pg, w=(0.7, 0.3), want_fused=True, want_branch
     fused = torch.empty(nq, nv, dtype=torch.float32, device=dev) if want_fused else None
     s0 = torch.empty(nq, nv, dtype=torch.float32, device=dev) if want_branches else None
     s1 = torch.empty(nq, nv, dtype=torch.float32, device=dev) if (want_branches and nb == 2) else None
-    if nq and nv and _variant() == "3":
-        _, _, _, u0, u1, n_units = _units(pg)
+    if nq and nv and _variant() in ("3", "4"):
+        if _variant() == "4":
+            _, _, _, _, u0, u1, _, n_units = _stream_plan(pg)
+        else:
+            _, _, _, u0, u1, n_units = _units(pg)
         native.check(L_.dldkd_simpool_finish_units(native.ptr(workspace), native.ptr(u0), native.ptr(u1), nq, nv, n_units, nb,
                                                    float(w[0]), float(w[1]), native.ptr(fused), native.ptr(s0), native.ptr(s1),
                                                    native.stream()), "simpool_finish_units")

@@ -95,6 +95,22 @@ int dldkd_simpool_finish_units(const void* workspace, const int32_t* video_unit0
                                int nv, int n_units, int n_branches, float w0, float w1, float* fused, float* s0,
                                float* s1, void* stream);
 
+/* Scorer v4 ("row stream").  The valid clips of all videos are laid end to end; wave w owns stream rows
+ * [128 w, 128 w + 128), so every wave computes 8 full 16-row tiles of real clips (scorer v2 rounds every video up to
+ * a multiple of 16 rows).  dldkd_simpool_plan_stream runs on the HOST (lens is a host array): it fills
+ *   rowsrc[max_waves * 128]  gallery blob row (v * Lp + clip) of every stream row, -1 = zero row,
+ *   tile_end / tile_unit [max_waves * 8], tail_unit[max_waves]  the segment metadata of every wave,
+ *   video_unit0 / video_unit1 [nv]  the 1-2 partial maxima ("units") of every video (-1 = none),
+ * and returns the number of waves and units.  max_waves >= (sum(lens) + 15 nv) / 128 + 1 always suffices.  The arrays
+ * are then copied to the device; stage 1 writes part[b][unit][q] (dldkd_simpool_units_workspace_bytes), stage 2 is
+ * dldkd_simpool_finish_units.  Same packed operands and same results as dldkd_simpool_eval_bf16 + dldkd_simpool_finish. */
+int dldkd_simpool_plan_stream(const int32_t* lens, int nv, int Lp, int max_waves, int32_t* rowsrc, int32_t* tile_end,
+                              int32_t* tile_unit, int32_t* tail_unit, int32_t* video_unit0, int32_t* video_unit1, int* n_waves,
+                              int* n_units);
+int dldkd_simpool_eval_stream_bf16(const void* const* q_packed, const void* const* g_packed, const int32_t* rowsrc,
+                                   const int32_t* tile_end, const int32_t* tile_unit, const int32_t* tail_unit, int nq, int n_waves,
+                                   int n_units, int n_branches, void* workspace, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Encoder towers, fp32 parity-grade forward (fp32-input MFMA: exact fp32 products and sums).
  * Together these replace DLDKD.encode_input / encode_context / encode_query (method/model.py:199-258).

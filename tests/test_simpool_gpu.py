@@ -138,3 +138,24 @@ def test_rank_parity_planted_gallery():
     assert 5.0 < ro[0] < 95.0, f"planted signal should give a non-trivial R@1, got {ro}"
     for a, b in zip(rh, ro):
         assert abs(a - b) <= 0.1, (rh, ro)
+
+
+@pytest.mark.parametrize("variant", ["3", "4"])
+@pytest.mark.parametrize("nq,nv,L,len_lo", [(200, 131, 128, 24), (97, 300, 40, 1), (33, 64, 128, 128), (50, 1, 7, 7)])
+def test_experimental_scorers_equal_the_shipped_one(monkeypatch, variant, nq, nv, L, len_lo):
+    """Scorer v3 (half-video units, two waves per SIMD) and v4 (row stream: every wave owns 128 consecutive valid clips,
+    segment-aware max-pool, host planner) are kept as measured experiments (neither beats v2).  Same packed
+    operands, and - because each score is the max of the same bf16 dot products accumulated in the same k order -
+    bit-identical results."""
+    from dldkd_amd import scoring
+    d0 = synth.make_gallery(300 + nq, nq, nv, L, len_lo, sigma=0.5)
+    d1 = synth.make_gallery(400 + nq, nq, nv, L, len_lo, sigma=1.0)
+    dev = "cuda:0"
+    pq = scoring.pack_queries([d0["q"].to(dev), d1["q"].to(dev)])
+    pg = scoring.pack_gallery([d0["g"].to(dev), (d1["g"] * d0["mask"].unsqueeze(-1)).to(dev)], d0["mask"].to(dev))
+    monkeypatch.setenv("DLDKD_SIMPOOL_VARIANT", "2")
+    ref = scoring.simpool_eval(pq, pg, want_branches=True)
+    monkeypatch.setenv("DLDKD_SIMPOOL_VARIANT", variant)
+    got = scoring.simpool_eval(pq, pg, want_branches=True)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
