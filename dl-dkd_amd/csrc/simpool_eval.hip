@@ -251,7 +251,13 @@ __global__ __launch_bounds__(256, 1) void simpool_eval_kernel(const SimpoolEvalA
         case 3: score_stream<3>(a, p, branch, vs, len, smem); break;
         case 2: score_stream<2>(a, p, branch, vs, len, smem); break;
         case 1: score_stream<1>(a, p, branch, vs, len, smem); break;
-        default: score_stream<0>(a, p, branch, vs, len, smem); break;   // padding wave: barriers + staging only
+        default:
+            score_stream<0>(a, p, branch, vs, len, smem);   // padding wave: barriers + staging only
+            if (vs < p.nv) {                                   // video without a valid clip: -1e10 (model.py:444)
+                float* row = p.part + ((size_t)branch * p.nv + vs) * p.nq_pad;
+                for (int q = lane; q < p.nq_pad; q += 64) row[q] = -1e10f;
+            }
+            break;
     }
 }
 
@@ -501,7 +507,14 @@ __global__ __launch_bounds__(256, 1) void simpool_eval16_kernel(const SimpoolEva
         case 3: score_stream16<3>(a, p, branch, vs, len, smem); break;
         case 2: score_stream16<2>(a, p, branch, vs, len, smem); break;
         case 1: score_stream16<1>(a, p, branch, vs, len, smem); break;
-        default: score_stream16<0>(a, p, branch, vs, len, smem); break;
+        default:
+            score_stream16<0>(a, p, branch, vs, len, smem);
+            // a real video with no valid clip: the reference's masked maximum is exactly -1e10 (mask_logits, model.py:444)
+            if (vs < p.nv) {
+                float* row = p.part + ((size_t)branch * p.nv + vs) * p.nq_pad;
+                for (int q = lane; q < p.nq_pad; q += 64) row[q] = -1e10f;
+            }
+            break;
     }
 }
 

@@ -159,3 +159,19 @@ def test_experimental_scorers_equal_the_shipped_one(monkeypatch, variant, nq, nv
     got = scoring.simpool_eval(pq, pg, want_branches=True)
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
+
+
+def test_video_without_valid_clips_scores_minus_1e10():
+    """An all-zero mask row: the reference's mask_logits leaves -1e10 on every clip, so the max is -1e10 in both
+    branches and in the fusion (0.7 + 0.3 of it)."""
+    d = synth.make_gallery(11, 37, 9, 48, 5, sigma=0.3)
+    mask = d["mask"].clone()
+    mask[4] = 0.0
+    g = d["g"] * mask.unsqueeze(-1)
+    fused, s0, s1, _ = _run([d["q"], d["q"]], [g, g], mask, True)
+    oi, _ = orc.eval_scores(d["q"], d["q"], g, g, mask)
+    assert torch.equal(oi[:, 4], torch.full((37,), -1e10))
+    assert torch.equal(s0[:, 4], oi[:, 4]) and torch.equal(s1[:, 4], oi[:, 4])
+    assert (fused[:, 4] - (-1e10)).abs().max() <= 1024.0          # 0.7 x + 0.3 x in fp32: within an ulp of -1e10
+    keep = [v for v in range(9) if v != 4]
+    assert (s0[:, keep] - oi[:, keep]).abs().max() <= TOL_BF16
