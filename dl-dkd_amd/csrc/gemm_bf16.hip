@@ -9,7 +9,7 @@
 namespace dldkd {
 
 #ifndef DLDKD_GEMM_BF16_BK
-#define DLDKD_GEMM_BF16_BK 64
+#define DLDKD_GEMM_BF16_BK 32   // 64 measured slower: 276-320 VGPRs -> one workgroup per CU (fwd 384x384: 46 vs 27 us)
 #endif
 constexpr int HBM_ = 128, HBN_ = 128, HBK_ = DLDKD_GEMM_BF16_BK;
 constexpr int KV_ = HBK_ / 4;            // float4 per tile row
