@@ -291,6 +291,20 @@ def extras(dev):
         cfg2 = cfg
         torch.manual_seed(0)
         m = DLDKD(cfg2, opt_).to(dev).eval()
+        # host -> device rate of raw features (the DataLoader side of compute_context_info, eval.py:130-134): what bounds
+        # an eval_epoch whose features start in host memory
+        hb = torch.empty(256, 128, 3072, dtype=torch.float32).pin_memory()          # 403 MB, one 256-video batch
+        db = torch.empty_like(hb, device=dev)
+        db.copy_(hb, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            db.copy_(hb, non_blocking=True)
+        torch.cuda.synchronize()
+        gbps = 5 * hb.numel() * 4 / (time.perf_counter() - t0) / 1e9
+        out["h2d_pinned_GBps"] = gbps
+        out["gallery_encode_videos_per_s_pcie_bound"] = gbps * 1e9 / (128 * 3072 * 4)
+        del hb, db
         xk = torch.nn.functional.normalize(torch.randn(400000, 3072, device=dev), dim=-1)      # 4.9 GB: beyond the L3
         fold = ops.FoldedInProj([m.visual_input_proj, m.exp_visual_input_proj])
         ops.in_proj_bf16(xk, fold)
