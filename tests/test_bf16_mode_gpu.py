@@ -171,3 +171,33 @@ def test_attention_bf16_vs_reference_math(bf16_mode, N, L):
     s2 = q @ k.transpose(-1, -2) / 96 ** 0.5
     ref2 = (torch.softmax(s2, -1) @ v).transpose(1, 2).reshape(N, L, 384)
     assert (none - ref2).abs().max().item() < 6e-3 * ref2.abs().max().item() + 1e-6
+
+
+def test_eval_epoch_throughput_mode_vs_parity_mode(golden_dir):
+    """The whole eval path with K4 + full-row bf16 linears + bf16 attention against the fp32-tower path on the G5
+    inputs: score matrices agree to bf16 grade, R@K moves by at most two of the 192 queries per cut (random-init
+    weights give near-ties), and both stay within that distance of the REFERENCE's own R@K (golden G5)."""
+    import types
+    from dldkd_amd import eval as ev, ops
+    g = np.load(f"{golden_dir}/g5_eval_epoch.npz")
+    m = _model(3072, 768, synth.make_params(51, 3072, 768))
+    vids, txts = synth.make_eval_sets(5, nv=64, caps=3, dv=3072, dq=768)
+    opt = types.SimpleNamespace(eval_context_bsz=25, eval_query_bsz=50, num_workers=0, pin_memory=False,
+                                device=torch.device(DEV), double_branch=True)
+    res = {}
+    try:
+        for mode in ("fp32", "bf16"):
+            ops.set_gemm_precision(mode)
+            m.fast_input_proj = mode == "bf16"
+            with torch.no_grad():
+                ctx = ev.compute_context_info(m, synth.ListDataset(list(vids)), opt, keep_frame_feats=False)
+                fused, s0, s1, qmetas = ev.score_queries(m, synth.ListDataset(list(txts)), opt, ctx)
+            _, t2v = ev.get_gt(ctx["video_metas"], qmetas)
+            res[mode] = (fused.cpu(), ev.eval_q2m(-fused, t2v))
+    finally:
+        ops.set_gemm_precision("fp32")
+        m.fast_input_proj = False
+    assert (res["bf16"][0] - res["fp32"][0]).abs().max().item() < 2e-2
+    step = 100.0 / 192
+    for a, b, r in zip(res["bf16"][1][:4], res["fp32"][1][:4], g["perf_fused"][:4]):
+        assert abs(a - b) <= 2 * step + 1e-9 and abs(a - r) <= 2 * step + 1e-9, (res["bf16"][1], res["fp32"][1], g["perf_fused"])
