@@ -175,3 +175,26 @@ def test_video_without_valid_clips_scores_minus_1e10():
     assert (fused[:, 4] - (-1e10)).abs().max() <= 1024.0          # 0.7 x + 0.3 x in fp32: within an ulp of -1e10
     keep = [v for v in range(9) if v != 4]
     assert (s0[:, keep] - oi[:, keep]).abs().max() <= TOL_BF16
+
+
+def test_fuzz_random_shapes_vs_oracle():
+    """40 random problems (any Nq / Nv, L in 1..128, lens in 0..L including videos without clips, 1-2 branches,
+    cosine or raw dot) against the oracle on the bf16-rounded operands: the exact-input bar of _check."""
+    rs = np.random.RandomState(2024)
+    for case in range(40):
+        nq, nv, L = int(rs.randint(1, 260)), int(rs.randint(1, 150)), int(rs.randint(1, 129))
+        nb, normalize = int(rs.randint(1, 3)), bool(rs.randint(0, 2))
+        lens = rs.randint(0 if case % 5 == 0 else 1, L + 1, size=nv)
+        mask = torch.from_numpy((np.arange(L)[None] < lens[:, None]).astype(np.float32))
+        g = torch.Generator().manual_seed(case)
+        qs = [torch.randn(nq, 384, generator=g) for _ in range(nb)]
+        gs = [torch.randn(nv, L, 384, generator=g) * mask.unsqueeze(-1) for _ in range(nb)]
+        fused, s0, s1, _ = _run(qs, gs, mask, normalize)
+        for b, out in enumerate([s0, s1][:nb]):
+            exact = _oracle_exact(qs[b], gs[b], mask, normalize)
+            has = torch.from_numpy(lens > 0)
+            scale = max(1.0, float(exact[:, has].abs().max())) if has.any() else 1.0
+            assert (out.double()[:, has] - exact[:, has]).abs().max().item() <= TOL_EXACT * scale if has.any() else True, (case, b)
+            assert bool((out[:, ~has] == -1e10).all()), (case, b)
+        if nb == 1:
+            assert torch.equal(fused, s0)
