@@ -290,3 +290,63 @@ def test_forward_at_c3_size_vs_oracle():
     _close(loss, ref["loss"])
     loss.backward()
     assert all(prm.grad is not None and torch.isfinite(prm.grad).all() for prm in m.parameters())
+
+
+def test_loss_kernels_fuzz_vs_oracle():
+    """Random batch structures (2..40 videos, 1..4 captions each, 1..48 clips, random alpha/beta, both negative
+    modes) through every loss kernel: value 1e-4 and gradient 2e-3 against the fp64 oracle."""
+    from dldkd_amd import functional as F_
+    rs = np.random.RandomState(77)
+    for case in range(12):
+        nv = int(rs.randint(2, 41))
+        counts = sorted(rs.randint(1, 5, size=nv).tolist(), reverse=True)
+        labels = [i for i, c in enumerate(counts) for _ in range(c)]
+        nq, L = len(labels), int(rs.randint(1, 49))
+        lens = rs.randint(1, L + 1, size=nv)
+        mask = torch.from_numpy((np.arange(L)[None] < lens[:, None]).astype(np.float32))
+        g = torch.Generator().manual_seed(1000 + case)
+        lab = _lab(labels)
+        # KL over the ground-truth video's clips
+        p = torch.randn(nq, nv, L, generator=g) * 0.5
+        t = torch.randn(nq, nv, L, generator=g) * 0.5
+        pd = p.to(DEV).requires_grad_(True)
+        kl = F_.kl_frame(pd, t.to(DEV), lab, torch.from_numpy(lens).int().to(DEV), 0.2)
+        po = p.permute(0, 2, 1).double().requires_grad_(True)
+        ko = orc.kl_frame_score(po, t.permute(0, 2, 1).double(), mask.double(), labels)
+        _close(kl, ko)
+        kl.backward()
+        ko.backward()
+        _gclose(pd.grad.permute(0, 2, 1), po.grad)
+        # InfoNCE, soft and hard labels
+        raw = torch.randn(nq, nv, generator=g) * 3.0
+        sims = torch.randn(nq, nv, generator=g) * 3.0
+        alpha, beta = float(rs.choice([0.0, 0.25, 0.8, 1.0])), float(rs.uniform(0.3, 0.9))
+        S = raw.to(DEV).requires_grad_(True)
+        v = F_.nce_soft(lab, S, sims.to(DEV), alpha, beta)
+        So = raw.double().requires_grad_(True)
+        vo = orc.nce_soft(labels, So, sims.double(), alpha, beta)
+        _close(v, vo)
+        v.backward()
+        vo.backward()
+        _gclose(S.grad, So.grad)
+        S2 = raw.to(DEV).requires_grad_(True)
+        v2 = F_.nce_hard(lab, S2)
+        So2 = raw.double().requires_grad_(True)
+        vo2 = orc.nce_hard(labels, So2)
+        _close(v2, vo2)
+        v2.backward()
+        vo2.backward()
+        _gclose(S2.grad, So2.grad)
+        # triplet, both negative modes, with the reference's random draws
+        cos = torch.tanh(torch.randn(nq, nv, generator=g))
+        for hard in (False, True):
+            torch.manual_seed(case)
+            r_v2t, r_t2v = orc.draw_triplet_randoms(labels, nv, hard, 20)
+            C = cos.to(DEV).requires_grad_(True)
+            tv = F_.triplet(C, lab, r_t2v.int().to(DEV), None if r_v2t is None else r_v2t.int().to(DEV), hard, 0.1)
+            Co = cos.double().requires_grad_(True)
+            to = orc.clip_triplet_loss(Co, labels, 0.1, hard, r_v2t, r_t2v)
+            _close(tv, to)
+            tv.backward()
+            to.backward()
+            _gclose(C.grad, Co.grad)
