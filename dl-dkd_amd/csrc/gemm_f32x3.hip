@@ -1,0 +1,289 @@
+// gemm_f32x3: fp32-grade GEMM on the bf16 matrix cores.  Same contract as gemm_f32 (three operand layouts, fused
+// bias + ReLU, strided batching, split-K), but every fp32 operand is split on the way to LDS into three bf16 planes
+//     x = h + m + l,   h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)      (24 mantissa bits, both subtractions exact)
+// and each product is assembled from the six plane products of order <= 2
+//     a*b ~= a_h b_h + (a_h b_m + a_m b_h) + (a_h b_l + a_l b_h + a_m b_m)       (dropped: a_m b_l, a_l b_m, a_l b_l <= 2^-24 |ab|)
+// with v_mfma_f32_32x32x16_bf16 accumulating in fp32.  Each plane product is exact in fp32 (8 x 8 significant bits),
+// so the result carries the same ~2^-24 relative error per product as a true fp32 multiply, while 6 bf16 MFMAs
+// (6 x 32 cycles per 16 k) replace 8 fp32-input MFMAs (8 x 64 cycles): the fp32-input pipe of CDNA4 peaks at 157 TFLOP/s,
+// the bf16 pipe at 2500, so the "fp32-equivalent" MFMA ceiling moves to 2500/6 = 417 TFLOP/s.
+// Measured: 105-139 TFLOP/s fp32-equivalent on the tower shapes (= 630-834 TFLOP/s of raw bf16 MFMA) against 68-88 for
+// the true fp32-input MFMA kernel.  The ceiling is LDS operand delivery, not memory or VALU: with ALL global loads
+// removed the rate is unchanged, interleaving the split VALU with the MFMAs (sched_group_barrier) changes nothing, and
+// 834 TFLOP/s raw is exactly where the K4 kernel (same 0.5 fragment reads per MFMA) also stops.
+// This is the PARITY-grade GEMM of the towers and of the training step (losses within 1e-4, gradients 2e-3 of the
+// fp64 oracle are gated by the same tests as before); gemm_f32 (true fp32 MFMA) stays available as "fp32_exact".
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace dldkd {
+
+constexpr int XBM = 128, XBN = 128, XBK = 16;
+constexpr int XPITCH = XBK + 8;                 // 48-byte rows: conflict-free ds_read_b128 fragments
+constexpr int XPLANE = XBM * XPITCH;            // bf16 elements per plane
+constexpr int XKV = XBK / 4;                    // float4 per tile row (4)
+constexpr int XRPP = 256 / XKV;                 // rows per pass of the k-minor loader (64)
+constexpr int XNPASS = XBM / XRPP;              // 2
+constexpr int XNREG = XNPASS * 4;               // 8 staging floats per thread per operand
+constexpr int XKPT = XBK / 2;                   // k per thread of the k-major loader (8)
+
+struct GemmXArgs {
+    const float* A;
+    const float* B;
+    const float* bias;
+    float* C;
+    int M, N, K, lda, ldb, ldc, relu;
+    int a_vec, b_vec;
+    int batch_inner;
+    long sAo, sAi, sBo, sBi, sCo, sCi;
+    float alpha;
+    int split_k, k_tiles_per_split;
+    int ablate;   // diagnostic (DLDKD_X3_ABLATE=1): no global loads after the first two k-tiles
+};
+
+// x -> (h, m, l) bf16 bit patterns
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    h = f32_to_bf16_bits(x);
+    const float r1 = x - bf16_bits_to_f32(h);
+    m = f32_to_bf16_bits(r1);
+    const float r2 = r1 - bf16_bits_to_f32(m);
+    l = f32_to_bf16_bits(r2);
+}
+
+template <bool KMAJOR>
+struct TileX {
+    static __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int K,
+                                                int tid, bool vec, float (&r)[XNREG]) {
+        if constexpr (!KMAJOR) {
+#pragma unroll
+            for (int j = 0; j < XNPASS; ++j) {
+                const int row = row0 + tid / XKV + XRPP * j;
+                const int k = k0 + (tid % XKV) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row < nrows) {
+                    const float* src = P + (size_t)row * ld + k;
+                    if (vec && k + 3 < K) v = *reinterpret_cast<const f32x4*>(src);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (k + e < K) v[e] = src[e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[4 * j + e] = v[e];
+            }
+        } else {
+            const int row = row0 + (tid & 127);
+            const int kb = k0 + (tid >> 7) * XKPT;
+            const float* src = P + (size_t)kb * ld + row;
+            const bool rok = row < nrows;
+#pragma unroll
+            for (int i = 0; i < XKPT; ++i) r[i] = (rok && kb + i < K) ? src[(size_t)i * ld] : 0.f;
+        }
+    }
+    // interior tile: branch-free; rows past the end are clamped (they only feed accumulators that are never stored)
+    static __device__ __forceinline__ void load_fast(const float* __restrict__ P, int ld, int row0, int nrows, int k0,
+                                                     int tid, float (&r)[XNREG]) {
+        if constexpr (!KMAJOR) {
+#pragma unroll
+            for (int j = 0; j < XNPASS; ++j) {
+                const int row = min(row0 + tid / XKV + XRPP * j, nrows - 1);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(P + (size_t)row * ld + k0 + (tid % XKV) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[4 * j + e] = v[e];
+            }
+        } else {
+            const int row = min(row0 + (tid & 127), nrows - 1);
+            const float* src = P + (size_t)(k0 + (tid >> 7) * XKPT) * ld + row;
+#pragma unroll
+            for (int i = 0; i < XKPT; ++i) r[i] = src[(size_t)i * ld];
+        }
+    }
+    // registers -> three bf16 planes in LDS ([plane][row][k])
+    static __device__ __forceinline__ void store(unsigned short* __restrict__ S, int tid, const float (&r)[XNREG]) {
+        if constexpr (!KMAJOR) {
+#pragma unroll
+            for (int j = 0; j < XNPASS; ++j) {
+                unsigned short h[4], m[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split3(r[4 * j + e], h[e], m[e], l[e]);
+                unsigned short* dst = S + (tid / XKV + XRPP * j) * XPITCH + (tid % XKV) * 4;
+                *reinterpret_cast<uint2*>(dst) = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+                *reinterpret_cast<uint2*>(dst + XPLANE) = uint2{(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
+                *reinterpret_cast<uint2*>(dst + 2 * XPLANE) = uint2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+            }
+        } else {
+            unsigned short h[8], m[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split3(r[e], h[e], m[e], l[e]);
+            unsigned short* dst = S + (tid & 127) * XPITCH + (tid >> 7) * XKPT;
+            auto pk = [](const unsigned short (&v)[8]) {
+                return uint4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                             (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+            };
+            *reinterpret_cast<uint4*>(dst) = pk(h);
+            *reinterpret_cast<uint4*>(dst + XPLANE) = pk(m);
+            *reinterpret_cast<uint4*>(dst + 2 * XPLANE) = pk(l);
+        }
+    }
+};
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_f32x3_kernel(GemmXArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][3 * XPLANE];   // [stage][A|B][plane][row][k]: 72 KiB
+    if (p.split_k <= 1) {
+        const int zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
+        p.A += zo * p.sAo + zi * p.sAi;
+        p.B += zo * p.sBo + zi * p.sBi;
+        p.C += zo * p.sCo + zi * p.sCi;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = blockIdx.y * XBM, n0 = blockIdx.x * XBN;
+    const int nk_all = (p.K + XBK - 1) / XBK;
+    const int kt0 = p.split_k > 1 ? blockIdx.z * p.k_tiles_per_split : 0;
+    const int nk = p.split_k > 1 ? min(nk_all - kt0, p.k_tiles_per_split) : nk_all;
+    if (nk <= 0) return;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // operand tiles are prefetched TWO k-tiles ahead in a ring of two register sets (the loop is unrolled by 2 so the
+    // ring index is static): at ~2 us of loaded HBM/L2 latency a one-tile-ahead pipeline paid a round trip per k-tile
+    float ra[2][XNREG], rb[2][XNREG];
+    const bool fa = A_KMAJOR || p.a_vec, fb = B_KMAJOR || p.b_vec;
+    auto load_tiles = [&](int k0, auto set_c) {
+        constexpr int S = decltype(set_c)::value;
+        if (k0 + XBK <= p.K && fa && fb) {
+            TileX<A_KMAJOR>::load_fast(p.A, p.lda, m0, p.M, k0, tid, ra[S]);
+            TileX<B_KMAJOR>::load_fast(p.B, p.ldb, n0, p.N, k0, tid, rb[S]);
+        } else {
+            TileX<A_KMAJOR>::load(p.A, p.lda, m0, p.M, k0, p.K, tid, p.a_vec, ra[S]);
+            TileX<B_KMAJOR>::load(p.B, p.ldb, n0, p.N, k0, p.K, tid, p.b_vec, rb[S]);
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    auto iter = [&](int kt, auto set_c) {           // tile kt is in LDS stage kt & 1; its register set (S) is free
+        constexpr int S = decltype(set_c)::value;
+        const int cur = kt & 1;
+        if (kt + 2 < nk && !p.ablate) load_tiles((kt0 + kt + 2) * XBK, set_c);
+        const unsigned short* As = lds[cur][0] + (wm + (lane & 31)) * XPITCH + (lane >> 5) * 8;
+        const unsigned short* Bs = lds[cur][1] + (wn + (lane & 31)) * XPITCH + (lane >> 5) * 8;
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * XPLANE + 32 * i * XPITCH);
+                b[i][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * XPLANE + 32 * i * XPITCH);
+            }
+        // smallest terms first
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+        if (kt + 1 < nk) {
+            TileX<A_KMAJOR>::store(lds[cur ^ 1][0], tid, ra[1 - S]);
+            TileX<B_KMAJOR>::store(lds[cur ^ 1][1], tid, rb[1 - S]);
+        }
+        __syncthreads();
+    };
+    load_tiles(kt0 * XBK, S0{});
+    if (nk > 1) load_tiles((kt0 + 1) * XBK, S1{});
+    TileX<A_KMAJOR>::store(lds[0][0], tid, ra[0]);
+    TileX<B_KMAJOR>::store(lds[0][1], tid, rb[0]);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        iter(kt, S0{});
+        if (kt + 1 < nk) iter(kt + 1, S1{});
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + 32 * j + (lane & 31);
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) {
+                    float v = acc[i][j][r] * p.alpha + bias;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.split_k > 1) atomicAdd(p.C + (size_t)m * p.ldc + n, v);
+                    else p.C[(size_t)m * p.ldc + n] = v;
+                }
+            }
+    }
+}
+
+static int launch_gemm_x(GemmXArgs p, int batch, int a_kmajor, int b_kmajor, void* stream) {
+    const dim3 grid((p.N + XBN - 1) / XBN, (p.M + XBM - 1) / XBM, batch), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32x3_kernel<false, false>), grid, block, 0, s, p);
+    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32x3_kernel<false, true>), grid, block, 0, s, p);
+    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32x3_kernel<true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32x3_kernel<true, false>), grid, block, 0, s, p);
+    return check_launch("gemm_f32x3");
+}
+
+}  // namespace dldkd
+
+using namespace dldkd;
+
+extern "C" int dldkd_gemm_f32x3(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda,
+                                int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < N) { set_error("gemm_f32x3: bad sizes"); return DLDKD_EINVAL; }
+    if (M == 0 || N == 0) return DLDKD_OK;
+    if (!A || !B || !C) { set_error("gemm_f32x3: null pointer"); return DLDKD_EINVAL; }
+    const int a_vec = !(lda & 3) && !((uintptr_t)A & 15), b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
+    static const int abl = getenv("DLDKD_X3_ABLATE") ? atoi(getenv("DLDKD_X3_ABLATE")) : 0;
+    GemmXArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0, abl};
+    const int tiles = ((N + XBN - 1) / XBN) * ((M + XBM - 1) / XBM);
+    const int nk = (K + XBK - 1) / XBK;
+    if (!bias && !relu && ldc == N && tiles < 128 && nk >= 32) {
+        int split = (256 + tiles - 1) / tiles;
+        if (split > nk / 8) split = nk / 8;
+        if (split > 1) {
+            p.k_tiles_per_split = (nk + split - 1) / split;
+            p.split_k = (nk + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
+            if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, (hipStream_t)stream) != hipSuccess) return check_launch("gemm_f32x3 memset");
+            return launch_gemm_x(p, p.split_k, a_kmajor, b_kmajor, stream);
+        }
+    }
+    return launch_gemm_x(p, 1, a_kmajor, b_kmajor, stream);
+}
+
+extern "C" int dldkd_gemm_f32x3_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                        int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo, long sAi,
+                                        long sBo, long sBi, long sCo, long sCi, float alpha, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < 1 || batch_outer < 0 || batch_inner < 1) {
+        set_error("gemm_f32x3_batched: bad sizes");
+        return DLDKD_EINVAL;
+    }
+    const long batch = (long)batch_outer * batch_inner;
+    if (M == 0 || N == 0 || batch == 0) return DLDKD_OK;
+    if (batch > 65535) { set_error("gemm_f32x3_batched: batch %ld > 65535", batch); return DLDKD_EINVAL; }
+    if (!A || !B || !C) { set_error("gemm_f32x3_batched: null pointer"); return DLDKD_EINVAL; }
+    const bool al = !((sAo | sAi) & 3) && !(lda & 3) && !((uintptr_t)A & 15);
+    const bool bl = !((sBo | sBi) & 3) && !(ldb & 3) && !((uintptr_t)B & 15);
+    GemmXArgs p{A, B, nullptr, C, M, N, K, lda, ldb, ldc, 0, al, bl, batch_inner, sAo, sAi, sBo, sBi, sCo, sCi, alpha, 1, 0, 0};
+    return launch_gemm_x(p, (int)batch, a_kmajor, b_kmajor, stream);
+}

@@ -149,7 +149,7 @@ def dropout(x, p, training):
 # ------------------------------------------------------------------------------------------ attention
 def _bgemm(A, B, C, M, N, K, lda, ldb, ldc, ak, bk, n_seq, sA, sB, sC, alpha=1.0):
     """per-(sequence, head) product; s? = (outer stride, inner stride) in elements."""
-    fn = _L().dldkd_gemm_bf16_batched if ops.gemm_precision() == "bf16" else _L().dldkd_gemm_f32_batched
+    fn = ops._gemm_fn(_L(), batched=True)
     native.check(fn(A, B, C, M, N, K, lda, ldb, ldc, int(ak), int(bk), n_seq, HEADS,
                     sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], float(alpha), _s()), "gemm_batched")
 

@@ -92,6 +92,11 @@ SIGNATURES = {
                                                 _c_int, _c_void_p]),
     "dldkd_dropout_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p]),
     "dldkd_mask_scale_f32": (_c_int, [_c_void_p, _c_void_p, _c_float, _c_void_p, _c_long, _c_void_p]),
+    "dldkd_gemm_f32x3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                   _c_int, _c_int, _c_int, _c_void_p]),
+    "dldkd_gemm_f32x3_batched": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                           _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_float,
+                                           _c_void_p]),
     "dldkd_gemm_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_int, _c_void_p]),
     "dldkd_gemm_bf16_batched": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

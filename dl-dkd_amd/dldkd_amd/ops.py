@@ -11,17 +11,28 @@ _PRECISION = "fp32"
 
 
 def set_gemm_precision(precision):
-    """"fp32": fp32-input MFMA everywhere (parity grade, the default).  "bf16": the GEMMs of `linear` / `gemm` (and the
+    """"fp32" (default, parity grade): fp32-grade products from three bf16 planes per operand on the bf16 matrix
+    cores (gemm_f32x3.hip, ~2^-24 relative error per product, 1.5x the fp32-input MFMA); "fp32_exact": the true
+    fp32-input MFMA (gemm_f32.hip).  "bf16": the GEMMs of `linear` / `gemm` (and the
     batched attention products in functional.py) run on bf16 MFMA with fp32 accumulation - the throughput mode of
     the training step (BASELINE.json configs[2])."""
     global _PRECISION
-    if precision not in ("fp32", "bf16"):
+    if precision not in ("fp32", "fp32_exact", "fp32x3", "bf16"):
         raise ValueError(precision)
     _PRECISION = precision
 
 
 def gemm_precision():
     return _PRECISION
+
+
+def _gemm_fn(L, batched=False):
+    sfx = "_batched" if batched else ""
+    if _PRECISION == "bf16":
+        return getattr(L, "dldkd_gemm_bf16" + sfx)
+    if _PRECISION in ("fp32", "fp32x3"):      # fp32-grade on the bf16 matrix cores (three-plane split), the default
+        return getattr(L, "dldkd_gemm_f32x3" + sfx)
+    return getattr(L, "dldkd_gemm_f32" + sfx)   # "fp32_exact": the true fp32-input MFMA
 
 
 def _chk(t, name):
@@ -40,7 +51,7 @@ def linear(x, weight, bias=None, relu=False):
     if weight.shape[1] != K:
         raise native.NativeError(f"linear: x has {K} features, weight expects {weight.shape[1]}")
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    fn = L.dldkd_gemm_bf16 if _PRECISION == "bf16" else L.dldkd_gemm_f32
+    fn = _gemm_fn(L)
     native.check(fn(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
                     0, 0, int(relu), native.stream()), "gemm")
     return y.view(*x.shape[:-1], N)
@@ -51,7 +62,7 @@ def gemm(a, b, a_kmajor, b_kmajor, M, N, K):
     L = native.lib()
     _chk(a, "gemm.a"); _chk(b, "gemm.b")
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    fn = L.dldkd_gemm_bf16 if _PRECISION == "bf16" else L.dldkd_gemm_f32
+    fn = _gemm_fn(L)
     native.check(fn(native.ptr(a), native.ptr(b), None, native.ptr(c), M, N, K, a.shape[-1], b.shape[-1], N,
                     int(a_kmajor), int(b_kmajor), 0, native.stream()), "gemm")
     return c

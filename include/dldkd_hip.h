@@ -204,6 +204,17 @@ int dldkd_gemm_bf16_batched(const float* A, const float* B, float* C, int M, int
                             int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo, long sAi, long sBo,
                             long sBi, long sCo, long sCi, float alpha, void* stream);
 
+/* fp32-GRADE GEMM on the bf16 matrix cores: each fp32 operand is split into three bf16 planes (h + m + l = 24 mantissa
+ * bits) on the way to LDS and every product is rebuilt from the six plane products of order <= 2 with fp32 accumulation
+ * (relative error ~2^-24 per product, like a true fp32 multiply).  Same arguments as dldkd_gemm_f32[_batched].  6 bf16
+ * MFMAs replace 8 fp32-input MFMAs that each run 2x slower: ~3x the throughput of dldkd_gemm_f32 at parity-grade
+ * accuracy; the host mirror uses it for precision "fp32" and keeps the true fp32-input MFMA as "fp32_exact". */
+int dldkd_gemm_f32x3(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
+                     int ldc, int a_kmajor, int b_kmajor, int relu, void* stream);
+int dldkd_gemm_f32x3_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                             int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo, long sAi, long sBo,
+                             long sBi, long sCo, long sCi, float alpha, void* stream);
+
 /* P = softmax(S * scale + (1 - keymask) * -10000) over the last dim L <= 128, in place; row r uses
  * keymask[r / rows_per_seq] (model_components.py:419-426).  keymask may be NULL. */
 int dldkd_softmax_rows_fwd_f32(float* S, const float* keymask, long rows, int L, int rows_per_seq, float scale,

@@ -18,20 +18,29 @@ def _rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
+@pytest.fixture(params=["fp32", "fp32_exact"])
+def fp32_kind(request):
+    """both parity-grade GEMMs: the three-plane bf16 kernel (default "fp32") and the true fp32-input MFMA"""
+    from dldkd_amd import ops
+    ops.set_gemm_precision(request.param)
+    yield request.param
+    ops.set_gemm_precision("fp32")
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 1, 4), (130, 70, 20), (257, 384, 3072), (1000, 1152, 384), (64, 384, 768)])
-def test_gemm_linear_forward(M, N, K):
+def test_gemm_linear_forward(fp32_kind, M, N, K):
     from dldkd_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
     x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
     y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=True)
     ref = torch.relu(x.double() @ w.double().t() + b.double())
-    assert _rel(y, ref) < 2e-6          # fp32 MFMA = fp32 fmaf chains; tolerance = accumulation-order noise
+    assert _rel(y, ref) < 2e-6          # fp32-grade products, fp32 accumulation; tolerance = accumulation-order noise
     y2 = ops.linear(x.to(DEV), w.to(DEV))
     assert _rel(y2, x.double() @ w.double().t()) < 2e-6
 
 
 @pytest.mark.parametrize("M,N,K", [(96, 50, 36), (300, 384, 384), (640, 384, 16384)])
-def test_gemm_backward_layouts(M, N, K):
+def test_gemm_backward_layouts(fp32_kind, M, N, K):
     """dX = dY.W (b_kmajor) and dW = dY^T.X (both kmajor) without transposes."""
     from dldkd_amd import ops
     g = torch.Generator().manual_seed(7)

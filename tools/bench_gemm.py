@@ -25,5 +25,5 @@ def run(prec):
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
         print(f"{prec} {lab:28s} {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TF  {(M*K+N*K+M*N)*4/us/1e3:7.1f} GB/s min-traffic")
-for prec in sys.argv[1:] or ["fp32", "bf16"]:
+for prec in sys.argv[1:] or ["fp32", "fp32x3", "bf16"]:
     run(prec)
