@@ -177,7 +177,7 @@ def extras(dev):
         torch.cuda.synchronize()
         out["c3_train_step_ms"] = (time.perf_counter() - t0) / 10 * 1e3
         out["c3_train_step_config"] = "TVR: 128 videos / 640 queries, L<=128, label_style=soft, hard negatives, dropout 0.2, " \
-                                      "forward+backward+fused BertAdam, fp32-input MFMA path (parity grade)"
+                                      "forward+backward+fused BertAdam, parity mode (fp32-grade GEMMs: three bf16 planes per operand on the bf16 matrix cores)"
         from dldkd_amd import ops
         ops.set_gemm_precision("bf16")    # throughput mode: the configuration BASELINE.json configs[2] names (bf16)
         try:
@@ -207,7 +207,7 @@ def extras(dev):
         dt = (time.perf_counter() - t0) / 5
         out["gallery_encode_videos_per_s"] = B / dt
         out["gallery_encode_raw_feature_GBps"] = B * Lc * 3072 * 4 / dt / 1e9
-        out["gallery_encode_config"] = "200 x 128 clips x 3072-d fp32 features, both branches, fp32-input MFMA towers"
+        out["gallery_encode_config"] = "200 x 128 clips x 3072-d fp32 features, both branches, parity-mode towers (fp32-grade three-plane GEMMs, fp32 attention)"
         m.fast_input_proj = True          # K4: bf16 input projection, LayerNorm folded, one pass over the features
         with torch.no_grad():
             m.encode_context(feats, mask)

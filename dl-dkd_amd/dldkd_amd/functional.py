@@ -269,7 +269,7 @@ def normalize(x):
 
 
 class _ClipScores(Function):
-    """S[q, v, l] = <q_q, g_{v,l}> as one fp32-MFMA GEMM: (Nq, D) x (Nv*L, D)^T (model.py:321,344)."""
+    """S[q, v, l] = <q_q, g_{v,l}> as one fp32-grade GEMM: (Nq, D) x (Nv*L, D)^T (model.py:321,344)."""
 
     @staticmethod
     def forward(ctx, q, g):

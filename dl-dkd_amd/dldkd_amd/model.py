@@ -198,7 +198,7 @@ class DLDKD(nn.Module):
     @staticmethod
     def get_sim_scores(modularied_query, context_feat, mask=None):
         """Cosine scores: (pooled (Nq, Nv), clip-level (Nq, L, Nv)) as model.py:307-329; masked clips are
-        exactly -1e10.  fp32-MFMA path (differentiable); the clip-level tensor is a permuted view of the
+        exactly -1e10.  fp32-grade GEMM path (differentiable); the clip-level tensor is a permuted view of the
         (Nq, Nv, L) buffer the kernels use."""
         pooled, clip = DLDKD._clip_level(modularied_query, context_feat, mask, True)
         return pooled, clip.permute(0, 2, 1)
