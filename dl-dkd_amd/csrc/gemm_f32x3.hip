@@ -41,7 +41,6 @@ struct GemmXArgs {
     long sAo, sAi, sBo, sBi, sCo, sCi;
     float alpha;
     int split_k, k_tiles_per_split;
-    int ablate;   // diagnostic (DLDKD_X3_ABLATE=1): no global loads after the first two k-tiles
 };
 
 // x -> (h, m, l) bf16 bit patterns
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_f32x3_kernel(GemmXArgs p) {
     auto iter = [&](int kt, auto set_c) {           // tile kt is in LDS stage kt & 1; its register set (S) is free
         constexpr int S = decltype(set_c)::value;
         const int cur = kt & 1;
-        if (kt + 2 < nk && !p.ablate) load_tiles((kt0 + kt + 2) * XBK, set_c);
+        if (kt + 2 < nk) load_tiles((kt0 + kt + 2) * XBK, set_c);
         const unsigned short* As = lds[cur][0] + (wm + (lane & 31)) * XPITCH + (lane >> 5) * 8;
         const unsigned short* Bs = lds[cur][1] + (wn + (lane & 31)) * XPITCH + (lane >> 5) * 8;
         bf16x8 a[2][3], b[2][3];
@@ -254,8 +253,7 @@ extern "C" int dldkd_gemm_f32x3(const float* A, const float* B, const float* bia
     if (M == 0 || N == 0) return DLDKD_OK;
     if (!A || !B || !C) { set_error("gemm_f32x3: null pointer"); return DLDKD_EINVAL; }
     const int a_vec = !(lda & 3) && !((uintptr_t)A & 15), b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
-    static const int abl = getenv("DLDKD_X3_ABLATE") ? atoi(getenv("DLDKD_X3_ABLATE")) : 0;
-    GemmXArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0, abl};
+    GemmXArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
     const int tiles = ((N + XBN - 1) / XBN) * ((M + XBM - 1) / XBM);
     const int nk = (K + XBK - 1) / XBK;
     if (!bias && !relu && ldc == N && tiles < 128 && nk >= 32) {
@@ -284,6 +282,6 @@ extern "C" int dldkd_gemm_f32x3_batched(const float* A, const float* B, float* C
     if (!A || !B || !C) { set_error("gemm_f32x3_batched: null pointer"); return DLDKD_EINVAL; }
     const bool al = !((sAo | sAi) & 3) && !(lda & 3) && !((uintptr_t)A & 15);
     const bool bl = !((sBo | sBi) & 3) && !(ldb & 3) && !((uintptr_t)B & 15);
-    GemmXArgs p{A, B, nullptr, C, M, N, K, lda, ldb, ldc, 0, al, bl, batch_inner, sAo, sAi, sBo, sBi, sCo, sCi, alpha, 1, 0, 0};
+    GemmXArgs p{A, B, nullptr, C, M, N, K, lda, ldb, ldc, 0, al, bl, batch_inner, sAo, sAi, sBo, sBi, sCo, sCi, alpha, 1, 0};
     return launch_gemm_x(p, (int)batch, a_kmajor, b_kmajor, stream);
 }
