@@ -66,12 +66,15 @@ def make_optimizer(model, opt, steps_per_epoch):
                     t_total=steps_per_epoch * opt.n_epoch, schedule="warmup_linear")
 
 
+DDP_MIN_WORLD = 2      # tests set 1 to drive the all-reduce branch with a one-rank group
+
+
 def train_step(model, batch, optimizer, opt):
     """zero_grad / forward / backward / [global clip] / step (train.py:141-151).  Returns (loss, loss_dict)."""
     optimizer.zero_grad()
     loss, loss_dict = model(batch)
     loss.backward()
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() >= DDP_MIN_WORLD:
         from . import dist as ddist
         optimizer.fp.rebind_grads()
         ddist.all_reduce_flat(optimizer.fp.grad)
