@@ -350,7 +350,13 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL kernels need CUs too, and the scorer parks a 512-register wave on every SIMD: give the collective's
+        # stream high priority so its workgroups are dispatched first whenever a scorer workgroup retires
+        try:
+            pg_opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group("nccl", device_id=dev, pg_options=pg_opts)
+        except Exception:   # noqa: BLE001  (older/newer torch without this option)
+            dist.init_process_group("nccl", device_id=dev)
 
     from dldkd_amd import native, scoring
     native.lib()   # fail loudly before anything else if the HIP library is missing
@@ -478,10 +484,19 @@ def main():
             del gs, fused
             torch.cuda.empty_cache()
             out["extras"] = extras(dev)
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line must be the LAST line of stdout: RCCL / the HIP runtime write banners through C stdio, which is
+        # flushed at exit - after Python's own prints - unless it is drained first
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:   # noqa: BLE001
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
