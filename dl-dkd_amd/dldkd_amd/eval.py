@@ -100,6 +100,9 @@ def cal_perf(t2v_all_errors, t2v_gt, test=False):
     return (r1, r5, r10, r100, medr, meanr, m)
 
 
+CONTEXT_SUPER_BATCH = 1024
+
+
 def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
     """Encode the gallery in batches of eval_context_bsz, zero-pad to the global max length, concatenate
     (eval.py:114-175).  Adds `_packed`: the resident bf16 gallery the scorer consumes.
@@ -113,21 +116,56 @@ def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
                         num_workers=opt.num_workers, shuffle=False, pin_memory=opt.pin_memory)
     metas, inh, exp, masks = [], [], [], []
     packer = None
+    pend_f, pend_m, pend_n = [], [], 0
+
+    def flush():
+        """encode the pending loader batches as ONE super-batch (zero-padded to its longest video; padded clips are
+        masked out of attention exactly): at eval_context_bsz = 200 a batch is 200 workgroups of 128 rows on 256 CUs, so
+        every tower kernel runs a single partly-filled round; 1024 videos give four full ones"""
+        nonlocal pend_f, pend_m, pend_n, packer
+        if not pend_f:
+            return
+        if len(pend_f) == 1:
+            feat, mask = pend_f[0], pend_m[0]
+        else:
+            lmax = max(f.shape[1] for f in pend_f)
+            feat = pend_f[0].new_zeros(pend_n, lmax, pend_f[0].shape[2])
+            mask = pend_m[0].new_zeros(pend_n, lmax)
+            o = 0
+            for f, m_ in zip(pend_f, pend_m):
+                feat[o:o + f.shape[0], :f.shape[1]] = f
+                mask[o:o + f.shape[0], :f.shape[1]] = m_
+                o += f.shape[0]
+        gi, ge = model.encode_context(feat, mask)
+        if keep_frame_feats:
+            # the reference's dict holds zeros beyond each LOADER batch's own longest video (cat_tensor, eval.py:139-155);
+            # positions between a video's length and that maximum keep the towers' output for padded clips, as there
+            o = 0
+            for f in pend_f:
+                if f.shape[1] < gi.shape[1]:
+                    gi[o:o + f.shape[0], f.shape[1]:] = 0
+                    if ge is not None:
+                        ge[o:o + f.shape[0], f.shape[1]:] = 0
+                o += f.shape[0]
+            inh.append(gi)
+            exp.append(ge)
+        else:
+            if packer is None:
+                packer = scoring.GalleryPacker(len(eval_dataset), int(_cfg_get(model.config, "max_ctx_l")),
+                                               2 if model.double_branch else 1, gi.device)
+            packer.add([gi, ge] if model.double_branch else [gi], mask)
+        masks.append(mask)
+        pend_f, pend_m, pend_n = [], [], 0
+
     with torch.no_grad():
         for batch in loader:
             metas.extend(batch[-1])
-            feat = batch[0].to(opt.device, non_blocking=True)
-            mask = batch[1].to(opt.device, non_blocking=True)
-            gi, ge = model.encode_context(feat, mask)
-            if keep_frame_feats:
-                inh.append(gi)
-                exp.append(ge)
-            else:
-                if packer is None:
-                    packer = scoring.GalleryPacker(len(eval_dataset), int(_cfg_get(model.config, "max_ctx_l")),
-                                                   2 if model.double_branch else 1, gi.device)
-                packer.add([gi, ge] if model.double_branch else [gi], mask)
-            masks.append(mask)
+            pend_f.append(batch[0].to(opt.device, non_blocking=True))
+            pend_m.append(batch[1].to(opt.device, non_blocking=True))
+            pend_n += batch[0].shape[0]
+            if pend_n >= CONTEXT_SUPER_BATCH:
+                flush()
+        flush()
 
     def cat(tensors):
         lmax = max(t.shape[1] for t in tensors)

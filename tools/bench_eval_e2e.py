@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "dl-dkd_amd"))
 import torch
 
 
-def stage_times(nv=21793, nq=10895, mode="fp32", dev="cuda:0"):
+def stage_times(nv=21793, nq=10895, mode="fp32", dev="cuda:0", B=None):
     from dldkd_amd.model import DLDKD
     from dldkd_amd import scoring, ops, eval as ev
     cfg = types.SimpleNamespace(visual_input_size=3072, query_input_size=768, inheritance_hidden=384, exploration_hidden=384,
@@ -27,9 +27,11 @@ def stage_times(nv=21793, nq=10895, mode="fp32", dev="cuda:0"):
         torch.cuda.synchronize()
         return time.perf_counter()
     out = {"mode": mode, "n_videos": nv, "n_queries": nq}
+    from dldkd_amd import eval as ev
     try:
         with torch.no_grad():
-            B, L = 200, 128
+            B = B or ev.CONTEXT_SUPER_BATCH          # videos per encode call (eval.py groups loader batches up to this)
+            L = 128
             feats = torch.nn.functional.normalize(torch.randn(B, L, 3072, generator=gen, device=dev), dim=-1)
             lens = torch.randint(24, L + 1, (B,), generator=gen, device=dev)
             mask = (torch.arange(L, device=dev).unsqueeze(0) < lens.unsqueeze(1)).float()
@@ -88,5 +90,6 @@ def stage_times(nv=21793, nq=10895, mode="fp32", dev="cuda:0"):
 if __name__ == "__main__":
     NV = int(sys.argv[1]) if len(sys.argv) > 1 else 21793
     NQ = int(sys.argv[2]) if len(sys.argv) > 2 else 10895
+    BB = int(os.environ.get("E2E_BATCH", "0")) or None
     for mode in (sys.argv[3:] or ["fp32", "fast"]):
-        print(stage_times(NV, NQ, mode))
+        print(stage_times(NV, NQ, mode, B=BB))
