@@ -228,6 +228,18 @@ def extras(dev):
                     m.encode_context(feats, mask)
                 torch.cuda.synchronize()
             out["gallery_encode_videos_per_s_all_bf16"] = B / ((time.perf_counter() - t0) / 5)
+            # the eval driver groups loader batches into 1024-video super-batches (eval.CONTEXT_SUPER_BATCH)
+            fb = torch.nn.functional.normalize(torch.randn(1024, Lc, 3072, device=dev), dim=-1)
+            mb = torch.ones(1024, Lc, device=dev)
+            with torch.no_grad():
+                m.encode_context(fb, mb)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    m.encode_context(fb, mb)
+                torch.cuda.synchronize()
+            out["gallery_encode_videos_per_s_all_bf16_superbatch1024"] = 1024 / ((time.perf_counter() - t0) / 3)
+            del fb, mb
         finally:
             ops.set_gemm_precision("fp32")
         # C5 (configs[4], one rank of the DDP job): Charades, 1024-d features, captions [3,2,2,...], dropout 0.15

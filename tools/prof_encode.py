@@ -14,11 +14,12 @@ m.fast_input_proj = len(sys.argv) > 1 and sys.argv[1] in ("fast", "allbf16")
 if len(sys.argv) > 1 and sys.argv[1] == "allbf16":
     from dldkd_amd import ops
     ops.set_gemm_precision("bf16")
-feats = torch.nn.functional.normalize(torch.randn(200, 128, 3072, device=DEV), dim=-1)
-mask = torch.ones(200, 128, device=DEV)
+NB = int(os.environ.get("ENC_BATCH", "200"))
+feats = torch.nn.functional.normalize(torch.randn(NB, 128, 3072, device=DEV), dim=-1)
+mask = torch.ones(NB, 128, device=DEV)
 with torch.no_grad():
     for _ in range(3): m.encode_context(feats, mask)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): m.encode_context(feats, mask)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-print(f"encode_context 200x128x3072 fast={m.fast_input_proj}: {dt*1e3:.2f} ms = {200/dt:.0f} videos/s")
+print(f"encode_context {NB}x128x3072 fast={m.fast_input_proj}: {dt*1e3:.2f} ms = {NB/dt:.0f} videos/s")
