@@ -67,8 +67,11 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
 // ---------------------------------------------------------------- LayerNorm backward
 // y = (x+add - mean) * rstd * gamma + beta.  dx (optional) = rstd * (g - mean(g) - xhat * mean(g * xhat)),
 // g = dy * gamma; dgamma += dy * xhat, dbeta += dy (atomics, one per column per workgroup).
-template <int MAXV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ add,
+// WAVES waves per workgroup: narrow rows (D <= 512) are latency-bound (4 dependent wave reductions per row), so they
+// run 16 waves x 4 rows per workgroup - the same 64 rows and the same atomic count as 4 waves x 16 rows, with 4x the
+// resident waves per SIMD to overlap the reductions.
+template <int MAXV, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                             int add_mod, const float* __restrict__ gamma,
                                                             const float* __restrict__ dy, float* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, long M,
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     f32x4 ag[MAXV], ab[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; }
-    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rows_per_wave;   // may be >= M: the wave then only joins the reduction
+    const long row0 = ((long)blockIdx.x * WAVES + (threadIdx.x >> 6)) * rows_per_wave;   // may be >= M: the wave then only joins the reduction
     for (long row = row0; row < row0 + rows_per_wave && row < M; ++row) {
         const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
         const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (add_mod > 0 ? row % add_mod : row) * D) : nullptr;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
     // dgamma / dbeta: combine the block's 4 waves in LDS, then ONE atomic per column per block (per-wave atomics
     // were 1.5M same-address adds per call: the contended case MI355X_MICROARCH.md measures at 14x slower).
-    extern __shared__ float ln_red[];            // [4 waves][2][D]
+    extern __shared__ float ln_red[];            // [WAVES][2][D]
     float* mine = ln_red + (size_t)(threadIdx.x >> 6) * 2 * D;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -153,8 +156,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * D; c += 256) {
-        const float v = ln_red[c] + ln_red[2 * D + c] + ln_red[4 * D + c] + ln_red[6 * D + c];
+    for (int c = threadIdx.x; c < 2 * D; c += 64 * WAVES) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) v += ln_red[(size_t)w * 2 * D + c];
         atomicAdd((c < D ? dgamma : dbeta - D) + c, v);
     }
 }
@@ -373,22 +378,26 @@ int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const
     if (M < 0 || D < 4 || (D & 3) || D > 4096) { set_error("layernorm_bwd: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0) return DLDKD_OK;
     if (!x || !gamma || !dy || !dgamma || !dbeta) { set_error("layernorm_bwd: null pointer"); return DLDKD_EINVAL; }
-    static const int rpw_env = getenv("DLDKD_LN_BWD_RPW") ? atoi(getenv("DLDKD_LN_BWD_RPW")) : 0;
-    const int rpw = rpw_env > 0 ? rpw_env : 16;  // rows per wave -> one atomic per column per 64 rows (after the in-block LDS combine)
-    const long waves = (M + rpw - 1) / rpw;
     const int nv = (D / 4 + 63) / 64;
     hipStream_t s = (hipStream_t)stream;
+    if (nv <= 2) {           // 16 waves x 4 rows per workgroup
+        const long waves = (M + 3) / 4;
+        hipLaunchKernelGGL((layernorm_bwd_kernel<2, 16>), dim3((unsigned)((waves + 15) / 16)), dim3(1024), (size_t)32 * D * sizeof(float), s,
+                           x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, 4);
+        return check_launch("layernorm_bwd");
+    }
+    const int rpw = 8;       // 4 waves x 8 rows
+    const long waves = (M + rpw - 1) / rpw;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     const size_t lds = (size_t)8 * D * sizeof(float);
     static const bool attr_ok = [] {
-        return hipFuncSetAttribute((const void*)layernorm_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4096 * 4) == hipSuccess &&
-               hipFuncSetAttribute((const void*)layernorm_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2048 * 4) == hipSuccess;
+        return hipFuncSetAttribute((const void*)layernorm_bwd_kernel<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4096 * 4) == hipSuccess &&
+               hipFuncSetAttribute((const void*)layernorm_bwd_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2048 * 4) == hipSuccess;
     }();
     (void)attr_ok;
-    if (nv <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
-    else if (nv <= 4) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
-    else if (nv <= 8) hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    if (nv <= 4) hipLaunchKernelGGL((layernorm_bwd_kernel<4, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    else if (nv <= 8) hipLaunchKernelGGL((layernorm_bwd_kernel<8, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    else hipLaunchKernelGGL((layernorm_bwd_kernel<16, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
     return check_launch("layernorm_bwd");
 }
 int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream) {
