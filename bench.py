@@ -336,6 +336,27 @@ def extras(dev):
     return out
 
 
+def mfma_sustained():
+    """tools/micro/mfma_peak (built by __graft_entry__.build()): the bf16 MFMA rate this chip sustains with REGISTER
+    operands only - no LDS, no memory - on all-zero and on random data, for the scorer's instruction.  On random data
+    the clock under load, not the issue rate, sets the ceiling; it is reported beside the spec peak, never instead of it."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "micro", "mfma_peak")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=120)
+        out = {}
+        for line in r.stdout.splitlines():
+            mm = re.match(r"(zero|random)\s+operands, mfma_(\S+):\s+[\d.]+ ms\s+(\d+) TFLOP/s", line)
+            if mm:
+                out[f"{mm.group(1)}_{mm.group(2)}"] = float(mm.group(3))
+        return out or None
+    except Exception:   # noqa: BLE001
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,6 +369,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    sustained = mfma_sustained() if (world == 1 and rank == 0) else None    # child process, before this one touches the GPU
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N (one rank per GPU)")
@@ -478,6 +500,9 @@ def main():
                          "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": flops_launch},
         }
+        if sustained and sustained.get("random_16x16x32"):
+            out["roofline"]["sustained_register_operand_mfma_TFLOPs"] = sustained
+            out["roofline"]["frac_of_sustained_random_data"] = achieved / sustained["random_16x16x32"]
         if world == 1 and overlap is None:
             out["recall_hip"] = dict(zip(("R@1", "R@5", "R@10", "R@100"), recalls(fused, gt)))
         if overlap is not None and world == 1:     # test hook: the chunked path must reproduce the one-launch matrix
