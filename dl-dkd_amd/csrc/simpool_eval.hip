@@ -362,7 +362,8 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
                         cur[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][ks], b[ks % kPF], cur[rt], 0, 0, 0);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                // (no fence here: the MFMAs, the ring read and the pool slice below form one scheduling region, see the
+                // sched_group_barrier sequence at its end)
                 // keep the B ring kPF k-steps ahead, across the sub-tile and the tile boundary (past the last
                 // tile this reads a stale ring slot: harmless, never consumed)
                 constexpr int idx = S * kKSteps16 + kPF + ks;
@@ -392,6 +393,15 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
                     m = xor32_max(m);
                 } else {
                     if (lane < 16) *prev_out = m;
+                }
+                // Place this k-step's pool slice (VALU) in the shadow of its MFMAs: groups of {2 MFMA, 2 VALU}.  With a hard
+                // fence between the 8 MFMAs and the slice (first version) the VALU issued after the last MFMA and only
+                // its 16-cycle shadow was free.  Same-box A/B at C2: 20.55-20.74 ms fenced, 20.07-20.20 ms {2,2};
+                // {1 MFMA, 1 VALU} x 8 gives nothing (20.70), {2,1} x 4 is equal to {2,2} (20.19).
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
