@@ -346,7 +346,7 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
 
         // one 16-query sub-tile: MFMAs into `cur`, max-pool of `prev` sliced between the k-steps
         auto subtile = [&](auto sub_c, f32x4 (&cur)[NRT], const f32x4 (&prev)[NRT], uint32_t cbase, uint32_t nbase,
-                           float* prev_out) {
+                           float* prev_out, const char* st_src, char* st_dst) {
             constexpr int S = decltype(sub_c)::value;
             auto step = [&](auto ks_c) {
                 constexpr int ks = decltype(ks_c)::value;
@@ -394,6 +394,11 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
                 } else {
                     if (lane < 16) *prev_out = m;
                 }
+                // one 1-KiB LDS-DMA piece of tile t+2 per k-step of sub-tile 0 (6 per wave) instead of all six at the top
+                // of the tile, where the MFMA pipe waited for their issue (same-box A/B: 20.27-20.42 -> 20.03-20.06 ms).
+                // They stay older than the tile's two result stores, so the vmcnt(2) before the next barrier still means
+                // "this DMA has landed".
+                if constexpr (S == 0 && ks < 6 && !(ABL & 2)) glds16(st_src + ks * 1024, st_dst + ks * 1024);
                 // Place this k-step's pool slice (VALU) in the shadow of its MFMAs: groups of {2 MFMA, 2 VALU}.  With a hard
                 // fence between the 8 MFMAs and the slice (first version) the VALU issued after the last MFMA and only
                 // its 16-cycle shadow was free.  Same-box A/B at C2: 20.55-20.74 ms fenced, 20.07-20.20 ms {2,2};
@@ -425,7 +430,10 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
             else if constexpr (!(ABL & 3)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (t == 0 || !(ABL & 4)) __builtin_amdgcn_s_barrier();
-            if constexpr (!(ABL & 2)) { if (t + 2 < T) stage(t + 2, slot2); }
+            // staging of tile t+2 is spread over the k-steps of sub-tile 0; past the end it re-stages tile T-1 into a free slot
+            const int t2 = t + 2 < T ? t + 2 : T - 1;
+            const char* st_src = qsrc + (size_t)t2 * kQTileBytes + (size_t)wave * 6 * 1024 + lane * 16;
+            char* st_dst = smem + slot2 * kQTileBytes + wave * 6 * 1024;
             const int nslot = slot == kRing - 1 ? 0 : slot + 1;
             const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
             const uint32_t cbase = smem_lds + slot * kQTileBytes + lane * 16;
@@ -439,8 +447,8 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
             }
             // t == 0: there is no previous sub-tile; its (garbage) result goes to queries 0..15, which the
             // next sub-tile's store - later in program order, same lanes, same addresses - overwrites.
-            subtile(std::integral_constant<int, 0>{}, accA, accB, cbase, nbase, outp + (t > 0 ? (size_t)t * kQTile - 16 : 0));
-            subtile(std::integral_constant<int, 1>{}, accB, accA, cbase, nbase, outp + (size_t)t * kQTile);
+            subtile(std::integral_constant<int, 0>{}, accA, accB, cbase, nbase, outp + (t > 0 ? (size_t)t * kQTile - 16 : 0), st_src, st_dst);
+            subtile(std::integral_constant<int, 1>{}, accB, accA, cbase, nbase, outp + (size_t)t * kQTile, st_src, st_dst);
             slot = nslot;
             slot2 = slot2 == kRing - 1 ? 0 : slot2 + 1;
         }
