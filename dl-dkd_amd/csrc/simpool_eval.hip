@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void pack_queries_kernel(const float* __restri
     }
 }
 
-// Gallery blob: row-major bf16 [nv][Lp][384], Lp = round_up(L, 32); rows l >= len_v are zero.
+// Gallery blob: row-major bf16 [nv][Lp][384], Lp = round_up(L, 32).  Rows l >= len_v inside the video's last 16-row tile
+// REPLICATE its last valid clip (their scores equal a real clip's, so the scorer's max-pool needs no padding mask);
+// rows beyond that tile are zero.
 // `out` points at the first video of this call; L is the row count of the SOURCE (g, mask), Lp the destination's.
 __global__ __launch_bounds__(256) void pack_gallery_kernel(const float* __restrict__ g, const float* __restrict__ mask,
                                                            int nv, int L, int Lp, int normalize,
@@ -83,13 +85,19 @@ __global__ __launch_bounds__(256) void pack_gallery_kernel(const float* __restri
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long)nv * Lp) return;
     const int v = (int)(row / Lp), l = (int)(row % Lp);
-    const bool valid = l < L && (mask == nullptr || mask[(size_t)v * L + l] > 0.f);
+    int len = L;                                  // masks are prefix masks (data_provider.py:81-84)
+    if (mask != nullptr) {
+        float c = 0.f;
+        for (int k = lane; k < L; k += 64) c += mask[(size_t)v * L + k] > 0.f ? 1.f : 0.f;
+        len = (int)wave_sum(c);
+    }
+    const int ls = l < len ? l : (len > 0 && l < ((len + 15) & ~15) ? len - 1 : -1);   // source clip, -1 = zero row
     float x[8];
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = 0.f;
-    if (valid && lane < kRowBf16x8) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(g + ((size_t)v * L + l) * kHidden + lane * 8);
+    if (ls >= 0 && lane < kRowBf16x8) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(g + ((size_t)v * L + ls) * kHidden + lane * 8);
         f32x4 a = src[0], b = src[1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { x[j] = a[j]; x[4 + j] = b[j]; }
@@ -329,9 +337,8 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
             slot2 = slot2 == kRing - 1 ? 0 : slot2 + 1;
         }
     } else {
-        // rows of the LAST row tile at or beyond `lim` (relative to this lane's 4-row group) are padding
-        const int lim = len - 16 * (NRT - 1) - 4 * (lane >> 4);
-        const bool ok0 = 0 < lim, ok1 = 1 < lim, ok2 = 2 < lim, ok3 = 3 < lim;
+        // no padding mask: rows of the last tile beyond `len` replicate the video's last valid clip (pack_gallery_kernel),
+        // so they can never change the maximum (same-box A/B against the masked form: 19.07 -> 18.94 ms)
         float* outp = p.part + ((size_t)branch * p.nv + vs) * p.nq_pad + (lane & 15);
         constexpr int V = NRT * 4;              // accumulator values per lane per sub-tile
         constexpr int kFoldSteps = 9;           // k-steps 0..8 fold the values, 9/10 cross lanes, 11 stores
@@ -381,10 +388,6 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
 #pragma unroll
                     for (int i = ks * kPer; i < (ks + 1) * kPer && i < V; ++i) {
                         float x = prev[i >> 2][i & 3];
-                        if ((i >> 2) == NRT - 1) {
-                            const bool ok = (i & 3) == 0 ? ok0 : (i & 3) == 1 ? ok1 : (i & 3) == 2 ? ok2 : ok3;
-                            x = ok ? x : -3.0e38f;
-                        }
                         m = fmaxf(m, x);
                     }
                 } else if constexpr (ks == 9) {
@@ -461,10 +464,6 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float x = accB[i >> 2][i & 3];
-            if ((i >> 2) == NRT - 1) {
-                const bool ok = (i & 3) == 0 ? ok0 : (i & 3) == 1 ? ok1 : (i & 3) == 2 ? ok2 : ok3;
-                x = ok ? x : -3.0e38f;
-            }
             m = fmaxf(m, x);
         }
         m = xor32_max(xor16_max(m));

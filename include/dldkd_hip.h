@@ -55,7 +55,9 @@ size_t dldkd_simpool_eval_workspace_bytes(int nq, int nv, int n_branches);
 int dldkd_pack_queries_bf16(const float* q, int nq, int normalize, void* q_packed, void* stream);
 
 /* g (nv, L, 384) fp32 + mask (nv, L) fp32 0/1 prefix masks (NULL = all valid) -> bf16 gallery blob,
- * lens[nv] int32 (number of valid clips, data_provider.py:81-84).  normalize as above (model.py:319). */
+ * lens[nv] int32 (number of valid clips, data_provider.py:81-84).  normalize as above (model.py:319).
+ * Blob layout: row-major bf16 [nv][round_up(L,32)][384]; rows past a video's length inside its last 16-row tile replicate
+ * its last valid clip (so the scorer needs no padding mask), rows beyond that tile are zero. */
 int dldkd_pack_gallery_bf16(const float* g, const float* mask, int nv, int L, int normalize,
                             void* g_packed, int32_t* lens, void* stream);
 
