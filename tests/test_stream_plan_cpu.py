@@ -68,3 +68,30 @@ def test_plan_rejects_bad_lengths():
     assert _plan([5, 0, 3], 32)[0] != 0
     assert _plan([5, 33], 32)[0] != 0
     assert _plan([129], 160)[0] != 0
+
+
+def test_plan_invariants_hypothesis():
+    """Property test over arbitrary length lists (hypothesis): the planner never loses, duplicates or reorders a clip,
+    never puts two segment ends in one tile, and every video ends up with 1-2 units that partition its rows."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(st.integers(min_value=1, max_value=128), min_size=1, max_size=120))
+    def check(lens):
+        rc, rowsrc, te, tu, tail, u0, u1, nw, nu = _plan(lens, 128)
+        assert rc == 0
+        used = rowsrc[:nw * 128]
+        valid = used[used >= 0]
+        assert (valid == np.concatenate([v * 128 + np.arange(n) for v, n in enumerate(lens)])).all()
+        ends = np.zeros(nw * 8, int)
+        pos = 0
+        where = {int(r): i for i, r in enumerate(used) if r >= 0}
+        for v, n in enumerate(lens):
+            s, e = where[v * 128], where[v * 128 + n - 1] + 1
+            assert e - s == n and s >= pos
+            pos = e
+            ends[(e - 1) // 16] += 1
+            two = s // 128 != (e - 1) // 128
+            assert (u1[v] >= 0) == two and u0[v] >= 0
+        assert ends.max() <= 1 and nu == len(lens) + int((u1 >= 0).sum())
+    check()
