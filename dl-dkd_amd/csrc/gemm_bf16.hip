@@ -230,7 +230,8 @@ extern "C" int dldkd_gemm_bf16(const float* A, const float* B, const float* bias
     GemmHArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
     const int tiles = ((N + HBN_ - 1) / HBN_) * ((M + HBM_ - 1) / HBM_);
     const int nk = (K + HBK_ - 1) / HBK_;
-    if (!bias && !relu && ldc == N && tiles < 128 && nk >= 16) {
+    // (never for the forward layout: split-K accumulates with unordered fp32 atomics; the forward pass must be reproducible)
+    if ((a_kmajor || b_kmajor) && !bias && !relu && ldc == N && tiles < 128 && nk >= 16) {
         int split = (256 + tiles - 1) / tiles;   // one block per CU: more splits only add atomics (measured)
         if (split > nk / 4) split = nk / 4;
         if (split > 1) {

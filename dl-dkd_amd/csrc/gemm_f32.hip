@@ -241,7 +241,9 @@ extern "C" int dldkd_gemm_f32(const float* A, const float* B, const float* bias,
     // split-K when the output grid cannot fill the chip and K is long (weight gradients, dq of the clip scores)
     const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
     const int nk = (K + BK - 1) / BK;
-    if (!bias && !relu && ldc == N && tiles < 128 && nk >= 32) {
+    // (never for the forward layout: split-K accumulates with unordered fp32 atomics, and the forward pass - hence the losses -
+    // must be bitwise reproducible run to run)
+    if ((a_kmajor || b_kmajor) && !bias && !relu && ldc == N && tiles < 128 && nk >= 32) {
         int split = (512 + tiles - 1) / tiles;
         if (split > nk / 8) split = nk / 8;
         if (split > 1) {

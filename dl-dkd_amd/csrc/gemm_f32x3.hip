@@ -256,7 +256,9 @@ extern "C" int dldkd_gemm_f32x3(const float* A, const float* B, const float* bia
     GemmXArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
     const int tiles = ((N + XBN - 1) / XBN) * ((M + XBM - 1) / XBM);
     const int nk = (K + XBK - 1) / XBK;
-    if (!bias && !relu && ldc == N && tiles < 128 && nk >= 32) {
+    // (never for the forward layout: split-K accumulates with unordered fp32 atomics, and the forward pass - hence the losses -
+    // must be bitwise reproducible run to run)
+    if ((a_kmajor || b_kmajor) && !bias && !relu && ldc == N && tiles < 128 && nk >= 32) {
         int split = (256 + tiles - 1) / tiles;
         if (split > nk / 8) split = nk / 8;
         if (split > 1) {
