@@ -321,24 +321,46 @@ __global__ __launch_bounds__(512, 2) void rows_linear_bf16_kernel(const InProjAr
         __syncthreads();
     }
 
+    // Epilogue through LDS: the accumulator layout puts 32 consecutive COLUMNS of one row on 32 lanes, i.e. 128-byte
+    // row segments as 4-byte stores.  Each wave instead parks one 32-row x 96-column tile at a time in its private LDS
+    // region (the W' / x buffers are dead after the last barrier) and writes it back as float4: 24 lanes cover the
+    // 384 contiguous bytes a row has in this wave's column range.
+    constexpr int SP = 104;                                  // staging pitch (floats): the two lane halves hit disjoint banks
+    float* stg = reinterpret_cast<float*>(lds_full) + wave * (32 * SP);
+    const int n0w = wc * 96;                                 // 96 divides 384: a wave's columns belong to one output
+    float* outb = p.y[n0w / kHidden] + (n0w % kHidden);
+    float csn[3], bbn[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int n = wc * 96 + 32 * j + (lane & 31);
-        float* out = p.y[n / kHidden] + (n % kHidden);
-        const float csn = LNFOLD ? p.cs[n] : 0.f, bbn = p.bb[n];
+        const int n = n0w + 32 * j + (lane & 31);
+        csn[j] = LNFOLD ? p.cs[n] : 0.f;
+        bbn[j] = p.bb[n];
+    }
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+    for (int i = 0; i < RT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ml = wr * (FBM / WR) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m0 + ml < p.M) {
-                    float v;
-                    if constexpr (LNFOLD) v = s_rstd[ml] * (acc[i][j][r] - s_mean[ml] * csn) + bbn;
-                    else v = acc[i][j][r] + bbn;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    out[(size_t)(m0 + ml) * p.ldy] = v;
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);       // row inside the 32-row tile
+                float v;
+                if constexpr (LNFOLD) {
+                    const int ml = wr * (FBM / WR) + 32 * i + rl;
+                    v = s_rstd[ml] * (acc[i][j][r] - s_mean[ml] * csn[j]) + bbn[j];
+                } else {
+                    v = acc[i][j][r] + bbn[j];
                 }
+                if (p.relu) v = fmaxf(v, 0.f);
+                stg[rl * SP + 32 * j + (lane & 31)] = v;
             }
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            const int idx = lane + 64 * it;                  // 768 float4 per tile
+            const int rl = idx / 24, c4 = idx % 24;
+            const long mrow = m0 + wr * (FBM / WR) + 32 * i + rl;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * SP + 4 * c4);
+            if (mrow < p.M) *reinterpret_cast<f32x4*>(outb + (size_t)mrow * p.ldy + 4 * c4) = v;
+        }
     }
 }
 
@@ -419,7 +441,7 @@ int dldkd_linear_rows_bf16(const float* x, const void* Wfrag, const float* bb, f
         (void)ok;
         hipLaunchKernelGGL((rows_linear_bf16_kernel<1, false>), grid, dim3(512), lds, (hipStream_t)stream, p);
     } else {
-        constexpr int lds = FW_TILE_BYTES + 2 * FBM * FPITCH * 2 + 2 * FBM * 4;
+        constexpr int lds = 8 * 32 * 104 * 4;     // the epilogue staging (104 KiB) exceeds the k-loop's 68 KiB
         static const bool ok = [] { return hipFuncSetAttribute((const void*)rows_linear_bf16_kernel<2, false>,
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess; }();
         (void)ok;
