@@ -45,6 +45,61 @@ __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_base_uni
         16, 0, 0);
 }
 
+
+// Epilogue of the 128x128-block / 64x64-per-wave MFMA GEMMs: C = act(alpha * acc + bias).  The 32x32 accumulator layout puts
+// 32 consecutive COLUMNS of one row on 32 lanes (128-byte row segments as 4-byte stores).  When the wave's 64 columns are
+// all in range and rows are 16-byte aligned, each 32 x 64 half is parked in the wave's private LDS region (the operand
+// tiles are dead after the k-loop's last barrier) and written back as float4: 16 lanes cover 256 contiguous bytes of a row.
+// Split-K launches (atomics) and ragged edges keep the element-wise path.
+template <typename Args>
+__device__ __forceinline__ void gemm_store_tile(const f32x16 (&acc)[2][2], const Args& p, int m0, int n0, int wm, int wn, int lane,
+                                                float* stg /* 32 x 72 floats, private to the wave */) {
+    constexpr int SP = 72;
+    const bool fast = p.split_k <= 1 && !(p.ldc & 3) && !((uintptr_t)p.C & 15) && n0 + wn + 64 <= p.N;
+    if (fast) {
+        float bias[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bias[j] = p.bias ? p.bias[n0 + wn + 32 * j + (lane & 31)] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] * p.alpha + bias[j];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SP + 32 * j + (lane & 31)] = v;
+                }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = lane + 64 * it, rl = idx >> 4, c4 = idx & 15;
+                const int m = m0 + wm + 32 * i + rl;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * SP + 4 * c4);
+                if (m < p.M) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n0 + wn + 4 * c4) = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + 32 * j + (lane & 31);
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) {
+                    float v = acc[i][j][r] * p.alpha + bias;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.split_k > 1) atomicAdd(p.C + (size_t)m * p.ldc + n, v);
+                    else p.C[(size_t)m * p.ldc + n] = v;
+                }
+            }
+    }
+}
+
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 

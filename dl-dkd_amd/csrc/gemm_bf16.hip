@@ -177,24 +177,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmHArgs p) {
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn + 32 * j + (lane & 31);
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) {
-                    float v = acc[i][j][r] * p.alpha + bias;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.split_k > 1) atomicAdd(p.C + (size_t)m * p.ldc + n, v);
-                    else p.C[(size_t)m * p.ldc + n] = v;
-                }
-            }
-    }
+    // (the k-loop ended with a barrier: every wave is done with the operand tiles, the LDS is free for staging)
+    gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(lds_raw) + wave * (32 * 72));
 }
 
 static int launch_gemm_h(GemmHArgs p, int batch, int a_kmajor, int b_kmajor, void* stream) {

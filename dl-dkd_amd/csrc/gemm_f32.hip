@@ -132,7 +132,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         p.B += zo * p.sBo + zi * p.sBi;
         p.C += zo * p.sCo + zi * p.sCi;
     }
-    __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_WORDS];   // [buffer][A|B]
+    // [buffer][A|B] operand tiles; sized to also hold the epilogue staging (4 waves x 32 x 72 floats)
+    constexpr int kLdsWords = 4 * TILE_WORDS > 4 * 32 * 72 ? 4 * TILE_WORDS : 4 * 32 * 72;
+    __shared__ __attribute__((aligned(16))) float lds_raw[kLdsWords];
+    float (*lds)[2][TILE_WORDS] = reinterpret_cast<float (*)[2][TILE_WORDS]>(lds_raw);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -192,26 +195,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    // epilogue: lane owns column n, rows (r&3) + 8(r>>2) + 4(lane>>5) of each 32x32 tile
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn + 32 * j + (lane & 31);
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) {
-                    float v = acc[i][j][r] * p.alpha + bias;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.split_k > 1) atomicAdd(p.C + (size_t)m * p.ldc + n, v);
-                    else p.C[(size_t)m * p.ldc + n] = v;
-                }
-            }
-        }
-    }
+    // (the k-loop ended with a barrier: every wave is done with the operand tiles, the LDS is free for staging)
+    gemm_store_tile(acc, p, m0, n0, wm, wn, lane, lds_raw + wave * (32 * 72));
 }
 
 }  // namespace dldkd
