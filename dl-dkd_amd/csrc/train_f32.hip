@@ -391,12 +391,11 @@ int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     const size_t lds = (size_t)8 * D * sizeof(float);
     static const bool attr_ok = [] {
-        return hipFuncSetAttribute((const void*)layernorm_bwd_kernel<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4096 * 4) == hipSuccess &&
-               hipFuncSetAttribute((const void*)layernorm_bwd_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2048 * 4) == hipSuccess;
+        return hipFuncSetAttribute((const void*)layernorm_bwd_kernel<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4096 * 4) == hipSuccess;
     }();
     (void)attr_ok;
     if (nv <= 4) hipLaunchKernelGGL((layernorm_bwd_kernel<4, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
-    else if (nv <= 8) hipLaunchKernelGGL((layernorm_bwd_kernel<8, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    // (no MAXV = 8 instantiation: hipcc spilled 248 registers in it; rows of 1028..2048 floats use the 16-wide form)
     else hipLaunchKernelGGL((layernorm_bwd_kernel<16, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
     return check_launch("layernorm_bwd");
 }

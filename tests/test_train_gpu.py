@@ -350,3 +350,24 @@ def test_loss_kernels_fuzz_vs_oracle():
             tv.backward()
             to.backward()
             _gclose(C.grad, Co.grad)
+
+
+@pytest.mark.parametrize("M,D", [(70, 64), (1000, 384), (257, 768), (300, 1024), (129, 1540), (200, 2048), (130, 3072), (65, 4096)])
+def test_layernorm_forward_backward_all_widths(M, D):
+    """Every template instantiation of the LayerNorm kernels (2 / 4 / 16 float4 per lane, 16- and 4-wave workgroups)
+    against fp64 autograd, with and without the residual input."""
+    from dldkd_amd import functional as F_
+    g = torch.Generator().manual_seed(M + D)
+    x, add = torch.randn(M, D, generator=g), torch.randn(M, D, generator=g)
+    gam, bet = 1 + 0.3 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    cot = torch.randn(M, D, generator=g)
+    for use_add in (False, True):
+        xs = [t.to(DEV).requires_grad_(True) for t in (x, gam, bet, add)]
+        y = F_.layernorm(xs[0], xs[1], xs[2], add=xs[3] if use_add else None, add_mod=0)
+        (y * cot.to(DEV)).sum().backward()
+        xo = [t.double().requires_grad_(True) for t in (x, gam, bet, add)]
+        yo = torch.nn.functional.layer_norm(xo[0] + (xo[3] if use_add else 0), (D,), xo[1], xo[2], 1e-5)
+        (yo * cot.double()).sum().backward()
+        assert (y.double().cpu() - yo.detach()).abs().max().item() < 2e-5
+        for a, b in zip(xs[:3] + ([xs[3]] if use_add else []), xo[:3] + ([xo[3]] if use_add else [])):
+            _gclose(a.grad, b.grad, tol=1e-3)
