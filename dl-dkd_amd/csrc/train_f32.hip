@@ -177,6 +177,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     atomicAdd(out + c, s);
 }
 
+// Wave-per-64-columns form: a wave reads 256 contiguous bytes of a row, 4 waves take interleaved rows of a 128-row slab,
+// combine in LDS, and issue ONE atomic per column per slab on 64 consecutive addresses.
+__global__ __launch_bounds__(256) void colsum64_kernel(const float* __restrict__ x, float* __restrict__ out, long M, long N) {
+    __shared__ float red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long c = (long)blockIdx.x * 64 + lane;
+    const long r0 = (long)blockIdx.y * 128;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < N) {
+        const long r1 = r0 + 128 < M ? r0 + 128 : M;
+        long r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {          // 4 independent loads in flight per lane
+            s0 += x[r * N + c];
+            s1 += x[(r + 4) * N + c];
+            s2 += x[(r + 8) * N + c];
+            s3 += x[(r + 12) * N + c];
+        }
+        for (; r < r1; r += 4) s0 += x[r * N + c];
+    }
+    const float s = (s0 + s1) + (s2 + s3);
+    if (wave > 0) red[wave - 1][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < N) atomicAdd(out + c, s + red[0][lane] + red[1][lane] + red[2][lane]);
+}
+
 __global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n && !(y[i] > 0.f)) dy[i] = 0.f;
@@ -402,6 +427,11 @@ int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const
 int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream) {
     if (M < 0 || N < 0) { set_error("colsum: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0 || N == 0) return DLDKD_OK;
+    if (M >= 512 && (M + 127) / 128 <= 65535) {
+        hipLaunchKernelGGL(colsum64_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 127) / 128)), dim3(256), 0,
+                           (hipStream_t)stream, x, out, M, N);
+        return check_launch("colsum64");
+    }
     const int rpb = 64;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((M + rpb - 1) / rpb)), dim3(256), 0,
                        (hipStream_t)stream, x, out, M, N, rpb);
