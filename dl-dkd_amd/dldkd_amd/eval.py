@@ -14,7 +14,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import native, scoring
-from .data import collate_frame_val, collate_text_val
+from .data import collate_frame_val, collate_text_val, host_threads
 
 logger = logging.getLogger(__name__)
 
@@ -157,7 +157,7 @@ def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
         masks.append(mask)
         pend_f, pend_m, pend_n = [], [], 0
 
-    with torch.no_grad():
+    with torch.no_grad(), host_threads():
         for batch in loader:
             metas.extend(batch[-1])
             pend_f.append(batch[0].to(opt.device, non_blocking=True))
@@ -219,7 +219,7 @@ def _encode_all_queries(model, eval_dataset, opt):
             qe.append(b.reshape(pend_n, -1))
         pend_f, pend_m, pend_n = [], [], 0
 
-    with torch.no_grad():
+    with torch.no_grad(), host_threads():
         for batch in loader:
             metas.extend(batch[-1])
             pend_f.append(batch[0].to(opt.device, non_blocking=True))
@@ -295,6 +295,11 @@ def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=Fal
 
 def eval_epoch(model, val_video_dataset, val_text_dataset, opt, test=False):
     """SumR (R@1 + R@5 + R@10 + R@100) of the fused scores; logs the three rankings (eval.py:237-263)."""
+    with host_threads():
+        return _eval_epoch(model, val_video_dataset, val_text_dataset, opt, test)
+
+
+def _eval_epoch(model, val_video_dataset, val_text_dataset, opt, test=False):
     model.eval()
     logger.info("Computing scores")
     context_info = compute_context_info(model, val_video_dataset, opt, keep_frame_feats=False)

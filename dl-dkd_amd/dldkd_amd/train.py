@@ -86,6 +86,12 @@ def train_step(model, batch, optimizer, opt):
 
 def train_epoch(model, train_loader, optimizer, opt, epoch_i, training=True):
     """One epoch (train.py:52-183).  Returns the mean of every loss entry."""
+    from .data import host_threads
+    with host_threads():
+        return _train_epoch(model, train_loader, optimizer, opt, epoch_i, training)
+
+
+def _train_epoch(model, train_loader, optimizer, opt, epoch_i, training=True):
     model.train(mode=training)
     if opt.hard_negative_start_epoch != -1 and epoch_i >= opt.hard_negative_start_epoch:
         model.set_hard_negative(True, opt.hard_pool_size)
