@@ -50,12 +50,13 @@ __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_base_uni
 // 32 consecutive COLUMNS of one row on 32 lanes (128-byte row segments as 4-byte stores).  When the wave's 64 columns are
 // all in range and rows are 16-byte aligned, each 32 x 64 half is parked in the wave's private LDS region (the operand
 // tiles are dead after the k-loop's last barrier) and written back as float4: 16 lanes cover 256 contiguous bytes of a row.
-// Split-K launches (atomics) and ragged edges keep the element-wise path.
+// Ragged edges keep the element-wise path.  Split-K launches write their partial plane the same way (C then points into
+// the split-K workspace, one plane per blockIdx.z) and a reduce pass sums the planes.
 template <typename Args>
 __device__ __forceinline__ void gemm_store_tile(const f32x16 (&acc)[2][2], const Args& p, int m0, int n0, int wm, int wn, int lane,
                                                 float* stg /* 32 x 72 floats, private to the wave */) {
     constexpr int SP = 72;
-    const bool fast = p.split_k <= 1 && !(p.ldc & 3) && !((uintptr_t)p.C & 15) && n0 + wn + 64 <= p.N;
+    const bool fast = !(p.ldc & 3) && !((uintptr_t)p.C & 15) && n0 + wn + 64 <= p.N;   // split-K planes are plain stores too
     if (fast) {
         float bias[2];
 #pragma unroll
@@ -93,13 +94,14 @@ __device__ __forceinline__ void gemm_store_tile(const f32x16 (&acc)[2][2], const
                 if (m < p.M) {
                     float v = acc[i][j][r] * p.alpha + bias;
                     if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.split_k > 1) atomicAdd(p.C + (size_t)m * p.ldc + n, v);
-                    else p.C[(size_t)m * p.ldc + n] = v;
+                    p.C[(size_t)m * p.ldc + n] = v;
                 }
             }
     }
 }
 
+float* splitk_workspace(size_t floats);
+int launch_splitk_reduce(const float* ws, float* out, int split, long n, hipStream_t s);
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 

@@ -114,7 +114,9 @@ template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmHArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_raw[];
     unsigned short (*lds)[2][HBM_ * HPITCH] = reinterpret_cast<unsigned short (*)[2][HBM_ * HPITCH]>(lds_raw);
-    if (p.split_k <= 1) {
+    if (p.split_k > 1) {
+        p.C += (size_t)blockIdx.z * p.M * p.ldc;      // this split's partial plane in the workspace
+    } else {
         const int zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
         p.A += zo * p.sAo + zi * p.sAi;
         p.B += zo * p.sBo + zi * p.sBi;
@@ -215,14 +217,19 @@ extern "C" int dldkd_gemm_bf16(const float* A, const float* B, const float* bias
     const int tiles = ((N + HBN_ - 1) / HBN_) * ((M + HBM_ - 1) / HBM_);
     const int nk = (K + HBK_ - 1) / HBK_;
     // (never for the forward layout: split-K accumulates with unordered fp32 atomics; the forward pass must be reproducible)
-    if ((a_kmajor || b_kmajor) && !bias && !relu && ldc == N && tiles < 128 && nk >= 16) {
-        int split = (256 + tiles - 1) / tiles;   // one block per CU: more splits only add atomics (measured)
+    if ((a_kmajor || b_kmajor) && !bias && !relu && ldc == N && !(((long)M * N) & 3) && !((uintptr_t)C & 15) && tiles < 128 && nk >= 16) {
+        int split = (256 + tiles - 1) / tiles;   // one block per CU
         if (split > nk / 4) split = nk / 4;
         if (split > 1) {
             p.k_tiles_per_split = (nk + split - 1) / split;
             p.split_k = (nk + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
-            if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, (hipStream_t)stream) != hipSuccess) return check_launch("gemm_bf16 memset");
-            return launch_gemm_h(p, p.split_k, a_kmajor, b_kmajor, stream);
+            // partial planes [split][M][N] in the cached workspace (plain stores), then one reduce pass into C
+            float* ws = splitk_workspace((size_t)p.split_k * M * N);
+            if (!ws) return DLDKD_ELAUNCH;
+            p.C = ws;
+            const int rc = launch_gemm_h(p, p.split_k, a_kmajor, b_kmajor, stream);
+            if (rc != DLDKD_OK) return rc;
+            return launch_splitk_reduce(ws, C, p.split_k, (long)M * N, (hipStream_t)stream);
         }
     }
     return launch_gemm_h(p, 1, a_kmajor, b_kmajor, stream);

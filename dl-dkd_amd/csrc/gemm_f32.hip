@@ -126,7 +126,9 @@ struct TileIO {
 
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
-    if (p.split_k <= 1) {
+    if (p.split_k > 1) {
+        p.C += (size_t)blockIdx.z * p.M * p.ldc;      // this split's partial plane in the workspace
+    } else {
         const int zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
         p.A += zo * p.sAo + zi * p.sAi;
         p.B += zo * p.sBo + zi * p.sBi;
@@ -228,15 +230,19 @@ extern "C" int dldkd_gemm_f32(const float* A, const float* B, const float* bias,
     const int nk = (K + BK - 1) / BK;
     // (never for the forward layout: split-K accumulates with unordered fp32 atomics, and the forward pass - hence the losses -
     // must be bitwise reproducible run to run)
-    if ((a_kmajor || b_kmajor) && !bias && !relu && ldc == N && tiles < 128 && nk >= 32) {
+    if ((a_kmajor || b_kmajor) && !bias && !relu && ldc == N && !(((long)M * N) & 3) && !((uintptr_t)C & 15) && tiles < 128 && nk >= 32) {
         int split = (512 + tiles - 1) / tiles;
         if (split > nk / 8) split = nk / 8;
         if (split > 1) {
             p.k_tiles_per_split = (nk + split - 1) / split;
             p.split_k = (nk + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
-            if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, (hipStream_t)stream) != hipSuccess)
-                return check_launch("gemm_f32 memset");
-            return launch_gemm(p, p.split_k, a_kmajor, b_kmajor, stream);
+            // partial planes [split][M][N] in the cached workspace (plain stores), then one reduce pass into C
+            float* ws = splitk_workspace((size_t)p.split_k * M * N);
+            if (!ws) return DLDKD_ELAUNCH;
+            p.C = ws;
+            const int rc = launch_gemm(p, p.split_k, a_kmajor, b_kmajor, stream);
+            if (rc != DLDKD_OK) return rc;
+            return launch_splitk_reduce(ws, C, p.split_k, (long)M * N, (hipStream_t)stream);
         }
     }
     return launch_gemm(p, 1, a_kmajor, b_kmajor, stream);
