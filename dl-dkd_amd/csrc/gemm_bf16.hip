@@ -218,7 +218,10 @@ extern "C" int dldkd_gemm_bf16(const float* A, const float* B, const float* bias
     const int nk = (K + HBK_ - 1) / HBK_;
     // (never for the forward layout: split-K accumulates with unordered fp32 atomics; the forward pass must be reproducible)
     if ((a_kmajor || b_kmajor) && !bias && !relu && ldc == N && !(((long)M * N) & 3) && !((uintptr_t)C & 15) && tiles < 128 && nk >= 16) {
-        int split = (256 + tiles - 1) / tiles;   // one block per CU
+        // blocks to aim for: two workgroups fit a CU; more splits mean more partial planes to write and reduce.  Measured
+        // (dW shapes of the C3 step): 384 is best for outputs of >= 400k elements (in-proj dW 158 -> 121 us), 256 below.
+        const int target = (long)M * N >= 400000 ? 384 : 256;
+        int split = (target + tiles - 1) / tiles;
         if (split > nk / 4) split = nk / 4;
         if (split > 1) {
             p.k_tiles_per_split = (nk + split - 1) / split;
