@@ -82,8 +82,8 @@ class _LayerNorm(Function):
         dy = _f32(dy)
         need_dx = ctx.needs_input_grad[0] or (add is not None and ctx.needs_input_grad[3])
         dx = torch.empty_like(x) if need_dx else None
-        dg = torch.zeros(D, dtype=torch.float32, device=x.device)
-        db = torch.zeros(D, dtype=torch.float32, device=x.device)
+        dgb = torch.zeros(2, D, dtype=torch.float32, device=x.device)      # one fill for both accumulators
+        dg, db = dgb[0], dgb[1]
         native.check(_L().dldkd_layernorm_bwd_f32(_p(x.reshape(-1, D)), _p(add), ctx.add_mod, _p(gamma), _p(dy.reshape(-1, D)),
                                                   _p(dx), _p(dg), _p(db), x.numel() // D, D, ops.LN_EPS, _s()), "layernorm_bwd")
         dadd = None
