@@ -28,8 +28,8 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(b) << 16);
 }
 
-template <int NKT>   // key tiles of 32
-__device__ __forceinline__ void attention_bf16_body(const float* __restrict__ qkv, const float* __restrict__ mask,
+template <int NKT, bool QKV16>   // key tiles of 32; QKV16: q|k|v arrive as bf16 (written by linear_rows with out_bf16)
+__device__ __forceinline__ void attention_bf16_body(const void* __restrict__ qkv_v, const float* __restrict__ mask,
                                                     float* __restrict__ out, int L, char* smem) {
     constexpr int LP = NKT * 32;
     constexpr int VP = LP + 8;       // V^T pitch (keys per d row)
@@ -39,23 +39,32 @@ __device__ __forceinline__ void attention_bf16_body(const float* __restrict__ qk
     unsigned short* Ks = Qs + LP * aQKP;                            // [LP][aQKP]
     unsigned short* Vt = Ks + LP * aQKP;                            // [96][VP]
     float* Ms = reinterpret_cast<float*>(Vt + aDh * VP);            // [LP] additive key mask
-    const float* base = qkv + (size_t)n * L * (3 * 384) + head * aDh;
     for (int i = tid; i < LP * 24; i += 256) {
         const int row = i / 24, c = i % 24;
-        f32x4 q = {0.f, 0.f, 0.f, 0.f}, k = q, v = q;
+        uint2 pq = {0u, 0u}, pk = pq, pv = pq;
         if (row < L) {
-            const float* r = base + (size_t)row * (3 * 384) + c * 4;
-            q = *reinterpret_cast<const f32x4*>(r);
-            k = *reinterpret_cast<const f32x4*>(r + 384);
-            v = *reinterpret_cast<const f32x4*>(r + 768);
+            const size_t off = ((size_t)n * L + row) * (3 * 384) + head * aDh + c * 4;
+            if constexpr (QKV16) {
+                const unsigned short* r = reinterpret_cast<const unsigned short*>(qkv_v) + off;
+                pq = *reinterpret_cast<const uint2*>(r);
+                pk = *reinterpret_cast<const uint2*>(r + 384);
+                pv = *reinterpret_cast<const uint2*>(r + 768);
+            } else {
+                const float* r = reinterpret_cast<const float*>(qkv_v) + off;
+                const f32x4 q = *reinterpret_cast<const f32x4*>(r);
+                const f32x4 k = *reinterpret_cast<const f32x4*>(r + 384);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(r + 768);
+                pq.x = pack2(q[0], q[1]); pq.y = pack2(q[2], q[3]);
+                pk.x = pack2(k[0], k[1]); pk.y = pack2(k[2], k[3]);
+                pv.x = pack2(v[0], v[1]); pv.y = pack2(v[2], v[3]);
+            }
         }
-        uint2 pq, pk;
-        pq.x = pack2(q[0], q[1]); pq.y = pack2(q[2], q[3]);
-        pk.x = pack2(k[0], k[1]); pk.y = pack2(k[2], k[3]);
         *reinterpret_cast<uint2*>(Qs + row * aQKP + c * 4) = pq;
         *reinterpret_cast<uint2*>(Ks + row * aQKP + c * 4) = pk;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Vt[(c * 4 + e) * VP + row] = f32_to_bf16_bits(v[e]);
+        Vt[(c * 4 + 0) * VP + row] = (unsigned short)(pv.x & 0xFFFFu);
+        Vt[(c * 4 + 1) * VP + row] = (unsigned short)(pv.x >> 16);
+        Vt[(c * 4 + 2) * VP + row] = (unsigned short)(pv.y & 0xFFFFu);
+        Vt[(c * 4 + 3) * VP + row] = (unsigned short)(pv.y >> 16);
     }
     for (int i = tid; i < LP; i += 256)
         Ms[i] = i < L ? (mask ? (1.f - mask[(size_t)n * L + i]) * -10000.f : 0.f) : -INFINITY;
@@ -142,15 +151,16 @@ __device__ __forceinline__ void attention_bf16_body(const float* __restrict__ qk
     }
 }
 
-__global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
+template <bool QKV16>
+__global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const void* __restrict__ qkv, const float* __restrict__ mask,
                                                                  float* __restrict__ out, int L) {
     extern __shared__ __attribute__((aligned(16))) char smem_a[];
     const int nkt = (L + 31) >> 5;
     switch (nkt) {
-        case 1: attention_bf16_body<1>(qkv, mask, out, L, smem_a); break;
-        case 2: attention_bf16_body<2>(qkv, mask, out, L, smem_a); break;
-        case 3: attention_bf16_body<3>(qkv, mask, out, L, smem_a); break;
-        default: attention_bf16_body<4>(qkv, mask, out, L, smem_a); break;
+        case 1: attention_bf16_body<1, QKV16>(qkv, mask, out, L, smem_a); break;
+        case 2: attention_bf16_body<2, QKV16>(qkv, mask, out, L, smem_a); break;
+        case 3: attention_bf16_body<3, QKV16>(qkv, mask, out, L, smem_a); break;
+        default: attention_bf16_body<4, QKV16>(qkv, mask, out, L, smem_a); break;
     }
 }
 
@@ -158,17 +168,19 @@ __global__ __launch_bounds__(256) void attention_fwd_bf16_kernel(const float* __
 
 using namespace dldkd;
 
-extern "C" int dldkd_attention_fwd_bf16(const float* qkv, const float* mask, float* out, int N, int L, void* stream) {
+extern "C" int dldkd_attention_fwd_bf16(const void* qkv, const float* mask, float* out, int N, int L, int qkv_is_bf16, void* stream) {
     if (N < 0 || L < 1 || L > aLmax) { set_error("attention_bf16: bad sizes N=%d L=%d (L <= %d)", N, L, aLmax); return DLDKD_EINVAL; }
     if (N == 0) return DLDKD_OK;
     if (!qkv || !out) { set_error("attention_bf16: null pointer"); return DLDKD_EINVAL; }
     const int LP = ((L + 31) / 32) * 32;
     const size_t lds = (size_t)(2 * LP * aQKP + aDh * (LP + 8)) * 2 + (size_t)LP * 4;
     static const bool attr_ok = [] {
-        return hipFuncSetAttribute((const void*)attention_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (2 * aLmax * aQKP + aDh * (aLmax + 8)) * 2 + aLmax * 4) == hipSuccess;
+        constexpr int mx = (2 * aLmax * aQKP + aDh * (aLmax + 8)) * 2 + aLmax * 4;
+        return hipFuncSetAttribute((const void*)attention_fwd_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) == hipSuccess &&
+               hipFuncSetAttribute((const void*)attention_fwd_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) == hipSuccess;
     }();
     (void)attr_ok;
-    hipLaunchKernelGGL(attention_fwd_bf16_kernel, dim3(N * aHeads), dim3(256), lds, (hipStream_t)stream, qkv, mask, out, L);
+    if (qkv_is_bf16) hipLaunchKernelGGL(attention_fwd_bf16_kernel<true>, dim3(N * aHeads), dim3(256), lds, (hipStream_t)stream, qkv, mask, out, L);
+    else hipLaunchKernelGGL(attention_fwd_bf16_kernel<false>, dim3(N * aHeads), dim3(256), lds, (hipStream_t)stream, qkv, mask, out, L);
     return check_launch("attention_fwd_bf16");
 }

@@ -56,7 +56,8 @@ struct InProjArgs {
     int N, K;
     float eps;
     int relu;
-    int ldy;               // row stride of y[*] in floats (full-row kernels; the tiled kernel writes 384-wide rows)
+    int ldy;               // row stride of y[*] in elements (full-row kernels; the tiled kernel writes 384-wide rows)
+    int out_bf16;          // full-row kernels: y[*] are bf16 buffers (q|k|v for attention_fwd_bf16, which rounds them anyway)
 };
 
 // BN = 256 (two branches, N = 768: three column tiles per row block) or 128 (one branch, N = 384).
@@ -353,13 +354,29 @@ __global__ __launch_bounds__(512, 2) void rows_linear_bf16_kernel(const InProjAr
                 if (p.relu) v = fmaxf(v, 0.f);
                 stg[rl * SP + 32 * j + (lane & 31)] = v;
             }
+        if (p.out_bf16) {                                     // 8 columns = one 16-byte store per lane
+            unsigned short* outh = reinterpret_cast<unsigned short*>(p.y[n0w / kHidden]) + (n0w % kHidden);
 #pragma unroll
-        for (int it = 0; it < 12; ++it) {
-            const int idx = lane + 64 * it;                  // 768 float4 per tile
-            const int rl = idx / 24, c4 = idx % 24;
-            const long mrow = m0 + wr * (FBM / WR) + 32 * i + rl;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * SP + 4 * c4);
-            if (mrow < p.M) *reinterpret_cast<f32x4*>(outb + (size_t)mrow * p.ldy + 4 * c4) = v;
+            for (int it = 0; it < 6; ++it) {
+                const int idx = lane + 64 * it;              // 384 chunks of 8 columns per tile
+                const int rl = idx / 12, c8 = idx % 12;
+                const long mrow = m0 + wr * (FBM / WR) + 32 * i + rl;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + rl * SP + 8 * c8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + rl * SP + 8 * c8 + 4);
+                bf16x8 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h[e] = (short)f32_to_bf16_bits(lo[e]); h[4 + e] = (short)f32_to_bf16_bits(hi[e]); }
+                if (mrow < p.M) *reinterpret_cast<bf16x8*>(outh + (size_t)mrow * p.ldy + 8 * c8) = h;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 12; ++it) {
+                const int idx = lane + 64 * it;              // 768 float4 per tile
+                const int rl = idx / 24, c4 = idx % 24;
+                const long mrow = m0 + wr * (FBM / WR) + 32 * i + rl;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * SP + 4 * c4);
+                if (mrow < p.M) *reinterpret_cast<f32x4*>(outb + (size_t)mrow * p.ldy + 4 * c4) = v;
+            }
         }
     }
 }
@@ -387,7 +404,7 @@ int dldkd_in_proj_bf16(const float* x, const void* Wf, const float* cs, const fl
     }
     if (M == 0) return DLDKD_OK;
     if (!x || !Wf || !cs || !bb || !y0 || (N == 2 * kHidden && !y1)) { set_error("in_proj_bf16: null pointer"); return DLDKD_EINVAL; }
-    InProjArgs p{x, (const bf16x8*)Wf, cs, bb, {y0, y1}, M, N, K, eps, relu, kHidden};
+    InProjArgs p{x, (const bf16x8*)Wf, cs, bb, {y0, y1}, M, N, K, eps, relu, kHidden, 0};
     const unsigned rows = (unsigned)((M + PBM - 1) / PBM);
     // 128-column tiles (6 for two branches).  Measured at M = 400k, K = 3072: BN 128 / BK 32 = 4.9 ms (1252 GB/s,
     // 384 TFLOP/s); BN 256 / BK 64 = 5.6 ms (one workgroup per CU at 255 VGPRs).
@@ -424,15 +441,15 @@ int dldkd_pack_linear_bf16_frag(const float* W, const float* bias, int N, int K,
     return check_launch("pack_linear_frag");
 }
 
-int dldkd_linear_rows_bf16(const float* x, const void* Wfrag, const float* bb, float* y0, float* y1, int ldy, long M, int N, int K,
-                           int relu, void* stream) {
-    if (M < 0 || (N != 384 && N != 768) || K < FBK || (K % FBK) || ldy < 384) {
+int dldkd_linear_rows_bf16(const float* x, const void* Wfrag, const float* bb, void* y0, void* y1, int ldy, long M, int N, int K,
+                           int relu, int out_bf16, void* stream) {
+    if (M < 0 || (N != 384 && N != 768) || K < FBK || (K % FBK) || ldy < 384 || (out_bf16 && (ldy & 7))) {
         set_error("linear_rows_bf16: need N = 384 or 768, K a multiple of %d, ldy >= 384 (M=%ld N=%d K=%d ldy=%d)", FBK, M, N, K, ldy);
         return DLDKD_EINVAL;
     }
     if (M == 0) return DLDKD_OK;
     if (!x || !Wfrag || !bb || !y0 || (N == 768 && !y1)) { set_error("linear_rows_bf16: null pointer"); return DLDKD_EINVAL; }
-    InProjArgs p{x, (const bf16x8*)Wfrag, nullptr, bb, {y0, y1}, M, N, K, 0.f, relu, ldy};
+    InProjArgs p{x, (const bf16x8*)Wfrag, nullptr, bb, {(float*)y0, (float*)y1}, M, N, K, 0.f, relu, ldy, out_bf16};
     const dim3 grid((unsigned)((M + FBM - 1) / FBM));
     if (N == 768) {
         constexpr int lds = 2 * FW_TILE_BYTES + 2 * FBM * FPITCH * 2 + 2 * FBM * 4;
@@ -455,7 +472,7 @@ int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, 
     if (M < 0 || K < FBK || (K % FBK)) { set_error("in_proj_bf16_full: K must be a multiple of %d", FBK); return DLDKD_EINVAL; }
     if (M == 0) return DLDKD_OK;
     if (!x || !Wfrag || !cs || !bb || !y0 || !y1) { set_error("in_proj_bf16_full: null pointer"); return DLDKD_EINVAL; }
-    InProjArgs p{x, (const bf16x8*)Wfrag, cs, bb, {y0, y1}, M, FN, K, eps, relu, kHidden};
+    InProjArgs p{x, (const bf16x8*)Wfrag, cs, bb, {y0, y1}, M, FN, K, eps, relu, kHidden, 0};
     constexpr int lds = 2 * FW_TILE_BYTES + 2 * FBM * FPITCH * 2 + 2 * FBM * 4;
     static const bool ok = [] { return hipFuncSetAttribute((const void*)rows_linear_bf16_kernel<1, true>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess; }();

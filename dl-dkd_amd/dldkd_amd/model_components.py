@@ -78,7 +78,13 @@ class BertSelfAttention(nn.Module):
         if ops.rows_kernel_ok(query_states):                      # inference, throughput mode: full-row bf16 kernel
             if getattr(self, "_packed_qkv", None) is None:
                 self._packed_qkv = ops.PackedLinear([self.query, self.key, self.value])
-            qkv = ops.linear_rows(query_states.float(), self._packed_qkv)
+            # q|k|v handed to the attention kernel as bf16 (it rounds them to bf16 itself otherwise: same numbers, half
+            # the bytes of the largest activation of the layer)
+            qkv = ops.linear_rows(query_states.float(), self._packed_qkv, out_bf16=True)
+            mask = None
+            if attention_mask is not None:
+                mask = attention_mask.reshape(attention_mask.shape[0], -1).float().contiguous()
+            return ops.attention(qkv.view(*query_states.shape[:-1], 3 * ops.HIDDEN), mask)
         else:
             w, b = self.fused_qkv()
             qkv = F_.linear(query_states, w, b)                   # one GEMM for the three projections

@@ -84,10 +84,10 @@ SIGNATURES = {
                                             _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_simpool_eval_stream_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
                                                  _c_int, _c_int, _c_void_p, _c_void_p]),
-    "dldkd_attention_fwd_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
+    "dldkd_attention_fwd_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "dldkd_pack_linear_bf16_frag": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_linear_rows_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_int, _c_int,
-                                         _c_int, _c_void_p]),
+                                         _c_int, _c_int, _c_void_p]),
     "dldkd_pack_gallery_chunk_bf16": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
                                                 _c_int, _c_void_p]),
     "dldkd_dropout_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p]),

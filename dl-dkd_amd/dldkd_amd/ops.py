@@ -82,11 +82,22 @@ def layernorm(x, gamma, beta, add=None, add_mod=0):
 def attention(qkv, mask):
     """qkv (N, L, 1152), mask (N, L) or None -> context (N, L, 384)."""
     L = native.lib()
-    _chk(qkv, "attention.qkv"); _chk(mask, "attention.mask")
+    _chk(mask, "attention.mask")
     N, Lq = qkv.shape[0], qkv.shape[1]
     out = torch.empty(N, Lq, HIDDEN, dtype=torch.float32, device=qkv.device)
-    fn = L.dldkd_attention_fwd_bf16 if _PRECISION == "bf16" else L.dldkd_attention_fwd_f32
-    native.check(fn(native.ptr(qkv), native.ptr(mask), native.ptr(out), N, Lq, native.stream()), "attention_fwd")
+    if qkv.dtype == torch.bfloat16:              # produced by linear_rows(out_bf16=True) in throughput mode
+        if not (qkv.is_cuda and qkv.is_contiguous()):
+            raise native.NativeError("attention.qkv: bf16 input must be a contiguous GPU tensor")
+        native.check(L.dldkd_attention_fwd_bf16(native.ptr(qkv), native.ptr(mask), native.ptr(out), N, Lq, 1, native.stream()),
+                     "attention_fwd_bf16")
+        return out
+    _chk(qkv, "attention.qkv")
+    if _PRECISION == "bf16":
+        native.check(L.dldkd_attention_fwd_bf16(native.ptr(qkv), native.ptr(mask), native.ptr(out), N, Lq, 0, native.stream()),
+                     "attention_fwd_bf16")
+    else:
+        native.check(L.dldkd_attention_fwd_f32(native.ptr(qkv), native.ptr(mask), native.ptr(out), N, Lq, native.stream()),
+                     "attention_fwd")
     return out
 
 
@@ -187,8 +198,9 @@ def rows_kernel_ok(x):
     return _PRECISION == "bf16" and not torch.is_grad_enabled() and x.shape[-1] % 32 == 0
 
 
-def linear_rows(x, packed, relu=False):
-    """x (..., K) fp32 -> (..., 384 * n_linears) fp32: y = act(x W^T + b) for the packed linears side by side."""
+def linear_rows(x, packed, relu=False, out_bf16=False):
+    """x (..., K) fp32 -> (..., 384 * n_linears) fp32 (bf16 with out_bf16): y = act(x W^T + b) for the packed linears
+    side by side."""
     import ctypes
     L = native.lib()
     f = packed.get()
@@ -198,13 +210,14 @@ def linear_rows(x, packed, relu=False):
     x2 = _chk(x.reshape(-1, K), "linear_rows.x")
     M = x2.shape[0]
     n_out = HIDDEN * len(f.linears)
-    y = torch.empty(M, n_out, dtype=torch.float32, device=x.device)
+    y = torch.empty(M, n_out, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    esz = 2 if out_bf16 else 4
     col = 0
     for wf, bb, n_total in f.groups:
-        y0 = ctypes.c_void_p(y.data_ptr() + 4 * col)
-        y1 = ctypes.c_void_p(y.data_ptr() + 4 * (col + HIDDEN)) if n_total == 2 * HIDDEN else None
+        y0 = ctypes.c_void_p(y.data_ptr() + esz * col)
+        y1 = ctypes.c_void_p(y.data_ptr() + esz * (col + HIDDEN)) if n_total == 2 * HIDDEN else None
         native.check(L.dldkd_linear_rows_bf16(native.ptr(x2), native.ptr(wf), native.ptr(bb), y0, y1, n_out, M, n_total, K, int(relu),
-                                              native.stream()), "linear_rows_bf16")
+                                              int(out_bf16), native.stream()), "linear_rows_bf16")
         col += n_total
     return y.view(*x.shape[:-1], n_out)
 

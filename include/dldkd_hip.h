@@ -138,8 +138,8 @@ int dldkd_layernorm_f32(const float* x, const float* add, int add_mod, const flo
  * layer.  softmax(QK^T / sqrt(96) + (1 - mask) * -10000) V; the L x L probabilities never leave the CU. */
 int dldkd_attention_fwd_f32(const float* qkv, const float* mask, float* out, int N, int L, void* stream);
 /* Same contract on bf16 MFMA (Q, K, V and the probabilities rounded to bf16; softmax statistics and output fp32):
- * the throughput-mode attention of the towers. */
-int dldkd_attention_fwd_bf16(const float* qkv, const float* mask, float* out, int N, int L, void* stream);
+ * the throughput-mode attention of the towers.  qkv_is_bf16 != 0: qkv is a (N, L, 1152) bf16 buffer. */
+int dldkd_attention_fwd_bf16(const void* qkv, const float* mask, float* out, int N, int L, int qkv_is_bf16, void* stream);
 
 /* get_modularized_queries (model.py:245-258): h (N, L, 384), mask (N, L), w (384) -> out (N, 384);
  * attn (N, L) optional (softmax weights, kept for the backward pass).  L <= 64. */
@@ -177,11 +177,12 @@ int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, 
  * dldkd_pack_linear_bf16_frag writes rows [n_offset, n_offset + N) of a weight block of n_total (384 or 768) output
  * columns in MFMA fragment order (bf16) and its bias into bb[n_offset ..]; call it once per source matrix.
  * dldkd_linear_rows_bf16: x (M, K) fp32 contiguous; output columns [0, 384) go to y0 and [384, 768) to y1, both with
- * row stride ldy floats (so a (M, 1152) q|k|v buffer is filled by one N = 768 and one N = 384 launch). */
+ * row stride ldy elements (so a (M, 1152) q|k|v buffer is filled by one N = 768 and one N = 384 launch).  out_bf16 != 0:
+ * y0 / y1 are bf16 buffers (ldy a multiple of 8) - what dldkd_attention_fwd_bf16 consumes with qkv_is_bf16 != 0. */
 int dldkd_pack_linear_bf16_frag(const float* W, const float* bias, int N, int K, int n_offset, int n_total, void* Wfrag, float* bb,
                                 void* stream);
-int dldkd_linear_rows_bf16(const float* x, const void* Wfrag, const float* bb, float* y0, float* y1, int ldy, long M, int N, int K,
-                           int relu, void* stream);
+int dldkd_linear_rows_bf16(const float* x, const void* Wfrag, const float* bb, void* y0, void* y1, int ldy, long M, int N, int K,
+                           int relu, int out_bf16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training path, fp32 (DLDKD.forward + backward, method/model.py:100-197,353-387;

@@ -201,3 +201,22 @@ def test_eval_epoch_throughput_mode_vs_parity_mode(golden_dir):
     step = 100.0 / 192
     for a, b, r in zip(res["bf16"][1][:4], res["fp32"][1][:4], g["perf_fused"][:4]):
         assert abs(a - b) <= 2 * step + 1e-9 and abs(a - r) <= 2 * step + 1e-9, (res["bf16"][1], res["fp32"][1], g["perf_fused"])
+
+
+def test_bf16_qkv_handoff_equals_fp32_handoff(bf16_mode):
+    """linear_rows(out_bf16) -> attention(bf16 qkv) is the same computation as fp32 qkv -> attention (which rounds
+    q|k|v to bf16 itself): bit-identical outputs."""
+    from dldkd_amd import ops
+    torch.manual_seed(5)
+    lins = [torch.nn.Linear(384, 384).to(DEV) for _ in range(3)]
+    pk = ops.PackedLinear(lins)
+    for shape in ((7, 50, 384), (3, 128, 384), (1, 1, 384)):
+        x = torch.randn(*shape, device=DEV)
+        mask = torch.ones(shape[0], shape[1], device=DEV)
+        if shape[1] > 20:
+            mask[0, 20:] = 0
+        with torch.no_grad():
+            q32 = ops.linear_rows(x, pk)
+            q16 = ops.linear_rows(x, pk, out_bf16=True)
+            assert q16.dtype == torch.bfloat16 and torch.equal(q16.float(), q32.bfloat16().float())
+            assert torch.equal(ops.attention(q32, mask), ops.attention(q16, mask))
