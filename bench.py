@@ -344,7 +344,7 @@ def extras(dev):
         ms = e0.elapsed_time(e1) / 5
         byts = 400000 * 3072 * 4 + 400000 * 768 * 4 + 768 * 3072 * 2
         out["k4_in_proj_roofline"] = {"bound": "hbm", "achieved": byts / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
-                                      "frac": byts / ms / 1e6 / 8000.0, "kernel": "in_proj_bf16_full_kernel", "kernel_ms": ms,
+                                      "frac": byts / ms / 1e6 / 8000.0, "kernel": "rows_linear_bf16_kernel<1,true> (dldkd_in_proj_bf16_full)", "kernel_ms": ms,
                                       "shape": "400000 rows x 3072 fp32 -> 2 x 384 fp32"}
     except Exception as e:   # noqa: BLE001
         out["error"] = repr(e)
