@@ -46,12 +46,18 @@ def _gt_csr(t2v_gt, n_q, device):
     return torch.from_numpy(ptr).to(device), torch.from_numpy(idx).to(device)
 
 
-def gt_ranks_gpu(scores, t2v_gt):
+def gt_csr(t2v_gt, n_q, device):
+    """Ground truth as CSR (ptr, idx) on the device: build it once when several score matrices are ranked against the
+    same ground truth (eval_epoch ranks three) and pass it to gt_ranks_gpu / cal_perf as `csr`."""
+    return _gt_csr(t2v_gt, n_q, device)
+
+
+def gt_ranks_gpu(scores, t2v_gt, csr=None):
     """scores: (Nq, Nv) fp32 GPU similarity (higher = better).  Returns (rank_best, rank_first) int32 GPU."""
     L = native.lib()
     scores = scores.contiguous()
     nq, nv = scores.shape
-    ptr, idx = _gt_csr(t2v_gt, nq, scores.device)
+    ptr, idx = csr if csr is not None else _gt_csr(t2v_gt, nq, scores.device)
     rb = torch.empty(nq, dtype=torch.int32, device=scores.device)
     rf = torch.empty(nq, dtype=torch.int32, device=scores.device)
     native.check(L.dldkd_rank_gt(native.ptr(scores), nq, nv, native.ptr(ptr), native.ptr(idx), native.ptr(rb),
@@ -84,12 +90,12 @@ def t2v_map(c2i, t2v_gts):
     return float((1.0 / rf.cpu().numpy().astype(np.float64)).mean())
 
 
-def cal_perf(t2v_all_errors, t2v_gt, test=False):
+def cal_perf(t2v_all_errors, t2v_gt, test=False, csr=None):
     """eval.py:223-234: logs and returns (r1, r5, r10, r100, medr, meanr, mAP)."""
     t = torch.as_tensor(t2v_all_errors)
     if not t.is_cuda:
         t = t.cuda()
-    rb, rf = gt_ranks_gpu(-t.float(), t2v_gt)
+    rb, rf = gt_ranks_gpu(-t.float(), t2v_gt, csr)
     r1, r5, r10, r100, medr, meanr = _recalls(rb.cpu().numpy(), t.shape[0])
     m = float((1.0 / rf.cpu().numpy().astype(np.float64)).mean())
     logging.info(" * Text to Video:")
@@ -305,13 +311,14 @@ def _eval_epoch(model, val_video_dataset, val_text_dataset, opt, test=False):
     context_info = compute_context_info(model, val_video_dataset, opt, keep_frame_feats=False)
     fused, s0, s1, query_metas = score_queries(model, val_text_dataset, opt, context_info)
     _, t2v_gt = get_gt(context_info["video_metas"], query_metas)
+    csr = gt_csr(t2v_gt, len(query_metas), fused.device)       # one host loop + upload for the three rankings
     if opt.double_branch:
         logging.info("inher_scores:")
-        cal_perf(-1 * s0, t2v_gt, test)
+        cal_perf(-1 * s0, t2v_gt, test, csr)
         logging.info("explore_scores:")
-        cal_perf(-1 * s1, t2v_gt, test)
+        cal_perf(-1 * s1, t2v_gt, test, csr)
         logging.info("score_sum:")
-        r1, r5, r10, r100, _, _, _ = cal_perf(-1 * fused, t2v_gt, test)
+        r1, r5, r10, r100, _, _, _ = cal_perf(-1 * fused, t2v_gt, test, csr)
     else:
-        r1, r5, r10, r100, _, _, _ = cal_perf(-1 * s0, t2v_gt, test)
+        r1, r5, r10, r100, _, _, _ = cal_perf(-1 * s0, t2v_gt, test, csr)
     return r1 + r5 + r10 + r100

@@ -76,8 +76,9 @@ def stage_times(nv=21793, nq=10895, mode="fp32", dev="cuda:0", B=None):
             gt = {q: [q % nv] for q in range(nq)}
             ev.gt_ranks_gpu(fused, gt)
             t0 = sync()
+            csr = ev.gt_csr(gt, nq, fused.device)          # once per epoch, as eval_epoch does
             for sc in (s0, s1, fused):                     # eval_epoch ranks all three (eval.py:246-254)
-                rb, rf = ev.gt_ranks_gpu(sc, gt)
+                rb, rf = ev.gt_ranks_gpu(sc, gt, csr)
                 rb.cpu(), rf.cpu()
             t1 = sync()
             out["ranking_3_matrices_s"] = t1 - t0
