@@ -18,6 +18,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no libdldkd_hip.so (built artefacts are git-ignored): build it once, like
+    __graft_entry__.build() does, so the ABI / planner tests (CPU) and every GPU test find it."""
+    so = os.path.join(ROOT, "dl-dkd_amd", "dldkd_amd", "libdldkd_hip.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "dl-dkd_amd", "csrc"), "-j4"], check=True)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
