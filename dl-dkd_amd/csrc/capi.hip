@@ -24,29 +24,9 @@ int check_launch(const char* what) {
     return DLDKD_OK;
 }
 
-// ---- split-K support shared by the three tiled GEMMs: partial planes in a cached workspace + one reduce pass
-// (replaces fp32 atomics: no same-address contention, and the weight gradients become bitwise reproducible).
-static float* g_splitk_ws = nullptr;
-static size_t g_splitk_floats = 0;
-
-float* splitk_workspace(size_t floats) {
-    if (floats > g_splitk_floats) {
-        if (g_splitk_ws) {
-            (void)hipDeviceSynchronize();     // rare (growth only): earlier launches may still read the old buffer
-            (void)hipFree(g_splitk_ws);
-        }
-        const size_t want = floats < (size_t)8 << 20 ? (size_t)8 << 20 : floats;     // >= 32 MiB
-        if (hipMalloc(&g_splitk_ws, want * sizeof(float)) != hipSuccess) {
-            g_splitk_ws = nullptr;
-            g_splitk_floats = 0;
-            set_error("split-K workspace: hipMalloc of %zu bytes failed", want * sizeof(float));
-            return nullptr;
-        }
-        g_splitk_floats = want;
-    }
-    return g_splitk_ws;
-}
-
+// ---- split-K support shared by the three tiled GEMMs: partial planes in a CALLER-PROVIDED workspace + one reduce pass
+// (no fp32 atomics: no same-address contention, and the weight gradients are bitwise reproducible).  The library never
+// allocates, frees or synchronises: every entry point only enqueues (include/dldkd_hip.h, Conventions).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int split, long n4,
                                                             long stride4) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -67,6 +47,17 @@ int launch_splitk_reduce(const float* ws, float* out, int split, long n, hipStre
 }  // namespace dldkd
 
 extern "C" {
-int dldkd_abi_version(void) { return 1; }
+size_t dldkd_gemm_workspace_bytes(int precision, int M, int N, int K, int a_kmajor, int b_kmajor) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    int per = 0, split = 1;
+    switch (precision) {
+        case DLDKD_GEMM_F32: split = dldkd::gemm_f32_split_plan(M, N, K, a_kmajor, b_kmajor, &per); break;
+        case DLDKD_GEMM_F32X3: split = dldkd::gemm_f32x3_split_plan(M, N, K, a_kmajor, b_kmajor, &per); break;
+        case DLDKD_GEMM_BF16: split = dldkd::gemm_bf16_split_plan(M, N, K, a_kmajor, b_kmajor, &per); break;
+        default: return 0;
+    }
+    return split > 1 ? (size_t)split * M * N * sizeof(float) : 0;
+}
+int dldkd_abi_version(void) { return 2; }
 const char* dldkd_last_error(void) { return dldkd::g_err; }
 }

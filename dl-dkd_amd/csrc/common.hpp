@@ -100,7 +100,10 @@ __device__ __forceinline__ void gemm_store_tile(const f32x16 (&acc)[2][2], const
     }
 }
 
-float* splitk_workspace(size_t floats);
+// split-K plans of the three tiled GEMMs (number of k-slices, 1 = none), shared with dldkd_gemm_workspace_bytes
+int gemm_f32_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor, int* k_tiles_per_split);
+int gemm_f32x3_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor, int* k_tiles_per_split);
+int gemm_bf16_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor, int* k_tiles_per_split);
 int launch_splitk_reduce(const float* ws, float* out, int split, long n, hipStream_t s);
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);

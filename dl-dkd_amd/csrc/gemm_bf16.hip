@@ -207,33 +207,41 @@ static int launch_gemm_h(GemmHArgs p, int batch, int a_kmajor, int b_kmajor, voi
 
 using namespace dldkd;
 
+// Split-K plan of the unbatched entry point (backward layouts only: the forward pass, hence every loss, stays one
+// k-ordered accumulation per element).  Returns the number of k-slices (1 = no split) and the k-tiles per slice.
+int dldkd::gemm_bf16_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor, int* k_tiles_per_split) {
+    const int tiles = ((N + HBN_ - 1) / HBN_) * ((M + HBM_ - 1) / HBM_);
+    const int nk = (K + HBK_ - 1) / HBK_;
+    *k_tiles_per_split = nk;
+    if (!(a_kmajor || b_kmajor) || (((long)M * N) & 3) || tiles >= 128 || nk < 16) return 1;
+    // blocks to aim for: two workgroups fit a CU; more splits mean more partial planes to write and reduce.  Measured
+    // (dW shapes of the C3 step): 384 is best for outputs of >= 400k elements (in-proj dW 158 -> 121 us), 256 below.
+    const int target = (long)M * N >= 400000 ? 384 : 256;
+    int split = (target + tiles - 1) / tiles;
+    if (split > nk / 4) split = nk / 4;
+    if (split <= 1) return 1;
+    *k_tiles_per_split = (nk + split - 1) / split;
+    return (nk + *k_tiles_per_split - 1) / *k_tiles_per_split;
+}
+
 extern "C" int dldkd_gemm_bf16(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda,
-                               int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* stream) {
+                               int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes,
+                               void* stream) {
     if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < N) { set_error("gemm_bf16: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0 || N == 0) return DLDKD_OK;
     if (!A || !B || !C) { set_error("gemm_bf16: null pointer"); return DLDKD_EINVAL; }
     const int a_vec = !(lda & 3) && !((uintptr_t)A & 15), b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
     GemmHArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
-    const int tiles = ((N + HBN_ - 1) / HBN_) * ((M + HBM_ - 1) / HBM_);
-    const int nk = (K + HBK_ - 1) / HBK_;
-    // (never for the forward layout: split-K accumulates with unordered fp32 atomics; the forward pass must be reproducible)
-    if ((a_kmajor || b_kmajor) && !bias && !relu && ldc == N && !(((long)M * N) & 3) && !((uintptr_t)C & 15) && tiles < 128 && nk >= 16) {
-        // blocks to aim for: two workgroups fit a CU; more splits mean more partial planes to write and reduce.  Measured
-        // (dW shapes of the C3 step): 384 is best for outputs of >= 400k elements (in-proj dW 158 -> 121 us), 256 below.
-        const int target = (long)M * N >= 400000 ? 384 : 256;
-        int split = (target + tiles - 1) / tiles;
-        if (split > nk / 4) split = nk / 4;
-        if (split > 1) {
-            p.k_tiles_per_split = (nk + split - 1) / split;
-            p.split_k = (nk + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
-            // partial planes [split][M][N] in the cached workspace (plain stores), then one reduce pass into C
-            float* ws = splitk_workspace((size_t)p.split_k * M * N);
-            if (!ws) return DLDKD_ELAUNCH;
-            p.C = ws;
-            const int rc = launch_gemm_h(p, p.split_k, a_kmajor, b_kmajor, stream);
-            if (rc != DLDKD_OK) return rc;
-            return launch_splitk_reduce(ws, C, p.split_k, (long)M * N, (hipStream_t)stream);
-        }
+    int per = 0;
+    const int split = (!bias && !relu && ldc == N && !((uintptr_t)C & 15)) ? gemm_bf16_split_plan(M, N, K, a_kmajor, b_kmajor, &per) : 1;
+    if (split > 1 && workspace && !((uintptr_t)workspace & 15) && workspace_bytes >= (size_t)split * M * N * sizeof(float)) {
+        // partial planes [split][M][N] in the caller's workspace (plain stores), then one reduce pass into C
+        p.k_tiles_per_split = per;
+        p.split_k = split;
+        p.C = (float*)workspace;
+        const int rc = launch_gemm_h(p, p.split_k, a_kmajor, b_kmajor, stream);
+        if (rc != DLDKD_OK) return rc;
+        return launch_splitk_reduce((const float*)workspace, C, p.split_k, (long)M * N, (hipStream_t)stream);
     }
     return launch_gemm_h(p, 1, a_kmajor, b_kmajor, stream);
 }

@@ -233,31 +233,36 @@ static int launch_gemm_x(GemmXArgs p, int batch, int a_kmajor, int b_kmajor, voi
 
 using namespace dldkd;
 
+int dldkd::gemm_f32x3_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor, int* k_tiles_per_split) {
+    const int tiles = ((N + XBN - 1) / XBN) * ((M + XBM - 1) / XBM);
+    const int nk = (K + XBK - 1) / XBK;
+    *k_tiles_per_split = nk;
+    // never for the forward layout: the forward pass - hence the losses - stays one k-ordered accumulation per element
+    if (!(a_kmajor || b_kmajor) || (((long)M * N) & 3) || tiles >= 128 || nk < 32) return 1;
+    int split = (256 + tiles - 1) / tiles;
+    if (split > nk / 8) split = nk / 8;
+    if (split <= 1) return 1;
+    *k_tiles_per_split = (nk + split - 1) / split;
+    return (nk + *k_tiles_per_split - 1) / *k_tiles_per_split;
+}
+
 extern "C" int dldkd_gemm_f32x3(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda,
-                                int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* stream) {
+                                int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes,
+                                void* stream) {
     if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < N) { set_error("gemm_f32x3: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0 || N == 0) return DLDKD_OK;
     if (!A || !B || !C) { set_error("gemm_f32x3: null pointer"); return DLDKD_EINVAL; }
     const int a_vec = !(lda & 3) && !((uintptr_t)A & 15), b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
     GemmXArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
-    const int tiles = ((N + XBN - 1) / XBN) * ((M + XBM - 1) / XBM);
-    const int nk = (K + XBK - 1) / XBK;
-    // (never for the forward layout: split-K accumulates with unordered fp32 atomics, and the forward pass - hence the losses -
-    // must be bitwise reproducible run to run)
-    if ((a_kmajor || b_kmajor) && !bias && !relu && ldc == N && !(((long)M * N) & 3) && !((uintptr_t)C & 15) && tiles < 128 && nk >= 32) {
-        int split = (256 + tiles - 1) / tiles;
-        if (split > nk / 8) split = nk / 8;
-        if (split > 1) {
-            p.k_tiles_per_split = (nk + split - 1) / split;
-            p.split_k = (nk + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
-            // partial planes [split][M][N] in the cached workspace (plain stores), then one reduce pass into C
-            float* ws = splitk_workspace((size_t)p.split_k * M * N);
-            if (!ws) return DLDKD_ELAUNCH;
-            p.C = ws;
-            const int rc = launch_gemm_x(p, p.split_k, a_kmajor, b_kmajor, stream);
-            if (rc != DLDKD_OK) return rc;
-            return launch_splitk_reduce(ws, C, p.split_k, (long)M * N, (hipStream_t)stream);
-        }
+    int per = 0;
+    const int split = (!bias && !relu && ldc == N && !((uintptr_t)C & 15)) ? gemm_f32x3_split_plan(M, N, K, a_kmajor, b_kmajor, &per) : 1;
+    if (split > 1 && workspace && !((uintptr_t)workspace & 15) && workspace_bytes >= (size_t)split * M * N * sizeof(float)) {
+        p.k_tiles_per_split = per;
+        p.split_k = split;
+        p.C = (float*)workspace;
+        const int rc = launch_gemm_x(p, p.split_k, a_kmajor, b_kmajor, stream);
+        if (rc != DLDKD_OK) return rc;
+        return launch_splitk_reduce((const float*)workspace, C, p.split_k, (long)M * N, (hipStream_t)stream);
     }
     return launch_gemm_x(p, 1, a_kmajor, b_kmajor, stream);
 }

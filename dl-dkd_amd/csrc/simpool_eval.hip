@@ -3,18 +3,26 @@
 // driven by compute_query2ctx_info (method/eval.py:200-208) and the fusion at method/eval.py:254.
 //
 // MI355X design (DESIGN.md section "K1"):
-//   * The contraction is [clips x 384] . [384 x queries] on bf16 MFMA 32x32x16 with CLIPS as the MFMA
-//     row index and QUERIES on the lanes, so the 32x32 fp32 result has one query per lane and the
-//     clip rows in the 16 accumulator registers: the key-clip max-pool is in-register v_max3 plus one
-//     cross-half exchange.  The (Nq, L, Nv) clip tensor of the reference is never materialised.
+//   * The contraction is [clips x 384] . [384 x queries] on bf16 MFMA 16x16x32 with CLIPS as the MFMA
+//     row index and QUERIES on the lanes, so the fp32 result has one query per lane and the clip rows in
+//     the accumulator registers: the key-clip max-pool is in-register v_max plus two cross-lane swaps.
+//     The (Nq, L, Nv) clip tensor of the reference is never materialised.
 //   * GALLERY-STATIONARY IN REGISTERS: a wave owns one (video, branch): all 128 clips x 384 dims
 //     (96 KiB) live in 384 of the wave's 512 registers for the wave's whole life; one wave per SIMD,
 //     4 videos per CU.  The gallery is read from HBM exactly once.
 //   * The queries are pre-packed into MFMA B-fragment order and streamed L2 -> LDS by LDS-DMA in 24 KiB
-//     tiles (32 queries) shared by the workgroup's 4 waves, double-buffered, one barrier per tile.
-//     Each B fragment read from LDS feeds up to 4 MFMAs (0.25 KiB of LDS read per MFMA).
-//   * ragged videos: only ceil(len/32) row tiles are computed (wave-uniform template dispatch); videos
+//     tiles (32 queries) shared by the workgroup's 4 waves, 3-slot ring, one barrier per tile.
+//     Each B fragment read from LDS feeds up to 8 MFMAs (0.125 KiB of LDS read per MFMA).
+//   * ragged videos: only ceil(len/16) row tiles are computed (wave-uniform template dispatch); videos
 //     are visited in a caller-given order (descending length balances the 4 waves of a workgroup).
+//   * QUERY SPLIT: the grid is [query range s][branch][group of 4 videos]; a workgroup streams only the
+//     query tiles of its range.  Small galleries (one rank's shard of ActivityNet: 615 videos = 308
+//     workgroups on 256 CUs) then still fill the chip: the host picks the split from a round-count model.
+//     Ranges are dispatched in order (range-major block index) and, on request, every workgroup bumps a
+//     per-range arrival counter after an agent-scope release of its scores, so a consumer stream
+//     (hipStreamWaitValue32) can finish / all-gather range s while ranges s+1.. are still being scored.
+//   (The 32x32x16 scorer v1, the half-video scorer v3 and the row-stream scorer v4 of round 1 were measured
+//    dead ends - profiles/r01/ablation_simpool_v2.md - and left the product in round 2; git 952aeba has them.)
 #include <stdlib.h>
 
 #include <type_traits>
@@ -23,9 +31,8 @@
 
 namespace dldkd {
 
-constexpr int kKSteps = kHidden / 16;          // 24 MFMA k-steps
-constexpr int kQTile = 32;                     // queries per B fragment / per LDS tile
-constexpr int kQTileBytes = kKSteps * 1024;    // 24 KiB: [24 k-steps][64 lanes][8 bf16]
+constexpr int kQTile = 32;                     // queries per LDS tile (two 16-query sub-tiles)
+constexpr int kQTileBytes = kQTile * kHidden * 2;   // 24 KiB: [2 sub-tiles][12 k-steps][64 lanes][8 bf16]
 constexpr int kRowBf16x8 = kHidden / 8;        // 48 16-byte chunks per gallery row
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -33,12 +40,10 @@ __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m *
 // ----------------------------------------------------------------------------------------------
 // packers (fp32 -> normalised bf16).  Tiny, bandwidth-bound, vectorised 16-byte stores.
 // ----------------------------------------------------------------------------------------------
-// Packed query layout: [tile = q/32][k-step ks][lane = 32*h + (q%32)][8 bf16 = k 16ks + 8h ..+8]
-// = the B operand of mfma_f32_32x32x16_bf16 (cdna_hip_programming.md section 3 lane maps).
-// layout 1 (scorer v2, mfma_f32_16x16x32_bf16): [tile = q/32][sub = (q%32)/16][k-step ks of 32][lane = 16*kg + q%16]
-// [8 bf16 = k 32ks + 8kg ..+8].
+// Packed query layout: [tile = q/32][sub = (q%32)/16][k-step ks of 32][lane = 16*kg + q%16][8 bf16 = k 32ks + 8kg ..+8]
+// = the B operand of mfma_f32_16x16x32_bf16 (cdna_hip_programming.md section 3 lane maps).
 __global__ __launch_bounds__(256) void pack_queries_kernel(const float* __restrict__ q, int nq, int nq_pad,
-                                                           int normalize, int layout, bf16x8* __restrict__ out) {
+                                                           int normalize, bf16x8* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= nq_pad) return;
@@ -64,13 +69,8 @@ __global__ __launch_bounds__(256) void pack_queries_kernel(const float* __restri
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (short)f32_to_bf16_bits(v[j] * scale);
-        if (layout == 0) {
-            const int ks = lane >> 1, h = lane & 1;
-            out[((size_t)(qi >> 5) * kKSteps + ks) * 64 + h * 32 + (qi & 31)] = o;
-        } else {
-            const int ks = lane >> 2, kg = lane & 3, sub = (qi >> 4) & 1;
-            out[(((size_t)(qi >> 5) * 2 + sub) * (kKSteps / 2) + ks) * 64 + kg * 16 + (qi & 15)] = o;
-        }
+        const int ks = lane >> 2, kg = lane & 3, sub = (qi >> 4) & 1;
+        out[(((size_t)(qi >> 5) * 2 + sub) * (kHidden / 32) + ks) * 64 + kg * 16 + (qi & 15)] = o;
     }
 }
 
@@ -139,140 +139,16 @@ struct SimpoolEvalArgs {
     const int32_t* lens;     // [nv]
     const int32_t* order;    // [nv] visiting order (sorted position -> video id)
     float* part;             // [n_branches][nv (sorted position)][nq_pad] partial pooled scores
+    int32_t* done;           // [n_qsplit] arrival counters (one increment per workgroup of the range) or null
     int nq_pad, nv, Lp, n_qtiles, n_groups;
-    int ablate;   // diagnostic only
+    int n_wg0;               // workgroups per query range = n_groups * n_branches
+    int tiles_per_range;     // query tiles of every range but the last
+    int ablate;              // diagnostic builds only
 };
 
-// Row r of a 32x32 accumulator register set lives at clip (r&3) + 8*(r>>2) + 4*(lane>>5) of the row tile
-// (cdna_hip_programming.md section 3).
-__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
-
-template <int NRT>
-__device__ __forceinline__ void score_stream(const bf16x8 (&a)[4][kKSteps], const SimpoolEvalArgs& p, int branch,
-                                             int vs, int len, char* smem) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const char* qsrc = reinterpret_cast<const char*>(p.q[branch]);
-    // clips of the LAST row tile at or beyond `lim` (in this lane's half) are padding
-    const int lim = len - 32 * (NRT - 1) - 4 * (lane >> 5);
-    float* outp = (NRT > 0) ? p.part + ((size_t)branch * p.nv + vs) * p.nq_pad + (lane & 31) : nullptr;
-
-    auto stage = [&](int t) {
-        char* dst = smem + (t & 1) * kQTileBytes;
-        const char* src = qsrc + (size_t)t * kQTileBytes;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int piece = wave * 6 + i;
-            glds16(src + piece * 1024 + lane * 16, dst + piece * 1024);
-        }
-    };
-
-    stage(0);
-    float pending = 0.f;   // result of tile t-1, stored one tile late so its write latency is hidden
-    for (int t = 0; t < p.n_qtiles; ++t) {
-        __syncthreads();   // tile t has landed (each wave drained its DMA); everyone is done with tile t-1
-        if (t + 1 < p.n_qtiles) stage(t + 1);
-        if constexpr (NRT > 0) {
-            if (t > 0 && lane < 32) outp[(size_t)(t - 1) * kQTile] = pending;
-            const char* bsrc = smem + (t & 1) * kQTileBytes + lane * 16;
-            f32x16 acc[NRT];
-            // B fragments run kPF k-steps ahead of the MFMAs that consume them (a ring of kPF registers
-            // sets), so an LDS round trip never sits between two MFMAs.
-            constexpr int kPF = 4;
-            bf16x8 b[kPF];
-#pragma unroll
-            for (int i = 0; i < kPF; ++i) b[i] = *reinterpret_cast<const bf16x8*>(bsrc + i * 1024);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < kKSteps; ++ks) {
-#pragma unroll
-                for (int rt = 0; rt < NRT; ++rt) {
-                    if (ks == 0) {
-                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][ks], b[ks % kPF], z, 0, 0, 0);
-                    } else {
-                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][ks], b[ks % kPF], acc[rt], 0, 0, 0);
-                    }
-                }
-                if (ks + kPF < kKSteps) b[ks % kPF] = *reinterpret_cast<const bf16x8*>(bsrc + (ks + kPF) * 1024);
-                // hipcc otherwise sinks the reads back next to their use ({2 reads, lgkmcnt(0), 8 MFMA})
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // key-clip max-pool in registers
-            float m = -3.0e38f;
-#pragma unroll
-            for (int rt = 0; rt < NRT - 1; ++rt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[rt][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, acc_row(r) < lim ? acc[NRT - 1][r] : -3.0e38f);
-            pending = fmaxf(m, __shfl_xor(m, 32));
-        }
-    }
-    if constexpr (NRT > 0) {
-        if (lane < 32) outp[(size_t)(p.n_qtiles - 1) * kQTile] = pending;
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void simpool_eval_kernel(const SimpoolEvalArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int branch = blockIdx.x / p.n_groups;
-    const int vs = (blockIdx.x % p.n_groups) * 4 + wave;
-    int len = 0, v = 0;
-    if (vs < p.nv) {
-        v = p.order[vs];
-        len = p.lens[v];
-    }
-    len = __builtin_amdgcn_readfirstlane(len);
-    const int nrt = (len + 31) >> 5;
-
-    // stationary operand: A fragments of the whole video, lane l holds clip (32rt + l%32), k 16ks+8(l/32)..+8
-    bf16x8 a[4][kKSteps];
-    const bf16x8* gv = p.g[branch] + (size_t)v * p.Lp * kRowBf16x8 + (lane & 31) * kRowBf16x8 + (lane >> 5);
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-        if (rt < nrt) {
-#pragma unroll
-            for (int ks = 0; ks < kKSteps; ++ks) a[rt][ks] = gv[(size_t)rt * 32 * kRowBf16x8 + ks * 2];
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < kKSteps; ++ks) a[rt][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-    }
-    // Pin register classes: 64 fragments in the accumulator half of the unified file, 32 in arch VGPRs.
-    // Without this hipcc allocates all of them as VGPR-class values, "spills" the overflow to AGPRs and
-    // copies each back before its MFMA (160 v_accvgpr_mov per 96 MFMAs).  The file is built with
-    // -mllvm -amdgpu-mfma-vgpr-form=1 so the MFMA results stay in arch VGPRs, where the max-pool VALU
-    // reads them directly (AGPR-form results cost one v_accvgpr_read per value).
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int ks = 0; ks < kKSteps; ++ks) {
-            if (rt * kKSteps + ks < 64) asm volatile("" : "+a"(a[rt][ks]));
-            else asm volatile("" : "+v"(a[rt][ks]));
-        }
-
-    switch (nrt) {
-        case 4: score_stream<4>(a, p, branch, vs, len, smem); break;
-        case 3: score_stream<3>(a, p, branch, vs, len, smem); break;
-        case 2: score_stream<2>(a, p, branch, vs, len, smem); break;
-        case 1: score_stream<1>(a, p, branch, vs, len, smem); break;
-        default:
-            score_stream<0>(a, p, branch, vs, len, smem);   // padding wave: barriers + staging only
-            if (vs < p.nv) {                                   // video without a valid clip: -1e10 (model.py:444)
-                float* row = p.part + ((size_t)branch * p.nv + vs) * p.nq_pad;
-                for (int q = lane; q < p.nq_pad; q += 64) row[q] = -1e10f;
-            }
-            break;
-    }
-}
-
-
 // ----------------------------------------------------------------------------------------------
-// scorer v2: mfma_f32_16x16x32_bf16.  Same gallery-stationary structure as v1, but
-//   * 16-clip row tiles: ragged videos waste < 16 padded rows instead of < 32;
+// mfma_f32_16x16x32_bf16, gallery-stationary:
+//   * 16-clip row tiles: ragged videos waste < 16 padded rows;
 //   * a 16-query sub-tile needs only 4 accumulator registers per row tile, so TWO accumulator sets fit:
 //     the max-pool VALU of sub-tile i is issued in slices between the MFMAs of sub-tile i+1;
 //   * 3-slot LDS ring: tile t+1 is already visible while tile t is computed, so the B-fragment
@@ -310,11 +186,11 @@ __device__ __forceinline__ void lds_read_frag_off(bf16x8& dst, uint32_t lds_addr
 // only the timing matters (cdna_hip_programming.md section 7, "Ablate").
 template <int NRT, int ABL = 0>
 __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], const SimpoolEvalArgs& p, int branch,
-                                               int vs, int len, char* smem) {
+                                               int vs, int t0, int T, char* smem) {
+    // this workgroup streams query tiles [t0, t0 + T) of the packed blob
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const char* qsrc = reinterpret_cast<const char*>(p.q[branch]);
-    const int T = p.n_qtiles;
+    const char* qsrc = reinterpret_cast<const char*>(p.q[branch]) + (size_t)t0 * kQTileBytes;
 
     auto stage = [&](int t, int slot) {
         char* dst = smem + slot * kQTileBytes;
@@ -339,7 +215,7 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
     } else {
         // no padding mask: rows of the last tile beyond `len` replicate the video's last valid clip (pack_gallery_kernel),
         // so they can never change the maximum (same-box A/B against the masked form: 19.07 -> 18.94 ms)
-        float* outp = p.part + ((size_t)branch * p.nv + vs) * p.nq_pad + (lane & 15);
+        float* outp = p.part + ((size_t)branch * p.nv + vs) * p.nq_pad + (size_t)t0 * kQTile + (lane & 15);
         constexpr int V = NRT * 4;              // accumulator values per lane per sub-tile
         constexpr int kFoldSteps = 9;           // k-steps 0..8 fold the values, 9/10 cross lanes, 11 stores
         constexpr int kPer = (V + kFoldSteps - 1) / kFoldSteps;
@@ -475,8 +351,14 @@ __global__ __launch_bounds__(256, 1) void simpool_eval16_kernel(const SimpoolEva
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int branch = blockIdx.x / p.n_groups;
-    const int vs = (blockIdx.x % p.n_groups) * 4 + wave;
+    // block index = [query range][branch][group]: ranges are dispatched in order, and at any moment the resident
+    // workgroups stream (nearly) the same query tiles, which keeps them L2-hot
+    const int range = blockIdx.x / p.n_wg0;
+    const int b0 = blockIdx.x - range * p.n_wg0;
+    const int branch = b0 / p.n_groups;
+    const int vs = (b0 - branch * p.n_groups) * 4 + wave;
+    const int t0 = range * p.tiles_per_range;
+    const int T = min(p.tiles_per_range, p.n_qtiles - t0);
     int len = 0, v = 0;
     if (vs < p.nv) {
         v = p.order[vs];
@@ -498,6 +380,11 @@ __global__ __launch_bounds__(256, 1) void simpool_eval16_kernel(const SimpoolEva
             for (int ks = 0; ks < kKSteps16; ++ks) a[rt][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
+    // Pin register classes: 64 fragments in the accumulator half of the unified file, 32 in arch VGPRs.
+    // Without this hipcc allocates all of them as VGPR-class values, "spills" the overflow to AGPRs and
+    // copies each back before its MFMA (160 v_accvgpr_mov per 96 MFMAs).  The file is built with
+    // -mllvm -amdgpu-mfma-vgpr-form=1 so the MFMA results stay in arch VGPRs, where the max-pool VALU
+    // reads them directly (AGPR-form results cost one v_accvgpr_read per value).
 #pragma unroll
     for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
@@ -509,81 +396,60 @@ __global__ __launch_bounds__(256, 1) void simpool_eval16_kernel(const SimpoolEva
 #ifdef DLDKD_DIAG_ABLATE   // `make DIAG=1`: co-compiled variants perturb the shipped one's codegen (rule 19)
     if (p.ablate && nrt == 8) {   // diagnostic timing builds, full-length videos only
         switch (p.ablate) {
-            case 1: score_stream16<8, 1>(a, p, branch, vs, len, smem); return;
-            case 2: score_stream16<8, 2>(a, p, branch, vs, len, smem); return;
-            case 4: score_stream16<8, 4>(a, p, branch, vs, len, smem); return;
-            case 8: score_stream16<8, 8>(a, p, branch, vs, len, smem); return;
-            case 15: score_stream16<8, 15>(a, p, branch, vs, len, smem); return;
+            case 1: score_stream16<8, 1>(a, p, branch, vs, t0, T, smem); return;
+            case 2: score_stream16<8, 2>(a, p, branch, vs, t0, T, smem); return;
+            case 4: score_stream16<8, 4>(a, p, branch, vs, t0, T, smem); return;
+            case 8: score_stream16<8, 8>(a, p, branch, vs, t0, T, smem); return;
+            case 15: score_stream16<8, 15>(a, p, branch, vs, t0, T, smem); return;
             default: break;
         }
     }
 #endif
     switch (nrt) {
-        case 8: score_stream16<8>(a, p, branch, vs, len, smem); break;
-        case 7: score_stream16<7>(a, p, branch, vs, len, smem); break;
-        case 6: score_stream16<6>(a, p, branch, vs, len, smem); break;
-        case 5: score_stream16<5>(a, p, branch, vs, len, smem); break;
-        case 4: score_stream16<4>(a, p, branch, vs, len, smem); break;
-        case 3: score_stream16<3>(a, p, branch, vs, len, smem); break;
-        case 2: score_stream16<2>(a, p, branch, vs, len, smem); break;
-        case 1: score_stream16<1>(a, p, branch, vs, len, smem); break;
+        case 8: score_stream16<8>(a, p, branch, vs, t0, T, smem); break;
+        case 7: score_stream16<7>(a, p, branch, vs, t0, T, smem); break;
+        case 6: score_stream16<6>(a, p, branch, vs, t0, T, smem); break;
+        case 5: score_stream16<5>(a, p, branch, vs, t0, T, smem); break;
+        case 4: score_stream16<4>(a, p, branch, vs, t0, T, smem); break;
+        case 3: score_stream16<3>(a, p, branch, vs, t0, T, smem); break;
+        case 2: score_stream16<2>(a, p, branch, vs, t0, T, smem); break;
+        case 1: score_stream16<1>(a, p, branch, vs, t0, T, smem); break;
         default:
-            score_stream16<0>(a, p, branch, vs, len, smem);
+            score_stream16<0>(a, p, branch, vs, t0, T, smem);
             // a real video with no valid clip: the reference's masked maximum is exactly -1e10 (mask_logits, model.py:444)
             if (vs < p.nv) {
-                float* row = p.part + ((size_t)branch * p.nv + vs) * p.nq_pad;
-                for (int q = lane; q < p.nq_pad; q += 64) row[q] = -1e10f;
+                float* row = p.part + ((size_t)branch * p.nv + vs) * p.nq_pad + (size_t)t0 * kQTile;
+                for (int q = lane; q < T * kQTile; q += 64) row[q] = -1e10f;
             }
             break;
     }
-}
-
-// fused[q, v] = w0 * part[0][pos(v)][q] + w1 * part[1][pos(v)][q]  (eval.py:254), plus per-branch copies.
-// 32x32 tile transpose through LDS: reads coalesced along q, writes coalesced along v.
-__global__ __launch_bounds__(256) void simpool_finish_kernel(const float* __restrict__ part, const int32_t* __restrict__ inv,
-                                                             int nq, int nq_pad, int nv, int n_branches, float w0, float w1,
-                                                             float* __restrict__ fused, float* __restrict__ s0,
-                                                             float* __restrict__ s1) {
-    __shared__ float t0[32][33];
-    __shared__ float t1[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const int q0 = blockIdx.x * 32, v0 = blockIdx.y * 32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int vv = v0 + ty + 8 * i;
-        float a = 0.f, b = 0.f;
-        if (vv < nv) {
-            const size_t row = (size_t)inv[vv] * nq_pad + q0 + tx;   // q0+tx < nq_pad always
-            a = part[row];
-            if (n_branches > 1) b = part[(size_t)nv * nq_pad + row];
-        }
-        t0[ty + 8 * i][tx] = a;
-        t1[ty + 8 * i][tx] = b;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int qq = q0 + ty + 8 * i, vv = v0 + tx;
-        if (qq < nq && vv < nv) {
-            const float a = t0[tx][ty + 8 * i], b = t1[tx][ty + 8 * i];
-            const size_t o = (size_t)qq * nv + vv;
-            if (fused) fused[o] = n_branches > 1 ? w0 * a + w1 * b : a;
-            if (s0) s0[o] = a;
-            if (s1) s1[o] = b;
+    if (p.done != nullptr) {
+        // publish this workgroup's scores of the range: every wave drains its stores, the workgroup meets, ONE lane
+        // releases at agent scope (write-back of the XCD's L2) and only then bumps the range's arrival counter
+        // (cdna_hip_programming.md Guideline 16; the asm wait after the fence is the ROCm 7.2 pitfall-12 guard).
+        // A stream parked on the counter (hipStreamWaitValue32) then launches kernels that read the scores from memory.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(p.done + range, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
-// 64 x 64 tiles: every gathered part row is read as 256 contiguous bytes (float4 per lane) and every output row
-// segment is written as 256 contiguous bytes; 32 x 32 tiles (above, kept for the v1 layout checks) move 128-byte
-// segments and reach 3.0 TB/s, this form is measured in DESIGN.md.
+// fused[q, v] = w0 * part[0][pos(v)][q] + w1 * part[1][pos(v)][q]  (eval.py:254), plus per-branch copies, for the
+// queries [q_lo, q_hi) (q_lo a multiple of 64); output row = q - q_lo.
+// 64 x 64 tiles through LDS: every gathered part row is read as 256 contiguous bytes (float4 per lane) and every output
+// row segment is written as 256 contiguous bytes (32 x 32 tiles moved 128-byte segments and reached 3.0 TB/s; this form is
+// measured in DESIGN.md).
 __global__ __launch_bounds__(256) void simpool_finish64_kernel(const float* __restrict__ part, const int32_t* __restrict__ inv,
-                                                               int nq, int nq_pad, int nv, int n_branches, float w0, float w1,
-                                                               float* __restrict__ fused, float* __restrict__ s0,
+                                                               int q_lo, int q_hi, int nq_pad, int nv, int n_branches, float w0,
+                                                               float w1, float* __restrict__ fused, float* __restrict__ s0,
                                                                float* __restrict__ s1) {
     __shared__ float t0[64][65];
     __shared__ float t1[64][65];
-    const int q0 = blockIdx.x * 64, v0 = blockIdx.y * 64;
+    const int q0 = q_lo + blockIdx.x * 64, v0 = blockIdx.y * 64;
     {
         const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 float4 along q x 16 video rows per pass
         const int q = q0 + 4 * tx;
@@ -609,9 +475,9 @@ __global__ __launch_bounds__(256) void simpool_finish64_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int ql = (threadIdx.x >> 6) + 4 * i, qq = q0 + ql;
-        if (qq < nq) {
+        if (qq < q_hi) {
             const float a = t0[vl][ql], b = t1[vl][ql];
-            const size_t o = (size_t)qq * nv + vv;
+            const size_t o = (size_t)(qq - q_lo) * nv + vv;
             if (fused) fused[o] = n_branches > 1 ? w0 * a + w1 * b : a;
             if (s0) s0[o] = a;
             if (s1) s1[o] = b;
@@ -623,14 +489,24 @@ __global__ __launch_bounds__(256) void simpool_finish64_kernel(const float* __re
 
 using namespace dldkd;
 
-// DLDKD_SIMPOOL_VARIANT=1 selects the 32x32x16 scorer (v1); default is the 16x16x32 scorer (v2).  The
-// packed-query layout follows the variant, so it is read once per process.
-static int simpool_variant() {
-    static const int v = [] {
-        const char* e = getenv("DLDKD_SIMPOOL_VARIANT");
-        return (e && e[0] == '1') ? 1 : 2;
-    }();
-    return v;
+// Query split of a launch: n_wg0 workgroups per range (one per CU: 512 registers per wave), n_qtiles query tiles.
+// Cost model in units of "one query tile on one CU": a workgroup pays a fixed prologue (its 4 videos = 384 KiB from HBM at
+// ~25 GB/s per CU = ~15 us = ~7 tile times of 2.15 us) plus its tiles; the chip runs ceil(workgroups / 256) rounds.
+// The split with the lowest modelled time wins; ranges keep >= 16 tiles so the prologue stays amortised.
+static int pick_q_split(int n_wg0, int n_qtiles, int min_split) {
+    constexpr int kCUs = 256, kPrologueTiles = 7, kMinTiles = 16, kMaxSplit = 64;
+    int best = 1;
+    long best_cost = -1;
+    for (int s = 1; s <= kMaxSplit && s <= n_qtiles; ++s) {
+        const int tiles = (n_qtiles + s - 1) / s;
+        if (s > 1 && tiles < kMinTiles && s > min_split) break;
+        const int ranges = (n_qtiles + tiles - 1) / tiles;          // the last range may vanish when tiles rounds up
+        if (ranges < min_split && s < n_qtiles) continue;
+        const long rounds = ((long)n_wg0 * ranges + kCUs - 1) / kCUs;
+        const long cost = rounds * (kPrologueTiles + tiles);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ranges; }
+    }
+    return best;
 }
 
 extern "C" {
@@ -650,7 +526,7 @@ int dldkd_pack_queries_bf16(const float* q, int nq, int normalize, void* q_packe
     if (nq == 0) return DLDKD_OK;
     const int nq_pad = round_up(nq, kQTile);
     hipLaunchKernelGGL(pack_queries_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, nq, nq_pad,
-                       normalize, simpool_variant() == 1 ? 0 : 1, (bf16x8*)q_packed);
+                       normalize, (bf16x8*)q_packed);
     return check_launch("pack_queries");
 }
 
@@ -688,11 +564,25 @@ int dldkd_pack_gallery_chunk_bf16(const float* g, const float* mask, int nv_chun
     return check_launch("pack_gallery_chunk");
 }
 
+int dldkd_simpool_eval_plan(int nq, int nv, int n_branches, int min_split, int* n_ranges, int* queries_per_range) {
+    if (nq < 0 || nv < 0 || n_branches < 1 || n_branches > 2 || min_split < 0 || !n_ranges || !queries_per_range) {
+        set_error("simpool_eval_plan: bad arguments");
+        return DLDKD_EINVAL;
+    }
+    const int n_qtiles = round_up(nq < 1 ? 1 : nq, kQTile) / kQTile;
+    const int n_wg0 = ((nv < 1 ? 1 : nv) + 3) / 4 * n_branches;
+    const int split = pick_q_split(n_wg0, n_qtiles, min_split < 1 ? 1 : min_split);
+    const int tiles = (n_qtiles + split - 1) / split;
+    *n_ranges = (n_qtiles + tiles - 1) / tiles;
+    *queries_per_range = tiles * kQTile;
+    return DLDKD_OK;
+}
+
 int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_packed, const int32_t* lens,
-                            const int32_t* order, int nq, int nv, int L, int n_branches, void* workspace,
-                            void* stream) {
-    if (nq < 0 || nv < 0 || L < 1 || L > DLDKD_MAX_CLIPS || n_branches < 1 || n_branches > 2) {
-        set_error("simpool_eval: bad sizes nq=%d nv=%d L=%d branches=%d", nq, nv, L, n_branches);
+                            const int32_t* order, int nq, int nv, int L, int n_branches, int q_split, int32_t* done,
+                            void* workspace, void* stream) {
+    if (nq < 0 || nv < 0 || L < 1 || L > DLDKD_MAX_CLIPS || n_branches < 1 || n_branches > 2 || q_split < 0) {
+        set_error("simpool_eval: bad sizes nq=%d nv=%d L=%d branches=%d q_split=%d", nq, nv, L, n_branches, q_split);
         return DLDKD_EINVAL;
     }
     if (nq == 0 || nv == 0) return DLDKD_OK;
@@ -709,47 +599,55 @@ int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_pa
     p.lens = lens;
     p.order = order;
     p.part = (float*)workspace;
+    p.done = done;
     p.nq_pad = round_up(nq, kQTile);
     p.nv = nv;
     p.Lp = round_up(L, 32);
     p.n_qtiles = p.nq_pad / kQTile;
     p.n_groups = (nv + 3) / 4;
-    {
-        const char* e = getenv("DLDKD_SIMPOOL_ABLATE");
-        p.ablate = e ? atoi(e) : 0;
-    }
-    if (simpool_variant() == 1) {
-        hipLaunchKernelGGL(simpool_eval_kernel, dim3(p.n_groups * n_branches), dim3(256), 2 * kQTileBytes,
-                           (hipStream_t)stream, p);
-    } else {
-        static const bool attr_ok = [] {
-            return hipFuncSetAttribute((const void*)simpool_eval16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kRing * kQTileBytes) == hipSuccess;
-        }();
-        (void)attr_ok;
-        hipLaunchKernelGGL(simpool_eval16_kernel, dim3(p.n_groups * n_branches), dim3(256), kRing * kQTileBytes,
-                           (hipStream_t)stream, p);
-    }
+    p.n_wg0 = p.n_groups * n_branches;
+    const int split = q_split > 0 ? (q_split < p.n_qtiles ? q_split : p.n_qtiles) : pick_q_split(p.n_wg0, p.n_qtiles, 1);
+    p.tiles_per_range = (p.n_qtiles + split - 1) / split;
+    const int n_ranges = (p.n_qtiles + p.tiles_per_range - 1) / p.tiles_per_range;
+    p.ablate = 0;
+#ifdef DLDKD_DIAG_ABLATE
+    static const int ablate_env = [] { const char* e = getenv("DLDKD_SIMPOOL_ABLATE"); return e ? atoi(e) : 0; }();
+    p.ablate = ablate_env;
+#endif
+    static const bool attr_ok = [] {
+        return hipFuncSetAttribute((const void*)simpool_eval16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kRing * kQTileBytes) == hipSuccess;
+    }();
+    (void)attr_ok;
+    hipLaunchKernelGGL(simpool_eval16_kernel, dim3((unsigned)p.n_wg0 * n_ranges), dim3(256), kRing * kQTileBytes,
+                       (hipStream_t)stream, p);
     return check_launch("simpool_eval");
+}
+
+int dldkd_simpool_finish_range(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches, float w0,
+                               float w1, int q_lo, int q_hi, float* fused, float* s0, float* s1, void* stream) {
+    if (nq < 0 || nv < 0 || n_branches < 1 || n_branches > 2 || q_lo < 0 || q_hi < q_lo || q_hi > nq || (q_lo & 3)) {
+        set_error("simpool_finish: bad sizes nq=%d nv=%d branches=%d range [%d, %d)", nq, nv, n_branches, q_lo, q_hi);
+        return DLDKD_EINVAL;
+    }
+    if (q_hi == q_lo || nv == 0 || (!fused && !s0 && !s1)) return DLDKD_OK;
+    if (!workspace || !inv_order) { set_error("simpool_finish: null pointer"); return DLDKD_EINVAL; }
+    const int nq_pad = round_up(nq, kQTile);
+    hipLaunchKernelGGL(simpool_finish64_kernel, dim3((q_hi - q_lo + 63) / 64, (nv + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, inv_order, q_lo, q_hi, nq_pad, nv, n_branches, w0, w1, fused, s0, s1);
+    return check_launch("simpool_finish");
 }
 
 int dldkd_simpool_finish(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches, float w0,
                          float w1, float* fused, float* s0, float* s1, void* stream) {
-    if (nq < 0 || nv < 0 || n_branches < 1 || n_branches > 2) {
-        set_error("simpool_finish: bad sizes nq=%d nv=%d branches=%d", nq, nv, n_branches);
-        return DLDKD_EINVAL;
-    }
-    if (nq == 0 || nv == 0 || (!fused && !s0 && !s1)) return DLDKD_OK;
-    if (!workspace || !inv_order) { set_error("simpool_finish: null pointer"); return DLDKD_EINVAL; }
-    const int nq_pad = round_up(nq, kQTile);
-    static const bool old = getenv("DLDKD_FINISH32") != nullptr;   // A/B switch
-    if (old)
-        hipLaunchKernelGGL(simpool_finish_kernel, dim3(nq_pad / 32, (nv + 31) / 32), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)workspace, inv_order, nq, nq_pad, nv, n_branches, w0, w1, fused, s0, s1);
-    else
-        hipLaunchKernelGGL(simpool_finish64_kernel, dim3((nq_pad + 63) / 64, (nv + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)workspace, inv_order, nq, nq_pad, nv, n_branches, w0, w1, fused, s0, s1);
-    return check_launch("simpool_finish");
+    return dldkd_simpool_finish_range(workspace, inv_order, nq, nv, n_branches, w0, w1, 0, nq < 0 ? 0 : nq, fused, s0, s1, stream);
+}
+
+int dldkd_stream_wait_counter(void* stream, int32_t* counter, int32_t at_least) {
+    if (!counter) { set_error("stream_wait_counter: null pointer"); return DLDKD_EINVAL; }
+    const hipError_t e = hipStreamWaitValue32((hipStream_t)stream, counter, (uint32_t)at_least, hipStreamWaitValueGte, 0xFFFFFFFFu);
+    if (e != hipSuccess) { set_error("stream_wait_counter: %s", hipGetErrorString(e)); return DLDKD_ELAUNCH; }
+    return DLDKD_OK;
 }
 
 }  // extern "C"

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdldkd_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -22,17 +22,22 @@ _c_long = ctypes.c_long
 SIGNATURES = {
     "dldkd_abi_version": (_c_int, []),
     "dldkd_last_error": (ctypes.c_char_p, []),
+    "dldkd_gemm_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "dldkd_packed_queries_bytes": (_c_size_t, [_c_int]),
     "dldkd_packed_gallery_bytes": (_c_size_t, [_c_int, _c_int]),
     "dldkd_simpool_eval_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "dldkd_pack_queries_bf16": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_pack_gallery_bf16": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
-    "dldkd_simpool_eval_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
-                                          _c_void_p, _c_void_p]),
+    "dldkd_simpool_eval_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                          _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_simpool_eval_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
+    "dldkd_simpool_finish_range": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_int, _c_int,
+                                             _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_stream_wait_counter": (_c_int, [_c_void_p, _c_void_p, ctypes.c_int32]),
     "dldkd_simpool_finish": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p,
                                        _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_gemm_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                 _c_int, _c_int, _c_int, _c_void_p]),
+                         _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
     "dldkd_layernorm_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
                                       _c_float, _c_void_p]),
     "dldkd_attention_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
@@ -71,19 +76,10 @@ SIGNATURES = {
     "dldkd_in_proj_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int,
                                      _c_float, _c_int, _c_void_p]),
     "dldkd_segment_mean_l2norm_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_float, _c_void_p]),
-    "dldkd_simpool_units_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
-    "dldkd_simpool_eval_units_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
-                                                _c_int, _c_void_p, _c_void_p]),
-    "dldkd_simpool_finish_units": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
-                                             _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_fold_ln_linear_bf16_frag": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
                                                  _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_in_proj_bf16_full": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
                                           _c_float, _c_int, _c_void_p]),
-    "dldkd_simpool_plan_stream": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                                            _c_void_p, _c_void_p, _c_void_p]),
-    "dldkd_simpool_eval_stream_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
-                                                 _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_attention_fwd_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "dldkd_pack_linear_bf16_frag": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_linear_rows_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_int, _c_int,
@@ -93,12 +89,12 @@ SIGNATURES = {
     "dldkd_dropout_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p]),
     "dldkd_mask_scale_f32": (_c_int, [_c_void_p, _c_void_p, _c_float, _c_void_p, _c_long, _c_void_p]),
     "dldkd_gemm_f32x3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                   _c_int, _c_int, _c_int, _c_void_p]),
+                         _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
     "dldkd_gemm_f32x3_batched": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                            _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_float,
                                            _c_void_p]),
     "dldkd_gemm_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                  _c_int, _c_int, _c_int, _c_void_p]),
+                         _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
     "dldkd_gemm_bf16_batched": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                           _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_float,
                                           _c_void_p]),

@@ -35,6 +35,18 @@ def _gemm_fn(L, batched=False):
     return getattr(L, "dldkd_gemm_f32" + sfx)   # "fp32_exact": the true fp32-input MFMA
 
 
+_PREC_ID = {"fp32_exact": 0, "fp32": 1, "fp32x3": 1, "bf16": 2}     # DLDKD_GEMM_F32 / _F32X3 / _BF16
+
+
+def _gemm_workspace(L, M, N, K, a_kmajor, b_kmajor, device):
+    """Split-K scratch for one GEMM call, from torch's caching allocator (stream-ordered, so it is safe under graph capture
+    and with several streams); None when the shape never splits.  The library itself never allocates."""
+    nbytes = L.dldkd_gemm_workspace_bytes(_PREC_ID[_PRECISION], M, N, K, int(a_kmajor), int(b_kmajor))
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
 def _chk(t, name):
     if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
         raise native.NativeError(f"{name}: need a contiguous fp32 GPU tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
@@ -53,7 +65,7 @@ def linear(x, weight, bias=None, relu=False):
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
     fn = _gemm_fn(L)
     native.check(fn(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
-                    0, 0, int(relu), native.stream()), "gemm")
+                    0, 0, int(relu), None, 0, native.stream()), "gemm")          # the forward layout never splits K
     return y.view(*x.shape[:-1], N)
 
 
@@ -63,8 +75,9 @@ def gemm(a, b, a_kmajor, b_kmajor, M, N, K):
     _chk(a, "gemm.a"); _chk(b, "gemm.b")
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
     fn = _gemm_fn(L)
+    ws, ws_bytes = _gemm_workspace(L, M, N, K, a_kmajor, b_kmajor, a.device)
     native.check(fn(native.ptr(a), native.ptr(b), None, native.ptr(c), M, N, K, a.shape[-1], b.shape[-1], N,
-                    int(a_kmajor), int(b_kmajor), 0, native.stream()), "gemm")
+                    int(a_kmajor), int(b_kmajor), 0, native.ptr(ws), ws_bytes, native.stream()), "gemm")
     return c
 
 

@@ -116,116 +116,52 @@ class GalleryPacker:
         return PackedGallery(self.blobs, lens, order, inv, self.nv, self.L)
 
 
-def _variant():
-    import os
-    return os.environ.get("DLDKD_SIMPOOL_VARIANT", "2")
+def plan_query_split(nq, nv, n_branches, min_split=1):
+    """(n_ranges, queries_per_range) the scorer would use / should be given for this problem (host-side cost model of
+    dldkd_simpool_eval_plan: a 615-video shard is 308 workgroups on 256 CUs, so the queries are split to fill the chip)."""
+    import ctypes
+    n, per = ctypes.c_int(0), ctypes.c_int(0)
+    native.check(native.lib().dldkd_simpool_eval_plan(nq, nv, n_branches, min_split, ctypes.byref(n), ctypes.byref(per)),
+                 "simpool_eval_plan")
+    return n.value, per.value
 
 
-def _units(pg):
-    """Half-video units of scorer v3, built once per gallery: (unit_video, unit_row0, unit_rows, video_unit0,
-    video_unit1, n_units).  Units are visited in descending ceil(rows/16) order."""
-    if getattr(pg, "_units", None) is None:
-        lens = pg.lens.long()
-        dev = lens.device
-        vid = torch.arange(pg.nv, device=dev)
-        two = lens > 64
-        uv = torch.cat([vid, vid[two]])
-        row0 = torch.cat([torch.zeros(pg.nv, dtype=torch.long, device=dev), torch.full((int(two.sum()),), 64, device=dev)])
-        rows = torch.cat([torch.clamp(lens, max=64), lens[two] - 64])
-        order = torch.argsort((rows + 15) // 16, descending=True, stable=True)
-        uv, row0, rows = uv[order], row0[order], rows[order]
-        n_units = uv.numel()
-        pos = torch.empty(n_units, dtype=torch.long, device=dev)
-        pos[order] = torch.arange(n_units, device=dev)
-        u0 = pos[:pg.nv]
-        u1 = torch.full((pg.nv,), -1, dtype=torch.long, device=dev)
-        u1[two] = pos[pg.nv:]
-        pg._units = tuple(t.to(torch.int32).contiguous() for t in (uv, row0, rows, u0, u1)) + (n_units,)
-    return pg._units
-
-
-def _stream_plan(pg):
-    """Row-stream plan of scorer v4, built once per gallery on the host (dldkd_simpool_plan_stream) and kept on the
-    device: (rowsrc, tile_end, tile_unit, tail_unit, video_unit0, video_unit1, n_waves, n_units)."""
-    if getattr(pg, "_stream", None) is None:
-        import ctypes
-        import numpy as np
-        lens = np.ascontiguousarray(pg.lens.cpu().numpy().astype(np.int32))
-        lp = (pg.L + 31) // 32 * 32
-        max_waves = int((int(lens.sum()) + 15 * pg.nv) // 128 + 2)
-        rowsrc = np.empty(max_waves * 128, np.int32)
-        te, tu = np.empty(max_waves * 8, np.int32), np.empty(max_waves * 8, np.int32)
-        tail = np.empty(max_waves, np.int32)
-        u0, u1 = np.empty(max(pg.nv, 1), np.int32), np.empty(max(pg.nv, 1), np.int32)
-        nw, nu = ctypes.c_int(0), ctypes.c_int(0)
-        hp = lambda a: ctypes.c_void_p(a.ctypes.data)   # noqa: E731
-        native.check(native.lib().dldkd_simpool_plan_stream(hp(lens), pg.nv, lp, max_waves, hp(rowsrc), hp(te), hp(tu), hp(tail),
-                                                            hp(u0), hp(u1), ctypes.cast(ctypes.byref(nw), ctypes.c_void_p),
-                                                            ctypes.cast(ctypes.byref(nu), ctypes.c_void_p)), "simpool_plan_stream")
-        nw, nu = nw.value, nu.value
-        dev = pg.lens.device
-        up = lambda a: torch.from_numpy(a).to(dev)      # noqa: E731
-        pg._stream = (up(rowsrc[:max(nw, 1) * 128]), up(te[:max(nw, 1) * 8]), up(tu[:max(nw, 1) * 8]), up(tail[:max(nw, 1)]),
-                      up(u0), up(u1), nw, nu)
-    return pg._stream
-
-
-def simpool_partials(pq, pg, workspace=None):
+def simpool_partials(pq, pg, workspace=None, q_split=0, done=None):
     """Stage 1 (the dominant kernel): per-branch pooled scores into the workspace, transposed and in
-    visiting order.  Returns the workspace tensor."""
+    visiting order.  Returns the workspace tensor.  q_split = number of query ranges (0: chosen by the library);
+    done = int32 GPU tensor of per-range arrival counters (zeroed by the caller) or None."""
     L_ = native.lib()
     nb = pg.n_branches
     if len(pq.blobs) != nb:
         raise native.NativeError("query / gallery branch count mismatch")
-    if _variant() == "4":
-        rowsrc, te, tu, tail, _, _, n_waves, n_units = _stream_plan(pg)
-        need = L_.dldkd_simpool_units_workspace_bytes(pq.nq, n_units, nb)
-        if workspace is None or workspace.numel() < need:
-            workspace = torch.empty(need, dtype=torch.uint8, device=pg.lens.device)
-        if pq.nq and pg.nv:
-            native.check(L_.dldkd_simpool_eval_stream_bf16(native.ptr_array(pq.blobs), native.ptr_array(pg.blobs), native.ptr(rowsrc),
-                                                           native.ptr(te), native.ptr(tu), native.ptr(tail), pq.nq, n_waves, n_units,
-                                                           nb, native.ptr(workspace), native.stream()), "simpool_eval_stream")
-        return workspace
-    if _variant() == "3":
-        uv, row0, rows, _, _, n_units = _units(pg)
-        need = L_.dldkd_simpool_units_workspace_bytes(pq.nq, n_units, nb)
-        if workspace is None or workspace.numel() < need:
-            workspace = torch.empty(need, dtype=torch.uint8, device=pg.lens.device)
-        if pq.nq and pg.nv:
-            native.check(L_.dldkd_simpool_eval_units_bf16(native.ptr_array(pq.blobs), native.ptr_array(pg.blobs), native.ptr(uv),
-                                                          native.ptr(row0), native.ptr(rows), pq.nq, n_units, pg.L, nb,
-                                                          native.ptr(workspace), native.stream()), "simpool_eval_units")
-        return workspace
     need = L_.dldkd_simpool_eval_workspace_bytes(pq.nq, pg.nv, nb)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=pg.lens.device)
+    if done is not None and (done.dtype != torch.int32 or done.numel() < max(q_split, 1)):
+        raise native.NativeError("simpool_partials: `done` must hold one int32 per query range")
     if pq.nq and pg.nv:
         native.check(L_.dldkd_simpool_eval_bf16(native.ptr_array(pq.blobs), native.ptr_array(pg.blobs), native.ptr(pg.lens),
-                                                native.ptr(pg.order), pq.nq, pg.nv, pg.L, nb, native.ptr(workspace),
-                                                native.stream()), "simpool_eval")
+                                                native.ptr(pg.order), pq.nq, pg.nv, pg.L, nb, int(q_split), native.ptr(done),
+                                                native.ptr(workspace), native.stream()), "simpool_eval")
     return workspace
 
 
-def simpool_finish(workspace, pq, pg, w=(0.7, 0.3), want_fused=True, want_branches=False):
-    """Stage 2: (Nq, Nv) outputs.  Returns (fused, s0, s1), each fp32 (Nq, Nv) or None."""
+def simpool_finish(workspace, pq, pg, w=(0.7, 0.3), want_fused=True, want_branches=False, q_range=None, out=None):
+    """Stage 2: (Nq, Nv) outputs.  Returns (fused, s0, s1), each fp32 (Nq, Nv) or None.  q_range = (lo, hi) restricts
+    the outputs to those query rows ((hi - lo, Nv) blocks); `out` = preallocated fused block."""
     L_ = native.lib()
     nb, nq, nv, dev = pg.n_branches, pq.nq, pg.nv, pg.lens.device
-    fused = torch.empty(nq, nv, dtype=torch.float32, device=dev) if want_fused else None
-    s0 = torch.empty(nq, nv, dtype=torch.float32, device=dev) if want_branches else None
-    s1 = torch.empty(nq, nv, dtype=torch.float32, device=dev) if (want_branches and nb == 2) else None
-    if nq and nv and _variant() in ("3", "4"):
-        if _variant() == "4":
-            _, _, _, _, u0, u1, _, n_units = _stream_plan(pg)
-        else:
-            _, _, _, u0, u1, n_units = _units(pg)
-        native.check(L_.dldkd_simpool_finish_units(native.ptr(workspace), native.ptr(u0), native.ptr(u1), nq, nv, n_units, nb,
-                                                   float(w[0]), float(w[1]), native.ptr(fused), native.ptr(s0), native.ptr(s1),
-                                                   native.stream()), "simpool_finish_units")
-    elif nq and nv:
-        native.check(L_.dldkd_simpool_finish(native.ptr(workspace), native.ptr(pg.inv_order), nq, nv, nb, float(w[0]),
-                                             float(w[1]), native.ptr(fused), native.ptr(s0), native.ptr(s1),
-                                             native.stream()), "simpool_finish")
+    lo, hi = (0, nq) if q_range is None else q_range
+    n = hi - lo
+    fused = (out if out is not None else torch.empty(n, nv, dtype=torch.float32, device=dev)) if want_fused else None
+    s0 = torch.empty(n, nv, dtype=torch.float32, device=dev) if want_branches else None
+    s1 = torch.empty(n, nv, dtype=torch.float32, device=dev) if (want_branches and nb == 2) else None
+    if fused is not None and (tuple(fused.shape) != (n, nv) or fused.dtype != torch.float32):
+        raise native.NativeError(f"simpool_finish: out must be fp32 ({n}, {nv})")
+    if n and nv:
+        native.check(L_.dldkd_simpool_finish_range(native.ptr(workspace), native.ptr(pg.inv_order), nq, nv, nb, float(w[0]),
+                                                   float(w[1]), lo, hi, native.ptr(fused), native.ptr(s0), native.ptr(s1),
+                                                   native.stream()), "simpool_finish")
     return fused, s0, s1
 
 

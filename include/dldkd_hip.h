@@ -11,8 +11,10 @@
  * Conventions
  *   - plain C: pointers are DEVICE pointers unless the name says host_; sizes are ints; `stream` is a
  *     hipStream_t passed as void* (NULL = the default stream).  No torch / C++ types.
- *   - every function only ENQUEUES work on `stream` (no allocation, no host sync: safe to capture in a
- *     hipGraph) and returns DLDKD_OK or a negative DLDKD_E* code; dldkd_last_error() gives the text.
+ *   - every function only ENQUEUES work on `stream` (no allocation, no free, no host sync, no process-global device
+ *     state: safe to capture in a hipGraph and to call from several streams) and returns DLDKD_OK or a negative
+ *     DLDKD_E* code; dldkd_last_error() gives the text.  Scratch memory is always the caller's (`workspace` arguments,
+ *     sized by the matching *_bytes() function).
  *   - float tensors are row-major fp32 unless stated; "bf16" buffers are opaque device blobs whose size
  *     comes from the matching *_bytes() function.
  */
@@ -72,10 +74,24 @@ int dldkd_pack_gallery_chunk_bf16(const float* g, const float* mask, int nv_chun
  *     part_b[pos(v), q] = max_{l < lens[v]} < q_packed[b][q], g_packed[b][v, l] >   (model.py:321-327)
  * written to `workspace` as [n_branches][nv][round_up(nq,32)] fp32, videos in `order` (order[pos] = v;
  * any permutation is valid; descending-length order balances the workgroups).  bf16 operands, fp32
- * accumulation; the (nq, L, nv) clip tensor of the reference is never formed. */
+ * accumulation; the (nq, L, nv) clip tensor of the reference is never formed.
+ *
+ * q_split: the queries are cut into that many contiguous ranges of whole 32-query tiles and the launch grid becomes
+ * [range][branch][4 videos]: a small gallery (one rank's shard when the gallery is sharded over 8 GPUs, the loop of
+ * eval.py:188-212) still fills the 256 CUs.  0 = choose (dldkd_simpool_eval_plan with min_split 1 tells what is chosen).
+ * Results do not depend on q_split, bit for bit.
+ * done: NULL, or int32 counters [number of ranges], zeroed by the caller on `stream` before this call.  Ranges are
+ * dispatched in order; every workgroup of range s adds 1 to done[s] after releasing its scores at agent scope, so
+ * done[s] == ceil(nv/4) * n_branches means "the scores of the queries of range s are in memory" while later ranges are
+ * still being computed (dldkd_stream_wait_counter parks a second stream on exactly that). */
 int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_packed, const int32_t* lens,
-                            const int32_t* order, int nq, int nv, int L, int n_branches, void* workspace,
-                            void* stream);
+                            const int32_t* order, int nq, int nv, int L, int n_branches, int q_split, int32_t* done,
+                            void* workspace, void* stream);
+
+/* HOST-side planning of the query split (no GPU work): the number of ranges (>= min_split when nq allows it) that
+ * minimises the modelled time of dldkd_simpool_eval_bf16 on 256 CUs, and the queries per range (a multiple of 32; the
+ * last range is shorter).  Pass *n_ranges as q_split. */
+int dldkd_simpool_eval_plan(int nq, int nv, int n_branches, int min_split, int* n_ranges, int* queries_per_range);
 
 /* Stage 2: (nq, nv) row-major outputs from the workspace.  inv_order[v] = pos(v).
  *     s_b[q, v]   = part_b[pos(v), q]                  what get_sim_scores returns, model.py:327-329
@@ -83,35 +99,17 @@ int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_pa
  * fused / s0 / s1 may each be NULL. */
 int dldkd_simpool_finish(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches,
                          float w0, float w1, float* fused, float* s0, float* s1, void* stream);
+/* The same for the queries [q_lo, q_hi) only (q_lo a multiple of 4): outputs are (q_hi - q_lo, nv) blocks. */
+int dldkd_simpool_finish_range(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches,
+                               float w0, float w1, int q_lo, int q_hi, float* fused, float* s0, float* s1,
+                               void* stream);
 
-/* Scorer v3 ("half-video units", two waves per SIMD).  The gallery is cut into units of <= 64 consecutive clips of
- * one video (unit_video / unit_row0 in {0, 64} / unit_rows in 1..64; any order - descending ceil(rows/16) balances
- * the 8 units of a workgroup); stage 1 writes part[b][unit][q]; stage 2 takes the max over the 1-2 units of every
- * video (video_unit0[v], video_unit1[v] or -1) and fuses the branches.  Same results as dldkd_simpool_eval_bf16 +
- * dldkd_simpool_finish, same packed operands. */
-size_t dldkd_simpool_units_workspace_bytes(int nq, int n_units, int n_branches);
-int dldkd_simpool_eval_units_bf16(const void* const* q_packed, const void* const* g_packed, const int32_t* unit_video,
-                                  const int32_t* unit_row0, const int32_t* unit_rows, int nq, int n_units, int L,
-                                  int n_branches, void* workspace, void* stream);
-int dldkd_simpool_finish_units(const void* workspace, const int32_t* video_unit0, const int32_t* video_unit1, int nq,
-                               int nv, int n_units, int n_branches, float w0, float w1, float* fused, float* s0,
-                               float* s1, void* stream);
-
-/* Scorer v4 ("row stream").  The valid clips of all videos are laid end to end; wave w owns stream rows
- * [128 w, 128 w + 128), so every wave computes 8 full 16-row tiles of real clips (scorer v2 rounds every video up to
- * a multiple of 16 rows).  dldkd_simpool_plan_stream runs on the HOST (lens is a host array): it fills
- *   rowsrc[max_waves * 128]  gallery blob row (v * Lp + clip) of every stream row, -1 = zero row,
- *   tile_end / tile_unit [max_waves * 8], tail_unit[max_waves]  the segment metadata of every wave,
- *   video_unit0 / video_unit1 [nv]  the 1-2 partial maxima ("units") of every video (-1 = none),
- * and returns the number of waves and units.  max_waves >= (sum(lens) + 15 nv) / 128 + 1 always suffices.  The arrays
- * are then copied to the device; stage 1 writes part[b][unit][q] (dldkd_simpool_units_workspace_bytes), stage 2 is
- * dldkd_simpool_finish_units.  Same packed operands and same results as dldkd_simpool_eval_bf16 + dldkd_simpool_finish. */
-int dldkd_simpool_plan_stream(const int32_t* lens, int nv, int Lp, int max_waves, int32_t* rowsrc, int32_t* tile_end,
-                              int32_t* tile_unit, int32_t* tail_unit, int32_t* video_unit0, int32_t* video_unit1, int* n_waves,
-                              int* n_units);
-int dldkd_simpool_eval_stream_bf16(const void* const* q_packed, const void* const* g_packed, const int32_t* rowsrc,
-                                   const int32_t* tile_end, const int32_t* tile_unit, const int32_t* tail_unit, int nq, int n_waves,
-                                   int n_units, int n_branches, void* workspace, void* stream);
+/* Enqueue on `stream` a wait until *counter >= at_least (hipStreamWaitValue32, no host involvement): everything
+ * enqueued on `stream` afterwards runs once the producer kernel - typically still running on another stream - has
+ * pushed the device counter that far.  Used with the `done` counters of dldkd_simpool_eval_bf16 to overlap the
+ * all-gather of one query range (the exchange BASELINE.json's north_star adds to eval.py:188-212) with the scoring of
+ * the next. */
+int dldkd_stream_wait_counter(void* stream, int32_t* counter, int32_t at_least);
 
 /* ---------------------------------------------------------------------------------------------
  * Encoder towers, fp32 parity-grade forward (fp32-input MFMA: exact fp32 products and sums).
@@ -122,9 +120,22 @@ int dldkd_simpool_eval_stream_bf16(const void* const* q_packed, const void* cons
  * the row index of that operand in memory.  (0,0): nn.Linear forward Y = X W^T + b
  * (model_components.py:302,388-390,442; model.py:39);  (0,1): dX = dY W;  (1,1): dW = dY^T X.
  * relu != 0 applies max(.,0) (LinearLayer, model_components.py:310-311).  bias may be NULL.
- * float4 loads are used when an operand is 16-byte aligned with a leading dimension divisible by 4. */
+ * float4 loads are used when an operand is 16-byte aligned with a leading dimension divisible by 4.
+ *
+ * workspace / workspace_bytes: device scratch for split-K.  The backward layouts with a small output and a long
+ * contraction (weight gradients dW = dY^T X: 384 x 3072 outputs over 16k-80k rows) are cut along K into partial planes
+ * that one reduce pass sums in a fixed order (no atomics: bitwise reproducible).  dldkd_gemm_workspace_bytes() tells how
+ * many bytes a shape wants (0 = this shape never splits).  NULL or too small a workspace is legal: the product is then
+ * computed unsplit (same result up to fp32 summation order, slower for those shapes).  The library itself never
+ * allocates: the workspace must stay valid until the work enqueued by this call has run, and two calls that may overlap
+ * (different streams) need different workspaces. */
+#define DLDKD_GEMM_F32 0    /* dldkd_gemm_f32   */
+#define DLDKD_GEMM_F32X3 1  /* dldkd_gemm_f32x3 */
+#define DLDKD_GEMM_BF16 2   /* dldkd_gemm_bf16  */
+size_t dldkd_gemm_workspace_bytes(int precision, int M, int N, int K, int a_kmajor, int b_kmajor);
 int dldkd_gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda,
-                   int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* stream);
+                   int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes,
+                   void* stream);
 
 /* out[row] = LayerNorm(x[row] + add[..]) * gamma + beta over the last dim D (nn.LayerNorm, eps inside the
  * sqrt).  add == NULL: plain LayerNorm (LinearLayer.LayerNorm, model_components.py:308); add_mod == L > 0:
@@ -202,7 +213,7 @@ int dldkd_gemm_f32_batched(const float* A, const float* B, float* C, int M, int 
  * operands in memory converted to bf16 on the way to LDS, bf16 MFMA with fp32 accumulation.  Used by the training
  * step when the precision is set to "bf16" (BASELINE.json configs[2]); the fp32 entry points remain the parity path. */
 int dldkd_gemm_bf16(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
-                    int ldc, int a_kmajor, int b_kmajor, int relu, void* stream);
+                    int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes, void* stream);
 int dldkd_gemm_bf16_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                             int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo, long sAi, long sBo,
                             long sBi, long sCo, long sCi, float alpha, void* stream);
@@ -213,7 +224,7 @@ int dldkd_gemm_bf16_batched(const float* A, const float* B, float* C, int M, int
  * MFMAs replace 8 fp32-input MFMAs that each run 2x slower: ~3x the throughput of dldkd_gemm_f32 at parity-grade
  * accuracy; the host mirror uses it for precision "fp32" and keeps the true fp32-input MFMA as "fp32_exact". */
 int dldkd_gemm_f32x3(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
-                     int ldc, int a_kmajor, int b_kmajor, int relu, void* stream);
+                     int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes, void* stream);
 int dldkd_gemm_f32x3_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                              int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo, long sAi, long sBo,
                              long sBi, long sCo, long sCi, float alpha, void* stream);

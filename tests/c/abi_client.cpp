@@ -112,7 +112,7 @@ int main() {
     HIPCHK(hipMemcpy(dorder, order.data(), NV * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dinv, inv.data(), NV * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&ws, dldkd_simpool_eval_workspace_bytes(NQ, NV, NB)));
-    ABICHK(dldkd_simpool_eval_bf16(pq, pg, dlens, dorder, NQ, NV, L, NB, ws, nullptr));
+    ABICHK(dldkd_simpool_eval_bf16(pq, pg, dlens, dorder, NQ, NV, L, NB, 0, nullptr, ws, nullptr));
     ABICHK(dldkd_simpool_finish(ws, dinv, NQ, NV, NB, 0.7f, 0.3f, dfused, nullptr, nullptr, nullptr));
     HIPCHK(hipDeviceSynchronize());
     std::vector<float> fused((size_t)NQ * NV);
@@ -120,7 +120,7 @@ int main() {
     double worst = 0;
     for (size_t i = 0; i < fused.size(); ++i) worst = std::fmax(worst, std::fabs(fused[i] - expect[i]));
     // error paths: sizes are validated, the message is retrievable
-    if (dldkd_simpool_eval_bf16(pq, pg, dlens, dorder, NQ, NV, DLDKD_MAX_CLIPS + 1, NB, ws, nullptr) == 0 ||
+    if (dldkd_simpool_eval_bf16(pq, pg, dlens, dorder, NQ, NV, DLDKD_MAX_CLIPS + 1, NB, 0, nullptr, ws, nullptr) == 0 ||
         std::strlen(dldkd_last_error()) == 0) { std::fprintf(stderr, "bad-size call was accepted\n"); return 5; }
     if (worst > 2e-5) { std::fprintf(stderr, "max |HIP - host| = %g\n", worst); return 6; }
     std::printf("abi_client ok: %d x %d x <=%d clips, 2 branches, max |HIP - host scalar loop| = %.2e\n", NQ, NV, L, worst);

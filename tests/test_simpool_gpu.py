@@ -140,25 +140,49 @@ def test_rank_parity_planted_gallery():
         assert abs(a - b) <= 0.1, (rh, ro)
 
 
-@pytest.mark.parametrize("variant", ["3", "4"])
-@pytest.mark.parametrize("nq,nv,L,len_lo", [(200, 131, 128, 24), (97, 300, 40, 1), (33, 64, 128, 128), (50, 1, 7, 7)])
-def test_experimental_scorers_equal_the_shipped_one(monkeypatch, variant, nq, nv, L, len_lo):
-    """Scorer v3 (half-video units, two waves per SIMD) and v4 (row stream: every wave owns 128 consecutive valid clips,
-    segment-aware max-pool, host planner) are kept as measured experiments (neither beats v2).  Same packed
-    operands, and - because each score is the max of the same bf16 dot products accumulated in the same k order -
-    bit-identical results."""
+@pytest.mark.parametrize("nq,nv,L,len_lo", [(200, 131, 128, 24), (97, 300, 40, 1), (33, 64, 128, 128), (50, 1, 7, 7), (1000, 9, 64, 0)])
+def test_query_split_is_bit_invariant(nq, nv, L, len_lo):
+    """The launch grid is [query range][branch][4 videos]; any split gives the same matrix bit for bit (each score is the
+    max of the same bf16 dot products accumulated in the same k order), including splits whose last range is short, and
+    the per-range arrival counters end at (workgroups per range)."""
     from dldkd_amd import scoring
     d0 = synth.make_gallery(300 + nq, nq, nv, L, len_lo, sigma=0.5)
     d1 = synth.make_gallery(400 + nq, nq, nv, L, len_lo, sigma=1.0)
     dev = "cuda:0"
     pq = scoring.pack_queries([d0["q"].to(dev), d1["q"].to(dev)])
     pg = scoring.pack_gallery([d0["g"].to(dev), (d1["g"] * d0["mask"].unsqueeze(-1)).to(dev)], d0["mask"].to(dev))
-    monkeypatch.setenv("DLDKD_SIMPOOL_VARIANT", "2")
-    ref = scoring.simpool_eval(pq, pg, want_branches=True)
-    monkeypatch.setenv("DLDKD_SIMPOOL_VARIANT", variant)
-    got = scoring.simpool_eval(pq, pg, want_branches=True)
-    for a, b in zip(got, ref):
-        assert torch.equal(a, b)
+    ref = scoring.simpool_finish(scoring.simpool_partials(pq, pg, q_split=1), pq, pg, want_branches=True)
+    n_tiles = (nq + 31) // 32
+    for split in (0, 2, 3, 5, n_tiles, n_tiles + 7):
+        done = torch.zeros(64, dtype=torch.int32, device=dev)
+        ws = scoring.simpool_partials(pq, pg, q_split=split, done=done if split else None)
+        got = scoring.simpool_finish(ws, pq, pg, want_branches=True)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), split
+        if split:
+            eff = min(split, n_tiles)
+            tiles = (n_tiles + eff - 1) // eff
+            n_ranges = (n_tiles + tiles - 1) // tiles
+            want = torch.zeros(64, dtype=torch.int32)
+            want[:n_ranges] = (nv + 3) // 4 * 2
+            assert torch.equal(done.cpu(), want), (split, done[:8].tolist())
+        # per-range finish assembles the same matrix
+        if split in (3, 5):
+            per = ((n_tiles + min(split, n_tiles) - 1) // min(split, n_tiles)) * 32
+            rows = [scoring.simpool_finish(ws, pq, pg, q_range=(lo, min(lo + per, nq)))[0] for lo in range(0, nq, per)]
+            assert torch.equal(torch.cat(rows, 0), ref[0])
+
+
+def test_planned_split_fills_the_chip():
+    """Host cost model: the TVR gallery on one GPU needs no split; one rank's 615-video ActivityNet shard (308 workgroups
+    on 256 CUs) is split so that the modelled rounds are >= 80 % full; min_split is honoured."""
+    from dldkd_amd import scoring
+    assert scoring.plan_query_split(10895, 21793, 2)[0] == 1
+    n, per = scoring.plan_query_split(17505, 615, 2)
+    wgs = 308 * n
+    assert n >= 3 and per % 32 == 0 and n * per >= 17505 and wgs / (256 * -(-wgs // 256)) >= 0.8
+    n8, per8 = scoring.plan_query_split(17505, 615, 2, min_split=8)
+    assert n8 >= 8 and per8 % 32 == 0 and (n8 - 1) * per8 < 17505 <= n8 * per8
 
 
 def test_video_without_valid_clips_scores_minus_1e10():

@@ -15,6 +15,7 @@ ap.add_argument("--nv", type=int, default=21793)
 ap.add_argument("--L", type=int, default=128)
 ap.add_argument("--len-lo", type=int, default=24)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--split", type=int, default=0, help="query ranges of the launch grid (0 = planned)")
 a = ap.parse_args()
 dev = "cuda:0"
 gen = torch.Generator(device=dev).manual_seed(2)
@@ -32,13 +33,21 @@ qs = [torch.randn(a.nq, 384, generator=gen, device=dev) for _ in range(2)]
 pq = scoring.pack_queries(qs)
 torch.cuda.synchronize()
 print(f"setup {time.time()-t0:.1f}s  sum(len)={int(lens.sum())}")
+def run():
+    ws = scoring.simpool_partials(pq, pg, run.ws, q_split=a.split)
+    run.ws = ws
+    return scoring.simpool_finish(ws, pq, pg)
+
+
+run.ws = None
+print("planned split", scoring.plan_query_split(a.nq, a.nv, 2), "used", a.split or "planned")
 for _ in range(2):
-    scoring.simpool_eval(pq, pg)
+    run()
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.iters + 1)]
 ev[0].record()
 for i in range(a.iters):
-    scoring.simpool_eval(pq, pg)
+    run()
     ev[i + 1].record()
 torch.cuda.synchronize()
 ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters))
