@@ -44,11 +44,14 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p,
                                                           float* __restrict__ v, const int32_t* __restrict__ chunk_tensor,
                                                           const int32_t* __restrict__ t_start, const int32_t* __restrict__ t_numel,
                                                           const float* __restrict__ norm2, const float* __restrict__ t_wd,
-                                                          const float* __restrict__ t_lr, float b1, float b2, float eps,
-                                                          float max_norm) {
+                                                          const float* __restrict__ t_lr, const float* __restrict__ t_active,
+                                                          float b1, float b2, float eps, float max_norm) {
     const int t = chunk_tensor[blockIdx.x];
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)t_start[t] + t_numel[t]) return;
+    // a parameter without a gradient is skipped entirely: no moment decay, no weight decay (`if p.grad is None: continue`,
+    // optimization.py:294-295)
+    if (t_active != nullptr && t_active[t] == 0.f) return;
     float coef = 1.f;
     if (max_norm > 0.f) coef = fminf(max_norm / (sqrtf(norm2[t]) + 1e-6f), 1.f);
     const float gr = g[i] * coef;
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p,
     p[i] -= t_lr[t] * upd;
 }
 
-// counts[q] = #{ v < nv : scores[q, v] > thr[q] }   (one workgroup per query row)
+// counts[q] = #{ v < nv : !(scores[q, v] <= thr[q]) }   (one workgroup per query row; NaN scores count as above, rank.hip)
 __global__ __launch_bounds__(256) void count_above_kernel(const float* __restrict__ scores, const float* __restrict__ thr,
                                                           int nv, int ld, int32_t* __restrict__ counts) {
     __shared__ int red[4];
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void count_above_kernel(const float* __restric
     const float* row = scores + (size_t)q * ld;
     const float t = thr[q];
     int c = 0;
-    for (int i = threadIdx.x; i < nv; i += 256) c += row[i] > t;
+    for (int i = threadIdx.x; i < nv; i += 256) c += !(row[i] <= t);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
@@ -86,8 +89,8 @@ extern "C" {
 
 int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const int32_t* chunk_tensor, int n_chunks,
                              const int32_t* t_start, const int32_t* t_numel, int n_tensors, float* norm2_scratch,
-                             const float* t_wd, const float* t_lr, float b1, float b2, float eps, float max_grad_norm,
-                             void* stream) {
+                             const float* t_wd, const float* t_lr, const float* t_active, float b1, float b2, float eps,
+                             float max_grad_norm, void* stream) {
     if (n_chunks < 0 || n_tensors < 0) { set_error("bert_adam: bad sizes"); return DLDKD_EINVAL; }
     if (n_chunks == 0) return DLDKD_OK;
     if (!p || !g || !m || !v || !chunk_tensor || !t_start || !t_numel || !norm2_scratch || !t_wd || !t_lr) {
@@ -101,7 +104,7 @@ int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const
                            t_numel, norm2_scratch, n_chunks);
     }
     hipLaunchKernelGGL(adam_update_kernel, dim3(n_chunks), dim3(256), 0, s, p, g, m, v, chunk_tensor, t_start, t_numel,
-                       norm2_scratch, t_wd, t_lr, b1, b2, eps, max_grad_norm);
+                       norm2_scratch, t_wd, t_lr, t_active, b1, b2, eps, max_grad_norm);
     return check_launch("bert_adam");
 }
 

@@ -233,10 +233,15 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 }
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           unsigned char* __restrict__ keep, long n, unsigned thresh, float scale,
-                                                          unsigned long long seed, unsigned long long offset) {
+                                                          unsigned long long seed, unsigned long long offset,
+                                                          const unsigned long long* __restrict__ state) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;      // group of 4 elements
     const long i = q * 4;
     if (i >= n) return;
+    if (state != nullptr) {       // hipGraph-captured step: (seed, base offset) live in device memory, refreshed per replay
+        seed = state[0];
+        offset += state[1];
+    }
     unsigned rnd[4];
     const unsigned long long ctr = offset + (unsigned long long)q;
     philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), rnd);
@@ -453,14 +458,14 @@ int dldkd_mul_f32(const float* a, const float* m, float scale, float* out, long 
     return check_launch("mul");
 }
 int dldkd_dropout_fwd_f32(const float* x, float* out, unsigned char* keep, long n, float p, unsigned long long seed,
-                          unsigned long long offset, void* stream) {
+                          unsigned long long offset, const unsigned long long* state, void* stream) {
     if (n < 0 || !(p >= 0.f && p < 1.f)) { set_error("dropout_fwd: bad n=%ld or p=%f", n, (double)p); return DLDKD_EINVAL; }
     if (n == 0) return DLDKD_OK;
     if (!x || !out || !keep) { set_error("dropout_fwd: null pointer"); return DLDKD_EINVAL; }
     if (((uintptr_t)x | (uintptr_t)out) & 15 || ((uintptr_t)keep & 3)) { set_error("dropout_fwd: unaligned buffer"); return DLDKD_EINVAL; }
     const double t = (double)p * 4294967296.0;
     const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
-    LAUNCH1D(dropout_fwd_kernel, (n + 3) / 4, 256, x, out, keep, n, thresh, 1.0f / (1.0f - p), seed, offset);
+    LAUNCH1D(dropout_fwd_kernel, (n + 3) / 4, 256, x, out, keep, n, thresh, 1.0f / (1.0f - p), seed, offset, state);
     return check_launch("dropout_fwd");
 }
 int dldkd_mask_scale_f32(const float* a, const unsigned char* keep, float scale, float* out, long n, void* stream) {

@@ -4,11 +4,12 @@ BASELINE.json's north_star adds.
 
 Eval: the gallery shards by video (independent units).  Rank r keeps videos [r*S, (r+1)*S), S = ceil(Nv/N);
 every rank scores ALL queries against its shard; then either
-  * gather_scores(): one all_gather of the (Nq, S) blocks -> (Nq, Nv) on every rank (north_star's exchange), or
+  * OverlappedShardScorer: all_gather of the (Nq_r, S) blocks, one query range at a time under the scoring of the next
+    ranges -> (Nq, Nv) on every rank (north_star's exchange), or
   * sharded_gt_ranks(): no matrix exchange at all - all-reduce(MAX) of the ground-truth scores (Nq floats),
     local count of shard videos above them, all-reduce(SUM) of the counts (Nq ints): exact R@K.
 Training: local in-batch losses (model.py:353-387 defines negatives within one batch), one flat fp32 gradient
-bucket all-reduced per step (FlatGradBucket)."""
+buffer (the optimizer's own, optimization.FlatParams.grad) mean-all-reduced per step (sync_gradients)."""
 import torch
 import torch.distributed as dist
 
@@ -18,15 +19,6 @@ def shard_range(n_videos, rank, world):
     s = (n_videos + world - 1) // world
     lo = min(rank * s, n_videos)
     return lo, min(lo + s, n_videos), s
-
-
-def gather_scores(local_scores, n_videos, group=None):
-    """local_scores (Nq, S) (columns beyond the rank's real videos are padding) -> (Nq, n_videos)."""
-    world = dist.get_world_size(group)
-    nq, s = local_scores.shape
-    out = torch.empty(world * nq, s, dtype=local_scores.dtype, device=local_scores.device)   # rank-major concatenation
-    dist.all_gather_into_tensor(out, local_scores.contiguous(), group=group)
-    return out.view(world, nq, s).permute(1, 0, 2).reshape(nq, world * s)[:, :n_videos].contiguous()
 
 
 def _count_above_hip(scores, thr, n_valid):
@@ -39,82 +31,147 @@ def _count_above_hip(scores, thr, n_valid):
 
 def sharded_gt_ranks(local_scores, gt_video, n_videos, group=None, count_fn=None):
     """Gather-free ranking.  local_scores (Nq, S) for this rank's shard; gt_video (Nq,) global index of each
-    query's ground-truth video.  Returns rank (Nq,) int64 = 1 + #videos scoring above the GT video, identical
-    on every rank."""
+    query's ground-truth video (-1: none).  Returns rank (Nq,) int64 = 1 + #videos scoring above the GT video, identical
+    on every rank; n_videos + 1 for a query without ground truth or with a NaN ground-truth score (rank.hip NaN policy)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi, s = shard_range(n_videos, rank, world)
     nq = local_scores.shape[0]
     gt_video = gt_video.to(local_scores.device).long()
     mine = (gt_video >= lo) & (gt_video < hi)
-    thr = torch.full((nq,), float("-inf"), dtype=torch.float32, device=local_scores.device)
+    # row 0: the ground-truth score (-inf where it is not ours), row 1: 1 where it is NaN; one MAX all-reduce for both
+    thr = torch.full((2, nq), float("-inf"), dtype=torch.float32, device=local_scores.device)
+    thr[1].zero_()
     idx = torch.nonzero(mine).squeeze(1)
-    thr[idx] = local_scores[idx, gt_video[idx] - lo].float()
+    if idx.numel():
+        g = local_scores[idx, gt_video[idx] - lo].float()
+        bad = torch.isnan(g)
+        thr[0, idx] = torch.where(bad, torch.full_like(g, float("-inf")), g)
+        thr[1, idx] = bad.float()
     dist.all_reduce(thr, op=dist.ReduceOp.MAX, group=group)
     count_fn = count_fn or _count_above_hip
-    counts = count_fn(local_scores.contiguous(), thr, hi - lo).to(torch.int64)
+    if hi > lo:
+        counts = count_fn(local_scores.contiguous(), thr[0].contiguous(), hi - lo).to(torch.int64)
+    else:                                                  # empty shard (world > n_videos): nothing to count
+        counts = torch.zeros(nq, dtype=torch.int64, device=local_scores.device)
     dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
-    return counts + 1
-
-
-class FlatGradBucket:
-    """All parameters' gradients as views of ONE flat fp32 buffer: the data-parallel step is a single
-    all-reduce of 23.0 MB (TVR) / 17.5 MB (ActivityNet, Charades), no per-tensor launches or copies."""
-
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
-        self._bind()
-
-    def _bind(self):
-        o = 0
-        for p in self.params:
-            v = self.flat[o:o + p.numel()].view(p.shape)
-            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
-                v.copy_(p.grad)
-            p.grad = v
-            o += p.numel()
-
-    def zero(self):
-        self.flat.zero_()
-        self._bind()
-
-    def all_reduce_mean(self, group=None):
-        self._bind()                       # autograd may have swapped in fresh .grad tensors
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        self.flat.div_(dist.get_world_size(group))
+    ranks = counts + 1
+    worst = (thr[1] > 0) | (gt_video < 0)
+    return torch.where(worst, torch.full_like(ranks, n_videos + 1), torch.clamp(ranks, max=n_videos + 1))
 
 
 def all_reduce_flat(flat, group=None):
-    """Mean all-reduce of an existing flat gradient buffer (BertAdam's FlatParams.grad)."""
+    """Mean all-reduce of a flat gradient buffer (BertAdam's FlatParams.grad: every parameter's gradient is a view of ONE
+    fp32 buffer, 23.0 MB for the TVR model / 17.5 MB for ActivityNet and Charades): one collective per step."""
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(dist.get_world_size(group))
 
 
+def sync_gradients(fp, group=None):
+    """The collective half of the data-parallel step (what DDP adds to method/train.py:141-151): gather whatever autograd left
+    in p.grad into the flat buffer (parameters without a gradient contribute zeros), mean all-reduce it, and leave every
+    p.grad pointing at its slice.  `fp` is an optimization.FlatParams; pure torch, so it runs on CPU tensors with gloo."""
+    fp.rebind_grads()
+    all_reduce_flat(fp.grad, group)
+    # after the mean every parameter HAS a gradient on every rank (zeros included): the replicas must take the same
+    # optimizer step, so the local "grad was None" flags no longer apply
+    fp._had = tuple(True for _ in fp.params)
+
+
+def broadcast_parameters(fp, src=0, group=None):
+    """All replicas start from rank `src`'s parameters: one broadcast of the flat parameter buffer."""
+    dist.broadcast(fp.flat, src=src, group=group)
+
+
+class ShardScorerBackend:
+    """What OverlappedShardScorer drives (one implementation on HIP, one injected by the CPU tests):
+        launch(done)            enqueue the scoring of ALL queries against the shard on the current stream; range r's
+                                 scores are complete once done[r] == self.arrivals
+        wait_range(done, r)      make the CURRENT stream wait for that (no host involvement)
+        finish_range(r, lo, hi, out)   write the fused (hi - lo, shard) fp32 block of queries [lo, hi) into `out`"""
+    arrivals = 0
+
+    def launch(self, done):
+        raise NotImplementedError
+
+    def wait_range(self, done, r):
+        raise NotImplementedError
+
+    def finish_range(self, r, lo, hi, out):
+        raise NotImplementedError
+
+
+class HipShardBackend(ShardScorerBackend):
+    """ONE launch of the MFMA scorer over all queries, grid [query range][branch][4 videos]: the ranges complete in order
+    and every workgroup bumps its range's arrival counter after releasing its scores (simpool_eval.hip).  The consumer
+    stream is parked on the counter with hipStreamWaitValue32 (dldkd_stream_wait_counter)."""
+
+    def __init__(self, queries, gallery, n_ranges, w=(0.7, 0.3)):
+        from . import native, scoring
+        self.native, self.scoring = native, scoring
+        self.queries, self.pg, self.n_ranges, self.w = queries, gallery, n_ranges, w
+        self.arrivals = (gallery.nv + 3) // 4 * gallery.n_branches
+        self.ws = torch.empty(native.lib().dldkd_simpool_eval_workspace_bytes(queries[0].shape[0], gallery.nv, gallery.n_branches),
+                              dtype=torch.uint8, device=gallery.lens.device)
+        self.pq = None
+
+    def launch(self, done):
+        self.pq = self.scoring.pack_queries(self.queries)             # F.normalize + bf16 (model.py:318)
+        self.scoring.simpool_partials(self.pq, self.pg, self.ws, q_split=self.n_ranges, done=done)
+
+    def wait_range(self, done, r):
+        native = self.native
+        native.check(native.lib().dldkd_stream_wait_counter(native.stream(), native.ptr(done[r:]), self.arrivals), "stream_wait_counter")
+
+    def finish_range(self, r, lo, hi, out):
+        self.scoring.simpool_finish(self.ws, self.pq, self.pg, self.w, q_range=(lo, hi), out=out)
+
+
 class OverlappedShardScorer:
-    """Score all queries against this rank's gallery shard in `n_chunks` query chunks and all-gather each chunk's
-    (nq_c, S) block asynchronously while the next chunk is being scored (the collective runs on RCCL's own stream;
-    xGMI is point-to-point, so the 7 peer transfers of one all-gather proceed in parallel and hide under compute).
+    """One rank of the sharded all-pairs scoring step (the loop of method/eval.py:188-212 with the gallery cut by video):
+    score all queries against this rank's shard in ONE launch whose query ranges complete in order, and, on a side stream,
+    for every range as it completes: finish its (nq_r, S) block and all-gather it asynchronously - the collective of range r
+    runs on RCCL's stream under the scoring of ranges r+1.. (xGMI is point-to-point: the 7 peer transfers of one all-gather
+    proceed in parallel).  Only the last range's gather is exposed.
 
-    score_chunk(lo, hi, out): writes the (hi - lo, S) fp32 block of queries [lo, hi) into `out`.
-    After step(): self.blocks[c] is (world * nq_c, S) rank-major; assemble() builds (Nq, n_videos)."""
+    bounds: [(lo, hi)] query rows of every range; after step(): blocks[r] is (world * nq_r, S) rank-major;
+    assemble() builds (Nq, n_videos)."""
 
-    def __init__(self, score_chunk, nq, shard, n_chunks, device, group=None):
-        self.score_chunk, self.nq, self.shard, self.group = score_chunk, nq, shard, group
+    def __init__(self, backend, bounds, shard, device, group=None, side_stream=None):
+        self.backend, self.bounds, self.shard, self.group = backend, list(bounds), shard, group
         self.world = dist.get_world_size(group)
-        n_chunks = max(1, min(n_chunks, nq))
-        step = (nq + n_chunks - 1) // n_chunks
-        self.bounds = [(lo, min(lo + step, nq)) for lo in range(0, nq, step)]
         self.local = [torch.empty(hi - lo, shard, dtype=torch.float32, device=device) for lo, hi in self.bounds]
         self.blocks = [torch.empty(self.world * (hi - lo), shard, dtype=torch.float32, device=device) for lo, hi in self.bounds]
+        self.done = torch.zeros(max(len(self.bounds), 1), dtype=torch.int32, device=device)
+        self.on_gpu = torch.device(device).type == "cuda"
+        self.side = side_stream if (side_stream is not None or not self.on_gpu) else torch.cuda.Stream(device=device)
 
     def step(self):
+        if not self.on_gpu:                                   # CPU tests (gloo): same order of operations, no streams
+            self.done.zero_()
+            self.backend.launch(self.done)
+            works = []
+            for r, (lo, hi) in enumerate(self.bounds):
+                self.backend.wait_range(self.done, r)
+                self.backend.finish_range(r, lo, hi, self.local[r])
+                works.append(dist.all_gather_into_tensor(self.blocks[r], self.local[r], group=self.group, async_op=True))
+            for w in works:
+                w.wait()
+            return
+        main = torch.cuda.current_stream()
+        self.done.zero_()
+        zeroed = torch.cuda.Event()
+        zeroed.record(main)                                   # the side stream may look at the counters from here on...
+        self.backend.launch(self.done)                        # ...while the scorer (main stream) is still running
         works = []
-        for (lo, hi), loc, blk in zip(self.bounds, self.local, self.blocks):
-            self.score_chunk(lo, hi, loc)
-            works.append(dist.all_gather_into_tensor(blk, loc, group=self.group, async_op=True))
-        for w in works:
-            w.wait()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(zeroed)
+            for r, (lo, hi) in enumerate(self.bounds):
+                self.backend.wait_range(self.done, r)
+                self.backend.finish_range(r, lo, hi, self.local[r])
+                works.append(dist.all_gather_into_tensor(self.blocks[r], self.local[r], group=self.group, async_op=True))
+            for w in works:
+                w.wait()                                      # side stream waits for RCCL's stream
+        main.wait_stream(self.side)
 
     def assemble(self, n_videos):
         rows = []
@@ -122,3 +179,7 @@ class OverlappedShardScorer:
             n = hi - lo
             rows.append(blk.view(self.world, n, self.shard).permute(1, 0, 2).reshape(n, self.world * self.shard))
         return torch.cat(rows, 0)[:, :n_videos].contiguous()
+
+
+def query_ranges(nq, n_ranges, per_range):
+    return [(lo, min(lo + per_range, nq)) for lo in range(0, nq, per_range)][:max(n_ranges, 1)]

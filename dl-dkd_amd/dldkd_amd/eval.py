@@ -183,8 +183,12 @@ def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
         return out
 
     if not keep_frame_feats:
+        if packer is None:          # empty gallery (a rank whose shard is empty: more ranks than videos)
+            packer = scoring.GalleryPacker(0, int(_cfg_get(model.config, "max_ctx_l")), 2 if model.double_branch else 1,
+                                           torch.device(opt.device))
+        vmask = cat(masks) if masks else torch.zeros(0, 0, device=torch.device(opt.device))
         return dict(video_metas=metas, inher_frame_feat=None, explore_frame_feat=None, teacher_frame_feat=None,
-                    video_mask=cat(masks), _packed=packer.finish())
+                    video_mask=vmask, _packed=packer.finish())
     info = dict(video_metas=metas, inher_frame_feat=cat(inh),
                 explore_frame_feat=cat(exp) if model.double_branch else None,
                 teacher_frame_feat=None, video_mask=cat(masks))
@@ -260,13 +264,44 @@ def _dist_world():
     return 0, 1
 
 
+def gallery_ids(dataset):
+    """Video ids of a gallery dataset WITHOUT reading features: the `video_ids` attribute of the reference's
+    VisDataSet4DLDKD (data_provider.py:270-275), else `ids`, else a `get_video_id(i)` accessor.  Last resort (with a
+    warning): item [2] of every sample, which loads every video's features - on every rank of a sharded eval."""
+    for attr in ("video_ids", "ids"):
+        ids = getattr(dataset, attr, None)
+        if ids is not None:
+            return list(ids)
+    fn = getattr(dataset, "get_video_id", None)
+    if fn is not None:
+        return [fn(i) for i in range(len(dataset))]
+    import warnings
+    warnings.warn("gallery dataset exposes neither video_ids / ids nor get_video_id(i): reading every item to collect the ids "
+                  "(loads all features on this rank)", stacklevel=2)
+    return [dataset[i][2] for i in range(len(dataset))]
+
+
+def _gt_columns(t2v_gt, nq):
+    """Ground truth as a dense (nq, kmax) int64 table, short rows padded with their last entry, -1 rows for queries without
+    ground truth (one host pass instead of a Python loop per GT slot)."""
+    rows = [t2v_gt.get(q, ()) for q in range(nq)]
+    kmax = max((len(r) for r in rows), default=0)
+    tab = np.full((nq, max(kmax, 1)), -1, np.int64)
+    for q, r in enumerate(rows):
+        if len(r):
+            tab[q, :len(r)] = r
+            tab[q, len(r):] = r[-1]
+    return torch.from_numpy(tab)
+
+
 def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=False):
     """eval_epoch with the gallery sharded by video over the ranks of the default process group (config C4).
 
-    Rank r encodes and keeps videos [r*S, (r+1)*S) only, every rank encodes all queries, scores them against its
-    shard, and the ranks come from dist.sharded_gt_ranks: all-reduce(MAX) of each query's ground-truth score, a local
-    count of shard videos above it, all-reduce(SUM) - no (Nq, Nv) matrix is ever exchanged or assembled, and R@K is
-    exactly that of the unsharded evaluation.  Returns SumR of the fused scores on every rank."""
+    Rank r encodes and keeps videos [r*S, (r+1)*S) only (its features are the only ones it reads), every rank encodes all
+    queries, scores them against its shard, and the ranks come from dist.sharded_gt_ranks: all-reduce(MAX) of each query's
+    ground-truth score, a local count of shard videos above it, all-reduce(SUM) - no (Nq, Nv) matrix is ever exchanged or
+    assembled, and R@K is exactly that of the unsharded evaluation (a caption whose video is not in the gallery ranks
+    n_videos + 1, as in the unsharded path).  Returns SumR of the fused scores on every rank."""
     from torch.utils.data import Subset
     from . import dist as ddist
     import torch.distributed as tdist
@@ -275,23 +310,25 @@ def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=Fal
     model.eval()
     n_videos = len(val_video_dataset)
     lo, hi, _ = ddist.shard_range(n_videos, rank, world)
-    # video ids of the WHOLE gallery are needed for the ground truth; only the ids, not the features
-    all_ids = [val_video_dataset[i][2] for i in range(n_videos)] if world > 1 else None
     ctx = compute_context_info(model, Subset(val_video_dataset, range(lo, hi)), opt, keep_frame_feats=False)
     fused, s0, s1, query_metas = score_queries(model, val_text_dataset, opt, ctx)
-    video_metas = all_ids if all_ids is not None else ctx["video_metas"]
+    video_metas = gallery_ids(val_video_dataset) if world > 1 else ctx["video_metas"]
     _, t2v_gt = get_gt(video_metas, query_metas)
     nq = len(query_metas)
+    gt_tab = _gt_columns(t2v_gt, nq)
     out = {}
     for name, sc in (("inher", s0), ("explore", s1), ("fused", fused if s1 is not None else s0)):
         if sc is None:
             continue
-        # best GT per query = the GT video with the highest score; with one GT per query (TVR, ActivityNet,
-        # Charades captions) that is simply t2v_gt[q][0]
+        # best GT per query = the GT video with the highest score = the minimum over the GT slots of the slot's rank; with
+        # one GT per query (TVR, ActivityNet, Charades captions) there is one slot
         ranks = None
-        for k in range(max(len(v) for v in t2v_gt.values())):
-            gt_k = torch.tensor([t2v_gt[q][min(k, len(t2v_gt[q]) - 1)] for q in range(nq)], dtype=torch.long)
-            r = ddist.sharded_gt_ranks(sc, gt_k, n_videos) if use_collectives else gt_ranks_gpu(sc, {q: [int(gt_k[q])] for q in range(nq)})[0].long()
+        for k in range(gt_tab.shape[1]):
+            gt_k = gt_tab[:, k]
+            if use_collectives:
+                r = ddist.sharded_gt_ranks(sc, gt_k, n_videos)
+            else:
+                r = gt_ranks_gpu(sc, {q: ([int(v)] if v >= 0 else []) for q, v in enumerate(gt_k.tolist())})[0].long()
             ranks = r if ranks is None else torch.minimum(ranks, r)
         out[name] = _recalls(ranks.cpu().numpy(), nq)
         logging.info(" * %s r_1_5_10_100: %s", name, [round(x, 1) for x in out[name][:4]])

@@ -105,20 +105,61 @@ def layernorm(x, gamma, beta, add=None, add_mod=0):
 
 
 # ------------------------------------------------------------------------------------------ dropout
+class PhiloxStepState:
+    """Philox (seed, base offset) of ONE training step in device memory, for hipGraph-captured steps (train.GraphedTrainStep).
+
+    Eager dropout calls read (seed, offset) from torch's CUDA generator on the host and pass them as kernel arguments; a
+    captured graph would replay the same numbers.  While a PhiloxStepState is active (capture), every dropout call instead
+    bakes only its RELATIVE offset inside the step into the graph and the kernel adds the base it finds in `dev` (two int64
+    words of the step's staged-scalars buffer).  Before each replay begin_step() takes (seed, offset) from torch's
+    generator, advances the generator by what the step consumes and writes them into the host staging slot.  The masks of
+    a captured run are therefore exactly those of the eager run with the same torch.manual_seed."""
+
+    def __init__(self, dev_words):
+        self.dev = dev_words             # int64[2] device view
+        self.consumed = 0                # offsets one step draws (fixed once captured)
+
+    def slot(self, n):
+        rel = self.consumed
+        self.consumed += 4 * ((n + 3) // 4)
+        return rel
+
+    def begin_step(self, host_words):
+        dev = self.dev.device
+        gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+        off = gen.get_offset()
+        gen.set_offset(off + self.consumed)
+        seed = gen.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        host_words[0] = seed - (1 << 64) if seed >= (1 << 63) else seed          # two's complement into int64
+        host_words[1] = off
+
+
+_philox_step = None        # the active PhiloxStepState (only while a training step is being captured)
+
+
+def set_philox_step(state):
+    global _philox_step
+    old, _philox_step = _philox_step, state
+    return old
+
+
 def _philox_slot(device, n):
-    """(seed, offset) for n elements from torch's CUDA generator; advances it like a torch op that draws n
-    numbers would, so torch.manual_seed / get_rng_state / set_rng_state govern our masks too."""
+    """(seed, offset, state pointer) for n elements.  Eager: from torch's CUDA generator, advanced like a torch op that
+    draws n numbers would, so torch.manual_seed / get_rng_state / set_rng_state govern our masks too.  Under capture: the
+    step-relative offset and the device state the kernel adds to it (PhiloxStepState)."""
+    if _philox_step is not None:
+        return 0, _philox_step.slot(n), _p(_philox_step.dev)
     gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
     off = gen.get_offset()
     gen.set_offset(off + 4 * ((n + 3) // 4))          # torch offsets move in multiples of 4
-    return gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, off
+    return gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, off, None
 
 
 def _dropout_fwd(x, p):
     out = torch.empty_like(x)
     keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-    seed, off = _philox_slot(x.device, x.numel())
-    native.check(_L().dldkd_dropout_fwd_f32(_p(x), _p(out), _p(keep), x.numel(), float(p), seed, off, _s()), "dropout_fwd")
+    seed, off, state = _philox_slot(x.device, x.numel())
+    native.check(_L().dldkd_dropout_fwd_f32(_p(x), _p(out), _p(keep), x.numel(), float(p), seed, off, state, _s()), "dropout_fwd")
     return out, keep
 
 
@@ -381,10 +422,11 @@ class _NCE(Function):
 
 
 def _part_coefs(n, hard_n, w_hard, w_soft, device):
-    c = torch.empty(n, dtype=torch.float32)
-    c[:hard_n] = w_hard
-    c[hard_n:] = w_soft
-    return c.to(device)
+    # two fills on the device (no pageable host-to-device copy: that blocks the host and cannot be graph-captured)
+    c = torch.full((n,), float(w_soft), dtype=torch.float32, device=device)
+    if hard_n > 0:
+        c[:hard_n] = float(w_hard)
+    return c
 
 
 def nce_soft(labels, S, T, alpha, beta):

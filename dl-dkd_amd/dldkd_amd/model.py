@@ -229,7 +229,13 @@ class DLDKD(nn.Module):
         r_t2v = torch.randint(1, hi, size=(len(labels_np),)).to(torch.int32)
         return hard, r_t2v, r_v2t
 
-    def get_clip_triplet_loss(self, query_context_scores, labels):
+    def get_clip_triplet_loss(self, query_context_scores, labels, _staged=None):
+        """model.py:353-387.  `_staged` (internal, train.GraphedTrainStep): (labels, r_t2v, r_v2t) already on the device -
+        the CPU torch.randint draws were made by the caller, in the reference's order, before the captured step replays."""
+        hard = bool(_cfg_get(self.config, "use_hard_negative"))
+        if _staged is not None:
+            lab, r_t2v, r_v2t = _staged
+            return F_.triplet(query_context_scores, lab, r_t2v, None if hard else r_v2t, hard, _cfg_get(self.config, "margin"))
         labels_np = np.asarray(labels)
         dev = query_context_scores.device
         hard, r_t2v, r_v2t = self._draw_triplet(labels_np, query_context_scores.shape[1])
@@ -239,10 +245,19 @@ class DLDKD(nn.Module):
 
     # ------------------------------------------------------------------ training forward (model.py:100-163)
     def forward(self, batch):
+        loss, parts = self.forward_tensors(batch)
+        out = {"loss_overall": float(loss.detach())}          # the reference returns a Python float here (model.py:160)
+        out.update(parts)
+        return loss, out
+
+    def forward_tensors(self, batch, staged=None):
+        """The training forward without its one host synchronisation: returns (loss, {inher_trip, ..., kl_intra}) as
+        tensors.  `staged` (train.GraphedTrainStep): an object with .labels_dev (int32) and .draws = [(r_t2v, r_v2t), ...]
+        on the device; nothing in here then touches host memory, so the whole step can be captured into a hipGraph."""
         labels = batch["text_labels"]
         mask = batch["student_videos_mask"].float()
         dev = mask.device
-        lab = torch.as_tensor(np.asarray(labels), dtype=torch.int32, device=dev)
+        lab = staged.labels_dev if staged is not None else torch.as_tensor(np.asarray(labels), dtype=torch.int32, device=dev)
         nv, L = mask.shape
         lens = self._lens(mask, nv, L, dev)
 
@@ -256,11 +271,15 @@ class DLDKD(nn.Module):
             pooled_raw, _, _ = F_.clip_pool(F_.clip_scores(q, g), lens)
             return pooled_cos, pooled_raw, (clip_cos if want_clip else None)
 
+        def trip(scores, call):
+            st = None if staged is None else (lab,) + tuple(staged.draws[call])
+            return self.get_clip_triplet_loss(scores, labels, _staged=st)
+
         with torch.no_grad():
             _, t_raw, t_clip = both(t_text, t_vid, True)
         i_cos, i_raw, i_clip = both(q_inh, g_inh, True)
 
-        inher_trip = self.get_clip_triplet_loss(i_cos, labels)
+        inher_trip = trip(i_cos, 0)
         soft = self.label_style == "soft"
         if soft:
             inher_nce = self.inher_nce_weight * F_.nce_soft(lab, i_raw, t_raw, self.alpha, self.belta)
@@ -269,7 +288,7 @@ class DLDKD(nn.Module):
         explore_trip, explore_nce = 0, 0
         if self.double_branch:
             e_cos, e_raw, _ = both(q_exp, g_exp, False)
-            explore_trip = self.get_clip_triplet_loss(e_cos, labels)
+            explore_trip = trip(e_cos, 1)
             if soft:
                 explore_nce = self.explore_nce_weight * F_.nce_soft(lab, e_raw, e_raw, self.alpha, self.belta)
             else:
@@ -277,5 +296,5 @@ class DLDKD(nn.Module):
         kl_intra = self.kl_intra_weight * self.weight * F_.kl_frame(i_clip, t_clip, lab, lens, 0.2)
         kl = kl_intra
         loss = inher_trip + inher_nce + kl + explore_trip + explore_nce
-        return loss, {"loss_overall": float(loss.detach()), "inher_trip": inher_trip, "inher_nce": inher_nce,
-                      "explore_trip": explore_trip, "explore_nce": explore_nce, "kl": kl, "kl_intra": kl_intra}
+        return loss, {"inher_trip": inher_trip, "inher_nce": inher_nce, "explore_trip": explore_trip,
+                      "explore_nce": explore_nce, "kl": kl, "kl_intra": kl_intra}

@@ -68,8 +68,8 @@ SIGNATURES = {
                                     _c_void_p, _c_float, _c_void_p]),
     "dldkd_sum_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p]),
     "dldkd_bert_adam_step_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p,
-                                           _c_int, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_float, _c_float, _c_float,
-                                           _c_void_p]),
+                                           _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_float, _c_float,
+                                           _c_float, _c_void_p]),
     "dldkd_count_above_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_fold_ln_linear_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
                                             _c_void_p, _c_void_p]),
@@ -86,7 +86,8 @@ SIGNATURES = {
                                          _c_int, _c_int, _c_void_p]),
     "dldkd_pack_gallery_chunk_bf16": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
                                                 _c_int, _c_void_p]),
-    "dldkd_dropout_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p]),
+    "dldkd_dropout_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p,
+                                        _c_void_p]),
     "dldkd_mask_scale_f32": (_c_int, [_c_void_p, _c_void_p, _c_float, _c_void_p, _c_long, _c_void_p]),
     "dldkd_gemm_f32x3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                          _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),

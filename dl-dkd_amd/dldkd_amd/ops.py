@@ -9,6 +9,22 @@ LN_EPS = 1e-5   # nn.LayerNorm default (model_components.py:274,301,443)
 
 _PRECISION = "fp32"
 
+# Packed / folded bf16 weight caches (FoldedInProj, PackedLinear) are keyed on (data_ptr, tensor._version) of their source
+# parameters AND on this counter.  The fused optimizer updates parameters through raw device pointers, which changes
+# neither - so BertAdam.step() (and anything else that writes parameter memory behind torch's back) bumps the counter and
+# every cache repacks on its next use.  Without it, validation after a training step ran on the initial q|k|v / dense /
+# out_mapping / input-projection weights.
+_PARAM_EPOCH = 0
+
+
+def bump_param_epoch():
+    global _PARAM_EPOCH
+    _PARAM_EPOCH += 1
+
+
+def param_epoch():
+    return _PARAM_EPOCH
+
 
 def set_gemm_precision(precision):
     """"fp32" (default, parity grade): fp32-grade products from three bf16 planes per operand on the bf16 matrix
@@ -128,7 +144,7 @@ def modpool(h, mask, w, want_attn=False):
 
 class FoldedInProj:
     """LayerNorm-folded bf16 weights of 1-2 LinearLayer modules (one per branch), rebuilt when a parameter
-    changes (tensor._version)."""
+    changes (tensor._version, data_ptr, or the optimizer's raw-pointer update: _PARAM_EPOCH)."""
 
     def __init__(self, layers, full_row=None):
         self.layers = layers
@@ -146,7 +162,7 @@ class FoldedInProj:
 
     def get(self):
         ps = self._params()
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        key = (_PARAM_EPOCH,) + tuple((p.data_ptr(), p._version) for p in ps)
         if key != self.key:
             L = native.lib()
             K = self.layers[0].net[1].weight.shape[1]
@@ -185,7 +201,7 @@ class PackedLinear:
 
     def get(self):
         ps = [t for l in self.linears for t in (l.weight, l.bias)]
-        key = tuple((t.data_ptr(), t._version) for t in ps)
+        key = (_PARAM_EPOCH,) + tuple((t.data_ptr(), t._version) for t in ps)
         if key != self.key:
             L = native.lib()
             K = self.linears[0].weight.shape[1]

@@ -2,7 +2,7 @@
 ONE fused multi-tensor HIP step over a flat parameter buffer instead of ~10 elementwise launches per tensor.
 
 At construction the parameters (and their .grad) are re-pointed into flat fp32 buffers (tensor starts aligned
-to 256 elements), which is also what the data-parallel gradient all-reduce uses (dist.FlatGradBucket)."""
+to 256 elements); the data-parallel step all-reduces that flat gradient buffer as it is (dist.sync_gradients)."""
 import math
 
 import torch
@@ -59,6 +59,7 @@ class FlatParams:
         self.t_start = torch.tensor(starts, dtype=torch.int32, device=dev)
         self.t_numel = torch.tensor(numels, dtype=torch.int32, device=dev)
         self._starts, self._numels, self._views = starts, numels, None     # host copies: no .tolist() sync per step
+        self._bound, self._had = False, tuple(True for _ in self.params)
 
     def views(self):
         if self._views is None:
@@ -71,12 +72,17 @@ class FlatParams:
         kernel per parameter (74 launches) plus a 23 MB fill."""
         for p in self.params:
             p.grad = None
+        self._bound = False
 
     def rebind_grads(self):
         """Gather whatever autograd (or a caller) left in p.grad into the flat buffer with one multi-tensor copy, zero the
-        views of parameters without a gradient, and re-point p.grad at the views."""
+        views of parameters without a gradient, and re-point p.grad at the views.  Returns the tuple of per-parameter
+        "had a gradient" flags (the reference's BertAdam skips parameters whose grad is None, optimization.py:294-295)."""
         views = self.views()
         dst, src = [], []
+        had = tuple(p.grad is not None for p in self.params)
+        if self._bound and all(p.grad is v for p, v in zip(self.params, views)):
+            return self._had               # second call in one step (all-reduce, then optimizer): nothing new to gather
         for p, view in zip(self.params, views):
             if p.grad is None:
                 view.zero_()
@@ -87,6 +93,8 @@ class FlatParams:
             p.grad = view
         if dst:
             torch._foreach_copy_(dst, src)
+        self._bound, self._had = True, had
+        return had
 
 
 class BertAdam(torch.optim.Optimizer):
@@ -117,6 +125,13 @@ class BertAdam(torch.optim.Optimizer):
         self.t_wd = torch.tensor(wd, dtype=torch.float32, device=dev)
         self._base_lr = lrs
         self.t_lr = torch.zeros(len(plist), dtype=torch.float32, device=dev)
+        # per-step host scalars reach the device through a ring of PINNED staging slots with asynchronous copies
+        # (staging.PinnedRing): no pageable H2D, which blocks the host until the stream drains
+        from .staging import PinnedRing
+        self._lr_ring = PinnedRing(4 * len(plist), dev)
+        self.t_active = torch.ones(len(plist), dtype=torch.float32, device=dev)
+        self._active_key = tuple(True for _ in plist)
+        self._base_lr_t = torch.tensor(lrs, dtype=torch.float32)
         self.norm2 = torch.zeros(len(plist), dtype=torch.float32, device=dev)
         self.step_count = 0
 
@@ -133,18 +148,40 @@ class BertAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=True):
         self.fp.drop_grads()
 
+    def host_prepare(self, lr_out=None):
+        """Host half of a step: this step's learning rates into `lr_out` (a CPU float32 tensor of one entry per parameter;
+        default: the next slot of the optimizer's own pinned ring), step counter advanced.  train.GraphedTrainStep stages
+        the rates together with the step's other host scalars and passes its own buffer."""
+        if lr_out is None:
+            lr_out = self._lr_ring.next()[:4 * len(self._base_lr)].view(torch.float32)
+        torch.mul(self._base_lr_t, self.schedule_multiplier(), out=lr_out)
+        self.step_count += 1
+
     @torch.no_grad()
-    def step(self, closure=None):
-        loss = closure() if closure is not None else None
-        self.fp.rebind_grads()
+    def enqueue(self, upload_lr=True):
+        """Device half: gather the gradients into the flat buffer, upload the staged learning rates (asynchronous copy
+        from pinned memory; upload_lr=False: the caller already put them into self.t_lr), one fused multi-tensor update.
+        Enqueue-only, hence capturable into a hipGraph."""
+        had = self.fp.rebind_grads()
         g = self.param_groups[0]
-        mult = self.schedule_multiplier()
-        self.t_lr.copy_(torch.tensor([lr * mult for lr in self._base_lr], dtype=torch.float32))
+        if upload_lr:
+            self._lr_ring.upload(self.t_lr.view(torch.uint8))
+        if had != self._active_key:                      # rare: the set of parameters with a gradient changed
+            self.t_active.copy_(torch.tensor(had, dtype=torch.float32))
+            self._active_key = had
         L = native.lib()
         native.check(L.dldkd_bert_adam_step_f32(native.ptr(self.fp.flat), native.ptr(self.fp.grad), native.ptr(self.m),
                                                 native.ptr(self.v), native.ptr(self.fp.chunk_tensor), self.fp.n_chunks,
                                                 native.ptr(self.fp.t_start), native.ptr(self.fp.t_numel), len(self.fp.params),
                                                 native.ptr(self.norm2), native.ptr(self.t_wd), native.ptr(self.t_lr),
-                                                g["b1"], g["b2"], g["e"], g["max_grad_norm"], native.stream()), "bert_adam_step")
-        self.step_count += 1
+                                                native.ptr(self.t_active), g["b1"], g["b2"], g["e"], g["max_grad_norm"],
+                                                native.stream()), "bert_adam_step")
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self.host_prepare()
+        self.enqueue()
+        from . import ops
+        ops.bump_param_epoch()        # parameters changed through raw pointers: packed bf16 weight caches must repack
         return loss

@@ -1,8 +1,15 @@
 """Training driver: per-epoch scalar schedules, the optimisation step, best-checkpoint saving, early stop.
 
 Mirrors reference method/train.py:52-247 for the part that touches the hot path; logging to
-TensorBoard, result directories and code zips are out of scope.  With torch.distributed initialised the step
-becomes data parallel: local in-batch losses, one flat gradient all-reduce (dist.all_reduce_flat)."""
+TensorBoard, result directories and code zips are out of scope.
+
+Data parallel (BASELINE.json configs[4]; the reference is single-GPU): with torch.distributed initialised, one process per
+GPU, every rank draws ITS OWN batches (DistributedSampler, reshuffled per epoch), starts from rank 0's parameters (one
+broadcast of the flat buffer), computes local in-batch losses (the reference defines negatives within a batch,
+model.py:353-387), and the step mean-all-reduces the one flat gradient buffer (dist.sync_gradients) before the fused
+BertAdam update, which therefore stays identical on all ranks.  Dropout / triplet-sampling RNG is seeded rank-offset
+(SURVEY 8e).  Rank 0 writes checkpoints; validation uses the gallery-sharded eval, whose SumR is identical on all ranks, so
+early stopping is too."""
 import logging
 import math
 
@@ -69,29 +76,209 @@ def make_optimizer(model, opt, steps_per_epoch):
 DDP_MIN_WORLD = 2      # tests set 1 to drive the all-reduce branch with a one-rank group
 
 
+def dist_info():
+    """(rank, world) of the default process group, (0, 1) without one."""
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        return tdist.get_rank(), tdist.get_world_size()
+    return 0, 1
+
+
 def train_step(model, batch, optimizer, opt):
-    """zero_grad / forward / backward / [global clip] / step (train.py:141-151).  Returns (loss, loss_dict)."""
+    """zero_grad / forward / backward / [gradient all-reduce] / [global clip] / step (train.py:141-151).
+    Returns (loss, loss_dict).  `optimizer` needs zero_grad(), step() and - for the data-parallel branch - `.fp`
+    (optimization.FlatParams): nothing here is GPU-specific, the CPU tests drive it with a toy model over gloo."""
     optimizer.zero_grad()
     loss, loss_dict = model(batch)
     loss.backward()
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() >= DDP_MIN_WORLD:
+    if dist_info()[1] >= DDP_MIN_WORLD:
         from . import dist as ddist
-        optimizer.fp.rebind_grads()
-        ddist.all_reduce_flat(optimizer.fp.grad)
+        ddist.sync_gradients(optimizer.fp)
     if getattr(opt, "grad_clip", -1) != -1:
         torch.nn.utils.clip_grad_norm_(model.parameters(), opt.grad_clip)
     optimizer.step()
     return loss, loss_dict
 
 
-def train_epoch(model, train_loader, optimizer, opt, epoch_i, training=True):
-    """One epoch (train.py:52-183).  Returns the mean of every loss entry."""
+class _CapturedStep:
+    """One hipGraph of the training step for one batch signature, with its static device inputs."""
+
+
+class GraphedTrainStep:
+    """train_step (method/train.py:141-151: zero_grad / forward / backward / optimizer step) replayed from a hipGraph.
+
+    The eager step of this path is launch-bound: ~350 kernel launches for ~7 ms of kernel time at the TVR batch (128 videos /
+    640 queries), so its wall time follows the host - 8 to 15 ms box to box.  Captured once per batch signature, the step
+    costs one graph launch.  What had to leave the captured region, and where it went:
+      * host scalars of a step (learning rates, the batch's labels, the reference's CPU torch.randint draws for the triplet
+        negatives - made here in the reference's order - and the Philox (seed, offset) of the dropout masks) are written into
+        ONE pinned staging slot (staging.PinnedRing) and reach ONE device buffer by one asynchronous copy enqueued just before
+        the graph; the captured kernels read them from that buffer;
+      * dropout calls bake only their offset inside the step (functional.PhiloxStepState), so replays draw fresh masks and
+        a captured run reproduces the eager run with the same torch.manual_seed;
+      * float(loss) - the reference's one sync per step - happens after the replay (or never: defer_loss_float).
+    The graph key holds everything that is baked in: tensor shapes, the caption-count structure, and the per-epoch scalars
+    (alpha, belta, KD weight, hard-negative mode); a new key runs eagerly the first time and is captured the second time; at
+    most `max_graphs` graphs are kept (least recently used is dropped).
+    Data parallel (world >= 2): the graph ends after the backward pass; gradient all-reduce and the optimizer update follow
+    eagerly (3 launches)."""
+
+    TENSOR_KEYS = ("student_videos", "student_videos_mask", "teacher_videos", "student_text", "student_text_mask", "teacher_text")
+
+    def __init__(self, model, optimizer, opt, max_graphs=4, defer_loss_float=False):
+        self.model, self.optimizer, self.opt = model, optimizer, opt
+        self.max_graphs, self.defer = max_graphs, defer_loss_float
+        self.graphs, self.seen = {}, {}
+        self.replays = self.eager_steps = self.captures = 0
+
+    # -- what is baked into a graph
+    def _key(self, batch):
+        m = self.model
+        cfg = m.config
+        get = (lambda k: cfg.get(k)) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k, None))
+        shapes = tuple((k, tuple(batch[k].shape), str(batch[k].dtype)) for k in self.TENSOR_KEYS)
+        return (shapes, tuple(batch["text_labels"]) if len(batch["text_labels"]) < 4096 else len(batch["text_labels"]),
+                float(m.alpha), float(m.belta), float(m.weight), bool(get("use_hard_negative")), get("hard_pool_size"),
+                m.label_style, bool(m.training), dist_info()[1] >= DDP_MIN_WORLD, getattr(self.opt, "grad_clip", -1))
+
+    def __call__(self, batch):
+        if getattr(self.opt, "grad_clip", -1) != -1:
+            self.eager_steps += 1
+            return train_step(self.model, batch, self.optimizer, self.opt)     # clip_grad_norm_ syncs: not capturable
+        key = self._key(batch)
+        e = self.graphs.get(key)
+        if e is None:
+            self.seen[key] = self.seen.get(key, 0) + 1
+            if self.seen[key] < 2:                        # first sight: eager (also loads every kernel the graph needs)
+                self.eager_steps += 1
+                return train_step(self.model, batch, self.optimizer, self.opt)
+            e = self._capture(batch, key)
+        else:
+            self.graphs[key] = self.graphs.pop(key)       # most recently used last
+        return self._replay(e, batch)
+
+    # -- staging layout (int32 words): [philox 4][lr n_t][labels nq][per triplet call: r_t2v nq, r_v2t nv]
+    def _layout(self, e, nq, nv, n_calls):
+        n_t = len(self.optimizer.fp.params)
+        e.off = {"philox": 0, "lr": 4, "labels": 4 + n_t}
+        o = 4 + n_t + nq
+        for c in range(n_calls):
+            e.off[("t2v", c)], e.off[("v2t", c)] = o, o + nq
+            o += nq + nv
+        e.words = o
+
+    def _capture(self, batch, key):
+        from . import functional as F_
+        from .staging import PinnedRing
+        m, opt_ = self.model, self.optimizer
+        dev = batch["student_videos"].device
+        e = _CapturedStep()
+        labels = list(batch["text_labels"])
+        nq, nv = len(labels), batch["student_videos"].shape[0]
+        e.hard = bool(key[5])
+        e.n_calls = 2 if m.double_branch else 1
+        self._layout(e, nq, nv, e.n_calls)
+        e.ring = PinnedRing(4 * e.words, dev)
+        e.dev_words = torch.zeros(e.words, dtype=torch.int32, device=dev)
+        view = lambda name, n: e.dev_words[e.off[name]:e.off[name] + n]     # noqa: E731
+        e.labels_dev = view("labels", nq)
+        e.draws = [(view(("t2v", c), nq), view(("v2t", c), nv)) for c in range(e.n_calls)]
+        e.philox = F_.PhiloxStepState(view("philox", 4).view(torch.int64))
+        e.static = {k: torch.empty_like(batch[k]) for k in self.TENSOR_KEYS}
+        e.static["text_labels"] = labels
+        e.labels_np, e.nq, e.nv = __import__("numpy").asarray(labels), nq, nv
+        e.ddp = bool(key[9])
+        old_lr = opt_.t_lr
+        opt_.t_lr = view("lr", len(opt_.fp.params)).view(torch.float32)      # the update kernel reads the staged rates
+        e.t_lr = opt_.t_lr
+        cap_stream = torch.cuda.Stream(device=dev)
+        cap_stream.wait_stream(torch.cuda.current_stream())
+        old = F_.set_philox_step(e.philox)
+        try:
+            with torch.cuda.stream(cap_stream):
+                opt_.zero_grad()
+                e.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(e.graph, stream=cap_stream):
+                    loss, parts = m.forward_tensors(e.static, staged=e)
+                    loss.backward()
+                    if e.ddp:
+                        opt_.fp.rebind_grads()
+                    else:
+                        opt_.enqueue(upload_lr=False)
+                    e.loss, e.parts = loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in parts.items()}
+        except Exception:
+            opt_.t_lr = old_lr
+            raise
+        finally:
+            F_.set_philox_step(old)
+        torch.cuda.current_stream().wait_stream(cap_stream)
+        while len(self.graphs) >= self.max_graphs:
+            self.graphs.pop(next(iter(self.graphs)))
+        self.graphs[key] = e
+        self.captures += 1
+        return e
+
+    def _replay(self, e, batch):
+        from . import ops
+        m, opt_ = self.model, self.optimizer
+        for k in self.TENSOR_KEYS:
+            e.static[k].copy_(batch[k], non_blocking=True)
+        slot = e.ring.next()[:4 * e.words].view(torch.int32)
+        e.philox.begin_step(slot[0:4].view(torch.int64))
+        opt_.t_lr = e.t_lr
+        n_t = len(opt_.fp.params)
+        opt_.host_prepare(lr_out=slot[e.off["lr"]:e.off["lr"] + n_t].view(torch.float32))
+        slot[e.off["labels"]:e.off["labels"] + e.nq] = torch.from_numpy(e.labels_np.astype("int32"))
+        for c in range(e.n_calls):                        # the reference's CPU draws, same order and arguments
+            _, r_t2v, r_v2t = m._draw_triplet(e.labels_np, e.nv)
+            slot[e.off[("t2v", c)]:e.off[("t2v", c)] + e.nq] = r_t2v
+            if r_v2t is not None:
+                slot[e.off[("v2t", c)]:e.off[("v2t", c)] + e.nv] = r_v2t
+        e.ring.upload(e.dev_words.view(torch.uint8))
+        e.graph.replay()
+        if e.ddp:
+            from . import dist as ddist
+            ddist.sync_gradients(opt_.fp)
+            opt_.enqueue(upload_lr=False)
+        ops.bump_param_epoch()
+        self.replays += 1
+        out = dict(e.parts)
+        loss_overall = e.loss if self.defer else float(e.loss)
+        return e.loss, {"loss_overall": loss_overall, **out}
+
+
+def make_train_loader(train_dataset, opt, rank=None, world=None):
+    """Single process: the reference's shuffled loader (train.py:283-289).  Data parallel: a DistributedSampler cuts every
+    epoch's permutation into disjoint per-rank parts (call loader.sampler.set_epoch(epoch) before each epoch: done by
+    train()); bsz stays the per-rank batch of 128 videos, so steps per epoch - hence BertAdam's t_total - shrink by the
+    world size, as they must for the warm-up/decay schedule to span the run."""
+    if rank is None or world is None:
+        rank, world = dist_info()
+    sampler = None
+    if world > 1:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(train_dataset, num_replicas=world, rank=rank, shuffle=True, seed=int(getattr(opt, "seed", 0) or 0),
+                                     drop_last=False)
+    return DataLoader(train_dataset, batch_size=opt.bsz, shuffle=sampler is None, sampler=sampler, pin_memory=opt.pin_memory,
+                      num_workers=opt.num_workers, collate_fn=collate_train)
+
+
+def seed_rank(opt, rank):
+    """Rank-offset seed for what must differ between replicas: dropout masks (torch's CUDA generator, functional._philox_slot)
+    and the triplet negatives (CPU torch.randint, model.py:366-380).  Parameters do not depend on it: they are broadcast."""
+    seed = int(getattr(opt, "seed", 0) or 0) + rank
+    torch.manual_seed(seed)
+    return seed
+
+
+def train_epoch(model, train_loader, optimizer, opt, epoch_i, training=True, stepper=None):
+    """One epoch (train.py:52-183).  Returns the mean of every loss entry.  stepper: a GraphedTrainStep (or None: eager)."""
     from .data import host_threads
     with host_threads():
-        return _train_epoch(model, train_loader, optimizer, opt, epoch_i, training)
+        return _train_epoch(model, train_loader, optimizer, opt, epoch_i, training, stepper)
 
 
-def _train_epoch(model, train_loader, optimizer, opt, epoch_i, training=True):
+def _train_epoch(model, train_loader, optimizer, opt, epoch_i, training=True, stepper=None):
     model.train(mode=training)
     if opt.hard_negative_start_epoch != -1 and epoch_i >= opt.hard_negative_start_epoch:
         model.set_hard_negative(True, opt.hard_pool_size)
@@ -107,7 +294,7 @@ def _train_epoch(model, train_loader, optimizer, opt, epoch_i, training=True):
     for batch_idx, batch in enumerate(train_loader):
         batch = {k: (v.to(opt.device, non_blocking=True) if k != "text_labels" else v) for k, v in batch.items()}
         if training:
-            _, loss_dict = train_step(model, batch, optimizer, opt)
+            _, loss_dict = (stepper or (lambda b: train_step(model, b, optimizer, opt)))(batch)
         else:
             with torch.no_grad():
                 _, loss_dict = model(batch)
@@ -135,20 +322,28 @@ def load_checkpoint(path, opt, map_location=None):
 
 def train(model, train_dataset, val_video_dataset, val_text_dataset, opt):
     """Epoch loop with eval after each epoch, best-checkpoint saving and early stop (train.py:191-247)."""
+    rank, world = dist_info()
     model.to(opt.device)
-    loader = DataLoader(train_dataset, batch_size=opt.bsz, shuffle=True, pin_memory=opt.pin_memory,
-                        num_workers=opt.num_workers, collate_fn=collate_train)
+    loader = make_train_loader(train_dataset, opt, rank, world)
     optimizer = make_optimizer(model, opt, len(loader))
+    if world > 1:
+        from . import dist as ddist
+        from .eval import eval_epoch_sharded
+        ddist.broadcast_parameters(optimizer.fp)          # every replica starts from rank 0's weights
+        seed_rank(opt, rank)
     best, es_cnt = 0.0, 0
     history = []
     for epoch_i in range(-1 if getattr(opt, "eval_untrained", False) else 0, opt.n_epoch):
+        if loader.sampler is not None and hasattr(loader.sampler, "set_epoch"):
+            loader.sampler.set_epoch(max(epoch_i, 0))
         losses = train_epoch(model, loader, optimizer, opt, epoch_i, training=True) if epoch_i > -1 else {}
         with torch.no_grad():
-            rsum = eval_epoch(model, val_video_dataset, val_text_dataset, opt)
+            # sharded eval: every rank encodes 1/world of the gallery; its SumR is the same number on every rank
+            rsum = (eval_epoch_sharded if world > 1 else eval_epoch)(model, val_video_dataset, val_text_dataset, opt)
         history.append((epoch_i, losses, rsum))
         if rsum > best:
             best, es_cnt = rsum, 0
-            if getattr(opt, "ckpt_filepath", None):
+            if getattr(opt, "ckpt_filepath", None) and rank == 0:
                 save_checkpoint(model, epoch_i, opt.ckpt_filepath)
         else:
             es_cnt += 1

@@ -252,10 +252,13 @@ int dldkd_mul_f32(const float* a, const float* m, float scale, float* out, long 
 /* Inverted dropout in one pass (reference: nn.Dropout in model_components.py / model.py input_drop, drop).
  * keep[i] = Philox4x32-10(key = seed, counter = offset + i/4)[i%4] >= p * 2^32;  out = keep ? x / (1-p) : 0.
  * The caller advances `offset` by ceil(n/4) per call (the host side draws seed/offset from torch's CUDA generator,
- * so torch.manual_seed makes a run reproducible).  dldkd_mask_scale_f32 is the backward: out = keep ? a*scale : 0
- * (out may alias a).  Buffers 16-byte aligned, keep 4-byte aligned. */
+ * so torch.manual_seed makes a run reproducible).  state: NULL, or two device uint64 {seed, base offset}: the kernel
+ * then uses state[0] as the seed and state[1] + offset as the offset - a hipGraph-captured training step bakes `offset`
+ * (the call's position inside the step) into the graph and refreshes `state` before every replay, so replays draw new
+ * masks and a captured run equals the eager run bit for bit.  dldkd_mask_scale_f32 is the backward:
+ * out = keep ? a*scale : 0 (out may alias a).  Buffers 16-byte aligned, keep 4-byte aligned. */
 int dldkd_dropout_fwd_f32(const float* x, float* out, unsigned char* keep, long n, float p, unsigned long long seed,
-                          unsigned long long offset, void* stream);
+                          unsigned long long offset, const unsigned long long* state, void* stream);
 int dldkd_mask_scale_f32(const float* a, const unsigned char* keep, float scale, float* out, long n, void* stream);
 
 /* F.normalize(x, dim=-1) (eps 1e-12, model.py:318-319): y, inv (1/norm per row); and its backward. */
@@ -308,7 +311,8 @@ int dldkd_sum_f32(const float* x, long n, float* out, void* stream);
  * GT videos of query q are gt_idx[gt_ptr[q] .. gt_ptr[q+1]) (CSR, built from get_gt, eval.py:43-57).
  * rank_best[q]  = 1 + #(scores[q,:] > best GT score)   -> gt_ranks of eval_q2m (min over GT videos);
  * rank_first[q] = 1 + #(scores[q,:] > first GT score)  -> AP = 1/rank for t2v_map (may be NULL).
- * Queries without GT get nv + 1 (eval.py:76). */
+ * Queries without GT get nv + 1 (eval.py:76).  NaN policy: "above" is evaluated as !(s <= gt), so NaN scores count as
+ * above and a NaN ground-truth score ranks nv + 1 - a diverged model scores R@K = 0, not 100. */
 int dldkd_rank_gt(const float* scores, int nq, int nv, const int32_t* gt_ptr, const int32_t* gt_idx,
                   int32_t* rank_best, int32_t* rank_first, void* stream);
 
@@ -320,11 +324,13 @@ int dldkd_rank_gt(const float* scores, int nq, int nv, const int32_t* gt_ptr, co
  * launches.  p/g/m/v: flat fp32 buffers; tensor t = [t_start[t], t_start[t]+t_numel[t]), t_start multiples of
  * 256; chunk_tensor[c] = tensor of 256-element chunk c.  Per-tensor clip to max_grad_norm (coef =
  * min(1, max/(norm+1e-6)), optimization.py:311-312), no bias correction, update += wd_t * p, p -= lr_t * update;
- * t_lr[t] = group lr x schedule multiplier (host).  norm2_scratch: n_tensors floats. */
+ * t_lr[t] = group lr x schedule multiplier (host).  norm2_scratch: n_tensors floats.  t_active (n_tensors floats, or
+ * NULL = all): 0 marks a tensor whose gradient is None this step - it is skipped entirely (no moment decay, no weight
+ * decay), as `if p.grad is None: continue` does (optimization.py:294-295). */
 int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const int32_t* chunk_tensor, int n_chunks,
                              const int32_t* t_start, const int32_t* t_numel, int n_tensors, float* norm2_scratch,
-                             const float* t_wd, const float* t_lr, float b1, float b2, float eps, float max_grad_norm,
-                             void* stream);
+                             const float* t_wd, const float* t_lr, const float* t_active, float b1, float b2, float eps,
+                             float max_grad_norm, void* stream);
 
 /* counts[q] = #{v < nv : scores[q*ld + v] > thr[q]}: the local half of gather-free sharded ranking (each rank
  * counts the videos of its shard that beat the query's ground-truth score; the counts are all-reduced). */

@@ -24,7 +24,7 @@ def test_splitk_dw_gemm_captures_into_a_hip_graph(prec):
         x = torch.randn(K, N, generator=g, device=DEV)
         eager = ops.gemm(dy, x, True, True, M, N, K)
         ref = dy.double().t() @ x.double()
-        tol = 2e-2 if prec == "bf16" else 3e-6
+        tol = 2e-2 if prec == "bf16" else 2e-5          # fp32 accumulation over K = 16384 terms (tests/test_gemm_x3_gpu.py scales the same way)
         assert ((eager.double() - ref).abs().max() / ref.abs().max()).item() < tol
         # no workspace: legal, unsplit, same numbers up to summation order
         c = torch.empty(M, N, device=DEV)

@@ -220,3 +220,42 @@ def test_bf16_qkv_handoff_equals_fp32_handoff(bf16_mode):
             q16 = ops.linear_rows(x, pk, out_bf16=True)
             assert q16.dtype == torch.bfloat16 and torch.equal(q16.float(), q32.bfloat16().float())
             assert torch.equal(ops.attention(q32, mask), ops.attention(q16, mask))
+
+
+def test_packed_weight_caches_follow_the_fused_optimizer(golden_dir):
+    """the throughput-mode towers run on packed bf16 copies of the weights (FoldedInProj, PackedLinear)
+    keyed on (data_ptr, _version); the fused BertAdam step writes parameters through raw pointers and changes neither.
+    eval -> native optimizer steps -> eval must equal a FRESH model built from the same state_dict."""
+    import types
+    from dldkd_amd import eval as ev, ops
+    from dldkd_amd.optimization import BertAdam
+    m = _model(3072, 768, synth.make_params(51, 3072, 768))
+    vids, txts = synth.make_eval_sets(5, nv=24, caps=2, dv=3072, dq=768)
+    opt = types.SimpleNamespace(eval_context_bsz=25, eval_query_bsz=50, num_workers=0, pin_memory=False,
+                                device=torch.device(DEV), double_branch=True)
+
+    def scores(model):
+        model.eval()
+        model.fast_input_proj = True
+        with torch.no_grad():
+            ctx = ev.compute_context_info(model, synth.ListDataset(list(vids)), opt, keep_frame_feats=False)
+            return ev.score_queries(model, synth.ListDataset(list(txts)), opt, ctx)[0].clone()
+    ops.set_gemm_precision("bf16")
+    try:
+        before = scores(m)                                         # builds every packed cache
+        optim = BertAdam([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=5e-3, warmup=-1, t_total=-1, schedule="none")
+        m.train()
+        batch = synth.make_train_batch(3, nv=16, caps=2, L=12, dv=3072, dq=768)
+        batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        for _ in range(3):
+            optim.zero_grad()
+            loss, _ = m(batch)
+            loss.backward()
+            optim.step()
+        after = scores(m)
+        fresh = _model(3072, 768, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+        want = scores(fresh)
+    finally:
+        ops.set_gemm_precision("fp32")
+    assert (after - before).abs().max().item() > 1e-3              # the steps changed the scores at all
+    assert torch.equal(after, want)                                # and eval sees the CURRENT weights, exactly

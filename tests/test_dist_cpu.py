@@ -1,8 +1,11 @@
-"""CPU, gloo, world_size 2: the N>1 plumbing of the path (sharding, score all-gather assembly, gather-free
-ranking, flat gradient bucket).  The scorer/count are injected (the oracle), since there is no GPU here; the
-collectives, shard arithmetic and padding are the code under test."""
+"""CPU, gloo, world_size 2: the N>1 plumbing of the path that is SHIPPED - gallery sharding, the overlapped per-range
+all-gather assembly (OverlappedShardScorer driven by an injected CPU backend: the oracle), gather-free ranking, and the
+data-parallel half of the training step (train.train_step -> dist.sync_gradients on optimization.FlatParams, with DIFFERENT
+batches per rank, a DistributedSampler-cut dataset and the parameter broadcast).  No GPU here: scorer, count and the optimizer
+update are injected; the collectives, shard arithmetic, padding, divisor and ordering are the code under test."""
 import os
 import socket
+import types
 
 import numpy as np
 import pytest
@@ -18,15 +21,40 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, nv, nq, ret):
+def _setup(rank, world, port):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in ("dl-dkd_amd", "oracle", "tests/golden"):
         sys.path.insert(0, os.path.join(root, p))
-    from dldkd_amd import dist as ddist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
+
+
+class _OracleBackend:
+    """CPU stand-in for dist.HipShardBackend: launch() scores everything (the oracle) and marks every range complete;
+    wait_range() checks the counter like the stream wait would."""
+
+    def __init__(self, q, g, mask, n_ranges):
+        self.q, self.g, self.mask, self.arrivals, self.n_ranges = q, g, mask, 3, n_ranges
+        self.launches = 0
+
+    def launch(self, done):
+        assert int(done.abs().sum()) == 0                   # the scorer zeroes the counters before every launch
+        self.full = orc.sim_scores(self.q, self.g, self.mask)[0]
+        done[:self.n_ranges] = self.arrivals
+        self.launches += 1
+
+    def wait_range(self, done, r):
+        assert int(done[r]) >= self.arrivals
+
+    def finish_range(self, r, lo, hi, out):
+        out.copy_(self.full[lo:hi])
+
+
+def _eval_worker(rank, world, port, nv, nq, ret):
+    _setup(rank, world, port)
+    from dldkd_amd import dist as ddist
     d = synth.make_gallery(77, nq, nv, 16, 3, sigma=3.0)
     lo, hi, s = ddist.shard_range(nv, rank, world)
     g, mask = d["g"][lo:hi], d["mask"][lo:hi]
@@ -34,25 +62,23 @@ def _worker(rank, world, port, nv, nq, ret):
         pad = s - (hi - lo)
         g = torch.cat([g, torch.zeros(pad, 16, 384)]); mask = torch.cat([mask, torch.zeros(pad, 16)]); mask[hi - lo:, 0] = 1
     local = orc.sim_scores(d["q"], g, mask)[0]        # (Nq, S): the injected scorer
-    full = ddist.gather_scores(local, nv)
-    ranks = ddist.sharded_gt_ranks(local, d["gt"], nv, count_fn=lambda sc, thr, n: (sc[:, :n] > thr[:, None]).sum(1).int())
-    # chunked, overlapped all-gather (what bench.py --gpus N runs)
-    def score_chunk(lo, hi, out):
-        out.copy_(orc.sim_scores(d["q"][lo:hi], g, mask)[0])
-    ov = ddist.OverlappedShardScorer(score_chunk, nq, s, 3, "cpu")
+    gt = d["gt"].clone()
+    gt[0] = -1                                        # a caption whose video is not in the gallery: rank nv + 1
+    ranks = ddist.sharded_gt_ranks(local, gt, nv, count_fn=lambda sc, thr, n: (~(sc[:, :n] <= thr[:, None])).sum(1).int())
+    # a NaN ground-truth score ranks last on every rank
+    local_nan = local.clone()
+    if lo <= int(d["gt"][1]) < hi:
+        local_nan[1, int(d["gt"][1]) - lo] = float("nan")
+    ranks_nan = ddist.sharded_gt_ranks(local_nan, d["gt"], nv, count_fn=lambda sc, thr, n: (~(sc[:, :n] <= thr[:, None])).sum(1).int())
+    # one launch, per-range finish + all-gather (what bench.py --gpus N runs)
+    bounds = ddist.query_ranges(nq, 3, 4)
+    be = _OracleBackend(d["q"], g, mask, len(bounds))
+    ov = ddist.OverlappedShardScorer(be, bounds, s, "cpu")
     ov.step()
-    ov.step()                                            # buffers are reusable across steps
+    ov.step()                                            # buffers and counters are reusable across steps
     full_ov = ov.assemble(nv)
-    # gradient bucket
-    torch.manual_seed(rank)
-    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
-    for p in ps:
-        p.grad = torch.full_like(p, float(rank + 1))
-    b = ddist.FlatGradBucket(ps)
-    b.all_reduce_mean()
     if rank == 0:
-        ret["full"], ret["ranks"], ret["grad"] = full.numpy(), ranks.numpy(), [p.grad.clone().numpy() for p in ps]
-        ret["full_ov"] = full_ov.numpy()
+        ret["ranks"], ret["ranks_nan"], ret["full_ov"], ret["launches"] = ranks.numpy(), ranks_nan.numpy(), full_ov.numpy(), be.launches
     dist.barrier()
     dist.destroy_process_group()
 
@@ -61,15 +87,15 @@ def _worker(rank, world, port, nv, nq, ret):
 def test_sharded_eval_two_ranks(nv, nq):
     world, port = 2, _free_port()
     mgr = mp.Manager(); ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, nv, nq, ret), nprocs=world, join=True)
+    mp.spawn(_eval_worker, args=(world, port, nv, nq, ret), nprocs=world, join=True)
     d = synth.make_gallery(77, nq, nv, 16, 3, sigma=3.0)
     ref = orc.sim_scores(d["q"], d["g"], d["mask"])[0].numpy()
-    np.testing.assert_allclose(ret["full"], ref, rtol=0, atol=1e-6)           # sharded == unsharded
-    np.testing.assert_allclose(ret["full_ov"], ref, rtol=0, atol=1e-6)        # chunked + overlapped gather too
+    np.testing.assert_allclose(ret["full_ov"], ref, rtol=0, atol=1e-6)        # per-range gathered == unsharded
+    assert ret["launches"] == 2                                               # ONE scorer launch per step
     gts = {q: [int(d["gt"][q])] for q in range(nq)}
-    assert (ret["ranks"] == orc.gt_ranks(-ref, gts)).all()                    # gather-free ranks are exact
-    for gr in ret["grad"]:
-        np.testing.assert_allclose(gr, 1.5)                                   # mean of ranks' grads (1, 2)
+    want = orc.gt_ranks(-ref, gts)
+    assert (ret["ranks"][1:] == want[1:]).all() and ret["ranks"][0] == nv + 1  # gather-free ranks are exact
+    assert ret["ranks_nan"][1] == nv + 1 and (np.delete(ret["ranks_nan"], 1) == np.delete(want, 1)).all()
 
 
 def test_shard_range_covers_everything():
@@ -82,3 +108,114 @@ def test_shard_range_covers_everything():
                 assert 0 <= hi - lo <= s
                 cover += list(range(lo, hi))
             assert cover == list(range(nv))
+    assert ddist.query_ranges(17505, 4, 4384) == [(0, 4384), (4384, 8768), (8768, 13152), (13152, 17505)]
+
+
+# ------------------------------------------------------------------------------------------ training, data parallel
+class _ToyModel(torch.nn.Module):
+    """Stands in for DLDKD in the CPU test of the shipped train_step: same calling convention (batch dict -> (loss, dict)),
+    several parameter shapes, one parameter that never receives a gradient."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(6, 5)
+        self.b = torch.nn.Linear(5, 1, bias=False)
+        self.unused = torch.nn.Parameter(torch.ones(3))
+
+    def forward(self, batch):
+        y = self.b(torch.tanh(self.a(batch["x"]))).squeeze(-1)
+        loss = ((y - batch["y"]) ** 2).mean()
+        return loss, {"loss_overall": float(loss.detach())}
+
+
+class _SGDOnFlat:
+    """Injected optimizer: the FlatParams machinery of BertAdam (shipped) with a plain SGD update (the fused HIP update needs a
+    GPU).  zero_grad / step follow BertAdam's: drop the grads, rebind, update the flat buffer."""
+
+    def __init__(self, params, lr):
+        from dldkd_amd.optimization import FlatParams
+        self.fp, self.lr = FlatParams(list(params)), lr
+
+    def zero_grad(self):
+        self.fp.drop_grads()
+
+    def step(self):
+        had = self.fp.rebind_grads()
+        self.fp.flat.sub_(self.lr * self.fp.grad)
+        return had
+
+
+def _data(n=24):
+    g = torch.Generator().manual_seed(5)
+    return torch.randn(n, 6, generator=g), torch.randn(n, generator=g)
+
+
+def _train_worker(rank, world, port, ret):
+    _setup(rank, world, port)
+    from torch.utils.data import TensorDataset
+    from dldkd_amd import dist as ddist
+    from dldkd_amd import train as T
+    torch.manual_seed(100 + rank)                       # replicas are BORN different ...
+    model = _ToyModel()
+    opt_ = _SGDOnFlat(model.parameters(), lr=0.1)
+    ddist.broadcast_parameters(opt_.fp)                  # ... and start from rank 0's weights
+    start = opt_.fp.flat.clone()
+    x, y = _data()
+    ds = TensorDataset(x, y)
+    cfg = types.SimpleNamespace(bsz=4, pin_memory=False, num_workers=0, seed=3, grad_clip=-1)
+    # per-rank data: the DistributedSampler of make_train_loader (collate replaced: toy items are (x, y) pairs)
+    loader = T.make_train_loader(ds, cfg, rank, world)
+    seen = []
+    hist = []
+    for epoch in range(2):
+        loader.sampler.set_epoch(epoch)
+        idx = list(iter(loader.sampler))
+        seen.append(idx)
+        for i in range(0, len(idx), cfg.bsz):
+            b = idx[i:i + cfg.bsz]
+            batch = {"x": x[b], "y": y[b]}
+            _, ld = T.train_step(model, batch, opt_, cfg)          # the shipped step: fwd, bwd, sync_gradients, update
+            hist.append((b, ld["loss_overall"], opt_.fp.grad.clone()))
+    ret[rank] = dict(start=start.numpy(), final=opt_.fp.flat.clone().numpy(), seen=seen,
+                     grads=[h[2].numpy() for h in hist], batches=[h[0] for h in hist],
+                     unused=model.unused.detach().numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shipped_train_step_two_ranks_different_batches():
+    """What the one-rank RCCL test could not catch (mean over one rank is the identity): the divisor, a missing reduce, replicas
+    that drift.  Two ranks, different batches; the averaged gradient must equal the mean of the per-rank gradients computed
+    here in ONE process, and both replicas must hold identical parameters after every step."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_train_worker, args=(world, port, ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    np.testing.assert_array_equal(r0["start"], r1["start"])                   # broadcast from rank 0
+    np.testing.assert_array_equal(r0["final"], r1["final"])                   # replicas never drift
+    np.testing.assert_array_equal(r0["unused"], np.ones(3, np.float32))
+    for e in range(2):                                                        # the sampler cuts each epoch disjointly
+        a, b = set(r0["seen"][e]), set(r1["seen"][e])
+        assert not (a & b) and a | b == set(range(24))
+    assert r0["seen"][0] != r0["seen"][1]                                     # set_epoch reshuffles
+    # replay in one process: same start, per-rank batches, gradient = MEAN of the two ranks' gradients
+    torch.manual_seed(100)
+    model = _ToyModel()
+    from dldkd_amd.optimization import FlatParams
+    fp = FlatParams(list(model.parameters()))
+    np.testing.assert_array_equal(fp.flat.numpy(), r0["start"])
+    x, y = _data()
+    for step, (b0, b1) in enumerate(zip(r0["batches"], r1["batches"])):
+        gs = []
+        for b in (b0, b1):
+            fp.drop_grads()
+            loss, _ = model({"x": x[b], "y": y[b]})
+            loss.backward()
+            fp.rebind_grads()
+            gs.append(fp.grad.clone())
+        mean = (gs[0] + gs[1]) / 2
+        assert not torch.equal(gs[0], gs[1])                                  # the batches really differ
+        np.testing.assert_allclose(r0["grads"][step], mean.numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(r0["grads"][step], r1["grads"][step])
+        fp.flat.sub_(0.1 * mean)
+    np.testing.assert_allclose(fp.flat.numpy(), r0["final"], rtol=1e-5, atol=1e-6)

@@ -1,0 +1,43 @@
+"""GPU, one-rank RCCL group: the sharded scoring step as bench.py --gpus N runs it - ONE scorer launch with per-range
+arrival counters, a side stream parked on each counter (hipStreamWaitValue32), per-range finish + all_gather - must
+reproduce the plain one-launch matrix bit for bit, step after step (counters and buffers are reused)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_overlapped_shard_scorer_one_rank_rccl():
+    import torch.distributed as dist
+    from dldkd_amd import dist as ddist
+    from dldkd_amd import scoring
+    nq, nv, L = 5000, 615, 128
+    g = torch.Generator(device=DEV).manual_seed(9)
+    lens = torch.randint(1, L + 1, (nv,), generator=g, device=DEV)
+    mask = (torch.arange(L, device=DEV)[None] < lens[:, None]).float()
+    gal = [torch.randn(nv, L, 384, generator=g, device=DEV) * mask[..., None] for _ in range(2)]
+    qs = [torch.randn(nq, 384, generator=g, device=DEV) for _ in range(2)]
+    pg = scoring.pack_gallery(gal, mask)
+    ref = scoring.simpool_eval(scoring.pack_queries(qs), pg)[0]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29593", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device(DEV))
+    try:
+        n, per = scoring.plan_query_split(nq, nv, 2, min_split=4)
+        assert n >= 4
+        backend = ddist.HipShardBackend(qs, pg, n)
+        ov = ddist.OverlappedShardScorer(backend, ddist.query_ranges(nq, n, per), nv, DEV)
+        for _ in range(3):
+            ov.step()
+        torch.cuda.synchronize()
+        assert torch.equal(ov.assemble(nv), ref)
+        assert ov.done.cpu().tolist() == [backend.arrivals] * n
+        # new queries through the same object: nothing stale survives a step
+        qs[0].copy_(torch.randn(nq, 384, generator=g, device=DEV))
+        ov.step()
+        torch.cuda.synchronize()
+        assert torch.equal(ov.assemble(nv), scoring.simpool_eval(scoring.pack_queries(qs), pg)[0])
+    finally:
+        dist.destroy_process_group()

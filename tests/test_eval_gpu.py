@@ -155,3 +155,44 @@ def test_streaming_context_and_query_super_batches_equal_per_batch_path():
         _, qs_big = ev._encode_all_queries(m, synth.ListDataset(list(txts)), opt)
         for x, y in zip(qs_small, qs_big):
             assert x.shape == y.shape and (x - y).abs().max().item() < 2e-6
+
+
+def test_eval_epoch_sharded_edge_cases(recwarn):
+    """ids come from the dataset's `video_ids` attribute (the reference's VisDataSet4DLDKD has it, data_provider.py:270-275):
+    no feature is read to build the ground truth; a caption whose video is missing from the gallery ranks nv + 1 like in the
+    unsharded path; an empty gallery shard (more ranks than videos) scores nothing and still returns."""
+    import os
+    import torch.distributed as dist
+    from dldkd_amd import eval as ev
+    m = _model(1024, 1024, synth.make_params(13, 1024, 1024))
+    vids, txts = synth.make_eval_sets(8, nv=21, caps=2, dv=1024, dq=1024)
+    txts = list(txts) + [(txts[0][0], len(txts), "no_such_video#enc#0")]
+
+    class CountingGallery(synth.ListDataset):
+        reads = 0
+
+        def __init__(self, items):
+            super().__init__(items)
+            self.video_ids = [it[2] for it in items]
+
+        def __getitem__(self, i):
+            CountingGallery.reads += 1
+            return self.items[i]
+    opt = _opt()
+    with torch.no_grad():
+        ref = ev.eval_epoch(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), opt)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29579", RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("nccl", device_id=torch.device(DEV))
+        try:
+            gal = CountingGallery(list(vids))
+            got = ev.eval_epoch_sharded(m, gal, synth.ListDataset(list(txts)), opt)
+            assert CountingGallery.reads == len(vids)              # each video read once (to encode it), none for the ids
+            assert ev.gallery_ids(gal) == [v[2] for v in vids]
+            # empty shard: what rank r >= n_videos sees
+            ctx = ev.compute_context_info(m, synth.ListDataset([]), opt, keep_frame_feats=False)
+            fused, s0, s1, _ = ev.score_queries(m, synth.ListDataset(list(txts)), opt, ctx)
+            assert fused.shape == (len(txts), 0) and ctx["_packed"].nv == 0
+        finally:
+            dist.destroy_process_group()
+    assert got == pytest.approx(ref)
+    assert not [w for w in recwarn.list if "video_ids" in str(w.message)]

@@ -67,3 +67,53 @@ def test_train_step_updates_all_parameters():
     assert float(opt.fp.grad.abs().sum()) > 0
     moved = [n for n, p in named if not torch.equal(p.detach(), before[n])]
     assert len(moved) == 74
+
+
+def test_parameters_without_gradient_are_skipped():
+    """`if p.grad is None: continue` (reference optimization.py:294-295): a parameter that received no gradient keeps its value
+    AND its moments - no weight decay, no moment decay - while the others step; when it gets a gradient again it steps from
+    the moments it had."""
+    from dldkd_amd.optimization import BertAdam
+    torch.manual_seed(0)
+    a = torch.nn.Parameter(torch.randn(300, device=DEV))
+    b = torch.nn.Parameter(torch.randn(10, 40, device=DEV))
+    opt = BertAdam([{"params": [a, b], "weight_decay": 0.01}], lr=1e-2, warmup=-1, t_total=-1, schedule="none")
+    a.grad, b.grad = torch.randn(300, device=DEV), torch.randn(10, 40, device=DEV)
+    opt.step()
+    a1, b1 = a.detach().clone(), b.detach().clone()
+    m1 = opt.m.clone()
+    opt.zero_grad()
+    a.grad = torch.randn(300, device=DEV)            # b gets nothing this step
+    opt.step()
+    assert not torch.equal(a.detach(), a1)
+    assert torch.equal(b.detach(), b1)               # untouched: no weight decay, no lr * m / sqrt(v)
+    sb = opt.fp._starts[1]
+    assert torch.equal(opt.m[sb:sb + 400], m1[sb:sb + 400])      # moments did not decay
+    opt.zero_grad()
+    a.grad, b.grad = torch.randn(300, device=DEV), torch.randn(10, 40, device=DEV)
+    opt.step()
+    assert not torch.equal(b.detach(), b1)
+
+
+def test_count_above_and_ranks_with_nan_scores():
+    """NaN policy (rank.hip): NaN scores count as above, a NaN ground-truth score ranks nv + 1: a diverged model must not
+    report R@K = 100 (with s > gt every comparison against NaN is false -> rank 1 for every query)."""
+    from dldkd_amd import dist as ddist
+    from dldkd_amd import eval as ev
+    s = torch.full((4, 200), float("nan"), device=DEV)
+    gts = {q: [q] for q in range(4)}
+    rb, rf = ev.gt_ranks_gpu(s, gts)
+    assert rb.cpu().tolist() == [201] * 4 and rf.cpu().tolist() == [201] * 4
+    assert ev.eval_q2m(-s, gts)[:4] == (0.0, 0.0, 0.0, 0.0)
+    g = torch.Generator().manual_seed(2)
+    s = torch.randn(6, 40, generator=g)
+    s[0, 7] = float("nan")                            # a NaN competitor counts as above the ground truth
+    s[1, 1] = float("nan")                            # a NaN ground truth ranks last
+    rb, _ = ev.gt_ranks_gpu(s.to(DEV), {q: [q] for q in range(6)})
+    want0 = 1 + int((s[0] > s[0, 0]).sum()) + 1
+    assert rb.cpu().tolist()[0] == want0 and rb.cpu().tolist()[1] == 41
+    for q in range(2, 6):
+        assert int(rb[q]) == 1 + int((s[q] > s[q, q]).sum())
+    thr = torch.tensor([0.0, float("nan")])
+    c = ddist._count_above_hip(torch.tensor([[1.0, float("nan"), -1.0], [0.5, 0.1, float("nan")]], device=DEV), thr.to(DEV), 3)
+    assert c.cpu().tolist() == [2, 3]

@@ -292,6 +292,38 @@ def test_forward_at_c3_size_vs_oracle():
     assert all(prm.grad is not None and torch.isfinite(prm.grad).all() for prm in m.parameters())
 
 
+@pytest.mark.parametrize("hard", [True, False])
+def test_forward_at_c5_size_vs_oracle(hard):
+    """BASELINE configs[4], one rank's step (Charades-STA: 128 videos, captions per video [3, 2, 2, ...] = 257 queries,
+    <= 64 clips, 1024-d student features for both modalities, /root/reference/do_charades.sh:6-14): the 7 losses of
+    DLDKD.forward against the fp32 oracle on the same tensors and the same CPU random draws, 1e-4 relative (north_star),
+    plus finite gradients on all 74 parameters.  Dropout off, like golden G4 (its Philox masks have no reference twin)."""
+    m = _model(1024, 1024, synth.make_params(45, 1024, 1024))
+    m.label_style = "soft"
+    m.set_hard_negative(hard, 20)
+    m.weight = 1.0
+    caps = sorted([3] + [2] * 127, reverse=True)
+    batch = synth.make_train_batch(5, nv=128, caps=caps, L=64, len_lo=8, dv=1024, dq=1024)
+    labels = batch["text_labels"]
+    assert len(labels) == 257
+    torch.manual_seed(55)
+    rnd = [orc.draw_triplet_randoms(labels, 128, hard, 20) for _ in range(2)]
+    p = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    cfg = dict(n_heads=4, margin=0.1, use_hard_negative=hard, label_style="soft", kl_intra_weight=0.1, weight=m.weight,
+               inher_nce_weight=0.04, explore_nce_weight=0.04, alpha=0.8, belta=0.8)
+    with torch.no_grad():
+        ref = orc.forward_losses(p, batch, cfg, rnd)
+    dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    torch.manual_seed(55)
+    loss, d = m(dbatch)
+    for k in ("inher_trip", "inher_nce", "explore_trip", "explore_nce", "kl_intra"):
+        _close(d[k], ref[k])
+    _close(d["kl"], ref["kl_intra"])
+    _close(loss, ref["loss"])
+    loss.backward()
+    assert all(prm.grad is not None and torch.isfinite(prm.grad).all() for prm in m.parameters())
+
+
 def test_loss_kernels_fuzz_vs_oracle():
     """Random batch structures (2..40 videos, 1..4 captions each, 1..48 clips, random alpha/beta, both negative
     modes) through every loss kernel: value 1e-4 and gradient 2e-3 against the fp64 oracle."""
