@@ -180,7 +180,7 @@ extern "C" int dldkd_attention_fwd_bf16(const void* qkv, const float* mask, floa
                hipFuncSetAttribute((const void*)attention_fwd_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) == hipSuccess;
     }();
     (void)attr_ok;
-    if (qkv_is_bf16) hipLaunchKernelGGL(attention_fwd_bf16_kernel<true>, dim3(N * aHeads), dim3(256), lds, (hipStream_t)stream, qkv, mask, out, L);
-    else hipLaunchKernelGGL(attention_fwd_bf16_kernel<false>, dim3(N * aHeads), dim3(256), lds, (hipStream_t)stream, qkv, mask, out, L);
+    if (qkv_is_bf16) DLDKD_LAUNCH(attention_fwd_bf16_kernel<true>, dim3(N * aHeads), dim3(256), lds, (hipStream_t)stream, qkv, mask, out, L);
+    else DLDKD_LAUNCH(attention_fwd_bf16_kernel<false>, dim3(N * aHeads), dim3(256), lds, (hipStream_t)stream, qkv, mask, out, L);
     return check_launch("attention_fwd_bf16");
 }

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 int launch_splitk_reduce(const float* ws, float* out, int split, long n, hipStream_t s) {
     // n = M * N is a multiple of 4 (N of the split shapes is a multiple of 128) and both buffers are 16-byte aligned
     if ((n & 3) || ((uintptr_t)out & 15)) { set_error("split-K reduce: unaligned output"); return DLDKD_EINVAL; }
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, ws, out, split, n / 4, n / 4);
+    DLDKD_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, ws, out, split, n / 4, n / 4);
     return check_launch("splitk_reduce");
 }
 

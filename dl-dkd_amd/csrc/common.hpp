@@ -100,11 +100,119 @@ __device__ __forceinline__ void gemm_store_tile(const f32x16 (&acc)[2][2], const
     }
 }
 
+// ---- training simpool epilogue (simpool_train.hip): the batched GEMM S_v = G_v Q^T (one video per blockIdx.z, M = L <= 128 clips on
+// the tile rows, queries on the columns) ends in a key-clip max-pool instead of a store, so the (Nq, Nv, L) clip tensor of
+// get_sim_scores / get_unnormalized_sim_scores (reference method/model.py:307-350) is never written:
+//   pooled_raw[n, v] = max_{l < len_v} S[l, n]                      arg_raw = its clip            (model.py:344-349)
+//   pooled_cos[n, v] = rq[n] * max_{l < len_v} S[l, n] * rg[v, l]   arg_cos = its clip            (model.py:318-327)
+//   clip_pos[n, l]   = S[l, n] * rg[v, l] * rq[n]  (l < len_v, else -1e10)  only where labels[n] == v: the one column of
+//                      the clip-level tensor that compute_kl_loss reads (model.py:183-197)
+// rq / rg = 1 / max(|row|, 1e-12) (F.normalize): cos = <q, g> / (|q| |g|) from the SAME raw product, half the GEMM work.
+struct PoolArgs {
+    const float* rg;        // [nv * L]
+    const float* rq;        // [nq]
+    const int32_t* lens;    // [nv]
+    const int32_t* labels;  // [nq]
+    float* pooled_raw;      // [nq, nv]
+    float* pooled_cos;      // [nq, nv]
+    int32_t* arg_raw;       // [nq, nv]
+    int32_t* arg_cos;       // [nq, nv]
+    float* clip_pos;        // [nq, L] or null
+    int nv, L;
+};
+
+// acc: the 128 x 128 block's accumulators in the layout of the three tiled GEMMs (wave (wm, wn) owns rows wm..wm+63, columns
+// wn..wn+63 as 2 x 2 tiles of 32 x 32: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).
+// scratch: >= 4 * 64 * 4 floats of LDS, free after the k-loop's last barrier.
+template <typename Args>
+__device__ __forceinline__ void gemm_pool_tile(const f32x16 (&acc)[2][2], const Args& p, const PoolArgs& pa, int v, int n0, int wm,
+                                               int wn, int lane, int wave, float* scratch) {
+    const int len = pa.lens[v];
+    const int half = lane >> 5;
+    float braw[2] = {-INFINITY, -INFINITY}, bcos[2] = {-INFINITY, -INFINITY};
+    int iraw[2] = {0x7fffffff, 0x7fffffff}, icos[2] = {0x7fffffff, 0x7fffffff};
+    const float* rgv = pa.rg + (size_t)v * pa.L;
+    int lab[2];
+    float rqn[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + 32 * j + (lane & 31);
+        lab[j] = n < p.N ? pa.labels[n] : -1;
+        rqn[j] = n < p.N ? pa.rq[n] : 0.f;
+    }
+    const bool any_pos = pa.clip_pos != nullptr && __any(lab[0] == v || lab[1] == v);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;     // increasing in (i, r): first maximum wins
+            const bool valid = row < len;
+            const float rgl = valid ? rgv[row] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float s = acc[i][j][r] * p.alpha;
+                const float c = s * rgl;
+                if (valid && s > braw[j]) { braw[j] = s; iraw[j] = row; }
+                if (valid && c > bcos[j]) { bcos[j] = c; icos[j] = row; }
+                if (any_pos && lab[j] == v && row < pa.L)
+                    pa.clip_pos[(size_t)(n0 + wn + 32 * j + (lane & 31)) * pa.L + row] = valid ? c * rqn[j] : -1e10f;
+            }
+        }
+    // other half of the wave (rows + 4), then the wave that holds the other 64 rows
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float ob = __shfl_xor(braw[j], 32), oc = __shfl_xor(bcos[j], 32);
+        const int oi = __shfl_xor(iraw[j], 32), oj = __shfl_xor(icos[j], 32);
+        if (ob > braw[j] || (ob == braw[j] && oi < iraw[j])) { braw[j] = ob; iraw[j] = oi; }
+        if (oc > bcos[j] || (oc == bcos[j] && oj < icos[j])) { bcos[j] = oc; icos[j] = oj; }
+    }
+    float* mine = scratch + wave * 256;
+    if (half == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* e = mine + (32 * j + lane) * 4;
+            e[0] = braw[j]; e[1] = __int_as_float(iraw[j]); e[2] = bcos[j]; e[3] = __int_as_float(icos[j]);
+        }
+    }
+    __syncthreads();
+    if (wm == 0 && half == 0) {
+        const float* other = scratch + (wave + 2) * 256;       // wave + 2: same columns, rows 64..127
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + lane;
+            if (n >= p.N) continue;
+            const float* e = other + (32 * j + lane) * 4;
+            const float ob = e[0], oc = e[2];
+            const int oi = __float_as_int(e[1]), oj = __float_as_int(e[3]);
+            if (ob > braw[j] || (ob == braw[j] && oi < iraw[j])) { braw[j] = ob; iraw[j] = oi; }
+            if (oc > bcos[j] || (oc == bcos[j] && oj < icos[j])) { bcos[j] = oc; icos[j] = oj; }
+            const size_t o = (size_t)n * pa.nv + v;
+            const bool none = len <= 0;                          // no valid clip: the reference's masked maximum (-1e10, clip 0)
+            pa.pooled_raw[o] = none ? -1e10f : braw[j];
+            pa.pooled_cos[o] = none ? -1e10f : bcos[j] * rqn[j];
+            pa.arg_raw[o] = none ? 0 : iraw[j];
+            pa.arg_cos[o] = none ? 0 : icos[j];
+        }
+    }
+}
+
 // split-K plans of the three tiled GEMMs (number of k-slices, 1 = none), shared with dldkd_gemm_workspace_bytes
 int gemm_f32_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor, int* k_tiles_per_split);
 int gemm_f32x3_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor, int* k_tiles_per_split);
 int gemm_bf16_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor, int* k_tiles_per_split);
+// pooled batched GEMMs (gemm_f32x3.hip / gemm_bf16.hip): g (nv, L, D), q (nq, D) -> the PoolArgs outputs
+int launch_simpool_pool_x3(const float* g, const float* q, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream);
+int launch_simpool_pool_bf16(const float* g, const float* q, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream);
 int launch_splitk_reduce(const float* ws, float* out, int split, long n, hipStream_t s);
+// Every kernel launch of the library: drop whatever error another library left in the runtime's sticky per-thread slot
+// (torch's caching allocator probes the runtime while a hipGraph is being captured and leaves hipErrorInvalidValue behind),
+// so that check_launch() reports THIS launch only.
+#define DLDKD_LAUNCH(...)                \
+    do {                                 \
+        (void)hipGetLastError();         \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 

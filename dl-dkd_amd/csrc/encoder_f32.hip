@@ -262,10 +262,10 @@ int dldkd_layernorm_f32(const float* x, const float* add, int add_mod, const flo
     const dim3 grid((unsigned)((M + 3) / 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int nv = (D / 4 + 63) / 64;
-    if (nv <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
-    else if (nv <= 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
-    else if (nv <= 8) hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
-    else hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
+    if (nv <= 2) DLDKD_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
+    else if (nv <= 4) DLDKD_LAUNCH(layernorm_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
+    else if (nv <= 8) DLDKD_LAUNCH(layernorm_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
+    else DLDKD_LAUNCH(layernorm_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
     return check_launch("layernorm");
 }
 
@@ -280,7 +280,7 @@ int dldkd_attention_fwd_f32(const float* qkv, const float* mask, float* out, int
                                    (2 * kLmax * kLdQK + kLmax * kDh + kLmax) * (int)sizeof(float)) == hipSuccess;
     }();
     (void)attr_ok;
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(N * kHeads), dim3(256), lds, (hipStream_t)stream, qkv, mask, out, L);
+    DLDKD_LAUNCH(attention_fwd_kernel, dim3(N * kHeads), dim3(256), lds, (hipStream_t)stream, qkv, mask, out, L);
     return check_launch("attention_fwd");
 }
 
@@ -289,7 +289,7 @@ int dldkd_modpool_fwd_f32(const float* h, const float* mask, const float* w, flo
     if (N < 0 || L < 1 || L > 64) { set_error("modpool: bad sizes N=%d L=%d (L <= 64)", N, L); return DLDKD_EINVAL; }
     if (N == 0) return DLDKD_OK;
     if (!h || !mask || !w || !out) { set_error("modpool: null pointer"); return DLDKD_EINVAL; }
-    hipLaunchKernelGGL(modpool_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, mask, w, out, attn, N, L);
+    DLDKD_LAUNCH(modpool_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, mask, w, out, attn, N, L);
     return check_launch("modpool_fwd");
 }
 

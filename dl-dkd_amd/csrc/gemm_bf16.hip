@@ -110,8 +110,8 @@ struct TileH {
     }
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmHArgs p) {
+template <bool A_KMAJOR, bool B_KMAJOR, bool POOL>
+__device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const PoolArgs* pa) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_raw[];
     unsigned short (*lds)[2][HBM_ * HPITCH] = reinterpret_cast<unsigned short (*)[2][HBM_ * HPITCH]>(lds_raw);
     if (p.split_k > 1) {
@@ -180,7 +180,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmHArgs p) {
         __syncthreads();
     }
     // (the k-loop ended with a barrier: every wave is done with the operand tiles, the LDS is free for staging)
-    gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(lds_raw) + wave * (32 * 72));
+    if constexpr (POOL) gemm_pool_tile(acc, p, *pa, (int)blockIdx.z, n0, wm, wn, lane, wave, reinterpret_cast<float*>(lds_raw));
+    else gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(lds_raw) + wave * (32 * 72));
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmHArgs p) {
+    gemm_bf16_body<A_KMAJOR, B_KMAJOR, false>(p, nullptr);
+}
+// training simpool: one video per blockIdx.z, max-pool epilogue (common.hpp, gemm_pool_tile)
+__global__ __launch_bounds__(256) void gemm_bf16_pool_kernel(GemmHArgs p, PoolArgs pa) {
+    gemm_bf16_body<false, false, true>(p, &pa);
 }
 
 static int launch_gemm_h(GemmHArgs p, int batch, int a_kmajor, int b_kmajor, void* stream) {
@@ -196,11 +206,21 @@ static int launch_gemm_h(GemmHArgs p, int batch, int a_kmajor, int b_kmajor, voi
         return ok;
     }();
     (void)attr_ok;
-    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, lds, s, p);
-    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, lds, s, p);
-    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, lds, s, p);
+    if (!a_kmajor && !b_kmajor) DLDKD_LAUNCH((gemm_bf16_kernel<false, false>), grid, block, lds, s, p);
+    else if (!a_kmajor && b_kmajor) DLDKD_LAUNCH((gemm_bf16_kernel<false, true>), grid, block, lds, s, p);
+    else if (a_kmajor && b_kmajor) DLDKD_LAUNCH((gemm_bf16_kernel<true, true>), grid, block, lds, s, p);
+    else DLDKD_LAUNCH((gemm_bf16_kernel<true, false>), grid, block, lds, s, p);
     return check_launch("gemm_bf16");
+}
+
+int launch_simpool_pool_bf16(const float* g, const float* q, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream) {
+    const bool al = !(D & 3) && !((uintptr_t)g & 15), bl = !(D & 3) && !((uintptr_t)q & 15);
+    GemmHArgs p{g, q, nullptr, nullptr, L, nq, D, D, D, nq, 0, al, bl, 1, (long)L * D, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+    constexpr size_t lds = sizeof(unsigned short) * 2 * 2 * HBM_ * HPITCH;
+    static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_bf16_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    (void)attr_ok;
+    DLDKD_LAUNCH(gemm_bf16_pool_kernel, dim3((nq + HBN_ - 1) / HBN_, 1, nv), dim3(256), lds, (hipStream_t)stream, p, pa);
+    return check_launch("simpool_train_fwd (bf16)");
 }
 
 }  // namespace dldkd

@@ -208,10 +208,10 @@ using namespace dldkd;
 static int launch_gemm(GemmArgs p, int batch, int a_kmajor, int b_kmajor, void* stream) {
     const dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p);
-    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p);
-    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, p);
+    if (!a_kmajor && !b_kmajor) DLDKD_LAUNCH((gemm_f32_kernel<false, false>), grid, block, 0, s, p);
+    else if (!a_kmajor && b_kmajor) DLDKD_LAUNCH((gemm_f32_kernel<false, true>), grid, block, 0, s, p);
+    else if (a_kmajor && b_kmajor) DLDKD_LAUNCH((gemm_f32_kernel<true, true>), grid, block, 0, s, p);
+    else DLDKD_LAUNCH((gemm_f32_kernel<true, false>), grid, block, 0, s, p);
     return check_launch("gemm_f32");
 }
 

@@ -129,8 +129,8 @@ struct TileX {
     }
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(256) void gemm_f32x3_kernel(GemmXArgs p) {
+template <bool A_KMAJOR, bool B_KMAJOR, bool POOL>
+__device__ __forceinline__ void gemm_f32x3_body(GemmXArgs p, const PoolArgs* pa) {
     __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][3 * XPLANE];   // [stage][A|B][plane][row][k]: 72 KiB
     if (p.split_k > 1) {
         p.C += (size_t)blockIdx.z * p.M * p.ldc;      // this split's partial plane in the workspace
@@ -216,17 +216,34 @@ __global__ __launch_bounds__(256) void gemm_f32x3_kernel(GemmXArgs p) {
         if (kt + 1 < nk) iter(kt + 1, S1{});
     }
     // (the k-loop ended with a barrier: every wave is done with the operand tiles, the LDS is free for staging)
-    gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(&lds[0][0][0]) + wave * (32 * 72));
+    if constexpr (POOL) gemm_pool_tile(acc, p, *pa, (int)blockIdx.z, n0, wm, wn, lane, wave, reinterpret_cast<float*>(&lds[0][0][0]));
+    else gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(&lds[0][0][0]) + wave * (32 * 72));
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_f32x3_kernel(GemmXArgs p) {
+    gemm_f32x3_body<A_KMAJOR, B_KMAJOR, false>(p, nullptr);
+}
+// training simpool: one video per blockIdx.z, max-pool epilogue (common.hpp, gemm_pool_tile)
+__global__ __launch_bounds__(256) void gemm_f32x3_pool_kernel(GemmXArgs p, PoolArgs pa) {
+    gemm_f32x3_body<false, false, true>(p, &pa);
 }
 
 static int launch_gemm_x(GemmXArgs p, int batch, int a_kmajor, int b_kmajor, void* stream) {
     const dim3 grid((p.N + XBN - 1) / XBN, (p.M + XBM - 1) / XBM, batch), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32x3_kernel<false, false>), grid, block, 0, s, p);
-    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32x3_kernel<false, true>), grid, block, 0, s, p);
-    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32x3_kernel<true, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_f32x3_kernel<true, false>), grid, block, 0, s, p);
+    if (!a_kmajor && !b_kmajor) DLDKD_LAUNCH((gemm_f32x3_kernel<false, false>), grid, block, 0, s, p);
+    else if (!a_kmajor && b_kmajor) DLDKD_LAUNCH((gemm_f32x3_kernel<false, true>), grid, block, 0, s, p);
+    else if (a_kmajor && b_kmajor) DLDKD_LAUNCH((gemm_f32x3_kernel<true, true>), grid, block, 0, s, p);
+    else DLDKD_LAUNCH((gemm_f32x3_kernel<true, false>), grid, block, 0, s, p);
     return check_launch("gemm_f32x3");
+}
+
+int launch_simpool_pool_x3(const float* g, const float* q, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream) {
+    const bool al = !(D & 3) && !((uintptr_t)g & 15), bl = !(D & 3) && !((uintptr_t)q & 15);
+    GemmXArgs p{g, q, nullptr, nullptr, L, nq, D, D, D, nq, 0, al, bl, 1, (long)L * D, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+    DLDKD_LAUNCH(gemm_f32x3_pool_kernel, dim3((nq + XBN - 1) / XBN, 1, nv), dim3(256), 0, (hipStream_t)stream, p, pa);
+    return check_launch("simpool_train_fwd (fp32x3)");
 }
 
 }  // namespace dldkd

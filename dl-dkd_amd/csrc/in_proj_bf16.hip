@@ -391,7 +391,7 @@ int dldkd_fold_ln_linear_bf16(const float* W, const float* bias, const float* ga
                               void* Wf, float* cs, float* bb, void* stream) {
     if (N < 1 || K < 1) { set_error("fold_ln_linear: bad sizes"); return DLDKD_EINVAL; }
     if (!W || !gamma || !beta || !Wf || !cs || !bb) { set_error("fold_ln_linear: null pointer"); return DLDKD_EINVAL; }
-    hipLaunchKernelGGL(fold_ln_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, bias, gamma, beta, N, K,
+    DLDKD_LAUNCH(fold_ln_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, bias, gamma, beta, N, K,
                        (unsigned short*)Wf, cs, bb);
     return check_launch("fold_ln_linear");
 }
@@ -409,7 +409,7 @@ int dldkd_in_proj_bf16(const float* x, const void* Wf, const float* cs, const fl
     // 128-column tiles (6 for two branches).  Measured at M = 400k, K = 3072: BN 128 / BK 32 = 4.9 ms (1252 GB/s,
     // 384 TFLOP/s); BN 256 / BK 64 = 5.6 ms (one workgroup per CU at 255 VGPRs).
     constexpr int lds = (2 * PBM * PITCH + 2 * 128 * PITCH) * 2;
-    hipLaunchKernelGGL(in_proj_bf16_kernel<128>, dim3(N / 128, rows), dim3(256), lds, (hipStream_t)stream, p);
+    DLDKD_LAUNCH(in_proj_bf16_kernel<128>, dim3(N / 128, rows), dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("in_proj_bf16");
 }
 
@@ -421,7 +421,7 @@ int dldkd_fold_ln_linear_bf16_frag(const float* W, const float* bias, const floa
         return DLDKD_EINVAL;
     }
     if (!W || !gamma || !beta || !Wfrag || !cs || !bb) { set_error("fold_ln_linear_frag: null pointer"); return DLDKD_EINVAL; }
-    hipLaunchKernelGGL(fold_ln_linear_frag_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, bias, gamma, beta, N,
+    DLDKD_LAUNCH(fold_ln_linear_frag_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, bias, gamma, beta, N,
                        K, n_offset, FN, (unsigned short*)Wfrag, cs, bb);
     return check_launch("fold_ln_linear_frag");
 }
@@ -435,7 +435,7 @@ int dldkd_pack_linear_bf16_frag(const float* W, const float* bias, int N, int K,
         return DLDKD_EINVAL;
     }
     if (!W || !Wfrag || !bb) { set_error("pack_linear_frag: null pointer"); return DLDKD_EINVAL; }
-    hipLaunchKernelGGL(fold_ln_linear_frag_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, bias,
+    DLDKD_LAUNCH(fold_ln_linear_frag_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, bias,
                        (const float*)nullptr, (const float*)nullptr, N, K, n_offset, n_total, (unsigned short*)Wfrag,
                        (float*)nullptr, bb);
     return check_launch("pack_linear_frag");
@@ -456,13 +456,13 @@ int dldkd_linear_rows_bf16(const float* x, const void* Wfrag, const float* bb, v
         static const bool ok = [] { return hipFuncSetAttribute((const void*)rows_linear_bf16_kernel<1, false>,
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess; }();
         (void)ok;
-        hipLaunchKernelGGL((rows_linear_bf16_kernel<1, false>), grid, dim3(512), lds, (hipStream_t)stream, p);
+        DLDKD_LAUNCH((rows_linear_bf16_kernel<1, false>), grid, dim3(512), lds, (hipStream_t)stream, p);
     } else {
         constexpr int lds = 8 * 32 * 104 * 4;     // the epilogue staging (104 KiB) exceeds the k-loop's 68 KiB
         static const bool ok = [] { return hipFuncSetAttribute((const void*)rows_linear_bf16_kernel<2, false>,
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess; }();
         (void)ok;
-        hipLaunchKernelGGL((rows_linear_bf16_kernel<2, false>), grid, dim3(512), lds, (hipStream_t)stream, p);
+        DLDKD_LAUNCH((rows_linear_bf16_kernel<2, false>), grid, dim3(512), lds, (hipStream_t)stream, p);
     }
     return check_launch("linear_rows_bf16");
 }
@@ -477,7 +477,7 @@ int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, 
     static const bool ok = [] { return hipFuncSetAttribute((const void*)rows_linear_bf16_kernel<1, true>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess; }();
     (void)ok;
-    hipLaunchKernelGGL((rows_linear_bf16_kernel<1, true>), dim3((unsigned)((M + FBM - 1) / FBM)), dim3(512), lds, (hipStream_t)stream, p);
+    DLDKD_LAUNCH((rows_linear_bf16_kernel<1, true>), dim3((unsigned)((M + FBM - 1) / FBM)), dim3(512), lds, (hipStream_t)stream, p);
     return check_launch("in_proj_bf16_full");
 }
 

@@ -47,7 +47,7 @@ extern "C" int dldkd_segment_mean_l2norm_f32(const float* frames, const int32_t*
     if (n_rows < 0 || D < 4 || (D & 3)) { set_error("segment_mean_l2norm: bad sizes (D must be a multiple of 4)"); return DLDKD_EINVAL; }
     if (n_rows == 0) return DLDKD_OK;
     if (!frames || !seg_start || !seg_end || !out) { set_error("segment_mean_l2norm: null pointer"); return DLDKD_EINVAL; }
-    hipLaunchKernelGGL(segment_mean_l2norm_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, frames,
+    DLDKD_LAUNCH(segment_mean_l2norm_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, frames,
                        seg_start, seg_end, out, n_rows, D, eps);
     return check_launch("segment_mean_l2norm");
 }

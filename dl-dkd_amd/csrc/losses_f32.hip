@@ -16,13 +16,15 @@ namespace dldkd {
 __global__ __launch_bounds__(256) void kl_frame_kernel(const float* __restrict__ Sp, const float* __restrict__ St,
                                                        const int32_t* __restrict__ labels, const int32_t* __restrict__ lens,
                                                        float temp, int nq, int nv, int L, float* __restrict__ out,
-                                                       float* __restrict__ dSp, float g) {
+                                                       float* __restrict__ dSp, const float* __restrict__ gp) {
+    const float g = gp ? *gp : 0.f;      // upstream gradient: a device scalar (no host read-back, capturable)
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
     const int v = labels[q];
     const int n = lens[v];
-    const size_t base = ((size_t)q * nv + v) * L;
+    // nv == 0: the compact form - Sp / St are (nq, L), already the positive column of every query (simpool_train.hip)
+    const size_t base = nv > 0 ? ((size_t)q * nv + v) * L : (size_t)q * L;
     float p[2], t[2];
     float mp = -INFINITY, mt = -INFINITY;
 #pragma unroll
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(256) void kl_frame_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void nce_rows_kernel(const float* __restrict__ S, const float* __restrict__ T,
                                                        const int32_t* __restrict__ labels, const float* __restrict__ cq,
                                                        int hardQ, float beta, int nq, int nv, float* __restrict__ terms,
-                                                       float* __restrict__ dS, float* __restrict__ dT, float g) {
+                                                       float* __restrict__ dS, float* __restrict__ dT, const float* __restrict__ gp) {
+    const float g = gp ? *gp : 0.f;
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(256) void nce_cols_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ labels, const float* __restrict__ cv,
                                                        int hardV, float beta, float eps, int nq, int nv,
                                                        float* __restrict__ terms, float* __restrict__ dS,
-                                                       float* __restrict__ dT, float g) {
+                                                       float* __restrict__ dT, const float* __restrict__ gp) {
+    const float g = gp ? *gp : 0.f;
     const int lane = threadIdx.x & 63;
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= nv) return;
@@ -202,7 +206,8 @@ __global__ __launch_bounds__(256) void nce_cols_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void trip_t2v_kernel(const float* __restrict__ C, const int32_t* __restrict__ labels,
                                                        const int32_t* __restrict__ rsel, float margin, float scale, int nq,
-                                                       int nv, float* __restrict__ terms, float* __restrict__ dC, float g) {
+                                                       int nv, float* __restrict__ terms, float* __restrict__ dC, const float* __restrict__ gp) {
+    const float g = gp ? *gp : 0.f;
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wave;
@@ -244,7 +249,8 @@ __global__ __launch_bounds__(256) void trip_t2v_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void trip_v2t_kernel(const float* __restrict__ C, const int32_t* __restrict__ labels,
                                                        const int32_t* __restrict__ rsel, int hard, float margin, float scale,
                                                        int nq, int nv, float* __restrict__ terms, float* __restrict__ dC,
-                                                       float g) {
+                                                       const float* __restrict__ gp) {
+    const float g = gp ? *gp : 0.f;
     extern __shared__ float sm[];
     __shared__ float red_s[4];
     __shared__ int red_i[4];
@@ -336,45 +342,45 @@ using namespace dldkd;
 extern "C" {
 
 int dldkd_kl_frame_f32(const float* Sp, const float* St, const int32_t* labels, const int32_t* lens, float temp, int nq,
-                       int nv, int L, float* out, float* dSp, float g, void* stream) {
-    if (nq < 0 || nv < 1 || L < 1 || L > 128 || temp <= 0.f) { set_error("kl_frame: bad sizes"); return DLDKD_EINVAL; }
+                       int nv, int L, float* out, float* dSp, const float* g, void* stream) {
+    if (nq < 0 || nv < 0 || L < 1 || L > 128 || temp <= 0.f) { set_error("kl_frame: bad sizes"); return DLDKD_EINVAL; }
     if (nq == 0) return DLDKD_OK;
     if (!Sp || !St || !labels || !lens) { set_error("kl_frame: null pointer"); return DLDKD_EINVAL; }
-    hipLaunchKernelGGL(kl_frame_kernel, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, Sp, St, labels, lens, temp, nq,
+    DLDKD_LAUNCH(kl_frame_kernel, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, Sp, St, labels, lens, temp, nq,
                        nv, L, out, dSp, g);
     return check_launch("kl_frame");
 }
 
 int dldkd_nce_f32(const float* S, const float* T, const int32_t* labels, const float* cq, const float* cv, int hardQ,
-                  int hardV, float beta, float eps, int nq, int nv, float* terms, float* dS, float* dT, float g,
+                  int hardV, float beta, float eps, int nq, int nv, float* terms, float* dS, float* dT, const float* g,
                   void* stream) {
     if (nq < 1 || nv < 1) { set_error("nce: bad sizes"); return DLDKD_EINVAL; }
     if (!S || !labels || !cq || !cv) { set_error("nce: null pointer"); return DLDKD_EINVAL; }
-    hipLaunchKernelGGL(nce_rows_kernel, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, T, labels, cq, hardQ, beta, nq,
+    DLDKD_LAUNCH(nce_rows_kernel, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, T, labels, cq, hardQ, beta, nq,
                        nv, terms, dS, dT, g);
-    hipLaunchKernelGGL(nce_cols_kernel, dim3((nv + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, T, labels, cv, hardV, beta, eps,
+    DLDKD_LAUNCH(nce_cols_kernel, dim3((nv + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, T, labels, cv, hardV, beta, eps,
                        nq, nv, terms ? terms + nq : nullptr, dS, dT, g);
     return check_launch("nce");
 }
 
 int dldkd_triplet_f32(const float* C, const int32_t* labels, const int32_t* r_t2v, const int32_t* r_v2t, int hard,
-                      float margin, int nq, int nv, float* terms, float* dC, float g, void* stream) {
+                      float margin, int nq, int nv, float* terms, float* dC, const float* g, void* stream) {
     if (nq < 1 || nv < 1) { set_error("triplet: bad sizes"); return DLDKD_EINVAL; }
     if (!C || !labels || !r_t2v || (!hard && !r_v2t)) { set_error("triplet: null pointer"); return DLDKD_EINVAL; }
     if ((size_t)nv * 4 * sizeof(float) > 64 * 1024 || (size_t)nq * sizeof(float) > 64 * 1024) {
         set_error("triplet: batch too large for the LDS row/column buffers");
         return DLDKD_EINVAL;
     }
-    hipLaunchKernelGGL(trip_t2v_kernel, dim3((nq + 3) / 4), dim3(256), (size_t)nv * 4 * sizeof(float), (hipStream_t)stream, C,
+    DLDKD_LAUNCH(trip_t2v_kernel, dim3((nq + 3) / 4), dim3(256), (size_t)nv * 4 * sizeof(float), (hipStream_t)stream, C,
                        labels, r_t2v, margin, 1.f / nq, nq, nv, terms, dC, g);
-    hipLaunchKernelGGL(trip_v2t_kernel, dim3(nv), dim3(256), (size_t)nq * sizeof(float), (hipStream_t)stream, C, labels, r_v2t,
+    DLDKD_LAUNCH(trip_v2t_kernel, dim3(nv), dim3(256), (size_t)nq * sizeof(float), (hipStream_t)stream, C, labels, r_v2t,
                        hard, margin, 1.f / nv, nq, nv, terms ? terms + nq : nullptr, dC, g);
     return check_launch("triplet");
 }
 
 int dldkd_sum_f32(const float* x, long n, float* out, void* stream) {
     if (n < 0 || !out) { set_error("sum: bad arguments"); return DLDKD_EINVAL; }
-    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    DLDKD_LAUNCH(sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, out);
     return check_launch("sum");
 }
 

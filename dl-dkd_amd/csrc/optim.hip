@@ -100,10 +100,10 @@ int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const
     hipStream_t s = (hipStream_t)stream;
     if (max_grad_norm > 0.f) {
         if (hipMemsetAsync(norm2_scratch, 0, sizeof(float) * n_tensors, s) != hipSuccess) return check_launch("bert_adam memset");
-        hipLaunchKernelGGL(adam_sumsq_kernel, dim3((n_chunks + kSumsqChunks - 1) / kSumsqChunks), dim3(256), 0, s, g, chunk_tensor, t_start,
+        DLDKD_LAUNCH(adam_sumsq_kernel, dim3((n_chunks + kSumsqChunks - 1) / kSumsqChunks), dim3(256), 0, s, g, chunk_tensor, t_start,
                            t_numel, norm2_scratch, n_chunks);
     }
-    hipLaunchKernelGGL(adam_update_kernel, dim3(n_chunks), dim3(256), 0, s, p, g, m, v, chunk_tensor, t_start, t_numel,
+    DLDKD_LAUNCH(adam_update_kernel, dim3(n_chunks), dim3(256), 0, s, p, g, m, v, chunk_tensor, t_start, t_numel,
                        norm2_scratch, t_wd, t_lr, t_active, b1, b2, eps, max_grad_norm);
     return check_launch("bert_adam");
 }
@@ -112,7 +112,7 @@ int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv,
     if (nq < 0 || nv < 0 || ld < nv) { set_error("count_above: bad sizes"); return DLDKD_EINVAL; }
     if (nq == 0) return DLDKD_OK;
     if (!scores || !thr || !counts) { set_error("count_above: null pointer"); return DLDKD_EINVAL; }
-    hipLaunchKernelGGL(count_above_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, scores, thr, nv, ld, counts);
+    DLDKD_LAUNCH(count_above_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, scores, thr, nv, ld, counts);
     return check_launch("count_above");
 }
 

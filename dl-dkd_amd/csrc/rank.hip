@@ -57,7 +57,7 @@ extern "C" int dldkd_rank_gt(const float* scores, int nq, int nv, const int32_t*
     if (nq < 0 || nv < 1) { set_error("rank_gt: bad sizes nq=%d nv=%d", nq, nv); return DLDKD_EINVAL; }
     if (nq == 0) return DLDKD_OK;
     if (!scores || !gt_ptr || !gt_idx || !rank_best) { set_error("rank_gt: null pointer"); return DLDKD_EINVAL; }
-    hipLaunchKernelGGL(rank_gt_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, scores, nv, gt_ptr, gt_idx, rank_best,
+    DLDKD_LAUNCH(rank_gt_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, scores, nv, gt_ptr, gt_idx, rank_best,
                        rank_first);
     return check_launch("rank_gt");
 }

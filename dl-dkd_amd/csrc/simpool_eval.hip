@@ -525,7 +525,7 @@ int dldkd_pack_queries_bf16(const float* q, int nq, int normalize, void* q_packe
     if (nq < 0 || (nq > 0 && (!q || !q_packed))) { set_error("pack_queries: bad arguments"); return DLDKD_EINVAL; }
     if (nq == 0) return DLDKD_OK;
     const int nq_pad = round_up(nq, kQTile);
-    hipLaunchKernelGGL(pack_queries_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, nq, nq_pad,
+    DLDKD_LAUNCH(pack_queries_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, nq, nq_pad,
                        normalize, (bf16x8*)q_packed);
     return check_launch("pack_queries");
 }
@@ -539,9 +539,9 @@ int dldkd_pack_gallery_bf16(const float* g, const float* mask, int nv, int L, in
     if (nv == 0) return DLDKD_OK;
     const int Lp = round_up(L, 32);
     const long rows = (long)nv * Lp;
-    hipLaunchKernelGGL(pack_gallery_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, mask,
+    DLDKD_LAUNCH(pack_gallery_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, mask,
                        nv, L, Lp, normalize, (bf16x8*)g_packed);
-    hipLaunchKernelGGL(mask_lens_kernel, dim3((nv + 3) / 4), dim3(256), 0, (hipStream_t)stream, mask, nv, L, lens);
+    DLDKD_LAUNCH(mask_lens_kernel, dim3((nv + 3) / 4), dim3(256), 0, (hipStream_t)stream, mask, nv, L, lens);
     return check_launch("pack_gallery");
 }
 
@@ -557,9 +557,9 @@ int dldkd_pack_gallery_chunk_bf16(const float* g, const float* mask, int nv_chun
     const int Lp = round_up(L_total, 32);
     const long rows = (long)nv_chunk * Lp;
     bf16x8* dst = (bf16x8*)g_packed + (size_t)v0 * Lp * kRowBf16x8;
-    hipLaunchKernelGGL(pack_gallery_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, mask,
+    DLDKD_LAUNCH(pack_gallery_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, mask,
                        nv_chunk, L_chunk, Lp, normalize, dst);
-    hipLaunchKernelGGL(mask_lens_kernel, dim3((nv_chunk + 3) / 4), dim3(256), 0, (hipStream_t)stream, mask, nv_chunk, L_chunk,
+    DLDKD_LAUNCH(mask_lens_kernel, dim3((nv_chunk + 3) / 4), dim3(256), 0, (hipStream_t)stream, mask, nv_chunk, L_chunk,
                        lens + v0);
     return check_launch("pack_gallery_chunk");
 }
@@ -619,7 +619,7 @@ int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_pa
                                    kRing * kQTileBytes) == hipSuccess;
     }();
     (void)attr_ok;
-    hipLaunchKernelGGL(simpool_eval16_kernel, dim3((unsigned)p.n_wg0 * n_ranges), dim3(256), kRing * kQTileBytes,
+    DLDKD_LAUNCH(simpool_eval16_kernel, dim3((unsigned)p.n_wg0 * n_ranges), dim3(256), kRing * kQTileBytes,
                        (hipStream_t)stream, p);
     return check_launch("simpool_eval");
 }
@@ -633,7 +633,7 @@ int dldkd_simpool_finish_range(const void* workspace, const int32_t* inv_order, 
     if (q_hi == q_lo || nv == 0 || (!fused && !s0 && !s1)) return DLDKD_OK;
     if (!workspace || !inv_order) { set_error("simpool_finish: null pointer"); return DLDKD_EINVAL; }
     const int nq_pad = round_up(nq, kQTile);
-    hipLaunchKernelGGL(simpool_finish64_kernel, dim3((q_hi - q_lo + 63) / 64, (nv + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+    DLDKD_LAUNCH(simpool_finish64_kernel, dim3((q_hi - q_lo + 63) / 64, (nv + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, inv_order, q_lo, q_hi, nq_pad, nv, n_branches, w0, w1, fused, s0, s1);
     return check_launch("simpool_finish");
 }

@@ -1,0 +1,247 @@
+// simpool (training): cosine AND raw key-clip max-pooled scores of every (query, video) pair plus the clip-level cosine
+// scores of every query's OWN video, forward and backward, without ever forming the (Nq, Nv, L) clip tensor.
+// Replaces, inside DLDKD.forward (reference method/model.py:113-129), the pairs
+//     get_sim_scores(q, ctx, mask)            model.py:307-329   (F.normalize, einsum, mask_logits, max)
+//     get_unnormalized_sim_scores(q, ctx, mask) model.py:331-350
+// and the [i, :, label_i] read of compute_kl_loss (model.py:183-197).  Round 1 ran, per (query set, gallery) pair, two
+// normalisations, TWO (Nq x Nv L x D) GEMMs that wrote 42 MB clip tensors, two pooling passes, and in the backward pass
+// two more GEMMs per operand over a clip-gradient tensor that is zero except at the arg-max clips.
+//
+//   forward   one batched MFMA GEMM S_v = G_v Q^T per video with the pooling epilogue of common.hpp (gemm_pool_tile); the
+//             cosine comes from the same raw product: cos = <q, g> rq rg, rq / rg = 1 / max(|.|, 1e-12) (row_invnorm_kernel).
+//   backward  the gradient of a max-pool is a scatter to the arg-max clip:
+//       dq[n]   = sum_v [ a_nv g[v, l_raw] + b_nv rq_n (rg g)[v, l_cos] ]  + sum_l e_nl rq_n (rg g)[lab_n, l]  -  rq_n^2 q_n ( sum_v b_nv cos_nv + sum_l e_nl c_nl )
+//       dg[v,l] = sum_n [ a_nv 1(l = l_raw) q_n + b_nv 1(l = l_cos) rg_vl rq_n q_n ] + sum_{n: lab_n = v} e_nl rg_vl rq_n q_n  -  rg_vl^2 g_vl ( ... the matching cos-weighted sums )
+//     with a = d pooled_raw, b = d pooled_cos, e = d clip_pos: two gather kernels (fp32 VALU, L2-resident operands).
+#include "common.hpp"
+
+namespace dldkd {
+
+// inv[r] = 1 / max(|x[r, :]|, 1e-12)   (F.normalize's clamp, model.py:318-319); one wave per row
+__global__ __launch_bounds__(256) void row_invnorm_kernel(const float* __restrict__ x, float* __restrict__ inv, long M, int D) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    float ss = 0.f;
+    const float* row = x + r * D;
+    if (!(D & 3) && !((uintptr_t)x & 15)) {
+        for (int c = lane * 4; c < D; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+    } else {
+        for (int c = lane; c < D; c += 64) ss += row[c] * row[c];
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) inv[r] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+}
+
+struct SimpoolBwdArgs {
+    const float* q;        // [nq, D]
+    const float* g;        // [nv, L, D]
+    const float* rq;       // [nq]
+    const float* rg;       // [nv * L]
+    const int32_t* lens;   // [nv]
+    const int32_t* labels; // [nq]
+    const int32_t* arg_raw;
+    const int32_t* arg_cos;   // [nq, nv]
+    const float* pooled_cos;  // [nq, nv]  cos at the arg-max
+    const float* clip_pos;    // [nq, L]   cos of the positive column (or null)
+    const float* d_raw;       // [nq, nv] or null
+    const float* d_cos;       // [nq, nv] or null
+    const float* d_clip;      // [nq, L] or null
+    float* dq;                // [nq, D]
+    float* dg;                // [nv, L, D]
+    int nq, nv, L, D;
+};
+
+// dq: one workgroup (128 threads x float4 = up to 512 columns) per query.  The 2 nv (+ len) gathered rows have addresses that
+// depend only on the index arrays, so the unrolled loop keeps several L2 round trips in flight.
+__global__ __launch_bounds__(128) void simpool_bwd_dq_kernel(const SimpoolBwdArgs p) {
+    const int n = blockIdx.x, t = threadIdx.x, c = 4 * t;
+    const bool act = c < p.D;
+    const float rq = p.rq[n];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float proj = 0.f;                                  // sum of (gradient x cosine): the projection onto q
+    const size_t rowq = (size_t)n * p.nv;
+    auto grow = [&](int v, int l) -> f32x4 {
+        return act ? *reinterpret_cast<const f32x4*>(p.g + ((size_t)v * p.L + l) * p.D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+#pragma unroll 4
+    for (int v = 0; v < p.nv; ++v) {
+        const bool has = p.lens[v] > 0;                // a video without clips pooled to the constant -1e10: no gradient
+        const float a = (p.d_raw && has) ? p.d_raw[rowq + v] : 0.f;
+        const float b = (p.d_cos && has) ? p.d_cos[rowq + v] : 0.f;
+        const int lr = p.arg_raw[rowq + v], lc = p.arg_cos[rowq + v];
+        const f32x4 xr = grow(v, lr), xc = grow(v, lc);
+        acc += a * xr;
+        acc += (b * rq * p.rg[(size_t)v * p.L + lc]) * xc;
+        proj += b * p.pooled_cos[rowq + v];
+    }
+    if (p.d_clip) {
+        const int v = p.labels[n], len = p.lens[v];
+#pragma unroll 4
+        for (int l = 0; l < len; ++l) {
+            const float e = p.d_clip[(size_t)n * p.L + l];
+            const f32x4 x = grow(v, l);
+            acc += (e * rq * p.rg[(size_t)v * p.L + l]) * x;
+            proj += e * p.clip_pos[(size_t)n * p.L + l];
+        }
+    }
+    if (act) {
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(p.q + (size_t)n * p.D + c);
+        *reinterpret_cast<f32x4*>(p.dq + (size_t)n * p.D + c) = acc - (proj * rq * rq) * qv;
+    }
+}
+
+// dg: one workgroup per (video, 128-column slab).  No accumulator in memory and no atomics: the (query, coefficient)
+// contributions of the video are first bucketed BY CLIP in LDS (a counting sort in query order, so the sums have a fixed
+// order), then every wave walks the clips it owns (clip % 4 == wave), accumulates a clip's gradient row in registers over
+// the clip's bucket - independent, prefetchable query-row loads - and writes it once.
+//   contribution of query n to clip l:  a_nv q_n  (l = arg_raw)   +   b_nv rq_n rg_l q_n  (l = arg_cos)
+//                                       + e_nl rq_n rg_l q_n  (n a caption of this video, every l < len)
+//   and the projection  - rg_l^2 g_l * sum( b_nv cos_nv [l = arg_cos] + e_nl c_nl )
+constexpr int kDgCols = 128;
+__global__ __launch_bounds__(256) void simpool_bwd_dg_kernel(const SimpoolBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int v = blockIdx.x, c0 = blockIdx.y * kDgCols, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = p.L, nq = p.nq, len = p.lens[v];
+    float* sc = lds;                                           // [nq][4]: a, b * rq, l_raw, l_cos
+    float* bcos = sc + 4 * (size_t)nq;                         // [nq]     b * cos
+    int* cnt = reinterpret_cast<int*>(bcos + nq);              // [L + 1]  bucket starts
+    float* rowproj = reinterpret_cast<float*>(cnt + L + 1);    // [L]
+    int* pos = reinterpret_cast<int*>(rowproj + L);            // [nq + 1] captions of this video, pos[nq] = their number
+    float2* ent = reinterpret_cast<float2*>(pos + nq + 1);     // [2 nq] (query, coefficient); word offset 6 nq + 2 L + 2: even
+    for (int n = tid; n < nq; n += 256) {
+        const size_t o = (size_t)n * p.nv + v;
+        const float b = (p.d_cos && len > 0) ? p.d_cos[o] : 0.f;
+        sc[4 * n + 0] = (p.d_raw && len > 0) ? p.d_raw[o] : 0.f;
+        sc[4 * n + 1] = b * p.rq[n];
+        sc[4 * n + 2] = __int_as_float(p.arg_raw[o]);
+        sc[4 * n + 3] = __int_as_float(p.arg_cos[o]);
+        bcos[n] = b * p.pooled_cos[o];
+    }
+    if (tid == 0) {                                            // captions of this video, in query order (a handful)
+        int k = 0;
+        if (p.d_clip != nullptr && len > 0)
+            for (int n = 0; n < nq; ++n) if (p.labels[n] == v) pos[k++] = n;
+        pos[nq] = k;
+    }
+    __syncthreads();
+    // counting sort by clip: thread l owns clip l (every thread reads the same sc word: an LDS broadcast)
+    if (tid < L) {
+        int k = 0;
+        for (int n = 0; n < nq; ++n) k += (__float_as_int(sc[4 * n + 2]) == tid) + (__float_as_int(sc[4 * n + 3]) == tid);
+        cnt[tid + 1] = k;
+    }
+    if (tid == 0) cnt[0] = 0;
+    __syncthreads();
+    if (tid == 0) for (int l = 0; l < L; ++l) cnt[l + 1] += cnt[l];
+    __syncthreads();
+    if (tid < L) {
+        int k = cnt[tid];
+        float pr = 0.f;
+        const float rgl = tid < len ? p.rg[(size_t)v * L + tid] : 0.f;
+        for (int n = 0; n < nq; ++n) {
+            if (__float_as_int(sc[4 * n + 2]) == tid) ent[k++] = float2{__int_as_float(n), sc[4 * n]};
+            if (__float_as_int(sc[4 * n + 3]) == tid) { ent[k++] = float2{__int_as_float(n), sc[4 * n + 1] * rgl}; pr += bcos[n]; }
+        }
+        const int np = pos[nq];
+        if (tid < len)
+            for (int i = 0; i < np; ++i) { const size_t o = (size_t)pos[i] * L + tid; pr += p.d_clip[o] * p.clip_pos[o]; }
+        rowproj[tid] = pr;
+    }
+    __syncthreads();
+    const int c = c0 + 2 * lane;
+    if (c >= p.D) return;
+    const int np = pos[nq];
+    for (int l = wave; l < L; l += 4) {
+        float2 acc = {0.f, 0.f};
+        const size_t o = ((size_t)v * L + l) * p.D + c;
+        if (l < len) {
+            const int e0 = cnt[l], e1 = cnt[l + 1];
+#pragma unroll 4
+            for (int e = e0; e < e1; ++e) {
+                const float2 en = ent[e];
+                const float2 qv = *reinterpret_cast<const float2*>(p.q + (size_t)__float_as_int(en.x) * p.D + c);
+                acc.x += en.y * qv.x;
+                acc.y += en.y * qv.y;
+            }
+            const float rgl = p.rg[(size_t)v * L + l];
+            for (int i = 0; i < np; ++i) {
+                const int n = pos[i];
+                const float w = p.d_clip[(size_t)n * L + l] * p.rq[n] * rgl;
+                const float2 qv = *reinterpret_cast<const float2*>(p.q + (size_t)n * p.D + c);
+                acc.x += w * qv.x;
+                acc.y += w * qv.y;
+            }
+            const float k = rowproj[l] * rgl * rgl;
+            const float2 gv = *reinterpret_cast<const float2*>(p.g + o);
+            acc.x -= k * gv.x;
+            acc.y -= k * gv.y;
+        }
+        *reinterpret_cast<float2*>(p.dg + o) = acc;
+    }
+}
+
+}  // namespace dldkd
+
+using namespace dldkd;
+
+extern "C" {
+
+int dldkd_row_invnorm_f32(const float* x, float* inv, long M, int D, void* stream) {
+    if (M < 0 || D < 1) { set_error("row_invnorm: bad sizes"); return DLDKD_EINVAL; }
+    if (M == 0) return DLDKD_OK;
+    if (!x || !inv) { set_error("row_invnorm: null pointer"); return DLDKD_EINVAL; }
+    DLDKD_LAUNCH(row_invnorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, inv, M, D);
+    return check_launch("row_invnorm");
+}
+
+int dldkd_simpool_train_fwd_f32(int precision, const float* q, const float* g, const float* rq, const float* rg,
+                                const int32_t* lens, const int32_t* labels, int nq, int nv, int L, int D, float* pooled_cos,
+                                float* pooled_raw, int32_t* arg_cos, int32_t* arg_raw, float* clip_pos, void* stream) {
+    if (nq < 0 || nv < 0 || L < 1 || L > DLDKD_MAX_CLIPS || D < 1 || nv > 65535) {
+        set_error("simpool_train_fwd: bad sizes nq=%d nv=%d L=%d D=%d", nq, nv, L, D);
+        return DLDKD_EINVAL;
+    }
+    if (nq == 0 || nv == 0) return DLDKD_OK;
+    if (!q || !g || !rq || !rg || !lens || !labels || !pooled_cos || !pooled_raw || !arg_cos || !arg_raw) {
+        set_error("simpool_train_fwd: null pointer");
+        return DLDKD_EINVAL;
+    }
+    PoolArgs pa{rg, rq, lens, labels, pooled_raw, pooled_cos, arg_raw, arg_cos, clip_pos, nv, L};
+    if (precision == DLDKD_GEMM_BF16) return launch_simpool_pool_bf16(g, q, nv, L, nq, D, pa, stream);
+    if (precision == DLDKD_GEMM_F32X3) return launch_simpool_pool_x3(g, q, nv, L, nq, D, pa, stream);
+    set_error("simpool_train_fwd: precision %d has no pooled kernel (DLDKD_GEMM_F32X3 or DLDKD_GEMM_BF16)", precision);
+    return DLDKD_EINVAL;
+}
+
+int dldkd_simpool_train_bwd_f32(const float* q, const float* g, const float* rq, const float* rg, const int32_t* lens,
+                                const int32_t* labels, const int32_t* arg_cos, const int32_t* arg_raw, const float* pooled_cos,
+                                const float* clip_pos, const float* d_cos, const float* d_raw, const float* d_clip, int nq, int nv,
+                                int L, int D, float* dq, float* dg, void* stream) {
+    if (nq < 0 || nv < 0 || L < 1 || L > DLDKD_MAX_CLIPS || D < 4 || (D & 3) || D > 512) {
+        set_error("simpool_train_bwd: bad sizes nq=%d nv=%d L=%d D=%d (D a multiple of 4, <= 512)", nq, nv, L, D);
+        return DLDKD_EINVAL;
+    }
+    if (nq == 0 || nv == 0) return DLDKD_OK;
+    if (!q || !g || !rq || !rg || !lens || !labels || !arg_cos || !arg_raw || !pooled_cos || (d_clip && !clip_pos)) {
+        set_error("simpool_train_bwd: null pointer");
+        return DLDKD_EINVAL;
+    }
+    if (((uintptr_t)q | (uintptr_t)g | (uintptr_t)dq | (uintptr_t)dg) & 15) { set_error("simpool_train_bwd: unaligned buffer"); return DLDKD_EINVAL; }
+    SimpoolBwdArgs p{q, g, rq, rg, lens, labels, arg_raw, arg_cos, pooled_cos, clip_pos, d_raw, d_cos, d_clip, dq, dg, nq, nv, L, D};
+    hipStream_t s = (hipStream_t)stream;
+    if (dq) DLDKD_LAUNCH(simpool_bwd_dq_kernel, dim3(nq), dim3(128), 0, s, p);
+    if (dg) {
+        const size_t lds = ((size_t)5 * nq + 2 * L + 2 + nq + 4 + (size_t)4 * nq) * sizeof(float);
+        if (lds > 160 * 1024) { set_error("simpool_train_bwd: %d queries need %zu bytes of LDS (max ~4000 queries per batch)", nq, lds); return DLDKD_EINVAL; }
+        static const bool attr_ok = hipFuncSetAttribute((const void*)simpool_bwd_dg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        (void)attr_ok;
+        DLDKD_LAUNCH(simpool_bwd_dg_kernel, dim3(nv, (D + kDgCols - 1) / kDgCols), dim3(256), lds, s, p);
+    }
+    return check_launch("simpool_train_bwd");
+}
+
+}  // extern "C"

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void modpool_bwd_kernel(const float* __restric
 using namespace dldkd;
 
 #define LAUNCH1D(kernel, n, per_block, ...) \
-    hipLaunchKernelGGL(kernel, dim3((unsigned)(((n) + (per_block) - 1) / (per_block))), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
+    DLDKD_LAUNCH(kernel, dim3((unsigned)(((n) + (per_block) - 1) / (per_block))), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
 
 extern "C" {
 
@@ -412,7 +412,7 @@ int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const
     hipStream_t s = (hipStream_t)stream;
     if (nv <= 2) {           // 16 waves x 4 rows per workgroup
         const long waves = (M + 3) / 4;
-        hipLaunchKernelGGL((layernorm_bwd_kernel<2, 16>), dim3((unsigned)((waves + 15) / 16)), dim3(1024), (size_t)32 * D * sizeof(float), s,
+        DLDKD_LAUNCH((layernorm_bwd_kernel<2, 16>), dim3((unsigned)((waves + 15) / 16)), dim3(1024), (size_t)32 * D * sizeof(float), s,
                            x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, 4);
         return check_launch("layernorm_bwd");
     }
@@ -424,21 +424,21 @@ int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const
         return hipFuncSetAttribute((const void*)layernorm_bwd_kernel<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4096 * 4) == hipSuccess;
     }();
     (void)attr_ok;
-    if (nv <= 4) hipLaunchKernelGGL((layernorm_bwd_kernel<4, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    if (nv <= 4) DLDKD_LAUNCH((layernorm_bwd_kernel<4, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
     // (no MAXV = 8 instantiation: hipcc spilled 248 registers in it; rows of 1028..2048 floats use the 16-wide form)
-    else hipLaunchKernelGGL((layernorm_bwd_kernel<16, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    else DLDKD_LAUNCH((layernorm_bwd_kernel<16, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
     return check_launch("layernorm_bwd");
 }
 int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream) {
     if (M < 0 || N < 0) { set_error("colsum: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0 || N == 0) return DLDKD_OK;
     if (M >= 512 && (M + 127) / 128 <= 65535) {
-        hipLaunchKernelGGL(colsum64_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 127) / 128)), dim3(256), 0,
+        DLDKD_LAUNCH(colsum64_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 127) / 128)), dim3(256), 0,
                            (hipStream_t)stream, x, out, M, N);
         return check_launch("colsum64");
     }
     const int rpb = 64;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((M + rpb - 1) / rpb)), dim3(256), 0,
+    DLDKD_LAUNCH(colsum_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((M + rpb - 1) / rpb)), dim3(256), 0,
                        (hipStream_t)stream, x, out, M, N, rpb);
     return check_launch("colsum");
 }

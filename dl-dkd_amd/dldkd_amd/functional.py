@@ -363,7 +363,65 @@ def clip_pool(S, lens):
     return _ClipPool.apply(_f32(S), lens)
 
 
+class _SimPoolTrain(Function):
+    """Fused training simpool (simpool_train.hip): (pooled cosine, pooled raw, positive-column clip cosines) of one
+    (query set, gallery) pair from one MFMA GEMM with a pooling epilogue; backward = two gather kernels."""
+
+    @staticmethod
+    def forward(ctx, q, g, lens, labels, want_clip):
+        Nq, D = q.shape
+        Nv, L, _ = g.shape
+        dev = q.device
+        rq = torch.empty(Nq, dtype=torch.float32, device=dev)
+        rg = torch.empty(Nv * L, dtype=torch.float32, device=dev)
+        native.check(_L().dldkd_row_invnorm_f32(_p(q), _p(rq), Nq, D, _s()), "row_invnorm")
+        native.check(_L().dldkd_row_invnorm_f32(_p(g), _p(rg), Nv * L, D, _s()), "row_invnorm")
+        pc = torch.empty(Nq, Nv, dtype=torch.float32, device=dev)
+        pr = torch.empty(Nq, Nv, dtype=torch.float32, device=dev)
+        ac = torch.empty(Nq, Nv, dtype=torch.int32, device=dev)
+        ar = torch.empty(Nq, Nv, dtype=torch.int32, device=dev)
+        clip = torch.empty(Nq, L, dtype=torch.float32, device=dev) if want_clip else None
+        native.check(_L().dldkd_simpool_train_fwd_f32(ops._PREC_ID[ops.gemm_precision()], _p(q), _p(g), _p(rq), _p(rg), _p(lens),
+                                                      _p(labels), Nq, Nv, L, D, _p(pc), _p(pr), _p(ac), _p(ar), _p(clip), _s()),
+                     "simpool_train_fwd")
+        ctx.save_for_backward(q, g, rq, rg, lens, labels, ac, ar, pc, clip)
+        ctx.mark_non_differentiable(ac, ar)
+        if clip is None:
+            return pc, pr, ac, ar
+        return pc, pr, ac, ar, clip
+
+    @staticmethod
+    def backward(ctx, d_cos, d_raw, _dac, _dar, d_clip=None):
+        q, g, rq, rg, lens, labels, ac, ar, pc, clip = ctx.saved_tensors
+        Nq, D = q.shape
+        Nv, L, _ = g.shape
+        dq = torch.empty_like(q) if ctx.needs_input_grad[0] else None
+        dg = torch.empty_like(g) if ctx.needs_input_grad[1] else None
+        f = lambda t: None if t is None else _f32(t)            # noqa: E731
+        native.check(_L().dldkd_simpool_train_bwd_f32(_p(q), _p(g), _p(rq), _p(rg), _p(lens), _p(labels), _p(ac), _p(ar), _p(pc),
+                                                      _p(clip), _p(f(d_cos)), _p(f(d_raw)), _p(f(d_clip)), Nq, Nv, L, D, _p(dq),
+                                                      _p(dg), _s()), "simpool_train_bwd")
+        return dq, dg, None, None, None
+
+
+def simpool_train_ok():
+    """The pooled GEMM exists for the parity ("fp32" = three bf16 planes) and the throughput ("bf16") precisions."""
+    return ops.gemm_precision() in ("fp32", "fp32x3", "bf16")
+
+
+def simpool_train(q, g, lens, labels, want_clip):
+    """(pooled_cos (Nq, Nv), pooled_raw (Nq, Nv), clip_pos (Nq, L) or None) - see _SimPoolTrain."""
+    out = _SimPoolTrain.apply(_f32(q), _f32(g), lens, labels, bool(want_clip))
+    return out[0], out[1], (out[4] if want_clip else None)
+
+
 # ------------------------------------------------------------------------------------------ losses
+def _gscalar(g):
+    """The upstream gradient of a scalar loss as a contiguous fp32 device scalar: the loss kernels read it on the device
+    (float(g) would be one host synchronisation per loss per step)."""
+    return g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+
+
 def _sum(x):
     out = torch.empty(1, dtype=torch.float32, device=x.device)
     native.check(_L().dldkd_sum_f32(_p(x), x.numel(), _p(out), _s()), "sum")
@@ -373,9 +431,9 @@ def _sum(x):
 class _KLFrame(Function):
     @staticmethod
     def forward(ctx, Sp, St, labels, lens, temp):
-        Nq, Nv, L = Sp.shape
+        Nq, Nv, L = Sp.shape if Sp.dim() == 3 else (Sp.shape[0], 0, Sp.shape[1])      # (Nq, L): the positive column only
         out = torch.empty(Nq, dtype=torch.float32, device=Sp.device)
-        native.check(_L().dldkd_kl_frame_f32(_p(Sp), _p(St), _p(labels), _p(lens), temp, Nq, Nv, L, _p(out), None, 0.0, _s()),
+        native.check(_L().dldkd_kl_frame_f32(_p(Sp), _p(St), _p(labels), _p(lens), temp, Nq, Nv, L, _p(out), None, None, _s()),
                      "kl_frame")
         ctx.save_for_backward(Sp, St, labels, lens)
         ctx.temp = temp
@@ -384,10 +442,10 @@ class _KLFrame(Function):
     @staticmethod
     def backward(ctx, g):
         Sp, St, labels, lens = ctx.saved_tensors
-        Nq, Nv, L = Sp.shape
+        Nq, Nv, L = Sp.shape if Sp.dim() == 3 else (Sp.shape[0], 0, Sp.shape[1])
         dSp = torch.zeros_like(Sp)
         native.check(_L().dldkd_kl_frame_f32(_p(Sp), _p(St), _p(labels), _p(lens), ctx.temp, Nq, Nv, L, None, _p(dSp),
-                                             float(g), _s()), "kl_frame")
+                                             _p(_gscalar(g)), _s()), "kl_frame")
         return dSp, None, None, None, None
 
 
@@ -402,7 +460,7 @@ class _NCE(Function):
         Nq, Nv = S.shape
         terms = torch.empty(Nq + Nv, dtype=torch.float32, device=S.device)
         native.check(_L().dldkd_nce_f32(_p(S), _p(T), _p(labels), _p(cq), _p(cv), hardQ, hardV, beta, eps, Nq, Nv, _p(terms),
-                                        None, None, 0.0, _s()), "nce")
+                                        None, None, None, _s()), "nce")
         ctx.save_for_backward(S, T, labels, cq, cv)
         ctx.cfg = (hardQ, hardV, beta, eps, t_is_s)
         return _sum(terms)
@@ -415,7 +473,7 @@ class _NCE(Function):
         dS = torch.empty_like(S)
         dT = torch.empty_like(S) if (T is not None and t_is_s) else None
         native.check(_L().dldkd_nce_f32(_p(S), _p(T), _p(labels), _p(cq), _p(cv), hardQ, hardV, beta, eps, Nq, Nv, None, _p(dS),
-                                        _p(dT), float(g), _s()), "nce")
+                                        _p(dT), _p(_gscalar(g)), _s()), "nce")
         if dT is not None:          # the exploration branch's soft labels are its own scores (model.py:149-150)
             _axpy(dS, dT)
         return dS, None, None, None, None, None, None, None, None, None
@@ -460,7 +518,7 @@ class _Triplet(Function):
         Nq, Nv = C.shape
         terms = torch.empty(Nq + Nv, dtype=torch.float32, device=C.device)
         native.check(_L().dldkd_triplet_f32(_p(C), _p(labels), _p(r_t2v), _p(r_v2t), int(hard), margin, Nq, Nv, _p(terms),
-                                            None, 0.0, _s()), "triplet")
+                                            None, None, _s()), "triplet")
         ctx.save_for_backward(C, labels, r_t2v, r_v2t)
         ctx.cfg = (hard, margin)
         return _sum(terms)
@@ -472,7 +530,7 @@ class _Triplet(Function):
         Nq, Nv = C.shape
         dC = torch.zeros_like(C)
         native.check(_L().dldkd_triplet_f32(_p(C), _p(labels), _p(r_t2v), _p(r_v2t), int(hard), margin, Nq, Nv, None, _p(dC),
-                                            float(g), _s()), "triplet")
+                                            _p(_gscalar(g)), _s()), "triplet")
         return dC, None, None, None, None, None
 
 

@@ -266,8 +266,14 @@ class DLDKD(nn.Module):
         t_text = batch["teacher_text"].float().reshape(len(labels), -1)          # .squeeze() of model.py:114
         t_vid = batch["teacher_videos"].float()
 
+        fused = F_.simpool_train_ok()
+
         def both(q, g, want_clip):
-            pooled_cos, clip_cos, _ = F_.clip_pool(F_.clip_scores(F_.normalize(q), F_.normalize(g)), lens)
+            if fused:
+                # one MFMA GEMM with a pooling epilogue: cosine and raw maxima + the positive column of the clip-level
+                # cosines (all compute_kl_loss reads, model.py:184); the (Nq, Nv, L) tensors are never formed
+                return F_.simpool_train(q, g, lens, lab, want_clip)
+            pooled_cos, clip_cos, _ = F_.clip_pool(F_.clip_scores(F_.normalize(q), F_.normalize(g)), lens)      # "fp32_exact"
             pooled_raw, _, _ = F_.clip_pool(F_.clip_scores(q, g), lens)
             return pooled_cos, pooled_raw, (clip_cos if want_clip else None)
 

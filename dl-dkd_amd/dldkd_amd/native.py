@@ -61,12 +61,16 @@ SIGNATURES = {
     "dldkd_modpool_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
                                         _c_void_p]),
     "dldkd_kl_frame_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_int, _c_int, _c_int, _c_void_p,
-                                     _c_void_p, _c_float, _c_void_p]),
+                                     _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_nce_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_float, _c_int,
-                                _c_int, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_void_p]),
+                                _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_triplet_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_float, _c_int, _c_int, _c_void_p,
-                                    _c_void_p, _c_float, _c_void_p]),
+                                    _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_sum_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p]),
+    "dldkd_row_invnorm_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
+    "dldkd_simpool_train_fwd_f32": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
+                                              _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_simpool_train_bwd_f32": (_c_int, [_c_void_p] * 13 + [_c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_bert_adam_step_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p,
                                            _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_float, _c_float,
                                            _c_float, _c_void_p]),

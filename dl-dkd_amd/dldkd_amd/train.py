@@ -130,6 +130,12 @@ class GraphedTrainStep:
         self.max_graphs, self.defer = max_graphs, defer_loss_float
         self.graphs, self.seen = {}, {}
         self.replays = self.eager_steps = self.captures = 0
+        # EVERY step of this object - eager, capture, replay - runs on this side stream.  Autograd binds a parameter's
+        # gradient-accumulation node to the stream that was current when the node was created and keeps it for as long as
+        # any graph that reaches it is alive; a node born on the default stream (an eager step whose loss tensors the caller
+        # still holds) would pull the default stream into a later capture on another stream through the engine's
+        # cross-stream event, and hipStreamEndCapture then dies on the unjoined stream (seen as a segfault).
+        self.stream = None
 
     # -- what is baked into a graph
     def _key(self, batch):
@@ -142,16 +148,31 @@ class GraphedTrainStep:
                 m.label_style, bool(m.training), dist_info()[1] >= DDP_MIN_WORLD, getattr(self.opt, "grad_clip", -1))
 
     def __call__(self, batch):
+        dev = batch["student_videos"].device
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            out = self._step(batch)
+        cur.wait_stream(self.stream)
+        return out
+
+    def _eager(self, batch):
+        self.eager_steps += 1
+        loss, d = train_step(self.model, batch, self.optimizer, self.opt)
+        # detached, like the replayed steps' outputs: the backward pass is over, nothing should keep the tape alive
+        return loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+    def _step(self, batch):
         if getattr(self.opt, "grad_clip", -1) != -1:
-            self.eager_steps += 1
-            return train_step(self.model, batch, self.optimizer, self.opt)     # clip_grad_norm_ syncs: not capturable
+            return self._eager(batch)                     # clip_grad_norm_ syncs: not capturable
         key = self._key(batch)
         e = self.graphs.get(key)
         if e is None:
             self.seen[key] = self.seen.get(key, 0) + 1
             if self.seen[key] < 2:                        # first sight: eager (also loads every kernel the graph needs)
-                self.eager_steps += 1
-                return train_step(self.model, batch, self.optimizer, self.opt)
+                return self._eager(batch)
             e = self._capture(batch, key)
         else:
             self.graphs[key] = self.graphs.pop(key)       # most recently used last
@@ -191,27 +212,24 @@ class GraphedTrainStep:
         old_lr = opt_.t_lr
         opt_.t_lr = view("lr", len(opt_.fp.params)).view(torch.float32)      # the update kernel reads the staged rates
         e.t_lr = opt_.t_lr
-        cap_stream = torch.cuda.Stream(device=dev)
-        cap_stream.wait_stream(torch.cuda.current_stream())
         old = F_.set_philox_step(e.philox)
         try:
-            with torch.cuda.stream(cap_stream):
-                opt_.zero_grad()
-                e.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(e.graph, stream=cap_stream):
-                    loss, parts = m.forward_tensors(e.static, staged=e)
-                    loss.backward()
-                    if e.ddp:
-                        opt_.fp.rebind_grads()
-                    else:
-                        opt_.enqueue(upload_lr=False)
-                    e.loss, e.parts = loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in parts.items()}
+            opt_.zero_grad()
+            e.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(e.graph, stream=self.stream):           # self.stream is the current stream (__call__)
+                loss, parts = m.forward_tensors(e.static, staged=e)
+                loss.backward()
+                if e.ddp:
+                    opt_.fp.rebind_grads()
+                else:
+                    opt_.enqueue(upload_lr=False)
+                e.loss, e.parts = loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in parts.items()}
+            del loss, parts
         except Exception:
             opt_.t_lr = old_lr
             raise
         finally:
             F_.set_philox_step(old)
-        torch.cuda.current_stream().wait_stream(cap_stream)
         while len(self.graphs) >= self.max_graphs:
             self.graphs.pop(next(iter(self.graphs)))
         self.graphs[key] = e

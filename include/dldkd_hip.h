@@ -278,10 +278,14 @@ int dldkd_modpool_bwd_f32(const float* h, const float* mask, const float* w, con
                           float* dh, float* dw, int N, int L, void* stream);
 
 /* compute_kl_loss(mode='frame_score') (model.py:183-197): out[q] (may be NULL) = KL(softmax(St/temp) ||
- * softmax(Sp/temp)) over the first lens[label_q] clips of Sp/St[q, label_q, :] ((nq, nv, L) clip scores);
- * dSp (may be NULL) += g * d out[q] / d Sp. */
+ * softmax(Sp/temp)) over the first lens[label_q] clips of Sp/St[q, label_q, :] ((nq, nv, L) clip scores; nv == 0: the
+ * compact form, Sp / St are (nq, L) = the positive column of every query as dldkd_simpool_train_fwd_f32 produces it);
+ * dSp (may be NULL) += *g * d out[q] / d Sp.  g (here and in the two losses below): the upstream gradient as a DEVICE
+ * scalar - autograd hands it over on the device; reading it back would put one host synchronisation per loss into
+ * every training step and make the step impossible to capture into a hipGraph.  Ignored (may be NULL) when no gradient
+ * output is requested. */
 int dldkd_kl_frame_f32(const float* Sp, const float* St, const int32_t* labels, const int32_t* lens, float temp,
-                       int nq, int nv, int L, float* out, float* dSp, float g, void* stream);
+                       int nq, int nv, int L, float* out, float* dSp, const float* g, void* stream);
 
 /* Symmetric InfoNCE on raw pooled scores S (nq, nv) (clip_nce_soft / clip_nce, model_components.py:126-234).
  * T = soft-label source scores or NULL (hard labels); rows q >= hardQ / columns v >= hardV use
@@ -291,7 +295,7 @@ int dldkd_kl_frame_f32(const float* Sp, const float* St, const int32_t* labels, 
  * dT (may be NULL) = g * dloss/dT through the soft targets (written). */
 int dldkd_nce_f32(const float* S, const float* T, const int32_t* labels, const float* cq, const float* cv,
                   int hardQ, int hardV, float beta, float eps, int nq, int nv, float* terms, float* dS, float* dT,
-                  float g, void* stream);
+                  const float* g, void* stream);
 
 /* get_clip_triplet_loss (model.py:353-387) on pooled cosine scores C (nq, nv): r_t2v[q] in [1, nv) = the
  * reference's torch.randint draw (rank of the sampled negative in the row sorted descending with the
@@ -299,7 +303,29 @@ int dldkd_nce_f32(const float* S, const float* T, const int32_t* labels, const f
  * hardest negative).  terms (nq + nv) = per-query / per-video hinge terms already divided by nq / nv;
  * dC (may be NULL) += g * dloss/dC. */
 int dldkd_triplet_f32(const float* C, const int32_t* labels, const int32_t* r_t2v, const int32_t* r_v2t, int hard,
-                      float margin, int nq, int nv, float* terms, float* dC, float g, void* stream);
+                      float margin, int nq, int nv, float* terms, float* dC, const float* g, void* stream);
+
+/* Training-side simpool: for one (query set, gallery) pair of DLDKD.forward (model.py:113-129) everything the losses read
+ * of get_sim_scores (model.py:307-329) and get_unnormalized_sim_scores (model.py:331-350), from ONE raw product
+ * S[n, v, l] = <q_n, g_vl> that is never written to memory:
+ *     pooled_raw[n, v] = max_{l < lens[v]} S             arg_raw = the clip          (model.py:344-349)
+ *     pooled_cos[n, v] = max_{l < lens[v]} S rq_n rg_vl   arg_cos = the clip          (model.py:318-327)
+ *     clip_pos[n, l]   = S[n, labels[n], l] rq_n rg_vl  (l < lens, else -1e10)  (nq, L): the [i, :, label_i] column that
+ *                        compute_kl_loss(frame_score) reads (model.py:183-197); may be NULL
+ * rq (nq) / rg (nv * L) = 1 / max(|row|, 1e-12) from dldkd_row_invnorm_f32 (F.normalize's clamp).  q (nq, D), g (nv, L, D)
+ * fp32, L <= 128.  precision: DLDKD_GEMM_F32X3 (parity grade) or DLDKD_GEMM_BF16.  A video without valid clips pools to
+ * -1e10 / clip 0 like the reference's masked maximum.
+ * Backward: d_cos / d_raw (nq, nv) and d_clip (nq, L) (each may be NULL) -> dq (nq, D), dg (nv, L, D) (each may be NULL;
+ * written, not accumulated): the max-pool gradient goes to the arg-max clip, the cosine through the normalisation Jacobian
+ * rq (ghat - cos qhat); D a multiple of 4, <= 512. */
+int dldkd_row_invnorm_f32(const float* x, float* inv, long M, int D, void* stream);
+int dldkd_simpool_train_fwd_f32(int precision, const float* q, const float* g, const float* rq, const float* rg,
+                                const int32_t* lens, const int32_t* labels, int nq, int nv, int L, int D, float* pooled_cos,
+                                float* pooled_raw, int32_t* arg_cos, int32_t* arg_raw, float* clip_pos, void* stream);
+int dldkd_simpool_train_bwd_f32(const float* q, const float* g, const float* rq, const float* rg, const int32_t* lens,
+                                const int32_t* labels, const int32_t* arg_cos, const int32_t* arg_raw, const float* pooled_cos,
+                                const float* clip_pos, const float* d_cos, const float* d_raw, const float* d_clip, int nq, int nv,
+                                int L, int D, float* dq, float* dg, void* stream);
 
 /* out[0] = sum of x[0..n) in a fixed order (single workgroup). */
 int dldkd_sum_f32(const float* x, long n, float* out, void* stream);

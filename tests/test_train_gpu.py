@@ -324,6 +324,66 @@ def test_forward_at_c5_size_vs_oracle(hard):
     assert all(prm.grad is not None and torch.isfinite(prm.grad).all() for prm in m.parameters())
 
 
+@pytest.mark.parametrize("prec,tol,gtol", [("fp32", 2e-6, 2e-5), ("bf16", 2e-2, 3e-2)])
+@pytest.mark.parametrize("nq,nv,L,D", [(640, 128, 128, 384), (257, 128, 64, 384), (37, 9, 50, 512), (5, 3, 1, 384), (130, 7, 128, 384)])
+def test_fused_training_simpool_vs_fp64(prec, tol, gtol, nq, nv, L, D):
+    """simpool_train.hip (one pooled MFMA GEMM forward, two gather kernels backward) against the reference formulas of
+    get_sim_scores / get_unnormalized_sim_scores / the [i, :, label_i] read of compute_kl_loss (model.py:307-350, 184) in
+    fp64 autograd: pooled cosine + raw maxima, the positive clip column, and the gradients of a random linear functional
+    of all three with respect to queries and gallery.  Includes a video without valid clips and ragged lengths."""
+    from dldkd_amd import functional as F_
+    from dldkd_amd import ops
+    g_ = torch.Generator().manual_seed(nq * 7 + nv)
+    q = torch.randn(nq, D, generator=g_)
+    g = torch.randn(nv, L, D, generator=g_)
+    lens = torch.randint(1, L + 1, (nv,), generator=g_)
+    if nv > 4:
+        lens[3] = 0                                      # a video without clips: pooled -1e10, no gradient
+    labels = torch.randint(0, nv, (nq,), generator=g_)
+    labels[labels == 3] = 0
+    mask = (torch.arange(L)[None] < lens[:, None])
+    g = g * mask[..., None]
+    Wc, Wr, We = torch.randn(nq, nv, generator=g_), torch.randn(nq, nv, generator=g_), torch.randn(nq, L, generator=g_)
+
+    def reference(q64, g64):
+        S = torch.einsum("nd,vld->nvl", q64, g64)
+        qn = torch.nn.functional.normalize(q64, dim=-1)
+        gn = torch.nn.functional.normalize(g64, dim=-1)
+        C = torch.einsum("nd,vld->nvl", qn, gn)
+        neg = torch.full_like(S, -1e10)
+        Sm, Cm = torch.where(mask[None], S, neg), torch.where(mask[None], C, neg)
+        pr, pc = Sm.max(-1).values, Cm.max(-1).values
+        clip = Cm[torch.arange(nq), labels]                               # (nq, L)
+        return pc, pr, clip
+    q64, g64 = q.double().requires_grad_(), g.double().requires_grad_()
+    pc64, pr64, clip64 = reference(q64, g64)
+    valid_pos = mask[labels]
+    (pc64 * Wc.double()).sum().add((pr64 * Wr.double()).sum()).add((clip64 * We.double() * valid_pos).sum()).backward()
+
+    ops.set_gemm_precision(prec)
+    try:
+        qd, gd = q.to(DEV).requires_grad_(), g.to(DEV).requires_grad_()
+        pc, pr, clip = F_.simpool_train(qd, gd, lens.to(DEV).int(), labels.to(DEV).int(), True)
+        ((pc * Wc.to(DEV)).sum() + (pr * Wr.to(DEV)).sum() + (clip * (We * valid_pos).to(DEV)).sum()).backward()
+    finally:
+        ops.set_gemm_precision("fp32")
+    has = lens > 0
+    sc = max(1.0, float(pr64.detach()[:, has].abs().max()))
+    assert (pr.detach().cpu().double()[:, has] - pr64.detach()[:, has]).abs().max().item() <= tol * sc
+    assert (pc.detach().cpu().double()[:, has] - pc64.detach()[:, has]).abs().max().item() <= tol
+    assert bool((pr.detach().cpu()[:, ~has] == -1e10).all()) and bool((pc.detach().cpu()[:, ~has] == -1e10).all())
+    cm = clip.detach().cpu().double()
+    assert (cm - clip64.detach())[valid_pos].abs().max().item() <= tol
+    assert bool((cm[~valid_pos] == -1e10).all())
+    if prec == "fp32":                # same arg-max clips as fp64 -> gradients agree to fp32 rounding
+        _gclose(qd.grad, q64.grad, gtol)
+        _gclose(gd.grad, g64.grad, gtol)
+    else:                             # bf16 products can pick a different clip at near-ties: compare in aggregate
+        for a, b in ((qd.grad, q64.grad), (gd.grad, g64.grad)):
+            a, b = a.double().cpu().flatten(), b.flatten()
+            assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.98
+
+
 def test_loss_kernels_fuzz_vs_oracle():
     """Random batch structures (2..40 videos, 1..4 captions each, 1..48 clips, random alpha/beta, both negative
     modes) through every loss kernel: value 1e-4 and gradient 2e-3 against the fp64 oracle."""

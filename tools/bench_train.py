@@ -1,30 +1,94 @@
-"""Time the C3 training step (TVR: 128 videos / 640 queries, soft labels, hard negatives) on the GPU box."""
-import os, sys, time, types
+"""Time the training step on the GPU box: C3 (TVR: 128 videos / 640 queries, soft labels, hard negatives) or C5 (Charades
+rank-local: 128 videos / 257 queries, 1024-d), eager and hipGraph-replayed (train.GraphedTrainStep).
+
+    python tools/bench_train.py [--config c3|c5] [--prec fp32|bf16] [--drop 0.2] [--steps 30] [--warmup 10]
+
+Per mode: HIP-event time of every step (stream time) AND host wall time, median / p90 over `steps` after `warmup`."""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("dl-dkd_amd", "tests/golden"):
     sys.path.insert(0, os.path.join(ROOT, p))
-import torch, synth
-from dldkd_amd.model import DLDKD
-from dldkd_amd.optimization import BertAdam
-DEV = "cuda:0"
-drop = float(sys.argv[1]) if len(sys.argv) > 1 else 0.2
-prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
-from dldkd_amd import ops
-ops.set_gemm_precision(prec)
-cfg = types.SimpleNamespace(visual_input_size=3072, query_input_size=768, inheritance_hidden=384, exploration_hidden=384,
-                            max_ctx_l=128, max_desc_l=30, input_drop=drop, drop=drop, n_heads=4, initializer_range=0.02,
-                            margin=0.1, use_hard_negative=True, hard_pool_size=20, label_style="soft")
-opt_ = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
-                             collection="tvr", alpha=0.8, belta=0.8)
-torch.manual_seed(0)
-m = DLDKD(cfg, opt_).to(DEV).train()
-opt = BertAdam([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=3e-4, warmup=0.01, t_total=1000)
-batch = synth.make_train_batch(3, nv=128, caps=5, L=128, len_lo=24, dv=3072, dq=768)
-batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
-def step():
-    opt.zero_grad(); loss, _ = m(batch); loss.backward(); opt.step(); return loss
-for _ in range(3): step()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10): l = step()
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-print(f"C3 train step ({prec} GEMMs, dropout {drop}): {dt*1e3:.2f} ms/step  loss {float(l):.4f}")
+import torch  # noqa: E402
+import synth  # noqa: E402
+
+
+def build(config, drop, dev):
+    from dldkd_amd.model import DLDKD
+    from dldkd_amd.optimization import BertAdam
+    dv, dq = (3072, 768) if config == "c3" else (1024, 1024)
+    cfg = types.SimpleNamespace(visual_input_size=dv, query_input_size=dq, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=128, max_desc_l=30, input_drop=drop, drop=drop, n_heads=4, initializer_range=0.02,
+                                margin=0.1, use_hard_negative=True, hard_pool_size=20, label_style="soft")
+    opt_ = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                 collection="tvr", alpha=0.8, belta=0.8)
+    torch.manual_seed(0)
+    m = DLDKD(cfg, opt_).to(dev).train()
+    opt = BertAdam([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=3e-4, warmup=0.01, t_total=100000)
+    if config == "c3":
+        batch = synth.make_train_batch(3, nv=128, caps=5, L=128, len_lo=24, dv=dv, dq=dq)
+    else:
+        batch = synth.make_train_batch(5, nv=128, caps=sorted([3] + [2] * 127, reverse=True), L=64, len_lo=8, dv=dv, dq=dq)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    return m, opt, batch
+
+
+def timed(step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    walls = []
+    ev[0].record()
+    t_all = time.perf_counter()
+    for i in range(steps):
+        t0 = time.perf_counter()
+        step()
+        ev[i + 1].record()
+        walls.append((time.perf_counter() - t0) * 1e3)
+    torch.cuda.synchronize()
+    total = (time.perf_counter() - t_all) * 1e3 / steps
+    gpu = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    walls.sort()
+    q = lambda a, f: a[min(len(a) - 1, int(f * len(a)))]      # noqa: E731
+    return {"ms_per_step_wall_mean": total, "stream_ms_median": q(gpu, 0.5), "stream_ms_p90": q(gpu, 0.9),
+            "host_ms_median": q(walls, 0.5), "host_ms_p90": q(walls, 0.9)}
+
+
+def run(config="c3", prec="bf16", drop=0.2, steps=30, warmup=10, dev="cuda:0", modes=("eager", "graph")):
+    from dldkd_amd import ops
+    from dldkd_amd import train as T
+    ops.set_gemm_precision(prec)
+    out = {"config": config, "precision": prec, "dropout": drop, "steps": steps, "warmup": warmup}
+    try:
+        topt = types.SimpleNamespace(grad_clip=-1)
+        if "eager" in modes:
+            m, opt, batch = build(config, drop, dev)
+            out["eager"] = timed(lambda: T.train_step(m, batch, opt, topt), steps, warmup)
+        if "graph" in modes:
+            m, opt, batch = build(config, drop, dev)
+            g = T.GraphedTrainStep(m, opt, topt, defer_loss_float=False)
+            out["graph"] = timed(lambda: g(batch), steps, warmup)
+            out["graph"]["replays"], out["graph"]["eager_steps"], out["graph"]["captures"] = g.replays, g.eager_steps, g.captures
+            g2 = T.GraphedTrainStep(m, opt, topt, defer_loss_float=True)
+            out["graph_no_loss_sync"] = timed(lambda: g2(batch), steps, warmup)
+    finally:
+        ops.set_gemm_precision("fp32")
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c3")
+    ap.add_argument("--prec", default="bf16")
+    ap.add_argument("--drop", type=float, default=0.2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--modes", default="eager,graph")
+    a = ap.parse_args()
+    print(json.dumps(run(a.config, a.prec, a.drop, a.steps, a.warmup, modes=tuple(a.modes.split(","))), indent=1))
