@@ -34,6 +34,11 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// fused = w0 * s0 + w1 * s1 (reference method/eval.py:254), written ONE way - fma(w0, a, w1 * b) - wherever it is computed (the
+// finish kernel that writes the fused matrix and the rank-from-partials kernel that never writes it), so that both see
+// bit-identical fused scores whatever contraction the compiler would pick per call site.
+__device__ __forceinline__ float fuse2(float w0, float a, float w1, float b) { return __builtin_fmaf(w0, a, w1 * b); }
+
 // LDS-DMA: one 16-byte piece per lane, 1 KiB per wave-instruction.  The LDS destination is the
 // wave-uniform base + lane*16 (cdna_hip_programming.md section 5 caveat); the global source is per lane.
 typedef __attribute__((address_space(3))) void lds_void;

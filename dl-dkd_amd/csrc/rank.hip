@@ -48,6 +48,88 @@ __global__ __launch_bounds__(256) void rank_gt_kernel(const float* __restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Ranks straight from the scorer's partial planes (part[b][pos(v)][q], simpool_eval.hip), for eval_epoch (eval.py:237-263), which
+// needs R@K of the inheritance, exploration and fused scores but never the (Nq, Nv) matrices themselves: no finish pass
+// (read 2 planes, write up to 3 matrices) and no three rank passes over them - one read of the two planes in their native,
+// query-contiguous layout.  Kernel 1: the ground-truth thresholds of every query (best / first GT video, per score kind);
+// kernel 2: counts of !(score <= threshold) per query, video chunks in parallel, integer atomics (exact, order-free).
+// Score kinds k: 0 = branch 0, 1 = branch 1, 2 = fused (fuse2, the finish kernel's expression).  thr / cnt: [kind][best|first][nq].
+// ---------------------------------------------------------------------------------------------------------------------
+struct RankPartArgs {
+    const float* part;
+    const int32_t* inv;      // [nv] video -> sorted position
+    const int32_t* gt_ptr;
+    const int32_t* gt_idx;
+    const float* q_bad;      // [nq] or null: queries flagged by pack_queries_kernel (NaN / Inf vector) rank last
+    float* thr;              // [3][2][nq]
+    int32_t* cnt;            // [3][2][nq]
+    int nq, nq_pad, nv, nb;
+    float w0, w1;
+};
+
+__global__ __launch_bounds__(256) void rank_part_thr_kernel(const RankPartArgs p) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= p.nq) return;
+    const int g0 = p.gt_ptr[q];
+    const int g1 = (p.q_bad != nullptr && p.q_bad[q] != 0.f) ? g0 : p.gt_ptr[q + 1];     // flagged: as if without ground truth
+    const float nan = __builtin_nanf("");
+    float best[3] = {-INFINITY, -INFINITY, -INFINITY}, first[3] = {nan, nan, nan};   // NaN threshold = "everything is above": rank nv + 1
+    for (int g = g0; g < g1; ++g) {
+        const size_t row = (size_t)p.inv[p.gt_idx[g]] * p.nq_pad + q;
+        float s[3];
+        s[0] = p.part[row];
+        s[1] = p.nb > 1 ? p.part[(size_t)p.nv * p.nq_pad + row] : s[0];
+        s[2] = p.nb > 1 ? fuse2(p.w0, s[0], p.w1, s[1]) : s[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (g == g0) first[k] = s[k];
+            best[k] = fmaxf(best[k], s[k]);           // drops NaNs; an all-NaN ground truth leaves -inf: everything finite is above
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p.thr[(size_t)(2 * k) * p.nq + q] = g1 > g0 ? best[k] : nan;
+        p.thr[(size_t)(2 * k + 1) * p.nq + q] = first[k];
+    }
+}
+
+constexpr int kRankVChunk = 512;
+__global__ __launch_bounds__(256) void rank_part_count_kernel(const RankPartArgs p) {
+    __shared__ int red[4][6][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    const int v0 = blockIdx.y * kRankVChunk, v1 = min(v0 + kRankVChunk, p.nv);
+    const bool act = q < p.nq;
+    float t[6];
+    int c[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k] = act ? p.thr[(size_t)k * p.nq + q] : 0.f;
+    const int qq = act ? q : 0;
+    // rows are visited in SORTED position order (any order counts the same): 256 contiguous bytes per wave and row
+#pragma unroll 4
+    for (int pos = v0 + wave; pos < v1; pos += 4) {
+        const size_t row = (size_t)pos * p.nq_pad + qq;
+        const float a = p.part[row];
+        const float b = p.nb > 1 ? p.part[(size_t)p.nv * p.nq_pad + row] : a;
+        const float f = p.nb > 1 ? fuse2(p.w0, a, p.w1, b) : a;
+        c[0] += !(a <= t[0]); c[1] += !(a <= t[1]);
+        c[2] += !(b <= t[2]); c[3] += !(b <= t[3]);
+        c[4] += !(f <= t[4]); c[5] += !(f <= t[5]);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[wave][k][lane] = c[k];
+    __syncthreads();
+    if (wave == 0 && act) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int s = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
+            if (s) atomicAdd(p.cnt + (size_t)k * p.nq + q, s);
+        }
+    }
+}
+
 }  // namespace dldkd
 
 using namespace dldkd;
@@ -60,4 +142,18 @@ extern "C" int dldkd_rank_gt(const float* scores, int nq, int nv, const int32_t*
     DLDKD_LAUNCH(rank_gt_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, scores, nv, gt_ptr, gt_idx, rank_best,
                        rank_first);
     return check_launch("rank_gt");
+}
+
+extern "C" int dldkd_simpool_rank_partials(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches, float w0,
+                                           float w1, const int32_t* gt_ptr, const int32_t* gt_idx, const float* q_bad,
+                                           float* thr_scratch, int32_t* counts, void* stream) {
+    if (nq < 0 || nv < 1 || n_branches < 1 || n_branches > 2) { set_error("rank_partials: bad sizes nq=%d nv=%d", nq, nv); return DLDKD_EINVAL; }
+    if (nq == 0) return DLDKD_OK;
+    if (!workspace || !inv_order || !gt_ptr || !gt_idx || !thr_scratch || !counts) { set_error("rank_partials: null pointer"); return DLDKD_EINVAL; }
+    RankPartArgs p{(const float*)workspace, inv_order, gt_ptr, gt_idx, q_bad, thr_scratch, counts, nq, (nq + 31) / 32 * 32, nv, n_branches, w0, w1};
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * 6 * (size_t)nq, s) != hipSuccess) return check_launch("rank_partials memset");
+    DLDKD_LAUNCH(rank_part_thr_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, p);
+    DLDKD_LAUNCH(rank_part_count_kernel, dim3((nq + 63) / 64, (nv + kRankVChunk - 1) / kRankVChunk), dim3(256), 0, s, p);
+    return check_launch("rank_partials");
 }

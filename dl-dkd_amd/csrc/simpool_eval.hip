@@ -43,7 +43,8 @@ __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m *
 // Packed query layout: [tile = q/32][sub = (q%32)/16][k-step ks of 32][lane = 16*kg + q%16][8 bf16 = k 32ks + 8kg ..+8]
 // = the B operand of mfma_f32_16x16x32_bf16 (cdna_hip_programming.md section 3 lane maps).
 __global__ __launch_bounds__(256) void pack_queries_kernel(const float* __restrict__ q, int nq, int nq_pad,
-                                                           int normalize, bf16x8* __restrict__ out) {
+                                                           int normalize, bf16x8* __restrict__ out,
+                                                           float* __restrict__ bad) {
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= nq_pad) return;
@@ -61,10 +62,12 @@ __global__ __launch_bounds__(256) void pack_queries_kernel(const float* __restri
         for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
     }
     float scale = 1.f;
-    if (normalize) {
-        ss = wave_sum(ss);
-        scale = 1.f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize eps, model.py:318
-    }
+    ss = wave_sum(ss);
+    if (normalize) scale = 1.f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize eps, model.py:318
+    // a query vector with a NaN / Inf component (a diverged model): the scorer's v_max pool would DROP the NaN products and
+    // hand every video the same sentinel score - a tie that ranks the ground truth first.  Flag it instead; the finish /
+    // rank kernels turn a flagged query's scores into NaN, which ranks last (rank.hip NaN policy).
+    if (bad != nullptr && lane == 0 && qi < nq && !(ss < INFINITY)) bad[qi] = 1.f;
     if (lane < kRowBf16x8) {
         bf16x8 o;
 #pragma unroll
@@ -445,8 +448,8 @@ __global__ __launch_bounds__(256, 1) void simpool_eval16_kernel(const SimpoolEva
 // measured in DESIGN.md).
 __global__ __launch_bounds__(256) void simpool_finish64_kernel(const float* __restrict__ part, const int32_t* __restrict__ inv,
                                                                int q_lo, int q_hi, int nq_pad, int nv, int n_branches, float w0,
-                                                               float w1, float* __restrict__ fused, float* __restrict__ s0,
-                                                               float* __restrict__ s1) {
+                                                               float w1, const float* __restrict__ q_bad, float* __restrict__ fused,
+                                                               float* __restrict__ s0, float* __restrict__ s1) {
     __shared__ float t0[64][65];
     __shared__ float t1[64][65];
     const int q0 = q_lo + blockIdx.x * 64, v0 = blockIdx.y * 64;
@@ -476,9 +479,10 @@ __global__ __launch_bounds__(256) void simpool_finish64_kernel(const float* __re
     for (int i = 0; i < 16; ++i) {
         const int ql = (threadIdx.x >> 6) + 4 * i, qq = q0 + ql;
         if (qq < q_hi) {
-            const float a = t0[vl][ql], b = t1[vl][ql];
+            float a = t0[vl][ql], b = t1[vl][ql];
+            if (q_bad != nullptr && q_bad[qq] != 0.f) a = b = __builtin_nanf("");      // flagged by pack_queries_kernel
             const size_t o = (size_t)(qq - q_lo) * nv + vv;
-            if (fused) fused[o] = n_branches > 1 ? w0 * a + w1 * b : a;
+            if (fused) fused[o] = n_branches > 1 ? fuse2(w0, a, w1, b) : a;
             if (s0) s0[o] = a;
             if (s1) s1[o] = b;
         }
@@ -521,12 +525,12 @@ size_t dldkd_simpool_eval_workspace_bytes(int nq, int nv, int n_branches) {
     return (size_t)n_branches * (nv < 1 ? 1 : nv) * round_up(nq < 1 ? 1 : nq, kQTile) * sizeof(float);
 }
 
-int dldkd_pack_queries_bf16(const float* q, int nq, int normalize, void* q_packed, void* stream) {
+int dldkd_pack_queries_bf16(const float* q, int nq, int normalize, void* q_packed, float* bad_flags, void* stream) {
     if (nq < 0 || (nq > 0 && (!q || !q_packed))) { set_error("pack_queries: bad arguments"); return DLDKD_EINVAL; }
     if (nq == 0) return DLDKD_OK;
     const int nq_pad = round_up(nq, kQTile);
     DLDKD_LAUNCH(pack_queries_kernel, dim3((nq_pad + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, nq, nq_pad,
-                       normalize, (bf16x8*)q_packed);
+                       normalize, (bf16x8*)q_packed, bad_flags);
     return check_launch("pack_queries");
 }
 
@@ -625,7 +629,7 @@ int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_pa
 }
 
 int dldkd_simpool_finish_range(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches, float w0,
-                               float w1, int q_lo, int q_hi, float* fused, float* s0, float* s1, void* stream) {
+                               float w1, int q_lo, int q_hi, const float* q_bad, float* fused, float* s0, float* s1, void* stream) {
     if (nq < 0 || nv < 0 || n_branches < 1 || n_branches > 2 || q_lo < 0 || q_hi < q_lo || q_hi > nq || (q_lo & 3)) {
         set_error("simpool_finish: bad sizes nq=%d nv=%d branches=%d range [%d, %d)", nq, nv, n_branches, q_lo, q_hi);
         return DLDKD_EINVAL;
@@ -634,13 +638,13 @@ int dldkd_simpool_finish_range(const void* workspace, const int32_t* inv_order, 
     if (!workspace || !inv_order) { set_error("simpool_finish: null pointer"); return DLDKD_EINVAL; }
     const int nq_pad = round_up(nq, kQTile);
     DLDKD_LAUNCH(simpool_finish64_kernel, dim3((q_hi - q_lo + 63) / 64, (nv + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)workspace, inv_order, q_lo, q_hi, nq_pad, nv, n_branches, w0, w1, fused, s0, s1);
+                       (const float*)workspace, inv_order, q_lo, q_hi, nq_pad, nv, n_branches, w0, w1, q_bad, fused, s0, s1);
     return check_launch("simpool_finish");
 }
 
 int dldkd_simpool_finish(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches, float w0,
                          float w1, float* fused, float* s0, float* s1, void* stream) {
-    return dldkd_simpool_finish_range(workspace, inv_order, nq, nv, n_branches, w0, w1, 0, nq < 0 ? 0 : nq, fused, s0, s1, stream);
+    return dldkd_simpool_finish_range(workspace, inv_order, nq, nv, n_branches, w0, w1, 0, nq < 0 ? 0 : nq, nullptr, fused, s0, s1, stream);
 }
 
 int dldkd_stream_wait_counter(void* stream, int32_t* counter, int32_t at_least) {

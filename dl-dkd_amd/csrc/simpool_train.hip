@@ -112,26 +112,40 @@ __global__ __launch_bounds__(256) void simpool_bwd_dg_kernel(const SimpoolBwdArg
     float* rowproj = reinterpret_cast<float*>(cnt + L + 1);    // [L]
     int* pos = reinterpret_cast<int*>(rowproj + L);            // [nq + 1] captions of this video, pos[nq] = their number
     float2* ent = reinterpret_cast<float2*>(pos + nq + 1);     // [2 nq] (query, coefficient); word offset 6 nq + 2 L + 2: even
-    for (int n = tid; n < nq; n += 256) {
-        const size_t o = (size_t)n * p.nv + v;
-        const float b = (p.d_cos && len > 0) ? p.d_cos[o] : 0.f;
-        sc[4 * n + 0] = (p.d_raw && len > 0) ? p.d_raw[o] : 0.f;
-        sc[4 * n + 1] = b * p.rq[n];
-        sc[4 * n + 2] = __int_as_float(p.arg_raw[o]);
-        sc[4 * n + 3] = __int_as_float(p.arg_cos[o]);
-        bcos[n] = b * p.pooled_cos[o];
-    }
-    if (tid == 0) {                                            // captions of this video, in query order (a handful)
-        int k = 0;
-        if (p.d_clip != nullptr && len > 0)
-            for (int n = 0; n < nq; ++n) if (p.labels[n] == v) pos[k++] = n;
-        pos[nq] = k;
-    }
+    int* wcnt = reinterpret_cast<int*>(ent);                   // 4 ints of scratch for the ordered compaction below (ent is filled later)
+    if (tid == 0) pos[nq] = 0;
     __syncthreads();
+    for (int n0 = 0; n0 < nq; n0 += 256) {
+        const int n = n0 + tid;
+        bool mine = false;
+        if (n < nq) {
+            const size_t o = (size_t)n * p.nv + v;
+            const float b = (p.d_cos && len > 0) ? p.d_cos[o] : 0.f;
+            sc[4 * n + 0] = (p.d_raw && len > 0) ? p.d_raw[o] : 0.f;
+            sc[4 * n + 1] = b * p.rq[n];
+            sc[4 * n + 2] = __int_as_float(p.arg_raw[o]);
+            sc[4 * n + 3] = __int_as_float(p.arg_cos[o]);
+            bcos[n] = b * p.pooled_cos[o];
+            mine = p.d_clip != nullptr && len > 0 && p.labels[n] == v;
+        }
+        // captions of this video, in query order: wave ballots + a 4-entry prefix (ordered, hence deterministic sums later)
+        const unsigned long long m = __ballot(mine);
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int base = pos[nq];
+        for (int w = 0; w < wave; ++w) base += wcnt[w];
+        if (mine) pos[base + __popcll(m & ((1ull << lane) - 1ull))] = n;
+        __syncthreads();
+        if (tid == 0) pos[nq] += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
     // counting sort by clip: thread l owns clip l (every thread reads the same sc word: an LDS broadcast)
     if (tid < L) {
         int k = 0;
-        for (int n = 0; n < nq; ++n) k += (__float_as_int(sc[4 * n + 2]) == tid) + (__float_as_int(sc[4 * n + 3]) == tid);
+        for (int n = 0; n < nq; ++n) {
+            const float2 ll = *reinterpret_cast<const float2*>(sc + 4 * n + 2);
+            k += (__float_as_int(ll.x) == tid) + (__float_as_int(ll.y) == tid);
+        }
         cnt[tid + 1] = k;
     }
     if (tid == 0) cnt[0] = 0;
@@ -143,8 +157,9 @@ __global__ __launch_bounds__(256) void simpool_bwd_dg_kernel(const SimpoolBwdArg
         float pr = 0.f;
         const float rgl = tid < len ? p.rg[(size_t)v * L + tid] : 0.f;
         for (int n = 0; n < nq; ++n) {
-            if (__float_as_int(sc[4 * n + 2]) == tid) ent[k++] = float2{__int_as_float(n), sc[4 * n]};
-            if (__float_as_int(sc[4 * n + 3]) == tid) { ent[k++] = float2{__int_as_float(n), sc[4 * n + 1] * rgl}; pr += bcos[n]; }
+            const float2 ll = *reinterpret_cast<const float2*>(sc + 4 * n + 2);
+            if (__float_as_int(ll.x) == tid) ent[k++] = float2{__int_as_float(n), sc[4 * n]};
+            if (__float_as_int(ll.y) == tid) { ent[k++] = float2{__int_as_float(n), sc[4 * n + 1] * rgl}; pr += bcos[n]; }
         }
         const int np = pos[nq];
         if (tid < len)

@@ -106,6 +106,18 @@ def cal_perf(t2v_all_errors, t2v_gt, test=False, csr=None):
     return (r1, r5, r10, r100, medr, meanr, m)
 
 
+def perf_from_ranks(rank_best, rank_first, n_q):
+    """cal_perf's seven numbers (and its log lines) from ranks that are already known."""
+    r1, r5, r10, r100, medr, meanr = _recalls(rank_best, n_q)
+    m = float((1.0 / rank_first.astype(np.float64)).mean())
+    logging.info(" * Text to Video:")
+    logging.info(" * r_1_5_10_100: {}".format([round(r1, 1), round(r5, 1), round(r10, 1), round(r100, 1)]))
+    logging.info(" * recall sum: {}".format(round(r1 + r5 + r10 + r100, 1)))
+    logging.info(" * mAP: {}".format(round(m, 4)))
+    logging.info(" * " + "-" * 10)
+    return (r1, r5, r10, r100, medr, meanr, m)
+
+
 CONTEXT_SUPER_BATCH = 1024
 
 
@@ -342,20 +354,33 @@ def eval_epoch(model, val_video_dataset, val_text_dataset, opt, test=False):
         return _eval_epoch(model, val_video_dataset, val_text_dataset, opt, test)
 
 
+def rank_queries(model, eval_dataset, opt, ctx_info, w=(0.7, 0.3)):
+    """What eval_epoch needs of compute_query2ctx_info + the three cal_perf calls, without the score matrices: encode the
+    queries, score them against the resident gallery (scorer partial planes only), and rank the ground-truth videos straight
+    from the planes (scoring.rank_partials).  Returns (ranks (3, 2, Nq) int32 numpy, query_metas)."""
+    model.eval()
+    metas, qs = _encode_all_queries(model, eval_dataset, opt)
+    pg = ctx_info["_packed"]
+    pq = scoring.pack_queries(qs)
+    ws = scoring.simpool_partials(pq, pg)
+    _, t2v_gt = get_gt(ctx_info["video_metas"], metas)
+    ptr, idx = gt_csr(t2v_gt, len(metas), pg.lens.device)
+    return scoring.rank_partials(ws, pq, pg, ptr, idx, w).cpu().numpy(), metas
+
+
 def _eval_epoch(model, val_video_dataset, val_text_dataset, opt, test=False):
     model.eval()
     logger.info("Computing scores")
     context_info = compute_context_info(model, val_video_dataset, opt, keep_frame_feats=False)
-    fused, s0, s1, query_metas = score_queries(model, val_text_dataset, opt, context_info)
-    _, t2v_gt = get_gt(context_info["video_metas"], query_metas)
-    csr = gt_csr(t2v_gt, len(query_metas), fused.device)       # one host loop + upload for the three rankings
+    ranks, query_metas = rank_queries(model, val_text_dataset, opt, context_info)
+    nq = len(query_metas)
     if opt.double_branch:
         logging.info("inher_scores:")
-        cal_perf(-1 * s0, t2v_gt, test, csr)
+        perf_from_ranks(ranks[0, 0], ranks[0, 1], nq)
         logging.info("explore_scores:")
-        cal_perf(-1 * s1, t2v_gt, test, csr)
+        perf_from_ranks(ranks[1, 0], ranks[1, 1], nq)
         logging.info("score_sum:")
-        r1, r5, r10, r100, _, _, _ = cal_perf(-1 * fused, t2v_gt, test, csr)
+        r1, r5, r10, r100, _, _, _ = perf_from_ranks(ranks[2, 0], ranks[2, 1], nq)
     else:
-        r1, r5, r10, r100, _, _, _ = cal_perf(-1 * s0, t2v_gt, test, csr)
+        r1, r5, r10, r100, _, _, _ = perf_from_ranks(ranks[0, 0], ranks[0, 1], nq)
     return r1 + r5 + r10 + r100

@@ -26,13 +26,13 @@ SIGNATURES = {
     "dldkd_packed_queries_bytes": (_c_size_t, [_c_int]),
     "dldkd_packed_gallery_bytes": (_c_size_t, [_c_int, _c_int]),
     "dldkd_simpool_eval_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
-    "dldkd_pack_queries_bf16": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "dldkd_pack_queries_bf16": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_pack_gallery_bf16": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_simpool_eval_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                           _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_simpool_eval_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "dldkd_simpool_finish_range": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_int, _c_int,
-                                             _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+                                             _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_stream_wait_counter": (_c_int, [_c_void_p, _c_void_p, ctypes.c_int32]),
     "dldkd_simpool_finish": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p,
                                        _c_void_p, _c_void_p, _c_void_p]),
@@ -42,6 +42,8 @@ SIGNATURES = {
                                       _c_float, _c_void_p]),
     "dldkd_attention_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
     "dldkd_modpool_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
+    "dldkd_simpool_rank_partials": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p, _c_void_p,
+                                              _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_rank_gt": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_gemm_f32_batched": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                          _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_float,

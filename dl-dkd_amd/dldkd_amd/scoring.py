@@ -19,11 +19,13 @@ def _f32c(t):
 
 
 class PackedQueries:
-    """bf16 queries in MFMA B-fragment order, one blob per branch."""
+    """bf16 queries in MFMA B-fragment order, one blob per branch; `bad` (Nq floats): 1 where a query vector of either branch
+    has a NaN / Inf component (its scores become NaN in simpool_finish / rank_partials: it ranks last)."""
 
-    def __init__(self, blobs, nq):
+    def __init__(self, blobs, nq, bad=None):
         self.blobs = blobs
         self.nq = nq
+        self.bad = bad
 
 
 class PackedGallery:
@@ -42,15 +44,16 @@ def pack_queries(qs, normalize=True):
     L = native.lib()
     nq = qs[0].shape[0]
     blobs = []
+    bad = torch.zeros(max(nq, 1), dtype=torch.float32, device=qs[0].device)
     for q in qs:
         if q.dim() != 2 or q.shape[1] != HIDDEN or q.shape[0] != nq:
             raise native.NativeError(f"queries must be (Nq, {HIDDEN}); got {tuple(q.shape)}")
         q = _f32c(q)
         blob = torch.empty(L.dldkd_packed_queries_bytes(nq), dtype=torch.uint8, device=q.device)
-        native.check(L.dldkd_pack_queries_bf16(native.ptr(q), nq, int(normalize), native.ptr(blob), native.stream()),
+        native.check(L.dldkd_pack_queries_bf16(native.ptr(q), nq, int(normalize), native.ptr(blob), native.ptr(bad), native.stream()),
                      "pack_queries")
         blobs.append(blob)
-    return PackedQueries(blobs, nq)
+    return PackedQueries(blobs, nq, bad)
 
 
 def pack_gallery(gs, mask=None, normalize=True):
@@ -160,9 +163,27 @@ def simpool_finish(workspace, pq, pg, w=(0.7, 0.3), want_fused=True, want_branch
         raise native.NativeError(f"simpool_finish: out must be fp32 ({n}, {nv})")
     if n and nv:
         native.check(L_.dldkd_simpool_finish_range(native.ptr(workspace), native.ptr(pg.inv_order), nq, nv, nb, float(w[0]),
-                                                   float(w[1]), lo, hi, native.ptr(fused), native.ptr(s0), native.ptr(s1),
-                                                   native.stream()), "simpool_finish")
+                                                   float(w[1]), lo, hi, native.ptr(pq.bad), native.ptr(fused), native.ptr(s0),
+                                                   native.ptr(s1), native.stream()), "simpool_finish")
     return fused, s0, s1
+
+
+def rank_partials(workspace, pq, pg, gt_ptr, gt_idx, w=(0.7, 0.3)):
+    """Ranks of the ground-truth videos straight from the scorer's partial planes (no (Nq, Nv) matrix is written or read).
+    gt_ptr / gt_idx: the ground truth as CSR int32 GPU tensors (eval.gt_csr).  Returns int32 GPU tensor (3, 2, Nq):
+    [kind: branch 0 / branch 1 / fused][rank of the best GT video (eval_q2m) / of the first listed one (t2v_map)]."""
+    L_ = native.lib()
+    nq, nv, dev = pq.nq, pg.nv, pg.lens.device
+    counts = torch.empty(3, 2, nq, dtype=torch.int32, device=dev)
+    if nq == 0:
+        return counts
+    if nv == 0:
+        return counts.fill_(1)
+    thr = torch.empty(6 * nq, dtype=torch.float32, device=dev)
+    native.check(L_.dldkd_simpool_rank_partials(native.ptr(workspace), native.ptr(pg.inv_order), nq, nv, pg.n_branches, float(w[0]),
+                                                float(w[1]), native.ptr(gt_ptr), native.ptr(gt_idx), native.ptr(pq.bad), native.ptr(thr),
+                                                native.ptr(counts), native.stream()), "simpool_rank_partials")
+    return torch.clamp_(counts.add_(1), max=nv + 1)
 
 
 def simpool_eval(pq, pg, w=(0.7, 0.3), want_fused=True, want_branches=False, workspace=None):

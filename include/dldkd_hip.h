@@ -53,8 +53,11 @@ size_t dldkd_packed_gallery_bytes(int nv, int L);
 size_t dldkd_simpool_eval_workspace_bytes(int nq, int nv, int n_branches);
 
 /* q (nq, 384) fp32 -> packed bf16 MFMA-fragment order; normalize != 0 applies F.normalize (eps 1e-12,
- * model.py:318) in fp32 before rounding. */
-int dldkd_pack_queries_bf16(const float* q, int nq, int normalize, void* q_packed, void* stream);
+ * model.py:318) in fp32 before rounding.  bad_flags (nq floats, zeroed by the caller, or NULL): set to 1 for every query
+ * vector with a NaN / Inf component.  The scorer's max-pool drops NaN products, so such a query would tie every video
+ * (and rank its ground truth FIRST); hand the flags to dldkd_simpool_finish_range / dldkd_simpool_rank_partials and the
+ * query's scores become NaN, which ranks last (dldkd_rank_gt's NaN policy): a diverged model scores R@K = 0, not 100. */
+int dldkd_pack_queries_bf16(const float* q, int nq, int normalize, void* q_packed, float* bad_flags, void* stream);
 
 /* g (nv, L, 384) fp32 + mask (nv, L) fp32 0/1 prefix masks (NULL = all valid) -> bf16 gallery blob,
  * lens[nv] int32 (number of valid clips, data_provider.py:81-84).  normalize as above (model.py:319).
@@ -99,10 +102,11 @@ int dldkd_simpool_eval_plan(int nq, int nv, int n_branches, int min_split, int* 
  * fused / s0 / s1 may each be NULL. */
 int dldkd_simpool_finish(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches,
                          float w0, float w1, float* fused, float* s0, float* s1, void* stream);
-/* The same for the queries [q_lo, q_hi) only (q_lo a multiple of 4): outputs are (q_hi - q_lo, nv) blocks. */
+/* The same for the queries [q_lo, q_hi) only (q_lo a multiple of 4): outputs are (q_hi - q_lo, nv) blocks.  q_bad: NULL or the
+ * bad_flags of dldkd_pack_queries_bf16 (nq floats): flagged queries get NaN scores. */
 int dldkd_simpool_finish_range(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches,
-                               float w0, float w1, int q_lo, int q_hi, float* fused, float* s0, float* s1,
-                               void* stream);
+                               float w0, float w1, int q_lo, int q_hi, const float* q_bad, float* fused, float* s0,
+                               float* s1, void* stream);
 
 /* Enqueue on `stream` a wait until *counter >= at_least (hipStreamWaitValue32, no host involvement): everything
  * enqueued on `stream` afterwards runs once the producer kernel - typically still running on another stream - has
@@ -341,6 +345,19 @@ int dldkd_sum_f32(const float* x, long n, float* out, void* stream);
  * above and a NaN ground-truth score ranks nv + 1 - a diverged model scores R@K = 0, not 100. */
 int dldkd_rank_gt(const float* scores, int nq, int nv, const int32_t* gt_ptr, const int32_t* gt_idx,
                   int32_t* rank_best, int32_t* rank_first, void* stream);
+
+/* Ranks of the ground-truth videos straight from the scorer's partial planes (the `workspace` of dldkd_simpool_eval_bf16),
+ * for eval_epoch (eval.py:237-263), which ranks the inheritance, exploration and fused scores but never needs the (nq, nv)
+ * matrices: replaces dldkd_simpool_finish + three dldkd_rank_gt passes by one read of the two planes.
+ * counts (int32, [3 kinds][2][nq], zeroed here): kind 0 / 1 / 2 = branch 0 / branch 1 / fused (w0 s0 + w1 s1, the same
+ * expression as dldkd_simpool_finish: bit-identical scores); [0] = #(scores above the BEST ground-truth video's score) ->
+ * rank_best = 1 + count (eval_q2m, eval.py:69-83), [1] = the same for the FIRST listed ground-truth video (t2v_map,
+ * eval.py:97-111).  "above" = !(s <= gt): the NaN policy of dldkd_rank_gt; a query without ground truth counts nv.
+ * With n_branches == 1 all three kinds equal branch 0.  q_bad: NULL or dldkd_pack_queries_bf16's flags (flagged queries
+ * count nv: they rank last).  thr_scratch: 6 * nq floats. */
+int dldkd_simpool_rank_partials(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches, float w0,
+                                float w1, const int32_t* gt_ptr, const int32_t* gt_idx, const float* q_bad, float* thr_scratch,
+                                int32_t* counts, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimiser step and sharded-ranking helper.

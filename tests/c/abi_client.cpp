@@ -95,7 +95,7 @@ int main() {
         HIPCHK(hipMemcpy(dg[b], g[b].data(), g[b].size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMalloc(&pq[b], dldkd_packed_queries_bytes(NQ)));
         HIPCHK(hipMalloc(&pg[b], dldkd_packed_gallery_bytes(NV, L)));
-        ABICHK(dldkd_pack_queries_bf16(dq[b], NQ, 1, pq[b], nullptr));
+        ABICHK(dldkd_pack_queries_bf16(dq[b], NQ, 1, pq[b], nullptr, nullptr));
         // the streaming packer, two chunks with different padded lengths (the eval driver's usage)
         const int v_split = 4, l0 = L, l1 = L;
         ABICHK(dldkd_pack_gallery_chunk_bf16(dg[b], dmask, v_split, l0, 1, pg[b], dlens, 0, NV, L, nullptr));

@@ -196,3 +196,55 @@ def test_eval_epoch_sharded_edge_cases(recwarn):
             dist.destroy_process_group()
     assert got == pytest.approx(ref)
     assert not [w for w in recwarn.list if "video_ids" in str(w.message)]
+
+
+@pytest.mark.parametrize("nq,nv,L,nb", [(10895, 2000, 128, 2), (333, 77, 40, 2), (64, 1, 9, 2), (50, 600, 128, 1)])
+def test_ranks_from_partials_equal_ranks_from_matrices(nq, nv, L, nb):
+    """scoring.rank_partials (eval_epoch's path: no score matrix written) against the matrix path
+    (simpool_finish + rank_gt per matrix): identical integer ranks for all three score kinds and both rank flavours, with
+    multi-GT queries, queries without ground truth, a video without clips and NaN scores (same NaN policy)."""
+    from dldkd_amd import eval as ev
+    from dldkd_amd import scoring
+    g = torch.Generator(device=DEV).manual_seed(nq + nv)
+    lens = torch.randint(1, L + 1, (nv,), generator=g, device=DEV)
+    if nv > 5:
+        lens[5] = 0
+    mask = (torch.arange(L, device=DEV)[None] < lens[:, None]).float()
+    gal = [torch.randn(nv, L, 384, generator=g, device=DEV) * mask[..., None] for _ in range(nb)]
+    qs = [torch.randn(nq, 384, generator=g, device=DEV) for _ in range(nb)]
+    if nq > 20:
+        qs[0][7] = float("nan")                               # a diverged query: NaN scores everywhere
+    pg, pq = scoring.pack_gallery(gal, mask), scoring.pack_queries(qs)
+    rs = np.random.RandomState(3)
+    gts = {}
+    for q in range(nq):
+        k = rs.randint(0, 4) if q % 11 == 0 else 1             # some queries without / with several ground-truth videos
+        if k:
+            gts[q] = [int(v) for v in rs.choice(nv, size=min(k, nv), replace=False)]
+    ptr, idx = ev.gt_csr(gts, nq, DEV)
+    ws = scoring.simpool_partials(pq, pg)
+    got = scoring.rank_partials(ws, pq, pg, ptr, idx).cpu()
+    fused, s0, s1 = scoring.simpool_finish(ws, pq, pg, want_branches=True)
+    mats = [s0, s1 if nb == 2 else s0, fused if nb == 2 else s0]
+    for k, m in enumerate(mats):
+        rb, rf = ev.gt_ranks_gpu(m, gts, (ptr, idx))
+        assert torch.equal(got[k, 0], rb.cpu()), k
+        assert torch.equal(got[k, 1], rf.cpu()), k
+    if nq > 20:
+        assert int(got[2, 0, 7]) == nv + 1                      # the NaN query ranks last
+
+
+def test_eval_epoch_equals_matrix_path(golden_dir):
+    """eval_epoch (ranks from the partial planes) returns exactly the SumR of the explicit matrix path of the reference's
+    eval_epoch (compute_query2ctx_info -> fuse -> cal_perf, eval.py:243-263)."""
+    from dldkd_amd import eval as ev
+    m = _model(3072, 768, synth.make_params(51, 3072, 768))
+    vids, txts = synth.make_eval_sets(5, nv=64, caps=3, dv=3072, dq=768)
+    opt = _opt()
+    with torch.no_grad():
+        sumr = ev.eval_epoch(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), opt)
+        ctx = ev.compute_context_info(m, synth.ListDataset(list(vids)), opt, keep_frame_feats=False)
+        fused, s0, s1, metas = ev.score_queries(m, synth.ListDataset(list(txts)), opt, ctx)
+    _, t2v = ev.get_gt(ctx["video_metas"], metas)
+    r = ev.cal_perf(-fused, t2v)
+    assert sumr == pytest.approx(r[0] + r[1] + r[2] + r[3], abs=1e-9)
