@@ -165,50 +165,33 @@ def extras(dev):
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
         import synth
+        from dldkd_amd import ops
         from dldkd_amd.model import DLDKD
-        from dldkd_amd.optimization import BertAdam
         cfg = types.SimpleNamespace(visual_input_size=3072, query_input_size=768, inheritance_hidden=384,
                                     exploration_hidden=384, max_ctx_l=128, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4,
                                     initializer_range=0.02, margin=0.1, use_hard_negative=True, hard_pool_size=20,
                                     label_style="soft")
         opt_ = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04,
                                      explore_nce_weight=0.04, collection="tvr", alpha=0.8, belta=0.8)
-        torch.manual_seed(0)
-        m = DLDKD(cfg, opt_).to(dev).train()
-        opt = BertAdam([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=3e-4, warmup=0.01, t_total=1000)
-        batch = synth.make_train_batch(3, nv=128, caps=5, L=128, len_lo=24, dv=3072, dq=768)
-        batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
-
-        def step():
-            opt.zero_grad()
-            loss, _ = m(batch)
-            loss.backward()
-            opt.step()
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            step()
-        torch.cuda.synchronize()
-        out["c3_train_step_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+        # C3 / C5 training step (tools/bench_train.py): >= 30 timed steps after >= 10 warm-ups per mode, HIP events around
+        # every step, median and p90; eager (train.train_step) and hipGraph-replayed (train.GraphedTrainStep, what
+        # train.train() runs).  c3_train_step_ms[_bf16] = the replayed step's median stream time incl. float(loss).
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_train
+        for cfgname, key in (("c3", "c3"), ("c5", "c5")):
+            for prec in ("fp32", "bf16"):
+                r = bench_train.run(cfgname, prec, 0.2 if cfgname == "c3" else 0.15, steps=30, warmup=10, dev=str(dev))
+                out[f"{key}_train_step_{prec}"] = r
+                out[f"{key}_train_step_ms" + ("_bf16" if prec == "bf16" else "") if key == "c3" else f"c5_train_step_ms_{prec}"] = \
+                    r["graph"]["stream_ms_median"]
         out["c3_train_step_config"] = "TVR: 128 videos / 640 queries, L<=128, label_style=soft, hard negatives, dropout 0.2, " \
-                                      "forward+backward+fused BertAdam, parity mode (fp32-grade GEMMs: three bf16 planes per operand on the bf16 matrix cores)"
-        from dldkd_amd import ops
-        ops.set_gemm_precision("bf16")    # throughput mode: the configuration BASELINE.json configs[2] names (bf16)
-        try:
-            for _ in range(3):
-                step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                step()
-            torch.cuda.synchronize()
-            out["c3_train_step_ms_bf16"] = (time.perf_counter() - t0) / 10 * 1e3
-            out["c3_train_step_bf16_config"] = "same step, every GEMM on bf16 MFMA with fp32 accumulation (fp32 master " \
-                                               "weights, fp32 activations in HBM, losses/normalisations/optimizer fp32)"
-        finally:
-            ops.set_gemm_precision("fp32")
+                                      "zero_grad + forward + backward + fused BertAdam; fp32 = parity mode (fp32-grade GEMMs: three bf16 " \
+                                      "planes per operand, losses within 1e-4 of the reference), bf16 = every GEMM on bf16 MFMA with fp32 " \
+                                      "accumulation (fp32 master weights / activations, losses 2e-2); *_ms = hipGraph-replayed step, median"
+        out["c5_train_step_config"] = "Charades rank-local step: 128 videos / 257 queries, L<=64, Dv=Dq=1024, dropout 0.15 " \
+                                      "(the gradient all-reduce of the 17.5 MB flat bucket is not part of a 1-GPU run)"
+        torch.manual_seed(0)
+        m = DLDKD(cfg, opt_).to(dev)
         m.eval()
         B, Lc = 200, 128
         feats = torch.nn.functional.normalize(torch.randn(B, Lc, 3072, device=dev), dim=-1)
@@ -258,37 +241,7 @@ def extras(dev):
             del fb, mb
         finally:
             ops.set_gemm_precision("fp32")
-        # C5 (configs[4], one rank of the DDP job): Charades, 1024-d features, captions [3,2,2,...], dropout 0.15
-        cfg5 = types.SimpleNamespace(**{**vars(cfg), "visual_input_size": 1024, "query_input_size": 1024, "input_drop": 0.15,
-                                        "drop": 0.15})
-        torch.manual_seed(5)
-        m5 = DLDKD(cfg5, opt_).to(dev).train()
-        opt5 = BertAdam([{"params": list(m5.parameters()), "weight_decay": 0.01}], lr=2.4e-4, warmup=0.01, t_total=1000)
-        caps5 = sorted([3] + [2] * 127, reverse=True)
-        b5 = synth.make_train_batch(5, nv=128, caps=caps5, L=64, len_lo=8, dv=1024, dq=1024)
-        b5 = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b5.items()}
-
-        def step5():
-            opt5.zero_grad()
-            loss, _ = m5(b5)
-            loss.backward()
-            opt5.step()
-        for prec in ("fp32", "bf16"):
-            ops.set_gemm_precision(prec)
-            try:
-                for _ in range(3):
-                    step5()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    step5()
-                torch.cuda.synchronize()
-                out["c5_train_step_ms_" + prec] = (time.perf_counter() - t0) / 10 * 1e3
-            finally:
-                ops.set_gemm_precision("fp32")
-        out["c5_train_step_config"] = "Charades rank-local step: 128 videos / 257 queries, L<=64, Dv=Dq=1024, dropout 0.15 " \
-                                      "(the gradient all-reduce of the 17.5 MB flat bucket is not part of a 1-GPU run)"
-        del m, opt, batch, m5, opt5, b5
+        del m
         torch.cuda.empty_cache()
         # C4 (configs[3]) on ONE GPU: ActivityNet gallery 4917 videos x 128 clips (all valid) x 17505 queries
         from dldkd_amd import scoring
@@ -310,6 +263,9 @@ def extras(dev):
                                       "config": "4917 videos x 128 clips (all valid) x 17505 queries, 2 branches + fusion, 1 GPU"}
         del pg4, q4
         torch.cuda.empty_cache()
+        # single-GPU proxy of the 8-GPU ActivityNet run: one rank's 615-video shard x all queries vs the whole gallery
+        from bench_shard_proxy import shard_proxy
+        out["c4_shard_proxy_1_of_8"] = shard_proxy(str(dev))
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from bench_eval_e2e import stage_times
         # GPU work of one eval_epoch at C2 from RAW features (encode gallery + queries, score, rank); SURVEY 8d

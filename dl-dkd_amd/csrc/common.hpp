@@ -39,6 +39,19 @@ __device__ __forceinline__ float wave_max(float v) {
 // bit-identical fused scores whatever contraction the compiler would pick per call site.
 __device__ __forceinline__ float fuse2(float w0, float a, float w1, float b) { return __builtin_fmaf(w0, a, w1 * b); }
 
+// Philox4x32-10 (Salmon et al., SC'11): the counter-based generator of every dropout mask (train_f32.hip, attention_train.hip)
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
 // LDS-DMA: one 16-byte piece per lane, 1 KiB per wave-instruction.  The LDS destination is the
 // wave-uniform base + lane*16 (cdna_hip_programming.md section 5 caveat); the global source is per lane.
 typedef __attribute__((address_space(3))) void lds_void;

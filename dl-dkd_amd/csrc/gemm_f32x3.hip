@@ -283,20 +283,3 @@ extern "C" int dldkd_gemm_f32x3(const float* A, const float* B, const float* bia
     }
     return launch_gemm_x(p, 1, a_kmajor, b_kmajor, stream);
 }
-
-extern "C" int dldkd_gemm_f32x3_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                                        int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo, long sAi,
-                                        long sBo, long sBi, long sCo, long sCi, float alpha, void* stream) {
-    if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < 1 || batch_outer < 0 || batch_inner < 1) {
-        set_error("gemm_f32x3_batched: bad sizes");
-        return DLDKD_EINVAL;
-    }
-    const long batch = (long)batch_outer * batch_inner;
-    if (M == 0 || N == 0 || batch == 0) return DLDKD_OK;
-    if (batch > 65535) { set_error("gemm_f32x3_batched: batch %ld > 65535", batch); return DLDKD_EINVAL; }
-    if (!A || !B || !C) { set_error("gemm_f32x3_batched: null pointer"); return DLDKD_EINVAL; }
-    const bool al = !((sAo | sAi) & 3) && !(lda & 3) && !((uintptr_t)A & 15);
-    const bool bl = !((sBo | sBi) & 3) && !(ldb & 3) && !((uintptr_t)B & 15);
-    GemmXArgs p{A, B, nullptr, C, M, N, K, lda, ldb, ldc, 0, al, bl, batch_inner, sAo, sAi, sBo, sBi, sCo, sCi, alpha, 1, 0};
-    return launch_gemm_x(p, (int)batch, a_kmajor, b_kmajor, stream);
-}

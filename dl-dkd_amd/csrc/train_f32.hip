@@ -14,56 +14,6 @@
 
 namespace dldkd {
 
-// ---------------------------------------------------------------- softmax over the last dim (<= 128)
-// rows = N*H*Lq; row r belongs to sequence r / (H*Lq); P = softmax(S*scale + (1-keymask)*-1e4), in place.
-__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float* __restrict__ S, const float* __restrict__ keymask,
-                                                               long rows, int L, int rows_per_seq, float scale) {
-    const int lane = threadIdx.x & 63;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    float* row = S + r * L;
-    const float* km = keymask ? keymask + (r / rows_per_seq) * L : nullptr;
-    float v[2];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = -INFINITY;
-        if (c < L) {
-            v[i] = row[c] * scale + (km ? (1.f - km[c]) * -10000.f : 0.f);
-            mx = fmaxf(mx, v[i]);
-        }
-    }
-    mx = wave_max(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { v[i] = (lane + 64 * i < L) ? expf(v[i] - mx) : 0.f; sum += v[i]; }
-    const float inv = 1.f / wave_sum(sum);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) if (lane + 64 * i < L) row[lane + 64 * i] = v[i] * inv;
-}
-
-// dS = scale * P * (dP - sum(dP * P)), written over dP
-__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, long rows,
-                                                               int L, float scale) {
-    const int lane = threadIdx.x & 63;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const float* p = P + r * L;
-    float* d = dP + r * L;
-    float pv[2], dv[2], dot = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = lane + 64 * i;
-        pv[i] = c < L ? p[c] : 0.f;
-        dv[i] = c < L ? d[c] : 0.f;
-        dot += pv[i] * dv[i];
-    }
-    dot = wave_sum(dot);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) if (lane + 64 * i < L) d[lane + 64 * i] = scale * pv[i] * (dv[i] - dot);
-}
-
 // ---------------------------------------------------------------- LayerNorm backward
 // y = (x+add - mean) * rstd * gamma + beta.  dx (optional) = rstd * (g - mean(g) - xhat * mean(g * xhat)),
 // g = dy * gamma; dgamma += dy * xhat, dbeta += dy (atomics, one per column per workgroup).
@@ -220,17 +170,6 @@ __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, c
 // Philox4x32-10 (Salmon et al., SC'11) keyed by `seed`, counter = (offset + i/4): four 32-bit draws per call, one
 // per element of a float4.  keep[i] = u32 >= p * 2^32;  out = keep ? x * scale : 0.  The byte mask is what the
 // backward pass re-reads (1 B/element instead of a 4 B float mask + a separate multiply kernel).
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
-                                              unsigned (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
-        c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           unsigned char* __restrict__ keep, long n, unsigned thresh, float scale,
                                                           unsigned long long seed, unsigned long long offset,
@@ -391,18 +330,6 @@ using namespace dldkd;
 
 extern "C" {
 
-int dldkd_softmax_rows_fwd_f32(float* S, const float* keymask, long rows, int L, int rows_per_seq, float scale, void* stream) {
-    if (rows < 0 || L < 1 || L > 128 || rows_per_seq < 1) { set_error("softmax_rows_fwd: bad sizes"); return DLDKD_EINVAL; }
-    if (rows == 0) return DLDKD_OK;
-    LAUNCH1D(softmax_rows_fwd_kernel, rows, 4, S, keymask, rows, L, rows_per_seq, scale);
-    return check_launch("softmax_rows_fwd");
-}
-int dldkd_softmax_rows_bwd_f32(const float* P, float* dP, long rows, int L, float scale, void* stream) {
-    if (rows < 0 || L < 1 || L > 128) { set_error("softmax_rows_bwd: bad sizes"); return DLDKD_EINVAL; }
-    if (rows == 0) return DLDKD_OK;
-    LAUNCH1D(softmax_rows_bwd_kernel, rows, 4, P, dP, rows, L, scale);
-    return check_launch("softmax_rows_bwd");
-}
 int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* dy, float* dx,
                             float* dgamma, float* dbeta, long M, int D, float eps, void* stream) {
     if (M < 0 || D < 4 || (D & 3) || D > 4096) { set_error("layernorm_bwd: bad sizes"); return DLDKD_EINVAL; }

@@ -66,12 +66,24 @@ def all_reduce_flat(flat, group=None):
     flat.div_(dist.get_world_size(group))
 
 
-def sync_gradients(fp, group=None):
+def sync_gradients(fp, group=None, comm_stream=None):
     """The collective half of the data-parallel step (what DDP adds to method/train.py:141-151): gather whatever autograd left
     in p.grad into the flat buffer (parameters without a gradient contribute zeros), mean all-reduce it, and leave every
-    p.grad pointing at its slice.  `fp` is an optimization.FlatParams; pure torch, so it runs on CPU tensors with gloo."""
+    p.grad pointing at its slice.  `fp` is an optimization.FlatParams; pure torch, so it runs on CPU tensors with gloo.
+
+    comm_stream (GPU): issue the collective from that stream, fenced both ways against the current one.  Recent torch runs
+    a blocking collective ON the issuing stream and its watchdog thread keeps polling the collective's completion event; if
+    the issuing stream later starts a hipGraph capture (train.GraphedTrainStep captures on its own stream) the poll fails
+    with hipErrorCapturedEvent and the watchdog takes the process down - so collectives stay off streams that capture."""
     fp.rebind_grads()
-    all_reduce_flat(fp.grad, group)
+    if comm_stream is not None:
+        cur = torch.cuda.current_stream(fp.grad.device)
+        comm_stream.wait_stream(cur)
+        with torch.cuda.stream(comm_stream):
+            all_reduce_flat(fp.grad, group)
+        cur.wait_stream(comm_stream)
+    else:
+        all_reduce_flat(fp.grad, group)
     # after the mean every parameter HAS a gradient on every rank (zeros included): the replicas must take the same
     # optimizer step, so the local "grad was None" flags no longer apply
     fp._had = tuple(True for _ in fp.params)

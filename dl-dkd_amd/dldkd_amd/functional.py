@@ -188,61 +188,32 @@ def dropout(x, p, training):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def _bgemm(A, B, C, M, N, K, lda, ldb, ldc, ak, bk, n_seq, sA, sB, sC, alpha=1.0):
-    """per-(sequence, head) product; s? = (outer stride, inner stride) in elements."""
-    fn = ops._gemm_fn(_L(), batched=True)
-    native.check(fn(A, B, C, M, N, K, lda, ldb, ldc, int(ak), int(bk), n_seq, HEADS,
-                    sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], float(alpha), _s()), "gemm_batched")
-
-
-def _off(t, elems):
-    import ctypes
-    return ctypes.c_void_p(t.data_ptr() + 4 * elems)
-
-
 class _AttentionTrain(Function):
-    """Training form of BertSelfAttention (model_components.py:398-436): batched GEMMs + row softmax, keeping
-    the probabilities for the backward pass.  qkv (N, L, 1152); returns the context layer (N, L, 384)."""
+    """Training form of BertSelfAttention (model_components.py:398-436), fused (attention_train.hip): one forward kernel
+    (probabilities saved, dropout in registers) and two backward kernels instead of six batched GEMMs + row softmax
+    fwd/bwd + dropout fwd/bwd.  qkv (N, L, 1152); returns the context layer (N, L, 384)."""
 
     @staticmethod
     def forward(ctx, qkv, mask, p_drop):
         N, L = qkv.shape[0], qkv.shape[1]
         P = torch.empty(N, HEADS, L, L, dtype=torch.float32, device=qkv.device)
-        sq = (L * 3 * HIDDEN, DH)
-        # S[q, key] = Q[q,:] . K[key,:]
-        _bgemm(_off(qkv, 0), _off(qkv, HIDDEN), _p(P), L, L, DH, 3 * HIDDEN, 3 * HIDDEN, L, 0, 0, N, sq, sq, (HEADS * L * L, L * L))
-        native.check(_L().dldkd_softmax_rows_fwd_f32(_p(P), _p(mask), N * HEADS * L, L, HEADS * L, 1.0 / math.sqrt(DH), _s()),
-                     "softmax_rows_fwd")
-        Pd, keep = P, None
-        if p_drop > 0.0:
-            Pd, keep = _dropout_fwd(P, p_drop)
         out = torch.empty(N, L, HIDDEN, dtype=torch.float32, device=qkv.device)
-        # ctx[q, d] = sum_key Pd[q,key] V[key,d]
-        _bgemm(_p(Pd), _off(qkv, 2 * HIDDEN), _p(out), L, DH, L, L, 3 * HIDDEN, HIDDEN, 0, 1, N, (HEADS * L * L, L * L), sq, (L * HIDDEN, DH))
-        ctx.save_for_backward(qkv, P, Pd if keep is not None else None, keep)
-        ctx.drop_scale = 1.0 / (1.0 - p_drop)
+        seed, off, state = _philox_slot(qkv.device, P.numel()) if p_drop > 0.0 else (0, 0, None)
+        native.check(_L().dldkd_attention_train_fwd_f32(_p(qkv), _p(mask), _p(P), _p(out), N, L, float(p_drop), seed, off, state,
+                                                        _s()), "attention_train_fwd")
+        ctx.save_for_backward(qkv, P)
+        ctx.rng = (float(p_drop), seed, off, state, _philox_step.dev if _philox_step is not None else None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, P, Pd, keep = ctx.saved_tensors
+        qkv, P = ctx.saved_tensors
+        p_drop, seed, off, state, _keep_alive = ctx.rng
         N, L = qkv.shape[0], qkv.shape[1]
-        dout = _f32(dout)
         dqkv = torch.empty_like(qkv)
-        sq, sp, so = (L * 3 * HIDDEN, DH), (HEADS * L * L, L * L), (L * HIDDEN, DH)
-        Puse = Pd if Pd is not None else P
-        # dV[key, d] = sum_q Pd[q,key] dout[q,d]
-        _bgemm(_p(Puse), _p(dout), _off(dqkv, 2 * HIDDEN), L, DH, L, L, HIDDEN, 3 * HIDDEN, 1, 1, N, sp, so, sq)
-        # dPd[q, key] = sum_d dout[q,d] V[key,d]
-        dP = torch.empty_like(P)
-        _bgemm(_p(dout), _off(qkv, 2 * HIDDEN), _p(dP), L, L, DH, HIDDEN, 3 * HIDDEN, L, 0, 0, N, so, sq, sp)
-        if keep is not None:
-            native.check(_L().dldkd_mask_scale_f32(_p(dP), _p(keep), ctx.drop_scale, _p(dP), dP.numel(), _s()), "mask_scale")
-        scale = 1.0 / math.sqrt(DH)
-        native.check(_L().dldkd_softmax_rows_bwd_f32(_p(P), _p(dP), N * HEADS * L, L, scale, _s()), "softmax_rows_bwd")
-        # dQ[q, d] = sum_key dS[q,key] K[key,d] ;  dK[key, d] = sum_q dS[q,key] Q[q,d]
-        _bgemm(_p(dP), _off(qkv, HIDDEN), _off(dqkv, 0), L, DH, L, L, 3 * HIDDEN, 3 * HIDDEN, 0, 1, N, sp, sq, sq)
-        _bgemm(_p(dP), _off(qkv, 0), _off(dqkv, HIDDEN), L, DH, L, L, 3 * HIDDEN, 3 * HIDDEN, 1, 1, N, sp, sq, sq)
+        dS = torch.empty_like(P)
+        native.check(_L().dldkd_attention_train_bwd_f32(_p(qkv), _p(_f32(dout)), _p(P), _p(dS), _p(dqkv), N, L, p_drop, seed, off,
+                                                        state, _s()), "attention_train_bwd")
         return dqkv, None, None
 
 
@@ -251,8 +222,6 @@ def attention(qkv, mask, p_drop=0.0, training=False):
     mask = _f32(mask) if mask is not None else None
     if _needs_grad(qkv) or (training and p_drop > 0.0):
         N, L = qkv.shape[0], qkv.shape[1]
-        if N * HEADS > 65535:
-            raise native.NativeError("training attention: at most 16383 sequences per call")
         return _AttentionTrain.apply(qkv, mask, float(p_drop) if training else 0.0)
     return ops.attention(qkv, mask)
 

@@ -45,11 +45,6 @@ SIGNATURES = {
     "dldkd_simpool_rank_partials": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p, _c_void_p,
                                               _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_rank_gt": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
-    "dldkd_gemm_f32_batched": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                         _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_float,
-                                         _c_void_p]),
-    "dldkd_softmax_rows_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_float, _c_void_p]),
-    "dldkd_softmax_rows_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_float, _c_void_p]),
     "dldkd_layernorm_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                           _c_long, _c_int, _c_float, _c_void_p]),
     "dldkd_colsum_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_long, _c_void_p]),
@@ -69,6 +64,10 @@ SIGNATURES = {
     "dldkd_triplet_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_float, _c_int, _c_int, _c_void_p,
                                     _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_sum_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p]),
+    "dldkd_attention_train_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float, ctypes.c_uint64,
+                                                ctypes.c_uint64, _c_void_p, _c_void_p]),
+    "dldkd_attention_train_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float,
+                                                ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p]),
     "dldkd_row_invnorm_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
     "dldkd_simpool_train_fwd_f32": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
                                               _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
@@ -97,14 +96,8 @@ SIGNATURES = {
     "dldkd_mask_scale_f32": (_c_int, [_c_void_p, _c_void_p, _c_float, _c_void_p, _c_long, _c_void_p]),
     "dldkd_gemm_f32x3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                          _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
-    "dldkd_gemm_f32x3_batched": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                           _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_float,
-                                           _c_void_p]),
     "dldkd_gemm_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                          _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
-    "dldkd_gemm_bf16_batched": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                          _c_int, _c_int, _c_int, _c_long, _c_long, _c_long, _c_long, _c_long, _c_long, _c_float,
-                                          _c_void_p]),
 }
 
 _lib = None

@@ -42,13 +42,12 @@ def gemm_precision():
     return _PRECISION
 
 
-def _gemm_fn(L, batched=False):
-    sfx = "_batched" if batched else ""
+def _gemm_fn(L):
     if _PRECISION == "bf16":
-        return getattr(L, "dldkd_gemm_bf16" + sfx)
+        return L.dldkd_gemm_bf16
     if _PRECISION in ("fp32", "fp32x3"):      # fp32-grade on the bf16 matrix cores (three-plane split), the default
-        return getattr(L, "dldkd_gemm_f32x3" + sfx)
-    return getattr(L, "dldkd_gemm_f32" + sfx)   # "fp32_exact": the true fp32-input MFMA
+        return L.dldkd_gemm_f32x3
+    return L.dldkd_gemm_f32                     # "fp32_exact": the true fp32-input MFMA
 
 
 _PREC_ID = {"fp32_exact": 0, "fp32": 1, "fp32x3": 1, "bf16": 2}     # DLDKD_GEMM_F32 / _F32X3 / _BF16

@@ -84,16 +84,17 @@ def dist_info():
     return 0, 1
 
 
-def train_step(model, batch, optimizer, opt):
+def train_step(model, batch, optimizer, opt, comm_stream=None):
     """zero_grad / forward / backward / [gradient all-reduce] / [global clip] / step (train.py:141-151).
     Returns (loss, loss_dict).  `optimizer` needs zero_grad(), step() and - for the data-parallel branch - `.fp`
-    (optimization.FlatParams): nothing here is GPU-specific, the CPU tests drive it with a toy model over gloo."""
+    (optimization.FlatParams): nothing here is GPU-specific, the CPU tests drive it with a toy model over gloo.
+    comm_stream: see dist.sync_gradients."""
     optimizer.zero_grad()
     loss, loss_dict = model(batch)
     loss.backward()
     if dist_info()[1] >= DDP_MIN_WORLD:
         from . import dist as ddist
-        ddist.sync_gradients(optimizer.fp)
+        ddist.sync_gradients(optimizer.fp, comm_stream=comm_stream)
     if getattr(opt, "grad_clip", -1) != -1:
         torch.nn.utils.clip_grad_norm_(model.parameters(), opt.grad_clip)
     optimizer.step()
@@ -136,6 +137,7 @@ class GraphedTrainStep:
         # still holds) would pull the default stream into a later capture on another stream through the engine's
         # cross-stream event, and hipStreamEndCapture then dies on the unjoined stream (seen as a segfault).
         self.stream = None
+        self.comm_stream = None      # gradient all-reduce: never on a stream that captures (dist.sync_gradients)
 
     # -- what is baked into a graph
     def _key(self, batch):
@@ -151,6 +153,7 @@ class GraphedTrainStep:
         dev = batch["student_videos"].device
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=dev)
+            self.comm_stream = torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
@@ -160,7 +163,7 @@ class GraphedTrainStep:
 
     def _eager(self, batch):
         self.eager_steps += 1
-        loss, d = train_step(self.model, batch, self.optimizer, self.opt)
+        loss, d = train_step(self.model, batch, self.optimizer, self.opt, comm_stream=self.comm_stream)
         # detached, like the replayed steps' outputs: the backward pass is over, nothing should keep the tape alive
         return loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in d.items()}
 
@@ -170,6 +173,8 @@ class GraphedTrainStep:
         key = self._key(batch)
         e = self.graphs.get(key)
         if e is None:
+            if len(self.seen) > 4096:                     # data whose every batch has its own signature: stay eager, stay small
+                self.seen.clear()
             self.seen[key] = self.seen.get(key, 0) + 1
             if self.seen[key] < 2:                        # first sight: eager (also loads every kernel the graph needs)
                 return self._eager(batch)
@@ -216,7 +221,11 @@ class GraphedTrainStep:
         try:
             opt_.zero_grad()
             e.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(e.graph, stream=self.stream):           # self.stream is the current stream (__call__)
+            # thread_local: only THIS thread's unsafe calls fail while the capture is open.  In the default "global" mode every
+            # thread's do - and RCCL's watchdog thread polls its events with hipEventQuery all the time: it then dies on
+            # hipErrorStreamCaptureUnsupported and the process aborts at destroy_process_group (seen one run in two).
+            # Kernels the autograd thread launches into the capturing stream are captured in either mode.
+            with torch.cuda.graph(e.graph, stream=self.stream, capture_error_mode="thread_local"):
                 loss, parts = m.forward_tensors(e.static, staged=e)
                 loss.backward()
                 if e.ddp:
@@ -256,7 +265,7 @@ class GraphedTrainStep:
         e.graph.replay()
         if e.ddp:
             from . import dist as ddist
-            ddist.sync_gradients(opt_.fp)
+            ddist.sync_gradients(opt_.fp, comm_stream=self.comm_stream)
             opt_.enqueue(upload_lr=False)
         ops.bump_param_epoch()
         self.replays += 1
@@ -308,7 +317,7 @@ def _train_epoch(model, train_loader, optimizer, opt, epoch_i, training=True, st
     if belta is not None:
         model.belta = belta
     logger.info(f"Epoch {epoch_i}, Alpha: {model.alpha}, belta: {model.belta}")
-    sums, n = {}, 0
+    keys, acc, n = None, None, 0
     for batch_idx, batch in enumerate(train_loader):
         batch = {k: (v.to(opt.device, non_blocking=True) if k != "text_labels" else v) for k, v in batch.items()}
         if training:
@@ -316,12 +325,19 @@ def _train_epoch(model, train_loader, optimizer, opt, epoch_i, training=True, st
         else:
             with torch.no_grad():
                 _, loss_dict = model(batch)
-        for k, v in loss_dict.items():
-            sums[k] = sums.get(k, 0.0) + float(v.detach() if torch.is_tensor(v) else v)
+        # running sums stay on the device (one stack + one add per step): the reference reads 7 scalars back per step
+        # (train.py:153-157), i.e. 7 host synchronisations; here the host reads once per epoch
+        keys = keys or list(loss_dict)
+        dev = torch.device(opt.device)
+        vec = torch.stack([(loss_dict[k].detach().float() if torch.is_tensor(loss_dict[k])
+                            else torch.tensor(float(loss_dict[k]), device=dev)).reshape(()).to(dev) for k in keys])
+        acc = vec if acc is None else acc + vec
         n += 1
         if getattr(opt, "debug", False) and batch_idx == 3:
             break
-    return {k: v / max(n, 1) for k, v in sums.items()}
+    if acc is None:
+        return {}
+    return {k: float(v) / max(n, 1) for k, v in zip(keys, acc.cpu().tolist())}
 
 
 def save_checkpoint(model, epoch_i, path):
@@ -351,10 +367,15 @@ def train(model, train_dataset, val_video_dataset, val_text_dataset, opt):
         seed_rank(opt, rank)
     best, es_cnt = 0.0, 0
     history = []
+    # the step replayed from a hipGraph (GraphedTrainStep) unless opt.graph_step is False or the model is not on a GPU;
+    # float(loss) per step is deferred: train_epoch reads the loss sums back once per epoch
+    stepper = None
+    if getattr(opt, "graph_step", True) and torch.device(opt.device).type == "cuda":
+        stepper = GraphedTrainStep(model, optimizer, opt, defer_loss_float=True)
     for epoch_i in range(-1 if getattr(opt, "eval_untrained", False) else 0, opt.n_epoch):
         if loader.sampler is not None and hasattr(loader.sampler, "set_epoch"):
             loader.sampler.set_epoch(max(epoch_i, 0))
-        losses = train_epoch(model, loader, optimizer, opt, epoch_i, training=True) if epoch_i > -1 else {}
+        losses = train_epoch(model, loader, optimizer, opt, epoch_i, training=True, stepper=stepper) if epoch_i > -1 else {}
         with torch.no_grad():
             # sharded eval: every rank encodes 1/world of the gallery; its SumR is the same number on every rank
             rsum = (eval_epoch_sharded if world > 1 else eval_epoch)(model, val_video_dataset, val_text_dataset, opt)

@@ -201,44 +201,25 @@ int dldkd_linear_rows_bf16(const float* x, const void* Wfrag, const float* bb, v
 
 /* ---------------------------------------------------------------------------------------------
  * Training path, fp32 (DLDKD.forward + backward, method/model.py:100-197,353-387;
- * method/model_components.py:106-234).  Heavy contractions = dldkd_gemm_f32{,_batched}; the rest is
+ * method/model_components.py:106-234).  Heavy contractions = dldkd_gemm_f32 / _f32x3 / _bf16; the rest is
  * row-wise.  "d*" pointers are gradients; functions documented "+=" accumulate into zero-initialised or
  * partially filled buffers.
  * ------------------------------------------------------------------------------------------- */
 
-/* Strided-batched form of dldkd_gemm_f32 (no bias/relu): for z = zo * batch_inner + zi,
- * C_z = alpha * A_z B_z^T-style product with operand offsets zo * s?o + zi * s?i (elements).  Used for the
- * per-(sequence, head) products of attention forward/backward (model_components.py:417,432). */
-int dldkd_gemm_f32_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
-                           int ldc, int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo,
-                           long sAi, long sBo, long sBi, long sCo, long sCi, float alpha, void* stream);
-
-/* Throughput-mode twins of dldkd_gemm_f32 / dldkd_gemm_f32_batched: same arguments and operand layouts, fp32
+/* Throughput-mode twin of dldkd_gemm_f32: same arguments and operand layouts, fp32
  * operands in memory converted to bf16 on the way to LDS, bf16 MFMA with fp32 accumulation.  Used by the training
  * step when the precision is set to "bf16" (BASELINE.json configs[2]); the fp32 entry points remain the parity path. */
 int dldkd_gemm_bf16(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
                     int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes, void* stream);
-int dldkd_gemm_bf16_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                            int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo, long sAi, long sBo,
-                            long sBi, long sCo, long sCi, float alpha, void* stream);
 
 /* fp32-GRADE GEMM on the bf16 matrix cores: each fp32 operand is split into three bf16 planes (h + m + l = 24 mantissa
  * bits) on the way to LDS and every product is rebuilt from the six plane products of order <= 2 with fp32 accumulation
- * (relative error ~2^-24 per product, like a true fp32 multiply).  Same arguments as dldkd_gemm_f32[_batched].  6 bf16
+ * (relative error ~2^-24 per product, like a true fp32 multiply).  Same arguments as dldkd_gemm_f32.  6 bf16
  * MFMAs replace 8 fp32-input MFMAs that each run 2x slower: ~3x the throughput of dldkd_gemm_f32 at parity-grade
  * accuracy; the host mirror uses it for precision "fp32" and keeps the true fp32-input MFMA as "fp32_exact". */
 int dldkd_gemm_f32x3(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
                      int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes, void* stream);
-int dldkd_gemm_f32x3_batched(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                             int a_kmajor, int b_kmajor, int batch_outer, int batch_inner, long sAo, long sAi, long sBo,
-                             long sBi, long sCo, long sCi, float alpha, void* stream);
 
-/* P = softmax(S * scale + (1 - keymask) * -10000) over the last dim L <= 128, in place; row r uses
- * keymask[r / rows_per_seq] (model_components.py:419-426).  keymask may be NULL. */
-int dldkd_softmax_rows_fwd_f32(float* S, const float* keymask, long rows, int L, int rows_per_seq, float scale,
-                               void* stream);
-/* dS = scale * P * (dP - sum(dP * P)), written over dP. */
-int dldkd_softmax_rows_bwd_f32(const float* P, float* dP, long rows, int L, float scale, void* stream);
 
 /* Backward of dldkd_layernorm_f32: dx (may be NULL) for the summed input; dgamma += , dbeta += . */
 int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* dy,
@@ -308,6 +289,22 @@ int dldkd_nce_f32(const float* S, const float* T, const int32_t* labels, const f
  * dC (may be NULL) += g * dloss/dC. */
 int dldkd_triplet_f32(const float* C, const int32_t* labels, const int32_t* r_t2v, const int32_t* r_v2t, int hard,
                       float margin, int nq, int nv, float* terms, float* dC, const float* g, void* stream);
+
+/* Training form of BertSelfAttention.forward (model_components.py:398-436), fused: forward with dropout on the attention
+ * probabilities, and its backward, for N sequences of L <= 128 tokens, 4 heads x 96, exact fp32 products (fp32-input MFMA).
+ *   fwd: qkv (N, L, 1152), mask (N, L) 0/1 or NULL -> probs (N, 4, L, L) = softmax(QK^T / sqrt(96) + (1 - mask) * -10000)
+ *        BEFORE dropout (saved for the backward pass), out (N, L, 384) = dropout(probs) V.
+ *   bwd: dout (N, L, 384) -> dqkv (N, L, 1152) (written in full); dS (N, 4, L, L) is scratch; probs is OVERWRITTEN with the
+ *        dropped probabilities (a saved tensor of a graph that is walked once).
+ * Dropout: keep iff Philox4x32-10(seed, offset + idx / 4)[idx % 4] >= p * 2^32 on the flat index of probs - the masks
+ * dldkd_dropout_fwd_f32 would draw for that tensor with the same (seed, offset); p_drop = 0 disables it.  state: NULL or
+ * device {seed, base offset} as in dldkd_dropout_fwd_f32 (hipGraph-captured step). */
+int dldkd_attention_train_fwd_f32(const float* qkv, const float* mask, float* probs, float* out, int N, int L, float p_drop,
+                                  unsigned long long seed, unsigned long long offset, const unsigned long long* state,
+                                  void* stream);
+int dldkd_attention_train_bwd_f32(const float* qkv, const float* dout, float* probs, float* dS, float* dqkv, int N, int L,
+                                  float p_drop, unsigned long long seed, unsigned long long offset,
+                                  const unsigned long long* state, void* stream);
 
 /* Training-side simpool: for one (query set, gallery) pair of DLDKD.forward (model.py:113-129) everything the losses read
  * of get_sim_scores (model.py:307-329) and get_unnormalized_sim_scores (model.py:331-350), from ONE raw product

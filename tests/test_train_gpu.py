@@ -384,6 +384,42 @@ def test_fused_training_simpool_vs_fp64(prec, tol, gtol, nq, nv, L, D):
             assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.98
 
 
+@pytest.mark.parametrize("N,L,p_drop", [(6, 40, 0.0), (5, 128, 0.2), (9, 30, 0.15), (3, 1, 0.0), (4, 97, 0.3), (130, 32, 0.1)])
+def test_fused_training_attention_vs_fp64(N, L, p_drop):
+    """attention_train.hip (one forward kernel, two backward kernels, exact fp32 MFMA products) against the reference math of
+    BertSelfAttention.forward (model_components.py:398-436) in fp64 autograd, with the dropout mask taken from the standalone
+    dropout kernel on a tensor of the probabilities' shape at the same Philox (seed, offset) - the fused kernels must draw
+    exactly those keep bits (also when L is not a multiple of 4 and a Philox call straddles two rows)."""
+    from dldkd_amd import functional as F_
+    g = torch.Generator().manual_seed(N * 131 + L)
+    qkv = (torch.randn(N, L, 1152, generator=g) * 0.5)
+    mask = torch.ones(N, L)
+    if L > 3:
+        mask[0, L // 2:] = 0
+        mask[N - 1, L - 1:] = 0
+    w = torch.randn(N, L, 384, generator=g)
+    torch.manual_seed(1234)
+    keep = torch.ones(N, 4, L, L)
+    if p_drop > 0:
+        _, kb = F_._dropout_fwd(torch.ones(N, 4, L, L, device=DEV), p_drop)      # the unfused kernel's mask for this slot
+        keep = kb.float().cpu()
+    q64 = qkv.double().requires_grad_()
+    x = q64.view(N, L, 3, 4, 96)
+    Q, K, V = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))                  # (N, 4, L, 96)
+    S = Q @ K.transpose(-1, -2) / 96 ** 0.5 + ((1.0 - mask.double()) * -10000.0)[:, None, None, :]
+    P = torch.softmax(S, -1)
+    Pd = P * keep.double() / (1.0 - p_drop)
+    ref = (Pd @ V).permute(0, 2, 1, 3).reshape(N, L, 384)
+    (ref * w.double()).sum().backward()
+    torch.manual_seed(1234)                                                        # same generator slot as the mask above
+    a = qkv.to(DEV).requires_grad_()
+    out = F_.attention(a, mask.to(DEV), p_drop, True)
+    (out * w.to(DEV)).sum().backward()
+    sc = ref.detach().abs().max().item()
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 3e-6 * max(1.0, sc)
+    _gclose(a.grad, q64.grad, 2e-5)
+
+
 def test_loss_kernels_fuzz_vs_oracle():
     """Random batch structures (2..40 videos, 1..4 captions each, 1..48 clips, random alpha/beta, both negative
     modes) through every loss kernel: value 1e-4 and gradient 2e-3 against the fp64 oracle."""

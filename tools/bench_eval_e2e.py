@@ -73,6 +73,7 @@ def stage_times(nv=21793, nq=10895, mode="fp32", dev="cuda:0", B=None):
             fused, s0, s1 = m.pooled_scores(qs, pg, want_branches=True)
             t1 = sync()
             out["scoring_3_matrices_s"] = t1 - t0
+            m3 = t1 - t0
             gt = {q: [q % nv] for q in range(nq)}
             ev.gt_ranks_gpu(fused, gt)
             t0 = sync()
@@ -82,7 +83,23 @@ def stage_times(nv=21793, nq=10895, mode="fp32", dev="cuda:0", B=None):
                 rb.cpu(), rf.cpu()
             t1 = sync()
             out["ranking_3_matrices_s"] = t1 - t0
+            r3 = t1 - t0
+            # what eval_epoch runs since round 2: scorer partial planes -> ranks of all three score kinds in one pass over
+            # the planes (no (Nq, Nv) matrix written or read), ranks to the host
+            pq = scoring.pack_queries(qs)
+            ws = scoring.simpool_partials(pq, pg)
+            scoring.rank_partials(ws, pq, pg, csr[0], csr[1])
+            t0 = sync()
+            pq = scoring.pack_queries(qs)
+            ws = scoring.simpool_partials(pq, pg, ws)
+            t1 = sync()
+            ranks = scoring.rank_partials(ws, pq, pg, csr[0], csr[1]).cpu()
+            t2 = sync()
+            out["scoring_partials_only_s"] = t1 - t0
+            out["ranking_from_partials_s"] = t2 - t1
+            del out["scoring_3_matrices_s"], out["ranking_3_matrices_s"]
             out["total_s"] = sum(v for k, v in out.items() if k.endswith("_s"))
+            out["matrix_path"] = {"scoring_3_matrices": m3, "ranking_3_matrices": r3}       # round-1 path, kept for comparison
     finally:
         ops.set_gemm_precision("fp32")
     return out
