@@ -55,10 +55,13 @@ struct SimpoolBwdArgs {
     int nq, nv, L, D;
 };
 
-// dq: one workgroup (128 threads x float4 = up to 512 columns) per query.  The 2 nv (+ len) gathered rows have addresses that
-// depend only on the index arrays, so the unrolled loop keeps several L2 round trips in flight.
-__global__ __launch_bounds__(128) void simpool_bwd_dq_kernel(const SimpoolBwdArgs p) {
-    const int n = blockIdx.x, t = threadIdx.x, c = 4 * t;
+// dq: one workgroup per query: 4 groups of 128 threads (x float4 = up to 512 columns) split the 2 nv (+ len) gathered rows
+// between them (every gather is an L2 round trip whose address depends only on the index arrays: four independent chains,
+// each unrolled by 4), then one LDS reduction.
+constexpr int kDqGroups = 4;
+__global__ __launch_bounds__(128 * kDqGroups) void simpool_bwd_dq_kernel(const SimpoolBwdArgs p) {
+    __shared__ float red[kDqGroups][516];
+    const int n = blockIdx.x, grp = threadIdx.x >> 7, t = threadIdx.x & 127, c = 4 * t;
     const bool act = c < p.D;
     const float rq = p.rq[n];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(128) void simpool_bwd_dq_kernel(const SimpoolBwdArg
         return act ? *reinterpret_cast<const f32x4*>(p.g + ((size_t)v * p.L + l) * p.D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
 #pragma unroll 4
-    for (int v = 0; v < p.nv; ++v) {
+    for (int v = grp; v < p.nv; v += kDqGroups) {
         const bool has = p.lens[v] > 0;                // a video without clips pooled to the constant -1e10: no gradient
         const float a = (p.d_raw && has) ? p.d_raw[rowq + v] : 0.f;
         const float b = (p.d_cos && has) ? p.d_cos[rowq + v] : 0.f;
@@ -81,14 +84,23 @@ __global__ __launch_bounds__(128) void simpool_bwd_dq_kernel(const SimpoolBwdArg
     if (p.d_clip) {
         const int v = p.labels[n], len = p.lens[v];
 #pragma unroll 4
-        for (int l = 0; l < len; ++l) {
+        for (int l = grp; l < len; l += kDqGroups) {
             const float e = p.d_clip[(size_t)n * p.L + l];
             const f32x4 x = grow(v, l);
             acc += (e * rq * p.rg[(size_t)v * p.L + l]) * x;
             proj += e * p.clip_pos[(size_t)n * p.L + l];
         }
     }
-    if (act) {
+    if (act) *reinterpret_cast<f32x4*>(&red[grp][c]) = acc;
+    if (t == 0) red[grp][512] = proj;
+    __syncthreads();
+    if (grp == 0 && act) {
+#pragma unroll
+        for (int g = 1; g < kDqGroups; ++g) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(&red[g][c]);
+            acc += o;
+        }
+        proj = red[0][512] + red[1][512] + red[2][512] + red[3][512];
         const f32x4 qv = *reinterpret_cast<const f32x4*>(p.q + (size_t)n * p.D + c);
         *reinterpret_cast<f32x4*>(p.dq + (size_t)n * p.D + c) = acc - (proj * rq * rq) * qv;
     }
@@ -101,8 +113,8 @@ __global__ __launch_bounds__(128) void simpool_bwd_dq_kernel(const SimpoolBwdArg
 //   contribution of query n to clip l:  a_nv q_n  (l = arg_raw)   +   b_nv rq_n rg_l q_n  (l = arg_cos)
 //                                       + e_nl rq_n rg_l q_n  (n a caption of this video, every l < len)
 //   and the projection  - rg_l^2 g_l * sum( b_nv cos_nv [l = arg_cos] + e_nl c_nl )
-constexpr int kDgCols = 128;
-__global__ __launch_bounds__(256) void simpool_bwd_dg_kernel(const SimpoolBwdArgs p) {
+constexpr int kDgCols = 128, kDgThreads = 1024, kDgWaves = kDgThreads / 64;
+__global__ __launch_bounds__(kDgThreads) void simpool_bwd_dg_kernel(const SimpoolBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int v = blockIdx.x, c0 = blockIdx.y * kDgCols, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = p.L, nq = p.nq, len = p.lens[v];
@@ -111,11 +123,11 @@ __global__ __launch_bounds__(256) void simpool_bwd_dg_kernel(const SimpoolBwdArg
     int* cnt = reinterpret_cast<int*>(bcos + nq);              // [L + 1]  bucket starts
     float* rowproj = reinterpret_cast<float*>(cnt + L + 1);    // [L]
     int* pos = reinterpret_cast<int*>(rowproj + L);            // [nq + 1] captions of this video, pos[nq] = their number
-    float2* ent = reinterpret_cast<float2*>(pos + nq + 1);     // [2 nq] (query, coefficient); word offset 6 nq + 2 L + 2: even
-    int* wcnt = reinterpret_cast<int*>(ent);                   // 4 ints of scratch for the ordered compaction below (ent is filled later)
+    int* wcnt = pos + nq + 1;                                  // [kDgWaves] scratch of the ordered compaction
+    float2* ent = reinterpret_cast<float2*>(wcnt + kDgWaves);  // [2 nq] (query, coefficient); word offset 6 nq + 2 L + 2 + 16: even
     if (tid == 0) pos[nq] = 0;
     __syncthreads();
-    for (int n0 = 0; n0 < nq; n0 += 256) {
+    for (int n0 = 0; n0 < nq; n0 += kDgThreads) {
         const int n = n0 + tid;
         bool mine = false;
         if (n < nq) {
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(256) void simpool_bwd_dg_kernel(const SimpoolBwdArg
             bcos[n] = b * p.pooled_cos[o];
             mine = p.d_clip != nullptr && len > 0 && p.labels[n] == v;
         }
-        // captions of this video, in query order: wave ballots + a 4-entry prefix (ordered, hence deterministic sums later)
+        // captions of this video, in query order: wave ballots + a per-wave prefix (ordered, hence deterministic sums later)
         const unsigned long long m = __ballot(mine);
         if (lane == 0) wcnt[wave] = __popcll(m);
         __syncthreads();
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(256) void simpool_bwd_dg_kernel(const SimpoolBwdArg
         for (int w = 0; w < wave; ++w) base += wcnt[w];
         if (mine) pos[base + __popcll(m & ((1ull << lane) - 1ull))] = n;
         __syncthreads();
-        if (tid == 0) pos[nq] += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        if (tid == 0) { int t = 0; for (int w = 0; w < kDgWaves; ++w) t += wcnt[w]; pos[nq] += t; }
         __syncthreads();
     }
     // counting sort by clip: thread l owns clip l (every thread reads the same sc word: an LDS broadcast)
@@ -170,7 +182,8 @@ __global__ __launch_bounds__(256) void simpool_bwd_dg_kernel(const SimpoolBwdArg
     const int c = c0 + 2 * lane;
     if (c >= p.D) return;
     const int np = pos[nq];
-    for (int l = wave; l < L; l += 4) {
+    // 16 waves, one clip row each at a time: the rows' gather chains (bucket entry -> query row, an L2 round trip) overlap
+    for (int l = wave; l < L; l += kDgWaves) {
         float2 acc = {0.f, 0.f};
         const size_t o = ((size_t)v * L + l) * p.D + c;
         if (l < len) {
@@ -248,13 +261,13 @@ int dldkd_simpool_train_bwd_f32(const float* q, const float* g, const float* rq,
     if (((uintptr_t)q | (uintptr_t)g | (uintptr_t)dq | (uintptr_t)dg) & 15) { set_error("simpool_train_bwd: unaligned buffer"); return DLDKD_EINVAL; }
     SimpoolBwdArgs p{q, g, rq, rg, lens, labels, arg_raw, arg_cos, pooled_cos, clip_pos, d_raw, d_cos, d_clip, dq, dg, nq, nv, L, D};
     hipStream_t s = (hipStream_t)stream;
-    if (dq) DLDKD_LAUNCH(simpool_bwd_dq_kernel, dim3(nq), dim3(128), 0, s, p);
+    if (dq) DLDKD_LAUNCH(simpool_bwd_dq_kernel, dim3(nq), dim3(128 * kDqGroups), 0, s, p);
     if (dg) {
-        const size_t lds = ((size_t)5 * nq + 2 * L + 2 + nq + 4 + (size_t)4 * nq) * sizeof(float);
+        const size_t lds = ((size_t)5 * nq + 2 * L + 2 + nq + 4 + kDgWaves + 2 + (size_t)4 * nq) * sizeof(float);
         if (lds > 160 * 1024) { set_error("simpool_train_bwd: %d queries need %zu bytes of LDS (max ~4000 queries per batch)", nq, lds); return DLDKD_EINVAL; }
         static const bool attr_ok = hipFuncSetAttribute((const void*)simpool_bwd_dg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         (void)attr_ok;
-        DLDKD_LAUNCH(simpool_bwd_dg_kernel, dim3(nv, (D + kDgCols - 1) / kDgCols), dim3(256), lds, s, p);
+        DLDKD_LAUNCH(simpool_bwd_dg_kernel, dim3(nv, (D + kDgCols - 1) / kDgCols), dim3(kDgThreads), lds, s, p);
     }
     return check_launch("simpool_train_bwd");
 }
