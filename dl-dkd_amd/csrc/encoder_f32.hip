@@ -20,10 +20,13 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                         int add_mod, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ out, long M,
-                                                        int D, float eps) {
+                                                        int D, float eps, unsigned char* __restrict__ keep, unsigned thresh,
+                                                        float dscale, unsigned long long seed, unsigned long long off,
+                                                        const unsigned long long* __restrict__ state) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
+    if (keep != nullptr && state != nullptr) { seed = state[0]; off += state[1]; }
     const int nv = D >> 2;
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
     const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (add_mod > 0 ? row % add_mod : row) * D) : nullptr;
@@ -61,6 +64,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            if (keep != nullptr) {      // fused inverted dropout on the normalised row: the masks dldkd_dropout_fwd_f32 would draw
+                const unsigned long long ctr = off + (unsigned long long)(row * nv + c);
+                unsigned rnd[4];
+                philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), rnd);
+                uchar4 k;
+                k.x = rnd[0] >= thresh; k.y = rnd[1] >= thresh; k.z = rnd[2] >= thresh; k.w = rnd[3] >= thresh;
+                o[0] = k.x ? o[0] * dscale : 0.f; o[1] = k.y ? o[1] * dscale : 0.f;
+                o[2] = k.z ? o[2] * dscale : 0.f; o[3] = k.w ? o[3] * dscale : 0.f;
+                reinterpret_cast<uchar4*>(keep + row * D)[c] = k;
+            }
             orow[c] = o;
         }
     }
@@ -251,10 +264,11 @@ using namespace dldkd;
 
 extern "C" {
 
-int dldkd_layernorm_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out,
-                        long M, int D, float eps, void* stream) {
-    if (M < 0 || D < 4 || (D & 3) || D > 4096 || add_mod < 0) {
-        set_error("layernorm: bad sizes M=%ld D=%d (D must be a multiple of 4, <= 4096)", M, D);
+static int launch_layernorm(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out,
+                            long M, int D, float eps, unsigned char* keep, float p_drop, unsigned long long seed,
+                            unsigned long long offset, const unsigned long long* state, void* stream) {
+    if (M < 0 || D < 4 || (D & 3) || D > 4096 || add_mod < 0 || !(p_drop >= 0.f && p_drop < 1.f)) {
+        set_error("layernorm: bad sizes M=%ld D=%d (D must be a multiple of 4, <= 4096) or p=%f", M, D, (double)p_drop);
         return DLDKD_EINVAL;
     }
     if (M == 0) return DLDKD_OK;
@@ -262,11 +276,26 @@ int dldkd_layernorm_f32(const float* x, const float* add, int add_mod, const flo
     const dim3 grid((unsigned)((M + 3) / 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int nv = (D / 4 + 63) / 64;
-    if (nv <= 2) DLDKD_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
-    else if (nv <= 4) DLDKD_LAUNCH(layernorm_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
-    else if (nv <= 8) DLDKD_LAUNCH(layernorm_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
-    else DLDKD_LAUNCH(layernorm_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps);
+    const double t = (double)p_drop * 4294967296.0;
+    const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    const float ds = 1.0f / (1.0f - p_drop);
+    if (nv <= 2) DLDKD_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state);
+    else if (nv <= 4) DLDKD_LAUNCH(layernorm_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state);
+    else if (nv <= 8) DLDKD_LAUNCH(layernorm_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state);
+    else DLDKD_LAUNCH(layernorm_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state);
     return check_launch("layernorm");
+}
+
+int dldkd_layernorm_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out,
+                        long M, int D, float eps, void* stream) {
+    return launch_layernorm(x, add, add_mod, gamma, beta, out, M, D, eps, nullptr, 0.f, 0, 0, nullptr, stream);
+}
+
+int dldkd_layernorm_dropout_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out,
+                                unsigned char* keep, long M, int D, float eps, float p_drop, unsigned long long seed,
+                                unsigned long long offset, const unsigned long long* state, void* stream) {
+    if (!keep || ((uintptr_t)keep & 3)) { set_error("layernorm_dropout: keep mask missing or unaligned"); return DLDKD_EINVAL; }
+    return launch_layernorm(x, add, add_mod, gamma, beta, out, M, D, eps, keep, p_drop, seed, offset, state, stream);
 }
 
 int dldkd_attention_fwd_f32(const float* qkv, const float* mask, float* out, int N, int L, void* stream) {

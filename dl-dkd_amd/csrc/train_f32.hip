@@ -25,7 +25,8 @@ __global__ __launch_bounds__(64 * WAVES) void layernorm_bwd_kernel(const float* 
                                                             int add_mod, const float* __restrict__ gamma,
                                                             const float* __restrict__ dy, float* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, long M,
-                                                            int D, float eps, int rows_per_wave) {
+                                                            int D, float eps, int rows_per_wave,
+                                                            const unsigned char* __restrict__ keep, float keep_scale) {
     const int lane = threadIdx.x & 63;
     const int nv = D >> 2;
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
@@ -48,6 +49,11 @@ __global__ __launch_bounds__(64 * WAVES) void layernorm_bwd_kernel(const float* 
                 v[i] = xr[c];
                 if (ar) { const f32x4 a = ar[c]; v[i] += a; }
                 d[i] = dyr[c];
+                if (keep != nullptr) {      // the forward pass dropped the normalised row (dldkd_layernorm_dropout_f32): mask dy first
+                    const uchar4 k = reinterpret_cast<const uchar4*>(keep + row * D)[c];
+                    d[i][0] = k.x ? d[i][0] * keep_scale : 0.f; d[i][1] = k.y ? d[i][1] * keep_scale : 0.f;
+                    d[i][2] = k.z ? d[i][2] * keep_scale : 0.f; d[i][3] = k.w ? d[i][3] * keep_scale : 0.f;
+                }
                 s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
             }
         }
@@ -331,7 +337,8 @@ using namespace dldkd;
 extern "C" {
 
 int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* dy, float* dx,
-                            float* dgamma, float* dbeta, long M, int D, float eps, void* stream) {
+                            float* dgamma, float* dbeta, long M, int D, float eps, const unsigned char* keep, float keep_scale,
+                            void* stream) {
     if (M < 0 || D < 4 || (D & 3) || D > 4096) { set_error("layernorm_bwd: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0) return DLDKD_OK;
     if (!x || !gamma || !dy || !dgamma || !dbeta) { set_error("layernorm_bwd: null pointer"); return DLDKD_EINVAL; }
@@ -340,7 +347,7 @@ int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const
     if (nv <= 2) {           // 16 waves x 4 rows per workgroup
         const long waves = (M + 3) / 4;
         DLDKD_LAUNCH((layernorm_bwd_kernel<2, 16>), dim3((unsigned)((waves + 15) / 16)), dim3(1024), (size_t)32 * D * sizeof(float), s,
-                           x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, 4);
+                           x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, 4, keep, keep_scale);
         return check_launch("layernorm_bwd");
     }
     const int rpw = 8;       // 4 waves x 8 rows
@@ -351,9 +358,9 @@ int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const
         return hipFuncSetAttribute((const void*)layernorm_bwd_kernel<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4096 * 4) == hipSuccess;
     }();
     (void)attr_ok;
-    if (nv <= 4) DLDKD_LAUNCH((layernorm_bwd_kernel<4, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    if (nv <= 4) DLDKD_LAUNCH((layernorm_bwd_kernel<4, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw, keep, keep_scale);
     // (no MAXV = 8 instantiation: hipcc spilled 248 registers in it; rows of 1028..2048 floats use the 16-wide form)
-    else DLDKD_LAUNCH((layernorm_bwd_kernel<16, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw);
+    else DLDKD_LAUNCH((layernorm_bwd_kernel<16, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw, keep, keep_scale);
     return check_launch("layernorm_bwd");
 }
 int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream) {

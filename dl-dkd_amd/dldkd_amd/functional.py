@@ -84,8 +84,10 @@ class _LayerNorm(Function):
         dx = torch.empty_like(x) if need_dx else None
         dgb = torch.zeros(2, D, dtype=torch.float32, device=x.device)      # one fill for both accumulators
         dg, db = dgb[0], dgb[1]
+        keep = ctx.keep if hasattr(ctx, "keep") else None
         native.check(_L().dldkd_layernorm_bwd_f32(_p(x.reshape(-1, D)), _p(add), ctx.add_mod, _p(gamma), _p(dy.reshape(-1, D)),
-                                                  _p(dx), _p(dg), _p(db), x.numel() // D, D, ops.LN_EPS, _s()), "layernorm_bwd")
+                                                  _p(dx), _p(dg), _p(db), x.numel() // D, D, ops.LN_EPS, _p(keep),
+                                                  getattr(ctx, "keep_scale", 1.0), _s()), "layernorm_bwd")
         dadd = None
         if add is not None and ctx.needs_input_grad[3]:
             if ctx.add_mod > 0:       # position table (L, D): sum over the batch
@@ -96,9 +98,35 @@ class _LayerNorm(Function):
         return (dx if ctx.needs_input_grad[0] else None), dg, db, dadd, None
 
 
-def layernorm(x, gamma, beta, add=None, add_mod=0):
+class _LayerNormDropout(Function):
+    """LayerNorm -> inverted dropout in one kernel forward (no normalised intermediate, no separate mask pass) and one kernel
+    backward (dy masked on load inside the LayerNorm backward)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, add, add_mod, p):
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D)
+        out = torch.empty_like(x2)
+        keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
+        seed, off, state = _philox_slot(x.device, x.numel())
+        native.check(_L().dldkd_layernorm_dropout_f32(_p(x2), _p(add), int(add_mod), _p(gamma), _p(beta), _p(out), _p(keep),
+                                                      x2.shape[0], D, ops.LN_EPS, float(p), seed, off, state, _s()),
+                     "layernorm_dropout")
+        ctx.save_for_backward(x, gamma, add)
+        ctx.add_mod, ctx.keep, ctx.keep_scale = add_mod, keep, 1.0 / (1.0 - p)
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _LayerNorm.backward(ctx, dy) + (None,)
+
+
+def layernorm(x, gamma, beta, add=None, add_mod=0, p_drop=0.0, training=False):
+    """LayerNorm(x [+ add]) [-> dropout(p_drop) when training]: the dropout is fused into the LayerNorm kernels."""
     x = _f32(x)
     add = _f32(add) if add is not None else None
+    if training and p_drop > 0.0:
+        return _LayerNormDropout.apply(x, gamma, beta, add, add_mod, float(p_drop))
     if _needs_grad(x, gamma, beta, add):
         return _LayerNorm.apply(x, gamma, beta, add, add_mod)
     return ops.layernorm(x, gamma, beta, add=add, add_mod=add_mod)

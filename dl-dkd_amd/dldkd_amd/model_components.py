@@ -26,8 +26,8 @@ class TrainablePositionalEncoding(nn.Module):
         if L > self.position_embeddings.num_embeddings:
             raise IndexError(f"sequence length {L} exceeds {self.position_embeddings.num_embeddings} positions")
         pos = self.position_embeddings.weight[:L]
-        out = F_.layernorm(input_feat, self.LayerNorm.weight, self.LayerNorm.bias, add=pos, add_mod=L)
-        return F_.dropout(out, self.dropout.p, self.training)
+        return F_.layernorm(input_feat, self.LayerNorm.weight, self.LayerNorm.bias, add=pos, add_mod=L,
+                            p_drop=self.dropout.p, training=self.training)            # LayerNorm + Dropout: one kernel
 
 
 class LinearLayer(nn.Module):
@@ -43,8 +43,9 @@ class LinearLayer(nn.Module):
 
     def forward(self, x):
         if self.layer_norm:
-            x = F_.layernorm(x, self.LayerNorm.weight, self.LayerNorm.bias)
-        x = F_.dropout(x, self.net[0].p, self.training)
+            x = F_.layernorm(x, self.LayerNorm.weight, self.LayerNorm.bias, p_drop=self.net[0].p, training=self.training)
+        else:
+            x = F_.dropout(x, self.net[0].p, self.training)
         lin = self.net[1]
         return F_.linear(x, lin.weight, lin.bias, relu=self.relu)
 

@@ -147,6 +147,14 @@ int dldkd_gemm_f32(const float* A, const float* B, const float* bias, float* C, 
  * residual (BertSelfOutput.forward :446-450). */
 int dldkd_layernorm_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta,
                         float* out, long M, int D, float eps, void* stream);
+/* LayerNorm followed by inverted dropout in ONE pass (LinearLayer: LayerNorm -> Dropout -> Linear, model_components.py:305-312;
+ * TrainablePositionalEncoding: LayerNorm(x + pos) -> Dropout, :277-284): out = keep ? LN(x + add) / (1-p) : 0, keep (M x D
+ * bytes, 4-byte aligned) = the mask for the backward pass.  The masks are those dldkd_dropout_fwd_f32 draws for a tensor of
+ * the output's shape at the same (seed, offset) / device state. */
+int dldkd_layernorm_dropout_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta,
+                                float* out, unsigned char* keep, long M, int D, float eps, float p_drop,
+                                unsigned long long seed, unsigned long long offset, const unsigned long long* state,
+                                void* stream);
 
 /* BertSelfAttention.forward (model_components.py:398-436) for N sequences of L <= 128 tokens, 4 heads x 96:
  * qkv (N, L, 1152) = [query | key | value] projections, mask (N, L) 0/1 or NULL, out (N, L, 384) context
@@ -221,9 +229,12 @@ int dldkd_gemm_f32x3(const float* A, const float* B, const float* bias, float* C
                      int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes, void* stream);
 
 
-/* Backward of dldkd_layernorm_f32: dx (may be NULL) for the summed input; dgamma += , dbeta += . */
+/* Backward of dldkd_layernorm_f32: dx (may be NULL) written, dgamma / dbeta += (zero-initialised by the caller).
+ * keep / keep_scale: NULL / any, or the byte mask and 1/(1-p) of dldkd_layernorm_dropout_f32: dy is masked and scaled on
+ * load (the backward of the fused dropout), so no separate dldkd_mask_scale_f32 pass over dy is needed. */
 int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* dy,
-                            float* dx, float* dgamma, float* dbeta, long M, int D, float eps, void* stream);
+                            float* dx, float* dgamma, float* dbeta, long M, int D, float eps, const unsigned char* keep,
+                            float keep_scale, void* stream);
 
 /* out[c] += sum_r x[r, c]  (bias gradients; position-table gradient with x viewed as (batch, L*D)). */
 int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream);

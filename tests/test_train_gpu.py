@@ -420,6 +420,38 @@ def test_fused_training_attention_vs_fp64(N, L, p_drop):
     _gclose(a.grad, q64.grad, 2e-5)
 
 
+@pytest.mark.parametrize("M,D,with_pos", [(300, 3072, False), (257, 768, False), (40 * 30, 384, True), (5, 1024, False)])
+def test_fused_layernorm_dropout_equals_layernorm_then_dropout(M, D, with_pos):
+    """LayerNorm -> Dropout as ONE kernel (LinearLayer / TrainablePositionalEncoding in training, model_components.py:277-312)
+    against the two separate kernels at the same Philox slot: identical outputs, and identical gradients for x, gamma, beta and
+    the position table (the fused backward masks dy inside the LayerNorm backward)."""
+    from dldkd_amd import functional as F_
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    pos = torch.randn(30, D, generator=g) if with_pos else None
+    w = torch.randn(M, D, generator=g).to(DEV)
+    res = []
+    for fused in (True, False):
+        xs, gs, bs = (t.to(DEV).requires_grad_() for t in (x, gamma, beta))
+        ps = pos.to(DEV).requires_grad_() if with_pos else None
+        xin = xs.view(M // 30, 30, D) if with_pos else xs
+        torch.manual_seed(77)
+        if fused:
+            y = F_.layernorm(xin, gs, bs, add=ps, add_mod=30 if with_pos else 0, p_drop=0.2, training=True)
+        else:
+            y = F_.dropout(F_.layernorm(xin, gs, bs, add=ps, add_mod=30 if with_pos else 0), 0.2, True)
+        (y.reshape(M, D) * w).sum().backward()
+        res.append((y.detach().reshape(M, D), xs.grad, gs.grad, bs.grad, ps.grad if with_pos else None))
+    assert torch.equal(res[0][0], res[1][0])
+    frac = (res[0][0] == 0).float().mean().item()
+    assert 0.15 < frac < 0.25
+    assert torch.equal(res[0][1], res[1][1])                      # dx: same arithmetic on the same masked dy
+    for a, b in zip(res[0][2:], res[1][2:]):                      # dgamma / dbeta / dpos accumulate with fp32 atomics
+        if a is not None:
+            _gclose(a, b, 1e-5)
+
+
 def test_loss_kernels_fuzz_vs_oracle():
     """Random batch structures (2..40 videos, 1..4 captions each, 1..48 clips, random alpha/beta, both negative
     modes) through every loss kernel: value 1e-4 and gradient 2e-3 against the fp64 oracle."""
