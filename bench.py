@@ -443,11 +443,11 @@ def main():
         # KiB units; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md section HBM) from the committed
         # profile of this same workload.  Not re-measured live (PMC needs the profiler), so N>1 reports null.
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_simpool_v2", "summary.json")
+        pmc = os.path.join(ROOT, "profiles", "r02", "pmc_simpool", "summary.json")
         if world == 1 and os.path.exists(pmc):
             d = json.load(open(pmc))
             traffic = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
-            traffic_src = "profiles/r01/pmc_simpool_v2/summary.json (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"
+            traffic_src = "profiles/r02/pmc_simpool/summary.json (rocprofv3 --pmc, separate passes; 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KiB units)"
         out = {
             "metric": metric, "value": NQ * NV * a.steps / dt, "unit": "pairs/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,

@@ -464,6 +464,11 @@ __global__ __launch_bounds__(256) void simpool_finish64_kernel(const float* __re
                 const size_t row = (size_t)inv[vv] * nq_pad + q;
                 a = *reinterpret_cast<const f32x4*>(part + row);
                 if (n_branches > 1) b = *reinterpret_cast<const f32x4*>(part + (size_t)nv * nq_pad + row);
+                if (q_bad != nullptr) {                      // queries flagged by pack_queries_kernel: NaN scores (rank last)
+                    const f32x4 f = *reinterpret_cast<const f32x4*>(q_bad + q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (f[e] != 0.f) a[e] = b[e] = __builtin_nanf("");
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -479,8 +484,7 @@ __global__ __launch_bounds__(256) void simpool_finish64_kernel(const float* __re
     for (int i = 0; i < 16; ++i) {
         const int ql = (threadIdx.x >> 6) + 4 * i, qq = q0 + ql;
         if (qq < q_hi) {
-            float a = t0[vl][ql], b = t1[vl][ql];
-            if (q_bad != nullptr && q_bad[qq] != 0.f) a = b = __builtin_nanf("");      // flagged by pack_queries_kernel
+            const float a = t0[vl][ql], b = t1[vl][ql];
             const size_t o = (size_t)(qq - q_lo) * nv + vv;
             if (fused) fused[o] = n_branches > 1 ? fuse2(w0, a, w1, b) : a;
             if (s0) s0[o] = a;

@@ -44,7 +44,7 @@ def pack_queries(qs, normalize=True):
     L = native.lib()
     nq = qs[0].shape[0]
     blobs = []
-    bad = torch.zeros(max(nq, 1), dtype=torch.float32, device=qs[0].device)
+    bad = torch.zeros((max(nq, 1) + 31) // 32 * 32, dtype=torch.float32, device=qs[0].device)
     for q in qs:
         if q.dim() != 2 or q.shape[1] != HIDDEN or q.shape[0] != nq:
             raise native.NativeError(f"queries must be (Nq, {HIDDEN}); got {tuple(q.shape)}")

@@ -53,7 +53,7 @@ size_t dldkd_packed_gallery_bytes(int nv, int L);
 size_t dldkd_simpool_eval_workspace_bytes(int nq, int nv, int n_branches);
 
 /* q (nq, 384) fp32 -> packed bf16 MFMA-fragment order; normalize != 0 applies F.normalize (eps 1e-12,
- * model.py:318) in fp32 before rounding.  bad_flags (nq floats, zeroed by the caller, or NULL): set to 1 for every query
+ * model.py:318) in fp32 before rounding.  bad_flags (nq rounded up to a multiple of 32 floats, zeroed by the caller, or NULL): set to 1 for every query
  * vector with a NaN / Inf component.  The scorer's max-pool drops NaN products, so such a query would tie every video
  * (and rank its ground truth FIRST); hand the flags to dldkd_simpool_finish_range / dldkd_simpool_rank_partials and the
  * query's scores become NaN, which ranks last (dldkd_rank_gt's NaN policy): a diverged model scores R@K = 0, not 100. */
