@@ -194,6 +194,11 @@ int dldkd_fold_ln_linear_bf16_frag(const float* W, const float* bias, const floa
                                    int n_offset, void* Wfrag, float* cs, float* bb, void* stream);
 int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                             long M, int K, float eps, int relu, void* stream);
+/* Second-generation kernel for the same contract (same Wfrag / cs / bb from dldkd_fold_ln_linear_bf16_frag with n_total = 768,
+ * same result up to fp32 summation order): 4 waves x (128 rows x 192 columns) per workgroup, the x operand loaded straight
+ * into MFMA fragments (never through LDS), per-wave private W' rings, no barrier in the k-loop (in_proj_rows128.hip). */
+int dldkd_in_proj_bf16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
+                               long M, int K, float eps, int relu, void* stream);
 
 /* Plain y = act(x W^T + b) on the same full-row bf16 MFMA kernel (no LayerNorm fold) for the 384-wide linears of the
  * towers in throughput mode (model_components.py:388-390 query/key/value, :442 dense; model.py:39 out_mapping_linear).

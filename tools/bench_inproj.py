@@ -17,16 +17,25 @@ opt_ = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_
 m = DLDKD(cfg, opt_).to(DEV).eval()
 x = torch.nn.functional.normalize(torch.randn(M, K, device=DEV), dim=-1)
 f = ops.FoldedInProj([m.visual_input_proj, m.exp_visual_input_proj])
-for _ in range(2): ops.in_proj_bf16(x, f)
-ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
-ev[0].record()
-for i in range(10):
-    ops.in_proj_bf16(x, f); ev[i + 1].record()
-torch.cuda.synchronize()
-ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(10)); med = ts[5]
 byts = M * K * 4 + M * 768 * 4 + 768 * K * 2
 flops = 2.0 * M * K * 768
-print(f"K4 in_proj_bf16 M={M} K={K}: {med:.3f} ms  algorithmic {byts/med/1e6:.0f} GB/s ({byts/med/1e6/8000*100:.1f}% of 8 TB/s)  {flops/med/1e9:.0f} TFLOP/s")
+outs = {}
+for kern in os.environ.get("K4_KERNELS", "full,rows128").split(","):
+    ops.INPROJ_KERNEL = kern
+    for _ in range(2): outs[kern] = ops.in_proj_bf16(x, f)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+    ev[0].record()
+    for i in range(10):
+        ops.in_proj_bf16(x, f); ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(10)); med = ts[5]
+    print(f"K4 in_proj_bf16[{kern}] M={M} K={K}: {med:.3f} ms  algorithmic {byts/med/1e6:.0f} GB/s ({byts/med/1e6/8000*100:.1f}% of 8 TB/s)  {flops/med/1e9:.0f} TFLOP/s", flush=True)
+if len(outs) == 2:
+    a, b = outs["full"], outs["rows128"]
+    for i in range(2):
+        d = (a[i] - b[i]).abs().max().item()
+        print(f"   branch {i}: max |full - rows128| = {d:.3e}  (|y| max {a[i].abs().max().item():.3f})  nan {torch.isnan(b[i]).sum().item()}")
+ops.INPROJ_KERNEL = "full"
 with torch.no_grad():
     t = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     xs = x[: 200 * 128].view(200, 128, K)
