@@ -1,26 +1,32 @@
 // K4, second generation: y = ReLU( LayerNorm(x) . W^T + b ) for the raw clip / word features, both branches (768 output
 // columns) in ONE pass over the fp32 rows.  Replaces LinearLayer.forward (reference method/model_components.py:305-312) on the
 // inference path, like rows_linear_bf16_kernel<1, true> (in_proj_bf16.hip), whose limits this kernel is built around
-// (profiles/r01/ablation_k4_in_proj.md): both MFMA operands came from LDS (0.58 fragment reads per MFMA: an LDS
-// operand-delivery ceiling of ~834 TFLOP/s raw, no memory traffic needed to hit it) and 8 waves marched in lock-step around one
-// barrier per k-tile.  The kernel needs ~1.1 PFLOP/s to move 3.6 TB/s (307 flop per byte).
+// (profiles/r01/ablation_k4_in_proj.md): 0.58 LDS fragment reads per MFMA and 8 waves in lock-step around a barrier with one
+// k-tile of loads in flight.  The kernel needs ~1.1 PFLOP/s to move 3.6 TB/s (307 flop per byte), i.e. the MFMA pipe busy
+// ~45 % of the time with ONE wave per SIMD - so every load has to be in flight long before it is needed, and nothing that is
+// in flight may cost registers:
 //
-//   * 4 waves per workgroup, ONE per SIMD, NO barrier in the k-loop.  Wave w owns ALL 128 rows of the workgroup x columns
-//     [192 w, 192 w + 192): 4 x 6 tiles of mfma_f32_32x32x16_bf16 = 384 accumulator registers - more than the 256 AGPRs, and
-//     hipcc allocates every MFMA of a kernel in one register class (a test compile copied 128 registers in and out of the AGPR
-//     half every k-step).  So the MFMAs are inline asm: the accumulators of column tiles 0-3 are constrained to AGPRs ("+a"),
-//     those of column tiles 4-5 to arch VGPRs ("+v"): 256 + 128, no copies.
-//   * the x operand never touches LDS: each lane loads the 8 consecutive fp32 of its A-fragment row straight from global memory
-//     (two dwordx4), converts them to bf16 in registers (v_cvt_pk_bf16_f32) and keeps them for the 6 column tiles of the k-step.
-//     The four waves load the same rows (L1 / L2 serve three of the four); rows are loaded ONE k-step ahead into a second
-//     register set, the loads hidden from hipcc in asm so that it does not drain the whole VMEM queue around the W' LDS-DMA
-//     (cdna_hip_programming.md section 5, trap (b)) - one hand-counted s_waitcnt per k-step.
-//   * W' (LayerNorm-folded weights, bf16, MFMA B-fragment order) streams L2 -> LDS by LDS-DMA into a PRIVATE 3-slot ring per
-//     wave (12 KiB per k-step: exactly the 6 column tiles the wave uses), two k-steps ahead; each 1-KiB fragment read from LDS
-//     feeds 4 MFMAs (0.25 fragment reads per MFMA).
+//   * 4 waves per workgroup, one per SIMD.  Wave w owns ALL 128 rows of the workgroup x columns [192 w, 192 w + 192):
+//     4 x 6 tiles of mfma_f32_32x32x16_bf16 = 384 accumulator registers - more than the 256 AGPRs, and hipcc allocates every
+//     MFMA of a kernel in one register class.  So the MFMAs are inline asm: column tiles 0-3 accumulate in AGPRs ("+a"),
+//     column tiles 4-5 in arch VGPRs ("+v"): 256 + 128, no copies.  A fragment feeds 6 MFMAs, a B fragment 4.
+//   * x streams HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) as fp32 into a 4-slot ring of 16-KiB k-tiles (128 rows x 32
+//     floats) shared by the four waves (each issues a quarter): three k-steps (48 KiB per CU) in flight, costing no registers.
+//     The DMA's per-lane SOURCE addresses are permuted so that the image is XOR-swizzled (16-B chunk c of row r sits at chunk
+//     c ^ ((r >> 1) & 7)): the A-fragment reads (ds_read_b128, lane = row) are conflict-free.  Each wave reads its fragments as
+//     fp32 one k-step ahead, converts with v_cvt_pk_bf16_f32 and keeps them for the step's 6 column tiles.
+//     (The first version of this kernel loaded x straight into registers, one k-step ahead: 1775 GB/s, every step waited ~2 us
+//     for HBM.)
+//   * W' (LayerNorm-folded weights, bf16, MFMA B-fragment order) streams L2 -> LDS by LDS-DMA into a PRIVATE ring per wave of
+//     24 1-KiB fragments = two k-steps of the wave's 6 column tiles.  A fragment's slot is refilled (two k-steps ahead) as soon
+//     as its ds_read has returned, so the DMA issue is spread over the step and each fragment has two full steps to land.
+//   * one s_barrier per k-step (x slot hand-over); all other waits are hand-counted: the VMEM queue of a wave holds, in issue
+//     order, 4 x pieces + 12 W' fragments per step, so "fragment f of this step has landed" is always s_waitcnt vmcnt(30).
+//     Loads and waits are asm / builtins the compiler cannot see through, so it does not drain the queue around the LDS-DMA
+//     (cdna_hip_programming.md section 5, trap (b)).
 //   * LayerNorm is folded as before: out = rstd (x.W'^T - mean colsum(W')) + (W.beta + b); wave w accumulates sum / sum of
-//     squares of rows 32 w .. 32 w + 31 from the fp32 values it converts anyway; one barrier after the k-loop publishes them.
-//   * epilogue: 32 x 192 tiles staged through the wave's (now idle) LDS ring and written as float4 rows.
+//     squares of rows 32 w .. 32 w + 31 from the fp32 values it converts anyway.
+//   * epilogue: 32 x 192 tiles staged through the wave's (now idle) 40-KiB LDS region and written as float4 rows.
 #include <type_traits>
 
 #include "common.hpp"
@@ -29,9 +35,11 @@ namespace dldkd {
 
 constexpr int RM = 128, RK = 32, RWC = 192;
 constexpr int RSLOT = 6 * 2 * 1024;       // bytes of W' per wave per k-step: [6 column tiles][2 kk][64 lanes][16 B]
-constexpr int RRING = 3;
+constexpr int XSLOT = RM * RK * 4;        // one k-tile of x as fp32: 16 KiB
+constexpr int WREGION = 2 * RSLOT + XSLOT;  // LDS per wave: [W' ring, 2 k-steps][x ring slot number `wave`] = 40 KiB
 constexpr int RSP = 200;                  // epilogue staging pitch (floats): the two lane halves (rows +4) hit disjoint banks
 constexpr int RW_TILE = 768 * RK * 2;     // bytes of W' per k-step for all 24 column tiles
+constexpr int RSTAT = 30 * 1024;          // LayerNorm statistics after the k-loop: behind wave 0's staging tile
 
 struct Rows128Args {
     const float* x;
@@ -46,16 +54,15 @@ struct Rows128Args {
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2n __attribute__((ext_vector_type(2)));
-// 8 fp32 -> one bf16 MFMA fragment with 4 v_cvt_pk_bf16_f32 (element-wise casts made hipcc convert singly and pack with v_perm)
-__device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 u;
-    u[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo[0], lo[1]}, bf16x2n));
-    u[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo[2], lo[3]}, bf16x2n));
-    u[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{hi[0], hi[1]}, bf16x2n));
-    u[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{hi[2], hi[3]}, bf16x2n));
-    return __builtin_bit_cast(bf16x8, u);
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// 8 fp32 -> one bf16 MFMA fragment: 4 v_cvt_pk_bf16_f32, pinned where they are written (between two MFMAs)
+__device__ __forceinline__ void cvt8(u32x4& dst, const f32x4& lo, const f32x4& hi) {
+    unsigned u0, u1, u2, u3;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u0) : "v"(lo[0]), "v"(lo[1]));
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u1) : "v"(lo[2]), "v"(lo[3]));
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u2) : "v"(hi[0]), "v"(hi[1]));
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u3) : "v"(hi[2]), "v"(hi[3]));
+    dst = u32x4{u0, u1, u2, u3};
 }
 
 template <int I, int N, typename F>
@@ -66,19 +73,15 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-__device__ __forceinline__ void mfma_agpr(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+__device__ __forceinline__ void mfma_agpr(f32x16& acc, const u32x4& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ void mfma_vgpr(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+__device__ __forceinline__ void mfma_vgpr(f32x16& acc, const u32x4& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
-template <int OFF>
-__device__ __forceinline__ void lds_frag(bf16x8& dst, uint32_t addr) {
+template <int OFF, typename T>
+__device__ __forceinline__ void lds_read16(T& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
-}
-template <int OFF>
-__device__ __forceinline__ void xload(f32x4& dst, uint32_t voff, const float* base) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "i"(OFF) : "memory");
 }
 
 __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Args p) {
@@ -87,22 +90,36 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long m0 = (long)blockIdx.x * RM;
     const int nk = p.K / RK;
-    char* ring = smem + wave * (RRING * RSLOT);                       // this wave's private W' ring
-    float* s_mean = reinterpret_cast<float*>(smem + 4 * RRING * RSLOT);
-    float* s_rstd = s_mean + RM;
-    const uint32_t ring_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ring)) + lane * 16;
-    const char* wsrc = p.Wf + (size_t)wave * RSLOT + lane * 16;       // + k-step * RW_TILE + piece * 1024
+    char* region = smem + wave * WREGION;                             // this wave's W' ring (+ x slot `wave` behind it)
+    const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
+    const uint32_t ring_lds = smem_lds + wave * WREGION + lane * 16;
+    const char* wsrc = p.Wf + (size_t)wave * RSLOT + lane * 16;       // + k-step * RW_TILE + fragment * 1024
 
-    // per-lane byte offsets of the 4 row tiles (rows past M are clamped: they feed accumulator rows that are never stored)
-    uint32_t voff[4];
+    // x LDS-DMA: piece t = 4 wave + q of a k-tile = rows 8 t .. 8 t + 7 (1 KiB, lane -> LDS chunk 64 t + lane).  The lane
+    // fetches the global chunk that belongs at that position of the swizzled image.  Rows past M are clamped (they feed
+    // accumulator rows that are never stored).
+    uint32_t voffx[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        long row = m0 + 32 * i + (lane & 31);
-        if (row > p.M - 1) row = p.M - 1;
-        voff[i] = (uint32_t)((row - m0) * p.K * 4 + (lane >> 5) * 32);
+    for (int q = 0; q < 4; ++q) {
+        const int t = 4 * wave + q, row = 8 * t + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        long rg = m0 + row;
+        if (rg > p.M - 1) rg = p.M - 1;
+        voffx[q] = (uint32_t)((rg - m0) * p.K * 4 + chunk * 16);
     }
-    const float* xb = p.x + m0 * p.K;                                  // wave-uniform, advanced by 32 floats per k-step
+    const char* xsrc = reinterpret_cast<const char*>(p.x + m0 * p.K);  // + k-step * 128 bytes
+    // A-fragment reads: lane (r = lane & 31, h = lane >> 5) takes chunks 4 kk + 2 h + e of row 32 i + r
+    uint32_t va[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = lane & 31, c = 4 * kk + 2 * (lane >> 5) + e;
+            va[kk][e] = smem_lds + 2 * RSLOT + r * 128 + ((c ^ ((r >> 1) & 7)) << 4);   // + slot * WREGION + i * 4096
+        }
 
+    unsigned long long ts[8];
+    ts[0] = __builtin_amdgcn_s_memtime(); ts[1] = __builtin_amdgcn_s_memrealtime();
     f32x16 acc[4][6];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -110,95 +127,121 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
         for (int j = 0; j < 6; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8 a[4][2];          // A fragments of the current k-step: row tile i, kk
-    f32x4 raw[4][2][2];      // fp32 of the NEXT k-step in flight: row tile i, kk, half of the 8 floats
-    float sum = 0.f, sq = 0.f;
+    u32x4 a[2][4][2];        // A fragments (bf16 pairs): [k-step parity][row tile i][kk]; the other parity is being filled
+    f32x4 tmp[2][2];         // fp32 of one (row tile, kk) pair of the NEXT k-step on its way from LDS to bf16, double-buffered
+    f32x2 sum2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
 
-    auto stage = [&](int kt) {                                        // 12 x 1 KiB LDS-DMA pieces into slot kt % 3
-        const char* src = wsrc + (size_t)kt * RW_TILE;
-        char* dst = ring + (kt % RRING) * RSLOT;
+    // k-steps are taken in rotated order, starting at kt0 = (workgroup % 8) eighths of the way: at K = 3072 the row stride is
+    // 3 x 4 KiB, and workgroups marching through the same k-tile at the same time kept hitting the same few HBM channels
+    // (12 % of the kernel's time).  Consecutive workgroups go to different XCDs, so the CUs that share an L2 still share W'.
+    const int kt0 = (p.relu & 16) ? 0 : (int)(blockIdx.x & 7) * nk / 8;
+    auto rot = [&](int k) { const int r = k + kt0; return r < nk ? r : r - nk; };
+    auto dma_x = [&](int kx, int slot) {                              // this wave's quarter of k-tile kx -> ring slot
+        const char* src = xsrc + ((p.relu & 4) ? 0 : (size_t)rot(kx) * (RK * 4));
+        char* dst = smem + slot * WREGION + 2 * RSLOT + (4 * wave) * 1024;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) glds16(src + i * 1024, dst + i * 1024);
+        for (int q = 0; q < 4; ++q) glds16(src + voffx[q], dst + q * 1024);
     };
-    auto issue_x = [&]() {
-        static_for<0, 4>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            xload<0>(raw[i][0][0], voff[i], xb);
-            xload<16>(raw[i][0][1], voff[i], xb);
-            xload<64>(raw[i][1][0], voff[i], xb);
-            xload<80>(raw[i][1][1], voff[i], xb);
+    auto stats = [&](const f32x4& lo, const f32x4& hi) {
+        const f32x2 v0 = {lo[0], lo[1]}, v1 = {lo[2], lo[3]}, v2 = {hi[0], hi[1]}, v3 = {hi[2], hi[3]};
+        sum2 += (v0 + v1) + (v2 + v3);
+        sq2 += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+    };
+
+    // prologue: x k-tiles 0..3 and W' k-steps 0, 1 (k-tiles past the end re-load the last one: the queue stays uniform)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dma_x(s < nk ? s : nk - 1, s);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int f = 0; f < 12; ++f) glds16(wsrc + (size_t)rot(s) * RW_TILE + f * 1024, region + s * RSLOT + f * 1024);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    static_for<0, 8>([&](auto pc) {                                   // k-tile 0 -> a[0], unpipelined
+        constexpr int pr = decltype(pc)::value, i = pr >> 1, kk = pr & 1;
+        lds_read16<i * 4096>(tmp[0][0], va[kk][0]);
+        lds_read16<i * 4096>(tmp[0][1], va[kk][1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tmp[0][0]), "+v"(tmp[0][1]) : : "memory");
+        cvt8(a[0][i][kk], tmp[0][0], tmp[0][1]);
+        if (wave == i) stats(tmp[0][0], tmp[0][1]);
+    });
+    bf16x8 b[2];
+    lds_read16<0>(b[0], ring_lds);                                    // B fragment 0 of k-step 0
+
+    // One k-step.  PAR = kt & 1: the W' ring half and the A-fragment set in use.  12 groups: B fragment g (column tile g / 2,
+    // kk = g & 1) x the 4 row tiles.  Riding along in the MFMA shadow (one wave per SIMD: <= ~24 issue cycles per MFMA gap):
+    //   * B fragment g + 1 (group 11: fragment 0 of the next step) is read one group ahead;
+    //   * the refill of fragment g's ring slot for k-step kt + 2 is issued as soon as fragment g is in registers;
+    //   * groups 0-7 read pair g = (row tile g / 2, kk = g & 1) of the NEXT k-tile as fp32; groups 1-8 convert the pair read one
+    //     group earlier into the other A-fragment set (and add it to the LayerNorm sums if the row tile is the wave's own).
+    // VMEM operations issued after B fragment g + 1 of this step was: 10 - g (rest of its step) + 16 (next step) + 4 (x, this
+    // step) + g (refills of this step) = 30; after fragment 0 of the next step: 11 + 4 + 11 = 26.
+    // LDS operations issued after fragment g: the pair of group g - 1 (2) and this group's 1 + 2.
+    auto step = [&](auto parc, int kt) {
+        constexpr int PAR = decltype(parc)::value;
+        asm volatile("s_barrier" ::: "memory");   // all waves are done with slot kt & 3; every quarter of k-tile kt + 1 has landed
+        dma_x(kt + 4 < nk ? kt + 4 : nk - 1, kt & 3);
+        const uint32_t so = ((kt + 1) & 3) * WREGION;
+        const uint32_t x00 = va[0][0] + so, x01 = va[0][1] + so, x10 = va[1][0] + so, x11 = va[1][1] + so;
+        const int stat_i = kt + 1 < nk ? wave : -1;
+        char* wdst = region + PAR * RSLOT;
+        const char* wnext = wsrc + ((p.relu & 2) ? 0 : (size_t)rot(kt + 2 < nk ? kt + 2 : kt + 2 - nk) * RW_TILE);
+        static_for<0, 12>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int j = g >> 1, kk = g & 1;
+            if constexpr (g < 11) {
+                asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+                lds_read16<PAR * RSLOT + (g + 1) * 1024>(b[(g + 1) & 1], ring_lds);
+            } else {
+                asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+                lds_read16<(PAR ^ 1) * RSLOT>(b[0], ring_lds);
+            }
+            if constexpr (g < 8) {
+                constexpr int i = g >> 1;
+                lds_read16<i * 4096>(tmp[g & 1][0], kk ? x10 : x00);
+                lds_read16<i * 4096>(tmp[g & 1][1], kk ? x11 : x01);
+                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(b[g & 1]), "+v"(tmp[(g + 1) & 1][0]), "+v"(tmp[(g + 1) & 1][1]) : : "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(b[g & 1]), "+v"(tmp[(g + 1) & 1][0]), "+v"(tmp[(g + 1) & 1][1]) : : "memory");
+            }
+            glds16(wnext + g * 1024, wdst + g * 1024);              // fragment g is in registers: refill its slot
+            if constexpr (j < 4) mfma_agpr(acc[0][j], a[PAR][0][kk], b[g & 1]); else mfma_vgpr(acc[0][j], a[PAR][0][kk], b[g & 1]);
+            if constexpr (g >= 1 && g <= 8) {
+                constexpr int pi = (g - 1) >> 1, pk = (g - 1) & 1;
+                cvt8(a[PAR ^ 1][pi][pk], tmp[(g - 1) & 1][0], tmp[(g - 1) & 1][1]);
+            }
+            if constexpr (j < 4) mfma_agpr(acc[1][j], a[PAR][1][kk], b[g & 1]); else mfma_vgpr(acc[1][j], a[PAR][1][kk], b[g & 1]);
+            if constexpr (g >= 1 && g <= 8) {
+                constexpr int pi = (g - 1) >> 1;
+                if (stat_i == pi) stats(tmp[(g - 1) & 1][0], tmp[(g - 1) & 1][1]);
+            }
+            if constexpr (j < 4) mfma_agpr(acc[2][j], a[PAR][2][kk], b[g & 1]); else mfma_vgpr(acc[2][j], a[PAR][2][kk], b[g & 1]);
+            if constexpr (j < 4) mfma_agpr(acc[3][j], a[PAR][3][kk], b[g & 1]); else mfma_vgpr(acc[3][j], a[PAR][3][kk], b[g & 1]);
         });
     };
-    auto convert = [&]() {                                            // raw -> bf16 fragments (+ LayerNorm sums of the wave's own row tile)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                a[i][kk] = pack8(raw[i][kk][0], raw[i][kk][1]);
-                if (wave == i) {                                      // wave-uniform
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float v = raw[i][kk][e >> 2][e & 3];
-                        sum += v;
-                        sq += v * v;
-                    }
-                }
-            }
-    };
-    auto wait_x = [&]() {          // every VMEM operation issued so far has landed (x of the next k-step, W' two steps ahead)
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(raw[0][0][0]), "+v"(raw[0][0][1]), "+v"(raw[0][1][0]), "+v"(raw[0][1][1]), "+v"(raw[1][0][0]),
-                       "+v"(raw[1][0][1]), "+v"(raw[1][1][0]), "+v"(raw[1][1][1]), "+v"(raw[2][0][0]), "+v"(raw[2][0][1]),
-                       "+v"(raw[2][1][0]), "+v"(raw[2][1][1]), "+v"(raw[3][0][0]), "+v"(raw[3][0][1]), "+v"(raw[3][1][0]),
-                       "+v"(raw[3][1][1])
-                     :
-                     : "memory");
-    };
-
-    // prologue
-    stage(0);
-    if (nk > 1) stage(1);
-    issue_x();
-    xb += RK;
-    wait_x();
-    convert();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 2 < nk) stage(kt + 2);
-        if (kt + 1 < nk) { issue_x(); xb += RK; }
-        const uint32_t slot = ring_lds + (kt % RRING) * RSLOT;
-        // 12 B fragments (column tile j, kk) in order f = 2 j + kk (their order in the slot); fragment f + 1 is read while the
-        // 4 MFMAs of fragment f run (128 cycles against ~100 of LDS latency); a 3-deep ring cost 4 registers the kernel lacks
-        bf16x8 b[2];
-        lds_frag<0>(b[0], slot);
-        static_for<0, 12>([&](auto fc) {
-            constexpr int f = decltype(fc)::value;
-            constexpr int j = f >> 1, kk = f & 1;
-            if constexpr (f + 1 < 12) {
-                lds_frag<(f + 1) * 1024>(b[(f + 1) & 1], slot);
-                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(b[f & 1]) : : "memory");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[f & 1]) : : "memory");
-            }
-            if constexpr (j < 4) {
-                mfma_agpr(acc[0][j], a[0][kk], b[f & 1]);
-                mfma_agpr(acc[1][j], a[1][kk], b[f & 1]);
-                mfma_agpr(acc[2][j], a[2][kk], b[f & 1]);
-                mfma_agpr(acc[3][j], a[3][kk], b[f & 1]);
-            } else {
-                mfma_vgpr(acc[0][j], a[0][kk], b[f & 1]);
-                mfma_vgpr(acc[1][j], a[1][kk], b[f & 1]);
-                mfma_vgpr(acc[2][j], a[2][kk], b[f & 1]);
-                mfma_vgpr(acc[3][j], a[3][kk], b[f & 1]);
-            }
-        });
-        if (kt + 1 < nk) {
-            wait_x();
-            convert();
-            asm volatile("s_nop 1");        // VALU-written fragments -> MFMA operands (cdna_hip_programming.md 5.7 item 2)
-        }
+    ts[2] = __builtin_amdgcn_s_memtime(); ts[3] = __builtin_amdgcn_s_memrealtime();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        step(std::integral_constant<int, 0>{}, kt);
+        step(std::integral_constant<int, 1>{}, kt + 1);
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");               // last MFMA results -> VALU readers below
+    if (kt < nk) step(std::integral_constant<int, 0>{}, kt);
+    float csn[6], bbn[6];                  // issued here: in flight during the drain and the statistics exchange
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const uint32_t off = (wave * RWC + 32 * j + (lane & 31)) * 4;
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(csn[j]) : "v"(off), "s"(p.cs) : "memory");
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(bbn[j]) : "v"(off), "s"(p.bb) : "memory");
+    }
+    float sum = sum2[0] + sum2[1], sq = sq2[0] + sq2[1];
+    ts[4] = __builtin_amdgcn_s_memtime(); ts[5] = __builtin_amdgcn_s_memrealtime();
+    // the re-loads past the end are still landing in the rings, which become staging space below
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\ts_nop 15\n\ts_nop 15"
+                 : "+v"(csn[0]), "+v"(csn[1]), "+v"(csn[2]), "+v"(csn[3]), "+v"(csn[4]), "+v"(csn[5]), "+v"(bbn[0]), "+v"(bbn[1]),
+                   "+v"(bbn[2]), "+v"(bbn[3]), "+v"(bbn[4]), "+v"(bbn[5])
+                 :
+                 : "memory");
+    float* s_mean = reinterpret_cast<float*>(smem + RSTAT);
+    float* s_rstd = s_mean + RM;
 
     // LayerNorm statistics of the wave's own row tile: the two lane halves hold the two 8-float chunks of every 16 k
     sum += __shfl_xor(sum, 32);
@@ -211,39 +254,58 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
     }
     __syncthreads();
 
-    // epilogue: wave w writes columns [192 w, 192 w + 192) = branch w / 2, columns (w & 1) * 192 ..
-    float* stg = reinterpret_cast<float*>(ring);                     // 32 x RSP floats = 25.6 KiB of the wave's 36 KiB
-    float* outb = p.y[wave >> 1] + (wave & 1) * RWC;
-    float csn[6], bbn[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int n = wave * RWC + 32 * j + (lane & 31);
-        csn[j] = p.cs[n];
-        bbn[j] = p.bb[n];
-    }
+    // epilogue: wave w writes columns [192 w, 192 w + 192) = branch w / 2, columns (w & 1) * 192 ..  One wave per SIMD: nothing
+    // hides a wait, so every operand is fetched in batches ahead of its use (the first version read the row statistics one
+    // ds_read_b32 + wait at a time: 50k cycles per tile, a sixth of the kernel)
+    float* stg = reinterpret_cast<float*>(region);                   // 32 x RSP floats = 25.6 KiB of the wave's 40 KiB
+    float* outb = p.y[wave >> 1] + (wave & 1) * RWC + (size_t)m0 * kHidden;
+    const bool relu = p.relu & 1, full = m0 + RM <= p.M;
+    const int hrow = 4 * (lane >> 5);
+    float* wr = stg + hrow * RSP + (lane & 31);
+    const float* rd = stg + (lane >> 4) * RSP + 4 * (lane & 15);
+    float* gw = outb + (size_t)(lane >> 4) * kHidden + 4 * (lane & 15);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        f32x4 mean4[4], rstd4[4];                                    // rows 32 i + 8 g + hrow + {0..3}: accumulator registers 4 g ..
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            mean4[g] = *reinterpret_cast<const f32x4*>(s_mean + 32 * i + 8 * g + hrow);
+            rstd4[g] = *reinterpret_cast<const f32x4*>(s_rstd + 32 * i + 8 * g + hrow);
+        }
 #pragma unroll
         for (int j = 0; j < 6; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int ml = 32 * i + rl;
-                float v = s_rstd[ml] * (acc[i][j][r] - s_mean[ml] * csn[j]) + bbn[j];
-                if (p.relu) v = fmaxf(v, 0.f);
-                stg[rl * RSP + 32 * j + (lane & 31)] = v;
+                float v = rstd4[r >> 2][r & 3] * (acc[i][j][r] - mean4[r >> 2][r & 3] * csn[j]) + bbn[j];
+                if (relu) v = fmaxf(v, 0.f);
+                wr[((r & 3) + 8 * (r >> 2)) * RSP + 32 * j] = v;
             }
-        // the wave's own staging region: no workgroup barrier needed, only the wave's own LDS writes must have landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the wave's own staging region and LDS operations of one wave execute in order: no barrier, no wait
+        f32x4 o[24];
 #pragma unroll
-        for (int it = 0; it < 24; ++it) {
-            const int idx = lane + 64 * it;                          // 32 rows x 48 float4
-            const int rl = idx / 48, c4 = idx % 48;
-            const long mrow = m0 + 32 * i + rl;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * RSP + 4 * c4);
-            if (mrow < p.M) *reinterpret_cast<f32x4*>(outb + (size_t)mrow * kHidden + 4 * c4) = v;
+        for (int it = 0; it < 24; ++it)                              // it = 8 cg + rg: rows 4 rg + lane / 16, float4 column 16 cg + lane % 16
+            o[it] = *reinterpret_cast<const f32x4*>(rd + 4 * (it & 7) * RSP + 64 * (it >> 3));
+        float* g = gw + (size_t)(32 * i) * kHidden;
+        if (full) {
+#pragma unroll
+            for (int it = 0; it < 24; ++it) *reinterpret_cast<f32x4*>(g + (size_t)(4 * (it & 7)) * kHidden + 64 * (it >> 3)) = o[it];
+        } else {
+#pragma unroll
+            for (int it = 0; it < 24; ++it)
+                if (m0 + 32 * i + 4 * (it & 7) + (lane >> 4) < p.M)
+                    *reinterpret_cast<f32x4*>(g + (size_t)(4 * (it & 7)) * kHidden + 64 * (it >> 3)) = o[it];
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // reads done before the next tile overwrites the staging
+    }
+    if (p.relu & 8) {
+        ts[6] = __builtin_amdgcn_s_memtime(); ts[7] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y[0] + (size_t)m0 * kHidden);
+            for (int i = 0; i < 8; ++i) o[i] = ts[i];
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            o[8] = xcc;
+        }
     }
 }
 
@@ -253,15 +315,15 @@ using namespace dldkd;
 
 extern "C" int dldkd_in_proj_bf16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                           long M, int K, float eps, int relu, void* stream) {
-    if (M < 0 || K < RK || (K % RK) || (long)127 * K * 4 + 64 > 0xFFFFFFFFL) {
-        set_error("in_proj_bf16_rows128: K must be a multiple of %d (M=%ld K=%d)", RK, M, K);
+    if (M < 0 || K < 4 * RK || (K % RK) || (long)127 * K * 4 + 64 > 0xFFFFFFFFL) {
+        set_error("in_proj_bf16_rows128: K must be a multiple of %d, at least %d (M=%ld K=%d)", RK, 4 * RK, M, K);
         return DLDKD_EINVAL;
     }
     if (M == 0) return DLDKD_OK;
     if (!x || !Wfrag || !cs || !bb || !y0 || !y1) { set_error("in_proj_bf16_rows128: null pointer"); return DLDKD_EINVAL; }
     if (((uintptr_t)x | (uintptr_t)y0 | (uintptr_t)y1) & 15) { set_error("in_proj_bf16_rows128: unaligned buffer"); return DLDKD_EINVAL; }
     Rows128Args p{x, (const char*)Wfrag, cs, bb, {y0, y1}, M, K, eps, relu};
-    constexpr int lds = 4 * RRING * RSLOT + 2 * RM * 4;
+    constexpr int lds = 4 * WREGION;            // all 160 KiB
     static const bool ok = hipFuncSetAttribute((const void*)in_proj_rows128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
     (void)ok;
     DLDKD_LAUNCH(in_proj_rows128_kernel, dim3((unsigned)((M + RM - 1) / RM)), dim3(256), lds, (hipStream_t)stream, p);

@@ -141,6 +141,7 @@ def modpool(h, mask, w, want_attn=False):
     return (out, attn) if want_attn else out
 
 
+INPROJ_DEBUG = 0
 INPROJ_KERNEL = "full"        # "full": rows_linear_bf16_kernel<1, true>;  "rows128": in_proj_rows128_kernel (same contract)
 
 
@@ -266,7 +267,7 @@ def in_proj_bf16(x, folded, relu=True):
     if f.full_row:
         fn = L.dldkd_in_proj_bf16_rows128 if INPROJ_KERNEL == "rows128" else L.dldkd_in_proj_bf16_full
         native.check(fn(native.ptr(x2), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb), native.ptr(ys[0]),
-                        native.ptr(ys[1]), M, K, LN_EPS, int(relu), native.stream()), "in_proj_bf16_" + INPROJ_KERNEL)
+                        native.ptr(ys[1]), M, K, LN_EPS, int(relu) | INPROJ_DEBUG, native.stream()), "in_proj_bf16_" + INPROJ_KERNEL)
         return [y.view(*x.shape[:-1], HIDDEN) for y in ys]
     native.check(L.dldkd_in_proj_bf16(native.ptr(x2), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb), native.ptr(ys[0]),
                                       native.ptr(ys[1]) if f.nb == 2 else None, M, f.nb * HIDDEN, K, LN_EPS, int(relu),

@@ -22,6 +22,7 @@ flops = 2.0 * M * K * 768
 outs = {}
 for kern in os.environ.get("K4_KERNELS", "full,rows128").split(","):
     ops.INPROJ_KERNEL = kern
+    ops.INPROJ_DEBUG = int(os.environ.get("K4_DEBUG", "0"), 0) if kern == "rows128" else 0
     for _ in range(2): outs[kern] = ops.in_proj_bf16(x, f)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
     ev[0].record()

@@ -1,0 +1,39 @@
+"""Diagnostic: per-workgroup timeline of in_proj_rows128_kernel (debug bit 8 makes each workgroup overwrite the start of its
+output tile with s_memtime / s_memrealtime stamps: start, loop start, loop end, kernel end)."""
+import os, sys, types
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dl-dkd_amd"))
+import torch, numpy as np
+from dldkd_amd import ops
+from dldkd_amd.model import DLDKD
+K, M = 3072, 400000
+cfg = types.SimpleNamespace(visual_input_size=K, query_input_size=768, inheritance_hidden=384, exploration_hidden=384,
+                            max_ctx_l=128, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4, initializer_range=0.02,
+                            margin=0.1, use_hard_negative=True, hard_pool_size=20, label_style="soft")
+opt_ = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                             collection="tvr", alpha=0.8, belta=0.8)
+m = DLDKD(cfg, opt_).to("cuda:0").eval()
+x = torch.nn.functional.normalize(torch.randn(M, K, device="cuda:0"), dim=-1)
+f = ops.FoldedInProj([m.visual_input_proj, m.exp_visual_input_proj])
+ops.INPROJ_KERNEL = "rows128"
+ops.INPROJ_DEBUG = 8 | int(os.environ.get("K4_DEBUG", "0"), 0)
+for _ in range(20): y = ops.in_proj_bf16(x, f)
+torch.cuda.synchronize()
+raw = y[0].view(-1, 384)[::128].contiguous().view(torch.int64)[:, :9].cpu().numpy()   # [tiles, 9]
+t0 = raw[:, 1].min()
+rt = (raw[:, [1, 3, 5, 7]] - t0) / 100.0      # us (100 MHz)
+cyc = raw[:, [2, 4, 6]] - raw[:, [0, 2, 4]]
+dur = rt[:, 1:] - rt[:, :-1]
+print("tiles", len(raw), "kernel span us", rt[:, 3].max())
+print("clock GHz (loop): median", np.median(cyc[:, 1] / dur[:, 1]) / 1e3)
+for name, i in (("prologue", 0), ("loop", 1), ("epilogue", 2)):
+    print(f"{name:9s} us: median {np.median(dur[:, i]):8.2f}  p10 {np.percentile(dur[:, i], 10):8.2f}  p90 {np.percentile(dur[:, i], 90):8.2f}   cycles median {np.median(cyc[:, i]):10.0f}")
+order = np.argsort(rt[:, 0])
+print("first 6 WG starts", rt[order[:6], 0], " last 6 ends", np.sort(rt[:, 3])[-6:])
+xcc = raw[:, 8] & 0xf
+print("tiles per XCC", np.bincount(xcc.astype(int)))
+late = rt[:, 0] > 1.0
+print("start times of later WGs: gaps after a predecessor ends -> (not tracked); loop us by start decile:")
+for q in range(0, 100, 20):
+    sel = (rt[:, 0] >= np.percentile(rt[:, 0], q)) & (rt[:, 0] <= np.percentile(rt[:, 0], q + 20))
+    print(f"   start {q}-{q+20}%: loop median {np.median(dur[sel, 1]):.2f} us")
