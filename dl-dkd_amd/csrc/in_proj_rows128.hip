@@ -79,6 +79,16 @@ __device__ __forceinline__ void mfma_agpr(f32x16& acc, const u32x4& a, const bf1
 __device__ __forceinline__ void mfma_vgpr(f32x16& acc, const u32x4& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
+// LDS-DMA, 16 B per lane: global address = scalar base + 32-bit lane offset + immediate (no 64-bit VALU add in the MFMA shadow),
+// LDS destination = wave-uniform lds_base (-> M0) + the SAME immediate + lane * 16.  hipcc treats M0 as reserved and re-materialises it before each
+// of its own uses, so the asm may overwrite it.
+template <int OFF>
+__device__ __forceinline__ void glds16_s(uint32_t voff, const char* sbase, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_base), "i"(OFF)
+                 : "memory");
+}
 template <int OFF, typename T>
 __device__ __forceinline__ void lds_read16(T& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
@@ -134,97 +144,116 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
     // k-steps are taken in rotated order, starting at kt0 = (workgroup % 8) eighths of the way: at K = 3072 the row stride is
     // 3 x 4 KiB, and workgroups marching through the same k-tile at the same time kept hitting the same few HBM channels
     // (12 % of the kernel's time).  Consecutive workgroups go to different XCDs, so the CUs that share an L2 still share W'.
-    const int kt0 = (p.relu & 16) ? 0 : (int)(blockIdx.x & 7) * nk / 8;
+    const int kt0 = (int)(blockIdx.x & 7) * nk / 8;
     auto rot = [&](int k) { const int r = k + kt0; return r < nk ? r : r - nk; };
-    auto dma_x = [&](int kx, int slot) {                              // this wave's quarter of k-tile kx -> ring slot
-        const char* src = xsrc + ((p.relu & 4) ? 0 : (size_t)rot(kx) * (RK * 4));
-        char* dst = smem + slot * WREGION + 2 * RSLOT + (4 * wave) * 1024;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(src + voffx[q], dst + q * 1024);
-    };
     auto stats = [&](const f32x4& lo, const f32x4& hi) {
         const f32x2 v0 = {lo[0], lo[1]}, v1 = {lo[2], lo[3]}, v2 = {hi[0], hi[1]}, v3 = {hi[2], hi[3]};
         sum2 += (v0 + v1) + (v2 + v3);
         sq2 += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
     };
+    const uint32_t wlane = lane * 16;
+    const uint32_t region_lds = smem_lds + wave * WREGION;
+    const char* wsrc_w = p.Wf + (size_t)wave * RSLOT;                  // wave-uniform: + k-step * RW_TILE + fragment * 1024
 
-    // prologue: x k-tiles 0..3 and W' k-steps 0, 1 (k-tiles past the end re-load the last one: the queue stays uniform)
+    // Every wave numbers the row tiles from its own: its tile i' is rows 32 ((i' + wave) % 4) ..  The wave's own tile (whose
+    // LayerNorm sums it accumulates) is then i' = 0 in every wave: the same instruction stream for all four, no branch in the loop
+    // (four specialised copies of the loop made hipcc spill).  The price is one scalar-operand add per A-fragment read.
+    uint32_t roff[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) dma_x(s < nk ? s : nk - 1, s);
+    for (int i = 0; i < 4; ++i) roff[i] = ((i + wave) & 3) * 4096;
+
+    // prologue: x k-tiles 0..3 and W' k-steps 0, 1.  The k-tile sequence wraps around at both ends of the loop: the queue stays
+    // uniform, and the last k-step converts k-tile 0 a second time - which is when it enters the LayerNorm sums (not here).
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 4; ++s) {
+        const char* src = xsrc + (size_t)rot(s) * (RK * 4);
+        const uint32_t dst = smem_lds + s * WREGION + 2 * RSLOT + (4 * wave) * 1024;
+        glds16_s<0>(voffx[0], src, dst);
+        glds16_s<0>(voffx[1], src, dst + 1024);
+        glds16_s<0>(voffx[2], src, dst + 2048);
+        glds16_s<0>(voffx[3], src, dst + 3072);
+    }
 #pragma unroll
-        for (int f = 0; f < 12; ++f) glds16(wsrc + (size_t)rot(s) * RW_TILE + f * 1024, region + s * RSLOT + f * 1024);
+    for (int s = 0; s < 2; ++s) {
+        const char* src = wsrc_w + (size_t)rot(s) * RW_TILE;
+        static_for<0, 12>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            glds16_s<(f & 3) * 1024>(wlane, src + (f >> 2) * 4096, region_lds + s * RSLOT + (f >> 2) * 4096);
+        });
+    }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     static_for<0, 8>([&](auto pc) {                                   // k-tile 0 -> a[0], unpipelined
         constexpr int pr = decltype(pc)::value, i = pr >> 1, kk = pr & 1;
-        lds_read16<i * 4096>(tmp[0][0], va[kk][0]);
-        lds_read16<i * 4096>(tmp[0][1], va[kk][1]);
+        lds_read16<0>(tmp[0][0], va[kk][0] + roff[i]);
+        lds_read16<0>(tmp[0][1], va[kk][1] + roff[i]);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tmp[0][0]), "+v"(tmp[0][1]) : : "memory");
         cvt8(a[0][i][kk], tmp[0][0], tmp[0][1]);
-        if (wave == i) stats(tmp[0][0], tmp[0][1]);
     });
-    bf16x8 b[2];
-    lds_read16<0>(b[0], ring_lds);                                    // B fragment 0 of k-step 0
+    uint32_t x00 = va[0][0], x01 = va[0][1], x10 = va[1][0], x11 = va[1][1];    // slot 0; every k-step advances them first
+    bf16x8 b[3];
+    lds_read16<0>(b[0], ring_lds);                                    // B fragments 0, 1 of k-step 0
+    lds_read16<1024>(b[1], ring_lds);
 
     // One k-step.  PAR = kt & 1: the W' ring half and the A-fragment set in use.  12 groups: B fragment g (column tile g / 2,
-    // kk = g & 1) x the 4 row tiles.  Riding along in the MFMA shadow (one wave per SIMD: <= ~24 issue cycles per MFMA gap):
-    //   * B fragment g + 1 (group 11: fragment 0 of the next step) is read one group ahead;
-    //   * the refill of fragment g's ring slot for k-step kt + 2 is issued as soon as fragment g is in registers;
-    //   * groups 0-7 read pair g = (row tile g / 2, kk = g & 1) of the NEXT k-tile as fp32; groups 1-8 convert the pair read one
-    //     group earlier into the other A-fragment set (and add it to the LayerNorm sums if the row tile is the wave's own).
-    // VMEM operations issued after B fragment g + 1 of this step was: 10 - g (rest of its step) + 16 (next step) + 4 (x, this
-    // step) + g (refills of this step) = 30; after fragment 0 of the next step: 11 + 4 + 11 = 26.
-    // LDS operations issued after fragment g: the pair of group g - 1 (2) and this group's 1 + 2.
+    // kk = g & 1) x the 4 row tiles = 4 MFMAs.  One wave per SIMD: whatever else the wave issues has to fit the MFMA shadow
+    // (an MFMA keeps the issue port 8 of its 32 cycles; every instruction after it costs 4-16 more; measured: the un-hidden
+    // rest cost a third of the loop), branches cost a refetch, and nothing may be waited for less than ~250 cycles after it was
+    // issued.  So there is no branch in the loop and the four gaps of a group carry one job each:
+    //   gap 0  read B fragment g + 2 (groups 10, 11: fragments 0, 1 of the next step) into the 3-deep register ring;
+    //   gap 1  groups 0-7: read pair g = (row tile g / 2, kk = g & 1) of the NEXT k-tile as fp32 (2-deep ring);
+    //          groups 8-11: one of the wave's 4 x LDS-DMA pieces, four k-tiles ahead;
+    //   gap 2  refill fragment g's ring slot for k-step kt + 2 (fragment g is in registers since the top of the group);
+    //   gap 3  groups 1-8: convert the pair read in the previous group (6 gaps earlier) into the other A-fragment set (+ the
+    //          LayerNorm sums for the wave's own row tile: groups 1, 2).
+    // Hand-counted waits (both queues complete in order).  VMEM operations issued after B fragment g + 2 was, at gap 0 of
+    // group g: kVm[g].  LDS operations issued after fragment g, at the top of group g: kLgTop[g]; after pair g - 1, at gap 3: kLgCvt.
     auto step = [&](auto parc, int kt) {
         constexpr int PAR = decltype(parc)::value;
+        constexpr int kVm[12] = {29, 29, 29, 29, 29, 29, 28, 27, 26, 26, 27, 28};
+        constexpr int kLgTop[12] = {1, 3, 5, 5, 5, 5, 5, 5, 5, 3, 1, 1};
+        constexpr int kLgCvt[8] = {3, 3, 3, 3, 3, 3, 3, 1};
         asm volatile("s_barrier" ::: "memory");   // all waves are done with slot kt & 3; every quarter of k-tile kt + 1 has landed
-        dma_x(kt + 4 < nk ? kt + 4 : nk - 1, kt & 3);
-        const uint32_t so = ((kt + 1) & 3) * WREGION;
-        const uint32_t x00 = va[0][0] + so, x01 = va[0][1] + so, x10 = va[1][0] + so, x11 = va[1][1] + so;
-        const int stat_i = kt + 1 < nk ? wave : -1;
-        char* wdst = region + PAR * RSLOT;
-        const char* wnext = wsrc + ((p.relu & 2) ? 0 : (size_t)rot(kt + 2 < nk ? kt + 2 : kt + 2 - nk) * RW_TILE);
+        {   // A-fragment read addresses move on to ring slot (kt + 1) & 3
+            const int adv = ((kt + 1) & 3) ? WREGION : -3 * WREGION;
+            x00 += adv, x01 += adv, x10 += adv, x11 += adv;
+        }
+        const uint32_t wdst = region_lds + PAR * RSLOT;
+        const char* wnext = wsrc_w + (size_t)rot(kt + 2 < nk ? kt + 2 : kt + 2 - nk) * RW_TILE;
+        const char* wn1 = wnext + 4096;
+        const char* wn2 = wnext + 8192;
+        const char* xnext = xsrc + (size_t)rot(kt + 4 < nk ? kt + 4 : kt + 4 - nk) * (RK * 4);
+        const uint32_t xdst = smem_lds + (kt & 3) * WREGION + 2 * RSLOT + (4 * wave) * 1024;
         static_for<0, 12>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int j = g >> 1, kk = g & 1;
-            if constexpr (g < 11) {
-                asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
-                lds_read16<PAR * RSLOT + (g + 1) * 1024>(b[(g + 1) & 1], ring_lds);
-            } else {
-                asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
-                lds_read16<(PAR ^ 1) * RSLOT>(b[0], ring_lds);
-            }
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(b[g % 3]) : "n"(kLgTop[g]) : "memory");
+            if constexpr (j < 4) mfma_agpr(acc[0][j], a[PAR][0][kk], b[g % 3]); else mfma_vgpr(acc[0][j], a[PAR][0][kk], b[g % 3]);
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kVm[g]) : "memory");
+            if constexpr (g < 10) lds_read16<PAR * RSLOT + (g + 2) * 1024>(b[(g + 2) % 3], ring_lds);
+            else lds_read16<(PAR ^ 1) * RSLOT + (g - 10) * 1024>(b[(g + 2) % 3], ring_lds);
+            if constexpr (j < 4) mfma_agpr(acc[1][j], a[PAR][1][kk], b[g % 3]); else mfma_vgpr(acc[1][j], a[PAR][1][kk], b[g % 3]);
             if constexpr (g < 8) {
-                constexpr int i = g >> 1;
-                lds_read16<i * 4096>(tmp[g & 1][0], kk ? x10 : x00);
-                lds_read16<i * 4096>(tmp[g & 1][1], kk ? x11 : x01);
-                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(b[g & 1]), "+v"(tmp[(g + 1) & 1][0]), "+v"(tmp[(g + 1) & 1][1]) : : "memory");
+                lds_read16<0>(tmp[g & 1][0], (kk ? x10 : x00) + roff[g >> 1]);
+                lds_read16<0>(tmp[g & 1][1], (kk ? x11 : x01) + roff[g >> 1]);
             } else {
-                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(b[g & 1]), "+v"(tmp[(g + 1) & 1][0]), "+v"(tmp[(g + 1) & 1][1]) : : "memory");
+                glds16_s<0>(voffx[g - 8], xnext, xdst + (g - 8) * 1024);
             }
-            glds16(wnext + g * 1024, wdst + g * 1024);              // fragment g is in registers: refill its slot
-            if constexpr (j < 4) mfma_agpr(acc[0][j], a[PAR][0][kk], b[g & 1]); else mfma_vgpr(acc[0][j], a[PAR][0][kk], b[g & 1]);
+            if constexpr (j < 4) mfma_agpr(acc[2][j], a[PAR][2][kk], b[g % 3]); else mfma_vgpr(acc[2][j], a[PAR][2][kk], b[g % 3]);
+            glds16_s<(g & 3) * 1024>(wlane, (g >> 2) == 0 ? wnext : (g >> 2) == 1 ? wn1 : wn2, wdst + (g >> 2) * 4096);
+            if constexpr (j < 4) mfma_agpr(acc[3][j], a[PAR][3][kk], b[g % 3]); else mfma_vgpr(acc[3][j], a[PAR][3][kk], b[g % 3]);
             if constexpr (g >= 1 && g <= 8) {
-                constexpr int pi = (g - 1) >> 1, pk = (g - 1) & 1;
-                cvt8(a[PAR ^ 1][pi][pk], tmp[(g - 1) & 1][0], tmp[(g - 1) & 1][1]);
+                constexpr int pr = g - 1, pi = pr >> 1, pk = pr & 1;
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(tmp[pr & 1][0]), "+v"(tmp[pr & 1][1]) : "n"(kLgCvt[pr]) : "memory");
+                cvt8(a[PAR ^ 1][pi][pk], tmp[pr & 1][0], tmp[pr & 1][1]);
+                if constexpr (pi == 0) stats(tmp[pr & 1][0], tmp[pr & 1][1]);
             }
-            if constexpr (j < 4) mfma_agpr(acc[1][j], a[PAR][1][kk], b[g & 1]); else mfma_vgpr(acc[1][j], a[PAR][1][kk], b[g & 1]);
-            if constexpr (g >= 1 && g <= 8) {
-                constexpr int pi = (g - 1) >> 1;
-                if (stat_i == pi) stats(tmp[(g - 1) & 1][0], tmp[(g - 1) & 1][1]);
-            }
-            if constexpr (j < 4) mfma_agpr(acc[2][j], a[PAR][2][kk], b[g & 1]); else mfma_vgpr(acc[2][j], a[PAR][2][kk], b[g & 1]);
-            if constexpr (j < 4) mfma_agpr(acc[3][j], a[PAR][3][kk], b[g & 1]); else mfma_vgpr(acc[3][j], a[PAR][3][kk], b[g & 1]);
         });
     };
     ts[2] = __builtin_amdgcn_s_memtime(); ts[3] = __builtin_amdgcn_s_memrealtime();
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
+    for (int kt = 0; kt < nk; kt += 2) {          // nk is even (entry point)
         step(std::integral_constant<int, 0>{}, kt);
         step(std::integral_constant<int, 1>{}, kt + 1);
     }
-    if (kt < nk) step(std::integral_constant<int, 0>{}, kt);
     float csn[6], bbn[6];                  // issued here: in flight during the drain and the statistics exchange
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -266,11 +295,12 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
     float* gw = outb + (size_t)(lane >> 4) * kHidden + 4 * (lane & 15);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        f32x4 mean4[4], rstd4[4];                                    // rows 32 i + 8 g + hrow + {0..3}: accumulator registers 4 g ..
+        const int ti = (i + wave) & 3;                               // the row tile behind the wave's accumulators acc[i][..]
+        f32x4 mean4[4], rstd4[4];                                    // rows 32 ti + 8 g + hrow + {0..3}: accumulator registers 4 g ..
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            mean4[g] = *reinterpret_cast<const f32x4*>(s_mean + 32 * i + 8 * g + hrow);
-            rstd4[g] = *reinterpret_cast<const f32x4*>(s_rstd + 32 * i + 8 * g + hrow);
+            mean4[g] = *reinterpret_cast<const f32x4*>(s_mean + 32 * ti + 8 * g + hrow);
+            rstd4[g] = *reinterpret_cast<const f32x4*>(s_rstd + 32 * ti + 8 * g + hrow);
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j)
@@ -285,14 +315,14 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
 #pragma unroll
         for (int it = 0; it < 24; ++it)                              // it = 8 cg + rg: rows 4 rg + lane / 16, float4 column 16 cg + lane % 16
             o[it] = *reinterpret_cast<const f32x4*>(rd + 4 * (it & 7) * RSP + 64 * (it >> 3));
-        float* g = gw + (size_t)(32 * i) * kHidden;
+        float* g = gw + (size_t)(32 * ti) * kHidden;
         if (full) {
 #pragma unroll
             for (int it = 0; it < 24; ++it) *reinterpret_cast<f32x4*>(g + (size_t)(4 * (it & 7)) * kHidden + 64 * (it >> 3)) = o[it];
         } else {
 #pragma unroll
             for (int it = 0; it < 24; ++it)
-                if (m0 + 32 * i + 4 * (it & 7) + (lane >> 4) < p.M)
+                if (m0 + 32 * ti + 4 * (it & 7) + (lane >> 4) < p.M)
                     *reinterpret_cast<f32x4*>(g + (size_t)(4 * (it & 7)) * kHidden + 64 * (it >> 3)) = o[it];
         }
     }
@@ -315,8 +345,8 @@ using namespace dldkd;
 
 extern "C" int dldkd_in_proj_bf16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                           long M, int K, float eps, int relu, void* stream) {
-    if (M < 0 || K < 4 * RK || (K % RK) || (long)127 * K * 4 + 64 > 0xFFFFFFFFL) {
-        set_error("in_proj_bf16_rows128: K must be a multiple of %d, at least %d (M=%ld K=%d)", RK, 4 * RK, M, K);
+    if (M < 0 || K < 4 * RK || (K % (2 * RK)) || (long)127 * K * 4 + 64 > 0xFFFFFFFFL) {
+        set_error("in_proj_bf16_rows128: K must be a multiple of %d, at least %d (M=%ld K=%d)", 2 * RK, 4 * RK, M, K);
         return DLDKD_EINVAL;
     }
     if (M == 0) return DLDKD_OK;
