@@ -301,8 +301,19 @@ def extras(dev):
         ms = e0.elapsed_time(e1) / 5
         byts = 400000 * 3072 * 4 + 400000 * 768 * 4 + 768 * 3072 * 2
         out["k4_in_proj_roofline"] = {"bound": "hbm", "achieved": byts / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
-                                      "frac": byts / ms / 1e6 / 8000.0, "kernel": "rows_linear_bf16_kernel<1,true> (dldkd_in_proj_bf16_full)", "kernel_ms": ms,
+                                      "frac": byts / ms / 1e6 / 8000.0, "kernel": "in_proj_rows128_kernel (dldkd_in_proj_bf16_rows128)", "kernel_ms": ms,
                                       "shape": "400000 rows x 3072 fp32 -> 2 x 384 fp32"}
+        ops.INPROJ_KERNEL = "full"                 # the round-1 kernel on the same box, same input
+        try:
+            ops.in_proj_bf16(xk, fold)
+            e0.record()
+            for _ in range(5):
+                ops.in_proj_bf16(xk, fold)
+            e1.record()
+            torch.cuda.synchronize()
+            out["k4_in_proj_roofline"]["round1_kernel_ms"] = e0.elapsed_time(e1) / 5
+        finally:
+            ops.INPROJ_KERNEL = "rows128"
     except Exception as e:   # noqa: BLE001
         out["error"] = repr(e)
     return out

@@ -51,6 +51,7 @@ struct Rows128Args {
     int K;
     float eps;
     int relu;
+    unsigned long long* stamps;   // diagnostics only (dldkd_debug_in_proj_rows128_timeline): 9 words per workgroup, else null
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -82,6 +83,11 @@ __device__ __forceinline__ void mfma_vgpr(f32x16& acc, const u32x4& a, const bf1
 // LDS-DMA, 16 B per lane: global address = scalar base + 32-bit lane offset + immediate (no 64-bit VALU add in the MFMA shadow),
 // LDS destination = wave-uniform lds_base (-> M0) + the SAME immediate + lane * 16.  hipcc treats M0 as reserved and re-materialises it before each
 // of its own uses, so the asm may overwrite it.
+__device__ __forceinline__ void glds_m0(uint32_t lds_base) { asm volatile("s_mov_b32 m0, %0" : : "s"(lds_base) : "memory"); }
+template <int OFF>                      // M0 set at least one instruction earlier by glds_m0
+__device__ __forceinline__ void glds16_m(uint32_t voff, const char* sbase) {
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
+}
 template <int OFF>
 __device__ __forceinline__ void glds16_s(uint32_t voff, const char* sbase, uint32_t lds_base) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
@@ -94,6 +100,7 @@ __device__ __forceinline__ void lds_read16(T& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
 }
 
+template <bool STAMP>
 __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
         }
 
     unsigned long long ts[8];
-    ts[0] = __builtin_amdgcn_s_memtime(); ts[1] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (STAMP) { ts[0] = __builtin_amdgcn_s_memtime(); ts[1] = __builtin_amdgcn_s_memrealtime(); }
     f32x16 acc[4][6];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -199,19 +206,19 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
     // (an MFMA keeps the issue port 8 of its 32 cycles; every instruction after it costs 4-16 more; measured: the un-hidden
     // rest cost a third of the loop), branches cost a refetch, and nothing may be waited for less than ~250 cycles after it was
     // issued.  So there is no branch in the loop and the four gaps of a group carry one job each:
-    //   gap 0  read B fragment g + 2 (groups 10, 11: fragments 0, 1 of the next step) into the 3-deep register ring;
+    //   gap 0  groups 2-9: convert the pair read two groups earlier into the other A-fragment set (+ the LayerNorm sums for the
+    //          wave's own row tile: groups 2, 3);
     //   gap 1  groups 0-7: read pair g = (row tile g / 2, kk = g & 1) of the NEXT k-tile as fp32 (2-deep ring);
     //          groups 8-11: one of the wave's 4 x LDS-DMA pieces, four k-tiles ahead;
     //   gap 2  refill fragment g's ring slot for k-step kt + 2 (fragment g is in registers since the top of the group);
-    //   gap 3  groups 1-8: convert the pair read in the previous group (6 gaps earlier) into the other A-fragment set (+ the
-    //          LayerNorm sums for the wave's own row tile: groups 1, 2).
-    // Hand-counted waits (both queues complete in order).  VMEM operations issued after B fragment g + 2 was, at gap 0 of
-    // group g: kVm[g].  LDS operations issued after fragment g, at the top of group g: kLgTop[g]; after pair g - 1, at gap 3: kLgCvt.
+    //   gap 3  read B fragment g + 2 (groups 10, 11: fragments 0, 1 of the next step) into the 3-deep register ring.
+    // ONE hand-counted wait per group, at its top (both queues complete in order): kVm[g] = VMEM operations issued after the
+    // ring slot that gap 3 will read was refilled; kLgTop[g] = LDS operations issued after fragment g (the pair for gap 0 is
+    // older).  M0 (LDS-DMA destination) is written a gap ahead of its use instead of padding with s_nop.
     auto step = [&](auto parc, int kt) {
         constexpr int PAR = decltype(parc)::value;
         constexpr int kVm[12] = {29, 29, 29, 29, 29, 29, 28, 27, 26, 26, 27, 28};
-        constexpr int kLgTop[12] = {1, 3, 5, 5, 5, 5, 5, 5, 5, 3, 1, 1};
-        constexpr int kLgCvt[8] = {3, 3, 3, 3, 3, 3, 3, 1};
+        constexpr int kLgTop[12] = {1, 3, 3, 3, 3, 3, 3, 3, 3, 1, 1, 1};
         asm volatile("s_barrier" ::: "memory");   // all waves are done with slot kt & 3; every quarter of k-tile kt + 1 has landed
         {   // A-fragment read addresses move on to ring slot (kt + 1) & 3
             const int adv = ((kt + 1) & 3) ? WREGION : -3 * WREGION;
@@ -226,30 +233,31 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
         static_for<0, 12>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int j = g >> 1, kk = g & 1;
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(b[g % 3]) : "n"(kLgTop[g]) : "memory");
+            asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(%2)" : "+v"(b[g % 3]) : "n"(kVm[g]), "n"(kLgTop[g]) : "memory");
             if constexpr (j < 4) mfma_agpr(acc[0][j], a[PAR][0][kk], b[g % 3]); else mfma_vgpr(acc[0][j], a[PAR][0][kk], b[g % 3]);
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kVm[g]) : "memory");
-            if constexpr (g < 10) lds_read16<PAR * RSLOT + (g + 2) * 1024>(b[(g + 2) % 3], ring_lds);
-            else lds_read16<(PAR ^ 1) * RSLOT + (g - 10) * 1024>(b[(g + 2) % 3], ring_lds);
-            if constexpr (j < 4) mfma_agpr(acc[1][j], a[PAR][1][kk], b[g % 3]); else mfma_vgpr(acc[1][j], a[PAR][1][kk], b[g % 3]);
-            if constexpr (g < 8) {
-                lds_read16<0>(tmp[g & 1][0], (kk ? x10 : x00) + roff[g >> 1]);
-                lds_read16<0>(tmp[g & 1][1], (kk ? x11 : x01) + roff[g >> 1]);
-            } else {
-                glds16_s<0>(voffx[g - 8], xnext, xdst + (g - 8) * 1024);
-            }
-            if constexpr (j < 4) mfma_agpr(acc[2][j], a[PAR][2][kk], b[g % 3]); else mfma_vgpr(acc[2][j], a[PAR][2][kk], b[g % 3]);
-            glds16_s<(g & 3) * 1024>(wlane, (g >> 2) == 0 ? wnext : (g >> 2) == 1 ? wn1 : wn2, wdst + (g >> 2) * 4096);
-            if constexpr (j < 4) mfma_agpr(acc[3][j], a[PAR][3][kk], b[g % 3]); else mfma_vgpr(acc[3][j], a[PAR][3][kk], b[g % 3]);
-            if constexpr (g >= 1 && g <= 8) {
-                constexpr int pr = g - 1, pi = pr >> 1, pk = pr & 1;
-                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(tmp[pr & 1][0]), "+v"(tmp[pr & 1][1]) : "n"(kLgCvt[pr]) : "memory");
+            if constexpr (g >= 2 && g <= 9) {                        // gap 0
+                constexpr int pr = g - 2, pi = pr >> 1, pk = pr & 1;
                 cvt8(a[PAR ^ 1][pi][pk], tmp[pr & 1][0], tmp[pr & 1][1]);
                 if constexpr (pi == 0) stats(tmp[pr & 1][0], tmp[pr & 1][1]);
             }
+            if constexpr (g >= 8) glds_m0(xdst + (g - 8) * 1024);
+            if constexpr (j < 4) mfma_agpr(acc[1][j], a[PAR][1][kk], b[g % 3]); else mfma_vgpr(acc[1][j], a[PAR][1][kk], b[g % 3]);
+            if constexpr (g < 8) {                                   // gap 1
+                if constexpr ((g & 3) == 0) glds_m0(wdst + (g >> 2) * 4096);
+                lds_read16<0>(tmp[g & 1][0], (kk ? x10 : x00) + roff[g >> 1]);
+                lds_read16<0>(tmp[g & 1][1], (kk ? x11 : x01) + roff[g >> 1]);
+            } else {
+                glds16_m<0>(voffx[g - 8], xnext);
+                glds_m0(wdst + 2 * 4096);
+            }
+            if constexpr (j < 4) mfma_agpr(acc[2][j], a[PAR][2][kk], b[g % 3]); else mfma_vgpr(acc[2][j], a[PAR][2][kk], b[g % 3]);
+            glds16_m<(g & 3) * 1024>(wlane, (g >> 2) == 0 ? wnext : (g >> 2) == 1 ? wn1 : wn2);       // gap 2
+            if constexpr (j < 4) mfma_agpr(acc[3][j], a[PAR][3][kk], b[g % 3]); else mfma_vgpr(acc[3][j], a[PAR][3][kk], b[g % 3]);
+            if constexpr (g < 10) lds_read16<PAR * RSLOT + (g + 2) * 1024>(b[(g + 2) % 3], ring_lds);    // gap 3
+            else lds_read16<(PAR ^ 1) * RSLOT + (g - 10) * 1024>(b[(g + 2) % 3], ring_lds);
         });
     };
-    ts[2] = __builtin_amdgcn_s_memtime(); ts[3] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (STAMP) { ts[2] = __builtin_amdgcn_s_memtime(); ts[3] = __builtin_amdgcn_s_memrealtime(); }
     for (int kt = 0; kt < nk; kt += 2) {          // nk is even (entry point)
         step(std::integral_constant<int, 0>{}, kt);
         step(std::integral_constant<int, 1>{}, kt + 1);
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
         asm volatile("global_load_dword %0, %1, %2" : "=v"(bbn[j]) : "v"(off), "s"(p.bb) : "memory");
     }
     float sum = sum2[0] + sum2[1], sq = sq2[0] + sq2[1];
-    ts[4] = __builtin_amdgcn_s_memtime(); ts[5] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (STAMP) { ts[4] = __builtin_amdgcn_s_memtime(); ts[5] = __builtin_amdgcn_s_memrealtime(); }
     // the re-loads past the end are still landing in the rings, which become staging space below
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\ts_nop 15\n\ts_nop 15"
                  : "+v"(csn[0]), "+v"(csn[1]), "+v"(csn[2]), "+v"(csn[3]), "+v"(csn[4]), "+v"(csn[5]), "+v"(bbn[0]), "+v"(bbn[1]),
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
     // ds_read_b32 + wait at a time: 50k cycles per tile, a sixth of the kernel)
     float* stg = reinterpret_cast<float*>(region);                   // 32 x RSP floats = 25.6 KiB of the wave's 40 KiB
     float* outb = p.y[wave >> 1] + (wave & 1) * RWC + (size_t)m0 * kHidden;
-    const bool relu = p.relu & 1, full = m0 + RM <= p.M;
+    const bool relu = p.relu, full = m0 + RM <= p.M;
     const int hrow = 4 * (lane >> 5);
     float* wr = stg + hrow * RSP + (lane & 31);
     const float* rd = stg + (lane >> 4) * RSP + 4 * (lane & 15);
@@ -326,15 +334,14 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
                     *reinterpret_cast<f32x4*>(g + (size_t)(4 * (it & 7)) * kHidden + 64 * (it >> 3)) = o[it];
         }
     }
-    if (p.relu & 8) {
+    if constexpr (STAMP) {               // s_memtime (shader clock) / s_memrealtime (100 MHz): start, loop start, loop end, end; XCC id
         ts[6] = __builtin_amdgcn_s_memtime(); ts[7] = __builtin_amdgcn_s_memrealtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) {
-            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.y[0] + (size_t)m0 * kHidden);
+            unsigned long long* o = p.stamps + (size_t)blockIdx.x * 9;
             for (int i = 0; i < 8; ++i) o[i] = ts[i];
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            o[8] = xcc;
+            o[8] = xcc & 0xf;
         }
     }
 }
@@ -343,19 +350,41 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
 
 using namespace dldkd;
 
-extern "C" int dldkd_in_proj_bf16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
-                                          long M, int K, float eps, int relu, void* stream) {
-    if (M < 0 || K < 4 * RK || (K % (2 * RK)) || (long)127 * K * 4 + 64 > 0xFFFFFFFFL) {
+static int launch_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1, long M, int K,
+                          float eps, int relu, unsigned long long* stamps, void* stream) {
+    if (M < 0 || K < 4 * RK || (K % (2 * RK)) || (long)127 * K * 4 + 128 > 0xFFFFFFFFL) {
         set_error("in_proj_bf16_rows128: K must be a multiple of %d, at least %d (M=%ld K=%d)", 2 * RK, 4 * RK, M, K);
         return DLDKD_EINVAL;
     }
     if (M == 0) return DLDKD_OK;
     if (!x || !Wfrag || !cs || !bb || !y0 || !y1) { set_error("in_proj_bf16_rows128: null pointer"); return DLDKD_EINVAL; }
-    if (((uintptr_t)x | (uintptr_t)y0 | (uintptr_t)y1) & 15) { set_error("in_proj_bf16_rows128: unaligned buffer"); return DLDKD_EINVAL; }
-    Rows128Args p{x, (const char*)Wfrag, cs, bb, {y0, y1}, M, K, eps, relu};
+    if (((uintptr_t)x | (uintptr_t)y0 | (uintptr_t)y1 | (uintptr_t)Wfrag) & 15) { set_error("in_proj_bf16_rows128: unaligned buffer"); return DLDKD_EINVAL; }
+    Rows128Args p{x, (const char*)Wfrag, cs, bb, {y0, y1}, M, K, eps, relu != 0, stamps};
     constexpr int lds = 4 * WREGION;            // all 160 KiB
-    static const bool ok = hipFuncSetAttribute((const void*)in_proj_rows128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
-    (void)ok;
-    DLDKD_LAUNCH(in_proj_rows128_kernel, dim3((unsigned)((M + RM - 1) / RM)), dim3(256), lds, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)((M + RM - 1) / RM));
+    if (stamps) {
+        static const bool ok = hipFuncSetAttribute((const void*)in_proj_rows128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        (void)ok;
+        DLDKD_LAUNCH(in_proj_rows128_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    } else {
+        static const bool ok = hipFuncSetAttribute((const void*)in_proj_rows128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        (void)ok;
+        DLDKD_LAUNCH(in_proj_rows128_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    }
     return check_launch("in_proj_bf16_rows128");
+}
+
+extern "C" int dldkd_in_proj_bf16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
+                                          long M, int K, float eps, int relu, void* stream) {
+    return launch_rows128(x, Wfrag, cs, bb, y0, y1, M, K, eps, relu, nullptr, stream);
+}
+
+extern "C" int dldkd_in_proj_bf16_rows128_ok(int K) { return K >= 4 * RK && K % (2 * RK) == 0 && (long)127 * K * 4 + 128 <= 0xFFFFFFFFL; }
+
+// Diagnostics: the same kernel with clock stamps; stamps = 9 x u64 per 128-row workgroup (tools/k4_timeline.py).
+extern "C" int dldkd_debug_in_proj_rows128_timeline(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0,
+                                                    float* y1, long M, int K, float eps, int relu, unsigned long long* stamps,
+                                                    void* stream) {
+    if (!stamps) { set_error("in_proj_rows128_timeline: stamps is null"); return DLDKD_EINVAL; }
+    return launch_rows128(x, Wfrag, cs, bb, y0, y1, M, K, eps, relu, stamps, stream);
 }

@@ -89,6 +89,9 @@ SIGNATURES = {
                                           _c_float, _c_int, _c_void_p]),
     "dldkd_in_proj_bf16_rows128": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
                                              _c_float, _c_int, _c_void_p]),
+    "dldkd_in_proj_bf16_rows128_ok": (_c_int, [_c_int]),
+    "dldkd_debug_in_proj_rows128_timeline": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long,
+                                                       _c_int, _c_float, _c_int, _c_void_p, _c_void_p]),
     "dldkd_attention_fwd_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "dldkd_pack_linear_bf16_frag": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_linear_rows_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_int, _c_int,

@@ -141,8 +141,9 @@ def modpool(h, mask, w, want_attn=False):
     return (out, attn) if want_attn else out
 
 
-INPROJ_DEBUG = 0
-INPROJ_KERNEL = "full"        # "full": rows_linear_bf16_kernel<1, true>;  "rows128": in_proj_rows128_kernel (same contract)
+# K4 kernel for the two-branch projection: "rows128" = in_proj_rows128_kernel (round 2; needs K % 64 == 0, else falls back),
+# "full" = rows_linear_bf16_kernel<1, true> (round 1).  Same contract; results differ in fp32 summation order only.
+INPROJ_KERNEL = "rows128"
 
 
 class FoldedInProj:
@@ -152,10 +153,8 @@ class FoldedInProj:
     def __init__(self, layers, full_row=None):
         self.layers = layers
         self.key = None
-        # two branches: the full-row kernel (weights in MFMA fragment order); DLDKD_INPROJ_VARIANT=tiled forces the
-        # column-tiled kernel for A/B runs
-        import os
-        self.full_row = (len(layers) == 2 and os.environ.get("DLDKD_INPROJ_VARIANT", "full") != "tiled") if full_row is None else full_row
+        # two branches: the full-row kernels (weights in MFMA fragment order); full_row=False forces the column-tiled kernel
+        self.full_row = (len(layers) == 2) if full_row is None else full_row
 
     def _params(self):
         ps = []
@@ -265,9 +264,10 @@ def in_proj_bf16(x, folded, relu=True):
     M = x2.shape[0]
     ys = [torch.empty(M, HIDDEN, dtype=torch.float32, device=x.device) for _ in range(f.nb)]
     if f.full_row:
-        fn = L.dldkd_in_proj_bf16_rows128 if INPROJ_KERNEL == "rows128" else L.dldkd_in_proj_bf16_full
+        rows128 = INPROJ_KERNEL == "rows128" and L.dldkd_in_proj_bf16_rows128_ok(K)
+        fn = L.dldkd_in_proj_bf16_rows128 if rows128 else L.dldkd_in_proj_bf16_full
         native.check(fn(native.ptr(x2), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb), native.ptr(ys[0]),
-                        native.ptr(ys[1]), M, K, LN_EPS, int(relu) | INPROJ_DEBUG, native.stream()), "in_proj_bf16_" + INPROJ_KERNEL)
+                        native.ptr(ys[1]), M, K, LN_EPS, int(relu), native.stream()), "in_proj_bf16_" + INPROJ_KERNEL)
         return [y.view(*x.shape[:-1], HIDDEN) for y in ys]
     native.check(L.dldkd_in_proj_bf16(native.ptr(x2), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb), native.ptr(ys[0]),
                                       native.ptr(ys[1]) if f.nb == 2 else None, M, f.nb * HIDDEN, K, LN_EPS, int(relu),

@@ -194,11 +194,18 @@ int dldkd_fold_ln_linear_bf16_frag(const float* W, const float* bias, const floa
                                    int n_offset, void* Wfrag, float* cs, float* bb, void* stream);
 int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                             long M, int K, float eps, int relu, void* stream);
-/* Second-generation kernel for the same contract (same Wfrag / cs / bb from dldkd_fold_ln_linear_bf16_frag with n_total = 768,
- * same result up to fp32 summation order): 4 waves x (128 rows x 192 columns) per workgroup, the x operand loaded straight
- * into MFMA fragments (never through LDS), per-wave private W' rings, no barrier in the k-loop (in_proj_rows128.hip). */
+/* Second-generation kernel for the same contract (same Wfrag / cs / bb from dldkd_fold_ln_linear_bf16_frag with n_total = 768;
+ * same result up to fp32 summation order: the k-tiles are summed in a rotated order).  One 128-row x 768-column tile per
+ * workgroup of 4 waves (128 rows x 192 columns each, 384 accumulator registers), x and W' streamed by LDS-DMA through rings that
+ * fill all 160 KiB of LDS, hand-counted waits, no branch in the k-loop (in_proj_rows128.hip).  Needs K % 64 == 0, K >= 128:
+ * dldkd_in_proj_bf16_rows128_ok(K) tells; otherwise use dldkd_in_proj_bf16_full.  Wfrag must be 16-byte aligned. */
 int dldkd_in_proj_bf16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                long M, int K, float eps, int relu, void* stream);
+int dldkd_in_proj_bf16_rows128_ok(int K);
+/* Diagnostics (tools/k4_timeline.py): the same launch, plus 9 u64 per 128-row workgroup in `stamps`: s_memtime / s_memrealtime
+ * at kernel start, k-loop start, k-loop end, kernel end, and the XCC id. */
+int dldkd_debug_in_proj_rows128_timeline(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
+                                         long M, int K, float eps, int relu, unsigned long long* stamps, void* stream);
 
 /* Plain y = act(x W^T + b) on the same full-row bf16 MFMA kernel (no LayerNorm fold) for the 384-wide linears of the
  * towers in throughput mode (model_components.py:388-390 query/key/value, :442 dense; model.py:39 out_mapping_linear).

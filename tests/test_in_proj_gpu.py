@@ -12,9 +12,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("dv,M", [(3072, 300), (1024, 129), (768, 1), (64, 515)])
-def test_in_proj_vs_oracle(dv, M):
+@pytest.mark.parametrize("kernel", ["rows128", "full"])
+@pytest.mark.parametrize("dv,M", [(3072, 300), (1024, 129), (768, 1), (64, 515), (128, 1000)])
+def test_in_proj_vs_oracle(dv, M, kernel, monkeypatch):
     from dldkd_amd import ops
+    monkeypatch.setattr(ops, "INPROJ_KERNEL", kernel)          # dv = 64: rows128 is not applicable and falls back
     m = _model(dv, dv, synth.make_params(7, dv, dv))
     g = torch.Generator().manual_seed(dv + M)
     x = torch.nn.functional.normalize(torch.randn(M, dv, generator=g).abs() + 0.1 * torch.randn(M, dv, generator=g), dim=-1)  # i3d-like: positive mean
@@ -32,6 +34,44 @@ def test_in_proj_vs_oracle(dv, M):
         m.visual_input_proj.net[1].bias.add_(1.0)
     y2 = ops.in_proj_bf16(x.to(DEV), folded)[0]
     assert (y2 - ys[0]).abs().max() > 0.5
+
+
+@pytest.mark.parametrize("K,M", [(3072, 128 * 300 + 77), (768, 30001), (128, 129), (3072, 1), (1024, 127)])
+def test_rows128_matches_full_kernel(K, M, monkeypatch):
+    """The two K4 kernels share one contract: same folded weights, same output up to fp32 summation order (the rows128
+    kernel adds the k-tiles in a rotated order per workgroup).  Ragged last tile, one-row input, smallest K."""
+    from dldkd_amd import ops, native
+    m = _model(K, K, synth.make_params(11, K, K))
+    g = torch.Generator().manual_seed(K + M)
+    x = torch.nn.functional.normalize(torch.randn(M, K, generator=g).abs() + 0.1 * torch.randn(M, K, generator=g), dim=-1).to(DEV)
+    folded = ops.FoldedInProj([m.visual_input_proj, m.exp_visual_input_proj])
+    assert native.lib().dldkd_in_proj_bf16_rows128_ok(K) == 1
+    out = {}
+    for kern in ("full", "rows128"):
+        monkeypatch.setattr(ops, "INPROJ_KERNEL", kern)
+        out[kern] = [y.clone() for y in ops.in_proj_bf16(x, folded, relu=(K != 1024))]
+    for a, b in zip(out["full"], out["rows128"]):
+        assert torch.isfinite(b).all()
+        assert (a - b).abs().max().item() <= 4e-5 * max(1.0, a.abs().max().item())
+    # rows past M are never written: a guard band behind the outputs stays untouched
+    L = native.lib()
+    f = folded.get()
+    ys = [torch.full((M + 128, 384), -7.0, device=DEV) for _ in range(2)]
+    native.check(L.dldkd_in_proj_bf16_rows128(native.ptr(x), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb), native.ptr(ys[0]),
+                                              native.ptr(ys[1]), M, K, 1e-5, 1, native.stream()), "rows128")
+    for y in ys:
+        assert (y[M:] == -7.0).all()
+
+
+def test_rows128_rejects_unsupported_k():
+    from dldkd_amd import native
+    L = native.lib()
+    assert L.dldkd_in_proj_bf16_rows128_ok(64) == 0 and L.dldkd_in_proj_bf16_rows128_ok(96) == 0 and L.dldkd_in_proj_bf16_rows128_ok(192) == 1
+    x = torch.zeros(4, 96, device=DEV)
+    y = torch.zeros(4, 384, device=DEV)
+    rc = L.dldkd_in_proj_bf16_rows128(native.ptr(x), native.ptr(x), native.ptr(x), native.ptr(x), native.ptr(y), native.ptr(y), 4, 96,
+                                      1e-5, 1, native.stream())
+    assert rc != 0
 
 
 def test_fast_path_keeps_rank_parity():

@@ -22,7 +22,6 @@ flops = 2.0 * M * K * 768
 outs = {}
 for kern in os.environ.get("K4_KERNELS", "full,rows128").split(","):
     ops.INPROJ_KERNEL = kern
-    ops.INPROJ_DEBUG = int(os.environ.get("K4_DEBUG", "0"), 0) if kern == "rows128" else 0
     for _ in range(2): outs[kern] = ops.in_proj_bf16(x, f)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
     ev[0].record()
@@ -36,7 +35,7 @@ if len(outs) == 2:
     for i in range(2):
         d = (a[i] - b[i]).abs().max().item()
         print(f"   branch {i}: max |full - rows128| = {d:.3e}  (|y| max {a[i].abs().max().item():.3f})  nan {torch.isnan(b[i]).sum().item()}")
-ops.INPROJ_KERNEL = "full"
+ops.INPROJ_KERNEL = "rows128"
 with torch.no_grad():
     t = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     xs = x[: 200 * 128].view(200, 128, K)

@@ -1,5 +1,5 @@
-"""Diagnostic: per-workgroup timeline of in_proj_rows128_kernel (debug bit 8 makes each workgroup overwrite the start of its
-output tile with s_memtime / s_memrealtime stamps: start, loop start, loop end, kernel end)."""
+"""Diagnostic: per-workgroup timeline of in_proj_rows128_kernel from dldkd_debug_in_proj_rows128_timeline (s_memtime /
+s_memrealtime stamps at kernel start, k-loop start, k-loop end, kernel end; the in-kernel clock under load)."""
 import os, sys, types
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dl-dkd_amd"))
@@ -15,11 +15,18 @@ opt_ = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_
 m = DLDKD(cfg, opt_).to("cuda:0").eval()
 x = torch.nn.functional.normalize(torch.randn(M, K, device="cuda:0"), dim=-1)
 f = ops.FoldedInProj([m.visual_input_proj, m.exp_visual_input_proj])
-ops.INPROJ_KERNEL = "rows128"
-ops.INPROJ_DEBUG = 8 | int(os.environ.get("K4_DEBUG", "0"), 0)
-for _ in range(20): y = ops.in_proj_bf16(x, f)
+from dldkd_amd import native
+L = native.lib()
+fo = f.get()
+ntile = (M + 127) // 128
+stamps = torch.zeros(ntile, 9, dtype=torch.int64, device="cuda:0")
+ys = [torch.empty(M, 384, device="cuda:0") for _ in range(2)]
+for _ in range(20):
+    native.check(L.dldkd_debug_in_proj_rows128_timeline(native.ptr(x), native.ptr(fo.Wf), native.ptr(fo.cs), native.ptr(fo.bb),
+                                                        native.ptr(ys[0]), native.ptr(ys[1]), M, K, 1e-5, 1, native.ptr(stamps),
+                                                        native.stream()), "timeline")
 torch.cuda.synchronize()
-raw = y[0].view(-1, 384)[::128].contiguous().view(torch.int64)[:, :9].cpu().numpy()   # [tiles, 9]
+raw = stamps.cpu().numpy()
 t0 = raw[:, 1].min()
 rt = (raw[:, [1, 3, 5, 7]] - t0) / 100.0      # us (100 MHz)
 cyc = raw[:, [2, 4, 6]] - raw[:, [0, 2, 4]]
