@@ -37,9 +37,7 @@ constexpr int RM = 128, RK = 32, RWC = 192;
 constexpr int RSLOT = 6 * 2 * 1024;       // bytes of W' per wave per k-step: [6 column tiles][2 kk][64 lanes][16 B]
 constexpr int XSLOT = RM * RK * 4;        // one k-tile of x as fp32: 16 KiB
 constexpr int WREGION = 2 * RSLOT + XSLOT;  // LDS per wave: [W' ring, 2 k-steps][x ring slot number `wave`] = 40 KiB
-constexpr int RSP = 200;                  // epilogue staging pitch (floats): the two lane halves (rows +4) hit disjoint banks
 constexpr int RW_TILE = 768 * RK * 2;     // bytes of W' per k-step for all 24 column tiles
-constexpr int RSTAT = 30 * 1024;          // LayerNorm statistics after the k-loop: behind wave 0's staging tile
 
 struct Rows128Args {
     const float* x;
@@ -100,31 +98,38 @@ __device__ __forceinline__ void lds_read16(T& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
 }
 
+template <int OFF>
+__device__ __forceinline__ void gstore32(uint32_t voff, float v, const char* sbase) {
+    asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(sbase), "i"(OFF) : "memory");
+}
+
 template <bool STAMP>
 __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long m0 = (long)blockIdx.x * RM;
     const int nk = p.K / RK;
-    char* region = smem + wave * WREGION;                             // this wave's W' ring (+ x slot `wave` behind it)
+    const long ntiles = (p.M + RM - 1) / RM;
     const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
-    const uint32_t ring_lds = smem_lds + wave * WREGION + lane * 16;
-    const char* wsrc = p.Wf + (size_t)wave * RSLOT + lane * 16;       // + k-step * RW_TILE + fragment * 1024
+    const uint32_t region_lds = smem_lds + wave * WREGION;            // this wave's W' ring (+ x slot `wave` behind it)
+    const uint32_t ring_lds = region_lds + lane * 16;
+    const uint32_t wlane = lane * 16;
+    const char* wsrc_w = p.Wf + (size_t)wave * RSLOT;                  // wave-uniform: + k-step * RW_TILE + fragment * 1024
 
     // x LDS-DMA: piece t = 4 wave + q of a k-tile = rows 8 t .. 8 t + 7 (1 KiB, lane -> LDS chunk 64 t + lane).  The lane
-    // fetches the global chunk that belongs at that position of the swizzled image.  Rows past M are clamped (they feed
-    // accumulator rows that are never stored).
+    // fetches the global chunk that belongs at that position of the swizzled image.  In a ragged last tile the byte offset is
+    // clamped to the tile's last valid chunk (rows past M feed accumulator rows that are never stored).
     uint32_t voffx[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int t = 4 * wave + q, row = 8 * t + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        long rg = m0 + row;
-        if (rg > p.M - 1) rg = p.M - 1;
-        voffx[q] = (uint32_t)((rg - m0) * p.K * 4 + chunk * 16);
+        voffx[q] = (uint32_t)((long)row * p.K * 4 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
     }
-    const char* xsrc = reinterpret_cast<const char*>(p.x + m0 * p.K);  // + k-step * 128 bytes
+    auto tile_src = [&](long t) { return reinterpret_cast<const char*>(p.x + t * RM * p.K); };
+    auto tile_maxoff = [&](long t) {
+        const long rv = p.M - t * RM < RM ? p.M - t * RM : RM;
+        return (uint32_t)((rv - 1) * p.K * 4 + 112);
+    };
     // A-fragment reads: lane (r = lane & 31, h = lane >> 5) takes chunks 4 kk + 2 h + e of row 32 i + r
     uint32_t va[2][2];
 #pragma unroll
@@ -132,21 +137,16 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int r = lane & 31, c = 4 * kk + 2 * (lane >> 5) + e;
-            va[kk][e] = smem_lds + 2 * RSLOT + r * 128 + ((c ^ ((r >> 1) & 7)) << 4);   // + slot * WREGION + i * 4096
+            va[kk][e] = smem_lds + 2 * RSLOT + r * 128 + ((c ^ ((r >> 1) & 7)) << 4);   // + slot * WREGION + row tile * 4096
         }
 
-    unsigned long long ts[8];
+    unsigned long long ts[10];
     if constexpr (STAMP) { ts[0] = __builtin_amdgcn_s_memtime(); ts[1] = __builtin_amdgcn_s_memrealtime(); }
     f32x16 acc[4][6];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     u32x4 a[2][4][2];        // A fragments (bf16 pairs): [k-step parity][row tile i][kk]; the other parity is being filled
     f32x4 tmp[2][2];         // fp32 of one (row tile, kk) pair of the NEXT k-step on its way from LDS to bf16, double-buffered
-    f32x2 sum2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
+    f32x2 sum2 = {0.f, 0.f}, sq2 = {0.f, 0.f};      // LayerNorm sums of the k-tiles converted so far (wave's own row tile)
+    f32x2 fsum2 = {0.f, 0.f}, fsq2 = {0.f, 0.f};    // ... of the tile being finished (taken before its last k-step, see below)
 
     // k-steps are taken in rotated order, starting at kt0 = (workgroup % 8) eighths of the way: at K = 3072 the row stride is
     // 3 x 4 KiB, and workgroups marching through the same k-tile at the same time kept hitting the same few HBM channels
@@ -158,9 +158,6 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
         sum2 += (v0 + v1) + (v2 + v3);
         sq2 += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
     };
-    const uint32_t wlane = lane * 16;
-    const uint32_t region_lds = smem_lds + wave * WREGION;
-    const char* wsrc_w = p.Wf + (size_t)wave * RSLOT;                  // wave-uniform: + k-step * RW_TILE + fragment * 1024
 
     // Every wave numbers the row tiles from its own: its tile i' is rows 32 ((i' + wave) % 4) ..  The wave's own tile (whose
     // LayerNorm sums it accumulates) is then i' = 0 in every wave: the same instruction stream for all four, no branch in the loop
@@ -169,37 +166,43 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
 #pragma unroll
     for (int i = 0; i < 4; ++i) roff[i] = ((i + wave) & 3) * 4096;
 
-    // prologue: x k-tiles 0..3 and W' k-steps 0, 1.  The k-tile sequence wraps around at both ends of the loop: the queue stays
-    // uniform, and the last k-step converts k-tile 0 a second time - which is when it enters the LayerNorm sums (not here).
+    // The workgroup is persistent: tiles blockIdx.x, + gridDim.x, ..  The two LDS-DMA streams never drain between tiles: the
+    // k-tile sequence is flat across them (x: four k-tiles ahead, from the NEXT tile's rows once the current tile's run out;
+    // W': two ahead, wrapping around).  The prologue below happens once per workgroup.
+    long tile = blockIdx.x;
+    const char* xsrc = tile_src(tile);
+    uint32_t xmax = tile_maxoff(tile);
+    {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const char* src = xsrc + (size_t)rot(s) * (RK * 4);
-        const uint32_t dst = smem_lds + s * WREGION + 2 * RSLOT + (4 * wave) * 1024;
-        glds16_s<0>(voffx[0], src, dst);
-        glds16_s<0>(voffx[1], src, dst + 1024);
-        glds16_s<0>(voffx[2], src, dst + 2048);
-        glds16_s<0>(voffx[3], src, dst + 3072);
-    }
+        for (int s = 0; s < 4; ++s) {
+            const char* src = xsrc + (size_t)rot(s) * (RK * 4);
+            const uint32_t dst = smem_lds + s * WREGION + 2 * RSLOT + (4 * wave) * 1024;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const char* src = wsrc_w + (size_t)rot(s) * RW_TILE;
-        static_for<0, 12>([&](auto fc) {
-            constexpr int f = decltype(fc)::value;
-            glds16_s<(f & 3) * 1024>(wlane, src + (f >> 2) * 4096, region_lds + s * RSLOT + (f >> 2) * 4096);
+            for (int q = 0; q < 4; ++q) glds16_s<0>(voffx[q] < xmax ? voffx[q] : xmax, src, dst + q * 1024);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const char* src = wsrc_w + (size_t)rot(s) * RW_TILE;
+            static_for<0, 12>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                glds16_s<(f & 3) * 1024>(wlane, src + (f >> 2) * 4096, region_lds + s * RSLOT + (f >> 2) * 4096);
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        static_for<0, 8>([&](auto pc) {                               // k-tile 0 of the first tile -> a[0], unpipelined
+            constexpr int pr = decltype(pc)::value, i = pr >> 1, kk = pr & 1;
+            lds_read16<0>(tmp[0][0], va[kk][0] + roff[i]);
+            lds_read16<0>(tmp[0][1], va[kk][1] + roff[i]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tmp[0][0]), "+v"(tmp[0][1]) : : "memory");
+            cvt8(a[0][i][kk], tmp[0][0], tmp[0][1]);
+            if constexpr (i == 0) stats(tmp[0][0], tmp[0][1]);
         });
     }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    static_for<0, 8>([&](auto pc) {                                   // k-tile 0 -> a[0], unpipelined
-        constexpr int pr = decltype(pc)::value, i = pr >> 1, kk = pr & 1;
-        lds_read16<0>(tmp[0][0], va[kk][0] + roff[i]);
-        lds_read16<0>(tmp[0][1], va[kk][1] + roff[i]);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tmp[0][0]), "+v"(tmp[0][1]) : : "memory");
-        cvt8(a[0][i][kk], tmp[0][0], tmp[0][1]);
-    });
     uint32_t x00 = va[0][0], x01 = va[0][1], x10 = va[1][0], x11 = va[1][1];    // slot 0; every k-step advances them first
     bf16x8 b[3];
     lds_read16<0>(b[0], ring_lds);                                    // B fragments 0, 1 of k-step 0
     lds_read16<1024>(b[1], ring_lds);
+    int nflat = 0;                                                    // k-steps done by this workgroup, mod 4: the x ring phase
 
     // One k-step.  PAR = kt & 1: the W' ring half and the A-fragment set in use.  12 groups: B fragment g (column tile g / 2,
     // kk = g & 1) x the 4 row tiles = 4 MFMAs.  One wave per SIMD: whatever else the wave issues has to fit the MFMA shadow
@@ -214,26 +217,36 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
     //   gap 3  read B fragment g + 2 (groups 10, 11: fragments 0, 1 of the next step) into the 3-deep register ring.
     // ONE hand-counted wait per group, at its top (both queues complete in order): kVm[g] = VMEM operations issued after the
     // ring slot that gap 3 will read was refilled; kLgTop[g] = LDS operations issued after fragment g (the pair for gap 0 is
-    // older).  M0 (LDS-DMA destination) is written a gap ahead of its use instead of padding with s_nop.
+    // older).  Operations the count does not know (the epilogue's stores and loads) only make a wait longer, never too short:
+    // loads complete in order.  M0 (LDS-DMA destination) is written a gap ahead of its use instead of padding with s_nop.
+    const char* xsrc_n = xsrc;           // rows of this workgroup's next tile (its own again when there is none: harmless re-reads)
+    uint32_t xmax_n = xmax;
     auto step = [&](auto parc, int kt) {
         constexpr int PAR = decltype(parc)::value;
         constexpr int kVm[12] = {29, 29, 29, 29, 29, 29, 28, 27, 26, 26, 27, 28};
         constexpr int kLgTop[12] = {1, 3, 3, 3, 3, 3, 3, 3, 3, 1, 1, 1};
-        asm volatile("s_barrier" ::: "memory");   // all waves are done with slot kt & 3; every quarter of k-tile kt + 1 has landed
-        {   // A-fragment read addresses move on to ring slot (kt + 1) & 3
-            const int adv = ((kt + 1) & 3) ? WREGION : -3 * WREGION;
+        asm volatile("s_barrier" ::: "memory");   // all waves are done with x slot n & 3; every quarter of the next k-tile has landed
+        const int n = nflat + kt;
+        {   // A-fragment read addresses move on to ring slot (n + 1) & 3
+            const int adv = ((n + 1) & 3) ? WREGION : -3 * WREGION;
             x00 += adv, x01 += adv, x10 += adv, x11 += adv;
         }
         const uint32_t wdst = region_lds + PAR * RSLOT;
         const char* wnext = wsrc_w + (size_t)rot(kt + 2 < nk ? kt + 2 : kt + 2 - nk) * RW_TILE;
         const char* wn1 = wnext + 4096;
         const char* wn2 = wnext + 8192;
-        const char* xnext = xsrc + (size_t)rot(kt + 4 < nk ? kt + 4 : kt + 4 - nk) * (RK * 4);
-        const uint32_t xdst = smem_lds + (kt & 3) * WREGION + 2 * RSLOT + (4 * wave) * 1024;
+        const bool over = kt + 4 >= nk;
+        const char* xnext = (over ? xsrc_n : xsrc) + (size_t)rot(over ? kt + 4 - nk : kt + 4) * (RK * 4);
+        const uint32_t xm = over ? xmax_n : xmax;
+        const uint32_t xdst = smem_lds + (n & 3) * WREGION + 2 * RSLOT + (4 * wave) * 1024;
         static_for<0, 12>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int j = g >> 1, kk = g & 1;
-            asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(%2)" : "+v"(b[g % 3]) : "n"(kVm[g]), "n"(kLgTop[g]) : "memory");
+            // (the pair converted in gap 0 is named too: its plain-C++ readers - the LayerNorm sums - must not be scheduled above the wait)
+            asm volatile("s_waitcnt vmcnt(%3) lgkmcnt(%4)"
+                         : "+v"(b[g % 3]), "+v"(tmp[g & 1][0]), "+v"(tmp[g & 1][1])
+                         : "n"(kVm[g]), "n"(kLgTop[g])
+                         : "memory");
             if constexpr (j < 4) mfma_agpr(acc[0][j], a[PAR][0][kk], b[g % 3]); else mfma_vgpr(acc[0][j], a[PAR][0][kk], b[g % 3]);
             if constexpr (g >= 2 && g <= 9) {                        // gap 0
                 constexpr int pr = g - 2, pi = pr >> 1, pk = pr & 1;
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
                 lds_read16<0>(tmp[g & 1][0], (kk ? x10 : x00) + roff[g >> 1]);
                 lds_read16<0>(tmp[g & 1][1], (kk ? x11 : x01) + roff[g >> 1]);
             } else {
-                glds16_m<0>(voffx[g - 8], xnext);
+                glds16_m<0>(voffx[g - 8] < xm ? voffx[g - 8] : xm, xnext);
                 glds_m0(wdst + 2 * 4096);
             }
             if constexpr (j < 4) mfma_agpr(acc[2][j], a[PAR][2][kk], b[g % 3]); else mfma_vgpr(acc[2][j], a[PAR][2][kk], b[g % 3]);
@@ -257,91 +270,126 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
             else lds_read16<(PAR ^ 1) * RSLOT + (g - 10) * 1024>(b[(g + 2) % 3], ring_lds);
         });
     };
-    if constexpr (STAMP) { ts[2] = __builtin_amdgcn_s_memtime(); ts[3] = __builtin_amdgcn_s_memrealtime(); }
-    for (int kt = 0; kt < nk; kt += 2) {          // nk is even (entry point)
-        step(std::integral_constant<int, 0>{}, kt);
-        step(std::integral_constant<int, 1>{}, kt + 1);
-    }
-    float csn[6], bbn[6];                  // issued here: in flight during the drain and the statistics exchange
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const uint32_t off = (wave * RWC + 32 * j + (lane & 31)) * 4;
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(csn[j]) : "v"(off), "s"(p.cs) : "memory");
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(bbn[j]) : "v"(off), "s"(p.bb) : "memory");
-    }
-    float sum = sum2[0] + sum2[1], sq = sq2[0] + sq2[1];
-    if constexpr (STAMP) { ts[4] = __builtin_amdgcn_s_memtime(); ts[5] = __builtin_amdgcn_s_memrealtime(); }
-    // the re-loads past the end are still landing in the rings, which become staging space below
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\ts_nop 15\n\ts_nop 15"
-                 : "+v"(csn[0]), "+v"(csn[1]), "+v"(csn[2]), "+v"(csn[3]), "+v"(csn[4]), "+v"(csn[5]), "+v"(bbn[0]), "+v"(bbn[1]),
-                   "+v"(bbn[2]), "+v"(bbn[3]), "+v"(bbn[4]), "+v"(bbn[5])
-                 :
-                 : "memory");
-    float* s_mean = reinterpret_cast<float*>(smem + RSTAT);
-    float* s_rstd = s_mean + RM;
 
-    // LayerNorm statistics of the wave's own row tile: the two lane halves hold the two 8-float chunks of every 16 k
-    sum += __shfl_xor(sum, 32);
-    sq += __shfl_xor(sq, 32);
-    if (lane < 32) {
-        const float mean = sum / p.K;
-        const float var = fmaxf(sq / p.K - mean * mean, 0.f);
-        s_mean[32 * wave + lane] = mean;
-        s_rstd[32 * wave + lane] = rsqrtf(var + p.eps);
-    }
-    __syncthreads();
-
-    // epilogue: wave w writes columns [192 w, 192 w + 192) = branch w / 2, columns (w & 1) * 192 ..  One wave per SIMD: nothing
-    // hides a wait, so every operand is fetched in batches ahead of its use (the first version read the row statistics one
-    // ds_read_b32 + wait at a time: 50k cycles per tile, a sixth of the kernel)
-    float* stg = reinterpret_cast<float*>(region);                   // 32 x RSP floats = 25.6 KiB of the wave's 40 KiB
-    float* outb = p.y[wave >> 1] + (wave & 1) * RWC + (size_t)m0 * kHidden;
-    const bool relu = p.relu, full = m0 + RM <= p.M;
+    const bool relu = p.relu;
     const int hrow = 4 * (lane >> 5);
-    float* wr = stg + hrow * RSP + (lane & 31);
-    const float* rd = stg + (lane >> 4) * RSP + 4 * (lane & 15);
-    float* gw = outb + (size_t)(lane >> 4) * kHidden + 4 * (lane & 15);
+    uint32_t vo[4];                      // output byte offsets of the lane's 4 rows of an accumulator register group
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ti = (i + wave) & 3;                               // the row tile behind the wave's accumulators acc[i][..]
-        f32x4 mean4[4], rstd4[4];                                    // rows 32 ti + 8 g + hrow + {0..3}: accumulator registers 4 g ..
+    for (int e = 0; e < 4; ++e) vo[e] = (uint32_t)((hrow + e) * (kHidden * 4) + ((wave & 1) * RWC + (lane & 31)) * 4);
+    const uint32_t coff = (wave * RWC + (lane & 31)) * 4;
+    bool first = true;
+
+    for (;;) {
+        const long tnext = tile + gridDim.x;
+        const bool more = tnext < ntiles;
+        xsrc_n = more ? tile_src(tnext) : xsrc;
+        xmax_n = more ? tile_maxoff(tnext) : xmax;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            mean4[g] = *reinterpret_cast<const f32x4*>(s_mean + 32 * ti + 8 * g + hrow);
-            rstd4[g] = *reinterpret_cast<const f32x4*>(s_rstd + 32 * ti + 8 * g + hrow);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if constexpr (STAMP) if (first) { ts[2] = __builtin_amdgcn_s_memtime(); ts[3] = __builtin_amdgcn_s_memrealtime(); }
+        for (int kt = 0; kt < nk; kt += 2) {      // nk is even (entry point)
+            step(std::integral_constant<int, 0>{}, kt);
+            // The conversions of the tile's LAST k-step belong to the next tile (its k-tile 0): the sums of this tile are taken
+            // before it.  (Its own k-tile 0 was converted by the previous tile's last step, or by the prologue.)
+            const bool last = kt + 2 >= nk;
+            fsum2 = last ? sum2 : fsum2, fsq2 = last ? sq2 : fsq2;
+            sum2 = last ? f32x2{0.f, 0.f} : sum2, sq2 = last ? f32x2{0.f, 0.f} : sq2;
+            step(std::integral_constant<int, 1>{}, kt + 1);
         }
+        nflat = (nflat + nk) & 3;
+        if constexpr (STAMP) if (first) { ts[4] = __builtin_amdgcn_s_memtime(); ts[5] = __builtin_amdgcn_s_memrealtime(); }
+
+        // ---- tile boundary.  The rings already hold (or are receiving) the next tile's first k-tiles; the A fragments of its
+        // k-step 0 are converted.  x slot nflat & 3 is free from the barrier below until group 8 of the next k-step: the row
+        // statistics cross the waves through it.
+        float csn[6], bbn[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < 6; ++j) {
+            asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(csn[j]) : "v"(coff), "s"(p.cs), "i"(128 * j) : "memory");
+            asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(bbn[j]) : "v"(coff), "s"(p.bb), "i"(128 * j) : "memory");
+        }
+        float* s_mean = reinterpret_cast<float*>(smem + (nflat & 3) * WREGION + 2 * RSLOT);
+        float* s_rstd = s_mean + RM;
+        float sum = fsum2[0] + fsum2[1], sq = fsq2[0] + fsq2[1];
+        sum += __shfl_xor(sum, 32);       // the two lane halves hold the two 8-float chunks of every 16 k
+        sq += __shfl_xor(sq, 32);
+        asm volatile("s_barrier" ::: "memory");                       // every wave has read the slot's k-tile
+        if (lane < 32) {
+            const float mean = sum / p.K;
+            const float var = fmaxf(sq / p.K - mean * mean, 0.f);
+            s_mean[32 * wave + lane] = mean;
+            s_rstd[32 * wave + lane] = rsqrtf(var + p.eps);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\ts_nop 15\n\ts_nop 15"
+                     : "+v"(csn[0]), "+v"(csn[1]), "+v"(csn[2]), "+v"(csn[3]), "+v"(csn[4]), "+v"(csn[5]), "+v"(bbn[0]), "+v"(bbn[1]),
+                       "+v"(bbn[2]), "+v"(bbn[3]), "+v"(bbn[4]), "+v"(bbn[5])
+                     :
+                     : "memory");
+
+        // epilogue: wave w writes columns [192 w, 192 w + 192) = branch w / 2, columns (w & 1) * 192 .. straight from the
+        // accumulators: a register holds one column of 2 x 4 rows; 32 lanes = one 128-byte row segment per store.  No LDS (it is
+        // full of the next tile), no wait inside (one wave per SIMD: nothing would hide it).
+        const long m0 = tile * RM;
+        const bool full = m0 + RM <= p.M;
+        const char* ybase = reinterpret_cast<const char*>(((wave >> 1) ? p.y[1] : p.y[0]) + (size_t)m0 * kHidden);
+        auto epilogue = [&](auto fullc) {
+            constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = rstd4[r >> 2][r & 3] * (acc[i][j][r] - mean4[r >> 2][r & 3] * csn[j]) + bbn[j];
-                if (relu) v = fmaxf(v, 0.f);
-                wr[((r & 3) + 8 * (r >> 2)) * RSP + 32 * j] = v;
+            for (int i = 0; i < 4; ++i) {
+                const int ti = (i + wave) & 3;                       // the row tile behind the wave's accumulators acc[i][..]
+                const char* yt = ybase + (size_t)(32 * ti) * (kHidden * 4);
+                static_for<0, 4>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    const char* yg = yt + g * 8 * (kHidden * 4);
+                    // rows 32 ti + 8 g + hrow + {0..3} = accumulator registers 4 g .. 4 g + 3 (all lanes of a half read one address)
+                    const f32x4 mean4 = *reinterpret_cast<const f32x4*>(s_mean + 32 * ti + 8 * g + hrow);
+                    const f32x4 rstd4 = *reinterpret_cast<const f32x4*>(s_rstd + 32 * ti + 8 * g + hrow);
+                    static_for<0, 4>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        float v[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            float t;     // AGPR accumulators are read where they are used (left to itself hipcc copied 238 of them ahead of the loop and spilled)
+                            if (j < 4) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[i][j][4 * g + e]));
+                            else t = acc[i][j][4 * g + e];
+                            v[j] = rstd4[e] * (t - mean4[e] * csn[j]) + bbn[j];
+                            if (relu) v[j] = fmaxf(v[j], 0.f);
+                        }
+                        if (FULL || m0 + 32 * ti + 8 * g + hrow + e < p.M) {
+                            gstore32<0>(vo[e], v[0], yg);
+                            gstore32<128>(vo[e], v[1], yg);
+                            gstore32<256>(vo[e], v[2], yg);
+                            gstore32<384>(vo[e], v[3], yg);
+                            gstore32<512>(vo[e], v[4], yg);
+                            gstore32<640>(vo[e], v[5], yg);
+                        }
+                    });
+                });
             }
-        // the wave's own staging region and LDS operations of one wave execute in order: no barrier, no wait
-        f32x4 o[24];
-#pragma unroll
-        for (int it = 0; it < 24; ++it)                              // it = 8 cg + rg: rows 4 rg + lane / 16, float4 column 16 cg + lane % 16
-            o[it] = *reinterpret_cast<const f32x4*>(rd + 4 * (it & 7) * RSP + 64 * (it >> 3));
-        float* g = gw + (size_t)(32 * ti) * kHidden;
-        if (full) {
-#pragma unroll
-            for (int it = 0; it < 24; ++it) *reinterpret_cast<f32x4*>(g + (size_t)(4 * (it & 7)) * kHidden + 64 * (it >> 3)) = o[it];
-        } else {
-#pragma unroll
-            for (int it = 0; it < 24; ++it)
-                if (m0 + 32 * ti + 4 * (it & 7) + (lane >> 4) < p.M)
-                    *reinterpret_cast<f32x4*>(g + (size_t)(4 * (it & 7)) * kHidden + 64 * (it >> 3)) = o[it];
-        }
+        };
+        if (full) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
+        if constexpr (STAMP) if (first) { ts[6] = __builtin_amdgcn_s_memtime(); ts[7] = __builtin_amdgcn_s_memrealtime(); }
+        first = false;
+        if (!more) break;
+        tile = tnext;
+        xsrc = xsrc_n;
+        xmax = xmax_n;
     }
-    if constexpr (STAMP) {               // s_memtime (shader clock) / s_memrealtime (100 MHz): start, loop start, loop end, end; XCC id
-        ts[6] = __builtin_amdgcn_s_memtime(); ts[7] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // LDS-DMAs of the look-ahead must not outlive the workgroup
+    if constexpr (STAMP) {      // s_memtime (shader clock) / s_memrealtime (100 MHz): start, first loop start / end, first epilogue end, end
+        ts[8] = __builtin_amdgcn_s_memtime(); ts[9] = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
-            unsigned long long* o = p.stamps + (size_t)blockIdx.x * 9;
-            for (int i = 0; i < 8; ++i) o[i] = ts[i];
+            unsigned long long* o = p.stamps + (size_t)blockIdx.x * 12;
+            for (int i = 0; i < 10; ++i) o[i] = ts[i];
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            o[8] = xcc & 0xf;
+            o[10] = xcc & 0xf;
+            o[11] = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
         }
     }
 }
@@ -361,7 +409,14 @@ static int launch_rows128(const float* x, const void* Wfrag, const float* cs, co
     if (((uintptr_t)x | (uintptr_t)y0 | (uintptr_t)y1 | (uintptr_t)Wfrag) & 15) { set_error("in_proj_bf16_rows128: unaligned buffer"); return DLDKD_EINVAL; }
     Rows128Args p{x, (const char*)Wfrag, cs, bb, {y0, y1}, M, K, eps, relu != 0, stamps};
     constexpr int lds = 4 * WREGION;            // all 160 KiB
-    const dim3 grid((unsigned)((M + RM - 1) / RM));
+    static int n_cu = 0;                        // one persistent workgroup per CU (all 160 KiB of LDS)
+    if (!n_cu) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu = v;
+    }
+    const long ntiles = (M + RM - 1) / RM;
+    const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));
     if (stamps) {
         static const bool ok = hipFuncSetAttribute((const void*)in_proj_rows128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
         (void)ok;
@@ -381,7 +436,7 @@ extern "C" int dldkd_in_proj_bf16_rows128(const float* x, const void* Wfrag, con
 
 extern "C" int dldkd_in_proj_bf16_rows128_ok(int K) { return K >= 4 * RK && K % (2 * RK) == 0 && (long)127 * K * 4 + 128 <= 0xFFFFFFFFL; }
 
-// Diagnostics: the same kernel with clock stamps; stamps = 9 x u64 per 128-row workgroup (tools/k4_timeline.py).
+// Diagnostics: the same kernel with clock stamps; stamps = 12 x u64 per workgroup (tools/k4_timeline.py).
 extern "C" int dldkd_debug_in_proj_rows128_timeline(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0,
                                                     float* y1, long M, int K, float eps, int relu, unsigned long long* stamps,
                                                     void* stream) {

@@ -202,8 +202,9 @@ int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, 
 int dldkd_in_proj_bf16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                long M, int K, float eps, int relu, void* stream);
 int dldkd_in_proj_bf16_rows128_ok(int K);
-/* Diagnostics (tools/k4_timeline.py): the same launch, plus 9 u64 per 128-row workgroup in `stamps`: s_memtime / s_memrealtime
- * at kernel start, k-loop start, k-loop end, kernel end, and the XCC id. */
+/* Diagnostics (tools/k4_timeline.py): the same launch, plus 12 u64 per workgroup in `stamps` (size it for ceil(M / 128)
+ * workgroups; the kernel is persistent and uses fewer): s_memtime / s_memrealtime at kernel start, first k-loop start / end, first
+ * epilogue end, kernel end; the XCC id; the number of tiles the workgroup did. */
 int dldkd_debug_in_proj_rows128_timeline(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                          long M, int K, float eps, int relu, unsigned long long* stamps, void* stream);
 

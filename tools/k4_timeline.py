@@ -19,7 +19,7 @@ from dldkd_amd import native
 L = native.lib()
 fo = f.get()
 ntile = (M + 127) // 128
-stamps = torch.zeros(ntile, 9, dtype=torch.int64, device="cuda:0")
+stamps = torch.zeros(ntile, 12, dtype=torch.int64, device="cuda:0")      # one row per (persistent) workgroup; unused rows stay 0
 ys = [torch.empty(M, 384, device="cuda:0") for _ in range(2)]
 for _ in range(20):
     native.check(L.dldkd_debug_in_proj_rows128_timeline(native.ptr(x), native.ptr(fo.Wf), native.ptr(fo.cs), native.ptr(fo.bb),
@@ -27,20 +27,17 @@ for _ in range(20):
                                                         native.stream()), "timeline")
 torch.cuda.synchronize()
 raw = stamps.cpu().numpy()
+raw = raw[raw[:, 1] != 0]
 t0 = raw[:, 1].min()
-rt = (raw[:, [1, 3, 5, 7]] - t0) / 100.0      # us (100 MHz)
-cyc = raw[:, [2, 4, 6]] - raw[:, [0, 2, 4]]
+rt = (raw[:, [1, 3, 5, 7, 9]] - t0) / 100.0      # us (100 MHz): start, first loop start, first loop end, first epilogue end, end
+cyc = raw[:, [2, 4, 6, 8]] - raw[:, [0, 2, 4, 6]]
 dur = rt[:, 1:] - rt[:, :-1]
-print("tiles", len(raw), "kernel span us", rt[:, 3].max())
-print("clock GHz (loop): median", np.median(cyc[:, 1] / dur[:, 1]) / 1e3)
-for name, i in (("prologue", 0), ("loop", 1), ("epilogue", 2)):
-    print(f"{name:9s} us: median {np.median(dur[:, i]):8.2f}  p10 {np.percentile(dur[:, i], 10):8.2f}  p90 {np.percentile(dur[:, i], 90):8.2f}   cycles median {np.median(cyc[:, i]):10.0f}")
-order = np.argsort(rt[:, 0])
-print("first 6 WG starts", rt[order[:6], 0], " last 6 ends", np.sort(rt[:, 3])[-6:])
-xcc = raw[:, 8] & 0xf
-print("tiles per XCC", np.bincount(xcc.astype(int)))
-late = rt[:, 0] > 1.0
-print("start times of later WGs: gaps after a predecessor ends -> (not tracked); loop us by start decile:")
-for q in range(0, 100, 20):
-    sel = (rt[:, 0] >= np.percentile(rt[:, 0], q)) & (rt[:, 0] <= np.percentile(rt[:, 0], q + 20))
-    print(f"   start {q}-{q+20}%: loop median {np.median(dur[sel, 1]):.2f} us")
+ntl = raw[:, 11]
+print("workgroups", len(raw), "tiles per workgroup", int(ntl.min()), "-", int(ntl.max()), " kernel span us", rt[:, 4].max())
+print("clock GHz (first loop): median", np.median(cyc[:, 1] / dur[:, 1]) / 1e3)
+for name, i in (("prologue", 0), ("first loop", 1), ("first epilogue", 2)):
+    print(f"{name:15s} us: median {np.median(dur[:, i]):8.2f}  p10 {np.percentile(dur[:, i], 10):8.2f}  p90 {np.percentile(dur[:, i], 90):8.2f}   cycles median {np.median(cyc[:, i]):10.0f}")
+rest = (rt[:, 4] - rt[:, 3]) / np.maximum(ntl - 1, 1)
+print(f"later tiles     us per tile (loop + boundary): median {np.median(rest):8.2f}  p10 {np.percentile(rest, 10):8.2f}  p90 {np.percentile(rest, 90):8.2f}"
+      f"   cycles median {np.median(cyc[:, 3] / np.maximum(ntl - 1, 1)):10.0f}")
+print("workgroups per XCC", np.bincount((raw[:, 10] & 0xf).astype(int)))
