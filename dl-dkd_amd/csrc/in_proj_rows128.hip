@@ -21,12 +21,18 @@
 //     24 1-KiB fragments = two k-steps of the wave's 6 column tiles.  A fragment's slot is refilled (two k-steps ahead) as soon
 //     as its ds_read has returned, so the DMA issue is spread over the step and each fragment has two full steps to land.
 //   * one s_barrier per k-step (x slot hand-over); all other waits are hand-counted: the VMEM queue of a wave holds, in issue
-//     order, 4 x pieces + 12 W' fragments per step, so "fragment f of this step has landed" is always s_waitcnt vmcnt(30).
-//     Loads and waits are asm / builtins the compiler cannot see through, so it does not drain the queue around the LDS-DMA
-//     (cdna_hip_programming.md section 5, trap (b)).
+//     order, 4 x pieces + 12 W' fragments per step, so "fragment f of this step has landed" is a fixed s_waitcnt vmcnt(26..29)
+//     (table kVm at the k-step).  Loads and waits are asm the compiler cannot see through, so it does not drain the queue around
+//     the LDS-DMA (cdna_hip_programming.md section 5, trap (b)); every register an asm load fills is named by the asm wait that
+//     covers it, or plain C++ readers could be scheduled above the wait.
 //   * LayerNorm is folded as before: out = rstd (x.W'^T - mean colsum(W')) + (W.beta + b); wave w accumulates sum / sum of
-//     squares of rows 32 w .. 32 w + 31 from the fp32 values it converts anyway.
-//   * epilogue: 32 x 192 tiles staged through the wave's (now idle) 40-KiB LDS region and written as float4 rows.
+//     squares of rows 32 w .. 32 w + 31 from the fp32 values it converts anyway.  No branch in the k-loop: every wave numbers
+//     the row tiles from its own, so "the wave's own tile" is tile 0 of the same instruction stream in all four waves.
+//   * the k-tiles are visited in an order rotated per XCD (workgroup b starts (b % 8) / 8 of the way through K): with a row
+//     stride of 3 x 4 KiB, workgroups in the same k phase kept hitting the same memory channels.
+//   * one persistent workgroup per CU: the LDS-DMA streams run through the tile boundary (the x look-ahead moves on to the next
+//     tile's rows), the row statistics cross the waves through the x slot that is free for one barrier, and the epilogue stores
+//     the accumulators straight to global memory (128-byte row segments per 32 lanes) while the next tile's k-tiles land.
 #include <type_traits>
 
 #include "common.hpp"
