@@ -191,6 +191,61 @@ class FoldedInProj:
         return self
 
 
+class FoldedInProjX3:
+    """Parity-grade counterpart of FoldedInProj for TWO LinearLayer modules (one per branch): gamma folded into the fp32
+    weights, split into three bf16 planes in the fragment order of in_proj_rows128x3_kernel; rebuilt when a parameter changes."""
+
+    def __init__(self, layers):
+        if len(layers) != 2:
+            raise ValueError("FoldedInProjX3 packs the two branches' input projections")
+        self.layers = layers
+        self.key = None
+
+    def get(self):
+        ps = []
+        for l in self.layers:
+            ps += [l.LayerNorm.weight, l.LayerNorm.bias, l.net[1].weight, l.net[1].bias]
+        key = (_PARAM_EPOCH,) + tuple((p.data_ptr(), p._version) for p in ps)
+        if key != self.key:
+            L = native.lib()
+            K = self.layers[0].net[1].weight.shape[1]
+            dev = ps[0].device
+            self.Wp = torch.empty(3 * 2 * HIDDEN * K * 2, dtype=torch.uint8, device=dev)
+            self.bb = torch.empty(2 * HIDDEN, dtype=torch.float32, device=dev)
+            for b, l in enumerate(self.layers):
+                lin = l.net[1]
+                native.check(L.dldkd_fold_ln_linear_planes(
+                    native.ptr(lin.weight.detach().contiguous()), native.ptr(lin.bias.detach()), native.ptr(l.LayerNorm.weight.detach()),
+                    native.ptr(l.LayerNorm.bias.detach()), HIDDEN, K, b * HIDDEN, native.ptr(self.Wp), native.ptr(self.bb),
+                    native.stream()), "fold_ln_linear_planes")
+            self.key, self.K = key, K
+        return self
+
+
+def in_proj_x3_ok(K):
+    return bool(native.lib().dldkd_in_proj_f32x3_rows128_ok(int(K)))
+
+
+def in_proj_x3(x, folded, relu=True):
+    """x (..., K) fp32 -> [branch 0, branch 1] (..., 384) fp32: LayerNorm + Linear (+ ReLU) of both branches with fp32-grade
+    products, one pass over x (after a row-statistics pass)."""
+    L = native.lib()
+    f = folded.get()
+    K = x.shape[-1]
+    if K != f.K:
+        raise native.NativeError(f"in_proj_x3: x has {K} features, weights expect {f.K}")
+    x2 = _chk(x.reshape(-1, K), "in_proj_x3.x")
+    M = x2.shape[0]
+    stats = torch.empty(2, M, dtype=torch.float32, device=x.device)
+    native.check(L.dldkd_row_meanrstd_f32(native.ptr(x2), native.ptr(stats[0]), native.ptr(stats[1]), M, K, LN_EPS, native.stream()),
+                 "row_meanrstd")
+    ys = [torch.empty(M, HIDDEN, dtype=torch.float32, device=x.device) for _ in range(2)]
+    native.check(L.dldkd_in_proj_f32x3_rows128(native.ptr(x2), native.ptr(stats[0]), native.ptr(stats[1]), native.ptr(f.Wp),
+                                               native.ptr(f.bb), native.ptr(ys[0]), native.ptr(ys[1]), M, K, int(relu),
+                                               native.stream()), "in_proj_f32x3_rows128")
+    return [y.view(*x.shape[:-1], HIDDEN) for y in ys]
+
+
 class PackedLinear:
     """bf16 MFMA-fragment-order copy of 1-3 nn.Linear modules with the same in_features and 384 outputs each (one
     q|k|v block, or a single dense layer) for `linear_rows`; rebuilt when a parameter changes (tensor._version)."""

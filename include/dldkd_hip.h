@@ -202,6 +202,21 @@ int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, 
 int dldkd_in_proj_bf16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                long M, int K, float eps, int relu, void* stream);
 int dldkd_in_proj_bf16_rows128_ok(int K);
+/* PARITY-grade two-branch input projection (in_proj_rows128x3.hip): y = ReLU(LayerNorm(x) W^T + b) with fp32-grade products
+ * (three bf16 planes per operand, six MFMAs per product: the scheme of dldkd_gemm_f32x3), both branches in one pass.
+ *   dldkd_row_meanrstd_f32: mean[M], rstd[M] of the rows exactly as dldkd_layernorm_f32 computes them (D % 4 == 0, D <= 4096).
+ *   dldkd_fold_ln_linear_planes: W' = gamma (.) W split into three bf16 planes in the kernel's fragment order
+ *       (Wplanes: 3 * 768 * K * 2 bytes for the two branches, 16-byte aligned; call once per branch with n_offset 0 / 384),
+ *       bb[n_offset + n] = W[n].beta + bias[n].
+ *   dldkd_in_proj_f32x3_rows128: out = relu(((x - mean) * rstd) . W'^T + bb); K % 32 == 0, 64 <= K <= 4096
+ *       (dldkd_in_proj_f32x3_rows128_ok).  Replaces reference LinearLayer.forward (method/model_components.py:305-312) on the
+ *       inference path of parity mode. */
+int dldkd_row_meanrstd_f32(const float* x, float* mean, float* rstd, long M, int D, float eps, void* stream);
+int dldkd_fold_ln_linear_planes(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K, int n_offset,
+                                void* Wplanes, float* bb, void* stream);
+int dldkd_in_proj_f32x3_rows128(const float* x, const float* mean, const float* rstd, const void* Wplanes, const float* bb, float* y0,
+                                float* y1, long M, int K, int relu, void* stream);
+int dldkd_in_proj_f32x3_rows128_ok(int K);
 /* Diagnostics (tools/k4_timeline.py): the same launch, plus 12 u64 per workgroup in `stamps` (size it for ceil(M / 128)
  * workgroups; the kernel is persistent and uses fewer): s_memtime / s_memrealtime at kernel start, first k-loop start / end, first
  * epilogue end, kernel end; the XCC id; the number of tiles the workgroup did. */

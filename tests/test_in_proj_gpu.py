@@ -74,6 +74,68 @@ def test_rows128_rejects_unsupported_k():
     assert rc != 0
 
 
+@pytest.mark.parametrize("K,M", [(3072, 300), (768, 1), (64, 129), (1024, 128 * 3 + 5), (4096, 77)])
+def test_parity_grade_in_proj_x3(K, M):
+    """in_proj_rows128x3_kernel (parity mode, inference): against fp64 math at the accuracy of the LayerNorm + gemm_f32x3 path
+    it replaces, and against that path; the row statistics equal the LayerNorm kernel's bit for bit."""
+    from dldkd_amd import ops, native
+    from dldkd_amd import functional as F_
+    m = _model(K, K, synth.make_params(13, K, K))
+    with torch.no_grad():                                   # non-trivial gamma / beta
+        for l in (m.visual_input_proj, m.exp_visual_input_proj):
+            g = torch.Generator().manual_seed(K)
+            l.LayerNorm.weight.add_((0.2 * torch.randn(K, generator=g)).to(DEV))
+            l.LayerNorm.bias.add_((0.2 * torch.randn(K, generator=g)).to(DEV))
+    g = torch.Generator().manual_seed(K + M)
+    x = torch.nn.functional.normalize(torch.randn(M, K, generator=g).abs() + 0.1 * torch.randn(M, K, generator=g), dim=-1).to(DEV)
+    assert ops.in_proj_x3_ok(K)
+    folded = ops.FoldedInProjX3([m.visual_input_proj, m.exp_visual_input_proj])
+    with torch.no_grad():
+        ys = ops.in_proj_x3(x, folded)
+        for y, l in zip(ys, (m.visual_input_proj, m.exp_visual_input_proj)):
+            old = l(x)                                      # LayerNorm kernel + gemm_f32x3 (+ bias, ReLU)
+            xn = torch.nn.functional.layer_norm(x.double(), (K,), l.LayerNorm.weight.double(), l.LayerNorm.bias.double(), 1e-5)
+            ref = torch.relu(xn @ l.net[1].weight.double().t() + l.net[1].bias.double())
+            scale = max(1.0, ref.abs().max().item())
+            assert torch.isfinite(y).all()
+            assert (y.double() - ref).abs().max().item() <= 6e-6 * scale, ((y.double() - ref).abs().max().item(), scale)
+            assert (y - old).abs().max().item() <= 8e-6 * scale
+    # row statistics: the LayerNorm kernel's own numbers (LayerNorm with gamma = 1, beta = 0 reproduces (x - mean) * rstd)
+    L = native.lib()
+    st = torch.empty(2, M, device=DEV)
+    native.check(L.dldkd_row_meanrstd_f32(native.ptr(x), native.ptr(st[0]), native.ptr(st[1]), M, K, 1e-5, native.stream()), "stats")
+    xhat = F_.layernorm(x, torch.ones(K, device=DEV), torch.zeros(K, device=DEV))
+    assert torch.equal(xhat, (x - st[0][:, None]) * st[1][:, None])
+    with torch.no_grad():
+        # batch-invariant bit for bit: a row's result does not depend on its position in the batch
+        if M > 130:
+            sub = ops.in_proj_x3(x[129:].contiguous(), folded)
+            assert torch.equal(sub[0], ys[0][129:]) and torch.equal(sub[1], ys[1][129:])
+        # a parameter change re-folds the planes
+        m.visual_input_proj.net[1].bias.add_(1.0)
+        assert (ops.in_proj_x3(x, folded)[0] - ys[0]).abs().max() > 0.5
+
+
+def test_parity_encode_uses_the_fused_projection_and_matches_the_unfused_one():
+    """encode_context / encode_query in parity mode, inference: fused_parity_input_proj on (default) vs off."""
+    m = _model(3072, 768, synth.make_params(17, 3072, 768))
+    g = torch.Generator().manual_seed(3)
+    v = torch.nn.functional.normalize(torch.randn(5, 40, 3072, generator=g).abs(), dim=-1).to(DEV)
+    vm = torch.ones(5, 40, device=DEV)
+    q = torch.nn.functional.normalize(torch.randn(7, 12, 768, generator=g), dim=-1).to(DEV)
+    qm = torch.ones(7, 12, device=DEV)
+    with torch.no_grad():
+        assert m._use_fast(v) and m._use_fast(q)
+        a = m.encode_context(v, vm) + m.encode_query(q, qm)
+        m.fused_parity_input_proj = False
+        assert not m._use_fast(v)
+        b = m.encode_context(v, vm) + m.encode_query(q, qm)
+    for x, y in zip(a, b):
+        assert (x - y).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+    m.train()
+    assert not m._use_fast(v)
+
+
 def test_fast_path_keeps_rank_parity():
     """End to end (towers + scorer) with fast_input_proj on: R@1/5/10/100 vs the fp32 oracle within the gate."""
     from dldkd_amd import eval as ev
