@@ -30,25 +30,32 @@
 
 namespace dldkd {
 
-constexpr int YM = 128, YWC = 192;
-constexpr int YHALF = 18 * 1024;            // W' planes per wave per half-step: [6 column tiles][3 planes][64 lanes][16 B]
-constexpr int YWRING = 2 * YHALF;           // 36 KiB per wave
+// JT = 32-column tiles per wave: 6 (N = 768: two 384-wide outputs) or 3 (N = 384)
+constexpr int YM = 128;
 constexpr int YXHALF = YM * 64;             // x half tile: 128 rows x 16 fp32 = 8 KiB
-constexpr int YXBASE = 4 * YWRING;          // x halves behind the four W' rings
-constexpr int YLDS = YXBASE + 2 * YXHALF;   // 160 KiB
-constexpr int YW_STEP = 768 * 32 * 2 * 3;   // bytes of W' planes per 32 k: [kk 2][wave 4][column tile 6][plane 3][1 KiB]
-constexpr int YSP = 200;                    // epilogue staging pitch (floats)
+template <int JT>
+struct YCfg {
+    static constexpr int NF = 3 * JT;               // W' fragments per wave per half-step: [JT column tiles][3 planes]
+    static constexpr int WC = 32 * JT;              // columns per wave
+    static constexpr int HALF = NF * 1024;          // bytes of them
+    static constexpr int WRING = 2 * HALF;          // ring per wave: two half-steps (36 / 18 KiB)
+    static constexpr int XBASE = 4 * WRING;         // x halves behind the four W' rings
+    static constexpr int LDS = XBASE + 2 * YXHALF;  // 160 / 88 KiB
+    static constexpr int W_STEP = 2 * 4 * HALF;     // bytes of W' planes per 32 k: [kk 2][wave 4][column tile JT][plane 3][1 KiB]
+    static constexpr int SP = WC + 8;               // epilogue staging pitch (floats): the two lane halves hit disjoint banks
+};
 
 struct Rows128X3Args {
     const float* x;
     const float* mean;     // [M]
     const float* rstd;     // [M]
-    const char* Wp;        // [K / 32][YW_STEP]
-    const float* bb;       // [768]
-    float* y[2];           // columns [0, 384) -> y[0], [384, 768) -> y[1]; row stride 384
+    const char* Wp;        // [K / 32][W_STEP]
+    const float* bb;       // [N]
+    float* y[2];           // columns [0, 384) -> y[0], [384, 768) -> y[1]; row stride ldy
     long M;
     int K;
     int relu;
+    int ldy;
 };
 
 typedef float f32x2y __attribute__((ext_vector_type(2)));
@@ -88,7 +95,10 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& h, unsi
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2y{s0, s1}, bf2));
 }
 
+template <int JT>
 __global__ __launch_bounds__(256, 1) void in_proj_rows128x3_kernel(const Rows128X3Args p) {
+    using C = YCfg<JT>;
+    constexpr int YHALF = C::HALF, YWRING = C::WRING, YXBASE = C::XBASE, YW_STEP = C::W_STEP, YSP = C::SP, YWC = C::WC, NF = C::NF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,15 +136,15 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128x3_kernel(const Rows128
     for (int i = 0; i < 4; ++i) {
         long r = m0 + 32 * i + (lane & 31);
         if (r > p.M - 1) r = p.M - 1;
-        mean_[i] = p.mean[r];
-        rstd_[i] = p.rstd[r];
+        mean_[i] = p.mean ? p.mean[r] : 0.f;         // no statistics: a plain linear layer ((v - 0) * 1 is exact)
+        rstd_[i] = p.rstd ? p.rstd[r] : 1.f;
     }
 
-    f32x16 acc[4][6];
+    f32x16 acc[4][JT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < JT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     u32x4y ap[2][3];         // A planes (h, m, l) of the row tile in use [i & 1] and of the one being converted
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128x3_kernel(const Rows128
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const char* src = wsrc_w + (size_t)rot(0) * YW_STEP + kk * 4 * YHALF;
-        static_for_y<0, 18>([&](auto fc) {
+        static_for_y<0, NF>([&](auto fc) {
             constexpr int f = decltype(fc)::value;
             if constexpr ((f & 3) == 0) { y_m0(ring_base + kk * YHALF + (f >> 2) * 4096); asm volatile("s_nop 0"); }
             y_glds<(f & 3) * 1024>(wlane, src + (f >> 2) * 4096);
@@ -203,21 +213,19 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128x3_kernel(const Rows128
         static_for_y<0, 4>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int CUR = i & 1, NXT = CUR ^ 1;
-            static_for_y<0, 6>([&](auto jc) {
+            static_for_y<0, JT>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                constexpr int BC = (i * 6 + j) & 1, BN = BC ^ 1;      // 24 blocks per half-step: the parity carries over
+                constexpr int BC = (i * JT + j) & 1, BN = BC ^ 1;     // 4 JT blocks per half-step (even): the parity carries over
                 // ---- top of the block: requests for the next block
                 if constexpr (i == 3 && j == 0) {
-                    // own x pieces of the OTHER half (requested a half-step ago) have landed: 18 refills were issued after them
-                    asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
+                    // own x pieces of the OTHER half (requested a half-step ago) have landed: NF refills were issued after them
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(NF) : "memory");
                     y_m0(smem_lds + YXBASE + KK * YXHALF + (2 * wave) * 1024);
                 }
-                if constexpr (j < 5) {
-                    // planes of (i, j + 1): for i = 0 they were refilled two half-steps ago
-                    if constexpr (i == 0) {
-                        constexpr int kVm[6] = {0, 32, 29, 26, 23, 20};
-                        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kVm[j + 1]) : "memory");
-                    }
+                if constexpr (j < JT - 1) {
+                    // planes of (i, j + 1): for i = 0 they were refilled two half-steps ago, with 3 (JT - 1 - c) + (2 + NF)
+                    // operations issued since (c = j + 1)
+                    if constexpr (i == 0) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(6 * JT - 1 - 3 * (j + 1)) : "memory");
                     y_lds16<KK * YHALF + (3 * (j + 1) + 0) * 1024>(b[BN][0], ring_lds);
                     y_lds16<KK * YHALF + (3 * (j + 1) + 1) * 1024>(b[BN][1], ring_lds);
                     y_lds16<KK * YHALF + (3 * (j + 1) + 2) * 1024>(b[BN][2], ring_lds);
@@ -226,7 +234,8 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128x3_kernel(const Rows128
                     y_lds16<KK * YHALF + 1024>(b[BN][1], ring_lds);
                     y_lds16<KK * YHALF + 2048>(b[BN][2], ring_lds);
                 } else {
-                    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");  // (0, 0) of the next half-step: the other ring half
+                    // (0, 0) of the next half-step, the other ring half: 3 (JT - 1) + 2 + 3 (JT - 1) operations since its refill
+                    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(6 * JT - 4) : "memory");
                     y_lds16<(KK ^ 1) * YHALF + 0>(b[BN][0], ring_lds);
                     y_lds16<(KK ^ 1) * YHALF + 1024>(b[BN][1], ring_lds);
                     y_lds16<(KK ^ 1) * YHALF + 2048>(b[BN][2], ring_lds);
@@ -257,8 +266,8 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128x3_kernel(const Rows128
                 };
                 M(ap[CUR][2], b[BC][0]);
                 M(ap[CUR][0], b[BC][2]);
-                if constexpr (j >= 1 && j <= 4) {
-                    constexpr int e = (j - 1) >> 1, hpart = (j - 1) & 1;   // float4 e, its first / second pair
+                auto quarter = [&](auto qc) {                          // a quarter of the next row tile's conversion
+                    constexpr int q = decltype(qc)::value, e = q >> 1, hpart = q & 1;   // float4 e, its first / second pair
                     asm volatile("" : "+v"(raw[e]) : : "memory");
                     unsigned h, m, l;
                     const f32x4 v = raw[e];
@@ -267,7 +276,10 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128x3_kernel(const Rows128
                     ap[NXT][1][2 * e + hpart] = m;
                     ap[NXT][2][2 * e + hpart] = l;
                     asm volatile("" : "+v"(ap[NXT][0]), "+v"(ap[NXT][1]), "+v"(ap[NXT][2]) : : "memory");
-                }
+                };
+                constexpr int QPB = JT >= 5 ? 1 : 2;                   // quarters per block, from block 1 on
+                constexpr int q0 = (j - 1) * QPB;
+                if constexpr (j >= 1 && q0 < 4) quarter(std::integral_constant<int, q0>{});
                 if constexpr (i == 3 && j == 0) {                      // this half's x for the next k-step (M0 set after the barrier)
                     y_glds<0>(voffx[0], xnext);
                     y_m0(smem_lds + YXBASE + KK * YXHALF + (2 * wave + 1) * 1024);
@@ -275,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128x3_kernel(const Rows128
                 M(ap[CUR][1], b[BC][1]);
                 if constexpr (i == 3 && j == 0) y_glds<0>(voffx[1], xnext);
                 M(ap[CUR][1], b[BC][0]);
+                if constexpr (QPB == 2 && j >= 1 && q0 + 1 < 4) quarter(std::integral_constant<int, q0 + 1>{});
                 if constexpr (i == 3) {                                // this column tile's three ring slots are free: refill
                     // slots 3 j .. 3 j + 2 of this ring half: M0 base per 4 fragments (the immediate spans 4 KiB)
                     static_for_y<0, 3>([&](auto pc) {
@@ -300,38 +313,36 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128x3_kernel(const Rows128
     // epilogue: wave w writes columns [192 w, 192 w + 192) = branch w / 2, columns (w & 1) * 192 .., one 32-row tile at a time
     // through its own LDS region (LDS operations of one wave execute in order: no barrier, no wait)
     float* stg = reinterpret_cast<float*>(smem + wave * YWRING);      // 32 x YSP floats = 25.6 KiB of the wave's 36
-    float* outb = (wave >> 1 ? p.y[1] : p.y[0]) + (wave & 1) * YWC + (size_t)m0 * kHidden;
+    const int col0 = wave * YWC;                                       // 384 is a multiple of YWC: one output per wave
+    float* outb = (col0 >= kHidden ? p.y[1] : p.y[0]) + (col0 % kHidden) + (size_t)m0 * p.ldy;
     const bool relu = p.relu, full = m0 + YM <= p.M;
     const int hrow = 4 * (lane >> 5);
     float* wr = stg + hrow * YSP + (lane & 31);
-    const float* rd = stg + (lane >> 4) * YSP + 4 * (lane & 15);
-    float* gw = outb + (size_t)(lane >> 4) * kHidden + 4 * (lane & 15);
-    float bbn[6];
+    float bbn[JT];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) bbn[j] = p.bb[wave * YWC + 32 * j + (lane & 31)];
+    for (int j = 0; j < JT; ++j) bbn[j] = p.bb[wave * YWC + 32 * j + (lane & 31)];
+    constexpr int F4R = 8 * JT;                                        // float4 per row of the wave's column range
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < JT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r] + bbn[j];
                 if (relu) v = fmaxf(v, 0.f);
                 wr[((r & 3) + 8 * (r >> 2)) * YSP + 32 * j] = v;
             }
-        f32x4 o[24];
+        f32x4 o[4 * JT];
 #pragma unroll
-        for (int it = 0; it < 24; ++it)                              // it = 8 cg + rg: rows 4 rg + lane / 16, float4 column 16 cg + lane % 16
-            o[it] = *reinterpret_cast<const f32x4*>(rd + 4 * (it & 7) * YSP + 64 * (it >> 3));
-        float* g = gw + (size_t)(32 * i) * kHidden;
-        if (full) {
+        for (int it = 0; it < 4 * JT; ++it) {
+            const int idx = lane + 64 * it;
+            o[it] = *reinterpret_cast<const f32x4*>(stg + (idx / F4R) * YSP + 4 * (idx % F4R));
+        }
 #pragma unroll
-            for (int it = 0; it < 24; ++it) *reinterpret_cast<f32x4*>(g + (size_t)(4 * (it & 7)) * kHidden + 64 * (it >> 3)) = o[it];
-        } else {
-#pragma unroll
-            for (int it = 0; it < 24; ++it)
-                if (m0 + 32 * i + 4 * (it & 7) + (lane >> 4) < p.M)
-                    *reinterpret_cast<f32x4*>(g + (size_t)(4 * (it & 7)) * kHidden + 64 * (it >> 3)) = o[it];
+        for (int it = 0; it < 4 * JT; ++it) {
+            const int idx = lane + 64 * it;
+            const long row = m0 + 32 * i + idx / F4R;
+            if (full || row < p.M) *reinterpret_cast<f32x4*>(outb + (size_t)(32 * i + idx / F4R) * p.ldy + 4 * (idx % F4R)) = o[it];
         }
     }
 }
@@ -339,28 +350,28 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128x3_kernel(const Rows128
 // W' = gamma (.) W split into three bf16 planes in the kernel's fragment order; bb = W.beta + b.  One wave per output column.
 __global__ __launch_bounds__(256) void fold_ln_linear_planes_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                    int N, int K, int n_offset, unsigned short* __restrict__ Wp,
+                                                                    int N, int K, int n_offset, int jt, unsigned short* __restrict__ Wp,
                                                                     float* __restrict__ bb) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
-    const int ng = n_offset + n, ct = ng >> 5, col = ng & 31;          // global column tile 0..23 = 6 wave + j
-    const int w = ct / 6, j = ct % 6;
+    const int ng = n_offset + n, ct = ng >> 5, col = ng & 31;          // global column tile = jt * wave + j
+    const int w = ct / jt, j = ct % jt;
     float t = 0.f;
     for (int k = lane; k < K; k += 64) {
         const float wv = W[(size_t)n * K + k];
-        const float wf = wv * gamma[k];
+        const float wf = gamma ? wv * gamma[k] : wv;
         const unsigned short h = f32_to_bf16_bits(wf);
         const float r1 = wf - bf16_bits_to_f32(h);
         const unsigned short m = f32_to_bf16_bits(r1);
         const unsigned short l = f32_to_bf16_bits(r1 - bf16_bits_to_f32(m));
         const int kt = k >> 5, kk = (k >> 4) & 1, half = (k >> 3) & 1, e = k & 7;
         // [kt][kk][wave][j][plane][lane = 32 half + col][8]
-        const size_t base = ((((size_t)kt * 2 + kk) * 4 + w) * 6 + j) * 3;
+        const size_t base = ((((size_t)kt * 2 + kk) * 4 + w) * jt + j) * 3;
         Wp[((base + 0) * 64 + half * 32 + col) * 8 + e] = h;
         Wp[((base + 1) * 64 + half * 32 + col) * 8 + e] = m;
         Wp[((base + 2) * 64 + half * 32 + col) * 8 + e] = l;
-        t += wv * beta[k];
+        if (beta) t += wv * beta[k];
     }
     t = wave_sum(t);
     if (lane == 0) bb[ng] = t + (bias ? bias[n] : 0.f);
@@ -420,30 +431,53 @@ extern "C" int dldkd_row_meanrstd_f32(const float* x, float* mean, float* rstd, 
     return check_launch("row_meanrstd");
 }
 
-extern "C" int dldkd_fold_ln_linear_planes(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
-                                           int n_offset, void* Wplanes, float* bb, void* stream) {
-    if (N < 1 || K < 32 || (K % 32) || n_offset < 0 || n_offset + N > 768 || (n_offset % 32)) {
-        set_error("fold_ln_linear_planes: need K a multiple of 32 and columns inside [0, 768)");
+extern "C" int dldkd_pack_linear_planes(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                                       int n_offset, int n_total, void* Wplanes, float* bb, void* stream) {
+    if (N < 1 || K < 32 || (K % 32) || (n_total != 384 && n_total != 768) || n_offset < 0 || n_offset + N > n_total || (n_offset % 32) ||
+        (N % 32)) {
+        set_error("pack_linear_planes: need K a multiple of 32, n_total 384 or 768 and whole 32-column tiles inside it");
         return DLDKD_EINVAL;
     }
-    if (!W || !gamma || !beta || !Wplanes || !bb) { set_error("fold_ln_linear_planes: null pointer"); return DLDKD_EINVAL; }
+    if (!W || !Wplanes || !bb || (gamma == nullptr) != (beta == nullptr)) { set_error("pack_linear_planes: null pointer"); return DLDKD_EINVAL; }
     DLDKD_LAUNCH(fold_ln_linear_planes_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, bias, gamma, beta, N, K,
-                 n_offset, (unsigned short*)Wplanes, bb);
-    return check_launch("fold_ln_linear_planes");
+                 n_offset, n_total / 128, (unsigned short*)Wplanes, bb);
+    return check_launch("pack_linear_planes");
+}
+
+extern "C" int dldkd_fold_ln_linear_planes(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                                           int n_offset, void* Wplanes, float* bb, void* stream) {
+    if (!gamma || !beta) { set_error("fold_ln_linear_planes: null pointer"); return DLDKD_EINVAL; }
+    return dldkd_pack_linear_planes(W, bias, gamma, beta, N, K, n_offset, 768, Wplanes, bb, stream);
+}
+
+extern "C" int dldkd_linear_f32x3_rows(const float* x, const float* mean, const float* rstd, const void* Wplanes, const float* bb,
+                                       float* y0, float* y1, long M, int N, int K, int ldy, int relu, void* stream) {
+    if (M < 0 || (N != 384 && N != 768) || !dldkd_in_proj_f32x3_rows128_ok(K) || ldy < 384 || (ldy & 3)) {
+        set_error("linear_f32x3_rows: N must be 384 or 768, K a multiple of 32 in [64, 4096], ldy >= 384 (M=%ld N=%d K=%d ldy=%d)", M, N, K, ldy);
+        return DLDKD_EINVAL;
+    }
+    if (M == 0) return DLDKD_OK;
+    if (!x || !Wplanes || !bb || !y0 || (N == 768 && !y1) || (mean == nullptr) != (rstd == nullptr)) {
+        set_error("linear_f32x3_rows: null pointer");
+        return DLDKD_EINVAL;
+    }
+    if (((uintptr_t)x | (uintptr_t)y0 | (uintptr_t)y1 | (uintptr_t)Wplanes) & 15) { set_error("linear_f32x3_rows: unaligned buffer"); return DLDKD_EINVAL; }
+    Rows128X3Args p{x, mean, rstd, (const char*)Wplanes, bb, {y0, y1}, M, K, relu != 0, ldy};
+    const dim3 grid((unsigned)((M + YM - 1) / YM));
+    if (N == 768) {
+        static const bool ok = hipFuncSetAttribute((const void*)in_proj_rows128x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, YCfg<6>::LDS) == hipSuccess;
+        (void)ok;
+        DLDKD_LAUNCH(in_proj_rows128x3_kernel<6>, grid, dim3(256), YCfg<6>::LDS, (hipStream_t)stream, p);
+    } else {
+        static const bool ok = hipFuncSetAttribute((const void*)in_proj_rows128x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, YCfg<3>::LDS) == hipSuccess;
+        (void)ok;
+        DLDKD_LAUNCH(in_proj_rows128x3_kernel<3>, grid, dim3(256), YCfg<3>::LDS, (hipStream_t)stream, p);
+    }
+    return check_launch("linear_f32x3_rows");
 }
 
 extern "C" int dldkd_in_proj_f32x3_rows128(const float* x, const float* mean, const float* rstd, const void* Wplanes, const float* bb,
                                            float* y0, float* y1, long M, int K, int relu, void* stream) {
-    if (M < 0 || !dldkd_in_proj_f32x3_rows128_ok(K)) {
-        set_error("in_proj_f32x3_rows128: K must be a multiple of 32 in [64, 4096] (M=%ld K=%d)", M, K);
-        return DLDKD_EINVAL;
-    }
-    if (M == 0) return DLDKD_OK;
-    if (!x || !mean || !rstd || !Wplanes || !bb || !y0 || !y1) { set_error("in_proj_f32x3_rows128: null pointer"); return DLDKD_EINVAL; }
-    if (((uintptr_t)x | (uintptr_t)y0 | (uintptr_t)y1 | (uintptr_t)Wplanes) & 15) { set_error("in_proj_f32x3_rows128: unaligned buffer"); return DLDKD_EINVAL; }
-    Rows128X3Args p{x, mean, rstd, (const char*)Wplanes, bb, {y0, y1}, M, K, relu != 0};
-    static const bool ok = hipFuncSetAttribute((const void*)in_proj_rows128x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, YLDS) == hipSuccess;
-    (void)ok;
-    DLDKD_LAUNCH(in_proj_rows128x3_kernel, dim3((unsigned)((M + YM - 1) / YM)), dim3(256), YLDS, (hipStream_t)stream, p);
-    return check_launch("in_proj_f32x3_rows128");
+    if (!mean || !rstd) { set_error("in_proj_f32x3_rows128: null pointer"); return DLDKD_EINVAL; }
+    return dldkd_linear_f32x3_rows(x, mean, rstd, Wplanes, bb, y0, y1, M, 768, K, 384, relu, stream);
 }

@@ -142,6 +142,10 @@ class DLDKD(nn.Module):
                 if pre + "out_map" not in self._folded:
                     self._folded[pre + "out_map"] = ops.PackedLinear([lin])
                 out.append(ops.linear_rows(h, self._folded[pre + "out_map"]))
+            elif ops.rows_x3_ok(h):
+                if pre + "out_map_x3" not in self._folded:
+                    self._folded[pre + "out_map_x3"] = ops.PackedLinearX3([lin])
+                out.append(ops.linear_rows_x3(h, self._folded[pre + "out_map_x3"]))
             else:
                 out.append(F_.linear(h, lin.weight, lin.bias))
         return (out[0], out[1]) if self.double_branch else (out[0], None)

@@ -86,6 +86,10 @@ class BertSelfAttention(nn.Module):
             if attention_mask is not None:
                 mask = attention_mask.reshape(attention_mask.shape[0], -1).float().contiguous()
             return ops.attention(qkv.view(*query_states.shape[:-1], 3 * ops.HIDDEN), mask)
+        elif ops.rows_x3_ok(query_states):                        # inference, parity mode: fp32-grade full-row kernel
+            if getattr(self, "_packed_qkv_x3", None) is None:
+                self._packed_qkv_x3 = ops.PackedLinearX3([self.query, self.key, self.value])
+            qkv = ops.linear_rows_x3(query_states.float(), self._packed_qkv_x3)
         else:
             w, b = self.fused_qkv()
             qkv = F_.linear(query_states, w, b)                   # one GEMM for the three projections
@@ -109,6 +113,10 @@ class BertSelfOutput(nn.Module):
             if getattr(self, "_packed_dense", None) is None:
                 self._packed_dense = ops.PackedLinear([self.dense])
             h = ops.linear_rows(hidden_states.float(), self._packed_dense)
+        elif ops.rows_x3_ok(hidden_states):
+            if getattr(self, "_packed_dense_x3", None) is None:
+                self._packed_dense_x3 = ops.PackedLinearX3([self.dense])
+            h = ops.linear_rows_x3(hidden_states.float(), self._packed_dense_x3)
         else:
             h = F_.linear(hidden_states, self.dense.weight, self.dense.bias)
         h = F_.dropout(h, self.dropout.p, self.training)

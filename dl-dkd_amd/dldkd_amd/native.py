@@ -96,6 +96,10 @@ SIGNATURES = {
     "dldkd_in_proj_f32x3_rows128": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long,
                                              _c_int, _c_int, _c_void_p]),
     "dldkd_in_proj_f32x3_rows128_ok": (_c_int, [_c_int]),
+    "dldkd_pack_linear_planes": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p,
+                                          _c_void_p, _c_void_p]),
+    "dldkd_linear_f32x3_rows": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
+                                         _c_int, _c_int, _c_int, _c_void_p]),
     "dldkd_debug_in_proj_rows128_timeline": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long,
                                                        _c_int, _c_float, _c_int, _c_void_p, _c_void_p]),
     "dldkd_attention_fwd_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),

@@ -279,6 +279,70 @@ class PackedLinear:
         return self
 
 
+class PackedLinearX3:
+    """Three-bf16-plane copy (fragment order of in_proj_rows128x3_kernel) of 1-3 nn.Linear modules with the same in_features and
+    384 outputs each, for `linear_rows_x3` (parity mode, inference); rebuilt when a parameter changes."""
+
+    def __init__(self, linears):
+        self.linears = list(linears)
+        if not 1 <= len(self.linears) <= 3 or any(l.weight.shape[0] != HIDDEN for l in self.linears):
+            raise native.NativeError("PackedLinearX3: 1-3 linears with 384 outputs each")
+        self.key = None
+
+    def get(self):
+        ps = [t for l in self.linears for t in (l.weight, l.bias)]
+        key = (_PARAM_EPOCH,) + tuple((t.data_ptr(), t._version) for t in ps)
+        if key != self.key:
+            L = native.lib()
+            K = self.linears[0].weight.shape[1]
+            dev = ps[0].device
+            groups = [self.linears[:2]] + ([self.linears[2:]] if len(self.linears) == 3 else [])   # N = 768 pass (+ N = 384 pass)
+            self.groups = []
+            for g in groups:
+                n_total = HIDDEN * len(g)
+                wp = torch.empty(3 * n_total * K * 2, dtype=torch.uint8, device=dev)
+                bb = torch.empty(n_total, dtype=torch.float32, device=dev)
+                for i, l in enumerate(g):
+                    native.check(L.dldkd_pack_linear_planes(native.ptr(l.weight.detach().contiguous()), native.ptr(l.bias.detach()), None,
+                                                            None, HIDDEN, K, i * HIDDEN, n_total, native.ptr(wp), native.ptr(bb),
+                                                            native.stream()), "pack_linear_planes")
+                self.groups.append((wp, bb, n_total))
+            self.key, self.K = key, K
+        return self
+
+
+def rows_x3_ok(x):
+    """The fp32-grade full-row kernel serves inference in parity mode: no autograd, in_features a multiple of 32 in [64, 4096]."""
+    return (_PRECISION in ("fp32", "fp32x3") and ROWS_X3 and not torch.is_grad_enabled() and in_proj_x3_ok(x.shape[-1])
+            and x.is_cuda)
+
+
+ROWS_X3 = True        # parity inference: 384/768-wide linears of the towers on in_proj_rows128x3_kernel instead of gemm_f32x3
+
+
+def linear_rows_x3(x, packed, relu=False):
+    """x (..., K) fp32 -> (..., 384 * n_linears) fp32: y = act(x W^T + b) for the packed linears side by side, fp32-grade
+    products (three bf16 planes), batch-invariant."""
+    import ctypes
+    L = native.lib()
+    f = packed.get()
+    K = x.shape[-1]
+    if K != f.K:
+        raise native.NativeError(f"linear_rows_x3: x has {K} features, weights expect {f.K}")
+    x2 = _chk(x.reshape(-1, K), "linear_rows_x3.x")
+    M = x2.shape[0]
+    n_out = HIDDEN * len(f.linears)
+    y = torch.empty(M, n_out, dtype=torch.float32, device=x.device)
+    col = 0
+    for wp, bb, n_total in f.groups:
+        y0 = ctypes.c_void_p(y.data_ptr() + 4 * col)
+        y1 = ctypes.c_void_p(y.data_ptr() + 4 * (col + HIDDEN)) if n_total == 2 * HIDDEN else None
+        native.check(L.dldkd_linear_f32x3_rows(native.ptr(x2), None, None, native.ptr(wp), native.ptr(bb), y0, y1, M, n_total, K,
+                                               n_out, int(relu), native.stream()), "linear_f32x3_rows")
+        col += n_total
+    return y.view(*x.shape[:-1], n_out)
+
+
 def rows_kernel_ok(x):
     """The full-row bf16 kernel serves inference in throughput mode: no autograd, in_features a multiple of 32."""
     return _PRECISION == "bf16" and not torch.is_grad_enabled() and x.shape[-1] % 32 == 0

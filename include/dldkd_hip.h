@@ -217,6 +217,15 @@ int dldkd_fold_ln_linear_planes(const float* W, const float* bias, const float* 
 int dldkd_in_proj_f32x3_rows128(const float* x, const float* mean, const float* rstd, const void* Wplanes, const float* bb, float* y0,
                                 float* y1, long M, int K, int relu, void* stream);
 int dldkd_in_proj_f32x3_rows128_ok(int K);
+/* The same kernel as a plain fp32-grade linear layer over full rows (the 384 / 768-wide linears of the towers, parity mode,
+ * inference): y = act(x W^T + b), N = 384 (y0) or 768 (columns [0, 384) -> y0, [384, 768) -> y1), output row stride ldy floats
+ * (so q | k | v can land side by side in one buffer), mean / rstd NULL (or both given: rows are normalised first).
+ * dldkd_pack_linear_planes: the weights of one nn.Linear (N % 32 == 0 columns at n_offset of n_total = 384 | 768) as three bf16
+ * planes in the kernel's fragment order (3 * n_total * K * 2 bytes), bb = bias (gamma, beta NULL) or the LayerNorm fold. */
+int dldkd_pack_linear_planes(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K, int n_offset,
+                             int n_total, void* Wplanes, float* bb, void* stream);
+int dldkd_linear_f32x3_rows(const float* x, const float* mean, const float* rstd, const void* Wplanes, const float* bb, float* y0,
+                            float* y1, long M, int N, int K, int ldy, int relu, void* stream);
 /* Diagnostics (tools/k4_timeline.py): the same launch, plus 12 u64 per workgroup in `stamps` (size it for ceil(M / 128)
  * workgroups; the kernel is persistent and uses fewer): s_memtime / s_memrealtime at kernel start, first k-loop start / end, first
  * epilogue end, kernel end; the XCC id; the number of tiles the workgroup did. */

@@ -116,6 +116,40 @@ def test_parity_grade_in_proj_x3(K, M):
         assert (ops.in_proj_x3(x, folded)[0] - ys[0]).abs().max() > 0.5
 
 
+@pytest.mark.parametrize("n_lin,K,M", [(1, 384, 300), (2, 384, 129), (3, 384, 128 * 2 + 1), (1, 64, 5), (3, 1024, 77)])
+def test_linear_rows_x3_vs_fp64(n_lin, K, M):
+    """The fp32-grade full-row linear (q | k | v side by side, dense, out mapping in parity inference) against fp64 and against
+    the gemm_f32x3 path; batch-invariant."""
+    from dldkd_amd import ops
+    from dldkd_amd import functional as F_
+    g = torch.Generator().manual_seed(n_lin * 1000 + K + M)
+    lins = [torch.nn.Linear(K, 384).to(DEV) for _ in range(n_lin)]
+    with torch.no_grad():
+        for l in lins:
+            l.weight.copy_(torch.randn(384, K, generator=g) * K ** -0.5)
+            l.bias.copy_(torch.randn(384, generator=g) * 0.1)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    packed = ops.PackedLinearX3(lins)
+    with torch.no_grad():
+        assert ops.rows_x3_ok(x)
+        for relu in (False, True):
+            y = ops.linear_rows_x3(x, packed, relu=relu)
+            assert y.shape == (M, 384 * n_lin)
+            for i, l in enumerate(lins):
+                ref = x.double() @ l.weight.double().t() + l.bias.double()
+                old = F_.linear(x, l.weight, l.bias, relu=relu)
+                if relu:
+                    ref = torch.relu(ref)
+                part = y[:, 384 * i:384 * (i + 1)]
+                scale = max(1.0, ref.abs().max().item())
+                assert (part.double() - ref).abs().max().item() <= 3e-6 * scale
+                assert (part - old).abs().max().item() <= 4e-6 * scale
+        if M > 130:
+            assert torch.equal(ops.linear_rows_x3(x[129:].contiguous(), packed), ops.linear_rows_x3(x, packed)[129:])
+    with torch.enable_grad():
+        assert not ops.rows_x3_ok(x)
+
+
 def test_parity_encode_uses_the_fused_projection_and_matches_the_unfused_one():
     """encode_context / encode_query in parity mode, inference: fused_parity_input_proj on (default) vs off."""
     m = _model(3072, 768, synth.make_params(17, 3072, 768))
@@ -129,7 +163,12 @@ def test_parity_encode_uses_the_fused_projection_and_matches_the_unfused_one():
         a = m.encode_context(v, vm) + m.encode_query(q, qm)
         m.fused_parity_input_proj = False
         assert not m._use_fast(v)
-        b = m.encode_context(v, vm) + m.encode_query(q, qm)
+        from dldkd_amd import ops
+        ops.ROWS_X3 = False
+        try:
+            b = m.encode_context(v, vm) + m.encode_query(q, qm)
+        finally:
+            ops.ROWS_X3 = True
     for x, y in zip(a, b):
         assert (x - y).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
     m.train()
