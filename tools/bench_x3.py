@@ -1,3 +1,5 @@
+"""Parity-grade fused input projection (in_proj_rows128x3_kernel) vs the LayerNorm + gemm_f32x3 path and fp64 math; with M >= 100000 also timed.
+    python tools/bench_x3.py [K] [M]"""
 import os, sys, types, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("dl-dkd_amd", "tests/golden", "tests"):
