@@ -214,12 +214,13 @@ def test_packed_weight_caches_follow_the_fused_optimizer(golden_dir):
     opt = types.SimpleNamespace(eval_context_bsz=25, eval_query_bsz=50, num_workers=0, pin_memory=False,
                                 device=torch.device(DEV), double_branch=True)
 
-    def scores(model):
+    def scores(model, fast=True):
         model.eval()
-        model.fast_input_proj = True
+        model.fast_input_proj = fast
         with torch.no_grad():
             ctx = ev.compute_context_info(model, synth.ListDataset(list(vids)), opt, keep_frame_feats=False)
             return ev.score_queries(model, synth.ListDataset(list(txts)), opt, ctx)[0].clone()
+    before_parity = scores(m, fast=False)                          # parity inference: FoldedInProjX3 / PackedLinearX3 planes
     ops.set_gemm_precision("bf16")
     try:
         before = scores(m)                                         # builds every packed cache
@@ -239,3 +240,6 @@ def test_packed_weight_caches_follow_the_fused_optimizer(golden_dir):
         ops.set_gemm_precision("fp32")
     assert (after - before).abs().max().item() > 1e-3              # the steps changed the scores at all
     assert torch.equal(after, want)                                # and eval sees the CURRENT weights, exactly
+    after_parity, want_parity = scores(m, fast=False), scores(fresh, fast=False)   # same for the three-plane caches of parity mode
+    assert (after_parity - before_parity).abs().max().item() > 1e-3
+    assert torch.equal(after_parity, want_parity)
