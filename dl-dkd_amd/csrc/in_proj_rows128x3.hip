@@ -13,7 +13,8 @@
 //
 // Structure (the measurements behind it: profiles/r02/ablation_k4_rows128.md):
 //   * 4 waves per workgroup, one per SIMD; wave w owns all 128 rows x columns [192 w, 192 w + 192): 384 accumulator registers
-//     (inline-asm MFMAs: column tiles 0-3 in AGPRs, 4-5 in VGPRs).
+//     (inline-asm MFMAs: column tiles 0-3 in AGPRs, 4-5 in VGPRs).  Template JT = 3: N = 384, 96 columns per wave - the
+//     384-wide linears of the towers (dldkd_linear_f32x3_rows, no normalisation).
 //   * a half-step = 16 k.  Row tile outermost: for row tile i, column tile j: 6 MFMAs on acc[i][j].  Only TWO row tiles' A planes
 //     are live (24 registers): the planes of the next row tile (or of row tile 0 of the next half-step) are normalised, split and
 //     converted piecewise in the MFMA shadow of the current one, each piece pinned between two groups of MFMAs by an empty asm.
@@ -199,9 +200,9 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128x3_kernel(const Rows128
 
     // One half-step (16 k), KK = h & 1 (compile time: ring half, x half).  Blocks (i, j) = 6 MFMAs on acc[i][j]; at the top of a
     // block the B planes of the NEXT block are requested, then one counted wait covers this block's planes.
-    //   VMEM queue per half-step (all in row tile 3): 2 x pieces, then 3 refills in each block (3, j): 20 operations.  A column
-    //   tile c >= 1 refilled two half-steps ago has 3 (5 - c) + 20 operations behind it when block (0, c - 1) asks for it
-    //   (kVm); column tile 0 is asked for at block (3, 5) of the half-step before: 15 + 2 + 15 = 32.
+    //   VMEM queue per half-step (all in row tile 3): 2 x pieces, then 3 refills in each block (3, j): 2 + 3 JT operations.  A
+    //   column tile c >= 1 refilled two half-steps ago has 3 (JT - 1 - c) + 2 + 3 JT operations behind it when block (0, c - 1)
+    //   asks for it; column tile 0 is asked for at block (3, JT - 1) of the half-step before: 3 (JT - 1) + 2 + 3 (JT - 1).
     //   LDS queue: 3 plane reads per block (+ 2 raw reads at blocks (i, 0)), so "this block's planes have landed" is
     //   lgkmcnt(5) at j = 0 and lgkmcnt(3) otherwise (at j = 1 that also covers the raw reads).
     auto half_step = [&](auto kkc, int kt) {
