@@ -150,6 +150,36 @@ def test_linear_rows_x3_vs_fp64(n_lin, K, M):
         assert not ops.rows_x3_ok(x)
 
 
+def test_in_proj_kernels_past_2_pow_32_elements():
+    """The whole C2 gallery in ONE call: 21,793 x 128 rows x 3072 fp32 = 8.6e9 elements (34 GB): row offsets past 2^31 and
+    2^32 elements must not wrap.  Slices around those offsets equal a call on the slice alone (bit for bit for the
+    batch-invariant parity kernel, to summation order for the bf16 one)."""
+    from dldkd_amd import ops
+    if torch.cuda.get_device_properties(0).total_memory < 80e9:
+        pytest.skip("needs 45 GB of device memory")
+    K, M = 3072, 21793 * 128
+    m = _model(K, 768, synth.make_params(19, K, 768))
+    x = torch.empty(M, K, device=DEV)
+    for lo in range(0, M, 200000):
+        x[lo:lo + 200000].normal_()
+    f16 = ops.FoldedInProj([m.visual_input_proj, m.exp_visual_input_proj])
+    f3 = ops.FoldedInProjX3([m.visual_input_proj, m.exp_visual_input_proj])
+    with torch.no_grad():
+        for fn, fold, exact in ((ops.in_proj_bf16, f16, False), (ops.in_proj_x3, f3, True)):
+            ys = fn(x, fold)
+            assert all(torch.isfinite(y).all().item() for y in ys)
+            for lo in (0, 699_000, 1_398_000, M - 2_000):            # 2^31 elements = row 699,051; 2^32 = row 1,398,101
+                sub = fn(x[lo:lo + 2_000].contiguous(), fold)
+                for a, b in zip(ys, sub):
+                    if exact:
+                        assert torch.equal(a[lo:lo + 2_000], b)
+                    else:
+                        assert (a[lo:lo + 2_000] - b).abs().max().item() < 5e-5
+            del ys
+    del x
+    torch.cuda.empty_cache()
+
+
 def test_parity_encode_uses_the_fused_projection_and_matches_the_unfused_one():
     """encode_context / encode_query in parity mode, inference: fused_parity_input_proj on (default) vs off."""
     m = _model(3072, 768, synth.make_params(17, 3072, 768))
