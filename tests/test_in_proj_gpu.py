@@ -36,7 +36,7 @@ def test_in_proj_vs_oracle(dv, M, kernel, monkeypatch):
     assert (y2 - ys[0]).abs().max() > 0.5
 
 
-@pytest.mark.parametrize("K,M", [(3072, 128 * 300 + 77), (768, 30001), (128, 129), (3072, 1), (1024, 127)])
+@pytest.mark.parametrize("K,M", [(3072, 128 * 300 + 77), (768, 30001), (128, 129), (3072, 1), (1024, 127), (192, 128 * 600 + 3), (320, 40000)])
 def test_rows128_matches_full_kernel(K, M, monkeypatch):
     """The two K4 kernels share one contract: same folded weights, same output up to fp32 summation order (the rows128
     kernel adds the k-tiles in a rotated order per workgroup).  Ragged last tile, one-row input, smallest K."""
@@ -74,7 +74,7 @@ def test_rows128_rejects_unsupported_k():
     assert rc != 0
 
 
-@pytest.mark.parametrize("K,M", [(3072, 300), (768, 1), (64, 129), (1024, 128 * 3 + 5), (4096, 77)])
+@pytest.mark.parametrize("K,M", [(3072, 300), (768, 1), (64, 129), (1024, 128 * 3 + 5), (4096, 77), (96, 700), (160, 131)])
 def test_parity_grade_in_proj_x3(K, M):
     """in_proj_rows128x3_kernel (parity mode, inference): against fp64 math at the accuracy of the LayerNorm + gemm_f32x3 path
     it replaces, and against that path; the row statistics equal the LayerNorm kernel's bit for bit."""
