@@ -291,27 +291,24 @@ def extras(dev):
         del hb, db
         xk = torch.nn.functional.normalize(torch.randn(400000, 3072, device=dev), dim=-1)      # 4.9 GB: beyond the L3
         fold = ops.FoldedInProj([m.visual_input_proj, m.exp_visual_input_proj])
-        ops.in_proj_bf16(xk, fold)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            ops.in_proj_bf16(xk, fold)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
+        def k4_ms():                                   # median of 10 single launches after 3 warm-ups (HIP events)
+            for _ in range(3):
+                ops.in_proj_bf16(xk, fold)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+            evs[0].record()
+            for i in range(10):
+                ops.in_proj_bf16(xk, fold)
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            return sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(10))[5]
+        ms = k4_ms()
         byts = 400000 * 3072 * 4 + 400000 * 768 * 4 + 768 * 3072 * 2
         out["k4_in_proj_roofline"] = {"bound": "hbm", "achieved": byts / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
                                       "frac": byts / ms / 1e6 / 8000.0, "kernel": "in_proj_rows128_kernel (dldkd_in_proj_bf16_rows128)", "kernel_ms": ms,
-                                      "shape": "400000 rows x 3072 fp32 -> 2 x 384 fp32"}
+                                      "shape": "400000 rows x 3072 fp32 -> 2 x 384 fp32", "timing": "median of 10 launches after 3 warm-ups"}
         ops.INPROJ_KERNEL = "full"                 # the round-1 kernel on the same box, same input
         try:
-            ops.in_proj_bf16(xk, fold)
-            e0.record()
-            for _ in range(5):
-                ops.in_proj_bf16(xk, fold)
-            e1.record()
-            torch.cuda.synchronize()
-            out["k4_in_proj_roofline"]["round1_kernel_ms"] = e0.elapsed_time(e1) / 5
+            out["k4_in_proj_roofline"]["round1_kernel_ms"] = k4_ms()
         finally:
             ops.INPROJ_KERNEL = "rows128"
     except Exception as e:   # noqa: BLE001
