@@ -1,0 +1,627 @@
+// K5: the whole clip / word tower AFTER the input projection as ONE kernel, one workgroup per (sequence, branch):
+//     h1 = LN(h0 + pos)                                   TrainablePositionalEncoding.forward, model_components.py:277-284
+//     q|k|v = h1 W^T + b ; P = softmax(q k^T / sqrt(96) + key mask) ; ctx = P v      BertSelfAttention.forward, :398-436
+//     h2 = LN(ctx Wd^T + bd + h1)                          BertSelfOutput.forward, :446-450 (BertAttention.forward :345-353)
+//     y  = h2 Wo^T + bo                                    out_mapping_linear, model.py:219 (video towers only)
+//     gallery row = bf16(y / max(|y|, 1e-12))              F.normalize of get_sim_scores, model.py:319, in the scorer's packed layout
+// (throughput mode: bf16 MFMA operands, fp32 accumulation / statistics; the parity towers keep their fp32-grade kernels).
+// Before this kernel the same work was 7+ launches per branch with fp32 activations round-tripping HBM between them
+// (profiles/r02/enc_fast_kernel_stats.csv: 1.64 ms per 1024 videos for ~0.2 ms of arithmetic).
+//
+// MI355X design
+//   * TRANSPOSED ACTIVATIONS IN REGISTERS.  Wave w owns rows 32 w .. 32 w + 31 of the sequence for the whole kernel.  Every
+//     linear layer is computed as Y^T = W X^T with mfma_f32_32x32x16_bf16: the weights are the A operand, the activations the B
+//     operand, so an accumulator tile holds 32 OUTPUT FEATURES on its 16 registers x 2 lane halves and the wave's 32 sequence
+//     rows on its lanes.  A following layer contracts over exactly that register index, so the accumulators - rounded to bf16
+//     in place - ARE its B operand (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand"): no LDS
+//     round trip, no lane movement between layers.  The k order inside such a fragment is permuted (element j of lane half h of
+//     k-step ks is feature 16 ks + 8 (j >> 2) + 4 h + (j & 3)); the weights are packed ONCE in that order (tower_pack_kernel).
+//     LayerNorm / L2-norm statistics run over the register index: in-register sums + one v_permlane32_swap.
+//   * ATTENTION WITHOUT TRANSPOSES.  Q^T and K^T come out transposed ([d][row]); V is computed in the normal orientation
+//     ([row][d]: the same bf16 registers of h1 serve as the A operand).  Then S^T = K Q^T takes K^T's accumulators as the A
+//     operand ("X^T B" form) and Q^T's as B; softmax runs over the accumulator registers (keys), P^T is the B operand of
+//     O^T = V^T P^T whose A operand is V's accumulators - every product sums over the previous one's register index.  Only
+//     K and V cross waves (a wave needs all 128 keys): 12 KiB per wave and head through LDS, written and read as raw 1-KiB
+//     fragments (ds_write_b128 / ds_read_b128 at base + lane * 16: conflict-free).
+//   * WEIGHTS STREAM L2 -> LDS -> all four waves: 1.44 MB of fragments per (sequence, branch) in consumption order, by LDS-DMA
+//     (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a 96-slot ring, 32-fragment chunks, two chunks in flight
+//     behind a counted vmcnt, one raw s_barrier per chunk; fragment reads run 3 deep behind hand-counted lgkmcnt (hipcc turns
+//     such a ring into read + lgkmcnt(0) pairs).  Blocks of one branch share an XCD (blockIdx & 4), so an L2 holds one branch's
+//     weights (1.47 MB of 4 MiB).
+//   * per-feature vectors (biases, gamma, beta) sit in LDS in fragment order (14 KiB); padded keys are masked through the
+//     INITIAL ACCUMULATOR of S^T (0 / -inf), padded key tiles are skipped.
+//   * A WORKGROUP IS FOUR 32-ROW SLOTS, not one sequence: the host packs the tiles of short sequences side by side (two
+//     64-clip videos, four 30-word queries) - a wave only ever talks to the slots of its own sequence (K / V).
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace dldkd {
+namespace tw {
+
+constexpr int kNKS = 24;                       // k-steps of 16 over 384 features
+constexpr int kChunk = 32, kDepth = 3;         // ring: fragments per chunk, fragment reads in flight
+constexpr int kHeadFrags = 3 * 3 * kNKS;       // Q | K | V of one head: 3 tiles x 24 k-steps each
+constexpr int kQKVFrags = 4 * kHeadFrags;      // 864
+constexpr int kSqFrags = 12 * kNKS;            // a 384 x 384 linear: 288
+constexpr int P_G1 = 0, P_B1 = 384, P_BQ = 768, P_BK = 1152, P_BV = 1536, P_BD = 1920, P_G2 = 2304, P_B2 = 2688, P_BO = 3072,
+              P_TOTAL = 3456;
+constexpr int kLdsKV = 96 * 1024;              // [ring 96 KiB][K/V exchange, later output staging: 50 KiB][params][key mask]
+constexpr int kKVBytes = 51200;
+constexpr int kLdsPar = kLdsKV + kKVBytes;
+constexpr int kLdsTotal = kLdsPar + P_TOTAL * 4 + 512;      // 163,840 = all 160 KiB
+constexpr int kStgPitch = 400;                 // output staging: 32 rows x 384 payload bytes per wave and pass
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// LDS-DMA of one 1-KiB piece: global address = scalar base + lane * 16, LDS destination = lds_base (-> M0) + lane * 16
+__device__ __forceinline__ void glds_piece(uint32_t voff, const char* sbase, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read16(bf16x8& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
+}
+__device__ __forceinline__ float half_swap_max(float m) {
+    const unsigned u = __builtin_bit_cast(unsigned, m);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float half_swap_sum(float m) {
+    const unsigned u = __builtin_bit_cast(unsigned, m);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (short)f32_to_bf16_bits(v[j]);
+    return o;
+}
+
+struct TowerArgs {
+    const float* h0[2];       // per branch: input-projection output, rows (., 384) fp32
+    const float* pos[2];      // per branch: position table [max_pos][384] fp32
+    const char* blob[2];      // per branch: weight fragments in stream order, then the parameter table
+    const int32_t* row0;      // [n_seq] first row of the sequence in h0 / out; null: seq * seq_rows
+    const int32_t* lens;      // [n_seq] valid rows (> 0 for every scheduled sequence)
+    const int32_t* items;     // [n_items][4]: what the four waves of a workgroup work on: (seq << 2) | tile, or -1 (idle slot);
+                              // the 32-row tiles of one sequence sit in consecutive slots, in order.  null: workgroup i = sequence i
+    int n_items, n_branches, max_pos;
+    float* out[2];            // OUTMODE 0: fp32 rows (., 384), indexed like h0
+    int seq_rows;             // OUTMODE 0: rows allotted per sequence (rows len .. seq_rows - 1 are written as zeros), 0 = ragged
+    char* gal[2];             // OUTMODE 1: gallery blobs bf16 [nv][Lp][384]
+    int v0, Lp;               // OUTMODE 1: gallery index of sequence 0, rows per video
+    int32_t* lens_out;        // OUTMODE 1: lens of the whole gallery (or null)
+};
+
+// OUTMAP: the stream ends with the 384 x 384 out_mapping_linear (video towers); OUTMODE 0: fp32 rows, 1: packed bf16 gallery
+template <bool OUTMAP, int OUTMODE>
+__global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
+    constexpr int NFRAG = kQKVFrags + kSqFrags + (OUTMAP ? kSqFrags : 0);
+    constexpr int NCH = NFRAG / kChunk;
+    static_assert(NFRAG % kChunk == 0, "whole chunks");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int branch = 0, item = blockIdx.x;
+    if (p.n_branches == 2) {        // blocks b and b + 8 share an XCD: blocks with (b & 4) equal share a branch's weights in L2
+        branch = (blockIdx.x >> 2) & 1;
+        item = (blockIdx.x >> 3) * 4 + (blockIdx.x & 3);
+    }
+    if (item >= p.n_items) return;
+    // this wave's slot: a 32-row tile of some sequence.  An idle slot re-computes slot 0's tile and stores nothing (the
+    // instruction stream, with its barriers and its share of the weight DMA, is the same for every wave).
+    int seq, tile;
+    bool live = true;
+    if (p.items != nullptr) {
+        int ent = p.items[item * 4 + wave];
+        if (ent < 0) { live = false; ent = p.items[item * 4]; }
+        seq = ent >> 2;
+        tile = ent & 3;
+    } else {
+        seq = item;
+        tile = wave;
+        if (wave > 0 && 32 * wave >= p.lens[item]) { live = false; tile = 0; }
+    }
+    const int len = p.lens[seq];
+    const int first = live ? wave - tile : 0;          // slot of the sequence's tile 0 (K / V fragments of key tile kt: slot first + kt)
+    const int row0 = p.row0 != nullptr ? p.row0[seq] : seq * p.seq_rows;
+    if (len <= 0) {     // only without an item table (the host never schedules an empty sequence): the workgroup IS the sequence
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (OUTMODE == 1) {
+            char* g = p.gal[branch] + (size_t)(p.v0 + seq) * p.Lp * (kHidden * 2);
+            for (int i = tid; i < p.Lp * 48; i += 256) *reinterpret_cast<f32x4*>(g + (size_t)i * 16) = z;
+            if (p.lens_out != nullptr && branch == 0 && tid == 0) p.lens_out[p.v0 + seq] = 0;
+        } else {
+            float* o = p.out[branch] + (size_t)row0 * kHidden;
+            for (int i = tid; i < p.seq_rows * 96; i += 256) *reinterpret_cast<f32x4*>(o + (size_t)i * 4) = z;
+        }
+        return;
+    }
+    const int ntiles = (len + 31) >> 5;                // 32-row tiles of the sequence (wave-uniform)
+    const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
+    const uint32_t lane16 = lane * 16;
+    const char* wsrc = p.blob[branch];
+    float* par = reinterpret_cast<float*>(smem + kLdsPar);
+
+    // ---- weight ring --------------------------------------------------------------------------------------------
+    auto issue_chunk = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const char* src = wsrc + (size_t)(c * kChunk + wave * 8) * 1024;
+        const uint32_t dst = smem_lds + ((c % 3) * kChunk + wave * 8) * 1024;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) glds_piece(lane16, src + i * 1024, dst + i * 1024);
+    };
+    bf16x8 fr[4];
+    const uint32_t ring_a = smem_lds + lane16, ring_b = ring_a + 48 * 1024;
+    auto ring_read = [&](auto nc) {
+        constexpr int n = decltype(nc)::value, slot = n % 96;
+        if constexpr (slot < 48) lds_read16<slot * 1024>(fr[n % 4], ring_a);
+        else lds_read16<(slot - 48) * 1024>(fr[n % 4], ring_b);
+    };
+    // everything that has to happen before the MFMA that consumes fragment n.  Fragment reads run kDepth ahead INSIDE a phase
+    // (one head's Q | K | V projection, the dense layer, the out mapping) and never across a phase end: between phases the
+    // compiler schedules its own code (attention, LayerNorm) and must not find asm loads in flight in registers it may move.
+    auto pre = [&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        constexpr int pbeg = n < kQKVFrags ? n / kHeadFrags * kHeadFrags : n < kQKVFrags + kSqFrags ? kQKVFrags : kQKVFrags + kSqFrags;
+        constexpr int pend = n < kQKVFrags ? pbeg + kHeadFrags : pbeg + kSqFrags;
+        if constexpr ((n + kDepth) % kChunk == 0 && n + kDepth < NFRAG) {
+            constexpr int c = (n + kDepth) / kChunk;           // chunk c is about to be read
+            if constexpr (c + 1 < NCH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but chunk c + 1's pieces
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");            // every wave's pieces of chunk c landed; chunk c - 1 is consumed
+            if constexpr (c + 2 < NCH) issue_chunk(std::integral_constant<int, c + 2>{});
+        }
+        if constexpr (n == pbeg) static_for<0, kDepth>([&](auto dc) { ring_read(std::integral_constant<int, pbeg + decltype(dc)::value>{}); });
+        if constexpr (n + kDepth < pend) ring_read(std::integral_constant<int, n + kDepth>{});
+        constexpr int after = pend - 1 - n < kDepth ? pend - 1 - n : kDepth;
+        bf16x8& f = fr[n % 4];                                 // (named first: an asm operand alone does not capture `fr`)
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(after) : "memory");
+    };
+
+    issue_chunk(std::integral_constant<int, 0>{});
+    issue_chunk(std::integral_constant<int, 1>{});
+
+    // ---- prologue: parameter table, h1 = LN(h0 + pos) ---------------------------------------------------------------
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wsrc + (size_t)NFRAG * 1024);
+        f32x4* dst = reinterpret_cast<f32x4*>(par);
+        for (int i = tid; i < P_TOTAL / 4; i += 256) dst[i] = src[i];
+    }
+    bf16x8 X1[kNKS];     // h1^T (later h2^T) as MFMA operand fragments: lane = (row r, half h), k-step ks, 8 features
+    {
+        const int l = 32 * tile + r;
+        const int lrow = l < len ? l : len - 1;                       // rows past the sequence: a finite copy (never stored)
+        const int lpos = l < p.max_pos ? l : p.max_pos - 1;
+        const float* xr = p.h0[branch] + (size_t)(row0 + lrow) * kHidden + 4 * h;
+        const float* pr = p.pos[branch] + (size_t)lpos * kHidden + 4 * h;
+        // h0 + pos for the lane's 192 features, parked in the accumulator half of the register file (x is needed twice: for the
+        // statistics and for the normalisation; 192 arch VGPRs plus the loads in flight do not fit beside anything else)
+        float x[kNKS][8];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < kNKS; kb += 6) {
+#pragma unroll
+            for (int ks = kb; ks < kb + 6; ++ks)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * ks + 8 * c);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(pr + 16 * ks + 8 * c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = a[e] + b[e];
+                        s += v;
+                        q += v * v;
+                        x[ks][4 * c + e] = v;
+                        asm volatile("" : "+a"(x[ks][4 * c + e]));
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);                         // at most 24 loads (96 registers) in flight
+        }
+        const float mean = half_swap_sum(s) * (1.f / kHidden);
+        const float rstd = rsqrtf(fmaxf(half_swap_sum(q) * (1.f / kHidden) - mean * mean, 0.f) + 1e-5f);
+        const float nmr = -mean * rstd;
+        __syncthreads();                                               // parameter table visible
+#pragma unroll
+        for (int ks = 0; ks < kNKS; ++ks) {
+            const f32x4* g = reinterpret_cast<const f32x4*>(par + P_G1 + ks * 16 + h * 8);
+            const f32x4* b = reinterpret_cast<const f32x4*>(par + P_B1 + ks * 16 + h * 8);
+            const f32x4 g0 = g[0], g1 = g[1], b0 = b[0], b1 = b[1];
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (x[ks][e] * rstd + nmr) * g0[e] + b0[e];
+                v[4 + e] = (x[ks][4 + e] * rstd + nmr) * g1[e] + b1[e];
+            }
+            X1[ks] = pack8(v);
+            asm volatile("" : "+a"(X1[ks]));                           // MFMA operand for the rest of the kernel: accumulator half
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // chunks 0, 1 (and every prologue load) have landed
+    asm volatile("s_barrier" ::: "memory");
+    issue_chunk(std::integral_constant<int, 2>{});
+    asm volatile("; TW_STREAM_BEGIN" ::: "memory");
+
+    // T-product: acc[feature][row] += W fragment (A) x activation fragment (B); N-product: acc[row][feature] (V)
+    auto tprod = [&](auto n0c, f32x16& acc, const bf16x8 (&X)[kNKS]) {
+        static_for<0, kNKS>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value, n = decltype(n0c)::value + ks;
+            pre(std::integral_constant<int, n>{});
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[n % 4], X[ks], acc, 0, 0, 0);
+        });
+    };
+    auto nprod = [&](auto n0c, f32x16& acc, const bf16x8 (&X)[kNKS]) {
+        static_for<0, kNKS>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value, n = decltype(n0c)::value + ks;
+            pre(std::integral_constant<int, n>{});
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[ks], fr[n % 4], acc, 0, 0, 0);
+        });
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // accumulator tile (features 32 t ..) + per-feature vector in fragment order -> the two operand fragments of k-steps 2t, 2t+1
+    auto tile_bias_pack = [&](const f32x16& acc, int tab, int t, bf16x8& f0, bf16x8& f1) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4* b = reinterpret_cast<const f32x4*>(par + tab + (2 * t + s) * 16 + h * 8);
+            const f32x4 b0 = b[0], b1 = b[1];
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[8 * s + e] + b0[e]; v[4 + e] = acc[8 * s + 4 + e] + b1[e]; }
+            (s == 0 ? f0 : f1) = pack8(v);
+        }
+    };
+
+    bf16x8* Kl = reinterpret_cast<bf16x8*>(smem + kLdsKV);             // [slot 4][k-step 6][lane]
+    bf16x8* Vl = Kl + 4 * 6 * 64;                                      // [slot 4][d tile 3][s 2][lane]
+    bf16x8 Cf[kNKS];                                                   // ctx^T fragments (all heads)
+    const int krem = len - 32 * (ntiles - 1) - 4 * h;                  // valid keys of the last key tile, from this lane half's first
+
+    static_for<0, 4>([&](auto hdc) {
+        constexpr int hd = decltype(hdc)::value, n0 = hd * kHeadFrags;
+        bf16x8 Qf[6], Kf[6], Vf[6];
+        static_for<0, 3>([&](auto dtc) {                               // Q^T (pre-scaled by log2(e) / sqrt(96) in the blob)
+            constexpr int dt = decltype(dtc)::value;
+            f32x16 a = zero16;
+            tprod(std::integral_constant<int, n0 + dt * kNKS>{}, a, X1);
+            tile_bias_pack(a, P_BQ, 3 * hd + dt, Qf[2 * dt], Qf[2 * dt + 1]);
+        });
+        static_for<0, 3>([&](auto dtc) {                               // K^T
+            constexpr int dt = decltype(dtc)::value;
+            f32x16 a = zero16;
+            tprod(std::integral_constant<int, n0 + 72 + dt * kNKS>{}, a, X1);
+            tile_bias_pack(a, P_BK, 3 * hd + dt, Kf[2 * dt], Kf[2 * dt + 1]);
+        });
+        static_for<0, 3>([&](auto dtc) {                               // V (rows on registers, d on lanes)
+            constexpr int dt = decltype(dtc)::value;
+            f32x16 a = zero16;
+            nprod(std::integral_constant<int, n0 + 144 + dt * kNKS>{}, a, X1);
+            const float bv = par[P_BV + 96 * hd + 32 * dt + r];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = a[8 * s + j] + bv;
+                Vf[2 * dt + s] = pack8(v);
+            }
+        });
+        __syncthreads();                                               // every wave is done with the previous head's K / V
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            Kl[(wave * 6 + i) * 64 + lane] = Kf[i];
+            Vl[(wave * 6 + i) * 64 + lane] = Vf[i];
+        }
+        __syncthreads();
+        // S^T[key][query] (log2 domain), keys on registers; the keys past the sequence (only in its last key tile) enter as
+        // -inf through the INITIAL accumulator; key tiles past the sequence are skipped
+        f32x16 sa[4];
+        static_for<0, 4>([&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
+            if (kt < ntiles) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sa[kt][e] = (kt == ntiles - 1 && (e & 3) + 8 * (e >> 2) >= krem) ? -INFINITY : 0.f;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    sa[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kl[((first + kt) * 6 + i) * 64 + lane], Qf[i], sa[kt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sa[kt][e] = -INFINITY;
+            }
+        });
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sa[kt][e]);
+        mx = half_swap_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                sa[kt][e] = __builtin_amdgcn_exp2f(sa[kt][e] - mx);
+                sum += sa[kt][e];
+            }
+        const float inv = 1.f / half_swap_sum(sum);
+        f32x16 oa[3] = {zero16, zero16, zero16};
+        static_for<0, 4>([&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
+            if (kt < ntiles) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = sa[kt][8 * s + j];
+                    const bf16x8 pf = pack8(v);
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt)
+                        oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Vl[((first + kt) * 6 + 2 * dt + s) * 64 + lane], pf, oa[dt], 0, 0, 0);
+                }
+            }
+        });
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = oa[dt][8 * s + j] * inv;
+                Cf[6 * hd + 2 * dt + s] = pack8(v);
+                asm volatile("" : "+a"(Cf[6 * hd + 2 * dt + s]));
+            }
+    });
+
+    // ---- dense + residual + LayerNorm -> h2^T (fp32 in `val`, bf16 fragments back into X1) ---------------------------
+    float val[12][16];
+    float s1 = 0.f, s2 = 0.f;
+    static_for<0, 12>([&](auto otc) {
+        constexpr int ot = decltype(otc)::value;
+        f32x16 a = zero16;
+        tprod(std::integral_constant<int, kQKVFrags + ot * kNKS>{}, a, Cf);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4* b = reinterpret_cast<const f32x4*>(par + P_BD + (2 * ot + s) * 16 + h * 8);
+            const f32x4 b0 = b[0], b1 = b[1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = a[8 * s + j] + (j < 4 ? b0[j & 3] : b1[j & 3]) + bf16_bits_to_f32((unsigned short)X1[2 * ot + s][j]);
+                s1 += v;
+                s2 += v * v;
+                val[ot][8 * s + j] = v;
+            }
+        }
+    });
+    {
+        const float mean = half_swap_sum(s1) * (1.f / kHidden);
+        const float rstd = rsqrtf(fmaxf(half_swap_sum(s2) * (1.f / kHidden) - mean * mean, 0.f) + 1e-5f);
+        const float nmr = -mean * rstd;
+#pragma unroll
+        for (int t = 0; t < 12; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x4* g = reinterpret_cast<const f32x4*>(par + P_G2 + (2 * t + s) * 16 + h * 8);
+                const f32x4* b = reinterpret_cast<const f32x4*>(par + P_B2 + (2 * t + s) * 16 + h * 8);
+                const f32x4 g0 = g[0], g1 = g[1], b0 = b[0], b1 = b[1];
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = (val[t][8 * s + j] * rstd + nmr) * (j < 4 ? g0[j & 3] : g1[j & 3]) + (j < 4 ? b0[j & 3] : b1[j & 3]);
+                    val[t][8 * s + j] = v[j];
+                }
+                if constexpr (OUTMAP) {
+                    X1[2 * t + s] = pack8(v);
+                    asm volatile("" : "+a"(X1[2 * t + s]));
+                }
+            }
+    }
+    if constexpr (OUTMAP) {
+        static_for<0, 12>([&](auto otc) {
+            constexpr int ot = decltype(otc)::value;
+            f32x16 a = zero16;
+            tprod(std::integral_constant<int, kQKVFrags + kSqFrags + ot * kNKS>{}, a, X1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x4* b = reinterpret_cast<const f32x4*>(par + P_BO + (2 * ot + s) * 16 + h * 8);
+                const f32x4 b0 = b[0], b1 = b[1];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) val[ot][8 * s + j] = a[8 * s + j] + (j < 4 ? b0[j & 3] : b1[j & 3]);
+            }
+        });
+    }
+    asm volatile("; TW_STREAM_END" ::: "memory");
+    if (!live) return;                                                 // (no barrier below this line)
+
+    // ---- output: val[t][e] = y^T[feature 32 t + (e & 3) + 8 (e >> 2) + 4 h][row r] ----------------------------------
+    // (the K / V region is free: the dense / out-mapping chunks put barriers between the last head and here; each wave stages
+    // through its own 12.5 KiB of it).  The wave of a sequence's LAST tile also writes the zero rows behind the sequence.
+    char* stg = smem + kLdsKV + wave * (32 * kStgPitch);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (OUTMODE == 1) {
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < 12; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ss += val[t][e] * val[t][e];
+        const float scale = 1.f / fmaxf(sqrtf(half_swap_sum(ss)), 1e-12f);       // F.normalize, model.py:319
+        const int len16 = (len + 15) & ~15;
+        const int lastr = (len - 1) & 31;                                          // replicated into its 16-row tile's padding
+        char* g = p.gal[branch] + (size_t)(p.v0 + seq) * p.Lp * (kHidden * 2);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    uint2 w2;
+                    w2.x = (unsigned)f32_to_bf16_bits(val[6 * pass + t][4 * q4 + 0] * scale) |
+                           ((unsigned)f32_to_bf16_bits(val[6 * pass + t][4 * q4 + 1] * scale) << 16);
+                    w2.y = (unsigned)f32_to_bf16_bits(val[6 * pass + t][4 * q4 + 2] * scale) |
+                           ((unsigned)f32_to_bf16_bits(val[6 * pass + t][4 * q4 + 3] * scale) << 16);
+                    *reinterpret_cast<uint2*>(stg + r * kStgPitch + (32 * t + 8 * q4 + 4 * h) * 2) = w2;
+                }
+#pragma unroll
+            for (int it = 0; it < 12; ++it) {
+                const int idx = lane + 64 * it, row = idx / 24, c = idx % 24;
+                const int l = 32 * tile + row;
+                if (l >= p.Lp) continue;
+                f32x4 v = z4;
+                if (l < len16) v = *reinterpret_cast<const f32x4*>(stg + (l < len ? row : lastr) * kStgPitch + 16 * c);
+                *reinterpret_cast<f32x4*>(g + (size_t)l * (kHidden * 2) + pass * 384 + 16 * c) = v;
+            }
+        }
+        if (tile == ntiles - 1)
+            for (int i = 32 * ntiles * 48 + lane; i < p.Lp * 48; i += 64) *reinterpret_cast<f32x4*>(g + (size_t)i * 16) = z4;
+        if (p.lens_out != nullptr && branch == 0 && tile == 0 && lane == 0) p.lens_out[p.v0 + seq] = len;
+    } else {
+        float* o = p.out[branch] + (size_t)row0 * kHidden;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 v = {val[3 * pass + t][4 * q4], val[3 * pass + t][4 * q4 + 1], val[3 * pass + t][4 * q4 + 2],
+                                     val[3 * pass + t][4 * q4 + 3]};
+                    *reinterpret_cast<f32x4*>(stg + r * kStgPitch + (32 * t + 8 * q4 + 4 * h) * 4) = v;
+                }
+#pragma unroll
+            for (int it = 0; it < 12; ++it) {
+                const int idx = lane + 64 * it, row = idx / 24, c = idx % 24;
+                const int l = 32 * tile + row;
+                if (l >= len && l >= p.seq_rows) continue;
+                f32x4 v = z4;
+                if (l < len) v = *reinterpret_cast<const f32x4*>(stg + row * kStgPitch + 16 * c);
+                *reinterpret_cast<f32x4*>(o + (size_t)l * kHidden + pass * 96 + 4 * c) = v;
+            }
+        }
+        if (tile == ntiles - 1)
+            for (int i = 32 * ntiles * 96 + lane; i < p.seq_rows * 96; i += 64) *reinterpret_cast<f32x4*>(o + (size_t)i * 4) = z4;
+    }
+}
+
+// ---- weight / parameter packing -----------------------------------------------------------------------------------
+struct PackArgs {
+    const float *g1, *b1, *wq, *bq, *wk, *bk, *wv, *bv, *wd, *bd, *g2, *b2, *wo, *bo;
+    unsigned short* frags;
+    float* par;
+    int nfrag;
+};
+// fragment n (stream order), lane, element j  <-  W[row base + (lane & 31)][16 ks + 8 (j >> 2) + 4 (lane >> 5) + (j & 3)]
+__global__ __launch_bounds__(256) void tower_pack_kernel(const PackArgs a) {
+    const float qscale = 1.4426950408889634f * 0.10206207261596577f;     // log2(e) / sqrt(96): softmax runs on exp2
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < (long)a.nfrag * 512) {
+        const int n = (int)(i >> 9), lane = (int)(i >> 3) & 63, j = (int)i & 7;
+        const float* W;
+        int rowbase, ks;
+        float sc = 1.f;
+        if (n < kQKVFrags) {
+            const int hd = n / kHeadFrags, m = n % kHeadFrags, which = m / 72, dt = (m % 72) / kNKS;
+            ks = m % kNKS;
+            W = which == 0 ? a.wq : which == 1 ? a.wk : a.wv;
+            if (which == 0) sc = qscale;
+            rowbase = 96 * hd + 32 * dt;
+        } else {
+            const int m = (n - kQKVFrags) % kSqFrags;
+            W = n < kQKVFrags + kSqFrags ? a.wd : a.wo;
+            rowbase = 32 * (m / kNKS);
+            ks = m % kNKS;
+        }
+        const int f = 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+        a.frags[i] = f32_to_bf16_bits(W[(size_t)(rowbase + (lane & 31)) * kHidden + f] * sc);
+    }
+    if (i < P_TOTAL) {
+        const int tab = (int)i / kHidden, x = (int)i % kHidden;
+        const int ks = x >> 4, hh = (x >> 3) & 1, j = x & 7;
+        const int f = 16 * ks + 8 * (j >> 2) + 4 * hh + (j & 3);             // fragment order: [ks][half][j]
+        float v;
+        switch (tab) {
+            case 0: v = a.g1[f]; break;
+            case 1: v = a.b1[f]; break;
+            case 2: v = a.bq[f] * qscale; break;
+            case 3: v = a.bk[f]; break;
+            case 4: v = a.bv[x]; break;                                        // V's features sit on lanes: natural order
+            case 5: v = a.bd[f]; break;
+            case 6: v = a.g2[f]; break;
+            case 7: v = a.b2[f]; break;
+            default: v = a.bo ? a.bo[f] : 0.f; break;
+        }
+        a.par[i] = v;
+    }
+}
+
+}  // namespace tw
+}  // namespace dldkd
+
+using namespace dldkd;
+
+extern "C" {
+
+size_t dldkd_tower_blob_bytes(int with_out_map) {
+    const size_t nfrag = tw::kQKVFrags + tw::kSqFrags + (with_out_map ? tw::kSqFrags : 0);
+    return nfrag * 1024 + (size_t)tw::P_TOTAL * 4;
+}
+
+int dldkd_tower_pack_bf16(const float* ln1_g, const float* ln1_b, const float* wq, const float* bq, const float* wk, const float* bk,
+                          const float* wv, const float* bv, const float* wd, const float* bd, const float* ln2_g, const float* ln2_b,
+                          const float* wo, const float* bo, void* blob, void* stream) {
+    if (!ln1_g || !ln1_b || !wq || !bq || !wk || !bk || !wv || !bv || !wd || !bd || !ln2_g || !ln2_b || !blob || (!wo != !bo)) {
+        set_error("tower_pack: null pointer");
+        return DLDKD_EINVAL;
+    }
+    if ((uintptr_t)blob & 15) { set_error("tower_pack: blob must be 16-byte aligned"); return DLDKD_EINVAL; }
+    const int nfrag = tw::kQKVFrags + tw::kSqFrags + (wo ? tw::kSqFrags : 0);
+    tw::PackArgs a{ln1_g, ln1_b, wq, bq, wk, bk, wv, bv, wd, bd, ln2_g, ln2_b, wo, bo, (unsigned short*)blob,
+                   (float*)((char*)blob + (size_t)nfrag * 1024), nfrag};
+    DLDKD_LAUNCH(tw::tower_pack_kernel, dim3((unsigned)(((long)nfrag * 512 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("tower_pack");
+}
+
+int dldkd_tower_seq_bf16(const float* const* h0, const float* const* pos, const void* const* blob, const int32_t* row0,
+                         const int32_t* lens, const int32_t* items, int n_items, int n_branches, int max_pos, int with_out_map,
+                         int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
+                         void* stream) {
+    if (n_items < 0 || (n_branches != 1 && n_branches != 2) || max_pos < 1 || (out_mode != 0 && out_mode != 1) || seq_rows < 0 ||
+        seq_rows > 128 || (!row0 && seq_rows < 1) || !with_out_map || (out_mode == 1 && (!with_out_map || Lp < 32 || Lp > 128 || (Lp & 31) || v0 < 0))) {
+        set_error("tower_seq: bad arguments (n_items=%d n_branches=%d max_pos=%d out_mode=%d seq_rows=%d Lp=%d)", n_items, n_branches,
+                  max_pos, out_mode, seq_rows, Lp);
+        return DLDKD_EINVAL;
+    }
+    if (n_items == 0) return DLDKD_OK;
+    if (!h0 || !pos || !blob || !lens || (out_mode == 0 && !out_rows) || (out_mode == 1 && !gallery)) {
+        set_error("tower_seq: null pointer");
+        return DLDKD_EINVAL;
+    }
+    tw::TowerArgs p{};
+    for (int b = 0; b < n_branches; ++b) {
+        p.h0[b] = h0[b]; p.pos[b] = pos[b]; p.blob[b] = (const char*)blob[b];
+        if (out_mode == 0) p.out[b] = out_rows[b]; else p.gal[b] = (char*)gallery[b];
+        if (!p.h0[b] || !p.pos[b] || !p.blob[b] || (out_mode == 0 ? !p.out[b] : !p.gal[b])) { set_error("tower_seq: null branch pointer"); return DLDKD_EINVAL; }
+        if (((uintptr_t)p.h0[b] | (uintptr_t)p.pos[b] | (uintptr_t)p.blob[b] | (uintptr_t)p.out[b] | (uintptr_t)p.gal[b]) & 15) {
+            set_error("tower_seq: buffers must be 16-byte aligned");
+            return DLDKD_EINVAL;
+        }
+    }
+    p.row0 = row0; p.lens = lens; p.items = items; p.n_items = n_items; p.n_branches = n_branches; p.max_pos = max_pos;
+    p.seq_rows = seq_rows; p.v0 = v0; p.Lp = Lp; p.lens_out = lens_out;
+    const dim3 grid(n_branches == 2 ? 8u * (unsigned)((n_items + 3) / 4) : (unsigned)n_items);
+    const void* fn = out_mode == 1 ? (const void*)tw::tower_seq_kernel<true, 1> : (const void*)tw::tower_seq_kernel<true, 0>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("tower_seq: cannot reserve %d bytes of LDS", tw::kLdsTotal);
+        return DLDKD_ELAUNCH;
+    }
+    if (out_mode == 1) DLDKD_LAUNCH((tw::tower_seq_kernel<true, 1>), grid, dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
+    else DLDKD_LAUNCH((tw::tower_seq_kernel<true, 0>), grid, dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
+    return check_launch("tower_seq");
+}
+
+}  // extern "C"

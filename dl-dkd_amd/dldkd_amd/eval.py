@@ -134,13 +134,13 @@ def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
                         num_workers=opt.num_workers, shuffle=False, pin_memory=opt.pin_memory)
     metas, inh, exp, masks = [], [], [], []
     packer = None
-    pend_f, pend_m, pend_n = [], [], 0
+    pend_f, pend_m, pend_l, pend_n = [], [], [], 0
 
     def flush():
         """encode the pending loader batches as ONE super-batch (zero-padded to its longest video; padded clips are
         masked out of attention exactly): at eval_context_bsz = 200 a batch is 200 workgroups of 128 rows on 256 CUs, so
         every tower kernel runs a single partly-filled round; 1024 videos give four full ones"""
-        nonlocal pend_f, pend_m, pend_n, packer
+        nonlocal pend_f, pend_m, pend_l, pend_n, packer
         if not pend_f:
             return
         if len(pend_f) == 1:
@@ -154,6 +154,15 @@ def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
                 feat[o:o + f.shape[0], :f.shape[1]] = f
                 mask[o:o + f.shape[0], :f.shape[1]] = m_
                 o += f.shape[0]
+        if not keep_frame_feats and getattr(model, "fast_input_proj", False):
+            # throughput mode: input projection + ONE fused tower kernel that writes the packed bf16 gallery rows
+            if packer is None:
+                packer = scoring.GalleryPacker(len(eval_dataset), int(_cfg_get(model.config, "max_ctx_l")),
+                                               2 if model.double_branch else 1, feat.device)
+            if model.encode_context_into(packer, feat, mask, lens_host=np.concatenate(pend_l)):
+                masks.append(mask)
+                pend_f, pend_m, pend_l, pend_n = [], [], [], 0
+                return
         gi, ge = model.encode_context(feat, mask)
         if keep_frame_feats:
             # the reference's dict holds zeros beyond each LOADER batch's own longest video (cat_tensor, eval.py:139-155);
@@ -173,11 +182,12 @@ def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
                                                2 if model.double_branch else 1, gi.device)
             packer.add([gi, ge] if model.double_branch else [gi], mask)
         masks.append(mask)
-        pend_f, pend_m, pend_n = [], [], 0
+        pend_f, pend_m, pend_l, pend_n = [], [], [], 0
 
     with torch.no_grad(), host_threads():
         for batch in loader:
             metas.extend(batch[-1])
+            pend_l.append((batch[1] > 0).sum(1).numpy())           # lengths on the host (the loader's mask is a CPU tensor)
             pend_f.append(batch[0].to(opt.device, non_blocking=True))
             pend_m.append(batch[1].to(opt.device, non_blocking=True))
             pend_n += batch[0].shape[0]

@@ -127,9 +127,44 @@ class DLDKD(nn.Module):
             mask = mask.float().unsqueeze(1)
         return encoder_layer(h, mask)
 
+    def _tower_packs(self, kind):
+        """ops.TowerPack per branch for the fused per-sequence tower kernel ("visual": with the out mapping)."""
+        key = kind + "_tower"
+        if key not in self._folded:
+            self._folded[key] = [ops.TowerPack(getattr(self, pre + kind + "_pos_embed"), getattr(self, pre + kind + "_encoder"),
+                                               getattr(self, pre + "out_mapping_linear"))
+                                 for pre in (("", "exp_") if self.double_branch else ("",))]
+        return self._folded[key]
+
+    def encode_context_into(self, packer, frame_video_feat, video_mask, lens_host=None):
+        """Throughput-mode gallery encode straight into the scorer's resident bf16 gallery (scoring.GalleryPacker): input
+        projection (K4) + ONE fused tower kernel per (32-row slot, branch) that L2-normalises and writes the packed rows - the
+        fp32 (n, L, 384) tower outputs are never formed.  lens_host (numpy, optional): the lengths on the host; with them short
+        videos share workgroups (ops.plan_tower_items).  Returns False when the fused path does not apply."""
+        if not (self.fast_input_proj and self._use_fast(frame_video_feat)):
+            return False
+        h0 = self._fast_proj("visual", frame_video_feat)
+        if not ops.tower_seq_ok(h0[0]):
+            return False
+        n, L = frame_video_feat.shape[0], frame_video_feat.shape[1]
+        lens = self._lens(video_mask, n, L, frame_video_feat.device)
+        items = None
+        if lens_host is not None:
+            items = torch.from_numpy(ops.plan_tower_items(lens_host)).to(lens.device, non_blocking=True)
+        v0 = packer.reserve(n, L)
+        ops.tower_seq(h0, self._tower_packs("visual"), lens, seq_rows=L, items=items, out_mode=1, gallery=packer.blobs, v0=v0,
+                      Lp=packer.Lp, lens_out=packer.lens)
+        return True
+
     def encode_context(self, frame_video_feat, video_mask=None):
         out = []
         fast = self._fast_proj("visual", frame_video_feat) if self._use_fast(frame_video_feat) else None
+        if fast is not None and self.fast_input_proj and ops.tower_seq_ok(fast[0]):
+            # throughput mode: everything behind the input projection is one kernel; rows past a video's length come out as zeros
+            # (the reference computes don't-care values there, masked out of every consumer: model.py:444-445)
+            n, L = frame_video_feat.shape[0], frame_video_feat.shape[1]
+            out = ops.tower_seq(fast, self._tower_packs("visual"), self._lens(video_mask, n, L, frame_video_feat.device), seq_rows=L)
+            return (out[0], out[1]) if self.double_branch else (out[0], None)
         for bi, pre in enumerate(("", "exp_") if self.double_branch else ("",)):
             if fast is not None:
                 h = self._encode_after_proj(fast[bi], video_mask, getattr(self, pre + "visual_encoder"),

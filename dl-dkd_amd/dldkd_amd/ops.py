@@ -392,3 +392,119 @@ def in_proj_bf16(x, folded, relu=True):
                                       native.ptr(ys[1]) if f.nb == 2 else None, M, f.nb * HIDDEN, K, LN_EPS, int(relu),
                                       native.stream()), "in_proj_bf16")
     return [y.view(*x.shape[:-1], HIDDEN) for y in ys]
+
+
+# ---------------------------------------------------------------------------------------------- K5: fused per-sequence tower
+TOWER_SEQ = True      # throughput-mode inference: everything behind the input projection as one kernel (tower_seq.hip)
+
+
+class TowerPack:
+    """One branch's tower behind the input projection (position LayerNorm, q | k | v, dense + LayerNorm, out mapping) as the
+    bf16 fragment blob of tower_seq_kernel; rebuilt when a parameter changes (like PackedLinear)."""
+
+    def __init__(self, pos_embed, encoder, out_linear):
+        self.pos_embed, self.encoder, self.out_linear = pos_embed, encoder, out_linear
+        self.key = None
+
+    def _params(self):
+        a, o = self.encoder.self, self.encoder.output
+        return [self.pos_embed.LayerNorm.weight, self.pos_embed.LayerNorm.bias, a.query.weight, a.query.bias, a.key.weight, a.key.bias,
+                a.value.weight, a.value.bias, o.dense.weight, o.dense.bias, o.LayerNorm.weight, o.LayerNorm.bias,
+                self.out_linear.weight, self.out_linear.bias]
+
+    def get(self):
+        ps = self._params()
+        key = (_PARAM_EPOCH,) + tuple((t.data_ptr(), t._version) for t in ps)
+        if key != self.key:
+            L = native.lib()
+            self.blob = torch.empty(L.dldkd_tower_blob_bytes(1), dtype=torch.uint8, device=ps[0].device)
+            args = [native.ptr(_chk(t.detach().contiguous(), "tower_pack")) for t in ps]
+            native.check(L.dldkd_tower_pack_bf16(*args, native.ptr(self.blob), native.stream()), "tower_pack")
+            self.key = key
+        return self
+
+    @property
+    def pos(self):
+        return self.pos_embed.position_embeddings.weight
+
+
+def tower_seq_ok(h0):
+    """The fused tower serves inference in throughput mode (bf16 GEMMs), hidden 384, at most 128 rows per sequence."""
+    return (TOWER_SEQ and _PRECISION == "bf16" and not torch.is_grad_enabled() and h0.is_cuda and h0.shape[-1] == HIDDEN
+            and h0.dim() == 3 and h0.shape[1] <= 128)
+
+
+def plan_tower_items(lens):
+    """Host-side packing of 32-row tiles into workgroups of four slots: int32 (n_items, 4) of (seq << 2) | tile, -1 = idle.
+    A sequence's tiles sit in consecutive slots of one workgroup; sequences of length 0 get no slot."""
+    import numpy as np
+    lens = np.asarray(lens, dtype=np.int64)
+    nt = (lens + 31) // 32
+    if (nt > 4).any():
+        raise native.NativeError("plan_tower_items: at most 128 rows per sequence")
+    by = {k: np.nonzero(nt == k)[0] for k in (1, 2, 3, 4)}
+    n1, n2, n3 = len(by[1]), len(by[2]), len(by[3])
+    rows = []
+
+    def block(seqs_tiles):          # list of (seq array, n tiles) columns side by side -> (n, 4) int32
+        n = len(seqs_tiles[0][0])
+        out = np.full((n, 4), -1, np.int64)
+        c = 0
+        for seqs, k in seqs_tiles:
+            for t in range(k):
+                out[:, c] = (seqs << 2) | t
+                c += 1
+        return out
+    if len(by[4]):
+        rows.append(block([(by[4], 4)]))
+    ones = by[1]
+    k31 = min(n3, n1)                                   # 3 + 1
+    if k31:
+        rows.append(block([(by[3][:k31], 3), (ones[:k31], 1)]))
+    if n3 > k31:
+        rows.append(block([(by[3][k31:], 3)]))
+    ones = ones[k31:]
+    k22 = n2 // 2                                       # 2 + 2
+    if k22:
+        rows.append(block([(by[2][:k22], 2), (by[2][k22:2 * k22], 2)]))
+    if n2 % 2:                                          # 2 + 1 + 1
+        it = np.full((1, 4), -1, np.int64)
+        s = by[2][-1]
+        it[0, 0], it[0, 1] = (s << 2), (s << 2) | 1
+        for c in (2, 3):
+            if len(ones):
+                it[0, c] = ones[0] << 2
+                ones = ones[1:]
+        rows.append(it)
+    if len(ones):                                       # 1 + 1 + 1 + 1
+        pad = (-len(ones)) % 4
+        o = np.concatenate([ones << 2, np.full(pad, -1, np.int64)]).reshape(-1, 4)
+        rows.append(o)
+    if not rows:
+        return np.zeros((0, 4), np.int32)
+    return np.ascontiguousarray(np.concatenate(rows, 0).astype(np.int32))
+
+
+def tower_seq(h0, packs, lens, seq_rows=0, row0=None, items=None, out_mode=0, gallery=None, v0=0, Lp=0, lens_out=None):
+    """h0: list (one per branch) of fp32 rows (..., 384) - the input projection's output; packs: list of TowerPack; lens int32
+    GPU (n_seq).  items: int32 GPU (n_items, 4) from plan_tower_items or None (workgroup i = sequence i, rows i * seq_rows ..).
+    out_mode 0 -> list of fp32 tensors shaped like h0; out_mode 1 -> writes videos v0 .. of the bf16 gallery blobs."""
+    L = native.lib()
+    nb = len(h0)
+    fs = [p.get() for p in packs]
+    hs = [_chk(x.reshape(-1, HIDDEN), "tower_seq.h0") for x in h0]
+    poss = [_chk(f.pos.detach(), "tower_seq.pos") for f in fs]
+    if lens.dtype != torch.int32 or not lens.is_cuda:
+        raise native.NativeError("tower_seq: lens must be an int32 GPU tensor")
+    n_items = lens.shape[0] if items is None else items.shape[0]
+    outs = None
+    if out_mode == 0:
+        outs = [torch.empty_like(x) for x in hs]
+    native.check(L.dldkd_tower_seq_bf16(native.ptr_array(hs), native.ptr_array(poss), native.ptr_array([f.blob for f in fs]),
+                                        native.ptr(row0), native.ptr(lens), native.ptr(items), n_items, nb, poss[0].shape[0], 1,
+                                        out_mode, native.ptr_array(outs) if outs is not None else None, int(seq_rows),
+                                        native.ptr_array(gallery) if gallery is not None else None, int(v0), int(Lp),
+                                        native.ptr(lens_out), native.stream()), "tower_seq")
+    if outs is not None:
+        return [o.view(x.shape) for o, x in zip(outs, h0)]
+    return None

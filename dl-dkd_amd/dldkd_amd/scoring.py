@@ -96,6 +96,19 @@ class GalleryPacker:
                       for _ in range(n_branches)]
         self.lens = torch.zeros(max(nv, 1), dtype=torch.int32, device=device)
 
+    @property
+    def Lp(self):
+        return (self.L + 31) // 32 * 32
+
+    def reserve(self, n, lc):
+        """Claim videos [filled, filled + n) for a producer that writes the packed rows itself (the fused tower kernel);
+        returns the first video index."""
+        if self.filled + n > self.nv or lc > self.L:
+            raise native.NativeError(f"GalleryPacker.reserve: batch of {n} x {lc} does not fit ({self.filled}/{self.nv} x {self.L})")
+        v0 = self.filled
+        self.filled += n
+        return v0
+
     def add(self, gs, mask):
         n, lc = gs[0].shape[0], gs[0].shape[1]
         if len(gs) != len(self.blobs) or self.filled + n > self.nv or lc > self.L:

@@ -425,6 +425,36 @@ int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const
 int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv, int ld, int32_t* counts, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K5: the whole tower behind the input projection as ONE kernel per (32-row tile slot, branch), throughput mode (bf16 MFMA):
+ *   h1 = LayerNorm(h0 + pos)                          TrainablePositionalEncoding.forward  method/model_components.py:277-284
+ *   ctx = softmax(q k^T / sqrt(96) + key mask) v      BertSelfAttention.forward            method/model_components.py:398-436
+ *   h2 = LayerNorm(ctx Wd^T + bd + h1)                BertSelfOutput / BertAttention       method/model_components.py:446-450,345-353
+ *   y = h2 Wo^T + bo                                  out_mapping_linear                   method/model.py:219
+ *   out_mode 1: row = bf16(y / max(|y|, 1e-12))       F.normalize in get_sim_scores        method/model.py:319
+ * dldkd_tower_blob_bytes / dldkd_tower_pack_bf16: one branch's weights as bf16 MFMA fragments in the kernel's consumption
+ * order (k permuted to the accumulator layout, q pre-scaled by log2(e) / sqrt(96)) followed by its bias / gamma / beta vectors;
+ * all weight matrices (384, 384) row-major, vectors (384).
+ * dldkd_tower_seq_bf16: h0 / pos / blob / out_rows / gallery are HOST arrays of n_branches device pointers.
+ *   h0[b] (rows, 384) fp32: the input projection's output; sequence s owns rows row0[s] .. row0[s] + lens[s] - 1
+ *     (row0 == NULL: s * seq_rows); lens[s] > 0 for every scheduled sequence; at most 128 rows per sequence.
+ *   pos[b] (max_pos, 384) fp32: position_embeddings.weight.
+ *   items (n_items, 4) int32 or NULL: the four 32-row slots of workgroup i: (s << 2) | tile, -1 = idle; the tiles of one
+ *     sequence occupy consecutive slots of ONE workgroup in order (short sequences share a workgroup).  NULL: workgroup i
+ *     is sequence i (n_items sequences).
+ *   out_mode 0: out_rows[b] (rows, 384) fp32 indexed like h0; rows lens[s] .. seq_rows - 1 of a sequence are written as zeros.
+ *   out_mode 1: gallery[b] = the scorer's bf16 blob [nv_total][Lp][384] (dldkd_pack_gallery_bf16's layout: rows past the
+ *     length inside the last 16-row tile replicate the last clip, further rows zero); sequence s is video v0 + s;
+ *     lens_out (whole gallery, or NULL) receives lens.  Lp a multiple of 32. */
+size_t dldkd_tower_blob_bytes(int with_out_map);
+int dldkd_tower_pack_bf16(const float* ln1_g, const float* ln1_b, const float* wq, const float* bq, const float* wk, const float* bk,
+                          const float* wv, const float* bv, const float* wd, const float* bd, const float* ln2_g, const float* ln2_b,
+                          const float* wo, const float* bo, void* blob, void* stream);
+int dldkd_tower_seq_bf16(const float* const* h0, const float* const* pos, const void* const* blob, const int32_t* row0,
+                         const int32_t* lens, const int32_t* items, int n_items, int n_branches, int max_pos, int with_out_map,
+                         int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Feature ingest: temporal down-sampling + L2 normalisation + padding of raw frame features on the GPU.
  * Replaces uniform_feature_sampling / l2_normalize_np_array / cat_videos (method/data_provider.py:52-86).
  * frames (n_frames, D) fp32; output row r (n_rows = batch * Lmax, D): padding when seg_start[r] < 0, else the

@@ -1,0 +1,216 @@
+"""K5, the fused per-sequence tower kernel (tower_seq.hip), throughput mode: against fp64 math that rounds to bf16 where the
+kernel does (layout / masking / packing bugs show as O(1) errors there), against plain fp64 math at the bf16-mode tolerance
+of the other throughput kernels, and the packed-gallery output against the packer it replaces."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from test_encoder_gpu import _model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+H = 384
+
+
+def _bf(t):
+    return t.float().bfloat16().double()
+
+
+class _Tower(torch.nn.Module):
+    """parameter holder with the attribute names ops.TowerPack reads"""
+
+    def __init__(self, seed, scale=0.06, max_pos=128):
+        super().__init__()
+        from dldkd_amd.model_components import BertAttention, TrainablePositionalEncoding
+        import types
+        g = torch.Generator().manual_seed(seed)
+        self.pos = TrainablePositionalEncoding(max_pos, H, 0.1)
+        self.enc = BertAttention(types.SimpleNamespace(hidden_size=H, num_attention_heads=4, hidden_dropout_prob=0.1,
+                                                       attention_probs_dropout_prob=0.1))
+        self.out = torch.nn.Linear(H, H)
+        for name, p in self.named_parameters():
+            if "LayerNorm.weight" in name:
+                p.data = 1.0 + 0.2 * torch.randn(p.shape, generator=g)
+            elif p.dim() == 1:
+                p.data = 0.2 * torch.randn(p.shape, generator=g)
+            elif "position" in name:
+                p.data = 0.5 * torch.randn(p.shape, generator=g)
+            else:
+                p.data = scale * torch.randn(p.shape, generator=g)
+
+
+def _ln(x, w, b):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + 1e-5) * w + b
+
+
+def _reference(t, h0, lens, rounded):
+    """fp64 tower of ONE sequence batch h0 (n, L, 384); rounded: bf16 roundings where the kernel has them"""
+    rd = _bf if rounded else (lambda z: z.double())
+    P = {k: v.detach().double().cpu() for k, v in t.named_parameters()}
+    n, L, _ = h0.shape
+    c = 1.4426950408889634 / 96 ** 0.5
+    x = h0.double() + P["pos.position_embeddings.weight"][:L]
+    h1 = rd(_ln(x, P["pos.LayerNorm.weight"], P["pos.LayerNorm.bias"]))
+    if rounded:
+        q = rd(h1 @ _bf(P["enc.self.query.weight"] * c).t() + (P["enc.self.query.bias"].float() * np.float32(c)).double())
+    else:
+        q = (h1 @ P["enc.self.query.weight"].t() + P["enc.self.query.bias"]) * c
+    k = rd(h1 @ rd(P["enc.self.key.weight"]).t() + P["enc.self.key.bias"])
+    v = rd(h1 @ rd(P["enc.self.value.weight"]).t() + P["enc.self.value.bias"])
+    q, k, v = [z.view(n, L, 4, 96).transpose(1, 2) for z in (q, k, v)]
+    s = q @ k.transpose(-1, -2)                                         # log2 domain
+    kmask = torch.arange(L)[None, :] >= lens[:, None]
+    s = s.masked_fill(kmask[:, None, None, :], float("-inf"))
+    p = torch.exp2(s - s.max(-1, keepdim=True).values)
+    o = (rd(p) @ v) / p.sum(-1, keepdim=True)
+    ctx = rd(o.transpose(1, 2).reshape(n, L, H))
+    d = ctx @ rd(P["enc.output.dense.weight"]).t() + P["enc.output.dense.bias"] + h1
+    h2 = rd(_ln(d, P["enc.output.LayerNorm.weight"], P["enc.output.LayerNorm.bias"]))
+    return h2 @ rd(P["out.weight"]).t() + P["out.bias"]
+
+
+LENS = [128, 1, 31, 32, 33, 64, 65, 96, 100, 127, 17]
+
+
+def _setup(seed=3, L=128, lens=LENS):
+    from dldkd_amd import ops
+    torch.manual_seed(seed)
+    ts = [_Tower(10 + seed).to(DEV), _Tower(20 + seed).to(DEV)]
+    packs = [ops.TowerPack(t.pos, t.enc, t.out) for t in ts]
+    n = len(lens)
+    g = torch.Generator().manual_seed(seed)
+    h0 = [torch.relu(torch.randn(n, L, H, generator=g)) for _ in range(2)]     # the input projection ends in a ReLU
+    lens_t = torch.tensor([min(x, L) for x in lens], dtype=torch.int32)
+    for x in h0:                                                       # rows past the length: whatever the projection left there
+        x[torch.arange(L)[None, :] >= lens_t[:, None]] = 7.0
+    return ts, packs, h0, lens_t
+
+
+@pytest.mark.parametrize("L", [128, 40])
+def test_tower_seq_rows_vs_rounded_fp64(L):
+    from dldkd_amd import ops
+    ts, packs, h0, lens = _setup(L=L)
+    out = ops.tower_seq([x.to(DEV) for x in h0], packs, lens.to(DEV), seq_rows=L)
+    torch.cuda.synchronize()
+    for b in range(2):
+        o = out[b].cpu().double()
+        ref_r = _reference(ts[b].cpu(), h0[b], lens.long(), True)
+        ref_p = _reference(ts[b].cpu(), h0[b], lens.long(), False)
+        for i, ln in enumerate(lens.tolist()):
+            sc = ref_p[i, :ln].abs().max().item()
+            e_r = (o[i, :ln] - ref_r[i, :ln]).abs().max().item()
+            e_p = (o[i, :ln] - ref_p[i, :ln]).abs().max().item()
+            # same roundings: what is left is fp32 accumulation order and operands that sit on a bf16 rounding boundary
+            assert e_r < 1.2e-2 * sc, (b, i, ln, e_r, sc)
+            assert (o[i, :ln] - ref_r[i, :ln]).abs().mean().item() < 1.5e-3 * sc, (b, i, ln)
+            assert e_p < 4e-2 * sc, (b, i, ln, e_p, sc)                # bf16 operands against exact math
+            assert torch.equal(o[i, ln:], torch.zeros_like(o[i, ln:])), (b, i, ln)      # rows past the sequence: zeros
+
+
+def test_tower_seq_packed_items_equal_one_sequence_per_workgroup():
+    """Short sequences sharing a workgroup (plan_tower_items) compute exactly what they compute alone."""
+    from dldkd_amd import ops
+    lens = [128, 1, 31, 32, 33, 64, 65, 96, 100, 127, 17, 5, 20, 30, 64, 50, 40, 97, 2, 64]
+    ts, packs, h0, lens_t = _setup(seed=5, lens=lens)
+    hd = [x.to(DEV) for x in h0]
+    a = ops.tower_seq(hd, packs, lens_t.to(DEV), seq_rows=128)
+    items = ops.plan_tower_items(lens_t.numpy())
+    assert items.shape[0] < len(lens)                                    # something was packed
+    b = ops.tower_seq(hd, packs, lens_t.to(DEV), seq_rows=128, items=torch.from_numpy(items).to(DEV))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_tower_seq_gallery_rows_equal_packer_of_the_fp32_rows():
+    """out_mode 1 (normalise + bf16 + the scorer's row layout) against pack_gallery of the out_mode 0 rows: same values up to
+    one bf16 ulp (the L2 norm is summed in a different order), same lens, same replicated / zero padding rows."""
+    from dldkd_amd import ops, scoring
+    lens = [128, 1, 31, 32, 33, 64, 65, 96, 100, 127, 17, 16, 15, 48]
+    ts, packs, h0, lens_t = _setup(seed=7, lens=lens)
+    hd = [x.to(DEV) for x in h0]
+    n = len(lens)
+    rows = ops.tower_seq(hd, packs, lens_t.to(DEV), seq_rows=128)
+    mask = (torch.arange(128)[None, :] < lens_t[:, None]).float().to(DEV)
+    want = scoring.pack_gallery(rows, mask)
+    for items in (None, torch.from_numpy(ops.plan_tower_items(lens_t.numpy())).to(DEV)):
+        pk = scoring.GalleryPacker(n + 3, 128, 2, torch.device(DEV))
+        for blob in pk.blobs:
+            blob.fill_(0x55)
+        v0 = 2
+        pk.filled = v0
+        pk.reserve(n, 128)
+        ops.tower_seq(hd, packs, lens_t.to(DEV), seq_rows=128, items=items, out_mode=1, gallery=pk.blobs, v0=v0, Lp=pk.Lp,
+                      lens_out=pk.lens)
+        torch.cuda.synchronize()
+        assert torch.equal(pk.lens[v0:v0 + n].cpu(), lens_t)
+        for b in range(2):
+            got = pk.blobs[b].view(torch.bfloat16).view(n + 3, 128, H)[v0:v0 + n].float().cpu()
+            ref = want.blobs[b].view(torch.bfloat16).view(n, 128, H).float().cpu()
+            assert (got - ref).abs().max().item() <= 2 ** -8 + 1e-9          # unit rows: |x| <= 1, bf16 ulp <= 2^-8
+            assert ((got - ref).abs() > 0).float().mean().item() < 0.02
+            for i, ln in enumerate(lens):
+                l16 = (ln + 15) // 16 * 16
+                assert torch.equal(got[i, ln:l16], got[i, ln - 1:ln].expand(l16 - ln, H))
+                assert torch.equal(got[i, l16:], torch.zeros(128 - l16, H))
+            other = pk.blobs[b].view(n + 3, -1)
+            assert (other[:v0] == 0x55).all() and (other[v0 + n:] == 0x55).all()    # nobody else's rows touched
+
+
+def test_encode_context_fused_vs_unfused_throughput_mode():
+    """DLDKD.encode_context in throughput mode: fused tower kernel against the kernel chain it replaces (K4 output is the
+    same tensor in both) and against the fp32 parity towers."""
+    from dldkd_amd import ops
+    m = _model(3072, 768, synth.make_params(31, 3072, 768))
+    rs = np.random.RandomState(4)
+    lens = np.array([128, 3, 64, 100, 33, 77, 128, 9])
+    vid, vmask = synth.make_videos(rs, 8, 128, 3072, lens)
+    vid, vmask = [torch.from_numpy(a.astype(np.float32)).to(DEV) for a in (vid, vmask)]
+    with torch.no_grad():
+        par = m.encode_context(vid, vmask)
+        m.fast_input_proj = True
+        ops.set_gemm_precision("bf16")
+        try:
+            fused = m.encode_context(vid, vmask)
+            ops.TOWER_SEQ = False
+            chain = m.encode_context(vid, vmask)
+        finally:
+            ops.TOWER_SEQ = True
+            ops.set_gemm_precision("fp32")
+            m.fast_input_proj = False
+    valid = vmask.bool()
+    for f, c, p_ in zip(fused, chain, par):
+        sc = p_[valid].abs().max().item()
+        assert (f[valid] - c[valid]).abs().max().item() < 3e-2 * sc
+        assert (f[valid] - p_[valid]).abs().max().item() < 3e-2 * sc
+        assert (f[~valid] == 0).all()
+
+
+def test_eval_epoch_fused_gallery_path(golden_dir):
+    """compute_context_info(keep_frame_feats=False) in throughput mode goes through encode_context_into (K4 + fused tower
+    straight into the packed gallery): scores against the fp32 parity path on the G5 inputs."""
+    import types
+    from dldkd_amd import eval as ev, ops
+    m = _model(3072, 768, synth.make_params(51, 3072, 768))
+    vids, txts = synth.make_eval_sets(5, nv=64, caps=3, dv=3072, dq=768)
+    opt = types.SimpleNamespace(eval_context_bsz=25, eval_query_bsz=50, num_workers=0, pin_memory=False,
+                                device=torch.device(DEV), double_branch=True)
+    res = {}
+    calls = []
+    real = m.encode_context_into
+    m.encode_context_into = lambda *a, **k: calls.append(1) or real(*a, **k)
+    try:
+        for mode in ("fp32", "bf16"):
+            ops.set_gemm_precision(mode)
+            m.fast_input_proj = mode == "bf16"
+            with torch.no_grad():
+                ctx = ev.compute_context_info(m, synth.ListDataset(list(vids)), opt, keep_frame_feats=False)
+                fused, s0, s1, qmetas = ev.score_queries(m, synth.ListDataset(list(txts)), opt, ctx)
+            res[mode] = fused.cpu()
+    finally:
+        ops.set_gemm_precision("fp32")
+        m.fast_input_proj = False
+    assert calls, "the throughput-mode eval driver did not take the fused gallery path"
+    assert (res["bf16"] - res["fp32"]).abs().max().item() < 2e-2
