@@ -95,7 +95,8 @@ struct TowerArgs {
                               // the 32-row tiles of one sequence sit in consecutive slots, in order.  null: workgroup i = sequence i
     int n_items, n_branches, max_pos;
     float* out[2];            // OUTMODE 0: fp32 rows (., 384), indexed like h0
-    int seq_rows;             // OUTMODE 0: rows allotted per sequence (rows len .. seq_rows - 1 are written as zeros), 0 = ragged
+    int seq_rows;             // OUTMODE 0: rows allotted per sequence, 0 = ragged.  Rows len .. seq_rows - 1: computed like the
+                              // reference does (no item table) or written as zeros (with an item table)
     char* gal[2];             // OUTMODE 1: gallery blobs bf16 [nv][Lp][384]
     int v0, Lp;               // OUTMODE 1: gallery index of sequence 0, rows per video
     int32_t* lens_out;        // OUTMODE 1: lens of the whole gallery (or null)
@@ -127,11 +128,16 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         seq = ent >> 2;
         tile = ent & 3;
     } else {
+        // without an item table the workgroup is sequence `item`.  OUTMODE 0 then computes ALL seq_rows rows: a clip past the
+        // length is a query like any other (only KEYS are masked, model_components.py:422), so its row comes out as the
+        // reference computes it from the zero features - don't-care values, but the same ones.
         seq = item;
         tile = wave;
-        if (wave > 0 && 32 * wave >= p.lens[item]) { live = false; tile = 0; }
+        const int rows = OUTMODE == 0 && p.seq_rows > p.lens[item] ? p.seq_rows : p.lens[item];
+        if (wave > 0 && 32 * wave >= rows) { live = false; tile = 0; }
     }
     const int len = p.lens[seq];
+    const int nrows = OUTMODE == 0 && p.items == nullptr && p.seq_rows > len ? p.seq_rows : len;   // rows computed and stored
     const int first = live ? wave - tile : 0;          // slot of the sequence's tile 0 (K / V fragments of key tile kt: slot first + kt)
     const int row0 = p.row0 != nullptr ? p.row0[seq] : seq * p.seq_rows;
     if (len <= 0) {     // only without an item table (the host never schedules an empty sequence): the workgroup IS the sequence
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
     bf16x8 X1[kNKS];     // h1^T (later h2^T) as MFMA operand fragments: lane = (row r, half h), k-step ks, 8 features
     {
         const int l = 32 * tile + r;
-        const int lrow = l < len ? l : len - 1;                       // rows past the sequence: a finite copy (never stored)
+        const int lrow = l < nrows ? l : nrows - 1;                   // rows past the sequence: a finite copy (never stored)
         const int lpos = l < p.max_pos ? l : p.max_pos - 1;
         const float* xr = p.h0[branch] + (size_t)(row0 + lrow) * kHidden + 4 * h;
         const float* pr = p.pos[branch] + (size_t)lpos * kHidden + 4 * h;
@@ -496,13 +502,13 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
             for (int it = 0; it < 12; ++it) {
                 const int idx = lane + 64 * it, row = idx / 24, c = idx % 24;
                 const int l = 32 * tile + row;
-                if (l >= len && l >= p.seq_rows) continue;
+                if (l >= nrows && l >= p.seq_rows) continue;
                 f32x4 v = z4;
-                if (l < len) v = *reinterpret_cast<const f32x4*>(stg + row * kStgPitch + 16 * c);
+                if (l < nrows) v = *reinterpret_cast<const f32x4*>(stg + row * kStgPitch + 16 * c);
                 *reinterpret_cast<f32x4*>(o + (size_t)l * kHidden + pass * 96 + 4 * c) = v;
             }
         }
-        if (tile == ntiles - 1)
+        if (p.items != nullptr && tile == ntiles - 1)                  // with an item table: zero rows behind the sequence
             for (int i = 32 * ntiles * 96 + lane; i < p.seq_rows * 96; i += 64) *reinterpret_cast<f32x4*>(o + (size_t)i * 4) = z4;
     }
 }
@@ -613,8 +619,11 @@ int dldkd_tower_seq_bf16(const float* const* h0, const float* const* pos, const 
     p.row0 = row0; p.lens = lens; p.items = items; p.n_items = n_items; p.n_branches = n_branches; p.max_pos = max_pos;
     p.seq_rows = seq_rows; p.v0 = v0; p.Lp = Lp; p.lens_out = lens_out;
     const dim3 grid(n_branches == 2 ? 8u * (unsigned)((n_items + 3) / 4) : (unsigned)n_items);
-    const void* fn = out_mode == 1 ? (const void*)tw::tower_seq_kernel<true, 1> : (const void*)tw::tower_seq_kernel<true, 0>;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) != hipSuccess) {
+    static const bool lds_ok = [] {           // once per process: the attribute call is a driver round trip
+        return hipFuncSetAttribute((const void*)tw::tower_seq_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) == hipSuccess &&
+               hipFuncSetAttribute((const void*)tw::tower_seq_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) == hipSuccess;
+    }();
+    if (!lds_ok) {
         (void)hipGetLastError();
         set_error("tower_seq: cannot reserve %d bytes of LDS", tw::kLdsTotal);
         return DLDKD_ELAUNCH;

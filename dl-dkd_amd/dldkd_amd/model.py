@@ -136,6 +136,21 @@ class DLDKD(nn.Module):
                                  for pre in (("", "exp_") if self.double_branch else ("",))]
         return self._folded[key]
 
+    def _upload_items(self, items_np, device):
+        """Slot table of the fused tower kernel -> device through a ring of pinned slots (staging.PinnedRing): a pageable copy
+        parks the host until the stream drains, and a fresh pin_memory() per call is a multi-millisecond driver allocation
+        whenever the host runs ahead of the GPU."""
+        from .staging import PinnedRing
+        nbytes = items_np.nbytes
+        ring = getattr(self, "_item_ring", None)
+        if ring is None or ring.bufs[0].numel() < nbytes:
+            ring = self._item_ring = PinnedRing(max(nbytes, 64 * 1024), device, slots=8)
+        slot = ring.next()
+        slot[:nbytes].view(torch.int32).view(-1, 4).copy_(torch.from_numpy(items_np))
+        dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        ring.upload(dev)
+        return dev.view(torch.int32).view(-1, 4)
+
     def encode_context_into(self, packer, frame_video_feat, video_mask, lens_host=None):
         """Throughput-mode gallery encode straight into the scorer's resident bf16 gallery (scoring.GalleryPacker): input
         projection (K4) + ONE fused tower kernel per (32-row slot, branch) that L2-normalises and writes the packed rows - the
@@ -143,14 +158,14 @@ class DLDKD(nn.Module):
         videos share workgroups (ops.plan_tower_items).  Returns False when the fused path does not apply."""
         if not (self.fast_input_proj and self._use_fast(frame_video_feat)):
             return False
+        items = None
+        if lens_host is not None:
+            items = self._upload_items(ops.plan_tower_items(lens_host), frame_video_feat.device)
         h0 = self._fast_proj("visual", frame_video_feat)
         if not ops.tower_seq_ok(h0[0]):
             return False
         n, L = frame_video_feat.shape[0], frame_video_feat.shape[1]
         lens = self._lens(video_mask, n, L, frame_video_feat.device)
-        items = None
-        if lens_host is not None:
-            items = torch.from_numpy(ops.plan_tower_items(lens_host)).to(lens.device, non_blocking=True)
         v0 = packer.reserve(n, L)
         ops.tower_seq(h0, self._tower_packs("visual"), lens, seq_rows=L, items=items, out_mode=1, gallery=packer.blobs, v0=v0,
                       Lp=packer.Lp, lens_out=packer.lens)
@@ -160,8 +175,8 @@ class DLDKD(nn.Module):
         out = []
         fast = self._fast_proj("visual", frame_video_feat) if self._use_fast(frame_video_feat) else None
         if fast is not None and self.fast_input_proj and ops.tower_seq_ok(fast[0]):
-            # throughput mode: everything behind the input projection is one kernel; rows past a video's length come out as zeros
-            # (the reference computes don't-care values there, masked out of every consumer: model.py:444-445)
+            # throughput mode: everything behind the input projection is one kernel (clips past a video's length included: they
+            # are queries like any other, as in the reference)
             n, L = frame_video_feat.shape[0], frame_video_feat.shape[1]
             out = ops.tower_seq(fast, self._tower_packs("visual"), self._lens(video_mask, n, L, frame_video_feat.device), seq_rows=L)
             return (out[0], out[1]) if self.double_branch else (out[0], None)

@@ -56,6 +56,18 @@ def pack_queries(qs, normalize=True):
     return PackedQueries(blobs, nq, bad)
 
 
+def visit_order(lens):
+    """(order, inv_order) int32: videos longest first, equal lengths in index order - the 4 waves of a scorer workgroup get
+    similar lengths and the tail of the grid is light (one small counting-sort kernel)."""
+    nv = lens.shape[0]
+    order = torch.empty(nv, dtype=torch.int32, device=lens.device)
+    inv = torch.empty(nv, dtype=torch.int32, device=lens.device)
+    if nv:
+        native.check(native.lib().dldkd_order_by_len_desc(native.ptr(lens.contiguous()), nv, native.ptr(order), native.ptr(inv),
+                                                          native.stream()), "order_by_len_desc")
+    return order, inv
+
+
 def pack_gallery(gs, mask=None, normalize=True):
     """gs: list (one per branch) of (Nv, L, 384) GPU tensors; mask (Nv, L) 0/1 prefix mask or None."""
     L_ = native.lib()
@@ -75,10 +87,7 @@ def pack_gallery(gs, mask=None, normalize=True):
                                                 native.ptr(lens), native.stream()), "pack_gallery")
         blobs.append(blob)
     lens = lens[:nv]
-    # longest first: the 4 waves of a workgroup get similar lengths and the tail of the grid is light
-    order = torch.argsort(lens, descending=True, stable=True).to(torch.int32)
-    inv = torch.empty_like(order)
-    inv[order.long()] = torch.arange(nv, dtype=torch.int32, device=dev)
+    order, inv = visit_order(lens)
     return PackedGallery(blobs, lens, order, inv, nv, L)
 
 
@@ -126,9 +135,7 @@ class GalleryPacker:
         if self.filled != self.nv:
             raise native.NativeError(f"GalleryPacker.finish: {self.filled} of {self.nv} videos packed")
         lens = self.lens[:self.nv]
-        order = torch.argsort(lens, descending=True, stable=True).to(torch.int32)
-        inv = torch.empty_like(order)
-        inv[order.long()] = torch.arange(self.nv, dtype=torch.int32, device=lens.device)
+        order, inv = visit_order(lens)
         return PackedGallery(self.blobs, lens, order, inv, self.nv, self.L)
 
 

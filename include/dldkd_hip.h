@@ -73,6 +73,11 @@ int dldkd_pack_gallery_bf16(const float* g, const float* mask, int nv, int L, in
 int dldkd_pack_gallery_chunk_bf16(const float* g, const float* mask, int nv_chunk, int L_chunk, int normalize,
                                   void* g_packed, int32_t* lens, int v0, int nv_total, int L_total, void* stream);
 
+/* The scorer's visiting order: order[pos] = video by DESCENDING lens (equal lengths in index order), inv_order[video] = pos.
+ * Any permutation is valid for dldkd_simpool_eval_bf16; this one keeps the four videos of a workgroup alike and the grid's tail
+ * light.  lens in [0, DLDKD_MAX_CLIPS] (clamped). */
+int dldkd_order_by_len_desc(const int32_t* lens, int nv, int32_t* order, int32_t* inv_order, void* stream);
+
 /* All-pairs pooled scores, stage 1 (the dominant kernel).  For each branch b < n_branches (1 or 2):
  *     part_b[pos(v), q] = max_{l < lens[v]} < q_packed[b][q], g_packed[b][v, l] >   (model.py:321-327)
  * written to `workspace` as [n_branches][nv][round_up(nq,32)] fp32, videos in `order` (order[pos] = v;
@@ -441,7 +446,9 @@ int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv,
  *   items (n_items, 4) int32 or NULL: the four 32-row slots of workgroup i: (s << 2) | tile, -1 = idle; the tiles of one
  *     sequence occupy consecutive slots of ONE workgroup in order (short sequences share a workgroup).  NULL: workgroup i
  *     is sequence i (n_items sequences).
- *   out_mode 0: out_rows[b] (rows, 384) fp32 indexed like h0; rows lens[s] .. seq_rows - 1 of a sequence are written as zeros.
+ *   out_mode 0: out_rows[b] (rows, 384) fp32 indexed like h0.  Rows lens[s] .. seq_rows - 1 of a sequence: without an item
+ *     table they are computed as the reference computes the clips past a video's length (queries like any other, only keys are
+ *     masked: method/model_components.py:422; don't-care values, but the same ones); with an item table they are zeros.
  *   out_mode 1: gallery[b] = the scorer's bf16 blob [nv_total][Lp][384] (dldkd_pack_gallery_bf16's layout: rows past the
  *     length inside the last 16-row tile replicate the last clip, further rows zero); sequence s is video v0 + s;
  *     lens_out (whole gallery, or NULL) receives lens.  Lp a multiple of 32. */

@@ -222,3 +222,17 @@ def test_fuzz_random_shapes_vs_oracle():
             assert bool((out[:, ~has] == -1e10).all()), (case, b)
         if nb == 1:
             assert torch.equal(fused, s0)
+
+
+@pytest.mark.parametrize("nv", [1, 5, 64, 1023, 1024, 1025, 21793])
+def test_visit_order_kernel_equals_stable_argsort(nv):
+    """dldkd_order_by_len_desc (counting sort) = torch.argsort(lens, descending, stable): the scorer's visiting order."""
+    from dldkd_amd import scoring
+    g = torch.Generator().manual_seed(nv)
+    lens = torch.randint(0, 129, (nv,), generator=g).to(torch.int32)
+    if nv > 4:
+        lens[:3] = torch.tensor([128, 0, 128])
+    order, inv = scoring.visit_order(lens.to("cuda:0"))
+    want = torch.argsort(lens, descending=True, stable=True).to(torch.int32)
+    assert torch.equal(order.cpu(), want)
+    assert torch.equal(inv.cpu()[want.long()], torch.arange(nv, dtype=torch.int32))

@@ -107,7 +107,9 @@ def test_tower_seq_rows_vs_rounded_fp64(L):
             assert e_r < 1.2e-2 * sc, (b, i, ln, e_r, sc)
             assert (o[i, :ln] - ref_r[i, :ln]).abs().mean().item() < 1.5e-3 * sc, (b, i, ln)
             assert e_p < 4e-2 * sc, (b, i, ln, e_p, sc)                # bf16 operands against exact math
-            assert torch.equal(o[i, ln:], torch.zeros_like(o[i, ln:])), (b, i, ln)      # rows past the sequence: zeros
+            if ln < L:     # rows past the sequence: queries like any other (only keys are masked), computed from what h0 holds there
+                e_pad = (o[i, ln:] - ref_r[i, ln:]).abs().max().item()
+                assert e_pad < 1.2e-2 * ref_r[i, ln:].abs().max().item(), (b, i, ln, e_pad)
 
 
 def test_tower_seq_packed_items_equal_one_sequence_per_workgroup():
@@ -120,8 +122,10 @@ def test_tower_seq_packed_items_equal_one_sequence_per_workgroup():
     items = ops.plan_tower_items(lens_t.numpy())
     assert items.shape[0] < len(lens)                                    # something was packed
     b = ops.tower_seq(hd, packs, lens_t.to(DEV), seq_rows=128, items=torch.from_numpy(items).to(DEV))
+    valid = (torch.arange(128)[None, :] < lens_t[:, None]).to(DEV)
     for x, y in zip(a, b):
-        assert torch.equal(x, y)
+        assert torch.equal(x[valid], y[valid])
+        assert (y[~valid] == 0).all()                                    # with an item table: zero rows behind a sequence
 
 
 def test_tower_seq_gallery_rows_equal_packer_of_the_fp32_rows():
@@ -185,7 +189,7 @@ def test_encode_context_fused_vs_unfused_throughput_mode():
         sc = p_[valid].abs().max().item()
         assert (f[valid] - c[valid]).abs().max().item() < 3e-2 * sc
         assert (f[valid] - p_[valid]).abs().max().item() < 3e-2 * sc
-        assert (f[~valid] == 0).all()
+        assert (f[~valid] - p_[~valid]).abs().max().item() < 3e-2 * p_.abs().max().item()    # clips past the length: same don't-cares
 
 
 def test_eval_epoch_fused_gallery_path(golden_dir):
