@@ -7,6 +7,7 @@ is on the hot path.  Differences in HOW (not in what is returned):
   * ranks are counted on the GPU (rank = 1 + #scores above the best ground-truth video) instead of
     np.argsort per query + a pure-Python AP loop (eval.py:69-83,97-111).
 """
+import contextlib
 import logging
 
 import numpy as np
@@ -332,8 +333,9 @@ def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=Fal
     model.eval()
     n_videos = len(val_video_dataset)
     lo, hi, _ = ddist.shard_range(n_videos, rank, world)
-    ctx = compute_context_info(model, Subset(val_video_dataset, range(lo, hi)), opt, keep_frame_feats=False)
-    fused, s0, s1, query_metas = score_queries(model, val_text_dataset, opt, ctx)
+    with eval_precision(model, opt):
+        ctx = compute_context_info(model, Subset(val_video_dataset, range(lo, hi)), opt, keep_frame_feats=False)
+        fused, s0, s1, query_metas = score_queries(model, val_text_dataset, opt, ctx)
     video_metas = gallery_ids(val_video_dataset) if world > 1 else ctx["video_metas"]
     _, t2v_gt = get_gt(video_metas, query_metas)
     nq = len(query_metas)
@@ -358,9 +360,35 @@ def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=Fal
     return r1 + r5 + r10 + r100
 
 
+# Precision of eval_epoch / eval_epoch_sharded (opt.eval_precision overrides):
+#   "throughput" (default; BASELINE configs[1] is bf16): bf16 input projection K4 + the fused bf16 tower kernel K5 + the bf16 scorer.
+#       Gated at R@1/5/10/100 within 0.1 of the fp32 oracle from raw features (tests/test_rk_gate_gpu.py, tools/rk_gate.py).
+#   "parity": whatever ops.gemm_precision() is set to - by default the fp32-grade towers every golden test runs on.
+EVAL_PRECISION = "throughput"
+
+
+@contextlib.contextmanager
+def eval_precision(model, opt):
+    from . import ops
+    mode = getattr(opt, "eval_precision", None) or EVAL_PRECISION
+    if mode not in ("throughput", "parity"):
+        raise ValueError(f"eval_precision must be 'throughput' or 'parity', got {mode!r}")
+    if mode == "parity":
+        yield
+        return
+    prev = (ops.gemm_precision(), model.fast_input_proj)
+    ops.set_gemm_precision("bf16")
+    model.fast_input_proj = True
+    try:
+        yield
+    finally:
+        ops.set_gemm_precision(prev[0])
+        model.fast_input_proj = prev[1]
+
+
 def eval_epoch(model, val_video_dataset, val_text_dataset, opt, test=False):
     """SumR (R@1 + R@5 + R@10 + R@100) of the fused scores; logs the three rankings (eval.py:237-263)."""
-    with host_threads():
+    with host_threads(), eval_precision(model, opt):
         return _eval_epoch(model, val_video_dataset, val_text_dataset, opt, test)
 
 

@@ -15,8 +15,10 @@ DEV = "cuda:0"
 
 
 def _opt():
+    # eval_precision="parity": these tests pin eval_epoch to the reference's outputs through the fp32-grade towers; the
+    # throughput default of eval_epoch is gated in tests/test_rk_gate_gpu.py
     return types.SimpleNamespace(eval_context_bsz=25, eval_query_bsz=50, num_workers=0, pin_memory=False,
-                                 device=torch.device(DEV), double_branch=True)
+                                 device=torch.device(DEV), double_branch=True, eval_precision="parity")
 
 
 def test_rank_kernel_vs_oracle():
