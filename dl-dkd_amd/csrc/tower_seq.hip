@@ -49,6 +49,8 @@ constexpr int P_G1 = 0, P_B1 = 384, P_BQ = 768, P_BK = 1152, P_BV = 1536, P_BD =
 constexpr int kLdsKV = 96 * 1024;              // [ring 96 KiB][K/V exchange, later output staging: 50 KiB][params][key mask]
 constexpr int kKVBytes = 51200;
 constexpr int kLdsPar = kLdsKV + kKVBytes;
+constexpr int P_WG = P_BO;                     // query towers (no out mapping): modular weight x gamma2 in the out-mapping bias slot
+constexpr int P_TAIL = 4;                      // ... followed by c1 = sum w gamma2, c2 = sum w beta2 (+ 2 unused words)
 constexpr int kLdsTotal = kLdsPar + P_TOTAL * 4 + 512;      // 163,840 = all 160 KiB
 constexpr int kStgPitch = 400;                 // output staging: 32 rows x 384 payload bytes per wave and pass
 
@@ -93,16 +95,19 @@ struct TowerArgs {
     const int32_t* lens;      // [n_seq] valid rows (> 0 for every scheduled sequence)
     const int32_t* items;     // [n_items][4]: what the four waves of a workgroup work on: (seq << 2) | tile, or -1 (idle slot);
                               // the 32-row tiles of one sequence sit in consecutive slots, in order.  null: workgroup i = sequence i
-    int n_items, n_branches, max_pos;
+    int n_items, n_seq, n_branches, max_pos;
     float* out[2];            // OUTMODE 0: fp32 rows (., 384), indexed like h0
     int seq_rows;             // OUTMODE 0: rows allotted per sequence, 0 = ragged.  Rows len .. seq_rows - 1: computed like the
                               // reference does (no item table) or written as zeros (with an item table)
     char* gal[2];             // OUTMODE 1: gallery blobs bf16 [nv][Lp][384]
     int v0, Lp;               // OUTMODE 1: gallery index of sequence 0, rows per video
     int32_t* lens_out;        // OUTMODE 1: lens of the whole gallery (or null)
+    float* pooled[2];         // OUTMODE 2: (n_seq, 384) fp32 modular query vectors
 };
 
-// OUTMAP: the stream ends with the 384 x 384 out_mapping_linear (video towers); OUTMODE 0: fp32 rows, 1: packed bf16 gallery
+// OUTMAP: the stream ends with the 384 x 384 out_mapping_linear (video towers); OUTMODE 0: fp32 rows, 1: packed bf16 gallery,
+// 2 (query towers, sequences of at most 32 words, one per wave): the modular attention pooling of get_modularized_queries
+// (method/model.py:245-258) on top: softmax_l(mask_logits(w . h2_l)) -> sum_l a_l h2_l, one 384-vector per sequence.
 template <bool OUTMAP, int OUTMODE>
 __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
     constexpr int NFRAG = kQKVFrags + kSqFrags + (OUTMAP ? kSqFrags : 0);
@@ -127,6 +132,10 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         if (ent < 0) { live = false; ent = p.items[item * 4]; }
         seq = ent >> 2;
         tile = ent & 3;
+    } else if constexpr (OUTMODE == 2) {
+        seq = item * 4 + wave;                         // four single-tile sequences per workgroup
+        tile = 0;
+        if (seq >= p.n_seq) { live = false; seq = item * 4; }
     } else {
         // without an item table the workgroup is sequence `item`.  OUTMODE 0 then computes ALL seq_rows rows: a clip past the
         // length is a query like any other (only KEYS are masked, model_components.py:422), so its row comes out as the
@@ -136,11 +145,12 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         const int rows = OUTMODE == 0 && p.seq_rows > p.lens[item] ? p.seq_rows : p.lens[item];
         if (wave > 0 && 32 * wave >= rows) { live = false; tile = 0; }
     }
-    const int len = p.lens[seq];
+    const int len_raw = p.lens[seq];
+    const int len = OUTMODE == 2 ? (len_raw < 1 ? 1 : len_raw > 32 ? 32 : len_raw) : len_raw;   // (query mode: host contract 1..32)
     const int nrows = OUTMODE == 0 && p.items == nullptr && p.seq_rows > len ? p.seq_rows : len;   // rows computed and stored
-    const int first = live ? wave - tile : 0;          // slot of the sequence's tile 0 (K / V fragments of key tile kt: slot first + kt)
+    const int first = (live || (OUTMODE == 2 && p.items == nullptr)) ? wave - tile : 0;   // slot of the sequence's tile 0 (K / V of key tile kt: slot first + kt)
     const int row0 = p.row0 != nullptr ? p.row0[seq] : seq * p.seq_rows;
-    if (len <= 0) {     // only without an item table (the host never schedules an empty sequence): the workgroup IS the sequence
+    if (OUTMODE != 2 && len <= 0) {     // only without an item table (the host never schedules an empty sequence): the workgroup IS the sequence
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         if constexpr (OUTMODE == 1) {
             char* g = p.gal[branch] + (size_t)(p.v0 + seq) * p.Lp * (kHidden * 2);
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(wsrc + (size_t)NFRAG * 1024);
         f32x4* dst = reinterpret_cast<f32x4*>(par);
-        for (int i = tid; i < P_TOTAL / 4; i += 256) dst[i] = src[i];
+        for (int i = tid; i < (P_TOTAL + P_TAIL) / 4; i += 256) dst[i] = src[i];
     }
     bf16x8 X1[kNKS];     // h1^T (later h2^T) as MFMA operand fragments: lane = (row r, half h), k-step ks, 8 features
     {
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
 
     // ---- dense + residual + LayerNorm -> h2^T (fp32 in `val`, bf16 fragments back into X1) ---------------------------
     float val[12][16];
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     static_for<0, 12>([&](auto otc) {
         constexpr int ot = decltype(otc)::value;
         f32x16 a = zero16;
@@ -403,8 +413,63 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
                 s2 += v * v;
                 val[ot][8 * s + j] = v;
             }
+            if constexpr (OUTMODE == 2) {          // sum_f (w gamma2)_f v_f: the modular logit, up to the row's LayerNorm statistics
+                const f32x4* wg = reinterpret_cast<const f32x4*>(par + P_WG + (2 * ot + s) * 16 + h * 8);
+                const f32x4 w0 = wg[0], w1 = wg[1];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s3 += val[ot][8 * s + j] * (j < 4 ? w0[j & 3] : w1[j & 3]);
+            }
         }
     });
+    if constexpr (OUTMODE == 2) {
+        // h2_l = (v_l rstd_l + nmr_l) gamma + beta is never formed.  With u_l = a_l rstd_l and U = sum_l a_l nmr_l (sum_l a_l = 1):
+        //   logit_l = rstd_l (w gamma . v_l) + nmr_l c1 + c2         pooled_f = gamma_f (sum_l u_l v_l[f] + U) + beta_f
+        asm volatile("; TW_STREAM_END" ::: "memory");
+        const float mean = half_swap_sum(s1) * (1.f / kHidden);
+        const float rstd = rsqrtf(fmaxf(half_swap_sum(s2) * (1.f / kHidden) - mean * mean, 0.f) + 1e-5f);
+        const float nmr = -mean * rstd;
+        float logit = rstd * half_swap_sum(s3) + nmr * par[P_TOTAL] + par[P_TOTAL + 1];
+        if (r >= len) logit = -1e10f;                                  // mask_logits, model.py:444-445 (exactly -1e10)
+        float mxl = logit;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) mxl = fmaxf(mxl, __shfl_xor(mxl, o));
+        const float e = __expf(logit - mxl);
+        float den = e;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) den += __shfl_xor(den, o);
+        const float a = e / den;
+        float U = a * nmr;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) U += __shfl_xor(U, o);
+        const float u = a * rstd;
+        if (!live) return;                                             // (no barrier below this line)
+        char* stg = smem + kLdsKV + wave * (32 * kStgPitch);
+        float* o = p.pooled[branch] + (size_t)seq * kHidden;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 v = {val[3 * pass + t][4 * q4] * u, val[3 * pass + t][4 * q4 + 1] * u, val[3 * pass + t][4 * q4 + 2] * u,
+                                     val[3 * pass + t][4 * q4 + 3] * u};
+                    *reinterpret_cast<f32x4*>(stg + r * kStgPitch + (32 * t + 8 * q4 + 4 * h) * 4) = v;
+                }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int c = lane + 64 * half;                        // feature of this pass summed by this lane
+                if (c < 96) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int row = 0; row < 32; ++row) acc += *reinterpret_cast<const float*>(stg + row * kStgPitch + 4 * c);
+                    const int f = 96 * pass + c, w16 = f & 15;
+                    const int ti = (f >> 4) * 16 + ((w16 >> 2) & 1) * 8 + ((w16 >> 3) << 2) + (w16 & 3);   // f in fragment order
+                    o[f] = len_raw >= 1 ? par[P_G2 + ti] * (acc + U) + par[P_B2 + ti] : 0.f;
+                }
+            }
+        }
+        return;
+    }
     {
         const float mean = half_swap_sum(s1) * (1.f / kHidden);
         const float rstd = rsqrtf(fmaxf(half_swap_sum(s2) * (1.f / kHidden) - mean * mean, 0.f) + 1e-5f);
@@ -515,7 +580,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
 
 // ---- weight / parameter packing -----------------------------------------------------------------------------------
 struct PackArgs {
-    const float *g1, *b1, *wq, *bq, *wk, *bk, *wv, *bv, *wd, *bd, *g2, *b2, *wo, *bo;
+    const float *g1, *b1, *wq, *bq, *wk, *bk, *wv, *bv, *wd, *bd, *g2, *b2, *wo, *bo, *mw;
     unsigned short* frags;
     float* par;
     int nfrag;
@@ -558,9 +623,15 @@ __global__ __launch_bounds__(256) void tower_pack_kernel(const PackArgs a) {
             case 5: v = a.bd[f]; break;
             case 6: v = a.g2[f]; break;
             case 7: v = a.b2[f]; break;
-            default: v = a.bo ? a.bo[f] : 0.f; break;
+            default: v = a.bo ? a.bo[f] : a.mw ? a.mw[f] * a.g2[f] : 0.f; break;
         }
         a.par[i] = v;
+    }
+    if (i == 0) {                     // query towers: the two constants of the folded modular logit
+        float c1 = 0.f, c2 = 0.f;
+        if (a.mw)
+            for (int f = 0; f < kHidden; ++f) { c1 += a.mw[f] * a.g2[f]; c2 += a.mw[f] * a.b2[f]; }
+        a.par[P_TOTAL] = c1; a.par[P_TOTAL + 1] = c2; a.par[P_TOTAL + 2] = 0.f; a.par[P_TOTAL + 3] = 0.f;
     }
 }
 
@@ -573,55 +644,58 @@ extern "C" {
 
 size_t dldkd_tower_blob_bytes(int with_out_map) {
     const size_t nfrag = tw::kQKVFrags + tw::kSqFrags + (with_out_map ? tw::kSqFrags : 0);
-    return nfrag * 1024 + (size_t)tw::P_TOTAL * 4;
+    return nfrag * 1024 + (size_t)(tw::P_TOTAL + tw::P_TAIL) * 4;
 }
 
 int dldkd_tower_pack_bf16(const float* ln1_g, const float* ln1_b, const float* wq, const float* bq, const float* wk, const float* bk,
                           const float* wv, const float* bv, const float* wd, const float* bd, const float* ln2_g, const float* ln2_b,
-                          const float* wo, const float* bo, void* blob, void* stream) {
-    if (!ln1_g || !ln1_b || !wq || !bq || !wk || !bk || !wv || !bv || !wd || !bd || !ln2_g || !ln2_b || !blob || (!wo != !bo)) {
-        set_error("tower_pack: null pointer");
+                          const float* wo, const float* bo, const float* mod_w, void* blob, void* stream) {
+    if (!ln1_g || !ln1_b || !wq || !bq || !wk || !bk || !wv || !bv || !wd || !bd || !ln2_g || !ln2_b || !blob || (!wo != !bo) ||
+        (!wo == !mod_w)) {
+        set_error("tower_pack: null pointer (a video tower has wo / bo, a query tower has mod_w)");
         return DLDKD_EINVAL;
     }
     if ((uintptr_t)blob & 15) { set_error("tower_pack: blob must be 16-byte aligned"); return DLDKD_EINVAL; }
     const int nfrag = tw::kQKVFrags + tw::kSqFrags + (wo ? tw::kSqFrags : 0);
-    tw::PackArgs a{ln1_g, ln1_b, wq, bq, wk, bk, wv, bv, wd, bd, ln2_g, ln2_b, wo, bo, (unsigned short*)blob,
+    tw::PackArgs a{ln1_g, ln1_b, wq, bq, wk, bk, wv, bv, wd, bd, ln2_g, ln2_b, wo, bo, mod_w, (unsigned short*)blob,
                    (float*)((char*)blob + (size_t)nfrag * 1024), nfrag};
     DLDKD_LAUNCH(tw::tower_pack_kernel, dim3((unsigned)(((long)nfrag * 512 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("tower_pack");
 }
 
 int dldkd_tower_seq_bf16(const float* const* h0, const float* const* pos, const void* const* blob, const int32_t* row0,
-                         const int32_t* lens, const int32_t* items, int n_items, int n_branches, int max_pos, int with_out_map,
+                         const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches, int max_pos,
                          int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
                          void* stream) {
-    if (n_items < 0 || (n_branches != 1 && n_branches != 2) || max_pos < 1 || (out_mode != 0 && out_mode != 1) || seq_rows < 0 ||
-        seq_rows > 128 || (!row0 && seq_rows < 1) || !with_out_map || (out_mode == 1 && (!with_out_map || Lp < 32 || Lp > 128 || (Lp & 31) || v0 < 0))) {
-        set_error("tower_seq: bad arguments (n_items=%d n_branches=%d max_pos=%d out_mode=%d seq_rows=%d Lp=%d)", n_items, n_branches,
-                  max_pos, out_mode, seq_rows, Lp);
+    if (n_items < 0 || n_seq < 0 || (n_branches != 1 && n_branches != 2) || max_pos < 1 || out_mode < 0 || out_mode > 2 || seq_rows < 0 ||
+        seq_rows > 128 || (!row0 && seq_rows < 1) || (out_mode == 1 && (Lp < 32 || Lp > 128 || (Lp & 31) || v0 < 0)) ||
+        (out_mode == 2 && !items && n_items != (n_seq + 3) / 4)) {
+        set_error("tower_seq: bad arguments (n_items=%d n_seq=%d n_branches=%d max_pos=%d out_mode=%d seq_rows=%d Lp=%d)", n_items, n_seq,
+                  n_branches, max_pos, out_mode, seq_rows, Lp);
         return DLDKD_EINVAL;
     }
     if (n_items == 0) return DLDKD_OK;
-    if (!h0 || !pos || !blob || !lens || (out_mode == 0 && !out_rows) || (out_mode == 1 && !gallery)) {
+    if (!h0 || !pos || !blob || !lens || (out_mode != 1 && !out_rows) || (out_mode == 1 && !gallery)) {
         set_error("tower_seq: null pointer");
         return DLDKD_EINVAL;
     }
     tw::TowerArgs p{};
     for (int b = 0; b < n_branches; ++b) {
         p.h0[b] = h0[b]; p.pos[b] = pos[b]; p.blob[b] = (const char*)blob[b];
-        if (out_mode == 0) p.out[b] = out_rows[b]; else p.gal[b] = (char*)gallery[b];
-        if (!p.h0[b] || !p.pos[b] || !p.blob[b] || (out_mode == 0 ? !p.out[b] : !p.gal[b])) { set_error("tower_seq: null branch pointer"); return DLDKD_EINVAL; }
-        if (((uintptr_t)p.h0[b] | (uintptr_t)p.pos[b] | (uintptr_t)p.blob[b] | (uintptr_t)p.out[b] | (uintptr_t)p.gal[b]) & 15) {
+        if (out_mode == 0) p.out[b] = out_rows[b]; else if (out_mode == 2) p.pooled[b] = out_rows[b]; else p.gal[b] = (char*)gallery[b];
+        if (!p.h0[b] || !p.pos[b] || !p.blob[b] || (out_mode == 1 ? !p.gal[b] : !out_rows[b])) { set_error("tower_seq: null branch pointer"); return DLDKD_EINVAL; }
+        if (((uintptr_t)p.h0[b] | (uintptr_t)p.pos[b] | (uintptr_t)p.blob[b] | (uintptr_t)p.out[b] | (uintptr_t)p.gal[b] | (uintptr_t)p.pooled[b]) & 15) {
             set_error("tower_seq: buffers must be 16-byte aligned");
             return DLDKD_EINVAL;
         }
     }
-    p.row0 = row0; p.lens = lens; p.items = items; p.n_items = n_items; p.n_branches = n_branches; p.max_pos = max_pos;
+    p.row0 = row0; p.lens = lens; p.items = items; p.n_items = n_items; p.n_seq = n_seq; p.n_branches = n_branches; p.max_pos = max_pos;
     p.seq_rows = seq_rows; p.v0 = v0; p.Lp = Lp; p.lens_out = lens_out;
     const dim3 grid(n_branches == 2 ? 8u * (unsigned)((n_items + 3) / 4) : (unsigned)n_items);
     static const bool lds_ok = [] {           // once per process: the attribute call is a driver round trip
         return hipFuncSetAttribute((const void*)tw::tower_seq_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) == hipSuccess &&
-               hipFuncSetAttribute((const void*)tw::tower_seq_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) == hipSuccess;
+               hipFuncSetAttribute((const void*)tw::tower_seq_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) == hipSuccess &&
+               hipFuncSetAttribute((const void*)tw::tower_seq_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) == hipSuccess;
     }();
     if (!lds_ok) {
         (void)hipGetLastError();
@@ -629,7 +703,8 @@ int dldkd_tower_seq_bf16(const float* const* h0, const float* const* pos, const 
         return DLDKD_ELAUNCH;
     }
     if (out_mode == 1) DLDKD_LAUNCH((tw::tower_seq_kernel<true, 1>), grid, dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
-    else DLDKD_LAUNCH((tw::tower_seq_kernel<true, 0>), grid, dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
+    else if (out_mode == 0) DLDKD_LAUNCH((tw::tower_seq_kernel<true, 0>), grid, dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
+    else DLDKD_LAUNCH((tw::tower_seq_kernel<false, 2>), grid, dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
     return check_launch("tower_seq");
 }
 

@@ -131,9 +131,13 @@ class DLDKD(nn.Module):
         """ops.TowerPack per branch for the fused per-sequence tower kernel ("visual": with the out mapping)."""
         key = kind + "_tower"
         if key not in self._folded:
-            self._folded[key] = [ops.TowerPack(getattr(self, pre + kind + "_pos_embed"), getattr(self, pre + kind + "_encoder"),
-                                               getattr(self, pre + "out_mapping_linear"))
-                                 for pre in (("", "exp_") if self.double_branch else ("",))]
+            pres = ("", "exp_") if self.double_branch else ("",)
+            if kind == "visual":
+                self._folded[key] = [ops.TowerPack(getattr(self, pre + "visual_pos_embed"), getattr(self, pre + "visual_encoder"),
+                                                   out_linear=getattr(self, pre + "out_mapping_linear")) for pre in pres]
+            else:
+                self._folded[key] = [ops.TowerPack(getattr(self, pre + "query_pos_embed"), getattr(self, pre + "query_encoder"),
+                                                   mod_linear=getattr(self, pre + "modular_vector_mapping")) for pre in pres]
         return self._folded[key]
 
     def _upload_items(self, items_np, device):
@@ -209,6 +213,13 @@ class DLDKD(nn.Module):
             query_feat, query_mask = query_feat.unsqueeze(0), query_mask.reshape(1, -1)
         out = []
         fast = self._fast_proj("query", query_feat) if self._use_fast(query_feat) else None
+        if fast is not None and self.fast_input_proj and ops.tower_seq_ok(fast[0]) and query_feat.shape[1] <= 32:
+            # throughput mode: input projection, then ONE kernel for position LayerNorm, attention block and modular pooling, four
+            # queries per workgroup
+            n, lq = query_feat.shape[0], query_feat.shape[1]
+            out = ops.tower_seq(fast, self._tower_packs("query"), self._lens(query_mask, n, lq, query_feat.device), seq_rows=lq,
+                                out_mode=2)
+            return (out[0], out[1]) if self.double_branch else (out[0], None)
         for bi, pre in enumerate(("", "exp_") if self.double_branch else ("",)):
             if fast is not None:
                 h = self._encode_after_proj(fast[bi], query_mask, getattr(self, pre + "query_encoder"),

@@ -115,7 +115,7 @@ SIGNATURES = {
                          _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
     "dldkd_order_by_len_desc": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_tower_blob_bytes": (_c_size_t, [_c_int]),
-    "dldkd_tower_pack_bf16": (_c_int, [_c_void_p] * 16),
+    "dldkd_tower_pack_bf16": (_c_int, [_c_void_p] * 17),
     "dldkd_tower_seq_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                                       _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_gemm_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

@@ -399,26 +399,31 @@ TOWER_SEQ = True      # throughput-mode inference: everything behind the input p
 
 
 class TowerPack:
-    """One branch's tower behind the input projection (position LayerNorm, q | k | v, dense + LayerNorm, out mapping) as the
-    bf16 fragment blob of tower_seq_kernel; rebuilt when a parameter changes (like PackedLinear)."""
+    """One branch's tower behind the input projection (position LayerNorm, q | k | v, dense + LayerNorm, then the out mapping of
+    a video tower or the modular pooling vector of a query tower) as the bf16 fragment blob of tower_seq_kernel; rebuilt when a
+    parameter changes (like PackedLinear)."""
 
-    def __init__(self, pos_embed, encoder, out_linear):
-        self.pos_embed, self.encoder, self.out_linear = pos_embed, encoder, out_linear
+    def __init__(self, pos_embed, encoder, out_linear=None, mod_linear=None):
+        if (out_linear is None) == (mod_linear is None):
+            raise native.NativeError("TowerPack: a video tower has an out mapping, a query tower a modular vector mapping")
+        self.pos_embed, self.encoder, self.out_linear, self.mod_linear = pos_embed, encoder, out_linear, mod_linear
         self.key = None
 
     def _params(self):
         a, o = self.encoder.self, self.encoder.output
-        return [self.pos_embed.LayerNorm.weight, self.pos_embed.LayerNorm.bias, a.query.weight, a.query.bias, a.key.weight, a.key.bias,
-                a.value.weight, a.value.bias, o.dense.weight, o.dense.bias, o.LayerNorm.weight, o.LayerNorm.bias,
-                self.out_linear.weight, self.out_linear.bias]
+        ps = [self.pos_embed.LayerNorm.weight, self.pos_embed.LayerNorm.bias, a.query.weight, a.query.bias, a.key.weight, a.key.bias,
+              a.value.weight, a.value.bias, o.dense.weight, o.dense.bias, o.LayerNorm.weight, o.LayerNorm.bias]
+        if self.out_linear is not None:
+            return ps + [self.out_linear.weight, self.out_linear.bias, None]
+        return ps + [None, None, self.mod_linear.weight]
 
     def get(self):
         ps = self._params()
-        key = (_PARAM_EPOCH,) + tuple((t.data_ptr(), t._version) for t in ps)
+        key = (_PARAM_EPOCH,) + tuple((t.data_ptr(), t._version) for t in ps if t is not None)
         if key != self.key:
             L = native.lib()
-            self.blob = torch.empty(L.dldkd_tower_blob_bytes(1), dtype=torch.uint8, device=ps[0].device)
-            args = [native.ptr(_chk(t.detach().contiguous(), "tower_pack")) for t in ps]
+            self.blob = torch.empty(L.dldkd_tower_blob_bytes(int(self.out_linear is not None)), dtype=torch.uint8, device=ps[0].device)
+            args = [None if t is None else native.ptr(_chk(t.detach().contiguous(), "tower_pack")) for t in ps]
             native.check(L.dldkd_tower_pack_bf16(*args, native.ptr(self.blob), native.stream()), "tower_pack")
             self.key = key
         return self
@@ -488,23 +493,29 @@ def plan_tower_items(lens):
 def tower_seq(h0, packs, lens, seq_rows=0, row0=None, items=None, out_mode=0, gallery=None, v0=0, Lp=0, lens_out=None):
     """h0: list (one per branch) of fp32 rows (..., 384) - the input projection's output; packs: list of TowerPack; lens int32
     GPU (n_seq).  items: int32 GPU (n_items, 4) from plan_tower_items or None (workgroup i = sequence i, rows i * seq_rows ..).
-    out_mode 0 -> list of fp32 tensors shaped like h0; out_mode 1 -> writes videos v0 .. of the bf16 gallery blobs."""
+    out_mode 0 -> list of fp32 tensors shaped like h0; out_mode 1 -> writes videos v0 .. of the bf16 gallery blobs;
+    out_mode 2 (query-tower packs, at most 32 rows per sequence) -> list of (n_seq, 384) modular query vectors."""
     L = native.lib()
     nb = len(h0)
     fs = [p.get() for p in packs]
+    if any((f.out_linear is None) != (out_mode == 2) for f in fs):
+        raise native.NativeError("tower_seq: out_mode 2 takes query-tower packs, out_mode 0 / 1 video-tower packs")
     hs = [_chk(x.reshape(-1, HIDDEN), "tower_seq.h0") for x in h0]
     poss = [_chk(f.pos.detach(), "tower_seq.pos") for f in fs]
     if lens.dtype != torch.int32 or not lens.is_cuda:
         raise native.NativeError("tower_seq: lens must be an int32 GPU tensor")
-    n_items = lens.shape[0] if items is None else items.shape[0]
+    n_seq = lens.shape[0]
+    n_items = items.shape[0] if items is not None else ((n_seq + 3) // 4 if out_mode == 2 else n_seq)
     outs = None
     if out_mode == 0:
         outs = [torch.empty_like(x) for x in hs]
+    elif out_mode == 2:
+        outs = [torch.empty(n_seq, HIDDEN, dtype=torch.float32, device=lens.device) for _ in hs]
     native.check(L.dldkd_tower_seq_bf16(native.ptr_array(hs), native.ptr_array(poss), native.ptr_array([f.blob for f in fs]),
-                                        native.ptr(row0), native.ptr(lens), native.ptr(items), n_items, nb, poss[0].shape[0], 1,
+                                        native.ptr(row0), native.ptr(lens), native.ptr(items), n_items, n_seq, nb, poss[0].shape[0],
                                         out_mode, native.ptr_array(outs) if outs is not None else None, int(seq_rows),
                                         native.ptr_array(gallery) if gallery is not None else None, int(v0), int(Lp),
                                         native.ptr(lens_out), native.stream()), "tower_seq")
-    if outs is not None:
+    if out_mode == 0:
         return [o.view(x.shape) for o, x in zip(outs, h0)]
-    return None
+    return outs

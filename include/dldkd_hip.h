@@ -436,28 +436,32 @@ int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv,
  *   h2 = LayerNorm(ctx Wd^T + bd + h1)                BertSelfOutput / BertAttention       method/model_components.py:446-450,345-353
  *   y = h2 Wo^T + bo                                  out_mapping_linear                   method/model.py:219
  *   out_mode 1: row = bf16(y / max(|y|, 1e-12))       F.normalize in get_sim_scores        method/model.py:319
+ *   out_mode 2 (query towers): modular pooling on top       get_modularized_queries      method/model.py:245-258
  * dldkd_tower_blob_bytes / dldkd_tower_pack_bf16: one branch's weights as bf16 MFMA fragments in the kernel's consumption
  * order (k permuted to the accumulator layout, q pre-scaled by log2(e) / sqrt(96)) followed by its bias / gamma / beta vectors;
- * all weight matrices (384, 384) row-major, vectors (384).
+ * all weight matrices (384, 384) row-major, vectors (384).  A video tower passes wo / bo (out_mapping_linear) and mod_w = NULL;
+ * a query tower passes wo = bo = NULL and mod_w = modular_vector_mapping.weight (384).
  * dldkd_tower_seq_bf16: h0 / pos / blob / out_rows / gallery are HOST arrays of n_branches device pointers.
  *   h0[b] (rows, 384) fp32: the input projection's output; sequence s owns rows row0[s] .. row0[s] + lens[s] - 1
- *     (row0 == NULL: s * seq_rows); lens[s] > 0 for every scheduled sequence; at most 128 rows per sequence.
+ *     (row0 == NULL: s * seq_rows); at most 128 rows per sequence.
  *   pos[b] (max_pos, 384) fp32: position_embeddings.weight.
  *   items (n_items, 4) int32 or NULL: the four 32-row slots of workgroup i: (s << 2) | tile, -1 = idle; the tiles of one
- *     sequence occupy consecutive slots of ONE workgroup in order (short sequences share a workgroup).  NULL: workgroup i
- *     is sequence i (n_items sequences).
- *   out_mode 0: out_rows[b] (rows, 384) fp32 indexed like h0.  Rows lens[s] .. seq_rows - 1 of a sequence: without an item
- *     table they are computed as the reference computes the clips past a video's length (queries like any other, only keys are
- *     masked: method/model_components.py:422; don't-care values, but the same ones); with an item table they are zeros.
- *   out_mode 1: gallery[b] = the scorer's bf16 blob [nv_total][Lp][384] (dldkd_pack_gallery_bf16's layout: rows past the
- *     length inside the last 16-row tile replicate the last clip, further rows zero); sequence s is video v0 + s;
- *     lens_out (whole gallery, or NULL) receives lens.  Lp a multiple of 32. */
+ *     sequence occupy consecutive slots of ONE workgroup in order (short sequences share a workgroup); every scheduled sequence
+ *     has lens > 0.  NULL: workgroup i is sequence i (n_items = n_seq; out_mode 2: sequences 4 i .. 4 i + 3, n_items = ceil(n_seq / 4)).
+ *   out_mode 0 (video-tower blobs): out_rows[b] (rows, 384) fp32 indexed like h0.  Rows lens[s] .. seq_rows - 1 of a sequence:
+ *     without an item table they are computed as the reference computes the clips past a video's length (queries like any other,
+ *     only keys are masked: method/model_components.py:422; don't-care values, but the same ones); with an item table zeros.
+ *   out_mode 1 (video-tower blobs): gallery[b] = the scorer's bf16 blob [nv_total][Lp][384] (dldkd_pack_gallery_bf16's layout:
+ *     rows past the length inside the last 16-row tile replicate the last clip, further rows zero); sequence s is video v0 + s;
+ *     lens_out (whole gallery, or NULL) receives lens.  Lp a multiple of 32.
+ *   out_mode 2 (query-tower blobs): out_rows[b] (n_seq, 384) fp32 = the modular query vectors; 1 <= lens[s] <= 32 (a sequence
+ *     with lens < 1 gives a zero vector). */
 size_t dldkd_tower_blob_bytes(int with_out_map);
 int dldkd_tower_pack_bf16(const float* ln1_g, const float* ln1_b, const float* wq, const float* bq, const float* wk, const float* bk,
                           const float* wv, const float* bv, const float* wd, const float* bd, const float* ln2_g, const float* ln2_b,
-                          const float* wo, const float* bo, void* blob, void* stream);
+                          const float* wo, const float* bo, const float* mod_w, void* blob, void* stream);
 int dldkd_tower_seq_bf16(const float* const* h0, const float* const* pos, const void* const* blob, const int32_t* row0,
-                         const int32_t* lens, const int32_t* items, int n_items, int n_branches, int max_pos, int with_out_map,
+                         const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches, int max_pos,
                          int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
                          void* stream);
 

@@ -20,7 +20,7 @@ def _bf(t):
 class _Tower(torch.nn.Module):
     """parameter holder with the attribute names ops.TowerPack reads"""
 
-    def __init__(self, seed, scale=0.06, max_pos=128):
+    def __init__(self, seed, scale=0.06, max_pos=128, query=False):
         super().__init__()
         from dldkd_amd.model_components import BertAttention, TrainablePositionalEncoding
         import types
@@ -28,7 +28,10 @@ class _Tower(torch.nn.Module):
         self.pos = TrainablePositionalEncoding(max_pos, H, 0.1)
         self.enc = BertAttention(types.SimpleNamespace(hidden_size=H, num_attention_heads=4, hidden_dropout_prob=0.1,
                                                        attention_probs_dropout_prob=0.1))
-        self.out = torch.nn.Linear(H, H)
+        if query:
+            self.mod = torch.nn.Linear(H, 1, bias=False)
+        else:
+            self.out = torch.nn.Linear(H, H)
         for name, p in self.named_parameters():
             if "LayerNorm.weight" in name:
                 p.data = 1.0 + 0.2 * torch.randn(p.shape, generator=g)
@@ -68,8 +71,12 @@ def _reference(t, h0, lens, rounded):
     o = (rd(p) @ v) / p.sum(-1, keepdim=True)
     ctx = rd(o.transpose(1, 2).reshape(n, L, H))
     d = ctx @ rd(P["enc.output.dense.weight"]).t() + P["enc.output.dense.bias"] + h1
-    h2 = rd(_ln(d, P["enc.output.LayerNorm.weight"], P["enc.output.LayerNorm.bias"]))
-    return h2 @ rd(P["out.weight"]).t() + P["out.bias"]
+    h2 = _ln(d, P["enc.output.LayerNorm.weight"], P["enc.output.LayerNorm.bias"])
+    if "mod.weight" in P:                                              # query tower: modular attention pooling (fp32 in the kernel)
+        logit = (h2 @ P["mod.weight"].t()).squeeze(-1)
+        logit = logit.masked_fill(kmask, -1e10)
+        return torch.einsum("nl,nld->nd", torch.softmax(logit, 1), h2)
+    return rd(h2) @ rd(P["out.weight"]).t() + P["out.bias"]
 
 
 LENS = [128, 1, 31, 32, 33, 64, 65, 96, 100, 127, 17]
@@ -79,7 +86,7 @@ def _setup(seed=3, L=128, lens=LENS):
     from dldkd_amd import ops
     torch.manual_seed(seed)
     ts = [_Tower(10 + seed).to(DEV), _Tower(20 + seed).to(DEV)]
-    packs = [ops.TowerPack(t.pos, t.enc, t.out) for t in ts]
+    packs = [ops.TowerPack(t.pos, t.enc, out_linear=t.out) for t in ts]
     n = len(lens)
     g = torch.Generator().manual_seed(seed)
     h0 = [torch.relu(torch.randn(n, L, H, generator=g)) for _ in range(2)]     # the input projection ends in a ReLU
@@ -218,3 +225,51 @@ def test_eval_epoch_fused_gallery_path(golden_dir):
         m.fast_input_proj = False
     assert calls, "the throughput-mode eval driver did not take the fused gallery path"
     assert (res["bf16"] - res["fp32"]).abs().max().item() < 2e-2
+
+
+def test_tower_seq_query_mode_vs_rounded_fp64():
+    """out_mode 2: four <= 32-word sequences per workgroup, modular attention pooling folded into the epilogue."""
+    from dldkd_amd import ops
+    lens = [30, 1, 5, 17, 29, 30, 2, 9, 12, 30, 7, 3, 21]           # 13 sequences: the last workgroup has one live wave
+    n, L = len(lens), 30
+    ts = [_Tower(41, max_pos=30, query=True).to(DEV), _Tower(42, max_pos=30, query=True).to(DEV)]
+    packs = [ops.TowerPack(t.pos, t.enc, mod_linear=t.mod) for t in ts]
+    g = torch.Generator().manual_seed(9)
+    h0 = [torch.relu(torch.randn(n, L, H, generator=g)) for _ in range(2)]
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    out = ops.tower_seq([x.to(DEV) for x in h0], packs, lens_t.to(DEV), seq_rows=L, out_mode=2)
+    torch.cuda.synchronize()
+    for b in range(2):
+        o = out[b].cpu().double()
+        assert o.shape == (n, H)
+        ref_r = _reference(ts[b].cpu(), h0[b], lens_t.long(), True)
+        ref_p = _reference(ts[b].cpu(), h0[b], lens_t.long(), False)
+        sc = ref_p.abs().max().item()
+        assert (o - ref_r).abs().max().item() < 1.2e-2 * sc
+        assert (o - ref_r).abs().mean().item() < 1.5e-3 * sc
+        assert (o - ref_p).abs().max().item() < 4e-2 * sc
+
+
+def test_encode_query_fused_vs_unfused_throughput_mode():
+    from dldkd_amd import ops
+    m = _model(3072, 768, synth.make_params(31, 3072, 768))
+    rs = np.random.RandomState(6)
+    qlens = np.array([30, 5, 17, 1, 22, 30, 9])
+    txt, tmask = synth.make_texts(rs, 7, 30, 768, qlens)
+    txt, tmask = [torch.from_numpy(a.astype(np.float32)).to(DEV) for a in (txt, tmask)]
+    with torch.no_grad():
+        par = m.encode_query(txt, tmask)
+        m.fast_input_proj = True
+        ops.set_gemm_precision("bf16")
+        try:
+            fused = m.encode_query(txt, tmask)
+            ops.TOWER_SEQ = False
+            chain = m.encode_query(txt, tmask)
+        finally:
+            ops.TOWER_SEQ = True
+            ops.set_gemm_precision("fp32")
+            m.fast_input_proj = False
+    for f, c, p_ in zip(fused, chain, par):
+        assert f.shape == p_.shape == (7, 384)
+        sc = p_.abs().max().item()
+        assert (f - c).abs().max().item() < 3e-2 * sc and (f - p_).abs().max().item() < 3e-2 * sc
