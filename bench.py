@@ -30,29 +30,57 @@ NQ, NV, L, LEN_LO, D, NB = 10895, 21793, 128, 24, 384, 2
 SIGMA = (5.5, 6.5)        # planted-signal noise (per branch) -> TVR-like R@1
 W_FUSE = (0.7, 0.3)       # eval.py:254
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+# Recalls of the synthetic C2 / C4 problems as ONE GPU measures them (python bench.py / tools/bench_c4_n1.py): the gallery and
+# the queries are the same tensors for every rank count, so an N-GPU run must print exactly these from its assembled matrix.
+RECALL_N1 = {"R@1": 13.144, "R@5": 22.726, "R@10": 27.48, "R@100": 48.196}
+RECALL_C4_N1 = {"R@1": 16.715, "R@5": 28.495, "R@10": 34.299, "R@100": 58.395}
 
 
-def synth_shard(dev, v_lo, v_hi, seed=2):
-    """Encoded-gallery shard [v_lo, v_hi) for both branches + planted queries (same on every rank)."""
-    lens_all = torch.randint(LEN_LO, L + 1, (NV,), generator=torch.Generator().manual_seed(seed)).to(dev)
-    n_loc = v_hi - v_lo
-    gs = []
-    for b in range(NB):
-        gen = torch.Generator(device=dev).manual_seed(1000 * seed + 10 * v_lo + b)
-        gs.append(torch.randn(n_loc, L, D, generator=gen, device=dev))
-    lens = lens_all[v_lo:v_hi]
-    mask = (torch.arange(L, device=dev).unsqueeze(0) < lens.unsqueeze(1)).float()
-    # queries: planted on a valid clip of video (q mod NV) when that video is local, plain noise otherwise
-    qgen = torch.Generator(device=dev).manual_seed(seed + 7)
-    gt = torch.arange(NQ, device=dev) % NV
-    lstar = (torch.rand(NQ, generator=qgen, device=dev) * lens_all[gt].float()).long().clamp(max=L - 1)
+C2 = dict(name="C2", nq=NQ, nv=NV, L=L, len_lo=LEN_LO, seed=2, sigma=SIGMA,
+          workload="C2: TVR full eval gallery text->video scoring (configs[1])")
+C4 = dict(name="C4", nq=17505, nv=4917, L=128, len_lo=128, seed=4, sigma=SIGMA,
+          workload="C4: ActivityNet full eval (i3d feats, 128-clip videos), gallery sharded across the ranks (configs[3])")
+BLK = 64      # videos per seeded block: a video's clips depend on (config seed, block, branch) only - never on the rank count
+
+
+def _lens_all(cfg):
+    return torch.randint(cfg["len_lo"], cfg["L"] + 1, (cfg["nv"],), generator=torch.Generator().manual_seed(cfg["seed"]))
+
+
+def synth_videos(dev, cfg, v_lo, v_hi):
+    """Encoded clips of videos [v_lo, v_hi) for both branches + their lengths: the SAME tensors whichever rank (or shard
+    layout) asks for them, so the N-GPU gallery is the 1-GPU gallery cut by video."""
+    n = max(v_hi - v_lo, 0)
+    gs = [torch.empty(n, cfg["L"], D, device=dev) for _ in range(NB)]
+    for blk in range(v_lo // BLK, (v_hi + BLK - 1) // BLK if n else 0):
+        lo, hi = max(blk * BLK, v_lo), min(blk * BLK + BLK, v_hi)
+        for b in range(NB):
+            gen = torch.Generator(device=dev).manual_seed(1_000_003 * cfg["seed"] + 2 * blk + b)
+            gs[b][lo - v_lo:hi - v_lo] = torch.randn(BLK, cfg["L"], D, generator=gen, device=dev)[lo - blk * BLK:hi - blk * BLK]
+    lens = _lens_all(cfg)[v_lo:v_hi].to(dev)
+    return gs, lens
+
+
+def synth_shard(dev, cfg, v_lo, v_hi, world=1, dist=None):
+    """Gallery shard [v_lo, v_hi) + the queries, IDENTICAL on every rank: query q is planted on a valid clip of video q mod nv;
+    the rank that holds that video contributes the clip, the others zeros, and one all-reduce(SUM) at setup gives every rank the
+    same query set (each ground-truth video is local to exactly one rank)."""
+    nq, nv, Lc = cfg["nq"], cfg["nv"], cfg["L"]
+    gs, lens = synth_videos(dev, cfg, v_lo, v_hi)
+    lens_all = _lens_all(cfg).to(dev)
+    mask = (torch.arange(Lc, device=dev).unsqueeze(0) < lens.unsqueeze(1)).float()
+    qgen = torch.Generator(device=dev).manual_seed(cfg["seed"] + 7)          # same stream on every rank
+    gt = torch.arange(nq, device=dev) % nv
+    lstar = (torch.rand(nq, generator=qgen, device=dev) * lens_all[gt].float()).long().clamp(max=Lc - 1)
+    local = (gt >= v_lo) & (gt < v_hi)
     qs = []
     for b in range(NB):
-        noise = torch.randn(NQ, D, generator=qgen, device=dev)
-        local = (gt >= v_lo) & (gt < v_hi)
-        base = torch.zeros(NQ, D, device=dev)
+        noise = torch.randn(nq, D, generator=qgen, device=dev)
+        base = torch.zeros(nq, D, device=dev)
         base[local] = gs[b][(gt[local] - v_lo), lstar[local]]
-        qs.append(base + SIGMA[b] * noise)
+        if world > 1:
+            dist.all_reduce(base, op=dist.ReduceOp.SUM)
+        qs.append(base + cfg["sigma"][b] * noise)
     return gs, mask, lens, qs, gt
 
 
@@ -337,6 +365,79 @@ def mfma_sustained():
         return None
 
 
+def run_sharded(cfg, dev, rank, world, dist, steps, warmup):
+    """One workload through dist.OverlappedShardScorer (what --gpus N runs): the gallery cut by video, ONE scorer launch per
+    step whose query ranges complete in order, per-range finish + RCCL all_gather on a side stream.  Runs on every rank;
+    returns the measurements (rank 0 adds the self-checks: recalls of the ASSEMBLED matrix and a sampled recompute)."""
+    from dldkd_amd import dist as ddist
+    from dldkd_amd import scoring
+    nq, nv = cfg["nq"], cfg["nv"]
+    shard = (nv + world - 1) // world
+    v_lo, v_hi = min(rank * shard, nv), min((rank + 1) * shard, nv)
+    gs, mask, lens, qs, gt = synth_shard(dev, cfg, v_lo, v_hi, world, dist)
+    n_loc = v_hi - v_lo
+    if n_loc < shard:   # pad the last shard with 1-clip zero videos so all_gather blocks are equal
+        pad = shard - n_loc
+        gs = [torch.cat([g, torch.zeros(pad, cfg["L"], D, device=dev)]) for g in gs]
+        mask = torch.cat([mask, torch.zeros(pad, cfg["L"], device=dev)])
+        mask[n_loc:, 0] = 1.0
+    t0 = time.perf_counter()
+    pg = scoring.pack_gallery(gs, mask)            # resident bf16 gallery (outside the timed region)
+    torch.cuda.synchronize()
+    pack_ms = (time.perf_counter() - t0) * 1e3
+    del gs
+    # >= 4 ranges so that the all-gather of range r (RCCL stream, parked on the range's arrival counter) runs under the
+    # scoring of ranges r+1..; the split is the kernel's own (HipShardBackend asks the library's planner)
+    backend = ddist.HipShardBackend(qs, pg, min_ranges=4, w=W_FUSE)
+    overlap = ddist.OverlappedShardScorer(backend, backend.bounds, shard, dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        overlap.step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i][0].record()
+        overlap.step()
+        ev[i][1].record()
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    res = {"ms_per_step": dt / steps * 1e3, "value": nq * nv * steps / dt, "step_stream_ms": sum(s_.elapsed_time(e) for s_, e in ev) / steps,
+           "n_ranges": len(overlap.bounds), "shard_videos": shard, "gallery_pack_ms_untimed": round(pack_ms, 2),
+           "flops_per_step_all_ranks": 2.0 * D * NB * nq * float(_lens_all(cfg).sum().item())}
+    if rank == 0:
+        full = overlap.assemble(nv)                                   # (nq, nv) fp32 as every rank holds it after the gathers
+        res["recall_hip"] = dict(zip(("R@1", "R@5", "R@10", "R@100"), recalls(full, gt)))
+        # sampled recompute: one BLK-video block out of every rank's shard (the last one ends at the last video), scored by a
+        # plain one-launch scorer call on THIS rank from re-generated clips, against the same columns of the assembled matrix
+        worst, n_s = 0.0, 0
+        for r in range(world):
+            lo = min(r * shard, nv)
+            hi = min(lo + BLK, min((r + 1) * shard, nv))
+            if r == world - 1:
+                lo, hi = max(nv - BLK, min(r * shard, nv)), nv
+            if hi <= lo:
+                continue
+            g_s, lens_s = synth_videos(dev, cfg, lo, hi)
+            m_s = (torch.arange(cfg["L"], device=dev).unsqueeze(0) < lens_s.unsqueeze(1)).float()
+            ref = scoring.simpool_eval(scoring.pack_queries(qs), scoring.pack_gallery(g_s, m_s), W_FUSE)[0]
+            worst = max(worst, (full[:, lo:hi] - ref).abs().max().item())
+            n_s += hi - lo
+        res["assembled_max_abs_diff"] = worst
+        res["assembled_check"] = f"{n_s} videos ({BLK} per shard) x all {nq} queries recomputed on rank 0 by a plain one-launch scorer call"
+        del full
+    del overlap, backend, pg
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -374,131 +475,124 @@ def main():
 
     from dldkd_amd import native, scoring
     native.lib()   # fail loudly before anything else if the HIP library is missing
+    metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    out = None
 
-    shard = (NV + world - 1) // world
-    v_lo, v_hi = min(rank * shard, NV), min((rank + 1) * shard, NV)
-    gs, mask, lens, qs, gt = synth_shard(dev, v_lo, v_hi)
-    n_loc = v_hi - v_lo
-    if n_loc < shard:   # pad the last shard with 1-clip zero videos so all_gather blocks are equal
-        pad = shard - n_loc
-        gs = [torch.cat([g, torch.zeros(pad, L, D, device=dev)]) for g in gs]
-        mask = torch.cat([mask, torch.zeros(pad, L, device=dev)])
-        mask[n_loc:, 0] = 1.0
-    t0 = time.perf_counter()
-    pg = scoring.pack_gallery(gs, mask)            # resident bf16 gallery (outside the timed region)
-    torch.cuda.synchronize()
-    pack_gallery_ms = (time.perf_counter() - t0) * 1e3
-    keep_fp32 = (world == 1 and not a.no_cpu_baseline)
-    if not keep_fp32:
-        gs = None
-    ws = torch.empty(native.lib().dldkd_simpool_eval_workspace_bytes(NQ, shard, NB), dtype=torch.uint8, device=dev)
-    overlap = None
-    if world > 1 or force_dist:
-        from dldkd_amd import dist as ddist
-        # ONE scorer launch over all queries, grid [query range][branch][4 videos]; >= 4 ranges so that the all-gather of
-        # range r (RCCL stream, parked on the range's arrival counter) runs under the scoring of ranges r+1..
-        n_ranges, per_range = scoring.plan_query_split(NQ, shard, NB, min_split=4)
-        backend = ddist.HipShardBackend(qs, pg, n_ranges, W_FUSE)
-        overlap = ddist.OverlappedShardScorer(backend, ddist.query_ranges(NQ, n_ranges, per_range), shard, dev)
-    flops_launch = 2.0 * D * NB * NQ * float(lens.sum().item())   # algorithmic: valid clips only
+    if dist is not None:
+        # ---- N ranks (or the one-rank test hook): the sharded step, self-verified, then the C4 workload the same way
+        r2 = run_sharded(C2, dev, rank, world, dist, a.steps, a.warmup)
+        r4 = run_sharded(C4, dev, rank, world, dist, max(min(a.steps, 20), 1), max(min(a.warmup, 3), 1)) if not a.no_extras else None
+        if rank == 0:
+            achieved = r2["flops_per_step_all_ranks"] / (r2["ms_per_step"] * 1e-3) / 1e12
+            out = {
+                "metric": metric, "value": r2["value"], "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": r2["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": C2["workload"], "n_queries": NQ, "n_videos": NV, "max_clips": L,
+                           "clip_len": f"U{{{LEN_LO}..{L}}}", "hidden": D, "branches": NB, "fusion": list(W_FUSE),
+                           "parallelism": f"gallery sharded x{world} by video ({r2['shard_videos']} per rank): one scorer launch per step, "
+                                          f"{r2['n_ranges']} query ranges completing in order, the all_gather of each range overlapped "
+                                          "with the scoring of the next",
+                           "step": "pack queries + simpool (sim + key-clip max-pool) + 0.7/0.3 fusion + all_gather",
+                           "gallery_pack_ms_untimed": r2["gallery_pack_ms_untimed"]},
+                "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS * world, "unit": "TFLOP/s",
+                             "frac": achieved / (PEAK_BF16_TFLOPS * world), "traffic": None,
+                             "kernel": "simpool_eval16_kernel on every rank (one launch, query ranges in order) + per-range finish and "
+                                       "all_gather on a side stream; `achieved` = all ranks' algorithmic flops / the step's wall time "
+                                       "(max over ranks), `peak` = world x 2.5 PF",
+                             "kernel_ms": r2["step_stream_ms"], "algorithmic_flops_per_launch": r2["flops_per_step_all_ranks"] / world},
+                "cpu_baseline": None,
+                # self-verification of the distributed path (the same synthetic gallery and queries for every N):
+                "recall_hip": r2["recall_hip"], "assembled_max_abs_diff": r2["assembled_max_abs_diff"],
+                "assembled_check": r2["assembled_check"],
+                "recall_expected_n1": RECALL_N1, "recall_matches_n1": r2["recall_hip"] == RECALL_N1,
+            }
+            if r4 is not None:
+                out["extras"] = {"c4_sharded": {
+                    "workload": C4["workload"], "n_queries": C4["nq"], "n_videos": C4["nv"], "clips": 128, "n_gpus": world,
+                    "ms_per_step": r4["ms_per_step"], "pairs_per_s": r4["value"], "n_ranges": r4["n_ranges"],
+                    "shard_videos": r4["shard_videos"],
+                    "algorithmic_TFLOPs_all_ranks": r4["flops_per_step_all_ranks"] / (r4["ms_per_step"] * 1e-3) / 1e12,
+                    "recall_hip": r4["recall_hip"], "assembled_max_abs_diff": r4["assembled_max_abs_diff"],
+                    "assembled_check": r4["assembled_check"], "recall_expected_n1": RECALL_C4_N1,
+                    "recall_matches_n1": r4["recall_hip"] == RECALL_C4_N1}}
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        # ---- one GPU: the headline line with the kernel's roofline, the CPU baseline and the extras
+        gs, mask, lens, qs, gt = synth_shard(dev, C2, 0, NV)
+        t0 = time.perf_counter()
+        pg = scoring.pack_gallery(gs, mask)            # resident bf16 gallery (outside the timed region)
+        torch.cuda.synchronize()
+        pack_gallery_ms = (time.perf_counter() - t0) * 1e3
+        keep_fp32 = not a.no_cpu_baseline
+        if not keep_fp32:
+            gs = None
+        ws = torch.empty(native.lib().dldkd_simpool_eval_workspace_bytes(NQ, NV, NB), dtype=torch.uint8, device=dev)
+        flops_launch = 2.0 * D * NB * NQ * float(lens.sum().item())   # algorithmic: valid clips only
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-
-    def step(i=None):
-        if overlap is not None:
-            # one launch; the RCCL all-gather of query range r overlaps the scoring of ranges r+1..
+        def step(i=None):
+            pq = scoring.pack_queries(qs)                                  # F.normalize + bf16 (model.py:318)
             if i is not None:
                 ev[i][0].record()
-            overlap.step()
+            scoring.simpool_partials(pq, pg, ws)                           # the dominant kernel
             if i is not None:
                 ev[i][1].record()
-            return overlap.local[-1]
-        pq = scoring.pack_queries(qs)                                  # F.normalize + bf16 (model.py:318)
-        if i is not None:
-            ev[i][0].record()
-        scoring.simpool_partials(pq, pg, ws)                           # the dominant kernel
-        if i is not None:
-            ev[i][1].record()
-        fused, _, _ = scoring.simpool_finish(ws, pq, pg, W_FUSE)       # (NQ, shard) fp32
-        return fused
+            fused, _, _ = scoring.simpool_finish(ws, pq, pg, W_FUSE)       # (NQ, NV) fp32
+            return fused
 
-    for _ in range(a.warmup):
-        step()
-
-    def fence():
+        for _ in range(a.warmup):
+            step()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        fused = step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(a.steps, 1)
-
-    out = None
-    if rank == 0:
-        metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            fused = step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kern_ms = sum(s_.elapsed_time(e) for s_, e in ev) / max(a.steps, 1)
         achieved = flops_launch / (kern_ms * 1e-3) / 1e12
         # HBM bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
         # KiB units; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md section HBM) from the committed
-        # profile of this same workload.  Not re-measured live (PMC needs the profiler), so N>1 reports null.
+        # profile of this same workload.  Not re-measured live (PMC needs the profiler).
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02", "pmc_simpool", "summary.json")
-        if world == 1 and os.path.exists(pmc):
-            d = json.load(open(pmc))
-            traffic = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
-            traffic_src = "profiles/r02/pmc_simpool/summary.json (rocprofv3 --pmc, separate passes; 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KiB units)"
+        for rnd in ("r03", "r02"):
+            pmc = os.path.join(ROOT, "profiles", rnd, "pmc_simpool", "summary.json")
+            if os.path.exists(pmc):
+                d = json.load(open(pmc))
+                traffic = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+                traffic_src = f"profiles/{rnd}/pmc_simpool/summary.json (rocprofv3 --pmc, separate passes; 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KiB units)"
+                break
         out = {
-            "metric": metric, "value": NQ * NV * a.steps / dt, "unit": "pairs/s", "n_gpus": world,
+            "metric": metric, "value": NQ * NV * a.steps / dt, "unit": "pairs/s", "n_gpus": 1,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "C2: TVR full eval gallery text->video scoring (configs[1])",
+            "config": {"workload": C2["workload"],
                        "n_queries": NQ, "n_videos": NV, "max_clips": L, "clip_len": f"U{{{LEN_LO}..{L}}}",
-                       "hidden": D, "branches": NB, "fusion": list(W_FUSE),
-                       "parallelism": "1 GPU" if world == 1 else f"gallery sharded x{world}: one scorer launch, {len(overlap.bounds)} query ranges completing in order, all_gather of each range overlapped with the scoring of the next",
-                       "step": "pack queries + simpool (sim + key-clip max-pool) + 0.7/0.3 fusion"
-                               + (" + all_gather" if world > 1 else ""),
+                       "hidden": D, "branches": NB, "fusion": list(W_FUSE), "parallelism": "1 GPU",
+                       "step": "pack queries + simpool (sim + key-clip max-pool) + 0.7/0.3 fusion",
                        "gallery_pack_ms_untimed": round(pack_gallery_ms, 2)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src,
-                         "kernel": "simpool_eval16_kernel" if overlap is None else
-                                   "simpool_eval16_kernel (one launch, query ranges in order) + per-range finish and all_gather on a side stream; kernel_ms spans the whole step",
-                         "kernel_ms": kern_ms,
+                         "traffic_source": traffic_src, "kernel": "simpool_eval16_kernel", "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": flops_launch},
         }
         if sustained and sustained.get("random_16x16x32"):
             out["roofline"]["sustained_register_operand_mfma_TFLOPs"] = sustained
             out["roofline"]["frac_of_sustained_random_data"] = achieved / sustained["random_16x16x32"]
-        if world == 1 and overlap is None:
-            out["recall_hip"] = dict(zip(("R@1", "R@5", "R@10", "R@100"), recalls(fused, gt)))
-        if overlap is not None and world == 1:     # test hook: the chunked path must reproduce the one-launch matrix
-            pq = scoring.pack_queries(qs)
-            scoring.simpool_partials(pq, pg, ws)
-            ref, _, _ = scoring.simpool_finish(ws, pq, pg, W_FUSE)
-            out["force_dist_max_abs_diff"] = (overlap.assemble(NV) - ref[:, :NV]).abs().max().item()
-        if keep_fp32 and overlap is None:
+        out["recall_hip"] = dict(zip(("R@1", "R@5", "R@10", "R@100"), recalls(fused, gt)))
+        out["recall_expected_n1"] = RECALL_N1          # what every N must reproduce (same gallery, same queries)
+        if keep_fp32:
             cb, err = cpu_baseline(gs, mask, qs, fused)
             out["cpu_baseline"] = cb
             out["parity_max_abs_err_vs_oracle_sample"] = err
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
         else:
             out["cpu_baseline"] = None
-        if world == 1 and not a.no_extras and overlap is None:
+        if not a.no_extras:
             del gs, fused
             torch.cuda.empty_cache()
             out["extras"] = extras(dev)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
         # the JSON line must be the LAST line of stdout: RCCL / the HIP runtime write banners through C stdio, which is
         # flushed at exit - after Python's own prints - unless it is drained first

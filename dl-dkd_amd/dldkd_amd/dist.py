@@ -84,9 +84,9 @@ def sync_gradients(fp, group=None, comm_stream=None):
         cur.wait_stream(comm_stream)
     else:
         all_reduce_flat(fp.grad, group)
-    # after the mean every parameter HAS a gradient on every rank (zeros included): the replicas must take the same
-    # optimizer step, so the local "grad was None" flags no longer apply
-    fp._had = tuple(True for _ in fp.params)
+    # The "this parameter had no gradient" flags stay as they are: every rank builds the same autograd graph, so they agree
+    # across ranks, and a parameter without a gradient on any rank must be SKIPPED by the optimizer (no weight decay, no moment
+    # decay: optimization.py:294-295), exactly as on one GPU.
 
 
 def broadcast_parameters(fp, src=0, group=None):
@@ -117,10 +117,18 @@ class HipShardBackend(ShardScorerBackend):
     and every workgroup bumps its range's arrival counter after releasing its scores (simpool_eval.hip).  The consumer
     stream is parked on the counter with hipStreamWaitValue32 (dldkd_stream_wait_counter)."""
 
-    def __init__(self, queries, gallery, n_ranges, w=(0.7, 0.3)):
+    def __init__(self, queries, gallery, min_ranges=4, w=(0.7, 0.3)):
         from . import native, scoring
         self.native, self.scoring = native, scoring
-        self.queries, self.pg, self.n_ranges, self.w = queries, gallery, n_ranges, w
+        self.queries, self.pg, self.w = queries, gallery, w
+        # the range split is the KERNEL's (one planner, scoring.plan_query_split): a caller-made split that names more ranges
+        # than the kernel creates would park the side stream on a counter nobody bumps
+        nq = queries[0].shape[0]
+        self.n_ranges, self.per_range = scoring.plan_query_split(nq, gallery.nv, gallery.n_branches, min_split=min_ranges)
+        self.bounds = [(lo, min(lo + self.per_range, nq)) for lo in range(0, max(nq, 1), self.per_range)]
+        if len(self.bounds) != self.n_ranges or self.bounds[0][0] != 0 or self.bounds[-1][1] != nq:
+            raise native.NativeError(f"HipShardBackend: {len(self.bounds)} ranges of {self.per_range} do not tile {nq} queries in "
+                                     f"{self.n_ranges} kernel ranges")
         self.arrivals = (gallery.nv + 3) // 4 * gallery.n_branches
         self.ws = torch.empty(native.lib().dldkd_simpool_eval_workspace_bytes(queries[0].shape[0], gallery.nv, gallery.n_branches),
                               dtype=torch.uint8, device=gallery.lens.device)
@@ -149,7 +157,10 @@ class OverlappedShardScorer:
     assemble() builds (Nq, n_videos)."""
 
     def __init__(self, backend, bounds, shard, device, group=None, side_stream=None):
-        self.backend, self.bounds, self.shard, self.group = backend, list(bounds), shard, group
+        bounds = list(bounds)
+        if any(b[0] != a[1] for a, b in zip(bounds, bounds[1:])) or (bounds and bounds[0][0] != 0):
+            raise ValueError(f"OverlappedShardScorer: ranges must tile the queries from 0 without gaps, got {bounds}")
+        self.backend, self.bounds, self.shard, self.group = backend, bounds, shard, group
         self.world = dist.get_world_size(group)
         self.local = [torch.empty(hi - lo, shard, dtype=torch.float32, device=device) for lo, hi in self.bounds]
         self.blocks = [torch.empty(self.world * (hi - lo), shard, dtype=torch.float32, device=device) for lo, hi in self.bounds]
@@ -194,4 +205,8 @@ class OverlappedShardScorer:
 
 
 def query_ranges(nq, n_ranges, per_range):
-    return [(lo, min(lo + per_range, nq)) for lo in range(0, nq, per_range)][:max(n_ranges, 1)]
+    """[(lo, hi)] of n_ranges ranges of per_range queries; raises if they do not cover [0, nq)."""
+    out = [(lo, min(lo + per_range, nq)) for lo in range(0, max(nq, 1), per_range)]
+    if len(out) != max(n_ranges, 1):
+        raise ValueError(f"{n_ranges} ranges of {per_range} queries do not tile {nq} queries")
+    return out

@@ -1,0 +1,41 @@
+"""bench.py's multi-rank path checks itself: run it through the one-rank RCCL hook and read the line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(env_extra, *args):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=1500,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_distributed_path_verifies_itself_on_one_rank():
+    """DLDKD_BENCH_FORCE_DIST=1: OverlappedShardScorer + RCCL with world size 1.  The gathered matrix equals a plain
+    one-launch recompute of sampled videos bit for bit, its recalls are the one-GPU recalls (same gallery, same queries for
+    every rank count), and the C4 workload goes through the same path."""
+    import bench
+    d = _line({"DLDKD_BENCH_FORCE_DIST": "1"}, "--steps", "2", "--warmup", "1")
+    assert d["assembled_max_abs_diff"] == 0.0
+    assert d["recall_hip"] == bench.RECALL_N1 and d["recall_matches_n1"] is True
+    assert 15.0 > d["recall_hip"]["R@1"] > 5.0                        # planted signal, not chance (1 / 21,793)
+    c4 = d["extras"]["c4_sharded"]
+    assert c4["assembled_max_abs_diff"] == 0.0 and c4["recall_hip"] == bench.RECALL_C4_N1 and c4["recall_matches_n1"] is True
+    assert c4["n_queries"] == 17505 and c4["n_videos"] == 4917 and c4["n_ranges"] >= 4
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d
+
+
+def test_bench_plain_run_prints_the_same_recalls():
+    import bench
+    d = _line({}, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras")
+    assert d["recall_hip"] == bench.RECALL_N1 and d["n_gpus"] == 1 and d["roofline"]["bound"] == "mfma"

@@ -219,3 +219,48 @@ def test_shipped_train_step_two_ranks_different_batches():
         np.testing.assert_array_equal(r0["grads"][step], r1["grads"][step])
         fp.flat.sub_(0.1 * mean)
     np.testing.assert_allclose(fp.flat.numpy(), r0["final"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ bench.py --gpus N setup
+_BENCH_CFG = dict(name="T", nq=57, nv=150, L=8, len_lo=2, seed=9, sigma=(0.5, 0.7), workload="test")
+
+
+def _bench_setup_worker(rank, world, port, ret):
+    _setup(rank, world, port)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cfg = _BENCH_CFG
+    shard = (cfg["nv"] + world - 1) // world
+    lo, hi = min(rank * shard, cfg["nv"]), min((rank + 1) * shard, cfg["nv"])
+    gs, mask, lens, qs, gt = bench.synth_shard("cpu", cfg, lo, hi, world, dist)
+    ret[rank] = dict(lo=lo, hi=hi, gs=[g.clone() for g in gs], lens=lens.clone(), qs=[q.clone() for q in qs], gt=gt.clone())
+    dist.destroy_process_group()
+
+
+def test_bench_multi_rank_setup_is_rank_invariant():
+    """bench.py --gpus N: every rank holds the SAME queries (planted clip all-reduced from the rank that owns
+    the ground-truth video) and the union of the shards IS the one-GPU gallery (per-block seeds, independent of the cut)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    world, port = 2, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_bench_setup_worker, args=(world, port, ret), nprocs=world, join=True)
+    cfg = _BENCH_CFG
+    gs1, mask1, lens1, qs1, gt1 = bench.synth_shard("cpu", cfg, 0, cfg["nv"])
+    a, b = ret[0], ret[1]
+    assert (a["lo"], a["hi"], b["lo"], b["hi"]) == (0, 75, 75, 150)
+    for br in range(2):
+        assert torch.equal(a["qs"][br], b["qs"][br])                       # identical query set on both ranks ...
+        assert torch.equal(a["qs"][br], qs1[br])                           # ... and it is the one-GPU query set
+        assert torch.equal(torch.cat([a["gs"][br], b["gs"][br]]), gs1[br])  # shards = the one-GPU gallery cut by video
+    assert torch.equal(torch.cat([a["lens"], b["lens"]]), lens1) and torch.equal(a["gt"], gt1)
+    # an odd cut (not on a block boundary) gives the same videos too
+    g_mid, l_mid = bench.synth_videos("cpu", cfg, 37, 101)
+    assert torch.equal(g_mid[1], gs1[1][37:101]) and torch.equal(l_mid, lens1[37:101])
+    # the planted signal survives: a query's own video holds its best-matching clip far more often than chance
+    import torch.nn.functional as F
+    sims = torch.einsum("qd,vld->qvl", F.normalize(qs1[0], dim=-1), F.normalize(gs1[0], dim=-1))
+    sims = sims.masked_fill(mask1[None] == 0, -2.0).amax(-1)
+    assert (sims.argmax(1) == gt1).float().mean().item() > 0.5

@@ -25,10 +25,12 @@ def test_overlapped_shard_scorer_one_rank_rccl():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29593", RANK="0", WORLD_SIZE="1")
     dist.init_process_group("nccl", device_id=torch.device(DEV))
     try:
-        n, per = scoring.plan_query_split(nq, nv, 2, min_split=4)
-        assert n >= 4
-        backend = ddist.HipShardBackend(qs, pg, n)
-        ov = ddist.OverlappedShardScorer(backend, ddist.query_ranges(nq, n, per), nv, DEV)
+        backend = ddist.HipShardBackend(qs, pg, min_ranges=4)
+        n = backend.n_ranges
+        assert n >= 4 and backend.bounds == ddist.query_ranges(nq, n, backend.per_range)
+        ov = ddist.OverlappedShardScorer(backend, backend.bounds, nv, DEV)
+        with pytest.raises(ValueError):                         # a split that does not tile the queries is refused up front
+            ddist.OverlappedShardScorer(backend, [(0, 100), (200, nq)], nv, DEV)
         for _ in range(3):
             ov.step()
         torch.cuda.synchronize()
