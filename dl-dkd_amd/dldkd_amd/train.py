@@ -118,18 +118,23 @@ class GraphedTrainStep:
       * dropout calls bake only their offset inside the step (functional.PhiloxStepState), so replays draw fresh masks and
         a captured run reproduces the eager run with the same torch.manual_seed;
       * float(loss) - the reference's one sync per step - happens after the replay (or never: defer_loss_float).
-    The graph key holds everything that is baked in: tensor shapes, the caption-count structure, and the per-epoch scalars
-    (alpha, belta, KD weight, hard-negative mode); a new key runs eagerly the first time and is captured the second time; at
-    most `max_graphs` graphs are kept (least recently used is dropped).
+    The graph key holds everything that is baked in: tensor shapes and the per-epoch scalars (alpha, belta, KD weight,
+    hard-negative mode) - not the labels: they are staged per step like the other host values.  Real loaders pad every batch to
+    ITS longest caption / video (data.collate_train, as the reference does), so raw shapes change from batch to batch; the
+    stepper therefore pads the word axis up to a multiple of 8 and the clip axis up to a multiple of 32 (the masks already make
+    padding exact), which leaves a handful of signatures.  A new key runs eagerly the first time and is captured the second
+    time; at most `max_graphs` graphs are kept (least recently used is dropped), an evicted key is never captured again and
+    after `max_captures` captures every unseen key stays eager (variable caption counts - ActivityNet, Charades - would
+    otherwise re-capture a 350-kernel graph far more often than they replay one).
     Data parallel (world >= 2): the graph ends after the backward pass; gradient all-reduce and the optimizer update follow
     eagerly (3 launches)."""
 
     TENSOR_KEYS = ("student_videos", "student_videos_mask", "teacher_videos", "student_text", "student_text_mask", "teacher_text")
 
-    def __init__(self, model, optimizer, opt, max_graphs=4, defer_loss_float=False):
+    def __init__(self, model, optimizer, opt, max_graphs=8, defer_loss_float=False, max_captures=24):
         self.model, self.optimizer, self.opt = model, optimizer, opt
-        self.max_graphs, self.defer = max_graphs, defer_loss_float
-        self.graphs, self.seen = {}, {}
+        self.max_graphs, self.defer, self.max_captures = max_graphs, defer_loss_float, max_captures
+        self.graphs, self.seen, self.evicted = {}, {}, set()
         self.replays = self.eager_steps = self.captures = 0
         # EVERY step of this object - eager, capture, replay - runs on this side stream.  Autograd binds a parameter's
         # gradient-accumulation node to the stream that was current when the node was created and keeps it for as long as
@@ -145,9 +150,31 @@ class GraphedTrainStep:
         cfg = m.config
         get = (lambda k: cfg.get(k)) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k, None))
         shapes = tuple((k, tuple(batch[k].shape), str(batch[k].dtype)) for k in self.TENSOR_KEYS)
-        return (shapes, tuple(batch["text_labels"]) if len(batch["text_labels"]) < 4096 else len(batch["text_labels"]),
+        return (shapes, len(batch["text_labels"]),
                 float(m.alpha), float(m.belta), float(m.weight), bool(get("use_hard_negative")), get("hard_pool_size"),
                 m.label_style, bool(m.training), dist_info()[1] >= DDP_MIN_WORLD, getattr(self.opt, "grad_clip", -1))
+
+    def _bucketed(self, batch):
+        """The batch with its word axis padded to a multiple of 8 (at most max_desc_l) and its clip axis to a multiple of 32 (at
+        most max_ctx_l): zero features, zero mask.  Padded positions are masked out of attention, pooling, max-pool and KL
+        exactly (exp(-10000) and exp(-1e10) are 0 in fp32), so the step computes what it computes on the unpadded batch."""
+        import torch.nn.functional as TF
+        cfg = self.model.config
+        get = (lambda k, d: cfg.get(k, d)) if isinstance(cfg, dict) else (lambda k, d: getattr(cfg, k, d))
+        lq, lv = batch["student_text"].shape[1], batch["student_videos"].shape[1]
+        lq_b = max(min(-(-lq // 8) * 8, int(get("max_desc_l", lq))), lq)
+        lv_b = max(min(-(-lv // 32) * 32, int(get("max_ctx_l", lv))), lv)
+        if lq_b == lq and lv_b == lv:
+            return batch
+        out = dict(batch)
+        if lq_b != lq:
+            out["student_text"] = TF.pad(batch["student_text"], (0, 0, 0, lq_b - lq))
+            out["student_text_mask"] = TF.pad(batch["student_text_mask"], (0, lq_b - lq))
+        if lv_b != lv:
+            for k in ("student_videos", "teacher_videos"):
+                out[k] = TF.pad(batch[k], (0, 0, 0, lv_b - lv))
+            out["student_videos_mask"] = TF.pad(batch["student_videos_mask"], (0, lv_b - lv))
+        return out
 
     def __call__(self, batch):
         dev = batch["student_videos"].device
@@ -170,9 +197,12 @@ class GraphedTrainStep:
     def _step(self, batch):
         if getattr(self.opt, "grad_clip", -1) != -1:
             return self._eager(batch)                     # clip_grad_norm_ syncs: not capturable
+        batch = self._bucketed(batch)
         key = self._key(batch)
         e = self.graphs.get(key)
         if e is None:
+            if key in self.evicted or self.captures >= self.max_captures:
+                return self._eager(batch)                 # capturing costs far more than an eager step: never twice for one key
             if len(self.seen) > 4096:                     # data whose every batch has its own signature: stay eager, stay small
                 self.seen.clear()
             self.seen[key] = self.seen.get(key, 0) + 1
@@ -211,8 +241,8 @@ class GraphedTrainStep:
         e.draws = [(view(("t2v", c), nq), view(("v2t", c), nv)) for c in range(e.n_calls)]
         e.philox = F_.PhiloxStepState(view("philox", 4).view(torch.int64))
         e.static = {k: torch.empty_like(batch[k]) for k in self.TENSOR_KEYS}
-        e.static["text_labels"] = labels
-        e.labels_np, e.nq, e.nv = __import__("numpy").asarray(labels), nq, nv
+        e.static["text_labels"] = labels                 # only len() of it is baked in; the values are staged per step
+        e.nq, e.nv = nq, nv
         e.ddp = bool(key[9])
         old_lr = opt_.t_lr
         opt_.t_lr = view("lr", len(opt_.fp.params)).view(torch.float32)      # the update kernel reads the staged rates
@@ -240,7 +270,9 @@ class GraphedTrainStep:
         finally:
             F_.set_philox_step(old)
         while len(self.graphs) >= self.max_graphs:
-            self.graphs.pop(next(iter(self.graphs)))
+            old_key = next(iter(self.graphs))
+            self.graphs.pop(old_key)
+            self.evicted.add(old_key)
         self.graphs[key] = e
         self.captures += 1
         return e
@@ -255,9 +287,10 @@ class GraphedTrainStep:
         opt_.t_lr = e.t_lr
         n_t = len(opt_.fp.params)
         opt_.host_prepare(lr_out=slot[e.off["lr"]:e.off["lr"] + n_t].view(torch.float32))
-        slot[e.off["labels"]:e.off["labels"] + e.nq] = torch.from_numpy(e.labels_np.astype("int32"))
+        labels_np = __import__("numpy").asarray(batch["text_labels"])      # THIS batch's caption -> video map
+        slot[e.off["labels"]:e.off["labels"] + e.nq] = torch.from_numpy(labels_np.astype("int32"))
         for c in range(e.n_calls):                        # the reference's CPU draws, same order and arguments
-            _, r_t2v, r_v2t = m._draw_triplet(e.labels_np, e.nv)
+            _, r_t2v, r_v2t = m._draw_triplet(labels_np, e.nv)
             slot[e.off[("t2v", c)]:e.off[("t2v", c)] + e.nq] = r_t2v
             if r_v2t is not None:
                 slot[e.off[("v2t", c)]:e.off[("v2t", c)] + e.nv] = r_v2t

@@ -189,7 +189,10 @@ def test_graphed_train_step_equals_eager(prec, drop):
                     m.alpha, m.weight = 0.6, 0.9
             og.fp.flat.copy_(oe.fp.flat); og.m.copy_(oe.m); og.v.copy_(oe.v); og.step_count = oe.step_count
             torch.manual_seed(100 + it)
-            le, _ = T.train_step(me, batches[it % 3], oe, topt)
+            # the stepper pads the clip axis (20 -> 32) and the word axis to its buckets.  Without dropout that is exact, so
+            # the eager replica gets the RAW batch; with dropout the Philox masks are indexed by position in the (padded)
+            # tensors, so the eager replica gets the same padded batch
+            le, _ = T.train_step(me, batches[it % 3] if drop == 0.0 else stepper._bucketed(batches[it % 3]), oe, topt)
             torch.manual_seed(100 + it)
             lg, dg = stepper(batches[it % 3])
             assert float(le) == pytest.approx(float(lg), rel=tol), it
@@ -201,3 +204,53 @@ def test_graphed_train_step_equals_eager(prec, drop):
     finally:
         ops.set_gemm_precision("fp32")
     assert stepper.replays == 10 and stepper.captures == 2 and stepper.eager_steps == 2     # each key: 1 eager sight, then captured
+
+
+def test_graphed_step_serves_variable_length_batches_from_a_few_graphs():
+    """real loaders pad every batch to ITS longest caption / video, so raw shapes change from batch to
+    batch.  The stepper buckets the word / clip axes (exact: no dropout here, every step is compared with the eager step on the
+    RAW batch), stages the labels per step (batches with the same shapes but another caption -> video map replay the same
+    graph), never re-captures an evicted key and stops capturing after max_captures: replays must far exceed captures."""
+    import synth
+    from dldkd_amd import train as T
+    from dldkd_amd.model import DLDKD
+    from dldkd_amd.optimization import BertAdam
+    cfg = types.SimpleNamespace(visual_input_size=256, query_input_size=128, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=128, max_desc_l=30, input_drop=0.0, drop=0.0, n_heads=4, initializer_range=0.02,
+                                margin=0.1, use_hard_negative=True, hard_pool_size=5, label_style="soft")
+    mopt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                 collection="tvr", alpha=0.8, belta=0.8)
+    topt = types.SimpleNamespace(grad_clip=-1)
+    rs = np.random.RandomState(0)
+    batches = []
+    for i in range(28):
+        L = int(rs.choice([40, 70, 100, 128, 33, 64, 90, 120]))
+        b = synth.make_train_batch(300 + i, nv=16, caps=2, L=L, len_lo=3, dv=256, dq=128, lq_lo=4, lq_hi=int(rs.randint(10, 31)))
+        if i % 2:                                                    # same shapes family, another caption -> video map
+            perm = torch.from_numpy(rs.permutation(len(b["text_labels"])))
+            for k in ("student_text", "student_text_mask", "teacher_text"):
+                b[k] = b[k][perm]
+            b["text_labels"] = [b["text_labels"][j] for j in perm.tolist()]
+        batches.append({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()})
+    assert len({(tuple(b["student_text"].shape), tuple(b["student_videos"].shape)) for b in batches}) >= 12   # raw signatures
+
+    def make():
+        torch.manual_seed(11)
+        m = DLDKD(types.SimpleNamespace(**vars(cfg)), mopt).to(DEV).train()
+        return m, BertAdam([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=1e-3, warmup=0.1, t_total=200)
+    me, oe = make()
+    mg, og = make()
+    stepper = T.GraphedTrainStep(mg, og, topt, max_graphs=3, max_captures=5)
+    for rep in range(3):
+        for it, b in enumerate(batches):
+            og.fp.flat.copy_(oe.fp.flat); og.m.copy_(oe.m); og.v.copy_(oe.v); og.step_count = oe.step_count
+            torch.manual_seed(500 + it)
+            le, _ = T.train_step(me, b, oe, topt)
+            torch.manual_seed(500 + it)
+            lg, _ = stepper(b)
+            assert float(le) == pytest.approx(float(lg), rel=2e-5), (rep, it)
+            assert (oe.fp.flat - og.fp.flat).abs().max().item() <= 2e-7 + 0.02 * og.get_lr()[0]
+    n = 3 * len(batches)
+    assert stepper.captures <= 5 and stepper.replays + stepper.eager_steps == n
+    assert stepper.replays >= 6 * stepper.captures, (stepper.replays, stepper.captures, stepper.eager_steps)
+    assert len(stepper.graphs) <= 3 and not (set(stepper.graphs) & stepper.evicted)
