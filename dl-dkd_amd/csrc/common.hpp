@@ -139,6 +139,16 @@ struct PoolArgs {
     int nv, L;
 };
 
+// Does candidate (v, i) replace the running best (bv, bi) of a max-pool with arg-max?  torch.max semantics (model.py:327,349):
+// the first maximum wins, and a NaN wins over everything (the first NaN): a diverged step then shows as a NaN loss, as in the
+// reference - with `s > best` alone an all-NaN column left the sentinel index in arg_* and the backward gather read 2^31 rows
+// past the gallery.  bi starts at 0x7fffffff with bv = -inf, so the first valid clip is always taken.
+__device__ __forceinline__ bool pool_better(float v, int i, float bv, int bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn || bn) return vn && (!bn || i < bi);
+    return v > bv || (v == bv && i < bi);
+}
+
 // acc: the 128 x 128 block's accumulators in the layout of the three tiled GEMMs (wave (wm, wn) owns rows wm..wm+63, columns
 // wn..wn+63 as 2 x 2 tiles of 32 x 32: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).
 // scratch: >= 4 * 64 * 4 floats of LDS, free after the k-loop's last barrier.
@@ -170,8 +180,8 @@ __device__ __forceinline__ void gemm_pool_tile(const f32x16 (&acc)[2][2], const 
             for (int j = 0; j < 2; ++j) {
                 const float s = acc[i][j][r] * p.alpha;
                 const float c = s * rgl;
-                if (valid && s > braw[j]) { braw[j] = s; iraw[j] = row; }
-                if (valid && c > bcos[j]) { bcos[j] = c; icos[j] = row; }
+                if (valid && pool_better(s, row, braw[j], iraw[j])) { braw[j] = s; iraw[j] = row; }
+                if (valid && pool_better(c, row, bcos[j], icos[j])) { bcos[j] = c; icos[j] = row; }
                 if (any_pos && lab[j] == v && row < pa.L)
                     pa.clip_pos[(size_t)(n0 + wn + 32 * j + (lane & 31)) * pa.L + row] = valid ? c * rqn[j] : -1e10f;
             }
@@ -181,8 +191,8 @@ __device__ __forceinline__ void gemm_pool_tile(const f32x16 (&acc)[2][2], const 
     for (int j = 0; j < 2; ++j) {
         const float ob = __shfl_xor(braw[j], 32), oc = __shfl_xor(bcos[j], 32);
         const int oi = __shfl_xor(iraw[j], 32), oj = __shfl_xor(icos[j], 32);
-        if (ob > braw[j] || (ob == braw[j] && oi < iraw[j])) { braw[j] = ob; iraw[j] = oi; }
-        if (oc > bcos[j] || (oc == bcos[j] && oj < icos[j])) { bcos[j] = oc; icos[j] = oj; }
+        if (pool_better(ob, oi, braw[j], iraw[j])) { braw[j] = ob; iraw[j] = oi; }
+        if (pool_better(oc, oj, bcos[j], icos[j])) { bcos[j] = oc; icos[j] = oj; }
     }
     float* mine = scratch + wave * 256;
     if (half == 0) {
@@ -202,14 +212,14 @@ __device__ __forceinline__ void gemm_pool_tile(const f32x16 (&acc)[2][2], const 
             const float* e = other + (32 * j + lane) * 4;
             const float ob = e[0], oc = e[2];
             const int oi = __float_as_int(e[1]), oj = __float_as_int(e[3]);
-            if (ob > braw[j] || (ob == braw[j] && oi < iraw[j])) { braw[j] = ob; iraw[j] = oi; }
-            if (oc > bcos[j] || (oc == bcos[j] && oj < icos[j])) { bcos[j] = oc; icos[j] = oj; }
+            if (pool_better(ob, oi, braw[j], iraw[j])) { braw[j] = ob; iraw[j] = oi; }
+            if (pool_better(oc, oj, bcos[j], icos[j])) { bcos[j] = oc; icos[j] = oj; }
             const size_t o = (size_t)n * pa.nv + v;
             const bool none = len <= 0;                          // no valid clip: the reference's masked maximum (-1e10, clip 0)
             pa.pooled_raw[o] = none ? -1e10f : braw[j];
             pa.pooled_cos[o] = none ? -1e10f : bcos[j] * rqn[j];
-            pa.arg_raw[o] = none ? 0 : iraw[j];
-            pa.arg_cos[o] = none ? 0 : icos[j];
+            pa.arg_raw[o] = none ? 0 : min(iraw[j], len - 1);    // always a clip of the video (the backward pass gathers it)
+            pa.arg_cos[o] = none ? 0 : min(icos[j], len - 1);
         }
     }
 }

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(128 * kDqGroups) void simpool_bwd_dq_kernel(const S
         const bool has = p.lens[v] > 0;                // a video without clips pooled to the constant -1e10: no gradient
         const float a = (p.d_raw && has) ? p.d_raw[rowq + v] : 0.f;
         const float b = (p.d_cos && has) ? p.d_cos[rowq + v] : 0.f;
-        const int lr = p.arg_raw[rowq + v], lc = p.arg_cos[rowq + v];
+        const int lr = min(max(p.arg_raw[rowq + v], 0), p.L - 1), lc = min(max(p.arg_cos[rowq + v], 0), p.L - 1);   // never outside the video
         const f32x4 xr = grow(v, lr), xc = grow(v, lc);
         acc += a * xr;
         acc += (b * rq * p.rg[(size_t)v * p.L + lc]) * xc;

@@ -531,3 +531,34 @@ def test_layernorm_forward_backward_all_widths(M, D):
         assert (y.double().cpu() - yo.detach()).abs().max().item() < 2e-5
         for a, b in zip(xs[:3] + ([xs[3]] if use_add else []), xo[:3] + ([xo[3]] if use_add else [])):
             _gclose(a.grad, b.grad, tol=1e-3)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_fused_training_simpool_nan_query_propagates_and_stays_in_bounds(prec):
+    """an all-NaN query row (a diverged step) must come out as NaN scores - torch.max propagates NaN,
+    model.py:327,349 - with arg-max indices INSIDE the video, so the backward gathers stay in bounds (the `s > best` pool left
+    the 0x7fffffff sentinel there and the gather read 2^31 rows past the gallery: a GPU memory fault)."""
+    from dldkd_amd import functional as F_
+    from dldkd_amd import ops
+    g_ = torch.Generator().manual_seed(5)
+    nq, nv, L, D = 70, 9, 40, 384
+    q = torch.randn(nq, D, generator=g_)
+    g = torch.randn(nv, L, D, generator=g_)
+    lens = torch.randint(1, L + 1, (nv,), generator=g_)
+    g = g * (torch.arange(L)[None] < lens[:, None])[..., None]
+    labels = torch.randint(0, nv, (nq,), generator=g_)
+    q[7] = float("nan")                                      # every product of this query is NaN
+    q[33, 5] = float("inf")
+    ops.set_gemm_precision(prec)
+    try:
+        qd, gd = q.to(DEV).requires_grad_(), g.to(DEV).requires_grad_()
+        pc, pr, clip = F_.simpool_train(qd, gd, lens.to(DEV).int(), labels.to(DEV).int(), True)
+        (pc.sum() + pr.sum()).backward()
+        torch.cuda.synchronize()                             # a wild gather would fault here
+    finally:
+        ops.set_gemm_precision("fp32")
+    assert torch.isnan(pr[7]).all() and torch.isnan(pc[7]).all()          # NaN propagates like torch.max
+    ok = torch.ones(nq, dtype=torch.bool)
+    ok[[7, 33]] = False
+    assert torch.isfinite(pr[ok.to(DEV)]).all() and torch.isfinite(pc[ok.to(DEV)]).all()
+    assert torch.isfinite(qd.grad[ok.to(DEV)]).all()
