@@ -117,8 +117,12 @@ def test_throughput_mode_training_learns_like_parity_mode(tmp_path):
         # the first epochs track closely (measured 3.8741/3.8736, 1.0748/1.0743, 0.33767/0.33762 with the fused training
         # simpool; 3.876/3.874, 1.079/1.074, 0.348/0.338 before it); later the two runs are different trajectories of the
         # same noisy optimisation (0.32/0.20, 0.21/0.13 one run; 0.25/0.20, 0.16/0.13 another): only "keeps falling" is checked
-        if i < 3:
-            assert abs(a - b) <= 0.06 * abs(b) + 0.02, (l_got, l_ref)
+        # (round 3: the stepper pads the word / clip axes to its buckets, which re-indexes the dropout masks: 3.8572/3.8563,
+        # 1.0631/1.0619, then 0.307/0.252 - the trajectories part one epoch earlier than with the round-2 masks)
+        if i < 2:
+            assert abs(a - b) <= 0.01 * abs(b) + 0.005, (l_got, l_ref)
+        elif i == 2:
+            assert abs(a - b) <= 0.3 * abs(b) + 0.02, (l_got, l_ref)
         else:
             assert a < l_got[2] and a < 3.0 * b + 0.05, (l_got, l_ref)
     s_ref, s_got = [h[2] for h in ref], [h[2] for h in got]
