@@ -17,6 +17,25 @@ if len(sys.argv) > 1 and sys.argv[1] == "allbf16":
 NB = int(os.environ.get("ENC_BATCH", "200"))
 feats = torch.nn.functional.normalize(torch.randn(NB, 128, 3072, device=DEV), dim=-1)
 mask = torch.ones(NB, 128, device=DEV)
+if len(sys.argv) > 1 and sys.argv[1] == "fused":
+    # round 3: what eval_epoch runs in throughput mode - K4 + the fused tower kernel K5 straight into the packed bf16 gallery,
+    # ragged lengths U{24..128}, short videos sharing workgroups
+    from dldkd_amd import ops, scoring
+    ops.set_gemm_precision("bf16")
+    m.fast_input_proj = True
+    g = torch.Generator(device=DEV).manual_seed(1)
+    lens = torch.randint(24, 129, (NB,), generator=g, device=DEV)
+    mask = (torch.arange(128, device=DEV)[None] < lens[:, None]).float()
+    feats = feats * mask[..., None]
+    lh = lens.cpu().numpy()
+    pk = scoring.GalleryPacker(NB * 14, 128, 2, torch.device(DEV))
+    with torch.no_grad():
+        for _ in range(3): m.encode_context_into(pk, feats, mask, lens_host=lh)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): m.encode_context_into(pk, feats, mask, lens_host=lh)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    print(f"encode_context_into {NB}x128x3072 ragged U{{24..128}}: {dt*1e3:.2f} ms = {NB/dt:.0f} videos/s")
+    sys.exit(0)
 with torch.no_grad():
     for _ in range(3): m.encode_context(feats, mask)
     torch.cuda.synchronize(); t0 = time.perf_counter()
