@@ -56,6 +56,10 @@ struct Rows128Args {
     float eps;
     int relu;
     unsigned long long* stamps;   // diagnostics only (dldkd_debug_in_proj_rows128_timeline): 9 words per workgroup, else null
+    const int32_t* grp;    // row-group table or null.  A 128-row tile is four GROUPS of 32 consecutive rows; with a table, group i of
+                           // tile t starts at row grp[4 t + i] (of x AND of y): only the groups that hold valid clips of a padded
+                           // (n, L, K) batch are visited.  null: group i of tile t = rows 128 t + 32 i.
+    long n_tiles;          // ceil(#groups / 4)
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = p.K / RK;
-    const long ntiles = (p.M + RM - 1) / RM;
+    const long ntiles = p.n_tiles;
     const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
     const uint32_t region_lds = smem_lds + wave * WREGION;            // this wave's W' ring (+ x slot `wave` behind it)
     const uint32_t ring_lds = region_lds + lane * 16;
@@ -125,15 +129,22 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
     // x LDS-DMA: piece t = 4 wave + q of a k-tile = rows 8 t .. 8 t + 7 (1 KiB, lane -> LDS chunk 64 t + lane).  The lane
     // fetches the global chunk that belongs at that position of the swizzled image.  In a ragged last tile the byte offset is
     // clamped to the tile's last valid chunk (rows past M feed accumulator rows that are never stored).
+    // (a wave's four pieces are rows 32 wave .. 32 wave + 31 of the tile = ONE row group: its global source is the group's own
+    // base, so a tile can be made of any four 32-row groups; offsets are relative to the group)
     uint32_t voffx[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int t = 4 * wave + q, row = 8 * t + (lane >> 3);
+        const int row = 8 * q + (lane >> 3);                         // row inside the wave's group
         voffx[q] = (uint32_t)((long)row * p.K * 4 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
     }
-    auto tile_src = [&](long t) { return reinterpret_cast<const char*>(p.x + t * RM * p.K); };
+    auto group_row = [&](long t, int i) -> long {                    // first row of group i of tile t, clamped into [0, M)
+        const long g = p.grp != nullptr ? (long)p.grp[4 * t + i] : t * RM + 32 * i;
+        return g < p.M ? g : p.M - 1;
+    };
+    auto tile_src = [&](long t) { return reinterpret_cast<const char*>(p.x + group_row(t, wave) * p.K); };
     auto tile_maxoff = [&](long t) {
-        const long rv = p.M - t * RM < RM ? p.M - t * RM : RM;
+        const long left = p.M - group_row(t, wave);
+        const long rv = left < 32 ? left : 32;
         return (uint32_t)((rv - 1) * p.K * 4 + 112);
     };
     // A-fragment reads: lane (r = lane & 31, h = lane >> 5) takes chunks 4 kk + 2 h + e of row 32 i + r
@@ -339,15 +350,18 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
         // epilogue: wave w writes columns [192 w, 192 w + 192) = branch w / 2, columns (w & 1) * 192 .. straight from the
         // accumulators: a register holds one column of 2 x 4 rows; 32 lanes = one 128-byte row segment per store.  No LDS (it is
         // full of the next tile), no wait inside (one wave per SIMD: nothing would hide it).
-        const long m0 = tile * RM;
-        const bool full = m0 + RM <= p.M;
-        const char* ybase = reinterpret_cast<const char*>(((wave >> 1) ? p.y[1] : p.y[0]) + (size_t)m0 * kHidden);
+        long grow[4];                                                // first output row of the tile's four groups
+#pragma unroll
+        for (int i = 0; i < 4; ++i) grow[i] = group_row(tile, i);
+        const bool full = grow[0] + 32 <= p.M && grow[1] + 32 <= p.M && grow[2] + 32 <= p.M && grow[3] + 32 <= p.M;
+        const char* ybranch = reinterpret_cast<const char*>((wave >> 1) ? p.y[1] : p.y[0]);
         auto epilogue = [&](auto fullc) {
             constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ti = (i + wave) & 3;                       // the row tile behind the wave's accumulators acc[i][..]
-                const char* yt = ybase + (size_t)(32 * ti) * (kHidden * 4);
+                const long m0 = ti == 0 ? grow[0] : ti == 1 ? grow[1] : ti == 2 ? grow[2] : grow[3];
+                const char* yt = ybranch + (size_t)m0 * (kHidden * 4);
                 static_for<0, 4>([&](auto gc) {
                     constexpr int g = decltype(gc)::value;
                     const char* yg = yt + g * 8 * (kHidden * 4);
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
                             v[j] = rstd4[e] * (t - mean4[e] * csn[j]) + bbn[j];
                             if (relu) v[j] = fmaxf(v[j], 0.f);
                         }
-                        if (FULL || m0 + 32 * ti + 8 * g + hrow + e < p.M) {
+                        if (FULL || m0 + 8 * g + hrow + e < p.M) {
                             gstore32<0>(vo[e], v[0], yg);
                             gstore32<128>(vo[e], v[1], yg);
                             gstore32<256>(vo[e], v[2], yg);
@@ -405,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128_kernel(const Rows128Ar
 using namespace dldkd;
 
 static int launch_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1, long M, int K,
-                          float eps, int relu, unsigned long long* stamps, void* stream) {
+                          float eps, int relu, unsigned long long* stamps, void* stream, const int32_t* groups = nullptr, long n_groups = 0) {
     if (M < 0 || K < 4 * RK || (K % (2 * RK)) || (long)127 * K * 4 + 128 > 0xFFFFFFFFL) {
         set_error("in_proj_bf16_rows128: K must be a multiple of %d, at least %d (M=%ld K=%d)", 2 * RK, 4 * RK, M, K);
         return DLDKD_EINVAL;
@@ -413,7 +427,10 @@ static int launch_rows128(const float* x, const void* Wfrag, const float* cs, co
     if (M == 0) return DLDKD_OK;
     if (!x || !Wfrag || !cs || !bb || !y0 || !y1) { set_error("in_proj_bf16_rows128: null pointer"); return DLDKD_EINVAL; }
     if (((uintptr_t)x | (uintptr_t)y0 | (uintptr_t)y1 | (uintptr_t)Wfrag) & 15) { set_error("in_proj_bf16_rows128: unaligned buffer"); return DLDKD_EINVAL; }
-    Rows128Args p{x, (const char*)Wfrag, cs, bb, {y0, y1}, M, K, eps, relu != 0, stamps};
+    if (groups != nullptr && (n_groups < 0 || (n_groups & 3))) { set_error("in_proj_bf16_rows128: the group table must hold a multiple of 4 groups"); return DLDKD_EINVAL; }
+    if (groups != nullptr && n_groups == 0) return DLDKD_OK;
+    const long ntiles = groups != nullptr ? n_groups / 4 : (M + RM - 1) / RM;
+    Rows128Args p{x, (const char*)Wfrag, cs, bb, {y0, y1}, M, K, eps, relu != 0, stamps, groups, ntiles};
     constexpr int lds = 4 * WREGION;            // all 160 KiB
     static int n_cu = 0;                        // one persistent workgroup per CU (all 160 KiB of LDS)
     if (!n_cu) {
@@ -421,7 +438,6 @@ static int launch_rows128(const float* x, const void* Wfrag, const float* cs, co
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         n_cu = v;
     }
-    const long ntiles = (M + RM - 1) / RM;
     const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));
     if (stamps) {
         static const bool ok = hipFuncSetAttribute((const void*)in_proj_rows128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
@@ -438,6 +454,12 @@ static int launch_rows128(const float* x, const void* Wfrag, const float* cs, co
 extern "C" int dldkd_in_proj_bf16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                           long M, int K, float eps, int relu, void* stream) {
     return launch_rows128(x, Wfrag, cs, bb, y0, y1, M, K, eps, relu, nullptr, stream);
+}
+
+extern "C" int dldkd_in_proj_bf16_rows128_groups(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
+                                                 long M, int K, float eps, int relu, const int32_t* groups, long n_groups, void* stream) {
+    if (!groups) { set_error("in_proj_bf16_rows128_groups: null group table"); return DLDKD_EINVAL; }
+    return launch_rows128(x, Wfrag, cs, bb, y0, y1, M, K, eps, relu, nullptr, stream, groups, n_groups);
 }
 
 extern "C" int dldkd_in_proj_bf16_rows128_ok(int K) { return K >= 4 * RK && K % (2 * RK) == 0 && (long)127 * K * 4 + 128 <= 0xFFFFFFFFL; }

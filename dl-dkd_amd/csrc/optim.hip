@@ -40,6 +40,13 @@ __global__ __launch_bounds__(256) void adam_sumsq_kernel(const float* __restrict
     if (threadIdx.x == 0 && cur >= 0) atomicAdd(norm2 + cur, acc);
 }
 
+// norm2 <- 0 as a KERNEL, not hipMemsetAsync: a memset NODE of a replayed hipGraph left every fourth word of this 296-byte
+// buffer unzeroed (stale 0x510c7186-like words) whenever the stream was idle at launch - ROCm 7.0.2, seen as per-tensor clip
+// coefficients of ~0 in replayed steps only (round 3; tests/test_train_loop_gpu.py variable-length test).
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ x, int n) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) x[i] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, const int32_t* __restrict__ chunk_tensor,
                                                           const int32_t* __restrict__ t_start, const int32_t* __restrict__ t_numel,
@@ -99,7 +106,7 @@ int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const
     }
     hipStream_t s = (hipStream_t)stream;
     if (max_grad_norm > 0.f) {
-        if (hipMemsetAsync(norm2_scratch, 0, sizeof(float) * n_tensors, s) != hipSuccess) return check_launch("bert_adam memset");
+        DLDKD_LAUNCH(zero_f32_kernel, dim3((n_tensors + 255) / 256), dim3(256), 0, s, norm2_scratch, n_tensors);
         DLDKD_LAUNCH(adam_sumsq_kernel, dim3((n_chunks + kSumsqChunks - 1) / kSumsqChunks), dim3(256), 0, s, g, chunk_tensor, t_start,
                            t_numel, norm2_scratch, n_chunks);
     }

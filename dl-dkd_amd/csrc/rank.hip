@@ -92,6 +92,9 @@ __global__ __launch_bounds__(256) void rank_part_thr_kernel(const RankPartArgs p
     for (int k = 0; k < 3; ++k) {
         p.thr[(size_t)(2 * k) * p.nq + q] = g1 > g0 ? best[k] : nan;
         p.thr[(size_t)(2 * k + 1) * p.nq + q] = first[k];
+        // the counters the next kernel adds into start at 0 (a kernel store, not a memset node: see optim.hip zero_f32_kernel)
+        p.cnt[(size_t)(2 * k) * p.nq + q] = 0;
+        p.cnt[(size_t)(2 * k + 1) * p.nq + q] = 0;
     }
 }
 
@@ -152,7 +155,6 @@ extern "C" int dldkd_simpool_rank_partials(const void* workspace, const int32_t*
     if (!workspace || !inv_order || !gt_ptr || !gt_idx || !thr_scratch || !counts) { set_error("rank_partials: null pointer"); return DLDKD_EINVAL; }
     RankPartArgs p{(const float*)workspace, inv_order, gt_ptr, gt_idx, q_bad, thr_scratch, counts, nq, (nq + 31) / 32 * 32, nv, n_branches, w0, w1};
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * 6 * (size_t)nq, s) != hipSuccess) return check_launch("rank_partials memset");
     DLDKD_LAUNCH(rank_part_thr_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, p);
     DLDKD_LAUNCH(rank_part_count_kernel, dim3((nq + 63) / 64, (nv + kRankVChunk - 1) / kRankVChunk), dim3(256), 0, s, p);
     return check_launch("rank_partials");

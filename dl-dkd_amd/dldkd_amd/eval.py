@@ -148,6 +148,8 @@ def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
             feat, mask = pend_f[0], pend_m[0]
         else:
             lmax = max(f.shape[1] for f in pend_f)
+            if getattr(model, "fast_input_proj", False):         # whole 32-row groups: the input projection then skips the padding
+                lmax = min(-(-lmax // 32) * 32, max(int(_cfg_get(model.config, "max_ctx_l")), lmax))
             feat = pend_f[0].new_zeros(pend_n, lmax, pend_f[0].shape[2])
             mask = pend_m[0].new_zeros(pend_n, lmax)
             o = 0

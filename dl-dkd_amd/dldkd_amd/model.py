@@ -98,7 +98,7 @@ class DLDKD(nn.Module):
             mask = mask.float().unsqueeze(1)
         return encoder_layer(h, mask)
 
-    def _fast_proj(self, kind, feat):
+    def _fast_proj(self, kind, feat, groups=None):
         """K4: both branches' LayerNorm+Linear+ReLU of the raw features in one pass (inference only): bf16 when
         fast_input_proj is set, otherwise the parity-grade three-plane kernel."""
         if not self.fast_input_proj:
@@ -108,7 +108,7 @@ class DLDKD(nn.Module):
         if kind not in self._folded:
             layers = [getattr(self, pre + kind + "_input_proj") for pre in (("", "exp_") if self.double_branch else ("",))]
             self._folded[kind] = ops.FoldedInProj(layers)
-        return ops.in_proj_bf16(feat.float().contiguous(), self._folded[kind])
+        return ops.in_proj_bf16(feat.float().contiguous(), self._folded[kind], groups=groups)
 
     def _use_fast(self, feat):
         if self.training or torch.is_grad_enabled():
@@ -162,13 +162,17 @@ class DLDKD(nn.Module):
         videos share workgroups (ops.plan_tower_items).  Returns False when the fused path does not apply."""
         if not (self.fast_input_proj and self._use_fast(frame_video_feat)):
             return False
-        items = None
+        items = groups = None
+        n, L = frame_video_feat.shape[0], frame_video_feat.shape[1]
         if lens_host is not None:
             items = self._upload_items(ops.plan_tower_items(lens_host), frame_video_feat.device)
-        h0 = self._fast_proj("visual", frame_video_feat)
+            if (L % 32 == 0 and self.double_branch and ops.INPROJ_KERNEL == "rows128"
+                    and native.lib().dldkd_in_proj_bf16_rows128_ok(frame_video_feat.shape[-1])):
+                # the input projection visits only the 32-row groups that hold valid clips (the tower never reads the others)
+                groups = self._upload_items(ops.plan_row_groups(lens_host, L).reshape(-1, 4), frame_video_feat.device).reshape(-1)
+        h0 = self._fast_proj("visual", frame_video_feat, groups=groups)
         if not ops.tower_seq_ok(h0[0]):
             return False
-        n, L = frame_video_feat.shape[0], frame_video_feat.shape[1]
         lens = self._lens(video_mask, n, L, frame_video_feat.device)
         v0 = packer.reserve(n, L)
         ops.tower_seq(h0, self._tower_packs("visual"), lens, seq_rows=L, items=items, out_mode=1, gallery=packer.blobs, v0=v0,

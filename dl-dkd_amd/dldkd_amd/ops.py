@@ -372,8 +372,27 @@ def linear_rows(x, packed, relu=False, out_bf16=False):
     return y.view(*x.shape[:-1], n_out)
 
 
-def in_proj_bf16(x, folded, relu=True):
-    """x (..., K) fp32 -> list of per-branch (..., 384) fp32 outputs, one pass over x (K4)."""
+def plan_row_groups(lens, L):
+    """Host side of in_proj_bf16(groups=...): the 32-row groups of a padded (n, L, K) batch that hold valid clips, as int32 first
+    rows (video v, clips 32 t ..: v L + 32 t, t < ceil(len_v / 32)), padded to a multiple of 4 by repeating the last group."""
+    import numpy as np
+    lens = np.asarray(lens, dtype=np.int64)
+    if L % 32:
+        raise native.NativeError("plan_row_groups: L must be a multiple of 32")
+    nt = np.minimum((lens + 31) // 32, L // 32)
+    v = np.repeat(np.arange(len(lens), dtype=np.int64), nt)
+    t = np.arange(int(nt.sum()), dtype=np.int64) - np.repeat(np.cumsum(nt) - nt, nt)
+    g = v * L + 32 * t
+    if len(g) == 0:
+        return np.zeros(0, np.int32)
+    if len(g) % 4:
+        g = np.concatenate([g, np.full(4 - len(g) % 4, g[-1], np.int64)])
+    return np.ascontiguousarray(g.astype(np.int32))
+
+
+def in_proj_bf16(x, folded, relu=True, groups=None):
+    """x (..., K) fp32 -> list of per-branch (..., 384) fp32 outputs, one pass over x (K4).  groups (int32 GPU tensor from
+    plan_row_groups, rows128 kernel only): only those 32-row groups are projected; the other output rows stay unwritten."""
     L = native.lib()
     f = folded.get()
     K = x.shape[-1]
@@ -382,6 +401,15 @@ def in_proj_bf16(x, folded, relu=True):
     x2 = _chk(x.reshape(-1, K), "in_proj.x")
     M = x2.shape[0]
     ys = [torch.empty(M, HIDDEN, dtype=torch.float32, device=x.device) for _ in range(f.nb)]
+    if groups is not None:
+        if not (f.full_row and INPROJ_KERNEL == "rows128" and L.dldkd_in_proj_bf16_rows128_ok(K)):
+            raise native.NativeError("in_proj_bf16: a row-group table needs the two-branch rows128 kernel")
+        if groups.dtype != torch.int32 or not groups.is_cuda:
+            raise native.NativeError("in_proj_bf16: groups must be an int32 GPU tensor")
+        native.check(L.dldkd_in_proj_bf16_rows128_groups(native.ptr(x2), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb),
+                                                         native.ptr(ys[0]), native.ptr(ys[1]), M, K, LN_EPS, int(relu),
+                                                         native.ptr(groups), groups.numel(), native.stream()), "in_proj_bf16_rows128_groups")
+        return [y.view(*x.shape[:-1], HIDDEN) for y in ys]
     if f.full_row:
         rows128 = INPROJ_KERNEL == "rows128" and L.dldkd_in_proj_bf16_rows128_ok(K)
         fn = L.dldkd_in_proj_bf16_rows128 if rows128 else L.dldkd_in_proj_bf16_full

@@ -207,6 +207,13 @@ int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, 
 int dldkd_in_proj_bf16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                long M, int K, float eps, int relu, void* stream);
 int dldkd_in_proj_bf16_rows128_ok(int K);
+/* The same kernel over a ROW-GROUP TABLE: x and y0 / y1 are (M, K) / (M, 384) as above, but only the rows of the listed groups
+ * are read and written.  groups[g] = first row of a group of 32 consecutive rows (g < n_groups, n_groups a multiple of 4: pad by
+ * repeating a group; groups[g] + 32 <= M).  For a padded (n, L, K) batch with L a multiple of 32 the host lists the groups that
+ * hold valid clips (video v, clips 32 t ..: row v L + 32 t for t < ceil(len_v / 32)): the rows of the padding are neither
+ * projected nor written - 29 % fewer rows on a TVR-like length mix. */
+int dldkd_in_proj_bf16_rows128_groups(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
+                                      long M, int K, float eps, int relu, const int32_t* groups, long n_groups, void* stream);
 /* PARITY-grade two-branch input projection (in_proj_rows128x3.hip): y = ReLU(LayerNorm(x) W^T + b) with fp32-grade products
  * (three bf16 planes per operand, six MFMAs per product: the scheme of dldkd_gemm_f32x3), both branches in one pass.
  *   dldkd_row_meanrstd_f32: mean[M], rstd[M] of the rows exactly as dldkd_layernorm_f32 computes them (D % 4 == 0, D <= 4096).

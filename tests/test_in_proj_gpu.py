@@ -225,3 +225,44 @@ def test_fast_path_keeps_rank_parity():
     # random-init weights: near-chance, near-tied rankings; allow two of 192 queries to cross a cut
     for x, y in zip(r0[:4], r1[:4]):
         assert abs(x - y) <= 1.05, (r0, r1)
+
+
+@pytest.mark.parametrize("K,L", [(3072, 128), (1024, 64), (768, 32)])
+def test_k4_row_groups_project_only_the_listed_groups(K, L):
+    """dldkd_in_proj_bf16_rows128_groups: the rows of the listed 32-row groups equal the dense projection (the k order is
+    rotated per workgroup, so equality is to fp32 summation order), every other output row stays untouched."""
+    from dldkd_amd import ops
+    torch.manual_seed(3)
+    layers = [torch.nn.Module() for _ in range(2)]
+    for l in layers:
+        l.LayerNorm = torch.nn.LayerNorm(K).to(DEV)
+        l.net = torch.nn.Sequential(torch.nn.Dropout(0.0), torch.nn.Linear(K, 384).to(DEV))
+        l.LayerNorm.weight.data.uniform_(0.5, 1.5); l.LayerNorm.bias.data.normal_(0, 0.1)
+    fold = ops.FoldedInProj(layers)
+    n = 37
+    g = torch.Generator().manual_seed(K)
+    lens = torch.randint(1, L + 1, (n,), generator=g)
+    lens[0], lens[1] = L, 1
+    x = torch.randn(n, L, K, generator=g).to(DEV)
+    dense = ops.in_proj_bf16(x, fold)
+    groups_np = ops.plan_row_groups(lens.numpy(), L)
+    assert len(groups_np) % 4 == 0 and len(groups_np) < n * (L // 32) + 4
+    groups = torch.from_numpy(groups_np).to(DEV)
+    L_ = __import__("dldkd_amd.native", fromlist=["x"]).lib()
+    ys = [torch.full((n * L, 384), -7.0, device=DEV) for _ in range(2)]
+    from dldkd_amd import native
+    f = fold.get()
+    native.check(L_.dldkd_in_proj_bf16_rows128_groups(native.ptr(x.view(-1, K)), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb),
+                                                      native.ptr(ys[0]), native.ptr(ys[1]), n * L, K, 1e-5, 1, native.ptr(groups),
+                                                      groups.numel(), native.stream()), "groups")
+    torch.cuda.synchronize()
+    listed = torch.zeros(n * L, dtype=torch.bool)
+    for r in groups_np.tolist():
+        listed[r:r + 32] = True
+    for b in range(2):
+        got, want = ys[b].cpu(), dense[b].view(-1, 384).cpu()
+        assert (got[listed] - want[listed]).abs().max().item() <= 2e-5 * want.abs().max().item() + 1e-6
+        assert (got[~listed] == -7.0).all()
+    # through the Python wrapper too
+    via = ops.in_proj_bf16(x, fold, groups=groups)
+    assert torch.equal(via[0].view(-1, 384).cpu()[listed], ys[0].cpu()[listed])
