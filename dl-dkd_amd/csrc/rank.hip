@@ -67,6 +67,12 @@ struct RankPartArgs {
     int32_t* cnt;            // [3][2][nq]
     int nq, nq_pad, nv, nb;
     float w0, w1;
+    // gallery sharded by video (dist.sharded_ranks_from_partials): the CSR lists only THIS shard's ground-truth videos (local
+    // indices); first_local[q] != 0 iff the query's first listed GT video is one of them.  Thresholds then come out NaN-free
+    // (-inf where this shard holds nothing: the all-reduce(MAX) across shards picks the owner's value) and nan_flag[3][2][nq]
+    // says where the owner's value was NaN (all-reduced too: that query ranks last, like a NaN threshold does unsharded).
+    const int32_t* first_local;
+    float* nan_flag;
 };
 
 __global__ __launch_bounds__(256) void rank_part_thr_kernel(const RankPartArgs p) {
@@ -88,6 +94,18 @@ __global__ __launch_bounds__(256) void rank_part_thr_kernel(const RankPartArgs p
             best[k] = fmaxf(best[k], s[k]);           // drops NaNs; an all-NaN ground truth leaves -inf: everything finite is above
         }
     }
+    if (p.nan_flag != nullptr) {         // shard mode
+        const bool own_first = g1 > g0 && p.first_local[q] != 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool fn = own_first && first[k] != first[k];
+            p.thr[(size_t)(2 * k) * p.nq + q] = best[k];                                  // -inf without a local GT video
+            p.thr[(size_t)(2 * k + 1) * p.nq + q] = (own_first && !fn) ? first[k] : -INFINITY;
+            p.nan_flag[(size_t)(2 * k) * p.nq + q] = 0.f;                                 // best drops NaNs (fmaxf), as unsharded
+            p.nan_flag[(size_t)(2 * k + 1) * p.nq + q] = fn ? 1.f : 0.f;
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         p.thr[(size_t)(2 * k) * p.nq + q] = g1 > g0 ? best[k] : nan;
@@ -96,6 +114,11 @@ __global__ __launch_bounds__(256) void rank_part_thr_kernel(const RankPartArgs p
         p.cnt[(size_t)(2 * k) * p.nq + q] = 0;
         p.cnt[(size_t)(2 * k + 1) * p.nq + q] = 0;
     }
+}
+
+__global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* __restrict__ x, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = 0;
 }
 
 constexpr int kRankVChunk = 512;
@@ -147,13 +170,40 @@ extern "C" int dldkd_rank_gt(const float* scores, int nq, int nv, const int32_t*
     return check_launch("rank_gt");
 }
 
+extern "C" int dldkd_simpool_rank_partials_thr(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches, float w0,
+                                               float w1, const int32_t* gt_ptr, const int32_t* gt_idx, const int32_t* first_local,
+                                               const float* q_bad, float* thr, float* nan_flag, void* stream) {
+    if (nq < 0 || nv < 0 || n_branches < 1 || n_branches > 2) { set_error("rank_partials_thr: bad sizes nq=%d nv=%d", nq, nv); return DLDKD_EINVAL; }
+    if (nq == 0) return DLDKD_OK;
+    if (!gt_ptr || !gt_idx || !first_local || !thr || !nan_flag || (nv > 0 && (!workspace || !inv_order))) { set_error("rank_partials_thr: null pointer"); return DLDKD_EINVAL; }
+    RankPartArgs p{(const float*)workspace, inv_order, gt_ptr, gt_idx, q_bad, thr, nullptr, nq, (nq + 31) / 32 * 32, nv, n_branches, w0, w1,
+                   first_local, nan_flag};
+    DLDKD_LAUNCH(rank_part_thr_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("rank_partials_thr");
+}
+
+extern "C" int dldkd_simpool_rank_partials_count(const void* workspace, int nq, int nv, int n_branches, float w0, float w1, const float* thr,
+                                                 int32_t* counts, void* stream) {
+    if (nq < 0 || nv < 0 || n_branches < 1 || n_branches > 2) { set_error("rank_partials_count: bad sizes nq=%d nv=%d", nq, nv); return DLDKD_EINVAL; }
+    if (nq == 0) return DLDKD_OK;
+    if (!thr || !counts || (nv > 0 && !workspace)) { set_error("rank_partials_count: null pointer"); return DLDKD_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    DLDKD_LAUNCH(zero_i32_kernel, dim3((6 * nq + 255) / 256), dim3(256), 0, s, counts, 6 * nq);
+    if (nv == 0) return check_launch("rank_partials_count");
+    RankPartArgs p{(const float*)workspace, nullptr, nullptr, nullptr, nullptr, const_cast<float*>(thr), counts, nq, (nq + 31) / 32 * 32, nv,
+                   n_branches, w0, w1, nullptr, nullptr};
+    DLDKD_LAUNCH(rank_part_count_kernel, dim3((nq + 63) / 64, (nv + kRankVChunk - 1) / kRankVChunk), dim3(256), 0, s, p);
+    return check_launch("rank_partials_count");
+}
+
 extern "C" int dldkd_simpool_rank_partials(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches, float w0,
                                            float w1, const int32_t* gt_ptr, const int32_t* gt_idx, const float* q_bad,
                                            float* thr_scratch, int32_t* counts, void* stream) {
     if (nq < 0 || nv < 1 || n_branches < 1 || n_branches > 2) { set_error("rank_partials: bad sizes nq=%d nv=%d", nq, nv); return DLDKD_EINVAL; }
     if (nq == 0) return DLDKD_OK;
     if (!workspace || !inv_order || !gt_ptr || !gt_idx || !thr_scratch || !counts) { set_error("rank_partials: null pointer"); return DLDKD_EINVAL; }
-    RankPartArgs p{(const float*)workspace, inv_order, gt_ptr, gt_idx, q_bad, thr_scratch, counts, nq, (nq + 31) / 32 * 32, nv, n_branches, w0, w1};
+    RankPartArgs p{(const float*)workspace, inv_order, gt_ptr, gt_idx, q_bad, thr_scratch, counts, nq, (nq + 31) / 32 * 32, nv, n_branches, w0, w1,
+                   nullptr, nullptr};
     hipStream_t s = (hipStream_t)stream;
     DLDKD_LAUNCH(rank_part_thr_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, p);
     DLDKD_LAUNCH(rank_part_count_kernel, dim3((nq + 63) / 64, (nv + kRankVChunk - 1) / kRankVChunk), dim3(256), 0, s, p);

@@ -40,7 +40,11 @@ namespace dldkd {
 namespace tw {
 
 constexpr int kNKS = 24;                       // k-steps of 16 over 384 features
-constexpr int kChunk = 32, kDepth = 3;         // ring: fragments per chunk, fragment reads in flight
+constexpr int kChunk = 32;                     // ring: fragments per chunk
+#ifndef TW_DEPTH
+#define TW_DEPTH 3
+#endif
+constexpr int kDepth = TW_DEPTH, kFr = kDepth < 4 ? 4 : 8;   // fragment reads in flight; fragment registers (a ring of kFr x 4 VGPRs)
 constexpr int kHeadFrags = 3 * 3 * kNKS;       // Q | K | V of one head: 3 tiles x 24 k-steps each
 constexpr int kQKVFrags = 4 * kHeadFrags;      // 864
 constexpr int kSqFrags = 12 * kNKS;            // a 384 x 384 linear: 288
@@ -176,12 +180,12 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) glds_piece(lane16, src + i * 1024, dst + i * 1024);
     };
-    bf16x8 fr[4];
+    bf16x8 fr[kFr];
     const uint32_t ring_a = smem_lds + lane16, ring_b = ring_a + 48 * 1024;
     auto ring_read = [&](auto nc) {
         constexpr int n = decltype(nc)::value, slot = n % 96;
-        if constexpr (slot < 48) lds_read16<slot * 1024>(fr[n % 4], ring_a);
-        else lds_read16<(slot - 48) * 1024>(fr[n % 4], ring_b);
+        if constexpr (slot < 48) lds_read16<slot * 1024>(fr[n % kFr], ring_a);
+        else lds_read16<(slot - 48) * 1024>(fr[n % kFr], ring_b);
     };
     // everything that has to happen before the MFMA that consumes fragment n.  Fragment reads run kDepth ahead INSIDE a phase
     // (one head's Q | K | V projection, the dense layer, the out mapping) and never across a phase end: between phases the
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         if constexpr (n == pbeg) static_for<0, kDepth>([&](auto dc) { ring_read(std::integral_constant<int, pbeg + decltype(dc)::value>{}); });
         if constexpr (n + kDepth < pend) ring_read(std::integral_constant<int, n + kDepth>{});
         constexpr int after = pend - 1 - n < kDepth ? pend - 1 - n : kDepth;
-        bf16x8& f = fr[n % 4];                                 // (named first: an asm operand alone does not capture `fr`)
+        bf16x8& f = fr[n % kFr];                                 // (named first: an asm operand alone does not capture `fr`)
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(after) : "memory");
     };
 
@@ -272,14 +276,14 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         static_for<0, kNKS>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value, n = decltype(n0c)::value + ks;
             pre(std::integral_constant<int, n>{});
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[n % 4], X[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[n % kFr], X[ks], acc, 0, 0, 0);
         });
     };
     auto nprod = [&](auto n0c, f32x16& acc, const bf16x8 (&X)[kNKS]) {
         static_for<0, kNKS>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value, n = decltype(n0c)::value + ks;
             pre(std::integral_constant<int, n>{});
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[ks], fr[n % 4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[ks], fr[n % kFr], acc, 0, 0, 0);
         });
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

@@ -59,6 +59,40 @@ def sharded_gt_ranks(local_scores, gt_video, n_videos, group=None, count_fn=None
     return torch.where(worst, torch.full_like(ranks, n_videos + 1), torch.clamp(ranks, max=n_videos + 1))
 
 
+def local_gt_csr(t2v_gt, nq, lo, hi):
+    """Ground truth cut to the shard [lo, hi): (ptr int32 (nq + 1), idx int32 local video indices, first_local int32 (nq,),
+    has_gt bool (nq,)) as numpy arrays."""
+    import numpy as np
+    ptr = np.zeros(nq + 1, np.int32)
+    idx, first, has = [], np.zeros(nq, np.int32), np.zeros(nq, bool)
+    for q in range(nq):
+        g = t2v_gt.get(q, []) if isinstance(t2v_gt, dict) else t2v_gt[q]
+        if len(g):
+            has[q] = True
+            first[q] = int(lo <= g[0] < hi)
+            idx.extend(v - lo for v in g if lo <= v < hi)
+        ptr[q + 1] = len(idx)
+    return ptr, np.asarray(idx if idx else [0], np.int32), first, has
+
+
+def sharded_ranks_from_partials(local_thr_fn, local_count_fn, has_gt, bad, n_videos, group=None):
+    """Exact ranks of the ground-truth videos with the gallery sharded by video and NO score matrix anywhere: every rank computes
+    thresholds over its own GT videos from its scorer's partial planes (local_thr_fn() -> (thr, nan_flag) fp32 (3, 2, Nq), -inf / 0
+    where it holds none), all-reduce(MAX); counts its videos above them (local_count_fn(thr) -> int (3, 2, Nq)), all-reduce(SUM).
+    has_gt (Nq,) bool and bad (Nq,) bool (NaN / Inf query vector) are the same on every rank.  Returns int64 (3, 2, Nq):
+    [branch 0 / branch 1 / fused][best GT / first GT]; n_videos + 1 where there is no ground truth, the query is flagged, or the
+    first GT video's score is NaN (rank.hip's NaN policy)."""
+    thr, flag = local_thr_fn()
+    both = torch.stack([thr, flag])                         # one collective for both
+    dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
+    thr, flag = both[0], both[1]
+    counts = local_count_fn(thr).to(torch.int64)
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    ranks = torch.clamp(counts + 1, max=n_videos + 1)
+    worst = (flag > 0) | (~has_gt.to(ranks.device) | bad.to(ranks.device))[None, None, :]
+    return torch.where(worst, torch.full_like(ranks, n_videos + 1), ranks)
+
+
 def all_reduce_flat(flat, group=None):
     """Mean all-reduce of a flat gradient buffer (BertAdam's FlatParams.grad: every parameter's gradient is a view of ONE
     fp32 buffer, 23.0 MB for the TVR model / 17.5 MB for ActivityNet and Charades): one collective per step."""

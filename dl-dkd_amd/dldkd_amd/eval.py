@@ -306,27 +306,16 @@ def gallery_ids(dataset):
     return [dataset[i][2] for i in range(len(dataset))]
 
 
-def _gt_columns(t2v_gt, nq):
-    """Ground truth as a dense (nq, kmax) int64 table, short rows padded with their last entry, -1 rows for queries without
-    ground truth (one host pass instead of a Python loop per GT slot)."""
-    rows = [t2v_gt.get(q, ()) for q in range(nq)]
-    kmax = max((len(r) for r in rows), default=0)
-    tab = np.full((nq, max(kmax, 1)), -1, np.int64)
-    for q, r in enumerate(rows):
-        if len(r):
-            tab[q, :len(r)] = r
-            tab[q, len(r):] = r[-1]
-    return torch.from_numpy(tab)
-
-
 def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=False):
     """eval_epoch with the gallery sharded by video over the ranks of the default process group (config C4).
 
     Rank r encodes and keeps videos [r*S, (r+1)*S) only (its features are the only ones it reads), every rank encodes all
-    queries, scores them against its shard, and the ranks come from dist.sharded_gt_ranks: all-reduce(MAX) of each query's
-    ground-truth score, a local count of shard videos above it, all-reduce(SUM) - no (Nq, Nv) matrix is ever exchanged or
-    assembled, and R@K is exactly that of the unsharded evaluation (a caption whose video is not in the gallery ranks
-    n_videos + 1, as in the unsharded path).  Returns SumR of the fused scores on every rank."""
+    queries, scores them against its shard (the scorer's two partial planes, nothing else), and the ranks of all three score
+    kinds come from dist.sharded_ranks_from_partials: thresholds over the local ground-truth videos straight from the planes,
+    all-reduce(MAX), counts of local videos above them straight from the planes, all-reduce(SUM).  No (Nq, Nv / N) score matrix
+    is written on any rank and nothing but 2 x (6 Nq) numbers crosses xGMI; R@K is exactly that of the unsharded evaluation (a
+    caption whose video is not in the gallery ranks n_videos + 1, as in the unsharded path).  Returns SumR of the fused scores
+    on every rank."""
     from torch.utils.data import Subset
     from . import dist as ddist
     import torch.distributed as tdist
@@ -337,26 +326,31 @@ def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=Fal
     lo, hi, _ = ddist.shard_range(n_videos, rank, world)
     with eval_precision(model, opt):
         ctx = compute_context_info(model, Subset(val_video_dataset, range(lo, hi)), opt, keep_frame_feats=False)
-        fused, s0, s1, query_metas = score_queries(model, val_text_dataset, opt, ctx)
+        query_metas, qs = _encode_all_queries(model, val_text_dataset, opt)
     video_metas = gallery_ids(val_video_dataset) if world > 1 else ctx["video_metas"]
     _, t2v_gt = get_gt(video_metas, query_metas)
     nq = len(query_metas)
-    gt_tab = _gt_columns(t2v_gt, nq)
+    pg = ctx["_packed"]
+    dev = pg.lens.device
+    pq = scoring.pack_queries(qs)
+    ws = scoring.simpool_partials(pq, pg)
+    ptr, idx, first, has = ddist.local_gt_csr(t2v_gt, nq, lo, hi)
+    ptr_d, idx_d, first_d = (torch.from_numpy(a).to(dev) for a in (ptr, idx, first))
+    bad = pq.bad[:nq] > 0
+    thr_fn = lambda: scoring.shard_thresholds(ws, pq, pg, ptr_d, idx_d, first_d)        # noqa: E731
+    cnt_fn = lambda thr: scoring.shard_counts(ws, pq, pg, thr)                          # noqa: E731
+    if use_collectives:
+        ranks = ddist.sharded_ranks_from_partials(thr_fn, cnt_fn, torch.from_numpy(has), bad, n_videos)
+    else:                                                     # no process group: the one shard is the gallery
+        thr, flag = thr_fn()
+        r = torch.clamp(cnt_fn(thr).to(torch.int64) + 1, max=n_videos + 1)
+        worst = (flag > 0) | (~torch.from_numpy(has).to(dev) | bad)[None, None, :]
+        ranks = torch.where(worst, torch.full_like(r, n_videos + 1), r)
+    ranks = ranks.cpu().numpy()
     out = {}
-    for name, sc in (("inher", s0), ("explore", s1), ("fused", fused if s1 is not None else s0)):
-        if sc is None:
-            continue
-        # best GT per query = the GT video with the highest score = the minimum over the GT slots of the slot's rank; with
-        # one GT per query (TVR, ActivityNet, Charades captions) there is one slot
-        ranks = None
-        for k in range(gt_tab.shape[1]):
-            gt_k = gt_tab[:, k]
-            if use_collectives:
-                r = ddist.sharded_gt_ranks(sc, gt_k, n_videos)
-            else:
-                r = gt_ranks_gpu(sc, {q: ([int(v)] if v >= 0 else []) for q, v in enumerate(gt_k.tolist())})[0].long()
-            ranks = r if ranks is None else torch.minimum(ranks, r)
-        out[name] = _recalls(ranks.cpu().numpy(), nq)
+    kinds = (("inher", 0), ("explore", 1), ("fused", 2)) if model.double_branch else (("inher", 0), ("fused", 0))
+    for name, k in kinds:
+        out[name] = _recalls(ranks[k, 0], nq)
         logging.info(" * %s r_1_5_10_100: %s", name, [round(x, 1) for x in out[name][:4]])
     r1, r5, r10, r100 = out["fused"][:4]
     return r1 + r5 + r10 + r100

@@ -44,6 +44,9 @@ SIGNATURES = {
     "dldkd_modpool_fwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
     "dldkd_simpool_rank_partials": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p, _c_void_p,
                                               _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_simpool_rank_partials_thr": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p, _c_void_p,
+                                                  _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_simpool_rank_partials_count": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_rank_gt": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_layernorm_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                           _c_long, _c_int, _c_float, _c_void_p, _c_float, _c_void_p]),

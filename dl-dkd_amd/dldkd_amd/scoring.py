@@ -206,6 +206,35 @@ def rank_partials(workspace, pq, pg, gt_ptr, gt_idx, w=(0.7, 0.3)):
     return torch.clamp_(counts.add_(1), max=nv + 1)
 
 
+def shard_thresholds(workspace, pq, pg, gt_ptr, gt_idx, first_local, w=(0.7, 0.3)):
+    """Local half 1 of sharded ranking from the partial planes: (thr, nan_flag) fp32 (3, 2, Nq) over THIS shard's ground-truth
+    videos (gt_ptr / gt_idx: CSR of local GT indices; first_local int32 (Nq,): the first listed GT video is local).  -inf / 0
+    where the shard holds none: all-reduce both with MAX."""
+    L_ = native.lib()
+    nq, dev = pq.nq, pg.lens.device
+    thr = torch.full((3, 2, nq), float("-inf"), dtype=torch.float32, device=dev)
+    flag = torch.zeros(3, 2, nq, dtype=torch.float32, device=dev)
+    if nq and pg.nv:
+        native.check(L_.dldkd_simpool_rank_partials_thr(native.ptr(workspace), native.ptr(pg.inv_order), nq, pg.nv, pg.n_branches,
+                                                        float(w[0]), float(w[1]), native.ptr(gt_ptr), native.ptr(gt_idx),
+                                                        native.ptr(first_local), native.ptr(pq.bad), native.ptr(thr), native.ptr(flag),
+                                                        native.stream()), "simpool_rank_partials_thr")
+    return thr, flag
+
+
+def shard_counts(workspace, pq, pg, thr, w=(0.7, 0.3)):
+    """Local half 2: counts int32 (3, 2, Nq) of this shard's videos scoring above the (all-reduced) thresholds, straight from
+    the partial planes.  All-reduce with SUM."""
+    L_ = native.lib()
+    nq, dev = pq.nq, pg.lens.device
+    counts = torch.zeros(3, 2, nq, dtype=torch.int32, device=dev)
+    if nq:
+        native.check(L_.dldkd_simpool_rank_partials_count(native.ptr(workspace) if pg.nv else None, nq, pg.nv, pg.n_branches, float(w[0]),
+                                                          float(w[1]), native.ptr(thr.contiguous()), native.ptr(counts), native.stream()),
+                     "simpool_rank_partials_count")
+    return counts
+
+
 def simpool_eval(pq, pg, w=(0.7, 0.3), want_fused=True, want_branches=False, workspace=None):
     """Pooled cosine/dot scores of every query against every video.
 

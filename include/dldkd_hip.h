@@ -416,6 +416,21 @@ int dldkd_simpool_rank_partials(const void* workspace, const int32_t* inv_order,
                                 float w1, const int32_t* gt_ptr, const int32_t* gt_idx, const float* q_bad, float* thr_scratch,
                                 int32_t* counts, void* stream);
 
+/* The two halves of dldkd_simpool_rank_partials for a gallery SHARDED by video (eval_epoch_sharded: the loop of
+ * method/eval.py:188-212 cut by video, ranked as method/eval.py:59-94 ranks).  Every rank holds the partial planes of ITS videos:
+ *   _thr:   thresholds over the shard's own ground-truth videos.  gt_ptr / gt_idx: CSR of the LOCAL GT videos (local indices);
+ *           first_local[q] != 0 iff the query's first listed GT video is local.  thr[3][2][nq] comes out NaN-free (-inf where
+ *           the shard holds no GT video of the query) and nan_flag[3][2][nq] = 1 where the owner's first-GT score is NaN.
+ *           The caller all-reduces both with MAX.
+ *   _count: counts[3][2][nq] = # of the shard's videos with !(score <= thr) (zeroed here).  The caller all-reduces with SUM;
+ *           rank = 1 + count, nv_total + 1 for a flagged query or one without ground truth.
+ * No (nq, nv / N) score matrix is written on any rank. */
+int dldkd_simpool_rank_partials_thr(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches, float w0, float w1,
+                                    const int32_t* gt_ptr, const int32_t* gt_idx, const int32_t* first_local, const float* q_bad,
+                                    float* thr, float* nan_flag, void* stream);
+int dldkd_simpool_rank_partials_count(const void* workspace, int nq, int nv, int n_branches, float w0, float w1, const float* thr,
+                                      int32_t* counts, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Optimiser step and sharded-ranking helper.
  * ------------------------------------------------------------------------------------------- */

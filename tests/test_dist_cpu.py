@@ -264,3 +264,68 @@ def test_bench_multi_rank_setup_is_rank_invariant():
     sims = torch.einsum("qd,vld->qvl", F.normalize(qs1[0], dim=-1), F.normalize(gs1[0], dim=-1))
     sims = sims.masked_fill(mask1[None] == 0, -2.0).amax(-1)
     assert (sims.argmax(1) == gt1).float().mean().item() > 0.5
+
+
+# ------------------------------------------------------------------------------------------------ sharded ranks from the partial planes
+def _ranks_worker(rank, world, port, ret):
+    _setup(rank, world, port)
+    from dldkd_amd import dist as ddist
+    g = torch.Generator().manual_seed(3)
+    nq, nv = 23, 11
+    s = torch.randn(3, nq, nv, generator=g)                         # three score kinds, the whole gallery
+    gt = {q: [int(v) for v in torch.randperm(nv, generator=g)[:1 + q % 3]] for q in range(nq)}
+    del gt[4]                                                       # a caption whose video is not in the gallery
+    s[:, 7, gt[7][0]] = float("nan")                                # NaN score of a first-listed GT video
+    bad = torch.zeros(nq, dtype=torch.bool); bad[9] = True          # a flagged (NaN / Inf) query
+    lo, hi, _ = ddist.shard_range(nv, rank, world)
+    ptr, idx, first, has = ddist.local_gt_csr(gt, nq, lo, hi)
+    loc = s[:, :, lo:hi]
+
+    def thr_fn():                                                   # what rank_part_thr_kernel computes in shard mode
+        thr = torch.full((3, 2, nq), float("-inf")); flag = torch.zeros(3, 2, nq)
+        for q in range(nq):
+            mine = idx[ptr[q]:ptr[q + 1]]
+            for k in range(3):
+                vals = loc[k, q, mine] if len(mine) else torch.empty(0)
+                ok = vals[~torch.isnan(vals)]
+                if len(ok):
+                    thr[k, 0, q] = ok.max()
+                if first[q]:
+                    f = loc[k, q, gt[q][0] - lo]
+                    if torch.isnan(f):
+                        flag[k, 1, q] = 1.0
+                    else:
+                        thr[k, 1, q] = f
+        return thr, flag
+
+    def count_fn(thr):
+        return (~(loc[:, None, :, :] <= thr[:, :, :, None])).sum(-1).int()          # (3, 2, nq)
+    ranks = ddist.sharded_ranks_from_partials(thr_fn, count_fn, torch.from_numpy(has), bad, nv)
+    ret[rank] = ranks.numpy()
+    if rank == 0:
+        want = np.zeros((3, 2, nq), np.int64)
+        for q in range(nq):
+            for k in range(3):
+                if q not in gt or bad[q]:
+                    want[k, :, q] = nv + 1
+                    continue
+                row = s[k, q]
+                vals = row[gt[q]]
+                ok = vals[~torch.isnan(vals)]
+                best = ok.max() if len(ok) else torch.tensor(float("-inf"))
+                want[k, 0, q] = min(1 + int((~(row <= best)).sum()), nv + 1)
+                f = row[gt[q][0]]
+                want[k, 1, q] = nv + 1 if torch.isnan(f) else min(1 + int((~(row <= f)).sum()), nv + 1)
+        ret["want"] = want
+    dist.destroy_process_group()
+
+
+def test_sharded_ranks_from_partials_two_ranks():
+    """dist.sharded_ranks_from_partials (eval_epoch_sharded's ranking: thresholds over local GT videos -> all-reduce MAX ->
+    local counts -> all-reduce SUM, no score matrix) equals ranking the whole matrix: several GT videos per query spread over
+    both shards, a query without ground truth, a flagged query, a NaN first-GT score."""
+    world, port = 2, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_ranks_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert (ret[0] == ret[1]).all()                                  # the same ranks on every rank
+    assert (ret[0] == ret["want"]).all(), (ret[0][0], ret["want"][0])

@@ -250,3 +250,45 @@ def test_eval_epoch_equals_matrix_path(golden_dir):
     _, t2v = ev.get_gt(ctx["video_metas"], metas)
     r = ev.cal_perf(-fused, t2v)
     assert sumr == pytest.approx(r[0] + r[1] + r[2] + r[3], abs=1e-9)
+
+
+@pytest.mark.parametrize("nq,nv,L,cuts", [(3000, 615, 128, (0, 200, 615)), (333, 77, 40, (0, 30, 30, 77)), (64, 9, 9, (0, 4, 9))])
+def test_sharded_ranks_from_partial_planes_equal_unsharded(nq, nv, L, cuts):
+    """The two local halves of eval_epoch_sharded's ranking (scoring.shard_thresholds / shard_counts: thresholds and counts straight
+    from each shard's partial planes) combined the way dist.sharded_ranks_from_partials combines them (MAX, then SUM; here in
+    one process, shards = separate packed galleries incl. an EMPTY shard) against scoring.rank_partials of the whole gallery:
+    identical ranks for all three score kinds and both flavours, with multi-GT queries spread over shards, queries without
+    ground truth, a NaN query, and a NaN first-GT score."""
+    from dldkd_amd import dist as ddist, eval as ev, scoring
+    g = torch.Generator(device=DEV).manual_seed(nq + nv)
+    lens = torch.randint(1, L + 1, (nv,), generator=g, device=DEV)
+    mask = (torch.arange(L, device=DEV)[None] < lens[:, None]).float()
+    gal = [torch.randn(nv, L, 384, generator=g, device=DEV) * mask[..., None] for _ in range(2)]
+    qs = [torch.randn(nq, 384, generator=g, device=DEV) for _ in range(2)]
+    qs[0][7] = float("nan")
+    rs = np.random.RandomState(5)
+    gts = {}
+    for q in range(nq):
+        k = rs.randint(0, 4) if q % 7 == 0 else 1
+        if k:
+            gts[q] = [int(v) for v in rs.choice(nv, size=min(k, nv), replace=False)]
+    gal[1][gts[3][0]] = float("nan")                            # a video whose exploration clips are NaN: NaN first-GT score of query 3
+    pq = scoring.pack_queries(qs)
+    pg = scoring.pack_gallery(gal, mask)
+    ptr, idx = ev.gt_csr(gts, nq, DEV)
+    want = scoring.rank_partials(scoring.simpool_partials(pq, pg), pq, pg, ptr, idx).cpu().long()
+    shards = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        pgs = scoring.pack_gallery([x[lo:hi] for x in gal], mask[lo:hi]) if hi > lo else scoring.GalleryPacker(0, L, 2, torch.device(DEV)).finish()
+        ws = scoring.simpool_partials(pq, pgs)
+        p_, i_, f_, has = ddist.local_gt_csr(gts, nq, lo, hi)
+        shards.append((pgs, ws, [torch.from_numpy(a).to(DEV) for a in (p_, i_, f_)], has))
+    parts = [scoring.shard_thresholds(ws, pq, pgs, *csr) for pgs, ws, csr, _ in shards]
+    thr = torch.stack([p[0] for p in parts]).amax(0)             # all-reduce(MAX)
+    flag = torch.stack([p[1] for p in parts]).amax(0)
+    counts = sum(scoring.shard_counts(ws, pq, pgs, thr).long() for pgs, ws, _, _ in shards)      # all-reduce(SUM)
+    ranks = torch.clamp(counts + 1, max=nv + 1)
+    worst = (flag > 0) | (~torch.from_numpy(shards[0][3]).to(DEV) | (pq.bad[:nq] > 0))[None, None, :]
+    ranks = torch.where(worst, torch.full_like(ranks, nv + 1), ranks).cpu()
+    assert torch.equal(ranks, want)
+    assert int(want[2, 0, 7]) == nv + 1 and int(want[1, 1, 3]) == nv + 1
