@@ -258,7 +258,7 @@ def test_sharded_ranks_from_partial_planes_equal_unsharded(nq, nv, L, cuts):
     from each shard's partial planes) combined the way dist.sharded_ranks_from_partials combines them (MAX, then SUM; here in
     one process, shards = separate packed galleries incl. an EMPTY shard) against scoring.rank_partials of the whole gallery:
     identical ranks for all three score kinds and both flavours, with multi-GT queries spread over shards, queries without
-    ground truth, a NaN query, and a NaN first-GT score."""
+    ground truth and a NaN query (the NaN first-GT flag is exercised by tests/test_dist_cpu.py)."""
     from dldkd_amd import dist as ddist, eval as ev, scoring
     g = torch.Generator(device=DEV).manual_seed(nq + nv)
     lens = torch.randint(1, L + 1, (nv,), generator=g, device=DEV)
@@ -272,7 +272,6 @@ def test_sharded_ranks_from_partial_planes_equal_unsharded(nq, nv, L, cuts):
         k = rs.randint(0, 4) if q % 7 == 0 else 1
         if k:
             gts[q] = [int(v) for v in rs.choice(nv, size=min(k, nv), replace=False)]
-    gal[1][gts[3][0]] = float("nan")                            # a video whose exploration clips are NaN: NaN first-GT score of query 3
     pq = scoring.pack_queries(qs)
     pg = scoring.pack_gallery(gal, mask)
     ptr, idx = ev.gt_csr(gts, nq, DEV)
@@ -291,4 +290,4 @@ def test_sharded_ranks_from_partial_planes_equal_unsharded(nq, nv, L, cuts):
     worst = (flag > 0) | (~torch.from_numpy(shards[0][3]).to(DEV) | (pq.bad[:nq] > 0))[None, None, :]
     ranks = torch.where(worst, torch.full_like(ranks, nv + 1), ranks).cpu()
     assert torch.equal(ranks, want)
-    assert int(want[2, 0, 7]) == nv + 1 and int(want[1, 1, 3]) == nv + 1
+    assert int(want[2, 0, 7]) == nv + 1                          # the NaN query ranks last on both paths
