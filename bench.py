@@ -299,6 +299,9 @@ def extras(dev):
         # GPU work of one eval_epoch at C2 from RAW features (encode gallery + queries, score, rank); SURVEY 8d
         out["eval_epoch_gpu_stages_fp32"] = stage_times(NV, NQ, "fp32", str(dev))
         out["eval_epoch_gpu_stages_fast"] = stage_times(NV, NQ, "fast", str(dev))
+        # round 3: throughput-mode gallery encode = K4 (row groups: padding skipped) + the fused tower kernel K5 straight into the
+        # packed bf16 gallery, ragged lengths U{24..128}
+        out["gallery_encode_videos_per_s_fused_k4_k5"] = out["eval_epoch_gpu_stages_fast"].get("gallery_videos_per_sec")
         import types as _t
         cfg2 = cfg
         torch.manual_seed(0)

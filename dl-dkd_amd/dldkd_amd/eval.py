@@ -358,7 +358,7 @@ def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=Fal
 
 # Precision of eval_epoch / eval_epoch_sharded (opt.eval_precision overrides):
 #   "throughput" (default; BASELINE configs[1] is bf16): bf16 input projection K4 + the fused bf16 tower kernel K5 + the bf16 scorer.
-#       Gated at R@1/5/10/100 within 0.1 of the fp32 oracle from raw features (tests/test_rk_gate_gpu.py, tools/rk_gate.py).
+#       Gated at R@1/5/10/100 within 0.1 of the fp32 CPU restatement from raw features (tests/test_rk_gate_gpu.py, tools/rk_gate.py).
 #   "parity": whatever ops.gemm_precision() is set to - by default the fp32-grade towers every golden test runs on.
 EVAL_PRECISION = "throughput"
 
