@@ -57,6 +57,8 @@ constexpr int P_WG = P_BO;                     // query towers (no out mapping):
 constexpr int P_TAIL = 4;                      // ... followed by c1 = sum w gamma2, c2 = sum w beta2 (+ 2 unused words)
 constexpr int kLdsTotal = kLdsPar + P_TOTAL * 4 + 512;      // 163,840 = all 160 KiB
 constexpr int kStgPitch = 400;                 // output staging: 32 rows x 384 payload bytes per wave and pass
+constexpr int kPosTile = kNKS * 64 * 8;        // floats of one 32-position tile of the position table in fragment order
+constexpr int kInStage = 32 * 1024;            // prologue: h0 half-rows are staged at [32 KiB + wave * 24 KiB, +24 KiB) of LDS
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -93,13 +95,13 @@ __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
 
 struct TowerArgs {
     const float* h0[2];       // per branch: input-projection output, rows (., 384) fp32
-    const float* pos[2];      // per branch: position table [max_pos][384] fp32
-    const char* blob[2];      // per branch: weight fragments in stream order, then the parameter table
+    const char* blob[2];      // per branch: weight fragments in stream order, the parameter table, the position table in
+                              // fragment order
     const int32_t* row0;      // [n_seq] first row of the sequence in h0 / out; null: seq * seq_rows
     const int32_t* lens;      // [n_seq] valid rows (> 0 for every scheduled sequence)
-    const int32_t* items;     // [n_items][4]: what the four waves of a workgroup work on: (seq << 2) | tile, or -1 (idle slot);
+    const int32_t* items;     // [n_items][4]: what the four waves of a workgroup work on: (seq << 10) | (tile << 8) | length, or -1 (idle);
                               // the 32-row tiles of one sequence sit in consecutive slots, in order.  null: workgroup i = sequence i
-    int n_items, n_seq, n_branches, max_pos;
+    int n_items, n_seq, n_branches;
     float* out[2];            // OUTMODE 0: fp32 rows (., 384), indexed like h0
     int seq_rows;             // OUTMODE 0: rows allotted per sequence, 0 = ragged.  Rows len .. seq_rows - 1: computed like the
                               // reference does (no item table) or written as zeros (with an item table)
@@ -107,13 +109,38 @@ struct TowerArgs {
     int v0, Lp;               // OUTMODE 1: gallery index of sequence 0, rows per video
     int32_t* lens_out;        // OUTMODE 1: lens of the whole gallery (or null)
     float* pooled[2];         // OUTMODE 2: (n_seq, 384) fp32 modular query vectors
+    unsigned long long* stamps;   // diagnostics only (dldkd_debug_tower_seq_timeline): 24 words per workgroup, else null
 };
 
 // OUTMAP: the stream ends with the 384 x 384 out_mapping_linear (video towers); OUTMODE 0: fp32 rows, 1: packed bf16 gallery,
 // 2 (query towers, sequences of at most 32 words, one per wave): the modular attention pooling of get_modularized_queries
 // (method/model.py:245-258) on top: softmax_l(mask_logits(w . h2_l)) -> sum_l a_l h2_l, one 384-vector per sequence.
-template <bool OUTMAP, int OUTMODE>
+template <bool OUTMAP, int OUTMODE, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
+    unsigned long long ts[16], tp[8];
+    int n_tp = 0;
+    int n_ts = 0;
+    auto stamp = [&]() {      // phase boundaries only: no hand-counted read is in flight there (cdna_hip_programming.md section 7)
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            ts[n_ts < 15 ? n_ts : 15] = t;
+            ++n_ts;
+        }
+    };
+    auto pstamp = [&]() {     // finer stamps inside the prologue (diagnostic build only)
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            tp[n_tp < 7 ? n_tp : 7] = t;
+            ++n_tp;
+        }
+    };
+    stamp();
     constexpr int NFRAG = kQKVFrags + kSqFrags + (OUTMAP ? kSqFrags : 0);
     constexpr int NCH = NFRAG / kChunk;
     static_assert(NFRAG % kChunk == 0, "whole chunks");
@@ -127,15 +154,31 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         item = (blockIdx.x >> 3) * 4 + (blockIdx.x & 3);
     }
     if (item >= p.n_items) return;
+    const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
+    const uint32_t lane16 = lane * 16;
+    const char* wsrc = p.blob[branch];
+    float* par = reinterpret_cast<float*>(smem + kLdsPar);
+    auto issue_chunk = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const char* src = wsrc + (size_t)(c * kChunk + wave * 8) * 1024;
+        const uint32_t dst = smem_lds + ((c % 3) * kChunk + wave * 8) * 1024;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) glds_piece(lane16, src + i * 1024, dst + i * 1024);
+    };
+    // the first weight chunk depends on the branch only: in flight before the (dependent, scalar) loads that say which sequence
+    // this wave works on
+    issue_chunk(std::integral_constant<int, 0>{});
     // this wave's slot: a 32-row tile of some sequence.  An idle slot re-computes slot 0's tile and stores nothing (the
     // instruction stream, with its barriers and its share of the weight DMA, is the same for every wave).
     int seq, tile;
     bool live = true;
+    int len_item = -1;
     if (p.items != nullptr) {
-        int ent = p.items[item * 4 + wave];
+        int ent = p.items[item * 4 + wave];                      // (seq << 10) | (tile << 8) | length: ONE scalar load per wave
         if (ent < 0) { live = false; ent = p.items[item * 4]; }
-        seq = ent >> 2;
-        tile = ent & 3;
+        seq = ent >> 10;
+        tile = (ent >> 8) & 3;
+        len_item = ent & 255;
     } else if constexpr (OUTMODE == 2) {
         seq = item * 4 + wave;                         // four single-tile sequences per workgroup
         tile = 0;
@@ -149,12 +192,13 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         const int rows = OUTMODE == 0 && p.seq_rows > p.lens[item] ? p.seq_rows : p.lens[item];
         if (wave > 0 && 32 * wave >= rows) { live = false; tile = 0; }
     }
-    const int len_raw = p.lens[seq];
+    const int len_raw = len_item >= 0 ? len_item : p.lens[seq];
     const int len = OUTMODE == 2 ? (len_raw < 1 ? 1 : len_raw > 32 ? 32 : len_raw) : len_raw;   // (query mode: host contract 1..32)
     const int nrows = OUTMODE == 0 && p.items == nullptr && p.seq_rows > len ? p.seq_rows : len;   // rows computed and stored
     const int first = (live || (OUTMODE == 2 && p.items == nullptr)) ? wave - tile : 0;   // slot of the sequence's tile 0 (K / V of key tile kt: slot first + kt)
     const int row0 = p.row0 != nullptr ? p.row0[seq] : seq * p.seq_rows;
-    if (OUTMODE != 2 && len <= 0) {     // only without an item table (the host never schedules an empty sequence): the workgroup IS the sequence
+    if (OUTMODE != 2 && len <= 0) {     // only without an item table
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (an LDS-DMA must not outlive its workgroup) (the host never schedules an empty sequence): the workgroup IS the sequence
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         if constexpr (OUTMODE == 1) {
             char* g = p.gal[branch] + (size_t)(p.v0 + seq) * p.Lp * (kHidden * 2);
@@ -167,19 +211,8 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         return;
     }
     const int ntiles = (len + 31) >> 5;                // 32-row tiles of the sequence (wave-uniform)
-    const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
-    const uint32_t lane16 = lane * 16;
-    const char* wsrc = p.blob[branch];
-    float* par = reinterpret_cast<float*>(smem + kLdsPar);
 
     // ---- weight ring --------------------------------------------------------------------------------------------
-    auto issue_chunk = [&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        const char* src = wsrc + (size_t)(c * kChunk + wave * 8) * 1024;
-        const uint32_t dst = smem_lds + ((c % 3) * kChunk + wave * 8) * 1024;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) glds_piece(lane16, src + i * 1024, dst + i * 1024);
-    };
     bf16x8 fr[kFr];
     const uint32_t ring_a = smem_lds + lane16, ring_b = ring_a + 48 * 1024;
     auto ring_read = [&](auto nc) {
@@ -208,49 +241,84 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(after) : "memory");
     };
 
-    issue_chunk(std::integral_constant<int, 0>{});
-    issue_chunk(std::integral_constant<int, 1>{});
-
     // ---- prologue: parameter table, h1 = LN(h0 + pos) ---------------------------------------------------------------
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(wsrc + (size_t)NFRAG * 1024);
-        f32x4* dst = reinterpret_cast<f32x4*>(par);
-        for (int i = tid; i < (P_TOTAL + P_TAIL) / 4; i += 256) dst[i] = src[i];
-    }
+    // h0 rows are 1.5 KiB of fp32 each; a lane needs 16-byte pieces of ONE row (fragment-shaped loads from HBM cost a third of
+    // the kernel: 32 lines per instruction, four serialised round trips).  Instead the wave's 32 rows come by LDS-DMA, whole
+    // half-rows (768 B) at a time, into 24 KiB of the LDS the weight ring and the K / V exchange do not use yet; the image is
+    // ROTATED by the row (16-byte position p of row r holds chunk (p + r) mod 48 - done on the per-lane SOURCE address, the
+    // LDS side of an LDS-DMA is linear), so the ds_read_b128 of 16 lanes = 16 different rows hit 16 different bank groups.
     bf16x8 X1[kNKS];     // h1^T (later h2^T) as MFMA operand fragments: lane = (row r, half h), k-step ks, 8 features
     {
-        const int l = 32 * tile + r;
-        const int lrow = l < nrows ? l : nrows - 1;                   // rows past the sequence: a finite copy (never stored)
-        const int lpos = l < p.max_pos ? l : p.max_pos - 1;
-        const float* xr = p.h0[branch] + (size_t)(row0 + lrow) * kHidden + 4 * h;
-        const float* pr = p.pos[branch] + (size_t)lpos * kHidden + 4 * h;
+        const uint32_t stage = smem_lds + kInStage + wave * (24 * 1024);
+        // wave-uniform (one sequence per wave); made provably so for the asm's "s" operand (cdna_hip_programming.md T20)
+        const uint64_t hs64 = reinterpret_cast<uint64_t>(p.h0[branch] + (size_t)row0 * kHidden);
+        const uint32_t hs_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hs64 >> 32));
+        const uint32_t hs_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hs64);      // (the builtin returns a SIGNED int)
+        const char* hsrc = reinterpret_cast<const char*>(((uint64_t)hs_hi << 32) | (uint64_t)hs_lo);
+        uint32_t vsrc[24];                                             // per piece: this lane's source offset inside the sequence's rows
+#pragma unroll
+        for (int j = 0; j < 24; ++j) {
+            const int t48 = (64 * j) % 48 + lane, d48 = (t48 >= 48) + (t48 >= 96);              // (no integer division by 48 per lane)
+            const int rl = (64 * j) / 48 + d48, pp = t48 - 48 * d48;                            // LDS slot 64 j + lane -> (row, position)
+            const int l = 32 * tile + rl, lrow = l < nrows ? l : nrows - 1;                     // rows past the sequence: a finite copy
+            vsrc[j] = (uint32_t)(lrow * (kHidden * 4) + ((pp + rl) % 48) * 16);
+        }
+        auto dma_half = [&](int half) {
+#pragma unroll
+            for (int j = 0; j < 24; ++j) glds_piece(vsrc[j], hsrc + half * 768, stage + j * 1024);
+        };
+        dma_half(0);
+        pstamp();                                                      // p0: first half's DMA issued
+        {   // parameter table (compiler-managed loads: their wait coincides with the wait for the first half)
+            const f32x4* src = reinterpret_cast<const f32x4*>(wsrc + (size_t)NFRAG * 1024);
+            f32x4* dst = reinterpret_cast<f32x4*>(par);
+            for (int i = tid; i < (P_TOTAL + P_TAIL) / 4; i += 256) dst[i] = src[i];
+        }
+        const float* posf = reinterpret_cast<const float*>(wsrc + (size_t)NFRAG * 1024 + (P_TOTAL + P_TAIL) * 4) +
+                            (size_t)tile * kPosTile + lane * 8;
         // h0 + pos for the lane's 192 features, parked in the accumulator half of the register file (x is needed twice: for the
-        // statistics and for the normalisation; 192 arch VGPRs plus the loads in flight do not fit beside anything else)
+        // statistics and for the normalisation)
         float x[kNKS][8];
         float s = 0.f, q = 0.f;
+        const int rot = 48 - r;                                        // (c - r) mod 48 = (c + rot) mod 48, c < 48
+        const char* stg_lane = smem + kInStage + wave * (24 * 1024) + r * 768;
 #pragma unroll
-        for (int kb = 0; kb < kNKS; kb += 6) {
+        for (int half = 0; half < 2; ++half) {
+            f32x4 pz[12][2];
 #pragma unroll
-            for (int ks = kb; ks < kb + 6; ++ks)
+            for (int k2 = 0; k2 < 12; ++k2) {
+                pz[k2][0] = *reinterpret_cast<const f32x4*>(posf + (12 * half + k2) * 512);
+                pz[k2][1] = *reinterpret_cast<const f32x4*>(posf + (12 * half + k2) * 512 + 4);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this half's rows (and the parameter / position loads) landed
+            pstamp();                                                  // p1 / p3: half landed
+#pragma unroll
+            for (int k2 = 0; k2 < 12; ++k2)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * ks + 8 * c);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(pr + 16 * ks + 8 * c);
+                    int pos16 = 4 * k2 + 2 * c + h + rot;
+                    pos16 = pos16 >= 48 ? pos16 - 48 : pos16;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(stg_lane + pos16 * 16);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float v = a[e] + b[e];
+                        const float v = a[e] + pz[k2][c][e];
                         s += v;
                         q += v * v;
-                        x[ks][4 * c + e] = v;
-                        asm volatile("" : "+a"(x[ks][4 * c + e]));
+                        x[12 * half + k2][4 * c + e] = v;
+                        asm volatile("" : "+a"(x[12 * half + k2][4 * c + e]));
                     }
                 }
-            __builtin_amdgcn_sched_barrier(0);                         // at most 24 loads (96 registers) in flight
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the staging reads are done before the next half overwrites them
+            pstamp();                                                  // p2 / p4: half read
+            if (half == 0) dma_half(1);
         }
         const float mean = half_swap_sum(s) * (1.f / kHidden);
         const float rstd = rsqrtf(fmaxf(half_swap_sum(q) * (1.f / kHidden) - mean * mean, 0.f) + 1e-5f);
         const float nmr = -mean * rstd;
-        __syncthreads();                                               // parameter table visible
+        __syncthreads();                                               // parameter table visible; every wave is done with its staging
+        pstamp();                                                      // p5: workgroup met
+        issue_chunk(std::integral_constant<int, 1>{});                 // (chunks 1 and 2 land where the staging was)
+        issue_chunk(std::integral_constant<int, 2>{});
 #pragma unroll
         for (int ks = 0; ks < kNKS; ++ks) {
             const f32x4* g = reinterpret_cast<const f32x4*>(par + P_G1 + ks * 16 + h * 8);
@@ -266,10 +334,9 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
             asm volatile("" : "+a"(X1[ks]));                           // MFMA operand for the rest of the kernel: accumulator half
         }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // chunks 0, 1 (and every prologue load) have landed
-    asm volatile("s_barrier" ::: "memory");
-    issue_chunk(std::integral_constant<int, 2>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("; TW_STREAM_BEGIN" ::: "memory");
+    stamp();                                                           // [1] prologue done
 
     // T-product: acc[feature][row] += W fragment (A) x activation fragment (B); N-product: acc[row][feature] (V)
     auto tprod = [&](auto n0c, f32x16& acc, const bf16x8 (&X)[kNKS]) {
@@ -333,6 +400,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
                 Vf[2 * dt + s] = pack8(v);
             }
         });
+        stamp();                                                       // [2 + 2 hd] this head's q | k | v projection done
         __syncthreads();                                               // every wave is done with the previous head's K / V
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -397,6 +465,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
                 Cf[6 * hd + 2 * dt + s] = pack8(v);
                 asm volatile("" : "+a"(Cf[6 * hd + 2 * dt + s]));
             }
+        stamp();                                                       // [3 + 2 hd] this head's attention done
     });
 
     // ---- dense + residual + LayerNorm -> h2^T (fp32 in `val`, bf16 fragments back into X1) ---------------------------
@@ -425,6 +494,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
             }
         }
     });
+    stamp();                                                           // [10] dense done
     if constexpr (OUTMODE == 2) {
         // h2_l = (v_l rstd_l + nmr_l) gamma + beta is never formed.  With u_l = a_l rstd_l and U = sum_l a_l nmr_l (sum_l a_l = 1):
         //   logit_l = rstd_l (w gamma . v_l) + nmr_l c1 + c2         pooled_f = gamma_f (sum_l u_l v_l[f] + U) + beta_f
@@ -497,6 +567,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
                 }
             }
     }
+    stamp();                                                           // [11] LayerNorm done
     if constexpr (OUTMAP) {
         static_for<0, 12>([&](auto otc) {
             constexpr int ot = decltype(otc)::value;
@@ -512,6 +583,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         });
     }
     asm volatile("; TW_STREAM_END" ::: "memory");
+    stamp();                                                           // [12] out mapping done
     if (!live) return;                                                 // (no barrier below this line)
 
     // ---- output: val[t][e] = y^T[feature 32 t + (e & 3) + 8 (e >> 2) + 4 h][row r] ----------------------------------
@@ -580,11 +652,20 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         if (p.items != nullptr && tile == ntiles - 1)                  // with an item table: zero rows behind the sequence
             for (int i = 32 * ntiles * 96 + lane; i < p.seq_rows * 96; i += 64) *reinterpret_cast<f32x4*>(o + (size_t)i * 4) = z4;
     }
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp();                                                       // [13] rows stored
+        if (tid == 0 && p.stamps != nullptr) {
+            for (int i = 0; i < 16; ++i) p.stamps[(size_t)blockIdx.x * 24 + i] = i < n_ts ? ts[i] : 0ull;
+            for (int i = 0; i < 8; ++i) p.stamps[(size_t)blockIdx.x * 24 + 16 + i] = i < n_tp ? tp[i] : 0ull;
+        }
+    }
 }
 
 // ---- weight / parameter packing -----------------------------------------------------------------------------------
 struct PackArgs {
-    const float *g1, *b1, *wq, *bq, *wk, *bk, *wv, *bv, *wd, *bd, *g2, *b2, *wo, *bo, *mw;
+    const float *g1, *b1, *wq, *bq, *wk, *bk, *wv, *bv, *wd, *bd, *g2, *b2, *wo, *bo, *mw, *pos;
+    int max_pos;
     unsigned short* frags;
     float* par;
     int nfrag;
@@ -631,6 +712,11 @@ __global__ __launch_bounds__(256) void tower_pack_kernel(const PackArgs a) {
         }
         a.par[i] = v;
     }
+    if (i < 4L * kPosTile) {          // position table, 4 tiles of 32 positions in fragment order [tile][ks][lane][8]
+        const int t = (int)(i / kPosTile), rem = (int)(i % kPosTile), ks = rem / 512, lane = (rem >> 3) & 63, j = rem & 7;
+        const int l = 32 * t + (lane & 31), f = 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+        a.par[P_TOTAL + P_TAIL + i] = l < a.max_pos ? a.pos[(size_t)l * kHidden + f] : 0.f;
+    }
     if (i == 0) {                     // query towers: the two constants of the folded modular logit
         float c1 = 0.f, c2 = 0.f;
         if (a.mw)
@@ -648,52 +734,52 @@ extern "C" {
 
 size_t dldkd_tower_blob_bytes(int with_out_map) {
     const size_t nfrag = tw::kQKVFrags + tw::kSqFrags + (with_out_map ? tw::kSqFrags : 0);
-    return nfrag * 1024 + (size_t)(tw::P_TOTAL + tw::P_TAIL) * 4;
+    return nfrag * 1024 + (size_t)(tw::P_TOTAL + tw::P_TAIL + 4 * tw::kPosTile) * 4;
 }
 
 int dldkd_tower_pack_bf16(const float* ln1_g, const float* ln1_b, const float* wq, const float* bq, const float* wk, const float* bk,
                           const float* wv, const float* bv, const float* wd, const float* bd, const float* ln2_g, const float* ln2_b,
-                          const float* wo, const float* bo, const float* mod_w, void* blob, void* stream) {
-    if (!ln1_g || !ln1_b || !wq || !bq || !wk || !bk || !wv || !bv || !wd || !bd || !ln2_g || !ln2_b || !blob || (!wo != !bo) ||
-        (!wo == !mod_w)) {
-        set_error("tower_pack: null pointer (a video tower has wo / bo, a query tower has mod_w)");
+                          const float* wo, const float* bo, const float* mod_w, const float* pos, int max_pos, void* blob, void* stream) {
+    if (!ln1_g || !ln1_b || !wq || !bq || !wk || !bk || !wv || !bv || !wd || !bd || !ln2_g || !ln2_b || !blob || !pos || (!wo != !bo) ||
+        (!wo == !mod_w) || max_pos < 1) {
+        set_error("tower_pack: null pointer (a video tower has wo / bo, a query tower has mod_w) or max_pos < 1");
         return DLDKD_EINVAL;
     }
     if ((uintptr_t)blob & 15) { set_error("tower_pack: blob must be 16-byte aligned"); return DLDKD_EINVAL; }
     const int nfrag = tw::kQKVFrags + tw::kSqFrags + (wo ? tw::kSqFrags : 0);
-    tw::PackArgs a{ln1_g, ln1_b, wq, bq, wk, bk, wv, bv, wd, bd, ln2_g, ln2_b, wo, bo, mod_w, (unsigned short*)blob,
+    tw::PackArgs a{ln1_g, ln1_b, wq, bq, wk, bk, wv, bv, wd, bd, ln2_g, ln2_b, wo, bo, mod_w, pos, max_pos, (unsigned short*)blob,
                    (float*)((char*)blob + (size_t)nfrag * 1024), nfrag};
     DLDKD_LAUNCH(tw::tower_pack_kernel, dim3((unsigned)(((long)nfrag * 512 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("tower_pack");
 }
 
-int dldkd_tower_seq_bf16(const float* const* h0, const float* const* pos, const void* const* blob, const int32_t* row0,
-                         const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches, int max_pos,
+int dldkd_tower_seq_bf16(const float* const* h0, const void* const* blob, const int32_t* row0,
+                         const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                          int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
                          void* stream) {
-    if (n_items < 0 || n_seq < 0 || (n_branches != 1 && n_branches != 2) || max_pos < 1 || out_mode < 0 || out_mode > 2 || seq_rows < 0 ||
+    if (n_items < 0 || n_seq < 0 || (n_branches != 1 && n_branches != 2) || out_mode < 0 || out_mode > 2 || seq_rows < 0 ||
         seq_rows > 128 || (!row0 && seq_rows < 1) || (out_mode == 1 && (Lp < 32 || Lp > 128 || (Lp & 31) || v0 < 0)) ||
         (out_mode == 2 && !items && n_items != (n_seq + 3) / 4)) {
-        set_error("tower_seq: bad arguments (n_items=%d n_seq=%d n_branches=%d max_pos=%d out_mode=%d seq_rows=%d Lp=%d)", n_items, n_seq,
-                  n_branches, max_pos, out_mode, seq_rows, Lp);
+        set_error("tower_seq: bad arguments (n_items=%d n_seq=%d n_branches=%d out_mode=%d seq_rows=%d Lp=%d)", n_items, n_seq,
+                  n_branches, out_mode, seq_rows, Lp);
         return DLDKD_EINVAL;
     }
     if (n_items == 0) return DLDKD_OK;
-    if (!h0 || !pos || !blob || !lens || (out_mode != 1 && !out_rows) || (out_mode == 1 && !gallery)) {
+    if (!h0 || !blob || !lens || (out_mode != 1 && !out_rows) || (out_mode == 1 && !gallery)) {
         set_error("tower_seq: null pointer");
         return DLDKD_EINVAL;
     }
     tw::TowerArgs p{};
     for (int b = 0; b < n_branches; ++b) {
-        p.h0[b] = h0[b]; p.pos[b] = pos[b]; p.blob[b] = (const char*)blob[b];
+        p.h0[b] = h0[b]; p.blob[b] = (const char*)blob[b];
         if (out_mode == 0) p.out[b] = out_rows[b]; else if (out_mode == 2) p.pooled[b] = out_rows[b]; else p.gal[b] = (char*)gallery[b];
-        if (!p.h0[b] || !p.pos[b] || !p.blob[b] || (out_mode == 1 ? !p.gal[b] : !out_rows[b])) { set_error("tower_seq: null branch pointer"); return DLDKD_EINVAL; }
-        if (((uintptr_t)p.h0[b] | (uintptr_t)p.pos[b] | (uintptr_t)p.blob[b] | (uintptr_t)p.out[b] | (uintptr_t)p.gal[b] | (uintptr_t)p.pooled[b]) & 15) {
+        if (!p.h0[b] || !p.blob[b] || (out_mode == 1 ? !p.gal[b] : !out_rows[b])) { set_error("tower_seq: null branch pointer"); return DLDKD_EINVAL; }
+        if (((uintptr_t)p.h0[b] | (uintptr_t)p.blob[b] | (uintptr_t)p.out[b] | (uintptr_t)p.gal[b] | (uintptr_t)p.pooled[b]) & 15) {
             set_error("tower_seq: buffers must be 16-byte aligned");
             return DLDKD_EINVAL;
         }
     }
-    p.row0 = row0; p.lens = lens; p.items = items; p.n_items = n_items; p.n_seq = n_seq; p.n_branches = n_branches; p.max_pos = max_pos;
+    p.row0 = row0; p.lens = lens; p.items = items; p.n_items = n_items; p.n_seq = n_seq; p.n_branches = n_branches;
     p.seq_rows = seq_rows; p.v0 = v0; p.Lp = Lp; p.lens_out = lens_out;
     const dim3 grid(n_branches == 2 ? 8u * (unsigned)((n_items + 3) / 4) : (unsigned)n_items);
     static const bool lds_ok = [] {           // once per process: the attribute call is a driver round trip
@@ -710,6 +796,27 @@ int dldkd_tower_seq_bf16(const float* const* h0, const float* const* pos, const 
     else if (out_mode == 0) DLDKD_LAUNCH((tw::tower_seq_kernel<true, 0>), grid, dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
     else DLDKD_LAUNCH((tw::tower_seq_kernel<false, 2>), grid, dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
     return check_launch("tower_seq");
+}
+
+/* Diagnostics: the gallery-mode kernel with s_memtime stamps at its phase boundaries; stamps = 16 x u64 per workgroup
+ * (tools/tower_timeline.py): [0] start, [1] prologue, [2 + 2h] head h projected, [3 + 2h] head h attended, [10] dense,
+ * [11] LayerNorm, [12] out mapping, [13] rows stored. */
+int dldkd_debug_tower_seq_timeline(const float* const* h0, const void* const* blob, const int32_t* lens,
+                                   const int32_t* items, int n_items, int n_seq, int seq_rows, void* const* gallery, int Lp,
+                                   unsigned long long* stamps, void* stream) {
+    if (!h0 || !blob || !lens || !gallery || !stamps || n_items < 1 || seq_rows < 1 || Lp < 32 || (Lp & 31)) {
+        set_error("tower_seq_timeline: bad arguments");
+        return DLDKD_EINVAL;
+    }
+    tw::TowerArgs p{};
+    for (int b = 0; b < 2; ++b) { p.h0[b] = h0[b]; p.blob[b] = (const char*)blob[b]; p.gal[b] = (char*)gallery[b]; }
+    p.lens = lens; p.items = items; p.n_items = n_items; p.n_seq = n_seq; p.n_branches = 2;
+    p.seq_rows = seq_rows; p.v0 = 0; p.Lp = Lp; p.stamps = stamps;
+    static const bool ok = hipFuncSetAttribute((const void*)tw::tower_seq_kernel<true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               tw::kLdsTotal) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); set_error("tower_seq_timeline: cannot reserve LDS"); return DLDKD_ELAUNCH; }
+    DLDKD_LAUNCH((tw::tower_seq_kernel<true, 1, true>), dim3(8u * (unsigned)((n_items + 3) / 4)), dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
+    return check_launch("tower_seq_timeline");
 }
 
 }  // extern "C"

@@ -120,9 +120,11 @@ SIGNATURES = {
                          _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
     "dldkd_order_by_len_desc": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_tower_blob_bytes": (_c_size_t, [_c_int]),
-    "dldkd_tower_pack_bf16": (_c_int, [_c_void_p] * 17),
-    "dldkd_tower_seq_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+    "dldkd_tower_pack_bf16": (_c_int, [_c_void_p] * 16 + [_c_int, _c_void_p, _c_void_p]),
+    "dldkd_tower_seq_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                       _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "dldkd_debug_tower_seq_timeline": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                                                _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "dldkd_gemm_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                          _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
 }

@@ -442,8 +442,8 @@ class TowerPack:
         ps = [self.pos_embed.LayerNorm.weight, self.pos_embed.LayerNorm.bias, a.query.weight, a.query.bias, a.key.weight, a.key.bias,
               a.value.weight, a.value.bias, o.dense.weight, o.dense.bias, o.LayerNorm.weight, o.LayerNorm.bias]
         if self.out_linear is not None:
-            return ps + [self.out_linear.weight, self.out_linear.bias, None]
-        return ps + [None, None, self.mod_linear.weight]
+            return ps + [self.out_linear.weight, self.out_linear.bias, None, self.pos_embed.position_embeddings.weight]
+        return ps + [None, None, self.mod_linear.weight, self.pos_embed.position_embeddings.weight]
 
     def get(self):
         ps = self._params()
@@ -452,13 +452,9 @@ class TowerPack:
             L = native.lib()
             self.blob = torch.empty(L.dldkd_tower_blob_bytes(int(self.out_linear is not None)), dtype=torch.uint8, device=ps[0].device)
             args = [None if t is None else native.ptr(_chk(t.detach().contiguous(), "tower_pack")) for t in ps]
-            native.check(L.dldkd_tower_pack_bf16(*args, native.ptr(self.blob), native.stream()), "tower_pack")
+            native.check(L.dldkd_tower_pack_bf16(*args, int(ps[-1].shape[0]), native.ptr(self.blob), native.stream()), "tower_pack")
             self.key = key
         return self
-
-    @property
-    def pos(self):
-        return self.pos_embed.position_embeddings.weight
 
 
 def tower_seq_ok(h0):
@@ -468,13 +464,13 @@ def tower_seq_ok(h0):
 
 
 def plan_tower_items(lens):
-    """Host-side packing of 32-row tiles into workgroups of four slots: int32 (n_items, 4) of (seq << 2) | tile, -1 = idle.
-    A sequence's tiles sit in consecutive slots of one workgroup; sequences of length 0 get no slot."""
+    """Host-side packing of 32-row tiles into workgroups of four slots: int32 (n_items, 4) of (seq << 10) | (tile << 8) | length,
+    -1 = idle.  A sequence's tiles sit in consecutive slots of one workgroup; sequences of length 0 get no slot."""
     import numpy as np
     lens = np.asarray(lens, dtype=np.int64)
     nt = (lens + 31) // 32
-    if (nt > 4).any():
-        raise native.NativeError("plan_tower_items: at most 128 rows per sequence")
+    if (nt > 4).any() or len(lens) >= (1 << 21):
+        raise native.NativeError("plan_tower_items: at most 128 rows per sequence and 2^21 sequences")
     by = {k: np.nonzero(nt == k)[0] for k in (1, 2, 3, 4)}
     n1, n2, n3 = len(by[1]), len(by[2]), len(by[3])
     rows = []
@@ -485,7 +481,7 @@ def plan_tower_items(lens):
         c = 0
         for seqs, k in seqs_tiles:
             for t in range(k):
-                out[:, c] = (seqs << 2) | t
+                out[:, c] = (seqs << 10) | (t << 8) | lens[seqs]
                 c += 1
         return out
     if len(by[4]):
@@ -503,15 +499,15 @@ def plan_tower_items(lens):
     if n2 % 2:                                          # 2 + 1 + 1
         it = np.full((1, 4), -1, np.int64)
         s = by[2][-1]
-        it[0, 0], it[0, 1] = (s << 2), (s << 2) | 1
+        it[0, 0], it[0, 1] = (s << 10) | lens[s], (s << 10) | (1 << 8) | lens[s]
         for c in (2, 3):
             if len(ones):
-                it[0, c] = ones[0] << 2
+                it[0, c] = (ones[0] << 10) | lens[ones[0]]
                 ones = ones[1:]
         rows.append(it)
     if len(ones):                                       # 1 + 1 + 1 + 1
         pad = (-len(ones)) % 4
-        o = np.concatenate([ones << 2, np.full(pad, -1, np.int64)]).reshape(-1, 4)
+        o = np.concatenate([(ones << 10) | lens[ones], np.full(pad, -1, np.int64)]).reshape(-1, 4)
         rows.append(o)
     if not rows:
         return np.zeros((0, 4), np.int32)
@@ -529,7 +525,6 @@ def tower_seq(h0, packs, lens, seq_rows=0, row0=None, items=None, out_mode=0, ga
     if any((f.out_linear is None) != (out_mode == 2) for f in fs):
         raise native.NativeError("tower_seq: out_mode 2 takes query-tower packs, out_mode 0 / 1 video-tower packs")
     hs = [_chk(x.reshape(-1, HIDDEN), "tower_seq.h0") for x in h0]
-    poss = [_chk(f.pos.detach(), "tower_seq.pos") for f in fs]
     if lens.dtype != torch.int32 or not lens.is_cuda:
         raise native.NativeError("tower_seq: lens must be an int32 GPU tensor")
     n_seq = lens.shape[0]
@@ -539,8 +534,8 @@ def tower_seq(h0, packs, lens, seq_rows=0, row0=None, items=None, out_mode=0, ga
         outs = [torch.empty_like(x) for x in hs]
     elif out_mode == 2:
         outs = [torch.empty(n_seq, HIDDEN, dtype=torch.float32, device=lens.device) for _ in hs]
-    native.check(L.dldkd_tower_seq_bf16(native.ptr_array(hs), native.ptr_array(poss), native.ptr_array([f.blob for f in fs]),
-                                        native.ptr(row0), native.ptr(lens), native.ptr(items), n_items, n_seq, nb, poss[0].shape[0],
+    native.check(L.dldkd_tower_seq_bf16(native.ptr_array(hs), native.ptr_array([f.blob for f in fs]),
+                                        native.ptr(row0), native.ptr(lens), native.ptr(items), n_items, n_seq, nb,
                                         out_mode, native.ptr_array(outs) if outs is not None else None, int(seq_rows),
                                         native.ptr_array(gallery) if gallery is not None else None, int(v0), int(Lp),
                                         native.ptr(lens_out), native.stream()), "tower_seq")

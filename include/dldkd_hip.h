@@ -463,11 +463,12 @@ int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv,
  * order (k permuted to the accumulator layout, q pre-scaled by log2(e) / sqrt(96)) followed by its bias / gamma / beta vectors;
  * all weight matrices (384, 384) row-major, vectors (384).  A video tower passes wo / bo (out_mapping_linear) and mod_w = NULL;
  * a query tower passes wo = bo = NULL and mod_w = modular_vector_mapping.weight (384).
- * dldkd_tower_seq_bf16: h0 / pos / blob / out_rows / gallery are HOST arrays of n_branches device pointers.
+ *   pos (max_pos, 384) = position_embeddings.weight goes into the blob too, re-arranged per 32-position tile (positions past
+ *   max_pos read as zeros).
+ * dldkd_tower_seq_bf16: h0 / blob / out_rows / gallery are HOST arrays of n_branches device pointers.
  *   h0[b] (rows, 384) fp32: the input projection's output; sequence s owns rows row0[s] .. row0[s] + lens[s] - 1
  *     (row0 == NULL: s * seq_rows); at most 128 rows per sequence.
- *   pos[b] (max_pos, 384) fp32: position_embeddings.weight.
- *   items (n_items, 4) int32 or NULL: the four 32-row slots of workgroup i: (s << 2) | tile, -1 = idle; the tiles of one
+ *   items (n_items, 4) int32 or NULL: the four 32-row slots of workgroup i: (s << 10) | (tile << 8) | lens[s], -1 = idle; the tiles of one
  *     sequence occupy consecutive slots of ONE workgroup in order (short sequences share a workgroup); every scheduled sequence
  *     has lens > 0.  NULL: workgroup i is sequence i (n_items = n_seq; out_mode 2: sequences 4 i .. 4 i + 3, n_items = ceil(n_seq / 4)).
  *   out_mode 0 (video-tower blobs): out_rows[b] (rows, 384) fp32 indexed like h0.  Rows lens[s] .. seq_rows - 1 of a sequence:
@@ -481,11 +482,18 @@ int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv,
 size_t dldkd_tower_blob_bytes(int with_out_map);
 int dldkd_tower_pack_bf16(const float* ln1_g, const float* ln1_b, const float* wq, const float* bq, const float* wk, const float* bk,
                           const float* wv, const float* bv, const float* wd, const float* bd, const float* ln2_g, const float* ln2_b,
-                          const float* wo, const float* bo, const float* mod_w, void* blob, void* stream);
-int dldkd_tower_seq_bf16(const float* const* h0, const float* const* pos, const void* const* blob, const int32_t* row0,
-                         const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches, int max_pos,
+                          const float* wo, const float* bo, const float* mod_w, const float* pos, int max_pos, void* blob, void* stream);
+int dldkd_tower_seq_bf16(const float* const* h0, const void* const* blob, const int32_t* row0,
+                         const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                          int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
                          void* stream);
+
+/* Diagnostics: the out_mode 1 kernel (two branches) with clock stamps at its phase boundaries; stamps = 24 x uint64 per workgroup
+ * (8 * ceil(n_items / 4) workgroups): [0] start, [1] prologue, [2 + 2 h] head h projected, [3 + 2 h] head h attended, [10] dense,
+ * [11] LayerNorm, [12] out mapping, [13] rows stored, [16..21] inside the prologue (tools/tower_timeline.py). */
+int dldkd_debug_tower_seq_timeline(const float* const* h0, const void* const* blob, const int32_t* lens,
+                                   const int32_t* items, int n_items, int n_seq, int seq_rows, void* const* gallery, int Lp,
+                                   unsigned long long* stamps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Feature ingest: temporal down-sampling + L2 normalisation + padding of raw frame features on the GPU.

@@ -36,7 +36,7 @@ def kernels(lines):
             continue
         if name is not None:
             body.append(ln)
-            if ln.strip().startswith("s_endpgm"):
+            if ln.startswith(".Lfunc_end"):            # (not the first s_endpgm: a kernel may have early exits)
                 yield name, body
                 name = None
 
@@ -111,6 +111,8 @@ def main(path):
     for name, body in kernels(lines):
         found += 1
         e, n_reads, n_dma = check_kernel(name, body)
+        if n_reads == 0 or n_dma == 0:
+            e.append(f"{name}: no ring reads / LDS-DMAs found between the stream markers (the audit would be vacuous)")
         errs += e
         print(f"{name}: {n_reads} ring reads, {n_dma} LDS-DMAs in the stream, {len(e)} violations")
     text = "\n".join(lines)
