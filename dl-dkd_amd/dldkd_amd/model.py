@@ -140,20 +140,29 @@ class DLDKD(nn.Module):
                                                    mod_linear=getattr(self, pre + "modular_vector_mapping")) for pre in pres]
         return self._folded[key]
 
-    def _upload_items(self, items_np, device):
-        """Slot table of the fused tower kernel -> device through a ring of pinned slots (staging.PinnedRing): a pageable copy
-        parks the host until the stream drains, and a fresh pin_memory() per call is a multi-millisecond driver allocation
-        whenever the host runs ahead of the GPU."""
+    def _upload_tables(self, tables_np, device):
+        """Host-planned int32 tables of the fused gallery encode (slot table of the tower kernel, row-group table of the input
+        projection) -> device in ONE upload through a ring of pinned slots (staging.PinnedRing): a pageable copy parks the host
+        until the stream drains, a fresh pin_memory() per call is a multi-millisecond driver allocation whenever the host runs
+        ahead of the GPU, and the copy engine costs two cross-engine hand-offs per upload (the slot is read by a kernel)."""
         from .staging import PinnedRing
-        nbytes = items_np.nbytes
+        sizes = [t.nbytes for t in tables_np]
+        nbytes = sum(sizes)
         ring = getattr(self, "_item_ring", None)
         if ring is None or ring.bufs[0].numel() < nbytes:
             ring = self._item_ring = PinnedRing(max(nbytes, 64 * 1024), device, slots=8)
         slot = ring.next()
-        slot[:nbytes].view(torch.int32).view(-1, 4).copy_(torch.from_numpy(items_np))
+        off = 0
+        for t, nb in zip(tables_np, sizes):
+            slot[off:off + nb].view(torch.int32).copy_(torch.from_numpy(t.reshape(-1)))
+            off += nb
         dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        ring.upload(dev)
-        return dev.view(torch.int32).view(-1, 4)
+        ring.upload(dev, by_kernel=True)
+        out, off = [], 0
+        for nb in sizes:
+            out.append(dev[off:off + nb].view(torch.int32))
+            off += nb
+        return out
 
     def encode_context_into(self, packer, frame_video_feat, video_mask, lens_host=None):
         """Throughput-mode gallery encode straight into the scorer's resident bf16 gallery (scoring.GalleryPacker): input
@@ -165,11 +174,14 @@ class DLDKD(nn.Module):
         items = groups = None
         n, L = frame_video_feat.shape[0], frame_video_feat.shape[1]
         if lens_host is not None:
-            items = self._upload_items(ops.plan_tower_items(lens_host), frame_video_feat.device)
+            tables = [ops.plan_tower_items(lens_host)]
             if (L % 32 == 0 and self.double_branch and ops.INPROJ_KERNEL == "rows128"
                     and native.lib().dldkd_in_proj_bf16_rows128_ok(frame_video_feat.shape[-1])):
                 # the input projection visits only the 32-row groups that hold valid clips (the tower never reads the others)
-                groups = self._upload_items(ops.plan_row_groups(lens_host, L).reshape(-1, 4), frame_video_feat.device).reshape(-1)
+                tables.append(ops.plan_row_groups(lens_host, L))
+            tables = self._upload_tables(tables, frame_video_feat.device)
+            items = tables[0].view(-1, 4)
+            groups = tables[1] if len(tables) > 1 else None
         h0 = self._fast_proj("visual", frame_video_feat, groups=groups)
         if not ops.tower_seq_ok(h0[0]):
             return False

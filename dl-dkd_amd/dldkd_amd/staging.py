@@ -24,10 +24,16 @@ class PinnedRing:
             ev.synchronize()
         return self.bufs[self.i]
 
-    def upload(self, dev_bytes):
+    def upload(self, dev_bytes, by_kernel=False):
         """Enqueue the asynchronous copy of the current slot into `dev_bytes` (uint8 device tensor of the same size) on the
-        current stream and remember when it is done."""
-        dev_bytes.copy_(self.bufs[self.i][:dev_bytes.numel()], non_blocking=True)
+        current stream and remember when it is done.  by_kernel: a few KB (size a multiple of 4) read from the pinned slot by a
+        kernel on the compute queue instead of the copy engine (native dldkd_upload_words says why)."""
+        if by_kernel and self.cuda:
+            from . import native
+            native.check(native.lib().dldkd_upload_words(self.bufs[self.i].data_ptr(), native.ptr(dev_bytes), dev_bytes.numel() // 4,
+                                                         native.stream()), "upload_words")
+        else:
+            dev_bytes.copy_(self.bufs[self.i][:dev_bytes.numel()], non_blocking=True)
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record()

@@ -504,6 +504,12 @@ int dldkd_debug_tower_seq_timeline(const float* const* h0, const void* const* bl
 int dldkd_segment_mean_l2norm_f32(const float* frames, const int32_t* seg_start, const int32_t* seg_end, float* out,
                                   long n_rows, int D, float eps, void* stream);
 
+/* Upload of a small host-produced int32 table (the slot and row-group tables of dldkd_tower_seq_bf16 /
+ * dldkd_in_proj_bf16_rows128_groups; nothing in the reference) by a kernel: pinned_src is page-locked, device-mapped host
+ * memory (hipHostMalloc / torch pin_memory), read over the bus on the compute queue - no copy-engine hand-off.  The caller keeps
+ * pinned_src unchanged until the launch has executed (an event, as for hipMemcpyAsync). */
+int dldkd_upload_words(const int32_t* pinned_src, int32_t* dst, long n_words, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -273,3 +273,27 @@ def test_encode_query_fused_vs_unfused_throughput_mode():
         assert f.shape == p_.shape == (7, 384)
         sc = p_.abs().max().item()
         assert (f - c).abs().max().item() < 3e-2 * sc and (f - p_).abs().max().item() < 3e-2 * sc
+
+
+@pytest.mark.gpu
+def test_table_upload_by_kernel_is_bit_exact_and_slot_safe():
+    """The slot / row-group tables reach the device through dldkd_upload_words (a kernel reading the pinned slot): bit exact,
+    and a slot is not rewritten before its upload has executed (more uploads in flight than the ring has slots)."""
+    from dldkd_amd.staging import PinnedRing
+    ring = PinnedRing(64 * 1024, "cuda:0", slots=3)
+    rng = np.random.RandomState(5)
+    blocker = torch.randn(4096, 4096, device="cuda:0")
+    want, got = [], []
+    for i in range(10):
+        if i == 2:
+            for _ in range(20):
+                blocker @ blocker                      # the stream is busy while the host runs ahead
+        t = rng.randint(-2 ** 31, 2 ** 31 - 1, size=rng.randint(1, 16000), dtype=np.int64).astype(np.int32)
+        slot = ring.next()
+        slot[:t.nbytes].view(torch.int32).copy_(torch.from_numpy(t))
+        dev = torch.empty(t.nbytes, dtype=torch.uint8, device="cuda:0")
+        ring.upload(dev, by_kernel=True)
+        want.append(t), got.append(dev)
+    torch.cuda.synchronize()
+    for t, d in zip(want, got):
+        assert np.array_equal(d.view(torch.int32).cpu().numpy(), t)

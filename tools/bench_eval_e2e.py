@@ -52,10 +52,19 @@ def stage_times(nv=21793, nq=10895, mode="fp32", dev="cuda:0", B=None):
             t0 = sync()
             evs[0].record()
             done = 0
+            prof = None
+            if os.environ.get("E2E_HOSTPROF"):                   # where does the host spend the enqueue loop?  (stderr)
+                import cProfile
+                prof = cProfile.Profile()
+                prof.enable()
             while done < nv:
                 n = min(B, nv - done)
                 encode(pk, n)
                 done += n
+            if prof is not None:
+                prof.disable()
+                import pstats
+                pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(14)
             evs[1].record()
             th = time.perf_counter()
             pg = pk.finish()
