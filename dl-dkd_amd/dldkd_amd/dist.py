@@ -123,6 +123,58 @@ def sync_gradients(fp, group=None, comm_stream=None):
     # decay: optimization.py:294-295), exactly as on one GPU.
 
 
+class BucketedGradSync:
+    """The same mean all-reduce, one collective per gradient bucket, each issued as soon as the backward pass has produced the
+    bucket's last gradient (train.backward_in_phases calls bucket_ready) - the collective of a tower's gradients then runs
+    while the next tower's backward kernels do (DDP's bucketed overlap, method/train.py:147-151 under DistributedDataParallel).
+    The buckets are the contiguous ranges FlatParams laid out (optimization.FlatParams.bucket_ranges); a sum over ranks is
+    element-wise, so the result is bit-identical to the single-bucket all-reduce.
+
+    GPU: collectives go to `comm_stream`, ordered after the gradient copies by an event and joined back in finish(); they never
+    run on a stream that captures (sync_gradients says why).  CPU / gloo: asynchronous work handles, waited in finish()."""
+
+    def __init__(self, fp, group=None, comm_stream=None):
+        self.fp, self.group, self.comm_stream = fp, group, comm_stream
+        self.world = dist.get_world_size(group)
+        self.pending, self.issued = [], set()
+
+    def _reduce(self, lo, hi):
+        if hi <= lo:
+            return
+        part = self.fp.grad[lo:hi]
+        if self.comm_stream is not None:
+            cur = torch.cuda.current_stream(part.device)
+            self.comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+                part.div_(self.world)
+        else:
+            self.pending.append((dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True), part))
+
+    def bucket_ready(self, b):
+        """Every gradient of bucket b is final: gather them into the flat range (eager) and start its all-reduce."""
+        self.fp.rebind_bucket(b)
+        self.issue(b)
+
+    def issue(self, b):
+        """Start the all-reduce of bucket b's range (the gradients are already in the flat buffer: replayed graph segment)."""
+        if b not in self.issued:
+            self.issued.add(b)
+            self._reduce(*self.fp.bucket_ranges[b])
+
+    def finish(self):
+        """Whatever has not been issued goes now; then the current stream waits for every collective."""
+        self.fp.rebind_grads()
+        for b in range(len(self.fp.bucket_ranges)):
+            self.issue(b)
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(self.fp.grad.device).wait_stream(self.comm_stream)
+        for work, part in self.pending:
+            work.wait()
+            part.div_(self.world)
+        self.pending, self.issued = [], set()
+
+
 def broadcast_parameters(fp, src=0, group=None):
     """All replicas start from rank `src`'s parameters: one broadcast of the flat parameter buffer."""
     dist.broadcast(fp.flat, src=src, group=group)

@@ -344,10 +344,36 @@ class DLDKD(nn.Module):
         out.update(parts)
         return loss, out
 
-    def forward_tensors(self, batch, staged=None):
+    # ------------------------------------------------------------------ data-parallel gradient buckets
+    TOWERS = (("g_inh", ("visual_", "out_mapping_linear.")), ("g_exp", ("exp_visual_", "exp_out_mapping_linear.")),
+              ("q_inh", ("query_", "modular_vector_mapping.")), ("q_exp", ("exp_query_", "exp_modular_vector_mapping.")))
+
+    def grad_buckets(self):
+        """One gradient bucket per tower, in the order train.backward_in_phases runs the towers' backward passes: the two video
+        towers first (8 MB of gradients each at TVR sizes - their all-reduce hides under the towers that follow), the query
+        towers (3.6 MB each) last, so the one collective nothing can hide is the smallest.  Every parameter of the model sits
+        in exactly one tower: the losses behind the tower outputs have none."""
+        named = list(self.named_parameters())
+        out = [[p for n, p in named if n.startswith(prefixes)] for _, prefixes in self.TOWERS]
+        return [b for b in out if b]
+
+    def forward_phased(self, batch, staged=None):
+        """forward_tensors plus the phases of its backward pass: [(tower output, that tower's parameters)] in grad_buckets()
+        order.  The loss depends on a tower's parameters only through its output, so d loss / d outputs first and then one
+        tower at a time yields the same gradients as loss.backward() (train.backward_in_phases)."""
+        taps = {}
+        loss, parts = self.forward_tensors(batch, staged=staged, taps=taps)
+        buckets = self.grad_buckets()
+        names = [n for n, _ in self.TOWERS if n in taps]
+        if len(names) != len(buckets):
+            raise RuntimeError("forward_phased: tower outputs and gradient buckets do not match")
+        return loss, parts, [(taps[n], b) for n, b in zip(names, buckets)]
+
+    def forward_tensors(self, batch, staged=None, taps=None):
         """The training forward without its one host synchronisation: returns (loss, {inher_trip, ..., kl_intra}) as
         tensors.  `staged` (train.GraphedTrainStep): an object with .labels_dev (int32) and .draws = [(r_t2v, r_v2t), ...]
-        on the device; nothing in here then touches host memory, so the whole step can be captured into a hipGraph."""
+        on the device; nothing in here then touches host memory, so the whole step can be captured into a hipGraph.
+        taps (dict, optional): receives the four tower outputs (forward_phased)."""
         labels = batch["text_labels"]
         mask = batch["student_videos_mask"].float()
         dev = mask.device
@@ -357,6 +383,8 @@ class DLDKD(nn.Module):
 
         g_inh, g_exp = self.encode_context(batch["student_videos"], mask)
         q_inh, q_exp = self.encode_query(batch["student_text"], batch["student_text_mask"])
+        if taps is not None:
+            taps.update({k: v for k, v in (("g_inh", g_inh), ("g_exp", g_exp), ("q_inh", q_inh), ("q_exp", q_exp)) if v is not None})
         t_text = batch["teacher_text"].float().reshape(len(labels), -1)          # .squeeze() of model.py:114
         t_vid = batch["teacher_videos"].float()
 

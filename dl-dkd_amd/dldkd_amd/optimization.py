@@ -34,16 +34,42 @@ SCHEDULES = {None: None, "none": None, "warmup_linear": warmup_linear, "warmup_c
 
 
 class FlatParams:
-    """Owns flat (param, grad) buffers and re-points every parameter's storage into them."""
+    """Owns flat (param, grad) buffers and re-points every parameter's storage into them.
 
-    def __init__(self, params):
+    grad_buckets (data parallel): a list of parameter lists, in the order in which the backward pass completes them (train.
+    backward_in_phases).  Every bucket then occupies ONE contiguous range of the flat buffers (bucket_ranges, element offsets),
+    so it is all-reduced by one collective as soon as its last gradient exists; parameters in no bucket form a last range.
+    Only the offsets change: every per-tensor array (t_start, t_numel, learning rates, weight decay) keeps the order of
+    `params`."""
+
+    def __init__(self, params, grad_buckets=None):
         self.params = [p for p in params]
         dev = self.params[0].device
-        starts, numels, off = [], [], 0
-        for p in self.params:
-            starts.append(off)
-            numels.append(p.numel())
-            off += (p.numel() + CHUNK - 1) // CHUNK * CHUNK
+        index = {id(p): i for i, p in enumerate(self.params)}
+        bucket_of = [None] * len(self.params)
+        n_b = 0
+        for b, plist in enumerate(grad_buckets or []):
+            for q in plist:
+                i = index.get(id(q))
+                if i is None:
+                    raise ValueError("FlatParams: a grad bucket holds a parameter the optimizer does not own")
+                if bucket_of[i] is not None:
+                    raise ValueError("FlatParams: a parameter sits in two grad buckets")
+                bucket_of[i] = b
+            n_b = b + 1
+        rest = [i for i, b in enumerate(bucket_of) if b is None]
+        for i in rest:
+            bucket_of[i] = n_b
+        self.bucket_params = [[i for i, bb in enumerate(bucket_of) if bb == b] for b in range(n_b + (1 if rest else 0))]
+        starts, numels, off = [0] * len(self.params), [p.numel() for p in self.params], 0
+        layout, self.bucket_ranges = [], []
+        for members in self.bucket_params:
+            lo = off
+            for i in members:
+                starts[i] = off
+                layout.append(i)
+                off += (numels[i] + CHUNK - 1) // CHUNK * CHUNK
+            self.bucket_ranges.append((lo, off))
         self.total = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -52,14 +78,15 @@ class FlatParams:
             p.data = self.flat[s:s + n].view(p.shape)
             p.grad = self.grad[s:s + n].view(p.shape)
         chunk_tensor = []
-        for t, (s, n) in enumerate(zip(starts, numels)):
-            chunk_tensor += [t] * ((n + CHUNK - 1) // CHUNK)
+        for t in layout:                                  # chunks follow the flat offsets, whatever the tensor order
+            chunk_tensor += [t] * ((numels[t] + CHUNK - 1) // CHUNK)
         self.n_chunks = len(chunk_tensor)
         self.chunk_tensor = torch.tensor(chunk_tensor, dtype=torch.int32, device=dev)
         self.t_start = torch.tensor(starts, dtype=torch.int32, device=dev)
         self.t_numel = torch.tensor(numels, dtype=torch.int32, device=dev)
         self._starts, self._numels, self._views = starts, numels, None     # host copies: no .tolist() sync per step
         self._bound, self._had = False, tuple(True for _ in self.params)
+        self._had_partial = {}
 
     def views(self):
         if self._views is None:
@@ -73,17 +100,14 @@ class FlatParams:
         for p in self.params:
             p.grad = None
         self._bound = False
+        self._had_partial = {}
 
-    def rebind_grads(self):
-        """Gather whatever autograd (or a caller) left in p.grad into the flat buffer with one multi-tensor copy, zero the
-        views of parameters without a gradient, and re-point p.grad at the views.  Returns the tuple of per-parameter
-        "had a gradient" flags (the reference's BertAdam skips parameters whose grad is None, optimization.py:294-295)."""
+    def _gather(self, members):
         views = self.views()
-        dst, src = [], []
-        had = tuple(p.grad is not None for p in self.params)
-        if self._bound and all(p.grad is v for p, v in zip(self.params, views)):
-            return self._had               # second call in one step (all-reduce, then optimizer): nothing new to gather
-        for p, view in zip(self.params, views):
+        dst, src, had = [], [], []
+        for i in members:
+            p, view = self.params[i], views[i]
+            had.append(p.grad is not None)
             if p.grad is None:
                 view.zero_()
             elif p.grad.data_ptr() != view.data_ptr():
@@ -93,8 +117,38 @@ class FlatParams:
             p.grad = view
         if dst:
             torch._foreach_copy_(dst, src)
-        self._bound, self._had = True, had
         return had
+
+    def bind_views(self, had):
+        """Point every p.grad at its flat view without copying (a replayed graph segment wrote the flat ranges itself)."""
+        for p, v in zip(self.params, self.views()):
+            p.grad = v
+        self._bound, self._had, self._had_partial = True, tuple(had), {}
+
+    def rebind_bucket(self, b):
+        """rebind_grads for the parameters of bucket b alone (their gradients are final: train.backward_in_phases)."""
+        if b not in self._had_partial:
+            self._had_partial[b] = self._gather(self.bucket_params[b])
+
+    def rebind_grads(self):
+        """Gather whatever autograd (or a caller) left in p.grad into the flat buffer with one multi-tensor copy, zero the
+        views of parameters without a gradient, and re-point p.grad at the views.  Returns the tuple of per-parameter
+        "had a gradient" flags (the reference's BertAdam skips parameters whose grad is None, optimization.py:294-295)."""
+        views = self.views()
+        if self._bound and all(p.grad is v for p, v in zip(self.params, views)):
+            return self._had               # second call in one step (all-reduce, then optimizer): nothing new to gather
+        had = [None] * len(self.params)
+        todo = []
+        for b, members in enumerate(self.bucket_params):
+            if b in self._had_partial:     # gathered when the bucket completed
+                for i, h in zip(members, self._had_partial[b]):
+                    had[i] = h
+            else:
+                todo += members
+        for i, h in zip(todo, self._gather(todo)):
+            had[i] = h
+        self._bound, self._had = True, tuple(had)
+        return self._had
 
 
 class BertAdam(torch.optim.Optimizer):
@@ -102,7 +156,7 @@ class BertAdam(torch.optim.Optimizer):
     weight_decay (train.py:203-213)."""
 
     def __init__(self, params, lr, warmup=-1, t_total=-1, schedule="warmup_linear", b1=0.9, b2=0.999, e=1e-6,
-                 weight_decay=0.01, max_grad_norm=1.0, **kwargs):
+                 weight_decay=0.01, max_grad_norm=1.0, grad_buckets=None, **kwargs):
         if lr < 0.0:
             raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
         if schedule not in SCHEDULES:
@@ -118,7 +172,7 @@ class BertAdam(torch.optim.Optimizer):
                 plist.append(p)
                 wd.append(grp["weight_decay"])
                 lrs.append(grp["lr"])
-        self.fp = FlatParams(plist)
+        self.fp = FlatParams(plist, grad_buckets)         # grad_buckets: see FlatParams (data-parallel overlap)
         dev = self.fp.flat.device
         self.m = torch.zeros_like(self.fp.flat)
         self.v = torch.zeros_like(self.fp.flat)

@@ -69,8 +69,10 @@ def make_optimizer(model, opt, steps_per_epoch):
     named = list(model.named_parameters())
     groups = [{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
               {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+    # data parallel: one contiguous gradient range per tower, all-reduced while the next tower's backward runs
+    buckets = model.grad_buckets() if dist_info()[1] >= DDP_MIN_WORLD and hasattr(model, "grad_buckets") else None
     return BertAdam(groups, lr=opt.lr, weight_decay=opt.wd, warmup=opt.lr_warmup_proportion,
-                    t_total=steps_per_epoch * opt.n_epoch, schedule="warmup_linear")
+                    t_total=steps_per_epoch * opt.n_epoch, schedule="warmup_linear", grad_buckets=buckets)
 
 
 DDP_MIN_WORLD = 2      # tests set 1 to drive the all-reduce branch with a one-rank group
@@ -84,17 +86,65 @@ def dist_info():
     return 0, 1
 
 
+def backward_in_phases(loss, phases, after_phase=None, between=None):
+    """loss.backward() cut at the tower outputs.  phases = [(tap, params)]: the loss reaches `params` only through the tensor
+    `tap` (tap None: parameters the loss reaches without crossing any tap - their gradients come with the first pass).  First
+    d loss / d taps, then one phase at a time d tap / d params with the tap's gradient fed in; after_phase(i) runs when phase
+    i's gradients are final (the caller starts that bucket's all-reduce), between(i) before the next phase starts (the graph
+    stepper closes one captured segment and opens the next there).  Per parameter these are the same kernels in the same order
+    as the one-call backward, so the gradients are the same numbers.  Every parameter must sit in exactly one phase."""
+    taps = [t for t, _ in phases if t is not None]
+    head = [p for t, ps in phases if t is None for p in ps]
+    grads = list(torch.autograd.grad(loss, taps + head, allow_unused=True))
+    tap_grads, head_grads = grads[:len(taps)], grads[len(taps):]
+    for p, g in zip(head, head_grads):
+        if g is not None:
+            p.grad = g if p.grad is None else p.grad + g
+    k = 0
+    for i, (tap, params) in enumerate(phases):
+        if tap is not None:
+            g, k = tap_grads[k], k + 1
+            if g is not None:
+                torch.autograd.backward([tap], [g], inputs=list(params))
+        if after_phase is not None:
+            after_phase(i)
+        if between is not None and i + 1 < len(phases):
+            between(i)
+
+
+def _check_phase_buckets(fp, phases):
+    """Phase i of the backward pass must complete exactly bucket i of the optimizer's flat layout."""
+    for i, (_, params) in enumerate(phases):
+        if i >= len(fp.bucket_params) or {id(fp.params[j]) for j in fp.bucket_params[i]} != {id(p) for p in params}:
+            raise RuntimeError("the optimizer's gradient buckets do not match the model's backward phases "
+                               "(build it with grad_buckets=model.grad_buckets())")
+
+
 def train_step(model, batch, optimizer, opt, comm_stream=None):
     """zero_grad / forward / backward / [gradient all-reduce] / [global clip] / step (train.py:141-151).
     Returns (loss, loss_dict).  `optimizer` needs zero_grad(), step() and - for the data-parallel branch - `.fp`
     (optimization.FlatParams): nothing here is GPU-specific, the CPU tests drive it with a toy model over gloo.
-    comm_stream: see dist.sync_gradients."""
+    Data parallel with a model that exposes forward_phased and an optimizer laid out in gradient buckets: the backward pass
+    runs tower by tower and each tower's all-reduce is issued as it completes (dist.BucketedGradSync), on comm_stream when
+    given (see dist.sync_gradients); otherwise one all-reduce of the whole flat buffer after the backward pass."""
     optimizer.zero_grad()
-    loss, loss_dict = model(batch)
-    loss.backward()
-    if dist_info()[1] >= DDP_MIN_WORLD:
+    ddp = dist_info()[1] >= DDP_MIN_WORLD
+    fp = getattr(optimizer, "fp", None)
+    if ddp and hasattr(model, "forward_phased") and len(fp.bucket_ranges) > 1:
         from . import dist as ddist
-        ddist.sync_gradients(optimizer.fp, comm_stream=comm_stream)
+        loss, loss_dict, phases = model.forward_phased(batch)
+        _check_phase_buckets(fp, phases)
+        sync = ddist.BucketedGradSync(fp, comm_stream=comm_stream)
+        backward_in_phases(loss, phases, after_phase=sync.bucket_ready)
+        sync.finish()
+        if "loss_overall" not in loss_dict:
+            loss_dict = {"loss_overall": float(loss.detach()), **loss_dict}
+    else:
+        loss, loss_dict = model(batch)
+        loss.backward()
+        if ddp:
+            from . import dist as ddist
+            ddist.sync_gradients(fp, comm_stream=comm_stream)
     if getattr(opt, "grad_clip", -1) != -1:
         torch.nn.utils.clip_grad_norm_(model.parameters(), opt.grad_clip)
     optimizer.step()
@@ -126,8 +176,10 @@ class GraphedTrainStep:
     time; at most `max_graphs` graphs are kept (least recently used is dropped), an evicted key is never captured again and
     after `max_captures` captures every unseen key stays eager (variable caption counts - ActivityNet, Charades - would
     otherwise re-capture a 350-kernel graph far more often than they replay one).
-    Data parallel (world >= 2): the graph ends after the backward pass; gradient all-reduce and the optimizer update follow
-    eagerly (3 launches)."""
+    Data parallel (world >= 2) with the optimizer laid out in gradient buckets (make_optimizer): the step is a chain of graphs,
+    one per tower of the backward pass; each tower's all-reduce is issued from the comm stream as its segment has been launched
+    and runs under the next segment; the optimizer update is the chain's last graph (_capture_segments).  Without buckets: one
+    graph that ends after the backward pass, one all-reduce, the optimizer update eagerly."""
 
     TENSOR_KEYS = ("student_videos", "student_videos_mask", "teacher_videos", "student_text", "student_text_mask", "teacher_text")
 
@@ -152,7 +204,8 @@ class GraphedTrainStep:
         shapes = tuple((k, tuple(batch[k].shape), str(batch[k].dtype)) for k in self.TENSOR_KEYS)
         return (shapes, len(batch["text_labels"]),
                 float(m.alpha), float(m.belta), float(m.weight), bool(get("use_hard_negative")), get("hard_pool_size"),
-                m.label_style, bool(m.training), dist_info()[1] >= DDP_MIN_WORLD, getattr(self.opt, "grad_clip", -1))
+                m.label_style, bool(m.training), dist_info()[1] >= DDP_MIN_WORLD, getattr(self.opt, "grad_clip", -1),
+                len(self.optimizer.fp.bucket_ranges))
 
     def _bucketed(self, batch):
         """The batch with its word axis padded to a multiple of 8 (at most max_desc_l) and its clip axis to a multiple of 32 (at
@@ -255,15 +308,18 @@ class GraphedTrainStep:
             # thread's do - and RCCL's watchdog thread polls its events with hipEventQuery all the time: it then dies on
             # hipErrorStreamCaptureUnsupported and the process aborts at destroy_process_group (seen one run in two).
             # Kernels the autograd thread launches into the capturing stream are captured in either mode.
-            with torch.cuda.graph(e.graph, stream=self.stream, capture_error_mode="thread_local"):
-                loss, parts = m.forward_tensors(e.static, staged=e)
-                loss.backward()
-                if e.ddp:
-                    opt_.fp.rebind_grads()
-                else:
-                    opt_.enqueue(upload_lr=False)
-                e.loss, e.parts = loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in parts.items()}
-            del loss, parts
+            if e.ddp and hasattr(m, "forward_phased") and len(opt_.fp.bucket_ranges) > 1:
+                self._capture_segments(e)
+            else:
+                with torch.cuda.graph(e.graph, stream=self.stream, capture_error_mode="thread_local"):
+                    loss, parts = m.forward_tensors(e.static, staged=e)
+                    loss.backward()
+                    if e.ddp:
+                        opt_.fp.rebind_grads()
+                    else:
+                        opt_.enqueue(upload_lr=False)
+                    e.loss, e.parts = loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in parts.items()}
+                del loss, parts
         except Exception:
             opt_.t_lr = old_lr
             raise
@@ -276,6 +332,45 @@ class GraphedTrainStep:
         self.graphs[key] = e
         self.captures += 1
         return e
+
+    def _capture_segments(self, e):
+        """Data parallel: the step as a CHAIN of graphs over one memory pool - segment i ends where tower i's gradients are in
+        their flat range, so the replay can start that bucket's all-reduce on the comm stream and launch segment i + 1 right
+        behind it; the fused optimizer update is the last graph of the chain (it runs once every collective has been joined).
+        Graphs of one pool replay in capture order, which is the only order _replay uses."""
+        m, opt_ = self.model, self.optimizer
+        e.segments, e.pool = [], torch.cuda.graph_pool_handle()
+        ctx = [None]
+
+        def open_segment():
+            g = torch.cuda.CUDAGraph()
+            c = torch.cuda.graph(g, pool=e.pool, stream=self.stream, capture_error_mode="thread_local")
+            c.__enter__()
+            ctx[0] = c
+            e.segments.append(g)
+
+        def close_segment(*exc):
+            c, ctx[0] = ctx[0], None
+            if c is not None:
+                c.__exit__(*(exc or (None, None, None)))
+
+        try:
+            open_segment()
+            loss, parts, phases = m.forward_phased(e.static, staged=e)
+            _check_phase_buckets(opt_.fp, phases)
+            backward_in_phases(loss, phases, after_phase=opt_.fp.rebind_bucket,
+                               between=lambda i: (close_segment(), open_segment()))
+            e.had = opt_.fp.rebind_grads()
+            e.loss, e.parts = loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in parts.items()}
+            del loss, parts, phases
+            close_segment()
+            open_segment()
+            opt_.enqueue(upload_lr=False)
+            close_segment()
+            e.opt_graph = e.segments.pop()
+        except BaseException as ex:
+            close_segment(type(ex), ex, ex.__traceback__)
+            raise
 
     def _replay(self, e, batch):
         from . import ops
@@ -295,11 +390,21 @@ class GraphedTrainStep:
             if r_v2t is not None:
                 slot[e.off[("v2t", c)]:e.off[("v2t", c)] + e.nv] = r_v2t
         e.ring.upload(e.dev_words.view(torch.uint8))
-        e.graph.replay()
-        if e.ddp:
+        if getattr(e, "segments", None):
             from . import dist as ddist
-            ddist.sync_gradients(opt_.fp, comm_stream=self.comm_stream)
-            opt_.enqueue(upload_lr=False)
+            sync = ddist.BucketedGradSync(opt_.fp, comm_stream=self.comm_stream)
+            opt_.fp.bind_views(e.had)                     # the captured copies fill the flat ranges: nothing to gather
+            for i, g in enumerate(e.segments):
+                g.replay()
+                sync.issue(i)                             # tower i's all-reduce runs under segment i + 1
+            sync.finish()
+            e.opt_graph.replay()
+        else:
+            e.graph.replay()
+            if e.ddp:
+                from . import dist as ddist
+                ddist.sync_gradients(opt_.fp, comm_stream=self.comm_stream)
+                opt_.enqueue(upload_lr=False)
         ops.bump_param_epoch()
         self.replays += 1
         out = dict(e.parts)

@@ -221,6 +221,87 @@ def test_shipped_train_step_two_ranks_different_batches():
     np.testing.assert_allclose(fp.flat.numpy(), r0["final"], rtol=1e-5, atol=1e-6)
 
 
+class _ToyPhased(_ToyModel):
+    """The toy with the phased-backward protocol of DLDKD.forward_phased: the loss reaches `a` only through the hidden
+    activation (the tap); `b` sits behind the tap (a head phase, tap None); `unused` is in no bucket (the rest range)."""
+
+    def grad_buckets(self):
+        return [list(self.a.parameters()), list(self.b.parameters())]
+
+    def forward_phased(self, batch):
+        h = torch.tanh(self.a(batch["x"]))
+        y = self.b(h).squeeze(-1)
+        loss = ((y - batch["y"]) ** 2).mean()
+        return loss, {"loss_overall": float(loss.detach())}, [(h, list(self.a.parameters())), (None, list(self.b.parameters()))]
+
+
+class _SGDBucketed(_SGDOnFlat):
+    def __init__(self, params, lr, buckets):
+        from dldkd_amd.optimization import FlatParams
+        self.fp, self.lr = FlatParams(list(params), buckets), lr
+
+
+def _bucketed_worker(rank, world, port, ret):
+    _setup(rank, world, port)
+    from dldkd_amd import train as T
+    x, y = _data()
+    cfg = types.SimpleNamespace(grad_clip=-1)
+    out = {}
+    for kind in ("single", "bucketed"):
+        torch.manual_seed(7)                                # same start on both ranks and in both variants
+        model = _ToyPhased() if kind == "bucketed" else _ToyModel()
+        opt_ = _SGDBucketed(model.parameters(), 0.1, model.grad_buckets()) if kind == "bucketed" else _SGDOnFlat(model.parameters(), 0.1)
+        if kind == "bucketed":
+            # the layout really is bucket by bucket: a | b | rest, contiguous and disjoint
+            assert len(opt_.fp.bucket_ranges) == 3 and opt_.fp.bucket_ranges[0][0] == 0
+            assert all(opt_.fp.bucket_ranges[i][1] == opt_.fp.bucket_ranges[i + 1][0] for i in range(2))
+        grads = []
+        for step in range(4):
+            b = [(8 * step + 4 * rank + i) % 24 for i in range(4)]      # different batches per rank
+            T.train_step(model, {"x": x[b], "y": y[b]}, opt_, cfg)
+            grads.append({n: p.grad.clone().numpy() for n, p in model.named_parameters()})
+        out[kind] = dict(final={n: p.detach().clone().numpy() for n, p in model.named_parameters()}, grads=grads)
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlap_equals_single_bucket_two_ranks():
+    """The data-parallel step with the backward pass run in phases and one all-reduce per gradient bucket (train.
+    backward_in_phases + dist.BucketedGradSync over the bucket-contiguous FlatParams layout) against the single all-reduce of the
+    whole buffer: same averaged gradients and same parameters, bit for bit, on both ranks, the gradient-less parameter
+    untouched."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_bucketed_worker, args=(world, port, ret), nprocs=world, join=True)
+    for rank in (0, 1):
+        one, many = ret[rank]["single"], ret[rank]["bucketed"]
+        for n in one["final"]:
+            np.testing.assert_array_equal(one["final"][n], many["final"][n])
+        for ga, gb in zip(one["grads"], many["grads"]):
+            for n in ga:
+                np.testing.assert_array_equal(ga[n], gb[n])
+        np.testing.assert_array_equal(many["final"]["unused"], np.ones(3, np.float32))
+    for n in ret[0]["bucketed"]["final"]:
+        np.testing.assert_array_equal(ret[0]["bucketed"]["final"][n], ret[1]["bucketed"]["final"][n])
+    assert not np.array_equal(ret[0]["bucketed"]["grads"][0]["a.weight"], np.zeros_like(ret[0]["bucketed"]["grads"][0]["a.weight"]))
+
+
+def test_flat_params_bucket_layout_keeps_tensor_order_of_per_tensor_arrays():
+    from dldkd_amd.optimization import FlatParams, CHUNK
+    ps = [torch.nn.Parameter(torch.full((n,), float(i))) for i, n in enumerate((5, 300, 7, 256, 1))]
+    fp = FlatParams(ps, [[ps[3], ps[1]], [ps[4]]])
+    assert fp.bucket_params == [[1, 3], [4], [0, 2]]
+    assert fp.bucket_ranges == [(0, 3 * CHUNK), (3 * CHUNK, 4 * CHUNK), (4 * CHUNK, 6 * CHUNK)]
+    assert fp.t_numel.tolist() == [5, 300, 7, 256, 1] and fp.t_start.tolist() == [4 * CHUNK, 0, 5 * CHUNK, 2 * CHUNK, 3 * CHUNK]
+    assert fp.chunk_tensor.tolist() == [1, 1, 3, 4, 0, 2]
+    for i, p in enumerate(ps):                              # values survive the move, storage is the flat buffer
+        assert torch.equal(p.data, torch.full_like(p.data, float(i)))
+        assert p.data.data_ptr() == fp.flat[fp.t_start[i]:].data_ptr()
+    with pytest.raises(ValueError):
+        FlatParams(ps, [[ps[0]], [ps[0]]])
+
+
 # ------------------------------------------------------------------------------------------------ bench.py --gpus N setup
 _BENCH_CFG = dict(name="T", nq=57, nv=150, L=8, len_lo=2, seed=9, sigma=(0.5, 0.7), workload="test")
 

@@ -258,3 +258,79 @@ def test_graphed_step_serves_variable_length_batches_from_a_few_graphs():
     assert stepper.captures <= 5 and stepper.replays + stepper.eager_steps == n
     assert stepper.replays >= 6 * stepper.captures, (stepper.replays, stepper.captures, stepper.eager_steps)
     assert len(stepper.graphs) <= 3 and not (set(stepper.graphs) & stepper.evicted)
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.2])
+def test_data_parallel_stepper_runs_the_step_as_a_chain_of_graph_segments(drop):
+    """Data parallel (one-rank RCCL group forced on, gradient buckets per tower): the stepper replays the step as a chain of
+    graphs - one per tower of the backward pass, each tower's all-reduce issued from the comm stream behind its segment - plus
+    the optimizer graph.  Against the plain single-graph stepper on the same seeds: same loss and parameters after every
+    step (a mean over one rank is the identity), with dropout too; eager data-parallel steps (phased backward) agree as well."""
+    import os
+    import synth
+    import torch.distributed as dist
+    from dldkd_amd import train as T
+    from dldkd_amd.model import DLDKD
+    from dldkd_amd.optimization import BertAdam
+    cfg = types.SimpleNamespace(visual_input_size=256, query_input_size=128, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=32, max_desc_l=30, input_drop=drop, drop=drop, n_heads=4, initializer_range=0.02,
+                                margin=0.1, use_hard_negative=True, hard_pool_size=5, label_style="soft")
+    mopt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                 collection="tvr", alpha=0.8, belta=0.8)
+    topt = types.SimpleNamespace(grad_clip=-1)
+    batches = [synth.make_train_batch(170 + i, nv=24, caps=2, L=32, len_lo=3, dv=256, dq=128, lq_lo=6, lq_hi=30) for i in range(3)]
+    batches = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
+
+    def make(buckets):
+        torch.manual_seed(11)
+        m = DLDKD(types.SimpleNamespace(**vars(cfg)), mopt).to(DEV).train()
+        return m, BertAdam([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=2e-3, warmup=0.1, t_total=40,
+                           grad_buckets=m.grad_buckets() if buckets else None)
+
+    def params(m):
+        return torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+
+    def give(dst_m, dst_o, src_m, src_o):                  # parameters and moments by NAME: the two flat layouts differ
+        for (pd, ps) in zip(dst_m.parameters(), src_m.parameters()):
+            pd.data.copy_(ps.data)
+        for name in ("m", "v"):
+            for i in range(len(dst_o.fp.params)):
+                sd, ns = dst_o.fp._starts[i], dst_o.fp._numels[i]
+                ss = src_o.fp._starts[i]
+                getattr(dst_o, name)[sd:sd + ns].copy_(getattr(src_o, name)[ss:ss + ns])
+        dst_o.step_count = src_o.step_count
+
+    mp_, op_ = make(False)
+    plain = T.GraphedTrainStep(mp_, op_, topt)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29595", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device(DEV))
+    old = T.DDP_MIN_WORLD
+    T.DDP_MIN_WORLD = 1
+    try:
+        md, od = make(True)
+        assert len(od.fp.bucket_ranges) == 4 and od.fp.bucket_ranges[-1][1] == od.fp.total
+        ddp = T.GraphedTrainStep(md, od, topt)
+        me, oe = make(True)
+        for it in range(8):
+            give(md, od, mp_, op_)
+            give(me, oe, mp_, op_)
+            T.DDP_MIN_WORLD = 2
+            torch.manual_seed(300 + it)
+            lp, _ = plain(batches[it % 3])
+            T.DDP_MIN_WORLD = 1
+            torch.manual_seed(300 + it)
+            ld, dd = ddp(batches[it % 3])
+            torch.manual_seed(300 + it)
+            le, _ = T.train_step(me, batches[it % 3], oe, topt)
+            assert float(lp) == pytest.approx(float(ld), rel=1e-5), it
+            assert float(lp) == pytest.approx(float(le), rel=1e-5), it
+            tol = 2e-7 + 0.02 * od.get_lr()[0]
+            assert (params(mp_) - params(md)).abs().max().item() <= tol, it
+            assert (params(mp_) - params(me)).abs().max().item() <= tol, it
+            assert od.step_count == op_.step_count
+        assert ddp.replays == 7 and ddp.captures == 1 and ddp.eager_steps == 1
+        e = next(iter(ddp.graphs.values()))
+        assert len(e.segments) == 4 and e.opt_graph is not None
+    finally:
+        T.DDP_MIN_WORLD = old
+        dist.destroy_process_group()
