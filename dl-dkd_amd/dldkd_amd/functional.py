@@ -245,11 +245,42 @@ class _AttentionTrain(Function):
         return dqkv, None, None
 
 
+class _AttentionTrainBf16(Function):
+    """Throughput-mode twin (attention_train_bf16.hip): every product on the bf16 matrix cores; nothing saved but qkv and the
+    mask - the one backward kernel recomputes the probabilities (same Philox slot, hence the same keep bits)."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask, p_drop):
+        N, L = qkv.shape[0], qkv.shape[1]
+        out = torch.empty(N, L, HIDDEN, dtype=torch.float32, device=qkv.device)
+        seed, off, state = _philox_slot(qkv.device, N * HEADS * L * L) if p_drop > 0.0 else (0, 0, None)
+        native.check(_L().dldkd_attention_train_fwd_bf16(_p(qkv), _p(mask), _p(out), N, L, float(p_drop), seed, off, state, _s()),
+                     "attention_train_fwd_bf16")
+        ctx.save_for_backward(qkv, mask)
+        ctx.rng = (float(p_drop), seed, off, state, _philox_step.dev if _philox_step is not None else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, mask = ctx.saved_tensors
+        p_drop, seed, off, state, _keep_alive = ctx.rng
+        N, L = qkv.shape[0], qkv.shape[1]
+        dqkv = torch.empty_like(qkv)
+        native.check(_L().dldkd_attention_train_bwd_bf16(_p(qkv), _p(mask), _p(_f32(dout)), _p(dqkv), N, L, p_drop, seed, off, state,
+                                                         _s()), "attention_train_bwd_bf16")
+        return dqkv, None, None
+
+
+ATTN_TRAIN_BF16 = True      # throughput mode: bf16-MFMA training attention (False: the exact-fp32 kernels in both modes)
+
+
 def attention(qkv, mask, p_drop=0.0, training=False):
     qkv = _f32(qkv)
     mask = _f32(mask) if mask is not None else None
     if _needs_grad(qkv) or (training and p_drop > 0.0):
         N, L = qkv.shape[0], qkv.shape[1]
+        if ATTN_TRAIN_BF16 and ops.gemm_precision() == "bf16" and qkv.is_cuda:
+            return _AttentionTrainBf16.apply(qkv, mask, float(p_drop) if training else 0.0)
         return _AttentionTrain.apply(qkv, mask, float(p_drop) if training else 0.0)
     return ops.attention(qkv, mask)
 

@@ -73,6 +73,10 @@ SIGNATURES = {
                                                 ctypes.c_uint64, _c_void_p, _c_void_p]),
     "dldkd_attention_train_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float,
                                                 ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p]),
+    "dldkd_attention_train_fwd_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float, ctypes.c_uint64,
+                                                 ctypes.c_uint64, _c_void_p, _c_void_p]),
+    "dldkd_attention_train_bwd_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float,
+                                                 ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p]),
     "dldkd_row_invnorm_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
     "dldkd_simpool_train_fwd_f32": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
                                               _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),

@@ -365,6 +365,16 @@ int dldkd_attention_train_fwd_f32(const float* qkv, const float* mask, float* pr
 int dldkd_attention_train_bwd_f32(const float* qkv, const float* dout, float* probs, float* dS, float* dqkv, int N, int L,
                                   float p_drop, unsigned long long seed, unsigned long long offset,
                                   const unsigned long long* state, void* stream);
+/* The same two passes with every product on the bf16 matrix cores (throughput mode, attention_train_bf16.hip): q, k, v, dO
+ * and the probabilities are rounded to bf16 as MFMA operands, accumulation and softmax stay fp32.  Nothing is saved between the
+ * passes: the backward pass recomputes the probabilities from qkv and `mask` (same Philox keep bits as the forward pass) and
+ * writes dqkv in ONE kernel; L <= 32 runs four (sequence, head) pairs per workgroup. */
+int dldkd_attention_train_fwd_bf16(const float* qkv, const float* mask, float* out, int N, int L, float p_drop,
+                                   unsigned long long seed, unsigned long long offset, const unsigned long long* state,
+                                   void* stream);
+int dldkd_attention_train_bwd_bf16(const float* qkv, const float* mask, const float* dout, float* dqkv, int N, int L, float p_drop,
+                                   unsigned long long seed, unsigned long long offset, const unsigned long long* state,
+                                   void* stream);
 
 /* Training-side simpool: for one (query set, gallery) pair of DLDKD.forward (model.py:113-129) everything the losses read
  * of get_sim_scores (model.py:307-329) and get_unnormalized_sim_scores (model.py:331-350), from ONE raw product

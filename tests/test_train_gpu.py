@@ -453,6 +453,99 @@ def test_fused_training_attention_vs_fp64(N, L, p_drop):
     _gclose(a.grad, q64.grad, 2e-5)
 
 
+@pytest.mark.parametrize("N,L,p_drop", [(6, 40, 0.0), (5, 128, 0.2), (9, 30, 0.15), (3, 1, 0.0), (4, 97, 0.3), (130, 32, 0.1),
+                                        (7, 64, 0.2), (3, 33, 0.0), (4, 80, 0.1)])
+def test_bf16_training_attention_vs_fp64(N, L, p_drop):
+    """attention_train_bf16.hip (throughput mode: one forward and ONE backward kernel, every product on the bf16 matrix cores,
+    probabilities recomputed in the backward pass, four (sequence, head) pairs per workgroup when L <= 32) against the same fp64
+    reference and the same dropout mask as the exact kernels, at the bf16 mode's tolerance (operands rounded to 8 bits of
+    mantissa: 2e-2 of the largest entry)."""
+    from dldkd_amd import functional as F_
+    from dldkd_amd import ops
+    g = torch.Generator().manual_seed(N * 131 + L)
+    qkv = (torch.randn(N, L, 1152, generator=g) * 0.5)
+    mask = torch.ones(N, L)
+    if L > 3:
+        mask[0, L // 2:] = 0
+        mask[N - 1, L - 1:] = 0
+    w = torch.randn(N, L, 384, generator=g)
+    torch.manual_seed(1234)
+    keep = torch.ones(N, 4, L, L)
+    if p_drop > 0:
+        _, kb = F_._dropout_fwd(torch.ones(N, 4, L, L, device=DEV), p_drop)
+        keep = kb.float().cpu()
+    q64 = qkv.double().requires_grad_()
+    x = q64.view(N, L, 3, 4, 96)
+    Q, K, V = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    S = Q @ K.transpose(-1, -2) / 96 ** 0.5 + ((1.0 - mask.double()) * -10000.0)[:, None, None, :]
+    P = torch.softmax(S, -1)
+    Pd = P * keep.double() / (1.0 - p_drop)
+    ref = (Pd @ V).permute(0, 2, 1, 3).reshape(N, L, 384)
+    (ref * w.double()).sum().backward()
+    ops.set_gemm_precision("bf16")
+    try:
+        torch.manual_seed(1234)
+        a = qkv.to(DEV).requires_grad_()
+        out = F_.attention(a, mask.to(DEV), p_drop, True)
+        assert type(out.grad_fn).__name__ == "_AttentionTrainBf16Backward"
+        (out * w.to(DEV)).sum().backward()
+    finally:
+        ops.set_gemm_precision("fp32")
+    sc = ref.detach().abs().max().item()
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 2e-2 * max(1.0, sc)
+    gd, g64 = a.grad.cpu().double(), q64.grad
+    assert torch.isfinite(gd).all()
+    assert (gd - g64).abs().max().item() <= 2e-2 * g64.abs().max().item()
+    for blk in range(3):                                   # dq, dk, dv each on its own scale
+        x_, y_ = gd[..., 384 * blk:384 * (blk + 1)].flatten(), g64[..., 384 * blk:384 * (blk + 1)].flatten()
+        if y_.norm() > 0:
+            assert torch.dot(x_, y_) / (x_.norm() * y_.norm()) > 0.999
+
+
+@pytest.mark.parametrize("L", [8, 30, 32, 64, 128])
+def test_bf16_training_attention_draws_the_exact_dropout_mask(L):
+    """The keep bits, read back exactly: q = k = 0 makes P uniform (1/L), p = 0.5 makes Pd = 2/L (a power of two for these L,
+    or exact in bf16), V[key][0] = 2^(key % 8) in column (key // 8) decodes the forward mask from the context; dO[q][0] =
+    2^(q % 8) in column (q // 8) decodes the backward pass's mask (phase 2 reads the bits phase 1 left in LDS) from dV."""
+    from dldkd_amd import functional as F_
+    from dldkd_amd import ops
+    N, p_drop = 3, 0.5
+    qkv = torch.zeros(N, L, 3, 4, 96)
+    for key in range(L):
+        qkv[:, key, 2, :, key // 8] = 2.0 ** (key % 8)
+    torch.manual_seed(99)
+    _, kb = F_._dropout_fwd(torch.ones(N, 4, L, L, device=DEV), p_drop)
+    keep = kb.float().cpu()                                                     # (N, 4, q, key)
+    w = torch.zeros(N, L, 4, 96)
+    for q in range(L):
+        w[:, q, :, q // 8] = 2.0 ** (q % 8)
+    ops.set_gemm_precision("bf16")
+    try:
+        torch.manual_seed(99)
+        a = qkv.reshape(N, L, 1152).to(DEV).requires_grad_()
+        out = F_.attention(a, None, p_drop, True)
+        (out * w.reshape(N, L, 384).to(DEV)).sum().backward()
+    finally:
+        ops.set_gemm_precision("fp32")
+    pd = 2.0 / L
+    exp_fwd = torch.zeros(N, L, 4, 96)
+    for c in range((L + 7) // 8):
+        ks = slice(8 * c, min(8 * c + 8, L))
+        wt = 2.0 ** torch.arange(ks.stop - ks.start).float()
+        exp_fwd[:, :, :, c] = (keep[:, :, :, ks] * wt).sum(-1).permute(0, 2, 1) * pd
+    got = out.detach().cpu().view(N, L, 4, 96)
+    tol = 0.0 if (L & (L - 1)) == 0 else 1e-2        # 2 / 30 is not a bf16 number
+    assert (got - exp_fwd).abs().max().item() <= tol * exp_fwd.abs().max().item()
+    # dV[key][head, c] = sum_q Pd[q][key] dO[q][head, c] = pd * sum_{q in 8c..8c+7} keep[q][key] 2^(q % 8)
+    exp_dv = torch.zeros(N, L, 4, 96)
+    for c in range((L + 7) // 8):
+        qs = slice(8 * c, min(8 * c + 8, L))
+        wt = 2.0 ** torch.arange(qs.stop - qs.start).float()
+        exp_dv[:, :, :, c] = (keep[:, :, qs, :] * wt[None, None, :, None]).sum(2).permute(0, 2, 1) * pd
+    dv = a.grad.cpu().view(N, L, 3, 4, 96)[:, :, 2]
+    assert (dv - exp_dv).abs().max().item() <= tol * exp_dv.abs().max().item()
+
+
 @pytest.mark.parametrize("M,D,with_pos", [(300, 3072, False), (257, 768, False), (40 * 30, 384, True), (5, 1024, False)])
 def test_fused_layernorm_dropout_equals_layernorm_then_dropout(M, D, with_pos):
     """LayerNorm -> Dropout as ONE kernel (LinearLayer / TrainablePositionalEncoding in training, model_components.py:277-312)
