@@ -132,6 +132,67 @@ def layernorm(x, gamma, beta, add=None, add_mod=0, p_drop=0.0, training=False):
     return ops.layernorm(x, gamma, beta, add=add, add_mod=add_mod)
 
 
+class _InProjTrain(Function):
+    """LinearLayer on RAW features in training, throughput mode (model_components.py:294-312): LayerNorm -> Dropout -> Linear ->
+    ReLU as one autograd node.  The features need no gradient, so the backward pass never forms the Linear's input gradient: the
+    LayerNorm parameter gradients come out of the accumulators of dy W (dldkd_linear_lngrad_bf16) - one GEMM-with-epilogue
+    instead of the dX GEMM (201 MB written at the TVR batch) plus a LayerNorm backward pass over x and that gradient."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, weight, bias, p, relu):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        keep = None
+        if p > 0.0:
+            z = torch.empty_like(x2)
+            keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
+            seed, off, state = _philox_slot(x.device, x.numel())
+            native.check(_L().dldkd_layernorm_dropout_f32(_p(x2), None, 0, _p(gamma), _p(beta), _p(z), _p(keep), x2.shape[0], K,
+                                                          ops.LN_EPS, float(p), seed, off, state, _s()), "layernorm_dropout")
+        else:
+            z = ops.layernorm(x2, gamma, beta)
+        y = ops.linear(z, weight, bias, relu=relu)
+        ctx.save_for_backward(x2, weight, z, y if relu else None, keep)
+        ctx.relu, ctx.has_bias, ctx.keep_scale = relu, bias is not None, 1.0 / (1.0 - p)
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, z, y, keep = ctx.saved_tensors
+        N, K = w.shape
+        M = x2.shape[0]
+        dy2 = _f32(dy).reshape(-1, N)
+        if ctx.relu:
+            dy2 = dy2.clone()
+            native.check(_L().dldkd_relu_bwd_f32(_p(dy2), _p(y.reshape(-1, N)), dy2.numel(), _s()), "relu_bwd")
+        dw = ops.gemm(dy2, z, True, True, N, K, M) if ctx.needs_input_grad[3] else None
+        db = _colsum(dy2, N) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
+        dg = dbeta = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            stats = torch.empty(2, M, dtype=torch.float32, device=x2.device)
+            native.check(_L().dldkd_row_meanrstd_f32(_p(x2), _p(stats[0]), _p(stats[1]), M, K, ops.LN_EPS, _s()), "row_meanrstd")
+            tiles = (M + 127) // 128
+            ws = torch.empty(2 * tiles * K, dtype=torch.float32, device=x2.device)
+            dgb = torch.zeros(2, K, dtype=torch.float32, device=x2.device)
+            native.check(_L().dldkd_linear_lngrad_bf16(_p(dy2), _p(w), _p(x2), _p(keep), ctx.keep_scale, _p(stats[0]), _p(stats[1]),
+                                                       _p(ws), ws.numel() * 4, _p(dgb[0]), _p(dgb[1]), M, N, K, _s()), "linear_lngrad")
+            dg, dbeta = dgb[0], dgb[1]
+        return None, dg, dbeta, dw, db, None, None
+
+
+IN_PROJ_TRAIN_FUSED = True
+
+
+def in_proj_train_ok(x, weight):
+    """Throughput mode, training, features without a gradient, row statistics kernel limits (D % 4 == 0, D <= 4096)."""
+    return (IN_PROJ_TRAIN_FUSED and ops.gemm_precision() == "bf16" and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad
+            and x.shape[-1] % 4 == 0 and x.shape[-1] <= 4096 and weight.requires_grad)
+
+
+def in_proj_train(x, gamma, beta, weight, bias, p_drop, training, relu=True):
+    return _InProjTrain.apply(_f32(x), gamma, beta, weight, bias, float(p_drop) if training else 0.0, bool(relu))
+
+
 # ------------------------------------------------------------------------------------------ dropout
 class PhiloxStepState:
     """Philox (seed, base offset) of ONE training step in device memory, for hipGraph-captured steps (train.GraphedTrainStep).

@@ -42,6 +42,11 @@ class LinearLayer(nn.Module):
         self.net = nn.Sequential(nn.Dropout(dropout), nn.Linear(in_hsz, out_hsz))
 
     def forward(self, x):
+        lin = self.net[1]
+        if self.layer_norm and F_.in_proj_train_ok(x, lin.weight):
+            # training on raw features, throughput mode: one autograd node whose backward pass skips the input gradient
+            return F_.in_proj_train(x, self.LayerNorm.weight, self.LayerNorm.bias, lin.weight, lin.bias, self.net[0].p,
+                                    self.training, relu=self.relu)
         if self.layer_norm:
             x = F_.layernorm(x, self.LayerNorm.weight, self.LayerNorm.bias, p_drop=self.net[0].p, training=self.training)
         else:

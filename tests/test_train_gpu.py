@@ -688,3 +688,56 @@ def test_fused_training_simpool_nan_query_propagates_and_stays_in_bounds(prec):
     ok[[7, 33]] = False
     assert torch.isfinite(pr[ok.to(DEV)]).all() and torch.isfinite(pc[ok.to(DEV)]).all()
     assert torch.isfinite(qd.grad[ok.to(DEV)]).all()
+
+
+@pytest.mark.parametrize("M,K,p_drop", [(300, 3072, 0.2), (257, 768, 0.15), (1000, 1024, 0.0), (5, 64, 0.3)])
+def test_fused_training_input_projection_vs_unfused(M, K, p_drop):
+    """LinearLayer on raw features in training, throughput mode, as ONE autograd node (functional._InProjTrain: the backward pass
+    takes LayerNorm's parameter gradients from the accumulators of dy W and never forms the input gradient) against the unfused
+    chain LayerNorm-dropout -> Linear (same kernels forward, dX GEMM + LayerNorm backward behind): identical forward, gradients
+    of W / b equal, gradients of gamma / beta within bf16-product rounding of the unfused ones and of an fp64 evaluation of the
+    same formula."""
+    from dldkd_amd import functional as F_
+    from dldkd_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g) * (1 + torch.rand(M, 1, generator=g))
+    gamma, beta = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    W, b = torch.randn(384, K, generator=g) * 0.02, 0.1 * torch.randn(384, generator=g)
+    w_out = torch.randn(M, 384, generator=g).to(DEV)
+    res = []
+    ops.set_gemm_precision("bf16")
+    try:
+        for fused in (True, False):
+            F_.IN_PROJ_TRAIN_FUSED = fused
+            gs, bs, Ws, bbs = (t.to(DEV).requires_grad_() for t in (gamma, beta, W, b))
+            torch.manual_seed(55)
+            xd = x.to(DEV)
+            if fused:
+                assert F_.in_proj_train_ok(xd, Ws)
+                y = F_.in_proj_train(xd, gs, bs, Ws, bbs, p_drop, True)
+                assert type(y.grad_fn).__name__ == "_InProjTrainBackward"
+            else:
+                y = F_.linear(F_.layernorm(xd, gs, bs, p_drop=p_drop, training=True), Ws, bbs, relu=True)
+            (y * w_out).sum().backward()
+            res.append((y.detach().cpu(), gs.grad.cpu(), bs.grad.cpu(), Ws.grad.cpu(), bbs.grad.cpu()))
+    finally:
+        F_.IN_PROJ_TRAIN_FUSED = True
+        ops.set_gemm_precision("fp32")
+    (yf, dgf, dbf, dWf, dbbf), (yu, dgu, dbu, dWu, dbbu) = res
+    assert torch.equal(yf, yu)
+    # (same kernels on the same operands; split-K planes and the column sums add with fp32 atomics, whose order varies)
+    assert torch.allclose(dWf, dWu, rtol=1e-4, atol=1e-5 * dWu.abs().max().item())
+    assert torch.allclose(dbbf, dbbu, rtol=1e-4, atol=1e-5 * dbbu.abs().max().item())
+    # fp64 evaluation from the fused run's own forward quantities (mask recovered from the dropped activations)
+    x64 = x.double()
+    mu, var = x64.mean(1, keepdim=True), x64.var(1, unbiased=False, keepdim=True)
+    xh = (x64 - mu) / torch.sqrt(var + 1e-5)
+    dy = (w_out.cpu().double() * (yf > 0))
+    dz = dy @ W.double()
+    if p_drop > 0:
+        torch.manual_seed(55)
+        _, kb = F_._dropout_fwd(torch.ones(M, K, device=DEV), p_drop)
+        dz = dz * kb.cpu().double() / (1 - p_drop)
+    dg64, db64 = (dz * xh).sum(0), dz.sum(0)
+    for got, ref in ((dgf, dg64), (dbf, db64), (dgu, dg64), (dbu, db64)):
+        assert (got.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
