@@ -50,6 +50,8 @@ class DLDKD(nn.Module):
         if self.double_branch:
             towers("exp_", c("exploration_hidden"))
 
+        self.tower_streams = False         # training: the four towers on four streams (_encode_towers)
+        self._side_streams = None
         self.weight = 1
         self.kl_intra_weight = opt.kl_intra_weight
         self.inher_nce_weight = opt.inher_nce_weight
@@ -344,6 +346,51 @@ class DLDKD(nn.Module):
         out.update(parts)
         return loss, out
 
+    # ------------------------------------------------------------------ the four towers side by side (training)
+    def _video_tower(self, pre, feat, mask):
+        h = self.encode_input(feat, mask, getattr(self, pre + "visual_input_proj"), getattr(self, pre + "visual_encoder"),
+                              getattr(self, pre + "visual_pos_embed"))
+        lin = getattr(self, pre + "out_mapping_linear")
+        return F_.linear(h, lin.weight, lin.bias)
+
+    def _query_tower(self, pre, feat, mask):
+        h = self.encode_input(feat, mask, getattr(self, pre + "query_input_proj"), getattr(self, pre + "query_encoder"),
+                              getattr(self, pre + "query_pos_embed"))
+        return self.get_modularized_queries(h, mask, inheritance=(pre == ""))
+
+    def _encode_towers(self, video, vmask, text, tmask):
+        """(g_inh, g_exp, q_inh, q_exp) of the training forward.  With tower_streams set (train.GraphedTrainStep sets it) the
+        four towers are enqueued on four streams forked from the current one and joined behind the last: they share nothing
+        but the raw features, and most of their kernels fill less than the chip (a 16,384 x 384 x 384 GEMM is 384 workgroups
+        for 512 slots, the attention kernels 512-640, the LayerNorm kernels fewer), so the hardware - and a captured hipGraph,
+        whose fork / join edges these become - runs them side by side.  Autograd runs every node's backward on the stream of
+        its forward, so the backward pass of the towers overlaps the same way."""
+        if not (self.tower_streams and self.training and video.is_cuda and torch.is_grad_enabled()):
+            g_inh, g_exp = self.encode_context(video, vmask)
+            q_inh, q_exp = self.encode_query(text, tmask)
+            return g_inh, g_exp, q_inh, q_exp
+        if text.dim() == 2:                  # the reference's collate .squeeze() drops a batch of one
+            text, tmask = text.unsqueeze(0), tmask.reshape(1, -1)
+        dev = video.device
+        cur = torch.cuda.current_stream(dev)
+        if self._side_streams is None or self._side_streams[0].device != dev:
+            self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        pres = ("", "exp_") if self.double_branch else ("",)
+        jobs = [(self._video_tower, pre, video, vmask) for pre in pres] + [(self._query_tower, pre, text, tmask) for pre in pres]
+        outs = []
+        for i, (fn, pre, x, m) in enumerate(jobs):
+            st = cur if i == 0 else self._side_streams[i - 1]
+            if st is not cur:
+                st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(fn(pre, x, m))
+        for i in range(1, len(jobs)):
+            cur.wait_stream(self._side_streams[i - 1])
+            outs[i].record_stream(cur)       # allocated on a side stream, consumed by the losses on this one
+        if self.double_branch:
+            return outs[0], outs[1], outs[2], outs[3]
+        return outs[0], None, outs[1], None
+
     # ------------------------------------------------------------------ data-parallel gradient buckets
     TOWERS = (("g_inh", ("visual_", "out_mapping_linear.")), ("g_exp", ("exp_visual_", "exp_out_mapping_linear.")),
               ("q_inh", ("query_", "modular_vector_mapping.")), ("q_exp", ("exp_query_", "exp_modular_vector_mapping.")))
@@ -381,8 +428,8 @@ class DLDKD(nn.Module):
         nv, L = mask.shape
         lens = self._lens(mask, nv, L, dev)
 
-        g_inh, g_exp = self.encode_context(batch["student_videos"], mask)
-        q_inh, q_exp = self.encode_query(batch["student_text"], batch["student_text_mask"])
+        g_inh, g_exp, q_inh, q_exp = self._encode_towers(batch["student_videos"], mask, batch["student_text"],
+                                                         batch["student_text_mask"])
         if taps is not None:
             taps.update({k: v for k, v in (("g_inh", g_inh), ("g_exp", g_exp), ("q_inh", q_inh), ("q_exp", q_exp)) if v is not None})
         t_text = batch["teacher_text"].float().reshape(len(labels), -1)          # .squeeze() of model.py:114

@@ -60,7 +60,7 @@ def timed(step, steps, warmup):
             "host_ms_median": q(walls, 0.5), "host_ms_p90": q(walls, 0.9)}
 
 
-def run(config="c3", prec="bf16", drop=0.2, steps=30, warmup=10, dev="cuda:0", modes=("eager", "graph")):
+def run(config="c3", prec="bf16", drop=0.2, steps=30, warmup=10, dev="cuda:0", modes=("eager", "graph"), tower_streams=None):
     from dldkd_amd import ops
     from dldkd_amd import train as T
     ops.set_gemm_precision(prec)
@@ -69,9 +69,13 @@ def run(config="c3", prec="bf16", drop=0.2, steps=30, warmup=10, dev="cuda:0", m
         topt = types.SimpleNamespace(grad_clip=-1)
         if "eager" in modes:
             m, opt, batch = build(config, drop, dev)
+            if tower_streams is not None:
+                m.tower_streams = tower_streams
             out["eager"] = timed(lambda: T.train_step(m, batch, opt, topt), steps, warmup)
         if "graph" in modes:
             m, opt, batch = build(config, drop, dev)
+            if tower_streams is not None:
+                m.tower_streams = tower_streams
             g = T.GraphedTrainStep(m, opt, topt, defer_loss_float=False)
             out["graph"] = timed(lambda: g(batch), steps, warmup)
             out["graph"]["replays"], out["graph"]["eager_steps"], out["graph"]["captures"] = g.replays, g.eager_steps, g.captures
@@ -90,5 +94,7 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--modes", default="eager,graph")
+    ap.add_argument("--tower-streams", type=int, default=-1, help="1 / 0: the four towers on four streams / one; -1: the default")
     a = ap.parse_args()
-    print(json.dumps(run(a.config, a.prec, a.drop, a.steps, a.warmup, modes=tuple(a.modes.split(","))), indent=1))
+    print(json.dumps(run(a.config, a.prec, a.drop, a.steps, a.warmup, modes=tuple(a.modes.split(",")),
+                         tower_streams=None if a.tower_streams < 0 else bool(a.tower_streams)), indent=1))
