@@ -124,7 +124,9 @@ def cpu_baseline(gs, mask, qs, fused_gpu, nq_s=500, nv_s=8718):
                sample=f"{nq_s} queries x {nv_s} videos (first 2/5 of the C2 gallery), both branches + fusion, "
                       f"fp32, 50-query chunks like eval.py:188-208; {dt:.1f} s with {best} threads "
                       f"(best of the probe {({k: int(v) for k, v in probe.items()})} pairs/s; host has {all_cores} logical cores)")
-    torch.set_num_threads(all_cores)
+    # back to a small host thread pool: with the probe's 256 OpenMP threads left alive, every blocking HIP wait of this process
+    # (event / device synchronize) woke up 2-60 ms late on the GPU box, and the eval-stage extras measured the host, not the GPU
+    torch.set_num_threads(min(all_cores, 8))
     try:
         out["c1"] = c1_cpu_vs_gpu(orc, fused_gpu.device)
     except Exception as e:   # noqa: BLE001

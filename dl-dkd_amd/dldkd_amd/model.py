@@ -152,7 +152,7 @@ class DLDKD(nn.Module):
         nbytes = sum(sizes)
         ring = getattr(self, "_item_ring", None)
         if ring is None or ring.bufs[0].numel() < nbytes:
-            ring = self._item_ring = PinnedRing(max(nbytes, 64 * 1024), device, slots=8)
+            ring = self._item_ring = PinnedRing(max(nbytes, 64 * 1024), device, slots=32)     # 2 MB pinned: an epoch's batches
         slot = ring.next()
         off = 0
         for t, nb in zip(tables_np, sizes):

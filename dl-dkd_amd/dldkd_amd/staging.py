@@ -6,6 +6,8 @@ masks.  A pageable `tensor.to(device)` blocks the host until the stream has drai
 buffer races with the host, which runs several steps ahead of the GPU and would overwrite the buffer before the copy engine has
 read it.  PinnedRing hands out pinned slots round robin and remembers, per slot, an event recorded after the slot's copy was
 enqueued: a slot is only handed out again once that copy has executed (normally long ago, so the wait is free)."""
+import time
+
 import torch
 
 
@@ -20,8 +22,15 @@ class PinnedRing:
         """The next free pinned slot (uint8 tensor); blocks only if its previous upload has not executed yet."""
         self.i = (self.i + 1) % len(self.bufs)
         ev = self.events[self.i]
-        if ev is not None:
-            ev.synchronize()
+        if ev is not None and not ev.query():
+            # The host is a whole ring ahead of the GPU.  Poll before parking: hipEventSynchronize on an incomplete event was
+            # measured at 0.5-2.4 ms per call on a loaded host (bench.py after its CPU baseline), i.e. the GPU had long drained
+            # its queue when the host woke up - the gallery encode ran at a quarter of its speed in such runs.
+            t_end = time.perf_counter() + 2e-3
+            while not ev.query():
+                if time.perf_counter() > t_end:
+                    ev.synchronize()
+                    break
         return self.bufs[self.i]
 
     def upload(self, dev_bytes, by_kernel=False):
