@@ -151,28 +151,63 @@ __global__ __launch_bounds__(kDgThreads) void simpool_bwd_dg_kernel(const Simpoo
         if (tid == 0) { int t = 0; for (int w = 0; w < kDgWaves; ++w) t += wcnt[w]; pos[nq] += t; }
         __syncthreads();
     }
-    // counting sort by clip: thread l owns clip l (every thread reads the same sc word: an LDS broadcast)
-    if (tid < L) {
-        int k = 0;
-        for (int n = 0; n < nq; ++n) {
-            const float2 ll = *reinterpret_cast<const float2*>(sc + 4 * n + 2);
-            k += (__float_as_int(ll.x) == tid) + (__float_as_int(ll.y) == tid);
-        }
-        cnt[tid + 1] = k;
+    // Stable counting sort of the 2 nq (query, coefficient) entries by clip, element e = 2 n + {0: raw, 1: cos}, in e order within
+    // a clip - the order the first version produced with ONE thread per clip walking all nq queries twice (2 x 640 dependent LDS
+    // broadcasts: ~30 us per workgroup, three workgroups per video).  Here: integer LDS atomics count the clips' entries, one
+    // thread prefixes the 128 counts, and the placement ranks an element among the equal keys of its wave with ballots (one round
+    // per distinct key in the wave) and adds the counts of the waves before it: same positions, a few microseconds.
+    float* rgs = reinterpret_cast<float*>(ent + 2 * (size_t)nq);   // [L] rg of this video's clips (0 past its length)
+    float* entp = rgs + L;                                        // [2 nq] b cos of the cos-type entries, 0 for raw ones
+    int* run = reinterpret_cast<int*>(entp + 2 * (size_t)nq);      // [L] entries of a clip placed by earlier chunks
+    int* wk = run + L;                                             // [kDgWaves][L] per-wave counts of the chunk
+    for (int i = tid; i <= L; i += kDgThreads) cnt[i] = 0;
+    for (int i = tid; i < L; i += kDgThreads) { run[i] = 0; rgs[i] = i < len ? p.rg[(size_t)v * L + i] : 0.f; }
+    __syncthreads();
+    const int ne = 2 * nq;
+    for (int e = tid; e < ne; e += kDgThreads) {
+        const int k = __float_as_int(sc[4 * (e >> 1) + 2 + (e & 1)]);
+        if (k >= 0 && k < L) atomicAdd(&cnt[k + 1], 1);
     }
-    if (tid == 0) cnt[0] = 0;
     __syncthreads();
     if (tid == 0) for (int l = 0; l < L; ++l) cnt[l + 1] += cnt[l];
-    __syncthreads();
-    if (tid < L) {
-        int k = cnt[tid];
-        float pr = 0.f;
-        const float rgl = tid < len ? p.rg[(size_t)v * L + tid] : 0.f;
-        for (int n = 0; n < nq; ++n) {
-            const float2 ll = *reinterpret_cast<const float2*>(sc + 4 * n + 2);
-            if (__float_as_int(ll.x) == tid) ent[k++] = float2{__int_as_float(n), sc[4 * n]};
-            if (__float_as_int(ll.y) == tid) { ent[k++] = float2{__int_as_float(n), sc[4 * n + 1] * rgl}; pr += bcos[n]; }
+    for (int e0 = 0; e0 < ne; e0 += kDgThreads) {
+        for (int i = tid; i < kDgWaves * L; i += kDgThreads) wk[i] = 0;
+        __syncthreads();
+        const int e = e0 + tid;
+        int key = -1, rank = 0;
+        if (e < ne) {
+            const int k = __float_as_int(sc[4 * (e >> 1) + 2 + (e & 1)]);
+            if (k >= 0 && k < L) key = k;
         }
+        unsigned long long todo = __ballot(key >= 0);
+        while (todo) {                                 // one round per distinct clip in the wave
+            const int lead = __ffsll((long long)todo) - 1;
+            const int K = __shfl(key, lead);
+            const unsigned long long m = __ballot(key == K);
+            if (key == K) rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == lead) wk[wave * L + K] = __popcll(m);
+            todo &= ~m;
+        }
+        __syncthreads();
+        if (key >= 0) {
+            int at = cnt[key] + run[key] + rank;
+            for (int w = 0; w < wave; ++w) at += wk[w * L + key];
+            const int n = e >> 1;
+            const bool is_cos = e & 1;
+            ent[at] = float2{__int_as_float(n), is_cos ? sc[4 * n + 1] * rgs[key] : sc[4 * n]};
+            entp[at] = is_cos ? bcos[n] : 0.f;
+        }
+        __syncthreads();
+        for (int l = tid; l < L; l += kDgThreads) {
+            int t = 0;
+            for (int w = 0; w < kDgWaves; ++w) t += wk[w * L + l];
+            run[l] += t;
+        }
+        __syncthreads();
+    }
+    if (tid < L) {
+        float pr = 0.f;
+        for (int k = cnt[tid]; k < cnt[tid + 1]; ++k) pr += entp[k];       // e order = the query order of the first version
         const int np = pos[nq];
         if (tid < len)
             for (int i = 0; i < np; ++i) { const size_t o = (size_t)pos[i] * L + tid; pr += p.d_clip[o] * p.clip_pos[o]; }
@@ -263,8 +298,10 @@ int dldkd_simpool_train_bwd_f32(const float* q, const float* g, const float* rq,
     hipStream_t s = (hipStream_t)stream;
     if (dq) DLDKD_LAUNCH(simpool_bwd_dq_kernel, dim3(nq), dim3(128 * kDqGroups), 0, s, p);
     if (dg) {
-        const size_t lds = ((size_t)5 * nq + 2 * L + 2 + nq + 4 + kDgWaves + 2 + (size_t)4 * nq) * sizeof(float);
-        if (lds > 160 * 1024) { set_error("simpool_train_bwd: %d queries need %zu bytes of LDS (max ~4000 queries per batch)", nq, lds); return DLDKD_EINVAL; }
+        // sc 4 nq, bcos nq, cnt L + 1, rowproj L, pos nq + 1, wcnt, ent 4 nq, rgs L, entp 2 nq, run L, per-wave counts 16 L
+        const size_t lds = ((size_t)5 * nq + 2 * L + 2 + nq + 4 + kDgWaves + 2 + (size_t)4 * nq + 2 * L + (size_t)2 * nq +
+                            (size_t)kDgWaves * L) * sizeof(float);
+        if (lds > 160 * 1024) { set_error("simpool_train_bwd: %d queries need %zu bytes of LDS (max ~3000 queries per batch)", nq, lds); return DLDKD_EINVAL; }
         static const bool attr_ok = hipFuncSetAttribute((const void*)simpool_bwd_dg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         (void)attr_ok;
         DLDKD_LAUNCH(simpool_bwd_dg_kernel, dim3(nv, (D + kDgCols - 1) / kDgCols), dim3(kDgThreads), lds, s, p);
