@@ -118,6 +118,105 @@ __device__ __forceinline__ void gemm_store_tile(const f32x16 (&acc)[2][2], const
     }
 }
 
+// Epilogue of the input projection's backward pass in training (LinearLayer: LayerNorm -> Dropout -> Linear -> ReLU on RAW
+// features, method/model_components.py:294-312).  The raw features need no gradient, so of the Linear's input gradient
+// dz' = dY W only LayerNorm's parameter gradients are wanted:
+//     dz = dz' (.) keep / (1 - p),   dgamma[k] = sum_m dz[m, k] xhat[m, k],   dbeta[k] = sum_m dz[m, k].
+// The tile of dz' stays in the accumulators: each lane multiplies its 64 values by the keep byte and the normalised feature
+// (x read once, coalesced: 32 lanes = 128 B of a row) and sums over its rows; lane halves, then the two waves that share the
+// columns, are combined and the workgroup writes ONE partial row per sum (part[row tile][k]) - no dz' in memory (201 MB written
+// and read back at the TVR batch), no LayerNorm backward pass over x and dz'.  A column sum over the row tiles finishes.
+struct LnGradArgs {
+    const float* x;              // [M, ldx] raw features
+    const unsigned char* keep;   // [M, ldx] dropout keep bytes or null
+    const float* mean;           // [M]
+    const float* rstd;           // [M]
+    float* part_g;               // [row tiles][N]
+    float* part_b;               // [row tiles][N]
+    int ldx;
+    float keep_scale;
+};
+
+template <typename Args>
+__device__ __forceinline__ void gemm_lngrad_tile(const f32x16 (&acc)[2][2], const Args& p, const LnGradArgs& la, int m0, int n0, int wm,
+                                                 int wn, int lane, int wave, float* lds_f) {
+    // Each 32 x 64 half of the wave's tile is parked in the wave's private LDS region (like gemm_store_tile) and read back
+    // row-wise: lane = (row rl = lane >> 4 (+ 4 per pass), 4 consecutive columns c4 = lane & 15), so x is read as float4 (16 lanes =
+    // 256 contiguous bytes of a row) and the keep bytes as one dword - the first version read them in the accumulator layout
+    // (4-byte and 1-byte accesses, 128 VMEM instructions per lane) and spent 165 us of 280 in this epilogue.
+    constexpr int SP = 72;
+    float* stg = lds_f + wave * (32 * SP);
+    float* red = lds_f + 4 * (32 * SP);                      // [4 waves][2 sums][64 columns] behind the staging regions
+    const int rl0 = lane >> 4, c4 = lane & 15;
+    const int col = n0 + wn + 4 * c4;
+    const bool vec = !(la.ldx & 3) && !((uintptr_t)la.x & 15) && col + 3 < p.N && (la.keep == nullptr || !((uintptr_t)la.keep & 3));
+    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SP + 32 * j + (lane & 31)] = acc[i][j][r];
+        f32x4 xv[8];
+        unsigned kw[8];
+        float mu[8], rs[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = m0 + wm + 32 * i + rl0 + 4 * it;
+            const int rowc = row < p.M ? row : p.M - 1;
+            const size_t at = (size_t)rowc * la.ldx + col;
+            mu[it] = la.mean[rowc];
+            rs[it] = row < p.M ? la.rstd[rowc] : 0.f;        // rows past the end: xhat = 0 and (below) dz = 0
+            kw[it] = 0x01010101u;
+            if (vec) {
+                xv[it] = *reinterpret_cast<const f32x4*>(la.x + at);
+                if (la.keep != nullptr) kw[it] = *reinterpret_cast<const unsigned*>(la.keep + at);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = col + e < p.N;
+                    xv[it][e] = ok ? la.x[at + e] : 0.f;
+                    if (la.keep != nullptr) kw[it] = (kw[it] & ~(0xffu << (8 * e))) | ((ok && la.keep[at + e] ? 1u : 0u) << (8 * e));
+                    else if (!ok) kw[it] &= ~(0xffu << (8 * e));
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const bool rok = m0 + wm + 32 * i + rl0 + 4 * it < p.M;
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(stg + (rl0 + 4 * it) * SP + 4 * c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dz = (rok && ((kw[it] >> (8 * e)) & 0xffu)) ? a4[e] * la.keep_scale : 0.f;
+                sg[e] += dz * ((xv[it][e] - mu[it]) * rs[it]);
+                sb[e] += dz;
+            }
+        }
+    }
+    // lanes l, l + 16, l + 32, l + 48 hold the same four columns (rows rl0 + 4 it): combine, then the wave that shares the columns
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sg[e] += __shfl_xor(sg[e], 16); sg[e] += __shfl_xor(sg[e], 32);
+        sb[e] += __shfl_xor(sb[e], 16); sb[e] += __shfl_xor(sb[e], 32);
+    }
+    float* mine = red + wave * 128;
+    if (lane < 16) {
+        *reinterpret_cast<f32x4*>(mine + 4 * c4) = sg;
+        *reinterpret_cast<f32x4*>(mine + 64 + 4 * c4) = sb;
+    }
+    __syncthreads();
+    if (wm == 0 && lane < 16) {
+        const float* other = red + (wave + 2) * 128;         // wave + 2: same columns, rows 64..127
+        const f32x4 og = *reinterpret_cast<const f32x4*>(other + 4 * c4), ob = *reinterpret_cast<const f32x4*>(other + 64 + 4 * c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (col + e >= p.N) continue;
+            la.part_g[(size_t)blockIdx.y * p.N + col + e] = sg[e] + og[e];
+            la.part_b[(size_t)blockIdx.y * p.N + col + e] = sb[e] + ob[e];
+        }
+    }
+}
+
 // ---- training simpool epilogue (simpool_train.hip): the batched GEMM S_v = G_v Q^T (one video per blockIdx.z, M = L <= 128 clips on
 // the tile rows, queries on the columns) ends in a key-clip max-pool instead of a store, so the (Nq, Nv, L) clip tensor of
 // get_sim_scores / get_unnormalized_sim_scores (reference method/model.py:307-350) is never written:
@@ -230,6 +329,9 @@ int gemm_f32x3_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor, int* 
 int gemm_bf16_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor, int* k_tiles_per_split);
 // pooled batched GEMMs (gemm_f32x3.hip / gemm_bf16.hip): g (nv, L, D), q (nq, D) -> the PoolArgs outputs
 int launch_simpool_pool_x3(const float* g, const float* q, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream);
+// dz' = dy W with the LayerNorm-parameter-gradient epilogue (gemm_lngrad_tile), per precision mode
+int launch_linear_lngrad_bf16(const float* dy, const float* W, long M, int N, int K, const LnGradArgs& la, void* stream);
+int launch_linear_lngrad_x3(const float* dy, const float* W, long M, int N, int K, const LnGradArgs& la, void* stream);
 int launch_simpool_pool_bf16(const float* g, const float* q, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream);
 int launch_splitk_reduce(const float* ws, float* out, int split, long n, hipStream_t s);
 // Every kernel launch of the library: drop whatever error another library left in the runtime's sticky per-thread slot

@@ -129,8 +129,9 @@ struct TileX {
     }
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool POOL>
-__device__ __forceinline__ void gemm_f32x3_body(GemmXArgs p, const PoolArgs* pa) {
+// EPI: 0 = store C, 1 = training simpool max-pool (PoolArgs), 2 = LayerNorm parameter gradients (LnGradArgs)
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, typename EArgs>
+__device__ __forceinline__ void gemm_f32x3_body(GemmXArgs p, const EArgs* pa) {
     __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][3 * XPLANE];   // [stage][A|B][plane][row][k]: 72 KiB
     if (p.split_k > 1) {
         p.C += (size_t)blockIdx.z * p.M * p.ldc;      // this split's partial plane in the workspace
@@ -216,17 +217,22 @@ __device__ __forceinline__ void gemm_f32x3_body(GemmXArgs p, const PoolArgs* pa)
         if (kt + 1 < nk) iter(kt + 1, S1{});
     }
     // (the k-loop ended with a barrier: every wave is done with the operand tiles, the LDS is free for staging)
-    if constexpr (POOL) gemm_pool_tile(acc, p, *pa, (int)blockIdx.z, n0, wm, wn, lane, wave, reinterpret_cast<float*>(&lds[0][0][0]));
+    if constexpr (EPI == 1) gemm_pool_tile(acc, p, *pa, (int)blockIdx.z, n0, wm, wn, lane, wave, reinterpret_cast<float*>(&lds[0][0][0]));
+    else if constexpr (EPI == 2) gemm_lngrad_tile(acc, p, *pa, m0, n0, wm, wn, lane, wave, reinterpret_cast<float*>(&lds[0][0][0]));
     else gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(&lds[0][0][0]) + wave * (32 * 72));
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256) void gemm_f32x3_kernel(GemmXArgs p) {
-    gemm_f32x3_body<A_KMAJOR, B_KMAJOR, false>(p, nullptr);
+    gemm_f32x3_body<A_KMAJOR, B_KMAJOR, 0, PoolArgs>(p, nullptr);
 }
 // training simpool: one video per blockIdx.z, max-pool epilogue (common.hpp, gemm_pool_tile)
 __global__ __launch_bounds__(256) void gemm_f32x3_pool_kernel(GemmXArgs p, PoolArgs pa) {
-    gemm_f32x3_body<false, false, true>(p, &pa);
+    gemm_f32x3_body<false, false, 1, PoolArgs>(p, &pa);
+}
+// dz' = dY W (the dX layout) with the LayerNorm-parameter-gradient epilogue: the parity-mode twin of gemm_bf16_lngrad_kernel
+__global__ __launch_bounds__(256) void gemm_f32x3_lngrad_kernel(GemmXArgs p, LnGradArgs la) {
+    gemm_f32x3_body<false, true, 2, LnGradArgs>(p, &la);
 }
 
 static int launch_gemm_x(GemmXArgs p, int batch, int a_kmajor, int b_kmajor, void* stream) {
@@ -237,6 +243,14 @@ static int launch_gemm_x(GemmXArgs p, int batch, int a_kmajor, int b_kmajor, voi
     else if (a_kmajor && b_kmajor) DLDKD_LAUNCH((gemm_f32x3_kernel<true, true>), grid, block, 0, s, p);
     else DLDKD_LAUNCH((gemm_f32x3_kernel<true, false>), grid, block, 0, s, p);
     return check_launch("gemm_f32x3");
+}
+
+int launch_linear_lngrad_x3(const float* dy, const float* W, long M, int N, int K, const LnGradArgs& la, void* stream) {
+    const int a_vec = !(N & 3) && !((uintptr_t)dy & 15);
+    GemmXArgs p{dy, W, nullptr, nullptr, (int)M, K, N, N, K, K, 0, a_vec, 0, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+    DLDKD_LAUNCH(gemm_f32x3_lngrad_kernel, dim3((K + XBN - 1) / XBN, (unsigned)((M + XBM - 1) / XBM), 1), dim3(256), 0,
+                 (hipStream_t)stream, p, la);
+    return check_launch("linear_lngrad (fp32x3)");
 }
 
 int launch_simpool_pool_x3(const float* g, const float* q, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream) {

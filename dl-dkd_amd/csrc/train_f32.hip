@@ -371,7 +371,7 @@ int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream) {
                            (hipStream_t)stream, x, out, M, N);
         return check_launch("colsum64");
     }
-    // few rows (the per-row-tile partial sums of dldkd_linear_lngrad_bf16: 128 x 3072): 64 rows per block left 24 workgroups
+    // few rows (the per-row-tile partial sums of dldkd_linear_lngrad: 128 x 3072): 64 rows per block left 24 workgroups
     // adding 64 dependent loads each (18 us); 8 rows per block is 192 workgroups
     const int rpb = M <= 256 ? 8 : 64;
     DLDKD_LAUNCH(colsum_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((M + rpb - 1) / rpb)), dim3(256), 0,

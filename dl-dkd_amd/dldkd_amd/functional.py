@@ -135,7 +135,7 @@ def layernorm(x, gamma, beta, add=None, add_mod=0, p_drop=0.0, training=False):
 class _InProjTrain(Function):
     """LinearLayer on RAW features in training, throughput mode (model_components.py:294-312): LayerNorm -> Dropout -> Linear ->
     ReLU as one autograd node.  The features need no gradient, so the backward pass never forms the Linear's input gradient: the
-    LayerNorm parameter gradients come out of the accumulators of dy W (dldkd_linear_lngrad_bf16) - one GEMM-with-epilogue
+    LayerNorm parameter gradients come out of the accumulators of dy W (dldkd_linear_lngrad) - one GEMM-with-epilogue
     instead of the dX GEMM (201 MB written at the TVR batch) plus a LayerNorm backward pass over x and that gradient."""
 
     @staticmethod
@@ -153,7 +153,7 @@ class _InProjTrain(Function):
             z = ops.layernorm(x2, gamma, beta)
         y = ops.linear(z, weight, bias, relu=relu)
         ctx.save_for_backward(x2, weight, z, y if relu else None, keep)
-        ctx.relu, ctx.has_bias, ctx.keep_scale = relu, bias is not None, 1.0 / (1.0 - p)
+        ctx.relu, ctx.has_bias, ctx.keep_scale, ctx.prec = relu, bias is not None, 1.0 / (1.0 - p), ops.gemm_precision()
         return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
@@ -174,7 +174,7 @@ class _InProjTrain(Function):
             tiles = (M + 127) // 128
             ws = torch.empty(2 * tiles * K, dtype=torch.float32, device=x2.device)
             dgb = torch.zeros(2, K, dtype=torch.float32, device=x2.device)
-            native.check(_L().dldkd_linear_lngrad_bf16(_p(dy2), _p(w), _p(x2), _p(keep), ctx.keep_scale, _p(stats[0]), _p(stats[1]),
+            native.check(_L().dldkd_linear_lngrad(ops._PREC_ID[ctx.prec], _p(dy2), _p(w), _p(x2), _p(keep), ctx.keep_scale, _p(stats[0]), _p(stats[1]),
                                                        _p(ws), ws.numel() * 4, _p(dgb[0]), _p(dgb[1]), M, N, K, _s()), "linear_lngrad")
             dg, dbeta = dgb[0], dgb[1]
         return None, dg, dbeta, dw, db, None, None
@@ -184,8 +184,9 @@ IN_PROJ_TRAIN_FUSED = True
 
 
 def in_proj_train_ok(x, weight):
-    """Throughput mode, training, features without a gradient, row statistics kernel limits (D % 4 == 0, D <= 4096)."""
-    return (IN_PROJ_TRAIN_FUSED and ops.gemm_precision() == "bf16" and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad
+    """Training, features without a gradient, a tiled-GEMM precision mode (bf16 or the three-plane fp32-grade one), row statistics
+    kernel limits (D % 4 == 0, D <= 4096)."""
+    return (IN_PROJ_TRAIN_FUSED and ops.gemm_precision() in ("bf16", "fp32", "fp32x3") and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad
             and x.shape[-1] % 4 == 0 and x.shape[-1] <= 4096 and weight.requires_grad)
 
 

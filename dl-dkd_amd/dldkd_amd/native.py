@@ -101,7 +101,7 @@ SIGNATURES = {
     "dldkd_in_proj_bf16_rows128_groups": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
                                                     _c_float, _c_int, _c_void_p, _c_long, _c_void_p]),
     "dldkd_row_meanrstd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_float, _c_void_p]),
-    "dldkd_linear_lngrad_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p,
+    "dldkd_linear_lngrad": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p,
                                            ctypes.c_size_t, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p]),
     "dldkd_fold_ln_linear_planes": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p,
                                              _c_void_p]),

@@ -225,15 +225,15 @@ int dldkd_in_proj_bf16_rows128_groups(const float* x, const void* Wfrag, const f
  *       inference path of parity mode. */
 int dldkd_row_meanrstd_f32(const float* x, float* mean, float* rstd, long M, int D, float eps, void* stream);
 /* Training backward of the input projection on RAW features (LinearLayer: LayerNorm -> Dropout -> Linear -> ReLU,
- * model_components.py:294-312; the features need no gradient), throughput mode: LayerNorm's parameter gradients straight from
- * the accumulators of dz' = dy W (bf16 MFMA, the dX layout of dldkd_gemm_bf16) - dz' is never written and no LayerNorm
+ * model_components.py:294-312; the features need no gradient): LayerNorm's parameter gradients straight from the accumulators of
+ * dz' = dy W (the dX layout of dldkd_gemm_bf16 / dldkd_gemm_f32x3; precision = DLDKD_GEMM_BF16 or DLDKD_GEMM_F32X3) - dz' is never written and no LayerNorm
  * backward pass runs over x:
  *     dz = dz' (.) keep * keep_scale,  dgamma[k] += sum_m dz[m,k] (x[m,k] - mean[m]) rstd[m],  dbeta[k] += sum_m dz[m,k].
  * dy (M, N) gradient behind the ReLU, W (N, K), x (M, K), keep (M, K) bytes of dldkd_layernorm_dropout_f32 or NULL, mean / rstd
  * from dldkd_row_meanrstd_f32; workspace >= 2 * ceil(M / 128) * K floats; dgamma / dbeta (K) zero-initialised by the caller. */
-int dldkd_linear_lngrad_bf16(const float* dy, const float* W, const float* x, const unsigned char* keep, float keep_scale,
-                             const float* mean, const float* rstd, float* workspace, size_t workspace_bytes, float* dgamma,
-                             float* dbeta, long M, int N, int K, void* stream);
+int dldkd_linear_lngrad(int precision, const float* dy, const float* W, const float* x, const unsigned char* keep, float keep_scale,
+                        const float* mean, const float* rstd, float* workspace, size_t workspace_bytes, float* dgamma,
+                        float* dbeta, long M, int N, int K, void* stream);
 int dldkd_fold_ln_linear_planes(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K, int n_offset,
                                 void* Wplanes, float* bb, void* stream);
 int dldkd_in_proj_f32x3_rows128(const float* x, const float* mean, const float* rstd, const void* Wplanes, const float* bb, float* y0,
