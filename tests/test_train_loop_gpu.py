@@ -334,3 +334,51 @@ def test_data_parallel_stepper_runs_the_step_as_a_chain_of_graph_segments(drop):
     finally:
         T.DDP_MIN_WORLD = old
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_tower_streams_at_c3_size_match_single_stream(prec):
+    """The stepper forks the four towers onto four streams (model._encode_towers) - at the TVR batch size (128 videos x 128
+    clips x 3072, 640 queries), where the towers' kernels really overlap.  40 steps, dropout on, three batches; before every step
+    the stepper's replica gets the single-stream eager replica's state, after it losses and parameters must agree to the
+    rounding of the fp32-atomic reductions.  A cross-stream race (a buffer recycled while another stream still reads it, a
+    missing join) shows up as a parameter off by far more than one Adam step can move it."""
+    import synth
+    from dldkd_amd import ops
+    from dldkd_amd import train as T
+    from dldkd_amd.model import DLDKD
+    from dldkd_amd.optimization import BertAdam
+    cfg = types.SimpleNamespace(visual_input_size=3072, query_input_size=768, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=128, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4, initializer_range=0.02,
+                                margin=0.1, use_hard_negative=True, hard_pool_size=20, label_style="soft")
+    mopt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                 collection="tvr", alpha=0.8, belta=0.8)
+    topt = types.SimpleNamespace(grad_clip=-1)
+    batches = [synth.make_train_batch(900 + i, nv=128, caps=5, L=128, len_lo=24, dv=3072, dq=768, lq_lo=6, lq_hi=30) for i in range(3)]
+    batches = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
+
+    def make():
+        torch.manual_seed(21)
+        m = DLDKD(types.SimpleNamespace(**vars(cfg)), mopt).to(DEV).train()
+        return m, BertAdam([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=3e-4, warmup=0.1, t_total=400)
+
+    ops.set_gemm_precision(prec)
+    try:
+        me, oe = make()
+        mg, og = make()
+        stepper = T.GraphedTrainStep(mg, og, topt)
+        assert mg.tower_streams and not me.tower_streams
+        worst = 0.0
+        for it in range(40):
+            og.fp.flat.copy_(oe.fp.flat); og.m.copy_(oe.m); og.v.copy_(oe.v); og.step_count = oe.step_count
+            torch.manual_seed(700 + it)
+            le, _ = T.train_step(me, batches[it % 3], oe, topt)
+            torch.manual_seed(700 + it)
+            lg, _ = stepper(batches[it % 3])
+            assert float(le.detach()) == pytest.approx(float(lg), rel=2e-5 if prec == "fp32" else 1e-3), it
+            d = (oe.fp.flat - og.fp.flat).abs().max().item()
+            worst = max(worst, d)
+            assert d <= (2e-7 if prec == "fp32" else 2e-5) + 0.05 * og.get_lr()[0], (it, d)
+        assert stepper.replays >= 38
+    finally:
+        ops.set_gemm_precision("fp32")
