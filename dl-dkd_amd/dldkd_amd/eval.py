@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
-from . import native, scoring
+from . import native, ops, scoring
 from .data import collate_frame_val, collate_text_val, host_threads
 
 logger = logging.getLogger(__name__)
@@ -120,6 +120,23 @@ def perf_from_ranks(rank_best, rank_first, n_q):
 
 
 CONTEXT_SUPER_BATCH = 1024
+TOWER_ITEM_BUDGET = 768        # slot groups of the fused tower kernel per super-batch: 3 rounds of the 256 CUs per branch
+
+
+def _tiles(lens_list):
+    return int(sum(int(((l + 31) // 32).sum()) for l in lens_list))
+
+
+def _take_for_budget(lens, budget):
+    """The longest prefix of the pending videos whose slot groups (ops.plan_tower_items) fit the budget."""
+    cum = np.cumsum((lens + 31) // 32)
+    n = int(np.searchsorted(cum, 4 * budget, side="right"))
+    while n > 1:
+        over = len(ops.plan_tower_items(lens[:n])) - budget
+        if over <= 0:
+            break
+        n -= max(1, over)                  # a video is at least one tile: dropping `over` videos frees at most 4 x over slots
+    return max(n, 1)
 
 
 def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
@@ -136,14 +153,40 @@ def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
     metas, inh, exp, masks = [], [], [], []
     packer = None
     pend_f, pend_m, pend_l, pend_n = [], [], [], 0
+    fused_path = not keep_frame_feats and getattr(model, "fast_input_proj", False) and ops.TOWER_SEQ
 
-    def flush():
-        """encode the pending loader batches as ONE super-batch (zero-padded to its longest video; padded clips are
-        masked out of attention exactly): at eval_context_bsz = 200 a batch is 200 workgroups of 128 rows on 256 CUs, so
-        every tower kernel runs a single partly-filled round; 1024 videos give four full ones"""
+    def split_pending(take):
+        """(first `take` pending videos, the rest), cutting a loader batch in two where the boundary falls inside it"""
+        head, tail, n = ([], [], []), ([], [], []), 0
+        for f, m_, l in zip(pend_f, pend_m, pend_l):
+            k = min(max(take - n, 0), f.shape[0])
+            if k > 0:
+                head[0].append(f[:k]); head[1].append(m_[:k]); head[2].append(l[:k])
+            if k < f.shape[0]:
+                tail[0].append(f[k:]); tail[1].append(m_[k:]); tail[2].append(l[k:])
+            n += f.shape[0]
+        return head, tail
+
+    def flush(take=None):
+        """encode the pending loader batches (their first `take` videos) as ONE super-batch (zero-padded to its longest video;
+        padded clips are masked out of attention exactly): at eval_context_bsz = 200 a batch is 200 workgroups of 128 rows on 256
+        CUs, so every tower kernel runs a single partly-filled round; 1024 videos give four full ones"""
         nonlocal pend_f, pend_m, pend_l, pend_n, packer
         if not pend_f:
             return
+        rest = None
+        if take is not None and take < pend_n:
+            (pend_f, pend_m, pend_l), rest = split_pending(take)
+            pend_n = take
+        try:
+            flush_all()
+        finally:
+            if rest is not None:
+                pend_f, pend_m, pend_l = rest
+                pend_n = sum(f.shape[0] for f in pend_f)
+
+    def flush_all():
+        nonlocal pend_f, pend_m, pend_l, pend_n, packer
         if len(pend_f) == 1:
             feat, mask = pend_f[0], pend_m[0]
         else:
@@ -194,7 +237,13 @@ def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
             pend_f.append(batch[0].to(opt.device, non_blocking=True))
             pend_m.append(batch[1].to(opt.device, non_blocking=True))
             pend_n += batch[0].shape[0]
-            if pend_n >= CONTEXT_SUPER_BATCH:
+            if fused_path:
+                # the fused tower kernel runs one workgroup per (four 32-clip slots, branch) and owns a CU: cut the super-batches
+                # where the planned workgroups fill whole rounds of the chip (1024 ragged videos planned to 773 slot groups = 6.04
+                # rounds per branch pair: a seventh round for 10 workgroups, +13 % of the kernel)
+                while pend_n and _tiles(pend_l) >= 4 * TOWER_ITEM_BUDGET:
+                    flush(_take_for_budget(np.concatenate(pend_l), TOWER_ITEM_BUDGET))
+            elif pend_n >= CONTEXT_SUPER_BATCH:
                 flush()
         flush()
 

@@ -37,6 +37,9 @@ def stage_times(nv=21793, nq=10895, mode="fp32", dev="cuda:0", B=None):
             mask = (torch.arange(L, device=dev).unsqueeze(0) < lens.unsqueeze(1)).float()
             feats = feats * mask.unsqueeze(-1)
             lens_host = lens.cpu().numpy()                       # eval.py has them from the loader's CPU mask
+            if mode == "fast":                                   # eval.py cuts super-batches where the tower kernel's workgroups fill whole rounds
+                B = ev._take_for_budget(lens_host, ev.TOWER_ITEM_BUDGET)
+                out["videos_per_super_batch"] = int(B)
 
             def encode(pk_, n):                                  # what compute_context_info's flush() does per super-batch
                 if not (mode == "fast" and m.encode_context_into(pk_, feats[:n], mask[:n], lens_host=lens_host[:n])):
