@@ -424,6 +424,10 @@ class DLDKD(nn.Module):
         labels = batch["text_labels"]
         mask = batch["student_videos_mask"].float()
         dev = mask.device
+        if self.training and torch.is_grad_enabled() and mask.is_cuda:
+            F_.begin_zero_arena(dev)          # one fill for the step's small zero-initialised gradient buffers
+        else:
+            F_.end_zero_arena()
         lab = staged.labels_dev if staged is not None else torch.as_tensor(np.asarray(labels), dtype=torch.int32, device=dev)
         nv, L = mask.shape
         lens = self._lens(mask, nv, L, dev)

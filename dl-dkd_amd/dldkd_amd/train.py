@@ -148,7 +148,17 @@ def train_step(model, batch, optimizer, opt, comm_stream=None):
     if getattr(opt, "grad_clip", -1) != -1:
         torch.nn.utils.clip_grad_norm_(model.parameters(), opt.grad_clip)
     optimizer.step()
+    _end_zero_arena()
     return loss, loss_dict
+
+
+def _end_zero_arena():
+    """The step's zero arena (functional.begin_zero_arena, opened by DLDKD.forward_tensors) is closed with the step: later
+    autograd calls outside a training step must not carve from it."""
+    import sys
+    f = sys.modules.get(__package__ + ".functional")
+    if f is not None:
+        f.end_zero_arena()
 
 
 class _CapturedStep:
@@ -410,6 +420,7 @@ class GraphedTrainStep:
                 ddist.sync_gradients(opt_.fp, comm_stream=self.comm_stream)
                 opt_.enqueue(upload_lr=False)
         ops.bump_param_epoch()
+        _end_zero_arena()
         self.replays += 1
         out = dict(e.parts)
         loss_overall = e.loss if self.defer else float(e.loss)
