@@ -146,3 +146,54 @@ def test_checkpoint_round_trip(tmp_path):
     m2.load_state_dict(ck["model"])
     for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1.cpu(), v2.cpu())
+
+
+def test_single_branch_model_throughput_paths_and_stepper():
+    """double_branch = False through the round-3 paths: the fused gallery encode (K4 round-1 kernel + the tower kernel with one
+    branch) and the fused query tower against the parity-mode towers; the graph stepper with two tower streams and two
+    gradient-bucket candidates against the eager step."""
+    from dldkd_amd import ops, scoring
+    from dldkd_amd import train as T
+    from dldkd_amd.optimization import BertAdam
+    m = _mk(double_branch=False, drop=0.1)
+    assert len(m.grad_buckets()) == 2
+    batch = synth.make_train_batch(14, nv=40, caps=2, L=64, len_lo=5, dv=1024, dq=1024)
+    batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    vid, vmask = batch["student_videos"], batch["student_videos_mask"]
+    m.eval()
+    with torch.no_grad():
+        gi, _ = m.encode_context(vid, vmask)
+        qi, _ = m.encode_query(batch["student_text"], batch["student_text_mask"])
+        ref = m.pooled_scores([qi], [gi], vmask)[0]
+        ops.set_gemm_precision("bf16")
+        m.fast_input_proj = True
+        try:
+            pk = scoring.GalleryPacker(vid.shape[0], 64, 1, torch.device(DEV))
+            lens_host = (vmask > 0).sum(1).cpu().numpy()
+            assert m.encode_context_into(pk, vid, vmask, lens_host=lens_host)
+            qf, qn = m.encode_query(batch["student_text"], batch["student_text_mask"])
+            assert qn is None
+            got = m.pooled_scores([qf], pk.finish())[0]
+        finally:
+            ops.set_gemm_precision("fp32")
+            m.fast_input_proj = False
+    assert (got - ref).abs().max().item() < 3e-2
+    # training: stepper (two tower streams) == eager, step by step
+    topt = types.SimpleNamespace(grad_clip=-1)
+
+    def make():
+        mm = _mk(double_branch=False, drop=0.1).train()
+        return mm, BertAdam([{"params": list(mm.parameters()), "weight_decay": 0.01}], lr=1e-3, warmup=0.1, t_total=50)
+    me, oe = make()
+    mg, og = make()
+    stepper = T.GraphedTrainStep(mg, og, topt)
+    for it in range(6):
+        og.fp.flat.copy_(oe.fp.flat); og.m.copy_(oe.m); og.v.copy_(oe.v); og.step_count = oe.step_count
+        torch.manual_seed(40 + it)
+        le, de = T.train_step(me, stepper._bucketed(batch), oe, topt)
+        torch.manual_seed(40 + it)
+        lg, dg = stepper(batch)
+        assert float(le.detach()) == pytest.approx(float(lg), rel=1e-5)
+        assert dg["explore_trip"] == 0 and dg["explore_nce"] == 0
+        assert (oe.fp.flat - og.fp.flat).abs().max().item() <= 2e-7 + 0.02 * og.get_lr()[0]
+    assert stepper.replays == 5
