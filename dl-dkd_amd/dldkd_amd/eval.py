@@ -9,6 +9,7 @@ is on the hot path.  Differences in HOW (not in what is returned):
 """
 import contextlib
 import logging
+import weakref
 
 import numpy as np
 import torch
@@ -119,6 +120,54 @@ def perf_from_ranks(rank_best, rank_first, n_q):
     return (r1, r5, r10, r100, medr, meanr, m)
 
 
+# ---- device-resident raw features of the evaluation datasets.  train() evaluates the SAME validation videos and captions after
+# every epoch; their raw features never change, only the towers do.  From host memory an eval epoch is PCIe-bound 10-35 : 1
+# (0.6-2.1 s of pinned H2D for the TVR gallery against 0.044 s of GPU work), so the loader batches of the first
+# pass stay on the device (34 GB of fp32 clips for TVR's 21,793 videos: 12 % of the 288 GB) and later passes replay them without
+# touching the DataLoader.  opt.eval_feature_cache = False turns it off; opt.eval_feature_cache_gb caps it (default 96).
+_FEATURE_CACHE = weakref.WeakKeyDictionary()          # dataset -> {kind: [device batches]}
+
+
+def clear_feature_cache():
+    _FEATURE_CACHE.clear()
+
+
+def _cached_batches(dataset, kind, n_items, opt, make_loader, to_device):
+    """Generator of the dataset's loader batches as device tuples: from the cache when this dataset (`kind` names the part of
+    it: "text", "video", or a rank's ("video", lo, hi) shard) has been through before, otherwise from the DataLoader (and into the
+    cache while it fits the cap)."""
+    dev = torch.device(opt.device)
+    use = bool(getattr(opt, "eval_feature_cache", True)) and dev.type == "cuda"
+    try:
+        slot = _FEATURE_CACHE.setdefault(dataset, {}) if use else None
+    except TypeError:                                   # a dataset object that cannot be weakly referenced
+        slot = None
+    if slot is not None and kind in slot and slot[kind]["complete"] and slot[kind]["n"] == n_items \
+            and slot[kind]["device"] == dev:
+        # a DataLoader iterator draws its base seed from the global CPU generator when it is created: keep that draw, so that
+        # a training run sees the same random stream (triplet negatives, shuffles) with and without the cache
+        torch.empty((), dtype=torch.int64).random_()
+        yield from slot[kind]["batches"]
+        return
+    cap = float(getattr(opt, "eval_feature_cache_gb", 96.0)) * 1e9
+    entry = {"batches": [], "bytes": 0, "complete": False, "n": n_items, "device": dev}
+    keep = slot is not None
+    for batch in make_loader():
+        b = to_device(batch)
+        if keep:
+            nbytes = sum(t.numel() * t.element_size() for t in b if torch.is_tensor(t))
+            total = sum(k["bytes"] for d in _FEATURE_CACHE.values() for k in d.values()) + entry["bytes"] + nbytes
+            if total > cap:
+                keep, entry = False, {"batches": [], "bytes": 0, "complete": False, "n": n_items, "device": dev}
+            else:
+                entry["batches"].append(b)
+                entry["bytes"] += nbytes
+        yield b
+    if keep:
+        entry["complete"] = True
+        slot[kind] = entry
+
+
 CONTEXT_SUPER_BATCH = 1024
 TOWER_ITEM_BUDGET = 768        # slot groups of the fused tower kernel per super-batch: 3 rounds of the 256 CUs per branch
 
@@ -139,7 +188,7 @@ def _take_for_budget(lens, budget):
     return max(n, 1)
 
 
-def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
+def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True, cache_owner=None, cache_kind="video"):
     """Encode the gallery in batches of eval_context_bsz, zero-pad to the global max length, concatenate
     (eval.py:114-175).  Adds `_packed`: the resident bf16 gallery the scorer consumes.
 
@@ -230,13 +279,18 @@ def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True):
         masks.append(mask)
         pend_f, pend_m, pend_l, pend_n = [], [], [], 0
 
+    def to_device(batch):       # (features, mask, lengths on the host - the loader's mask is a CPU tensor -, metas)
+        return (batch[0].to(opt.device, non_blocking=True), batch[1].to(opt.device, non_blocking=True),
+                (batch[1] > 0).sum(1).numpy(), list(batch[-1]))
+
     with torch.no_grad(), host_threads():
-        for batch in loader:
-            metas.extend(batch[-1])
-            pend_l.append((batch[1] > 0).sum(1).numpy())           # lengths on the host (the loader's mask is a CPU tensor)
-            pend_f.append(batch[0].to(opt.device, non_blocking=True))
-            pend_m.append(batch[1].to(opt.device, non_blocking=True))
-            pend_n += batch[0].shape[0]
+        for feat_d, mask_d, lens_h, meta in _cached_batches(cache_owner if cache_owner is not None else eval_dataset, cache_kind,
+                                                             len(eval_dataset), opt, lambda: loader, to_device):
+            metas.extend(meta)
+            pend_l.append(lens_h)
+            pend_f.append(feat_d)
+            pend_m.append(mask_d)
+            pend_n += feat_d.shape[0]
             if fused_path:
                 # the fused tower kernel runs one workgroup per (four 32-clip slots, branch) and owns a CU: cut the super-batches
                 # where the planned workgroups fill whole rounds of the chip (1024 ragged videos planned to 773 slot groups = 6.04
@@ -303,12 +357,15 @@ def _encode_all_queries(model, eval_dataset, opt):
             qe.append(b.reshape(pend_n, -1))
         pend_f, pend_m, pend_n = [], [], 0
 
+    def to_device(batch):
+        return (batch[0].to(opt.device, non_blocking=True), batch[1].to(opt.device, non_blocking=True), list(batch[-1]))
+
     with torch.no_grad(), host_threads():
-        for batch in loader:
-            metas.extend(batch[-1])
-            pend_f.append(batch[0].to(opt.device, non_blocking=True))
-            pend_m.append(batch[1].to(opt.device, non_blocking=True))
-            pend_n += batch[0].shape[0]
+        for feat_d, mask_d, meta in _cached_batches(eval_dataset, "text", len(eval_dataset), opt, lambda: loader, to_device):
+            metas.extend(meta)
+            pend_f.append(feat_d)
+            pend_m.append(mask_d)
+            pend_n += feat_d.shape[0]
             if pend_n >= QUERY_SUPER_BATCH:
                 flush()
         flush()
@@ -374,7 +431,9 @@ def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=Fal
     n_videos = len(val_video_dataset)
     lo, hi, _ = ddist.shard_range(n_videos, rank, world)
     with eval_precision(model, opt):
-        ctx = compute_context_info(model, Subset(val_video_dataset, range(lo, hi)), opt, keep_frame_feats=False)
+        # (the shard is a fresh Subset object every epoch: its cached features are filed under the gallery dataset itself)
+        ctx = compute_context_info(model, Subset(val_video_dataset, range(lo, hi)), opt, keep_frame_feats=False,
+                                   cache_owner=val_video_dataset, cache_kind=("video", lo, hi))
         query_metas, qs = _encode_all_queries(model, val_text_dataset, opt)
     video_metas = gallery_ids(val_video_dataset) if world > 1 else ctx["video_metas"]
     _, t2v_gt = get_gt(video_metas, query_metas)

@@ -291,3 +291,46 @@ def test_sharded_ranks_from_partial_planes_equal_unsharded(nq, nv, L, cuts):
     ranks = torch.where(worst, torch.full_like(ranks, nv + 1), ranks).cpu()
     assert torch.equal(ranks, want)
     assert int(want[2, 0, 7]) == nv + 1                          # the NaN query ranks last on both paths
+
+
+def test_eval_feature_cache_replays_without_the_loader():
+    """train() evaluates the same validation sets after every epoch: the raw features of the first pass stay on the device and
+    later passes never touch the datasets (eval.py _cached_batches).  Same SumR before and after a weight change as with the
+    cache off; the second epoch reads no item; another dataset object, a changed length, or the cap miss the cache."""
+    from dldkd_amd import eval as ev
+
+    class Counting(synth.ListDataset):
+        reads = 0
+
+        def __getitem__(self, i):
+            type(self).reads += 1
+            return super().__getitem__(i)
+
+    ev.clear_feature_cache()
+    m = _model(3072, 768, synth.make_params(53, 3072, 768))
+    vids, txts = synth.make_eval_sets(7, nv=40, caps=2, dv=3072, dq=768)
+    dv, dt = Counting(list(vids)), Counting(list(txts))
+    opt = _opt()
+    opt.eval_precision = "throughput"
+    off = types.SimpleNamespace(**vars(opt), eval_feature_cache=False)
+    with torch.no_grad():
+        ref1 = ev.eval_epoch(m, dv, dt, off)
+        Counting.reads = 0
+        s1 = ev.eval_epoch(m, dv, dt, opt)                  # fills the cache
+        assert Counting.reads == 40 + 80
+        s2 = ev.eval_epoch(m, dv, dt, opt)                  # replays it
+        assert Counting.reads == 40 + 80 and s1 == s2 == ref1
+        for p in m.parameters():                             # "an epoch of training"
+            p.data.mul_(1.01)
+        s3 = ev.eval_epoch(m, dv, dt, opt)
+        assert Counting.reads == 40 + 80 and s3 == ev.eval_epoch(m, dv, dt, off)
+        n = Counting.reads
+        ev.eval_epoch(m, Counting(list(vids)), dt, opt)      # another gallery object: its own entry
+        assert Counting.reads == n + 40
+        tiny = types.SimpleNamespace(**vars(opt), eval_feature_cache_gb=1e-6)
+        ev.clear_feature_cache()
+        ev.eval_epoch(m, dv, dt, tiny)
+        n = Counting.reads
+        ev.eval_epoch(m, dv, dt, tiny)                        # nothing fitted under the cap: read again
+        assert Counting.reads == n + 120
+    ev.clear_feature_cache()
