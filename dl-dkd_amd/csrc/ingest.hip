@@ -46,9 +46,45 @@ __global__ __launch_bounds__(256) void upload_words_kernel(const int32_t* __rest
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = __builtin_nontemporal_load(src + i);
 }
 
+// Batch assembly from device-resident ragged tables (data.DeviceTrainSet): out[b, l, :] = src[row_start[items[b]] + l, :] for
+// l < lens[items[b]], zeros beyond, mask[b, l] = 1 / 0 - what the reference's collate (pad to the longest item + mask,
+// data_provider.py:75-86,111-136) produces on the host, followed by an H2D copy of the padded batch.  One wave per output row.
+__global__ __launch_bounds__(256) void gather_pad_rows_kernel(const float* __restrict__ src, const long long* __restrict__ row_start,
+                                                              const int32_t* __restrict__ lens, const int32_t* __restrict__ items,
+                                                              float* __restrict__ out, float* __restrict__ mask, long n_rows, int Lmax,
+                                                              int D) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int b = (int)(r / Lmax), l = (int)(r - (long)b * Lmax);
+    const int it = items[b];
+    const bool valid = l < lens[it];
+    if (mask != nullptr && lane == 0) mask[r] = valid ? 1.f : 0.f;
+    f32x4* o = reinterpret_cast<f32x4*>(out + r * D);
+    const int nv = D >> 2;
+    if (valid) {
+        const f32x4* s = reinterpret_cast<const f32x4*>(src + (size_t)(row_start[it] + l) * D);
+        for (int c = lane; c < nv; c += 64) o[c] = s[c];
+    } else {
+        for (int c = lane; c < nv; c += 64) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 }  // namespace dldkd
 
 using namespace dldkd;
+
+extern "C" int dldkd_gather_pad_rows_f32(const float* src, const long long* row_start, const int32_t* lens, const int32_t* items,
+                                         int n_items, int Lmax, int D, float* out, float* mask, void* stream) {
+    if (n_items < 0 || Lmax < 0 || D < 4 || (D & 3)) { set_error("gather_pad_rows: bad sizes (D must be a multiple of 4)"); return DLDKD_EINVAL; }
+    const long n_rows = (long)n_items * Lmax;
+    if (n_rows == 0) return DLDKD_OK;
+    if (!src || !row_start || !lens || !items || !out) { set_error("gather_pad_rows: null pointer"); return DLDKD_EINVAL; }
+    if (((uintptr_t)src | (uintptr_t)out) & 15) { set_error("gather_pad_rows: unaligned buffer"); return DLDKD_EINVAL; }
+    DLDKD_LAUNCH(gather_pad_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, row_start, lens,
+                       items, out, mask, n_rows, Lmax, D);
+    return check_launch("gather_pad_rows");
+}
 
 extern "C" int dldkd_upload_words(const int32_t* pinned_src, int32_t* dst, long n_words, void* stream) {
     if (n_words < 0) { set_error("upload_words: bad size"); return DLDKD_EINVAL; }

@@ -73,3 +73,131 @@ def collate_train(data):
     return dict(student_videos=student_videos, teacher_videos=teacher_videos, student_videos_mask=student_mask,
                 student_text=student_text, student_text_mask=student_text_mask, teacher_text=teacher_text,
                 text_labels=labels)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Device-resident training set (the callers of the hot path).  The reference reads, pads and uploads every
+# training item again in every epoch (DataLoader -> collate_train -> .to(device): ~200 MB of padded clips per TVR batch over
+# PCIe, after a host-side pad of 128 ragged videos), although the items never change.  Here every item is read ONCE into ragged
+# row tables on the device (TVR: 17,435 videos x <= 128 clips x 3072 fp32 = 27 GB of 288), and a batch is a gather from those
+# tables by a kernel: the tensors collate_train + .to(device) would have produced, bit for bit, in the same order.
+class DeviceTrainSet:
+    TABLES = ("student_videos", "teacher_videos", "student_text", "teacher_text")
+
+    def __init__(self, dataset, device, num_workers=0, cap_gb=160.0):
+        import numpy as np
+        from torch.utils.data import DataLoader
+        self.device = torch.device(device)
+        rows = {k: [] for k in self.TABLES}
+        lens = {k: [] for k in self.TABLES}
+        self.caps_of = []                       # per video: (first caption, number of captions)
+        loader = DataLoader(dataset, batch_size=64, shuffle=False, num_workers=num_workers, collate_fn=lambda x: x)
+        rng = torch.get_rng_state()             # the reading pass must not move the run's random stream (a DataLoader iterator
+        try:                                    # draws its base seed from the global generator)
+            chunks = list(self._read(loader, rows, lens, cap_gb))
+        finally:
+            torch.set_rng_state(rng)
+        n_caps = chunks[-1] if chunks else 0
+        self._finish(rows, lens, n_caps)
+
+    def _read(self, loader, rows, lens, cap_gb):
+        n_caps, nbytes = 0, 0
+        for chunk in loader:                    # 64 items at a time: host memory holds one chunk, the device the tables
+            part = {k: [] for k in self.TABLES}
+            for item in chunk:
+                s_vid, caps, t_vid, t_caps = item[0], item[1], item[2], item[3]
+                for k, seqs in (("student_videos", [s_vid]), ("teacher_videos", [t_vid]), ("student_text", caps), ("teacher_text", t_caps)):
+                    for a in seqs:
+                        a = torch.as_tensor(a, dtype=torch.float32)
+                        part[k].append(a)
+                        lens[k].append(int(a.shape[0]))
+                        nbytes += a.numel() * 4
+                if len(caps) != len(t_caps):
+                    raise ValueError("DeviceTrainSet: an item's caption and teacher-caption lists differ in length")
+                self.caps_of.append((n_caps, len(caps)))
+                n_caps += len(caps)
+            if nbytes > cap_gb * 1e9:
+                raise MemoryError(f"DeviceTrainSet: the training set exceeds the {cap_gb} GB cap")
+            for k in self.TABLES:
+                if part[k]:
+                    rows[k].append(torch.cat(part[k], 0).to(self.device))
+            yield n_caps
+
+    def _finish(self, rows, lens, n_caps):
+        import numpy as np
+        self.n_videos, self.n_caps = len(self.caps_of), n_caps
+        self.lens_host = {k: np.asarray(v, dtype=np.int32) for k, v in lens.items()}
+        self.src, self.row_start, self.lens_dev, self.dim = {}, {}, {}, {}
+        for k in self.TABLES:
+            if not rows[k]:
+                raise ValueError("DeviceTrainSet: empty dataset")
+            self.dim[k] = int(rows[k][0].shape[1])
+            if self.dim[k] % 4:
+                raise ValueError("DeviceTrainSet: feature widths must be multiples of 4")
+            self.src[k] = rows[k][0] if len(rows[k]) == 1 else torch.cat(rows[k], 0)
+            start = np.zeros(len(lens[k]), dtype=np.int64)
+            start[1:] = np.cumsum(self.lens_host[k][:-1], dtype=np.int64)
+            self.row_start[k] = torch.from_numpy(start).to(self.device)
+            self.lens_dev[k] = torch.from_numpy(self.lens_host[k]).to(self.device)
+            rows[k] = None
+        self.n_caps_of = np.asarray([c for _, c in self.caps_of], dtype=np.int64)
+        self._ring = None
+
+    def __len__(self):
+        return self.n_videos
+
+    def _gather(self, k, items_dev, items_host):
+        from . import native
+        lmax = int(self.lens_host[k][items_host].max())
+        n, D = len(items_host), self.dim[k]
+        out = torch.empty(n, lmax, D, dtype=torch.float32, device=self.device)
+        mask = torch.empty(n, lmax, dtype=torch.float32, device=self.device)
+        native.check(native.lib().dldkd_gather_pad_rows_f32(native.ptr(self.src[k]), native.ptr(self.row_start[k]), native.ptr(self.lens_dev[k]),
+                                                            native.ptr(items_dev), n, lmax, D, native.ptr(out), native.ptr(mask),
+                                                            native.stream()), "gather_pad_rows")
+        return out, mask
+
+    def batch(self, indices):
+        """The training batch of dataset items `indices` (in sampler order): collate_train's dict with device tensors."""
+        import numpy as np
+        from .staging import PinnedRing
+        idx = np.asarray(indices, dtype=np.int64)
+        order = np.argsort(-self.n_caps_of[idx], kind="stable")        # most captions first, ties in sampler order (sorted() is stable)
+        vids = idx[order]
+        caps = np.concatenate([np.arange(self.caps_of[v][0], self.caps_of[v][0] + self.caps_of[v][1]) for v in vids])
+        labels = [vi for vi, v in enumerate(vids) for _ in range(self.caps_of[v][1])]
+        # one upload for both index lists (pinned slot read by a kernel: staging.PinnedRing / dldkd_upload_words)
+        both = np.concatenate([vids, caps]).astype(np.int32)
+        if self._ring is None or self._ring.bufs[0].numel() < both.nbytes:
+            self._ring = PinnedRing(max(both.nbytes, 1 << 16), self.device, slots=8)
+        slot = self._ring.next()
+        slot[:both.nbytes].view(torch.int32).copy_(torch.from_numpy(both))
+        dev = torch.empty(both.nbytes, dtype=torch.uint8, device=self.device)
+        self._ring.upload(dev, by_kernel=True)
+        dev = dev.view(torch.int32)
+        v_dev, c_dev = dev[:len(vids)], dev[len(vids):]
+        sv, sm = self._gather("student_videos", v_dev, vids)
+        tv, _ = self._gather("teacher_videos", v_dev, vids)
+        st, stm = self._gather("student_text", c_dev, caps)
+        tt, _ = self._gather("teacher_text", c_dev, caps)
+        return dict(student_videos=sv, teacher_videos=tv, student_videos_mask=sm, student_text=st, student_text_mask=stm,
+                    teacher_text=tt, text_labels=labels)
+
+
+class DeviceTrainLoader:
+    """Iterates DeviceTrainSet batches in the order - and with the random draws - of the DataLoader it stands in for: an index-only
+    DataLoader with the same batch size / shuffle / sampler produces the index lists (same base-seed and permutation draws from the
+    global generator), the batches themselves are gathered on the device."""
+
+    def __init__(self, devset, batch_size, shuffle=True, sampler=None):
+        from torch.utils.data import DataLoader
+        self.devset, self.sampler = devset, sampler
+        self._index_loader = DataLoader(range(len(devset)), batch_size=batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
+                                        num_workers=0, collate_fn=lambda x: [int(i) for i in x])
+
+    def __len__(self):
+        return len(self._index_loader)
+
+    def __iter__(self):
+        for idx in self._index_loader:
+            yield self.devset.batch(idx)

@@ -439,6 +439,16 @@ def make_train_loader(train_dataset, opt, rank=None, world=None):
         from torch.utils.data.distributed import DistributedSampler
         sampler = DistributedSampler(train_dataset, num_replicas=world, rank=rank, shuffle=True, seed=int(getattr(opt, "seed", 0) or 0),
                                      drop_last=False)
+    if getattr(opt, "device_resident_train", False) and torch.device(getattr(opt, "device", "cpu")).type == "cuda":
+        # the training set read once into ragged tables on the device, batches gathered there (data.DeviceTrainSet): same
+        # batches in the same order with the same random draws, no per-epoch DataLoader / pad / H2D
+        from .data import DeviceTrainLoader, DeviceTrainSet
+        if sampler is not None:
+            sampler = DistributedSampler(range(len(train_dataset)), num_replicas=world, rank=rank, shuffle=True,
+                                         seed=int(getattr(opt, "seed", 0) or 0), drop_last=False)
+        devset = DeviceTrainSet(train_dataset, opt.device, num_workers=opt.num_workers,
+                                cap_gb=float(getattr(opt, "train_feature_cache_gb", 160.0)))
+        return DeviceTrainLoader(devset, opt.bsz, shuffle=True, sampler=sampler)
     return DataLoader(train_dataset, batch_size=opt.bsz, shuffle=sampler is None, sampler=sampler, pin_memory=opt.pin_memory,
                       num_workers=opt.num_workers, collate_fn=collate_train)
 

@@ -524,6 +524,13 @@ int dldkd_debug_tower_seq_timeline(const float* const* h0, const void* const* bl
 int dldkd_segment_mean_l2norm_f32(const float* frames, const int32_t* seg_start, const int32_t* seg_end, float* out,
                                   long n_rows, int D, float eps, void* stream);
 
+/* Batch assembly from device-resident ragged feature tables (dldkd_amd.data.DeviceTrainSet): replaces the host-side padding of
+ * collate_train / collate_frame_val (method/data_provider.py:75-86,111-136) and the H2D copy of the padded batch.
+ * src (total_rows, D) fp32; item i owns rows [row_start[i], row_start[i] + lens[i]); out (n_items, Lmax, D):
+ * out[b, l] = src row row_start[items[b]] + l for l < lens[items[b]], zeros beyond; mask (n_items, Lmax) = 1 / 0 or NULL. */
+int dldkd_gather_pad_rows_f32(const float* src, const long long* row_start, const int32_t* lens, const int32_t* items, int n_items,
+                              int Lmax, int D, float* out, float* mask, void* stream);
+
 /* Upload of a small host-produced int32 table (the slot and row-group tables of dldkd_tower_seq_bf16 /
  * dldkd_in_proj_bf16_rows128_groups; nothing in the reference) by a kernel: pinned_src is page-locked, device-mapped host
  * memory (hipHostMalloc / torch pin_memory), read over the bus on the compute queue - no copy-engine hand-off.  The caller keeps

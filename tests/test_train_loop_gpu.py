@@ -382,3 +382,62 @@ def test_tower_streams_at_c3_size_match_single_stream(prec):
         assert stepper.replays >= 38
     finally:
         ops.set_gemm_precision("fp32")
+
+
+def test_device_resident_train_set_yields_the_collated_batches():
+    """data.DeviceTrainSet / DeviceTrainLoader (the training items read once into ragged device tables, batches gathered by
+    dldkd_gather_pad_rows_f32) against DataLoader + collate_train + .to(device): the same batches - tensors bit for bit, labels,
+    order - epoch after epoch under the same seed (the index-only DataLoader makes the same draws from the global generator),
+    with variable caption counts (collate_train's stable most-captions-first order) and a ragged last batch."""
+    from torch.utils.data import DataLoader
+    from dldkd_amd.data import DeviceTrainLoader, DeviceTrainSet, collate_train
+    ds = TinySet(n=37)
+    g = torch.Generator().manual_seed(3)
+    for i in range(0, 37, 3):                     # a third caption on some videos, one caption on others
+        it = list(ds.items[i])
+        if i % 2:
+            it[1], it[3], it[5] = it[1][:1], it[3][:1], it[5][:1]
+        else:
+            it[1] = it[1] + [torch.nn.functional.normalize(torch.randn(7, it[1][0].shape[1], generator=g), dim=-1)]
+            it[3] = it[3] + [it[3][0] * 0.5]
+            it[5] = it[5] + [it[5][0] + "x"]
+        ds.items[i] = tuple(it)
+    devset = DeviceTrainSet(ds, DEV)
+    assert len(devset) == 37 and devset.n_caps == sum(len(it[1]) for it in ds.items)
+    for epoch in range(2):
+        torch.manual_seed(100 + epoch)
+        ref = list(DataLoader(ds, batch_size=8, shuffle=True, num_workers=0, collate_fn=collate_train))
+        after_ref = torch.rand(1)
+        torch.manual_seed(100 + epoch)
+        got = list(DeviceTrainLoader(devset, 8, shuffle=True))
+        assert torch.equal(after_ref, torch.rand(1))                      # the global generator is where the DataLoader leaves it
+        assert len(got) == len(ref) == 5
+        for a, b in zip(got, ref):
+            assert a["text_labels"] == b["text_labels"]
+            for k in ("student_videos", "teacher_videos", "student_videos_mask", "student_text", "student_text_mask", "teacher_text"):
+                assert a[k].is_cuda and torch.equal(a[k].cpu(), b[k]), k
+
+
+def test_train_with_the_device_resident_set_follows_the_host_loader_run(tmp_path):
+    """train() with opt.device_resident_train: the same history (losses, SumR) as with the DataLoader + collate + H2D path."""
+    from dldkd_amd.model import DLDKD
+    from dldkd_amd import train as T
+    hist = []
+    for resident in (False, True):
+        ds = TinySet()
+        cfg = types.SimpleNamespace(visual_input_size=256, query_input_size=128, inheritance_hidden=384, exploration_hidden=384,
+                                    max_ctx_l=128, max_desc_l=30, input_drop=0.1, drop=0.1, n_heads=4, initializer_range=0.02,
+                                    margin=0.1, use_hard_negative=False, hard_pool_size=5, label_style="soft")
+        opt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                    collection="tiny", alpha=0.8, belta=0.8, device=torch.device(DEV), bsz=8, pin_memory=False,
+                                    num_workers=0, lr=1e-3, wd=0.01, lr_warmup_proportion=0.05, n_epoch=3, max_es_cnt=10,
+                                    hard_negative_start_epoch=0, hard_pool_size=5, distill_loss_decay="exp", exponential_k=0.95,
+                                    selfDistil_sigmoid_k=800, alpha_decay="sigmoid", belta_decay="sigmoid", grad_clip=-1,
+                                    eval_context_bsz=16, eval_query_bsz=50, eval_untrained=False, ckpt_filepath=None,
+                                    device_resident_train=resident)
+        torch.manual_seed(0)
+        m = DLDKD(cfg, opt)
+        hist.append(T.train(m, ds, L(ds.videos()), L(ds.texts()), opt))
+    for a, b in zip(*hist):
+        assert a[1]["loss_overall"] == pytest.approx(b[1]["loss_overall"], rel=2e-3)      # fp32-atomic reductions vary run to run
+        assert abs(a[2] - b[2]) <= 12.0
