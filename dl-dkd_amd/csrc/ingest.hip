@@ -70,9 +70,60 @@ __global__ __launch_bounds__(256) void gather_pad_rows_kernel(const float* __res
     }
 }
 
+
+// Raw feature rows -> the resident form K4b (in_proj_rows128b.hip) consumes: bf16 (round to nearest even: what K4's
+// v_cvt_pk_bf16_f32 does to the same values on their way to the MFMA) + the row's fp32 LayerNorm statistics, taken from the
+// fp32 values (two passes: mean, then the centred second moment - torch's LayerNorm, method/model_components.py:297,308).
+// Valid rows of a padded (n_items, L, K) batch are APPENDED to a ragged table: item b's row l < lens[b] goes to table row
+// dst_row0[b] + l.  One wave per source row; the second pass re-reads the row from L1 / L2.
+__global__ __launch_bounds__(256) void rows_to_bf16_stats_kernel(const float* __restrict__ src, const int32_t* __restrict__ lens,
+                                                                 const long long* __restrict__ dst_row0, unsigned short* __restrict__ xb,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd, long n_rows, int L,
+                                                                 int K, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int b = (int)(r / L), l = (int)(r - (long)b * L);
+    if (lens != nullptr && l >= lens[b]) return;
+    const long d = dst_row0 != nullptr ? (long)dst_row0[b] + l : r;
+    const f32x4* s = reinterpret_cast<const f32x4*>(src + (size_t)r * K);
+    const int nv = K >> 2;
+    float sum = 0.f;
+    for (int c = lane; c < nv; c += 64) { const f32x4 v = s[c]; sum += (v[0] + v[1]) + (v[2] + v[3]); }
+    const float mu = wave_sum(sum) / (float)K;
+    float sq = 0.f;
+    uint2* o = reinterpret_cast<uint2*>(xb + (size_t)d * K);
+    for (int c = lane; c < nv; c += 64) {
+        const f32x4 v = s[c];
+        const float d0 = v[0] - mu, d1 = v[1] - mu, d2 = v[2] - mu, d3 = v[3] - mu;
+        sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+        pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        o[c] = pk;
+    }
+    const float var = wave_sum(sq) / (float)K;
+    if (lane == 0) {
+        mean[d] = mu;
+        rstd[d] = rsqrtf(var + eps);
+    }
+}
+
 }  // namespace dldkd
 
 using namespace dldkd;
+
+extern "C" int dldkd_rows_to_bf16_stats(const float* src, const int32_t* lens, const long long* dst_row0, int n_items, int L, int K,
+                                        float eps, void* x_bf16, float* mean, float* rstd, void* stream) {
+    if (n_items < 0 || L < 0 || K < 4 || (K & 3)) { set_error("rows_to_bf16_stats: bad sizes (K must be a multiple of 4)"); return DLDKD_EINVAL; }
+    const long n_rows = (long)n_items * L;
+    if (n_rows == 0) return DLDKD_OK;
+    if (!src || !x_bf16 || !mean || !rstd) { set_error("rows_to_bf16_stats: null pointer"); return DLDKD_EINVAL; }
+    if (((uintptr_t)src & 15) || ((uintptr_t)x_bf16 & 7)) { set_error("rows_to_bf16_stats: unaligned buffer"); return DLDKD_EINVAL; }
+    DLDKD_LAUNCH(rows_to_bf16_stats_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, lens, dst_row0,
+                       (unsigned short*)x_bf16, mean, rstd, n_rows, L, K, eps);
+    return check_launch("rows_to_bf16_stats");
+}
 
 extern "C" int dldkd_gather_pad_rows_f32(const float* src, const long long* row_start, const int32_t* lens, const int32_t* items,
                                          int n_items, int Lmax, int D, float* out, float* mask, void* stream) {

@@ -132,6 +132,10 @@ def clear_feature_cache():
     _FEATURE_CACHE.clear()
 
 
+def _cache_bytes():
+    return sum(k["bytes"] if isinstance(k, dict) else k.table.nbytes() for d in _FEATURE_CACHE.values() for k in d.values())
+
+
 def _cached_batches(dataset, kind, n_items, opt, make_loader, to_device):
     """Generator of the dataset's loader batches as device tuples: from the cache when this dataset (`kind` names the part of
     it: "text", "video", or a rank's ("video", lo, hi) shard) has been through before, otherwise from the DataLoader (and into the
@@ -156,7 +160,7 @@ def _cached_batches(dataset, kind, n_items, opt, make_loader, to_device):
         b = to_device(batch)
         if keep:
             nbytes = sum(t.numel() * t.element_size() for t in b if torch.is_tensor(t))
-            total = sum(k["bytes"] for d in _FEATURE_CACHE.values() for k in d.values()) + entry["bytes"] + nbytes
+            total = _cache_bytes() + entry["bytes"] + nbytes
             if total > cap:
                 keep, entry = False, {"batches": [], "bytes": 0, "complete": False, "n": n_items, "device": dev}
             else:
@@ -166,6 +170,106 @@ def _cached_batches(dataset, kind, n_items, opt, make_loader, to_device):
     if keep:
         entry["complete"] = True
         slot[kind] = entry
+
+
+# ---- the gallery's raw features in their RESIDENT form (throughput mode).  What the input projection consumes is bf16 rows and
+# the rows' LayerNorm statistics (K4 rounds the fp32 features to bf16 on their way to the MFMA and sums the statistics on the
+# side); so the first pass converts every loader batch ONCE into a ragged table of exactly that (ops.ResidentRows: no padding
+# rows, 6 KB per clip instead of 12: 10 GB for TVR's 1.66 M clips against 34 GB of padded fp32 batches), and every gallery
+# encode - the first one included - is the input projection over the whole table (K4b: dense 128-row tiles, no conversions in
+# the k-loop, no per-batch tail) + the fused tower kernel over the whole gallery: two launches per chunk of RESIDENT_CHUNK_ROWS
+# clips, no DataLoader, no H2D, no host-side padding or concatenation of batches, tables planned once.
+RESIDENT_FEATURES = True          # throughput-mode eval_epoch keeps the gallery's raw features as ops.ResidentRows
+RESIDENT_STREAM_ROWS = 1 << 17      # clips staged per encode when the table is not kept (256 CUs x 4 tiles of 128 rows)
+RESIDENT_CHUNK_ROWS = 1 << 21       # clips per chunk: the projection's fp32 output of a chunk is 2 x 3.2 GB
+
+
+class ResidentGallery:
+    def __init__(self, K, device):
+        self.table = ops.ResidentRows(K, device)
+        self.metas, self.complete, self.chunks = [], False, None
+
+    def plan(self, device):
+        """Per chunk of whole videos: (first video, #videos, first row, end row, lens int32 GPU, row0 int32 GPU relative to the
+        chunk, slot table of the tower kernel) - planned and uploaded once."""
+        lens = np.asarray(self.table.lens, dtype=np.int64)
+        start = np.concatenate([[0], np.cumsum(lens)])
+        self.lens_host, self.chunks, va = lens, [], 0
+        while va < len(lens):
+            vb = int(np.searchsorted(start, start[va] + RESIDENT_CHUNK_ROWS, side="right")) - 1
+            vb = min(max(vb, va + 1), len(lens))
+            l = lens[va:vb]
+            meta = np.concatenate([l, start[va:vb] - start[va]]).astype(np.int32)
+            meta_d = torch.from_numpy(meta).to(device)
+            items = torch.from_numpy(ops.plan_tower_items(l)).to(device)
+            self.chunks.append((va, vb - va, int(start[va]), int(start[vb]), meta_d[:vb - va], meta_d[vb - va:], items))
+            va = vb
+        self.lens_dev = torch.from_numpy(lens.astype(np.int32)).to(device)
+
+
+def _resident_context_info(model, eval_dataset, opt, loader, owner, kind):
+    """compute_context_info(keep_frame_feats=False) through a resident feature table; None when the path does not apply (the
+    caller then encodes padded fp32 super-batches as before).  With the feature cache on, the table of the first pass stays (up to
+    opt.eval_feature_cache_gb) and later passes replay it; without it (or past the cap) the table is a staging buffer that is
+    encoded and emptied every RESIDENT_STREAM_ROWS clips."""
+    from .model import _cfg_get
+    dev = torch.device(opt.device)
+    if not (dev.type == "cuda" and model.resident_encode_ok()):
+        return None
+    n = len(eval_dataset)
+    L = int(_cfg_get(model.config, "max_ctx_l"))
+    if n == 0 or L > 128:
+        return None
+    slot = None
+    if bool(getattr(opt, "eval_feature_cache", True)):
+        try:
+            slot = _FEATURE_CACHE.setdefault(owner, {})
+        except TypeError:                                   # a dataset object that cannot be weakly referenced
+            slot = None
+    key = ("resident", kind)
+    res = slot.get(key) if slot is not None else None
+    packer = scoring.GalleryPacker(n, L, 2, dev)
+    if res is not None and res.complete and len(res.metas) == n and res.table.device == dev:
+        torch.empty((), dtype=torch.int64).random_()        # the DataLoader iterator's base-seed draw (see _cached_batches)
+        with torch.no_grad():
+            model.encode_resident_into(packer, res)
+        metas, lens_all = list(res.metas), res.lens_dev
+    else:
+        cap = float(getattr(opt, "eval_feature_cache_gb", 96.0)) * 1e9
+        other = _cache_bytes()
+        keep = slot is not None
+        res = ResidentGallery(int(model.visual_input_proj.net[1].weight.shape[1]), dev)
+        metas, lens_parts = [], []
+
+        def encode_table():
+            res.plan(dev)
+            with torch.no_grad():
+                model.encode_resident_into(packer, res)
+            lens_parts.append(res.lens_dev)
+
+        with host_threads():
+            for batch in loader:
+                feat = batch[0].to(dev, non_blocking=True)
+                lens_h = (batch[1] > 0).sum(1).numpy()
+                if feat.shape[-1] != res.table.K or int(lens_h.max(initial=0)) > L:
+                    raise native.NativeError("eval: a gallery batch does not match the model's feature width / max_ctx_l")
+                res.table.append(feat.float(), lens_h)
+                metas.extend(batch[-1])
+                if keep and other + res.table.nbytes() > cap:
+                    keep = False
+                if not keep and res.table.rows >= RESIDENT_STREAM_ROWS:
+                    encode_table()
+                    res.table.clear()
+        if keep:
+            res.metas, res.complete = metas, True
+            slot[key] = res
+        if res.table.rows or not lens_parts:
+            encode_table()
+        lens_all = lens_parts[0] if len(lens_parts) == 1 else torch.cat(lens_parts)
+    lmax = int(lens_all.max().item()) if lens_all.numel() else 0
+    vmask = (torch.arange(lmax, device=dev).unsqueeze(0) < lens_all.unsqueeze(1)).float()
+    return dict(video_metas=metas, inher_frame_feat=None, explore_frame_feat=None, teacher_frame_feat=None,
+                video_mask=vmask, _packed=packer.finish())
 
 
 CONTEXT_SUPER_BATCH = 1024
@@ -203,6 +307,11 @@ def compute_context_info(model, eval_dataset, opt, keep_frame_feats=True, cache_
     packer = None
     pend_f, pend_m, pend_l, pend_n = [], [], [], 0
     fused_path = not keep_frame_feats and getattr(model, "fast_input_proj", False) and ops.TOWER_SEQ
+    if fused_path and RESIDENT_FEATURES:
+        info = _resident_context_info(model, eval_dataset, opt, loader, cache_owner if cache_owner is not None else eval_dataset,
+                                      cache_kind)
+        if info is not None:
+            return info
 
     def split_pending(take):
         """(first `take` pending videos, the rest), cutting a loader batch in two where the boundary falls inside it"""

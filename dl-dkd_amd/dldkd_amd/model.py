@@ -193,6 +193,27 @@ class DLDKD(nn.Module):
                       Lp=packer.Lp, lens_out=packer.lens)
         return True
 
+    def resident_encode_ok(self):
+        """The gallery encode from resident bf16 rows (ops.ResidentRows -> K4b -> fused tower kernel): throughput mode, inference,
+        two branches, a feature width the K4b kernel takes."""
+        return bool(self.fast_input_proj and self.double_branch and not self.training and not torch.is_grad_enabled()
+                    and ops.TOWER_SEQ and ops.gemm_precision() == "bf16" and ops.INPROJ_KERNEL == "rows128"
+                    and ops.in_proj_rows_ok(self.visual_input_proj.net[1].weight.shape[1]))
+
+    def encode_resident_into(self, packer, res):
+        """Gallery encode of a resident feature table (eval.ResidentGallery) straight into the scorer's packed bf16 gallery: per
+        chunk ONE input-projection launch over its rows (K4b) and ONE fused tower launch over its videos (K5, rows addressed by
+        row0: the projection's output stays ragged)."""
+        if "visual" not in self._folded:
+            self._folded["visual"] = ops.FoldedInProj([self.visual_input_proj, self.exp_visual_input_proj])
+        packs = self._tower_packs("visual")
+        for (va, n, r0, r1, lens_d, row0_d, items) in res.chunks:
+            y = ops.in_proj_resident(res.table, r0, r1, self._folded["visual"])
+            v0 = packer.reserve(n, int(res.lens_host[va:va + n].max(initial=0)))
+            if items.shape[0]:
+                ops.tower_seq(y, packs, lens_d, seq_rows=0, row0=row0_d, items=items, out_mode=1, gallery=packer.blobs, v0=v0,
+                              Lp=packer.Lp, lens_out=packer.lens)
+
     def encode_context(self, frame_video_feat, video_mask=None):
         out = []
         fast = self._fast_proj("visual", frame_video_feat) if self._use_fast(frame_video_feat) else None

@@ -91,6 +91,11 @@ SIGNATURES = {
                                      _c_float, _c_int, _c_void_p]),
     "dldkd_segment_mean_l2norm_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_float, _c_void_p]),
     "dldkd_upload_words": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p]),
+    "dldkd_rows_to_bf16_stats": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_void_p,
+                                           _c_void_p, _c_void_p]),
+    "dldkd_in_proj_bf16_rows128b": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                              _c_long, _c_int, _c_int, _c_void_p, _c_long, _c_void_p]),
+    "dldkd_in_proj_bf16_rows128b_ok": (_c_int, [_c_int]),
     "dldkd_gather_pad_rows_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p,
                                             _c_void_p]),
     "dldkd_fold_ln_linear_bf16_frag": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,

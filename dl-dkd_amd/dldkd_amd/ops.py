@@ -422,6 +422,80 @@ def in_proj_bf16(x, folded, relu=True, groups=None):
     return [y.view(*x.shape[:-1], HIDDEN) for y in ys]
 
 
+# ------------------------------------------------------------------------------------ K4b: projection of resident bf16 rows
+class ResidentRows:
+    """Raw feature rows in their device-resident form: bf16 (rows, K) + fp32 LayerNorm statistics per row (mean, rstd), ragged
+    (item i owns rows [start[i], start[i] + lens[i])).  Filled by appending padded fp32 batches (dldkd_rows_to_bf16_stats)."""
+
+    def __init__(self, K, device, capacity_rows=0):
+        self.K, self.device = int(K), torch.device(device)
+        self.rows = 0
+        self.lens = []                                   # host: rows per item, in append order
+        self._alloc(max(int(capacity_rows), 1))
+
+    def _alloc(self, cap):
+        cap = -(-cap // 128) * 128 + 128                 # slack: whole 128-row tiles
+        xb = torch.empty(cap, self.K, dtype=torch.bfloat16, device=self.device)
+        mean = torch.empty(cap, dtype=torch.float32, device=self.device)
+        rstd = torch.empty(cap, dtype=torch.float32, device=self.device)
+        if self.rows:
+            xb[:self.rows] = self.xb[:self.rows]
+            mean[:self.rows] = self.mean[:self.rows]
+            rstd[:self.rows] = self.rstd[:self.rows]
+        self.xb, self.mean, self.rstd, self.cap = xb, mean, rstd, cap
+
+    def append(self, feat, lens_host):
+        """feat (n, L, K) fp32 GPU (a padded batch), lens_host (n) ints: the valid rows of every item join the table."""
+        import numpy as np
+        lens_host = np.asarray(lens_host, dtype=np.int64)
+        n, L, K = feat.shape
+        if K != self.K or len(lens_host) != n or (lens_host > L).any() or (lens_host < 0).any():
+            raise native.NativeError("ResidentRows.append: batch does not match the table")
+        add = int(lens_host.sum())
+        if self.rows + add > self.cap - 128:
+            self._alloc(max(2 * self.cap, self.rows + add))
+        start = self.rows + np.concatenate([[0], np.cumsum(lens_host)[:-1]]) if n else np.zeros(0, np.int64)
+        meta = torch.from_numpy(np.concatenate([start.astype(np.int64), lens_host])).to(self.device)   # (2 n) int64: one upload
+        lens_d = meta[n:].to(torch.int32)
+        x = _chk(feat.reshape(n * L, K), "ResidentRows.append")
+        native.check(native.lib().dldkd_rows_to_bf16_stats(native.ptr(x), native.ptr(lens_d), native.ptr(meta), n, L, K, LN_EPS,
+                                                           native.ptr(self.xb), native.ptr(self.mean), native.ptr(self.rstd),
+                                                           native.stream()), "rows_to_bf16_stats")
+        self.lens.extend(int(v) for v in lens_host)
+        self.rows += add
+
+    def clear(self):
+        self.rows, self.lens = 0, []
+
+    def nbytes(self):
+        return self.rows * (self.K * 2 + 8)
+
+
+def in_proj_rows_ok(K):
+    return bool(native.lib().dldkd_in_proj_bf16_rows128b_ok(int(K)))
+
+
+def in_proj_resident(table, row_lo, row_hi, folded, relu=True, out=None):
+    """K4b: rows [row_lo, row_hi) of a ResidentRows table -> per-branch (row_hi - row_lo, 384) fp32 (both branches, one pass)."""
+    L = native.lib()
+    f = folded.get()
+    if not (f.full_row and f.nb == 2 and f.K == table.K and in_proj_rows_ok(table.K)):
+        raise native.NativeError("in_proj_resident: needs the two-branch fragment-order weights and K % 64 == 0, K >= 256")
+    M = int(row_hi - row_lo)
+    if row_lo < 0 or row_hi > table.rows or M < 0:
+        raise native.NativeError("in_proj_resident: row range outside the table")
+    ys = out if out is not None else [torch.empty(M, HIDDEN, dtype=torch.float32, device=table.device) for _ in range(2)]
+    if any(y.shape[0] < M or y.shape[1] != HIDDEN or y.dtype != torch.float32 or not y.is_contiguous() for y in ys):
+        raise native.NativeError("in_proj_resident: out tensors must be contiguous fp32 (>= rows, 384)")
+    if M == 0:
+        return ys
+    native.check(L.dldkd_in_proj_bf16_rows128b(native.ptr(table.xb[row_lo:]), native.ptr(table.mean[row_lo:]),
+                                               native.ptr(table.rstd[row_lo:]), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb),
+                                               native.ptr(ys[0]), native.ptr(ys[1]), M, table.K, int(relu), None, 0,
+                                               native.stream()), "in_proj_bf16_rows128b")
+    return ys
+
+
 # ---------------------------------------------------------------------------------------------- K5: fused per-sequence tower
 TOWER_SEQ = True      # throughput-mode inference: everything behind the input projection as one kernel (tower_seq.hip)
 

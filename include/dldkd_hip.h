@@ -214,6 +214,18 @@ int dldkd_in_proj_bf16_rows128_ok(int K);
  * projected nor written - 29 % fewer rows on a TVR-like length mix. */
 int dldkd_in_proj_bf16_rows128_groups(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                       long M, int K, float eps, int relu, const int32_t* groups, long n_groups, void* stream);
+/* K4b: the same projection on rows in their RESIDENT form - bf16 features (M, K) plus the rows' fp32 LayerNorm statistics
+ * mean[M], rstd[M] - written once by dldkd_rows_to_bf16_stats when a dataset's raw features become device-resident (the
+ * reference re-reads, re-pads and re-uploads the fp32 features of the validation videos in every epoch: method/eval.py:114-175
+ * through method/data_provider.py:111-136).  Same arithmetic as dldkd_in_proj_bf16_rows128 (which rounds x to bf16 before the
+ * MFMA and takes the statistics from the fp32 values), same Wfrag / cs / bb, same row-group table (groups == NULL: all rows,
+ * tile t = rows 128 t ..; the table rows index x, mean, rstd and y alike) - without the fp32 fragment reads, conversions and
+ * LayerNorm sums in the k-loop and with half the bytes per row (in_proj_rows128b.hip).  Needs K % 64 == 0, K >= 256
+ * (dldkd_in_proj_bf16_rows128b_ok); x_bf16 and Wfrag 16-byte aligned. */
+int dldkd_in_proj_bf16_rows128b(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
+                                const float* bb, float* y0, float* y1, long M, int K, int relu, const int32_t* groups, long n_groups,
+                                void* stream);
+int dldkd_in_proj_bf16_rows128b_ok(int K);
 /* PARITY-grade two-branch input projection (in_proj_rows128x3.hip): y = ReLU(LayerNorm(x) W^T + b) with fp32-grade products
  * (three bf16 planes per operand, six MFMAs per product: the scheme of dldkd_gemm_f32x3), both branches in one pass.
  *   dldkd_row_meanrstd_f32: mean[M], rstd[M] of the rows exactly as dldkd_layernorm_f32 computes them (D % 4 == 0, D <= 4096).
@@ -530,6 +542,14 @@ int dldkd_segment_mean_l2norm_f32(const float* frames, const int32_t* seg_start,
  * out[b, l] = src row row_start[items[b]] + l for l < lens[items[b]], zeros beyond; mask (n_items, Lmax) = 1 / 0 or NULL. */
 int dldkd_gather_pad_rows_f32(const float* src, const long long* row_start, const int32_t* lens, const int32_t* items, int n_items,
                               int Lmax, int D, float* out, float* mask, void* stream);
+
+/* Raw feature rows -> their device-resident form (dldkd_in_proj_bf16_rows128b): bf16 (round to nearest even) + fp32 LayerNorm
+ * statistics of the fp32 values (mean, rstd = 1 / sqrt(biased variance + eps): nn.LayerNorm, method/model_components.py:297).
+ * src (n_items, L, K) fp32, a padded batch as collate_frame_val builds it (method/data_provider.py:111-136); row l of item b goes
+ * to table row dst_row0[b] + l when l < lens[b] (lens == NULL: every row; dst_row0 == NULL: row b L + l): the padding is dropped,
+ * the table is ragged.  x_bf16 (rows, K) 8-byte aligned, mean / rstd (rows). */
+int dldkd_rows_to_bf16_stats(const float* src, const int32_t* lens, const long long* dst_row0, int n_items, int L, int K, float eps,
+                             void* x_bf16, float* mean, float* rstd, void* stream);
 
 /* Upload of a small host-produced int32 table (the slot and row-group tables of dldkd_tower_seq_bf16 /
  * dldkd_in_proj_bf16_rows128_groups; nothing in the reference) by a kernel: pinned_src is page-locked, device-mapped host

@@ -334,3 +334,56 @@ def test_eval_feature_cache_replays_without_the_loader():
         ev.eval_epoch(m, dv, dt, tiny)                        # nothing fitted under the cap: read again
         assert Counting.reads == n + 120
     ev.clear_feature_cache()
+
+
+def test_resident_gallery_features_match_the_padded_super_batches(monkeypatch):
+    """Throughput-mode eval_epoch keeps the gallery's raw features as a ragged bf16 table with the rows' LayerNorm statistics
+    (eval.ResidentGallery / ops.ResidentRows) and encodes it with K4b + the fused tower kernel over the whole table.  Against
+    the padded fp32 super-batches through K4 + the fused tower kernel (RESIDENT_FEATURES off): same lengths and visiting order,
+    packed gallery rows within one bf16 step, same R@K; chunked tables (several K4b / K5 launch pairs) and the streaming form
+    (table emptied every few clips: no cache) give the same; the kept table is 6 KB per clip."""
+    from dldkd_amd import eval as ev, scoring
+    m = _model(3072, 768, synth.make_params(61, 3072, 768))
+    vids, txts = synth.make_eval_sets(11, nv=70, caps=2, dv=3072, dq=768)
+    dv, dt = synth.ListDataset(list(vids)), synth.ListDataset(list(txts))
+    opt = _opt()
+    opt.eval_precision = "throughput"
+
+    def run(**patch):
+        ev.clear_feature_cache()
+        for k, v in patch.items():
+            monkeypatch.setattr(ev, k, v)
+        with torch.no_grad(), ev.eval_precision(m, opt):
+            info = ev.compute_context_info(m, dv, opt, keep_frame_feats=False)
+            ranks, _ = ev.rank_queries(m, dt, opt, info)
+        for k in patch:
+            monkeypatch.undo()
+        return info, ranks
+
+    old, r_old = run(RESIDENT_FEATURES=False)
+    new, r_new = run()
+    n_clips = int(new["_packed"].lens.sum())
+    res = next(iter(ev._FEATURE_CACHE[dv].values()))
+    assert res.complete and res.table.rows == n_clips and res.table.nbytes() == n_clips * (3072 * 2 + 8)
+    chunked, r_ch = run(RESIDENT_CHUNK_ROWS=100)
+    assert len(next(iter(ev._FEATURE_CACHE[dv].values())).chunks) > 3
+    off = types.SimpleNamespace(**vars(opt), eval_feature_cache=False)
+    ev.clear_feature_cache()
+    monkeypatch.setattr(ev, "RESIDENT_STREAM_ROWS", 150)
+    with torch.no_grad(), ev.eval_precision(m, off):
+        streamed = ev.compute_context_info(m, dv, off, keep_frame_feats=False)
+        r_st, _ = ev.rank_queries(m, dt, off, streamed)
+    assert dv not in ev._FEATURE_CACHE or not ev._FEATURE_CACHE[dv]
+    for info, ranks in ((new, r_new), (chunked, r_ch), (streamed, r_st)):
+        # (the padded super-batches round the mask's width up to whole 32-clip groups; the table's mask has the reference's width:
+        # the longest video, eval.py:139-155)
+        assert info["video_metas"] == old["video_metas"] and torch.equal(info["video_mask"].sum(1), old["video_mask"].sum(1))
+        assert info["video_mask"].shape[1] == int(info["_packed"].lens.max())
+        a, b = info["_packed"], old["_packed"]
+        assert torch.equal(a.lens, b.lens) and torch.equal(a.order, b.order)
+        for x, y in zip(a.blobs, b.blobs):
+            xf, yf = x.view(torch.bfloat16).float(), y.view(torch.bfloat16).float()
+            assert (xf - yf).abs().max().item() <= 2 ** -8 and (xf != yf).float().mean().item() < 0.02
+        assert np.abs(ranks.astype(np.int64) - r_old.astype(np.int64)).max() <= 1
+        assert (ranks != r_old).mean() < 0.02
+    ev.clear_feature_cache()

@@ -266,3 +266,58 @@ def test_k4_row_groups_project_only_the_listed_groups(K, L):
     # through the Python wrapper too
     via = ops.in_proj_bf16(x, fold, groups=groups)
     assert torch.equal(via[0].view(-1, 384).cpu()[listed], ys[0].cpu()[listed])
+
+
+@pytest.mark.parametrize("K,shape", [(3072, (37, 128)), (1024, (9, 64)), (256, (130, 32)), (3072, (300, 96))])
+def test_k4b_resident_rows_match_k4_and_fp64(K, shape):
+    """K4b (in_proj_rows128b: bf16 rows + precomputed LayerNorm statistics, ops.ResidentRows) against K4 on the fp32 rows it
+    was filled from, and against fp64 with the kernels' roundings (bf16 x, bf16 W' = gamma (.) W): the ragged table holds
+    exactly the valid rows (bf16 RNE of the features, statistics within fp32 rounding of fp64), the two kernels agree to fp32
+    summation order (the k-steps are visited in a rotated order per workgroup), a row range in the middle of the table is
+    served from its own tile grid."""
+    from dldkd_amd import ops, model_components as mc
+    torch.manual_seed(K + shape[0])
+    n, L = shape
+    layers = [mc.LinearLayer(K, 384, layer_norm=True, dropout=0.0, relu=True).to(DEV) for _ in range(2)]
+    for l in layers:
+        torch.nn.init.normal_(l.LayerNorm.weight, 1.0, 0.2)
+        torch.nn.init.normal_(l.LayerNorm.bias, 0.0, 0.2)
+    fold = ops.FoldedInProj(layers)
+    lens = torch.randint(0, L + 1, (n,)).numpy()
+    lens[0] = L
+    x = torch.randn(n, L, K, device=DEV) * (1 + torch.rand(n, L, 1, device=DEV)) + 0.3
+    tab = ops.ResidentRows(K, DEV)
+    tab.append(x[: n // 2], lens[: n // 2])                  # two batches: the second is appended behind the first
+    tab.append(x[n // 2:], lens[n // 2:])
+    rows = torch.cat([x[i, :lens[i]] for i in range(n)], 0).contiguous()
+    assert tab.rows == rows.shape[0] and tab.lens == [int(v) for v in lens]
+    assert torch.equal(tab.xb[:tab.rows], rows.to(torch.bfloat16))
+    mu, var = rows.double().mean(1), rows.double().var(1, unbiased=False)
+    assert (tab.mean[:tab.rows].double() - mu).abs().max() < 1e-6
+    assert (tab.rstd[:tab.rows].double() * (var + 1e-5).sqrt() - 1).abs().max() < 1e-5
+    with torch.no_grad():
+        y = ops.in_proj_resident(tab, 0, tab.rows, fold)
+        y_k4 = ops.in_proj_bf16(rows, fold)
+        lo, hi = 7, tab.rows - 3
+        y_mid = ops.in_proj_resident(tab, lo, hi, fold)
+    for b, l in enumerate(layers):
+        Wp = (l.net[1].weight * l.LayerNorm.weight).to(torch.bfloat16).double()
+        ref = (rows.to(torch.bfloat16).double() @ Wp.T - mu[:, None] * Wp.sum(1)[None]) / (var + 1e-5).sqrt()[:, None] \
+            + (l.net[1].weight.double() @ l.LayerNorm.bias.double() + l.net[1].bias.double())
+        ref = ref.clamp_min(0)
+        scale = ref.abs().max().item()
+        assert (y[b].double() - ref).abs().max().item() < 2e-5 * max(scale, 1.0)
+        assert (y[b] - y_k4[b]).abs().max().item() < 1e-5 * max(scale, 1.0)
+        assert (y_mid[b] - y[b][lo:hi]).abs().max().item() < 1e-5 * max(scale, 1.0)
+
+
+def test_k4b_rejects_what_it_cannot_serve():
+    from dldkd_amd import native, ops
+    assert not ops.in_proj_rows_ok(128) and not ops.in_proj_rows_ok(3072 + 32) and ops.in_proj_rows_ok(256)
+    tab = ops.ResidentRows(256, DEV)
+    with pytest.raises(native.NativeError):
+        tab.append(torch.zeros(2, 4, 128, device=DEV), [4, 4])           # wrong feature width
+    with pytest.raises(native.NativeError):
+        tab.append(torch.zeros(2, 4, 256, device=DEV), [4, 5])           # a length past the padded batch
+    tab.append(torch.zeros(2, 4, 256, device=DEV), [4, 0])
+    assert tab.rows == 4

@@ -36,8 +36,9 @@ def test_eval_epoch_runs_throughput_mode_by_default_and_restores_the_precision()
     mk = lambda **kw: types.SimpleNamespace(eval_context_bsz=25, eval_query_bsz=50, num_workers=0, pin_memory=False,   # noqa: E731
                                             device=torch.device("cuda:0"), double_branch=True, **kw)
     seen = []
-    real = m.encode_context_into
+    real, real_res = m.encode_context_into, m.encode_resident_into      # padded super-batches / the resident feature table
     m.encode_context_into = lambda *a, **k: seen.append(ops.gemm_precision()) or real(*a, **k)
+    m.encode_resident_into = lambda *a, **k: seen.append(ops.gemm_precision()) or real_res(*a, **k)
     with torch.no_grad():
         fast = ev.eval_epoch(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), mk())
         assert seen and set(seen) == {"bf16"}

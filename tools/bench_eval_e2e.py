@@ -18,7 +18,7 @@ def stage_times(nv=21793, nq=10895, mode="fp32", dev="cuda:0", B=None):
                                  collection="tvr", alpha=0.8, belta=0.8)
     torch.manual_seed(0)
     m = DLDKD(cfg, opt_).to(dev).eval()
-    if mode == "fast":                       # K4 input projection + every tower GEMM on bf16 MFMA
+    if mode in ("fast", "resident"):         # K4 input projection + every tower GEMM on bf16 MFMA
         m.fast_input_proj = True
         ops.set_gemm_precision("bf16")
     gen = torch.Generator(device=dev).manual_seed(1)
@@ -37,46 +37,84 @@ def stage_times(nv=21793, nq=10895, mode="fp32", dev="cuda:0", B=None):
             mask = (torch.arange(L, device=dev).unsqueeze(0) < lens.unsqueeze(1)).float()
             feats = feats * mask.unsqueeze(-1)
             lens_host = lens.cpu().numpy()                       # eval.py has them from the loader's CPU mask
-            if mode == "fast":                                   # eval.py cuts super-batches where the tower kernel's workgroups fill whole rounds
+            if mode == "resident":
+                # what eval_epoch runs in throughput mode since round 3b: the gallery's raw features live on the device as a
+                # ragged bf16 table + per-row LayerNorm statistics (filled once, from the first pass's loader batches); an epoch's
+                # gallery encode is K4b over the whole table + the fused tower kernel over all videos
+                res = ev.ResidentGallery(3072, torch.device(dev))
+                t0 = sync()
+                done = 0
+                while done < nv:
+                    n = min(B, nv - done)
+                    res.table.append(feats[:n], lens_host[:n])
+                    done += n
+                t1 = sync()
+                out["resident_fill_once"] = {"s": t1 - t0, "table_GB": res.table.nbytes() / 1e9, "clips": res.table.rows,
+                                             "padded_fp32_batches_GB": nv * L * 3072 * 4 / 1e9}
+                res.complete = True
+                res.plan(torch.device(dev))
+                out["chunks"] = len(res.chunks)
+                for _ in range(2):
+                    wpk = scoring.GalleryPacker(nv, L, 2, torch.device(dev))
+                    m.encode_resident_into(wpk, res)
+                    wpk.finish()
+                del wpk
+                pk = scoring.GalleryPacker(nv, L, 2, torch.device(dev))
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                t0 = sync()
+                evs[0].record()
+                m.encode_resident_into(pk, res)
+                evs[1].record()
+                th = time.perf_counter()
+                pg = pk.finish()
+                evs[2].record()
+                t1 = sync()
+                out["gallery_encode_and_pack_s"] = t1 - t0
+                out["gallery_detail"] = {"host_enqueue_ms": (th - t0) * 1e3, "gpu_encode_ms": evs[0].elapsed_time(evs[1]),
+                                         "gpu_finish_order_ms": evs[1].elapsed_time(evs[2])}
+                out["gallery_videos_per_sec"] = nv / (t1 - t0)
+                del res
+            elif mode == "fast":                                 # eval.py cuts super-batches where the tower kernel's workgroups fill whole rounds
                 B = ev._take_for_budget(lens_host, ev.TOWER_ITEM_BUDGET)
                 out["videos_per_super_batch"] = int(B)
 
-            def encode(pk_, n):                                  # what compute_context_info's flush() does per super-batch
-                if not (mode == "fast" and m.encode_context_into(pk_, feats[:n], mask[:n], lens_host=lens_host[:n])):
-                    gi, ge = m.encode_context(feats[:n], mask[:n])
-                    pk_.add([gi, ge], mask[:n])
-            for _ in range(2):                                   # warm-up: kernel modules, allocator pools, torch's lazy sort
-                wpk = scoring.GalleryPacker(B, L, 2, torch.device(dev))
-                encode(wpk, B)
-                wpk.finish()
-            del wpk
-            pk = scoring.GalleryPacker(nv, L, 2, torch.device(dev))   # 2 x 2.1 GB: first-touch hipMalloc is not GPU work
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            t0 = sync()
-            evs[0].record()
-            done = 0
-            prof = None
-            if os.environ.get("E2E_HOSTPROF"):                   # where does the host spend the enqueue loop?  (stderr)
-                import cProfile
-                prof = cProfile.Profile()
-                prof.enable()
-            while done < nv:
-                n = min(B, nv - done)
-                encode(pk, n)
-                done += n
-            if prof is not None:
-                prof.disable()
-                import pstats
-                pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(14)
-            evs[1].record()
-            th = time.perf_counter()
-            pg = pk.finish()
-            evs[2].record()
-            t1 = sync()
-            out["gallery_encode_and_pack_s"] = t1 - t0
-            out["gallery_detail"] = {"host_enqueue_loop_ms": (th - t0) * 1e3, "gpu_loop_ms": evs[0].elapsed_time(evs[1]),
-                                     "gpu_finish_order_ms": evs[1].elapsed_time(evs[2])}
-            out["gallery_videos_per_sec"] = nv / (t1 - t0)
+            if mode != "resident":
+                def encode(pk_, n):                                  # what compute_context_info's flush() does per super-batch
+                    if not (mode == "fast" and m.encode_context_into(pk_, feats[:n], mask[:n], lens_host=lens_host[:n])):
+                        gi, ge = m.encode_context(feats[:n], mask[:n])
+                        pk_.add([gi, ge], mask[:n])
+                for _ in range(2):                                   # warm-up: kernel modules, allocator pools, torch's lazy sort
+                    wpk = scoring.GalleryPacker(B, L, 2, torch.device(dev))
+                    encode(wpk, B)
+                    wpk.finish()
+                del wpk
+                pk = scoring.GalleryPacker(nv, L, 2, torch.device(dev))   # 2 x 2.1 GB: first-touch hipMalloc is not GPU work
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                t0 = sync()
+                evs[0].record()
+                done = 0
+                prof = None
+                if os.environ.get("E2E_HOSTPROF"):                   # where does the host spend the enqueue loop?  (stderr)
+                    import cProfile
+                    prof = cProfile.Profile()
+                    prof.enable()
+                while done < nv:
+                    n = min(B, nv - done)
+                    encode(pk, n)
+                    done += n
+                if prof is not None:
+                    prof.disable()
+                    import pstats
+                    pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(14)
+                evs[1].record()
+                th = time.perf_counter()
+                pg = pk.finish()
+                evs[2].record()
+                t1 = sync()
+                out["gallery_encode_and_pack_s"] = t1 - t0
+                out["gallery_detail"] = {"host_enqueue_loop_ms": (th - t0) * 1e3, "gpu_loop_ms": evs[0].elapsed_time(evs[1]),
+                                         "gpu_finish_order_ms": evs[1].elapsed_time(evs[2])}
+                out["gallery_videos_per_sec"] = nv / (t1 - t0)
             SB = ev.QUERY_SUPER_BATCH
             words = torch.nn.functional.normalize(torch.randn(SB, 30, 768, generator=gen, device=dev), dim=-1)
             wl = torch.randint(5, 31, (SB,), generator=gen, device=dev)
