@@ -64,6 +64,27 @@ __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_base_uni
 }
 
 
+// XCD-aware order of a 3-D tile grid (cdna_hip_programming.md section 5 "XCD swizzle must be bijective", T1): the workgroups with
+// equal launch id % 8 share an XCD (round-robin placement: a speed assumption only) and are handed a contiguous run of tile ids,
+// x fastest.  Returns the tile this workgroup computes in place of blockIdx.
+struct Tile3 { int x, y, z; };
+__device__ __forceinline__ Tile3 xcd_tile_order() {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned nwg = gx * gy * gridDim.z;
+    const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    unsigned t = orig;
+    if (nwg >= 16) {
+        const unsigned q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    Tile3 o;
+    o.x = (int)(t % gx);
+    const unsigned yz = t / gx;
+    o.y = (int)(yz % gy);
+    o.z = (int)(yz / gy);
+    return o;
+}
+
 // Epilogue of the 128x128-block / 64x64-per-wave MFMA GEMMs: C = act(alpha * acc + bias).  The 32x32 accumulator layout puts
 // 32 consecutive COLUMNS of one row on 32 lanes (128-byte row segments as 4-byte stores).  When the wave's 64 columns are
 // all in range and rows are 16-byte aligned, each 32 x 64 half is parked in the wave's private LDS region (the operand
@@ -211,8 +232,8 @@ __device__ __forceinline__ void gemm_lngrad_tile(const f32x16 (&acc)[2][2], cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (col + e >= p.N) continue;
-            la.part_g[(size_t)blockIdx.y * p.N + col + e] = sg[e] + og[e];
-            la.part_b[(size_t)blockIdx.y * p.N + col + e] = sb[e] + ob[e];
+            la.part_g[(size_t)(m0 / 128) * p.N + col + e] = sg[e] + og[e];
+            la.part_b[(size_t)(m0 / 128) * p.N + col + e] = sb[e] + ob[e];
         }
     }
 }

@@ -22,7 +22,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ beta, float* __restrict__ out, long M,
                                                         int D, float eps, unsigned char* __restrict__ keep, unsigned thresh,
                                                         float dscale, unsigned long long seed, unsigned long long off,
-                                                        const unsigned long long* __restrict__ state) {
+                                                        const unsigned long long* __restrict__ state,
+                                                        unsigned short* __restrict__ out16, float* __restrict__ stats) {
+    // out16 != null: the row is written as bf16 (round to nearest even) instead of fp32 - the operand form of the bf16 GEMMs that
+    // consume it (dldkd_gemm_bf16_mixed); stats != null: mean -> stats[row], rstd -> stats[M + row] (kept for the backward pass)
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -53,7 +56,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    if (stats != nullptr && lane == 0) { stats[row] = mean; stats[M + row] = rstd; }
     f32x4* orow = reinterpret_cast<f32x4*>(out + row * D);
+    uint2* orow16 = reinterpret_cast<uint2*>(out16 + row * D);
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
     const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
 #pragma unroll
@@ -74,7 +79,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 o[2] = k.z ? o[2] * dscale : 0.f; o[3] = k.w ? o[3] * dscale : 0.f;
                 reinterpret_cast<uchar4*>(keep + row * D)[c] = k;
             }
-            orow[c] = o;
+            if (out16 != nullptr) {
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16_bits(o[0]) | ((unsigned)f32_to_bf16_bits(o[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16_bits(o[2]) | ((unsigned)f32_to_bf16_bits(o[3]) << 16);
+                orow16[c] = pk;
+            } else {
+                orow[c] = o;
+            }
         }
     }
 }
@@ -266,23 +278,24 @@ extern "C" {
 
 static int launch_layernorm(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out,
                             long M, int D, float eps, unsigned char* keep, float p_drop, unsigned long long seed,
-                            unsigned long long offset, const unsigned long long* state, void* stream) {
+                            unsigned long long offset, const unsigned long long* state, void* stream,
+                            unsigned short* out16 = nullptr, float* stats = nullptr) {
     if (M < 0 || D < 4 || (D & 3) || D > 4096 || add_mod < 0 || !(p_drop >= 0.f && p_drop < 1.f)) {
         set_error("layernorm: bad sizes M=%ld D=%d (D must be a multiple of 4, <= 4096) or p=%f", M, D, (double)p_drop);
         return DLDKD_EINVAL;
     }
     if (M == 0) return DLDKD_OK;
-    if (!x || !gamma || !beta || !out) { set_error("layernorm: null pointer"); return DLDKD_EINVAL; }
+    if (!x || !gamma || !beta || (!out && !out16)) { set_error("layernorm: null pointer"); return DLDKD_EINVAL; }
     const dim3 grid((unsigned)((M + 3) / 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int nv = (D / 4 + 63) / 64;
     const double t = (double)p_drop * 4294967296.0;
     const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     const float ds = 1.0f / (1.0f - p_drop);
-    if (nv <= 2) DLDKD_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state);
-    else if (nv <= 4) DLDKD_LAUNCH(layernorm_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state);
-    else if (nv <= 8) DLDKD_LAUNCH(layernorm_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state);
-    else DLDKD_LAUNCH(layernorm_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state);
+    if (nv <= 2) DLDKD_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats);
+    else if (nv <= 4) DLDKD_LAUNCH(layernorm_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats);
+    else if (nv <= 8) DLDKD_LAUNCH(layernorm_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats);
+    else DLDKD_LAUNCH(layernorm_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats);
     return check_launch("layernorm");
 }
 
@@ -296,6 +309,15 @@ int dldkd_layernorm_dropout_f32(const float* x, const float* add, int add_mod, c
                                 unsigned long long offset, const unsigned long long* state, void* stream) {
     if (!keep || ((uintptr_t)keep & 3)) { set_error("layernorm_dropout: keep mask missing or unaligned"); return DLDKD_EINVAL; }
     return launch_layernorm(x, add, add_mod, gamma, beta, out, M, D, eps, keep, p_drop, seed, offset, state, stream);
+}
+
+int dldkd_layernorm_dropout_bf16(const float* x, const float* gamma, const float* beta, void* out_bf16, unsigned char* keep, float* stats,
+                                 long M, int D, float eps, float p_drop, unsigned long long seed, unsigned long long offset,
+                                 const unsigned long long* state, void* stream) {
+    if (!out_bf16 || ((uintptr_t)out_bf16 & 7)) { set_error("layernorm_dropout_bf16: output missing or unaligned"); return DLDKD_EINVAL; }
+    if (p_drop > 0.f && (!keep || ((uintptr_t)keep & 3))) { set_error("layernorm_dropout_bf16: keep mask missing or unaligned"); return DLDKD_EINVAL; }
+    return launch_layernorm(x, nullptr, 0, gamma, beta, nullptr, M, D, eps, p_drop > 0.f ? keep : nullptr, p_drop, seed, offset, state, stream,
+                            (unsigned short*)out_bf16, stats);
 }
 
 int dldkd_attention_fwd_f32(const float* qkv, const float* mask, float* out, int N, int L, void* stream) {

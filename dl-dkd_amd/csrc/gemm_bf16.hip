@@ -36,11 +36,36 @@ struct GemmHArgs {
 //   k-minor memory [row][k]: 4 float4 loads (8 threads cover a row's 128 B), packed 8-byte LDS writes.
 //   k-major memory [k][row]: the thread owns ONE row and 16 consecutive k (dword loads, coalesced across the wave
 //     along the row index), so the transposed LDS write is two 16-byte stores - no 2-byte scatter, no conflicts.
-template <bool KMAJOR>
+// SRC16: the operand sits in memory as bf16 already (the LayerNorm-dropout output of the training input projection,
+// dldkd_layernorm_dropout_bf16): half the bytes per tile, no rounding here (bf16 -> fp32 -> bf16 is exact).
+//   k-minor bf16: same thread -> (row, 4 k) map, 8-byte loads.
+//   k-major bf16: the thread owns TWO adjacent rows and 8 consecutive k (dword loads of a bf16 pair, coalesced along the row
+//     index; two 16-byte LDS stores); needs an even ld and row count.
+template <bool KMAJOR, bool SRC16 = false>
 struct TileH {
     static __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int K,
                                                 int tid, bool vec, float (&r)[NREG_]) {
-        if constexpr (!KMAJOR) {
+        if constexpr (SRC16) {
+            const unsigned short* P16 = reinterpret_cast<const unsigned short*>(P);
+            if constexpr (!KMAJOR) {
+#pragma unroll
+                for (int j = 0; j < NPASS_; ++j) {
+                    const int row = row0 + tid / KV_ + RPP_ * j;
+                    const int k = k0 + (tid % KV_) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[4 * j + e] = (row < nrows && k + e < K) ? bf16_bits_to_f32(P16[(size_t)row * ld + k + e]) : 0.f;
+                }
+            } else {
+                const int row = row0 + 2 * (tid & 63);
+                const int kb = k0 + (tid >> 6) * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool kok = kb + i < K;
+                    r[i] = (kok && row < nrows) ? bf16_bits_to_f32(P16[(size_t)(kb + i) * ld + row]) : 0.f;
+                    r[8 + i] = (kok && row + 1 < nrows) ? bf16_bits_to_f32(P16[(size_t)(kb + i) * ld + row + 1]) : 0.f;
+                }
+            }
+        } else if constexpr (!KMAJOR) {
 #pragma unroll
             for (int j = 0; j < NPASS_; ++j) {
                 const int row = row0 + tid / KV_ + RPP_ * j;
@@ -70,7 +95,27 @@ struct TileH {
     // last row instead of zeroed - they only feed accumulator rows/columns that are never stored.
     static __device__ __forceinline__ void load_fast(const float* __restrict__ P, int ld, int row0, int nrows, int k0,
                                                      int tid, float (&r)[NREG_]) {
-        if constexpr (!KMAJOR) {
+        if constexpr (SRC16) {
+            const unsigned short* P16 = reinterpret_cast<const unsigned short*>(P);
+            if constexpr (!KMAJOR) {
+#pragma unroll
+                for (int j = 0; j < NPASS_; ++j) {
+                    const int row = min(row0 + tid / KV_ + RPP_ * j, nrows - 1);
+                    const uint2 v = *reinterpret_cast<const uint2*>(P16 + (size_t)row * ld + k0 + (tid % KV_) * 4);
+                    r[4 * j + 0] = __builtin_bit_cast(float, v.x << 16); r[4 * j + 1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+                    r[4 * j + 2] = __builtin_bit_cast(float, v.y << 16); r[4 * j + 3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+                }
+            } else {
+                const int row = min(row0 + 2 * (tid & 63), nrows - 2);          // (nrows even, >= 2: entry point)
+                const unsigned short* src = P16 + (size_t)(k0 + (tid >> 6) * 8) * ld + row;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned v = *reinterpret_cast<const unsigned*>(src + (size_t)i * ld);
+                    r[i] = __builtin_bit_cast(float, v << 16);
+                    r[8 + i] = __builtin_bit_cast(float, v & 0xffff0000u);
+                }
+            }
+        } else if constexpr (!KMAJOR) {
 #pragma unroll
             for (int j = 0; j < NPASS_; ++j) {
                 const int row = min(row0 + tid / KV_ + RPP_ * j, nrows - 1);
@@ -86,7 +131,18 @@ struct TileH {
         }
     }
     static __device__ __forceinline__ void store(unsigned short* __restrict__ S, int tid, const float (&r)[NREG_]) {
-        if constexpr (!KMAJOR) {
+        if constexpr (SRC16 && KMAJOR) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                    // rows 2 p and 2 p + 1, k (tid >> 6) * 8 .. + 7
+                unsigned short* dst = S + (2 * (tid & 63) + h) * HPITCH + (tid >> 6) * 8;
+                uint4 pk;
+                pk.x = (__builtin_bit_cast(unsigned, r[8 * h + 0]) >> 16) | (__builtin_bit_cast(unsigned, r[8 * h + 1]) & 0xffff0000u);
+                pk.y = (__builtin_bit_cast(unsigned, r[8 * h + 2]) >> 16) | (__builtin_bit_cast(unsigned, r[8 * h + 3]) & 0xffff0000u);
+                pk.z = (__builtin_bit_cast(unsigned, r[8 * h + 4]) >> 16) | (__builtin_bit_cast(unsigned, r[8 * h + 5]) & 0xffff0000u);
+                pk.w = (__builtin_bit_cast(unsigned, r[8 * h + 6]) >> 16) | (__builtin_bit_cast(unsigned, r[8 * h + 7]) & 0xffff0000u);
+                *reinterpret_cast<uint4*>(dst) = pk;
+            }
+        } else if constexpr (!KMAJOR) {
 #pragma unroll
             for (int j = 0; j < NPASS_; ++j) {
                 unsigned short* dst = S + (tid / KV_ + RPP_ * j) * HPITCH + (tid % KV_) * 4;
@@ -111,23 +167,30 @@ struct TileH {
 };
 
 // EPI: 0 = store C (bias / ReLU / split-K plane), 1 = training simpool max-pool (PoolArgs), 2 = LayerNorm parameter gradients (LnGradArgs)
-template <bool A_KMAJOR, bool B_KMAJOR, int EPI, typename EArgs>
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, typename EArgs, bool A16 = false, bool B16 = false>
 __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_raw[];
     unsigned short (*lds)[2][HBM_ * HPITCH] = reinterpret_cast<unsigned short (*)[2][HBM_ * HPITCH]>(lds_raw);
+    // XCD-aware tile order (cdna_hip_programming.md T1, bijective form).  Workgroups are dealt round-robin over the 8 XCDs, each
+    // with its own L2: in launch order the 3 (N = 384) or 9 (N = 1152) column tiles that share a 128-row block of A ran on
+    // different XCDs and every one of them pulled the block through the fabric again (16,384 x 384 x 384: 100 MB moved for 50 MB
+    // of operands + result, 16,384 x 1152 x 384: 300 MB for 100 MB - their measured times at ~5 TB/s).  Remapped, the workgroups
+    // that share an XCD (equal id % 8: a group label, never used for correctness) take CONSECUTIVE tiles, column tile fastest, so
+    // a row block's tiles - and for split-K launches the row tiles that share a B slab - run side by side behind one L2.
+    const Tile3 bid = xcd_tile_order();
     if (p.split_k > 1) {
-        p.C += (size_t)blockIdx.z * p.M * p.ldc;      // this split's partial plane in the workspace
+        p.C += (size_t)bid.z * p.M * p.ldc;      // this split's partial plane in the workspace
     } else {
-        const int zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
+        const int zo = bid.z / p.batch_inner, zi = bid.z % p.batch_inner;
         p.A += zo * p.sAo + zi * p.sAi;
         p.B += zo * p.sBo + zi * p.sBi;
         p.C += zo * p.sCo + zi * p.sCi;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int m0 = blockIdx.y * HBM_, n0 = blockIdx.x * HBN_;
+    const int m0 = bid.y * HBM_, n0 = bid.x * HBN_;
     const int nk_all = (p.K + HBK_ - 1) / HBK_;
-    const int kt0 = p.split_k > 1 ? blockIdx.z * p.k_tiles_per_split : 0;
+    const int kt0 = p.split_k > 1 ? bid.z * p.k_tiles_per_split : 0;
     const int nk = p.split_k > 1 ? min(nk_all - kt0, p.k_tiles_per_split) : nk_all;
     if (nk <= 0) return;
 
@@ -144,16 +207,16 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
     const bool fa = A_KMAJOR || p.a_vec, fb = B_KMAJOR || p.b_vec;
     auto load_tiles = [&](int k0) {
         if (k0 + HBK_ <= p.K && fa && fb) {
-            TileH<A_KMAJOR>::load_fast(p.A, p.lda, m0, p.M, k0, tid, ra);
-            TileH<B_KMAJOR>::load_fast(p.B, p.ldb, n0, p.N, k0, tid, rb);
+            TileH<A_KMAJOR, A16>::load_fast(p.A, p.lda, m0, p.M, k0, tid, ra);
+            TileH<B_KMAJOR, B16>::load_fast(p.B, p.ldb, n0, p.N, k0, tid, rb);
         } else {
-            TileH<A_KMAJOR>::load(p.A, p.lda, m0, p.M, k0, p.K, tid, p.a_vec, ra);
-            TileH<B_KMAJOR>::load(p.B, p.ldb, n0, p.N, k0, p.K, tid, p.b_vec, rb);
+            TileH<A_KMAJOR, A16>::load(p.A, p.lda, m0, p.M, k0, p.K, tid, p.a_vec, ra);
+            TileH<B_KMAJOR, B16>::load(p.B, p.ldb, n0, p.N, k0, p.K, tid, p.b_vec, rb);
         }
     };
     load_tiles(kt0 * HBK_);
-    TileH<A_KMAJOR>::store(lds[0][0], tid, ra);
-    TileH<B_KMAJOR>::store(lds[0][1], tid, rb);
+    TileH<A_KMAJOR, A16>::store(lds[0][0], tid, ra);
+    TileH<B_KMAJOR, B16>::store(lds[0][1], tid, rb);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -175,13 +238,13 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) {
-            TileH<A_KMAJOR>::store(lds[cur ^ 1][0], tid, ra);
-            TileH<B_KMAJOR>::store(lds[cur ^ 1][1], tid, rb);
+            TileH<A_KMAJOR, A16>::store(lds[cur ^ 1][0], tid, ra);
+            TileH<B_KMAJOR, B16>::store(lds[cur ^ 1][1], tid, rb);
         }
         __syncthreads();
     }
     // (the k-loop ended with a barrier: every wave is done with the operand tiles, the LDS is free for staging)
-    if constexpr (EPI == 1) gemm_pool_tile(acc, p, *pa, (int)blockIdx.z, n0, wm, wn, lane, wave, reinterpret_cast<float*>(lds_raw));
+    if constexpr (EPI == 1) gemm_pool_tile(acc, p, *pa, bid.z, n0, wm, wn, lane, wave, reinterpret_cast<float*>(lds_raw));
     else if constexpr (EPI == 2) gemm_lngrad_tile(acc, p, *pa, m0, n0, wm, wn, lane, wave, reinterpret_cast<float*>(lds_raw));
     else gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(lds_raw) + wave * (32 * 72));
 }
@@ -189,6 +252,13 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmHArgs p) {
     gemm_bf16_body<A_KMAJOR, B_KMAJOR, 0, PoolArgs>(p, nullptr);
+}
+// operands that are bf16 in memory: forward (A = the bf16 LayerNorm-dropout rows) and dW (B = the same rows, k-major)
+__global__ __launch_bounds__(256) void gemm_bf16_a16_kernel(GemmHArgs p) {
+    gemm_bf16_body<false, false, 0, PoolArgs, true, false>(p, nullptr);
+}
+__global__ __launch_bounds__(256) void gemm_bf16_dw_b16_kernel(GemmHArgs p) {
+    gemm_bf16_body<true, true, 0, PoolArgs, false, true>(p, nullptr);
 }
 // training simpool: one video per blockIdx.z, max-pool epilogue (common.hpp, gemm_pool_tile)
 __global__ __launch_bounds__(256) void gemm_bf16_pool_kernel(GemmHArgs p, PoolArgs pa) {
@@ -217,6 +287,20 @@ static int launch_gemm_h(GemmHArgs p, int batch, int a_kmajor, int b_kmajor, voi
     else if (a_kmajor && b_kmajor) DLDKD_LAUNCH((gemm_bf16_kernel<true, true>), grid, block, lds, s, p);
     else DLDKD_LAUNCH((gemm_bf16_kernel<true, false>), grid, block, lds, s, p);
     return check_launch("gemm_bf16");
+}
+
+static int launch_gemm_h_mixed(GemmHArgs p, int batch, int dw, void* stream) {
+    const dim3 grid((p.N + HBN_ - 1) / HBN_, (p.M + HBM_ - 1) / HBM_, batch), block(256);
+    constexpr size_t lds = sizeof(unsigned short) * 2 * 2 * HBM_ * HPITCH;
+    static const bool attr_ok = [] {
+        bool ok = hipFuncSetAttribute((const void*)gemm_bf16_a16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)gemm_bf16_dw_b16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        return ok;
+    }();
+    (void)attr_ok;
+    if (dw) DLDKD_LAUNCH(gemm_bf16_dw_b16_kernel, grid, block, lds, (hipStream_t)stream, p);
+    else DLDKD_LAUNCH(gemm_bf16_a16_kernel, grid, block, lds, (hipStream_t)stream, p);
+    return check_launch("gemm_bf16_mixed");
 }
 
 int launch_simpool_pool_bf16(const float* g, const float* q, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream) {
@@ -307,4 +391,36 @@ extern "C" int dldkd_gemm_bf16(const float* A, const float* B, const float* bias
         return launch_splitk_reduce((const float*)workspace, C, p.split_k, (long)M * N, (hipStream_t)stream);
     }
     return launch_gemm_h(p, 1, a_kmajor, b_kmajor, stream);
+}
+
+// The two GEMMs of the training input projection whose activation operand is stored as bf16 (dldkd_layernorm_dropout_bf16):
+//   dw == 0  forward:  C[M, N] = act(A16[M, K] . B[N, K]^T + bias)    A16 bf16 row-major (lda elements), B fp32 (N, K)
+//   dw != 0  dW:       C[M, N] = sum_k A[k, m] B16[k, n]              A fp32 (K, M) = dy, B16 bf16 (K, N) = the saved rows;
+//                                                                     split-K as dldkd_gemm_bf16 (workspace from
+//                                                                     dldkd_gemm_workspace_bytes(DLDKD_GEMM_BF16, M, N, K, 1, 1))
+extern "C" int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda,
+                                     int ldb, int ldc, int relu, void* workspace, size_t workspace_bytes, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < N) { set_error("gemm_bf16_mixed: bad sizes"); return DLDKD_EINVAL; }
+    if (M == 0 || N == 0) return DLDKD_OK;
+    if (!A || !B || !C) { set_error("gemm_bf16_mixed: null pointer"); return DLDKD_EINVAL; }
+    if (!dw) {
+        if ((lda & 3) || ((uintptr_t)A & 7)) { set_error("gemm_bf16_mixed: bf16 A needs lda %% 4 == 0 and 8-byte alignment"); return DLDKD_EINVAL; }
+        const int b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
+        GemmHArgs p{(const float*)A, (const float*)B, bias, C, M, N, K, lda, ldb, ldc, relu, 1, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+        return launch_gemm_h_mixed(p, 1, 0, stream);
+    }
+    if (bias || relu) { set_error("gemm_bf16_mixed: the dW layout takes no bias / ReLU"); return DLDKD_EINVAL; }
+    if ((ldb & 1) || (N & 1) || N < 2 || ((uintptr_t)B & 3)) { set_error("gemm_bf16_mixed: bf16 k-major B needs even ldb and N"); return DLDKD_EINVAL; }
+    GemmHArgs p{(const float*)A, (const float*)B, nullptr, C, M, N, K, lda, ldb, ldc, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+    int per = 0;
+    const int split = (ldc == N && !((uintptr_t)C & 15)) ? gemm_bf16_split_plan(M, N, K, 1, 1, &per) : 1;
+    if (split > 1 && workspace && !((uintptr_t)workspace & 15) && workspace_bytes >= (size_t)split * M * N * sizeof(float)) {
+        p.k_tiles_per_split = per;
+        p.split_k = split;
+        p.C = (float*)workspace;
+        const int rc = launch_gemm_h_mixed(p, p.split_k, 1, stream);
+        if (rc != DLDKD_OK) return rc;
+        return launch_splitk_reduce((const float*)workspace, C, p.split_k, (long)M * N, (hipStream_t)stream);
+    }
+    return launch_gemm_h_mixed(p, 1, 1, stream);
 }

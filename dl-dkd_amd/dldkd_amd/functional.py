@@ -175,35 +175,62 @@ class _InProjTrain(Function):
     def forward(ctx, x, gamma, beta, weight, bias, p, relu):
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
-        keep = None
-        if p > 0.0:
-            z = torch.empty_like(x2)
-            keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
-            seed, off, state = _philox_slot(x.device, x.numel())
-            native.check(_L().dldkd_layernorm_dropout_f32(_p(x2), None, 0, _p(gamma), _p(beta), _p(z), _p(keep), x2.shape[0], K,
-                                                          ops.LN_EPS, float(p), seed, off, state, _s()), "layernorm_dropout")
+        M, N = x2.shape[0], weight.shape[0]
+        keep = stats = None
+        # throughput mode: the LayerNorm-dropout rows are WRITTEN as bf16 - what the bf16 GEMMs round them to anyway - so the
+        # forward GEMM and dW read half the bytes (201 -> 100 MB per branch at the TVR batch), and the row statistics are kept
+        # for the backward pass instead of being recomputed from x there
+        z16 = IN_PROJ_TRAIN_BF16_ROWS and ops.gemm_precision() == "bf16" and K % 4 == 0 and N % 2 == 0
+        if z16:
+            z = torch.empty(x2.shape, dtype=torch.bfloat16, device=x.device)
+            stats = torch.empty(2, M, dtype=torch.float32, device=x.device)
+            seed, off, state = (0, 0, None)
+            if p > 0.0:
+                keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
+                seed, off, state = _philox_slot(x.device, x.numel())
+            native.check(_L().dldkd_layernorm_dropout_bf16(_p(x2), _p(gamma), _p(beta), _p(z), _p(keep), _p(stats), M, K, ops.LN_EPS,
+                                                           float(p), seed, off, state, _s()), "layernorm_dropout_bf16")
+            y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+            native.check(_L().dldkd_gemm_bf16_mixed(0, _p(z), _p(weight), _p(bias), _p(y), M, N, K, K, K, N, int(relu), None, 0, _s()),
+                         "gemm_bf16_mixed")
         else:
-            z = ops.layernorm(x2, gamma, beta)
-        y = ops.linear(z, weight, bias, relu=relu)
-        ctx.save_for_backward(x2, weight, z, y if relu else None, keep)
+            if p > 0.0:
+                z = torch.empty_like(x2)
+                keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
+                seed, off, state = _philox_slot(x.device, x.numel())
+                native.check(_L().dldkd_layernorm_dropout_f32(_p(x2), None, 0, _p(gamma), _p(beta), _p(z), _p(keep), M, K,
+                                                              ops.LN_EPS, float(p), seed, off, state, _s()), "layernorm_dropout")
+            else:
+                z = ops.layernorm(x2, gamma, beta)
+            y = ops.linear(z, weight, bias, relu=relu)
+        ctx.save_for_backward(x2, weight, z, y if relu else None, keep, stats)
         ctx.relu, ctx.has_bias, ctx.keep_scale, ctx.prec = relu, bias is not None, 1.0 / (1.0 - p), ops.gemm_precision()
-        return y.view(*x.shape[:-1], weight.shape[0])
+        return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, z, y, keep = ctx.saved_tensors
+        x2, w, z, y, keep, stats = ctx.saved_tensors
         N, K = w.shape
         M = x2.shape[0]
         dy2 = _f32(dy).reshape(-1, N)
         if ctx.relu:
             dy2 = dy2.clone()
             native.check(_L().dldkd_relu_bwd_f32(_p(dy2), _p(y.reshape(-1, N)), dy2.numel(), _s()), "relu_bwd")
-        dw = ops.gemm(dy2, z, True, True, N, K, M) if ctx.needs_input_grad[3] else None
+        dw = None
+        if ctx.needs_input_grad[3]:
+            if z.dtype == torch.bfloat16:
+                dw = torch.empty(N, K, dtype=torch.float32, device=x2.device)
+                ws, ws_bytes = ops._gemm_workspace(_L(), N, K, M, True, True, x2.device, precision="bf16")
+                native.check(_L().dldkd_gemm_bf16_mixed(1, _p(dy2), _p(z), None, _p(dw), N, K, M, N, K, K, 0, _p(ws), ws_bytes, _s()),
+                             "gemm_bf16_mixed")
+            else:
+                dw = ops.gemm(dy2, z, True, True, N, K, M)
         db = _colsum(dy2, N) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
         dg = dbeta = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            stats = torch.empty(2, M, dtype=torch.float32, device=x2.device)
-            native.check(_L().dldkd_row_meanrstd_f32(_p(x2), _p(stats[0]), _p(stats[1]), M, K, ops.LN_EPS, _s()), "row_meanrstd")
+            if stats is None:
+                stats = torch.empty(2, M, dtype=torch.float32, device=x2.device)
+                native.check(_L().dldkd_row_meanrstd_f32(_p(x2), _p(stats[0]), _p(stats[1]), M, K, ops.LN_EPS, _s()), "row_meanrstd")
             tiles = (M + 127) // 128
             ws = torch.empty(2 * tiles * K, dtype=torch.float32, device=x2.device)
             dgb = _zeros((2, K), x2.device)
@@ -213,6 +240,7 @@ class _InProjTrain(Function):
         return None, dg, dbeta, dw, db, None, None
 
 
+IN_PROJ_TRAIN_BF16_ROWS = True        # throughput mode: the saved LayerNorm-dropout rows of the input projection are bf16
 IN_PROJ_TRAIN_FUSED = True
 
 

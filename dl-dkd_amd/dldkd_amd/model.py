@@ -379,6 +379,8 @@ class DLDKD(nn.Module):
                               getattr(self, pre + "query_pos_embed"))
         return self.get_modularized_queries(h, mask, inheritance=(pre == ""))
 
+    TOWER_FORK = "pair"
+
     def _encode_towers(self, video, vmask, text, tmask):
         """(g_inh, g_exp, q_inh, q_exp) of the training forward.  With tower_streams set (train.GraphedTrainStep sets it) the
         four towers are enqueued on four streams forked from the current one and joined behind the last: they share nothing
@@ -399,9 +401,19 @@ class DLDKD(nn.Module):
         pres = ("", "exp_") if self.double_branch else ("",)
         jobs = [(self._video_tower, pre, video, vmask) for pre in pres] + [(self._query_tower, pre, text, tmask) for pre in pres]
         outs = []
+        # Where the side streams fork matters: a stream that waits for `cur` AFTER tower 0 was enqueued there waits for tower 0
+        # (the first 0.6 ms of the C3 step ran one tower alone).  TOWER_FORK = "pair": the second video tower forks before
+        # anything is enqueued, so the two long towers run side by side from the start; the query towers fork behind tower 0.
+        # "all" forks the three side streams up front (C3 bf16 step 4.45 instead of 4.7 ms) but hipGraphLaunch of ROCm 7.0.2
+        # segfaults on the second or third graph captured that way in one process (tests/test_train_loop_gpu.py: three batch
+        # signatures; a chain of waits or a first kernel per branch does not help) - not used.  "late": every side stream forks
+        # behind tower 0.
+        early = {"pair": 1, "all": len(jobs) - 1, "late": 0}[self.TOWER_FORK]
+        for i in range(1, early + 1):
+            self._side_streams[i - 1].wait_stream(cur)
         for i, (fn, pre, x, m) in enumerate(jobs):
             st = cur if i == 0 else self._side_streams[i - 1]
-            if st is not cur:
+            if i > early:
                 st.wait_stream(cur)
             with torch.cuda.stream(st):
                 outs.append(fn(pre, x, m))

@@ -53,10 +53,10 @@ def _gemm_fn(L):
 _PREC_ID = {"fp32_exact": 0, "fp32": 1, "fp32x3": 1, "bf16": 2}     # DLDKD_GEMM_F32 / _F32X3 / _BF16
 
 
-def _gemm_workspace(L, M, N, K, a_kmajor, b_kmajor, device):
+def _gemm_workspace(L, M, N, K, a_kmajor, b_kmajor, device, precision=None):
     """Split-K scratch for one GEMM call, from torch's caching allocator (stream-ordered, so it is safe under graph capture
     and with several streams); None when the shape never splits.  The library itself never allocates."""
-    nbytes = L.dldkd_gemm_workspace_bytes(_PREC_ID[_PRECISION], M, N, K, int(a_kmajor), int(b_kmajor))
+    nbytes = L.dldkd_gemm_workspace_bytes(_PREC_ID[precision or _PRECISION], M, N, K, int(a_kmajor), int(b_kmajor))
     if nbytes == 0:
         return None, 0
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes

@@ -160,6 +160,14 @@ int dldkd_layernorm_dropout_f32(const float* x, const float* add, int add_mod, c
                                 float* out, unsigned char* keep, long M, int D, float eps, float p_drop,
                                 unsigned long long seed, unsigned long long offset, const unsigned long long* state,
                                 void* stream);
+/* The same LayerNorm (+ inverted dropout when p_drop > 0: same masks) writing the row as bf16 (round to nearest even) - the
+ * operand form of the bf16 GEMMs that consume it (dldkd_gemm_bf16_mixed) - and, when stats != NULL, the row statistics
+ * (mean -> stats[row], rstd -> stats[M + row]) the backward pass would otherwise recompute.  Training input projection in
+ * throughput mode: LinearLayer.forward's LayerNorm -> Dropout (method/model_components.py:305-310).  keep may be NULL when
+ * p_drop == 0; out_bf16 8-byte aligned. */
+int dldkd_layernorm_dropout_bf16(const float* x, const float* gamma, const float* beta, void* out_bf16, unsigned char* keep, float* stats,
+                                 long M, int D, float eps, float p_drop, unsigned long long seed, unsigned long long offset,
+                                 const unsigned long long* state, void* stream);
 
 /* BertSelfAttention.forward (model_components.py:398-436) for N sequences of L <= 128 tokens, 4 heads x 96:
  * qkv (N, L, 1152) = [query | key | value] projections, mask (N, L) 0/1 or NULL, out (N, L, 384) context
@@ -290,6 +298,14 @@ int dldkd_linear_rows_bf16(const float* x, const void* Wfrag, const float* bb, v
  * step when the precision is set to "bf16" (BASELINE.json configs[2]); the fp32 entry points remain the parity path. */
 int dldkd_gemm_bf16(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
                     int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes, void* stream);
+/* The two GEMMs of the training input projection whose activation operand is stored as bf16 (dldkd_layernorm_dropout_bf16),
+ * bf16 MFMA with fp32 accumulation as dldkd_gemm_bf16 (which would round the same values to bf16 itself: same result):
+ *   dw == 0  forward  C[M, N] = act(A16[M, K] . B[N, K]^T + bias)   A16 bf16 row-major (lda elements, lda % 4 == 0), B fp32 (N, K)
+ *   dw != 0  dW       C[M, N] = sum_k A[k, m] B16[k, n]             A fp32 (K, M) = dy, B16 bf16 (K, N) = the saved rows (ldb, N even);
+ *                     no bias / ReLU; split-K like dldkd_gemm_bf16 with a workspace of
+ *                     dldkd_gemm_workspace_bytes(DLDKD_GEMM_BF16, M, N, K, 1, 1) bytes (NULL: no split). */
+int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
+                          int ldc, int relu, void* workspace, size_t workspace_bytes, void* stream);
 
 /* fp32-GRADE GEMM on the bf16 matrix cores: each fp32 operand is split into three bf16 planes (h + m + l = 24 mantissa
  * bits) on the way to LDS and every product is rebuilt from the six plane products of order <= 2 with fp32 accumulation

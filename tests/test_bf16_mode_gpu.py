@@ -243,3 +243,47 @@ def test_packed_weight_caches_follow_the_fused_optimizer(golden_dir):
     after_parity, want_parity = scores(m, fast=False), scores(fresh, fast=False)   # same for the three-plane caches of parity mode
     assert (after_parity - before_parity).abs().max().item() > 1e-3
     assert torch.equal(after_parity, want_parity)
+
+
+@pytest.mark.parametrize("M,N,K,p_drop", [(300, 384, 3072, 0.2), (129, 384, 776, 0.0), (1000, 130, 100, 0.5), (64, 2, 36, 0.1)])
+def test_bf16_rows_of_the_training_input_projection(bf16_mode, M, N, K, p_drop):
+    """dldkd_layernorm_dropout_bf16 + dldkd_gemm_bf16_mixed (functional._InProjTrain in throughput mode: the LayerNorm-dropout
+    rows are stored as bf16, the forward GEMM and dW read them as they are) against the fp32-row kernels they replace: the rows
+    are the bf16 rounding of dldkd_layernorm_dropout_f32's (same masks), the statistics those of dldkd_row_meanrstd_f32, and
+    both GEMMs give the numbers dldkd_gemm_bf16 gives on the fp32 rows (which it rounds to bf16 itself) - ragged edge tiles,
+    K not a multiple of the k-tile, split-K dW included."""
+    from dldkd_amd import native, ops
+    L = native.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * (1 + torch.rand(M, 1, generator=g)) + 0.2).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(K, generator=g)).to(DEV), (0.1 * torch.randn(K, generator=g)).to(DEV)
+    W, b = (torch.randn(N, K, generator=g) * 0.05).to(DEV), (0.1 * torch.randn(N, generator=g)).to(DEV)
+    dy = torch.randn(M, N, generator=g).to(DEV)
+    z32, k32 = torch.empty(M, K, device=DEV), torch.empty(M, K, dtype=torch.uint8, device=DEV)
+    z16, k16 = torch.empty(M, K, dtype=torch.bfloat16, device=DEV), torch.empty(M, K, dtype=torch.uint8, device=DEV)
+    stats, ref_stats = torch.empty(2, M, device=DEV), torch.empty(2, M, device=DEV)
+    if p_drop > 0:
+        native.check(L.dldkd_layernorm_dropout_f32(native.ptr(x), None, 0, native.ptr(gamma), native.ptr(beta), native.ptr(z32), native.ptr(k32),
+                                                   M, K, 1e-5, p_drop, 1234, 40, None, native.stream()), "ln")
+    else:
+        z32 = ops.layernorm(x, gamma, beta)
+    native.check(L.dldkd_layernorm_dropout_bf16(native.ptr(x), native.ptr(gamma), native.ptr(beta), native.ptr(z16),
+                                                native.ptr(k16) if p_drop > 0 else None, native.ptr(stats), M, K, 1e-5, p_drop, 1234, 40, None,
+                                                native.stream()), "ln16")
+    native.check(L.dldkd_row_meanrstd_f32(native.ptr(x), native.ptr(ref_stats[0]), native.ptr(ref_stats[1]), M, K, 1e-5, native.stream()), "stats")
+    assert torch.equal(z16, z32.to(torch.bfloat16)) and torch.equal(stats, ref_stats)
+    if p_drop > 0:
+        assert torch.equal(k16, k32) and 0.5 * (1 - p_drop) < k16.float().mean().item() < 1 - 0.5 * p_drop
+    y = torch.empty(M, N, device=DEV)
+    native.check(L.dldkd_gemm_bf16_mixed(0, native.ptr(z16), native.ptr(W), native.ptr(b), native.ptr(y), M, N, K, K, K, N, 1, None, 0,
+                                         native.stream()), "fwd")
+    assert torch.equal(y, ops.linear(z32, W, b, relu=True))
+    dw = torch.empty(N, K, device=DEV)
+    ws, nb = ops._gemm_workspace(L, N, K, M, True, True, x.device)
+    native.check(L.dldkd_gemm_bf16_mixed(1, native.ptr(dy), native.ptr(z16), None, native.ptr(dw), N, K, M, N, K, K, 0, native.ptr(ws), nb,
+                                         native.stream()), "dw")
+    ref = ops.gemm(dy, z32, True, True, N, K, M)
+    assert torch.allclose(dw, ref, rtol=1e-5, atol=1e-6 * ref.abs().max().item())        # (split-K planes: fp32 sums in another order)
+    with pytest.raises(native.NativeError):                                                # odd ldb / N of the bf16 k-major operand
+        native.check(L.dldkd_gemm_bf16_mixed(1, native.ptr(dy), native.ptr(z16), None, native.ptr(dw), N, K - 1, M, N, K - 1, K - 1, 0, None, 0,
+                                             native.stream()), "dw")
