@@ -304,6 +304,10 @@ def extras(dev):
         # round 3: throughput-mode gallery encode = K4 (row groups: padding skipped) + the fused tower kernel K5 straight into the
         # packed bf16 gallery, ragged lengths U{24..128}
         out["gallery_encode_videos_per_s_fused_k4_k5"] = out["eval_epoch_gpu_stages_fast"].get("gallery_videos_per_sec")
+        # round 3, second half: what eval_epoch runs now - the gallery's raw features resident as a ragged bf16 table with the
+        # rows' LayerNorm statistics (filled once), K4b over the whole table + the fused tower kernel over all videos
+        out["eval_epoch_gpu_stages_resident"] = stage_times(NV, NQ, "resident", str(dev))
+        out["gallery_encode_videos_per_s_resident_k4b_k5"] = out["eval_epoch_gpu_stages_resident"].get("gallery_videos_per_sec")
         import types as _t
         cfg2 = cfg
         torch.manual_seed(0)
@@ -339,6 +343,30 @@ def extras(dev):
         out["k4_in_proj_roofline"] = {"bound": "hbm", "achieved": byts / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
                                       "frac": byts / ms / 1e6 / 8000.0, "kernel": "in_proj_rows128_kernel (dldkd_in_proj_bf16_rows128)", "kernel_ms": ms,
                                       "shape": "400000 rows x 3072 fp32 -> 2 x 384 fp32", "timing": "median of 10 launches after 3 warm-ups"}
+        # K4b on the same rows in their resident form (bf16 + row statistics): 307 -> 560 flop per byte, the MFMA pipe is its bound
+        tab = ops.ResidentRows(3072, dev, 400000)
+        for lo in range(0, 400000, 50000):
+            tab.append(xk[lo:lo + 50000].view(50, 1000, 3072), [1000] * 50)
+        outs_b = [torch.empty(400000, 384, device=dev) for _ in range(2)]
+        def k4b_ms():
+            for _ in range(3):
+                ops.in_proj_resident(tab, 0, 400000, fold, out=outs_b)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+            evs[0].record()
+            for i in range(10):
+                ops.in_proj_resident(tab, 0, 400000, fold, out=outs_b)
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            return sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(10))[5]
+        msb = k4b_ms()
+        flops = 2.0 * 400000 * 3072 * 768
+        bytes_b = 400000 * 3072 * 2 + 400000 * 8 + 400000 * 768 * 4 + 768 * 3072 * 2
+        out["k4b_in_proj_roofline"] = {"bound": "mfma", "achieved": flops / msb / 1e9, "peak": 2500.0, "unit": "TFLOP/s",
+                                       "frac": flops / msb / 1e9 / 2500.0, "kernel": "in_proj_rows128b_kernel (dldkd_in_proj_bf16_rows128b)",
+                                       "kernel_ms": msb, "shape": "400000 rows x 3072 bf16 (+ mean, rstd) -> 2 x 384 fp32",
+                                       "algorithmic_GB": bytes_b / 1e9, "hbm_GBps": bytes_b / msb / 1e6,
+                                       "same_rows_fp32_k4_ms": ms, "timing": "median of 10 launches after 3 warm-ups"}
+        del tab, outs_b
         ops.INPROJ_KERNEL = "full"                 # the round-1 kernel on the same box, same input
         try:
             out["k4_in_proj_roofline"]["round1_kernel_ms"] = k4_ms()

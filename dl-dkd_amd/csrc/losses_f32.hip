@@ -120,6 +120,12 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(const float* __restrict__
 //   dT[u,v] += g*cv * (1-beta) * smT[u] * (-r[u] + sum_q smT[q] r[q]),  r = w / (IV + eps)       (soft columns)
 // eps = 1e-12 for the soft loss (model_components.py:171), 0 for clip_nce (LSE over the positives only).
 // ---------------------------------------------------------------------------------------------
+// REG (nq <= 64 * kNceMaxQ): the lane's S / T / label entries of the column are loaded ONCE into registers - the column is read
+// with a stride of nv floats (one cache line per lane), and the passes below depend on each other through wave reductions, so
+// re-reading it in each of the 5-6 passes was 20-36 us of exposed latency per call at the TVR batch (640 x 128).  Same
+// arithmetic in the same order as the memory form (the fallback for longer columns).
+constexpr int kNceMaxQ = 16;
+template <bool REG>
 __global__ __launch_bounds__(256) void nce_cols_kernel(const float* __restrict__ S, const float* __restrict__ T,
                                                        const int32_t* __restrict__ labels, const float* __restrict__ cv,
                                                        int hardV, float beta, float eps, int nq, int nv,
@@ -130,12 +136,34 @@ __global__ __launch_bounds__(256) void nce_cols_kernel(const float* __restrict__
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= nv) return;
     const bool soft = T != nullptr && v >= hardV;
+    float sreg[REG ? kNceMaxQ : 1], treg[REG ? kNceMaxQ : 1];
+    unsigned ohm = 0;                                   // bit i: labels[lane + 64 i] == v
+    if constexpr (REG) {
+#pragma unroll
+        for (int i = 0; i < kNceMaxQ; ++i) {
+            const int q = lane + 64 * i;
+            sreg[i] = treg[i] = 0.f;
+            if (q < nq) {
+                sreg[i] = S[(size_t)q * nv + v];
+                if (soft) treg[i] = T[(size_t)q * nv + v];
+                ohm |= (labels[q] == v ? 1u : 0u) << i;
+            }
+        }
+    }
+    const int npass = REG ? kNceMaxQ : (nq + 63) / 64;
+    auto Sv = [&](int i, int q) { if constexpr (REG) return sreg[i]; else return S[(size_t)q * nv + v]; };
+    auto Tv = [&](int i, int q) { if constexpr (REG) return treg[i]; else return T[(size_t)q * nv + v]; };
+    auto Oh = [&](int i, int q) { if constexpr (REG) return (ohm >> i) & 1u ? 1.f : 0.f; else return labels[q] == v ? 1.f : 0.f; };
     float ms = -INFINITY, mt = -INFINITY;
     int cnt = 0;
-    for (int q = lane; q < nq; q += 64) {
-        ms = fmaxf(ms, S[(size_t)q * nv + v]);
-        if (soft) mt = fmaxf(mt, T[(size_t)q * nv + v]);
-        cnt += labels[q] == v;
+#pragma unroll
+    for (int i = 0; i < npass; ++i) {
+        const int q = lane + 64 * i;
+        if (q < nq) {
+            ms = fmaxf(ms, Sv(i, q));
+            if (soft) mt = fmaxf(mt, Tv(i, q));
+            cnt += Oh(i, q) != 0.f;
+        }
     }
     ms = wave_max(ms);
     if (soft) mt = wave_max(mt);
@@ -146,29 +174,41 @@ __global__ __launch_bounds__(256) void nce_cols_kernel(const float* __restrict__
         return;
     }
     float zs = 0.f, zt = 0.f;
-    for (int q = lane; q < nq; q += 64) {
-        zs += expf(S[(size_t)q * nv + v] - ms);
-        if (soft) zt += expf(T[(size_t)q * nv + v] - mt);
+#pragma unroll
+    for (int i = 0; i < npass; ++i) {
+        const int q = lane + 64 * i;
+        if (q < nq) {
+            zs += expf(Sv(i, q) - ms);
+            if (soft) zt += expf(Tv(i, q) - mt);
+        }
     }
     const float lse = ms + logf(wave_sum(zs));
     const float izt = soft ? 1.f / wave_sum(zt) : 0.f;
     // nominator LSE: max first
     float mn = -INFINITY;
-    for (int q = lane; q < nq; q += 64) {
-        const float oh = labels[q] == v ? 1.f : 0.f;
-        const float sm = soft ? expf(T[(size_t)q * nv + v] - mt) * izt : 0.f;
-        const float iv = soft ? fmaxf((1.f - beta) * sm + beta * oh, 0.f) : oh;
-        const float a = iv + eps;
-        if (a > 0.f) mn = fmaxf(mn, logf(a) + S[(size_t)q * nv + v]);
+#pragma unroll
+    for (int i = 0; i < npass; ++i) {
+        const int q = lane + 64 * i;
+        if (q < nq) {
+            const float oh = Oh(i, q);
+            const float sm = soft ? expf(Tv(i, q) - mt) * izt : 0.f;
+            const float iv = soft ? fmaxf((1.f - beta) * sm + beta * oh, 0.f) : oh;
+            const float a = iv + eps;
+            if (a > 0.f) mn = fmaxf(mn, logf(a) + Sv(i, q));
+        }
     }
     mn = wave_max(mn);
     float zn = 0.f;
-    for (int q = lane; q < nq; q += 64) {
-        const float oh = labels[q] == v ? 1.f : 0.f;
-        const float sm = soft ? expf(T[(size_t)q * nv + v] - mt) * izt : 0.f;
-        const float iv = soft ? fmaxf((1.f - beta) * sm + beta * oh, 0.f) : oh;
-        const float a = iv + eps;
-        if (a > 0.f) zn += expf(logf(a) + S[(size_t)q * nv + v] - mn);
+#pragma unroll
+    for (int i = 0; i < npass; ++i) {
+        const int q = lane + 64 * i;
+        if (q < nq) {
+            const float oh = Oh(i, q);
+            const float sm = soft ? expf(Tv(i, q) - mt) * izt : 0.f;
+            const float iv = soft ? fmaxf((1.f - beta) * sm + beta * oh, 0.f) : oh;
+            const float a = iv + eps;
+            if (a > 0.f) zn += expf(logf(a) + Sv(i, q) - mn);
+        }
     }
     const float nom = mn + logf(wave_sum(zn));
     const float coef = cv[v];
@@ -176,24 +216,33 @@ __global__ __launch_bounds__(256) void nce_cols_kernel(const float* __restrict__
     if (dS) {
         float rbar = 0.f;
         if (soft && dT) {
-            for (int q = lane; q < nq; q += 64) {
-                const float oh = labels[q] == v ? 1.f : 0.f;
-                const float sm = expf(T[(size_t)q * nv + v] - mt) * izt;
-                const float a = fmaxf((1.f - beta) * sm + beta * oh, 0.f) + eps;
-                const float w = expf(logf(a) + S[(size_t)q * nv + v] - nom);
-                rbar += sm * (w / a);
+#pragma unroll
+            for (int i = 0; i < npass; ++i) {
+                const int q = lane + 64 * i;
+                if (q < nq) {
+                    const float oh = Oh(i, q);
+                    const float sm = expf(Tv(i, q) - mt) * izt;
+                    const float a = fmaxf((1.f - beta) * sm + beta * oh, 0.f) + eps;
+                    const float w = expf(logf(a) + Sv(i, q) - nom);
+                    rbar += sm * (w / a);
+                }
             }
             rbar = wave_sum(rbar);
         }
-        for (int q = lane; q < nq; q += 64) {
-            const size_t i = (size_t)q * nv + v;
-            const float oh = labels[q] == v ? 1.f : 0.f;
-            const float sm = soft ? expf(T[i] - mt) * izt : 0.f;
-            const float iv = soft ? fmaxf((1.f - beta) * sm + beta * oh, 0.f) : oh;
-            const float a = iv + eps;
-            const float w = a > 0.f ? expf(logf(a) + S[i] - nom) : 0.f;
-            dS[i] += g * coef * (expf(S[i] - lse) - w);
-            if (soft && dT) dT[i] += g * coef * (1.f - beta) * sm * (-(w / a) + rbar);
+#pragma unroll
+        for (int i = 0; i < npass; ++i) {
+            const int q = lane + 64 * i;
+            if (q < nq) {
+                const size_t ix = (size_t)q * nv + v;
+                const float oh = Oh(i, q);
+                const float sq = Sv(i, q);
+                const float sm = soft ? expf(Tv(i, q) - mt) * izt : 0.f;
+                const float iv = soft ? fmaxf((1.f - beta) * sm + beta * oh, 0.f) : oh;
+                const float a = iv + eps;
+                const float w = a > 0.f ? expf(logf(a) + sq - nom) : 0.f;
+                dS[ix] += g * coef * (expf(sq - lse) - w);
+                if (soft && dT) dT[ix] += g * coef * (1.f - beta) * sm * (-(w / a) + rbar);
+            }
         }
     }
 }
@@ -208,7 +257,7 @@ __global__ __launch_bounds__(256) void trip_t2v_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ rsel, float margin, float scale, int nq,
                                                        int nv, float* __restrict__ terms, float* __restrict__ dC, const float* __restrict__ gp) {
     const float g = gp ? *gp : 0.f;
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wave;
     float* row = sm + (size_t)wave * nv;
@@ -217,12 +266,23 @@ __global__ __launch_bounds__(256) void trip_t2v_kernel(const float* __restrict__
     if (q >= nq) return;
     const int lab = labels[q];
     const int want = rsel[q] - 1;               // 0-based rank among the others
+    const bool vec = (nv & 3) == 0;
     int found = -1;
     for (int v = lane; v < nv; v += 64) {
         if (v == lab) continue;
         const float x = row[v];
         int rank = 0;
-        for (int u = 0; u < nv; ++u) {
+        int u = 0;
+        for (; u + 4 <= nv; u += 4) {           // 16-byte LDS reads (the row is 16-byte aligned: nv * 4 bytes per wave, nv % 4 == 0 checked by `vec`)
+            if (!vec) break;
+            const f32x4 y4 = *reinterpret_cast<const f32x4*>(row + u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = y4[e];
+                rank += (u + e != lab) && ((y > x) || (y == x && u + e < v));
+            }
+        }
+        for (; u < nv; ++u) {
             if (u == lab) continue;
             const float y = row[u];
             rank += (y > x) || (y == x && u < v);
@@ -358,8 +418,12 @@ int dldkd_nce_f32(const float* S, const float* T, const int32_t* labels, const f
     if (!S || !labels || !cq || !cv) { set_error("nce: null pointer"); return DLDKD_EINVAL; }
     DLDKD_LAUNCH(nce_rows_kernel, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, T, labels, cq, hardQ, beta, nq,
                        nv, terms, dS, dT, g);
-    DLDKD_LAUNCH(nce_cols_kernel, dim3((nv + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, T, labels, cv, hardV, beta, eps,
-                       nq, nv, terms ? terms + nq : nullptr, dS, dT, g);
+    if (nq <= 64 * kNceMaxQ)
+        DLDKD_LAUNCH(nce_cols_kernel<true>, dim3((nv + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, T, labels, cv, hardV, beta, eps,
+                           nq, nv, terms ? terms + nq : nullptr, dS, dT, g);
+    else
+        DLDKD_LAUNCH(nce_cols_kernel<false>, dim3((nv + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, T, labels, cv, hardV, beta, eps,
+                           nq, nv, terms ? terms + nq : nullptr, dS, dT, g);
     return check_launch("nce");
 }
 

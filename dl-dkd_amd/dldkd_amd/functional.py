@@ -630,11 +630,23 @@ class _NCE(Function):
         return dS, None, None, None, None, None, None, None, None, None
 
 
+_COEF_CACHE = {}
+
+
 def _part_coefs(n, hard_n, w_hard, w_soft, device):
-    # two fills on the device (no pageable host-to-device copy: that blocks the host and cannot be graph-captured)
+    """c[:hard_n] = w_hard, c[hard_n:] = w_soft as a device vector.  The vectors depend on (batch shape, alpha) only, so they are
+    built once (two fills on the device - no pageable host-to-device copy: that blocks the host and cannot be graph-captured)
+    and kept: the 12 fills per step were 4.7 us each in the replayed step.  A vector first needed while a capture is open is
+    built inside it and not kept (its memory belongs to the graph's pool)."""
+    key = (int(n), int(hard_n), float(w_hard), float(w_soft), str(device))
+    c = _COEF_CACHE.get(key)
+    if c is not None:
+        return c
     c = torch.full((n,), float(w_soft), dtype=torch.float32, device=device)
     if hard_n > 0:
         c[:hard_n] = float(w_hard)
+    if torch.device(device).type == "cuda" and not torch.cuda.is_current_stream_capturing():
+        _COEF_CACHE[key] = c              # never evicted: captured graphs read these vectors by address (a few KB per (shape, alpha))
     return c
 
 
@@ -658,8 +670,8 @@ def nce_hard(labels, S):
     """clip_nce.forward (model_components.py:216-234)."""
     S = _f32(S)
     Nq, Nv = S.shape
-    cq = torch.full((Nq,), 1.0 / Nq, dtype=torch.float32, device=S.device)
-    cv = torch.full((Nv,), 1.0 / Nv, dtype=torch.float32, device=S.device)
+    cq = _part_coefs(Nq, 0, 0.0, 1.0 / Nq, S.device)
+    cv = _part_coefs(Nv, 0, 0.0, 1.0 / Nv, S.device)
     return _NCE.apply(S, None, labels, cq, cv, Nq, Nv, 0.0, 0.0, False)
 
 

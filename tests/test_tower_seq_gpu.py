@@ -200,8 +200,9 @@ def test_encode_context_fused_vs_unfused_throughput_mode():
 
 
 def test_eval_epoch_fused_gallery_path(golden_dir):
-    """compute_context_info(keep_frame_feats=False) in throughput mode goes through encode_context_into (K4 + fused tower
-    straight into the packed gallery): scores against the fp32 parity path on the G5 inputs."""
+    """compute_context_info(keep_frame_feats=False) in throughput mode goes through the fused gallery encode (K4b on the resident
+    feature table - or K4 on padded super-batches - + the fused tower straight into the packed gallery): scores against the fp32
+    parity path on the G5 inputs."""
     import types
     from dldkd_amd import eval as ev, ops
     m = _model(3072, 768, synth.make_params(51, 3072, 768))
@@ -210,8 +211,9 @@ def test_eval_epoch_fused_gallery_path(golden_dir):
                                 device=torch.device(DEV), double_branch=True)
     res = {}
     calls = []
-    real = m.encode_context_into
+    real, real_res = m.encode_context_into, m.encode_resident_into     # padded super-batches / the resident feature table (K4b)
     m.encode_context_into = lambda *a, **k: calls.append(1) or real(*a, **k)
+    m.encode_resident_into = lambda *a, **k: calls.append(1) or real_res(*a, **k)
     try:
         for mode in ("fp32", "bf16"):
             ops.set_gemm_precision(mode)

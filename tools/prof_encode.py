@@ -36,6 +36,34 @@ if len(sys.argv) > 1 and sys.argv[1] == "fused":
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
     print(f"encode_context_into {NB}x128x3072 ragged U{{24..128}}: {dt*1e3:.2f} ms = {NB/dt:.0f} videos/s")
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "resident":
+    # round 3, second half: what eval_epoch runs in throughput mode - the whole gallery (NV videos, ragged U{24..128}) resident as a
+    # bf16 table with row statistics, ONE K4b launch + ONE fused tower launch per encode
+    from dldkd_amd import ops, scoring, eval as ev
+    ops.set_gemm_precision("bf16")
+    m.fast_input_proj = True
+    NV = int(os.environ.get("ENC_VIDEOS", "21793"))
+    g = torch.Generator(device=DEV).manual_seed(1)
+    lens = torch.randint(24, 129, (NB,), generator=g, device=DEV)
+    feats = feats * (torch.arange(128, device=DEV)[None] < lens[:, None]).float()[..., None]
+    lh = lens.cpu().numpy()
+    res = ev.ResidentGallery(3072, torch.device(DEV))
+    done = 0
+    while done < NV:
+        n = min(NB, NV - done)
+        res.table.append(feats[:n], lh[:n])
+        done += n
+    res.complete = True
+    res.plan(torch.device(DEV))
+    with torch.no_grad():
+        for _ in range(2):
+            pk = scoring.GalleryPacker(NV, 128, 2, torch.device(DEV)); m.encode_resident_into(pk, res)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            pk = scoring.GalleryPacker(NV, 128, 2, torch.device(DEV)); m.encode_resident_into(pk, res)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    print(f"encode_resident_into {NV} videos ({res.table.rows} clips, {res.table.nbytes()/1e9:.1f} GB resident): {dt*1e3:.2f} ms = {NV/dt:.0f} videos/s")
+    sys.exit(0)
 with torch.no_grad():
     for _ in range(3): m.encode_context(feats, mask)
     torch.cuda.synchronize(); t0 = time.perf_counter()
