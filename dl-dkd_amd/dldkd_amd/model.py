@@ -52,6 +52,7 @@ class DLDKD(nn.Module):
 
         self.tower_streams = False         # training: the four towers on four streams (_encode_towers)
         self._side_streams = None
+        self._tower_runner = None
         self.weight = 1
         self.kl_intra_weight = opt.kl_intra_weight
         self.inher_nce_weight = opt.inher_nce_weight
@@ -380,6 +381,7 @@ class DLDKD(nn.Module):
         return self.get_modularized_queries(h, mask, inheritance=(pre == ""))
 
     TOWER_FORK = "pair"
+    QUERY_TOWERS_FIRST = True
 
     def _encode_towers(self, video, vmask, text, tmask):
         """(g_inh, g_exp, q_inh, q_exp) of the training forward.  With tower_streams set (train.GraphedTrainStep sets it) the
@@ -389,8 +391,12 @@ class DLDKD(nn.Module):
         whose fork / join edges these become - runs them side by side.  Autograd runs every node's backward on the stream of
         its forward, so the backward pass of the towers overlaps the same way."""
         if not (self.tower_streams and self.training and video.is_cuda and torch.is_grad_enabled()):
-            g_inh, g_exp = self.encode_context(video, vmask)
-            q_inh, q_exp = self.encode_query(text, tmask)
+            if self.training and self.QUERY_TOWERS_FIRST:       # same order (= same dropout draws) as the four-stream form below
+                q_inh, q_exp = self.encode_query(text, tmask)
+                g_inh, g_exp = self.encode_context(video, vmask)
+            else:
+                g_inh, g_exp = self.encode_context(video, vmask)
+                q_inh, q_exp = self.encode_query(text, tmask)
             return g_inh, g_exp, q_inh, q_exp
         if text.dim() == 2:                  # the reference's collate .squeeze() drops a batch of one
             text, tmask = text.unsqueeze(0), tmask.reshape(1, -1)
@@ -400,6 +406,21 @@ class DLDKD(nn.Module):
             self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
         pres = ("", "exp_") if self.double_branch else ("",)
         jobs = [(self._video_tower, pre, video, vmask) for pre in pres] + [(self._query_tower, pre, text, tmask) for pre in pres]
+        nvt = len(pres)
+        if self.QUERY_TOWERS_FIRST:
+            # autograd runs the towers' backward chains in reverse creation order, and the graph executor starts the parallel
+            # branches of a replayed step in capture order, two or three at a time: created LAST, the two long video towers are
+            # the first backward chains to start instead of the last
+            jobs = jobs[nvt:] + jobs[:nvt]
+        if self._tower_runner is not None:
+            # train.GraphedTrainStep, one GPU: every tower is captured into its OWN graph on its own stream (the runner closes the
+            # graph that is open, captures the thunks one by one and opens the graph of the losses); the replay launches the four
+            # forward graphs - and later the four backward graphs - on four real streams
+            outs = self._tower_runner([(lambda fn=fn, pre=pre, x=x, m=m: fn(pre, x, m)) for fn, pre, x, m in jobs],
+                                      [int(x.numel()) for _, _, x, _ in jobs])
+            if self.QUERY_TOWERS_FIRST:
+                outs = outs[len(jobs) - nvt:] + outs[:len(jobs) - nvt]
+            return (outs[0], outs[1], outs[2], outs[3]) if self.double_branch else (outs[0], None, outs[1], None)
         outs = []
         # Where the side streams fork matters: a stream that waits for `cur` AFTER tower 0 was enqueued there waits for tower 0
         # (the first 0.6 ms of the C3 step ran one tower alone).  TOWER_FORK = "pair": the second video tower forks before
@@ -420,6 +441,8 @@ class DLDKD(nn.Module):
         for i in range(1, len(jobs)):
             cur.wait_stream(self._side_streams[i - 1])
             outs[i].record_stream(cur)       # allocated on a side stream, consumed by the losses on this one
+        if self.QUERY_TOWERS_FIRST:
+            outs = outs[len(jobs) - nvt:] + outs[:len(jobs) - nvt]
         if self.double_branch:
             return outs[0], outs[1], outs[2], outs[3]
         return outs[0], None, outs[1], None

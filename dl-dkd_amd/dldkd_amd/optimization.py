@@ -87,6 +87,8 @@ class FlatParams:
         self._starts, self._numels, self._views = starts, numels, None     # host copies: no .tolist() sync per step
         self._bound, self._had = False, tuple(True for _ in self.params)
         self._had_partial = {}
+        self._had_subset = {}
+        self._index = index
 
     def views(self):
         if self._views is None:
@@ -101,6 +103,7 @@ class FlatParams:
             p.grad = None
         self._bound = False
         self._had_partial = {}
+        self._had_subset = {}
 
     def _gather(self, members):
         views = self.views()
@@ -123,7 +126,15 @@ class FlatParams:
         """Point every p.grad at its flat view without copying (a replayed graph segment wrote the flat ranges itself)."""
         for p, v in zip(self.params, self.views()):
             p.grad = v
-        self._bound, self._had, self._had_partial = True, tuple(had), {}
+        self._bound, self._had, self._had_partial, self._had_subset = True, tuple(had), {}, {}
+
+    def gather_subset(self, params):
+        """rebind_grads for an arbitrary subset of the parameters whose gradients are final (one tower's, on the stream that
+        computed them: train.GraphedTrainStep captures a tower's backward pass and this copy into that tower's own graph)."""
+        idx = [self._index[id(p)] for p in params]
+        idx = [i for i in idx if i not in self._had_subset]
+        for i, h in zip(idx, self._gather(idx)):
+            self._had_subset[i] = h
 
     def rebind_bucket(self, b):
         """rebind_grads for the parameters of bucket b alone (their gradients are final: train.backward_in_phases)."""
@@ -145,6 +156,10 @@ class FlatParams:
                     had[i] = h
             else:
                 todo += members
+        for i in todo:
+            if i in self._had_subset:      # gathered with its tower (gather_subset)
+                had[i] = self._had_subset[i]
+        todo = [i for i in todo if i not in self._had_subset]
         for i, h in zip(todo, self._gather(todo)):
             had[i] = h
         self._bound, self._had = True, tuple(had)

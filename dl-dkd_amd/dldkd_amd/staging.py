@@ -47,3 +47,39 @@ class PinnedRing:
             ev = torch.cuda.Event()
             ev.record()
             self.events[self.i] = ev
+
+
+def concurrent_streams(device, n, candidates=16, cycles=1_000_000):
+    """n torch streams that run side by side on the device.  HIP multiplexes its streams onto GPU_MAX_HW_QUEUES (default 4)
+    hardware queues, and two streams that share a queue execute their kernels in order: of torch's pooled streams number 0 shares
+    a queue with 7 and 11, 3 with 4 and 8, ... (tools/probe_stream_queues.py) - the training stepper's four tower streams were
+    two pairs on two queues.  The mapping is not visible through the API, so it is measured once: a one-workgroup spin kernel
+    (torch.cuda._sleep) on a pair of streams takes one kernel time when they have their own queues and two when they share
+    one.  Greedy: a candidate joins the set when it overlaps with every stream already in it."""
+    import time
+    device = torch.device(device)
+    cands = [torch.cuda.Stream(device=device) for _ in range(max(candidates, n))]
+
+    def run(streams):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for s in streams:
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(cycles)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+
+    run(cands[:1])
+    one = min(run(cands[:1]) for _ in range(3))
+    chosen = [cands[0]]
+    for c in cands[1:]:
+        if len(chosen) == n:
+            break
+        if all(min(run([c, o]) for _ in range(2)) < 1.5 * one for o in chosen):
+            chosen.append(c)
+    for c in cands:                    # fewer than n distinct queues (GPU_MAX_HW_QUEUES < n): fill up with what there is
+        if len(chosen) == n:
+            break
+        if c not in chosen:
+            chosen.append(c)
+    return chosen

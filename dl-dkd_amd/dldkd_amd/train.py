@@ -209,6 +209,9 @@ class GraphedTrainStep:
         # their under-filled kernels side by side (C3 bf16 step 5.9 -> 5.3 ms); opt.tower_streams = False keeps one stream
         if hasattr(model, "tower_streams"):
             model.tower_streams = bool(getattr(opt, "tower_streams", True))
+        # one GPU: the towers as separate graphs replayed on their own streams (_capture_parallel); opt.parallel_tower_graphs =
+        # False keeps the single graph with fork / join edges
+        self.parallel_towers = bool(getattr(opt, "parallel_tower_graphs", True))
 
     # -- what is baked into a graph
     def _key(self, batch):
@@ -246,7 +249,13 @@ class GraphedTrainStep:
     def __call__(self, batch):
         dev = batch["student_videos"].device
         if self.stream is None:
-            self.stream = torch.cuda.Stream(device=dev)
+            if self.parallel_towers and getattr(self.model, "tower_streams", False) and hasattr(self.model, "_side_streams"):
+                # this stepper's stream and the model's three side streams on four DIFFERENT hardware queues (measured once)
+                from .staging import concurrent_streams
+                st = concurrent_streams(dev, 4)
+                self.stream, self.model._side_streams = st[0], list(st[1:4])
+            else:
+                self.stream = torch.cuda.Stream(device=dev)
             self.comm_stream = torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
         self.stream.wait_stream(cur)
@@ -324,6 +333,9 @@ class GraphedTrainStep:
             # Kernels the autograd thread launches into the capturing stream are captured in either mode.
             if e.ddp and hasattr(m, "forward_phased") and len(opt_.fp.bucket_ranges) > 1:
                 self._capture_segments(e)
+            elif (not e.ddp and self.parallel_towers and hasattr(m, "forward_phased") and hasattr(m, "_tower_runner")
+                  and getattr(m, "tower_streams", False) and hasattr(opt_.fp, "gather_subset")):
+                self._capture_parallel(e)
             else:
                 with torch.cuda.graph(e.graph, stream=self.stream, capture_error_mode="thread_local"):
                     loss, parts = m.forward_tensors(e.static, staged=e)
@@ -386,6 +398,123 @@ class GraphedTrainStep:
             close_segment(type(ex), ex, ex.__traceback__)
             raise
 
+    def _capture_parallel(self, e):
+        """One GPU: the step as 3 + 2 T graphs (T towers) - [zero arena, lengths] -> T x [tower forward] -> [losses + their
+        backward pass down to the tower outputs] -> T x [tower backward + gather of its gradients] -> [optimizer] - where every
+        tower graph is captured on ITS OWN stream with its own memory pool and the replay launches the T forward graphs (and
+        later the T backward graphs) on those T streams between events.  A single graph with fork / join edges leaves the
+        overlap to the graph executor, which (ROCm 7.0.2) runs the four backward chains of the C3 step two at a time in a
+        fixed order - the second video tower started when the first query tower was done (profiles/r03/
+        step_timeline_bf16_graph.txt) - and crashes when three side streams fork from one point in several graphs of a
+        process (DLDKD.TOWER_FORK).  Here every graph is a linear chain on one stream and the concurrency is that of T real
+        streams.  Graphs of one pool are captured and replayed in the same order on one stream (forward i, backward i;
+        the three main-stream graphs); tensors that cross pools (tower outputs, their gradients, saved activations, the zero
+        arena) are alive while their consumer is captured, and nothing is captured into their pool afterwards that could run
+        before that consumer."""
+        m, opt_ = self.model, self.optimizer
+        dev = e.static["student_videos"].device
+        ctx = [None]
+        pools = {}
+
+        def pool(k):
+            if k not in pools:
+                pools[k] = torch.cuda.graph_pool_handle()
+            return pools[k]
+
+        def open_graph(stream, pool_key):
+            g = torch.cuda.CUDAGraph()
+            c = torch.cuda.graph(g, pool=pool(pool_key), stream=stream, capture_error_mode="thread_local")
+            c.__enter__()
+            ctx[0] = c
+            return g
+
+        def close_graph(*exc):
+            c, ctx[0] = ctx[0], None
+            if c is not None:
+                c.__exit__(*(exc or (None, None, None)))
+
+        e.par = {"fwd": [], "bwd": [], "streams": []}
+        stream_of = {}
+
+        def runner(thunks, weights):
+            close_graph()                                   # the graph in front of the towers ends here
+            # launch order of the replay: the towers with the most input first.  Launching a graph costs the host ~10 us per
+            # kernel node, so the T graphs of a phase reach the GPU 0.3-0.5 ms apart: the long video towers must not be last
+            e.par["order"] = sorted(range(len(thunks)), key=lambda i: -weights[i])
+            # tower i on the stream the eager step (model._encode_towers) runs it on: this stepper's stream and the model's
+            # side streams - a parameter's gradient-accumulation node stays bound to the stream of its first use
+            if m._side_streams is None or m._side_streams[0].device != dev:
+                m._side_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+            streams = ([self.stream] + list(m._side_streams))[:len(thunks)]
+            if len(streams) < len(thunks):
+                raise RuntimeError("parallel tower graphs: more towers than streams")
+            outs = []
+            for i, th in enumerate(thunks):
+                e.par["fwd"].append(open_graph(streams[i], ("tower", i)))
+                outs.append(th())
+                close_graph()
+            e.par["streams"] = streams
+            e.par["loss"] = open_graph(self.stream, "main")
+            # the losses read the tower outputs through views made HERE, on the main stream: d loss / d view is then captured
+            # at a node of this stream (no cross-stream hand-over inside the capture); the tower's own backward graph starts from
+            # the original output with that gradient fed in
+            views = [o.view_as(o) for o in outs]
+            for i, (v, o) in enumerate(zip(views, outs)):
+                stream_of[id(v)] = (i, o)
+            return views
+
+        m._tower_runner = runner
+        try:
+            e.par["pre"] = open_graph(self.stream, "main")
+            loss, parts, phases = m.forward_phased(e.static, staged=e)
+            taps = [t for t, _ in phases]
+            if any(t is None or id(t) not in stream_of for t in taps):
+                raise RuntimeError("parallel tower graphs: a backward phase is not one of the towers")
+            grads = torch.autograd.grad(loss, taps, allow_unused=True)
+            e.loss, e.parts = loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in parts.items()}
+            close_graph()
+            e.par["bwd"] = [None] * len(e.par["fwd"])
+            for (tap, params), g in zip(phases, grads):
+                i, out = stream_of[id(tap)]
+                e.par["bwd"][i] = open_graph(e.par["streams"][i], ("tower", i))
+                if g is not None:
+                    torch.autograd.backward([out], [g], inputs=list(params))
+                opt_.fp.gather_subset(params)
+                close_graph()
+            del out, tap
+            stream_of.clear()
+            del loss, parts, phases, taps, grads
+            e.par["opt"] = open_graph(self.stream, "main")
+            e.had = opt_.fp.rebind_grads()
+            opt_.enqueue(upload_lr=False)
+            close_graph()
+            n = len(e.par["fwd"])
+            e.par["ev"] = {k: [torch.cuda.Event() for _ in range(n)] for k in ("fwd", "bwd")}
+            e.par["ev_pre"], e.par["ev_loss"] = torch.cuda.Event(), torch.cuda.Event()
+        except BaseException as ex:
+            close_graph(type(ex), ex, ex.__traceback__)
+            raise
+        finally:
+            m._tower_runner = None
+
+    def _replay_parallel(self, e):
+        par, main = e.par, self.stream
+        par["pre"].replay()
+        par["ev_pre"].record(main)
+        for phase, ev_in in (("fwd", par["ev_pre"]), ("bwd", par["ev_loss"])):
+            for i in par["order"]:
+                st = par["streams"][i]
+                st.wait_event(ev_in)
+                with torch.cuda.stream(st):
+                    par[phase][i].replay()
+                    par["ev"][phase][i].record(st)
+            for ev in par["ev"][phase]:
+                main.wait_event(ev)
+            if phase == "fwd":
+                par["loss"].replay()
+                par["ev_loss"].record(main)
+        par["opt"].replay()
+
     def _replay(self, e, batch):
         from . import ops
         m, opt_ = self.model, self.optimizer
@@ -404,7 +533,10 @@ class GraphedTrainStep:
             if r_v2t is not None:
                 slot[e.off[("v2t", c)]:e.off[("v2t", c)] + e.nv] = r_v2t
         e.ring.upload(e.dev_words.view(torch.uint8))
-        if getattr(e, "segments", None):
+        if getattr(e, "par", None):
+            opt_.fp.bind_views(e.had)                     # the captured copies fill the flat ranges: nothing to gather
+            self._replay_parallel(e)
+        elif getattr(e, "segments", None):
             from . import dist as ddist
             sync = ddist.BucketedGradSync(opt_.fp, comm_stream=self.comm_stream)
             opt_.fp.bind_views(e.had)                     # the captured copies fill the flat ranges: nothing to gather

@@ -441,3 +441,63 @@ def test_train_with_the_device_resident_set_follows_the_host_loader_run(tmp_path
     for a, b in zip(*hist):
         assert a[1]["loss_overall"] == pytest.approx(b[1]["loss_overall"], rel=2e-3)      # fp32-atomic reductions vary run to run
         assert abs(a[2] - b[2]) <= 12.0
+
+
+def test_parallel_tower_graphs_are_used_and_match_the_single_graph():
+    """One GPU: GraphedTrainStep captures the step as 3 + 2 T graphs - every tower's forward and backward pass in its own graph,
+    on its own stream and memory pool - and replays the tower graphs side by side on streams that were MEASURED to have their
+    own hardware queues (staging.concurrent_streams).  Against the single graph with fork / join edges (opt.parallel_tower_graphs
+    = False): same losses and parameters step by step, with dropout, across two graph keys; the captured entry really is the
+    multi-graph form and the four streams overlap pairwise."""
+    import synth
+    from dldkd_amd import ops, staging
+    from dldkd_amd import train as T
+    from dldkd_amd.model import DLDKD
+    from dldkd_amd.optimization import BertAdam
+    cfg = types.SimpleNamespace(visual_input_size=256, query_input_size=128, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=32, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4, initializer_range=0.02,
+                                margin=0.1, use_hard_negative=False, hard_pool_size=20, label_style="soft")
+    mopt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                 collection="tvr", alpha=0.8, belta=0.8)
+    batches = [synth.make_train_batch(80 + i, nv=24, caps=2, L=20 + 20 * (i % 2), len_lo=3, dv=256, dq=128) for i in range(2)]
+    batches = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
+
+    def make(par):
+        torch.manual_seed(13)
+        m = DLDKD(types.SimpleNamespace(**vars(cfg), ), mopt).to(DEV).train()
+        o = BertAdam([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=2e-3, warmup=0.1, t_total=40)
+        return m, o, T.GraphedTrainStep(m, o, types.SimpleNamespace(grad_clip=-1, parallel_tower_graphs=par))
+
+    ops.set_gemm_precision("bf16")
+    try:
+        ma, oa, sa = make(True)
+        mb, ob, sb = make(False)
+        for it in range(10):
+            ob.fp.flat.copy_(oa.fp.flat); ob.m.copy_(oa.m); ob.v.copy_(oa.v); ob.step_count = oa.step_count
+            torch.manual_seed(300 + it)
+            la, _ = sa(batches[it % 2])
+            torch.manual_seed(300 + it)
+            lb, _ = sb(batches[it % 2])
+            assert float(la) == pytest.approx(float(lb), rel=1e-3), it
+            assert (oa.fp.flat - ob.fp.flat).abs().max().item() <= 2e-5 + 0.05 * oa.get_lr()[0], it
+        assert sa.replays >= 6 and sb.replays >= 6
+        assert all(getattr(e, "par", None) for e in sa.graphs.values()) and len(sa.graphs) == 2
+        assert not any(getattr(e, "par", None) for e in sb.graphs.values())
+        e = next(iter(sa.graphs.values()))
+        assert len(e.par["fwd"]) == len(e.par["bwd"]) == 4 and len({id(s) for s in e.par["streams"]}) == 4
+        # the four streams run a one-workgroup spin kernel side by side (their own hardware queues)
+        import time
+        def spin(streams):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for s in streams:
+                with torch.cuda.stream(s):
+                    torch.cuda._sleep(2_000_000)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        spin(e.par["streams"][:1])
+        one = min(spin(e.par["streams"][:1]) for _ in range(3))
+        assert min(spin(e.par["streams"]) for _ in range(3)) < 1.6 * one
+        assert len(staging.concurrent_streams(torch.device(DEV), 3)) == 3
+    finally:
+        ops.set_gemm_precision("fp32")
