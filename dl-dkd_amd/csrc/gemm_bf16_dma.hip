@@ -1,0 +1,162 @@
+// gemm_bf16_nt: C[M, N] = act(A[M, K] . B[N, K]^T + bias), fp32 operands in memory (both k-minor: the Linear forward layout, and
+// dX once the weight has been transposed), bf16 MFMA, fp32 accumulation - the throughput-mode GEMM of the towers' 384- and
+// 1152-wide layers (reference model_components.py:302,388-390,442) where gemm_bf16_kernel is latency-bound: at 16,384 x 384 x
+// 384 a workgroup of that kernel makes 12 dependent round trips (global load -> registers -> convert -> LDS -> barrier, one
+// k-tile of prefetch) for 2 us of MFMA work, 23 us in all against ~10 us for moving the 50 MB once.
+// Here the operand tiles go HBM / L2 -> LDS by LDS-DMA as fp32 (no staging registers, no conversion on the way in), a whole
+// ring of NST k-tiles per operand is in flight from the first instruction, and the fragments are read from LDS as fp32 and
+// rounded to bf16 (v_cvt_pk_bf16_f32, RNE - the rounding gemm_bf16_kernel applies on its way INTO the LDS: same products, same
+// k order per element, so the results are bit-identical to gemm_bf16_kernel's).
+//   * 128 x 128 tile, 4 waves of 64 x 64 (2 x 2 mfma_f32_32x32x16_bf16 tiles), k-tiles of 32: 16 KiB per operand and stage.
+//   * LDS image of a k-tile = K4's (in_proj_rows128.hip): 128-byte rows, 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7),
+//     produced by permuting the per-lane SOURCE address of the DMA; fragment reads (lane = row, 2 x ds_read_b128) are
+//     conflict-free.
+//   * NST = 2 stages, 64 KiB per workgroup, two workgroups per CU (a 16,384 x 384 GEMM is 384 workgroups: one round).
+//     The DMA of tile t + 1 is issued before the fragment reads of tile t; its wait (asm vmcnt(0): the compiler does not see
+//     the DMA and so does not drain the queue before unrelated LDS reads) sits in front of the tile's closing barrier.
+//   * epilogue: gemm_store_tile (bias, ReLU, float4 rows through the wave's LDS), XCD-aware tile order.
+#include "common.hpp"
+
+namespace dldkd {
+namespace gdma {
+
+constexpr int BM = 128, BN = 128, BK = 32, NST = 2;
+constexpr int TILE_B = BM * BK * 4;                 // 16 KiB: one operand's k-tile as fp32
+constexpr int STAGE_B = 2 * TILE_B;                 // A then B
+
+struct Args {
+    const float* A;
+    const float* B;
+    const float* bias;
+    float* C;
+    int M, N, K, lda, ldb, ldc, relu;
+    float alpha;
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void glds16_s(uint32_t voff, const char* sbase, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ bf16x8 cvt8(const f32x4& lo, const f32x4& hi) {
+    u32x4 u;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[0]) : "v"(lo[0]), "v"(lo[1]));
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[1]) : "v"(lo[2]), "v"(lo[3]));
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[2]) : "v"(hi[0]), "v"(hi[1]));
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[3]) : "v"(hi[2]), "v"(hi[3]));
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Tile3 bid = xcd_tile_order();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = bid.y * BM, n0 = bid.x * BN;
+    const int nk = p.K / BK;
+    const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
+
+    // DMA: piece t = 4 wave + q of a tile = rows 8 t .. 8 t + 7 (1 KiB); lane -> LDS chunk 64 t + lane = row 8 t + (lane >> 3),
+    // position lane & 7, which holds global chunk (lane & 7) ^ ((row >> 1) & 7) of that row.  Rows past the end are clamped
+    // (they feed accumulator rows / columns that are never stored).
+    uint32_t voa[4], vob[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = 8 * (4 * wave + q) + (lane >> 3);
+        const int ch = ((lane & 7) ^ ((row >> 1) & 7)) << 4;
+        const int ra = min(m0 + row, p.M - 1) - m0, rb = min(n0 + row, p.N - 1) - n0;     // may be negative only if the tile is empty (never launched)
+        voa[q] = (uint32_t)(ra * p.lda * 4 + ch);
+        vob[q] = (uint32_t)(rb * p.ldb * 4 + ch);
+    }
+    const char* abase = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
+    const char* bbase = reinterpret_cast<const char*>(p.B + (size_t)n0 * p.ldb);
+    auto issue = [&](int kt, int stage) {
+        const char* as = abase + (size_t)kt * (BK * 4);
+        const char* bs = bbase + (size_t)kt * (BK * 4);
+        const uint32_t dst = smem_lds + stage * STAGE_B + (4 * wave) * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16_s(voa[q], as, dst + q * 1024);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16_s(vob[q], bs, dst + TILE_B + q * 1024);
+    };
+
+    // fragment reads: lane (r = lane & 31, h = lane >> 5) takes chunks 4 kk + 2 h + e (e = 0, 1) of row `base + r`
+    int fo[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = lane & 31, c = 4 * kk + 2 * (lane >> 5) + e;
+            fo[kk][e] = r * 128 + ((c ^ ((r >> 1) & 7)) << 4);        // (rows 32 i + r: (r >> 1) & 7 is unchanged by + 32 i)
+        }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, st ^ 1);
+        const char* As = smem + st * STAGE_B + wm * 128;
+        const char* Bs = smem + st * STAGE_B + TILE_B + wn * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(As + i * 4096 + fo[kk][0]);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(As + i * 4096 + fo[kk][1]);
+                a[i] = cvt8(lo, hi);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(Bs + j * 4096 + fo[kk][0]);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(Bs + j * 4096 + fo[kk][1]);
+                b[j] = cvt8(lo, hi);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile has landed (this wave's pieces; the barrier covers the others)
+        __syncthreads();                                       // and everyone is done reading this one
+    }
+    gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * 72));
+}
+
+}  // namespace gdma
+}  // namespace dldkd
+
+using namespace dldkd;
+
+extern "C" int dldkd_gemm_bf16_nt_ok(int M, int N, int K, int lda, int ldb) {
+    return M > 0 && N > 0 && K >= gdma::BK && (K % gdma::BK) == 0 && !(lda & 3) && !(ldb & 3) &&
+           (long)127 * lda * 4 + 128 <= 0x7fffffffL && (long)127 * ldb * 4 + 128 <= 0x7fffffffL;
+}
+
+extern "C" int dldkd_gemm_bf16_nt(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
+                                  int ldc, int relu, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || lda < K || ldb < K || ldc < N) { set_error("gemm_bf16_nt: bad sizes"); return DLDKD_EINVAL; }
+    if (M == 0 || N == 0) return DLDKD_OK;
+    if (!A || !B || !C) { set_error("gemm_bf16_nt: null pointer"); return DLDKD_EINVAL; }
+    if (!dldkd_gemm_bf16_nt_ok(M, N, K, lda, ldb) || (((uintptr_t)A | (uintptr_t)B) & 15)) {
+        set_error("gemm_bf16_nt: needs K %% 32 == 0, lda / ldb %% 4 == 0 and 16-byte aligned operands (M=%d N=%d K=%d)", M, N, K);
+        return DLDKD_EINVAL;
+    }
+    gdma::Args p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu != 0, 1.0f};
+    constexpr int lds = gdma::NST * gdma::STAGE_B;
+    static const bool ok = hipFuncSetAttribute((const void*)gdma::gemm_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    (void)ok;
+    const dim3 grid((N + gdma::BN - 1) / gdma::BN, (M + gdma::BM - 1) / gdma::BM, 1);
+    DLDKD_LAUNCH(gdma::gemm_bf16_nt_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    return check_launch("gemm_bf16_nt");
+}

@@ -42,6 +42,9 @@ def gemm_precision():
     return _PRECISION
 
 
+GEMM_NT_DMA = True       # throughput mode: forward-layout GEMMs with >= 1024 rows on the LDS-DMA staged kernel
+
+
 def _gemm_fn(L):
     if _PRECISION == "bf16":
         return L.dldkd_gemm_bf16
@@ -78,6 +81,11 @@ def linear(x, weight, bias=None, relu=False):
     if weight.shape[1] != K:
         raise native.NativeError(f"linear: x has {K} features, weight expects {weight.shape[1]}")
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    if GEMM_NT_DMA and _PRECISION == "bf16" and M >= 1024 and L.dldkd_gemm_bf16_nt_ok(M, N, K, K, K):
+        # throughput mode, many rows: operand tiles by LDS-DMA (gemm_bf16_dma.hip; bit-identical to dldkd_gemm_bf16)
+        native.check(L.dldkd_gemm_bf16_nt(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
+                                          int(relu), native.stream()), "gemm_bf16_nt")
+        return y.view(*x.shape[:-1], N)
     fn = _gemm_fn(L)
     native.check(fn(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
                     0, 0, int(relu), None, 0, native.stream()), "gemm")          # the forward layout never splits K
@@ -89,6 +97,13 @@ def gemm(a, b, a_kmajor, b_kmajor, M, N, K):
     L = native.lib()
     _chk(a, "gemm.a"); _chk(b, "gemm.b")
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if (GEMM_NT_DMA and _PRECISION == "bf16" and not a_kmajor and b_kmajor and M >= 1024 and b.dim() == 2 and b.shape[0] == K
+            and L.dldkd_gemm_bf16_nt_ok(M, N, K, a.shape[-1], K)):
+        # dX = dy . W with a weight of a few hundred rows: transpose W (K x N, < 2 MB) and the product has the forward layout
+        bt = b.t().contiguous()
+        native.check(L.dldkd_gemm_bf16_nt(native.ptr(a), native.ptr(bt), None, native.ptr(c), M, N, K, a.shape[-1], K, N, 0,
+                                          native.stream()), "gemm_bf16_nt")
+        return c
     fn = _gemm_fn(L)
     ws, ws_bytes = _gemm_workspace(L, M, N, K, a_kmajor, b_kmajor, a.device)
     native.check(fn(native.ptr(a), native.ptr(b), None, native.ptr(c), M, N, K, a.shape[-1], b.shape[-1], N,

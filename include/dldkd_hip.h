@@ -306,6 +306,14 @@ int dldkd_gemm_bf16(const float* A, const float* B, const float* bias, float* C,
  *                     dldkd_gemm_workspace_bytes(DLDKD_GEMM_BF16, M, N, K, 1, 1) bytes (NULL: no split). */
 int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
                           int ldc, int relu, void* workspace, size_t workspace_bytes, void* stream);
+/* The forward layout of dldkd_gemm_bf16 - C[M, N] = act(A[M, K] . B[N, K]^T + bias), both operands fp32 and k-minor (a Linear's
+ * forward pass; its input gradient once the weight is transposed) - with the operand tiles staged HBM -> LDS by LDS-DMA instead
+ * of through registers (gemm_bf16_dma.hip): same products in the same order, bit-identical results, about half the time on
+ * the towers' 16,384-row x 384 / 1152-wide layers, which are latency-bound in the register-staged kernel.  Needs K % 32 == 0,
+ * lda / ldb % 4 == 0, 16-byte aligned operands (dldkd_gemm_bf16_nt_ok); no split-K. */
+int dldkd_gemm_bf16_nt(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       int relu, void* stream);
+int dldkd_gemm_bf16_nt_ok(int M, int N, int K, int lda, int ldb);
 
 /* fp32-GRADE GEMM on the bf16 matrix cores: each fp32 operand is split into three bf16 planes (h + m + l = 24 mantissa
  * bits) on the way to LDS and every product is rebuilt from the six plane products of order <= 2 with fp32 accumulation

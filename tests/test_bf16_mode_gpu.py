@@ -287,3 +287,38 @@ def test_bf16_rows_of_the_training_input_projection(bf16_mode, M, N, K, p_drop):
     with pytest.raises(native.NativeError):                                                # odd ldb / N of the bf16 k-major operand
         native.check(L.dldkd_gemm_bf16_mixed(1, native.ptr(dy), native.ptr(z16), None, native.ptr(dw), N, K - 1, M, N, K - 1, K - 1, 0, None, 0,
                                              native.stream()), "dw")
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(16384, 384, 384, True), (19200, 1152, 384, False), (1000, 130, 96, True), (2049, 384, 3072, False),
+                                        (1024, 64, 32, True)])
+def test_gemm_bf16_nt_dma_is_bit_identical_to_gemm_bf16(bf16_mode, M, N, K, relu):
+    """dldkd_gemm_bf16_nt (operand tiles HBM -> LDS by LDS-DMA as fp32, rounded to bf16 at the fragment read) against
+    dldkd_gemm_bf16 (rounded on the way into the LDS): the same products in the same order - equal bit for bit, ragged row and
+    column edges included; ops.linear / the dX layout of ops.gemm route through it in throughput mode."""
+    from dldkd_amd import native, ops
+    L = native.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    assert L.dldkd_gemm_bf16_nt_ok(M, N, K, K, K)
+    y_new, y_old = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    native.check(L.dldkd_gemm_bf16_nt(native.ptr(a), native.ptr(w), native.ptr(b), native.ptr(y_new), M, N, K, K, K, N, int(relu),
+                                      native.stream()), "nt")
+    native.check(L.dldkd_gemm_bf16(native.ptr(a), native.ptr(w), native.ptr(b), native.ptr(y_old), M, N, K, K, K, N, 0, 0, int(relu), None, 0,
+                                   native.stream()), "old")
+    assert torch.equal(y_new, y_old)
+    ref = a.to(torch.bfloat16).double() @ w.to(torch.bfloat16).double().T + b.double()
+    ref = ref.clamp_min(0) if relu else ref
+    assert (y_new.double() - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+    # the wrappers: forward and dX (weight transposed on the fly) against the register-staged kernel
+    dy = torch.randn(M, N, generator=g).to(DEV)
+    try:
+        ops.GEMM_NT_DMA = True
+        y1, dx1 = ops.linear(a, w, b, relu=relu), ops.gemm(dy, w, False, True, M, K, N)
+        ops.GEMM_NT_DMA = False
+        y0, dx0 = ops.linear(a, w, b, relu=relu), ops.gemm(dy, w, False, True, M, K, N)
+    finally:
+        ops.GEMM_NT_DMA = True
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+    assert not L.dldkd_gemm_bf16_nt_ok(M, N, K + 8, K + 8, K + 8)
