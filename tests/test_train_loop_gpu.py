@@ -455,7 +455,7 @@ def test_parallel_tower_graphs_are_used_and_match_the_single_graph():
     from dldkd_amd.model import DLDKD
     from dldkd_amd.optimization import BertAdam
     cfg = types.SimpleNamespace(visual_input_size=256, query_input_size=128, inheritance_hidden=384, exploration_hidden=384,
-                                max_ctx_l=32, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4, initializer_range=0.02,
+                                max_ctx_l=64, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4, initializer_range=0.02,
                                 margin=0.1, use_hard_negative=False, hard_pool_size=20, label_style="soft")
     mopt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
                                  collection="tvr", alpha=0.8, belta=0.8)
