@@ -133,19 +133,20 @@ struct TileX {
 template <bool A_KMAJOR, bool B_KMAJOR, int EPI, typename EArgs>
 __device__ __forceinline__ void gemm_f32x3_body(GemmXArgs p, const EArgs* pa) {
     __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][3 * XPLANE];   // [stage][A|B][plane][row][k]: 72 KiB
+    const Tile3 bid = xcd_tile_order();              // column tiles of a row block (split-K: row tiles of a B slab) behind one L2: gemm_bf16.hip
     if (p.split_k > 1) {
-        p.C += (size_t)blockIdx.z * p.M * p.ldc;      // this split's partial plane in the workspace
+        p.C += (size_t)bid.z * p.M * p.ldc;      // this split's partial plane in the workspace
     } else {
-        const int zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
+        const int zo = bid.z / p.batch_inner, zi = bid.z % p.batch_inner;
         p.A += zo * p.sAo + zi * p.sAi;
         p.B += zo * p.sBo + zi * p.sBi;
         p.C += zo * p.sCo + zi * p.sCi;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int m0 = blockIdx.y * XBM, n0 = blockIdx.x * XBN;
+    const int m0 = bid.y * XBM, n0 = bid.x * XBN;
     const int nk_all = (p.K + XBK - 1) / XBK;
-    const int kt0 = p.split_k > 1 ? blockIdx.z * p.k_tiles_per_split : 0;
+    const int kt0 = p.split_k > 1 ? bid.z * p.k_tiles_per_split : 0;
     const int nk = p.split_k > 1 ? min(nk_all - kt0, p.k_tiles_per_split) : nk_all;
     if (nk <= 0) return;
 
@@ -217,7 +218,7 @@ __device__ __forceinline__ void gemm_f32x3_body(GemmXArgs p, const EArgs* pa) {
         if (kt + 1 < nk) iter(kt + 1, S1{});
     }
     // (the k-loop ended with a barrier: every wave is done with the operand tiles, the LDS is free for staging)
-    if constexpr (EPI == 1) gemm_pool_tile(acc, p, *pa, (int)blockIdx.z, n0, wm, wn, lane, wave, reinterpret_cast<float*>(&lds[0][0][0]));
+    if constexpr (EPI == 1) gemm_pool_tile(acc, p, *pa, bid.z, n0, wm, wn, lane, wave, reinterpret_cast<float*>(&lds[0][0][0]));
     else if constexpr (EPI == 2) gemm_lngrad_tile(acc, p, *pa, m0, n0, wm, wn, lane, wave, reinterpret_cast<float*>(&lds[0][0][0]));
     else gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(&lds[0][0][0]) + wave * (32 * 72));
 }
