@@ -44,3 +44,56 @@ def test_collate_train_contract():
     assert batch["student_videos_mask"].sum(1).tolist() == [9, 2, 5]
     assert batch["student_text"].shape == (6, 5, 6) and batch["teacher_text"].shape == (6, 1, 512)
     assert batch["student_text_mask"].sum(1).tolist() == [3, 4, 5, 3, 4, 3]
+
+
+def test_flat_params_gather_subset_then_rebind():
+    """optimization.FlatParams.gather_subset (one tower's gradients copied into the flat buffer by that tower's own graph,
+    train.GraphedTrainStep._capture_parallel) followed by rebind_grads: every gradient lands in its flat view once, parameters
+    without a gradient are zeroed and flagged, nothing is gathered twice, drop_grads forgets the subsets."""
+    from dldkd_amd.optimization import FlatParams
+    g = torch.Generator().manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in ((3, 5), (7,), (2, 2, 2), (300,), (4, 4))]
+    fp = FlatParams(ps)
+    fp.drop_grads()
+    grads = [torch.randn(p.shape, generator=g) for p in ps]
+    for i in (0, 1, 3):
+        ps[i].grad = grads[i].clone()
+    fp.grad.fill_(9.0)
+    fp.gather_subset([ps[1], ps[3]])                       # "tower A": both have gradients
+    assert ps[1].grad.data_ptr() == fp.views()[1].data_ptr() and torch.equal(ps[3].grad, grads[3])
+    ps[3].grad.add_(1.0)                                   # a later write through the view must survive the final rebind
+    fp.gather_subset([ps[2], ps[3]])                       # "tower B": ps[2] has none; ps[3] is not gathered again
+    had = fp.rebind_grads()
+    assert had == (True, True, False, True, False)
+    for i, p in enumerate(ps):
+        assert p.grad.data_ptr() == fp.views()[i].data_ptr()
+    assert torch.equal(ps[0].grad, grads[0]) and torch.equal(ps[1].grad, grads[1]) and torch.equal(ps[3].grad, grads[3] + 1.0)
+    assert float(ps[2].grad.abs().sum()) == 0.0 and float(ps[4].grad.abs().sum()) == 0.0
+    fp.drop_grads()
+    assert fp._had_subset == {} and all(p.grad is None for p in ps)
+
+
+def test_resident_gallery_chunk_plan():
+    """eval.ResidentGallery.plan: chunks of whole videos of at most RESIDENT_CHUNK_ROWS clips (a longer video alone), rows
+    relative to the chunk, lengths and slot tables per chunk - on a stand-in table (the plan is host logic)."""
+    import numpy as np
+    from dldkd_amd import eval as ev, ops
+    lens = [5, 0, 128, 33, 64, 1, 127, 96, 2]
+    res = ev.ResidentGallery.__new__(ev.ResidentGallery)
+    res.table = types.SimpleNamespace(lens=lens)
+    old = ev.RESIDENT_CHUNK_ROWS
+    try:
+        ev.RESIDENT_CHUNK_ROWS = 200
+        res.plan(torch.device("cpu"))
+    finally:
+        ev.RESIDENT_CHUNK_ROWS = old
+    start = np.concatenate([[0], np.cumsum(lens)])
+    assert [c[0] for c in res.chunks] == [0, 4, 7] and sum(c[1] for c in res.chunks) == len(lens)
+    for va, n, r0, r1, lens_d, row0_d, items in res.chunks:
+        assert (r0, r1) == (start[va], start[va + n]) and r1 - r0 <= 200
+        assert lens_d.tolist() == lens[va:va + n] and row0_d.tolist() == (start[va:va + n] - start[va]).tolist()
+        want = ops.plan_tower_items(np.asarray(lens[va:va + n]))
+        assert items.dtype == torch.int32 and np.array_equal(items.numpy(), want)
+        seqs = {int(e) >> 10 for e in want.reshape(-1) if e >= 0}
+        assert seqs == {i for i in range(n) if lens[va + i] > 0}          # every non-empty video has its slots, empty ones none
+    assert res.lens_dev.tolist() == lens
