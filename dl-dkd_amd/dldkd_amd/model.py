@@ -488,10 +488,6 @@ class DLDKD(nn.Module):
         nv, L = mask.shape
         lens = self._lens(mask, nv, L, dev)
 
-        g_inh, g_exp, q_inh, q_exp = self._encode_towers(batch["student_videos"], mask, batch["student_text"],
-                                                         batch["student_text_mask"])
-        if taps is not None:
-            taps.update({k: v for k, v in (("g_inh", g_inh), ("g_exp", g_exp), ("q_inh", q_inh), ("q_exp", q_exp)) if v is not None})
         t_text = batch["teacher_text"].float().reshape(len(labels), -1)          # .squeeze() of model.py:114
         t_vid = batch["teacher_videos"].float()
 
@@ -510,8 +506,14 @@ class DLDKD(nn.Module):
             st = None if staged is None else (lab,) + tuple(staged.draws[call])
             return self.get_clip_triplet_loss(scores, labels, _staged=st)
 
+        # the teacher's scores need nothing of the towers: enqueued in front of them they run beside the tower graphs (the
+        # stepper's main stream is idle there) instead of at the head of the serial loss section
         with torch.no_grad():
             _, t_raw, t_clip = both(t_text, t_vid, True)
+        g_inh, g_exp, q_inh, q_exp = self._encode_towers(batch["student_videos"], mask, batch["student_text"],
+                                                         batch["student_text_mask"])
+        if taps is not None:
+            taps.update({k: v for k, v in (("g_inh", g_inh), ("g_exp", g_exp), ("q_inh", q_inh), ("q_exp", q_exp)) if v is not None})
         i_cos, i_raw, i_clip = both(q_inh, g_inh, True)
 
         inher_trip = trip(i_cos, 0)

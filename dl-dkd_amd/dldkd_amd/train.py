@@ -499,8 +499,10 @@ class GraphedTrainStep:
 
     def _replay_parallel(self, e):
         par, main = e.par, self.stream
-        par["pre"].replay()
+        # the towers read the staged batch only (the zero arena of the graph in front is for the backward passes, which wait for
+        # the loss graph): the side streams start here, beside that graph's teacher scores
         par["ev_pre"].record(main)
+        par["pre"].replay()
         for phase, ev_in in (("fwd", par["ev_pre"]), ("bwd", par["ev_loss"])):
             for i in par["order"]:
                 st = par["streams"][i]
