@@ -53,6 +53,7 @@ class DLDKD(nn.Module):
         self.tower_streams = False         # training: the four towers on four streams (_encode_towers)
         self._side_streams = None
         self._tower_runner = None
+        self._branch_runner = None
         self.weight = 1
         self.kl_intra_weight = opt.kl_intra_weight
         self.inher_nce_weight = opt.inher_nce_weight
@@ -514,24 +515,40 @@ class DLDKD(nn.Module):
                                                          batch["student_text_mask"])
         if taps is not None:
             taps.update({k: v for k, v in (("g_inh", g_inh), ("g_exp", g_exp), ("q_inh", q_inh), ("q_exp", q_exp)) if v is not None})
-        i_cos, i_raw, i_clip = both(q_inh, g_inh, True)
-
-        inher_trip = trip(i_cos, 0)
         soft = self.label_style == "soft"
-        if soft:
-            inher_nce = self.inher_nce_weight * F_.nce_soft(lab, i_raw, t_raw, self.alpha, self.belta)
-        else:
-            inher_nce = self.inher_nce_weight * F_.nce_hard(lab, i_raw)
-        explore_trip, explore_nce = 0, 0
-        if self.double_branch:
-            e_cos, e_raw, _ = both(q_exp, g_exp, False)
+
+        def inh_part(q, g):
+            i_cos, i_raw, i_clip = both(q, g, True)
+            inher_trip = trip(i_cos, 0)
+            if soft:
+                inher_nce = self.inher_nce_weight * F_.nce_soft(lab, i_raw, t_raw, self.alpha, self.belta)
+            else:
+                inher_nce = self.inher_nce_weight * F_.nce_hard(lab, i_raw)
+            kl_intra = self.kl_intra_weight * self.weight * F_.kl_frame(i_clip, t_clip, lab, lens, 0.2)
+            return inher_trip, inher_nce, kl_intra
+
+        def exp_part(q, g):
+            e_cos, e_raw, _ = both(q, g, False)
             explore_trip = trip(e_cos, 1)
             if soft:
                 explore_nce = self.explore_nce_weight * F_.nce_soft(lab, e_raw, e_raw, self.alpha, self.belta)
             else:
                 explore_nce = self.explore_nce_weight * F_.nce_hard(lab, e_raw)
-        kl_intra = self.kl_intra_weight * self.weight * F_.kl_frame(i_clip, t_clip, lab, lens, 0.2)
-        kl = kl_intra
-        loss = inher_trip + inher_nce + kl + explore_trip + explore_nce
+            return explore_trip, explore_nce
+
+        explore_trip, explore_nce = 0, 0
+        if self.double_branch and self._branch_runner is not None:
+            # train.GraphedTrainStep, one GPU: the two branches' losses - and their backward passes down to the tower outputs -
+            # are independent of each other: the runner captures each into its own graph on its own stream
+            (inher_trip, inher_nce, kl_intra), (explore_trip, explore_nce) = self._branch_runner(
+                [(inh_part, (q_inh, g_inh)), (exp_part, (q_exp, g_exp))])
+            kl = kl_intra
+            loss = (inher_trip + inher_nce + kl) + (explore_trip + explore_nce)
+        else:
+            inher_trip, inher_nce, kl_intra = inh_part(q_inh, g_inh)
+            if self.double_branch:
+                explore_trip, explore_nce = exp_part(q_exp, g_exp)
+            kl = kl_intra
+            loss = inher_trip + inher_nce + kl + explore_trip + explore_nce
         return loss, {"inher_trip": inher_trip, "inher_nce": inher_nce, "explore_trip": explore_trip,
                       "explore_nce": explore_nce, "kl": kl, "kl_intra": kl_intra}

@@ -334,7 +334,8 @@ class GraphedTrainStep:
             if e.ddp and hasattr(m, "forward_phased") and len(opt_.fp.bucket_ranges) > 1:
                 self._capture_segments(e)
             elif (not e.ddp and self.parallel_towers and hasattr(m, "forward_phased") and hasattr(m, "_tower_runner")
-                  and getattr(m, "tower_streams", False) and hasattr(opt_.fp, "gather_subset")):
+                  and getattr(m, "tower_streams", False) and getattr(m, "double_branch", False)
+                  and hasattr(opt_.fp, "gather_subset")):
                 self._capture_parallel(e)
             else:
                 with torch.cuda.graph(e.graph, stream=self.stream, capture_error_mode="thread_local"):
@@ -433,13 +434,13 @@ class GraphedTrainStep:
             if c is not None:
                 c.__exit__(*(exc or (None, None, None)))
 
-        e.par = {"fwd": [], "bwd": [], "streams": []}
-        stream_of = {}
+        e.par = {"fwd": [], "bwd": [], "streams": [], "loss": []}
+        stream_of, tap_grads = {}, {}
 
         def runner(thunks, weights):
             close_graph()                                   # the graph in front of the towers ends here
-            # launch order of the replay: the towers with the most input first.  Launching a graph costs the host ~10 us per
-            # kernel node, so the T graphs of a phase reach the GPU 0.3-0.5 ms apart: the long video towers must not be last
+            # launch order of the replay: the towers with the most input first (the graphs of a phase reach the GPU one after
+            # the other: the long video towers must not be last)
             e.par["order"] = sorted(range(len(thunks)), key=lambda i: -weights[i])
             # tower i on the stream the eager step (model._encode_towers) runs it on: this stepper's stream and the model's
             # side streams - a parameter's gradient-accumulation node stays bound to the stream of its first use
@@ -453,68 +454,98 @@ class GraphedTrainStep:
                 e.par["fwd"].append(open_graph(streams[i], ("tower", i)))
                 outs.append(th())
                 close_graph()
+                stream_of[id(outs[-1])] = i
             e.par["streams"] = streams
-            e.par["loss"] = open_graph(self.stream, "main")
-            # the losses read the tower outputs through views made HERE, on the main stream: d loss / d view is then captured
-            # at a node of this stream (no cross-stream hand-over inside the capture); the tower's own backward graph starts from
-            # the original output with that gradient fed in
-            views = [o.view_as(o) for o in outs]
-            for i, (v, o) in enumerate(zip(views, outs)):
-                stream_of[id(v)] = (i, o)
-            return views
+            return outs                                     # no graph is open: the model calls the branch runner next
 
-        m._tower_runner = runner
+        def branch_runner(parts):
+            """parts = [(fn, (q, g))] per branch: fn(q, g) -> that branch's loss terms.  Each branch gets ONE graph - its losses
+            and their backward pass down to the two tower outputs - on the stream of its query tower (branch 0: the main
+            stream), reading the tower outputs through views made on that stream inside that graph, so that d loss / d view
+            is captured at a node of the capturing stream (no cross-stream hand-over inside a capture)."""
+            res = []
+            for b, (fn, (q, g)) in enumerate(parts):
+                iq, ig = stream_of[id(q)], stream_of[id(g)]
+                st = e.par["streams"][iq]
+                gr = open_graph(st, ("loss", b))
+                qv, gv = q.view_as(q), g.view_as(g)
+                terms = fn(qv, gv)
+                total = terms[0]
+                for t in terms[1:]:
+                    total = total + t
+                gq, gg = torch.autograd.grad(total, [qv, gv], allow_unused=True)
+                close_graph()
+                e.par["loss"].append((gr, iq, (iq, ig)))
+                tap_grads[iq], tap_grads[ig] = gq, gg
+                res.append(terms)
+                del total, qv, gv
+            e.par["tail"] = open_graph(self.stream, "main")  # the sum of the two branches' terms
+            return res
+
+        m._tower_runner, m._branch_runner = runner, branch_runner
         try:
             e.par["pre"] = open_graph(self.stream, "main")
             loss, parts, phases = m.forward_phased(e.static, staged=e)
-            taps = [t for t, _ in phases]
-            if any(t is None or id(t) not in stream_of for t in taps):
+            if any(t is None or id(t) not in stream_of for t, _ in phases) or "tail" not in e.par:
                 raise RuntimeError("parallel tower graphs: a backward phase is not one of the towers")
-            grads = torch.autograd.grad(loss, taps, allow_unused=True)
             e.loss, e.parts = loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in parts.items()}
             close_graph()
-            e.par["bwd"] = [None] * len(e.par["fwd"])
-            for (tap, params), g in zip(phases, grads):
-                i, out = stream_of[id(tap)]
+            n = len(e.par["fwd"])
+            e.par["bwd"], e.par["loss_of"] = [None] * n, [None] * n
+            for b, (_, _, towers) in enumerate(e.par["loss"]):
+                for t in towers:
+                    e.par["loss_of"][t] = b
+            for tap, params in phases:
+                i = stream_of[id(tap)]
                 e.par["bwd"][i] = open_graph(e.par["streams"][i], ("tower", i))
-                if g is not None:
-                    torch.autograd.backward([out], [g], inputs=list(params))
+                if tap_grads.get(i) is not None:
+                    torch.autograd.backward([tap], [tap_grads[i]], inputs=list(params))
                 opt_.fp.gather_subset(params)
                 close_graph()
-            del out, tap
+            del loss, parts, phases, tap
             stream_of.clear()
-            del loss, parts, phases, taps, grads
+            tap_grads.clear()
             e.par["opt"] = open_graph(self.stream, "main")
             e.had = opt_.fp.rebind_grads()
             opt_.enqueue(upload_lr=False)
             close_graph()
-            n = len(e.par["fwd"])
-            e.par["ev"] = {k: [torch.cuda.Event() for _ in range(n)] for k in ("fwd", "bwd")}
-            e.par["ev_pre"], e.par["ev_loss"] = torch.cuda.Event(), torch.cuda.Event()
+            e.par["ev"] = {"fwd": [torch.cuda.Event() for _ in range(n)], "bwd": [torch.cuda.Event() for _ in range(n)],
+                           "loss": [torch.cuda.Event() for _ in e.par["loss"]]}
+            e.par["ev_pre"], e.par["ev_pre_done"] = torch.cuda.Event(), torch.cuda.Event()
         except BaseException as ex:
             close_graph(type(ex), ex, ex.__traceback__)
             raise
         finally:
-            m._tower_runner = None
+            m._tower_runner = m._branch_runner = None
 
     def _replay_parallel(self, e):
         par, main = e.par, self.stream
+        streams, ev = par["streams"], par["ev"]
         # the towers read the staged batch only (the zero arena of the graph in front is for the backward passes, which wait for
-        # the loss graph): the side streams start here, beside that graph's teacher scores
+        # a loss graph that runs behind it): the side streams start here, beside that graph's teacher scores
         par["ev_pre"].record(main)
         par["pre"].replay()
-        for phase, ev_in in (("fwd", par["ev_pre"]), ("bwd", par["ev_loss"])):
-            for i in par["order"]:
-                st = par["streams"][i]
-                st.wait_event(ev_in)
-                with torch.cuda.stream(st):
-                    par[phase][i].replay()
-                    par["ev"][phase][i].record(st)
-            for ev in par["ev"][phase]:
-                main.wait_event(ev)
-            if phase == "fwd":
-                par["loss"].replay()
-                par["ev_loss"].record(main)
+        par["ev_pre_done"].record(main)
+        for i in par["order"]:
+            streams[i].wait_event(par["ev_pre"])
+            with torch.cuda.stream(streams[i]):
+                par["fwd"][i].replay()
+                ev["fwd"][i].record(streams[i])
+        for b, (g, si, towers) in enumerate(par["loss"]):   # a branch's losses + their backward pass to its two tower outputs
+            streams[si].wait_event(par["ev_pre_done"])      # lengths, teacher scores, zero arena
+            for t in towers:
+                streams[si].wait_event(ev["fwd"][t])
+            with torch.cuda.stream(streams[si]):
+                g.replay()
+                ev["loss"][b].record(streams[si])
+        for i in par["order"]:
+            streams[i].wait_event(ev["loss"][par["loss_of"][i]])
+            with torch.cuda.stream(streams[i]):
+                par["bwd"][i].replay()
+                ev["bwd"][i].record(streams[i])
+        for x in ev["bwd"] + ev["loss"]:
+            main.wait_event(x)
+        par["tail"].replay()
         par["opt"].replay()
 
     def _replay(self, e, batch):
