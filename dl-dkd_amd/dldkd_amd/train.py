@@ -400,10 +400,10 @@ class GraphedTrainStep:
             raise
 
     def _capture_parallel(self, e):
-        """One GPU: the step as 3 + 2 T graphs (T towers) - [zero arena, lengths] -> T x [tower forward] -> [losses + their
-        backward pass down to the tower outputs] -> T x [tower backward + gather of its gradients] -> [optimizer] - where every
-        tower graph is captured on ITS OWN stream with its own memory pool and the replay launches the T forward graphs (and
-        later the T backward graphs) on those T streams between events.  A single graph with fork / join edges leaves the
+        """One GPU: the step as a handful of LINEAR graphs - [zero arena, lengths, teacher scores] -> T x [tower forward] ->
+        2 x [one branch's losses + their backward pass down to its two tower outputs] -> T x [tower backward + gather of its
+        gradients] -> [sum of the loss terms] -> [optimizer] - where every tower and every branch is captured on ITS OWN stream
+        with its own memory pool and the replay launches them on those streams between events.  A single graph with fork / join edges leaves the
         overlap to the graph executor, which (ROCm 7.0.2) runs the four backward chains of the C3 step two at a time in a
         fixed order - the second video tower started when the first query tower was done (profiles/r03/
         step_timeline_bf16_graph.txt) - and crashes when three side streams fork from one point in several graphs of a
@@ -538,7 +538,7 @@ class GraphedTrainStep:
             with torch.cuda.stream(streams[si]):
                 g.replay()
                 ev["loss"][b].record(streams[si])
-        for i in par["order"]:
+        for i in par["order"]:                              # (the submission order makes no difference here: measured)
             streams[i].wait_event(ev["loss"][par["loss_of"][i]])
             with torch.cuda.stream(streams[i]):
                 par["bwd"][i].replay()
