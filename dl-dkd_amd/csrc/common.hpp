@@ -189,7 +189,12 @@ __device__ __forceinline__ void gemm_lngrad_tile(const f32x16 (&acc)[2][2], cons
             mu[it] = la.mean[rowc];
             rs[it] = row < p.M ? la.rstd[rowc] : 0.f;        // rows past the end: xhat = 0 and (below) dz = 0
             kw[it] = 0x01010101u;
-            if (vec) {
+            xv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rs[it] == 0.f) {
+                // rstd == 0 marks a row of the padding (dldkd_layernorm_dropout_bf16 with a row mask; a real row has rstd > 0): its
+                // features are not read and it contributes nothing
+                kw[it] = 0u;
+            } else if (vec) {
                 xv[it] = *reinterpret_cast<const f32x4*>(la.x + at);
                 if (la.keep != nullptr) kw[it] = *reinterpret_cast<const unsigned*>(la.keep + at);
             } else {
@@ -208,8 +213,9 @@ __device__ __forceinline__ void gemm_lngrad_tile(const f32x16 (&acc)[2][2], cons
             const f32x4 a4 = *reinterpret_cast<const f32x4*>(stg + (rl0 + 4 * it) * SP + 4 * c4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float dz = (rok && ((kw[it] >> (8 * e)) & 0xffu)) ? a4[e] * la.keep_scale : 0.f;
-                sg[e] += dz * ((xv[it][e] - mu[it]) * rs[it]);
+                const bool on = rok && ((kw[it] >> (8 * e)) & 0xffu);
+                const float dz = on ? a4[e] * la.keep_scale : 0.f;
+                sg[e] += on ? dz * ((xv[it][e] - mu[it]) * rs[it]) : 0.f;
                 sb[e] += dz;
             }
         }

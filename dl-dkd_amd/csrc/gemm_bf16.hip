@@ -30,6 +30,8 @@ struct GemmHArgs {
     long sAo, sAi, sBo, sBi, sCo, sCi;
     float alpha;
     int split_k, k_tiles_per_split;
+    const unsigned char* kflags;   // per k-tile (32 consecutive k): 0 = every operand row of the tile is padding (exact zeros in one
+                                   // operand): the tile is skipped.  null: all tiles.  Used by the dW layout only
 };
 
 // One operand tile: 128 rows x 32 k, 16 floats per thread.
@@ -214,34 +216,49 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
             TileH<B_KMAJOR, B16>::load(p.B, p.ldb, n0, p.N, k0, p.K, tid, p.b_vec, rb);
         }
     };
-    load_tiles(kt0 * HBK_);
-    TileH<A_KMAJOR, A16>::store(lds[0][0], tid, ra);
-    TileH<B_KMAJOR, B16>::store(lds[0][1], tid, rb);
+    // k-tiles whose flag is 0 are skipped (neither loaded nor multiplied).  The flags of this workgroup's k-range become two
+    // wave-uniform 64-bit masks up front (one coalesced byte load per lane), ranges of more than 128 tiles are not filtered.
+    unsigned long long km0 = ~0ull, km1 = ~0ull;
+    if (p.kflags != nullptr && nk <= 128) {
+        km0 = __ballot(lane < nk ? p.kflags[kt0 + lane] != 0 : false);
+        km1 = __ballot(64 + lane < nk ? p.kflags[kt0 + 64 + lane] != 0 : false);
+    }
+    auto tile_ok = [&](int kt) { return kt < 64 ? ((km0 >> kt) & 1ull) != 0 : kt < 128 ? ((km1 >> (kt - 64)) & 1ull) != 0 : true; };
+    bool cur_ok = tile_ok(0);
+    if (cur_ok) {
+        load_tiles(kt0 * HBK_);
+        TileH<A_KMAJOR, A16>::store(lds[0][0], tid, ra);
+        TileH<B_KMAJOR, B16>::store(lds[0][1], tid, rb);
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt0 + kt + 1) * HBK_);
-        const unsigned short* As = lds[cur][0];
-        const unsigned short* Bs = lds[cur][1];
+        const bool nxt_ok = kt + 1 < nk && tile_ok(kt + 1);
+        if (nxt_ok) load_tiles((kt0 + kt + 1) * HBK_);
+        if (cur_ok) {
+            const unsigned short* As = lds[cur][0];
+            const unsigned short* Bs = lds[cur][1];
 #pragma unroll
-        for (int kk = 0; kk < HBK_ / 16; ++kk) {
-            bf16x8 a[2], b[2];
+            for (int kk = 0; kk < HBK_ / 16; ++kk) {
+                bf16x8 a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                a[i] = *reinterpret_cast<const bf16x8*>(As + (wm + 32 * i + (lane & 31)) * HPITCH + kk * 16 + (lane >> 5) * 8);
+                for (int i = 0; i < 2; ++i)
+                    a[i] = *reinterpret_cast<const bf16x8*>(As + (wm + 32 * i + (lane & 31)) * HPITCH + kk * 16 + (lane >> 5) * 8);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn + 32 * j + (lane & 31)) * HPITCH + kk * 16 + (lane >> 5) * 8);
+                for (int j = 0; j < 2; ++j)
+                    b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn + 32 * j + (lane & 31)) * HPITCH + kk * 16 + (lane >> 5) * 8);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
-        if (kt + 1 < nk) {
+        if (nxt_ok) {
             TileH<A_KMAJOR, A16>::store(lds[cur ^ 1][0], tid, ra);
             TileH<B_KMAJOR, B16>::store(lds[cur ^ 1][1], tid, rb);
         }
         __syncthreads();
+        cur_ok = nxt_ok;
     }
     // (the k-loop ended with a barrier: every wave is done with the operand tiles, the LDS is free for staging)
     if constexpr (EPI == 1) gemm_pool_tile(acc, p, *pa, bid.z, n0, wm, wn, lane, wave, reinterpret_cast<float*>(lds_raw));
@@ -396,10 +413,12 @@ extern "C" int dldkd_gemm_bf16(const float* A, const float* B, const float* bias
 // The two GEMMs of the training input projection whose activation operand is stored as bf16 (dldkd_layernorm_dropout_bf16):
 //   dw == 0  forward:  C[M, N] = act(A16[M, K] . B[N, K]^T + bias)    A16 bf16 row-major (lda elements), B fp32 (N, K)
 //   dw != 0  dW:       C[M, N] = sum_k A[k, m] B16[k, n]              A fp32 (K, M) = dy, B16 bf16 (K, N) = the saved rows;
+//                      k_flags (one byte per 32 consecutive k, or NULL): 0 = the tile's rows are padding (zero rows) - skipped;
 //                                                                     split-K as dldkd_gemm_bf16 (workspace from
 //                                                                     dldkd_gemm_workspace_bytes(DLDKD_GEMM_BF16, M, N, K, 1, 1))
 extern "C" int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda,
-                                     int ldb, int ldc, int relu, void* workspace, size_t workspace_bytes, void* stream) {
+                                     int ldb, int ldc, int relu, void* workspace, size_t workspace_bytes, const unsigned char* k_flags,
+                                     void* stream) {
     if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < N) { set_error("gemm_bf16_mixed: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0 || N == 0) return DLDKD_OK;
     if (!A || !B || !C) { set_error("gemm_bf16_mixed: null pointer"); return DLDKD_EINVAL; }
@@ -411,7 +430,9 @@ extern "C" int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const
     }
     if (bias || relu) { set_error("gemm_bf16_mixed: the dW layout takes no bias / ReLU"); return DLDKD_EINVAL; }
     if ((ldb & 1) || (N & 1) || N < 2 || ((uintptr_t)B & 3)) { set_error("gemm_bf16_mixed: bf16 k-major B needs even ldb and N"); return DLDKD_EINVAL; }
+    static_assert(HBK_ == 32, "k_flags are per 32 contraction rows");
     GemmHArgs p{(const float*)A, (const float*)B, nullptr, C, M, N, K, lda, ldb, ldc, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+    p.kflags = k_flags;            // (K + 31) / 32 bytes or NULL
     int per = 0;
     const int split = (ldc == N && !((uintptr_t)C & 15)) ? gemm_bf16_split_plan(M, N, K, 1, 1, &per) : 1;
     if (split > 1 && workspace && !((uintptr_t)workspace & 15) && workspace_bytes >= (size_t)split * M * N * sizeof(float)) {

@@ -172,11 +172,11 @@ class _InProjTrain(Function):
     instead of the dX GEMM (201 MB written at the TVR batch) plus a LayerNorm backward pass over x and that gradient."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, weight, bias, p, relu):
+    def forward(ctx, x, gamma, beta, weight, bias, p, relu, row_mask=None):
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
         M, N = x2.shape[0], weight.shape[0]
-        keep = stats = None
+        keep = stats = gflags = None
         # throughput mode: the LayerNorm-dropout rows are WRITTEN as bf16 - what the bf16 GEMMs round them to anyway - so the
         # forward GEMM and dW read half the bytes (201 -> 100 MB per branch at the TVR batch), and the row statistics are kept
         # for the backward pass instead of being recomputed from x there
@@ -188,11 +188,18 @@ class _InProjTrain(Function):
             if p > 0.0:
                 keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
                 seed, off, state = _philox_slot(x.device, x.numel())
+            # rows of the padding (row_mask == 0) are never read and come out as zero rows; when the padded length is a multiple of
+            # 32 the kernel also flags the 32-row groups that hold valid rows, and dW below skips the others
+            rm = None
+            if row_mask is not None and IN_PROJ_SKIP_PADDING and x.dim() == 3 and row_mask.numel() == M:
+                rm = _f32(row_mask).reshape(-1)
+                if x.shape[1] % 32 == 0:
+                    gflags = torch.empty(M // 32, dtype=torch.uint8, device=x.device)
             native.check(_L().dldkd_layernorm_dropout_bf16(_p(x2), _p(gamma), _p(beta), _p(z), _p(keep), _p(stats), M, K, ops.LN_EPS,
-                                                           float(p), seed, off, state, _s()), "layernorm_dropout_bf16")
+                                                           float(p), seed, off, state, _p(rm), _p(gflags), _s()), "layernorm_dropout_bf16")
             y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-            native.check(_L().dldkd_gemm_bf16_mixed(0, _p(z), _p(weight), _p(bias), _p(y), M, N, K, K, K, N, int(relu), None, 0, _s()),
-                         "gemm_bf16_mixed")
+            native.check(_L().dldkd_gemm_bf16_mixed(0, _p(z), _p(weight), _p(bias), _p(y), M, N, K, K, K, N, int(relu), None, 0, None,
+                                                    _s()), "gemm_bf16_mixed")
         else:
             if p > 0.0:
                 z = torch.empty_like(x2)
@@ -203,13 +210,13 @@ class _InProjTrain(Function):
             else:
                 z = ops.layernorm(x2, gamma, beta)
             y = ops.linear(z, weight, bias, relu=relu)
-        ctx.save_for_backward(x2, weight, z, y if relu else None, keep, stats)
+        ctx.save_for_backward(x2, weight, z, y if relu else None, keep, stats, gflags)
         ctx.relu, ctx.has_bias, ctx.keep_scale, ctx.prec = relu, bias is not None, 1.0 / (1.0 - p), ops.gemm_precision()
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, z, y, keep, stats = ctx.saved_tensors
+        x2, w, z, y, keep, stats, gflags = ctx.saved_tensors
         N, K = w.shape
         M = x2.shape[0]
         dy2 = _f32(dy).reshape(-1, N)
@@ -221,8 +228,8 @@ class _InProjTrain(Function):
             if z.dtype == torch.bfloat16:
                 dw = torch.empty(N, K, dtype=torch.float32, device=x2.device)
                 ws, ws_bytes = ops._gemm_workspace(_L(), N, K, M, True, True, x2.device, precision="bf16")
-                native.check(_L().dldkd_gemm_bf16_mixed(1, _p(dy2), _p(z), None, _p(dw), N, K, M, N, K, K, 0, _p(ws), ws_bytes, _s()),
-                             "gemm_bf16_mixed")
+                native.check(_L().dldkd_gemm_bf16_mixed(1, _p(dy2), _p(z), None, _p(dw), N, K, M, N, K, K, 0, _p(ws), ws_bytes, _p(gflags),
+                                                        _s()), "gemm_bf16_mixed")
             else:
                 dw = ops.gemm(dy2, z, True, True, N, K, M)
         db = _colsum(dy2, N) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
@@ -237,9 +244,10 @@ class _InProjTrain(Function):
             native.check(_L().dldkd_linear_lngrad(ops._PREC_ID[ctx.prec], _p(dy2), _p(w), _p(x2), _p(keep), ctx.keep_scale, _p(stats[0]), _p(stats[1]),
                                                        _p(ws), ws.numel() * 4, _p(dgb[0]), _p(dgb[1]), M, N, K, _s()), "linear_lngrad")
             dg, dbeta = dgb[0], dgb[1]
-        return None, dg, dbeta, dw, db, None, None
+        return None, dg, dbeta, dw, db, None, None, None
 
 
+IN_PROJ_SKIP_PADDING = True           # ... and the rows of the padding (a row mask given) are neither normalised nor multiplied
 IN_PROJ_TRAIN_BF16_ROWS = True        # throughput mode: the saved LayerNorm-dropout rows of the input projection are bf16
 IN_PROJ_TRAIN_FUSED = True
 
@@ -251,8 +259,8 @@ def in_proj_train_ok(x, weight):
             and x.shape[-1] % 4 == 0 and x.shape[-1] <= 4096 and weight.requires_grad)
 
 
-def in_proj_train(x, gamma, beta, weight, bias, p_drop, training, relu=True):
-    return _InProjTrain.apply(_f32(x), gamma, beta, weight, bias, float(p_drop) if training else 0.0, bool(relu))
+def in_proj_train(x, gamma, beta, weight, bias, p_drop, training, relu=True, row_mask=None):
+    return _InProjTrain.apply(_f32(x), gamma, beta, weight, bias, float(p_drop) if training else 0.0, bool(relu), row_mask)
 
 
 # ------------------------------------------------------------------------------------------ dropout

@@ -96,7 +96,10 @@ class DLDKD(nn.Module):
     @staticmethod
     def encode_input(feat, mask, input_proj_layer, encoder_layer, pos_embed_layer):
         feat = feat.float().contiguous()
-        h = input_proj_layer(feat)
+        if mask is not None and input_proj_layer.training and feat.dim() == 3 and mask.dim() == 2 and mask.shape == feat.shape[:2]:
+            h = input_proj_layer(feat, row_mask=mask)        # training: the input projection skips the rows of the padding
+        else:
+            h = input_proj_layer(feat)
         h = pos_embed_layer(h)
         if mask is not None:
             mask = mask.float().unsqueeze(1)

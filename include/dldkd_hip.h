@@ -164,10 +164,14 @@ int dldkd_layernorm_dropout_f32(const float* x, const float* add, int add_mod, c
  * operand form of the bf16 GEMMs that consume it (dldkd_gemm_bf16_mixed) - and, when stats != NULL, the row statistics
  * (mean -> stats[row], rstd -> stats[M + row]) the backward pass would otherwise recompute.  Training input projection in
  * throughput mode: LinearLayer.forward's LayerNorm -> Dropout (method/model_components.py:305-310).  keep may be NULL when
- * p_drop == 0; out_bf16 8-byte aligned. */
+ * p_drop == 0; out_bf16 8-byte aligned.  row_mask (M floats, or NULL): rows with row_mask[row] == 0 - the clips past a video's
+ * length in a padded batch (collate_train's mask, method/data_provider.py:75-86) - are not read; their output row, keep bytes
+ * and statistics are zeros (no loss term depends on them and their gradients are exactly zero).  group_flags (M / 32 bytes, or
+ * NULL; needs row_mask, M % 32 == 0 and a padded length that is a multiple of 32): 1 when the 32-row group starts with a valid
+ * row - what dldkd_gemm_bf16_mixed(dw = 1, ..., k_flags) skips by. */
 int dldkd_layernorm_dropout_bf16(const float* x, const float* gamma, const float* beta, void* out_bf16, unsigned char* keep, float* stats,
                                  long M, int D, float eps, float p_drop, unsigned long long seed, unsigned long long offset,
-                                 const unsigned long long* state, void* stream);
+                                 const unsigned long long* state, const float* row_mask, unsigned char* group_flags, void* stream);
 
 /* BertSelfAttention.forward (model_components.py:398-436) for N sequences of L <= 128 tokens, 4 heads x 96:
  * qkv (N, L, 1152) = [query | key | value] projections, mask (N, L) 0/1 or NULL, out (N, L, 384) context
@@ -303,9 +307,10 @@ int dldkd_gemm_bf16(const float* A, const float* B, const float* bias, float* C,
  *   dw == 0  forward  C[M, N] = act(A16[M, K] . B[N, K]^T + bias)   A16 bf16 row-major (lda elements, lda % 4 == 0), B fp32 (N, K)
  *   dw != 0  dW       C[M, N] = sum_k A[k, m] B16[k, n]             A fp32 (K, M) = dy, B16 bf16 (K, N) = the saved rows (ldb, N even);
  *                     no bias / ReLU; split-K like dldkd_gemm_bf16 with a workspace of
- *                     dldkd_gemm_workspace_bytes(DLDKD_GEMM_BF16, M, N, K, 1, 1) bytes (NULL: no split). */
+ *                     dldkd_gemm_workspace_bytes(DLDKD_GEMM_BF16, M, N, K, 1, 1) bytes (NULL: no split); k_flags (one byte per 32
+ *                     consecutive k, or NULL): tiles flagged 0 hold zero rows (padding) and are skipped (dw != 0 only). */
 int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
-                          int ldc, int relu, void* workspace, size_t workspace_bytes, void* stream);
+                          int ldc, int relu, void* workspace, size_t workspace_bytes, const unsigned char* k_flags, void* stream);
 /* The forward layout of dldkd_gemm_bf16 - C[M, N] = act(A[M, K] . B[N, K]^T + bias), both operands fp32 and k-minor (a Linear's
  * forward pass; its input gradient once the weight is transposed) - with the operand tiles staged HBM -> LDS by LDS-DMA instead
  * of through registers (gemm_bf16_dma.hip): same products in the same order, bit-identical results, about half the time on

@@ -269,23 +269,23 @@ def test_bf16_rows_of_the_training_input_projection(bf16_mode, M, N, K, p_drop):
         z32 = ops.layernorm(x, gamma, beta)
     native.check(L.dldkd_layernorm_dropout_bf16(native.ptr(x), native.ptr(gamma), native.ptr(beta), native.ptr(z16),
                                                 native.ptr(k16) if p_drop > 0 else None, native.ptr(stats), M, K, 1e-5, p_drop, 1234, 40, None,
-                                                native.stream()), "ln16")
+                                                None, None, native.stream()), "ln16")
     native.check(L.dldkd_row_meanrstd_f32(native.ptr(x), native.ptr(ref_stats[0]), native.ptr(ref_stats[1]), M, K, 1e-5, native.stream()), "stats")
     assert torch.equal(z16, z32.to(torch.bfloat16)) and torch.equal(stats, ref_stats)
     if p_drop > 0:
         assert torch.equal(k16, k32) and 0.5 * (1 - p_drop) < k16.float().mean().item() < 1 - 0.5 * p_drop
     y = torch.empty(M, N, device=DEV)
-    native.check(L.dldkd_gemm_bf16_mixed(0, native.ptr(z16), native.ptr(W), native.ptr(b), native.ptr(y), M, N, K, K, K, N, 1, None, 0,
+    native.check(L.dldkd_gemm_bf16_mixed(0, native.ptr(z16), native.ptr(W), native.ptr(b), native.ptr(y), M, N, K, K, K, N, 1, None, 0, None,
                                          native.stream()), "fwd")
     assert torch.equal(y, ops.linear(z32, W, b, relu=True))
     dw = torch.empty(N, K, device=DEV)
     ws, nb = ops._gemm_workspace(L, N, K, M, True, True, x.device)
-    native.check(L.dldkd_gemm_bf16_mixed(1, native.ptr(dy), native.ptr(z16), None, native.ptr(dw), N, K, M, N, K, K, 0, native.ptr(ws), nb,
+    native.check(L.dldkd_gemm_bf16_mixed(1, native.ptr(dy), native.ptr(z16), None, native.ptr(dw), N, K, M, N, K, K, 0, native.ptr(ws), nb, None,
                                          native.stream()), "dw")
     ref = ops.gemm(dy, z32, True, True, N, K, M)
     assert torch.allclose(dw, ref, rtol=1e-5, atol=1e-6 * ref.abs().max().item())        # (split-K planes: fp32 sums in another order)
     with pytest.raises(native.NativeError):                                                # odd ldb / N of the bf16 k-major operand
-        native.check(L.dldkd_gemm_bf16_mixed(1, native.ptr(dy), native.ptr(z16), None, native.ptr(dw), N, K - 1, M, N, K - 1, K - 1, 0, None, 0,
+        native.check(L.dldkd_gemm_bf16_mixed(1, native.ptr(dy), native.ptr(z16), None, native.ptr(dw), N, K - 1, M, N, K - 1, K - 1, 0, None, 0, None,
                                              native.stream()), "dw")
 
 
@@ -322,3 +322,36 @@ def test_gemm_bf16_nt_dma_is_bit_identical_to_gemm_bf16(bf16_mode, M, N, K, relu
         ops.GEMM_NT_DMA = True
     assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
     assert not L.dldkd_gemm_bf16_nt_ok(M, N, K + 8, K + 8, K + 8)
+
+
+@pytest.mark.parametrize("nv,L,K,p_drop", [(128, 128, 3072, 0.2), (37, 64, 512, 0.0), (16, 96, 256, 0.3)])
+def test_training_input_projection_skips_the_padding(bf16_mode, nv, L, K, p_drop):
+    """functional.in_proj_train with the batch's mask: rows of the padding are never read (NaN features there change nothing) and
+    come out as relu(bias); dW skips the 32-row groups without a valid row.  Against the same call without the mask on the
+    zero-padded batch: valid rows of the output bit-identical, gradients of W / b / gamma / beta equal up to summation order
+    when the upstream gradient is zero on the padding (as every loss makes it)."""
+    from dldkd_amd import functional as F_
+    g = torch.Generator().manual_seed(nv + L + K)
+    lens = torch.randint(1, L + 1, (nv,), generator=g)
+    lens[0] = L
+    mask = (torch.arange(L)[None] < lens[:, None]).float()
+    x = torch.randn(nv, L, K, generator=g) * mask[..., None]
+    gamma, beta = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    W, b = torch.randn(384, K, generator=g) * 0.02, 0.1 * torch.randn(384, generator=g)
+    w_out = (torch.randn(nv, L, 384, generator=g) * mask[..., None]).to(DEV)          # d loss / d y: zero on the padding
+    res = []
+    for use_mask in (True, False):
+        gs, bs, Ws, bbs = (t.to(DEV).requires_grad_() for t in (gamma, beta, W, b))
+        xd = x.to(DEV)
+        if use_mask:
+            xd = torch.where(mask.to(DEV)[..., None] > 0, xd, torch.full_like(xd, float("nan")))      # the padding must not be read
+        torch.manual_seed(77)
+        y = F_.in_proj_train(xd, gs, bs, Ws, bbs, p_drop, True, row_mask=mask.to(DEV) if use_mask else None)
+        (y * w_out).sum().backward()
+        res.append((y.detach().cpu(), gs.grad.cpu(), bs.grad.cpu(), Ws.grad.cpu(), bbs.grad.cpu()))
+    (ym, dgm, dbm, dWm, dbbm), (y0, dg0, db0, dW0, dbb0) = res
+    valid = mask.bool()
+    assert torch.equal(ym[valid], y0[valid]) and torch.isfinite(ym).all()
+    assert torch.equal(ym[~valid], torch.relu(b).expand(int((~valid).sum()), -1))
+    for a, r in ((dWm, dW0), (dbbm, dbb0), (dgm, dg0), (dbm, db0)):
+        assert torch.isfinite(a).all() and torch.allclose(a, r, rtol=1e-4, atol=1e-5 * r.abs().max().item())
