@@ -30,6 +30,8 @@ struct GemmHArgs {
     long sAo, sAi, sBo, sBi, sCo, sCi;
     float alpha;
     int split_k, k_tiles_per_split;
+    const unsigned char* mflags;   // per 32 rows of A / C (k-minor A only, M % 128 == 0): 0 = rows of the padding - not loaded, not
+                                   // multiplied; their accumulators stay zero (C rows = act(bias), LayerNorm-gradient terms 0).  null: all
     const unsigned char* kflags;   // per k-tile (32 consecutive k): 0 = every operand row of the tile is padding (exact zeros in one
                                    // operand): the tile is skipped.  null: all tiles.  Used by the dW layout only
 };
@@ -45,13 +47,15 @@ struct GemmHArgs {
 //     index; two 16-byte LDS stores); needs an even ld and row count.
 template <bool KMAJOR, bool SRC16 = false>
 struct TileH {
+    // pm (k-minor operands): bit j = pass j (rows 32 j .. 32 j + 31 of the tile) is wanted; the others are neither loaded nor stored
     static __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int K,
-                                                int tid, bool vec, float (&r)[NREG_]) {
+                                                int tid, bool vec, float (&r)[NREG_], unsigned pm = 0xFu) {
         if constexpr (SRC16) {
             const unsigned short* P16 = reinterpret_cast<const unsigned short*>(P);
             if constexpr (!KMAJOR) {
 #pragma unroll
                 for (int j = 0; j < NPASS_; ++j) {
+                    if (!((pm >> j) & 1u)) continue;
                     const int row = row0 + tid / KV_ + RPP_ * j;
                     const int k = k0 + (tid % KV_) * 4;
 #pragma unroll
@@ -70,6 +74,7 @@ struct TileH {
         } else if constexpr (!KMAJOR) {
 #pragma unroll
             for (int j = 0; j < NPASS_; ++j) {
+                if (!((pm >> j) & 1u)) continue;
                 const int row = row0 + tid / KV_ + RPP_ * j;
                 const int k = k0 + (tid % KV_) * 4;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -96,12 +101,13 @@ struct TileH {
     // Interior tile (all k in range, 16-byte aligned rows): branch-free.  Rows past the end are CLAMPED to the
     // last row instead of zeroed - they only feed accumulator rows/columns that are never stored.
     static __device__ __forceinline__ void load_fast(const float* __restrict__ P, int ld, int row0, int nrows, int k0,
-                                                     int tid, float (&r)[NREG_]) {
+                                                     int tid, float (&r)[NREG_], unsigned pm = 0xFu) {
         if constexpr (SRC16) {
             const unsigned short* P16 = reinterpret_cast<const unsigned short*>(P);
             if constexpr (!KMAJOR) {
 #pragma unroll
                 for (int j = 0; j < NPASS_; ++j) {
+                    if (!((pm >> j) & 1u)) continue;
                     const int row = min(row0 + tid / KV_ + RPP_ * j, nrows - 1);
                     const uint2 v = *reinterpret_cast<const uint2*>(P16 + (size_t)row * ld + k0 + (tid % KV_) * 4);
                     r[4 * j + 0] = __builtin_bit_cast(float, v.x << 16); r[4 * j + 1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
@@ -120,6 +126,7 @@ struct TileH {
         } else if constexpr (!KMAJOR) {
 #pragma unroll
             for (int j = 0; j < NPASS_; ++j) {
+                if (!((pm >> j) & 1u)) continue;
                 const int row = min(row0 + tid / KV_ + RPP_ * j, nrows - 1);
                 const f32x4 v = *reinterpret_cast<const f32x4*>(P + (size_t)row * ld + k0 + (tid % KV_) * 4);
 #pragma unroll
@@ -132,7 +139,7 @@ struct TileH {
             for (int i = 0; i < KPT_; ++i) r[i] = src[(size_t)i * ld];
         }
     }
-    static __device__ __forceinline__ void store(unsigned short* __restrict__ S, int tid, const float (&r)[NREG_]) {
+    static __device__ __forceinline__ void store(unsigned short* __restrict__ S, int tid, const float (&r)[NREG_], unsigned pm = 0xFu) {
         if constexpr (SRC16 && KMAJOR) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {                    // rows 2 p and 2 p + 1, k (tid >> 6) * 8 .. + 7
@@ -147,6 +154,7 @@ struct TileH {
         } else if constexpr (!KMAJOR) {
 #pragma unroll
             for (int j = 0; j < NPASS_; ++j) {
+                if (!((pm >> j) & 1u)) continue;
                 unsigned short* dst = S + (tid / KV_ + RPP_ * j) * HPITCH + (tid % KV_) * 4;
                 uint2 pk;
                 pk.x = (unsigned)f32_to_bf16_bits(r[4 * j]) | ((unsigned)f32_to_bf16_bits(r[4 * j + 1]) << 16);
@@ -205,17 +213,29 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float ra[NREG_], rb[NREG_];
+#pragma unroll
+    for (int i = 0; i < NREG_; ++i) ra[i] = 0.f;
+    // which 32-row groups of this tile's A rows hold anything (wave-uniform 4-bit mask; all without flags)
+    unsigned pm = 0xFu;
+    if constexpr (!A_KMAJOR) {
+        if (p.mflags != nullptr) {
+            const unsigned w = *reinterpret_cast<const unsigned*>(p.mflags + (m0 >> 5));         // 4 flag bytes (M % 128 == 0: entry point)
+            pm = ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
+            pm = __builtin_amdgcn_readfirstlane(pm);
+        }
+    }
     // k-minor operands need 16-byte aligned rows for the fast path; k-major ones use dword loads (always fine)
     const bool fa = A_KMAJOR || p.a_vec, fb = B_KMAJOR || p.b_vec;
     auto load_tiles = [&](int k0) {
         if (k0 + HBK_ <= p.K && fa && fb) {
-            TileH<A_KMAJOR, A16>::load_fast(p.A, p.lda, m0, p.M, k0, tid, ra);
+            TileH<A_KMAJOR, A16>::load_fast(p.A, p.lda, m0, p.M, k0, tid, ra, pm);
             TileH<B_KMAJOR, B16>::load_fast(p.B, p.ldb, n0, p.N, k0, tid, rb);
         } else {
-            TileH<A_KMAJOR, A16>::load(p.A, p.lda, m0, p.M, k0, p.K, tid, p.a_vec, ra);
+            TileH<A_KMAJOR, A16>::load(p.A, p.lda, m0, p.M, k0, p.K, tid, p.a_vec, ra, pm);
             TileH<B_KMAJOR, B16>::load(p.B, p.ldb, n0, p.N, k0, p.K, tid, p.b_vec, rb);
         }
     };
+    const bool rt_ok[2] = {((pm >> (wm / 32)) & 1u) != 0, ((pm >> (wm / 32 + 1)) & 1u) != 0};      // this wave's two 32-row tiles
     // k-tiles whose flag is 0 are skipped (neither loaded nor multiplied).  The flags of this workgroup's k-range become two
     // wave-uniform 64-bit masks up front (one coalesced byte load per lane), ranges of more than 128 tiles are not filtered.
     unsigned long long km0 = ~0ull, km1 = ~0ull;
@@ -227,7 +247,7 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
     bool cur_ok = tile_ok(0);
     if (cur_ok) {
         load_tiles(kt0 * HBK_);
-        TileH<A_KMAJOR, A16>::store(lds[0][0], tid, ra);
+        TileH<A_KMAJOR, A16>::store(lds[0][0], tid, ra, pm);
         TileH<B_KMAJOR, B16>::store(lds[0][1], tid, rb);
     }
     __syncthreads();
@@ -242,19 +262,19 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
             for (int kk = 0; kk < HBK_ / 16; ++kk) {
                 bf16x8 a[2], b[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    a[i] = *reinterpret_cast<const bf16x8*>(As + (wm + 32 * i + (lane & 31)) * HPITCH + kk * 16 + (lane >> 5) * 8);
-#pragma unroll
                 for (int j = 0; j < 2; ++j)
                     b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn + 32 * j + (lane & 31)) * HPITCH + kk * 16 + (lane >> 5) * 8);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) {
+                    if (!rt_ok[i]) continue;                 // a 32-row tile of padding: its LDS rows were never written
+                    a[i] = *reinterpret_cast<const bf16x8*>(As + (wm + 32 * i + (lane & 31)) * HPITCH + kk * 16 + (lane >> 5) * 8);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
             }
         }
         if (nxt_ok) {
-            TileH<A_KMAJOR, A16>::store(lds[cur ^ 1][0], tid, ra);
+            TileH<A_KMAJOR, A16>::store(lds[cur ^ 1][0], tid, ra, pm);
             TileH<B_KMAJOR, B16>::store(lds[cur ^ 1][1], tid, rb);
         }
         __syncthreads();
@@ -353,10 +373,12 @@ int dldkd::gemm_bf16_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor,
 
 extern "C" int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream);
 
-int dldkd::launch_linear_lngrad_bf16(const float* dy, const float* W, long M, int N, int K, const LnGradArgs& la, void* stream) {
+int dldkd::launch_linear_lngrad_bf16(const float* dy, const float* W, long M, int N, int K, const LnGradArgs& la, void* stream,
+                                     const unsigned char* row_flags) {
     // C[M, K] = dy[M, N] . W[N, K]: contraction over the Linear's outputs, B in the k-major (dX) layout
     const int a_vec = !(N & 3) && !((uintptr_t)dy & 15);
     GemmHArgs p{dy, W, nullptr, nullptr, (int)M, K, N, N, K, K, 0, a_vec, 0, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+    p.mflags = (M % HBM_ == 0 && !((uintptr_t)row_flags & 3)) ? row_flags : nullptr;
     constexpr size_t lds = sizeof(unsigned short) * 2 * 2 * HBM_ * HPITCH;
     static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_bf16_lngrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
     (void)attr_ok;
@@ -369,7 +391,7 @@ extern "C" int dldkd_colsum_f32(const float* x, float* out, long M, long N, void
 
 extern "C" int dldkd_linear_lngrad(int precision, const float* dy, const float* W, const float* x, const unsigned char* keep,
                                    float keep_scale, const float* mean, const float* rstd, float* workspace, size_t workspace_bytes,
-                                   float* dgamma, float* dbeta, long M, int N, int K, void* stream) {
+                                   float* dgamma, float* dbeta, long M, int N, int K, const unsigned char* row_flags, void* stream) {
     if (M < 0 || N < 1 || K < 1 || M > 0x7fffffffL) { set_error("linear_lngrad: bad sizes"); return DLDKD_EINVAL; }
     if (precision != DLDKD_GEMM_BF16 && precision != DLDKD_GEMM_F32X3) {
         set_error("linear_lngrad: precision %d has no such kernel (DLDKD_GEMM_F32X3 or DLDKD_GEMM_BF16)", precision);
@@ -380,7 +402,7 @@ extern "C" int dldkd_linear_lngrad(int precision, const float* dy, const float* 
     const long tiles = (M + 127) / 128;
     if (workspace_bytes < (size_t)2 * tiles * K * sizeof(float)) { set_error("linear_lngrad: workspace too small"); return DLDKD_EINVAL; }
     LnGradArgs la{x, keep, mean, rstd, workspace, workspace + (size_t)tiles * K, K, keep_scale};
-    int rc = precision == DLDKD_GEMM_BF16 ? launch_linear_lngrad_bf16(dy, W, M, N, K, la, stream)
+    int rc = precision == DLDKD_GEMM_BF16 ? launch_linear_lngrad_bf16(dy, W, M, N, K, la, stream, row_flags)
                                           : launch_linear_lngrad_x3(dy, W, M, N, K, la, stream);
     if (rc != DLDKD_OK) return rc;
     rc = dldkd_colsum_f32(la.part_g, dgamma, tiles, K, stream);
@@ -426,6 +448,7 @@ extern "C" int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const
         if ((lda & 3) || ((uintptr_t)A & 7)) { set_error("gemm_bf16_mixed: bf16 A needs lda %% 4 == 0 and 8-byte alignment"); return DLDKD_EINVAL; }
         const int b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
         GemmHArgs p{(const float*)A, (const float*)B, bias, C, M, N, K, lda, ldb, ldc, relu, 1, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+        p.mflags = (M % HBM_ == 0 && !((uintptr_t)k_flags & 3)) ? k_flags : nullptr;     // forward: the flags are per 32 ROWS of A / C
         return launch_gemm_h_mixed(p, 1, 0, stream);
     }
     if (bias || relu) { set_error("gemm_bf16_mixed: the dW layout takes no bias / ReLU"); return DLDKD_EINVAL; }

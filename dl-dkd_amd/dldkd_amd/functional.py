@@ -198,8 +198,8 @@ class _InProjTrain(Function):
             native.check(_L().dldkd_layernorm_dropout_bf16(_p(x2), _p(gamma), _p(beta), _p(z), _p(keep), _p(stats), M, K, ops.LN_EPS,
                                                            float(p), seed, off, state, _p(rm), _p(gflags), _s()), "layernorm_dropout_bf16")
             y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-            native.check(_L().dldkd_gemm_bf16_mixed(0, _p(z), _p(weight), _p(bias), _p(y), M, N, K, K, K, N, int(relu), None, 0, None,
-                                                    _s()), "gemm_bf16_mixed")
+            native.check(_L().dldkd_gemm_bf16_mixed(0, _p(z), _p(weight), _p(bias), _p(y), M, N, K, K, K, N, int(relu), None, 0,
+                                                    _p(gflags), _s()), "gemm_bf16_mixed")
         else:
             if p > 0.0:
                 z = torch.empty_like(x2)
@@ -242,7 +242,7 @@ class _InProjTrain(Function):
             ws = torch.empty(2 * tiles * K, dtype=torch.float32, device=x2.device)
             dgb = _zeros((2, K), x2.device)
             native.check(_L().dldkd_linear_lngrad(ops._PREC_ID[ctx.prec], _p(dy2), _p(w), _p(x2), _p(keep), ctx.keep_scale, _p(stats[0]), _p(stats[1]),
-                                                       _p(ws), ws.numel() * 4, _p(dgb[0]), _p(dgb[1]), M, N, K, _s()), "linear_lngrad")
+                                                       _p(ws), ws.numel() * 4, _p(dgb[0]), _p(dgb[1]), M, N, K, _p(gflags), _s()), "linear_lngrad")
             dg, dbeta = dgb[0], dgb[1]
         return None, dg, dbeta, dw, db, None, None, None
 

@@ -116,7 +116,7 @@ SIGNATURES = {
                                                     _c_float, _c_int, _c_void_p, _c_long, _c_void_p]),
     "dldkd_row_meanrstd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_float, _c_void_p]),
     "dldkd_linear_lngrad": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p,
-                                           ctypes.c_size_t, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p]),
+                                           ctypes.c_size_t, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_fold_ln_linear_planes": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p,
                                              _c_void_p]),
     "dldkd_in_proj_f32x3_rows128": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long,

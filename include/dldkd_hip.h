@@ -254,10 +254,11 @@ int dldkd_row_meanrstd_f32(const float* x, float* mean, float* rstd, long M, int
  * backward pass runs over x:
  *     dz = dz' (.) keep * keep_scale,  dgamma[k] += sum_m dz[m,k] (x[m,k] - mean[m]) rstd[m],  dbeta[k] += sum_m dz[m,k].
  * dy (M, N) gradient behind the ReLU, W (N, K), x (M, K), keep (M, K) bytes of dldkd_layernorm_dropout_f32 or NULL, mean / rstd
- * from dldkd_row_meanrstd_f32; workspace >= 2 * ceil(M / 128) * K floats; dgamma / dbeta (K) zero-initialised by the caller. */
+ * from dldkd_row_meanrstd_f32; workspace >= 2 * ceil(M / 128) * K floats; dgamma / dbeta (K) zero-initialised by the caller.  *   row_flags (M / 32 bytes from dldkd_layernorm_dropout_bf16, or NULL; bf16 precision, M % 128 == 0): 32-row groups flagged 0 are
+ *   rows of the padding (dy and the statistics are zero there) - neither loaded nor multiplied. */
 int dldkd_linear_lngrad(int precision, const float* dy, const float* W, const float* x, const unsigned char* keep, float keep_scale,
                         const float* mean, const float* rstd, float* workspace, size_t workspace_bytes, float* dgamma,
-                        float* dbeta, long M, int N, int K, void* stream);
+                        float* dbeta, long M, int N, int K, const unsigned char* row_flags, void* stream);
 int dldkd_fold_ln_linear_planes(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K, int n_offset,
                                 void* Wplanes, float* bb, void* stream);
 int dldkd_in_proj_f32x3_rows128(const float* x, const float* mean, const float* rstd, const void* Wplanes, const float* bb, float* y0,
