@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         float dscale, unsigned long long seed, unsigned long long off,
                                                         const unsigned long long* __restrict__ state,
                                                         unsigned short* __restrict__ out16, float* __restrict__ stats,
-                                                        const float* __restrict__ row_mask, unsigned char* __restrict__ gflags) {
+                                                        const float* __restrict__ row_mask, unsigned char* __restrict__ gflags,
+                                                        const unsigned char* __restrict__ gin) {
     // out16 != null: the row is written as bf16 (round to nearest even) instead of fp32 - the operand form of the bf16 GEMMs that
     // consume it (dldkd_gemm_bf16_mixed); stats != null: mean -> stats[row], rstd -> stats[M + row] (kept for the backward pass)
     const int lane = threadIdx.x & 63;
@@ -32,12 +33,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (row >= M) return;
     if (keep != nullptr && state != nullptr) { seed = state[0]; off += state[1]; }
     const int nv = D >> 2;
-    if (row_mask != nullptr) {
+    if (row_mask != nullptr || gin != nullptr) {
         // rows of the padding (row_mask[row] == 0: clips past a video's length in a padded batch) are not read: their output row
         // is zeros (keep bytes 0, statistics 0) - no loss term depends on them and their gradients are exactly zero, so the
         // GEMMs behind this kernel may skip them (gflags[g] = 1 when the 32-row group g starts with a valid row: masks are
         // prefixes, groups never straddle two sequences when the padded length is a multiple of 32)
-        const bool valid = row_mask[row] > 0.f;
+        // (gin: the group flags an earlier kernel of the tower wrote - validity per 32-row group instead of per row)
+        const bool valid = row_mask != nullptr ? row_mask[row] > 0.f : gin[row >> 5] != 0;
         if (gflags != nullptr && lane == 0 && (row & 31) == 0) gflags[row >> 5] = valid ? 1 : 0;
         if (!valid) {
             if (stats != nullptr && lane == 0) { stats[row] = 0.f; stats[M + row] = 0.f; }
@@ -298,7 +300,7 @@ static int launch_layernorm(const float* x, const float* add, int add_mod, const
                             long M, int D, float eps, unsigned char* keep, float p_drop, unsigned long long seed,
                             unsigned long long offset, const unsigned long long* state, void* stream,
                             unsigned short* out16 = nullptr, float* stats = nullptr, const float* row_mask = nullptr,
-                            unsigned char* gflags = nullptr) {
+                            unsigned char* gflags = nullptr, const unsigned char* gin = nullptr) {
     if (M < 0 || D < 4 || (D & 3) || D > 4096 || add_mod < 0 || !(p_drop >= 0.f && p_drop < 1.f)) {
         set_error("layernorm: bad sizes M=%ld D=%d (D must be a multiple of 4, <= 4096) or p=%f", M, D, (double)p_drop);
         return DLDKD_EINVAL;
@@ -311,10 +313,10 @@ static int launch_layernorm(const float* x, const float* add, int add_mod, const
     const double t = (double)p_drop * 4294967296.0;
     const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     const float ds = 1.0f / (1.0f - p_drop);
-    if (nv <= 2) DLDKD_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags);
-    else if (nv <= 4) DLDKD_LAUNCH(layernorm_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags);
-    else if (nv <= 8) DLDKD_LAUNCH(layernorm_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags);
-    else DLDKD_LAUNCH(layernorm_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags);
+    if (nv <= 2) DLDKD_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
+    else if (nv <= 4) DLDKD_LAUNCH(layernorm_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
+    else if (nv <= 8) DLDKD_LAUNCH(layernorm_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
+    else DLDKD_LAUNCH(layernorm_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
     return check_launch("layernorm");
 }
 
@@ -328,6 +330,15 @@ int dldkd_layernorm_dropout_f32(const float* x, const float* add, int add_mod, c
                                 unsigned long long offset, const unsigned long long* state, void* stream) {
     if (!keep || ((uintptr_t)keep & 3)) { set_error("layernorm_dropout: keep mask missing or unaligned"); return DLDKD_EINVAL; }
     return launch_layernorm(x, add, add_mod, gamma, beta, out, M, D, eps, keep, p_drop, seed, offset, state, stream);
+}
+
+int dldkd_layernorm_groups_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out,
+                               unsigned char* keep, long M, int D, float eps, float p_drop, unsigned long long seed,
+                               unsigned long long offset, const unsigned long long* state, const unsigned char* group_flags, void* stream) {
+    if (p_drop > 0.f && (!keep || ((uintptr_t)keep & 3))) { set_error("layernorm_groups: keep mask missing or unaligned"); return DLDKD_EINVAL; }
+    if (group_flags && (M & 31)) { set_error("layernorm_groups: M %% 32 != 0"); return DLDKD_EINVAL; }
+    return launch_layernorm(x, add, add_mod, gamma, beta, out, M, D, eps, p_drop > 0.f ? keep : nullptr, p_drop, seed, offset, state, stream,
+                            nullptr, nullptr, nullptr, nullptr, group_flags);
 }
 
 int dldkd_layernorm_dropout_bf16(const float* x, const float* gamma, const float* beta, void* out_bf16, unsigned char* keep, float* stats,

@@ -436,6 +436,7 @@ extern "C" int dldkd_gemm_bf16(const float* A, const float* B, const float* bias
 //   dw == 0  forward:  C[M, N] = act(A16[M, K] . B[N, K]^T + bias)    A16 bf16 row-major (lda elements), B fp32 (N, K)
 //   dw != 0  dW:       C[M, N] = sum_k A[k, m] B16[k, n]              A fp32 (K, M) = dy, B16 bf16 (K, N) = the saved rows;
 //                      k_flags (one byte per 32 consecutive k, or NULL): 0 = the tile's rows are padding (zero rows) - skipped;
+//   dw == 2  the same with B fp32 (K, N): dldkd_gemm_bf16's dW layout plus the k-tile filter
 //                                                                     split-K as dldkd_gemm_bf16 (workspace from
 //                                                                     dldkd_gemm_workspace_bytes(DLDKD_GEMM_BF16, M, N, K, 1, 1))
 extern "C" int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda,
@@ -452,6 +453,21 @@ extern "C" int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const
         return launch_gemm_h_mixed(p, 1, 0, stream);
     }
     if (bias || relu) { set_error("gemm_bf16_mixed: the dW layout takes no bias / ReLU"); return DLDKD_EINVAL; }
+    if (dw == 2) {          // both operands fp32 and k-major (the plain dW of dldkd_gemm_bf16) with the k-tile filter
+        GemmHArgs p{(const float*)A, (const float*)B, nullptr, C, M, N, K, lda, ldb, ldc, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+        p.kflags = k_flags;
+        int per = 0;
+        const int split = (ldc == N && !((uintptr_t)C & 15)) ? gemm_bf16_split_plan(M, N, K, 1, 1, &per) : 1;
+        if (split > 1 && workspace && !((uintptr_t)workspace & 15) && workspace_bytes >= (size_t)split * M * N * sizeof(float)) {
+            p.k_tiles_per_split = per;
+            p.split_k = split;
+            p.C = (float*)workspace;
+            const int rc = launch_gemm_h(p, p.split_k, 1, 1, stream);
+            if (rc != DLDKD_OK) return rc;
+            return launch_splitk_reduce((const float*)workspace, C, p.split_k, (long)M * N, (hipStream_t)stream);
+        }
+        return launch_gemm_h(p, 1, 1, 1, stream);
+    }
     if ((ldb & 1) || (N & 1) || N < 2 || ((uintptr_t)B & 3)) { set_error("gemm_bf16_mixed: bf16 k-major B needs even ldb and N"); return DLDKD_EINVAL; }
     static_assert(HBK_ == 32, "k_flags are per 32 contraction rows");
     GemmHArgs p{(const float*)A, (const float*)B, nullptr, C, M, N, K, lda, ldb, ldc, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};

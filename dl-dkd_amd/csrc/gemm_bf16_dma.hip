@@ -31,6 +31,8 @@ struct Args {
     float* C;
     int M, N, K, lda, ldb, ldc, relu;
     float alpha;
+    const unsigned char* mflags;      // per 32 rows of A / C (M % 128 == 0), or null: 0 = rows of the padding (zero operand rows or
+                                      // don't-care outputs) - not loaded, not multiplied; their C rows come out as act(bias)
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -71,12 +73,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const Args p) {
     }
     const char* abase = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
     const char* bbase = reinterpret_cast<const char*>(p.B + (size_t)n0 * p.ldb);
+    // row groups: wave w's four A pieces ARE group w of the tile (rows 32 w .. 32 w + 31)
+    unsigned pm = 0xFu;
+    if (p.mflags != nullptr) {
+        const unsigned w4 = *reinterpret_cast<const unsigned*>(p.mflags + (m0 >> 5));
+        pm = ((w4 & 0xffu) ? 1u : 0u) | ((w4 & 0xff00u) ? 2u : 0u) | ((w4 & 0xff0000u) ? 4u : 0u) | ((w4 & 0xff000000u) ? 8u : 0u);
+        pm = __builtin_amdgcn_readfirstlane(pm);
+    }
+    const bool load_a = ((pm >> wave) & 1u) != 0;
+    const bool rt_ok[2] = {((pm >> (wm / 32)) & 1u) != 0, ((pm >> (wm / 32 + 1)) & 1u) != 0};
     auto issue = [&](int kt, int stage) {
         const char* as = abase + (size_t)kt * (BK * 4);
         const char* bs = bbase + (size_t)kt * (BK * 4);
         const uint32_t dst = smem_lds + stage * STAGE_B + (4 * wave) * 1024;
+        if (load_a) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) glds16_s(voa[q], as, dst + q * 1024);
+            for (int q = 0; q < 4; ++q) glds16_s(voa[q], as, dst + q * 1024);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) glds16_s(vob[q], bs, dst + TILE_B + q * 1024);
     };
@@ -111,21 +124,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const Args p) {
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(As + i * 4096 + fo[kk][0]);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(As + i * 4096 + fo[kk][1]);
-                a[i] = cvt8(lo, hi);
-            }
-#pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(Bs + j * 4096 + fo[kk][0]);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(Bs + j * 4096 + fo[kk][1]);
                 b[j] = cvt8(lo, hi);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                if (!rt_ok[i]) continue;                          // rows of the padding: never loaded
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(As + i * 4096 + fo[kk][0]);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(As + i * 4096 + fo[kk][1]);
+                a[i] = cvt8(lo, hi);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile has landed (this wave's pieces; the barrier covers the others)
         __syncthreads();                                       // and everyone is done reading this one
@@ -144,7 +156,7 @@ extern "C" int dldkd_gemm_bf16_nt_ok(int M, int N, int K, int lda, int ldb) {
 }
 
 extern "C" int dldkd_gemm_bf16_nt(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
-                                  int ldc, int relu, void* stream) {
+                                  int ldc, int relu, const unsigned char* row_flags, void* stream) {
     if (M < 0 || N < 0 || K < 0 || lda < K || ldb < K || ldc < N) { set_error("gemm_bf16_nt: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0 || N == 0) return DLDKD_OK;
     if (!A || !B || !C) { set_error("gemm_bf16_nt: null pointer"); return DLDKD_EINVAL; }
@@ -152,7 +164,8 @@ extern "C" int dldkd_gemm_bf16_nt(const float* A, const float* B, const float* b
         set_error("gemm_bf16_nt: needs K %% 32 == 0, lda / ldb %% 4 == 0 and 16-byte aligned operands (M=%d N=%d K=%d)", M, N, K);
         return DLDKD_EINVAL;
     }
-    gdma::Args p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu != 0, 1.0f};
+    gdma::Args p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu != 0, 1.0f,
+                 (M % gdma::BM == 0 && !((uintptr_t)row_flags & 3)) ? row_flags : nullptr};
     constexpr int lds = gdma::NST * gdma::STAGE_B;
     static const bool ok = hipFuncSetAttribute((const void*)gdma::gemm_bf16_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
     (void)ok;

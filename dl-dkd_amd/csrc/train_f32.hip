@@ -26,7 +26,8 @@ __global__ __launch_bounds__(64 * WAVES) void layernorm_bwd_kernel(const float* 
                                                             const float* __restrict__ dy, float* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, long M,
                                                             int D, float eps, int rows_per_wave,
-                                                            const unsigned char* __restrict__ keep, float keep_scale) {
+                                                            const unsigned char* __restrict__ keep, float keep_scale,
+                                                            const unsigned char* __restrict__ gin) {
     const int lane = threadIdx.x & 63;
     const int nv = D >> 2;
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
@@ -35,6 +36,15 @@ __global__ __launch_bounds__(64 * WAVES) void layernorm_bwd_kernel(const float* 
     for (int i = 0; i < MAXV; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; }
     const long row0 = ((long)blockIdx.x * WAVES + (threadIdx.x >> 6)) * rows_per_wave;   // may be >= M: the wave then only joins the reduction
     for (long row = row0; row < row0 + rows_per_wave && row < M; ++row) {
+        if (gin != nullptr && gin[row >> 5] == 0) {
+            // a row of the padding (32-row group flagged 0 by the tower's first kernel): dy is zero there - no contribution to the
+            // parameter gradients, a zero input gradient - and neither x nor dy is read
+            if (dx) {
+                f32x4* dxr = reinterpret_cast<f32x4*>(dx + row * D);
+                for (int c = lane; c < nv; c += 64) dxr[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            continue;
+        }
         const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
         const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (add_mod > 0 ? row % add_mod : row) * D) : nullptr;
         const f32x4* dyr = reinterpret_cast<const f32x4*>(dy + row * D);
@@ -336,9 +346,26 @@ using namespace dldkd;
 
 extern "C" {
 
+static int launch_layernorm_bwd(const float* x, const float* add, int add_mod, const float* gamma, const float* dy, float* dx,
+                                float* dgamma, float* dbeta, long M, int D, float eps, const unsigned char* keep, float keep_scale,
+                                const unsigned char* gin, void* stream);
+
 int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* dy, float* dx,
                             float* dgamma, float* dbeta, long M, int D, float eps, const unsigned char* keep, float keep_scale,
                             void* stream) {
+    return launch_layernorm_bwd(x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, keep, keep_scale, nullptr, stream);
+}
+
+int dldkd_layernorm_bwd_groups_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* dy, float* dx,
+                                   float* dgamma, float* dbeta, long M, int D, float eps, const unsigned char* keep, float keep_scale,
+                                   const unsigned char* group_flags, void* stream) {
+    if (group_flags && (M & 31)) { set_error("layernorm_bwd_groups: M %% 32 != 0"); return DLDKD_EINVAL; }
+    return launch_layernorm_bwd(x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, keep, keep_scale, group_flags, stream);
+}
+
+static int launch_layernorm_bwd(const float* x, const float* add, int add_mod, const float* gamma, const float* dy, float* dx,
+                                float* dgamma, float* dbeta, long M, int D, float eps, const unsigned char* keep, float keep_scale,
+                                const unsigned char* gin, void* stream) {
     if (M < 0 || D < 4 || (D & 3) || D > 4096) { set_error("layernorm_bwd: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0) return DLDKD_OK;
     if (!x || !gamma || !dy || !dgamma || !dbeta) { set_error("layernorm_bwd: null pointer"); return DLDKD_EINVAL; }
@@ -347,7 +374,7 @@ int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const
     if (nv <= 2) {           // 16 waves x 4 rows per workgroup
         const long waves = (M + 3) / 4;
         DLDKD_LAUNCH((layernorm_bwd_kernel<2, 16>), dim3((unsigned)((waves + 15) / 16)), dim3(1024), (size_t)32 * D * sizeof(float), s,
-                           x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, 4, keep, keep_scale);
+                           x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, 4, keep, keep_scale, gin);
         return check_launch("layernorm_bwd");
     }
     const int rpw = 8;       // 4 waves x 8 rows
@@ -358,9 +385,9 @@ int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const
         return hipFuncSetAttribute((const void*)layernorm_bwd_kernel<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4096 * 4) == hipSuccess;
     }();
     (void)attr_ok;
-    if (nv <= 4) DLDKD_LAUNCH((layernorm_bwd_kernel<4, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw, keep, keep_scale);
+    if (nv <= 4) DLDKD_LAUNCH((layernorm_bwd_kernel<4, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw, keep, keep_scale, gin);
     // (no MAXV = 8 instantiation: hipcc spilled 248 registers in it; rows of 1028..2048 floats use the 16-wide form)
-    else DLDKD_LAUNCH((layernorm_bwd_kernel<16, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw, keep, keep_scale);
+    else DLDKD_LAUNCH((layernorm_bwd_kernel<16, 4>), grid, block, lds, s, x, add, add_mod, gamma, dy, dx, dgamma, dbeta, M, D, eps, rpw, keep, keep_scale, gin);
     return check_launch("layernorm_bwd");
 }
 int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream) {

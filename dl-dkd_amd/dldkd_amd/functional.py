@@ -71,7 +71,8 @@ def _axpy(a, b, alpha=1.0):
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
-        y = ops.linear(x, weight, bias, relu=relu)
+        ctx.rg = ops.row_groups(x.numel() // x.shape[-1])      # the tower's row-group flags (padding skipped) or None
+        y = ops.linear(x, weight, bias, relu=relu, row_flags=ctx.rg)
         ctx.relu = relu
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.has_bias = bias is not None
@@ -87,8 +88,8 @@ class _Linear(Function):
             native.check(_L().dldkd_relu_bwd_f32(_p(dy2), _p(y.reshape(-1, N)), dy2.numel(), _s()), "relu_bwd")
         x2 = x.reshape(-1, K)
         M = x2.shape[0]
-        dx = ops.gemm(dy2, w, False, True, M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw = ops.gemm(dy2, x2, True, True, N, K, M) if ctx.needs_input_grad[1] else None
+        dx = ops.gemm(dy2, w, False, True, M, K, N, row_flags=ctx.rg).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = ops.gemm(dy2, x2, True, True, N, K, M, row_flags=ctx.rg) if ctx.needs_input_grad[1] else None
         db = _colsum(dy2, N) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None
 
@@ -106,6 +107,14 @@ class _LayerNorm(Function):
     def forward(ctx, x, gamma, beta, add, add_mod):
         ctx.save_for_backward(x, gamma, add)
         ctx.add_mod = add_mod
+        D = x.shape[-1]
+        ctx.rg = ops.row_groups(x.numel() // D)
+        if ctx.rg is not None:
+            x2 = x.reshape(-1, D)
+            out = torch.empty_like(x2)
+            native.check(_L().dldkd_layernorm_groups_f32(_p(x2), _p(add), int(add_mod), _p(gamma), _p(beta), _p(out), None, x2.shape[0], D,
+                                                         ops.LN_EPS, 0.0, 0, 0, None, _p(ctx.rg), _s()), "layernorm_groups")
+            return out.view(x.shape)
         return ops.layernorm(x, gamma, beta, add=add, add_mod=add_mod)
 
     @staticmethod
@@ -118,9 +127,15 @@ class _LayerNorm(Function):
         dgb = _zeros((2, D), x.device)      # both accumulators
         dg, db = dgb[0], dgb[1]
         keep = ctx.keep if hasattr(ctx, "keep") else None
-        native.check(_L().dldkd_layernorm_bwd_f32(_p(x.reshape(-1, D)), _p(add), ctx.add_mod, _p(gamma), _p(dy.reshape(-1, D)),
-                                                  _p(dx), _p(dg), _p(db), x.numel() // D, D, ops.LN_EPS, _p(keep),
-                                                  getattr(ctx, "keep_scale", 1.0), _s()), "layernorm_bwd")
+        rg = getattr(ctx, "rg", None)
+        if rg is not None:
+            native.check(_L().dldkd_layernorm_bwd_groups_f32(_p(x.reshape(-1, D)), _p(add), ctx.add_mod, _p(gamma), _p(dy.reshape(-1, D)),
+                                                             _p(dx), _p(dg), _p(db), x.numel() // D, D, ops.LN_EPS, _p(keep),
+                                                             getattr(ctx, "keep_scale", 1.0), _p(rg), _s()), "layernorm_bwd_groups")
+        else:
+            native.check(_L().dldkd_layernorm_bwd_f32(_p(x.reshape(-1, D)), _p(add), ctx.add_mod, _p(gamma), _p(dy.reshape(-1, D)),
+                                                      _p(dx), _p(dg), _p(db), x.numel() // D, D, ops.LN_EPS, _p(keep),
+                                                      getattr(ctx, "keep_scale", 1.0), _s()), "layernorm_bwd")
         dadd = None
         if add is not None and ctx.needs_input_grad[3]:
             if ctx.add_mod > 0:       # position table (L, D): sum over the batch
@@ -142,9 +157,14 @@ class _LayerNormDropout(Function):
         out = torch.empty_like(x2)
         keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
         seed, off, state = _philox_slot(x.device, x.numel())
-        native.check(_L().dldkd_layernorm_dropout_f32(_p(x2), _p(add), int(add_mod), _p(gamma), _p(beta), _p(out), _p(keep),
-                                                      x2.shape[0], D, ops.LN_EPS, float(p), seed, off, state, _s()),
-                     "layernorm_dropout")
+        ctx.rg = ops.row_groups(x2.shape[0])
+        if ctx.rg is not None:
+            native.check(_L().dldkd_layernorm_groups_f32(_p(x2), _p(add), int(add_mod), _p(gamma), _p(beta), _p(out), _p(keep), x2.shape[0], D,
+                                                         ops.LN_EPS, float(p), seed, off, state, _p(ctx.rg), _s()), "layernorm_groups")
+        else:
+            native.check(_L().dldkd_layernorm_dropout_f32(_p(x2), _p(add), int(add_mod), _p(gamma), _p(beta), _p(out), _p(keep),
+                                                          x2.shape[0], D, ops.LN_EPS, float(p), seed, off, state, _s()),
+                         "layernorm_dropout")
         ctx.save_for_backward(x, gamma, add)
         ctx.add_mod, ctx.keep, ctx.keep_scale = add_mod, keep, 1.0 / (1.0 - p)
         return out.view(x.shape)
@@ -210,6 +230,8 @@ class _InProjTrain(Function):
             else:
                 z = ops.layernorm(x2, gamma, beta)
             y = ops.linear(z, weight, bias, relu=relu)
+        global _LAST_GROUP_FLAGS
+        _LAST_GROUP_FLAGS = (gflags, M) if gflags is not None else None
         ctx.save_for_backward(x2, weight, z, y if relu else None, keep, stats, gflags)
         ctx.relu, ctx.has_bias, ctx.keep_scale, ctx.prec = relu, bias is not None, 1.0 / (1.0 - p), ops.gemm_precision()
         return y.view(*x.shape[:-1], N)
@@ -245,6 +267,16 @@ class _InProjTrain(Function):
                                                        _p(ws), ws.numel() * 4, _p(dgb[0]), _p(dgb[1]), M, N, K, _p(gflags), _s()), "linear_lngrad")
             dg, dbeta = dgb[0], dgb[1]
         return None, dg, dbeta, dw, db, None, None, None
+
+
+_LAST_GROUP_FLAGS = None
+
+
+def take_group_flags():
+    """(flags, M) of the input projection that just ran with a row mask (None otherwise); cleared by the call."""
+    global _LAST_GROUP_FLAGS
+    r, _LAST_GROUP_FLAGS = _LAST_GROUP_FLAGS, None
+    return r
 
 
 IN_PROJ_SKIP_PADDING = True           # ... and the rows of the padding (a row mask given) are neither normalised nor multiplied

@@ -98,6 +98,11 @@ class DLDKD(nn.Module):
         feat = feat.float().contiguous()
         if mask is not None and input_proj_layer.training and feat.dim() == 3 and mask.dim() == 2 and mask.shape == feat.shape[:2]:
             h = input_proj_layer(feat, row_mask=mask)        # training: the input projection skips the rows of the padding
+            rg = F_.take_group_flags()
+            if rg is not None and DLDKD.TOWER_SKIPS_PADDING:
+                # ... and so does everything behind it: the flags stay current (ops.row_groups) until the tower's caller clears
+                # them (_video_tower / encode_context)
+                ops.set_row_groups(*rg)
         else:
             h = input_proj_layer(feat)
         h = pos_embed_layer(h)
@@ -246,6 +251,7 @@ class DLDKD(nn.Module):
                 out.append(ops.linear_rows_x3(h, self._folded[pre + "out_map_x3"]))
             else:
                 out.append(F_.linear(h, lin.weight, lin.bias))
+            ops.set_row_groups(None, 0)          # a training tower's row groups (encode_input) end with the tower
         return (out[0], out[1]) if self.double_branch else (out[0], None)
 
     def get_modularized_queries(self, encoded_query, query_mask, inheritance=False):
@@ -373,16 +379,24 @@ class DLDKD(nn.Module):
         return loss, out
 
     # ------------------------------------------------------------------ the four towers side by side (training)
+    TOWER_SKIPS_PADDING = True
+
     def _video_tower(self, pre, feat, mask):
-        h = self.encode_input(feat, mask, getattr(self, pre + "visual_input_proj"), getattr(self, pre + "visual_encoder"),
-                              getattr(self, pre + "visual_pos_embed"))
-        lin = getattr(self, pre + "out_mapping_linear")
-        return F_.linear(h, lin.weight, lin.bias)
+        try:
+            h = self.encode_input(feat, mask, getattr(self, pre + "visual_input_proj"), getattr(self, pre + "visual_encoder"),
+                                  getattr(self, pre + "visual_pos_embed"))
+            lin = getattr(self, pre + "out_mapping_linear")
+            return F_.linear(h, lin.weight, lin.bias)
+        finally:
+            ops.set_row_groups(None, 0)
 
     def _query_tower(self, pre, feat, mask):
-        h = self.encode_input(feat, mask, getattr(self, pre + "query_input_proj"), getattr(self, pre + "query_encoder"),
-                              getattr(self, pre + "query_pos_embed"))
-        return self.get_modularized_queries(h, mask, inheritance=(pre == ""))
+        try:
+            h = self.encode_input(feat, mask, getattr(self, pre + "query_input_proj"), getattr(self, pre + "query_encoder"),
+                                  getattr(self, pre + "query_pos_embed"))
+            return self.get_modularized_queries(h, mask, inheritance=(pre == ""))
+        finally:
+            ops.set_row_groups(None, 0)
 
     TOWER_FORK = "pair"
     QUERY_TOWERS_FIRST = True
@@ -395,12 +409,15 @@ class DLDKD(nn.Module):
         whose fork / join edges these become - runs them side by side.  Autograd runs every node's backward on the stream of
         its forward, so the backward pass of the towers overlaps the same way."""
         if not (self.tower_streams and self.training and video.is_cuda and torch.is_grad_enabled()):
-            if self.training and self.QUERY_TOWERS_FIRST:       # same order (= same dropout draws) as the four-stream form below
-                q_inh, q_exp = self.encode_query(text, tmask)
-                g_inh, g_exp = self.encode_context(video, vmask)
-            else:
-                g_inh, g_exp = self.encode_context(video, vmask)
-                q_inh, q_exp = self.encode_query(text, tmask)
+            try:
+                if self.training and self.QUERY_TOWERS_FIRST:   # same order (= same dropout draws) as the four-stream form below
+                    q_inh, q_exp = self.encode_query(text, tmask)
+                    g_inh, g_exp = self.encode_context(video, vmask)
+                else:
+                    g_inh, g_exp = self.encode_context(video, vmask)
+                    q_inh, q_exp = self.encode_query(text, tmask)
+            finally:
+                ops.set_row_groups(None, 0)                     # (encode_input leaves a training tower's row groups current)
             return g_inh, g_exp, q_inh, q_exp
         if text.dim() == 2:                  # the reference's collate .squeeze() drops a batch of one
             text, tmask = text.unsqueeze(0), tmask.reshape(1, -1)

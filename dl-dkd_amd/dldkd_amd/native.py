@@ -50,6 +50,8 @@ SIGNATURES = {
     "dldkd_rank_gt": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_layernorm_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                           _c_long, _c_int, _c_float, _c_void_p, _c_float, _c_void_p]),
+    "dldkd_layernorm_bwd_groups_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                          _c_long, _c_int, _c_float, _c_void_p, _c_float, _c_void_p, _c_void_p]),
     "dldkd_layernorm_dropout_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
                                               _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p]),
     "dldkd_layernorm_dropout_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_float,
@@ -57,7 +59,9 @@ SIGNATURES = {
     "dldkd_gemm_bf16_mixed": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                         _c_int, _c_void_p, _c_size_t, _c_void_p, _c_void_p]),
     "dldkd_gemm_bf16_nt": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                     _c_void_p]),
+                                     _c_void_p, _c_void_p]),
+    "dldkd_layernorm_groups_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
+                                             _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_gemm_bf16_nt_ok": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "dldkd_colsum_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_long, _c_void_p]),
     "dldkd_relu_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p]),

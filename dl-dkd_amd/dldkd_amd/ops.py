@@ -42,6 +42,25 @@ def gemm_precision():
     return _PRECISION
 
 
+# ---- row groups of a padded batch (training, throughput mode).  The input projection of a video tower flags the 32-row groups of
+# its (n, L, .) batch that hold valid clips (functional._InProjTrain); while that tower is being built the flags are current here
+# and every row-wise kernel of the tower - linears, LayerNorms, their backward passes - skips the other groups: rows of the padding
+# are never read, their values are act(bias) / zeros (finite don't-cares: padded KEYS are masked out of attention, padded clips out
+# of every loss), their gradients exact zeros.
+_ROW_GROUPS = None       # (uint8 flags (M / 32), M)
+
+
+def set_row_groups(flags, M):
+    global _ROW_GROUPS
+    _ROW_GROUPS = None if flags is None else (flags, int(M))
+
+
+def row_groups(M):
+    """The current tower's group flags when a tensor of M rows is one row per (item, position) of its padded batch."""
+    rg = _ROW_GROUPS
+    return rg[0] if (rg is not None and rg[1] == int(M) and _PRECISION == "bf16") else None
+
+
 GEMM_NT_DMA = True       # throughput mode: forward-layout GEMMs with >= 1024 rows on the LDS-DMA staged kernel
 
 
@@ -71,8 +90,9 @@ def _chk(t, name):
     return t
 
 
-def linear(x, weight, bias=None, relu=False):
-    """y = act(x @ weight.T + bias); x (..., K), weight (N, K)."""
+def linear(x, weight, bias=None, relu=False, row_flags=None):
+    """y = act(x @ weight.T + bias); x (..., K), weight (N, K).  row_flags (uint8 per 32 rows, throughput mode): groups flagged 0
+    are rows of the padding - not read; their output rows are act(bias)."""
     L = native.lib()
     K = x.shape[-1]
     x2 = _chk(x.reshape(-1, K), "linear.x")
@@ -84,7 +104,7 @@ def linear(x, weight, bias=None, relu=False):
     if GEMM_NT_DMA and _PRECISION == "bf16" and M >= 1024 and L.dldkd_gemm_bf16_nt_ok(M, N, K, K, K):
         # throughput mode, many rows: operand tiles by LDS-DMA (gemm_bf16_dma.hip; bit-identical to dldkd_gemm_bf16)
         native.check(L.dldkd_gemm_bf16_nt(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
-                                          int(relu), native.stream()), "gemm_bf16_nt")
+                                          int(relu), native.ptr(row_flags), native.stream()), "gemm_bf16_nt")
         return y.view(*x.shape[:-1], N)
     fn = _gemm_fn(L)
     native.check(fn(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
@@ -92,17 +112,24 @@ def linear(x, weight, bias=None, relu=False):
     return y.view(*x.shape[:-1], N)
 
 
-def gemm(a, b, a_kmajor, b_kmajor, M, N, K):
-    """C[M,N] = sum_k A(m,k) B(n,k) with explicit operand layouts (used by the backward passes)."""
+def gemm(a, b, a_kmajor, b_kmajor, M, N, K, row_flags=None):
+    """C[M,N] = sum_k A(m,k) B(n,k) with explicit operand layouts (used by the backward passes).  row_flags (throughput mode): per
+    32 rows of the ACTIVATION operand(s) - of A's rows in the dX layout, of the contraction index in the dW layout; groups
+    flagged 0 are rows of the padding (zero rows of dy) and are skipped."""
     L = native.lib()
     _chk(a, "gemm.a"); _chk(b, "gemm.b")
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if row_flags is not None and _PRECISION == "bf16" and a_kmajor and b_kmajor:
+        ws, ws_bytes = _gemm_workspace(L, M, N, K, True, True, a.device)
+        native.check(L.dldkd_gemm_bf16_mixed(2, native.ptr(a), native.ptr(b), None, native.ptr(c), M, N, K, a.shape[-1], b.shape[-1], N, 0,
+                                             native.ptr(ws), ws_bytes, native.ptr(row_flags), native.stream()), "gemm_bf16_mixed")
+        return c
     if (GEMM_NT_DMA and _PRECISION == "bf16" and not a_kmajor and b_kmajor and M >= 1024 and b.dim() == 2 and b.shape[0] == K
             and L.dldkd_gemm_bf16_nt_ok(M, N, K, a.shape[-1], K)):
         # dX = dy . W with a weight of a few hundred rows: transpose W (K x N, < 2 MB) and the product has the forward layout
         bt = b.t().contiguous()
         native.check(L.dldkd_gemm_bf16_nt(native.ptr(a), native.ptr(bt), None, native.ptr(c), M, N, K, a.shape[-1], K, N, 0,
-                                          native.stream()), "gemm_bf16_nt")
+                                          native.ptr(row_flags), native.stream()), "gemm_bf16_nt")
         return c
     fn = _gemm_fn(L)
     ws, ws_bytes = _gemm_workspace(L, M, N, K, a_kmajor, b_kmajor, a.device)

@@ -160,6 +160,12 @@ int dldkd_layernorm_dropout_f32(const float* x, const float* add, int add_mod, c
                                 float* out, unsigned char* keep, long M, int D, float eps, float p_drop,
                                 unsigned long long seed, unsigned long long offset, const unsigned long long* state,
                                 void* stream);
+/* dldkd_layernorm_f32 / _dropout_f32 with a row-group filter: group_flags (M / 32 bytes, M % 32 == 0, or NULL) as written by
+ * dldkd_layernorm_dropout_bf16 for the padded batch this tensor's rows belong to - rows of a group flagged 0 (clips past a video's
+ * length) are not read, their output row (and keep bytes) are zeros.  keep may be NULL when p_drop == 0. */
+int dldkd_layernorm_groups_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out,
+                               unsigned char* keep, long M, int D, float eps, float p_drop, unsigned long long seed,
+                               unsigned long long offset, const unsigned long long* state, const unsigned char* group_flags, void* stream);
 /* The same LayerNorm (+ inverted dropout when p_drop > 0: same masks) writing the row as bf16 (round to nearest even) - the
  * operand form of the bf16 GEMMs that consume it (dldkd_gemm_bf16_mixed) - and, when stats != NULL, the row statistics
  * (mean -> stats[row], rstd -> stats[M + row]) the backward pass would otherwise recompute.  Training input projection in
@@ -309,16 +315,19 @@ int dldkd_gemm_bf16(const float* A, const float* B, const float* bias, float* C,
  *   dw != 0  dW       C[M, N] = sum_k A[k, m] B16[k, n]             A fp32 (K, M) = dy, B16 bf16 (K, N) = the saved rows (ldb, N even);
  *                     no bias / ReLU; split-K like dldkd_gemm_bf16 with a workspace of
  *                     dldkd_gemm_workspace_bytes(DLDKD_GEMM_BF16, M, N, K, 1, 1) bytes (NULL: no split); k_flags (one byte per 32
- *                     consecutive k, or NULL): tiles flagged 0 hold zero rows (padding) and are skipped (dw != 0 only). */
+ *                     consecutive k, or NULL): tiles flagged 0 hold zero rows (padding) and are skipped;
+ *   dw == 2           the dW layout with B fp32 (K, N) as well (dldkd_gemm_bf16's) plus k_flags;
+ *   dw == 0           k_flags, if given, are per 32 ROWS of A16 / C (M % 128 == 0): the groups flagged 0 are not multiplied. */
 int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
                           int ldc, int relu, void* workspace, size_t workspace_bytes, const unsigned char* k_flags, void* stream);
 /* The forward layout of dldkd_gemm_bf16 - C[M, N] = act(A[M, K] . B[N, K]^T + bias), both operands fp32 and k-minor (a Linear's
  * forward pass; its input gradient once the weight is transposed) - with the operand tiles staged HBM -> LDS by LDS-DMA instead
  * of through registers (gemm_bf16_dma.hip): same products in the same order, bit-identical results, about half the time on
  * the towers' 16,384-row x 384 / 1152-wide layers, which are latency-bound in the register-staged kernel.  Needs K % 32 == 0,
- * lda / ldb % 4 == 0, 16-byte aligned operands (dldkd_gemm_bf16_nt_ok); no split-K. */
+ * lda / ldb % 4 == 0, 16-byte aligned operands (dldkd_gemm_bf16_nt_ok); no split-K.  row_flags (M / 32 bytes, or NULL; M % 128 == 0):
+ * 32-row groups of A flagged 0 are rows of the padding - not loaded, not multiplied; their C rows are act(bias). */
 int dldkd_gemm_bf16_nt(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                       int relu, void* stream);
+                       int relu, const unsigned char* row_flags, void* stream);
 int dldkd_gemm_bf16_nt_ok(int M, int N, int K, int lda, int ldb);
 
 /* fp32-GRADE GEMM on the bf16 matrix cores: each fp32 operand is split into three bf16 planes (h + m + l = 24 mantissa
@@ -336,6 +345,11 @@ int dldkd_gemm_f32x3(const float* A, const float* B, const float* bias, float* C
 int dldkd_layernorm_bwd_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* dy,
                             float* dx, float* dgamma, float* dbeta, long M, int D, float eps, const unsigned char* keep,
                             float keep_scale, void* stream);
+/* ... and its backward pass: rows of a group flagged 0 contribute nothing to dgamma / dbeta and get a zero dx row (their dy is
+ * zero: no loss term depends on a padded clip); neither x nor dy is read there. */
+int dldkd_layernorm_bwd_groups_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* dy, float* dx,
+                                   float* dgamma, float* dbeta, long M, int D, float eps, const unsigned char* keep, float keep_scale,
+                                   const unsigned char* group_flags, void* stream);
 
 /* out[c] += sum_r x[r, c]  (bias gradients; position-table gradient with x viewed as (batch, L*D)). */
 int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream);

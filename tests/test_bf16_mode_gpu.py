@@ -303,7 +303,7 @@ def test_gemm_bf16_nt_dma_is_bit_identical_to_gemm_bf16(bf16_mode, M, N, K, relu
     b = torch.randn(N, generator=g).to(DEV)
     assert L.dldkd_gemm_bf16_nt_ok(M, N, K, K, K)
     y_new, y_old = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
-    native.check(L.dldkd_gemm_bf16_nt(native.ptr(a), native.ptr(w), native.ptr(b), native.ptr(y_new), M, N, K, K, K, N, int(relu),
+    native.check(L.dldkd_gemm_bf16_nt(native.ptr(a), native.ptr(w), native.ptr(b), native.ptr(y_new), M, N, K, K, K, N, int(relu), None,
                                       native.stream()), "nt")
     native.check(L.dldkd_gemm_bf16(native.ptr(a), native.ptr(w), native.ptr(b), native.ptr(y_old), M, N, K, K, K, N, 0, 0, int(relu), None, 0,
                                    native.stream()), "old")
@@ -355,3 +355,44 @@ def test_training_input_projection_skips_the_padding(bf16_mode, nv, L, K, p_drop
     assert torch.equal(ym[~valid], torch.relu(b).expand(int((~valid).sum()), -1))
     for a, r in ((dWm, dW0), (dbbm, dbb0), (dgm, dg0), (dbm, db0)):
         assert torch.isfinite(a).all() and torch.allclose(a, r, rtol=1e-4, atol=1e-5 * r.abs().max().item())
+
+
+def test_video_tower_skips_the_padding_without_changing_the_step(bf16_mode):
+    """Training, throughput mode: with the batch's mask the input projection flags the 32-row groups that hold valid clips and
+    every row-wise kernel of the video towers (LayerNorms, linears, their backward passes) skips the others (ops.row_groups).
+    No loss term reads a padded clip and padded keys are masked out of attention, so losses and all 74 gradients must equal
+    those of the run that computes the padding too - up to fp32 summation order - with dropout on (masks are indexed by
+    position, the same in both runs)."""
+    import types
+    from dldkd_amd import functional as F_
+    from dldkd_amd.model import DLDKD
+    cfg = types.SimpleNamespace(visual_input_size=512, query_input_size=256, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=64, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4, initializer_range=0.02,
+                                margin=0.1, use_hard_negative=False, hard_pool_size=20, label_style="soft")
+    mopt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                 collection="tvr", alpha=0.8, belta=0.8)
+    batch = synth.make_train_batch(31, nv=48, caps=3, L=64, len_lo=5, dv=512, dq=256)
+    batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    assert batch["student_videos"].shape[1] == 64 and float(batch["student_videos_mask"].mean()) < 0.8
+    res = []
+    try:
+        for skip in (True, False):
+            F_.IN_PROJ_SKIP_PADDING = DLDKD.TOWER_SKIPS_PADDING = skip
+            torch.manual_seed(5)
+            m = DLDKD(types.SimpleNamespace(**vars(cfg)), mopt).to(DEV).train()
+            torch.manual_seed(9)
+            loss, parts = m(batch)
+            loss.backward()
+            res.append((float(loss), {k: float(v) for k, v in parts.items() if torch.is_tensor(v)},
+                        {n: p.grad.detach().clone() for n, p in m.named_parameters()}))
+    finally:
+        F_.IN_PROJ_SKIP_PADDING = DLDKD.TOWER_SKIPS_PADDING = True
+    (la, pa, ga), (lb, pb, gb) = res
+    assert la == pytest.approx(lb, rel=1e-5)
+    for k in pa:
+        assert pa[k] == pytest.approx(pb[k], rel=1e-4, abs=1e-6), k
+    assert len(ga) == 74
+    for n in ga:
+        assert torch.isfinite(ga[n]).all(), n
+        scale = gb[n].abs().max().item()
+        assert (ga[n] - gb[n]).abs().max().item() <= 2e-4 * max(scale, 1e-6) + 1e-7, (n, scale)
