@@ -359,7 +359,8 @@ int launch_simpool_pool_x3(const float* g, const float* q, int nv, int L, int nq
 // dz' = dy W with the LayerNorm-parameter-gradient epilogue (gemm_lngrad_tile), per precision mode
 int launch_linear_lngrad_bf16(const float* dy, const float* W, long M, int N, int K, const LnGradArgs& la, void* stream,
                               const unsigned char* row_flags = nullptr);
-int launch_linear_lngrad_x3(const float* dy, const float* W, long M, int N, int K, const LnGradArgs& la, void* stream);
+int launch_linear_lngrad_x3(const float* dy, const float* W, long M, int N, int K, const LnGradArgs& la, void* stream,
+                            const unsigned char* row_flags = nullptr);
 int launch_simpool_pool_bf16(const float* g, const float* q, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream);
 int launch_splitk_reduce(const float* ws, float* out, int split, long n, hipStream_t s);
 // Every kernel launch of the library: drop whatever error another library left in the runtime's sticky per-thread slot

@@ -341,6 +341,15 @@ int dldkd_layernorm_groups_f32(const float* x, const float* add, int add_mod, co
                             nullptr, nullptr, nullptr, nullptr, group_flags);
 }
 
+int dldkd_layernorm_dropout_rows_f32(const float* x, const float* gamma, const float* beta, float* out, unsigned char* keep, float* stats,
+                                     long M, int D, float eps, float p_drop, unsigned long long seed, unsigned long long offset,
+                                     const unsigned long long* state, const float* row_mask, unsigned char* group_flags, void* stream) {
+    if (p_drop > 0.f && (!keep || ((uintptr_t)keep & 3))) { set_error("layernorm_dropout_rows: keep mask missing or unaligned"); return DLDKD_EINVAL; }
+    if (group_flags && (!row_mask || (M & 31))) { set_error("layernorm_dropout_rows: group flags need a row mask and M %% 32 == 0"); return DLDKD_EINVAL; }
+    return launch_layernorm(x, nullptr, 0, gamma, beta, out, M, D, eps, p_drop > 0.f ? keep : nullptr, p_drop, seed, offset, state, stream,
+                            nullptr, stats, row_mask, group_flags);
+}
+
 int dldkd_layernorm_dropout_bf16(const float* x, const float* gamma, const float* beta, void* out_bf16, unsigned char* keep, float* stats,
                                  long M, int D, float eps, float p_drop, unsigned long long seed, unsigned long long offset,
                                  const unsigned long long* state, const float* row_mask, unsigned char* group_flags, void* stream) {

@@ -403,7 +403,7 @@ extern "C" int dldkd_linear_lngrad(int precision, const float* dy, const float* 
     if (workspace_bytes < (size_t)2 * tiles * K * sizeof(float)) { set_error("linear_lngrad: workspace too small"); return DLDKD_EINVAL; }
     LnGradArgs la{x, keep, mean, rstd, workspace, workspace + (size_t)tiles * K, K, keep_scale};
     int rc = precision == DLDKD_GEMM_BF16 ? launch_linear_lngrad_bf16(dy, W, M, N, K, la, stream, row_flags)
-                                          : launch_linear_lngrad_x3(dy, W, M, N, K, la, stream);
+                                          : launch_linear_lngrad_x3(dy, W, M, N, K, la, stream, row_flags);
     if (rc != DLDKD_OK) return rc;
     rc = dldkd_colsum_f32(la.part_g, dgamma, tiles, K, stream);
     if (rc != DLDKD_OK) return rc;

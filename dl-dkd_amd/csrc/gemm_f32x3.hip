@@ -41,6 +41,8 @@ struct GemmXArgs {
     long sAo, sAi, sBo, sBi, sCo, sCi;
     float alpha;
     int split_k, k_tiles_per_split;
+    const unsigned char* mflags;   // per 32 rows of A / C (k-minor A, M % 128 == 0) or null: 0 = rows of the padding - not multiplied
+    const unsigned char* kflags;   // per 32 contraction rows (dW layout) or null: 0 = zero rows - the k-tiles are skipped
 };
 
 // x -> (h, m, l) bf16 bit patterns
@@ -158,6 +160,29 @@ __device__ __forceinline__ void gemm_f32x3_body(GemmXArgs p, const EArgs* pa) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // rows of the padding (gemm_bf16.hip has the same two filters): a wave's 32-row tiles whose group is flagged 0 are not
+    // multiplied (k-minor A: six MFMAs per product saved; the rows are still loaded - they hold zeros), and in the dW layout the
+    // k-tiles of flagged-0 contraction groups are neither loaded nor multiplied
+    unsigned pm = 0xFu;
+    if constexpr (!A_KMAJOR) {
+        if (p.mflags != nullptr) {
+            const unsigned w4 = *reinterpret_cast<const unsigned*>(p.mflags + (m0 >> 5));
+            pm = ((w4 & 0xffu) ? 1u : 0u) | ((w4 & 0xff00u) ? 2u : 0u) | ((w4 & 0xff0000u) ? 4u : 0u) | ((w4 & 0xff000000u) ? 8u : 0u);
+            pm = __builtin_amdgcn_readfirstlane(pm);
+        }
+    }
+    const bool rt_ok[2] = {((pm >> (wm / 32)) & 1u) != 0, ((pm >> (wm / 32 + 1)) & 1u) != 0};
+    const int g0 = kt0 >> 1;                               // first 32-row contraction group of this workgroup's k-range (XBK = 16)
+    unsigned long long km0 = ~0ull, km1 = ~0ull;
+    if (p.kflags != nullptr && ((kt0 + nk - 1) >> 1) - g0 < 128) {
+        const int ng = ((kt0 + nk - 1) >> 1) - g0 + 1;
+        km0 = __ballot(lane < ng ? p.kflags[g0 + lane] != 0 : false);
+        km1 = __ballot(64 + lane < ng ? p.kflags[g0 + 64 + lane] != 0 : false);
+    }
+    auto tile_ok = [&](int kt) {
+        const int g = ((kt0 + kt) >> 1) - g0;
+        return g < 64 ? ((km0 >> g) & 1ull) != 0 : g < 128 ? ((km1 >> (g - 64)) & 1ull) != 0 : true;
+    };
     // operand tiles are prefetched TWO k-tiles ahead in a ring of two register sets (the loop is unrolled by 2 so the
     // ring index is static): at ~2 us of loaded HBM/L2 latency a one-tile-ahead pipeline paid a round trip per k-tile
     float ra[2][XNREG], rb[2][XNREG];
@@ -177,22 +202,26 @@ __device__ __forceinline__ void gemm_f32x3_body(GemmXArgs p, const EArgs* pa) {
     auto iter = [&](int kt, auto set_c) {           // tile kt is in LDS stage kt & 1; its register set (S) is free
         constexpr int S = decltype(set_c)::value;
         const int cur = kt & 1;
-        if (kt + 2 < nk) load_tiles((kt0 + kt + 2) * XBK, set_c);
+        if (kt + 2 < nk && tile_ok(kt + 2)) load_tiles((kt0 + kt + 2) * XBK, set_c);
+        const bool this_ok = tile_ok(kt);
         const unsigned short* As = lds[cur][0] + (wm + (lane & 31)) * XPITCH + (lane >> 5) * 8;
         const unsigned short* Bs = lds[cur][1] + (wn + (lane & 31)) * XPITCH + (lane >> 5) * 8;
         bf16x8 a[2][3], b[2][3];
+        if (this_ok) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * XPLANE + 32 * i * XPITCH);
-                b[i][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * XPLANE + 32 * i * XPITCH);
-            }
+                for (int pl = 0; pl < 3; ++pl) {
+                    if (rt_ok[i]) a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * XPLANE + 32 * i * XPITCH);
+                    b[i][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * XPLANE + 32 * i * XPITCH);
+                }
+        }
         // smallest terms first
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                if (!this_ok || !rt_ok[i]) continue;
                 f32x16 c = acc[i][j];
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
@@ -202,16 +231,18 @@ __device__ __forceinline__ void gemm_f32x3_body(GemmXArgs p, const EArgs* pa) {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
                 acc[i][j] = c;
             }
-        if (kt + 1 < nk) {
+        if (kt + 1 < nk && tile_ok(kt + 1)) {
             TileX<A_KMAJOR>::store(lds[cur ^ 1][0], tid, ra[1 - S]);
             TileX<B_KMAJOR>::store(lds[cur ^ 1][1], tid, rb[1 - S]);
         }
         __syncthreads();
     };
-    load_tiles(kt0 * XBK, S0{});
-    if (nk > 1) load_tiles((kt0 + 1) * XBK, S1{});
-    TileX<A_KMAJOR>::store(lds[0][0], tid, ra[0]);
-    TileX<B_KMAJOR>::store(lds[0][1], tid, rb[0]);
+    if (tile_ok(0)) load_tiles(kt0 * XBK, S0{});
+    if (nk > 1 && tile_ok(1)) load_tiles((kt0 + 1) * XBK, S1{});
+    if (tile_ok(0)) {
+        TileX<A_KMAJOR>::store(lds[0][0], tid, ra[0]);
+        TileX<B_KMAJOR>::store(lds[0][1], tid, rb[0]);
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
         iter(kt, S0{});
@@ -246,9 +277,11 @@ static int launch_gemm_x(GemmXArgs p, int batch, int a_kmajor, int b_kmajor, voi
     return check_launch("gemm_f32x3");
 }
 
-int launch_linear_lngrad_x3(const float* dy, const float* W, long M, int N, int K, const LnGradArgs& la, void* stream) {
+int launch_linear_lngrad_x3(const float* dy, const float* W, long M, int N, int K, const LnGradArgs& la, void* stream,
+                            const unsigned char* row_flags) {
     const int a_vec = !(N & 3) && !((uintptr_t)dy & 15);
     GemmXArgs p{dy, W, nullptr, nullptr, (int)M, K, N, N, K, K, 0, a_vec, 0, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+    p.mflags = (M % XBM == 0 && !((uintptr_t)row_flags & 3)) ? row_flags : nullptr;
     DLDKD_LAUNCH(gemm_f32x3_lngrad_kernel, dim3((K + XBN - 1) / XBN, (unsigned)((M + XBM - 1) / XBM), 1), dim3(256), 0,
                  (hipStream_t)stream, p, la);
     return check_launch("linear_lngrad (fp32x3)");
@@ -278,14 +311,34 @@ int dldkd::gemm_f32x3_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor
     return (nk + *k_tiles_per_split - 1) / *k_tiles_per_split;
 }
 
+static int gemm_f32x3_impl(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda,
+                           int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes,
+                           const unsigned char* flags, void* stream);
+
 extern "C" int dldkd_gemm_f32x3(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda,
                                 int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes,
                                 void* stream) {
+    return gemm_f32x3_impl(A, B, bias, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, relu, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int dldkd_gemm_f32x3_flags(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda,
+                                      int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes,
+                                      const unsigned char* flags, void* stream) {
+    return gemm_f32x3_impl(A, B, bias, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, relu, workspace, workspace_bytes, flags, stream);
+}
+
+static int gemm_f32x3_impl(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda,
+                           int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes,
+                           const unsigned char* flags, void* stream) {
     if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < N) { set_error("gemm_f32x3: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0 || N == 0) return DLDKD_OK;
     if (!A || !B || !C) { set_error("gemm_f32x3: null pointer"); return DLDKD_EINVAL; }
     const int a_vec = !(lda & 3) && !((uintptr_t)A & 15), b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
     GemmXArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+    // flags: one byte per 32 rows of the activation operand - A's rows when A is k-minor (forward, dX; M % 128 == 0), the
+    // contraction index when both operands are k-major (dW)
+    if (flags != nullptr && !a_kmajor && M % XBM == 0 && !((uintptr_t)flags & 3)) p.mflags = flags;
+    if (flags != nullptr && a_kmajor && b_kmajor) p.kflags = flags;
     int per = 0;
     const int split = (!bias && !relu && ldc == N && !((uintptr_t)C & 15)) ? gemm_f32x3_split_plan(M, N, K, a_kmajor, b_kmajor, &per) : 1;
     if (split > 1 && workspace && !((uintptr_t)workspace & 15) && workspace_bytes >= (size_t)split * M * N * sizeof(float)) {

@@ -220,6 +220,21 @@ class _InProjTrain(Function):
             y = torch.empty(M, N, dtype=torch.float32, device=x.device)
             native.check(_L().dldkd_gemm_bf16_mixed(0, _p(z), _p(weight), _p(bias), _p(y), M, N, K, K, K, N, int(relu), None, 0,
                                                     _p(gflags), _s()), "gemm_bf16_mixed")
+        elif (row_mask is not None and IN_PROJ_SKIP_PADDING and x.dim() == 3 and row_mask.numel() == M and x.shape[1] % 32 == 0
+              and M % 128 == 0 and ops.gemm_precision() in ("fp32", "fp32x3")):
+            # parity mode with the batch's mask: the same padding skip with fp32 rows (the three-plane GEMMs are compute-bound:
+            # the 32-row groups that are not multiplied are time saved one for one)
+            z = torch.empty_like(x2)
+            stats = torch.empty(2, M, dtype=torch.float32, device=x.device)
+            gflags = torch.empty(M // 32, dtype=torch.uint8, device=x.device)
+            seed, off, state = (0, 0, None)
+            if p > 0.0:
+                keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
+                seed, off, state = _philox_slot(x.device, x.numel())
+            native.check(_L().dldkd_layernorm_dropout_rows_f32(_p(x2), _p(gamma), _p(beta), _p(z), _p(keep), _p(stats), M, K, ops.LN_EPS,
+                                                               float(p), seed, off, state, _p(_f32(row_mask).reshape(-1)), _p(gflags),
+                                                               _s()), "layernorm_dropout_rows")
+            y = ops.linear(z, weight, bias, relu=relu, row_flags=gflags)
         else:
             if p > 0.0:
                 z = torch.empty_like(x2)
@@ -253,7 +268,7 @@ class _InProjTrain(Function):
                 native.check(_L().dldkd_gemm_bf16_mixed(1, _p(dy2), _p(z), None, _p(dw), N, K, M, N, K, K, 0, _p(ws), ws_bytes, _p(gflags),
                                                         _s()), "gemm_bf16_mixed")
             else:
-                dw = ops.gemm(dy2, z, True, True, N, K, M)
+                dw = ops.gemm(dy2, z, True, True, N, K, M, row_flags=gflags)
         db = _colsum(dy2, N) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
         dg = dbeta = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:

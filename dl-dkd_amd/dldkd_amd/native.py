@@ -54,6 +54,8 @@ SIGNATURES = {
                                           _c_long, _c_int, _c_float, _c_void_p, _c_float, _c_void_p, _c_void_p]),
     "dldkd_layernorm_dropout_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
                                               _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p]),
+    "dldkd_layernorm_dropout_rows_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_float,
+                                                   _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_layernorm_dropout_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_float,
                                                _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_gemm_bf16_mixed": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -143,6 +145,8 @@ SIGNATURES = {
     "dldkd_mask_scale_f32": (_c_int, [_c_void_p, _c_void_p, _c_float, _c_void_p, _c_long, _c_void_p]),
     "dldkd_gemm_f32x3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                          _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
+    "dldkd_gemm_f32x3_flags": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                         _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p, _c_void_p]),
     "dldkd_order_by_len_desc": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_tower_blob_bytes": (_c_size_t, [_c_int]),
     "dldkd_tower_pack_bf16": (_c_int, [_c_void_p] * 16 + [_c_int, _c_void_p, _c_void_p]),

@@ -58,7 +58,7 @@ def set_row_groups(flags, M):
 def row_groups(M):
     """The current tower's group flags when a tensor of M rows is one row per (item, position) of its padded batch."""
     rg = _ROW_GROUPS
-    return rg[0] if (rg is not None and rg[1] == int(M) and _PRECISION == "bf16") else None
+    return rg[0] if (rg is not None and rg[1] == int(M) and _PRECISION in ("bf16", "fp32", "fp32x3")) else None
 
 
 GEMM_NT_DMA = True       # throughput mode: forward-layout GEMMs with >= 1024 rows on the LDS-DMA staged kernel
@@ -106,6 +106,10 @@ def linear(x, weight, bias=None, relu=False, row_flags=None):
         native.check(L.dldkd_gemm_bf16_nt(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
                                           int(relu), native.ptr(row_flags), native.stream()), "gemm_bf16_nt")
         return y.view(*x.shape[:-1], N)
+    if row_flags is not None and _PRECISION in ("fp32", "fp32x3"):
+        native.check(L.dldkd_gemm_f32x3_flags(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
+                                              0, 0, int(relu), None, 0, native.ptr(row_flags), native.stream()), "gemm_f32x3_flags")
+        return y.view(*x.shape[:-1], N)
     fn = _gemm_fn(L)
     native.check(fn(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
                     0, 0, int(relu), None, 0, native.stream()), "gemm")          # the forward layout never splits K
@@ -133,6 +137,11 @@ def gemm(a, b, a_kmajor, b_kmajor, M, N, K, row_flags=None):
         return c
     fn = _gemm_fn(L)
     ws, ws_bytes = _gemm_workspace(L, M, N, K, a_kmajor, b_kmajor, a.device)
+    if row_flags is not None and _PRECISION in ("fp32", "fp32x3") and (not a_kmajor or b_kmajor):
+        native.check(L.dldkd_gemm_f32x3_flags(native.ptr(a), native.ptr(b), None, native.ptr(c), M, N, K, a.shape[-1], b.shape[-1], N,
+                                              int(a_kmajor), int(b_kmajor), 0, native.ptr(ws), ws_bytes, native.ptr(row_flags),
+                                              native.stream()), "gemm_f32x3_flags")
+        return c
     native.check(fn(native.ptr(a), native.ptr(b), None, native.ptr(c), M, N, K, a.shape[-1], b.shape[-1], N,
                     int(a_kmajor), int(b_kmajor), 0, native.ptr(ws), ws_bytes, native.stream()), "gemm")
     return c

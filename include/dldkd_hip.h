@@ -166,6 +166,11 @@ int dldkd_layernorm_dropout_f32(const float* x, const float* add, int add_mod, c
 int dldkd_layernorm_groups_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out,
                                unsigned char* keep, long M, int D, float eps, float p_drop, unsigned long long seed,
                                unsigned long long offset, const unsigned long long* state, const unsigned char* group_flags, void* stream);
+/* The fp32-row twin of dldkd_layernorm_dropout_bf16 (parity mode): same row mask / group flags / statistics, fp32 output. */
+int dldkd_layernorm_dropout_rows_f32(const float* x, const float* gamma, const float* beta, float* out, unsigned char* keep, float* stats,
+                                     long M, int D, float eps, float p_drop, unsigned long long seed, unsigned long long offset,
+                                     const unsigned long long* state, const float* row_mask, unsigned char* group_flags, void* stream);
+
 /* The same LayerNorm (+ inverted dropout when p_drop > 0: same masks) writing the row as bf16 (round to nearest even) - the
  * operand form of the bf16 GEMMs that consume it (dldkd_gemm_bf16_mixed) - and, when stats != NULL, the row statistics
  * (mean -> stats[row], rstd -> stats[M + row]) the backward pass would otherwise recompute.  Training input projection in
@@ -337,6 +342,12 @@ int dldkd_gemm_bf16_nt_ok(int M, int N, int K, int lda, int ldb);
  * accuracy; the host mirror uses it for precision "fp32" and keeps the true fp32-input MFMA as "fp32_exact". */
 int dldkd_gemm_f32x3(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
                      int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes, void* stream);
+/* dldkd_gemm_f32x3 with a filter for the rows of the padding: flags = one byte per 32 rows of the ACTIVATION operand - A's rows
+ * when A is k-minor (forward / dX; M % 128 == 0: groups flagged 0 are not multiplied, their C rows come out as act(bias)), the
+ * contraction index when both operands are k-major (dW: the k-tiles of groups flagged 0 - zero rows of dy - are skipped). */
+int dldkd_gemm_f32x3_flags(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
+                           int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes,
+                           const unsigned char* flags, void* stream);
 
 
 /* Backward of dldkd_layernorm_f32: dx (may be NULL) written, dgamma / dbeta += (zero-initialised by the caller).

@@ -743,3 +743,46 @@ def test_fused_training_input_projection_vs_unfused(M, K, p_drop, prec):
     tol = 2e-2 if prec == "bf16" else 2e-5          # parity mode: fp32-grade products (three bf16 planes per operand)
     for got, ref in ((dgf, dg64), (dbf, db64), (dgu, dg64), (dbu, db64)):
         assert (got.double() - ref).abs().max().item() <= tol * ref.abs().max().item()
+
+
+def test_video_tower_skips_the_padding_in_parity_mode():
+    """The padding skip of the training video towers (input projection with the batch's mask -> 32-row group flags -> every row-wise
+    kernel of the tower skips the groups without a valid clip) in parity mode: fp32 rows, three-plane GEMMs
+    (dldkd_gemm_f32x3_flags: row tiles / k-tiles of the padding are not multiplied).  Losses and all 74 gradients equal those of
+    the run that computes the padding, up to fp32 summation order, with dropout on."""
+    import types
+    import synth
+    from dldkd_amd import functional as F_, ops
+    from dldkd_amd.model import DLDKD
+    cfg = types.SimpleNamespace(visual_input_size=512, query_input_size=256, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=64, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4, initializer_range=0.02,
+                                margin=0.1, use_hard_negative=False, hard_pool_size=20, label_style="soft")
+    mopt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                 collection="tvr", alpha=0.8, belta=0.8)
+    batch = synth.make_train_batch(33, nv=48, caps=3, L=64, len_lo=5, dv=512, dq=256)
+    batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    assert ops.gemm_precision() in ("fp32", "fp32x3") and batch["student_videos"].shape[1] == 64
+    res, seen = [], []
+    real = ops.row_groups
+    try:
+        ops.row_groups = lambda M: seen.append(real(M) is not None) or real(M)
+        for skip in (True, False):
+            F_.IN_PROJ_SKIP_PADDING = DLDKD.TOWER_SKIPS_PADDING = skip
+            n0 = sum(seen)
+            torch.manual_seed(5)
+            m = DLDKD(types.SimpleNamespace(**vars(cfg)), mopt).to(DEV).train()
+            torch.manual_seed(9)
+            loss, parts = m(batch)
+            loss.backward()
+            assert (sum(seen) > n0) == skip                       # the tower's kernels did / did not get the flags
+            res.append((float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters()}))
+    finally:
+        ops.row_groups = real
+        F_.IN_PROJ_SKIP_PADDING = DLDKD.TOWER_SKIPS_PADDING = True
+    (la, ga), (lb, gb) = res
+    assert la == pytest.approx(lb, rel=2e-6)
+    assert len(ga) == 74
+    for n in ga:
+        assert torch.isfinite(ga[n]).all(), n
+        scale = gb[n].abs().max().item()
+        assert (ga[n] - gb[n]).abs().max().item() <= 2e-5 * max(scale, 1e-6) + 1e-8, (n, scale)
