@@ -27,16 +27,16 @@ R = import_reference()
 torch.set_num_threads(8)
 
 
-def ref_model(dv, dq, params, label_style="soft", hard=False, margin=0.1, alpha=0.8, belta=0.8):
+def ref_model(dv, dq, params, label_style="soft", hard=False, margin=0.1, alpha=0.8, belta=0.8, drop=0.2, train=False):
     cfg = R.EasyDict(visual_input_size=dv, query_input_size=dq, inheritance_hidden=384,
-                     exploration_hidden=384, max_ctx_l=128, max_desc_l=30, input_drop=0.2, drop=0.2,
+                     exploration_hidden=384, max_ctx_l=128, max_desc_l=30, input_drop=drop, drop=drop,
                      n_heads=4, initializer_range=0.02, device=[0], margin=margin,
                      use_hard_negative=hard, hard_pool_size=20, label_style=label_style)
     opt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04,
                                 explore_nce_weight=0.04, collection="tvr", alpha=alpha, belta=belta)
     m = R.model.DLDKD(cfg, opt)
     m.load_state_dict(params, strict=True)
-    m.eval()
+    m.train(train)
     return m
 
 
@@ -201,6 +201,61 @@ def g4_forward():
     np.savez(os.path.join(HERE, "g4_forward.npz"), **out)
 
 
+def g4t_forward_train_mode():
+    """Full DLDKD.forward + backward with the reference in model.train() and drop = input_drop = 0 (nn.Dropout(0) is the identity:
+    the step is deterministic) on a batch whose videos are padded to L = 64 with 3..64 valid clips - about half of them leave a
+    whole 32-row group of padding, the rows the build's training towers skip.  7 losses + all 74 gradients."""
+    out = {}
+    for tag, hard, caps, nv, seed in synth.G4T_CASES:
+        dv, dq = 3072, 768
+        p = synth.make_params(seed, dv, dq)
+        m = ref_model(dv, dq, p, label_style="soft", hard=hard, drop=0.0, train=True)
+        assert m.training
+        m.weight = 0.95 ** 3
+        batch = synth.make_train_batch(seed, nv=nv, caps=synth.g4t_caps(caps, nv), L=64, len_lo=3, dv=dv, dq=dq)
+        lens = batch["student_videos_mask"].sum(1).long()
+        assert int((lens <= 32).sum()) >= nv // 4, "the batch must hold videos with an all-padding 32-row group"
+        labels = batch["text_labels"]
+        torch.manual_seed(777)
+        loss, d = m(batch)
+        m.zero_grad()
+        loss.backward()
+        torch.manual_seed(777)
+        r0 = orc.draw_triplet_randoms(labels, nv, hard, 20)
+        r1 = orc.draw_triplet_randoms(labels, nv, hard, 20)
+        cfg = dict(n_heads=4, margin=0.1, use_hard_negative=hard, label_style="soft", kl_intra_weight=0.1, weight=0.95 ** 3,
+                   inher_nce_weight=0.04, explore_nce_weight=0.04, alpha=0.8, belta=0.8)
+        p64 = {k: v.double().requires_grad_(True) for k, v in p.items()}
+        b64 = {k: (v.double() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        od = orc.forward_losses(p64, b64, cfg, (r0, r1))
+        od["loss"].backward()
+        for k in ("inher_trip", "inher_nce", "explore_trip", "explore_nce", "kl_intra"):
+            close(od[k], torch.as_tensor(d[k]).reshape(()), 2e-5, f"{tag} {k}")
+            out[f"{tag}_{k}"] = torch.as_tensor(d[k]).detach().reshape(()).numpy()
+        close(od["loss"], loss, 2e-5, f"{tag} loss")
+        out[f"{tag}_loss"] = loss.detach().numpy()
+        out[f"{tag}_lens"] = lens.numpy()
+        for i, r in enumerate((r0, r1)):
+            if r[0] is not None:
+                out[f"{tag}_r{i}_v2t"] = r[0].numpy()
+            out[f"{tag}_r{i}_t2v"] = r[1].numpy()
+        worst = 0.0
+        gmax = max(q.grad.abs().max().item() for q in m.parameters())
+        for name, prm in m.named_parameters():
+            g = prm.grad.detach().reshape(-1)
+            og = p64[name].grad.reshape(-1)
+            e = (og - g.double()).abs().max().item() / max(g.abs().max().item(), 1e-6 * gmax)
+            worst = max(worst, e)
+            idx = sample_idx(g.numel())
+            out[f"{tag}_grad/{name}/norm"] = np.float64(g.double().norm().item())
+            out[f"{tag}_grad/{name}/sum"] = np.float64(g.double().sum().item())
+            out[f"{tag}_grad/{name}/sample"] = g[idx].numpy()
+        assert worst < 5e-4, f"{tag}: oracle fp64 grads vs reference fp32 grads rel err {worst}"
+        print(f"  g4t {tag}: loss {float(loss):.6f}  videos with <= 32 clips {int((lens <= 32).sum())}/{nv}  "
+              f"worst grad rel err (oracle fp64 vs ref fp32) {worst:.2e}")
+    np.savez(os.path.join(HERE, "g4t_forward_train.npz"), **out)
+
+
 def g5_eval_epoch():
     dv, dq = 3072, 768
     p = synth.make_params(51, dv, dq)
@@ -289,7 +344,9 @@ def g7_ingest():
 if __name__ == "__main__":
     import warnings
     warnings.filterwarnings("ignore")
-    for fn in (g1_simpool, g2_encoders, g3_losses, g4_forward, g5_eval_epoch, g6_bert_adam, g7_ingest):
+    fns = (g1_simpool, g2_encoders, g3_losses, g4_forward, g4t_forward_train_mode, g5_eval_epoch, g6_bert_adam, g7_ingest)
+    only = set(sys.argv[1:])
+    for fn in [f for f in fns if not only or f.__name__ in only]:
         print(fn.__name__)
         fn()
     print("golden vectors written to", HERE)

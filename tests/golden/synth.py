@@ -96,6 +96,23 @@ def make_train_batch(seed, nv=64, caps=1, L=16, len_lo=4, dv=3072, dq=768, lq_lo
                 text_labels=labels)
 
 
+# golden G4t (the reference's forward + backward in model.train() with dropout 0, padded to L = 64 with 3..64 valid clips):
+# (tag, hard negatives, captions per video, videos, seed)
+G4T_CASES = (("t_hard", True, "mixed", 48, 51), ("t_rand", False, 2, 40, 52))
+
+
+def g4t_caps(caps, nv):
+    """Captions per video, sorted descending like collate_train (data_provider.py:116-117)."""
+    if caps != "mixed":
+        return caps
+    return sorted([3] * (nv // 8) + [2] * (nv // 2) + [1] * (nv - nv // 8 - nv // 2), reverse=True)
+
+
+def g4t_batch(tag, dtype=torch.float32):
+    _, hard, caps, nv, seed = next(c for c in G4T_CASES if c[0] == tag)
+    return make_train_batch(seed, nv=nv, caps=g4t_caps(caps, nv), L=64, len_lo=3, dv=3072, dq=768, dtype=dtype), hard, nv, seed
+
+
 def make_eval_sets(seed, nv=64, caps=3, len_lo=4, len_hi=16, dv=3072, dq=768, lq_lo=5, lq_hi=30):
     """In-memory stand-ins for VisDataSet4DLDKD / TxtDataSet4DLDKD (data_provider.py:307-309,
     :344-354): lists of (feat (len,D) float32, index, id)."""

@@ -117,6 +117,36 @@ def test_g4_forward_and_grads(golden_dir, tag, label_style, hard, caps):
         assert abs(float(gr.norm()) - float(g[f"{tag}_grad/{n}/norm"])) <= 5e-4 * max(float(g[f"{tag}_grad/{n}/norm"]), 1e-6 * nmax), n
 
 
+@pytest.mark.parametrize("tag", [c[0] for c in synth.G4T_CASES])
+def test_g4t_train_mode_forward_and_grads(golden_dir, tag):
+    """The reference's step in model.train() with dropout 0 (golden G4t): the oracle has no train / eval switch - with p = 0 the
+    reference's nn.Dropout is the identity - so this pins that the train-mode reference IS the function the oracle restates."""
+    g = np.load(os.path.join(golden_dir, "g4t_forward_train.npz"))
+    batch, hard, nv, seed = synth.g4t_batch(tag, dtype=torch.float64)
+    p = {k: v.double().requires_grad_(True) for k, v in synth.make_params(seed, 3072, 768).items()}
+    assert (batch["student_videos_mask"].sum(1).long().numpy() == g[f"{tag}_lens"]).all()
+    rnd = []
+    for i in range(2):
+        v2t = torch.from_numpy(g[f"{tag}_r{i}_v2t"]) if not hard else None
+        rnd.append((v2t, torch.from_numpy(g[f"{tag}_r{i}_t2v"])))
+    cfg = dict(n_heads=4, margin=0.1, use_hard_negative=hard, label_style="soft", kl_intra_weight=0.1,
+               weight=0.95 ** 3, inher_nce_weight=0.04, explore_nce_weight=0.04, alpha=0.8, belta=0.8)
+    d = orc.forward_losses(p, batch, cfg, rnd)
+    for k in ("inher_trip", "inher_nce", "explore_trip", "explore_nce", "kl_intra", "loss"):
+        ref = float(g[f"{tag}_{k}"].reshape(()))
+        assert abs(float(d[k]) - ref) <= 2e-5 * max(1.0, abs(ref)), (k, float(d[k]), ref)
+    d["loss"].backward()
+    gmax = max(float(np.abs(g[f"{tag}_grad/{n}/sample"]).max()) for n in p)
+    nmax = max(float(g[f"{tag}_grad/{n}/norm"]) for n in p)
+    for n, t in p.items():
+        gr = t.grad.reshape(-1)
+        idx = np.unique(np.linspace(0, gr.numel() - 1, min(48, gr.numel())).astype(np.int64))
+        ref = g[f"{tag}_grad/{n}/sample"].astype(np.float64)
+        scale = max(np.abs(ref).max(), 1e-6 * gmax)
+        assert np.abs(gr[idx].numpy() - ref).max() <= 5e-4 * scale, n
+        assert abs(float(gr.norm()) - float(g[f"{tag}_grad/{n}/norm"])) <= 5e-4 * max(float(g[f"{tag}_grad/{n}/norm"]), 1e-6 * nmax), n
+
+
 def test_g5_eval_metrics(golden_dir):
     g = np.load(os.path.join(golden_dir, "g5_eval_epoch.npz"))
     m = orc.eval_metrics(g["inh"], g["exp"], list(g["video_metas"]), list(g["query_metas"]))
