@@ -471,6 +471,92 @@ def run_sharded(cfg, dev, rank, world, dist, steps, warmup):
     return res
 
 
+def c5_rank_batch(rank, device="cpu"):
+    """One rank's Charades-STA batch (BASELINE configs[4]; /root/reference/do_charades.sh:6-14): 128 videos, captions per video
+    [3, 2, 2, ...] = 257 queries, 8..64 clips, 1024-d student features, seed 5 + rank (every rank draws its own batch)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import synth
+    caps = sorted([3] + [2] * 127, reverse=True)
+    b = synth.make_train_batch(5 + rank, nv=128, caps=caps, L=64, len_lo=8, dv=1024, dq=1024)
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()}
+
+
+def replicas_max_abs_diff(flat, dist, group=None):
+    """max over ranks and elements of |this rank's parameters - rank 0's|: 0.0 iff the replicas are identical (all-reduce MAX, so
+    every rank returns the same number).  Works on CPU tensors over gloo (tests) and on GPU tensors over RCCL."""
+    ref = flat.detach().clone()
+    dist.broadcast(ref, src=0, group=group)
+    d = (flat.detach() - ref).abs().max().reshape(1).to(torch.float64)
+    dist.all_reduce(d, op=dist.ReduceOp.MAX, group=group)
+    return float(d.item())
+
+
+def run_c5_ddp(dev, rank, world, dist, steps, warmup):
+    """BASELINE configs[4]: the Charades-STA training step, data parallel over the ranks (method/train.py:147-151 under DDP): every
+    rank steps on ITS batch, the flat gradient buffer is mean-all-reduced over RCCL, the fused BertAdam update follows - replayed by
+    train.GraphedTrainStep exactly as train() runs it.  Measured per gradient layout (one bucket = the default; tower buckets =
+    opt.ddp_bucketed_overlap): step ms (max over ranks), the same step with the collective taken out (the rank-local replay), their
+    difference = the exposed all-reduce time; self-check: after the timed steps the replicas' parameters are bit-identical."""
+    import types
+    from dldkd_amd import ops
+    from dldkd_amd import train as T
+    from dldkd_amd.model import DLDKD
+    cfg = types.SimpleNamespace(visual_input_size=1024, query_input_size=1024, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=128, max_desc_l=30, input_drop=0.15, drop=0.15, n_heads=4, initializer_range=0.02,
+                                margin=0.2, use_hard_negative=True, hard_pool_size=20, label_style="soft")
+    mopt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                 collection="charades", alpha=0.8, belta=0.8)
+    batch = c5_rank_batch(rank, dev)
+    res = {"workload": "Charades-STA training step (128 videos / 257 queries per rank, 1024-d, dropout 0.15), DDP over RCCL, bf16 GEMMs",
+           "n_gpus": world, "grad_bytes": None}
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(stepper):
+        for _ in range(warmup):
+            stepper(batch)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stepper(batch)
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item() / steps * 1e3
+
+    ops.set_gemm_precision("bf16")
+    old_min = T.DDP_MIN_WORLD
+    try:
+        for name, bucketed in (("single_bucket", False), ("tower_buckets", True)):
+            topt = types.SimpleNamespace(grad_clip=-1, lr=2.4e-4, wd=0.01, lr_warmup_proportion=0.01, n_epoch=100,
+                                         ddp_bucketed_overlap=bucketed, seed=0)
+            torch.manual_seed(0)                            # same initial weights on every rank; rank 0's are broadcast anyway
+            m = DLDKD(cfg, mopt).to(dev).train()
+            T.DDP_MIN_WORLD = min(old_min, max(world, 1))   # the one-rank test hook drives the data-parallel branch too
+            optim = T.make_optimizer(m, topt, 1000)
+            from dldkd_amd import dist as ddist
+            ddist.broadcast_parameters(optim.fp)
+            T.seed_rank(topt, rank)                         # dropout masks / triplet negatives differ between the replicas
+            ddp_ms = timed(T.GraphedTrainStep(m, optim, topt, defer_loss_float=True))
+            diff = replicas_max_abs_diff(optim.fp.flat, dist)
+            # the same replayed step without the collective (the data-parallel branch switched off): what the all-reduce costs on top
+            T.DDP_MIN_WORLD = world + 1
+            local_ms = timed(T.GraphedTrainStep(m, optim, topt, defer_loss_float=True))
+            res[name] = {"step_ms": ddp_ms, "step_ms_without_allreduce": local_ms, "exposed_allreduce_ms": ddp_ms - local_ms,
+                         "replicas_max_abs_param_diff_after_timed_steps": diff, "replicas_identical": diff == 0.0,
+                         "n_buckets": len(optim.fp.bucket_ranges)}
+            res["grad_bytes"] = int(optim.fp.grad.numel() * 4)
+            del m, optim
+            torch.cuda.empty_cache()
+    finally:
+        T.DDP_MIN_WORLD = old_min
+        ops.set_gemm_precision("fp32")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -515,6 +601,7 @@ def main():
         # ---- N ranks (or the one-rank test hook): the sharded step, self-verified, then the C4 workload the same way
         r2 = run_sharded(C2, dev, rank, world, dist, a.steps, a.warmup)
         r4 = run_sharded(C4, dev, rank, world, dist, max(min(a.steps, 20), 1), max(min(a.warmup, 3), 1)) if not a.no_extras else None
+        r5 = run_c5_ddp(dev, rank, world, dist, max(min(a.steps, 20), 2), max(min(a.warmup, 5), 3)) if not a.no_extras else None
         if rank == 0:
             achieved = r2["flops_per_step_all_ranks"] / (r2["ms_per_step"] * 1e-3) / 1e12
             out = {
@@ -548,7 +635,8 @@ def main():
                     "algorithmic_TFLOPs_all_ranks": r4["flops_per_step_all_ranks"] / (r4["ms_per_step"] * 1e-3) / 1e12,
                     "recall_hip": r4["recall_hip"], "assembled_max_abs_diff": r4["assembled_max_abs_diff"],
                     "assembled_check": r4["assembled_check"], "recall_expected_n1": RECALL_C4_N1,
-                    "recall_matches_n1": r4["recall_hip"] == RECALL_C4_N1}}
+                    "recall_matches_n1": r4["recall_hip"] == RECALL_C4_N1},
+                    "c5_ddp": r5}
         dist.barrier()
         dist.destroy_process_group()
     else:

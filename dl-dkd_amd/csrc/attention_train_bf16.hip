@@ -31,11 +31,13 @@ constexpr int kPitchB = 208;                    // bytes per image row (96 bf16 
 constexpr float kScale = 0.10206207261596577f;  // 1/sqrt(96), model_components.py:419
 
 struct Args {
-    const float* qkv;      // (N, L, 1152)
+    const float* qkv;      // (N, L, 1152)   (IO16 kernels: bf16, as every tensor below but the mask)
     const float* mask;     // (N, L) or null
     float* out;            // forward: context (N, L, 384)
     const float* dout;     // backward: gradient of the context
     float* dqkv;           // backward: (N, L, 1152)
+    const int* lens;       // IO16 kernels: valid rows per sequence or null (= L): rows past it are never read (the fused training
+                           // towers do not write the rows of all-padding 32-row groups) and enter as zero rows
     int N, L, n_items;     // n_items = N * 4
     unsigned thresh;
     float dscale;
@@ -110,6 +112,29 @@ __device__ __forceinline__ void fill_images(char* const (&img)[NIMG], const floa
     }
 }
 
+// the same for tensors that are bf16 in memory (the fused training towers, tower_train.hip): 16-byte pieces, LP * 12 / nthr = 6 per
+// thread and image; rows >= Lv (the sequence's valid rows) are zero rows and are not read
+template <int NIMG>
+__device__ __forceinline__ void fill_images16(char* const (&img)[NIMG], const unsigned short* const (&src)[NIMG], const int (&ld)[NIMG],
+                                              int Lv, int t, int nthr) {
+    bf16x8 v[NIMG][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int i = t + j * nthr, row = i / 12, c = i - row * 12;
+#pragma unroll
+        for (int m = 0; m < NIMG; ++m) {
+            v[m][j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (row < Lv) v[m][j] = *reinterpret_cast<const bf16x8*>(src[m] + (size_t)row * ld[m] + c * 8);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int i = t + j * nthr, row = i / 12, c = i - row * 12;
+#pragma unroll
+        for (int m = 0; m < NIMG; ++m) *reinterpret_cast<bf16x8*>(img[m] + row * kPitchB + c * 16) = v[m][j];
+    }
+}
+
 __device__ __forceinline__ bf16x8 frag(const char* img, int row, int ks, int h) {
     return *reinterpret_cast<const bf16x8*>(img + row * kPitchB + (16 * ks + 8 * h) * 2);
 }
@@ -142,6 +167,18 @@ __device__ __forceinline__ void store_rows_t(float* dst_row, const f32x16 (&o)[3
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = o[dt][r4 * 4 + e];
             *reinterpret_cast<f32x4*>(dst_row + dt * 32 + 8 * r4 + 4 * h) = v;
+        }
+}
+
+__device__ __forceinline__ void store_rows_t16(unsigned short* dst_row, const f32x16 (&o)[3], int h) {
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16_bits(o[dt][r4 * 4]) | ((unsigned)f32_to_bf16_bits(o[dt][r4 * 4 + 1]) << 16);
+            pk.y = (unsigned)f32_to_bf16_bits(o[dt][r4 * 4 + 2]) | ((unsigned)f32_to_bf16_bits(o[dt][r4 * 4 + 3]) << 16);
+            *reinterpret_cast<uint2*>(dst_row + dt * 32 + 8 * r4 + 4 * h) = pk;
         }
 }
 
@@ -212,7 +249,7 @@ __device__ __forceinline__ void scores_a(const char* Qi, const char* Ki, const f
 }
 
 // ---------------------------------------------------------------------------------------------------------------- forward
-template <int NKT>
+template <int NKT, bool IO16 = false>
 __device__ __forceinline__ void fwd_body(const Args& p, char* smem) {
     constexpr int LP = NKT * 32;
     constexpr int kImg = LP * kPitchB;
@@ -223,8 +260,15 @@ __device__ __forceinline__ void fwd_body(const Args& p, char* smem) {
     char* Ki = Qi + kImg;
     char* Vi = Ki + kImg;
     float* Ms = reinterpret_cast<float*>(Vi + kImg);
-    const float* base = p.qkv + (size_t)it.n * L * (3 * kHidden) + it.head * kDh;
-    {
+    const int Lv = (IO16 && p.lens != nullptr) ? min(p.lens[it.n], L) : L;
+    if constexpr (IO16) {
+        const unsigned short* base = reinterpret_cast<const unsigned short*>(p.qkv) + (size_t)it.n * L * (3 * kHidden) + it.head * kDh;
+        char* const imgs[3] = {Qi, Ki, Vi};
+        const unsigned short* const srcs[3] = {base, base + kHidden, base + 2 * kHidden};
+        const int lds_[3] = {3 * kHidden, 3 * kHidden, 3 * kHidden};
+        fill_images16<3>(imgs, srcs, lds_, Lv, it.t, it.nthr);
+    } else {
+        const float* base = p.qkv + (size_t)it.n * L * (3 * kHidden) + it.head * kDh;
         char* const imgs[3] = {Qi, Ki, Vi};
         const float* const srcs[3] = {base, base + kHidden, base + 2 * kHidden};
         const int lds_[3] = {3 * kHidden, 3 * kHidden, 3 * kHidden};
@@ -234,7 +278,7 @@ __device__ __forceinline__ void fwd_body(const Args& p, char* smem) {
         Ms[i] = i < L ? (p.mask ? (1.f - p.mask[(size_t)it.n * L + i]) * -10000.f : 0.f) : -INFINITY;
     __syncthreads();
     const int q0 = it.wave_in_item * 32;
-    if (!it.active || q0 >= L) return;
+    if (!it.active || q0 >= Lv) return;           // (IO16: the rows of a query tile past the sequence are not written)
     unsigned long long seed = p.seed, off = p.offset;
     if (p.state != nullptr) { seed = p.state[0]; off += p.state[1]; }
 
@@ -266,17 +310,21 @@ __device__ __forceinline__ void fwd_body(const Args& p, char* smem) {
             for (int dt = 0; dt < 3; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather(Vi, kt * 32, ks, h, dt * 32 + r32), b, o[dt], 0, 0, 0);
         }
-    if (q < L) store_rows_t(p.out + ((size_t)it.n * L + q) * kHidden + it.head * kDh, o, h);
+    if constexpr (IO16) {
+        if (q < L) store_rows_t16(reinterpret_cast<unsigned short*>(p.out) + ((size_t)it.n * L + q) * kHidden + it.head * kDh, o, h);
+    } else {
+        if (q < L) store_rows_t(p.out + ((size_t)it.n * L + q) * kHidden + it.head * kDh, o, h);
+    }
 }
 
-template <int NKT>
+template <int NKT, bool IO16 = false>
 __global__ __launch_bounds__(NKT == 1 ? 256 : 64 * NKT) void attn_bf16_fwd_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
-    fwd_body<NKT>(p, smem_c);
+    fwd_body<NKT, IO16>(p, smem_c);
 }
 
 // --------------------------------------------------------------------------------------------------------------- backward
-template <int NKT>
+template <int NKT, bool IO16 = false>
 __device__ __forceinline__ void bwd_body(const Args& p, char* smem) {
     constexpr int LP = NKT * 32;
     constexpr int kImg = LP * kPitchB;
@@ -292,8 +340,16 @@ __device__ __forceinline__ void bwd_body(const Args& p, char* smem) {
     float* Iv = Mx + LP;
     float* Dl = Iv + LP;
     unsigned* Kb = reinterpret_cast<unsigned*>(Dl + LP);           // [LP queries][NKT key tiles]: keep bit of key 32 kt + b
-    const float* base = p.qkv + (size_t)it.n * L * (3 * kHidden) + it.head * kDh;
-    {
+    const int Lv = (IO16 && p.lens != nullptr) ? min(p.lens[it.n], L) : L;
+    if constexpr (IO16) {
+        const unsigned short* base = reinterpret_cast<const unsigned short*>(p.qkv) + (size_t)it.n * L * (3 * kHidden) + it.head * kDh;
+        char* const imgs[4] = {Qi, Ki, Vi, Gi};
+        const unsigned short* const srcs[4] = {base, base + kHidden, base + 2 * kHidden,
+                                               reinterpret_cast<const unsigned short*>(p.dout) + (size_t)it.n * L * kHidden + it.head * kDh};
+        const int lds_[4] = {3 * kHidden, 3 * kHidden, 3 * kHidden, kHidden};
+        fill_images16<4>(imgs, srcs, lds_, Lv, it.t, it.nthr);
+    } else {
+        const float* base = p.qkv + (size_t)it.n * L * (3 * kHidden) + it.head * kDh;
         char* const imgs[4] = {Qi, Ki, Vi, Gi};
         const float* const srcs[4] = {base, base + kHidden, base + 2 * kHidden, p.dout + (size_t)it.n * L * kHidden + it.head * kDh};
         const int lds_[4] = {3 * kHidden, 3 * kHidden, 3 * kHidden, kHidden};
@@ -303,10 +359,14 @@ __device__ __forceinline__ void bwd_body(const Args& p, char* smem) {
         Ms[i] = i < L ? (p.mask ? (1.f - p.mask[(size_t)it.n * L + i]) * -10000.f : 0.f) : -INFINITY;
     __syncthreads();
     const int t0 = it.wave_in_item * 32;          // this wave's query tile (phase 1) and key tile (phase 2)
-    const bool work = it.active && t0 < L;
+    // IO16: tiles past the sequence do nothing - their dO rows are zero rows (dQ = dK = dV = 0 there) and the rows of dqkv they
+    // would write are never read (tower_train.hip visits the same row groups)
+    const bool work = it.active && t0 < Lv;
     unsigned long long seed = p.seed, off = p.offset;
     if (p.state != nullptr) { seed = p.state[0]; off += p.state[1]; }
     float* drow_base = p.dqkv + (size_t)it.n * L * (3 * kHidden) + it.head * kDh;
+    unsigned short* drow_base16 = reinterpret_cast<unsigned short*>(p.dqkv) + (size_t)it.n * L * (3 * kHidden) + it.head * kDh;
+    (void)drow_base; (void)drow_base16;
 
     // ---- phase 1: orientation A, queries t0.. on lanes
     if (work) {
@@ -366,7 +426,8 @@ __device__ __forceinline__ void bwd_body(const Args& p, char* smem) {
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather(Ki, kt * 32, ks, h, dt * 32 + r32), b, o[dt], 0, 0, 0);
             }
         }
-        if (q < L) store_rows_t(drow_base + (size_t)q * (3 * kHidden), o, h);
+        if constexpr (IO16) { if (q < L) store_rows_t16(drow_base16 + (size_t)q * (3 * kHidden), o, h); }
+        else { if (q < L) store_rows_t(drow_base + (size_t)q * (3 * kHidden), o, h); }
     }
     __syncthreads();
     if (!work) return;
@@ -379,7 +440,7 @@ __device__ __forceinline__ void bwd_body(const Args& p, char* smem) {
     for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-    const int nqt = (L + 31) >> 5;
+    const int nqt = (Lv + 31) >> 5;               // (query tiles past the sequence: dO = 0 there, they add nothing)
     for (int qt = 0; qt < nqt; ++qt) {
         f32x16 s, dp;
 #pragma unroll
@@ -417,19 +478,25 @@ __device__ __forceinline__ void bwd_body(const Args& p, char* smem) {
         }
     }
     if (key < L) {
-        float* krow = drow_base + (size_t)key * (3 * kHidden) + kHidden;
-        store_rows_t(krow, dk, h);
-        store_rows_t(krow + kHidden, dv, h);
+        if constexpr (IO16) {
+            unsigned short* krow = drow_base16 + (size_t)key * (3 * kHidden) + kHidden;
+            store_rows_t16(krow, dk, h);
+            store_rows_t16(krow + kHidden, dv, h);
+        } else {
+            float* krow = drow_base + (size_t)key * (3 * kHidden) + kHidden;
+            store_rows_t(krow, dk, h);
+            store_rows_t(krow + kHidden, dv, h);
+        }
     }
 }
 
-template <int NKT>
+template <int NKT, bool IO16 = false>
 __global__ __launch_bounds__(NKT == 1 ? 256 : 64 * NKT) void attn_bf16_bwd_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
-    bwd_body<NKT>(p, smem_c);
+    bwd_body<NKT, IO16>(p, smem_c);
 }
 
-template <int NKT>
+template <int NKT, bool IO16 = false>
 static int launch(const Args& a, bool backward, hipStream_t s) {
     constexpr int LP = NKT * 32, kImg = LP * kPitchB;
     constexpr int per_item = (NKT == 1 ? 4 : 1);
@@ -437,13 +504,13 @@ static int launch(const Args& a, bool backward, hipStream_t s) {
     constexpr int lds_b = per_item * (4 * kImg + LP * 4 * 4 + LP * NKT * 4);
     const dim3 grid((a.n_items + per_item - 1) / per_item), block(NKT == 1 ? 256 : 64 * NKT);
     static const bool ok = [] {
-        bool r = hipFuncSetAttribute((const void*)attn_bf16_fwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f) == hipSuccess;
-        r &= hipFuncSetAttribute((const void*)attn_bf16_bwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b) == hipSuccess;
+        bool r = hipFuncSetAttribute((const void*)attn_bf16_fwd_kernel<NKT, IO16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f) == hipSuccess;
+        r &= hipFuncSetAttribute((const void*)attn_bf16_bwd_kernel<NKT, IO16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b) == hipSuccess;
         return r;
     }();
     (void)ok;
-    if (backward) { DLDKD_LAUNCH(attn_bf16_bwd_kernel<NKT>, grid, block, lds_b, s, a); }
-    else { DLDKD_LAUNCH(attn_bf16_fwd_kernel<NKT>, grid, block, lds_f, s, a); }
+    if (backward) { DLDKD_LAUNCH((attn_bf16_bwd_kernel<NKT, IO16>), grid, block, lds_b, s, a); }
+    else { DLDKD_LAUNCH((attn_bf16_fwd_kernel<NKT, IO16>), grid, block, lds_f, s, a); }
     return DLDKD_OK;
 }
 
@@ -466,13 +533,14 @@ static int fill_args(Args& a, int N, int L, float p_drop, unsigned long long see
     return DLDKD_OK;
 }
 
+template <bool IO16 = false>
 static int dispatch(const Args& a, bool backward, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     switch ((a.L + 31) >> 5) {
-        case 1: launch<1>(a, backward, s); break;
-        case 2: launch<2>(a, backward, s); break;
-        case 3: launch<3>(a, backward, s); break;
-        default: launch<4>(a, backward, s); break;
+        case 1: launch<1, IO16>(a, backward, s); break;
+        case 2: launch<2, IO16>(a, backward, s); break;
+        case 3: launch<3, IO16>(a, backward, s); break;
+        default: launch<4, IO16>(a, backward, s); break;
     }
     return check_launch(backward ? "attention_train_bwd_bf16" : "attention_train_fwd_bf16");
 }
@@ -493,7 +561,7 @@ int dldkd_attention_train_fwd_bf16(const float* qkv, const float* mask, float* o
     if (N == 0) return DLDKD_OK;
     if (!qkv || !out) { set_error("attention_train_fwd_bf16: null pointer"); return DLDKD_EINVAL; }
     a.qkv = qkv; a.mask = mask; a.out = out;
-    return atb::dispatch(a, false, stream);
+    return atb::dispatch<false>(a, false, stream);
 }
 
 int dldkd_attention_train_bwd_bf16(const float* qkv, const float* mask, const float* dout, float* dqkv, int N, int L, float p_drop,
@@ -505,7 +573,36 @@ int dldkd_attention_train_bwd_bf16(const float* qkv, const float* mask, const fl
     if (N == 0) return DLDKD_OK;
     if (!qkv || !dout || !dqkv) { set_error("attention_train_bwd_bf16: null pointer"); return DLDKD_EINVAL; }
     a.qkv = qkv; a.mask = mask; a.dout = dout; a.dqkv = dqkv;
-    return atb::dispatch(a, true, stream);
+    return atb::dispatch<false>(a, true, stream);
+}
+
+// The same kernels with every tensor but the mask stored as bf16 (the fused training towers, tower_train.hip) and the sequences'
+// valid lengths: rows past lens[n] are not read (they enter as zero rows) and the query / key tiles past it are skipped.
+int dldkd_attention_train_fwd_bf16io(const void* qkv, const float* mask, const int* lens, void* out, int N, int L, float p_drop,
+                                     unsigned long long seed, unsigned long long offset, const unsigned long long* state,
+                                     void* stream) {
+    atb::Args a{};
+    const int rc = atb::fill_args(a, N, L, p_drop, seed, offset, state, "attention_train_fwd_bf16io");
+    if (rc != DLDKD_OK) return rc;
+    if (N == 0) return DLDKD_OK;
+    if (!qkv || !out || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) { set_error("attention_train_fwd_bf16io: null or unaligned pointer"); return DLDKD_EINVAL; }
+    a.qkv = (const float*)qkv; a.mask = mask; a.lens = lens; a.out = (float*)out;
+    return atb::dispatch<true>(a, false, stream);
+}
+
+int dldkd_attention_train_bwd_bf16io(const void* qkv, const float* mask, const int* lens, const void* dout, void* dqkv, int N, int L,
+                                     float p_drop, unsigned long long seed, unsigned long long offset,
+                                     const unsigned long long* state, void* stream) {
+    atb::Args a{};
+    const int rc = atb::fill_args(a, N, L, p_drop, seed, offset, state, "attention_train_bwd_bf16io");
+    if (rc != DLDKD_OK) return rc;
+    if (N == 0) return DLDKD_OK;
+    if (!qkv || !dout || !dqkv || ((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 7)) {
+        set_error("attention_train_bwd_bf16io: null or unaligned pointer");
+        return DLDKD_EINVAL;
+    }
+    a.qkv = (const float*)qkv; a.mask = mask; a.lens = lens; a.dout = (const float*)dout; a.dqkv = (float*)dqkv;
+    return atb::dispatch<true>(a, true, stream);
 }
 
 }  // extern "C"

@@ -34,6 +34,9 @@ struct GemmHArgs {
                                    // multiplied; their accumulators stay zero (C rows = act(bias), LayerNorm-gradient terms 0).  null: all
     const unsigned char* kflags;   // per k-tile (32 consecutive k): 0 = every operand row of the tile is padding (exact zeros in one
                                    // operand): the tile is skipped.  null: all tiles.  Used by the dW layout only
+    float* a_colsum;               // k-major A only (the dW layout, A = dY): a_colsum[m] += sum_k A[k, m] over the k-tiles this workgroup
+                                   // visits (atomics; zeroed by the caller) - the bias gradient, taken from the A tiles on their way to
+                                   // LDS by the workgroups of the first column tile.  null: not wanted
 };
 
 // One operand tile: 128 rows x 32 k, 16 floats per thread.
@@ -244,9 +247,27 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
         km1 = __ballot(64 + lane < nk ? p.kflags[kt0 + 64 + lane] != 0 : false);
     }
     auto tile_ok = [&](int kt) { return kt < 64 ? ((km0 >> kt) & 1ull) != 0 : kt < 128 ? ((km1 >> (kt - 64)) & 1ull) != 0 : true; };
+    // bias gradient (a_colsum): every thread sums the A values it stages - k-major loaders own one (fp32) or two (bf16) columns of
+    // A and 16 / 8 consecutive k of every tile
+    float cs0 = 0.f, cs1 = 0.f;
+    const bool want_cs = A_KMAJOR && p.a_colsum != nullptr && bid.x == 0;
+    auto add_cs = [&]() {
+        if constexpr (A_KMAJOR) {
+            if (want_cs) {
+                if constexpr (A16) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { cs0 += ra[i]; cs1 += ra[8 + i]; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NREG_; ++i) cs0 += ra[i];
+                }
+            }
+        }
+    };
     bool cur_ok = tile_ok(0);
     if (cur_ok) {
         load_tiles(kt0 * HBK_);
+        add_cs();
         TileH<A_KMAJOR, A16>::store(lds[0][0], tid, ra, pm);
         TileH<B_KMAJOR, B16>::store(lds[0][1], tid, rb);
     }
@@ -254,7 +275,7 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool nxt_ok = kt + 1 < nk && tile_ok(kt + 1);
-        if (nxt_ok) load_tiles((kt0 + kt + 1) * HBK_);
+        if (nxt_ok) { load_tiles((kt0 + kt + 1) * HBK_); add_cs(); }
         if (cur_ok) {
             const unsigned short* As = lds[cur][0];
             const unsigned short* Bs = lds[cur][1];
@@ -280,6 +301,19 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
         __syncthreads();
         cur_ok = nxt_ok;
     }
+    if constexpr (A_KMAJOR) {
+        if (want_cs) {
+            // (rows past M were clamped to the last row by the fast loader or zeroed by the slow one: only real columns are added)
+            if constexpr (A16) {
+                const int m = m0 + 2 * (tid & 63);
+                if (m < p.M) atomicAdd(p.a_colsum + m, cs0);
+                if (m + 1 < p.M) atomicAdd(p.a_colsum + m + 1, cs1);
+            } else {
+                const int m = m0 + (tid & 127);
+                if (m < p.M) atomicAdd(p.a_colsum + m, cs0);
+            }
+        }
+    }
     // (the k-loop ended with a barrier: every wave is done with the operand tiles, the LDS is free for staging)
     if constexpr (EPI == 1) gemm_pool_tile(acc, p, *pa, bid.z, n0, wm, wn, lane, wave, reinterpret_cast<float*>(lds_raw));
     else if constexpr (EPI == 2) gemm_lngrad_tile(acc, p, *pa, m0, n0, wm, wn, lane, wave, reinterpret_cast<float*>(lds_raw));
@@ -296,6 +330,35 @@ __global__ __launch_bounds__(256) void gemm_bf16_a16_kernel(GemmHArgs p) {
 }
 __global__ __launch_bounds__(256) void gemm_bf16_dw_b16_kernel(GemmHArgs p) {
     gemm_bf16_body<true, true, 0, PoolArgs, false, true>(p, nullptr);
+}
+// both operands bf16 and k-major: the weight gradients of the fused training towers (tower_train.hip: dY and X are saved bf16 rows)
+__global__ __launch_bounds__(256) void gemm_bf16_dw_a16b16_kernel(GemmHArgs p) {
+    gemm_bf16_body<true, true, 0, PoolArgs, true, true>(p, nullptr);
+}
+// The weight gradients of one fused training tower as ONE product (tower_train.hip): the output rows are 384-row blocks [Wo | Wd | Wq |
+// Wk | Wv] (or without Wo), every block with its own operands - A = the gradient of that layer's output (fp32 or bf16 rows, a column
+// range of them), B = that layer's saved input rows (bf16) - and all of them contracted over the same batch rows with the same
+// split-K plan and k-tile filter: one launch + one reduce instead of three of each, and 45 output tiles per k-slice to fill the chip.
+struct DwGroupArgs {
+    GemmHArgs base;              // M = 384 n_blocks, N = 384, K = batch rows, ldb = ldc = 384
+    const void* A[5];
+    const void* B[5];
+    int lda[5], acol[5], a16[5];
+};
+__global__ __launch_bounds__(256) void gemm_bf16_dw_group_kernel(DwGroupArgs g) {
+    GemmHArgs p = g.base;
+    const int blk = xcd_tile_order().y / (kHidden / HBM_);
+    // global output row m = 384 blk + j is column acol + j of this block's A: shift the base pointer instead of the index
+    const long shift = (long)g.acol[blk] - (long)kHidden * blk;
+    p.lda = g.lda[blk];
+    p.B = (const float*)g.B[blk];
+    if (g.a16[blk]) {
+        p.A = (const float*)((const unsigned short*)g.A[blk] + shift);
+        gemm_bf16_body<true, true, 0, PoolArgs, true, true>(p, nullptr);
+    } else {
+        p.A = (const float*)g.A[blk] + shift;
+        gemm_bf16_body<true, true, 0, PoolArgs, false, true>(p, nullptr);
+    }
 }
 // training simpool: one video per blockIdx.z, max-pool epilogue (common.hpp, gemm_pool_tile)
 __global__ __launch_bounds__(256) void gemm_bf16_pool_kernel(GemmHArgs p, PoolArgs pa) {
@@ -332,10 +395,12 @@ static int launch_gemm_h_mixed(GemmHArgs p, int batch, int dw, void* stream) {
     static const bool attr_ok = [] {
         bool ok = hipFuncSetAttribute((const void*)gemm_bf16_a16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
         ok &= hipFuncSetAttribute((const void*)gemm_bf16_dw_b16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)gemm_bf16_dw_a16b16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
         return ok;
     }();
     (void)attr_ok;
-    if (dw) DLDKD_LAUNCH(gemm_bf16_dw_b16_kernel, grid, block, lds, (hipStream_t)stream, p);
+    if (dw == 3) DLDKD_LAUNCH(gemm_bf16_dw_a16b16_kernel, grid, block, lds, (hipStream_t)stream, p);
+    else if (dw) DLDKD_LAUNCH(gemm_bf16_dw_b16_kernel, grid, block, lds, (hipStream_t)stream, p);
     else DLDKD_LAUNCH(gemm_bf16_a16_kernel, grid, block, lds, (hipStream_t)stream, p);
     return check_launch("gemm_bf16_mixed");
 }
@@ -437,11 +502,71 @@ extern "C" int dldkd_gemm_bf16(const float* A, const float* B, const float* bias
 //   dw != 0  dW:       C[M, N] = sum_k A[k, m] B16[k, n]              A fp32 (K, M) = dy, B16 bf16 (K, N) = the saved rows;
 //                      k_flags (one byte per 32 consecutive k, or NULL): 0 = the tile's rows are padding (zero rows) - skipped;
 //   dw == 2  the same with B fp32 (K, N): dldkd_gemm_bf16's dW layout plus the k-tile filter
+//   dw == 3  the same with A bf16 (K, M) too (even lda and M): the fused training towers' weight gradients
 //                                                                     split-K as dldkd_gemm_bf16 (workspace from
 //                                                                     dldkd_gemm_workspace_bytes(DLDKD_GEMM_BF16, M, N, K, 1, 1))
+static int gemm_bf16_mixed_impl(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda,
+                                int ldb, int ldc, int relu, void* workspace, size_t workspace_bytes, const unsigned char* k_flags,
+                                float* a_colsum, void* stream);
+
+extern "C" size_t dldkd_tower_train_dw_workspace_bytes(int n_blocks, long rows) {
+    int per = 0;
+    const int split = gemm_bf16_split_plan(kHidden * n_blocks, kHidden, (int)rows, 1, 1, &per);
+    return split > 1 ? (size_t)split * kHidden * n_blocks * kHidden * sizeof(float) : 0;
+}
+
+extern "C" int dldkd_tower_train_dw(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
+                                    const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
+                                    size_t workspace_bytes, const unsigned char* k_flags, void* stream) {
+    if (n_blocks < 1 || n_blocks > 5 || rows < 0 || rows > 0x7fffffffL || !host_A || !host_lda || !host_acol || !host_a16 || !host_B || !dW) {
+        set_error("tower_train_dw: bad arguments");
+        return DLDKD_EINVAL;
+    }
+    if (rows == 0) return DLDKD_OK;
+    DwGroupArgs g{};
+    const int M = kHidden * n_blocks;
+    for (int b = 0; b < n_blocks; ++b) {
+        if (!host_A[b] || !host_B[b] || host_lda[b] < kHidden || (host_lda[b] & 1) || (host_acol[b] & 1) || host_acol[b] + kHidden > host_lda[b] ||
+            ((uintptr_t)host_A[b] & 3) || ((uintptr_t)host_B[b] & 3)) {
+            set_error("tower_train_dw: block %d: operands need even strides / column offsets, 4-byte alignment, a 384-column range", b);
+            return DLDKD_EINVAL;
+        }
+        g.A[b] = host_A[b]; g.B[b] = host_B[b]; g.lda[b] = host_lda[b]; g.acol[b] = host_acol[b]; g.a16[b] = host_a16[b];
+    }
+    g.base = GemmHArgs{nullptr, nullptr, nullptr, dW, M, kHidden, (int)rows, 0, kHidden, kHidden, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+    g.base.kflags = k_flags;
+    g.base.a_colsum = dbias;
+    int per = 0;
+    const int split = ((uintptr_t)dW & 15) ? 1 : gemm_bf16_split_plan(M, kHidden, (int)rows, 1, 1, &per);
+    const bool use_split = split > 1 && workspace && !((uintptr_t)workspace & 15) && workspace_bytes >= (size_t)split * M * kHidden * sizeof(float);
+    if (use_split) { g.base.split_k = split; g.base.k_tiles_per_split = per; g.base.C = (float*)workspace; }
+    constexpr size_t lds = sizeof(unsigned short) * 2 * 2 * HBM_ * HPITCH;
+    static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_bf16_dw_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    (void)attr_ok;
+    DLDKD_LAUNCH(gemm_bf16_dw_group_kernel, dim3(kHidden / HBN_, M / HBM_, use_split ? split : 1), dim3(256), lds, (hipStream_t)stream, g);
+    int rc = check_launch("tower_train_dw");
+    if (rc != DLDKD_OK || !use_split) return rc;
+    return launch_splitk_reduce((const float*)workspace, dW, split, (long)M * kHidden, (hipStream_t)stream);
+}
+
 extern "C" int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda,
                                      int ldb, int ldc, int relu, void* workspace, size_t workspace_bytes, const unsigned char* k_flags,
                                      void* stream) {
+    return gemm_bf16_mixed_impl(dw, A, B, bias, C, M, N, K, lda, ldb, ldc, relu, workspace, workspace_bytes, k_flags, nullptr, stream);
+}
+
+// The dW layouts (dw = 1: A fp32, dw = 3: A bf16; B bf16) with the bias gradient on the side: a_colsum[m] += sum_k A[k, m] over the
+// k-tiles that are not skipped (zeroed by the caller; fp32 atomics).
+extern "C" int dldkd_gemm_bf16_dw_bias(int dw, const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb,
+                                       void* workspace, size_t workspace_bytes, const unsigned char* k_flags, float* a_colsum,
+                                       void* stream) {
+    if (dw != 1 && dw != 3) { set_error("gemm_bf16_dw_bias: dw must be 1 or 3"); return DLDKD_EINVAL; }
+    return gemm_bf16_mixed_impl(dw, A, B, nullptr, C, M, N, K, lda, ldb, N, 0, workspace, workspace_bytes, k_flags, a_colsum, stream);
+}
+
+static int gemm_bf16_mixed_impl(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda,
+                                int ldb, int ldc, int relu, void* workspace, size_t workspace_bytes, const unsigned char* k_flags,
+                                float* a_colsum, void* stream) {
     if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < N) { set_error("gemm_bf16_mixed: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0 || N == 0) return DLDKD_OK;
     if (!A || !B || !C) { set_error("gemm_bf16_mixed: null pointer"); return DLDKD_EINVAL; }
@@ -469,18 +594,20 @@ extern "C" int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const
         return launch_gemm_h(p, 1, 1, 1, stream);
     }
     if ((ldb & 1) || (N & 1) || N < 2 || ((uintptr_t)B & 3)) { set_error("gemm_bf16_mixed: bf16 k-major B needs even ldb and N"); return DLDKD_EINVAL; }
+    if (dw == 3 && ((lda & 1) || (M & 1) || M < 2 || ((uintptr_t)A & 3))) { set_error("gemm_bf16_mixed: bf16 k-major A needs even lda and M"); return DLDKD_EINVAL; }
     static_assert(HBK_ == 32, "k_flags are per 32 contraction rows");
     GemmHArgs p{(const float*)A, (const float*)B, nullptr, C, M, N, K, lda, ldb, ldc, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
     p.kflags = k_flags;            // (K + 31) / 32 bytes or NULL
+    p.a_colsum = a_colsum;
     int per = 0;
     const int split = (ldc == N && !((uintptr_t)C & 15)) ? gemm_bf16_split_plan(M, N, K, 1, 1, &per) : 1;
     if (split > 1 && workspace && !((uintptr_t)workspace & 15) && workspace_bytes >= (size_t)split * M * N * sizeof(float)) {
         p.k_tiles_per_split = per;
         p.split_k = split;
         p.C = (float*)workspace;
-        const int rc = launch_gemm_h_mixed(p, p.split_k, 1, stream);
+        const int rc = launch_gemm_h_mixed(p, p.split_k, dw == 3 ? 3 : 1, stream);
         if (rc != DLDKD_OK) return rc;
         return launch_splitk_reduce((const float*)workspace, C, p.split_k, (long)M * N, (hipStream_t)stream);
     }
-    return launch_gemm_h_mixed(p, 1, 1, stream);
+    return launch_gemm_h_mixed(p, 1, dw == 3 ? 3 : 1, stream);
 }

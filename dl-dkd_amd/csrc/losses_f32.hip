@@ -13,13 +13,12 @@ namespace dldkd {
 // Sp / St: (Nq, Nv, L) clip scores (student cosine / teacher cosine).  One wave per query, L <= 128.
 // dSp (optional): += g * (softmax(p/temp) - softmax(t/temp)) / temp at [q, label_q, l < len].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kl_frame_kernel(const float* __restrict__ Sp, const float* __restrict__ St,
-                                                       const int32_t* __restrict__ labels, const int32_t* __restrict__ lens,
-                                                       float temp, int nq, int nv, int L, float* __restrict__ out,
-                                                       float* __restrict__ dSp, const float* __restrict__ gp) {
-    const float g = gp ? *gp : 0.f;      // upstream gradient: a device scalar (no host read-back, capturable)
+__device__ __forceinline__ void kl_frame_body(int bid, const float* __restrict__ Sp, const float* __restrict__ St,
+                                              const int32_t* __restrict__ labels, const int32_t* __restrict__ lens,
+                                              float temp, int nq, int nv, int L, float* __restrict__ out,
+                                              float* __restrict__ dSp, float g) {
     const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int q = bid * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
     const int v = labels[q];
     const int n = lens[v];
@@ -56,6 +55,13 @@ __global__ __launch_bounds__(256) void kl_frame_kernel(const float* __restrict__
     kl = wave_sum(kl);
     if (lane == 0 && out) out[q] = kl;
 }
+__global__ __launch_bounds__(256) void kl_frame_kernel(const float* __restrict__ Sp, const float* __restrict__ St,
+                                                       const int32_t* __restrict__ labels, const int32_t* __restrict__ lens,
+                                                       float temp, int nq, int nv, int L, float* __restrict__ out,
+                                                       float* __restrict__ dSp, const float* __restrict__ gp) {
+    // upstream gradient: a device scalar (no host read-back, capturable)
+    kl_frame_body(blockIdx.x, Sp, St, labels, lens, temp, nq, nv, L, out, dSp, gp ? *gp : 0.f);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Symmetric InfoNCE, row pass (text -> video).  One wave per query row.
@@ -65,13 +71,15 @@ __global__ __launch_bounds__(256) void kl_frame_kernel(const float* __restrict__
 //   dS[q,v]  = g*cq[q] * (sum(IQ) * softmax(S[q,:])[v] - IQ[q,v])
 //   dT[q,u]  = g*cq[q] * (1-beta) * smT[u] * (c[u] - sum_v smT[v] c[v]),  c[v] = LSE - S[q,v]   (soft rows)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nce_rows_kernel(const float* __restrict__ S, const float* __restrict__ T,
-                                                       const int32_t* __restrict__ labels, const float* __restrict__ cq,
-                                                       int hardQ, float beta, int nq, int nv, float* __restrict__ terms,
-                                                       float* __restrict__ dS, float* __restrict__ dT, const float* __restrict__ gp) {
-    const float g = gp ? *gp : 0.f;
+// FOLD_T: the soft targets are the scores themselves (exploration branch, model.py:149-150): the gradient through the targets is added
+// to dS instead of written to dT
+template <bool FOLD_T = false>
+__device__ __forceinline__ void nce_rows_body(int bid, const float* __restrict__ S, const float* __restrict__ T,
+                                              const int32_t* __restrict__ labels, const float* __restrict__ cq,
+                                              int hardQ, float beta, int nq, int nv, float* __restrict__ terms,
+                                              float* __restrict__ dS, float* __restrict__ dT, float g) {
     const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int q = bid * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
     const float* s = S + (size_t)q * nv;
     const bool soft = T != nullptr && q >= hardQ;
@@ -105,10 +113,22 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(const float* __restrict__
             const float oh = v == lab ? 1.f : 0.f;
             const float sm = soft ? expf(t[v] - mt) * izt : 0.f;
             const float iq = soft ? fmaxf((1.f - beta) * sm + beta * oh, 0.f) : oh;
-            dS[(size_t)q * nv + v] = g * coef * (sumiq * expf(s[v] - lse) - iq);
-            if (dT) dT[(size_t)q * nv + v] = soft ? g * coef * (1.f - beta) * sm * ((lse - s[v]) - cbar) : 0.f;
+            const float ds = g * coef * (sumiq * expf(s[v] - lse) - iq);
+            const float dt = soft ? g * coef * (1.f - beta) * sm * ((lse - s[v]) - cbar) : 0.f;
+            if constexpr (FOLD_T) {
+                dS[(size_t)q * nv + v] = ds + dt;
+            } else {
+                dS[(size_t)q * nv + v] = ds;
+                if (dT) dT[(size_t)q * nv + v] = dt;
+            }
         }
     }
+}
+__global__ __launch_bounds__(256) void nce_rows_kernel(const float* __restrict__ S, const float* __restrict__ T,
+                                                       const int32_t* __restrict__ labels, const float* __restrict__ cq,
+                                                       int hardQ, float beta, int nq, int nv, float* __restrict__ terms,
+                                                       float* __restrict__ dS, float* __restrict__ dT, const float* __restrict__ gp) {
+    nce_rows_body<false>(blockIdx.x, S, T, labels, cq, hardQ, beta, nq, nv, terms, dS, dT, gp ? *gp : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -125,15 +145,14 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(const float* __restrict__
 // re-reading it in each of the 5-6 passes was 20-36 us of exposed latency per call at the TVR batch (640 x 128).  Same
 // arithmetic in the same order as the memory form (the fallback for longer columns).
 constexpr int kNceMaxQ = 16;
-template <bool REG>
-__global__ __launch_bounds__(256) void nce_cols_kernel(const float* __restrict__ S, const float* __restrict__ T,
-                                                       const int32_t* __restrict__ labels, const float* __restrict__ cv,
-                                                       int hardV, float beta, float eps, int nq, int nv,
-                                                       float* __restrict__ terms, float* __restrict__ dS,
-                                                       float* __restrict__ dT, const float* __restrict__ gp) {
-    const float g = gp ? *gp : 0.f;
+template <bool REG, bool FOLD_T = false>
+__device__ __forceinline__ void nce_cols_body(int bid, const float* __restrict__ S, const float* __restrict__ T,
+                                              const int32_t* __restrict__ labels, const float* __restrict__ cv,
+                                              int hardV, float beta, float eps, int nq, int nv,
+                                              float* __restrict__ terms, float* __restrict__ dS,
+                                              float* __restrict__ dT, float g) {
     const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int v = bid * 4 + (threadIdx.x >> 6);
     if (v >= nv) return;
     const bool soft = T != nullptr && v >= hardV;
     float sreg[REG ? kNceMaxQ : 1], treg[REG ? kNceMaxQ : 1];
@@ -215,7 +234,7 @@ __global__ __launch_bounds__(256) void nce_cols_kernel(const float* __restrict__
     if (lane == 0 && terms) terms[v] = coef * (lse - nom);
     if (dS) {
         float rbar = 0.f;
-        if (soft && dT) {
+        if (soft && (dT || FOLD_T)) {
 #pragma unroll
             for (int i = 0; i < npass; ++i) {
                 const int q = lane + 64 * i;
@@ -240,11 +259,24 @@ __global__ __launch_bounds__(256) void nce_cols_kernel(const float* __restrict__
                 const float iv = soft ? fmaxf((1.f - beta) * sm + beta * oh, 0.f) : oh;
                 const float a = iv + eps;
                 const float w = a > 0.f ? expf(logf(a) + sq - nom) : 0.f;
-                dS[ix] += g * coef * (expf(sq - lse) - w);
-                if (soft && dT) dT[ix] += g * coef * (1.f - beta) * sm * (-(w / a) + rbar);
+                const float ds = g * coef * (expf(sq - lse) - w);
+                if constexpr (FOLD_T) {
+                    dS[ix] += ds + (soft ? g * coef * (1.f - beta) * sm * (-(w / a) + rbar) : 0.f);
+                } else {
+                    dS[ix] += ds;
+                    if (soft && dT) dT[ix] += g * coef * (1.f - beta) * sm * (-(w / a) + rbar);
+                }
             }
         }
     }
+}
+template <bool REG>
+__global__ __launch_bounds__(256) void nce_cols_kernel(const float* __restrict__ S, const float* __restrict__ T,
+                                                       const int32_t* __restrict__ labels, const float* __restrict__ cv,
+                                                       int hardV, float beta, float eps, int nq, int nv,
+                                                       float* __restrict__ terms, float* __restrict__ dS,
+                                                       float* __restrict__ dT, const float* __restrict__ gp) {
+    nce_cols_body<REG, false>(blockIdx.x, S, T, labels, cv, hardV, beta, eps, nq, nv, terms, dS, dT, gp ? *gp : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -253,13 +285,11 @@ __global__ __launch_bounds__(256) void nce_cols_kernel(const float* __restrict__
 // to rank 0 with 999 and indexes the sorted row at r).  Selection by rank counting, no sort.
 // term[q] = max(0, margin + neg - pos) * scale;  dC[q,neg] += g*scale, dC[q,label] -= g*scale when active.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void trip_t2v_kernel(const float* __restrict__ C, const int32_t* __restrict__ labels,
-                                                       const int32_t* __restrict__ rsel, float margin, float scale, int nq,
-                                                       int nv, float* __restrict__ terms, float* __restrict__ dC, const float* __restrict__ gp) {
-    const float g = gp ? *gp : 0.f;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ __forceinline__ void trip_t2v_body(int bid, float* sm, const float* __restrict__ C, const int32_t* __restrict__ labels,
+                                              const int32_t* __restrict__ rsel, float margin, float scale, int nq,
+                                              int nv, float* __restrict__ terms, float* __restrict__ dC, float g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = blockIdx.x * 4 + wave;
+    const int q = bid * 4 + wave;
     float* row = sm + (size_t)wave * nv;
     if (q < nq) for (int v = lane; v < nv; v += 64) row[v] = C[(size_t)q * nv + v];
     __syncthreads();
@@ -301,22 +331,25 @@ __global__ __launch_bounds__(256) void trip_t2v_kernel(const float* __restrict__
         }
     }
 }
+__global__ __launch_bounds__(256) void trip_t2v_kernel(const float* __restrict__ C, const int32_t* __restrict__ labels,
+                                                       const int32_t* __restrict__ rsel, float margin, float scale, int nq,
+                                                       int nv, float* __restrict__ terms, float* __restrict__ dC, const float* __restrict__ gp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    trip_t2v_body(blockIdx.x, sm, C, labels, rsel, margin, scale, nq, nv, terms, dC, gp ? *gp : 0.f);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Triplet, video -> text (model.py:360-369).  One workgroup per video i: positive = mean of C[q in i, i];
 // negative = max (hard) or the rsel[i]-th largest (0-based) of C[q not in i, i].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void trip_v2t_kernel(const float* __restrict__ C, const int32_t* __restrict__ labels,
-                                                       const int32_t* __restrict__ rsel, int hard, float margin, float scale,
-                                                       int nq, int nv, float* __restrict__ terms, float* __restrict__ dC,
-                                                       const float* __restrict__ gp) {
-    const float g = gp ? *gp : 0.f;
-    extern __shared__ float sm[];
+__device__ __forceinline__ void trip_v2t_body(int bid, float* sm, const float* __restrict__ C, const int32_t* __restrict__ labels,
+                                              const int32_t* __restrict__ rsel, int hard, float margin, float scale,
+                                              int nq, int nv, float* __restrict__ terms, float* __restrict__ dC, float g) {
     __shared__ float red_s[4];
     __shared__ int red_i[4];
     __shared__ int sel;
     float* col = sm;
-    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = bid, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int q = tid; q < nq; q += 256) col[q] = C[(size_t)q * nv + i];
     if (tid == 0) sel = -1;
     __syncthreads();
@@ -383,6 +416,90 @@ __global__ __launch_bounds__(256) void trip_v2t_kernel(const float* __restrict__
             if (labels[q] == i) atomicAdd(dC + (size_t)q * nv + i, -g * scale / (float)pcnt);
     }
 }
+__global__ __launch_bounds__(256) void trip_v2t_kernel(const float* __restrict__ C, const int32_t* __restrict__ labels,
+                                                       const int32_t* __restrict__ rsel, int hard, float margin, float scale,
+                                                       int nq, int nv, float* __restrict__ terms, float* __restrict__ dC,
+                                                       const float* __restrict__ gp) {
+    extern __shared__ float sm[];
+    trip_v2t_body(blockIdx.x, sm, C, labels, rsel, hard, margin, scale, nq, nv, terms, dC, gp ? *gp : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One branch's losses (model.py:137-155) with their gradients, three launches instead of ~18 + ATen glue:
+//   A  [triplet t2v | triplet v2t | InfoNCE rows | KL]   independent of each other: one grid, the block index picks the part
+//   B  [InfoNCE columns]                                   adds into the rows' dS
+//   C  the three sums (fixed order), loss weights applied
+// Values AND gradients in the same pass: the loss weights (inher / explore_nce_weight, kl_intra_weight * weight(epoch)) are host
+// scalars of the step, the gradients are written for an upstream gradient of 1 and scaled by the actual one in the backward
+// pass (branch_scale_kernel).
+// ---------------------------------------------------------------------------------------------
+struct BranchArgs {
+    const float* C;              // (nq, nv) pooled cosines
+    const float* S;              // (nq, nv) pooled raw scores
+    const float* T;              // (nq, nv) soft-label scores (teacher) or null: hard labels / T = S (fold_t)
+    const float* clip_p;         // (nq, L) positive-column clip cosines, student; null: no KL term
+    const float* clip_t;         // (nq, L) teacher
+    const int32_t* labels;
+    const int32_t* lens;
+    const int32_t* r_t2v;
+    const int32_t* r_v2t;
+    const float* cq;
+    const float* cv;
+    int nq, nv, L, hard, hardQ, hardV, fold_t;
+    float margin, beta, eps, temp, w_nce, w_kl;
+    float* terms;                // [nq + nv | nq + nv | nq]: triplet, InfoNCE, KL terms
+    float* dC;                   // (nq, nv) zeroed by the caller (atomics)
+    float* dS;                   // (nq, nv) written
+    float* dclip;                // (nq, L) zeroed by the caller
+    float* out;                  // [3]: triplet, w_nce * InfoNCE, w_kl * KL
+};
+
+__global__ __launch_bounds__(256) void branch_loss_a_kernel(const BranchArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int nb_q = (p.nq + 3) / 4;
+    int b = blockIdx.x;
+    if (b < nb_q) { trip_t2v_body(b, sm, p.C, p.labels, p.r_t2v, p.margin, 1.f / p.nq, p.nq, p.nv, p.terms, p.dC, 1.f); return; }
+    b -= nb_q;
+    if (b < p.nv) { trip_v2t_body(b, sm, p.C, p.labels, p.r_v2t, p.hard, p.margin, 1.f / p.nv, p.nq, p.nv, p.terms + p.nq, p.dC, 1.f); return; }
+    b -= p.nv;
+    float* nterms = p.terms + p.nq + p.nv;
+    if (b < nb_q) {
+        if (p.fold_t) nce_rows_body<true>(b, p.S, p.S, p.labels, p.cq, p.hardQ, p.beta, p.nq, p.nv, nterms, p.dS, nullptr, p.w_nce);
+        else nce_rows_body<false>(b, p.S, p.T, p.labels, p.cq, p.hardQ, p.beta, p.nq, p.nv, nterms, p.dS, nullptr, p.w_nce);
+        return;
+    }
+    b -= nb_q;
+    if (p.clip_p != nullptr) kl_frame_body(b, p.clip_p, p.clip_t, p.labels, p.lens, p.temp, p.nq, 0, p.L, p.terms + 2 * (p.nq + p.nv), p.dclip, p.w_kl);
+}
+
+template <bool REG>
+__global__ __launch_bounds__(256) void branch_loss_b_kernel(const BranchArgs p) {
+    float* nterms = p.terms + p.nq + p.nv + p.nq;
+    if (p.fold_t) nce_cols_body<REG, true>(blockIdx.x, p.S, p.S, p.labels, p.cv, p.hardV, p.beta, p.eps, p.nq, p.nv, nterms, p.dS, nullptr, p.w_nce);
+    else nce_cols_body<REG, false>(blockIdx.x, p.S, p.T, p.labels, p.cv, p.hardV, p.beta, p.eps, p.nq, p.nv, nterms, p.dS, nullptr, p.w_nce);
+}
+
+// block k sums segment k of the terms in a fixed order
+__global__ __launch_bounds__(256) void branch_loss_c_kernel(const BranchArgs p) {
+    __shared__ float red[4];
+    const int k = blockIdx.x, n2 = p.nq + p.nv;
+    const float* x = p.terms + (k == 0 ? 0 : k == 1 ? n2 : 2 * n2);
+    const long n = k == 2 ? (p.clip_p != nullptr ? p.nq : 0) : n2;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) p.out[k] = (red[0] + red[1] + red[2] + red[3]) * (k == 0 ? 1.f : k == 1 ? p.w_nce : p.w_kl);
+}
+
+// dC *= g[0], dS *= g[1], dclip *= g[2] (g: the upstream gradients of the three loss terms, device scalars)
+__global__ __launch_bounds__(256) void branch_scale_kernel(float* dC, float* dS, long n, float* dclip, long nk, const float* g0,
+                                                           const float* g1, const float* g2) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { dC[i] *= *g0; dS[i] *= *g1; }
+    if (dclip != nullptr && i < nk) dclip[i] *= *g2;
+}
 
 // out[0] = sum x[0..n)   (single workgroup, deterministic order)
 __global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
@@ -440,6 +557,42 @@ int dldkd_triplet_f32(const float* C, const int32_t* labels, const int32_t* r_t2
     DLDKD_LAUNCH(trip_v2t_kernel, dim3(nv), dim3(256), (size_t)nq * sizeof(float), (hipStream_t)stream, C, labels, r_v2t,
                        hard, margin, 1.f / nv, nq, nv, terms ? terms + nq : nullptr, dC, g);
     return check_launch("triplet");
+}
+
+int dldkd_branch_losses_f32(const float* C, const float* S, const float* T, const float* clip_p, const float* clip_t,
+                            const int32_t* labels, const int32_t* lens, const int32_t* r_t2v, const int32_t* r_v2t, const float* cq,
+                            const float* cv, int nq, int nv, int L, int hard, int hardQ, int hardV, int fold_t, float margin, float beta,
+                            float eps, float temp, float w_nce, float w_kl, float* terms, float* dC, float* dS, float* dclip, float* out,
+                            void* stream) {
+    if (nq < 1 || nv < 1 || (clip_p && (L < 1 || L > 128)) || temp <= 0.f) { set_error("branch_losses: bad sizes"); return DLDKD_EINVAL; }
+    if (!C || !S || !labels || !r_t2v || (!hard && !r_v2t) || !cq || !cv || !terms || !dC || !dS || !out || (clip_p && (!clip_t || !lens || !dclip))) {
+        set_error("branch_losses: null pointer");
+        return DLDKD_EINVAL;
+    }
+    if ((size_t)nv * 4 * sizeof(float) > 64 * 1024 || (size_t)nq * sizeof(float) > 64 * 1024) {
+        set_error("branch_losses: batch too large for the LDS row/column buffers");
+        return DLDKD_EINVAL;
+    }
+    BranchArgs p{C, S, T, clip_p, clip_t, labels, lens, r_t2v, r_v2t, cq, cv, nq, nv, L, hard, hardQ, hardV, fold_t, margin, beta, eps,
+                 temp, w_nce, w_kl, terms, dC, dS, dclip, out};
+    const int nb_q = (nq + 3) / 4;
+    const size_t lds = sizeof(float) * (size_t)((nv * 4 > nq) ? nv * 4 : nq);
+    hipStream_t s = (hipStream_t)stream;
+    DLDKD_LAUNCH(branch_loss_a_kernel, dim3(nb_q + nv + nb_q + (clip_p ? nb_q : 0)), dim3(256), lds, s, p);
+    if (nq <= 64 * kNceMaxQ) DLDKD_LAUNCH(branch_loss_b_kernel<true>, dim3((nv + 3) / 4), dim3(256), 0, s, p);
+    else DLDKD_LAUNCH(branch_loss_b_kernel<false>, dim3((nv + 3) / 4), dim3(256), 0, s, p);
+    DLDKD_LAUNCH(branch_loss_c_kernel, dim3(3), dim3(256), 0, s, p);
+    return check_launch("branch_losses");
+}
+
+int dldkd_branch_losses_scale_f32(float* dC, float* dS, long n, float* dclip, long n_clip, const float* g_trip, const float* g_nce,
+                                  const float* g_kl, void* stream) {
+    if (n < 0 || n_clip < 0 || !dC || !dS || !g_trip || !g_nce || (dclip && !g_kl)) { set_error("branch_losses_scale: bad arguments"); return DLDKD_EINVAL; }
+    const long m = n > n_clip ? n : n_clip;
+    if (m == 0) return DLDKD_OK;
+    DLDKD_LAUNCH(branch_scale_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dC, dS, n, dclip, n_clip,
+                 g_trip, g_nce, g_kl);
+    return check_launch("branch_losses_scale");
 }
 
 int dldkd_sum_f32(const float* x, long n, float* out, void* stream) {

@@ -606,6 +606,13 @@ int dldkd_pack_gallery_bf16(const float* g, const float* mask, int nv, int L, in
     return check_launch("pack_gallery");
 }
 
+int dldkd_mask_lens_f32(const float* mask, int n, int L, int32_t* lens, void* stream) {
+    if (n < 0 || L < 1 || (n > 0 && (!mask || !lens))) { set_error("mask_lens: bad arguments"); return DLDKD_EINVAL; }
+    if (n == 0) return DLDKD_OK;
+    DLDKD_LAUNCH(mask_lens_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, mask, n, L, lens);
+    return check_launch("mask_lens");
+}
+
 int dldkd_pack_gallery_chunk_bf16(const float* g, const float* mask, int nv_chunk, int L_chunk, int normalize,
                                   void* g_packed, int32_t* lens, int v0, int nv_total, int L_total, void* stream) {
     if (nv_chunk < 0 || v0 < 0 || nv_total < 0 || (long)v0 + nv_chunk > nv_total || L_chunk < 1 || L_total < L_chunk ||

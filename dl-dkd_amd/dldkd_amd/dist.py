@@ -109,7 +109,8 @@ def sync_gradients(fp, group=None, comm_stream=None):
     a blocking collective ON the issuing stream and its watchdog thread keeps polling the collective's completion event; if
     the issuing stream later starts a hipGraph capture (train.GraphedTrainStep captures on its own stream) the poll fails
     with hipErrorCapturedEvent and the watchdog takes the process down - so collectives stay off streams that capture."""
-    fp.rebind_grads()
+    had = fp.rebind_grads()
+    check_had_flags(fp, had, group)
     if comm_stream is not None:
         cur = torch.cuda.current_stream(fp.grad.device)
         comm_stream.wait_stream(cur)
@@ -121,6 +122,27 @@ def sync_gradients(fp, group=None, comm_stream=None):
     # The "this parameter had no gradient" flags stay as they are: every rank builds the same autograd graph, so they agree
     # across ranks, and a parameter without a gradient on any rank must be SKIPPED by the optimizer (no weight decay, no moment
     # decay: optimization.py:294-295), exactly as on one GPU.
+
+
+def check_had_flags(fp, had, group=None):
+    """First data-parallel step of an optimizer: every rank must hold a gradient for the SAME parameters.  The optimizer skips a
+    parameter without one (no weight decay, no moment decay: optimization.py:294-295); if the sets differed between ranks one
+    replica would decay a parameter another skips and they would drift apart with no error.  One small all-gather,
+    once per optimizer (and again whenever this rank's set changes); never under a graph capture."""
+    key = tuple(bool(h) for h in had)
+    if getattr(fp, "_had_checked", None) == key:
+        return
+    if fp.grad.is_cuda and torch.cuda.is_current_stream_capturing():
+        return
+    mine = torch.tensor([1.0 if h else 0.0 for h in key], dtype=torch.float32, device=fp.grad.device)
+    lo, hi = mine.clone(), mine.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not torch.equal(lo.cpu(), hi.cpu()):
+        bad = [i for i, (a, b) in enumerate(zip(lo.cpu().tolist(), hi.cpu().tolist())) if a != b]
+        raise RuntimeError(f"data parallel: the ranks disagree on which parameters have a gradient (parameter indices {bad[:8]}...): "
+                           "the replicas would diverge")
+    fp._had_checked = key
 
 
 class BucketedGradSync:
@@ -164,7 +186,7 @@ class BucketedGradSync:
 
     def finish(self):
         """Whatever has not been issued goes now; then the current stream waits for every collective."""
-        self.fp.rebind_grads()
+        check_had_flags(self.fp, self.fp.rebind_grads(), self.group)
         for b in range(len(self.fp.bucket_ranges)):
             self.issue(b)
         if self.comm_stream is not None:

@@ -192,7 +192,7 @@ class _InProjTrain(Function):
     instead of the dX GEMM (201 MB written at the TVR batch) plus a LayerNorm backward pass over x and that gradient."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, weight, bias, p, relu, row_mask=None):
+    def forward(ctx, x, gamma, beta, weight, bias, p, relu, row_mask=None, grad_premasked=False):
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
         M, N = x2.shape[0], weight.shape[0]
@@ -247,8 +247,10 @@ class _InProjTrain(Function):
             y = ops.linear(z, weight, bias, relu=relu)
         global _LAST_GROUP_FLAGS
         _LAST_GROUP_FLAGS = (gflags, M) if gflags is not None else None
-        ctx.save_for_backward(x2, weight, z, y if relu else None, keep, stats, gflags)
-        ctx.relu, ctx.has_bias, ctx.keep_scale, ctx.prec = relu, bias is not None, 1.0 / (1.0 - p), ops.gemm_precision()
+        # grad_premasked: the node behind this one (the fused training tower) hands back a gradient that already carries the ReLU mask
+        # [y > 0] - it reads y anyway - so the backward pass here neither keeps y nor runs relu_bwd over a clone of dy
+        ctx.save_for_backward(x2, weight, z, y if (relu and not grad_premasked) else None, keep, stats, gflags)
+        ctx.relu, ctx.has_bias, ctx.keep_scale, ctx.prec = (relu and not grad_premasked), bias is not None, 1.0 / (1.0 - p), ops.gemm_precision()
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -281,7 +283,7 @@ class _InProjTrain(Function):
             native.check(_L().dldkd_linear_lngrad(ops._PREC_ID[ctx.prec], _p(dy2), _p(w), _p(x2), _p(keep), ctx.keep_scale, _p(stats[0]), _p(stats[1]),
                                                        _p(ws), ws.numel() * 4, _p(dgb[0]), _p(dgb[1]), M, N, K, _p(gflags), _s()), "linear_lngrad")
             dg, dbeta = dgb[0], dgb[1]
-        return None, dg, dbeta, dw, db, None, None, None
+        return None, dg, dbeta, dw, db, None, None, None, None
 
 
 _LAST_GROUP_FLAGS = None
@@ -306,8 +308,9 @@ def in_proj_train_ok(x, weight):
             and x.shape[-1] % 4 == 0 and x.shape[-1] <= 4096 and weight.requires_grad)
 
 
-def in_proj_train(x, gamma, beta, weight, bias, p_drop, training, relu=True, row_mask=None):
-    return _InProjTrain.apply(_f32(x), gamma, beta, weight, bias, float(p_drop) if training else 0.0, bool(relu), row_mask)
+def in_proj_train(x, gamma, beta, weight, bias, p_drop, training, relu=True, row_mask=None, grad_premasked=False):
+    return _InProjTrain.apply(_f32(x), gamma, beta, weight, bias, float(p_drop) if training else 0.0, bool(relu), row_mask,
+                              bool(grad_premasked))
 
 
 # ------------------------------------------------------------------------------------------ dropout
@@ -461,6 +464,140 @@ def attention(qkv, mask, p_drop=0.0, training=False):
             return _AttentionTrainBf16.apply(qkv, mask, float(p_drop) if training else 0.0)
         return _AttentionTrain.apply(qkv, mask, float(p_drop) if training else 0.0)
     return ops.attention(qkv, mask)
+
+
+# ------------------------------------------------------------------------------------------ fused training tower
+TOWER_TRAIN_FUSED = True      # throughput mode, training: everything behind the input projection as 2 + 2 row kernels (tower_train.hip)
+
+
+def tower_train_ok(is_cuda, L):
+    return TOWER_TRAIN_FUSED and ops.gemm_precision() == "bf16" and is_cuda and torch.is_grad_enabled() and 1 <= L <= 128
+
+
+def _bf16(shape, device):
+    return torch.empty(shape, dtype=torch.bfloat16, device=device)
+
+
+def _tt_pack(jobs, device):
+    """jobs = [(sources, mode)] -> the packed weights as views of one buffer; one kernel launch (dldkd_tower_train_pack)."""
+    import ctypes
+    L_ = _L()
+    sizes = [L_.dldkd_tower_train_pack_bytes(len(srcs)) for srcs, _ in jobs]
+    buf = torch.empty(sum(sizes), dtype=torch.uint8, device=device)
+    outs, off = [], 0
+    for sz in sizes:
+        outs.append(buf[off:off + sz])
+        off += sz
+    n = len(jobs)
+    src = (ctypes.c_void_p * (3 * n))()
+    nsrc, mode, out = (ctypes.c_int * n)(), (ctypes.c_int * n)(), (ctypes.c_void_p * n)()
+    for j, (srcs, md) in enumerate(jobs):
+        for c, w in enumerate(srcs):
+            if w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != (HIDDEN, HIDDEN):
+                raise native.NativeError("tower_train: weights must be contiguous fp32 (384, 384)")
+            src[3 * j + c] = w.data_ptr()
+        nsrc[j], mode[j], out[j] = len(srcs), md, outs[j].data_ptr()
+    native.check(L_.dldkd_tower_train_pack(src, nsrc, mode, out, n, _s()), "tower_train_pack")
+    return outs
+
+
+class _TowerTrain(Function):
+    """One encoder tower behind its input projection, training, throughput mode (reference model_components.py:277-284, 398-450 and
+    model.py:219): position LayerNorm + dropout -> q | k | v (one row kernel), attention (bf16 in / out), dense + dropout + residual +
+    LayerNorm [+ out mapping] (one row kernel); the backward pass mirrors it with two row kernels around the attention backward
+    kernel, weight gradients as GEMMs over the saved bf16 rows.  Dropout masks are recomputed from their Philox slots (the slots are
+    drawn in the order of the unfused layers: the masks are the unfused path's, bit for bit)."""
+
+    @staticmethod
+    def forward(ctx, y0, pos, g1, b1, wq, bq, wk, bk, wv, bv, wd, bd, g2, b2, wo, bo, mask, lens, flags, p_in, p_attn, p_hid,
+                relu_mask):
+        N, L, _ = y0.shape
+        M, dev = N * L, y0.device
+        video = wo is not None
+        if flags is None:
+            lens = None          # the attention kernels skip the 32-row tiles past a sequence only where the row kernels skip them too
+        jobs = [([wq, wk, wv], 0), ([wd], 0)] + ([([wo], 1), ([wo], 2)] if video else []) + [([wd], 3), ([wq, wk, wv], 2)]
+        packs = _tt_pack(jobs, dev)
+        if video:
+            pk_qkv, pk_d, pk_o, pk_ot, pk_dt, pk_qkvt = packs
+        else:
+            (pk_qkv, pk_d, pk_dt, pk_qkvt), pk_o, pk_ot = packs, None, None
+        slot = lambda p, n: _philox_slot(dev, n) if p > 0.0 else (0, 0, None)      # noqa: E731
+        sa, sb, sc = slot(p_in, M * HIDDEN), slot(p_attn, N * HEADS * L * L), slot(p_hid, M * HIDDEN)
+        h1d, qkv, ctxl, xh2 = _bf16((M, HIDDEN), dev), _bf16((M, 3 * HIDDEN), dev), _bf16((M, HIDDEN), dev), _bf16((M, HIDDEN), dev)
+        xh1 = _bf16((M, HIDDEN), dev)
+        stats = torch.empty(2, M, dtype=torch.float32, device=dev)
+        rstd2 = torch.empty(M, dtype=torch.float32, device=dev)
+        h2 = _bf16((M, HIDDEN), dev) if video else torch.empty(N, L, HIDDEN, dtype=torch.float32, device=dev)
+        out = torch.empty(N, L, HIDDEN, dtype=torch.float32, device=dev) if video else h2
+        L_ = _L()
+        native.check(L_.dldkd_tower_train_f1(_p(y0), _p(pos), L, _p(g1), _p(b1), ops.LN_EPS, float(p_in), sa[0], sa[1], sa[2], _p(pk_qkv),
+                                             _p(bq), _p(bk), _p(bv), _p(flags), M, _p(h1d), _p(xh1), _p(stats), _p(qkv), _s()), "tower_train_f1")
+        native.check(L_.dldkd_attention_train_fwd_bf16io(_p(qkv), _p(mask), _p(lens), _p(ctxl), N, L, float(p_attn), sb[0], sb[1], sb[2],
+                                                         _s()), "attention_train_fwd_bf16io")
+        native.check(L_.dldkd_tower_train_f3(_p(ctxl), _p(h1d), _p(pk_d), _p(bd), float(p_hid), sc[0], sc[1], sc[2], _p(g2), _p(b2),
+                                             ops.LN_EPS, _p(pk_o), _p(bo), _p(flags), M, _p(xh2), _p(rstd2), _p(h2) if video else None,
+                                             None if video else _p(h2), _p(out) if video else None, _s()), "tower_train_f3")
+        ctx.save_for_backward(xh1, pos, g1, g2, mask, lens, flags, h1d, stats, qkv, ctxl, xh2, rstd2, h2 if video else None,
+                              pk_ot, pk_dt, pk_qkvt)
+        ctx.shape = (N, L)
+        keep = _philox_step.dev if _philox_step is not None else None
+        ctx.cfg = (video, float(p_in), float(p_attn), float(p_hid), sa, sb, sc, bool(relu_mask), keep)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xh1, pos, g1, g2, mask, lens, flags, h1d, stats, qkv, ctxl, xh2, rstd2, h2, pk_ot, pk_dt, pk_qkvt = ctx.saved_tensors
+        video, p_in, p_attn, p_hid, sa, sb, sc, relu_mask, _keep = ctx.cfg
+        N, L = ctx.shape
+        M, dev = N * L, xh1.device
+        dout = _f32(dout)
+        L_ = _L()
+        lnp = _zeros((4, HIDDEN), dev)                           # dgamma2, dbeta2, dgamma1, dbeta1 (atomics)
+        ddo, dctx, dres, dqkv = _bf16((M, HIDDEN), dev), _bf16((M, HIDDEN), dev), _bf16((M, HIDDEN), dev), _bf16((M, 3 * HIDDEN), dev)
+        native.check(L_.dldkd_tower_train_b3(_p(dout), _p(pk_ot), _p(xh2), _p(rstd2), _p(g2), p_hid, sc[0], sc[1], sc[2], _p(pk_dt),
+                                             _p(flags), M, _p(ddo), _p(dctx), _p(dres), _p(lnp[0]), _p(lnp[1]), _s()), "tower_train_b3")
+        native.check(L_.dldkd_attention_train_bwd_bf16io(_p(qkv), _p(mask), _p(lens), _p(dctx), _p(dqkv), N, L, p_attn, sb[0], sb[1],
+                                                         sb[2], _s()), "attention_train_bwd_bf16io")
+        need_pos = ctx.needs_input_grad[1]
+        dy0 = torch.empty(N, L, HIDDEN, dtype=torch.float32, device=dev)
+        dx1 = torch.empty(N, L * HIDDEN, dtype=torch.float32, device=dev) if need_pos else None
+        native.check(L_.dldkd_tower_train_b1(_p(dqkv), _p(dres), _p(pk_qkvt), _p(xh1), _p(stats), _p(g1), p_in, sa[0], sa[1],
+                                             sa[2], _p(flags), M, int(relu_mask), _p(dy0), _p(dx1), _p(lnp[2]), _p(lnp[3]), _s()),
+                     "tower_train_b1")
+
+        # weight + bias gradients: ONE split-K product over the saved bf16 rows, blocks [Wo |] Wd | Wq | Wk | Wv (gemm_bf16.hip)
+        import ctypes
+        blocks = ([(dout, HIDDEN, 0, 0, h2)] if video else []) + [(ddo, HIDDEN, 0, 1, ctxl)] + [(dqkv, 3 * HIDDEN, c * HIDDEN, 1, h1d) for c in range(3)]
+        nb = len(blocks)
+        dW = torch.empty(nb * HIDDEN, HIDDEN, dtype=torch.float32, device=dev)
+        dB = _zeros((nb * HIDDEN,), dev)
+        ws_bytes = L_.dldkd_tower_train_dw_workspace_bytes(nb, M)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+        hA, hB = (ctypes.c_void_p * nb)(), (ctypes.c_void_p * nb)()
+        hl, hc, h16 = (ctypes.c_int * nb)(), (ctypes.c_int * nb)(), (ctypes.c_int * nb)()
+        for i, (a_, lda, col, a16, b_) in enumerate(blocks):
+            hA[i], hB[i], hl[i], hc[i], h16[i] = a_.data_ptr(), b_.data_ptr(), lda, col, a16
+        native.check(L_.dldkd_tower_train_dw(hA, hl, hc, h16, hB, nb, M, _p(dW), _p(dB), _p(ws), ws_bytes, _p(flags), _s()), "tower_train_dw")
+        H = HIDDEN
+        o = 1 if video else 0
+        dwo, dbo = (dW[:H], dB[:H]) if video else (None, None)
+        dwd, dbd = dW[o * H:(o + 1) * H], dB[o * H:(o + 1) * H]
+        dwq, dwk, dwv = (dW[(o + 1 + c) * H:(o + 2 + c) * H] for c in range(3))
+        dbq, dbk, dbv = (dB[(o + 1 + c) * H:(o + 2 + c) * H] for c in range(3))
+        dpos = _colsum(dx1, L * HIDDEN).view(L, HIDDEN) if need_pos else None
+        return (dy0, dpos, lnp[2], lnp[3], dwq, dbq, dwk, dbk, dwv, dbv, dwd, dbd, lnp[0], lnp[1], dwo, dbo,
+                None, None, None, None, None, None, None)
+
+
+def tower_train(y0, pos, g1, b1, qkv_layers, dense, g2, b2, out_linear, mask, lens, flags, p_in, p_attn, p_hid, training, relu_mask=True):
+    """See _TowerTrain.  qkv_layers = (query, key, value) nn.Linear, dense / out_linear nn.Linear (out_linear None: query towers,
+    the result is the LayerNorm output h2).  Dropout rates apply when `training`."""
+    q, k, v = qkv_layers
+    pz = (lambda p: float(p) if training else 0.0)               # noqa: E731
+    wo, bo = (out_linear.weight, out_linear.bias) if out_linear is not None else (None, None)
+    return _TowerTrain.apply(_f32(y0), _f32(pos), g1, b1, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, dense.weight, dense.bias,
+                             g2, b2, wo, bo, _f32(mask), lens, flags, pz(p_in), pz(p_attn), pz(p_hid), bool(relu_mask))
 
 
 # ------------------------------------------------------------------------------------------ modular pooling
@@ -728,6 +865,69 @@ def nce_hard(labels, S):
     cq = _part_coefs(Nq, 0, 0.0, 1.0 / Nq, S.device)
     cv = _part_coefs(Nv, 0, 0.0, 1.0 / Nv, S.device)
     return _NCE.apply(S, None, labels, cq, cv, Nq, Nv, 0.0, 0.0, False)
+
+
+BRANCH_LOSS_FUSED = True      # a branch's triplet + InfoNCE + KL terms and their gradients as three launches (losses_f32.hip)
+
+
+class _BranchLoss(Function):
+    """The loss terms of one branch (model.py:137-155) from its pooled scores, values and gradients in one pass: the gradients are
+    computed with the values (for an upstream gradient of 1) and scaled by the actual upstream gradients in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, C, S, T, clip_p, clip_t, labels, lens, r_t2v, r_v2t, cq, cv, cfg):
+        hard, hardQ, hardV, fold_t, margin, beta, eps, temp, w_nce, w_kl = cfg
+        nq, nv = C.shape
+        dev = C.device
+        Lc = clip_p.shape[1] if clip_p is not None else 0
+        terms = torch.empty(2 * (nq + nv) + nq, dtype=torch.float32, device=dev)
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        dC = _zeros((nq, nv), dev)
+        dS = torch.empty(nq, nv, dtype=torch.float32, device=dev)
+        dclip = _zeros((nq, Lc), dev) if clip_p is not None else None
+        native.check(_L().dldkd_branch_losses_f32(_p(C), _p(S), _p(T), _p(clip_p), _p(clip_t), _p(labels), _p(lens), _p(r_t2v), _p(r_v2t),
+                                                  _p(cq), _p(cv), nq, nv, Lc, int(hard), int(hardQ), int(hardV), int(fold_t), float(margin),
+                                                  float(beta), float(eps), float(temp), float(w_nce), float(w_kl), _p(terms), _p(dC), _p(dS),
+                                                  _p(dclip), _p(out), _s()), "branch_losses")
+        ctx.save_for_backward(dC, dS, dclip)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_trip, g_nce, g_kl):
+        dC, dS, dclip = ctx.saved_tensors
+        one = None
+        def gs(g):                                             # an unused term has no upstream gradient: its gradients are zero
+            nonlocal one
+            if g is not None:
+                return _gscalar(g)
+            if one is None:
+                one = _zeros((1,), dC.device)
+            return one
+        native.check(_L().dldkd_branch_losses_scale_f32(_p(dC), _p(dS), dC.numel(), _p(dclip), 0 if dclip is None else dclip.numel(),
+                                                        _p(gs(g_trip)), _p(gs(g_nce)), _p(gs(g_kl)), _s()), "branch_losses_scale")
+        return dC, dS, None, dclip, None, None, None, None, None, None, None, None
+
+
+def branch_losses(C, S, T, clip_p, clip_t, labels, lens, r_t2v, r_v2t, hard, margin, soft, alpha, beta, w_nce, w_kl, fold_t):
+    """(triplet, w_nce * InfoNCE, w_kl * KL) of one branch.  soft: clip_nce_soft with soft-label scores T (fold_t: T is S itself,
+    exploration branch), else clip_nce.  clip_p None: no KL term (the third value is 0)."""
+    C, S = _f32(C), _f32(S)
+    Nq, Nv = S.shape
+    if soft:
+        hardQ, hardV = math.floor(alpha * Nq), math.floor(alpha * Nv)
+        softQ, softV = Nq - hardQ, Nv - hardV
+        use_hard = hardQ != 0 and hardV != 0
+        use_soft = softQ != 0 and softV != 0
+        cq = _part_coefs(Nq, hardQ, alpha / hardQ if use_hard else 0.0, (1 - alpha) / softQ if use_soft else 0.0, S.device)
+        cv = _part_coefs(Nv, hardV, alpha / hardV if use_hard else 0.0, (1 - alpha) / softV if use_soft else 0.0, S.device)
+        eps, Tt = 1e-12, (None if fold_t else _f32(T).detach())
+    else:
+        hardQ, hardV, eps, Tt, fold_t, beta = Nq, Nv, 0.0, None, False, 0.0
+        cq = _part_coefs(Nq, 0, 0.0, 1.0 / Nq, S.device)
+        cv = _part_coefs(Nv, 0, 0.0, 1.0 / Nv, S.device)
+    cfg = (bool(hard), hardQ, hardV, bool(fold_t), float(margin), float(beta), eps, 0.2, float(w_nce), float(w_kl))
+    return _BranchLoss.apply(C, S, Tt, None if clip_p is None else _f32(clip_p), None if clip_t is None else _f32(clip_t).detach(), labels, lens,
+                             r_t2v, r_v2t, cq, cv, cfg)
 
 
 class _Triplet(Function):

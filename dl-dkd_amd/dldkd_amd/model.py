@@ -234,6 +234,9 @@ class DLDKD(nn.Module):
             out = ops.tower_seq(fast, self._tower_packs("visual"), self._lens(video_mask, n, L, frame_video_feat.device), seq_rows=L)
             return (out[0], out[1]) if self.double_branch else (out[0], None)
         for bi, pre in enumerate(("", "exp_") if self.double_branch else ("",)):
+            if fast is None and self._tower_fused_ok(frame_video_feat, video_mask):
+                out.append(self._tower_fused(pre, "visual", frame_video_feat, video_mask))
+                continue
             if fast is not None:
                 h = self._encode_after_proj(fast[bi], video_mask, getattr(self, pre + "visual_encoder"),
                                             getattr(self, pre + "visual_pos_embed"))
@@ -271,6 +274,9 @@ class DLDKD(nn.Module):
                                 out_mode=2)
             return (out[0], out[1]) if self.double_branch else (out[0], None)
         for bi, pre in enumerate(("", "exp_") if self.double_branch else ("",)):
+            if fast is None and self._tower_fused_ok(query_feat, query_mask):
+                out.append(self._query_tower(pre, query_feat, query_mask))
+                continue
             if fast is not None:
                 h = self._encode_after_proj(fast[bi], query_mask, getattr(self, pre + "query_encoder"),
                                             getattr(self, pre + "query_pos_embed"))
@@ -304,11 +310,28 @@ class DLDKD(nn.Module):
         return s0, s1
 
     # ------------------------------------------------------------------ fp32 scoring with clip-level output
+    _LENS_CACHE = [None] * 6              # (mask storage pointer, mask._version, shape, stream) of the last masks -> their lengths
+
     @staticmethod
     def _lens(mask, nv, L, device):
+        """Valid clips / words per sequence, int32.  GPU masks: one kernel, and the towers of one step ask for the same two masks
+        (video, query) again and again - the last few results are kept (keyed on the mask's storage and version)."""
         if mask is None:
             return torch.full((nv,), L, dtype=torch.int32, device=device)
-        return (mask > 0).sum(1).to(torch.int32)
+        if not mask.is_cuda or mask.dtype != torch.float32 or not mask.is_contiguous() or mask.dim() != 2:
+            return (mask > 0).sum(1).to(torch.int32)
+        # (per stream: the towers of a step run on their own streams / graphs and do not wait for each other's small kernels)
+        key = (mask.data_ptr(), mask._version, tuple(mask.shape), torch.cuda.is_current_stream_capturing(),
+               torch.cuda.current_stream(mask.device).cuda_stream)
+        for ent in DLDKD._LENS_CACHE:
+            if ent is not None and ent[0] == key and ent[2]() is mask:
+                return ent[1]
+        import weakref
+        lens = torch.empty(mask.shape[0], dtype=torch.int32, device=mask.device)
+        native.check(native.lib().dldkd_mask_lens_f32(native.ptr(mask), mask.shape[0], mask.shape[1], native.ptr(lens), native.stream()),
+                     "mask_lens")
+        DLDKD._LENS_CACHE = [(key, lens, weakref.ref(mask))] + DLDKD._LENS_CACHE[:5]
+        return lens
 
     @staticmethod
     def _clip_level(q, ctx, mask, normalize):
@@ -381,7 +404,30 @@ class DLDKD(nn.Module):
     # ------------------------------------------------------------------ the four towers side by side (training)
     TOWER_SKIPS_PADDING = True
 
+    def _tower_fused_ok(self, feat, mask):
+        """Training, throughput mode: the tower behind the input projection as the fused row kernels (functional._TowerTrain)."""
+        return (self.training and mask is not None and feat.dim() == 3 and mask.dim() == 2 and tuple(mask.shape) == tuple(feat.shape[:2])
+                and F_.tower_train_ok(feat.is_cuda, feat.shape[1]))
+
+    def _tower_fused(self, pre, kind, feat, mask):
+        proj, pos, enc = (getattr(self, pre + kind + s) for s in ("_input_proj", "_pos_embed", "_encoder"))
+        feat = feat.float().contiguous()
+        n, L = feat.shape[0], feat.shape[1]
+        if L > pos.position_embeddings.num_embeddings:
+            raise IndexError(f"sequence length {L} exceeds {pos.position_embeddings.num_embeddings} positions")
+        fused_proj = F_.in_proj_train_ok(feat, proj.net[1].weight) and proj.relu
+        y0 = proj(feat, row_mask=mask, grad_premasked=True) if fused_proj else proj(feat)
+        rg = F_.take_group_flags()
+        flags = rg[0] if (rg is not None and self.TOWER_SKIPS_PADDING and rg[1] == n * L) else None
+        out_lin = getattr(self, pre + "out_mapping_linear") if kind == "visual" else None
+        return F_.tower_train(y0, pos.position_embeddings.weight[:L], pos.LayerNorm.weight, pos.LayerNorm.bias,
+                              (enc.self.query, enc.self.key, enc.self.value), enc.output.dense, enc.output.LayerNorm.weight,
+                              enc.output.LayerNorm.bias, out_lin, mask, self._lens(mask, n, L, feat.device), flags,
+                              pos.dropout.p, enc.self.dropout.p, enc.output.dropout.p, self.training, relu_mask=fused_proj)
+
     def _video_tower(self, pre, feat, mask):
+        if self._tower_fused_ok(feat, mask):
+            return self._tower_fused(pre, "visual", feat, mask)
         try:
             h = self.encode_input(feat, mask, getattr(self, pre + "visual_input_proj"), getattr(self, pre + "visual_encoder"),
                                   getattr(self, pre + "visual_pos_embed"))
@@ -391,6 +437,8 @@ class DLDKD(nn.Module):
             ops.set_row_groups(None, 0)
 
     def _query_tower(self, pre, feat, mask):
+        if self._tower_fused_ok(feat, mask):
+            return self.get_modularized_queries(self._tower_fused(pre, "query", feat, mask), mask, inheritance=(pre == ""))
         try:
             h = self.encode_input(feat, mask, getattr(self, pre + "query_input_proj"), getattr(self, pre + "query_encoder"),
                                   getattr(self, pre + "query_pos_embed"))
@@ -527,6 +575,18 @@ class DLDKD(nn.Module):
             st = None if staged is None else (lab,) + tuple(staged.draws[call])
             return self.get_clip_triplet_loss(scores, labels, _staged=st)
 
+        hard_neg = bool(_cfg_get(self.config, "use_hard_negative"))
+        fused_losses = fused and F_.BRANCH_LOSS_FUSED and mask.is_cuda
+
+        def draws(call):
+            """(r_t2v, r_v2t) of get_clip_triplet_loss call `call` on the device: staged by the graph stepper, or drawn here with the
+            reference's CPU torch.randint calls (model.py:366-380), in its order."""
+            if staged is not None:
+                r_t2v, r_v2t = staged.draws[call]
+                return r_t2v, (None if hard_neg else r_v2t)
+            _, r_t2v, r_v2t = self._draw_triplet(np.asarray(labels), nv)
+            return r_t2v.to(dev), (None if r_v2t is None else r_v2t.to(dev))
+
         # the teacher's scores need nothing of the towers: enqueued in front of them they run beside the tower graphs (the
         # stepper's main stream is idle there) instead of at the head of the serial loss section
         with torch.no_grad():
@@ -539,6 +599,10 @@ class DLDKD(nn.Module):
 
         def inh_part(q, g):
             i_cos, i_raw, i_clip = both(q, g, True)
+            if fused_losses:
+                r_t2v, r_v2t = draws(0)
+                return F_.branch_losses(i_cos, i_raw, t_raw, i_clip, t_clip, lab, lens, r_t2v, r_v2t, hard_neg, _cfg_get(self.config, "margin"),
+                                        soft, self.alpha, self.belta, self.inher_nce_weight, self.kl_intra_weight * self.weight, False)
             inher_trip = trip(i_cos, 0)
             if soft:
                 inher_nce = self.inher_nce_weight * F_.nce_soft(lab, i_raw, t_raw, self.alpha, self.belta)
@@ -549,6 +613,10 @@ class DLDKD(nn.Module):
 
         def exp_part(q, g):
             e_cos, e_raw, _ = both(q, g, False)
+            if fused_losses:
+                r_t2v, r_v2t = draws(1)
+                return F_.branch_losses(e_cos, e_raw, None, None, None, lab, lens, r_t2v, r_v2t, hard_neg, _cfg_get(self.config, "margin"),
+                                        soft, self.alpha, self.belta, self.explore_nce_weight, 0.0, True)[:2]
             explore_trip = trip(e_cos, 1)
             if soft:
                 explore_nce = self.explore_nce_weight * F_.nce_soft(lab, e_raw, e_raw, self.alpha, self.belta)

@@ -41,14 +41,15 @@ class LinearLayer(nn.Module):
             self.LayerNorm = nn.LayerNorm(in_hsz)
         self.net = nn.Sequential(nn.Dropout(dropout), nn.Linear(in_hsz, out_hsz))
 
-    def forward(self, x, row_mask=None):
+    def forward(self, x, row_mask=None, grad_premasked=False):
         """row_mask (optional, training): the (n, L) mask of the padded batch x (n, L, K) - rows of the padding may then be skipped
-        (their outputs are don't-care values nothing downstream of the towers reads)."""
+        (their outputs are don't-care values nothing downstream of the towers reads).  grad_premasked: the consumer's backward pass
+        applies this layer's ReLU mask itself (functional._TowerTrain)."""
         lin = self.net[1]
         if self.layer_norm and F_.in_proj_train_ok(x, lin.weight):
             # training on raw features, throughput mode: one autograd node whose backward pass skips the input gradient
             return F_.in_proj_train(x, self.LayerNorm.weight, self.LayerNorm.bias, lin.weight, lin.bias, self.net[0].p,
-                                    self.training, relu=self.relu, row_mask=row_mask)
+                                    self.training, relu=self.relu, row_mask=row_mask, grad_premasked=grad_premasked)
         if self.layer_norm:
             x = F_.layernorm(x, self.LayerNorm.weight, self.LayerNorm.bias, p_drop=self.net[0].p, training=self.training)
         else:

@@ -58,6 +58,33 @@ SIGNATURES = {
                                                    _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_layernorm_dropout_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_float,
                                                _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_attention_train_fwd_bf16io": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float, ctypes.c_uint64,
+                                                   ctypes.c_uint64, _c_void_p, _c_void_p]),
+    "dldkd_attention_train_bwd_bf16io": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float,
+                                                   ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p]),
+    "dldkd_tower_train_pack_bytes": (_c_size_t, [_c_int]),
+    "dldkd_tower_train_pack": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p]),
+    "dldkd_tower_train_f1": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64,
+                                       _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p,
+                                       _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_tower_train_f3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p,
+                                       _c_void_p, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p,
+                                       _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_tower_train_b3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, ctypes.c_uint64, ctypes.c_uint64,
+                                       _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                       _c_void_p]),
+    "dldkd_tower_train_b1": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float,
+                                       ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p,
+                                       _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_tower_train_dw_workspace_bytes": (_c_size_t, [_c_int, _c_long]),
+    "dldkd_tower_train_dw": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_void_p, _c_void_p, _c_void_p,
+                                       _c_size_t, _c_void_p, _c_void_p]),
+    "dldkd_mask_lens_f32": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "dldkd_colsum_bf16": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_branch_losses_f32": (_c_int, [_c_void_p] * 11 + [_c_int] * 7 + [_c_float] * 6 + [_c_void_p] * 6),
+    "dldkd_branch_losses_scale_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_gemm_bf16_dw_bias": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_size_t,
+                                          _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_gemm_bf16_mixed": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                         _c_int, _c_void_p, _c_size_t, _c_void_p, _c_void_p]),
     "dldkd_gemm_bf16_nt": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

@@ -69,8 +69,13 @@ def make_optimizer(model, opt, steps_per_epoch):
     named = list(model.named_parameters())
     groups = [{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
               {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
-    # data parallel: one contiguous gradient range per tower, all-reduced while the next tower's backward runs
-    buckets = model.grad_buckets() if dist_info()[1] >= DDP_MIN_WORLD and hasattr(model, "grad_buckets") else None
+    # data parallel: ONE flat gradient range, one all-reduce behind the backward pass (a single replayed graph + a collective on the
+    # comm stream).  opt.ddp_bucketed_overlap = True lays the flat buffers out tower by tower instead (one contiguous range per
+    # tower, all-reduced while the next tower's backward pass runs: a chain of graph segments, _capture_segments): measured on a
+    # one-rank RCCL group only, never against real RCCL kernels on two or more GPUs - off until a multi-GPU run has shown its
+    # gradients and parameters equal the single-bucket run's over mixed eager / capture / replay steps.
+    bucketed = bool(getattr(opt, "ddp_bucketed_overlap", False))
+    buckets = model.grad_buckets() if (bucketed and dist_info()[1] >= DDP_MIN_WORLD and hasattr(model, "grad_buckets")) else None
     return BertAdam(groups, lr=opt.lr, weight_decay=opt.wd, warmup=opt.lr_warmup_proportion,
                     t_total=steps_per_epoch * opt.n_epoch, schedule="warmup_linear", grad_buckets=buckets)
 
@@ -186,10 +191,11 @@ class GraphedTrainStep:
     time; at most `max_graphs` graphs are kept (least recently used is dropped), an evicted key is never captured again and
     after `max_captures` captures every unseen key stays eager (variable caption counts - ActivityNet, Charades - would
     otherwise re-capture a 350-kernel graph far more often than they replay one).
-    Data parallel (world >= 2) with the optimizer laid out in gradient buckets (make_optimizer): the step is a chain of graphs,
-    one per tower of the backward pass; each tower's all-reduce is issued from the comm stream as its segment has been launched
-    and runs under the next segment; the optimizer update is the chain's last graph (_capture_segments).  Without buckets: one
-    graph that ends after the backward pass, one all-reduce, the optimizer update eagerly."""
+    Data parallel (world >= 2), default: one graph that ends after the backward pass, one all-reduce of the flat gradient buffer from
+    the comm stream, the optimizer update eagerly.  With the optimizer laid out in gradient buckets (opt.ddp_bucketed_overlap,
+    make_optimizer): the step is a chain of graphs, one per tower of the backward pass; each tower's all-reduce is issued from the
+    comm stream as its segment has been launched and runs under the next segment; the optimizer update is the chain's last graph
+    (_capture_segments)."""
 
     TENSOR_KEYS = ("student_videos", "student_videos_mask", "teacher_videos", "student_text", "student_text_mask", "teacher_text")
 
@@ -198,6 +204,15 @@ class GraphedTrainStep:
         self.max_graphs, self.defer, self.max_captures = max_graphs, defer_loss_float, max_captures
         self.graphs, self.seen, self.evicted = {}, {}, set()
         self.replays = self.eager_steps = self.captures = 0
+        # Self-check of every newly captured graph (opt.graph_self_check, default on): the capture step runs the batch TWICE from the
+        # same optimizer / RNG state - eagerly and as the first replay - and keeps the graph only if loss and parameters agree.  The
+        # multi-graph stepper leans on hipGraph behaviour that has changed between ROCm point releases (a MEMSET node that left stale
+        # words, a launch that faulted with three forks): a disagreement or a failed capture drops to the single-graph stepper, then
+        # to eager steps, with a log line - never silently wrong, never an abort.
+        # (one process only: under data parallelism the check would add a second gradient all-reduce to the capture step of ONE rank -
+        # batch signatures differ between ranks - and the ranks' collectives would no longer pair up)
+        self.self_check = bool(getattr(opt, "graph_self_check", True)) and dist_info()[1] < 2
+        self.check_failures, self.capture_failures, self.fallbacks = 0, 0, []
         # EVERY step of this object - eager, capture, replay - runs on this side stream.  Autograd binds a parameter's
         # gradient-accumulation node to the stream that was current when the node was created and keeps it for as long as
         # any graph that reaches it is alive; a node born on the default stream (an eager step whose loss tensors the caller
@@ -284,10 +299,87 @@ class GraphedTrainStep:
             self.seen[key] = self.seen.get(key, 0) + 1
             if self.seen[key] < 2:                        # first sight: eager (also loads every kernel the graph needs)
                 return self._eager(batch)
-            e = self._capture(batch, key)
+            return self._capture_checked(batch, key)
         else:
             self.graphs[key] = self.graphs.pop(key)       # most recently used last
         return self._replay(e, batch)
+
+    # -- capture with a guarded first replay
+    def _snapshot(self):
+        o = self.optimizer
+        dev = o.fp.flat.device
+        gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+        return {"flat": o.fp.flat.clone(), "m": o.m.clone(), "v": o.v.clone(), "step": o.step_count, "cpu_rng": torch.get_rng_state(),
+                "gen_off": gen.get_offset(), "gen": gen}
+
+    def _restore(self, st, params_too=True):
+        from . import ops
+        o = self.optimizer
+        if params_too:
+            o.fp.flat.copy_(st["flat"]); o.m.copy_(st["m"]); o.v.copy_(st["v"])
+            ops.bump_param_epoch()
+        o.step_count = st["step"]
+        torch.set_rng_state(st["cpu_rng"])
+        st["gen"].set_offset(st["gen_off"])
+
+    def _capture_checked(self, batch, key):
+        """Capture `key`; with the self-check on, the batch is stepped eagerly first (the reference), the state is rewound, the graph
+        is captured and replayed once from the same state, and loss + parameters are compared.  Returns the step's result."""
+        if not self.self_check:
+            try:
+                return self._replay(self._capture(batch, key), batch)
+            except Exception as ex:   # noqa: BLE001
+                return self._capture_failed(batch, key, ex, None)
+        st0 = self._snapshot()
+        ref_loss, ref_dict = self._eager(batch)
+        self.eager_steps -= 1                              # (bookkeeping: this eager run is the check's reference, not a step of its own)
+        ref = {"flat": self.optimizer.fp.flat.clone(), "m": self.optimizer.m.clone(), "v": self.optimizer.v.clone(),
+               "step": self.optimizer.step_count, "cpu_rng": torch.get_rng_state(), "gen_off": st0["gen"].get_offset(), "gen": st0["gen"]}
+        self._restore(st0)
+        try:
+            e = self._capture(batch, key)
+            loss, d = self._replay(e, batch)
+        except Exception as ex:   # noqa: BLE001
+            return self._capture_failed(batch, key, ex, (ref, ref_loss, ref_dict))
+        o = self.optimizer
+        lr = max(o.get_lr() + [0.0]) if hasattr(o, "get_lr") else 0.0
+        dl = abs(float(loss) - float(ref_loss))
+        dp = float((o.fp.flat - ref["flat"]).abs().max())
+        ok = dl <= 5e-3 * max(abs(float(ref_loss)), 1e-3) and dp <= 1e-4 + 0.1 * max(lr, float(o._base_lr[0]) if getattr(o, "_base_lr", None) else 0.0)
+        if ok:
+            return loss, d
+        self.check_failures += 1
+        self.graphs.pop(key, None)
+        self.captures -= 1
+        self._restore(ref)                                 # the eager step's result stands
+        self._degrade(key, f"replay disagrees with the eager step (|d loss| = {dl:.3e}, max |d param| = {dp:.3e})")
+        return ref_loss, ref_dict
+
+    def _degrade(self, key, why):
+        """One notch down: parallel tower graphs -> single graph -> this key stays eager."""
+        if self.parallel_towers and not (dist_info()[1] >= DDP_MIN_WORLD):
+            self.parallel_towers = False
+            self.seen[key] = 1                             # captured again (as a single graph) at its next sight
+            what = "falling back to the single-graph stepper"
+        else:
+            self.evicted.add(key)
+            what = "this batch signature stays eager"
+        self.fallbacks.append((why, what))
+        logger.warning(f"GraphedTrainStep: {why}: {what}")
+
+    def _capture_failed(self, batch, key, ex, ref):
+        from . import functional as F_
+        self.capture_failures += 1
+        F_.set_philox_step(None)
+        if hasattr(self.model, "_tower_runner"):
+            self.model._tower_runner = self.model._branch_runner = None
+        self.graphs.pop(key, None)
+        self._degrade(key, f"capture failed ({type(ex).__name__}: {str(ex)[:200]})")
+        if ref is not None:
+            st, loss, d = ref
+            self._restore(st)
+            return loss, d
+        return self._eager(batch)
 
     # -- staging layout (int32 words): [philox 4][lr n_t][labels nq][per triplet call: r_t2v nq, r_v2t nv]
     def _layout(self, e, nq, nv, n_calls):

@@ -59,6 +59,9 @@ size_t dldkd_simpool_eval_workspace_bytes(int nq, int nv, int n_branches);
  * query's scores become NaN, which ranks last (dldkd_rank_gt's NaN policy): a diverged model scores R@K = 0, not 100. */
 int dldkd_pack_queries_bf16(const float* q, int nq, int normalize, void* q_packed, float* bad_flags, void* stream);
 
+/* lens[i] = number of entries > 0 of row i of a (n, L) 0/1 mask (model.py:192 counts a video's clips this way; masks are prefix
+ * masks, data_provider.py:81-84): one kernel in place of (mask > 0).sum(1).to(int32). */
+int dldkd_mask_lens_f32(const float* mask, int n, int L, int32_t* lens, void* stream);
 /* g (nv, L, 384) fp32 + mask (nv, L) fp32 0/1 prefix masks (NULL = all valid) -> bf16 gallery blob,
  * lens[nv] int32 (number of valid clips, data_provider.py:81-84).  normalize as above (model.py:319).
  * Blob layout: row-major bf16 [nv][round_up(L,32)][384]; rows past a video's length inside its last 16-row tile replicate
@@ -322,9 +325,15 @@ int dldkd_gemm_bf16(const float* A, const float* B, const float* bias, float* C,
  *                     dldkd_gemm_workspace_bytes(DLDKD_GEMM_BF16, M, N, K, 1, 1) bytes (NULL: no split); k_flags (one byte per 32
  *                     consecutive k, or NULL): tiles flagged 0 hold zero rows (padding) and are skipped;
  *   dw == 2           the dW layout with B fp32 (K, N) as well (dldkd_gemm_bf16's) plus k_flags;
+ *   dw == 3           the dW layout with A bf16 (K, M) too (lda, M even): both operands are saved bf16 rows (fused training towers);
  *   dw == 0           k_flags, if given, are per 32 ROWS of A16 / C (M % 128 == 0): the groups flagged 0 are not multiplied. */
 int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
                           int ldc, int relu, void* workspace, size_t workspace_bytes, const unsigned char* k_flags, void* stream);
+/* dldkd_gemm_bf16_mixed(dw = 1 or 3) with the bias gradient on the side: a_colsum[m] += sum_k A[k, m] over the k-tiles that are not
+ * skipped (fp32 atomics into a buffer zeroed by the caller) - in nn.Linear's backward pass A is dY, so this is the bias gradient, taken
+ * from the A tiles on their way to LDS instead of by a second pass over dY (ldc = N, no bias / ReLU). */
+int dldkd_gemm_bf16_dw_bias(int dw, const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, void* workspace,
+                            size_t workspace_bytes, const unsigned char* k_flags, float* a_colsum, void* stream);
 /* The forward layout of dldkd_gemm_bf16 - C[M, N] = act(A[M, K] . B[N, K]^T + bias), both operands fp32 and k-minor (a Linear's
  * forward pass; its input gradient once the weight is transposed) - with the operand tiles staged HBM -> LDS by LDS-DMA instead
  * of through registers (gemm_bf16_dma.hip): same products in the same order, bit-identical results, about half the time on
@@ -452,6 +461,74 @@ int dldkd_attention_train_fwd_bf16(const float* qkv, const float* mask, float* o
 int dldkd_attention_train_bwd_bf16(const float* qkv, const float* mask, const float* dout, float* dqkv, int N, int L, float p_drop,
                                    unsigned long long seed, unsigned long long offset, const unsigned long long* state,
                                    void* stream);
+/* The same two kernels with qkv / out / dout / dqkv stored as bf16 (the fused training towers below keep every activation in
+ * bf16) and the sequences' valid lengths: rows >= lens[n] of a sequence are never read (they enter as zero rows: padded keys are
+ * masked by `mask` as in the reference, model_components.py:422) and the 32-row query / key tiles past lens[n] are neither
+ * computed nor written.  lens == NULL: every sequence has L rows.  Pointers 16-byte aligned. */
+int dldkd_attention_train_fwd_bf16io(const void* qkv, const float* mask, const int* lens, void* out, int N, int L, float p_drop,
+                                     unsigned long long seed, unsigned long long offset, const unsigned long long* state,
+                                     void* stream);
+int dldkd_attention_train_bwd_bf16io(const void* qkv, const float* mask, const int* lens, const void* dout, void* dqkv, int N, int L,
+                                     float p_drop, unsigned long long seed, unsigned long long offset,
+                                     const unsigned long long* state, void* stream);
+
+/* Fused training towers, throughput mode (tower_train.hip): everything of an encoder tower behind the input projection -
+ * TrainablePositionalEncoding.forward (method/model_components.py:277-284), the q / k / v projections of BertSelfAttention
+ * (:398-410), BertSelfOutput (:446-450) and out_mapping_linear (method/model.py:219) - as two row kernels forward (f1, f3) and two
+ * backward (b3, b1) around the attention kernels above; activations cross HBM once, as bf16.  M = N L rows of the padded batch,
+ * row = n L + l; flags (one byte per 32 consecutive rows, or NULL = all): groups flagged 0 hold no valid clip and are neither read
+ * nor written (b1 writes zero rows for them).  Dropout: p_drop with the Philox (seed, offset, state) convention of
+ * dldkd_dropout_fwd_f32 on the flat index of the (N, L, 384) tensor; the backward kernels recompute the masks from the same
+ * arguments.  Weights reach the kernels in MFMA fragment order (dldkd_tower_train_pack; 288 KiB per 384 x 384 matrix):
+ *   mode 0 / 1: W as the A operand of Y^T = W X^T, k natural / in the permuted order of an accumulator tile used as operand
+ *   mode 2 / 3: W^T likewise (input gradients); up to three (384, 384) sources are concatenated along the OUTPUT axis (q | k | v).
+ * host_src (3 per job), host_nsrc, host_mode, host_out are HOST arrays of njobs <= 6 entries (the pointers in them are device
+ * pointers); the call enqueues one kernel.
+ *   f1: y0 (M, 384) fp32 (the input projection's output) + pos (L, 384) -> LayerNorm(gamma, beta) -> dropout -> h1d (M, 384) bf16,
+ *       stats [2][M] (mean, rstd), qkv (M, 1152) bf16 = h1d Wqkv^T + (bq | bk | bv)          wqkv_pack: mode 0, three sources;
+ *       xh1 (M, 384) bf16: the normalised rows with bit 0 of every element replaced by [y0 > 0] - all b1 needs of y0 and pos
+ *   f3: ctx (M, 384) bf16 -> dense (wd_pack: mode 0) + bd -> dropout -> + h1d -> LayerNorm -> xh2 (normalised rows, bf16),
+ *       rstd2 [M], and h2 = xh2 gamma + beta as bf16 (h2_bf16) followed by the out mapping g = h2 Wo^T + bo (fp32; wo_pack:
+ *       mode 1) when wo_pack != NULL, as fp32 rows (h2_f32) otherwise (query towers: get_modularized_queries reads them)
+ *   b3: dg (M, 384) fp32 = gradient of g (wot_pack: mode 2) or of h2 (wot_pack NULL) -> LayerNorm backward (dgamma, dbeta: [384],
+ *       ADDED with atomics, zeroed by the caller) -> ddo = gradient of the dense output (bf16), dres = gradient reaching h1d through
+ *       the residual (bf16), dctx = ddo Wd (bf16; wdt_pack: mode 3)
+ *   b1: dqkv (M, 1152) bf16 -> dh1d = dqkv Wqkv + dres (wqkvt_pack: mode 2, three sources) -> dropout mask -> LayerNorm backward
+ *       from xh1 and stats (dgamma, dbeta added) -> dx1 (M, 384) fp32 (gradient of y0 + pos; NULL: not written) and dy0 = dx1 (.) [y0 > 0] when
+ *       relu_mask (the ReLU of LinearLayer, model_components.py:311), else dy0 = dx1.
+ * Weight gradients are dldkd_gemm_bf16_mixed(dw = 3 / 1) over the saved bf16 rows, bias gradients dldkd_colsum_bf16 /
+ * dldkd_colsum_f32. */
+size_t dldkd_tower_train_pack_bytes(int n_mats);
+int dldkd_tower_train_pack(const float* const* host_src, const int* host_nsrc, const int* host_mode, void* const* host_out, int njobs,
+                           void* stream);
+int dldkd_tower_train_f1(const float* y0, const float* pos, int L, const float* gamma, const float* beta, float eps, float p_drop,
+                         unsigned long long seed, unsigned long long offset, const unsigned long long* state, const void* wqkv_pack,
+                         const float* bq, const float* bk, const float* bv, const unsigned char* flags, long M, void* h1d, void* xh1,
+                         float* stats, void* qkv, void* stream);
+int dldkd_tower_train_f3(const void* ctx, const void* h1d, const void* wd_pack, const float* bd, float p_drop, unsigned long long seed,
+                         unsigned long long offset, const unsigned long long* state, const float* gamma, const float* beta, float eps,
+                         const void* wo_pack, const float* bo, const unsigned char* flags, long M, void* xh2, float* rstd2, void* h2_bf16,
+                         float* h2_f32, float* g, void* stream);
+int dldkd_tower_train_b3(const float* dg, const void* wot_pack, const void* xh2, const float* rstd2, const float* gamma, float p_drop,
+                         unsigned long long seed, unsigned long long offset, const unsigned long long* state, const void* wdt_pack,
+                         const unsigned char* flags, long M, void* ddo, void* dctx, void* dres, float* dgamma, float* dbeta, void* stream);
+int dldkd_tower_train_b1(const void* dqkv, const void* dres, const void* wqkvt_pack, const void* xh1, const float* stats,
+                         const float* gamma, float p_drop, unsigned long long seed, unsigned long long offset,
+                         const unsigned long long* state, const unsigned char* flags, long M, int relu_mask, float* dy0, float* dx1,
+                         float* dgamma, float* dbeta, void* stream);
+/* The weight and bias gradients of one fused training tower as ONE split-K product: dW (384 n_blocks, 384) fp32, block b =
+ * sum over the batch rows r of A_b[r, acol_b .. acol_b + 384)^T B_b[r, :] (A_b: the gradient of layer b's output, fp32 or bf16
+ * (a16_b) rows of lda_b elements; B_b: the layer's saved bf16 input rows (rows, 384)), dbias (384 n_blocks; NULL: not wanted;
+ * zeroed by the caller) += the column sums of the A_b ranges.  k_flags as dldkd_gemm_bf16_mixed(dw = 1).  host_* are HOST arrays of
+ * n_blocks <= 5 entries; workspace of dldkd_tower_train_dw_workspace_bytes(n_blocks, rows) bytes (NULL: no split-K). */
+size_t dldkd_tower_train_dw_workspace_bytes(int n_blocks, long rows);
+int dldkd_tower_train_dw(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
+                         const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
+                         size_t workspace_bytes, const unsigned char* k_flags, void* stream);
+/* out[c] += sum over the rows r of x[r, c0 + c] (x (M, ld) bf16, c < N) whose 32-row group is flagged (flags NULL: all rows); out is
+ * zeroed by the caller.  The bias gradients of the fused training towers (rows of skipped groups are not written: they must not be
+ * read). */
+int dldkd_colsum_bf16(const void* x, int ld, int c0, int N, long M, const unsigned char* flags, float* out, void* stream);
 
 /* Training-side simpool: for one (query set, gallery) pair of DLDKD.forward (model.py:113-129) everything the losses read
  * of get_sim_scores (model.py:307-329) and get_unnormalized_sim_scores (model.py:331-350), from ONE raw product
@@ -475,6 +552,22 @@ int dldkd_simpool_train_bwd_f32(const float* q, const float* g, const float* rq,
                                 const float* clip_pos, const float* d_cos, const float* d_raw, const float* d_clip, int nq, int nv,
                                 int L, int D, float* dq, float* dg, void* stream);
 
+/* One branch's loss terms of DLDKD.forward (method/model.py:137-155: get_clip_triplet_loss + 0.04 clip_nce_soft / clip_nce +
+ * kl_intra_weight weight compute_kl_loss) with their gradients in three launches: [triplet t2v | triplet v2t | InfoNCE rows | KL] as
+ * one grid, the InfoNCE column pass, the three sums.  Same arithmetic as dldkd_triplet_f32 / dldkd_nce_f32 / dldkd_kl_frame_f32.
+ * C / S (nq, nv): pooled cosine / raw scores; T: soft-label scores (nq, nv), NULL with fold_t != 0 (the targets are S itself and
+ * their gradient is added to dS: exploration branch) or for hard labels (hardQ = nq, hardV = nv, eps = 0); clip_p / clip_t (nq, L):
+ * positive-column clip cosines of student / teacher (NULL: no KL term); cq / cv: the per-row / per-column coefficients of
+ * dldkd_nce_f32.  terms: scratch of 2 (nq + nv) + nq floats; dC (nq, nv) and dclip (nq, L) zeroed by the caller, dS (nq, nv) written;
+ * out[3] = triplet, w_nce InfoNCE, w_kl KL.  Gradients are those of out[] for an upstream gradient of 1;
+ * dldkd_branch_losses_scale_f32 multiplies them by the actual upstream gradients (device scalars) in place. */
+int dldkd_branch_losses_f32(const float* C, const float* S, const float* T, const float* clip_p, const float* clip_t,
+                            const int32_t* labels, const int32_t* lens, const int32_t* r_t2v, const int32_t* r_v2t, const float* cq,
+                            const float* cv, int nq, int nv, int L, int hard, int hardQ, int hardV, int fold_t, float margin, float beta,
+                            float eps, float temp, float w_nce, float w_kl, float* terms, float* dC, float* dS, float* dclip, float* out,
+                            void* stream);
+int dldkd_branch_losses_scale_f32(float* dC, float* dS, long n, float* dclip, long n_clip, const float* g_trip, const float* g_nce,
+                                  const float* g_kl, void* stream);
 /* out[0] = sum of x[0..n) in a fixed order (single workgroup). */
 int dldkd_sum_f32(const float* x, long n, float* out, void* stream);
 

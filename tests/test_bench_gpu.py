@@ -30,6 +30,13 @@ def test_bench_distributed_path_verifies_itself_on_one_rank():
     c4 = d["extras"]["c4_sharded"]
     assert c4["assembled_max_abs_diff"] == 0.0 and c4["recall_hip"] == bench.RECALL_C4_N1 and c4["recall_matches_n1"] is True
     assert c4["n_queries"] == 17505 and c4["n_videos"] == 4917 and c4["n_ranges"] >= 4
+    # BASELINE configs[4]: the data-parallel Charades step through the same hook (RCCL group of one rank)
+    c5 = d["extras"]["c5_ddp"]
+    assert c5["grad_bytes"] == 4371968 * 4 + 0 or c5["grad_bytes"] >= 4371968 * 4          # 17.5 MB of fp32 gradients (+ chunk padding)
+    for layout, nb in (("single_bucket", 1), ("tower_buckets", 4)):
+        r = c5[layout]
+        assert r["n_buckets"] == nb and r["replicas_identical"] is True and r["replicas_max_abs_param_diff_after_timed_steps"] == 0.0
+        assert 0.2 < r["step_ms"] < 50.0 and 0.2 < r["step_ms_without_allreduce"] < 50.0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d

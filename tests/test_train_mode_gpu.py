@@ -56,6 +56,16 @@ class _FlagLog:
                 self.calls.append((flags, int(M)))
             return real(flags, M)
         monkeypatch.setattr(ops, "set_row_groups", spy)
+        # throughput mode: the fused training towers (functional._TowerTrain) take the flags as an argument instead
+        from dldkd_amd import functional as F_
+        real_tt = F_.tower_train
+
+        def spy_tt(y0, *a, **k):
+            flags = a[10] if len(a) > 10 else k.get("flags")
+            if flags is not None:
+                self.calls.append((flags, int(y0.shape[0] * y0.shape[1])))
+            return real_tt(y0, *a, **k)
+        monkeypatch.setattr(F_, "tower_train", spy_tt)
 
     def assert_skipped(self, lens, L):
         """Both video towers published flags, and they are exactly `group holds a valid clip`."""

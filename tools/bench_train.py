@@ -95,6 +95,10 @@ if __name__ == "__main__":
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--modes", default="eager,graph")
     ap.add_argument("--tower-streams", type=int, default=-1, help="1 / 0: the four towers on four streams / one; -1: the default")
+    ap.add_argument("--fused-towers", type=int, default=1, help="0: the unfused kernel chain of the training towers (A/B)")
+    ap.add_argument("--fused-losses", type=int, default=1, help="0: one kernel pair per loss term (A/B)")
     a = ap.parse_args()
+    from dldkd_amd import functional as F_
+    F_.TOWER_TRAIN_FUSED, F_.BRANCH_LOSS_FUSED = bool(a.fused_towers), bool(a.fused_losses)
     print(json.dumps(run(a.config, a.prec, a.drop, a.steps, a.warmup, modes=tuple(a.modes.split(",")),
                          tower_streams=None if a.tower_streams < 0 else bool(a.tower_streams)), indent=1))
