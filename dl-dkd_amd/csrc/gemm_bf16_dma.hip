@@ -145,10 +145,153 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const Args p) {
     gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * 72));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same kernel with BOTH operands bf16 in memory (the training input projection: A = the LayerNorm-dropout rows that
+// dldkd_layernorm_dropout_bf16 writes, B = the weight cast once per step): a k-tile is 64 elements = the same 128-byte rows, the
+// same DMA and the same XOR image, but a 16-byte chunk now IS one lane's fragment (8 bf16) - no conversion, one ds_read_b128 per
+// fragment - and a tile carries four k-steps = 16 MFMAs per wave per barrier instead of 8, half as many dependent round trips
+// for a given K (16,384 x 384 x 3,072: 48 instead of 96 - this GEMM was 150 us in the register-staged kernel for 40 us of MFMA work).
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int BK16 = 64;
+
+struct Args16 {
+    const unsigned short* A;
+    const unsigned short* B;
+    const float* bias;
+    float* C;
+    int M, N, K, lda, ldb, ldc, relu;
+    float alpha;
+    const unsigned char* mflags;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt16_kernel(const Args16 p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Tile3 bid = xcd_tile_order();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = bid.y * BM, n0 = bid.x * BN;
+    const int nk = p.K / BK16;
+    const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
+    uint32_t voa[4], vob[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = 8 * (4 * wave + q) + (lane >> 3);
+        const int ch = ((lane & 7) ^ ((row >> 1) & 7)) << 4;
+        const int ra = min(m0 + row, p.M - 1) - m0, rb = min(n0 + row, p.N - 1) - n0;
+        voa[q] = (uint32_t)(ra * p.lda * 2 + ch);
+        vob[q] = (uint32_t)(rb * p.ldb * 2 + ch);
+    }
+    const char* abase = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
+    const char* bbase = reinterpret_cast<const char*>(p.B + (size_t)n0 * p.ldb);
+    unsigned pm = 0xFu;
+    if (p.mflags != nullptr) {
+        const unsigned w4 = *reinterpret_cast<const unsigned*>(p.mflags + (m0 >> 5));
+        pm = ((w4 & 0xffu) ? 1u : 0u) | ((w4 & 0xff00u) ? 2u : 0u) | ((w4 & 0xff0000u) ? 4u : 0u) | ((w4 & 0xff000000u) ? 8u : 0u);
+        pm = __builtin_amdgcn_readfirstlane(pm);
+    }
+    const bool load_a = ((pm >> wave) & 1u) != 0;
+    const bool rt_ok[2] = {((pm >> (wm / 32)) & 1u) != 0, ((pm >> (wm / 32 + 1)) & 1u) != 0};
+    auto issue = [&](int kt, int stage) {
+        const char* as = abase + (size_t)kt * (BK16 * 2);
+        const char* bs = bbase + (size_t)kt * (BK16 * 2);
+        const uint32_t dst = smem_lds + stage * STAGE_B + (4 * wave) * 1024;
+        if (load_a) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) glds16_s(voa[q], as, dst + q * 1024);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16_s(vob[q], bs, dst + TILE_B + q * 1024);
+    };
+    // fragment of k-step kk (16 k = chunks 2 kk, 2 kk + 1): lane (r = lane & 31, h = lane >> 5) reads chunk 2 kk + h of its row
+    int fo[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int r = lane & 31, c = 2 * kk + (lane >> 5);
+        fo[kk] = r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, st ^ 1);
+        const char* As = smem + st * STAGE_B + wm * 128;
+        const char* Bs = smem + st * STAGE_B + TILE_B + wn * 128;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 4096 + fo[kk]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (!rt_ok[i]) continue;
+                a[i] = *reinterpret_cast<const bf16x8*>(As + i * 4096 + fo[kk]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * 72));
+}
+
+// x (n) fp32 -> bf16 (round to nearest even): the weight operand of gemm_bf16_nt16, once per optimizer step
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    uint2 pk;
+    pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+    pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+    reinterpret_cast<uint2*>(y)[i] = pk;
+}
+
 }  // namespace gdma
 }  // namespace dldkd
 
 using namespace dldkd;
+
+extern "C" int dldkd_cast_bf16(const float* x, void* y, long n, void* stream) {
+    if (n < 0 || (n & 3)) { set_error("cast_bf16: n must be a multiple of 4"); return DLDKD_EINVAL; }
+    if (n == 0) return DLDKD_OK;
+    if (!x || !y || ((uintptr_t)x & 15) || ((uintptr_t)y & 7)) { set_error("cast_bf16: null or unaligned pointer"); return DLDKD_EINVAL; }
+    DLDKD_LAUNCH(gdma::cast_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)y, n / 4);
+    return check_launch("cast_bf16");
+}
+
+extern "C" int dldkd_gemm_bf16_nt16_ok(int M, int N, int K, int lda, int ldb) {
+    return M > 0 && N > 0 && K >= gdma::BK16 && (K % gdma::BK16) == 0 && !(lda & 7) && !(ldb & 7) &&
+           (long)127 * lda * 2 + 128 <= 0x7fffffffL && (long)127 * ldb * 2 + 128 <= 0x7fffffffL;
+}
+
+extern "C" int dldkd_gemm_bf16_nt16(const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
+                                    int ldc, int relu, const unsigned char* row_flags, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || lda < K || ldb < K || ldc < N) { set_error("gemm_bf16_nt16: bad sizes"); return DLDKD_EINVAL; }
+    if (M == 0 || N == 0) return DLDKD_OK;
+    if (!A || !B || !C) { set_error("gemm_bf16_nt16: null pointer"); return DLDKD_EINVAL; }
+    if (!dldkd_gemm_bf16_nt16_ok(M, N, K, lda, ldb) || (((uintptr_t)A | (uintptr_t)B) & 15)) {
+        set_error("gemm_bf16_nt16: needs K %% 64 == 0, lda / ldb %% 8 == 0 and 16-byte aligned operands (M=%d N=%d K=%d)", M, N, K);
+        return DLDKD_EINVAL;
+    }
+    gdma::Args16 p{(const unsigned short*)A, (const unsigned short*)B, bias, C, M, N, K, lda, ldb, ldc, relu != 0, 1.0f,
+                   (M % gdma::BM == 0 && !((uintptr_t)row_flags & 3)) ? row_flags : nullptr};
+    constexpr int lds = gdma::NST * gdma::STAGE_B;
+    static const bool ok = hipFuncSetAttribute((const void*)gdma::gemm_bf16_nt16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    (void)ok;
+    const dim3 grid((N + gdma::BN - 1) / gdma::BN, (M + gdma::BM - 1) / gdma::BM, 1);
+    DLDKD_LAUNCH(gdma::gemm_bf16_nt16_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    return check_launch("gemm_bf16_nt16");
+}
 
 extern "C" int dldkd_gemm_bf16_nt_ok(int M, int N, int K, int lda, int ldb) {
     return M > 0 && N > 0 && K >= gdma::BK && (K % gdma::BK) == 0 && !(lda & 3) && !(ldb & 3) &&

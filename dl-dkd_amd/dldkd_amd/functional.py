@@ -218,8 +218,15 @@ class _InProjTrain(Function):
             native.check(_L().dldkd_layernorm_dropout_bf16(_p(x2), _p(gamma), _p(beta), _p(z), _p(keep), _p(stats), M, K, ops.LN_EPS,
                                                            float(p), seed, off, state, _p(rm), _p(gflags), _s()), "layernorm_dropout_bf16")
             y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-            native.check(_L().dldkd_gemm_bf16_mixed(0, _p(z), _p(weight), _p(bias), _p(y), M, N, K, K, K, N, int(relu), None, 0,
-                                                    _p(gflags), _s()), "gemm_bf16_mixed")
+            if IN_PROJ_TRAIN_NT16 and M >= 1024 and _L().dldkd_gemm_bf16_nt16_ok(M, N, K, K, K) and weight.is_contiguous():
+                # both operands bf16, tiles by LDS-DMA (gemm_bf16_dma.hip): the weight is cast once here (1.2 M elements)
+                w16 = torch.empty(N, K, dtype=torch.bfloat16, device=x.device)
+                native.check(_L().dldkd_cast_bf16(_p(weight), _p(w16), N * K, _s()), "cast_bf16")
+                native.check(_L().dldkd_gemm_bf16_nt16(_p(z), _p(w16), _p(bias), _p(y), M, N, K, K, K, N, int(relu), _p(gflags), _s()),
+                             "gemm_bf16_nt16")
+            else:
+                native.check(_L().dldkd_gemm_bf16_mixed(0, _p(z), _p(weight), _p(bias), _p(y), M, N, K, K, K, N, int(relu), None, 0,
+                                                        _p(gflags), _s()), "gemm_bf16_mixed")
         elif (row_mask is not None and IN_PROJ_SKIP_PADDING and x.dim() == 3 and row_mask.numel() == M and x.shape[1] % 32 == 0
               and M % 128 == 0 and ops.gemm_precision() in ("fp32", "fp32x3")):
             # parity mode with the batch's mask: the same padding skip with fp32 rows (the three-plane GEMMs are compute-bound:
@@ -299,6 +306,7 @@ def take_group_flags():
 IN_PROJ_SKIP_PADDING = True           # ... and the rows of the padding (a row mask given) are neither normalised nor multiplied
 IN_PROJ_TRAIN_BF16_ROWS = True        # throughput mode: the saved LayerNorm-dropout rows of the input projection are bf16
 IN_PROJ_TRAIN_FUSED = True
+IN_PROJ_TRAIN_NT16 = True             # throughput mode: the forward GEMM of the input projection on the bf16 x bf16 LDS-DMA kernel
 
 
 def in_proj_train_ok(x, weight):

@@ -91,6 +91,10 @@ SIGNATURES = {
                                      _c_void_p, _c_void_p]),
     "dldkd_layernorm_groups_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
                                              _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_cast_bf16": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p]),
+    "dldkd_gemm_bf16_nt16_ok": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "dldkd_gemm_bf16_nt16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                       _c_void_p, _c_void_p]),
     "dldkd_gemm_bf16_nt_ok": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "dldkd_colsum_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_long, _c_void_p]),
     "dldkd_relu_bwd_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p]),

@@ -329,6 +329,14 @@ int dldkd_gemm_bf16(const float* A, const float* B, const float* bias, float* C,
  *   dw == 0           k_flags, if given, are per 32 ROWS of A16 / C (M % 128 == 0): the groups flagged 0 are not multiplied. */
 int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
                           int ldc, int relu, void* workspace, size_t workspace_bytes, const unsigned char* k_flags, void* stream);
+/* dldkd_gemm_bf16_nt with BOTH operands bf16 in memory (A (M, K) = the rows dldkd_layernorm_dropout_bf16 writes, B (N, K) = the
+ * weight cast by dldkd_cast_bf16): k-tiles of 64, no conversion on the way to the MFMA, half the dependent tile round trips.  The
+ * forward GEMM of the training input projection (LinearLayer.forward, model_components.py:305-312).  K % 64 == 0, lda / ldb % 8 == 0,
+ * 16-byte aligned operands (dldkd_gemm_bf16_nt16_ok); row_flags as dldkd_gemm_bf16_nt. */
+int dldkd_cast_bf16(const float* x, void* y, long n, void* stream);
+int dldkd_gemm_bf16_nt16_ok(int M, int N, int K, int lda, int ldb);
+int dldkd_gemm_bf16_nt16(const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                         int relu, const unsigned char* row_flags, void* stream);
 /* dldkd_gemm_bf16_mixed(dw = 1 or 3) with the bias gradient on the side: a_colsum[m] += sum_k A[k, m] over the k-tiles that are not
  * skipped (fp32 atomics into a buffer zeroed by the caller) - in nn.Linear's backward pass A is dY, so this is the bias gradient, taken
  * from the A tiles on their way to LDS instead of by a second pass over dY (ldc = N, no bias / ReLU). */

@@ -149,3 +149,37 @@ def test_fused_towers_match_the_unfused_chain_with_the_same_dropout_masks(drop):
         worst = max(worst, rel)
         assert rel <= 0.15, (n, rel)                        # two bf16-grade evaluations of the same function
     print(f"  fused vs unfused (drop {drop}): loss {lf:.5f} / {lu:.5f}, worst gradient rel l2 difference {worst:.3e}")
+
+
+@pytest.mark.parametrize("M,N,K,relu,flags", [(2048, 384, 3072, True, True), (1280, 384, 768, False, False), (130, 200, 64, True, False),
+                                                (1024, 1152, 1024, False, True)])
+def test_gemm_bf16_nt16_vs_fp64(M, N, K, relu, flags):
+    """The bf16 x bf16 LDS-DMA GEMM of the training input projection (gemm_bf16_dma.hip): exact products of the bf16 operands with
+    fp32 accumulation against fp64, bias / ReLU epilogue, ragged M / N, and the 32-row group filter (rows of skipped groups come out
+    as act(bias))."""
+    from dldkd_amd import native
+    L_ = native.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g)
+    w16 = torch.empty(N, K, dtype=torch.bfloat16, device=DEV)
+    native.check(L_.dldkd_cast_bf16(native.ptr(w.to(DEV)), native.ptr(w16), N * K, native.stream()), "cast")
+    assert torch.equal(w16.cpu(), w.to(torch.bfloat16))                                  # round to nearest even, like torch
+    fl = None
+    keep = torch.ones(M, dtype=torch.bool)
+    if flags:
+        fb = (torch.rand(M // 32, generator=g) > 0.3)
+        fl = fb.to(torch.uint8).to(DEV)
+        keep = fb.repeat_interleave(32)
+    y = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ad = a.to(DEV)
+    assert L_.dldkd_gemm_bf16_nt16_ok(M, N, K, K, K)
+    native.check(L_.dldkd_gemm_bf16_nt16(native.ptr(ad), native.ptr(w16), native.ptr(bias.to(DEV)), native.ptr(y), M, N, K, K, K, N, int(relu),
+                                         native.ptr(fl), native.stream()), "nt16")
+    ref = a.double() @ w.to(torch.bfloat16).double().t() + bias.double()
+    ref[~keep] = bias.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
