@@ -152,10 +152,11 @@ struct LnGradArgs {
     const unsigned char* keep;   // [M, ldx] dropout keep bytes or null
     const float* mean;           // [M]
     const float* rstd;           // [M]
-    float* part_g;               // [row tiles][N]
-    float* part_b;               // [row tiles][N]
+    float* part_g;               // [row tiles][ldp]
+    float* part_b;               // [row tiles][ldp]
     int ldx;
     float keep_scale;
+    int ldp;                     // row stride of the partial sums (N, or 2 N with part_b = part_g + N: ONE column sum finishes both)
 };
 
 template <typename Args>
@@ -238,8 +239,8 @@ __device__ __forceinline__ void gemm_lngrad_tile(const f32x16 (&acc)[2][2], cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (col + e >= p.N) continue;
-            la.part_g[(size_t)(m0 / 128) * p.N + col + e] = sg[e] + og[e];
-            la.part_b[(size_t)(m0 / 128) * p.N + col + e] = sb[e] + ob[e];
+            la.part_g[(size_t)(m0 / 128) * la.ldp + col + e] = sg[e] + og[e];
+            la.part_b[(size_t)(m0 / 128) * la.ldp + col + e] = sb[e] + ob[e];
         }
     }
 }

@@ -466,10 +466,14 @@ extern "C" int dldkd_linear_lngrad(int precision, const float* dy, const float* 
     if (!dy || !W || !x || !mean || !rstd || !workspace || !dgamma || !dbeta) { set_error("linear_lngrad: null pointer"); return DLDKD_EINVAL; }
     const long tiles = (M + 127) / 128;
     if (workspace_bytes < (size_t)2 * tiles * K * sizeof(float)) { set_error("linear_lngrad: workspace too small"); return DLDKD_EINVAL; }
-    LnGradArgs la{x, keep, mean, rstd, workspace, workspace + (size_t)tiles * K, K, keep_scale};
+    // dgamma | dbeta contiguous (the caller's (2, K) buffer): the partial rows are laid out [tile][dgamma K | dbeta K] and ONE column
+    // sum over 2 K columns finishes both; otherwise two planes and two column sums
+    const bool joined = dbeta == dgamma + K;
+    LnGradArgs la{x, keep, mean, rstd, workspace, joined ? workspace + K : workspace + (size_t)tiles * K, K, keep_scale, joined ? 2 * K : K};
     int rc = precision == DLDKD_GEMM_BF16 ? launch_linear_lngrad_bf16(dy, W, M, N, K, la, stream, row_flags)
                                           : launch_linear_lngrad_x3(dy, W, M, N, K, la, stream, row_flags);
     if (rc != DLDKD_OK) return rc;
+    if (joined) return dldkd_colsum_f32(la.part_g, dgamma, tiles, 2L * K, stream);
     rc = dldkd_colsum_f32(la.part_g, dgamma, tiles, K, stream);
     if (rc != DLDKD_OK) return rc;
     return dldkd_colsum_f32(la.part_b, dbeta, tiles, K, stream);

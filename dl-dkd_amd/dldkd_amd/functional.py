@@ -269,16 +269,20 @@ class _InProjTrain(Function):
         if ctx.relu:
             dy2 = dy2.clone()
             native.check(_L().dldkd_relu_bwd_f32(_p(dy2), _p(y.reshape(-1, N)), dy2.numel(), _s()), "relu_bwd")
-        dw = None
+        dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[4]
         if ctx.needs_input_grad[3]:
             if z.dtype == torch.bfloat16:
                 dw = torch.empty(N, K, dtype=torch.float32, device=x2.device)
                 ws, ws_bytes = ops._gemm_workspace(_L(), N, K, M, True, True, x2.device, precision="bf16")
-                native.check(_L().dldkd_gemm_bf16_mixed(1, _p(dy2), _p(z), None, _p(dw), N, K, M, N, K, K, 0, _p(ws), ws_bytes, _p(gflags),
-                                                        _s()), "gemm_bf16_mixed")
+                if want_db:         # the bias gradient = the column sums of dy: taken from the dy tiles the weight-gradient GEMM stages anyway
+                    db = _zeros((N,), x2.device)
+                native.check(_L().dldkd_gemm_bf16_dw_bias(1, _p(dy2), _p(z), _p(dw), N, K, M, N, K, _p(ws), ws_bytes, _p(gflags), _p(db),
+                                                          _s()), "gemm_bf16_dw_bias")
             else:
                 dw = ops.gemm(dy2, z, True, True, N, K, M, row_flags=gflags)
-        db = _colsum(dy2, N) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
+        if want_db and db is None:
+            db = _colsum(dy2, N)
         dg = dbeta = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             if stats is None:
