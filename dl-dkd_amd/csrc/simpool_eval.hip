@@ -221,6 +221,12 @@ __device__ __forceinline__ float xor32_max(float m) {
     return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
 }
 
+// lanes 0..31: max(a[l], a[l + 32]); lanes 32..63: max(b[l - 32], b[l])  - the xor-32 step of two reductions in one swap
+__device__ __forceinline__ float halves_max2(float a, float b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+
 // LDS fragment read the compiler does not track (cdna_hip_programming.md 5.7 form (iii)): hipcc turned the
 // 4-deep B ring into {issue read, s_waitcnt lgkmcnt(0)} pairs, i.e. a full LDS round trip every few k-steps
 // (22 % of wave cycles parked, PMC SQ_WAIT_ANY).  With the reads in asm the waits are hand-counted: exactly
@@ -494,6 +500,295 @@ __global__ __launch_bounds__(256, 1) void simpool_eval16_kernel(const SimpoolEva
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Two videos per wave (pair waves, simpool_eval16p_kernel): all 128 rows of the wave are in use - rows [0, cA) are video A (cA = its
+// length rounded up to 4), rows cA.. video B (its last clip replicated to row 127).  KB = cA / 16 is a template parameter: the
+// tiles below KB fold into mA and the tiles above it into mB exactly like the one-video kernel's running maximum (max3 chains, 2 VALU
+// per tile); only tile KB can hold both videos, and there a lane group (lane >> 4) owns rows 4 g .. 4 g + 3, all of ONE video
+// because the boundary is a multiple of 4: the tile's in-lane maximum goes to both sides through one packed add of the lane's
+// (0, -3e38) / (-3e38, 0) routing pair (x + 0 is exact; x - 3e38 loses to every real score).  19 VALU per sub-tile instead of 16.
+// The kernel is issue-bound at one wave per SIMD (every VALU instruction shows up in the time: measured, ablation_simpool_ragged.md),
+// so the two cross-lane reductions are ONE: permlane32_swap(mA, mB) puts the halves of mA side by side in lanes 0..31 and those of
+// mB in lanes 32..63; one max and one xor-16 step later lanes 0..31 hold video A's scores and lanes 32..63 video B's, and a single
+// store with a per-lane row pointer writes both.  Instruction for instruction the one-video loop + 3 VALU.
+template <int KB>
+__device__ __forceinline__ void score_stream16p(const bf16x8 (&a)[8][kKSteps16], const SimpoolEvalArgs& p, int branch,
+                                                int posA, int posB, int cA, int t0, int T, char* smem) {
+    constexpr int ABL = 0;
+    constexpr int NRT = 8;
+    // this workgroup streams query tiles [t0, t0 + T) of the packed blob
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const char* qsrc = reinterpret_cast<const char*>(p.q[branch]) + (size_t)t0 * kQTileBytes;
+
+    auto stage = [&](int t, int slot) {
+        char* dst = smem + slot * kQTileBytes;
+        const char* src = qsrc + (size_t)t * kQTileBytes;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int piece = wave * 6 + i;
+            glds16(src + piece * 1024 + lane * 16, dst + piece * 1024);
+        }
+    };
+
+    stage(0, 0);
+    if (T > 1) stage(1, 1);
+
+    if constexpr (NRT == 0) {   // padding wave: staging + barriers only
+        int slot2 = 2;
+        for (int t = 0; t < T; ++t) {
+            __syncthreads();
+            if (t + 2 < T) stage(t + 2, slot2);
+            slot2 = slot2 == kRing - 1 ? 0 : slot2 + 1;
+        }
+    } else {
+        // no padding mask: rows of the last tile beyond `len` replicate the video's last valid clip (pack_gallery_kernel),
+        // so they can never change the maximum (same-box A/B against the masked form: 19.07 -> 18.94 ms)
+        float* outp = p.part + ((size_t)branch * p.nv + (lane < 32 ? posA : posB)) * p.nq_pad + (size_t)t0 * kQTile + (lane & 15);
+        const int rowg = 4 * (lane >> 4);
+        constexpr int kPF = 4;                  // B-fragment ring depth (divides 12); lgkmcnt(3) below = kPF - 1
+
+        f32x4 accA[NRT], accB[NRT];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) accB[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 b[kPF];
+        float m = 0.f, m2 = 0.f;
+        const bool first = rowg < cA - 16 * KB;
+        f32x2 route = {first ? 0.f : -3.0e38f, first ? -3.0e38f : 0.f};
+        asm volatile("" : "+v"(route));
+
+        // one 16-query sub-tile: MFMAs into `cur`, max-pool of `prev` sliced between the k-steps
+        auto subtile = [&](auto sub_c, f32x4 (&cur)[NRT], const f32x4 (&prev)[NRT], uint32_t cbase, uint32_t nbase,
+                           float* prev_out, const char* st_src, char* st_dst) {
+            constexpr int S = decltype(sub_c)::value;
+            auto step = [&](auto ks_c) {
+                constexpr int ks = decltype(ks_c)::value;
+                // the ring holds kPF reads in flight, issued one per k-step: all but the 3 newest have landed
+                // (the wait does not name b[]: the MFMAs below are compiler-visible and are kept behind it by the scheduling fence
+                // on the next line; naming the fragment - "+v"(b[ks % kPF]) - measured +0.5 % on the same box, 19.33-19.38 vs
+                // 19.21-19.26 ms)
+                if constexpr (!(ABL & 8)) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) {
+                    if (ks == 0) {
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        cur[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][ks], b[ks % kPF], z, 0, 0, 0);
+                    } else {
+                        cur[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][ks], b[ks % kPF], cur[rt], 0, 0, 0);
+                    }
+                }
+                // (no fence here: the MFMAs, the ring read and the pool slice below form one scheduling region, see the
+                // sched_group_barrier sequence at its end)
+                // keep the B ring kPF k-steps ahead, across the sub-tile and the tile boundary (past the last
+                // tile this reads a stale ring slot: harmless, never consumed)
+                constexpr int idx = S * kKSteps16 + kPF + ks;
+                if constexpr (ABL & 8) { asm volatile("" : "+v"(b[ks % kPF])); }
+                else if constexpr (idx < 2 * kKSteps16) lds_read_frag_off<idx * 1024>(b[ks % kPF], cbase);
+                else lds_read_frag_off<(idx - 2 * kKSteps16) * 1024>(b[ks % kPF], nbase);
+                // slice of the previous sub-tile's key-clip max-pool
+                if constexpr (ABL & 1) {
+                    if constexpr (ks == 11) {   // keep every accumulator (hence every MFMA) live: rule 17
+#pragma unroll
+                        for (int rt = 0; rt < NRT; ++rt) asm volatile("" :: "v"(prev[rt]));
+                    }
+                } else if constexpr (ks < 9) {
+                    if (ks == 0) { m = -3.0e38f; m2 = -3.0e38f; }
+                    if constexpr (ks < KB) {
+                        m = fmaxf(fmaxf(m, prev[ks][0]), prev[ks][1]);
+                        m = fmaxf(fmaxf(m, prev[ks][2]), prev[ks][3]);
+                    } else if constexpr (ks == KB) {
+                        const float tm = fmaxf(fmaxf(prev[ks][0], prev[ks][1]), fmaxf(prev[ks][2], prev[ks][3]));
+                        const f32x2 r = f32x2{tm, tm} + route;
+                        m = fmaxf(m, r[0]);
+                        m2 = fmaxf(m2, r[1]);
+                    } else if constexpr (ks < NRT) {
+                        m2 = fmaxf(fmaxf(m2, prev[ks][0]), prev[ks][1]);
+                        m2 = fmaxf(fmaxf(m2, prev[ks][2]), prev[ks][3]);
+                    }
+                } else if constexpr (ks == 9) {
+                    m = halves_max2(m, m2);
+                } else if constexpr (ks == 10) {
+                    m = xor16_max(m);
+                } else {
+                    *prev_out = m;
+                }
+                // one 1-KiB LDS-DMA piece of tile t+2 per k-step of sub-tile 0 (6 per wave) instead of all six at the top
+                // of the tile, where the MFMA pipe waited for their issue (same-box A/B: 20.27-20.42 -> 20.03-20.06 ms).
+                // They stay older than the tile's two result stores, so the vmcnt(2) before the next barrier still means
+                // "this DMA has landed".
+                if constexpr (S == 0 && ks < 6 && !(ABL & 2)) glds16(st_src + ks * 1024, st_dst + ks * 1024);
+                // Place this k-step's pool slice (VALU) in the shadow of its MFMAs: groups of {2 MFMA, 2 VALU}.  With a hard
+                // fence between the 8 MFMAs and the slice (first version) the VALU issued after the last MFMA and only
+                // its 16-cycle shadow was free.  Same-box A/B at C2: 20.55-20.74 ms fenced, 20.07-20.20 ms {2,2};
+                // {1 MFMA, 1 VALU} x 8 gives nothing (20.70), {2,1} x 4 is equal to {2,2} (20.19).
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+            step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 9>{});
+            step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+        };
+
+        int slot = 0, slot2 = 2;
+        for (int t = 0; t < T; ++t) {
+            // Tile t+1 (and t) must have landed before the barrier; every wave is then done with tile t-1.
+            // VMEM ops retire in order: at t >= 1 the only ops younger than tile t+1's DMA are this wave's two
+            // result stores of iteration t-1, so vmcnt(2) waits for the DMA but not for the stores (a plain
+            // __syncthreads() = vmcnt(0) lgkmcnt(0) also waits for those stores and drains the B-fragment ring).
+            // Measured alternatives that did NOT help (kept out): staging the tile through registers
+            // (global_load + ds_write spread over k-steps) instead of LDS-DMA: 21.1 ms vs 20.4 ms at C2.
+            if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (!(ABL & 3)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t == 0 || !(ABL & 4)) __builtin_amdgcn_s_barrier();
+            // staging of tile t+2 is spread over the k-steps of sub-tile 0; past the end it re-stages tile T-1 into a free slot
+            const int t2 = t + 2 < T ? t + 2 : T - 1;
+            const char* st_src = qsrc + (size_t)t2 * kQTileBytes + (size_t)wave * 6 * 1024 + lane * 16;
+            char* st_dst = smem + slot2 * kQTileBytes + wave * 6 * 1024;
+            const int nslot = slot == kRing - 1 ? 0 : slot + 1;
+            const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
+            const uint32_t cbase = smem_lds + slot * kQTileBytes + lane * 16;
+            const uint32_t nbase = smem_lds + nslot * kQTileBytes + lane * 16;
+            if (t == 0) {
+                lds_read_frag_off<0>(b[0], cbase);
+                lds_read_frag_off<1024>(b[1], cbase);
+                lds_read_frag_off<2048>(b[2], cbase);
+                lds_read_frag_off<3072>(b[3], cbase);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // t == 0: there is no previous sub-tile; its (garbage) result goes to queries 0..15, which the
+            // next sub-tile's store - later in program order, same lanes, same addresses - overwrites.
+            subtile(std::integral_constant<int, 0>{}, accA, accB, cbase, nbase, outp + (t > 0 ? (size_t)t * kQTile - 16 : 0), st_src, st_dst);
+            subtile(std::integral_constant<int, 1>{}, accB, accA, cbase, nbase, outp + (size_t)t * kQTile, st_src, st_dst);
+            slot = nslot;
+            slot2 = slot2 == kRing - 1 ? 0 : slot2 + 1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // retire the (unused) tail of the ring
+        // drain: max-pool of the very last sub-tile
+        m = -3.0e38f;
+        m2 = -3.0e38f;
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            const float tm = fmaxf(fmaxf(accB[rt][0], accB[rt][1]), fmaxf(accB[rt][2], accB[rt][3]));
+            if (rt < KB) m = fmaxf(m, tm);
+            else if (rt > KB) m2 = fmaxf(m2, tm);
+            else { m = fmaxf(m, tm + route[0]); m2 = fmaxf(m2, tm + route[1]); }
+        }
+        m = xor16_max(halves_max2(m, m2));
+        if ((lane & 31) < 16) outp[(size_t)(T - 1) * kQTile + 16] = m;
+    }
+}
+
+struct SimpoolPairArgs {
+    SimpoolEvalArgs e;
+    const int32_t* pairs;    // [n_waves][2]: sorted positions (posA, posB or -1) of the videos a wave scores
+    int n_waves;
+};
+
+// K1 with TWO videos per wave where they fill it: a pair wave's 128 register-resident rows
+// hold video A and, behind it on a 4-row boundary, video B - chosen by the host (scoring.pair_waves) so that
+// 112 < round_up(len A, 4) + len B <= 128.  The ragged TVR gallery (U{24..128} clips) needs ~13.7 k waves instead of 21.8 k and
+// ~5 % fewer 16-row MFMA tiles, every one of them amortising the per-sub-tile costs (B-fragment reads, staging, barrier, pooling
+// tail) over 8 row tiles.  A wave with one video runs the one-video loop unchanged.  Scores are bit-identical to
+// simpool_eval16_kernel's: the same MFMA accumulation per clip row, the same maxima over the same clips.
+__global__ __launch_bounds__(256, 1) void simpool_eval16p_kernel(const SimpoolPairArgs pp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SimpoolEvalArgs& p = pp.e;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int range = blockIdx.x / p.n_wg0;
+    const int b0 = blockIdx.x - range * p.n_wg0;
+    const int branch = b0 / p.n_groups;
+    const int w = (b0 - branch * p.n_groups) * 4 + wave;
+    const int t0 = range * p.tiles_per_range;
+    const int T = min(p.tiles_per_range, p.n_qtiles - t0);
+    int posA = 0, posB = -1, vA = 0, vB = 0, lenA = 0, lenB = 0;
+    if (w < pp.n_waves) {
+        posA = pp.pairs[2 * w];
+        posB = pp.pairs[2 * w + 1];
+        vA = p.order[posA];
+        lenA = p.lens[vA];
+        if (posB >= 0) { vB = p.order[posB]; lenB = p.lens[vB]; }
+    }
+    posA = __builtin_amdgcn_readfirstlane(posA); posB = __builtin_amdgcn_readfirstlane(posB);
+    lenA = __builtin_amdgcn_readfirstlane(lenA); lenB = __builtin_amdgcn_readfirstlane(lenB);
+    const bool pair = posB >= 0 && lenA >= 1 && lenB >= 1 && ((lenA + 3) & ~3) + lenB <= 128;   // (a plan that breaks the rule: A only)
+    const int cA = pair ? (lenA + 3) & ~3 : 128;              // rows [0, cA): video A (its last clip replicated past lenA)
+    const int nrt = pair ? 8 : (lenA + 15) >> 4;
+
+    // stationary operand: lane l holds row (16 rt + l % 16) of the wave, k 32 ks + 8 (l / 16) .. + 8; a row past its video's
+    // length reads the video's last clip (it can tie, never beat, a real clip: no padding mask in the pool)
+    bf16x8 a[8][kKSteps16];
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+        if (rt < nrt) {
+            const int r = 16 * rt + (lane & 15);
+            const bool inA = r < cA;
+            const int v = inA ? vA : vB;
+            const int row = inA ? min(r, max(lenA - 1, 0)) : min(r - cA, lenB - 1);
+            const bf16x8* gv = p.g[branch] + ((size_t)v * p.Lp + row) * kRowBf16x8 + (lane >> 4);
+#pragma unroll
+            for (int ks = 0; ks < kKSteps16; ++ks) a[rt][ks] = gv[ks * 4];
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < kKSteps16; ++ks) a[rt][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < kKSteps16; ++ks) {
+            if (rt * kKSteps16 + ks < 64) asm volatile("" : "+a"(a[rt][ks]));
+            else asm volatile("" : "+v"(a[rt][ks]));
+        }
+    switch (pair ? 8 + (cA >> 4) : nrt) {
+        case 15: score_stream16p<7>(a, p, branch, posA, posB, cA, t0, T, smem); break;
+        case 14: score_stream16p<6>(a, p, branch, posA, posB, cA, t0, T, smem); break;
+        case 13: score_stream16p<5>(a, p, branch, posA, posB, cA, t0, T, smem); break;
+        case 12: score_stream16p<4>(a, p, branch, posA, posB, cA, t0, T, smem); break;
+        case 11: score_stream16p<3>(a, p, branch, posA, posB, cA, t0, T, smem); break;
+        case 10: score_stream16p<2>(a, p, branch, posA, posB, cA, t0, T, smem); break;
+        case 9: score_stream16p<1>(a, p, branch, posA, posB, cA, t0, T, smem); break;
+        case 8:
+            if (pair) score_stream16p<0>(a, p, branch, posA, posB, cA, t0, T, smem);
+            else score_stream16<8>(a, p, branch, posA, t0, T, smem);
+            break;
+        case 7: score_stream16<7>(a, p, branch, posA, t0, T, smem); break;
+        case 6: score_stream16<6>(a, p, branch, posA, t0, T, smem); break;
+        case 5: score_stream16<5>(a, p, branch, posA, t0, T, smem); break;
+        case 4: score_stream16<4>(a, p, branch, posA, t0, T, smem); break;
+        case 3: score_stream16<3>(a, p, branch, posA, t0, T, smem); break;
+        case 2: score_stream16<2>(a, p, branch, posA, t0, T, smem); break;
+        case 1: score_stream16<1>(a, p, branch, posA, t0, T, smem); break;
+        default:
+            score_stream16<0>(a, p, branch, 0, t0, T, smem);           // staging + barriers only
+            // a real video with no valid clip (always a wave of its own): the reference's masked maximum is exactly -1e10
+            if (w < pp.n_waves) {
+                float* row = p.part + ((size_t)branch * p.nv + posA) * p.nq_pad + (size_t)t0 * kQTile;
+                for (int q = lane; q < T * kQTile; q += 64) row[q] = -1e10f;
+            }
+            break;
+    }
+    if (p.done != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(p.done + range, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // fused[q, v] = w0 * part[0][pos(v)][q] + w1 * part[1][pos(v)][q]  (eval.py:254), plus per-branch copies, for the
 // queries [q_lo, q_hi) (q_lo a multiple of 64); output row = q - q_lo.
 // 64 x 64 tiles through LDS: every gathered part row is read as 256 contiguous bytes (float4 per lane) and every output
@@ -698,6 +993,50 @@ int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_pa
     DLDKD_LAUNCH(simpool_eval16_kernel, dim3((unsigned)p.n_wg0 * n_ranges), dim3(256), kRing * kQTileBytes,
                        (hipStream_t)stream, p);
     return check_launch("simpool_eval");
+}
+
+int dldkd_simpool_eval_pairs_bf16(const void* const* q_packed, const void* const* g_packed, const int32_t* lens,
+                                  const int32_t* order, const int32_t* pairs, int n_waves, int nq, int nv, int L, int n_branches,
+                                  int q_split, int32_t* done, void* workspace, void* stream) {
+    if (nq < 0 || nv < 0 || n_waves < 0 || n_waves > nv || L < 1 || L > DLDKD_MAX_CLIPS || n_branches < 1 || n_branches > 2 || q_split < 0) {
+        set_error("simpool_eval_pairs: bad sizes nq=%d nv=%d waves=%d L=%d branches=%d q_split=%d", nq, nv, n_waves, L, n_branches, q_split);
+        return DLDKD_EINVAL;
+    }
+    if (nq == 0 || nv == 0) return DLDKD_OK;
+    if (!q_packed || !g_packed || !lens || !order || !pairs || !workspace || !q_packed[0] || !g_packed[0] ||
+        (n_branches == 2 && (!q_packed[1] || !g_packed[1]))) {
+        set_error("simpool_eval_pairs: null pointer");
+        return DLDKD_EINVAL;
+    }
+    SimpoolPairArgs pp;
+    SimpoolEvalArgs& p = pp.e;
+    for (int b = 0; b < 2; ++b) {
+        p.q[b] = (const bf16x8*)q_packed[b < n_branches ? b : 0];
+        p.g[b] = (const bf16x8*)g_packed[b < n_branches ? b : 0];
+    }
+    p.lens = lens;
+    p.order = order;
+    p.part = (float*)workspace;
+    p.done = done;
+    p.nq_pad = round_up(nq, kQTile);
+    p.nv = nv;
+    p.Lp = round_up(L, 32);
+    p.n_qtiles = p.nq_pad / kQTile;
+    p.n_groups = (n_waves + 3) / 4;
+    p.n_wg0 = p.n_groups * n_branches;
+    const int split = q_split > 0 ? (q_split < p.n_qtiles ? q_split : p.n_qtiles) : pick_q_split(p.n_wg0, p.n_qtiles, 1);
+    p.tiles_per_range = (p.n_qtiles + split - 1) / split;
+    const int n_ranges = (p.n_qtiles + p.tiles_per_range - 1) / p.tiles_per_range;
+    p.ablate = 0;
+    pp.pairs = pairs;
+    pp.n_waves = n_waves;
+    static const bool attr_ok = [] {
+        return hipFuncSetAttribute((const void*)simpool_eval16p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kRing * kQTileBytes) == hipSuccess;
+    }();
+    (void)attr_ok;
+    DLDKD_LAUNCH(simpool_eval16p_kernel, dim3((unsigned)p.n_wg0 * n_ranges), dim3(256), kRing * kQTileBytes, (hipStream_t)stream, pp);
+    return check_launch("simpool_eval_pairs");
 }
 
 int dldkd_simpool_finish_range(const void* workspace, const int32_t* inv_order, int nq, int nv, int n_branches, float w0,

@@ -232,12 +232,14 @@ class HipShardBackend(ShardScorerBackend):
         # the range split is the KERNEL's (one planner, scoring.plan_query_split): a caller-made split that names more ranges
         # than the kernel creates would park the side stream on a counter nobody bumps
         nq = queries[0].shape[0]
-        self.n_ranges, self.per_range = scoring.plan_query_split(nq, gallery.nv, gallery.n_branches, min_split=min_ranges)
+        # (the grid is made of WAVES: with pair waves - two short videos per wave - fewer than one per video)
+        waves = gallery.scorer_waves()
+        self.n_ranges, self.per_range = scoring.plan_query_split(nq, waves, gallery.n_branches, min_split=min_ranges)
         self.bounds = [(lo, min(lo + self.per_range, nq)) for lo in range(0, max(nq, 1), self.per_range)]
         if len(self.bounds) != self.n_ranges or self.bounds[0][0] != 0 or self.bounds[-1][1] != nq:
             raise native.NativeError(f"HipShardBackend: {len(self.bounds)} ranges of {self.per_range} do not tile {nq} queries in "
                                      f"{self.n_ranges} kernel ranges")
-        self.arrivals = (gallery.nv + 3) // 4 * gallery.n_branches
+        self.arrivals = (waves + 3) // 4 * gallery.n_branches
         self.ws = torch.empty(native.lib().dldkd_simpool_eval_workspace_bytes(queries[0].shape[0], gallery.nv, gallery.n_branches),
                               dtype=torch.uint8, device=gallery.lens.device)
         self.pq = None

@@ -30,6 +30,8 @@ SIGNATURES = {
     "dldkd_pack_gallery_bf16": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_simpool_eval_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                           _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_simpool_eval_pairs_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                                                _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_simpool_eval_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "dldkd_simpool_finish_range": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_float, _c_int, _c_int,
                                              _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),

@@ -4,12 +4,16 @@ Mirrors what DLDKD.get_sim_scores + compute_query2ctx_info + eval_epoch's fusion
 (method/model.py:307-329, method/eval.py:200-208,254) but keeps the gallery resident in a packed bf16
 layout and never builds the (Nq, L, Nv) clip tensor.
 """
+import os
+
 import torch
 
 from . import native
 
 HIDDEN = 384
 MAX_CLIPS = 128
+# K1 with two videos per wave where they fit (dldkd_simpool_eval_pairs_bf16; profiles/r04/ablation_simpool_ragged.md)
+PAIR_WAVES = os.environ.get("DLDKD_K1_PAIR_WAVES", "1") == "1"
 
 
 def _f32c(t):
@@ -37,6 +41,69 @@ class PackedGallery:
     @property
     def n_branches(self):
         return len(self.blobs)
+
+    def pair_plan(self):
+        """(pairs int32 GPU tensor (n_waves, 2), n_waves, n_paired) for dldkd_simpool_eval_pairs_bf16, built once per gallery (one
+        copy of the lens to the host: part of packing, outside any timed region)."""
+        if getattr(self, "_pairs", None) is None:
+            host = pair_waves(self.lens[self.order.long()].cpu().numpy())
+            self._pairs = (torch.from_numpy(host).to(self.lens.device), int(host.shape[0]), int((host[:, 1] >= 0).sum()))
+        return self._pairs
+
+    def scorer_waves(self):
+        """Waves of one branch of the scorer launch (its grid is ceil(waves / 4) workgroups per branch and query range)."""
+        if PAIR_WAVES and self.nv:
+            n_waves, n_paired = self.pair_plan()[1:]
+            if n_paired:
+                return n_waves
+        return self.nv
+
+
+def pair_waves(sorted_lens, rows=MAX_CLIPS):
+    """Two videos per scorer wave where they FILL it.  sorted_lens: clip counts in visiting order (descending, <= rows).  Video A of
+    a pair ends on a 4-row boundary (the pooling routes whole 4-row lane groups) and a pair is only formed if it needs all eight
+    16-row tiles (the pair loop is built for 8): round_up(len A, 4) + len B in (rows - 16, rows].  Greedy on the length histogram,
+    longest first: a video takes the longest unplaced video that still fits behind it (best fit); everything else stays a wave of
+    its own.  Videos of one length are interchangeable, so the plan is made per (len A, len B) class - a few hundred steps
+    whatever the gallery size - and materialised with numpy.  Returns int32 (n_waves, 2) rows (posA, posB or -1) in wave order:
+    long and full waves first, the grid's tail light."""
+    import numpy as np
+    sl = np.asarray(sorted_lens, dtype=np.int64)
+    n = int(sl.shape[0])
+    if n == 0:
+        return np.zeros((0, 2), dtype=np.int32)
+    if int(sl.max()) > rows or int(sl.min()) < 0 or (n > 1 and bool((sl[1:] > sl[:-1]).any())):
+        raise native.NativeError("pair_waves: lengths must be descending and in [0, %d]" % rows)
+    cnt = np.bincount(sl, minlength=rows + 1)
+    start = n - np.cumsum(cnt)                      # positions of length a: start[a] .. start[a] + cnt[a] - 1
+    front = [0] * (rows + 1)                        # taken from the front of a class (as A or alone) / from its back (as B)
+    back = [0] * (rows + 1)
+    cnt = cnt.tolist()
+    pa, pb = [], []
+    for a in range(rows, -1, -1):
+        a4 = (a + 3) // 4 * 4
+        while cnt[a] - front[a] - back[a] > 0:
+            free_a = cnt[a] - front[a] - back[a]
+            b, k = -1, 0
+            if a > 0:
+                for c in range(min(rows - a4, a), max(rows - 16 - a4, 0), -1):
+                    free_c = cnt[c] - front[c] - back[c]
+                    k = free_c // 2 if c == a else min(free_a, free_c)
+                    if k > 0:
+                        b = c
+                        break
+            first = int(start[a]) + front[a]
+            if b < 0:
+                pa.append(np.arange(first, first + free_a))
+                pb.append(np.full(free_a, -1, dtype=np.int64))
+                front[a] += free_a
+            else:
+                last = int(start[b]) + cnt[b] - 1 - back[b]
+                pa.append(np.arange(first, first + k))
+                pb.append(np.arange(last, last - k, -1))
+                front[a] += k
+                back[b] += k
+    return np.stack([np.concatenate(pa), np.concatenate(pb)], axis=1).astype(np.int32)
 
 
 def pack_queries(qs, normalize=True):
@@ -162,7 +229,13 @@ def simpool_partials(pq, pg, workspace=None, q_split=0, done=None):
         workspace = torch.empty(need, dtype=torch.uint8, device=pg.lens.device)
     if done is not None and (done.dtype != torch.int32 or done.numel() < max(q_split, 1)):
         raise native.NativeError("simpool_partials: `done` must hold one int32 per query range")
-    if pq.nq and pg.nv:
+    if pq.nq and pg.nv and pg.scorer_waves() != pg.nv:
+        pairs, n_waves, _ = pg.pair_plan()
+        native.check(L_.dldkd_simpool_eval_pairs_bf16(native.ptr_array(pq.blobs), native.ptr_array(pg.blobs), native.ptr(pg.lens),
+                                                      native.ptr(pg.order), native.ptr(pairs), n_waves, pq.nq, pg.nv, pg.L, nb,
+                                                      int(q_split), native.ptr(done), native.ptr(workspace), native.stream()),
+                     "simpool_eval_pairs")
+    elif pq.nq and pg.nv:
         native.check(L_.dldkd_simpool_eval_bf16(native.ptr_array(pq.blobs), native.ptr_array(pg.blobs), native.ptr(pg.lens),
                                                 native.ptr(pg.order), pq.nq, pg.nv, pg.L, nb, int(q_split), native.ptr(done),
                                                 native.ptr(workspace), native.stream()), "simpool_eval")

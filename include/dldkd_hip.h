@@ -99,6 +99,17 @@ int dldkd_simpool_eval_bf16(const void* const* q_packed, const void* const* g_pa
                             const int32_t* order, int nq, int nv, int L, int n_branches, int q_split, int32_t* done,
                             void* workspace, void* stream);
 
+/* The same scores from PAIR WAVES: wave w of the launch scores the videos at sorted positions pairs[2 w] and pairs[2 w + 1]
+ * (-1 = none) in its 128 register-resident rows - video A in rows [0, round_up(len A, 4)), video B behind it; the caller pairs
+ * them so that 112 < round_up(len A, 4) + len B <= 128 (scoring.pair_waves; a pair that does not fit is scored as A alone).  A
+ * ragged gallery then needs fewer, full waves (TVR lengths U{24..128}: ~13.7 k waves instead of 21.8 k, 5 % fewer 16-row MFMA
+ * tiles).  Every position of `order` appears in exactly one wave.  The workspace layout and contents are those of
+ * dldkd_simpool_eval_bf16, bit for bit (same finish / rank entry points); done[s] counts ceil(n_waves/4) * n_branches
+ * workgroups. */
+int dldkd_simpool_eval_pairs_bf16(const void* const* q_packed, const void* const* g_packed, const int32_t* lens,
+                                  const int32_t* order, const int32_t* pairs, int n_waves, int nq, int nv, int L, int n_branches,
+                                  int q_split, int32_t* done, void* workspace, void* stream);
+
 /* HOST-side planning of the query split (no GPU work): the number of ranges (>= min_split when nq allows it) that
  * minimises the modelled time of dldkd_simpool_eval_bf16 on 256 CUs, and the queries per range (a multiple of 32; the
  * last range is shorter).  Pass *n_ranges as q_split. */

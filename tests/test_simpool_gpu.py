@@ -164,13 +164,48 @@ def test_query_split_is_bit_invariant(nq, nv, L, len_lo):
             tiles = (n_tiles + eff - 1) // eff
             n_ranges = (n_tiles + tiles - 1) // tiles
             want = torch.zeros(64, dtype=torch.int32)
-            want[:n_ranges] = (nv + 3) // 4 * 2
+            want[:n_ranges] = (pg.scorer_waves() + 3) // 4 * 2         # (pair waves: fewer than one wave per video)
             assert torch.equal(done.cpu(), want), (split, done[:8].tolist())
         # per-range finish assembles the same matrix
         if split in (3, 5):
             per = ((n_tiles + min(split, n_tiles) - 1) // min(split, n_tiles)) * 32
             rows = [scoring.simpool_finish(ws, pq, pg, q_range=(lo, min(lo + per, nq)))[0] for lo in range(0, nq, per)]
             assert torch.equal(torch.cat(rows, 0), ref[0])
+
+
+@pytest.mark.parametrize("nq,nv,L,len_lo", [(100, 37, 128, 0), (257, 301, 128, 1), (64, 5, 32, 3), (1000, 2000, 128, 24), (33, 1, 128, 128),
+                                            (500, 777, 100, 1), (129, 64, 64, 60), (70, 333, 128, 100), (40, 50, 128, 57)])
+def test_pair_waves_are_bit_identical_to_one_video_per_wave(nq, nv, L, len_lo):
+    """dldkd_simpool_eval_pairs_bf16 (two videos per wave where they fill its 128 rows: the default on ragged galleries) against
+    dldkd_simpool_eval_bf16 on the same packed operands: the partial planes must be equal BIT FOR BIT - the same MFMA accumulation
+    per clip row, the same maxima over the same clips - for every boundary position (len A mod 16, mod 4), zero-length videos,
+    galleries where nothing pairs, with and without a query split and its arrival counters."""
+    from dldkd_amd import scoring
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(1000 + nv)
+    lens = torch.randint(len_lo, L + 1, (nv,), generator=g)
+    mask = (torch.arange(L)[None, :] < lens[:, None]).float().to(dev)
+    gs = [torch.randn(nv, L, 384, generator=g).to(dev) for _ in range(2)]
+    pq = scoring.pack_queries([torch.randn(nq, 384, generator=g).to(dev) for _ in range(2)])
+    pg = scoring.pack_gallery(gs, mask)
+    n = 2 * nv * ((nq + 31) // 32 * 32)
+    was = scoring.PAIR_WAVES
+    try:
+        scoring.PAIR_WAVES = False
+        assert pg.scorer_waves() == nv
+        ref = scoring.simpool_partials(pq, pg).view(torch.int32)[:n].clone()
+        scoring.PAIR_WAVES = True
+        plan, n_waves, n_paired = pg.pair_plan()
+        for split in (0, 3):
+            done = torch.zeros(8, dtype=torch.int32, device=dev) if split else None
+            got = scoring.simpool_partials(pq, pg, q_split=split, done=done).view(torch.int32)[:n]
+            assert torch.equal(got, ref), (split, n_waves, n_paired)
+            if split and (nq + 31) // 32 >= 3:
+                assert done[:3].tolist() == [(pg.scorer_waves() + 3) // 4 * 2] * 3
+    finally:
+        scoring.PAIR_WAVES = was
+    if len_lo in (1, 24, 57, 60):
+        assert n_paired > 0 and n_waves == nv - n_paired
 
 
 def test_planned_split_fills_the_chip():
