@@ -617,7 +617,7 @@ def main():
                            "gallery_pack_ms_untimed": r2["gallery_pack_ms_untimed"]},
                 "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS * world, "unit": "TFLOP/s",
                              "frac": achieved / (PEAK_BF16_TFLOPS * world), "traffic": None,
-                             "kernel": "simpool_eval16_kernel on every rank (one launch, query ranges in order) + per-range finish and "
+                             "kernel": "simpool_eval16p_kernel on every rank (one launch, query ranges in order) + per-range finish and "
                                        "all_gather on a side stream; `achieved` = all ranks' algorithmic flops / the step's wall time "
                                        "(max over ranks), `peak` = world x 2.5 PF",
                              "kernel_ms": r2["step_stream_ms"], "algorithmic_flops_per_launch": r2["flops_per_step_all_ranks"] / world},
@@ -677,7 +677,7 @@ def main():
         # KiB units; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md section HBM) from the committed
         # profile of this same workload.  Not re-measured live (PMC needs the profiler).
         traffic, traffic_src = None, None
-        for rnd in ("r03", "r02"):
+        for rnd in ("r04", "r03", "r02"):
             pmc = os.path.join(ROOT, "profiles", rnd, "pmc_simpool", "summary.json")
             if os.path.exists(pmc):
                 d = json.load(open(pmc))
@@ -695,7 +695,9 @@ def main():
                        "gallery_pack_ms_untimed": round(pack_gallery_ms, 2)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src, "kernel": "simpool_eval16_kernel", "kernel_ms": kern_ms,
+                         "traffic_source": traffic_src, "kernel_ms": kern_ms,
+                         "kernel": "simpool_eval16p_kernel" if pg.scorer_waves() != pg.nv else "simpool_eval16_kernel",
+                         "scorer_waves": pg.scorer_waves(),
                          "algorithmic_flops_per_launch": flops_launch},
         }
         if sustained and sustained.get("random_16x16x32"):

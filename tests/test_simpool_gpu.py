@@ -200,8 +200,11 @@ def test_pair_waves_are_bit_identical_to_one_video_per_wave(nq, nv, L, len_lo):
             done = torch.zeros(8, dtype=torch.int32, device=dev) if split else None
             got = scoring.simpool_partials(pq, pg, q_split=split, done=done).view(torch.int32)[:n]
             assert torch.equal(got, ref), (split, n_waves, n_paired)
-            if split and (nq + 31) // 32 >= 3:
-                assert done[:3].tolist() == [(pg.scorer_waves() + 3) // 4 * 2] * 3
+            if split:
+                n_tiles = (nq + 31) // 32
+                per = -(-n_tiles // min(split, n_tiles))
+                n_ranges = -(-n_tiles // per)
+                assert done.tolist() == [(pg.scorer_waves() + 3) // 4 * 2] * n_ranges + [0] * (8 - n_ranges)
     finally:
         scoring.PAIR_WAVES = was
     if len_lo in (1, 24, 57, 60):
