@@ -37,6 +37,7 @@ struct Args {
     const float* cs;           // [768] colsum of W'
     const float* bb;           // [768] W.beta + b
     float* y[2];               // columns [0, 384) -> y[0], [384, 768) -> y[1]; row stride 384
+    int y16;                   // y[] are bf16 rows (row stride 384 bf16) - what the fused tower reads (dldkd_tower_seq_bf16_h16)
     long M;
     int K;
     int relu;
@@ -81,6 +82,7 @@ __device__ __forceinline__ void gstore32(uint32_t voff, float v, const char* sba
     asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(sbase), "i"(OFF) : "memory");
 }
 
+template <bool Y16>
 __global__ __launch_bounds__(256, 1) void in_proj_rows128b_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -315,8 +317,56 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128b_kernel(const Args p) 
                 });
             }
         };
-        if (full) epilogue(std::true_type{});
-        else epilogue(std::false_type{});
+        // the same as bf16 rows: a lane holds ONE column of 4 rows; lanes 2 c', 2 c' + 1 trade a value (DPP quad_perm [1,0,3,2]) so
+        // that the even lane owns columns (c, c + 1) of row e and the odd lane the same columns of row e + 1: one
+        // v_cvt_pk_bf16_f32 and one dword store each - 16 lanes = a 64-byte row segment, half the store instructions of the fp32 form
+        auto epilogue16 = [&](auto fullc) {
+            constexpr bool FULL = decltype(fullc)::value;
+            const bool odd = lane & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ti = (i + wave) & 3;
+                const long m0 = ti == 0 ? grow[0] : ti == 1 ? grow[1] : ti == 2 ? grow[2] : grow[3];
+                const char* yt = ybranch + (size_t)m0 * (kHidden * 2);
+                static_for<0, 4>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    const char* yg = yt + g * 8 * (kHidden * 2);
+                    const f32x4 mean4 = *reinterpret_cast<const f32x4*>(s_mean + 32 * ti + 8 * g + hrow);
+                    const f32x4 rstd4 = *reinterpret_cast<const f32x4*>(s_rstd + 32 * ti + 8 * g + hrow);
+                    static_for<0, 2>([&](auto pc) {
+                        constexpr int e0 = 2 * decltype(pc)::value;
+                        // (rows e0 + lane parity, the lane pair's two columns)
+                        const uint32_t vo16 = (uint32_t)((hrow + e0 + (lane & 1)) * (kHidden * 2) + ((wave & 1) * RWC + (lane & 30)) * 2);
+                        const bool inside = FULL || m0 + 8 * g + hrow + e0 + (odd ? 1 : 0) < p.M;
+                        static_for<0, 6>([&](auto jc) {
+                            constexpr int j = decltype(jc)::value;
+                            float t0, t1;
+                            if constexpr (j < 4) {
+                                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t0) : "a"(acc[i][j][4 * g + e0]));
+                                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t1) : "a"(acc[i][j][4 * g + e0 + 1]));
+                            } else {
+                                t0 = acc[i][j][4 * g + e0];
+                                t1 = acc[i][j][4 * g + e0 + 1];
+                            }
+                            float v0 = rstd4[e0] * (t0 - mean4[e0] * csn[j]) + bbn[j];
+                            float v1 = rstd4[e0 + 1] * (t1 - mean4[e0 + 1] * csn[j]) + bbn[j];
+                            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                            const float give = odd ? v0 : v1;                       // what the partner lane needs
+                            const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
+                            const unsigned lo = f32_to_bf16_bits(odd ? got : v0), hi = f32_to_bf16_bits(odd ? v1 : got);
+                            if (inside) gstore32<64 * j>(vo16, __builtin_bit_cast(float, lo | (hi << 16)), yg);
+                        });
+                    });
+                });
+            }
+        };
+        if constexpr (Y16) {
+            if (full) epilogue16(std::true_type{});
+            else epilogue16(std::false_type{});
+        } else {
+            if (full) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
+        }
         if (!more) break;
         tile = tnext;
         xsrc = xsrc_n;
@@ -332,9 +382,25 @@ using namespace dldkd;
 
 extern "C" int dldkd_in_proj_bf16_rows128b_ok(int K) { return K >= 8 * k4b::RK && K % (2 * k4b::RK) == 0 && (long)127 * K * 2 + 128 <= 0xFFFFFFFFL; }
 
+static int rows128b_launch(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
+                           const float* bb, void* y0, void* y1, int y16, long M, int K, int relu, const int32_t* groups,
+                           long n_groups, void* stream);
+
 extern "C" int dldkd_in_proj_bf16_rows128b(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
                                            const float* bb, float* y0, float* y1, long M, int K, int relu, const int32_t* groups,
                                            long n_groups, void* stream) {
+    return rows128b_launch(x_bf16, mean, rstd, Wfrag, cs, bb, y0, y1, 0, M, K, relu, groups, n_groups, stream);
+}
+
+extern "C" int dldkd_in_proj_bf16_rows128b_out16(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
+                                                 const float* bb, void* y0_bf16, void* y1_bf16, long M, int K, int relu,
+                                                 const int32_t* groups, long n_groups, void* stream) {
+    return rows128b_launch(x_bf16, mean, rstd, Wfrag, cs, bb, y0_bf16, y1_bf16, 1, M, K, relu, groups, n_groups, stream);
+}
+
+static int rows128b_launch(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
+                           const float* bb, void* y0, void* y1, int y16, long M, int K, int relu, const int32_t* groups,
+                           long n_groups, void* stream) {
     if (M < 0 || !dldkd_in_proj_bf16_rows128b_ok(K)) {
         set_error("in_proj_bf16_rows128b: K must be a multiple of %d, at least %d (M=%ld K=%d)", 2 * k4b::RK, 8 * k4b::RK, M, K);
         return DLDKD_EINVAL;
@@ -345,7 +411,7 @@ extern "C" int dldkd_in_proj_bf16_rows128b(const void* x_bf16, const float* mean
     if (groups != nullptr && (n_groups < 0 || (n_groups & 3))) { set_error("in_proj_bf16_rows128b: the group table must hold a multiple of 4 groups"); return DLDKD_EINVAL; }
     if (groups != nullptr && n_groups == 0) return DLDKD_OK;
     const long ntiles = groups != nullptr ? n_groups / 4 : (M + k4b::RM - 1) / k4b::RM;
-    k4b::Args p{(const unsigned short*)x_bf16, mean, rstd, (const char*)Wfrag, cs, bb, {y0, y1}, M, K, relu != 0, groups, ntiles};
+    k4b::Args p{(const unsigned short*)x_bf16, mean, rstd, (const char*)Wfrag, cs, bb, {(float*)y0, (float*)y1}, y16, M, K, relu != 0, groups, ntiles};
     constexpr int lds = 4 * k4b::WREGION;       // all 160 KiB
     static int n_cu = 0;                        // one persistent workgroup per CU
     if (!n_cu) {
@@ -354,8 +420,10 @@ extern "C" int dldkd_in_proj_bf16_rows128b(const void* x_bf16, const float* mean
         n_cu = v;
     }
     const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu));
-    static const bool ok = hipFuncSetAttribute((const void*)k4b::in_proj_rows128b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    static const bool ok = hipFuncSetAttribute((const void*)k4b::in_proj_rows128b_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
+                           hipFuncSetAttribute((const void*)k4b::in_proj_rows128b_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
     (void)ok;
-    DLDKD_LAUNCH(k4b::in_proj_rows128b_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    if (y16) DLDKD_LAUNCH(k4b::in_proj_rows128b_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    else DLDKD_LAUNCH(k4b::in_proj_rows128b_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("in_proj_bf16_rows128b");
 }

@@ -60,6 +60,8 @@ constexpr int kStgPitch = 400;                 // output staging: 32 rows x 384 
 constexpr int kPosTile = kNKS * 64 * 8;        // floats of one 32-position tile of the position table in fragment order
 constexpr int kInStage = 32 * 1024;            // prologue: h0 half-rows are staged at [32 KiB + wave * 24 KiB, +24 KiB) of LDS
 
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -94,7 +96,8 @@ __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
 }
 
 struct TowerArgs {
-    const float* h0[2];       // per branch: input-projection output, rows (., 384) fp32
+    const float* h0[2];       // per branch: input-projection output, rows (., 384) fp32 ...
+    const unsigned short* h0b[2];   // ... or (H16 kernels) the same rows as bf16, written so by K4b (dldkd_in_proj_bf16_rows128b_out16)
     const char* blob[2];      // per branch: weight fragments in stream order, the parameter table, the position table in
                               // fragment order
     const int32_t* row0;      // [n_seq] first row of the sequence in h0 / out; null: seq * seq_rows
@@ -115,7 +118,7 @@ struct TowerArgs {
 // OUTMAP: the stream ends with the 384 x 384 out_mapping_linear (video towers); OUTMODE 0: fp32 rows, 1: packed bf16 gallery,
 // 2 (query towers, sequences of at most 32 words, one per wave): the modular attention pooling of get_modularized_queries
 // (method/model.py:245-258) on top: softmax_l(mask_logits(w . h2_l)) -> sum_l a_l h2_l, one 384-vector per sequence.
-template <bool OUTMAP, int OUTMODE, bool STAMP = false>
+template <bool OUTMAP, int OUTMODE, bool STAMP = false, bool H16 = false>
 __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
     unsigned long long ts[16], tp[8];
     int n_tp = 0;
@@ -248,7 +251,55 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
     // ROTATED by the row (16-byte position p of row r holds chunk (p + r) mod 48 - done on the per-lane SOURCE address, the
     // LDS side of an LDS-DMA is linear), so the ds_read_b128 of 16 lanes = 16 different rows hit 16 different bank groups.
     bf16x8 X1[kNKS];     // h1^T (later h2^T) as MFMA operand fragments: lane = (row r, half h), k-step ks, 8 features
-    {
+    float x[kNKS][8];    // h0 + pos for the lane's 192 features, parked in the accumulator half of the register file (x is needed
+                         // twice: for the statistics and for the normalisation)
+    float s = 0.f, q = 0.f;
+    if constexpr (H16) {
+        // bf16 h0 (K4b writes it so: half the bytes both ways): a row is 768 B, the lane pair (r, 0), (r, 1) reads 32 contiguous
+        // bytes of row r per k-step - features 16 ks + 8 h .. + 7 - and one v_permlane32_swap per dword pair turns that into the
+        // fragment's feature set {16 ks + 4 h + 0..3, 16 ks + 8 + 4 h + 0..3}.  All 24 loads (96 VGPRs) fly at once: ONE HBM round
+        // trip, no LDS staging, no rotation.
+        const int l = 32 * tile + r, lrow = l < nrows ? l : nrows - 1;                          // rows past the sequence: a finite copy
+        const u32x4v* src = reinterpret_cast<const u32x4v*>(p.h0b[branch] + ((size_t)row0 + lrow) * kHidden + 8 * h);
+        u32x4v raw[kNKS];
+#pragma unroll
+        for (int ks = 0; ks < kNKS; ++ks) raw[ks] = __builtin_nontemporal_load(src + 2 * ks);
+        pstamp();                                                      // p0: row loads issued
+        {   // parameter table
+            const f32x4* psrc = reinterpret_cast<const f32x4*>(wsrc + (size_t)NFRAG * 1024);
+            f32x4* dst = reinterpret_cast<f32x4*>(par);
+            for (int i = tid; i < (P_TOTAL + P_TAIL) / 4; i += 256) dst[i] = psrc[i];
+        }
+        const float* posf = reinterpret_cast<const float*>(wsrc + (size_t)NFRAG * 1024 + (P_TOTAL + P_TAIL) * 4) +
+                            (size_t)tile * kPosTile + lane * 8;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 pz[12][2];
+#pragma unroll
+            for (int k2 = 0; k2 < 12; ++k2) {
+                pz[k2][0] = *reinterpret_cast<const f32x4*>(posf + (12 * half + k2) * 512);
+                pz[k2][1] = *reinterpret_cast<const f32x4*>(posf + (12 * half + k2) * 512 + 4);
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 12; ++k2) {
+                const int ks = 12 * half + k2;
+                const auto s0 = __builtin_amdgcn_permlane32_swap(raw[ks][0], raw[ks][2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(raw[ks][1], raw[ks][3], false, false);
+                const unsigned w[4] = {(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};   // feature pairs in order
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float hv = __builtin_bit_cast(float, (e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16));
+                    const float v = hv + pz[k2][e >> 2][e & 3];
+                    s += v;
+                    q += v * v;
+                    x[ks][e] = v;
+                    asm volatile("" : "+a"(x[ks][e]));
+                }
+            }
+            if (half == 0) pstamp();                                   // p1: rows landed, first half combined
+        }
+        pstamp(); pstamp(); pstamp();                                  // (p2 .. p4: stages of the fp32 prologue only)
+    } else {
         const uint32_t stage = smem_lds + kInStage + wave * (24 * 1024);
         // wave-uniform (one sequence per wave); made provably so for the asm's "s" operand (cdna_hip_programming.md T20)
         const uint64_t hs64 = reinterpret_cast<uint64_t>(p.h0[branch] + (size_t)row0 * kHidden);
@@ -276,10 +327,6 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         }
         const float* posf = reinterpret_cast<const float*>(wsrc + (size_t)NFRAG * 1024 + (P_TOTAL + P_TAIL) * 4) +
                             (size_t)tile * kPosTile + lane * 8;
-        // h0 + pos for the lane's 192 features, parked in the accumulator half of the register file (x is needed twice: for the
-        // statistics and for the normalisation)
-        float x[kNKS][8];
-        float s = 0.f, q = 0.f;
         const int rot = 48 - r;                                        // (c - r) mod 48 = (c + rot) mod 48, c < 48
         const char* stg_lane = smem + kInStage + wave * (24 * 1024) + r * 768;
 #pragma unroll
@@ -312,9 +359,12 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
             pstamp();                                                  // p2 / p4: half read
             if (half == 0) dma_half(1);
         }
+    }
+    {
         const float mean = half_swap_sum(s) * (1.f / kHidden);
         const float rstd = rsqrtf(fmaxf(half_swap_sum(q) * (1.f / kHidden) - mean * mean, 0.f) + 1e-5f);
         const float nmr = -mean * rstd;
+        if constexpr (H16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // weight chunk 0 landed (older than the row loads)
         __syncthreads();                                               // parameter table visible; every wave is done with its staging
         pstamp();                                                      // p5: workgroup met
         issue_chunk(std::integral_constant<int, 1>{});                 // (chunks 1 and 2 land where the staging was)
@@ -753,10 +803,30 @@ int dldkd_tower_pack_bf16(const float* ln1_g, const float* ln1_b, const float* w
     return check_launch("tower_pack");
 }
 
+static int tower_seq_launch(const void* const* h0, int h16, const void* const* blob, const int32_t* row0,
+                            const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
+                            int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
+                            void* stream);
+
 int dldkd_tower_seq_bf16(const float* const* h0, const void* const* blob, const int32_t* row0,
                          const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                          int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
                          void* stream) {
+    return tower_seq_launch((const void* const*)h0, 0, blob, row0, lens, items, n_items, n_seq, n_branches, out_mode, out_rows, seq_rows,
+                            gallery, v0, Lp, lens_out, stream);
+}
+
+int dldkd_tower_seq_bf16_h16(const void* const* h0_bf16, const void* const* blob, const int32_t* row0,
+                             const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
+                             void* const* gallery, int v0, int Lp, int32_t* lens_out, void* stream) {
+    return tower_seq_launch(h0_bf16, 1, blob, row0, lens, items, n_items, n_seq, n_branches, 1, nullptr, 0, gallery, v0, Lp, lens_out,
+                            stream);
+}
+
+static int tower_seq_launch(const void* const* h0, int h16, const void* const* blob, const int32_t* row0,
+                            const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
+                            int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
+                            void* stream) {
     if (n_items < 0 || n_seq < 0 || (n_branches != 1 && n_branches != 2) || out_mode < 0 || out_mode > 2 || seq_rows < 0 ||
         seq_rows > 128 || (!row0 && seq_rows < 1) || (out_mode == 1 && (Lp < 32 || Lp > 128 || (Lp & 31) || v0 < 0)) ||
         (out_mode == 2 && !items && n_items != (n_seq + 3) / 4)) {
@@ -771,7 +841,7 @@ int dldkd_tower_seq_bf16(const float* const* h0, const void* const* blob, const 
     }
     tw::TowerArgs p{};
     for (int b = 0; b < n_branches; ++b) {
-        p.h0[b] = h0[b]; p.blob[b] = (const char*)blob[b];
+        p.h0[b] = (const float*)h0[b]; p.h0b[b] = (const unsigned short*)h0[b]; p.blob[b] = (const char*)blob[b];
         if (out_mode == 0) p.out[b] = out_rows[b]; else if (out_mode == 2) p.pooled[b] = out_rows[b]; else p.gal[b] = (char*)gallery[b];
         if (!p.h0[b] || !p.blob[b] || (out_mode == 1 ? !p.gal[b] : !out_rows[b])) { set_error("tower_seq: null branch pointer"); return DLDKD_EINVAL; }
         if (((uintptr_t)p.h0[b] | (uintptr_t)p.blob[b] | (uintptr_t)p.out[b] | (uintptr_t)p.gal[b] | (uintptr_t)p.pooled[b]) & 15) {
@@ -785,6 +855,7 @@ int dldkd_tower_seq_bf16(const float* const* h0, const void* const* blob, const 
     static const bool lds_ok = [] {           // once per process: the attribute call is a driver round trip
         return hipFuncSetAttribute((const void*)tw::tower_seq_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) == hipSuccess &&
                hipFuncSetAttribute((const void*)tw::tower_seq_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) == hipSuccess &&
+               hipFuncSetAttribute((const void*)tw::tower_seq_kernel<true, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) == hipSuccess &&
                hipFuncSetAttribute((const void*)tw::tower_seq_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) == hipSuccess;
     }();
     if (!lds_ok) {
@@ -792,7 +863,8 @@ int dldkd_tower_seq_bf16(const float* const* h0, const void* const* blob, const 
         set_error("tower_seq: cannot reserve %d bytes of LDS", tw::kLdsTotal);
         return DLDKD_ELAUNCH;
     }
-    if (out_mode == 1) DLDKD_LAUNCH((tw::tower_seq_kernel<true, 1>), grid, dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
+    if (h16) DLDKD_LAUNCH((tw::tower_seq_kernel<true, 1, false, true>), grid, dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
+    else if (out_mode == 1) DLDKD_LAUNCH((tw::tower_seq_kernel<true, 1>), grid, dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
     else if (out_mode == 0) DLDKD_LAUNCH((tw::tower_seq_kernel<true, 0>), grid, dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
     else DLDKD_LAUNCH((tw::tower_seq_kernel<false, 2>), grid, dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
     return check_launch("tower_seq");

@@ -218,7 +218,7 @@ class DLDKD(nn.Module):
             self._folded["visual"] = ops.FoldedInProj([self.visual_input_proj, self.exp_visual_input_proj])
         packs = self._tower_packs("visual")
         for (va, n, r0, r1, lens_d, row0_d, items) in res.chunks:
-            y = ops.in_proj_resident(res.table, r0, r1, self._folded["visual"])
+            y = ops.in_proj_resident(res.table, r0, r1, self._folded["visual"], out_bf16=ops.RESIDENT_H0_BF16)
             v0 = packer.reserve(n, int(res.lens_host[va:va + n].max(initial=0)))
             if items.shape[0]:
                 ops.tower_seq(y, packs, lens_d, seq_rows=0, row0=row0_d, items=items, out_mode=1, gallery=packer.blobs, v0=v0,

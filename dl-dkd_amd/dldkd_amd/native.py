@@ -141,6 +141,8 @@ SIGNATURES = {
                                            _c_void_p, _c_void_p]),
     "dldkd_in_proj_bf16_rows128b": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                               _c_long, _c_int, _c_int, _c_void_p, _c_long, _c_void_p]),
+    "dldkd_in_proj_bf16_rows128b_out16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                              _c_long, _c_int, _c_int, _c_void_p, _c_long, _c_void_p]),
     "dldkd_in_proj_bf16_rows128b_ok": (_c_int, [_c_int]),
     "dldkd_gather_pad_rows_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p,
                                             _c_void_p]),
@@ -185,6 +187,8 @@ SIGNATURES = {
     "dldkd_tower_pack_bf16": (_c_int, [_c_void_p] * 16 + [_c_int, _c_void_p, _c_void_p]),
     "dldkd_tower_seq_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                       _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "dldkd_tower_seq_bf16_h16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                                          _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_debug_tower_seq_timeline": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                                 _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "dldkd_gemm_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

@@ -1,4 +1,6 @@
 """Thin tensor-level wrappers over the C ABI (one function per kernel).  No math happens here."""
+import os
+
 import torch
 
 from . import native
@@ -526,8 +528,13 @@ def in_proj_rows_ok(K):
     return bool(native.lib().dldkd_in_proj_bf16_rows128b_ok(int(K)))
 
 
-def in_proj_resident(table, row_lo, row_hi, folded, relu=True, out=None):
-    """K4b: rows [row_lo, row_hi) of a ResidentRows table -> per-branch (row_hi - row_lo, 384) fp32 (both branches, one pass)."""
+# the resident gallery encode hands h0 from K4b to the fused tower as bf16 rows (DLDKD_H0_BF16=0: fp32 rows, for A/B runs)
+RESIDENT_H0_BF16 = os.environ.get("DLDKD_H0_BF16", "1") == "1"
+
+
+def in_proj_resident(table, row_lo, row_hi, folded, relu=True, out=None, out_bf16=False):
+    """K4b: rows [row_lo, row_hi) of a ResidentRows table -> per-branch (row_hi - row_lo, 384) fp32 (both branches, one pass);
+    out_bf16: bf16 rows instead (what tower_seq's gallery mode reads with half the traffic)."""
     L = native.lib()
     f = folded.get()
     if not (f.full_row and f.nb == 2 and f.K == table.K and in_proj_rows_ok(table.K)):
@@ -535,15 +542,15 @@ def in_proj_resident(table, row_lo, row_hi, folded, relu=True, out=None):
     M = int(row_hi - row_lo)
     if row_lo < 0 or row_hi > table.rows or M < 0:
         raise native.NativeError("in_proj_resident: row range outside the table")
-    ys = out if out is not None else [torch.empty(M, HIDDEN, dtype=torch.float32, device=table.device) for _ in range(2)]
-    if any(y.shape[0] < M or y.shape[1] != HIDDEN or y.dtype != torch.float32 or not y.is_contiguous() for y in ys):
-        raise native.NativeError("in_proj_resident: out tensors must be contiguous fp32 (>= rows, 384)")
+    dt = torch.bfloat16 if out_bf16 else torch.float32
+    ys = out if out is not None else [torch.empty(M, HIDDEN, dtype=dt, device=table.device) for _ in range(2)]
+    if any(y.shape[0] < M or y.shape[1] != HIDDEN or y.dtype != dt or not y.is_contiguous() for y in ys):
+        raise native.NativeError("in_proj_resident: out tensors must be contiguous %s (>= rows, 384)" % dt)
     if M == 0:
         return ys
-    native.check(L.dldkd_in_proj_bf16_rows128b(native.ptr(table.xb[row_lo:]), native.ptr(table.mean[row_lo:]),
-                                               native.ptr(table.rstd[row_lo:]), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb),
-                                               native.ptr(ys[0]), native.ptr(ys[1]), M, table.K, int(relu), None, 0,
-                                               native.stream()), "in_proj_bf16_rows128b")
+    fn = L.dldkd_in_proj_bf16_rows128b_out16 if out_bf16 else L.dldkd_in_proj_bf16_rows128b
+    native.check(fn(native.ptr(table.xb[row_lo:]), native.ptr(table.mean[row_lo:]), native.ptr(table.rstd[row_lo:]), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb),
+                    native.ptr(ys[0]), native.ptr(ys[1]), M, table.K, int(relu), None, 0, native.stream()), "in_proj_bf16_rows128b")
     return ys
 
 
@@ -649,7 +656,14 @@ def tower_seq(h0, packs, lens, seq_rows=0, row0=None, items=None, out_mode=0, ga
     fs = [p.get() for p in packs]
     if any((f.out_linear is None) != (out_mode == 2) for f in fs):
         raise native.NativeError("tower_seq: out_mode 2 takes query-tower packs, out_mode 0 / 1 video-tower packs")
-    hs = [_chk(x.reshape(-1, HIDDEN), "tower_seq.h0") for x in h0]
+    h16 = h0[0].dtype == torch.bfloat16
+    if h16:
+        if out_mode != 1 or row0 is None or any(x.dtype != torch.bfloat16 or not x.is_cuda or not x.is_contiguous() or x.shape[-1] != HIDDEN
+                                                for x in h0):
+            raise native.NativeError("tower_seq: bf16 h0 rows serve the gallery mode (out_mode 1) with a row0 table only")
+        hs = [x.reshape(-1, HIDDEN) for x in h0]
+    else:
+        hs = [_chk(x.reshape(-1, HIDDEN), "tower_seq.h0") for x in h0]
     if lens.dtype != torch.int32 or not lens.is_cuda:
         raise native.NativeError("tower_seq: lens must be an int32 GPU tensor")
     n_seq = lens.shape[0]
@@ -659,6 +673,11 @@ def tower_seq(h0, packs, lens, seq_rows=0, row0=None, items=None, out_mode=0, ga
         outs = [torch.empty_like(x) for x in hs]
     elif out_mode == 2:
         outs = [torch.empty(n_seq, HIDDEN, dtype=torch.float32, device=lens.device) for _ in hs]
+    if h16:
+        native.check(L.dldkd_tower_seq_bf16_h16(native.ptr_array(hs), native.ptr_array([f.blob for f in fs]), native.ptr(row0),
+                                                native.ptr(lens), native.ptr(items), n_items, n_seq, nb, native.ptr_array(gallery),
+                                                int(v0), int(Lp), native.ptr(lens_out), native.stream()), "tower_seq_h16")
+        return None
     native.check(L.dldkd_tower_seq_bf16(native.ptr_array(hs), native.ptr_array([f.blob for f in fs]),
                                         native.ptr(row0), native.ptr(lens), native.ptr(items), n_items, n_seq, nb,
                                         out_mode, native.ptr_array(outs) if outs is not None else None, int(seq_rows),

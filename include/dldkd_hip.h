@@ -263,6 +263,12 @@ int dldkd_in_proj_bf16_rows128b(const void* x_bf16, const float* mean, const flo
                                 const float* bb, float* y0, float* y1, long M, int K, int relu, const int32_t* groups, long n_groups,
                                 void* stream);
 int dldkd_in_proj_bf16_rows128b_ok(int K);
+/* The same with BF16 output rows (round to nearest even, row stride 384 bf16): what the fused tower reads through
+ * dldkd_tower_seq_bf16_h16 - half the bytes written here and read there (2 x 1.28 GB instead of 2 x 2.56 GB per branch pair at
+ * TVR's 1.67 M clips), and the tower's prologue becomes one round of 16-byte loads straight into its operand registers. */
+int dldkd_in_proj_bf16_rows128b_out16(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
+                                      const float* bb, void* y0_bf16, void* y1_bf16, long M, int K, int relu, const int32_t* groups,
+                                      long n_groups, void* stream);
 /* PARITY-grade two-branch input projection (in_proj_rows128x3.hip): y = ReLU(LayerNorm(x) W^T + b) with fp32-grade products
  * (three bf16 planes per operand, six MFMAs per product: the scheme of dldkd_gemm_f32x3), both branches in one pass.
  *   dldkd_row_meanrstd_f32: mean[M], rstd[M] of the rows exactly as dldkd_layernorm_f32 computes them (D % 4 == 0, D <= 4096).
@@ -686,6 +692,11 @@ int dldkd_tower_seq_bf16(const float* const* h0, const void* const* blob, const 
                          const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                          int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
                          void* stream);
+/* out_mode 1 from BF16 h0 rows (dldkd_in_proj_bf16_rows128b_out16; ragged: row0 required): the prologue is one round of
+ * 16-byte loads straight into the operand registers (no LDS staging); everything else as above. */
+int dldkd_tower_seq_bf16_h16(const void* const* h0_bf16, const void* const* blob, const int32_t* row0,
+                             const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
+                             void* const* gallery, int v0, int Lp, int32_t* lens_out, void* stream);
 
 /* Diagnostics: the out_mode 1 kernel (two branches) with clock stamps at its phase boundaries; stamps = 24 x uint64 per workgroup
  * (8 * ceil(n_items / 4) workgroups): [0] start, [1] prologue, [2 + 2 h] head h projected, [3 + 2 h] head h attended, [10] dense,

@@ -16,13 +16,14 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 
 def test_recall_gate_from_raw_features_both_modes():
     import rk_gate
-    out = rk_gate.run(nv=1536, nq=2048, sigma=14.0, seed=11, modes=("parity", "fast"))
+    out = rk_gate.run(nv=1536, nq=2048, sigma=14.0, seed=11, modes=("parity", "fast", "resident"))
     assert 15.0 <= out["oracle"][0] <= 40.0, out["oracle"]                  # TVR-like operating point
     assert out["oracle"][3] < 95.0
-    for mode in ("parity", "fast"):
+    for mode in ("parity", "fast", "resident"):                             # resident = eval_epoch's default (bf16 table, bf16 h0)
         d = out[mode]["delta_vs_oracle"]
         assert max(abs(x) for x in d) <= 0.1 + 1e-9, (mode, out[mode])     # the gate: +-0.1 on every cut (2 of 2,048 queries)
     assert out["parity"]["max_abs_score_err"] < 2e-3 and out["fast"]["max_abs_score_err"] < 4e-3, out
+    assert out["resident"]["max_abs_score_err"] < 4e-3, out
 
 
 def test_eval_epoch_runs_throughput_mode_by_default_and_restores_the_precision():

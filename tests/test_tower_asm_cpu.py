@@ -33,8 +33,8 @@ def _run(path):
 def test_tower_rings_are_disciplined(tower_asm, capsys):
     assert _run(tower_asm) == 0
     out = capsys.readouterr().out
-    assert out.count("0 violations") == 4                                   # gallery, rows, query and the stamped diagnostic build
-    assert out.count("1440 ring reads") == 3 and out.count("1152 ring reads") == 1   # every weight fragment goes through the ring once
+    assert out.count("0 violations") == 5                    # gallery (fp32 / bf16 h0), rows, query and the stamped diagnostic build
+    assert out.count("1440 ring reads") == 4 and out.count("1152 ring reads") == 1   # every weight fragment goes through the ring once
 
 
 def test_checker_catches_a_register_touched_before_its_wait(tower_asm, tmp_path):

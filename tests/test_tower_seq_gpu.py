@@ -299,3 +299,50 @@ def test_table_upload_by_kernel_is_bit_exact_and_slot_safe():
     torch.cuda.synchronize()
     for t, d in zip(want, got):
         assert np.array_equal(d.view(torch.int32).cpu().numpy(), t)
+
+
+def test_tower_seq_bf16_h0_rows_equal_the_fp32_h0_kernel_bit_for_bit():
+    """dldkd_tower_seq_bf16_h16 (gallery mode from ragged bf16 h0 rows: 16-byte loads straight into the operand registers, one
+    v_permlane32_swap per dword pair) against dldkd_tower_seq_bf16 on the SAME values as fp32: the prologue adds the position
+    rows and accumulates the LayerNorm sums in the same order, so the packed gallery must be identical bit for bit - for ragged
+    row0 tables, rows past a sequence's end clamped, packed slot groups."""
+    from dldkd_amd import ops, scoring
+    lens = [128, 1, 31, 32, 33, 64, 65, 96, 100, 127, 17, 16, 15, 48, 3, 77]
+    ts, packs, _, lens_t = _setup(seed=9, lens=lens)
+    n, rows = len(lens), int(sum(lens))
+    g = torch.Generator().manual_seed(5)
+    h16 = [torch.relu(torch.randn(rows + 1, H, generator=g)).bfloat16().to(DEV) for _ in range(2)]
+    row0 = torch.tensor([0] + np.cumsum(lens)[:-1].tolist(), dtype=torch.int32, device=DEV)
+    items = torch.from_numpy(ops.plan_tower_items(lens_t.numpy())).to(DEV)
+    blobs = []
+    for hs in ([x[:rows] for x in h16], [x[:rows].float() for x in h16]):
+        pk = scoring.GalleryPacker(n, 128, 2, torch.device(DEV))
+        for blob in pk.blobs:
+            blob.fill_(0x55)
+        pk.reserve(n, 128)
+        ops.tower_seq(hs, packs, lens_t.to(DEV), seq_rows=0, row0=row0, items=items, out_mode=1, gallery=pk.blobs, v0=0, Lp=pk.Lp,
+                      lens_out=pk.lens)
+        torch.cuda.synchronize()
+        assert torch.equal(pk.lens[:n].cpu(), lens_t)
+        blobs.append([b.clone() for b in pk.blobs])
+    for a, b in zip(*blobs):
+        assert torch.equal(a, b)
+    with pytest.raises(Exception):
+        ops.tower_seq([x[:rows] for x in h16], packs, lens_t.to(DEV), seq_rows=128, out_mode=1, gallery=blobs[0], Lp=128)   # no row0
+
+
+def test_in_proj_resident_bf16_rows_are_the_rounded_fp32_rows():
+    """dldkd_in_proj_bf16_rows128b_out16 == bf16(round to nearest even) of dldkd_in_proj_bf16_rows128b, bit for bit, for row counts
+    that end inside a 128-row tile (the paired-row stores mask per lane)."""
+    from dldkd_amd import ops
+    m = _model(3072, 768, synth.make_params(61, 3072, 768)).to(DEV).eval()
+    folded = ops.FoldedInProj([m.visual_input_proj, m.exp_visual_input_proj])
+    for rows in (1, 127, 128, 129, 1000, 4097):
+        g = torch.Generator().manual_seed(rows)
+        table = ops.ResidentRows(3072, torch.device(DEV), rows)
+        table.append(torch.randn(1, rows, 3072, generator=g).to(DEV), [rows])
+        y32 = ops.in_proj_resident(table, 0, rows, folded)
+        y16 = ops.in_proj_resident(table, 0, rows, folded, out_bf16=True)
+        torch.cuda.synchronize()
+        for a, b in zip(y32, y16):
+            assert b.dtype == torch.bfloat16 and torch.equal(a.bfloat16().view(torch.int16), b.view(torch.int16)), rows

@@ -82,16 +82,27 @@ def oracle_scores(m, d, threads=16):
 
 
 def hip_scores(m, d, mode, dev="cuda:0", chunk=512, tower_seq=True):
-    """mode 'parity' | 'fast' (K4 + fused tower) | 'fast_chain' (the kernel chain K5 replaced) | 'k4_only' (bf16 K4, fp32 towers)"""
+    """mode 'parity' | 'fast' (K4 + fused tower) | 'resident' (eval_epoch's default: ragged bf16 feature table -> K4b -> bf16 h0 ->
+    fused tower) | 'fast_chain' (the kernel chain K5 replaced) | 'k4_only' (bf16 K4, fp32 towers)"""
     from dldkd_amd import ops, scoring
-    ops.set_gemm_precision("bf16" if mode in ("fast", "fast_chain") else "fp32")
+    ops.set_gemm_precision("bf16" if mode in ("fast", "fast_chain", "resident") else "fp32")
     m.fast_input_proj = mode != "parity"
     ops.TOWER_SEQ = mode != "fast_chain"
     try:
         nv, L = d["vid"].shape[:2]
         pk = scoring.GalleryPacker(nv, L, 2, torch.device(dev))
         with torch.no_grad():
-            for s in range(0, nv, chunk):
+            if mode == "resident":
+                from dldkd_amd import eval as ev
+                m.eval()
+                assert m.resident_encode_ok()
+                res = ev.ResidentGallery(d["vid"].shape[2], torch.device(dev))
+                for s in range(0, nv, chunk):
+                    res.table.append(d["vid"][s:s + chunk].to(dev), d["lens"][s:s + chunk].numpy())
+                res.complete = True
+                res.plan(torch.device(dev))
+                m.encode_resident_into(pk, res)
+            for s in range(0, nv if mode != "resident" else 0, chunk):
                 v, vm = d["vid"][s:s + chunk].to(dev), d["vmask"][s:s + chunk].to(dev)
                 if not (mode == "fast" and m.encode_context_into(pk, v, vm, lens_host=d["lens"][s:s + chunk].numpy())):
                     gi, ge = m.encode_context(v, vm)

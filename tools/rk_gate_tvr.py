@@ -8,7 +8,8 @@ fixed random map R^3072 -> R^768, the teacher's 512-d features under another - t
 ways from RAW features:
     oracle   fp32 oracle towers + oracle scoring on the CPU (the reference's arithmetic)
     parity   HIP, fp32-grade towers, bf16 scorer
-    fast     HIP throughput mode (bf16 input projection, fused bf16 tower kernel, bf16 scorer): what eval_epoch runs by default
+    fast     HIP throughput mode (bf16 input projection, fused bf16 tower kernel, bf16 scorer) on padded fp32 super-batches
+    resident the same from the ragged bf16 feature table (K4b -> bf16 h0 rows -> fused tower): what eval_epoch runs by default
 For every eval seed: R@1/5/10/100 of each, the NET deltas against the oracle and the GROSS number of queries that cross each cut
 in either direction (a net delta can hide crossings that cancel).
 
@@ -87,7 +88,7 @@ def train_model(steps, sigma, P, Pt, dev="cuda:0", seed=0, bsz=128, caps=5, L=64
     return m.eval(), losses
 
 
-def compare(m, d, modes=("parity", "fast"), dev="cuda:0"):
+def compare(m, d, modes=("parity", "fast", "resident"), dev="cuda:0"):
     import rk_gate
     out = {}
     ref, _, _ = rk_gate.oracle_scores(m, d, threads=32)
@@ -117,9 +118,9 @@ def run(seeds=3, nv=4096, nq=8192, steps=400, sigma=6.0, L=64, log=print):
         r = compare(m, d)
         r["seed"], r["seconds"] = 500 + s, round(time.time() - t1, 1)
         res["seeds"].append(r)
-        log(f"  eval seed {500 + s}: oracle {['%.3f' % x for x in r['oracle']]}  parity d {['%+.3f' % x for x in r['parity']['delta_vs_oracle']]} "
-            f"x {r['parity']['queries_crossing_a_cut']}  fast d {['%+.3f' % x for x in r['fast']['delta_vs_oracle']]} x {r['fast']['queries_crossing_a_cut']}")
-    for mode in ("parity", "fast"):
+        log(f"  eval seed {500 + s}: oracle {['%.3f' % x for x in r['oracle']]}  " + "  ".join(
+            f"{k} d {['%+.3f' % x for x in r[k]['delta_vs_oracle']]} x {r[k]['queries_crossing_a_cut']}" for k in ("parity", "fast", "resident")))
+    for mode in ("parity", "fast", "resident"):
         res[mode + "_worst_abs_net_delta"] = max(abs(x) for r in res["seeds"] for x in r[mode]["delta_vs_oracle"])
         res[mode + "_worst_gross_crossings_pct"] = max(x for r in res["seeds"] for x in r[mode]["crossings_pct"])
     return res
