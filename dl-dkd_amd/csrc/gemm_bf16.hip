@@ -180,10 +180,14 @@ struct TileH {
 };
 
 // EPI: 0 = store C (bias / ReLU / split-K plane), 1 = training simpool max-pool (PoolArgs), 2 = LayerNorm parameter gradients (LnGradArgs)
-template <bool A_KMAJOR, bool B_KMAJOR, int EPI, typename EArgs, bool A16 = false, bool B16 = false>
+// DUAL (the dW layout of the training input projection, inproj_bwd below): a second accumulator set takes the SAME A tiles against
+// the 0 / 1 mask [B != 0] of the B tiles (made while the tile is staged: one more LDS tile, no memory traffic) and goes to a second
+// plane behind C's (C + M ldc).
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, typename EArgs, bool A16 = false, bool B16 = false, bool DUAL = false>
 __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_raw[];
     unsigned short (*lds)[2][HBM_ * HPITCH] = reinterpret_cast<unsigned short (*)[2][HBM_ * HPITCH]>(lds_raw);
+    unsigned short (*ldm)[HBM_ * HPITCH] = reinterpret_cast<unsigned short (*)[HBM_ * HPITCH]>(lds_raw + 2 * 2 * HBM_ * HPITCH);   // DUAL: [2]
     // XCD-aware tile order (cdna_hip_programming.md T1, bijective form).  Workgroups are dealt round-robin over the 8 XCDs, each
     // with its own L2: in launch order the 3 (N = 384) or 9 (N = 1152) column tiles that share a 128-row block of A ran on
     // different XCDs and every one of them pulled the block through the fabric again (16,384 x 384 x 384: 100 MB moved for 50 MB
@@ -192,7 +196,7 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
     // a row block's tiles - and for split-K launches the row tiles that share a B slab - run side by side behind one L2.
     const Tile3 bid = xcd_tile_order();
     if (p.split_k > 1) {
-        p.C += (size_t)bid.z * p.M * p.ldc;      // this split's partial plane in the workspace
+        p.C += (size_t)bid.z * p.M * p.ldc * (DUAL ? 2 : 1);      // this split's partial plane(s) in the workspace
     } else {
         const int zo = bid.z / p.batch_inner, zi = bid.z % p.batch_inner;
         p.A += zo * p.sAo + zi * p.sAi;
@@ -207,13 +211,24 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
     const int nk = p.split_k > 1 ? min(nk_all - kt0, p.k_tiles_per_split) : nk_all;
     if (nk <= 0) return;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], acc2[DUAL ? 2 : 1][DUAL ? 2 : 1];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (DUAL) acc2[i][j][r] = 0.f;
+            }
+    auto store_mask = [&](unsigned short* S, const float (&rb_)[NREG_]) {
+        if constexpr (DUAL) {
+            float rm[NREG_];
+#pragma unroll
+            for (int i = 0; i < NREG_; ++i) rm[i] = rb_[i] != 0.f ? 1.f : 0.f;
+            TileH<B_KMAJOR, B16>::store(S, tid, rm);
+        }
+    };
 
     float ra[NREG_], rb[NREG_];
 #pragma unroll
@@ -270,6 +285,7 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
         add_cs();
         TileH<A_KMAJOR, A16>::store(lds[0][0], tid, ra, pm);
         TileH<B_KMAJOR, B16>::store(lds[0][1], tid, rb);
+        store_mask(ldm[0], rb);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -281,22 +297,28 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
             const unsigned short* Bs = lds[cur][1];
 #pragma unroll
             for (int kk = 0; kk < HBK_ / 16; ++kk) {
-                bf16x8 a[2], b[2];
+                bf16x8 a[2], b[2], bm[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j) {
                     b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn + 32 * j + (lane & 31)) * HPITCH + kk * 16 + (lane >> 5) * 8);
+                    if constexpr (DUAL) bm[j] = *reinterpret_cast<const bf16x8*>(ldm[cur] + (wn + 32 * j + (lane & 31)) * HPITCH + kk * 16 + (lane >> 5) * 8);
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     if (!rt_ok[i]) continue;                 // a 32-row tile of padding: its LDS rows were never written
                     a[i] = *reinterpret_cast<const bf16x8*>(As + (wm + 32 * i + (lane & 31)) * HPITCH + kk * 16 + (lane >> 5) * 8);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        if constexpr (DUAL) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bm[j], acc2[i][j], 0, 0, 0);
+                    }
                 }
             }
         }
         if (nxt_ok) {
             TileH<A_KMAJOR, A16>::store(lds[cur ^ 1][0], tid, ra, pm);
             TileH<B_KMAJOR, B16>::store(lds[cur ^ 1][1], tid, rb);
+            store_mask(ldm[cur ^ 1], rb);
         }
         __syncthreads();
         cur_ok = nxt_ok;
@@ -317,7 +339,13 @@ __device__ __forceinline__ void gemm_bf16_body(GemmHArgs p, const EArgs* pa) {
     // (the k-loop ended with a barrier: every wave is done with the operand tiles, the LDS is free for staging)
     if constexpr (EPI == 1) gemm_pool_tile(acc, p, *pa, bid.z, n0, wm, wn, lane, wave, reinterpret_cast<float*>(lds_raw));
     else if constexpr (EPI == 2) gemm_lngrad_tile(acc, p, *pa, m0, n0, wm, wn, lane, wave, reinterpret_cast<float*>(lds_raw));
-    else gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(lds_raw) + wave * (32 * 72));
+    else {
+        gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(lds_raw) + wave * (32 * 72));
+        if constexpr (DUAL) {
+            p.C += (size_t)p.M * p.ldc;
+            gemm_store_tile(acc2, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(lds_raw) + wave * (32 * 72));
+        }
+    }
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR>
@@ -358,6 +386,118 @@ __global__ __launch_bounds__(256) void gemm_bf16_dw_group_kernel(DwGroupArgs g) 
     } else {
         p.A = (const float*)g.A[blk] + shift;
         gemm_bf16_body<true, true, 0, PoolArgs, false, true>(p, nullptr);
+    }
+}
+// Backward pass of the training input projection, bf16 mode (LinearLayer on raw features: LayerNorm -> Dropout -> Linear,
+// method/model_components.py:294-312; the features need no gradient).  With z = keep s (xhat gamma + beta) the saved bf16 rows,
+// dY the output gradient and mask = [z != 0]:
+//     dW[n, k]   = sum_m dY[m, n] z[m, k]                                  (the weight gradient, as before)
+//     H[n, k]    = s sum_m dY[m, n] mask[m, k]
+//     dbeta[k]   = sum_m (dY W)[m, k] s mask[m, k]         = sum_n W[n, k] H[n, k]
+//     dgamma[k]  = sum_m (dY W)[m, k] s mask[m, k] xhat[m, k] = (sum_n W[n, k] dW[n, k] - beta[k] dbeta[k]) / gamma[k]
+// i.e. the (M x K) product dY W of dldkd_linear_lngrad - a GEMM with a 384-long contraction whose 50 M results were reduced on the
+// spot, 191 us at the TVR batch - is REASSOCIATED into a second accumulator of the weight-gradient GEMM (same dY tiles, the mask
+// made from the z tile on its way to LDS): one launch with a 16,384-long contraction does both.  A column with |gamma| below
+// kSmallGamma cannot be recovered from z (it holds beta only): the finishing kernel recomputes those columns from x exactly.
+__global__ __launch_bounds__(256, 2) void gemm_bf16_dw_dual_kernel(GemmHArgs p) {
+    gemm_bf16_body<true, true, 0, PoolArgs, false, true, true>(p, nullptr);
+}
+constexpr float kSmallGamma = 0.05f;
+struct InprojFinishArgs {
+    const float* part;           // [split][2][N][K] partial planes (or split = 1: the planes themselves)
+    const float* W;              // [N][K]
+    float* dW;                   // [N][K]
+    float* dg;                   // [K] accumulators (zeroed by the caller): sum_n W dW
+    float* db;                   // [K]                                      sum_n W H  (unscaled)
+    int split, N, K;
+};
+// grid (K / 256, N / 8): thread = one column k, 8 rows n: reduces the split planes, writes dW, accumulates the two dot products
+__global__ __launch_bounds__(256) void inproj_bwd_reduce_kernel(const InprojFinishArgs a) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= a.K) return;
+    const size_t plane = (size_t)a.N * a.K;
+    float sg = 0.f, sb = 0.f;
+    const int n_hi = min(a.N, (int)(blockIdx.y + 1) * 8);
+    for (int n = blockIdx.y * 8; n < n_hi; ++n) {
+        const size_t at = (size_t)n * a.K + k;
+        float dw = 0.f, h = 0.f;
+        for (int s = 0; s < a.split; ++s) {
+            dw += a.part[(size_t)s * 2 * plane + at];
+            h += a.part[(size_t)s * 2 * plane + plane + at];
+        }
+        a.dW[at] = dw;
+        const float w = a.W[at];
+        sg += w * dw;
+        sb += w * h;
+    }
+    atomicAdd(a.dg + k, sg);
+    atomicAdd(a.db + k, sb);
+}
+struct InprojFinalArgs {
+    float* dg;                   // in: sum_n W dW, out: dgamma
+    float* db;                   // in: sum_n W H (unscaled), out: dbeta
+    const float* gamma;
+    const float* beta;
+    float keep_scale;
+    int K;
+    // the exact path for columns with a small gamma
+    const float* dy;             // [M][N]
+    const float* W;              // [N][K]
+    const float* x;              // [M][K]
+    const unsigned char* keep;   // [M][K] or null
+    const float* mean;
+    const float* rstd;           // (0 for rows of the padding)
+    long M;
+    int N;
+};
+__global__ __launch_bounds__(256) void inproj_bwd_final_kernel(const InprojFinalArgs a) {
+    __shared__ float wcol[kHidden];
+    __shared__ float red[2][4];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    bool small = false;
+    if (k < a.K) {
+        const float g = a.gamma[k], dbeta = a.keep_scale * a.db[k];
+        small = fabsf(g) < kSmallGamma;
+        a.db[k] = dbeta;
+        if (!small) a.dg[k] = (a.dg[k] - a.beta[k] * dbeta) / g;
+    }
+    // (rare) columns whose gamma is too small to divide by: dz'[m] = dY[m, :] . W[:, k] row by row, against x and the keep bytes
+    for (int w = 0; w < 4; ++w) {
+        unsigned long long todo = __ballot(small);
+        __shared__ unsigned long long todo_s[4];
+        if ((threadIdx.x & 63) == 0) todo_s[threadIdx.x >> 6] = todo;
+        __syncthreads();
+        todo = todo_s[w];
+        while (todo) {
+            const int bit = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int kc = blockIdx.x * 256 + 64 * w + bit;
+            for (int n = threadIdx.x; n < a.N && n < kHidden; n += 256) wcol[n] = a.W[(size_t)n * a.K + kc];
+            __syncthreads();
+            float sg = 0.f, sb = 0.f;
+            for (long m = threadIdx.x; m < a.M; m += 256) {
+                const float rs = a.rstd[m];
+                if (rs == 0.f) continue;
+                const float kp = a.keep != nullptr ? (a.keep[(size_t)m * a.K + kc] ? a.keep_scale : 0.f) : a.keep_scale;
+                if (kp == 0.f) continue;
+                float dz = 0.f;
+                const float* dyr = a.dy + (size_t)m * a.N;
+                for (int n = 0; n < a.N; ++n) dz += dyr[n] * wcol[n];
+                dz *= kp;
+                sb += dz;
+                sg += dz * (a.x[(size_t)m * a.K + kc] - a.mean[m]) * rs;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { sg += __shfl_xor(sg, o); sb += __shfl_xor(sb, o); }
+            if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sg; red[1][threadIdx.x >> 6] = sb; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                a.dg[kc] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+                a.db[kc] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            }
+            __syncthreads();
+        }
+        __syncthreads();
     }
 }
 // training simpool: one video per blockIdx.z, max-pool epilogue (common.hpp, gemm_pool_tile)
@@ -551,6 +691,52 @@ extern "C" int dldkd_tower_train_dw(const void* const* host_A, const int* host_l
     int rc = check_launch("tower_train_dw");
     if (rc != DLDKD_OK || !use_split) return rc;
     return launch_splitk_reduce((const float*)workspace, dW, split, (long)M * kHidden, (hipStream_t)stream);
+}
+
+extern "C" size_t dldkd_inproj_bwd_workspace_bytes(int N, int K, long M) {
+    int per = 0;
+    const int split = gemm_bf16_split_plan(N, K, (int)M, 1, 1, &per);
+    return (size_t)(split > 1 ? split : 1) * 2 * N * K * sizeof(float);
+}
+
+extern "C" int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const float* W, const float* gamma, const float* beta,
+                                     float keep_scale, const float* x, const unsigned char* keep, const float* mean, const float* rstd,
+                                     float* dW, float* dbias, float* dgamma, float* dbeta, long M, int N, int K, void* workspace,
+                                     size_t workspace_bytes, const unsigned char* k_flags, void* stream) {
+    if (M < 0 || M > 0x7fffffffL || N < 1 || N > kHidden || K < 2 || (K & 3) || (N & 1)) {
+        set_error("inproj_bwd: bad sizes (M=%ld N=%d K=%d; N <= 384, K a multiple of 4)", M, N, K);
+        return DLDKD_EINVAL;
+    }
+    if (M == 0) return DLDKD_OK;
+    if (!dy || !z_bf16 || !W || !gamma || !beta || !x || !mean || !rstd || !dW || !dgamma || !dbeta || !workspace) {
+        set_error("inproj_bwd: null pointer");
+        return DLDKD_EINVAL;
+    }
+    if (((uintptr_t)z_bf16 & 3) || ((uintptr_t)workspace & 15) || ((uintptr_t)dW & 15) || workspace_bytes < dldkd_inproj_bwd_workspace_bytes(N, K, M)) {
+        set_error("inproj_bwd: unaligned buffer or workspace too small");
+        return DLDKD_EINVAL;
+    }
+    // C[n, k] over the batch rows: A = dY (rows, N) fp32 k-major, B = z (rows, K) bf16 k-major; planes [split][dW | H] in the workspace
+    GemmHArgs p{dy, (const float*)z_bf16, nullptr, (float*)workspace, N, K, (int)M, N, K, K, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+    p.kflags = k_flags;
+    p.a_colsum = dbias;
+    int per = 0;
+    int split = gemm_bf16_split_plan(N, K, (int)M, 1, 1, &per);
+    if (split > 1) { p.split_k = split; p.k_tiles_per_split = per; } else split = 1;
+    hipStream_t s = (hipStream_t)stream;
+    constexpr size_t lds = sizeof(unsigned short) * 3 * 2 * HBM_ * HPITCH;
+    static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_bf16_dw_dual_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    (void)attr_ok;
+    DLDKD_LAUNCH(gemm_bf16_dw_dual_kernel, dim3((K + HBN_ - 1) / HBN_, (N + HBM_ - 1) / HBM_, split), dim3(256), lds, s, p);
+    int rc = check_launch("inproj_bwd (dual dW)");
+    if (rc != DLDKD_OK) return rc;
+    const InprojFinishArgs f{(const float*)workspace, W, dW, dgamma, dbeta, split, N, K};
+    DLDKD_LAUNCH(inproj_bwd_reduce_kernel, dim3((K + 255) / 256, (N + 7) / 8), dim3(256), 0, s, f);
+    rc = check_launch("inproj_bwd (reduce)");
+    if (rc != DLDKD_OK) return rc;
+    const InprojFinalArgs g{dgamma, dbeta, gamma, beta, keep_scale, K, dy, W, x, keep, mean, rstd, M, N};
+    DLDKD_LAUNCH(inproj_bwd_final_kernel, dim3((K + 255) / 256), dim3(256), 0, s, g);
+    return check_launch("inproj_bwd (final)");
 }
 
 extern "C" int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda,

@@ -256,13 +256,13 @@ class _InProjTrain(Function):
         _LAST_GROUP_FLAGS = (gflags, M) if gflags is not None else None
         # grad_premasked: the node behind this one (the fused training tower) hands back a gradient that already carries the ReLU mask
         # [y > 0] - it reads y anyway - so the backward pass here neither keeps y nor runs relu_bwd over a clone of dy
-        ctx.save_for_backward(x2, weight, z, y if (relu and not grad_premasked) else None, keep, stats, gflags)
+        ctx.save_for_backward(x2, weight, z, y if (relu and not grad_premasked) else None, keep, stats, gflags, gamma, beta)
         ctx.relu, ctx.has_bias, ctx.keep_scale, ctx.prec = (relu and not grad_premasked), bias is not None, 1.0 / (1.0 - p), ops.gemm_precision()
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, z, y, keep, stats, gflags = ctx.saved_tensors
+        x2, w, z, y, keep, stats, gflags, gamma, beta = ctx.saved_tensors
         N, K = w.shape
         M = x2.shape[0]
         dy2 = _f32(dy).reshape(-1, N)
@@ -271,6 +271,19 @@ class _InProjTrain(Function):
             native.check(_L().dldkd_relu_bwd_f32(_p(dy2), _p(y.reshape(-1, N)), dy2.numel(), _s()), "relu_bwd")
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[4]
+        if (IN_PROJ_BWD_DUAL and z.dtype == torch.bfloat16 and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
+                and N <= 384 and N % 2 == 0 and w.is_contiguous()):
+            # ONE weight-gradient GEMM with two accumulator sets gives dW and the LayerNorm parameter gradients (the (M, K) product
+            # dy W of dldkd_linear_lngrad reassociated into dW's M-long contraction: gemm_bf16.hip, gemm_bf16_dw_dual_kernel)
+            dw = torch.empty(N, K, dtype=torch.float32, device=x2.device)
+            db = _zeros((N,), x2.device) if want_db else None
+            dgb = _zeros((2, K), x2.device)
+            nbytes = _L().dldkd_inproj_bwd_workspace_bytes(N, K, M)
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2.device)
+            native.check(_L().dldkd_inproj_bwd_bf16(_p(dy2), _p(z), _p(w), _p(gamma), _p(beta), ctx.keep_scale, _p(x2), _p(keep),
+                                                    _p(stats[0]), _p(stats[1]), _p(dw), _p(db), _p(dgb[0]), _p(dgb[1]), M, N, K, _p(ws),
+                                                    nbytes, _p(gflags), _s()), "inproj_bwd_bf16")
+            return None, dgb[0], dgb[1], dw, db, None, None, None, None
         if ctx.needs_input_grad[3]:
             if z.dtype == torch.bfloat16:
                 dw = torch.empty(N, K, dtype=torch.float32, device=x2.device)
@@ -310,6 +323,7 @@ def take_group_flags():
 IN_PROJ_SKIP_PADDING = True           # ... and the rows of the padding (a row mask given) are neither normalised nor multiplied
 IN_PROJ_TRAIN_BF16_ROWS = True        # throughput mode: the saved LayerNorm-dropout rows of the input projection are bf16
 IN_PROJ_TRAIN_FUSED = True
+IN_PROJ_BWD_DUAL = True               # throughput mode: dW and the LayerNorm parameter gradients from one two-accumulator GEMM
 IN_PROJ_TRAIN_NT16 = True             # throughput mode: the forward GEMM of the input projection on the bf16 x bf16 LDS-DMA kernel
 
 

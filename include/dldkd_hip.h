@@ -359,6 +359,21 @@ int dldkd_gemm_bf16_nt16(const void* A, const void* B, const float* bias, float*
  * from the A tiles on their way to LDS instead of by a second pass over dY (ldc = N, no bias / ReLU). */
 int dldkd_gemm_bf16_dw_bias(int dw, const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, void* workspace,
                             size_t workspace_bytes, const unsigned char* k_flags, float* a_colsum, void* stream);
+
+/* Backward pass of the training input projection in bf16 mode as ONE weight-gradient GEMM with two accumulator sets (replaces
+ * dldkd_gemm_bf16_dw_bias + dldkd_linear_lngrad for LinearLayer on raw features, method/model_components.py:294-312):
+ *     dW[n, k]  = sum_m dy[m, n] z[m, k]                      z = the saved bf16 LayerNorm-dropout rows (dldkd_layernorm_dropout_bf16)
+ *     H[n, k]   = sum_m dy[m, n] [z[m, k] != 0]
+ *     dbeta[k]  = keep_scale sum_n W[n, k] H[n, k]            dgamma[k] = (sum_n W[n, k] dW[n, k] - beta[k] dbeta[k]) / gamma[k]
+ * - the (M, K) product dy W of dldkd_linear_lngrad reassociated into the M-long contraction of the weight gradient.  Columns with
+ * |gamma[k]| < 0.05 (z holds no trace of xhat there) are recomputed exactly from x / keep / mean / rstd (rstd = 0 marks padding rows).
+ * dy (M, N) fp32, N <= 384; z (M, K) bf16; W (N, K); dW (N, K); dbias (N) zeroed by the caller or NULL; dgamma, dbeta (K) ZEROED by
+ * the caller (used as accumulators); k_flags as in dldkd_gemm_bf16_mixed; workspace: dldkd_inproj_bwd_workspace_bytes. */
+size_t dldkd_inproj_bwd_workspace_bytes(int N, int K, long M);
+int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const float* W, const float* gamma, const float* beta,
+                          float keep_scale, const float* x, const unsigned char* keep, const float* mean, const float* rstd,
+                          float* dW, float* dbias, float* dgamma, float* dbeta, long M, int N, int K, void* workspace,
+                          size_t workspace_bytes, const unsigned char* k_flags, void* stream);
 /* The forward layout of dldkd_gemm_bf16 - C[M, N] = act(A[M, K] . B[N, K]^T + bias), both operands fp32 and k-minor (a Linear's
  * forward pass; its input gradient once the weight is transposed) - with the operand tiles staged HBM -> LDS by LDS-DMA instead
  * of through registers (gemm_bf16_dma.hip): same products in the same order, bit-identical results, about half the time on

@@ -396,3 +396,59 @@ def test_video_tower_skips_the_padding_without_changing_the_step(bf16_mode):
         assert torch.isfinite(ga[n]).all(), n
         scale = gb[n].abs().max().item()
         assert (ga[n] - gb[n]).abs().max().item() <= 2e-4 * max(scale, 1e-6) + 1e-7, (n, scale)
+
+
+@pytest.mark.parametrize("nv,L,K,N,p_drop,masked", [(128, 128, 3072, 384, 0.2, True), (40, 30, 768, 384, 0.1, False), (9, 64, 256, 130, 0.0, True),
+                                                     (300, 32, 512, 384, 0.5, True)])
+def test_input_projection_backward_as_one_two_accumulator_gemm(bf16_mode, nv, L, K, N, p_drop, masked):
+    """dldkd_inproj_bwd_bf16 (functional.IN_PROJ_BWD_DUAL): dW and the LayerNorm parameter gradients of the training input
+    projection from ONE weight-gradient GEMM with a second accumulator set against the mask [z != 0] - the (M, K) product dy W of
+    dldkd_linear_lngrad reassociated.  Against the two-GEMM path it replaces (same saved rows, same dropout mask: dW and the bias
+    gradient equal up to summation order, dgamma / dbeta within the bf16 rounding of the saved rows) and against fp64 on the exact
+    normalised rows; columns with gamma = 0 or tiny (nothing of xhat left in z) go through the exact per-column path, including
+    gamma = beta = 0 where the mask [z != 0] itself is empty."""
+    from dldkd_amd import functional as F_
+    g = torch.Generator().manual_seed(nv + L + K)
+    lens = torch.randint(1, L + 1, (nv,), generator=g)
+    lens[0] = L
+    mask = (torch.arange(L)[None] < lens[:, None]).float() if masked else torch.ones(nv, L)
+    x = (torch.randn(nv, L, K, generator=g) * (1 + torch.rand(nv, L, 1, generator=g)) + 0.3) * mask[..., None]
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    gamma[3], gamma[7], gamma[K - 1], gamma[11] = 0.0, 1e-3, -0.02, 0.0
+    beta[11] = 0.0
+    W, b = torch.randn(N, K, generator=g) * 0.03, 0.1 * torch.randn(N, generator=g)
+    w_out = (torch.randn(nv, L, N, generator=g) * mask[..., None]).to(DEV)          # d loss / d y: zero on the padding
+    res = {}
+    try:
+        for dual in (True, False):
+            F_.IN_PROJ_BWD_DUAL = dual
+            gs, bs, Ws, bbs = (t.to(DEV).requires_grad_() for t in (gamma, beta, W, b))
+            torch.manual_seed(5)
+            y = F_.in_proj_train(x.to(DEV), gs, bs, Ws, bbs, p_drop, True, row_mask=mask.to(DEV) if masked else None)
+            (y * w_out).sum().backward()
+            res[dual] = [t.grad.double().cpu() for t in (gs, bs, Ws, bbs)] + [y.detach()]
+    finally:
+        F_.IN_PROJ_BWD_DUAL = True
+    (dg1, db1, dW1, dbb1, y1), (dg0, db0, dW0, dbb0, y0) = res[True], res[False]
+    assert torch.equal(y1, y0)
+    assert torch.allclose(dW1, dW0, rtol=1e-4, atol=1e-5 * dW0.abs().max().item()) and torch.allclose(dbb1, dbb0, rtol=1e-4, atol=1e-5 * dbb0.abs().max().item())
+    rel = lambda a, r: ((a - r).norm() / r.norm()).item()                                   # noqa: E731
+    # the two paths round different things (two GEMMs: dy and W to bf16; one GEMM: dy and, for dgamma, the saved rows): a few 1e-3
+    print(f"  one GEMM vs two: dgamma rel l2 {rel(dg1, dg0):.2e}, dbeta {rel(db1, db0):.2e}")
+    assert rel(dg1, dg0) <= 5e-3 and rel(db1, db0) <= 5e-3
+    sg, sb = dg0.abs().max().item(), db0.abs().max().item()
+    for k in (3, 7, K - 1, 11):                                                             # the exact columns (fp32 x, W, dy)
+        assert abs(dg1[k] - dg0[k]) <= 5e-3 * sg and abs(db1[k] - db0[k]) <= 5e-3 * sb, (k, dg1[k], dg0[k], db1[k], db0[k])
+    assert torch.isfinite(dg1).all() and torch.isfinite(db1).all()
+    if p_drop == 0.0:
+        # no dropout: fp64 from the definition, with the ReLU mask the kernels saw - both paths against it
+        xd, gd, bd, Wd = x.double().reshape(-1, K), gamma.double(), beta.double(), W.double()
+        mu = xd.mean(1, keepdim=True)
+        xhat = (xd - mu) / torch.sqrt(((xd - mu) ** 2).mean(1, keepdim=True) + 1e-5)
+        dyr = (w_out.double().cpu() * (y1.double().cpu() > 0)).reshape(-1, N) * mask.double().reshape(-1, 1)
+        dz = dyr @ Wd
+        ref_g, ref_b = (dz * xhat).sum(0), dz.sum(0)
+        print(f"  vs fp64: one GEMM dgamma {rel(dg1, ref_g):.2e} dbeta {rel(db1, ref_b):.2e}; two GEMMs {rel(dg0, ref_g):.2e} {rel(db0, ref_b):.2e}")
+        assert rel(dg1, ref_g) <= 5e-3 and rel(db1, ref_b) <= 5e-3
+        for k in (3, 7, K - 1, 11):
+            assert abs(dg1[k] - ref_g[k]) <= 1e-4 * sg and abs(db1[k] - ref_b[k]) <= 1e-4 * sb
