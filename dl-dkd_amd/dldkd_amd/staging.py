@@ -48,6 +48,16 @@ class PinnedRing:
             ev.record()
             self.events[self.i] = ev
 
+    def upload_range(self, dev_bytes, lo, hi, last):
+        """Bytes [lo, hi) of the current slot into the same range of `dev_bytes` (asynchronous, current stream): a slot uploaded in
+        pieces - what the first consumers need right away, the rest once the host has produced it.  last: this piece completes
+        the slot (its event is recorded here)."""
+        dev_bytes[lo:hi].copy_(self.bufs[self.i][lo:hi], non_blocking=True)
+        if last and self.cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events[self.i] = ev
+
 
 def concurrent_streams(device, n, candidates=16, cycles=1_000_000):
     """n torch streams that run side by side on the device.  HIP multiplexes its streams onto GPU_MAX_HW_QUEUES (default 4)

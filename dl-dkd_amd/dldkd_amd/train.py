@@ -197,6 +197,7 @@ class GraphedTrainStep:
     comm stream as its segment has been launched and runs under the next segment; the optimizer update is the chain's last graph
     (_capture_segments)."""
 
+    EARLY_VIDEO_START = True      # replay: the video towers start behind the video features' copy, not behind the whole batch's
     TENSOR_KEYS = ("student_videos", "student_videos_mask", "teacher_videos", "student_text", "student_text_mask", "teacher_text")
 
     def __init__(self, model, optimizer, opt, max_graphs=8, defer_loss_float=False, max_captures=24):
@@ -534,6 +535,7 @@ class GraphedTrainStep:
             # launch order of the replay: the towers with the most input first (the graphs of a phase reach the GPU one after
             # the other: the long video towers must not be last)
             e.par["order"] = sorted(range(len(thunks)), key=lambda i: -weights[i])
+            e.par["video"] = [w == e.static["student_videos"].numel() and w != e.static["student_text"].numel() for w in weights]
             # tower i on the stream the eager step (model._encode_towers) runs it on: this stepper's stream and the model's
             # side streams - a parameter's gradient-accumulation node stays bound to the stream of its first use
             if m._side_streams is None or m._side_streams[0].device != dev:
@@ -603,7 +605,7 @@ class GraphedTrainStep:
             close_graph()
             e.par["ev"] = {"fwd": [torch.cuda.Event() for _ in range(n)], "bwd": [torch.cuda.Event() for _ in range(n)],
                            "loss": [torch.cuda.Event() for _ in e.par["loss"]]}
-            e.par["ev_pre"], e.par["ev_pre_done"] = torch.cuda.Event(), torch.cuda.Event()
+            e.par["ev_pre"], e.par["ev_pre_done"], e.par["ev_in_video"] = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         except BaseException as ex:
             close_graph(type(ex), ex, ex.__traceback__)
             raise
@@ -619,7 +621,12 @@ class GraphedTrainStep:
         par["pre"].replay()
         par["ev_pre_done"].record(main)
         for i in par["order"]:
-            streams[i].wait_event(par["ev_pre"])
+            # (a tower on the main stream runs behind the graph in front anyway; a video tower on a side stream needs the video
+            # features and the dropout state only.  Launching those two graphs BEFORE the host's other work for the step was tried:
+            # C3 2.69 -> 2.63 ms but C5 1.42 -> 1.50 with float(loss) every step, no change without - the host's launch order is
+            # then the wrong way round for the short C5 towers - not kept)
+            early = self.EARLY_VIDEO_START and par["video"][i] and streams[i] is not main
+            streams[i].wait_event(par["ev_in_video"] if early else par["ev_pre"])
             with torch.cuda.stream(streams[i]):
                 par["fwd"][i].replay()
                 ev["fwd"][i].record(streams[i])
@@ -643,10 +650,24 @@ class GraphedTrainStep:
     def _replay(self, e, batch):
         from . import ops
         m, opt_ = self.model, self.optimizer
-        for k in self.TENSOR_KEYS:
-            e.static[k].copy_(batch[k], non_blocking=True)
+
+        def stage(keys):
+            for k in keys:                                # (a data path that fills e.static itself hands the same storage back: no copy)
+                if batch[k].data_ptr() != e.static[k].data_ptr():
+                    e.static[k].copy_(batch[k], non_blocking=True)
+
+        # the video features first - the largest copy (201 MB at the TVR batch: 72 us) feeding the longest chains; the video towers
+        # start behind it and the step's scalars (ev_in_video below) while the other inputs are still being copied
+        stage(self.TENSOR_KEYS[:2])
         slot = e.ring.next()[:4 * e.words].view(torch.int32)
         e.philox.begin_step(slot[0:4].view(torch.int64))
+        par = getattr(e, "par", None)
+        if par:
+            # ... and the dropout state (the slot's first 16 bytes) - all a tower's forward pass reads of the step's scalars - goes up
+            # before the host draws the triplet negatives: a step that begins on an idle GPU (float(loss) every step) starts its
+            # video towers ~0.1 ms earlier
+            e.ring.upload_range(e.dev_words.view(torch.uint8), 0, 16, last=False)
+            par["ev_in_video"].record(self.stream)
         opt_.t_lr = e.t_lr
         n_t = len(opt_.fp.params)
         opt_.host_prepare(lr_out=slot[e.off["lr"]:e.off["lr"] + n_t].view(torch.float32))
@@ -657,8 +678,12 @@ class GraphedTrainStep:
             slot[e.off[("t2v", c)]:e.off[("t2v", c)] + e.nq] = r_t2v
             if r_v2t is not None:
                 slot[e.off[("v2t", c)]:e.off[("v2t", c)] + e.nv] = r_v2t
-        e.ring.upload(e.dev_words.view(torch.uint8))
-        if getattr(e, "par", None):
+        if par:
+            e.ring.upload_range(e.dev_words.view(torch.uint8), 16, 4 * e.words, last=True)
+        else:
+            e.ring.upload(e.dev_words.view(torch.uint8))
+        stage(self.TENSOR_KEYS[2:])
+        if par:
             opt_.fp.bind_views(e.had)                     # the captured copies fill the flat ranges: nothing to gather
             self._replay_parallel(e)
         elif getattr(e, "segments", None):
