@@ -59,7 +59,7 @@ class PinnedRing:
             self.events[self.i] = ev
 
 
-def concurrent_streams(device, n, candidates=16, cycles=1_000_000):
+def concurrent_streams(device, n, candidates=16, cycles=1_000_000, high_priority=0):
     """n torch streams that run side by side on the device.  HIP multiplexes its streams onto GPU_MAX_HW_QUEUES (default 4)
     hardware queues, and two streams that share a queue execute their kernels in order: of torch's pooled streams number 0 shares
     a queue with 7 and 11, 3 with 4 and 8, ... (tools/probe_stream_queues.py) - the training stepper's four tower streams were
@@ -68,7 +68,11 @@ def concurrent_streams(device, n, candidates=16, cycles=1_000_000):
     one.  Greedy: a candidate joins the set when it overlaps with every stream already in it."""
     import time
     device = torch.device(device)
-    cands = [torch.cuda.Stream(device=device) for _ in range(max(candidates, n))]
+    # high_priority: the first that many streams of the result are high-priority streams (their kernels are dispatched ahead of the
+    # others' when both are ready: the short query-tower chains of the training step next to the chip-filling video towers)
+    cands = [torch.cuda.Stream(device=device, priority=-1) for _ in range(max(candidates // 2, high_priority) if high_priority else 0)]
+    n_high = len(cands)
+    cands += [torch.cuda.Stream(device=device) for _ in range(max(candidates, n))]
 
     def run(streams):
         torch.cuda.synchronize(device)
@@ -82,9 +86,11 @@ def concurrent_streams(device, n, candidates=16, cycles=1_000_000):
     run(cands[:1])
     one = min(run(cands[:1]) for _ in range(3))
     chosen = [cands[0]]
-    for c in cands[1:]:
+    for j, c in enumerate(cands[1:], 1):
         if len(chosen) == n:
             break
+        if j < n_high and len(chosen) >= high_priority:      # enough high-priority streams: on to the normal ones
+            continue
         if all(min(run([c, o]) for _ in range(2)) < 1.5 * one for o in chosen):
             chosen.append(c)
     for c in cands:                    # fewer than n distinct queues (GPU_MAX_HW_QUEUES < n): fill up with what there is

@@ -13,6 +13,8 @@ early stopping is too."""
 import logging
 import math
 
+import os
+
 import torch
 from torch.utils.data import DataLoader
 
@@ -197,6 +199,7 @@ class GraphedTrainStep:
     comm stream as its segment has been launched and runs under the next segment; the optimizer update is the chain's last graph
     (_capture_segments)."""
 
+    QUERY_STREAMS_HIGH_PRIORITY = os.environ.get("DLDKD_QUERY_PRIO", "0") == "1"
     EARLY_VIDEO_START = True      # replay: the video towers start behind the video features' copy, not behind the whole batch's
     TENSOR_KEYS = ("student_videos", "student_videos_mask", "teacher_videos", "student_text", "student_text_mask", "teacher_text")
 
@@ -268,7 +271,8 @@ class GraphedTrainStep:
             if self.parallel_towers and getattr(self.model, "tower_streams", False) and hasattr(self.model, "_side_streams"):
                 # this stepper's stream and the model's three side streams on four DIFFERENT hardware queues (measured once)
                 from .staging import concurrent_streams
-                st = concurrent_streams(dev, 4)
+                # (QUERY_TOWERS_FIRST: towers 0, 1 - this stream and the first side stream - are the query towers)
+                st = concurrent_streams(dev, 4, high_priority=2 if self.QUERY_STREAMS_HIGH_PRIORITY else 0)
                 self.stream, self.model._side_streams = st[0], list(st[1:4])
             else:
                 self.stream = torch.cuda.Stream(device=dev)
