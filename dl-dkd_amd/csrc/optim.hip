@@ -7,9 +7,12 @@
 // Layout: all parameters of the model live in ONE flat fp32 buffer (and so do grads and both moments);
 // tensor t occupies [start[t], start[t] + numel[t]) with start[t] a multiple of 256, so a 256-element chunk
 // never straddles two tensors and chunk_tensor[chunk] names its tensor.
+#include <atomic>
+
 #include "common.hpp"
 
 namespace dldkd {
+static std::atomic<int> g_zero_by_memset{0};
 
 constexpr int kSumsqChunks = 16;
 
@@ -94,6 +97,29 @@ using namespace dldkd;
 
 extern "C" {
 
+/* Zero n floats on `stream` the way the captured step's entry points zero their scratch buffers: by a kernel (default) or, after
+ * dldkd_set_zero_by_memset(1), by hipMemsetAsync - a MEMSET node under capture.  Round 3 found such a node defective on ROCm 7.0.2
+ * (a replayed memset node left every fourth word of BertAdam's 296-byte norm scratch stale whenever the stream was idle at launch:
+ * garbage clip coefficients in replayed steps only); staging.memset_node_defect captures THIS call in a one-node graph and replays
+ * it over a poisoned buffer to find out what the runtime at hand does (allocation, synchronisation and the read-back are the
+ * caller's: this library only enqueues). */
+int dldkd_zero_scratch_f32(float* x, int n, void* stream) {
+    if (n < 0 || (n > 0 && !x)) { set_error("zero_scratch: bad arguments"); return DLDKD_EINVAL; }
+    if (n == 0) return DLDKD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (g_zero_by_memset.load(std::memory_order_relaxed)) {
+        if (hipMemsetAsync(x, 0, (size_t)n * sizeof(float), s) != hipSuccess) return check_launch("zero_scratch (memset)");
+        return DLDKD_OK;
+    }
+    DLDKD_LAUNCH(zero_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n);
+    return check_launch("zero_scratch");
+}
+
+/* How the entry points that zero a small scratch buffer inside a captured step do it (dldkd_bert_adam_step_f32's norm scratch):
+ * 0 = a kernel (default, immune to the defect above), 1 = hipMemsetAsync (a memset node under capture).  Returns the previous
+ * setting.  train.GraphedTrainStep sets it from the probe's result. */
+int dldkd_set_zero_by_memset(int on) { return g_zero_by_memset.exchange(on ? 1 : 0); }
+
 int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const int32_t* chunk_tensor, int n_chunks,
                              const int32_t* t_start, const int32_t* t_numel, int n_tensors, float* norm2_scratch,
                              const float* t_wd, const float* t_lr, const float* t_active, float b1, float b2, float eps,
@@ -106,7 +132,13 @@ int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const
     }
     hipStream_t s = (hipStream_t)stream;
     if (max_grad_norm > 0.f) {
-        DLDKD_LAUNCH(zero_f32_kernel, dim3((n_tensors + 255) / 256), dim3(256), 0, s, norm2_scratch, n_tensors);
+        // zeroed by a kernel unless the start-up probe (staging.memset_node_defect) found this runtime's memset nodes clean and the
+        // caller switched them on (dldkd_set_zero_by_memset)
+        if (g_zero_by_memset.load(std::memory_order_relaxed)) {
+            if (hipMemsetAsync(norm2_scratch, 0, (size_t)n_tensors * sizeof(float), s) != hipSuccess) return check_launch("bert_adam (memset)");
+        } else {
+            DLDKD_LAUNCH(zero_f32_kernel, dim3((n_tensors + 255) / 256), dim3(256), 0, s, norm2_scratch, n_tensors);
+        }
         DLDKD_LAUNCH(adam_sumsq_kernel, dim3((n_chunks + kSumsqChunks - 1) / kSumsqChunks), dim3(256), 0, s, g, chunk_tensor, t_start,
                            t_numel, norm2_scratch, n_chunks);
     }

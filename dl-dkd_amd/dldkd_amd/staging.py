@@ -99,3 +99,56 @@ def concurrent_streams(device, n, candidates=16, cycles=1_000_000, high_priority
         if c not in chosen:
             chosen.append(c)
     return chosen
+
+
+_MEMSET_PROBE = {}
+
+
+def memset_node_defect(device, replays=48, log=None, select=False):
+    """True / False: does a replayed hipGraph MEMSET node leave stale words on this runtime?  Probed once per process and device:
+    the native call that zeroes a scratch buffer by hipMemsetAsync is captured as a one-node graph over 74 floats (BertAdam's
+    296-byte norm scratch, where ROCm 7.0.2 showed the defect) and replayed on a drained stream over a freshly poisoned buffer;
+    the graph is [memset node, a kernel that adds 1 to every word] - the optimizer's [zero the norms, accumulate into them] - and a
+    word that is not exactly 1.0 afterwards is the defect.  select=True (opt.scratch_zeroing = "probe"): the native zeroing mode
+    follows the result - clean -> memset nodes, defect or a probe that could not run -> kernel fills.  The default keeps the
+    kernel fills whatever the probe says and only logs it: on the round-4 boxes (same ROCm 7.0.2) this probe found 0 stale words in
+    48 replays although round 3 saw the defect inside the full optimizer graph - a clean probe is weak evidence, a dirty one is
+    proof."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return False
+    if device not in _MEMSET_PROBE:
+        from . import native
+        lib = native.lib()
+        stale, err = 0, None
+        prev = lib.dldkd_set_zero_by_memset(1)
+        try:
+            st = torch.cuda.Stream(device=device)
+            buf = torch.empty(74, dtype=torch.float32, device=device)
+            ones = torch.ones(74, dtype=torch.float32, device=device)
+            torch.cuda.synchronize(device)
+            with torch.cuda.stream(st):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+                    native.check(lib.dldkd_zero_scratch_f32(native.ptr(buf), 74, native.stream()), "zero_scratch")
+                    native.check(lib.dldkd_axpy_f32(native.ptr(buf), native.ptr(ones), 1.0, 74, native.stream()), "axpy")
+                for r in range(int(replays)):
+                    buf.view(torch.int32).fill_(0x510c7186 + r)
+                    st.synchronize()                       # the graph is launched on an idle stream
+                    g.replay()
+                    st.synchronize()
+                    stale += int((buf != 1.0).sum())
+            del g
+        except Exception as ex:                            # noqa: BLE001 - a probe that cannot run selects the safe mode
+            err = repr(ex)
+        finally:
+            lib.dldkd_set_zero_by_memset(prev)
+        defect = err is not None or stale != 0
+        _MEMSET_PROBE[device] = (defect, stale, err)
+        if log is not None:
+            log(f"hipGraph memset-node probe on {device}: {stale} stale words in {replays} replays" + (f" (probe failed: {err})" if err else ""))
+    defect = _MEMSET_PROBE[device][0]
+    if select:
+        from . import native
+        native.lib().dldkd_set_zero_by_memset(0 if defect else 1)
+    return defect

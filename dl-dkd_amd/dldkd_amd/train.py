@@ -398,9 +398,13 @@ class GraphedTrainStep:
 
     def _capture(self, batch, key):
         from . import functional as F_
-        from .staging import PinnedRing
+        from .staging import PinnedRing, memset_node_defect
         m, opt_ = self.model, self.optimizer
         dev = batch["student_videos"].device
+        # the hipGraph memset-node defect is probed on THIS runtime (once per process; never while a capture is open) and logged;
+        # opt.scratch_zeroing = "probe" lets the result choose how the captured optimizer zeroes its norm scratch (memset node if
+        # clean), the default "kernel" keeps the kernel fill
+        self.memset_defect = memset_node_defect(dev, log=logger.info, select=getattr(self.opt, "scratch_zeroing", "kernel") == "probe")
         e = _CapturedStep()
         labels = list(batch["text_labels"])
         nq, nv = len(labels), batch["student_videos"].shape[0]

@@ -655,6 +655,15 @@ int dldkd_simpool_rank_partials_count(const void* workspace, int nq, int nv, int
  * Optimiser step and sharded-ranking helper.
  * ------------------------------------------------------------------------------------------- */
 
+/* Zero n floats on `stream` the way the captured step's entry points zero their scratch (BertAdam's per-tensor norms): by a kernel
+ * (default) or, after dldkd_set_zero_by_memset(1), by hipMemsetAsync = a MEMSET node under capture.  ROCm 7.0.2 replayed such a
+ * node with every fourth word of a 296-byte buffer left stale when the stream was idle at launch; the host side captures this call
+ * in a one-node graph and replays it over a poisoned buffer to learn what the runtime at hand does (staging.memset_node_defect). */
+int dldkd_zero_scratch_f32(float* x, int n, void* stream);
+/* 0 (default): small scratch buffers inside captured steps are zeroed by a kernel; 1: by hipMemsetAsync (a memset node).
+ * Returns the previous setting.  The training stepper sets it from the probe. */
+int dldkd_set_zero_by_memset(int on);
+
 /* One BertAdam step (method/optimization.py:278-343) over ALL tensors of a flat parameter buffer in two
  * launches.  p/g/m/v: flat fp32 buffers; tensor t = [t_start[t], t_start[t]+t_numel[t]), t_start multiples of
  * 256; chunk_tensor[c] = tensor of 256-element chunk c.  Per-tensor clip to max_grad_norm (coef =

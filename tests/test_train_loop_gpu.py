@@ -501,3 +501,46 @@ def test_parallel_tower_graphs_are_used_and_match_the_single_graph():
         assert len(staging.concurrent_streams(torch.device(DEV), 3)) == 3
     finally:
         ops.set_gemm_precision("fp32")
+
+
+def test_memset_node_probe_selects_the_zeroing_mode_by_evidence():
+    """staging.memset_node_defect: one memset node over the 296-byte buffer that showed the defect, replayed on an idle stream over a
+    poisoned buffer; the native zeroing mode follows the result (defect -> kernel fills, clean -> memset nodes), and the replayed
+    BertAdam step with gradient clipping - the consumer of that scratch buffer - equals the eager one in either mode."""
+    from dldkd_amd import native, staging
+    lib = native.lib()
+    staging._MEMSET_PROBE.clear()
+    seen = []
+    lib.dldkd_set_zero_by_memset(0)
+    defect = staging.memset_node_defect(torch.device(DEV), log=seen.append)
+    assert len(seen) == 1 and "memset-node probe" in seen[0] and isinstance(defect, bool)
+    print("  " + seen[0])
+    assert lib.dldkd_set_zero_by_memset(0) == 0                           # logging only: the default keeps the kernel fill
+    assert staging.memset_node_defect(torch.device(DEV), select=True) == defect and len(seen) == 1     # cached; now it selects
+    assert lib.dldkd_set_zero_by_memset(0) == (0 if defect else 1)
+    x = torch.full((1000,), 3.0, device=DEV)
+    for mode in (0, 1):                                                   # the zeroing entry point itself, eager, both modes
+        lib.dldkd_set_zero_by_memset(mode)
+        x.fill_(3.0)
+        native.check(lib.dldkd_zero_scratch_f32(native.ptr(x), 999, native.stream()), "zero")
+        torch.cuda.synchronize()
+        assert float(x[:999].abs().sum()) == 0.0 and float(x[999]) == 3.0
+    # the optimizer entry point in both modes: per-tensor clipping of a flat gradient, eager launches (no graph: the mode only
+    # changes HOW the scratch is zeroed)
+    from dldkd_amd import optimization as optim
+    torch.manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(n, device=DEV)) for n in (300, 5, 4097)]
+    res = []
+    for mode in (0, 1):
+        lib.dldkd_set_zero_by_memset(mode)
+        qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        o = optim.BertAdam(qs, lr=1e-2, warmup=0.1, t_total=10, weight_decay=0.01, max_grad_norm=1.0)
+        for it in range(3):
+            for q in qs:
+                q.grad = torch.full_like(q, 0.5 + it)
+            o.step()
+        torch.cuda.synchronize()
+        res.append([q.detach().clone() for q in qs])
+    lib.dldkd_set_zero_by_memset(0)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
