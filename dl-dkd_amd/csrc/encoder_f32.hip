@@ -36,11 +36,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (row_mask != nullptr || gin != nullptr) {
         // rows of the padding (row_mask[row] == 0: clips past a video's length in a padded batch) are not read: their output row
         // is zeros (keep bytes 0, statistics 0) - no loss term depends on them and their gradients are exactly zero, so the
-        // GEMMs behind this kernel may skip them (gflags[g] = 1 when the 32-row group g starts with a valid row: masks are
-        // prefixes, groups never straddle two sequences when the padded length is a multiple of 32)
+        // GEMMs behind this kernel may skip them (gflags[g] = 1 when ANY of the 32 rows of group g is valid - the wave of the
+        // group's first row reads the 32 mask values; a mask need not be a prefix: ADVICE r03 - and M % 32 == 0, entry points)
         // (gin: the group flags an earlier kernel of the tower wrote - validity per 32-row group instead of per row)
         const bool valid = row_mask != nullptr ? row_mask[row] > 0.f : gin[row >> 5] != 0;
-        if (gflags != nullptr && lane == 0 && (row & 31) == 0) gflags[row >> 5] = valid ? 1 : 0;
+        if (gflags != nullptr && (row & 31) == 0) {
+            const bool any = row_mask != nullptr ? __ballot(lane < 32 && row_mask[row + (lane & 31)] > 0.f) != 0ull : valid;
+            if (lane == 0) gflags[row >> 5] = any ? 1 : 0;
+        }
         if (!valid) {
             if (stats != nullptr && lane == 0) { stats[row] = 0.f; stats[M + row] = 0.f; }
             for (int c = lane; c < nv; c += 64) {

@@ -452,3 +452,29 @@ def test_input_projection_backward_as_one_two_accumulator_gemm(bf16_mode, nv, L,
         assert rel(dg1, ref_g) <= 5e-3 and rel(db1, ref_b) <= 5e-3
         for k in (3, 7, K - 1, 11):
             assert abs(dg1[k] - ref_g[k]) <= 1e-4 * sg and abs(db1[k] - ref_b[k]) <= 1e-4 * sb
+
+
+def test_row_group_flags_are_the_or_over_the_32_rows_of_a_group(bf16_mode):
+    """The padding skip's group flags (written by the LayerNorm-dropout kernel of the training input projection) say "some row of
+    these 32 is valid" for ANY mask - not only for prefix masks, whose first row decides: a scattered mask flags every
+    group that holds a valid row, and the rows are normalised exactly where the mask says."""
+    from dldkd_amd import native
+    L = native.lib()
+    g = torch.Generator().manual_seed(3)
+    M, K = 32 * 40, 256
+    x = torch.randn(M, K, generator=g).to(DEV)
+    mask = (torch.rand(M, generator=g) < 0.05).float()
+    mask[32 * 7:32 * 8] = 0                                              # an empty group
+    mask[32 * 9] = 0; mask[32 * 9 + 31] = 1                              # a group whose first row is padding and last row valid
+    gamma, beta = torch.ones(K, device=DEV), torch.zeros(K, device=DEV)
+    z = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    stats = torch.empty(2, M, device=DEV)
+    flags = torch.full((M // 32,), 7, dtype=torch.uint8, device=DEV)
+    native.check(L.dldkd_layernorm_dropout_bf16(native.ptr(x), native.ptr(gamma), native.ptr(beta), native.ptr(z), None, native.ptr(stats), M, K,
+                                                1e-5, 0.0, 0, 0, None, native.ptr(mask.to(DEV)), native.ptr(flags), native.stream()), "ln")
+    want = mask.view(-1, 32).amax(1).to(torch.uint8)
+    assert torch.equal(flags.cpu(), want) and int(want[7]) == 0 and int(want[9]) == 1
+    ref = torch.nn.functional.layer_norm(x.cpu(), (K,), eps=1e-5)
+    got = z.float().cpu()
+    assert torch.equal(got[mask == 0], torch.zeros_like(got[mask == 0]))
+    assert (got[mask > 0] - ref[mask > 0]).abs().max().item() < 2e-2

@@ -47,6 +47,12 @@ def test_eval_epoch_runs_throughput_mode_by_default_and_restores_the_precision()
         n = len(seen)
         par = ev.eval_epoch(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), mk(eval_precision="parity"))
         assert len(seen) == n                                                 # parity mode never enters the fused path
+        # the final / test evaluation (test=True) reports fp32-grade numbers unless the caller asks for throughput mode
+        final = ev.eval_epoch(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), mk(), test=True)
+        assert len(seen) == n and final == par
+        ev.eval_epoch(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), mk(eval_precision="throughput"), test=True)
+        assert len(seen) > n
+        assert ev.eval_precision_mode(mk()) == "throughput" and ev.eval_precision_mode(mk(), test=True) == "parity"
     assert abs(fast - par) <= 4 * 100.0 / 192 * 2 + 1e-9                      # 192 queries, random-init near-ties: <= 2 queries per cut
     with pytest.raises(ValueError):
         ev.eval_epoch(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), mk(eval_precision="fp8"))
