@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdldkd_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
