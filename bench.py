@@ -640,7 +640,6 @@ def main():
                     "recall_matches_n1": r4["recall_hip"] == RECALL_C4_N1},
                     "c5_ddp": r5}
         dist.barrier()
-        dist.destroy_process_group()
     else:
         # ---- one GPU: the headline line with the kernel's roofline, the CPU baseline and the extras
         gs, mask, lens, qs, gt = synth_shard(dev, C2, 0, NV)
@@ -728,6 +727,14 @@ def main():
         except Exception:   # noqa: BLE001
             pass
         print(json.dumps(out), flush=True)
+    if world > 1 or os.environ.get("DLDKD_BENCH_FORCE_DIST") == "1":
+        # The line is out.  Leave without tearing the process group down: destroy_process_group() of this RCCL build aborts now
+        # and then (seen once per ~20 one-rank runs, always at teardown, never in a collective) and an abort here would turn a
+        # finished measurement into a failed run.  Every rank has passed the barrier above; nothing is in flight.
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -611,7 +611,10 @@ class _TowerTrain(Function):
         dwd, dbd = dW[o * H:(o + 1) * H], dB[o * H:(o + 1) * H]
         dwq, dwk, dwv = (dW[(o + 1 + c) * H:(o + 2 + c) * H] for c in range(3))
         dbq, dbk, dbv = (dB[(o + 1 + c) * H:(o + 2 + c) * H] for c in range(3))
-        dpos = _colsum(dx1, L * HIDDEN).view(L, HIDDEN) if need_pos else None
+        dpos = None
+        if need_pos:                                         # gradient of the whole table: rows >= L stay zero (arena)
+            dpos = _zeros((pos.shape[0], HIDDEN), dev)
+            native.check(L_.dldkd_colsum_f32(_p(dx1), _p(dpos), dx1.shape[0], L * HIDDEN, _s()), "colsum")
         return (dy0, dpos, lnp[2], lnp[3], dwq, dbq, dwk, dbk, dwv, dbv, dwd, dbd, lnp[0], lnp[1], dwo, dbo,
                 None, None, None, None, None, None, None)
 
@@ -755,6 +758,8 @@ class _SimPoolTrain(Function):
                      "simpool_train_fwd")
         ctx.save_for_backward(q, g, rq, rg, lens, labels, ac, ar, pc, clip)
         ctx.mark_non_differentiable(ac, ar)
+        ctx.set_materialize_grads(False)       # unused outputs (the arg-max planes, a clip row nobody reads) arrive as None in backward
+                                               # instead of freshly filled zero tensors (2 int + up to 2 float fill kernels per call)
         if clip is None:
             return pc, pr, ac, ar
         return pc, pr, ac, ar, clip
@@ -916,6 +921,7 @@ class _BranchLoss(Function):
                                                   float(beta), float(eps), float(temp), float(w_nce), float(w_kl), _p(terms), _p(dC), _p(dS),
                                                   _p(dclip), _p(out), _s()), "branch_losses")
         ctx.save_for_backward(dC, dS, dclip)
+        ctx.set_materialize_grads(False)       # a term nobody uses has no upstream gradient (None, handled in backward): no zero fill
         return out[0], out[1], out[2]
 
     @staticmethod

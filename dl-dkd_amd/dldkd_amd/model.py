@@ -420,7 +420,9 @@ class DLDKD(nn.Module):
         rg = F_.take_group_flags()
         flags = rg[0] if (rg is not None and self.TOWER_SKIPS_PADDING and rg[1] == n * L) else None
         out_lin = getattr(self, pre + "out_mapping_linear") if kind == "visual" else None
-        return F_.tower_train(y0, pos.position_embeddings.weight[:L], pos.LayerNorm.weight, pos.LayerNorm.bias,
+        # (the WHOLE position table goes in - the kernels read its first L rows: a [:L] view here costs a zeros + copy pair per tower
+        # in autograd's slice backward)
+        return F_.tower_train(y0, pos.position_embeddings.weight, pos.LayerNorm.weight, pos.LayerNorm.bias,
                               (enc.self.query, enc.self.key, enc.self.value), enc.output.dense, enc.output.LayerNorm.weight,
                               enc.output.LayerNorm.bias, out_lin, mask, self._lens(mask, n, L, feat.device), flags,
                               pos.dropout.p, enc.self.dropout.p, enc.output.dropout.p, self.training, relu_mask=fused_proj)

@@ -30,3 +30,28 @@ def pytest_sessionstart(session):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def in_child_process(fn):
+    """Run a test that creates an RCCL process group in a pytest CHILD process of its own.  destroy_process_group() of this RCCL
+    build aborts the interpreter now and then (always at teardown - never in a collective - and not reproducibly: about one run in
+    ten of the suite); in the suite's own process that abort would take every later test with it.  The child runs exactly this test
+    and, when the body has returned, leaves through os._exit(0) without tearing the group down; a failing assertion is reported by
+    the child's pytest and comes back as a non-zero exit code with its output."""
+    import functools
+    import inspect
+    import subprocess
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        name = fn.__module__ + "::" + fn.__name__
+        if os.environ.get("DLDKD_TEST_CHILD") == name:
+            fn(*a, **k)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
+        node = f"{inspect.getsourcefile(fn)}::{fn.__name__}"
+        r = subprocess.run([sys.executable, "-m", "pytest", node, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"],
+                           env=dict(os.environ, DLDKD_TEST_CHILD=name), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+        assert r.returncode == 0, f"child pytest of {name} exited with {r.returncode}\n{r.stdout[-6000:]}\n{r.stderr[-3000:]}"
+    return wrapper

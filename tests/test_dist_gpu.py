@@ -4,12 +4,14 @@ reproduce the plain one-launch matrix bit for bit, step after step (counters and
 import os
 
 import pytest
+from conftest import in_child_process
 import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@in_child_process
 def test_overlapped_shard_scorer_one_rank_rccl():
     import torch.distributed as dist
     from dldkd_amd import dist as ddist
@@ -42,4 +44,4 @@ def test_overlapped_shard_scorer_one_rank_rccl():
         torch.cuda.synchronize()
         assert torch.equal(ov.assemble(nv), scoring.simpool_eval(scoring.pack_queries(qs), pg)[0])
     finally:
-        dist.destroy_process_group()
+        pass                                     # (no teardown of the RCCL group: conftest.in_child_process)

@@ -5,6 +5,7 @@ import types
 
 import numpy as np
 import pytest
+from conftest import in_child_process
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -129,6 +130,7 @@ def test_throughput_mode_training_learns_like_parity_mode(tmp_path):
     assert max(s_got[1:]) > s_got[0] + 20 and max(s_got[1:]) >= max(s_ref[1:]) - 25, (s_got, s_ref)
 
 
+@in_child_process
 def test_data_parallel_step_on_one_rank_rccl_group(tmp_path):
     """The DDP branch of train_step (flat gradient bucket all-reduced over RCCL) with a one-rank group forced on:
     identical history to the plain run (mean over one rank is the identity)."""
@@ -144,7 +146,7 @@ def test_data_parallel_step_on_one_rank_rccl_group(tmp_path):
         got = _fit("fp32", tmp_path)
     finally:
         T.DDP_MIN_WORLD = old
-        dist.destroy_process_group()
+        pass                                     # (no teardown of the RCCL group: conftest.in_child_process)
     for a, b in zip(got[1:], ref[1:]):
         # not bitwise: split-K weight gradients and LayerNorm gamma/beta gradients accumulate with fp32 atomics, whose
         # order differs run to run; the difference stays at rounding level over the five epochs
@@ -261,6 +263,7 @@ def test_graphed_step_serves_variable_length_batches_from_a_few_graphs():
 
 
 @pytest.mark.parametrize("drop", [0.0, 0.2])
+@in_child_process
 def test_data_parallel_stepper_runs_the_step_as_a_chain_of_graph_segments(drop):
     """Data parallel (one-rank RCCL group forced on, gradient buckets per tower): the stepper replays the step as a chain of
     graphs - one per tower of the backward pass, each tower's all-reduce issued from the comm stream behind its segment - plus
@@ -333,7 +336,7 @@ def test_data_parallel_stepper_runs_the_step_as_a_chain_of_graph_segments(drop):
         assert len(e.segments) == 4 and e.opt_graph is not None
     finally:
         T.DDP_MIN_WORLD = old
-        dist.destroy_process_group()
+        pass                                     # (no teardown of the RCCL group: conftest.in_child_process)
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
