@@ -41,6 +41,9 @@ namespace tw {
 
 constexpr int kNKS = 24;                       // k-steps of 16 over 384 features
 constexpr int kChunk = 32;                     // ring: fragments per chunk
+#ifndef TW_PERS_EXP
+#define TW_PERS_EXP 0
+#endif
 #ifndef TW_DEPTH
 #define TW_DEPTH 3
 #endif
@@ -56,6 +59,7 @@ constexpr int kLdsPar = kLdsKV + kKVBytes;
 constexpr int P_WG = P_BO;                     // query towers (no out mapping): modular weight x gamma2 in the out-mapping bias slot
 constexpr int P_TAIL = 4;                      // ... followed by c1 = sum w gamma2, c2 = sum w beta2 (+ 2 unused words)
 constexpr int kLdsTotal = kLdsPar + P_TOTAL * 4 + 512;      // 163,840 = all 160 KiB
+constexpr int kLdsSink = kLdsPar + P_TOTAL * 4 + 256;       // 256 bytes nobody reads: where the L2 touch loads of the persistent kernel land
 constexpr int kStgPitch = 400;                 // output staging: 32 rows x 384 payload bytes per wave and pass
 constexpr int kPosTile = kNKS * 64 * 8;        // floats of one 32-position tile of the position table in fragment order
 constexpr int kInStage = 32 * 1024;            // prologue: h0 half-rows are staged at [32 KiB + wave * 24 KiB, +24 KiB) of LDS
@@ -148,17 +152,26 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
     constexpr int NCH = NFRAG / kChunk;
     static_assert(NFRAG % kChunk == 0, "whole chunks");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
+    // (not const: the persistent form passes them through an empty asm at the top of every item - see there)
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int r = lane & 31, h = lane >> 5;
+    // PERS (the bf16-h0 gallery kernel): a PERSISTENT workgroup - one per CU - walks items item, item + stride, ...; the next item's
+    // slot entry, row0 and h0 rows and the first weight chunks are fetched under the current item's tail, so that an item's
+    // prologue no longer waits for three dependent scalar loads and an HBM round trip (25 k of a workgroup's 158 k cycles in the
+    // stamped build) and its row stores drain under the next item's products.
+    constexpr bool PERS = H16 && !STAMP && !(TW_PERS_EXP & 4);
     int branch = 0, item = blockIdx.x;
     if (p.n_branches == 2) {        // blocks b and b + 8 share an XCD: blocks with (b & 4) equal share a branch's weights in L2
         branch = (blockIdx.x >> 2) & 1;
         item = (blockIdx.x >> 3) * 4 + (blockIdx.x & 3);
     }
+    const int first_item = item;
+    const int stride = p.n_branches == 2 ? (int)(gridDim.x >> 1) : (int)gridDim.x;   // PERS: items between two of this workgroup's
     if (item >= p.n_items) return;
-    const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
-    const uint32_t lane16 = lane * 16;
+    uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
+    uint32_t lane16 = lane * 16;
     const char* wsrc = p.blob[branch];
     float* par = reinterpret_cast<float*>(smem + kLdsPar);
     auto issue_chunk = [&](auto cc) {
@@ -171,12 +184,70 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
     // the first weight chunk depends on the branch only: in flight before the (dependent, scalar) loads that say which sequence
     // this wave works on
     issue_chunk(std::integral_constant<int, 0>{});
+    if constexpr (PERS) issue_chunk(std::integral_constant<int, 1>{});
+    // PERS: what the NEXT iteration works on, fetched one iteration ahead (ent: the slot entry, row0: its sequence's first row)
+    int ent_cur = 0, row0_cur = 0, ent_nxt = 0, row0_nxt = 0, ent_nn = 0;     // this item, the next, the one after
+    auto slot_entry = [&](int it) {
+        int e = p.items[it * 4 + wave];
+        if (e < 0) e = p.items[it * 4] | (int)0x80000000;          // idle slot: slot 0's tile, marked (entries are < 2^31)
+        return __builtin_amdgcn_readfirstlane(e);
+    };
+    // (PERS) pull a slot's 32 h0 rows (24 KiB = 192 lines of 128 B: three loads per lane, results discarded) into L2 one item
+    // ahead: the prologue's row loads then meet L2, not HBM under load.  Keeping the rows themselves in registers across the
+    // item boundary was tried first: the register allocator answered with 96 registers of scratch and a wait behind every load.
+    auto touch_rows = [&](int e, int row0_) {
+        const int len_ = e & 255, tile_ = (e >> 8) & 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int line = lane + 64 * i, row = line / 6, part = line - 6 * row;
+            const int l = 32 * tile_ + row, lrow = l < len_ ? l : len_ - 1;
+            const char* a = reinterpret_cast<const char*>(p.h0b[branch] + ((size_t)row0_ + lrow) * kHidden) + part * 128;
+            // an LDS-DMA into 256 spare bytes behind the parameter table: a load with a REGISTER destination would write it when the
+            // data arrives - long after the compiler, which sees an unused result, has given that register to a live value (the
+            // first build did exactly that: every item but a workgroup's last came out wrong)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(a), "s"(smem_lds + kLdsSink) : "memory");
+        }
+    };
+    if constexpr (PERS) {
+        ent_cur = slot_entry(item);
+        row0_cur = __builtin_amdgcn_readfirstlane(p.row0[(ent_cur & 0x7fffffff) >> 10]);
+        if (item + stride < p.n_items) ent_nxt = slot_entry(item + stride);
+        {   // parameter table: once per workgroup (the branch is fixed)
+            const f32x4* psrc = reinterpret_cast<const f32x4*>(wsrc + (size_t)(kQKVFrags + 2 * kSqFrags) * 1024);
+            f32x4* dst = reinterpret_cast<f32x4*>(par);
+            for (int i = tid; i < (P_TOTAL + P_TAIL) / 4; i += 256) dst[i] = psrc[i];
+        }
+    }
+    for (;;) {          // (not PERS: one pass)
+    // The loop makes every address the body forms from these seven values loop-invariant, and LLVM hoists them all in front of it:
+    // 360 64-bit weight-chunk pointers, hundreds of per-lane LDS addresses - 765 SGPR and 330 VGPR spills in the first build.
+    // Opaque per iteration, they are recomputed where they are used, as in the one-pass kernel.
+    // (the wave-uniform ones go through a VGPR and v_readfirstlane: LLVM takes the result of an asm for divergent and then puts
+    // "s" operands of later asm statements into VGPRs - `s_mov_b32 m0, v1` - which only the assembler notices)
+    if constexpr (PERS) {
+        int w_ = wave;
+        uint32_t sl_ = smem_lds, lo_ = (uint32_t)reinterpret_cast<uint64_t>(wsrc), hi_ = (uint32_t)(reinterpret_cast<uint64_t>(wsrc) >> 32);
+        asm volatile("" : "+v"(lane), "+v"(w_), "+v"(sl_), "+v"(lo_), "+v"(hi_));
+        r = lane & 31;                                                 // (re-derived: the compiler may rematerialise them from `lane`)
+        h = lane >> 5;
+        lane16 = lane * 16;
+        wave = __builtin_amdgcn_readfirstlane(w_);
+        smem_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl_);
+        wsrc = reinterpret_cast<const char*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi_) << 32) |
+                                             (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo_));
+    }
     // this wave's slot: a 32-row tile of some sequence.  An idle slot re-computes slot 0's tile and stores nothing (the
     // instruction stream, with its barriers and its share of the weight DMA, is the same for every wave).
     int seq, tile;
     bool live = true;
     int len_item = -1;
-    if (p.items != nullptr) {
+    if constexpr (PERS) {                              // fetched one iteration ahead (entry point: an item table and row0 are given)
+        live = ent_cur >= 0;
+        const int ent = ent_cur & 0x7fffffff;
+        seq = ent >> 10;
+        tile = (ent >> 8) & 3;
+        len_item = ent & 255;
+    } else if (p.items != nullptr) {
         int ent = p.items[item * 4 + wave];                      // (seq << 10) | (tile << 8) | length: ONE scalar load per wave
         if (ent < 0) { live = false; ent = p.items[item * 4]; }
         seq = ent >> 10;
@@ -199,8 +270,8 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
     const int len = OUTMODE == 2 ? (len_raw < 1 ? 1 : len_raw > 32 ? 32 : len_raw) : len_raw;   // (query mode: host contract 1..32)
     const int nrows = OUTMODE == 0 && p.items == nullptr && p.seq_rows > len ? p.seq_rows : len;   // rows computed and stored
     const int first = (live || (OUTMODE == 2 && p.items == nullptr)) ? wave - tile : 0;   // slot of the sequence's tile 0 (K / V of key tile kt: slot first + kt)
-    const int row0 = p.row0 != nullptr ? p.row0[seq] : seq * p.seq_rows;
-    if (OUTMODE != 2 && len <= 0) {     // only without an item table
+    const int row0 = PERS ? row0_cur : p.row0 != nullptr ? p.row0[seq] : seq * p.seq_rows;
+    if (!PERS && OUTMODE != 2 && len <= 0) {     // only without an item table
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (an LDS-DMA must not outlive its workgroup) (the host never schedules an empty sequence): the workgroup IS the sequence
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         if constexpr (OUTMODE == 1) {
@@ -214,6 +285,13 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         return;
     }
     const int ntiles = (len + 31) >> 5;                // 32-row tiles of the sequence (wave-uniform)
+    const bool has_next = PERS && item + stride < p.n_items;
+    if constexpr (PERS) {
+        // two independent fetches, issued here and complete at the prologue's vmcnt(0) - i.e. before the hand-counted stream begins:
+        // the next item's row0 (its slot entry came in one iteration ago) and the slot entry of the item after it
+        if (has_next) row0_nxt = __builtin_amdgcn_readfirstlane(p.row0[(ent_nxt & 0x7fffffff) >> 10]);
+        if (item + 2 * stride < p.n_items) ent_nn = slot_entry(item + 2 * stride);
+    }
 
     // ---- weight ring --------------------------------------------------------------------------------------------
     bf16x8 fr[kFr];
@@ -232,10 +310,13 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         constexpr int pend = n < kQKVFrags ? pbeg + kHeadFrags : pbeg + kSqFrags;
         if constexpr ((n + kDepth) % kChunk == 0 && n + kDepth < NFRAG) {
             constexpr int c = (n + kDepth) / kChunk;           // chunk c is about to be read
-            if constexpr (c + 1 < NCH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but chunk c + 1's pieces
+            // (PERS: the stream runs on into the next item's chunks 0 and 1 - issued below whether or not there is a next item: a
+            // wasted 64 KiB of L2 traffic at the end of a workgroup's life buys one form of the counted wait)
+            if constexpr (c + 1 < NCH || (PERS && !(TW_PERS_EXP & 1))) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but chunk c + 1's pieces
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");            // every wave's pieces of chunk c landed; chunk c - 1 is consumed
             if constexpr (c + 2 < NCH) issue_chunk(std::integral_constant<int, c + 2>{});
+            else if constexpr (PERS && !(TW_PERS_EXP & 1)) issue_chunk(std::integral_constant<int, c + 2 - NCH>{});
         }
         if constexpr (n == pbeg) static_for<0, kDepth>([&](auto dc) { ring_read(std::integral_constant<int, pbeg + decltype(dc)::value>{}); });
         if constexpr (n + kDepth < pend) ring_read(std::integral_constant<int, n + kDepth>{});
@@ -265,7 +346,8 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
 #pragma unroll
         for (int ks = 0; ks < kNKS; ++ks) raw[ks] = __builtin_nontemporal_load(src + 2 * ks);
         pstamp();                                                      // p0: row loads issued
-        {   // parameter table
+        if constexpr (!PERS) {
+            // parameter table
             const f32x4* psrc = reinterpret_cast<const f32x4*>(wsrc + (size_t)NFRAG * 1024);
             f32x4* dst = reinterpret_cast<f32x4*>(par);
             for (int i = tid; i < (P_TOTAL + P_TAIL) / 4; i += 256) dst[i] = psrc[i];
@@ -364,11 +446,17 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         const float mean = half_swap_sum(s) * (1.f / kHidden);
         const float rstd = rsqrtf(fmaxf(half_swap_sum(q) * (1.f / kHidden) - mean * mean, 0.f) + 1e-5f);
         const float nmr = -mean * rstd;
+        // (PERS: also the previous item's row stores and the look-ahead chunks 0 and 1; the barrier below is the item boundary -
+        // every wave is past the previous item's last chunk and its output staging in the K / V region)
         if constexpr (H16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // weight chunk 0 landed (older than the row loads)
         __syncthreads();                                               // parameter table visible; every wave is done with its staging
         pstamp();                                                      // p5: workgroup met
-        issue_chunk(std::integral_constant<int, 1>{});                 // (chunks 1 and 2 land where the staging was)
-        issue_chunk(std::integral_constant<int, 2>{});
+        if constexpr (PERS && (TW_PERS_EXP & 1)) {                     // (experiment: no look-ahead chunks)
+            if (item != first_item) { issue_chunk(std::integral_constant<int, 0>{}); issue_chunk(std::integral_constant<int, 1>{}); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+        }
+        if constexpr (!PERS) issue_chunk(std::integral_constant<int, 1>{});    // (chunks 1 and 2 land where the staging was)
+        issue_chunk(std::integral_constant<int, 2>{});                 // (PERS: chunk 1 is in flight since the previous item's tail;
+                                                                       // slot 2 is free now: every wave is past that item's last chunk)
 #pragma unroll
         for (int ks = 0; ks < kNKS; ++ks) {
             const f32x4* g = reinterpret_cast<const f32x4*>(par + P_G1 + ks * 16 + h * 8);
@@ -634,7 +722,11 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
     }
     asm volatile("; TW_STREAM_END" ::: "memory");
     stamp();                                                           // [12] out mapping done
-    if (!live) return;                                                 // (no barrier below this line)
+    if constexpr (PERS) {
+        if (has_next && !(TW_PERS_EXP & 2)) touch_rows(ent_nxt, row0_nxt);                   // the next item's h0 rows on their way to L2 under the row stores below
+    }
+    if (!PERS && !live) return;                                        // (no barrier below this line)
+    if (live) {
 
     // ---- output: val[t][e] = y^T[feature 32 t + (e & 3) + 8 (e >> 2) + 4 h][row r] ----------------------------------
     // (the K / V region is free: the dense / out-mapping chunks put barriers between the last head and here; each wave stages
@@ -702,6 +794,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         if (p.items != nullptr && tile == ntiles - 1)                  // with an item table: zero rows behind the sequence
             for (int i = 32 * ntiles * 96 + lane; i < p.seq_rows * 96; i += 64) *reinterpret_cast<f32x4*>(o + (size_t)i * 4) = z4;
     }
+    }   // if (live)
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp();                                                       // [13] rows stored
@@ -710,6 +803,13 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
             for (int i = 0; i < 8; ++i) p.stamps[(size_t)blockIdx.x * 24 + 16 + i] = i < n_tp ? tp[i] : 0ull;
         }
     }
+    if (!has_next) break;
+    item += stride;
+    ent_cur = ent_nxt;
+    row0_cur = row0_nxt;
+    ent_nxt = ent_nn;
+    }   // for (;;): the items of a persistent workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (PERS: the look-ahead LDS-DMAs must not outlive the workgroup)
 }
 
 // ---- weight / parameter packing -----------------------------------------------------------------------------------
@@ -851,7 +951,19 @@ static int tower_seq_launch(const void* const* h0, int h16, const void* const* b
     }
     p.row0 = row0; p.lens = lens; p.items = items; p.n_items = n_items; p.n_seq = n_seq; p.n_branches = n_branches;
     p.seq_rows = seq_rows; p.v0 = v0; p.Lp = Lp; p.lens_out = lens_out;
-    const dim3 grid(n_branches == 2 ? 8u * (unsigned)((n_items + 3) / 4) : (unsigned)n_items);
+    dim3 grid(n_branches == 2 ? 8u * (unsigned)((n_items + 3) / 4) : (unsigned)n_items);
+    if (h16 && !(TW_PERS_EXP & 4)) {
+        // persistent workgroups, one per CU (a multiple of 8 so that a workgroup's branch = its XCD half stays put): workgroup w walks
+        // items w', w' + grid / 2, ... of its branch
+        if (!items || !row0) { set_error("tower_seq_h16: needs the slot table and row0"); return DLDKD_EINVAL; }
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256;
+            n_cu = v & ~7;
+        }
+        if (grid.x > (unsigned)n_cu) grid.x = (unsigned)n_cu;
+    }
     static const bool lds_ok = [] {           // once per process: the attribute call is a driver round trip
         return hipFuncSetAttribute((const void*)tw::tower_seq_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) == hipSuccess &&
                hipFuncSetAttribute((const void*)tw::tower_seq_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, tw::kLdsTotal) == hipSuccess &&
@@ -875,19 +987,22 @@ static int tower_seq_launch(const void* const* h0, int h16, const void* const* b
  * [11] LayerNorm, [12] out mapping, [13] rows stored. */
 int dldkd_debug_tower_seq_timeline(const float* const* h0, const void* const* blob, const int32_t* lens,
                                    const int32_t* items, int n_items, int n_seq, int seq_rows, void* const* gallery, int Lp,
-                                   unsigned long long* stamps, void* stream) {
+                                   unsigned long long* stamps, int h16, void* stream) {
     if (!h0 || !blob || !lens || !gallery || !stamps || n_items < 1 || seq_rows < 1 || Lp < 32 || (Lp & 31)) {
         set_error("tower_seq_timeline: bad arguments");
         return DLDKD_EINVAL;
     }
     tw::TowerArgs p{};
-    for (int b = 0; b < 2; ++b) { p.h0[b] = h0[b]; p.blob[b] = (const char*)blob[b]; p.gal[b] = (char*)gallery[b]; }
+    for (int b = 0; b < 2; ++b) { p.h0[b] = h0[b]; p.h0b[b] = (const unsigned short*)h0[b]; p.blob[b] = (const char*)blob[b]; p.gal[b] = (char*)gallery[b]; }
     p.lens = lens; p.items = items; p.n_items = n_items; p.n_seq = n_seq; p.n_branches = 2;
     p.seq_rows = seq_rows; p.v0 = 0; p.Lp = Lp; p.stamps = stamps;
     static const bool ok = hipFuncSetAttribute((const void*)tw::tower_seq_kernel<true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               tw::kLdsTotal) == hipSuccess &&
+                           hipFuncSetAttribute((const void*)tw::tower_seq_kernel<true, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                tw::kLdsTotal) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); set_error("tower_seq_timeline: cannot reserve LDS"); return DLDKD_ELAUNCH; }
-    DLDKD_LAUNCH((tw::tower_seq_kernel<true, 1, true>), dim3(8u * (unsigned)((n_items + 3) / 4)), dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
+    if (h16) DLDKD_LAUNCH((tw::tower_seq_kernel<true, 1, true, true>), dim3(8u * (unsigned)((n_items + 3) / 4)), dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
+    else DLDKD_LAUNCH((tw::tower_seq_kernel<true, 1, true>), dim3(8u * (unsigned)((n_items + 3) / 4)), dim3(256), tw::kLdsTotal, (hipStream_t)stream, p);
     return check_launch("tower_seq_timeline");
 }
 

@@ -196,7 +196,7 @@ SIGNATURES = {
     "dldkd_tower_seq_bf16_h16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                           _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_debug_tower_seq_timeline": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
-                                                _c_void_p, _c_int, _c_void_p, _c_void_p]),
+                                                _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p]),
     "dldkd_gemm_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                          _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
 }

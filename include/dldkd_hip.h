@@ -723,11 +723,12 @@ int dldkd_tower_seq_bf16_h16(const void* const* h0_bf16, const void* const* blob
                              void* const* gallery, int v0, int Lp, int32_t* lens_out, void* stream);
 
 /* Diagnostics: the out_mode 1 kernel (two branches) with clock stamps at its phase boundaries; stamps = 24 x uint64 per workgroup
+ * (h16: h0 holds bf16 rows, the dldkd_tower_seq_bf16_h16 kernel)
  * (8 * ceil(n_items / 4) workgroups): [0] start, [1] prologue, [2 + 2 h] head h projected, [3 + 2 h] head h attended, [10] dense,
  * [11] LayerNorm, [12] out mapping, [13] rows stored, [16..21] inside the prologue (tools/tower_timeline.py). */
 int dldkd_debug_tower_seq_timeline(const float* const* h0, const void* const* blob, const int32_t* lens,
                                    const int32_t* items, int n_items, int n_seq, int seq_rows, void* const* gallery, int Lp,
-                                   unsigned long long* stamps, void* stream);
+                                   unsigned long long* stamps, int h16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Feature ingest: temporal down-sampling + L2 normalisation + padding of raw frame features on the GPU.

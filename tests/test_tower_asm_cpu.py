@@ -33,8 +33,9 @@ def _run(path):
 def test_tower_rings_are_disciplined(tower_asm, capsys):
     assert _run(tower_asm) == 0
     out = capsys.readouterr().out
-    assert out.count("0 violations") == 5                    # gallery (fp32 / bf16 h0), rows, query and the stamped diagnostic build
-    assert out.count("1440 ring reads") == 4 and out.count("1152 ring reads") == 1   # every weight fragment goes through the ring once
+    assert out.count("0 violations") == 6           # gallery (fp32 h0; bf16 h0 = persistent), rows, query, two stamped diagnostic builds
+    assert out.count("1440 ring reads") == 5 and out.count("1152 ring reads") == 1
+    assert out.count("352 LDS-DMAs in the stream") == 1      # the persistent kernel: 42 chunks + the next item's chunks 0 and 1   # every weight fragment goes through the ring once
 
 
 def test_checker_catches_a_register_touched_before_its_wait(tower_asm, tmp_path):

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 
-def main(n=1024, dev="cuda:0", ragged=True):
+def main(n=1024, dev="cuda:0", ragged=True, h16=False):
     from dldkd_amd.model import DLDKD
     from dldkd_amd import native, ops, scoring
     cfg = types.SimpleNamespace(visual_input_size=3072, query_input_size=768, inheritance_hidden=384, exploration_hidden=384,
@@ -30,12 +30,12 @@ def main(n=1024, dev="cuda:0", ragged=True):
     n_wg = 8 * ((items.shape[0] + 3) // 4)
     stamps = torch.zeros(n_wg, 24, dtype=torch.int64, device=dev)
     L = native.lib()
-    hs = [x.view(-1, 384) for x in h0]
+    hs = [(x.bfloat16() if h16 else x).view(-1, 384) for x in h0]
     for _ in range(3):
         native.check(L.dldkd_debug_tower_seq_timeline(native.ptr_array(hs),
                                                       native.ptr_array([p.blob for p in packs]), native.ptr(lens), native.ptr(items),
                                                       items.shape[0], n, 128, native.ptr_array(pk.blobs), pk.Lp, native.ptr(stamps),
-                                                      native.stream()), "timeline")
+                                                      int(h16), native.stream()), "timeline")
     torch.cuda.synchronize()
     t = stamps.cpu().numpy().astype(np.float64)
     t = t[t[:, 13] > 0]
@@ -56,4 +56,4 @@ def main(n=1024, dev="cuda:0", ragged=True):
 
 
 if __name__ == "__main__":
-    main(ragged=(len(sys.argv) < 2 or sys.argv[1] != "full"))
+    main(ragged="full" not in sys.argv[1:], h16="h16" in sys.argv[1:])
