@@ -411,27 +411,31 @@ struct InprojFinishArgs {
     float* db;                   // [K]                                      sum_n W H  (unscaled)
     int split, N, K;
 };
-// grid (K / 256, N / 8): thread = one column k, 8 rows n: reduces the split planes, writes dW, accumulates the two dot products
+// grid (K / 1024, N / 4): thread = FOUR consecutive columns (16-byte accesses: the first version read 4 bytes per load and ran at
+// 1.6 TB/s), 4 rows n: reduces the split planes, writes dW, accumulates the two dot products
 __global__ __launch_bounds__(256) void inproj_bwd_reduce_kernel(const InprojFinishArgs a) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (k >= a.K) return;
     const size_t plane = (size_t)a.N * a.K;
-    float sg = 0.f, sb = 0.f;
-    const int n_hi = min(a.N, (int)(blockIdx.y + 1) * 8);
-    for (int n = blockIdx.y * 8; n < n_hi; ++n) {
+    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+    const int n_hi = min(a.N, (int)(blockIdx.y + 1) * 4);
+    for (int n = blockIdx.y * 4; n < n_hi; ++n) {
         const size_t at = (size_t)n * a.K + k;
-        float dw = 0.f, h = 0.f;
+        f32x4 dw = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < a.split; ++s) {
-            dw += a.part[(size_t)s * 2 * plane + at];
-            h += a.part[(size_t)s * 2 * plane + plane + at];
+            dw += *reinterpret_cast<const f32x4*>(a.part + (size_t)s * 2 * plane + at);
+            h += *reinterpret_cast<const f32x4*>(a.part + (size_t)s * 2 * plane + plane + at);
         }
-        a.dW[at] = dw;
-        const float w = a.W[at];
+        *reinterpret_cast<f32x4*>(a.dW + at) = dw;
+        const f32x4 w = *reinterpret_cast<const f32x4*>(a.W + at);
         sg += w * dw;
         sb += w * h;
     }
-    atomicAdd(a.dg + k, sg);
-    atomicAdd(a.db + k, sb);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        atomicAdd(a.dg + k + e, sg[e]);
+        atomicAdd(a.db + k + e, sb[e]);
+    }
 }
 struct InprojFinalArgs {
     float* dg;                   // in: sum_n W dW, out: dgamma
@@ -712,7 +716,7 @@ extern "C" int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const 
         set_error("inproj_bwd: null pointer");
         return DLDKD_EINVAL;
     }
-    if (((uintptr_t)z_bf16 & 3) || ((uintptr_t)workspace & 15) || ((uintptr_t)dW & 15) || workspace_bytes < dldkd_inproj_bwd_workspace_bytes(N, K, M)) {
+    if (((uintptr_t)z_bf16 & 3) || ((uintptr_t)workspace & 15) || ((uintptr_t)dW & 15) || ((uintptr_t)W & 15) || workspace_bytes < dldkd_inproj_bwd_workspace_bytes(N, K, M)) {
         set_error("inproj_bwd: unaligned buffer or workspace too small");
         return DLDKD_EINVAL;
     }
@@ -731,7 +735,7 @@ extern "C" int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const 
     int rc = check_launch("inproj_bwd (dual dW)");
     if (rc != DLDKD_OK) return rc;
     const InprojFinishArgs f{(const float*)workspace, W, dW, dgamma, dbeta, split, N, K};
-    DLDKD_LAUNCH(inproj_bwd_reduce_kernel, dim3((K + 255) / 256, (N + 7) / 8), dim3(256), 0, s, f);
+    DLDKD_LAUNCH(inproj_bwd_reduce_kernel, dim3((K + 1023) / 1024, (N + 3) / 4), dim3(256), 0, s, f);
     rc = check_launch("inproj_bwd (reduce)");
     if (rc != DLDKD_OK) return rc;
     const InprojFinalArgs g{dgamma, dbeta, gamma, beta, keep_scale, K, dy, W, x, keep, mean, rstd, M, N};

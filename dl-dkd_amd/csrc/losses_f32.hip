@@ -514,6 +514,17 @@ __global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, l
 
 }  // namespace dldkd
 
+namespace dldkd {
+struct ScalarPtrs { const float* p[8]; };
+__global__ void sum_scalars_kernel(const ScalarPtrs a, int n, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        float s = a.p[0][0];
+        for (int i = 1; i < n; ++i) s += a.p[i][0];
+        out[0] = s;
+    }
+}
+}  // namespace dldkd
+
 using namespace dldkd;
 
 extern "C" {
@@ -593,6 +604,19 @@ int dldkd_branch_losses_scale_f32(float* dC, float* dS, long n, float* dclip, lo
     DLDKD_LAUNCH(branch_scale_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dC, dS, n, dclip, n_clip,
                  g_trip, g_nce, g_kl);
     return check_launch("branch_losses_scale");
+}
+
+/* out[0] = ((((x0 + x1) + x2) + x3) + ...) of n <= 8 device scalars, left to right in fp32 - the order in which the reference adds
+ * its loss terms (loss = inher_trip + inher_nce + kl + explore_trip + explore_nce, model.py:157-160); one launch instead of n - 1. */
+int dldkd_sum_scalars_f32(const float* const* host_ptrs, int n, float* out, void* stream) {
+    if (!host_ptrs || !out || n < 1 || n > 8) { set_error("sum_scalars: 1..8 scalars"); return DLDKD_EINVAL; }
+    ScalarPtrs a{};
+    for (int i = 0; i < n; ++i) {
+        if (!host_ptrs[i]) { set_error("sum_scalars: null scalar"); return DLDKD_EINVAL; }
+        a.p[i] = host_ptrs[i];
+    }
+    DLDKD_LAUNCH(sum_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, n, out);
+    return check_launch("sum_scalars");
 }
 
 int dldkd_sum_f32(const float* x, long n, float* out, void* stream) {

@@ -796,6 +796,34 @@ def _gscalar(g):
     return g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
 
 
+class _SumScalars(Function):
+    """loss = t0 + t1 + ... of scalar terms, left to right (the reference's order, model.py:157-160), as ONE launch; every term's
+    gradient is the upstream gradient itself."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        import ctypes
+        ctx.n = len(ts)
+        out = torch.empty((), dtype=torch.float32, device=ts[0].device)
+        ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        native.check(_L().dldkd_sum_scalars_f32(ptrs, len(ts), _p(out), _s()), "sum_scalars")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) * ctx.n
+
+
+def sum_scalars(*ts):
+    """Sum of 0-dim fp32 GPU tensors in the given order; falls back to torch adds for anything else."""
+    if 1 < len(ts) <= 8 and all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 for t in ts):
+        return _SumScalars.apply(*[t.reshape(()) if t.dim() else t for t in ts])
+    out = ts[0]
+    for t in ts[1:]:
+        out = out + t
+    return out
+
+
 def _sum(x):
     out = torch.empty(1, dtype=torch.float32, device=x.device)
     native.check(_L().dldkd_sum_f32(_p(x), x.numel(), _p(out), _s()), "sum")

@@ -633,12 +633,13 @@ class DLDKD(nn.Module):
             (inher_trip, inher_nce, kl_intra), (explore_trip, explore_nce) = self._branch_runner(
                 [(inh_part, (q_inh, g_inh)), (exp_part, (q_exp, g_exp))])
             kl = kl_intra
-            loss = (inher_trip + inher_nce + kl) + (explore_trip + explore_nce)
+            loss = F_.sum_scalars(inher_trip, inher_nce, kl, explore_trip, explore_nce)     # one launch, the reference's order
         else:
             inher_trip, inher_nce, kl_intra = inh_part(q_inh, g_inh)
             if self.double_branch:
                 explore_trip, explore_nce = exp_part(q_exp, g_exp)
             kl = kl_intra
-            loss = inher_trip + inher_nce + kl + explore_trip + explore_nce
+            loss = (F_.sum_scalars(inher_trip, inher_nce, kl, explore_trip, explore_nce) if self.double_branch and inher_trip.is_cuda
+                    else inher_trip + inher_nce + kl + explore_trip + explore_nce)
         return loss, {"inher_trip": inher_trip, "inher_nce": inher_nce, "explore_trip": explore_trip,
                       "explore_nce": explore_nce, "kl": kl, "kl_intra": kl_intra}

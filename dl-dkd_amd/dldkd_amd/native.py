@@ -85,6 +85,7 @@ SIGNATURES = {
     "dldkd_colsum_bf16": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_branch_losses_f32": (_c_int, [_c_void_p] * 11 + [_c_int] * 7 + [_c_float] * 6 + [_c_void_p] * 6),
     "dldkd_branch_losses_scale_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_sum_scalars_f32": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
     "dldkd_zero_scratch_f32": (_c_int, [_c_void_p, _c_int, _c_void_p]),
     "dldkd_set_zero_by_memset": (_c_int, [_c_int]),
     "dldkd_inproj_bwd_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_long]),

@@ -368,7 +368,9 @@ int dldkd_gemm_bf16_dw_bias(int dw, const void* A, const void* B, float* C, int 
  * - the (M, K) product dy W of dldkd_linear_lngrad reassociated into the M-long contraction of the weight gradient.  Columns with
  * |gamma[k]| < 0.05 (z holds no trace of xhat there) are recomputed exactly from x / keep / mean / rstd (rstd = 0 marks padding rows).
  * dy (M, N) fp32, N <= 384; z (M, K) bf16; W (N, K); dW (N, K); dbias (N) zeroed by the caller or NULL; dgamma, dbeta (K) ZEROED by
- * the caller (used as accumulators); k_flags as in dldkd_gemm_bf16_mixed; workspace: dldkd_inproj_bwd_workspace_bytes. */
+ * the caller (used as accumulators); k_flags as in dldkd_gemm_bf16_mixed; workspace: dldkd_inproj_bwd_workspace_bytes.
+ * (Three launches: the GEMM, the plane reduce + dot products, the finalisation.  Merging the last two behind an arrival ticket was
+ * measured: the __threadfence of every workgroup made the finish 2-4 x slower than the two kernels.) */
 size_t dldkd_inproj_bwd_workspace_bytes(int N, int K, long M);
 int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const float* W, const float* gamma, const float* beta,
                           float keep_scale, const float* x, const unsigned char* keep, const float* mean, const float* rstd,
@@ -610,6 +612,9 @@ int dldkd_branch_losses_scale_f32(float* dC, float* dS, long n, float* dclip, lo
                                   const float* g_kl, void* stream);
 /* out[0] = sum of x[0..n) in a fixed order (single workgroup). */
 int dldkd_sum_f32(const float* x, long n, float* out, void* stream);
+/* out[0] = (((x0 + x1) + x2) + ...) of n <= 8 device scalars, left to right in fp32: the reference's sum of its loss terms
+ * (model.py:157-160) as one launch.  host_ptrs: HOST array of n device pointers. */
+int dldkd_sum_scalars_f32(const float* const* host_ptrs, int n, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Ranking (the step after scoring).  Replaces the np.argsort loop of eval_q2m (method/eval.py:69-83) and

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /root/repo
-python -m pytest tests/test_tower_train_gpu.py tests/test_train_mode_gpu.py tests/test_train_loop_gpu.py tests/test_train_gpu.py -q -m gpu -x > gpurun_out/r04_count_tests.log 2>&1; grep "passed\|failed" gpurun_out/r04_count_tests.log | tail -2
+timeout 900 python -m pytest tests/test_tower_train_gpu.py tests/test_train_mode_gpu.py tests/test_train_loop_gpu.py tests/test_train_gpu.py tests/test_bf16_mode_gpu.py -q -m gpu -x > gpurun_out/r04_count_tests.log 2>&1; grep "passed\|failed" gpurun_out/r04_count_tests.log | tail -2
 R=$PWD; O=$R/gpurun_out/r04c; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for cfg in c3 c5; do
