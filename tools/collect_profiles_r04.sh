@@ -7,7 +7,7 @@ O=$R/gpurun_out/r04p
 mkdir -p $O
 WHAT="${*:-bench train enc pmc}"
 cd /tmp && export TMPDIR=/tmp
-copy_stats() { f=$(grep -l "dldkd::" $(find $O/$1 -name "*kernel_stats.csv") | head -1); [ -n "$f" ] && cp $f $O/$1_kernel_stats.csv; }
+copy_stats() { f=$(ls -t $(grep -l "dldkd::" $(find $O/$1 -name "*kernel_stats.csv")) | head -1); [ -n "$f" ] && cp $f $O/$1_kernel_stats.csv; }
 for w in $WHAT; do case $w in
 bench)   # headline bench: kernel trace + stats of the contract command (extras and CPU baseline off: the timed region only)
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python3 $R/bench.py --no-extras --no-cpu-baseline --steps 12 > $O/bench.log 2>&1
