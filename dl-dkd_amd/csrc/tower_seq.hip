@@ -124,7 +124,7 @@ struct TowerArgs {
 // (method/model.py:245-258) on top: softmax_l(mask_logits(w . h2_l)) -> sum_l a_l h2_l, one 384-vector per sequence.
 template <bool OUTMAP, int OUTMODE, bool STAMP = false, bool H16 = false>
 __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
-    unsigned long long ts[16], tp[8];
+    unsigned long long ts[16], tp[8], t_dma = 0, t_bar = 0;
     int n_tp = 0;
     int n_ts = 0;
     auto stamp = [&]() {      // phase boundaries only: no hand-counted read is in flight there (cdna_hip_programming.md section 7)
@@ -312,9 +312,18 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
             constexpr int c = (n + kDepth) / kChunk;           // chunk c is about to be read
             // (PERS: the stream runs on into the next item's chunks 0 and 1 - issued below whether or not there is a next item: a
             // wasted 64 KiB of L2 traffic at the end of a workgroup's life buys one form of the counted wait)
+            unsigned long long tb0 = 0, tb1 = 0;               // (stamped build: cycles parked at this chunk's wait + barrier)
+            if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0) :: "memory");
             if constexpr (c + 1 < NCH || (PERS && !(TW_PERS_EXP & 1))) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but chunk c + 1's pieces
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1) :: "memory");
             asm volatile("s_barrier" ::: "memory");            // every wave's pieces of chunk c landed; chunk c - 1 is consumed
+            if constexpr (STAMP) {
+                unsigned long long tb2;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb2) :: "memory");
+                t_dma += tb1 - tb0;
+                t_bar += tb2 - tb1;
+            }
             if constexpr (c + 2 < NCH) issue_chunk(std::integral_constant<int, c + 2>{});
             else if constexpr (PERS && !(TW_PERS_EXP & 1)) issue_chunk(std::integral_constant<int, c + 2 - NCH>{});
         }
@@ -800,6 +809,8 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         stamp();                                                       // [13] rows stored
         if (tid == 0 && p.stamps != nullptr) {
             for (int i = 0; i < 16; ++i) p.stamps[(size_t)blockIdx.x * 24 + i] = i < n_ts ? ts[i] : 0ull;
+            p.stamps[(size_t)blockIdx.x * 24 + 14] = t_dma;           // wave 0: cycles in the 44 chunk waits (its own LDS-DMA pieces) ...
+            p.stamps[(size_t)blockIdx.x * 24 + 15] = t_bar;           // ... and in the barriers behind them (the other waves' pieces)
             for (int i = 0; i < 8; ++i) p.stamps[(size_t)blockIdx.x * 24 + 16 + i] = i < n_tp ? tp[i] : 0ull;
         }
     }

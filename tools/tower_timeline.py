@@ -52,6 +52,9 @@ def main(n=1024, dev="cuda:0", ragged=True, h16=False):
                                                      "-> half 1 read", "-> workgroup barrier", "-> LN1 applied, chunks 1-2 issued"],
                                                     [float(np.median(pd[:, i])) for i in range(7)]))
     out["share_of_workgroup_time"] = {k: float(np.median(v / tot)) for k, v in grouped.items()}
+    # wave 0's cycles parked at the 44 chunk hand-overs of the weight stream: waiting for its own LDS-DMA pieces, then at the barrier
+    out["chunk_wait_median_cycles"] = {"own_dma_pieces": float(np.median(t[:, 14])), "barrier": float(np.median(t[:, 15])),
+                                       "share_of_workgroup_time": float(np.median((t[:, 14] + t[:, 15]) / tot))}
     print(json.dumps(out, indent=1))
 
 
