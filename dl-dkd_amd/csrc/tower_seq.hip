@@ -44,6 +44,9 @@ constexpr int kChunk = 32;                     // ring: fragments per chunk
 #ifndef TW_PERS_EXP
 #define TW_PERS_EXP 0
 #endif
+#ifndef TW_SPREAD
+#define TW_SPREAD 1
+#endif
 #ifndef TW_DEPTH
 #define TW_DEPTH 3
 #endif
@@ -180,6 +183,12 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         const uint32_t dst = smem_lds + ((c % 3) * kChunk + wave * 8) * 1024;
 #pragma unroll
         for (int i = 0; i < 8; ++i) glds_piece(lane16, src + i * 1024, dst + i * 1024);
+    };
+    auto issue_piece = [&](auto cc, auto ic) {
+        constexpr int c = decltype(cc)::value, i = decltype(ic)::value;
+        const char* src = wsrc + (size_t)(c * kChunk + wave * 8 + i) * 1024;
+        const uint32_t dst = smem_lds + ((c % 3) * kChunk + wave * 8 + i) * 1024;
+        glds_piece(lane16, src, dst);
     };
     // the first weight chunk depends on the branch only: in flight before the (dependent, scalar) loads that say which sequence
     // this wave works on
@@ -324,8 +333,18 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
                 t_dma += tb1 - tb0;
                 t_bar += tb2 - tb1;
             }
-            if constexpr (c + 2 < NCH) issue_chunk(std::integral_constant<int, c + 2>{});
-            else if constexpr (PERS && !(TW_PERS_EXP & 1)) issue_chunk(std::integral_constant<int, c + 2 - NCH>{});
+            if constexpr (!TW_SPREAD) {
+                if constexpr (c + 2 < NCH) issue_chunk(std::integral_constant<int, c + 2>{});
+                else if constexpr (PERS && !(TW_PERS_EXP & 1)) issue_chunk(std::integral_constant<int, c + 2 - NCH>{});
+            }
+        }
+        if constexpr (TW_SPREAD && n + kDepth >= kChunk && n + kDepth < NFRAG && (n + kDepth) % 4 == 0) {
+            // TW_SPREAD: the 8 pieces of chunk c + 2 one by one, every fourth product of chunk c's period (all eight are out before
+            // the next chunk wait, so the counted waits keep their meaning) instead of back to back behind the barrier: an LDS-DMA
+            // issued among MFMAs costs the wave 100-185 cycles where eight of them queue up (MI355X_MICROARCH.md, kernel-cost table)
+            constexpr int c = (n + kDepth) / kChunk, i = ((n + kDepth) % kChunk) / 4;
+            if constexpr (c + 2 < NCH) issue_piece(std::integral_constant<int, c + 2>{}, std::integral_constant<int, i>{});
+            else if constexpr (PERS && !(TW_PERS_EXP & 1)) issue_piece(std::integral_constant<int, c + 2 - NCH>{}, std::integral_constant<int, i>{});
         }
         if constexpr (n == pbeg) static_for<0, kDepth>([&](auto dc) { ring_read(std::integral_constant<int, pbeg + decltype(dc)::value>{}); });
         if constexpr (n + kDepth < pend) ring_read(std::integral_constant<int, n + kDepth>{});
