@@ -520,15 +520,27 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         });
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // accumulator tile (features 32 t ..) + per-feature vector in fragment order -> the two operand fragments of k-steps 2t, 2t+1
-    auto tile_bias_pack = [&](const f32x16& acc, int tab, int t, bf16x8& f0, bf16x8& f1) {
+    // The per-feature vector of a T-product (bias) goes in as the INITIAL accumulator - four 16-byte LDS reads straight into the
+    // tile's registers (fragment order: register 8 s + j of lane half h is feature 32 t + 16 s + 8 h' ...) - instead of 16 adds behind
+    // the chain: the kernel is issue-bound, every VALU instruction between two MFMA chains shows.
+    auto bias_tile = [&](int tab, int t) {
+        f32x16 a;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const f32x4* b = reinterpret_cast<const f32x4*>(par + tab + (2 * t + s) * 16 + h * 8);
             const f32x4 b0 = b[0], b1 = b[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[8 * s + e] = b0[e]; a[8 * s + 4 + e] = b1[e]; }
+        }
+        return a;
+    };
+    // accumulator tile (features 32 t .., bias already in) -> the two operand fragments of k-steps 2t, 2t+1
+    auto tile_pack = [&](const f32x16& acc, bf16x8& f0, bf16x8& f1) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = acc[8 * s + e] + b0[e]; v[4 + e] = acc[8 * s + 4 + e] + b1[e]; }
+            for (int e = 0; e < 8; ++e) v[e] = acc[8 * s + e];
             (s == 0 ? f0 : f1) = pack8(v);
         }
     };
@@ -543,26 +555,27 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         bf16x8 Qf[6], Kf[6], Vf[6];
         static_for<0, 3>([&](auto dtc) {                               // Q^T (pre-scaled by log2(e) / sqrt(96) in the blob)
             constexpr int dt = decltype(dtc)::value;
-            f32x16 a = zero16;
+            f32x16 a = bias_tile(P_BQ, 3 * hd + dt);
             tprod(std::integral_constant<int, n0 + dt * kNKS>{}, a, X1);
-            tile_bias_pack(a, P_BQ, 3 * hd + dt, Qf[2 * dt], Qf[2 * dt + 1]);
+            tile_pack(a, Qf[2 * dt], Qf[2 * dt + 1]);
         });
         static_for<0, 3>([&](auto dtc) {                               // K^T
             constexpr int dt = decltype(dtc)::value;
-            f32x16 a = zero16;
+            f32x16 a = bias_tile(P_BK, 3 * hd + dt);
             tprod(std::integral_constant<int, n0 + 72 + dt * kNKS>{}, a, X1);
-            tile_bias_pack(a, P_BK, 3 * hd + dt, Kf[2 * dt], Kf[2 * dt + 1]);
+            tile_pack(a, Kf[2 * dt], Kf[2 * dt + 1]);
         });
         static_for<0, 3>([&](auto dtc) {                               // V (rows on registers, d on lanes)
             constexpr int dt = decltype(dtc)::value;
             f32x16 a = zero16;
             nprod(std::integral_constant<int, n0 + 144 + dt * kNKS>{}, a, X1);
-            const float bv = par[P_BV + 96 * hd + 32 * dt + r];
+            // (the value bias is not added here: softmax rows sum to 1, so P (V + 1 bv^T) = P V + bv^T - it enters the context as the
+            // addend of the normalising multiply below, which becomes an FMA: 16 VALU per tile less)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = a[8 * s + j] + bv;
+                for (int j = 0; j < 8; ++j) v[j] = a[8 * s + j];
                 Vf[2 * dt + s] = pack8(v);
             }
         });
@@ -625,9 +638,12 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
+                // context feature of register 8 s + j, lane half h: 96 hd + 32 dt + 16 s + 8 (j >> 2) + 4 h + (j & 3) (accumulator rows)
+                const float* bvp = par + P_BV + 96 * hd + 32 * dt + 16 * s + 4 * h;
+                const f32x4 bv0 = *reinterpret_cast<const f32x4*>(bvp), bv1 = *reinterpret_cast<const f32x4*>(bvp + 8);
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = oa[dt][8 * s + j] * inv;
+                for (int j = 0; j < 8; ++j) v[j] = oa[dt][8 * s + j] * inv + (j < 4 ? bv0[j & 3] : bv1[j & 3]);
                 Cf[6 * hd + 2 * dt + s] = pack8(v);
                 asm volatile("" : "+a"(Cf[6 * hd + 2 * dt + s]));
             }
@@ -639,15 +655,13 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     static_for<0, 12>([&](auto otc) {
         constexpr int ot = decltype(otc)::value;
-        f32x16 a = zero16;
+        f32x16 a = bias_tile(P_BD, ot);
         tprod(std::integral_constant<int, kQKVFrags + ot * kNKS>{}, a, Cf);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const f32x4* b = reinterpret_cast<const f32x4*>(par + P_BD + (2 * ot + s) * 16 + h * 8);
-            const f32x4 b0 = b[0], b1 = b[1];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float v = a[8 * s + j] + (j < 4 ? b0[j & 3] : b1[j & 3]) + bf16_bits_to_f32((unsigned short)X1[2 * ot + s][j]);
+                const float v = a[8 * s + j] + bf16_bits_to_f32((unsigned short)X1[2 * ot + s][j]);
                 s1 += v;
                 s2 += v * v;
                 val[ot][8 * s + j] = v;
@@ -737,15 +751,10 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
     if constexpr (OUTMAP) {
         static_for<0, 12>([&](auto otc) {
             constexpr int ot = decltype(otc)::value;
-            f32x16 a = zero16;
+            f32x16 a = bias_tile(P_BO, ot);
             tprod(std::integral_constant<int, kQKVFrags + kSqFrags + ot * kNKS>{}, a, X1);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const f32x4* b = reinterpret_cast<const f32x4*>(par + P_BO + (2 * ot + s) * 16 + h * 8);
-                const f32x4 b0 = b[0], b1 = b[1];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) val[ot][8 * s + j] = a[8 * s + j] + (j < 4 ? b0[j & 3] : b1[j & 3]);
-            }
+            for (int e = 0; e < 16; ++e) val[ot][e] = a[e];
         });
     }
     asm volatile("; TW_STREAM_END" ::: "memory");

@@ -62,13 +62,16 @@ def _reference(t, h0, lens, rounded):
     else:
         q = (h1 @ P["enc.self.query.weight"].t() + P["enc.self.query.bias"]) * c
     k = rd(h1 @ rd(P["enc.self.key.weight"]).t() + P["enc.self.key.bias"])
-    v = rd(h1 @ rd(P["enc.self.value.weight"]).t() + P["enc.self.value.bias"])
+    # (the kernel adds the value bias AFTER the attention product - softmax rows sum to 1 - in fp32)
+    v = rd(h1 @ rd(P["enc.self.value.weight"]).t()) if rounded else h1 @ P["enc.self.value.weight"].t() + P["enc.self.value.bias"]
     q, k, v = [z.view(n, L, 4, 96).transpose(1, 2) for z in (q, k, v)]
     s = q @ k.transpose(-1, -2)                                         # log2 domain
     kmask = torch.arange(L)[None, :] >= lens[:, None]
     s = s.masked_fill(kmask[:, None, None, :], float("-inf"))
     p = torch.exp2(s - s.max(-1, keepdim=True).values)
     o = (rd(p) @ v) / p.sum(-1, keepdim=True)
+    if rounded:
+        o = o + P["enc.self.value.bias"].view(4, 1, 96)
     ctx = rd(o.transpose(1, 2).reshape(n, L, H))
     d = ctx @ rd(P["enc.output.dense.weight"]).t() + P["enc.output.dense.bias"] + h1
     h2 = _ln(d, P["enc.output.LayerNorm.weight"], P["enc.output.LayerNorm.bias"])
