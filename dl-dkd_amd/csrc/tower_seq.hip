@@ -44,6 +44,9 @@ constexpr int kChunk = 32;                     // ring: fragments per chunk
 #ifndef TW_PERS_EXP
 #define TW_PERS_EXP 0
 #endif
+#ifndef TW_FOLD_LN2
+#define TW_FOLD_LN2 1
+#endif
 #ifndef TW_SPREAD
 #define TW_SPREAD 1
 #endif
@@ -732,18 +735,27 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         for (int t = 0; t < 12; ++t)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const f32x4* g = reinterpret_cast<const f32x4*>(par + P_G2 + (2 * t + s) * 16 + h * 8);
-                const f32x4* b = reinterpret_cast<const f32x4*>(par + P_B2 + (2 * t + s) * 16 + h * 8);
-                const f32x4 g0 = g[0], g1 = g[1], b0 = b[0], b1 = b[1];
                 float v[8];
+                if constexpr (OUTMAP && TW_FOLD_LN2) {
+                    // gamma2 / beta2 live in the out mapping's weights and bias (folded at pack time: y = xhat2 (Wo diag(gamma2))^T +
+                    // (bo + Wo beta2)): the operand is the normalised row itself - one FMA per element, no vector reads
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    v[j] = (val[t][8 * s + j] * rstd + nmr) * (j < 4 ? g0[j & 3] : g1[j & 3]) + (j < 4 ? b0[j & 3] : b1[j & 3]);
-                    val[t][8 * s + j] = v[j];
-                }
-                if constexpr (OUTMAP) {
+                    for (int j = 0; j < 8; ++j) v[j] = val[t][8 * s + j] * rstd + nmr;
                     X1[2 * t + s] = pack8(v);
                     asm volatile("" : "+a"(X1[2 * t + s]));
+                } else {
+                    const f32x4* g = reinterpret_cast<const f32x4*>(par + P_G2 + (2 * t + s) * 16 + h * 8);
+                    const f32x4* b = reinterpret_cast<const f32x4*>(par + P_B2 + (2 * t + s) * 16 + h * 8);
+                    const f32x4 g0 = g[0], g1 = g[1], b0 = b[0], b1 = b[1];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[j] = (val[t][8 * s + j] * rstd + nmr) * (j < 4 ? g0[j & 3] : g1[j & 3]) + (j < 4 ? b0[j & 3] : b1[j & 3]);
+                        val[t][8 * s + j] = v[j];
+                    }
+                    if constexpr (OUTMAP) {
+                        X1[2 * t + s] = pack8(v);
+                        asm volatile("" : "+a"(X1[2 * t + s]));
+                    }
                 }
             }
     }
@@ -881,6 +893,7 @@ __global__ __launch_bounds__(256) void tower_pack_kernel(const PackArgs a) {
             ks = m % kNKS;
         }
         const int f = 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+        if (TW_FOLD_LN2 && n >= kQKVFrags + kSqFrags) sc = a.g2[f];             // out mapping: LayerNorm 2's gamma folded in (its beta: the bias below)
         a.frags[i] = f32_to_bf16_bits(W[(size_t)(rowbase + (lane & 31)) * kHidden + f] * sc);
     }
     if (i < P_TOTAL) {
@@ -897,7 +910,14 @@ __global__ __launch_bounds__(256) void tower_pack_kernel(const PackArgs a) {
             case 5: v = a.bd[f]; break;
             case 6: v = a.g2[f]; break;
             case 7: v = a.b2[f]; break;
-            default: v = a.bo ? a.bo[f] : a.mw ? a.mw[f] * a.g2[f] : 0.f; break;
+            default:
+                if (a.bo) {                                                    // bo + Wo beta2 (see the out mapping's fragments)
+                    v = a.bo[f];
+                    for (int c = 0; TW_FOLD_LN2 && c < kHidden; ++c) v += a.wo[(size_t)f * kHidden + c] * a.b2[c];
+                } else {
+                    v = a.mw ? a.mw[f] * a.g2[f] : 0.f;
+                }
+                break;
         }
         a.par[i] = v;
     }
