@@ -601,24 +601,27 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
                     sa[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kl[((first + kt) * 6 + i) * 64 + lane], Qf[i], sa[kt], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sa[kt][e] = -INFINITY;
             }
         });
+        // (key tiles past the sequence - 4 - ntiles of them, wave-uniform - take no part: no -inf fill, no max / exp / sum over them:
+        // on the ragged gallery a third of the softmax's VALU)
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
+            if (kt < ntiles) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sa[kt][e]);
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sa[kt][e]);
+            }
         mx = half_swap_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
+            if (kt < ntiles) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                sa[kt][e] = __builtin_amdgcn_exp2f(sa[kt][e] - mx);
-                sum += sa[kt][e];
+                for (int e = 0; e < 16; ++e) {
+                    sa[kt][e] = __builtin_amdgcn_exp2f(sa[kt][e] - mx);
+                    sum += sa[kt][e];
+                }
             }
         const float inv = 1.f / half_swap_sum(sum);
         f32x16 oa[3] = {zero16, zero16, zero16};
