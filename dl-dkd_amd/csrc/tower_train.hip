@@ -85,6 +85,18 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
     return b;
 }
 
+// acc[t][4 g + e] = vec[32 t + 8 g + 4 h + e]: a product's bias as its INITIAL accumulator (16-byte LDS reads straight into the
+// tiles) instead of 192 adds behind the chain - the row kernels issue from one wave per SIMD, every VALU instruction shows
+__device__ __forceinline__ void bias_acc(f32x16 (&acc)[kT], const float* lds_vec_plus_4h) {
+#pragma unroll
+    for (int t = 0; t < kT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lds_vec_plus_4h + 32 * t + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = b[e];
+        }
+}
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[kT]) {
 #pragma unroll
     for (int t = 0; t < kT; ++t)
@@ -328,18 +340,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) {
         f32x16 acc[kT];
-        zero_acc(acc);
+        bias_acc(acc, vs[2 + c] + 4 * h);
         gemm24(acc, p.wqkv + (size_t)c * kMatFrags * 64, xb, lane);
-        const float* bias = vs[2 + c] + 4 * h;
         u16* orow = p.qkv + w.row * (3 * kD) + c * kD + 4 * h;
 #pragma unroll
         for (int t = 0; t < kT; ++t) {
             Tile4 o;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b = vec4(bias, 32 * t + 8 * g);
-                o.v[g] = pack4(acc[t][4 * g] + b[0], acc[t][4 * g + 1] + b[1], acc[t][4 * g + 2] + b[2], acc[t][4 * g + 3] + b[3]);
-            }
+            for (int g = 0; g < 4; ++g) o.v[g] = pack4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
             store_tile16(orow, t, o, w.valid);
         }
     }
@@ -385,11 +393,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int ks = 0; ks < kKS; ++ks) xb[ks] = *reinterpret_cast<const bf16x8*>(cr + 16 * ks);
     }
     f32x16 acc[kT];
-    zero_acc(acc);
+    bias_acc(acc, vs[0] + 4 * h);                               // dense bias as the initial accumulator
     gemm24(acc, p.wd, xb, lane);
     const u16* hres = p.h1d + w.rowc * kD + 4 * h;
     float s = 0.f;
-    const float* bdp = vs[0] + 4 * h;
     const size_t didx = (size_t)w.row * kD + 4 * h;
     Tile4 nxt = load_tile16(hres, 0);
 #pragma unroll
@@ -400,13 +407,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int fo = 32 * t + 8 * g;
-            const f32x4 b = vec4(bdp, fo);
             const unsigned kb = keep4(p.drop, seed, off, didx + fo);
             float r4[4];
             unpack4(cur.v[g], r4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float v = acc[t][4 * g + e] + b[e];
+                const float v = acc[t][4 * g + e];
                 const float y = (((kb >> e) & 1u) ? v * p.drop.scale : 0.f) + r4[e];
                 acc[t][4 * g + e] = y;
                 s += y;
@@ -459,19 +465,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     if constexpr (!VIDEO) return;
-    zero_acc(acc);
+    bias_acc(acc, vs[3] + 4 * h);
     gemm24(acc, p.wo, xb, lane);
-    const float* bop = vs[3] + 4 * h;
     float* gr = p.g + w.row * kD + 4 * h;
 #pragma unroll
     for (int t = 0; t < kT; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int fo = 32 * t + 8 * g;
-            const f32x4 b = vec4(bop, fo);
             if (w.valid)
-                *reinterpret_cast<f32x4*>(gr + fo) =
-                    f32x4{acc[t][4 * g] + b[0], acc[t][4 * g + 1] + b[1], acc[t][4 * g + 2] + b[2], acc[t][4 * g + 3] + b[3]};
+                *reinterpret_cast<f32x4*>(gr + fo) = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
         }
 }
 
