@@ -63,6 +63,15 @@ __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_base_uni
         16, 0, 0);
 }
 
+// The same with an instruction offset: OFF moves the global AND the LDS address, so a run of pieces shares one address register pair
+// and one M0 value (no 64-bit add and no M0 arithmetic per piece)
+template <int OFF>
+__device__ __forceinline__ void glds16_off(const void* gsrc_lane, void* lds_base_uniform) {
+    __builtin_amdgcn_global_load_lds(
+        reinterpret_cast<global_cvoid*>(reinterpret_cast<uintptr_t>(gsrc_lane)),
+        reinterpret_cast<lds_void*>(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_base_uniform))),
+        16, OFF, 0);
+}
 
 // XCD-aware order of a 3-D tile grid (cdna_hip_programming.md section 5 "XCD swizzle must be bijective", T1): the workgroups with
 // equal launch id % 8 share an XCD (round-robin placement: a speed assumption only) and are handed a contiguous run of tile ids,

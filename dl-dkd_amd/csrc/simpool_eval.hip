@@ -209,6 +209,9 @@ struct SimpoolEvalArgs {
 // ----------------------------------------------------------------------------------------------
 constexpr int kKSteps16 = kHidden / 32;   // 12
 constexpr int kRing = 3;
+#ifndef K1_GLDS_OFF
+#define K1_GLDS_OFF 1
+#endif
 
 __device__ __forceinline__ float xor16_max(float m) {
     const unsigned u = __builtin_bit_cast(unsigned, m);
@@ -342,7 +345,11 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
                 // of the tile, where the MFMA pipe waited for their issue (same-box A/B: 20.27-20.42 -> 20.03-20.06 ms).
                 // They stay older than the tile's two result stores, so the vmcnt(2) before the next barrier still means
                 // "this DMA has landed".
-                if constexpr (S == 0 && ks < 6 && !(ABL & 2)) glds16(st_src + ks * 1024, st_dst + ks * 1024);
+                if constexpr (S == 0 && ks < 6 && !(ABL & 2)) {
+                    // (one base and one M0 per four pieces - the immediate reaches 4095: the scorer is issue-bound)
+                    if constexpr (K1_GLDS_OFF) glds16_off<(ks & 3) * 1024>(st_src + (ks >> 2) * 4096, st_dst + (ks >> 2) * 4096);
+                    else glds16(st_src + ks * 1024, st_dst + ks * 1024);
+                }
                 // Place this k-step's pool slice (VALU) in the shadow of its MFMAs: groups of {2 MFMA, 2 VALU}.  With a hard
                 // fence between the 8 MFMAs and the slice (first version) the VALU issued after the last MFMA and only
                 // its 16-cycle shadow was free.  Same-box A/B at C2: 20.55-20.74 ms fenced, 20.07-20.20 ms {2,2};
@@ -618,7 +625,11 @@ __device__ __forceinline__ void score_stream16p(const bf16x8 (&a)[8][kKSteps16],
                 // of the tile, where the MFMA pipe waited for their issue (same-box A/B: 20.27-20.42 -> 20.03-20.06 ms).
                 // They stay older than the tile's two result stores, so the vmcnt(2) before the next barrier still means
                 // "this DMA has landed".
-                if constexpr (S == 0 && ks < 6 && !(ABL & 2)) glds16(st_src + ks * 1024, st_dst + ks * 1024);
+                if constexpr (S == 0 && ks < 6 && !(ABL & 2)) {
+                    // (one base and one M0 per four pieces - the immediate reaches 4095: the scorer is issue-bound)
+                    if constexpr (K1_GLDS_OFF) glds16_off<(ks & 3) * 1024>(st_src + (ks >> 2) * 4096, st_dst + (ks >> 2) * 4096);
+                    else glds16(st_src + ks * 1024, st_dst + ks * 1024);
+                }
                 // Place this k-step's pool slice (VALU) in the shadow of its MFMAs: groups of {2 MFMA, 2 VALU}.  With a hard
                 // fence between the 8 MFMAs and the slice (first version) the VALU issued after the last MFMA and only
                 // its 16-cycle shadow was free.  Same-box A/B at C2: 20.55-20.74 ms fenced, 20.07-20.20 ms {2,2};
