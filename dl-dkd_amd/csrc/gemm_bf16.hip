@@ -663,9 +663,43 @@ extern "C" size_t dldkd_tower_train_dw_workspace_bytes(int n_blocks, long rows) 
     return split > 1 ? (size_t)split * kHidden * n_blocks * kHidden * sizeof(float) : 0;
 }
 
-extern "C" int dldkd_tower_train_dw(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
-                                    const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
-                                    size_t workspace_bytes, const unsigned char* k_flags, void* stream) {
+// The split-K reduce of the towers' weight gradients and the column sums that make the position table's gradient (dpos[c] += sum over
+// the n_seq sequences of dx1[n, c], c < cols = L * 384) as ONE launch: workgroups [0, red_blocks) reduce, the others sum rows_per_block
+// sequences of 256 columns each (colsum_kernel's form; one atomic per column and workgroup).
+__global__ __launch_bounds__(256) void splitk_reduce_colsum_kernel(const float* __restrict__ ws, float* __restrict__ out, int split, long n4,
+                                                                   int red_blocks, const float* __restrict__ x, float* __restrict__ csum,
+                                                                   long n_seq, long cols, int rows_per_block, int col_blocks) {
+    if ((int)blockIdx.x < red_blocks) {
+        const long i = (long)blockIdx.x * 256 + threadIdx.x;
+        if (i >= n4) return;
+        const f32x4* w = reinterpret_cast<const f32x4*>(ws) + i;
+        f32x4 a = w[0];
+        for (int z = 1; z < split; ++z) { const f32x4 b = w[(size_t)z * n4]; a += b; }
+        reinterpret_cast<f32x4*>(out)[i] = a;
+        return;
+    }
+    const int b = (int)blockIdx.x - red_blocks, bx = b % col_blocks, by = b / col_blocks;
+    const long c = (long)bx * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const long r0 = (long)by * rows_per_block, r1 = r0 + rows_per_block < n_seq ? r0 + rows_per_block : n_seq;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long r = r0;
+    for (; r + 3 < r1; r += 4) {            // 4 independent loads in flight per lane
+        s0 += x[r * cols + c];
+        s1 += x[(r + 1) * cols + c];
+        s2 += x[(r + 2) * cols + c];
+        s3 += x[(r + 3) * cols + c];
+    }
+    for (; r < r1; ++r) s0 += x[r * cols + c];
+    atomicAdd(csum + c, (s0 + s1) + (s2 + s3));
+}
+
+extern "C" int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream);
+
+static int tower_train_dw_impl(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
+                               const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
+                               size_t workspace_bytes, const unsigned char* k_flags, const float* dx1, float* dpos, long n_seq, long cols,
+                               void* stream) {
     if (n_blocks < 1 || n_blocks > 5 || rows < 0 || rows > 0x7fffffffL || !host_A || !host_lda || !host_acol || !host_a16 || !host_B || !dW) {
         set_error("tower_train_dw: bad arguments");
         return DLDKD_EINVAL;
@@ -693,9 +727,42 @@ extern "C" int dldkd_tower_train_dw(const void* const* host_A, const int* host_l
     (void)attr_ok;
     DLDKD_LAUNCH(gemm_bf16_dw_group_kernel, dim3(kHidden / HBN_, M / HBM_, use_split ? split : 1), dim3(256), lds, (hipStream_t)stream, g);
     int rc = check_launch("tower_train_dw");
-    if (rc != DLDKD_OK || !use_split) return rc;
-    return launch_splitk_reduce((const float*)workspace, dW, split, (long)M * kHidden, (hipStream_t)stream);
+    if (rc != DLDKD_OK) return rc;
+    const bool pos = dx1 != nullptr && dpos != nullptr && n_seq > 0 && cols > 0;
+    if (use_split && pos) {
+        const long n4 = (long)M * kHidden / 4;
+        const int red_blocks = (int)((n4 + 255) / 256);
+        const int rpb = n_seq <= 256 ? 8 : 32;
+        const long col_blocks = (cols + 255) / 256, row_blocks = (n_seq + rpb - 1) / rpb;
+        if (col_blocks * row_blocks + red_blocks < 0x7fffffffL) {
+            DLDKD_LAUNCH(splitk_reduce_colsum_kernel, dim3((unsigned)(red_blocks + col_blocks * row_blocks)), dim3(256), 0, (hipStream_t)stream,
+                         (const float*)workspace, dW, split, n4, red_blocks, dx1, dpos, n_seq, cols, rpb, (int)col_blocks);
+            return check_launch("tower_train_dw (reduce + position sums)");
+        }
+    }
+    if (use_split) {
+        rc = launch_splitk_reduce((const float*)workspace, dW, split, (long)M * kHidden, (hipStream_t)stream);
+        if (rc != DLDKD_OK) return rc;
+    }
+    return pos ? dldkd_colsum_f32(dx1, dpos, n_seq, cols, stream) : DLDKD_OK;
 }
+
+extern "C" int dldkd_tower_train_dw(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
+                                    const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
+                                    size_t workspace_bytes, const unsigned char* k_flags, void* stream) {
+    return tower_train_dw_impl(host_A, host_lda, host_acol, host_a16, host_B, n_blocks, rows, dW, dbias, workspace, workspace_bytes, k_flags,
+                               nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int dldkd_tower_train_dw_pos(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
+                                        const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
+                                        size_t workspace_bytes, const unsigned char* k_flags, const float* dx1, float* dpos, long n_seq,
+                                        long cols, void* stream) {
+    if (!dx1 || !dpos || n_seq < 0 || cols < 1) { set_error("tower_train_dw_pos: bad position-gradient arguments"); return DLDKD_EINVAL; }
+    return tower_train_dw_impl(host_A, host_lda, host_acol, host_a16, host_B, n_blocks, rows, dW, dbias, workspace, workspace_bytes, k_flags,
+                               dx1, dpos, n_seq, cols, stream);
+}
+
 
 extern "C" size_t dldkd_inproj_bwd_workspace_bytes(int N, int K, long M) {
     int per = 0;

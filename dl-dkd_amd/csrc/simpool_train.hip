@@ -18,10 +18,7 @@
 namespace dldkd {
 
 // inv[r] = 1 / max(|x[r, :]|, 1e-12)   (F.normalize's clamp, model.py:318-319); one wave per row
-__global__ __launch_bounds__(256) void row_invnorm_kernel(const float* __restrict__ x, float* __restrict__ inv, long M, int D) {
-    const int lane = threadIdx.x & 63;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= M) return;
+__device__ __forceinline__ void row_invnorm_row(const float* __restrict__ x, float* __restrict__ inv, long r, int D, int lane) {
     float ss = 0.f;
     const float* row = x + r * D;
     if (!(D & 3) && !((uintptr_t)x & 15)) {
@@ -34,6 +31,20 @@ __global__ __launch_bounds__(256) void row_invnorm_kernel(const float* __restric
     }
     ss = wave_sum(ss);
     if (lane == 0) inv[r] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+}
+
+__global__ __launch_bounds__(256) void row_invnorm_kernel(const float* __restrict__ x, float* __restrict__ inv, long M, int D) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r < M) row_invnorm_row(x, inv, r, D, threadIdx.x & 63);
+}
+
+// the two operands of one scored pair (queries, gallery clips) in one launch: workgroups [0, ceil(M0 / 4)) take x0's rows
+__global__ __launch_bounds__(256) void row_invnorm2_kernel(const float* __restrict__ x0, float* __restrict__ inv0, long M0,
+                                                           const float* __restrict__ x1, float* __restrict__ inv1, long M1, int D) {
+    const long b0 = (M0 + 3) / 4;
+    const bool first = (long)blockIdx.x < b0;
+    const long r = ((long)blockIdx.x - (first ? 0 : b0)) * 4 + (threadIdx.x >> 6);
+    if (r < (first ? M0 : M1)) row_invnorm_row(first ? x0 : x1, first ? inv0 : inv1, r, D, threadIdx.x & 63);
 }
 
 struct SimpoolBwdArgs {
@@ -259,6 +270,15 @@ int dldkd_row_invnorm_f32(const float* x, float* inv, long M, int D, void* strea
     if (!x || !inv) { set_error("row_invnorm: null pointer"); return DLDKD_EINVAL; }
     DLDKD_LAUNCH(row_invnorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, inv, M, D);
     return check_launch("row_invnorm");
+}
+
+int dldkd_row_invnorm2_f32(const float* x0, float* inv0, long M0, const float* x1, float* inv1, long M1, int D, void* stream) {
+    if (M0 < 0 || M1 < 0 || D < 1) { set_error("row_invnorm2: bad sizes"); return DLDKD_EINVAL; }
+    if (M0 + M1 == 0) return DLDKD_OK;
+    if ((M0 && (!x0 || !inv0)) || (M1 && (!x1 || !inv1))) { set_error("row_invnorm2: null pointer"); return DLDKD_EINVAL; }
+    DLDKD_LAUNCH(row_invnorm2_kernel, dim3((unsigned)((M0 + 3) / 4 + (M1 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x0, inv0, M0, x1, inv1,
+                 M1, D);
+    return check_launch("row_invnorm2");
 }
 
 int dldkd_simpool_train_fwd_f32(int precision, const float* q, const float* g, const float* rq, const float* rg,

@@ -761,19 +761,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // mode 1: permuted, forward  the same with in = 32 (ks >> 1) + 16 (ks & 1) + 8 (j >> 2) + 4 h + (j & 3)
 // mode 2: natural, transposed A[i][k = out] = W[out][i]           fragments [ks over all sources' outputs][t], t = 32-input tile
 // mode 3: permuted, transposed
+// mode 4: plain cast of src[0] (nsrc groups of 8 consecutive elements) to bf16 - the input projection's weight, which the tower's
+//         first GEMM (gemm_bf16_nt16) reads as bf16: one launch per tower and step prepares every weight operand
 struct PackJob {
     const float* src[3];         // (384, 384) row-major weights (nn.Linear: [out][in])
     int nsrc, mode;
     bf16x8* out;
 };
 struct PackArgs {
-    PackJob job[6];
+    PackJob job[7];
     int njobs;
+    const float* mask;           // optional extra job (blockIdx.y == njobs): lens[n] = number of mask[n, :L] entries > 0, one wave per sequence
+    int n_seq, L;
+    int32_t* lens;
 };
 
 __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
-    const PackJob& jb = a.job[blockIdx.y];
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    if ((int)blockIdx.y == a.njobs) {
+        const int n = idx >> 6, lane = idx & 63;
+        if (n >= a.n_seq) return;
+        float c = 0.f;
+        for (int l = lane; l < a.L; l += 64) c += a.mask[(size_t)n * a.L + l] > 0.f ? 1.f : 0.f;
+        c = wave_sum(c);
+        if (lane == 0) a.lens[n] = (int32_t)c;
+        return;
+    }
+    const PackJob& jb = a.job[blockIdx.y];
+    if (jb.mode == 4) {
+        if (idx >= jb.nsrc) return;
+        const f32x4 lo = reinterpret_cast<const f32x4*>(jb.src[0])[2 * (size_t)idx], hi = reinterpret_cast<const f32x4*>(jb.src[0])[2 * (size_t)idx + 1];
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = (short)f32_to_bf16_bits(lo[j]); v[4 + j] = (short)f32_to_bf16_bits(hi[j]); }
+        jb.out[idx] = v;
+        return;
+    }
     const int frag = idx >> 6, lane = idx & 63, r32 = lane & 31, h = lane >> 5;
     if (frag >= jb.nsrc * kMatFrags) return;
     bf16x8 v;
@@ -843,14 +866,27 @@ extern "C" {
 
 size_t dldkd_tower_train_pack_bytes(int n_mats) { return (size_t)n_mats * tt::kMatFrags * 1024; }
 
-int dldkd_tower_train_pack(const float* const* host_src, const int* host_nsrc, const int* host_mode, void* const* host_out, int njobs,
-                           void* stream) {
-    if (njobs < 1 || njobs > 6 || !host_src || !host_nsrc || !host_mode || !host_out) { set_error("tower_train_pack: 1..6 jobs"); return DLDKD_EINVAL; }
+static int tower_train_pack_impl(const float* const* host_src, const int* host_nsrc, const int* host_mode, void* const* host_out, int njobs,
+                                 const float* mask, int n_seq, int L, int32_t* lens, void* stream) {
+    if (njobs < 1 || njobs > 7 || !host_src || !host_nsrc || !host_mode || !host_out) { set_error("tower_train_pack: 1..7 jobs"); return DLDKD_EINVAL; }
     tt::PackArgs a{};
     a.njobs = njobs;
     int max_src = 1;
+    long max_idx = 0;
     for (int j = 0; j < njobs; ++j) {
         const int ns = host_nsrc[j];
+        if (host_mode[j] == 4) {           // plain cast: ns = groups of 8 elements
+            if (ns < 1 || !host_src[3 * j] || ((uintptr_t)host_src[3 * j] & 15) || !host_out[j] || ((uintptr_t)host_out[j] & 15)) {
+                set_error("tower_train_pack: job %d: cast needs >= 1 group and 16-byte aligned pointers", j);
+                return DLDKD_EINVAL;
+            }
+            a.job[j].src[0] = host_src[3 * j];
+            a.job[j].nsrc = ns;
+            a.job[j].mode = 4;
+            a.job[j].out = (bf16x8*)host_out[j];
+            if (ns > max_idx) max_idx = ns;
+            continue;
+        }
         if (ns < 1 || ns > 3 || host_mode[j] < 0 || host_mode[j] > 3 || !host_out[j] || ((uintptr_t)host_out[j] & 15)) {
             set_error("tower_train_pack: job %d: 1..3 sources, mode 0..3, 16-byte aligned output", j);
             return DLDKD_EINVAL;
@@ -864,8 +900,25 @@ int dldkd_tower_train_pack(const float* const* host_src, const int* host_nsrc, c
         a.job[j].out = (bf16x8*)host_out[j];
         if (ns > max_src) max_src = ns;
     }
-    DLDKD_LAUNCH(tt::pack_kernel, dim3((unsigned)(max_src * tt::kMatFrags * 64 / 256), (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, a);
+    if ((long)max_src * tt::kMatFrags * 64 > max_idx) max_idx = (long)max_src * tt::kMatFrags * 64;
+    const bool want_lens = mask != nullptr && n_seq > 0;
+    if (want_lens) {
+        a.mask = mask; a.n_seq = n_seq; a.L = L; a.lens = lens;
+        if ((long)n_seq * 64 > max_idx) max_idx = (long)n_seq * 64;
+    }
+    DLDKD_LAUNCH(tt::pack_kernel, dim3((unsigned)((max_idx + 255) / 256), (unsigned)(njobs + (want_lens ? 1 : 0))), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("tower_train_pack");
+}
+
+int dldkd_tower_train_pack(const float* const* host_src, const int* host_nsrc, const int* host_mode, void* const* host_out, int njobs,
+                           void* stream) {
+    return tower_train_pack_impl(host_src, host_nsrc, host_mode, host_out, njobs, nullptr, 0, 0, nullptr, stream);
+}
+
+int dldkd_tower_train_prepare(const float* const* host_src, const int* host_nsrc, const int* host_mode, void* const* host_out, int njobs,
+                              const float* mask, int n_seq, int L, int32_t* lens, void* stream) {
+    if (n_seq < 0 || L < 1 || (n_seq > 0 && (!mask || !lens))) { set_error("tower_train_prepare: bad mask arguments"); return DLDKD_EINVAL; }
+    return tower_train_pack_impl(host_src, host_nsrc, host_mode, host_out, njobs, mask, n_seq, L, lens, stream);
 }
 
 int dldkd_tower_train_f1(const float* y0, const float* pos, int L, const float* gamma, const float* beta, float eps, float p_drop,

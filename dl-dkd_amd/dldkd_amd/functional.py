@@ -4,6 +4,7 @@ torch supplies tensors, the tape and the stream; every number is produced by lib
 torch.no_grad() the same entry points run the fused inference kernels (ops.attention etc.).
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -220,8 +221,10 @@ class _InProjTrain(Function):
             y = torch.empty(M, N, dtype=torch.float32, device=x.device)
             if IN_PROJ_TRAIN_NT16 and M >= 1024 and _L().dldkd_gemm_bf16_nt16_ok(M, N, K, K, K) and weight.is_contiguous():
                 # both operands bf16, tiles by LDS-DMA (gemm_bf16_dma.hip): the weight is cast once here (1.2 M elements)
-                w16 = torch.empty(N, K, dtype=torch.bfloat16, device=x.device)
-                native.check(_L().dldkd_cast_bf16(_p(weight), _p(w16), N * K, _s()), "cast_bf16")
+                w16 = _take_prepacked("w16", weight.data_ptr())
+                if w16 is None:
+                    w16 = torch.empty(N, K, dtype=torch.bfloat16, device=x.device)
+                    native.check(_L().dldkd_cast_bf16(_p(weight), _p(w16), N * K, _s()), "cast_bf16")
                 native.check(_L().dldkd_gemm_bf16_nt16(_p(z), _p(w16), _p(bias), _p(y), M, N, K, K, K, N, int(relu), _p(gflags), _s()),
                              "gemm_bf16_nt16")
             else:
@@ -504,11 +507,13 @@ def _bf16(shape, device):
     return torch.empty(shape, dtype=torch.bfloat16, device=device)
 
 
-def _tt_pack(jobs, device):
-    """jobs = [(sources, mode)] -> the packed weights as views of one buffer; one kernel launch (dldkd_tower_train_pack)."""
+def _tt_pack(jobs, device, mask=None):
+    """jobs = [(sources, mode)] -> the packed weights as views of one buffer; one kernel launch (dldkd_tower_train_pack).
+    mode 4: sources = [w], any contiguous fp32 tensor with numel % 8 == 0 -> its plain bf16 cast (same shape).
+    mask (n, L) fp32 contiguous: the sequence lengths (int32) come out of the same launch, appended to the result."""
     import ctypes
     L_ = _L()
-    sizes = [L_.dldkd_tower_train_pack_bytes(len(srcs)) for srcs, _ in jobs]
+    sizes = [(srcs[0].numel() * 2 + 15) // 16 * 16 if md == 4 else L_.dldkd_tower_train_pack_bytes(len(srcs)) for srcs, md in jobs]
     buf = torch.empty(sum(sizes), dtype=torch.uint8, device=device)
     outs, off = [], 0
     for sz in sizes:
@@ -518,13 +523,64 @@ def _tt_pack(jobs, device):
     src = (ctypes.c_void_p * (3 * n))()
     nsrc, mode, out = (ctypes.c_int * n)(), (ctypes.c_int * n)(), (ctypes.c_void_p * n)()
     for j, (srcs, md) in enumerate(jobs):
+        if md == 4:
+            w = srcs[0]
+            if w.dtype != torch.float32 or not w.is_contiguous() or w.numel() % 8:
+                raise native.NativeError("tower_train: the cast job needs a contiguous fp32 tensor of 8 k elements")
+            src[3 * j] = w.data_ptr()
+            nsrc[j], mode[j], out[j] = w.numel() // 8, 4, outs[j].data_ptr()
+            outs[j] = outs[j][:w.numel() * 2].view(torch.bfloat16).view(w.shape)
+            continue
         for c, w in enumerate(srcs):
             if w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != (HIDDEN, HIDDEN):
                 raise native.NativeError("tower_train: weights must be contiguous fp32 (384, 384)")
             src[3 * j + c] = w.data_ptr()
         nsrc[j], mode[j], out[j] = len(srcs), md, outs[j].data_ptr()
+    if mask is not None:
+        lens = torch.empty(mask.shape[0], dtype=torch.int32, device=device)
+        native.check(L_.dldkd_tower_train_prepare(src, nsrc, mode, out, n, _p(mask), mask.shape[0], mask.shape[1], _p(lens), _s()),
+                     "tower_train_prepare")
+        return outs + [lens]
     native.check(L_.dldkd_tower_train_pack(src, nsrc, mode, out, n, _s()), "tower_train_pack")
     return outs
+
+
+# One launch per tower and step for every weight operand: model._tower_fused calls tower_prepack() in front of the input projection;
+# _InProjTrain.forward (the bf16 weight of its GEMM) and _TowerTrain.forward (the fragment packs) take what was prepared for THEIR
+# weights (matched by storage and parameter epoch) and fall back to their own launches otherwise.
+TOWER_PREPACK = os.environ.get("DLDKD_TOWER_PREPACK", "1") == "1"
+_PREPACKED = {}
+
+
+def _tt_jobs(wq, wk, wv, wd, wo):
+    return [([wq, wk, wv], 0), ([wd], 0)] + ([([wo], 1), ([wo], 2)] if wo is not None else []) + [([wd], 3), ([wq, wk, wv], 2)]
+
+
+def tower_prepack(w_in, wq, wk, wv, wd, wo, mask=None):
+    """Prepares (bf16 cast of the input projection's weight w_in - None: not wanted, fragment packs of the tower's matrices) in one
+    launch and leaves them for the two consumers; with the batch's mask ((n, L) fp32) the same launch counts the sequence lengths,
+    which are returned (int32; None without a usable mask)."""
+    jobs = _tt_jobs(wq, wk, wv, wd, wo)
+    cast = w_in is not None and w_in.is_contiguous() and w_in.dtype == torch.float32 and w_in.numel() % 8 == 0
+    lens = None
+    if mask is not None and not (mask.is_cuda and mask.dtype == torch.float32 and mask.is_contiguous() and mask.dim() == 2):
+        mask = None
+    outs = _tt_pack(jobs + ([([w_in], 4)] if cast else []), wq.device, mask=mask)
+    if mask is not None:
+        lens = outs.pop()
+    _PREPACKED.clear()
+    ep = ops.param_epoch()
+    if cast:
+        _PREPACKED["w16"] = (w_in.data_ptr(), ep, outs.pop())
+    _PREPACKED["packs"] = (tuple(w.data_ptr() for w in (wq, wk, wv, wd) + ((wo,) if wo is not None else ())), ep, outs)
+    return lens
+
+
+def _take_prepacked(kind, key):
+    ent = _PREPACKED.pop(kind, None)
+    if ent is not None and ent[0] == key and ent[1] == ops.param_epoch():
+        return ent[2]
+    return None
 
 
 class _TowerTrain(Function):
@@ -542,8 +598,9 @@ class _TowerTrain(Function):
         video = wo is not None
         if flags is None:
             lens = None          # the attention kernels skip the 32-row tiles past a sequence only where the row kernels skip them too
-        jobs = [([wq, wk, wv], 0), ([wd], 0)] + ([([wo], 1), ([wo], 2)] if video else []) + [([wd], 3), ([wq, wk, wv], 2)]
-        packs = _tt_pack(jobs, dev)
+        packs = _take_prepacked("packs", tuple(w.data_ptr() for w in (wq, wk, wv, wd) + ((wo,) if video else ())))
+        if packs is None:
+            packs = _tt_pack(_tt_jobs(wq, wk, wv, wd, wo), dev)
         if video:
             pk_qkv, pk_d, pk_o, pk_ot, pk_dt, pk_qkvt = packs
         else:
@@ -604,17 +661,19 @@ class _TowerTrain(Function):
         hl, hc, h16 = (ctypes.c_int * nb)(), (ctypes.c_int * nb)(), (ctypes.c_int * nb)()
         for i, (a_, lda, col, a16, b_) in enumerate(blocks):
             hA[i], hB[i], hl[i], hc[i], h16[i] = a_.data_ptr(), b_.data_ptr(), lda, col, a16
-        native.check(L_.dldkd_tower_train_dw(hA, hl, hc, h16, hB, nb, M, _p(dW), _p(dB), _p(ws), ws_bytes, _p(flags), _s()), "tower_train_dw")
+        dpos = None
+        if need_pos:                                         # gradient of the whole table: rows >= L stay zero (arena); summed over the
+            dpos = _zeros((pos.shape[0], HIDDEN), dev)       # sequences inside the launch that reduces the split-K planes
+            native.check(L_.dldkd_tower_train_dw_pos(hA, hl, hc, h16, hB, nb, M, _p(dW), _p(dB), _p(ws), ws_bytes, _p(flags), _p(dx1), _p(dpos),
+                                                     dx1.shape[0], L * HIDDEN, _s()), "tower_train_dw_pos")
+        else:
+            native.check(L_.dldkd_tower_train_dw(hA, hl, hc, h16, hB, nb, M, _p(dW), _p(dB), _p(ws), ws_bytes, _p(flags), _s()), "tower_train_dw")
         H = HIDDEN
         o = 1 if video else 0
         dwo, dbo = (dW[:H], dB[:H]) if video else (None, None)
         dwd, dbd = dW[o * H:(o + 1) * H], dB[o * H:(o + 1) * H]
         dwq, dwk, dwv = (dW[(o + 1 + c) * H:(o + 2 + c) * H] for c in range(3))
         dbq, dbk, dbv = (dB[(o + 1 + c) * H:(o + 2 + c) * H] for c in range(3))
-        dpos = None
-        if need_pos:                                         # gradient of the whole table: rows >= L stay zero (arena)
-            dpos = _zeros((pos.shape[0], HIDDEN), dev)
-            native.check(L_.dldkd_colsum_f32(_p(dx1), _p(dpos), dx1.shape[0], L * HIDDEN, _s()), "colsum")
         return (dy0, dpos, lnp[2], lnp[3], dwq, dbq, dwk, dbk, dwv, dbv, dwd, dbd, lnp[0], lnp[1], dwo, dbo,
                 None, None, None, None, None, None, None)
 
@@ -746,8 +805,7 @@ class _SimPoolTrain(Function):
         dev = q.device
         rq = torch.empty(Nq, dtype=torch.float32, device=dev)
         rg = torch.empty(Nv * L, dtype=torch.float32, device=dev)
-        native.check(_L().dldkd_row_invnorm_f32(_p(q), _p(rq), Nq, D, _s()), "row_invnorm")
-        native.check(_L().dldkd_row_invnorm_f32(_p(g), _p(rg), Nv * L, D, _s()), "row_invnorm")
+        native.check(_L().dldkd_row_invnorm2_f32(_p(q), _p(rq), Nq, _p(g), _p(rg), Nv * L, D, _s()), "row_invnorm2")
         pc = torch.empty(Nq, Nv, dtype=torch.float32, device=dev)
         pr = torch.empty(Nq, Nv, dtype=torch.float32, device=dev)
         ac = torch.empty(Nq, Nv, dtype=torch.int32, device=dev)
@@ -929,6 +987,28 @@ def nce_hard(labels, S):
 BRANCH_LOSS_FUSED = True      # a branch's triplet + InfoNCE + KL terms and their gradients as three launches (losses_f32.hip)
 
 
+_UNIT_GRADS = {}
+
+
+def unit_grad(device):
+    """The constant 1.0 (0-dim fp32) a caller passes as the upstream gradient of loss terms it only sums (train.GraphedTrainStep's
+    branch graphs: grad_outputs of torch.autograd.grad).  _BranchLoss.backward recognises it by its storage and skips the scaling
+    launch - the gradients were computed for an upstream gradient of 1.  Made once per device, outside any capture."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0))
+    t = _UNIT_GRADS.get(key)
+    if t is None:
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("unit_grad: first use on a device must be outside a stream capture")
+        t = _UNIT_GRADS[key] = torch.ones((), dtype=torch.float32, device=dev)
+    return t
+
+
+def _is_unit(g):
+    t = _UNIT_GRADS.get((g.device.type, g.device.index if g.device.index is not None else 0))
+    return t is not None and g.data_ptr() == t.data_ptr() and g.numel() == 1
+
+
 class _BranchLoss(Function):
     """The loss terms of one branch (model.py:137-155) from its pooled scores, values and gradients in one pass: the gradients are
     computed with the values (for an upstream gradient of 1) and scaled by the actual upstream gradients in the backward pass."""
@@ -955,6 +1035,9 @@ class _BranchLoss(Function):
     @staticmethod
     def backward(ctx, g_trip, g_nce, g_kl):
         dC, dS, dclip = ctx.saved_tensors
+        if (g_trip is not None and g_nce is not None and _is_unit(g_trip) and _is_unit(g_nce)
+                and (dclip is None or (g_kl is not None and _is_unit(g_kl)))):
+            return dC, dS, None, dclip, None, None, None, None, None, None, None, None      # scaling by exactly 1: nothing to launch
         one = None
         def gs(g):                                             # an unused term has no upstream gradient: its gradients are zero
             nonlocal one

@@ -416,15 +416,23 @@ class DLDKD(nn.Module):
         if L > pos.position_embeddings.num_embeddings:
             raise IndexError(f"sequence length {L} exceeds {pos.position_embeddings.num_embeddings} positions")
         fused_proj = F_.in_proj_train_ok(feat, proj.net[1].weight) and proj.relu
+        out_lin = getattr(self, pre + "out_mapping_linear") if kind == "visual" else None
+        lens = None
+        if F_.TOWER_PREPACK:
+            # every weight operand of the tower - the projection's bf16 weight, the fragment packs - and the batch's sequence lengths
+            # from ONE launch
+            lens = F_.tower_prepack(proj.net[1].weight if fused_proj else None, enc.self.query.weight, enc.self.key.weight,
+                                    enc.self.value.weight, enc.output.dense.weight, None if out_lin is None else out_lin.weight, mask=mask)
+        if lens is None:
+            lens = self._lens(mask, n, L, feat.device)
         y0 = proj(feat, row_mask=mask, grad_premasked=True) if fused_proj else proj(feat)
         rg = F_.take_group_flags()
         flags = rg[0] if (rg is not None and self.TOWER_SKIPS_PADDING and rg[1] == n * L) else None
-        out_lin = getattr(self, pre + "out_mapping_linear") if kind == "visual" else None
         # (the WHOLE position table goes in - the kernels read its first L rows: a [:L] view here costs a zeros + copy pair per tower
         # in autograd's slice backward)
         return F_.tower_train(y0, pos.position_embeddings.weight, pos.LayerNorm.weight, pos.LayerNorm.bias,
                               (enc.self.query, enc.self.key, enc.self.value), enc.output.dense, enc.output.LayerNorm.weight,
-                              enc.output.LayerNorm.bias, out_lin, mask, self._lens(mask, n, L, feat.device), flags,
+                              enc.output.LayerNorm.bias, out_lin, mask, lens, flags,
                               pos.dropout.p, enc.self.dropout.p, enc.output.dropout.p, self.training, relu_mask=fused_proj)
 
     def _video_tower(self, pre, feat, mask):

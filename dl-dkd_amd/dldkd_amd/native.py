@@ -66,6 +66,7 @@ SIGNATURES = {
                                                    ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p]),
     "dldkd_tower_train_pack_bytes": (_c_size_t, [_c_int]),
     "dldkd_tower_train_pack": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p]),
+    "dldkd_tower_train_prepare": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_tower_train_f1": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64,
                                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p,
                                        _c_void_p, _c_void_p, _c_void_p]),
@@ -81,6 +82,8 @@ SIGNATURES = {
     "dldkd_tower_train_dw_workspace_bytes": (_c_size_t, [_c_int, _c_long]),
     "dldkd_tower_train_dw": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_void_p, _c_void_p, _c_void_p,
                                        _c_size_t, _c_void_p, _c_void_p]),
+    "dldkd_tower_train_dw_pos": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_void_p, _c_void_p, _c_void_p,
+                                           _c_size_t, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_long, _c_void_p]),
     "dldkd_mask_lens_f32": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_colsum_bf16": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_branch_losses_f32": (_c_int, [_c_void_p] * 11 + [_c_int] * 7 + [_c_float] * 6 + [_c_void_p] * 6),
@@ -131,6 +134,7 @@ SIGNATURES = {
     "dldkd_attention_train_bwd_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float,
                                                  ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p]),
     "dldkd_row_invnorm_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
+    "dldkd_row_invnorm2_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
     "dldkd_simpool_train_fwd_f32": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
                                               _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_simpool_train_bwd_f32": (_c_int, [_c_void_p] * 13 + [_c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),

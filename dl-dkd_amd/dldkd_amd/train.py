@@ -200,7 +200,8 @@ class GraphedTrainStep:
     (_capture_segments)."""
 
     QUERY_STREAMS_HIGH_PRIORITY = os.environ.get("DLDKD_QUERY_PRIO", "0") == "1"
-    EARLY_VIDEO_START = True      # replay: the video towers start behind the video features' copy, not behind the whole batch's
+    EARLY_VIDEO_START = True        # replay: the video towers start behind the video features' copy, not behind the whole batch's
+    UNIT_BRANCH_GRADS = True        # the branch graphs pass the constant 1 as the terms' upstream gradient (see branch_runner)
     TENSOR_KEYS = ("student_videos", "student_videos_mask", "teacher_videos", "student_text", "student_text_mask", "teacher_text")
 
     def __init__(self, model, optimizer, opt, max_graphs=8, defer_loss_float=False, max_captures=24):
@@ -513,6 +514,7 @@ class GraphedTrainStep:
         the three main-stream graphs); tensors that cross pools (tower outputs, their gradients, saved activations, the zero
         arena) are alive while their consumer is captured, and nothing is captured into their pool afterwards that could run
         before that consumer."""
+        from . import functional as F_
         m, opt_ = self.model, self.optimizer
         dev = e.static["student_videos"].device
         ctx = [None]
@@ -537,6 +539,7 @@ class GraphedTrainStep:
 
         e.par = {"fwd": [], "bwd": [], "streams": [], "loss": []}
         stream_of, tap_grads = {}, {}
+        unit = F_.unit_grad(dev)
 
         def runner(thunks, weights):
             close_graph()                                   # the graph in front of the towers ends here
@@ -572,10 +575,17 @@ class GraphedTrainStep:
                 gr = open_graph(st, ("loss", b))
                 qv, gv = q.view_as(q), g.view_as(g)
                 terms = fn(qv, gv)
-                total = terms[0]
-                for t in terms[1:]:
-                    total = total + t
-                gq, gg = torch.autograd.grad(total, [qv, gv], allow_unused=True)
+                if self.UNIT_BRANCH_GRADS and all(torch.is_tensor(t) and t.dim() == 0 and t.dtype == torch.float32 for t in terms):
+                    # the step's loss is the plain sum of the terms (model.py:157-160): every term's upstream gradient is the
+                    # constant 1 - handed over as such there is no add per term, no ones fill and (functional._BranchLoss) no
+                    # scaling launch in the branch's graph
+                    gq, gg = torch.autograd.grad(list(terms), [qv, gv], grad_outputs=[unit] * len(terms), allow_unused=True)
+                    total = None
+                else:
+                    total = terms[0]
+                    for t in terms[1:]:
+                        total = total + t
+                    gq, gg = torch.autograd.grad(total, [qv, gv], allow_unused=True)
                 close_graph()
                 e.par["loss"].append((gr, iq, (iq, ig)))
                 tap_grads[iq], tap_grads[ig] = gq, gg

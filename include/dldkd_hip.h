@@ -524,7 +524,9 @@ int dldkd_attention_train_bwd_bf16io(const void* qkv, const float* mask, const i
  * arguments.  Weights reach the kernels in MFMA fragment order (dldkd_tower_train_pack; 288 KiB per 384 x 384 matrix):
  *   mode 0 / 1: W as the A operand of Y^T = W X^T, k natural / in the permuted order of an accumulator tile used as operand
  *   mode 2 / 3: W^T likewise (input gradients); up to three (384, 384) sources are concatenated along the OUTPUT axis (q | k | v).
- * host_src (3 per job), host_nsrc, host_mode, host_out are HOST arrays of njobs <= 6 entries (the pointers in them are device
+ *   mode 4:     plain cast of host_src[3 j] to bf16, host_nsrc[j] = number of 8-element groups (the input projection's weight for
+ *               dldkd_gemm_bf16_nt16, so that one launch per tower and step prepares every weight operand)
+ * host_src (3 per job), host_nsrc, host_mode, host_out are HOST arrays of njobs <= 7 entries (the pointers in them are device
  * pointers); the call enqueues one kernel.
  *   f1: y0 (M, 384) fp32 (the input projection's output) + pos (L, 384) -> LayerNorm(gamma, beta) -> dropout -> h1d (M, 384) bf16,
  *       stats [2][M] (mean, rstd), qkv (M, 1152) bf16 = h1d Wqkv^T + (bq | bk | bv)          wqkv_pack: mode 0, three sources;
@@ -543,6 +545,10 @@ int dldkd_attention_train_bwd_bf16io(const void* qkv, const float* mask, const i
 size_t dldkd_tower_train_pack_bytes(int n_mats);
 int dldkd_tower_train_pack(const float* const* host_src, const int* host_nsrc, const int* host_mode, void* const* host_out, int njobs,
                            void* stream);
+/* dldkd_tower_train_pack plus the sequence lengths of the tower's batch in the same launch: lens[n] = number of mask[n, :L]
+ * entries > 0 (mask (n_seq, L) fp32, a prefix mask: data_provider.py:81-84), as dldkd_mask_lens_f32. */
+int dldkd_tower_train_prepare(const float* const* host_src, const int* host_nsrc, const int* host_mode, void* const* host_out, int njobs,
+                              const float* mask, int n_seq, int L, int32_t* lens, void* stream);
 int dldkd_tower_train_f1(const float* y0, const float* pos, int L, const float* gamma, const float* beta, float eps, float p_drop,
                          unsigned long long seed, unsigned long long offset, const unsigned long long* state, const void* wqkv_pack,
                          const float* bq, const float* bk, const float* bv, const unsigned char* flags, long M, void* h1d, void* xh1,
@@ -567,6 +573,13 @@ size_t dldkd_tower_train_dw_workspace_bytes(int n_blocks, long rows);
 int dldkd_tower_train_dw(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
                          const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
                          size_t workspace_bytes, const unsigned char* k_flags, void* stream);
+/* The same plus the gradient of the position table (TrainablePositionalEncoding, model_components.py:277-284): dpos[c] += sum over
+ * the n_seq sequences of dx1[n, c], c < cols = L * 384 (dx1 from dldkd_tower_train_b1; dpos zeroed by the caller) - inside the launch
+ * that reduces the split-K planes (one launch fewer per tower than dldkd_tower_train_dw + dldkd_colsum_f32). */
+int dldkd_tower_train_dw_pos(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
+                             const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
+                             size_t workspace_bytes, const unsigned char* k_flags, const float* dx1, float* dpos, long n_seq, long cols,
+                             void* stream);
 /* out[c] += sum over the rows r of x[r, c0 + c] (x (M, ld) bf16, c < N) whose 32-row group is flagged (flags NULL: all rows); out is
  * zeroed by the caller.  The bias gradients of the fused training towers (rows of skipped groups are not written: they must not be
  * read). */
@@ -586,6 +599,8 @@ int dldkd_colsum_bf16(const void* x, int ld, int c0, int N, long M, const unsign
  * written, not accumulated): the max-pool gradient goes to the arg-max clip, the cosine through the normalisation Jacobian
  * rq (ghat - cos qhat); D a multiple of 4, <= 512. */
 int dldkd_row_invnorm_f32(const float* x, float* inv, long M, int D, void* stream);
+/* The same for the two operands of one scored pair (x0: M0 rows, x1: M1 rows, both D wide) in ONE launch. */
+int dldkd_row_invnorm2_f32(const float* x0, float* inv0, long M0, const float* x1, float* inv1, long M1, int D, void* stream);
 int dldkd_simpool_train_fwd_f32(int precision, const float* q, const float* g, const float* rq, const float* rg,
                                 const int32_t* lens, const int32_t* labels, int nq, int nv, int L, int D, float* pooled_cos,
                                 float* pooled_raw, int32_t* arg_cos, int32_t* arg_raw, float* clip_pos, void* stream);
