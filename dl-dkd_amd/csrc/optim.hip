@@ -43,6 +43,50 @@ __global__ __launch_bounds__(256) void adam_sumsq_kernel(const float* __restrict
     if (threadIdx.x == 0 && cur >= 0) atomicAdd(norm2 + cur, acc);
 }
 
+// One tower's gradients (wherever autograd left them) -> their ranges of the flat gradient buffer, and the per-tensor sums of squares the
+// clip needs, in ONE pass: a gradient is read once between the kernel that produced it and the update (the multi-tensor copy + the
+// separate sum-of-squares pass read it twice and wrote it once, as two launches at the serial end of the step).
+constexpr int kGatherMax = 32;          // tensors per launch
+constexpr int kGatherSpan = 4096;       // elements per workgroup: 4 float4 per thread
+struct GatherArgs {
+    const float* src[kGatherMax];
+    int start[kGatherMax], numel[kGatherMax], tensor[kGatherMax], vec[kGatherMax];
+    int blk0[kGatherMax + 1];
+    int n;
+    float* flat;
+    float* norm2;                       // null: copy only
+};
+
+__global__ __launch_bounds__(256) void gather_sumsq_kernel(const GatherArgs a) {
+    __shared__ float red[4];
+    int j = 0;
+    while (j + 1 < a.n && (int)blockIdx.x >= a.blk0[j + 1]) ++j;
+    const float* __restrict__ src = a.src[j];
+    float* __restrict__ dst = a.flat + a.start[j];
+    const int n = a.numel[j], base = ((int)blockIdx.x - a.blk0[j]) * kGatherSpan;
+    float acc = 0.f;
+    if (a.vec[j]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + (k * 256 + (int)threadIdx.x) * 4;
+            if (i + 3 < n) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+                *reinterpret_cast<f32x4*>(dst + i) = v;
+                acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            } else {
+                for (int e = i; e < n; ++e) { const float v = src[e]; dst[e] = v; acc += v * v; }
+            }
+        }
+    } else {
+        for (int i = base + (int)threadIdx.x; i < base + kGatherSpan && i < n; i += 256) { const float v = src[i]; dst[i] = v; acc += v * v; }
+    }
+    if (a.norm2 == nullptr) return;
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(a.norm2 + a.tensor[j], (red[0] + red[1]) + (red[2] + red[3]));
+}
+
 // norm2 <- 0 as a KERNEL, not hipMemsetAsync: a memset NODE of a replayed hipGraph left every fourth word of this 296-byte
 // buffer unzeroed (stale 0x510c7186-like words) whenever the stream was idle at launch - ROCm 7.0.2, seen as per-tensor clip
 // coefficients of ~0 in replayed steps only (round 3; tests/test_train_loop_gpu.py variable-length test).
@@ -120,10 +164,39 @@ int dldkd_zero_scratch_f32(float* x, int n, void* stream) {
  * setting.  train.GraphedTrainStep sets it from the probe's result. */
 int dldkd_set_zero_by_memset(int on) { return g_zero_by_memset.exchange(on ? 1 : 0); }
 
-int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const int32_t* chunk_tensor, int n_chunks,
-                             const int32_t* t_start, const int32_t* t_numel, int n_tensors, float* norm2_scratch,
-                             const float* t_wd, const float* t_lr, const float* t_active, float b1, float b2, float eps,
-                             float max_grad_norm, void* stream) {
+int dldkd_gather_sumsq_f32(const float* const* host_src, const int* host_start, const int* host_numel, const int* host_tensor, int n,
+                           float* flat_grad, float* norm2, void* stream) {
+    if (n < 0 || n > kGatherMax) { set_error("gather_sumsq: 0..%d tensors per call", kGatherMax); return DLDKD_EINVAL; }
+    if (n == 0) return DLDKD_OK;
+    if (!host_src || !host_start || !host_numel || !host_tensor || !flat_grad || ((uintptr_t)flat_grad & 15)) {
+        set_error("gather_sumsq: null or unaligned pointer");
+        return DLDKD_EINVAL;
+    }
+    GatherArgs a{};
+    int blocks = 0, used = 0;
+    for (int j = 0; j < n; ++j) {
+        if (host_numel[j] < 0 || host_start[j] < 0 || host_tensor[j] < 0 || (host_numel[j] > 0 && !host_src[j])) {
+            set_error("gather_sumsq: tensor %d: bad range or null source", j);
+            return DLDKD_EINVAL;
+        }
+        if (host_numel[j] == 0) continue;
+        a.src[used] = host_src[j]; a.start[used] = host_start[j]; a.numel[used] = host_numel[j]; a.tensor[used] = host_tensor[j];
+        a.vec[used] = !((uintptr_t)host_src[j] & 15) && !(host_start[j] & 3);
+        a.blk0[used] = blocks;
+        blocks += (host_numel[j] + kGatherSpan - 1) / kGatherSpan;
+        ++used;
+    }
+    if (used == 0) return DLDKD_OK;
+    a.blk0[used] = blocks;
+    a.n = used; a.flat = flat_grad; a.norm2 = norm2;
+    DLDKD_LAUNCH(gather_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("gather_sumsq");
+}
+
+static int bert_adam_impl(float* p, const float* g, float* m, float* v, const int32_t* chunk_tensor, int n_chunks,
+                          const int32_t* t_start, const int32_t* t_numel, int n_tensors, float* norm2_scratch,
+                          const float* t_wd, const float* t_lr, const float* t_active, float b1, float b2, float eps,
+                          float max_grad_norm, bool norms_ready, void* stream) {
     if (n_chunks < 0 || n_tensors < 0) { set_error("bert_adam: bad sizes"); return DLDKD_EINVAL; }
     if (n_chunks == 0) return DLDKD_OK;
     if (!p || !g || !m || !v || !chunk_tensor || !t_start || !t_numel || !norm2_scratch || !t_wd || !t_lr) {
@@ -131,7 +204,7 @@ int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const
         return DLDKD_EINVAL;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (max_grad_norm > 0.f) {
+    if (max_grad_norm > 0.f && !norms_ready) {
         // zeroed by a kernel unless the start-up probe (staging.memset_node_defect) found this runtime's memset nodes clean and the
         // caller switched them on (dldkd_set_zero_by_memset)
         if (g_zero_by_memset.load(std::memory_order_relaxed)) {
@@ -145,6 +218,22 @@ int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const
     DLDKD_LAUNCH(adam_update_kernel, dim3(n_chunks), dim3(256), 0, s, p, g, m, v, chunk_tensor, t_start, t_numel,
                        norm2_scratch, t_wd, t_lr, t_active, b1, b2, eps, max_grad_norm);
     return check_launch("bert_adam");
+}
+
+int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const int32_t* chunk_tensor, int n_chunks,
+                             const int32_t* t_start, const int32_t* t_numel, int n_tensors, float* norm2_scratch,
+                             const float* t_wd, const float* t_lr, const float* t_active, float b1, float b2, float eps,
+                             float max_grad_norm, void* stream) {
+    return bert_adam_impl(p, g, m, v, chunk_tensor, n_chunks, t_start, t_numel, n_tensors, norm2_scratch, t_wd, t_lr, t_active, b1, b2, eps,
+                          max_grad_norm, false, stream);
+}
+
+int dldkd_bert_adam_update_f32(float* p, const float* g, float* m, float* v, const int32_t* chunk_tensor, int n_chunks,
+                               const int32_t* t_start, const int32_t* t_numel, int n_tensors, const float* norm2,
+                               const float* t_wd, const float* t_lr, const float* t_active, float b1, float b2, float eps,
+                               float max_grad_norm, void* stream) {
+    return bert_adam_impl(p, g, m, v, chunk_tensor, n_chunks, t_start, t_numel, n_tensors, const_cast<float*>(norm2), t_wd, t_lr, t_active, b1,
+                          b2, eps, max_grad_norm, true, stream);
 }
 
 int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv, int ld, int32_t* counts, void* stream) {

@@ -141,6 +141,10 @@ SIGNATURES = {
     "dldkd_bert_adam_step_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p,
                                            _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_float, _c_float,
                                            _c_float, _c_void_p]),
+    "dldkd_bert_adam_update_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p,
+                                             _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_float, _c_float,
+                                             _c_float, _c_void_p]),
+    "dldkd_gather_sumsq_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_count_above_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_fold_ln_linear_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
                                             _c_void_p, _c_void_p]),

@@ -88,6 +88,7 @@ class FlatParams:
         self._bound, self._had = False, tuple(True for _ in self.params)
         self._had_partial = {}
         self._had_subset = {}
+        self._norm_done = set()
         self._index = index
 
     def views(self):
@@ -104,9 +105,48 @@ class FlatParams:
         self._bound = False
         self._had_partial = {}
         self._had_subset = {}
+        self._norm_done = set()
 
-    def _gather(self, members):
+    FUSED_GATHER = True     # GPU: one native launch per gather (dldkd_gather_sumsq_f32) instead of torch's multi-tensor copy
+
+    def _gather_native(self, members, norm2):
+        """members' gradients -> their flat ranges (+ their sums of squares added to norm2) with dldkd_gather_sumsq_f32; False when a
+        gradient is not a plain fp32 contiguous tensor of its parameter's size (the caller then copies the torch way)."""
+        import ctypes
         views = self.views()
+        todo = [i for i in members if self.params[i].grad is not None
+                and (norm2 is not None or self.params[i].grad.data_ptr() != views[i].data_ptr())]
+        for i in todo:
+            g = self.params[i].grad
+            if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.numel() == self._numels[i]):
+                return False
+        L = native.lib()
+        for lo in range(0, len(todo), 32):
+            part = todo[lo:lo + 32]
+            n = len(part)
+            src = (ctypes.c_void_p * n)(*[self.params[i].grad.data_ptr() for i in part])
+            st = (ctypes.c_int * n)(*[self._starts[i] for i in part])
+            nu = (ctypes.c_int * n)(*[self._numels[i] for i in part])
+            tt = (ctypes.c_int * n)(*part)
+            native.check(L.dldkd_gather_sumsq_f32(src, st, nu, tt, n, native.ptr(self.grad), native.ptr(norm2), native.stream()),
+                         "gather_sumsq")
+        return True
+
+    def _gather(self, members, norm2=None):
+        """norm2 (per-tensor fp32 scratch, zeroed by the caller this step): the members' sums of squares are added to it in the same
+        pass; self._norm_done then lists them (BertAdam.enqueue skips its own pass when every tensor is listed)."""
+        views = self.views()
+        if self.FUSED_GATHER and self.grad.is_cuda and self._gather_native(members, norm2):
+            had = []
+            for i in members:
+                p = self.params[i]
+                had.append(p.grad is not None)
+                if p.grad is None:
+                    views[i].zero_()
+                p.grad = views[i]
+            if norm2 is not None:
+                self._norm_done.update(members)
+            return had
         dst, src, had = [], [], []
         for i in members:
             p, view = self.params[i], views[i]
@@ -127,14 +167,20 @@ class FlatParams:
         for p, v in zip(self.params, self.views()):
             p.grad = v
         self._bound, self._had, self._had_partial, self._had_subset = True, tuple(had), {}, {}
+        self._norm_done = set()
 
-    def gather_subset(self, params):
+    def gather_subset(self, params, norm2=None):
         """rebind_grads for an arbitrary subset of the parameters whose gradients are final (one tower's, on the stream that
-        computed them: train.GraphedTrainStep captures a tower's backward pass and this copy into that tower's own graph)."""
+        computed them: train.GraphedTrainStep captures a tower's backward pass and this copy into that tower's own graph).
+        norm2: see _gather."""
         idx = [self._index[id(p)] for p in params]
         idx = [i for i in idx if i not in self._had_subset]
-        for i, h in zip(idx, self._gather(idx)):
+        for i, h in zip(idx, self._gather(idx, norm2)):
             self._had_subset[i] = h
+
+    def norms_ready(self):
+        """Every tensor's sum of squares was accumulated by this step's gathers."""
+        return len(self._norm_done) == len(self.params)
 
     def rebind_bucket(self, b):
         """rebind_grads for the parameters of bucket b alone (their gradients are final: train.backward_in_phases)."""
@@ -227,10 +273,17 @@ class BertAdam(torch.optim.Optimizer):
         self.step_count += 1
 
     @torch.no_grad()
+    def zero_norms(self):
+        """Zero the per-tensor norm scratch (the head of a step whose gathers accumulate the sums of squares: FlatParams._gather)."""
+        native.check(native.lib().dldkd_zero_scratch_f32(native.ptr(self.norm2), self.norm2.numel(), native.stream()), "zero_scratch")
+
+    @torch.no_grad()
     def enqueue(self, upload_lr=True):
         """Device half: gather the gradients into the flat buffer, upload the staged learning rates (asynchronous copy
         from pinned memory; upload_lr=False: the caller already put them into self.t_lr), one fused multi-tensor update.
-        Enqueue-only, hence capturable into a hipGraph."""
+        Enqueue-only, hence capturable into a hipGraph.  When this step's gathers already accumulated every tensor's sum of
+        squares into self.norm2 (fp.norms_ready()) the update alone is launched."""
+        norms_ready = self.fp.norms_ready()
         had = self.fp.rebind_grads()
         g = self.param_groups[0]
         if upload_lr:
@@ -239,12 +292,13 @@ class BertAdam(torch.optim.Optimizer):
             self.t_active.copy_(torch.tensor(had, dtype=torch.float32))
             self._active_key = had
         L = native.lib()
-        native.check(L.dldkd_bert_adam_step_f32(native.ptr(self.fp.flat), native.ptr(self.fp.grad), native.ptr(self.m),
+        fn, what = (L.dldkd_bert_adam_update_f32, "bert_adam_update") if norms_ready else (L.dldkd_bert_adam_step_f32, "bert_adam_step")
+        native.check(fn(native.ptr(self.fp.flat), native.ptr(self.fp.grad), native.ptr(self.m),
                                                 native.ptr(self.v), native.ptr(self.fp.chunk_tensor), self.fp.n_chunks,
                                                 native.ptr(self.fp.t_start), native.ptr(self.fp.t_numel), len(self.fp.params),
                                                 native.ptr(self.norm2), native.ptr(self.t_wd), native.ptr(self.t_lr),
                                                 native.ptr(self.t_active), g["b1"], g["b2"], g["e"], g["max_grad_norm"],
-                                                native.stream()), "bert_adam_step")
+                                                native.stream()), what)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -201,6 +201,7 @@ class GraphedTrainStep:
 
     QUERY_STREAMS_HIGH_PRIORITY = os.environ.get("DLDKD_QUERY_PRIO", "0") == "1"
     EARLY_VIDEO_START = True        # replay: the video towers start behind the video features' copy, not behind the whole batch's
+    GATHER_WITH_NORMS = True        # one GPU: a tower's gather also accumulates the clip's sums of squares (see _capture_parallel)
     UNIT_BRANCH_GRADS = True        # the branch graphs pass the constant 1 as the terms' upstream gradient (see branch_runner)
     TENSOR_KEYS = ("student_videos", "student_videos_mask", "teacher_videos", "student_text", "student_text_mask", "teacher_text")
 
@@ -597,6 +598,13 @@ class GraphedTrainStep:
         m._tower_runner, m._branch_runner = runner, branch_runner
         try:
             e.par["pre"] = open_graph(self.stream, "main")
+            # the clip's per-tensor sums of squares are accumulated by the towers' gathers (one pass over a tower's gradients on that
+            # tower's stream: FlatParams._gather) into the scratch zeroed here, at the head of the step; the optimizer graph is then
+            # the update alone
+            norm2 = None
+            if self.GATHER_WITH_NORMS and hasattr(opt_, "zero_norms") and opt_.param_groups[0].get("max_grad_norm", -1) > 0:
+                opt_.zero_norms()
+                norm2 = opt_.norm2
             loss, parts, phases = m.forward_phased(e.static, staged=e)
             if any(t is None or id(t) not in stream_of for t, _ in phases) or "tail" not in e.par:
                 raise RuntimeError("parallel tower graphs: a backward phase is not one of the towers")
@@ -612,7 +620,7 @@ class GraphedTrainStep:
                 e.par["bwd"][i] = open_graph(e.par["streams"][i], ("tower", i))
                 if tap_grads.get(i) is not None:
                     torch.autograd.backward([tap], [tap_grads[i]], inputs=list(params))
-                opt_.fp.gather_subset(params)
+                opt_.fp.gather_subset(params, norm2=norm2) if norm2 is not None else opt_.fp.gather_subset(params)
                 close_graph()
             del loss, parts, phases, tap
             stream_of.clear()

@@ -695,6 +695,18 @@ int dldkd_bert_adam_step_f32(float* p, const float* g, float* m, float* v, const
                              const int32_t* t_start, const int32_t* t_numel, int n_tensors, float* norm2_scratch,
                              const float* t_wd, const float* t_lr, const float* t_active, float b1, float b2, float eps,
                              float max_grad_norm, void* stream);
+/* The step in two halves, for a caller whose gradients become final tower by tower (the graphed training step, one graph per tower):
+ * dldkd_gather_sumsq_f32 copies n <= 32 gradient tensors (host arrays: device pointer, flat offset = t_start of the tensor, element
+ * count, tensor index) into the flat gradient buffer and ADDS each one's sum of squares to norm2[tensor] (norm2 zeroed by the caller
+ * once per step, dldkd_zero_scratch_f32; NULL: copy only; src may be the tensor's flat range itself) - one launch per tower, on that
+ * tower's stream; dldkd_bert_adam_update_f32 is then the update alone, reading the finished norm2 (same arguments and arithmetic as
+ * dldkd_bert_adam_step_f32, whose first two launches it leaves out). */
+int dldkd_gather_sumsq_f32(const float* const* host_src, const int* host_start, const int* host_numel, const int* host_tensor, int n,
+                           float* flat_grad, float* norm2, void* stream);
+int dldkd_bert_adam_update_f32(float* p, const float* g, float* m, float* v, const int32_t* chunk_tensor, int n_chunks,
+                               const int32_t* t_start, const int32_t* t_numel, int n_tensors, const float* norm2,
+                               const float* t_wd, const float* t_lr, const float* t_active, float b1, float b2, float eps,
+                               float max_grad_norm, void* stream);
 
 /* counts[q] = #{v < nv : scores[q*ld + v] > thr[q]}: the local half of gather-free sharded ranking (each rank
  * counts the videos of its shard that beat the query's ground-truth score; the counts are all-reduced). */

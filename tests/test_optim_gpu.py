@@ -34,6 +34,68 @@ def test_bert_adam_vs_golden_g6(golden_dir):
     assert opt.get_lr()[0] == pytest.approx(3e-4 * orc.warmup_linear(4, 200, 0.01))
 
 
+def test_bert_adam_split_step_vs_golden_g6(golden_dir):
+    """The step as the graphed trainer runs it - the norm scratch zeroed, the gradients gathered subset by subset with their sums of
+    squares (dldkd_gather_sumsq_f32), then the update alone (dldkd_bert_adam_update_f32) - follows the reference's trajectories like
+    the one-call step; the gathered flat gradients are the sources bit for bit (also from an unaligned source)."""
+    from dldkd_amd.optimization import BertAdam
+    g = np.load(f"{golden_dir}/g6_bert_adam.npz")
+    rs = np.random.RandomState(61)
+    shapes = [(384, 16), (384,), (7,)]
+    names = ["a.weight", "a.bias", "b.LayerNorm.weight"]
+    prm = [torch.nn.Parameter(torch.from_numpy(rs.standard_normal(s).astype(np.float32)).to(DEV)) for s in shapes]
+    groups = [{"params": [prm[0]], "weight_decay": 0.01}, {"params": prm[1:], "weight_decay": 0.0}]
+    opt = BertAdam(groups, lr=3e-4, weight_decay=0.01, warmup=0.01, t_total=200, schedule="warmup_linear")
+    for step in range(4):
+        grads = [torch.from_numpy((rs.standard_normal(s) * (3.0 if step % 2 else 0.01)).astype(np.float32)) for s in shapes]
+        opt.zero_grad()
+        pad = torch.zeros(384 + 1, device=DEV)
+        pad[1:] = grads[1].to(DEV)
+        for q, gr in zip(prm, grads):
+            q.grad = gr.to(DEV)
+        prm[1].grad = pad[1:]                       # a source that is not 16-byte aligned
+        opt.host_prepare()
+        opt.zero_norms()
+        opt.fp.gather_subset([prm[0], prm[2]], norm2=opt.norm2)
+        assert not opt.fp.norms_ready()
+        opt.fp.gather_subset([prm[1]], norm2=opt.norm2)
+        assert opt.fp.norms_ready()
+        for q, gr, v in zip(prm, grads, opt.fp.views()):
+            assert q.grad is v and torch.equal(v.cpu(), gr)
+        n2 = opt.norm2.cpu().numpy()
+        for i, gr in enumerate(grads):
+            assert n2[i] == pytest.approx(float((gr.double() ** 2).sum()), rel=1e-5)
+        opt.enqueue()
+        for i in range(3):
+            ref = g[f"step{step}_{names[i]}"]
+            assert np.abs(prm[i].detach().cpu().numpy() - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (step, i)
+
+
+def test_gather_sumsq_many_tensors_and_sizes():
+    """dldkd_gather_sumsq_f32 over > 32 tensors of awkward sizes (1, 3, 4095, 4096, 4097 ... elements): flat ranges equal the
+    sources, untouched padding stays zero, norms match fp64."""
+    from dldkd_amd.optimization import FlatParams
+    gen = torch.Generator().manual_seed(5)
+    sizes = [1, 3, 4, 255, 256, 257, 4095, 4096, 4097, 12289, 384 * 384] + [5 + 7 * i for i in range(30)]
+    prm = [torch.nn.Parameter(torch.zeros(n, device=DEV)) for n in sizes]
+    fp = FlatParams(prm)
+    fp.drop_grads()
+    grads = [torch.randn(n, generator=gen) for n in sizes]
+    for q, gr in zip(prm, grads):
+        q.grad = gr.to(DEV)
+    norm2 = torch.zeros(len(sizes), device=DEV)
+    fp.gather_subset(prm, norm2=norm2)
+    torch.cuda.synchronize()
+    flat = fp.grad.cpu()
+    covered = torch.zeros(flat.numel(), dtype=torch.bool)
+    for i, gr in enumerate(grads):
+        s0 = fp._starts[i]
+        assert torch.equal(flat[s0:s0 + gr.numel()], gr), i
+        covered[s0:s0 + gr.numel()] = True
+        assert float(norm2[i]) == pytest.approx(float((gr.double() ** 2).sum()), rel=2e-5), i
+    assert not flat[~covered].any()
+
+
 def test_count_above_matches_torch():
     from dldkd_amd import dist as ddist
     g = torch.Generator().manual_seed(1)
