@@ -201,6 +201,8 @@ class GraphedTrainStep:
 
     QUERY_STREAMS_HIGH_PRIORITY = os.environ.get("DLDKD_QUERY_PRIO", "0") == "1"
     EARLY_VIDEO_START = True        # replay: the video towers start behind the video features' copy, not behind the whole batch's
+    BWD_ORDER_REVERSED = os.environ.get("DLDKD_BWD_REV", "0") == "1"
+    LOSS_SUM_IN_OPT_GRAPH = True
     GATHER_WITH_NORMS = True        # one GPU: a tower's gather also accumulates the clip's sums of squares (see _capture_parallel)
     UNIT_BRANCH_GRADS = True        # the branch graphs pass the constant 1 as the terms' upstream gradient (see branch_runner)
     TENSOR_KEYS = ("student_videos", "student_videos_mask", "teacher_videos", "student_text", "student_text_mask", "teacher_text")
@@ -626,6 +628,13 @@ class GraphedTrainStep:
             stream_of.clear()
             tap_grads.clear()
             e.par["opt"] = open_graph(self.stream, "main")
+            # the step's loss value (the sum of the five terms, in the model's order) at the head of the optimizer graph instead of
+            # in a graph of its own between the towers and the optimizer: one graph launch fewer on the serial tail
+            keys = ("inher_trip", "inher_nce", "kl", "explore_trip", "explore_nce")
+            if self.LOSS_SUM_IN_OPT_GRAPH and all(torch.is_tensor(e.parts.get(k)) and e.parts[k].is_cuda and e.parts[k].dim() == 0 for k in keys):
+                with torch.no_grad():
+                    e.loss = F_.sum_scalars(*[e.parts[k] for k in keys]).detach()
+                e.par["tail_kept"], e.par["tail"] = e.par["tail"], None      # (kept alive: its pool holds the branch graphs' tensors)
             e.had = opt_.fp.rebind_grads()
             opt_.enqueue(upload_lr=False)
             close_graph()
@@ -652,25 +661,34 @@ class GraphedTrainStep:
             # C3 2.69 -> 2.63 ms but C5 1.42 -> 1.50 with float(loss) every step, no change without - the host's launch order is
             # then the wrong way round for the short C5 towers - not kept)
             early = self.EARLY_VIDEO_START and par["video"][i] and streams[i] is not main
-            streams[i].wait_event(par["ev_in_video"] if early else par["ev_pre"])
+            if streams[i] is not main:
+                streams[i].wait_event(par["ev_in_video"] if early else par["ev_pre"])
             with torch.cuda.stream(streams[i]):
                 par["fwd"][i].replay()
                 ev["fwd"][i].record(streams[i])
+        # (cross-stream waits only: an event recorded on the waiting stream itself is implied by the stream's order, and every wait
+        # that is enqueued costs the stream ~7 us of barrier processing - the six waits in front of the optimizer graph were
+        # 40 us of the step's serial tail: tools/graph_timeline.py)
         for b, (g, si, towers) in enumerate(par["loss"]):   # a branch's losses + their backward pass to its two tower outputs
-            streams[si].wait_event(par["ev_pre_done"])      # lengths, teacher scores, zero arena
+            if streams[si] is not main:
+                streams[si].wait_event(par["ev_pre_done"])  # lengths, teacher scores, zero arena
             for t in towers:
-                streams[si].wait_event(ev["fwd"][t])
+                if streams[t] is not streams[si]:
+                    streams[si].wait_event(ev["fwd"][t])
             with torch.cuda.stream(streams[si]):
                 g.replay()
                 ev["loss"][b].record(streams[si])
-        for i in par["order"]:                              # (the submission order makes no difference here: measured)
-            streams[i].wait_event(ev["loss"][par["loss_of"][i]])
+        for i in (par["order"][::-1] if self.BWD_ORDER_REVERSED else par["order"]):
+            if streams[par["loss"][par["loss_of"][i]][1]] is not streams[i]:
+                streams[i].wait_event(ev["loss"][par["loss_of"][i]])
             with torch.cuda.stream(streams[i]):
                 par["bwd"][i].replay()
                 ev["bwd"][i].record(streams[i])
-        for x in ev["bwd"] + ev["loss"]:
-            main.wait_event(x)
-        par["tail"].replay()
+        for i, x in enumerate(ev["bwd"]):                   # (a branch's loss graph is followed by a tower's backward graph on its stream)
+            if streams[i] is not main:
+                main.wait_event(x)
+        if par["tail"] is not None:
+            par["tail"].replay()
         par["opt"].replay()
 
     def _replay(self, e, batch):
