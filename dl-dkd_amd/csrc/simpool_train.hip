@@ -67,11 +67,17 @@ struct SimpoolBwdArgs {
 };
 
 // dq: one workgroup per query: 4 groups of 128 threads (x float4 = up to 512 columns) split the 2 nv (+ len) gathered rows
-// between them (every gather is an L2 round trip whose address depends only on the index arrays: four independent chains,
-// each unrolled by 4), then one LDS reduction.
+// between them, then one LDS reduction.  Every gather is an L2 round trip; its address and coefficient come from five index /
+// gradient arrays.  Those are staged FIRST - thread v of the workgroup loads video v's entry (coalesced) and leaves (coefficients,
+// clip indices) in LDS - so that the gather loop has no load in front of its addresses and runs 8 videos = 16 independent row
+// loads deep (round 4: the loop with the index loads inside it, unrolled by 4, took 87 us for 640 queries x 128 videos - 0.25 GB of
+// L2-resident rows - twice the time of everything else in the branch's backward pass).
 constexpr int kDqGroups = 4;
+constexpr int kDqStage = 512;            // videos staged per pass (= the workgroup's threads)
 __global__ __launch_bounds__(128 * kDqGroups) void simpool_bwd_dq_kernel(const SimpoolBwdArgs p) {
     __shared__ float red[kDqGroups][516];
+    __shared__ float st_a[kDqStage], st_b[kDqStage], st_p[kDqStage];
+    __shared__ int st_l[kDqStage];       // l_raw | l_cos << 16
     const int n = blockIdx.x, grp = threadIdx.x >> 7, t = threadIdx.x & 127, c = 4 * t;
     const bool act = c < p.D;
     const float rq = p.rq[n];
@@ -81,16 +87,29 @@ __global__ __launch_bounds__(128 * kDqGroups) void simpool_bwd_dq_kernel(const S
     auto grow = [&](int v, int l) -> f32x4 {
         return act ? *reinterpret_cast<const f32x4*>(p.g + ((size_t)v * p.L + l) * p.D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
-#pragma unroll 4
-    for (int v = grp; v < p.nv; v += kDqGroups) {
-        const bool has = p.lens[v] > 0;                // a video without clips pooled to the constant -1e10: no gradient
-        const float a = (p.d_raw && has) ? p.d_raw[rowq + v] : 0.f;
-        const float b = (p.d_cos && has) ? p.d_cos[rowq + v] : 0.f;
-        const int lr = min(max(p.arg_raw[rowq + v], 0), p.L - 1), lc = min(max(p.arg_cos[rowq + v], 0), p.L - 1);   // never outside the video
-        const f32x4 xr = grow(v, lr), xc = grow(v, lc);
-        acc += a * xr;
-        acc += (b * rq * p.rg[(size_t)v * p.L + lc]) * xc;
-        proj += b * p.pooled_cos[rowq + v];
+    for (int v0 = 0; v0 < p.nv; v0 += kDqStage) {
+        const int nst = min(kDqStage, p.nv - v0);
+        if (v0) __syncthreads();                       // the previous pass has been consumed
+        if ((int)threadIdx.x < nst) {
+            const int v = v0 + threadIdx.x;
+            const bool has = p.lens[v] > 0;            // a video without clips pooled to the constant -1e10: no gradient
+            const float a = (p.d_raw && has) ? p.d_raw[rowq + v] : 0.f;
+            const float b = (p.d_cos && has) ? p.d_cos[rowq + v] : 0.f;
+            const int lr = min(max(p.arg_raw[rowq + v], 0), p.L - 1), lc = min(max(p.arg_cos[rowq + v], 0), p.L - 1);   // never outside the video
+            st_a[threadIdx.x] = a;
+            st_b[threadIdx.x] = b * rq * p.rg[(size_t)v * p.L + lc];
+            st_p[threadIdx.x] = b * p.pooled_cos[rowq + v];
+            st_l[threadIdx.x] = lr | (lc << 16);
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int i = grp; i < nst; i += kDqGroups) {
+            const int lrc = st_l[i];
+            const f32x4 xr = grow(v0 + i, lrc & 0xffff), xc = grow(v0 + i, lrc >> 16);
+            acc += st_a[i] * xr;
+            acc += st_b[i] * xc;
+            proj += st_p[i];
+        }
     }
     if (p.d_clip) {
         const int v = p.labels[n], len = p.lens[v];
