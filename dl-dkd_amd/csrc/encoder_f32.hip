@@ -257,40 +257,72 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
 
 // ----------------------------------------------------------------------------------------------
 // Modular query pooling: logits_l = h_l . w, masked words -> exactly -1e10 (mask_logits, model.py:444),
-// softmax over words, out = sum_l a_l h_l.  One wave per query (L <= 64 words; config max_desc_l = 30).
+// softmax over words, out = sum_l a_l h_l.  One WORKGROUP per query (L <= 64 words; config max_desc_l = 30): wave w takes the
+// words l = w (mod 4) and issues the loads of 8 of them before the first reduction; the weighted sum is one column (+ one of the
+// last 128) per thread over the words in order.  (Round 4: one wave per query walked the words one after the other - a load
+// round trip per word, twice: 30 us for 640 queries, on the query towers' serial chains.  Same per-word dot products, same
+// per-column summation order: the results are bit-identical.)
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void modpool_fwd_kernel(const float* __restrict__ h, const float* __restrict__ mask,
                                                           const float* __restrict__ w, float* __restrict__ out,
                                                           float* __restrict__ attn, int N, int L) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
+    __shared__ float lg[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+    const int n = blockIdx.x;
     const float* hn = h + (size_t)n * L * kHidden;
     float wv[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) wv[j] = w[lane + 64 * j];
-    float my_logit = -INFINITY;   // lane l keeps word l's logit
-    for (int l = 0; l < L; ++l) {
-        float d = 0.f;
+    for (int i0 = 0; wave + 4 * i0 < L; i0 += 8) {
+        float x[8][6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) d += hn[(size_t)l * kHidden + lane + 64 * j] * wv[j];
-        d = wave_sum(d);
-        const float m = mask[(size_t)n * L + l];
-        d = d * m + (1.f - m) * -1e10f;
-        if (lane == l) my_logit = d;
+        for (int i = 0; i < 8; ++i) {
+            const int l = wave + 4 * (i0 + i);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) x[i][j] = l < L ? hn[(size_t)l * kHidden + lane + 64 * j] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int l = wave + 4 * (i0 + i);
+            if (l < L) {                                   // (uniform per wave)
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) d += x[i][j] * wv[j];
+                d = wave_sum(d);
+                const float m = mask[(size_t)n * L + l];
+                d = d * m + (1.f - m) * -1e10f;
+                if (lane == 0) lg[l] = d;
+            }
+        }
     }
+    __syncthreads();
+    const float my_logit = lane < L ? lg[lane] : -INFINITY;   // lane l keeps word l's logit (every wave, redundantly)
     const float mx = wave_max(my_logit);
     const float e = lane < L ? expf(my_logit - mx) : 0.f;
     const float a = e / wave_sum(e);
-    if (attn && lane < L) attn[(size_t)n * L + lane] = a;
-    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int l = 0; l < L; ++l) {
-        const float al = __shfl(a, l);
+    if (attn && wave == 0 && lane < L) attn[(size_t)n * L + lane] = a;
+    const bool two = tid < kHidden - 256;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int l0 = 0; l0 < L; l0 += 8) {                // 8 words' loads in flight (a partial unroll of a loop with a shuffle in it is refused)
+        float x0[8], x1[8];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc[j] += al * hn[(size_t)l * kHidden + lane + 64 * j];
+        for (int i = 0; i < 8; ++i) {
+            const int l = l0 + i;
+            x0[i] = l < L ? hn[(size_t)l * kHidden + tid] : 0.f;
+            x1[i] = (two && l < L) ? hn[(size_t)l * kHidden + 256 + tid] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int l = l0 + i;
+            if (l < L) {
+                const float al = __shfl(a, l);
+                acc0 += al * x0[i];
+                acc1 += al * x1[i];
+            }
+        }
     }
-#pragma unroll
-    for (int j = 0; j < 6; ++j) out[(size_t)n * kHidden + lane + 64 * j] = acc[j];
+    out[(size_t)n * kHidden + tid] = acc0;
+    if (two) out[(size_t)n * kHidden + 256 + tid] = acc1;
 }
 
 }  // namespace dldkd
@@ -383,7 +415,7 @@ int dldkd_modpool_fwd_f32(const float* h, const float* mask, const float* w, flo
     if (N < 0 || L < 1 || L > 64) { set_error("modpool: bad sizes N=%d L=%d (L <= 64)", N, L); return DLDKD_EINVAL; }
     if (N == 0) return DLDKD_OK;
     if (!h || !mask || !w || !out) { set_error("modpool: null pointer"); return DLDKD_EINVAL; }
-    DLDKD_LAUNCH(modpool_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, mask, w, out, attn, N, L);
+    DLDKD_LAUNCH(modpool_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, h, mask, w, out, attn, N, L);
     return check_launch("modpool_fwd");
 }
 

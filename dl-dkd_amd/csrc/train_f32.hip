@@ -297,44 +297,73 @@ __global__ __launch_bounds__(256) void clip_pool_bwd_kernel(const float* __restr
 
 // ---------------------------------------------------------------- modular pooling backward
 // out = sum_l a_l h_l, a = softmax(logit), logit_l = m_l * (h_l . w) + (1 - m_l) * -1e10
+// One workgroup per query, like the forward kernel: da_l = dout . h_l by the wave l (mod 4), 8 words' loads in flight; then one
+// column (+ one of the last 128) per thread over the words in order: dh and the column's part of dw.
 __global__ __launch_bounds__(256) void modpool_bwd_kernel(const float* __restrict__ h, const float* __restrict__ mask,
                                                           const float* __restrict__ w, const float* __restrict__ attn,
                                                           const float* __restrict__ dout, float* __restrict__ dh,
                                                           float* __restrict__ dw, int N, int L) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    float wacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (n < N) {
-        const float* hn = h + (size_t)n * L * kHidden;
-        float* dhn = dh + (size_t)n * L * kHidden;
-        float wv[6], dv[6];
+    __shared__ float da[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+    const int n = blockIdx.x;
+    const float* hn = h + (size_t)n * L * kHidden;
+    float* dhn = dh + (size_t)n * L * kHidden;
+    float dv[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { wv[j] = w[lane + 64 * j]; dv[j] = dout[(size_t)n * kHidden + lane + 64 * j]; }
-        const float a = lane < L ? attn[(size_t)n * L + lane] : 0.f;
-        float my_da = 0.f;   // lane l keeps da_l = dout . h_l
-        for (int l = 0; l < L; ++l) {
-            float d = 0.f;
+    for (int j = 0; j < 6; ++j) dv[j] = dout[(size_t)n * kHidden + lane + 64 * j];
+    for (int i0 = 0; wave + 4 * i0 < L; i0 += 8) {
+        float x[8][6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) d += hn[(size_t)l * kHidden + lane + 64 * j] * dv[j];
-            d = wave_sum(d);
-            if (lane == l) my_da = d;
+        for (int i = 0; i < 8; ++i) {
+            const int l = wave + 4 * (i0 + i);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) x[i][j] = l < L ? hn[(size_t)l * kHidden + lane + 64 * j] : 0.f;
         }
-        const float dot = wave_sum(a * my_da);
-        const float dlogit = a * (my_da - dot) * (lane < L ? mask[(size_t)n * L + lane] : 0.f);
-        for (int l = 0; l < L; ++l) {
-            const float al = __shfl(a, l), dl = __shfl(dlogit, l);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float hv = hn[(size_t)l * kHidden + lane + 64 * j];
-                dhn[(size_t)l * kHidden + lane + 64 * j] = al * dv[j] + dl * wv[j];
-                wacc[j] += dl * hv;
+        for (int i = 0; i < 8; ++i) {
+            const int l = wave + 4 * (i0 + i);
+            if (l < L) {
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) d += x[i][j] * dv[j];
+                d = wave_sum(d);
+                if (lane == 0) da[l] = d;
             }
         }
     }
-    if (n < N) {
+    __syncthreads();
+    const float a = lane < L ? attn[(size_t)n * L + lane] : 0.f;
+    const float my_da = lane < L ? da[lane] : 0.f;     // lane l keeps da_l = dout . h_l
+    const float dot = wave_sum(a * my_da);
+    const float dlogit = a * (my_da - dot) * (lane < L ? mask[(size_t)n * L + lane] : 0.f);
+    const bool two = tid < kHidden - 256;
+    const float d0 = dout[(size_t)n * kHidden + tid], w0 = w[tid];
+    const float d1 = two ? dout[(size_t)n * kHidden + 256 + tid] : 0.f, w1 = two ? w[256 + tid] : 0.f;
+    float wacc0 = 0.f, wacc1 = 0.f;
+    for (int l0 = 0; l0 < L; l0 += 8) {                // 8 words' loads in flight
+        float x0[8], x1[8];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) atomicAdd(dw + lane + 64 * j, wacc[j]);
+        for (int i = 0; i < 8; ++i) {
+            const int l = l0 + i;
+            x0[i] = l < L ? hn[(size_t)l * kHidden + tid] : 0.f;
+            x1[i] = (two && l < L) ? hn[(size_t)l * kHidden + 256 + tid] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int l = l0 + i;
+            if (l < L) {
+                const float al = __shfl(a, l), dl = __shfl(dlogit, l);
+                dhn[(size_t)l * kHidden + tid] = al * d0 + dl * w0;
+                wacc0 += dl * x0[i];
+                if (two) {
+                    dhn[(size_t)l * kHidden + 256 + tid] = al * d1 + dl * w1;
+                    wacc1 += dl * x1[i];
+                }
+            }
+        }
     }
+    atomicAdd(dw + tid, wacc0);
+    if (two) atomicAdd(dw + 256 + tid, wacc1);
 }
 
 }  // namespace dldkd
@@ -469,7 +498,7 @@ int dldkd_modpool_bwd_f32(const float* h, const float* mask, const float* w, con
                           float* dw, int N, int L, void* stream) {
     if (N < 0 || L < 1 || L > 64) { set_error("modpool_bwd: bad sizes"); return DLDKD_EINVAL; }
     if (N == 0) return DLDKD_OK;
-    LAUNCH1D(modpool_bwd_kernel, N, 4, h, mask, w, attn, dout, dh, dw, N, L);
+    LAUNCH1D(modpool_bwd_kernel, N, 1, h, mask, w, attn, dout, dh, dw, N, L);
     return check_launch("modpool_bwd");
 }
 
