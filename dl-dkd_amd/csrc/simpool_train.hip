@@ -244,6 +244,9 @@ __global__ __launch_bounds__(kDgThreads) void simpool_bwd_dg_kernel(const Simpoo
         rowproj[tid] = pr;
     }
     __syncthreads();
+#if defined(DG_ABLATE) && DG_ABLATE == 1       // (measurement only: the set-up phases without the gather)
+    return;
+#endif
     const int c = c0 + 2 * lane;
     if (c >= p.D) return;
     const int np = pos[nq];
