@@ -245,6 +245,90 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt16_kernel(const Args16 p) 
     gemm_store_tile(acc, p, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem) + wave * (32 * 72));
 }
 
+// Training simpool with bf16 operands (the queries and the gallery clips cast once by dldkd_row_invnorm2_cast_f32, the pass that
+// reads every row for its norm anyway): S_v = G_v Q^T, one video per blockIdx.z on the tile rows (L <= 128 clips), 128 queries on the
+// columns, the key-clip max-pool epilogue of gemm_pool_tile instead of a store.  Same DMA tiles and fragments as the kernel above;
+// row tiles past the video's LENGTH are neither loaded nor multiplied (their clips are masked in the epilogue).  Replaces the
+// register-staged fp32-operand kernel (gemm_bf16_pool_kernel: 93 us for 8 GFLOP at the TVR batch, converting both operands on
+// their way to LDS 32 k at a time).
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt16_pool_kernel(const Args16 p, const PoolArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int v = blockIdx.z, n0 = blockIdx.x * BN;
+    const int nk = p.K / BK16;
+    const int len = min(pa.lens[v], p.M);
+    const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
+    uint32_t voa[4], vob[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = 8 * (4 * wave + q) + (lane >> 3);
+        const int ch = ((lane & 7) ^ ((row >> 1) & 7)) << 4;
+        const int ra = min(row, p.M - 1), rb = min(n0 + row, p.N - 1) - n0;
+        voa[q] = (uint32_t)(ra * p.lda * 2 + ch);
+        vob[q] = (uint32_t)(rb * p.ldb * 2 + ch);
+    }
+    const char* abase = reinterpret_cast<const char*>(p.A + (size_t)v * p.M * p.lda);
+    const char* bbase = reinterpret_cast<const char*>(p.B + (size_t)n0 * p.ldb);
+    const int tiles = (len + 31) >> 5;
+    const unsigned pm = __builtin_amdgcn_readfirstlane(tiles >= 4 ? 0xFu : ((1u << tiles) - 1u));
+    const bool load_a = ((pm >> wave) & 1u) != 0;
+    const bool rt_ok[2] = {((pm >> (wm / 32)) & 1u) != 0, ((pm >> (wm / 32 + 1)) & 1u) != 0};
+    auto issue = [&](int kt, int stage) {
+        const char* as = abase + (size_t)kt * (BK16 * 2);
+        const char* bs = bbase + (size_t)kt * (BK16 * 2);
+        const uint32_t dst = smem_lds + stage * STAGE_B + (4 * wave) * 1024;
+        if (load_a) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) glds16_s(voa[q], as, dst + q * 1024);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16_s(vob[q], bs, dst + TILE_B + q * 1024);
+    };
+    int fo[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int r = lane & 31, c = 2 * kk + (lane >> 5);
+        fo[kk] = r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (pm != 0u) {                                   // (a video without clips: nothing to multiply, the epilogue writes the constants)
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int st = kt & 1;
+            if (kt + 1 < nk) issue(kt + 1, st ^ 1);
+            const char* As = smem + st * STAGE_B + wm * 128;
+            const char* Bs = smem + st * STAGE_B + TILE_B + wn * 128;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 4096 + fo[kk]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (!rt_ok[i]) continue;
+                    a[i] = *reinterpret_cast<const bf16x8*>(As + i * 4096 + fo[kk]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    gemm_pool_tile(acc, p, pa, v, n0, wm, wn, lane, wave, reinterpret_cast<float*>(smem));
+}
+
 // x (n) fp32 -> bf16 (round to nearest even): the weight operand of gemm_bf16_nt16, once per optimizer step
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n4) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -292,6 +376,22 @@ extern "C" int dldkd_gemm_bf16_nt16(const void* A, const void* B, const float* b
     DLDKD_LAUNCH(gdma::gemm_bf16_nt16_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("gemm_bf16_nt16");
 }
+
+// g16 (nv, L, D) / q16 (nq, D) bf16 -> the PoolArgs outputs (simpool_train.hip: dldkd_simpool_train_fwd_bf16in)
+namespace dldkd {
+int launch_simpool_pool_bf16_dma(const void* g16, const void* q16, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream) {
+    if (L < 1 || L > gdma::BM || !dldkd_gemm_bf16_nt16_ok(L, nq, D, D, D) || (((uintptr_t)g16 | (uintptr_t)q16) & 15)) {
+        set_error("simpool_train_fwd_bf16in: needs L <= 128, D %% 64 == 0 and 16-byte aligned operands (L=%d nq=%d D=%d)", L, nq, D);
+        return DLDKD_EINVAL;
+    }
+    gdma::Args16 p{(const unsigned short*)g16, (const unsigned short*)q16, nullptr, nullptr, L, nq, D, D, D, nq, 0, 1.0f, nullptr};
+    constexpr int lds = gdma::NST * gdma::STAGE_B;
+    static const bool ok = hipFuncSetAttribute((const void*)gdma::gemm_bf16_nt16_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    (void)ok;
+    DLDKD_LAUNCH(gdma::gemm_bf16_nt16_pool_kernel, dim3((nq + gdma::BN - 1) / gdma::BN, 1, nv), dim3(256), lds, (hipStream_t)stream, p, pa);
+    return check_launch("simpool_train_fwd (bf16 operands)");
+}
+}  // namespace dldkd
 
 extern "C" int dldkd_gemm_bf16_nt_ok(int M, int N, int K, int lda, int ldb) {
     return M > 0 && N > 0 && K >= gdma::BK && (K % gdma::BK) == 0 && !(lda & 3) && !(ldb & 3) &&

@@ -794,6 +794,9 @@ def clip_pool(S, lens):
     return _ClipPool.apply(_f32(S), lens)
 
 
+SIMPOOL_TRAIN_BF16_OPERANDS = os.environ.get("DLDKD_SIMPOOL_BF16_OPERANDS", "1") == "1"
+
+
 class _SimPoolTrain(Function):
     """Fused training simpool (simpool_train.hip): (pooled cosine, pooled raw, positive-column clip cosines) of one
     (query set, gallery) pair from one MFMA GEMM with a pooling epilogue; backward = two gather kernels."""
@@ -805,15 +808,25 @@ class _SimPoolTrain(Function):
         dev = q.device
         rq = torch.empty(Nq, dtype=torch.float32, device=dev)
         rg = torch.empty(Nv * L, dtype=torch.float32, device=dev)
-        native.check(_L().dldkd_row_invnorm2_f32(_p(q), _p(rq), Nq, _p(g), _p(rg), Nv * L, D, _s()), "row_invnorm2")
         pc = torch.empty(Nq, Nv, dtype=torch.float32, device=dev)
         pr = torch.empty(Nq, Nv, dtype=torch.float32, device=dev)
         ac = torch.empty(Nq, Nv, dtype=torch.int32, device=dev)
         ar = torch.empty(Nq, Nv, dtype=torch.int32, device=dev)
         clip = torch.empty(Nq, L, dtype=torch.float32, device=dev) if want_clip else None
-        native.check(_L().dldkd_simpool_train_fwd_f32(ops._PREC_ID[ops.gemm_precision()], _p(q), _p(g), _p(rq), _p(rg), _p(lens),
-                                                      _p(labels), Nq, Nv, L, D, _p(pc), _p(pr), _p(ac), _p(ar), _p(clip), _s()),
-                     "simpool_train_fwd")
+        if SIMPOOL_TRAIN_BF16_OPERANDS and ops.gemm_precision() == "bf16" and D % 64 == 0 and L <= 128:
+            # throughput mode: the norm pass (which reads every row anyway) leaves the two operands as bf16 rows and the pooled GEMM
+            # takes its tiles from those by LDS-DMA (gemm_bf16_nt16_pool_kernel); the backward gathers keep reading the fp32 rows
+            q16 = torch.empty(Nq, D, dtype=torch.bfloat16, device=dev)
+            g16 = torch.empty(Nv * L, D, dtype=torch.bfloat16, device=dev)
+            native.check(_L().dldkd_row_invnorm2_cast_f32(_p(q), _p(rq), _p(q16), Nq, _p(g), _p(rg), _p(g16), Nv * L, D, _s()),
+                         "row_invnorm2_cast")
+            native.check(_L().dldkd_simpool_train_fwd_bf16in(_p(q16), _p(g16), _p(rq), _p(rg), _p(lens), _p(labels), Nq, Nv, L, D, _p(pc),
+                                                             _p(pr), _p(ac), _p(ar), _p(clip), _s()), "simpool_train_fwd_bf16in")
+        else:
+            native.check(_L().dldkd_row_invnorm2_f32(_p(q), _p(rq), Nq, _p(g), _p(rg), Nv * L, D, _s()), "row_invnorm2")
+            native.check(_L().dldkd_simpool_train_fwd_f32(ops._PREC_ID[ops.gemm_precision()], _p(q), _p(g), _p(rq), _p(rg), _p(lens),
+                                                          _p(labels), Nq, Nv, L, D, _p(pc), _p(pr), _p(ac), _p(ar), _p(clip), _s()),
+                         "simpool_train_fwd")
         ctx.save_for_backward(q, g, rq, rg, lens, labels, ac, ar, pc, clip)
         ctx.mark_non_differentiable(ac, ar)
         ctx.set_materialize_grads(False)       # unused outputs (the arg-max planes, a clip row nobody reads) arrive as None in backward

@@ -135,6 +135,9 @@ SIGNATURES = {
                                                  ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p]),
     "dldkd_row_invnorm_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
     "dldkd_row_invnorm2_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
+    "dldkd_row_invnorm2_cast_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
+                                             _c_void_p]),
+    "dldkd_simpool_train_fwd_bf16in": (_c_int, [_c_void_p] * 6 + [_c_int] * 4 + [_c_void_p] * 6),
     "dldkd_simpool_train_fwd_f32": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
                                               _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_simpool_train_bwd_f32": (_c_int, [_c_void_p] * 13 + [_c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),

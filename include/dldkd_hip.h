@@ -601,6 +601,15 @@ int dldkd_colsum_bf16(const void* x, int ld, int c0, int N, long M, const unsign
 int dldkd_row_invnorm_f32(const float* x, float* inv, long M, int D, void* stream);
 /* The same for the two operands of one scored pair (x0: M0 rows, x1: M1 rows, both D wide) in ONE launch. */
 int dldkd_row_invnorm2_f32(const float* x0, float* inv0, long M0, const float* x1, float* inv1, long M1, int D, void* stream);
+/* ... which also writes both operands as bf16 rows (round to nearest even; y0 (M0, D), y1 (M1, D)), and the pooled forward product
+ * over those: the outputs of dldkd_simpool_train_fwd_f32(DLDKD_GEMM_BF16) from bf16 operands by LDS-DMA tiles (L <= 128, D % 64 ==
+ * 0, 16-byte aligned operands; row tiles past a video's length are neither loaded nor multiplied).  The operands are rounded
+ * exactly as the fp32-operand kernel rounds them on their way to LDS; the products differ in summation order only. */
+int dldkd_row_invnorm2_cast_f32(const float* x0, float* inv0, void* y0_bf16, long M0, const float* x1, float* inv1, void* y1_bf16, long M1,
+                                int D, void* stream);
+int dldkd_simpool_train_fwd_bf16in(const void* q_bf16, const void* g_bf16, const float* rq, const float* rg, const int32_t* lens,
+                                   const int32_t* labels, int nq, int nv, int L, int D, float* pooled_cos, float* pooled_raw,
+                                   int32_t* arg_cos, int32_t* arg_raw, float* clip_pos, void* stream);
 int dldkd_simpool_train_fwd_f32(int precision, const float* q, const float* g, const float* rq, const float* rg,
                                 const int32_t* lens, const int32_t* labels, int nq, int nv, int L, int D, float* pooled_cos,
                                 float* pooled_raw, int32_t* arg_cos, int32_t* arg_raw, float* clip_pos, void* stream);

@@ -478,3 +478,40 @@ def test_row_group_flags_are_the_or_over_the_32_rows_of_a_group(bf16_mode):
     got = z.float().cpu()
     assert torch.equal(got[mask == 0], torch.zeros_like(got[mask == 0]))
     assert (got[mask > 0] - ref[mask > 0]).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("nq,nv,L,D", [(640, 128, 128, 384), (257, 128, 64, 384), (70, 5, 33, 128)])
+def test_pooled_forward_from_bf16_operands_matches_the_fp32_operand_kernel(nq, nv, L, D):
+    """gemm_bf16_nt16_pool_kernel (bf16 rows cast by the norm pass, LDS-DMA tiles, row tiles past a video's length skipped) against
+    gemm_bf16_pool_kernel (fp32 rows rounded on their way to LDS): the same rounded operands, so the pooled maxima agree to fp32
+    summation order, the arg-max clips agree except at such near-ties, and masked / empty videos give the same constants."""
+    from dldkd_amd import functional as F_
+    from dldkd_amd import ops
+    gen = torch.Generator().manual_seed(nq + L)
+    q = torch.randn(nq, D, generator=gen).to(DEV)
+    g = torch.randn(nv, L, D, generator=gen).to(DEV)
+    lens = torch.randint(1, L + 1, (nv,), generator=gen)
+    lens[1] = 0
+    lens[2] = L
+    labels = torch.randint(0, nv, (nq,), generator=gen)
+    labels[labels == 1] = 0
+    lens_d, labels_d = lens.to(DEV).int(), labels.to(DEV).int()
+    ops.set_gemm_precision("bf16")
+    old = F_.SIMPOOL_TRAIN_BF16_OPERANDS
+    try:
+        F_.SIMPOOL_TRAIN_BF16_OPERANDS = True
+        new = F_._SimPoolTrain.apply(q, g, lens_d, labels_d, True)
+        F_.SIMPOOL_TRAIN_BF16_OPERANDS = False
+        ref = F_._SimPoolTrain.apply(q, g, lens_d, labels_d, True)
+    finally:
+        F_.SIMPOOL_TRAIN_BF16_OPERANDS = old
+        ops.set_gemm_precision("fp32")
+    pc, pr, ac, ar, clip = [t.cpu() for t in new]
+    pc0, pr0, ac0, ar0, clip0 = [t.cpu() for t in ref]
+    scale = float(pr0[:, lens > 0].abs().max())
+    assert float((pr - pr0).abs().max()) <= 2e-5 * scale
+    assert float((pc - pc0).abs().max()) <= 2e-5
+    assert float((clip - clip0).abs().max()) <= 2e-5
+    assert bool((pr[:, 1] == -1e10).all()) and bool((pc[:, 1] == -1e10).all())
+    assert float((ar != ar0).float().mean()) < 1e-3 and float((ac != ac0).float().mean()) < 1e-3
+    assert bool((ar < lens.clamp(min=1)[None]).all()) and bool((ac < lens.clamp(min=1)[None]).all())
