@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (i >= n4) return;
     const f32x4* w = reinterpret_cast<const f32x4*>(ws) + i;
     f32x4 a = w[0];
+#pragma unroll 8
     for (int z = 1; z < split; ++z) { const f32x4 b = w[(size_t)z * stride4]; a += b; }
     reinterpret_cast<f32x4*>(out)[i] = a;
 }

@@ -411,30 +411,43 @@ struct InprojFinishArgs {
     float* db;                   // [K]                                      sum_n W H  (unscaled)
     int split, N, K;
 };
-// grid (K / 1024, N / 4): thread = FOUR consecutive columns (16-byte accesses: the first version read 4 bytes per load and ran at
-// 1.6 TB/s), 4 rows n: reduces the split planes, writes dW, accumulates the two dot products
+// grid (K / 256, N / 16): a workgroup = 256 columns x 16 rows n; lane = FOUR consecutive columns (16-byte accesses: the first version
+// read 4 bytes per load and ran at 1.6 TB/s), wave w = rows 4 w .. 4 w + 3 of the 16: reduces the split planes, writes dW,
+// accumulates the two dot products, which the four waves combine in LDS - ONE atomic per column and workgroup (the version with a
+// workgroup per 4 rows issued 96 same-address atomics per column: 590 k of them at the TVR projection, most of its 26 us).
 __global__ __launch_bounds__(256) void inproj_bwd_reduce_kernel(const InprojFinishArgs a) {
-    const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (k >= a.K) return;
+    __shared__ f32x4 red[2][3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = (blockIdx.x * 64 + lane) * 4;
+    const bool act = k < a.K;
     const size_t plane = (size_t)a.N * a.K;
     f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
-    const int n_hi = min(a.N, (int)(blockIdx.y + 1) * 4);
-    for (int n = blockIdx.y * 4; n < n_hi; ++n) {
-        const size_t at = (size_t)n * a.K + k;
-        f32x4 dw = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < a.split; ++s) {
-            dw += *reinterpret_cast<const f32x4*>(a.part + (size_t)s * 2 * plane + at);
-            h += *reinterpret_cast<const f32x4*>(a.part + (size_t)s * 2 * plane + plane + at);
+    const int n_lo = blockIdx.y * 16 + wave * 4, n_hi = min(a.N, n_lo + 4);
+    if (act) {
+        for (int n = n_lo; n < n_hi; ++n) {
+            const size_t at = (size_t)n * a.K + k;
+            f32x4 dw = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int s = 0; s < a.split; ++s) {
+                dw += *reinterpret_cast<const f32x4*>(a.part + (size_t)s * 2 * plane + at);
+                h += *reinterpret_cast<const f32x4*>(a.part + (size_t)s * 2 * plane + plane + at);
+            }
+            *reinterpret_cast<f32x4*>(a.dW + at) = dw;
+            const f32x4 w = *reinterpret_cast<const f32x4*>(a.W + at);
+            sg += w * dw;
+            sb += w * h;
         }
-        *reinterpret_cast<f32x4*>(a.dW + at) = dw;
-        const f32x4 w = *reinterpret_cast<const f32x4*>(a.W + at);
-        sg += w * dw;
-        sb += w * h;
     }
+    if (wave > 0) { red[0][wave - 1][lane] = sg; red[1][wave - 1][lane] = sb; }
+    __syncthreads();
+    if (wave == 0 && act) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        atomicAdd(a.dg + k + e, sg[e]);
-        atomicAdd(a.db + k + e, sb[e]);
+        for (int w = 0; w < 3; ++w) { sg += red[0][w][lane]; sb += red[1][w][lane]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(a.dg + k + e, sg[e]);
+            atomicAdd(a.db + k + e, sb[e]);
+        }
     }
 }
 struct InprojFinalArgs {
@@ -674,6 +687,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_colsum_kernel(const float* 
         if (i >= n4) return;
         const f32x4* w = reinterpret_cast<const f32x4*>(ws) + i;
         f32x4 a = w[0];
+#pragma unroll 8
         for (int z = 1; z < split; ++z) { const f32x4 b = w[(size_t)z * n4]; a += b; }
         reinterpret_cast<f32x4*>(out)[i] = a;
         return;
@@ -802,7 +816,7 @@ extern "C" int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const 
     int rc = check_launch("inproj_bwd (dual dW)");
     if (rc != DLDKD_OK) return rc;
     const InprojFinishArgs f{(const float*)workspace, W, dW, dgamma, dbeta, split, N, K};
-    DLDKD_LAUNCH(inproj_bwd_reduce_kernel, dim3((K + 1023) / 1024, (N + 3) / 4), dim3(256), 0, s, f);
+    DLDKD_LAUNCH(inproj_bwd_reduce_kernel, dim3((K + 255) / 256, (N + 15) / 16), dim3(256), 0, s, f);
     rc = check_launch("inproj_bwd (reduce)");
     if (rc != DLDKD_OK) return rc;
     const InprojFinalArgs g{dgamma, dbeta, gamma, beta, keep_scale, K, dy, W, x, keep, mean, rstd, M, N};
