@@ -297,20 +297,28 @@ __global__ __launch_bounds__(256) void clip_pool_bwd_kernel(const float* __restr
 
 // ---------------------------------------------------------------- modular pooling backward
 // out = sum_l a_l h_l, a = softmax(logit), logit_l = m_l * (h_l . w) + (1 - m_l) * -1e10
-// One workgroup per query, like the forward kernel: da_l = dout . h_l by the wave l (mod 4), 8 words' loads in flight; then one
-// column (+ one of the last 128) per thread over the words in order: dh and the column's part of dw.
-__global__ __launch_bounds__(256) void modpool_bwd_kernel(const float* __restrict__ h, const float* __restrict__ mask,
-                                                          const float* __restrict__ w, const float* __restrict__ attn,
-                                                          const float* __restrict__ dout, float* __restrict__ dh,
-                                                          float* __restrict__ dw, int N, int L) {
-    __shared__ float da[64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
-    const int n = blockIdx.x;
-    const float* hn = h + (size_t)n * L * kHidden;
-    float* dhn = dh + (size_t)n * L * kHidden;
+// One 256-thread group per query, like the forward kernel - da_l = dout . h_l by the group's wave l (mod 4), 8 words' loads in
+// flight; then one column (+ one of the last 128) per thread over the words in order: dh and the column's part of dw - and FOUR
+// groups per workgroup, which add their dw parts in LDS: one atomic per column and four queries (640 queries hitting the same 384
+// addresses was most of this kernel's time).
+constexpr int kModGroups = 4;
+__global__ __launch_bounds__(256 * kModGroups) void modpool_bwd_kernel(const float* __restrict__ h, const float* __restrict__ mask,
+                                                                       const float* __restrict__ w, const float* __restrict__ attn,
+                                                                       const float* __restrict__ dout, float* __restrict__ dh,
+                                                                       float* __restrict__ dw, int N, int L) {
+    __shared__ float da_s[kModGroups][64];
+    __shared__ float wred[kModGroups - 1][kHidden];
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x * kModGroups + grp;
+    const bool valid = n < N;
+    const int nn = valid ? n : N - 1;                      // (a group past the last query reads the last one and writes nothing)
+    float* da = da_s[grp];
+    const float* hn = h + (size_t)nn * L * kHidden;
+    float* dhn = dh + (size_t)nn * L * kHidden;
     float dv[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) dv[j] = dout[(size_t)n * kHidden + lane + 64 * j];
+    for (int j = 0; j < 6; ++j) dv[j] = dout[(size_t)nn * kHidden + lane + 64 * j];
     for (int i0 = 0; wave + 4 * i0 < L; i0 += 8) {
         float x[8][6];
 #pragma unroll
@@ -332,13 +340,13 @@ __global__ __launch_bounds__(256) void modpool_bwd_kernel(const float* __restric
         }
     }
     __syncthreads();
-    const float a = lane < L ? attn[(size_t)n * L + lane] : 0.f;
+    const float a = lane < L ? attn[(size_t)nn * L + lane] : 0.f;
     const float my_da = lane < L ? da[lane] : 0.f;     // lane l keeps da_l = dout . h_l
     const float dot = wave_sum(a * my_da);
-    const float dlogit = a * (my_da - dot) * (lane < L ? mask[(size_t)n * L + lane] : 0.f);
+    const float dlogit = a * (my_da - dot) * (lane < L ? mask[(size_t)nn * L + lane] : 0.f);
     const bool two = tid < kHidden - 256;
-    const float d0 = dout[(size_t)n * kHidden + tid], w0 = w[tid];
-    const float d1 = two ? dout[(size_t)n * kHidden + 256 + tid] : 0.f, w1 = two ? w[256 + tid] : 0.f;
+    const float d0 = dout[(size_t)nn * kHidden + tid], w0 = w[tid];
+    const float d1 = two ? dout[(size_t)nn * kHidden + 256 + tid] : 0.f, w1 = two ? w[256 + tid] : 0.f;
     float wacc0 = 0.f, wacc1 = 0.f;
     for (int l0 = 0; l0 < L; l0 += 8) {                // 8 words' loads in flight
         float x0[8], x1[8];
@@ -353,17 +361,30 @@ __global__ __launch_bounds__(256) void modpool_bwd_kernel(const float* __restric
             const int l = l0 + i;
             if (l < L) {
                 const float al = __shfl(a, l), dl = __shfl(dlogit, l);
-                dhn[(size_t)l * kHidden + tid] = al * d0 + dl * w0;
+                if (valid) dhn[(size_t)l * kHidden + tid] = al * d0 + dl * w0;
                 wacc0 += dl * x0[i];
                 if (two) {
-                    dhn[(size_t)l * kHidden + 256 + tid] = al * d1 + dl * w1;
+                    if (valid) dhn[(size_t)l * kHidden + 256 + tid] = al * d1 + dl * w1;
                     wacc1 += dl * x1[i];
                 }
             }
         }
     }
-    atomicAdd(dw + tid, wacc0);
-    if (two) atomicAdd(dw + 256 + tid, wacc1);
+    if (!valid) { wacc0 = 0.f; wacc1 = 0.f; }
+    if (grp > 0) {
+        wred[grp - 1][tid] = wacc0;
+        if (two) wred[grp - 1][256 + tid] = wacc1;
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int g = 0; g < kModGroups - 1; ++g) {
+            wacc0 += wred[g][tid];
+            if (two) wacc1 += wred[g][256 + tid];
+        }
+        atomicAdd(dw + tid, wacc0);
+        if (two) atomicAdd(dw + 256 + tid, wacc1);
+    }
 }
 
 }  // namespace dldkd
@@ -498,7 +519,8 @@ int dldkd_modpool_bwd_f32(const float* h, const float* mask, const float* w, con
                           float* dw, int N, int L, void* stream) {
     if (N < 0 || L < 1 || L > 64) { set_error("modpool_bwd: bad sizes"); return DLDKD_EINVAL; }
     if (N == 0) return DLDKD_OK;
-    LAUNCH1D(modpool_bwd_kernel, N, 1, h, mask, w, attn, dout, dh, dw, N, L);
+    DLDKD_LAUNCH(modpool_bwd_kernel, dim3((unsigned)((N + kModGroups - 1) / kModGroups)), dim3(256 * kModGroups), 0, (hipStream_t)stream, h, mask, w, attn, dout, dh,
+                 dw, N, L);
     return check_launch("modpool_bwd");
 }
 
