@@ -61,7 +61,7 @@ def synth_videos(dev, cfg, v_lo, v_hi):
     return gs, lens
 
 
-def synth_shard(dev, cfg, v_lo, v_hi, world=1, dist=None):
+def synth_shard(dev, cfg, v_lo, v_hi, world=1, comm=None):
     """Gallery shard [v_lo, v_hi) + the queries, IDENTICAL on every rank: query q is planted on a valid clip of video q mod nv;
     the rank that holds that video contributes the clip, the others zeros, and one all-reduce(SUM) at setup gives every rank the
     same query set (each ground-truth video is local to exactly one rank)."""
@@ -79,7 +79,7 @@ def synth_shard(dev, cfg, v_lo, v_hi, world=1, dist=None):
         base = torch.zeros(nq, D, device=dev)
         base[local] = gs[b][(gt[local] - v_lo), lstar[local]]
         if world > 1:
-            dist.all_reduce(base, op=dist.ReduceOp.SUM)
+            comm.all_reduce(base, "sum")
         qs.append(base + cfg["sigma"][b] * noise)
     return gs, mask, lens, qs, gt
 
@@ -400,16 +400,17 @@ def mfma_sustained():
         return None
 
 
-def run_sharded(cfg, dev, rank, world, dist, steps, warmup):
+def run_sharded(cfg, dev, rank, world, comm, steps, warmup):
     """One workload through dist.OverlappedShardScorer (what --gpus N runs): the gallery cut by video, ONE scorer launch per
-    step whose query ranges complete in order, per-range finish + RCCL all_gather on a side stream.  Runs on every rank;
+    step whose query ranges complete in order, per-range finish on a side stream + RCCL all_gather (comm.RcclComm: one enqueue per
+    range on the collectives' stream).  Runs on every rank;
     returns the measurements (rank 0 adds the self-checks: recalls of the ASSEMBLED matrix and a sampled recompute)."""
     from dldkd_amd import dist as ddist
     from dldkd_amd import scoring
     nq, nv = cfg["nq"], cfg["nv"]
     shard = (nv + world - 1) // world
     v_lo, v_hi = min(rank * shard, nv), min((rank + 1) * shard, nv)
-    gs, mask, lens, qs, gt = synth_shard(dev, cfg, v_lo, v_hi, world, dist)
+    gs, mask, lens, qs, gt = synth_shard(dev, cfg, v_lo, v_hi, world, comm)
     n_loc = v_hi - v_lo
     if n_loc < shard:   # pad the last shard with 1-clip zero videos so all_gather blocks are equal
         pad = shard - n_loc
@@ -424,12 +425,12 @@ def run_sharded(cfg, dev, rank, world, dist, steps, warmup):
     # >= 4 ranges so that the all-gather of range r (RCCL stream, parked on the range's arrival counter) runs under the
     # scoring of ranges r+1..; the split is the kernel's own (HipShardBackend asks the library's planner)
     backend = ddist.HipShardBackend(qs, pg, min_ranges=4, w=W_FUSE)
-    overlap = ddist.OverlappedShardScorer(backend, backend.bounds, shard, dev)
+    overlap = ddist.OverlappedShardScorer(backend, backend.bounds, shard, dev, comm=comm)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
     def fence():
         torch.cuda.synchronize()
-        dist.barrier()
+        comm.barrier()
         torch.cuda.synchronize()
     for _ in range(warmup):
         overlap.step()
@@ -441,9 +442,7 @@ def run_sharded(cfg, dev, rank, world, dist, steps, warmup):
         ev[i][1].record()
     fence()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = t.item()
+    dt = comm.max_over_ranks(dt, dev)
     res = {"ms_per_step": dt / steps * 1e3, "value": nq * nv * steps / dt, "step_stream_ms": sum(s_.elapsed_time(e) for s_, e in ev) / steps,
            "n_ranges": len(overlap.bounds), "shard_videos": shard, "gallery_pack_ms_untimed": round(pack_ms, 2),
            "flops_per_step_all_ranks": 2.0 * D * NB * nq * float(_lens_all(cfg).sum().item())}
@@ -483,17 +482,17 @@ def c5_rank_batch(rank, device="cpu"):
     return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()}
 
 
-def replicas_max_abs_diff(flat, dist, group=None):
+def replicas_max_abs_diff(flat, comm):
     """max over ranks and elements of |this rank's parameters - rank 0's|: 0.0 iff the replicas are identical (all-reduce MAX, so
-    every rank returns the same number).  Works on CPU tensors over gloo (tests) and on GPU tensors over RCCL."""
+    every rank returns the same number).  `comm`: a dldkd_amd.comm communicator (gloo group in the CPU tests, RCCL on the GPU)."""
     ref = flat.detach().clone()
-    dist.broadcast(ref, src=0, group=group)
+    comm.broadcast(ref, src=0)
     d = (flat.detach() - ref).abs().max().reshape(1).to(torch.float64)
-    dist.all_reduce(d, op=dist.ReduceOp.MAX, group=group)
+    comm.all_reduce(d, "max")
     return float(d.item())
 
 
-def run_c5_ddp(dev, rank, world, dist, steps, warmup):
+def run_c5_ddp(dev, rank, world, comm, steps, warmup):
     """BASELINE configs[4]: the Charades-STA training step, data parallel over the ranks (method/train.py:147-151 under DDP): every
     rank steps on ITS batch, the flat gradient buffer is mean-all-reduced over RCCL, the fused BertAdam update follows - replayed by
     train.GraphedTrainStep exactly as train() runs it.  Measured per gradient layout (one bucket = the default; tower buckets =
@@ -514,7 +513,7 @@ def run_c5_ddp(dev, rank, world, dist, steps, warmup):
 
     def fence():
         torch.cuda.synchronize()
-        dist.barrier()
+        comm.barrier()
         torch.cuda.synchronize()
 
     def timed(stepper):
@@ -525,9 +524,7 @@ def run_c5_ddp(dev, rank, world, dist, steps, warmup):
         for _ in range(steps):
             stepper(batch)
         fence()
-        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return t.item() / steps * 1e3
+        return comm.max_over_ranks(time.perf_counter() - t0, dev) / steps * 1e3
 
     ops.set_gemm_precision("bf16")
     old_min = T.DDP_MIN_WORLD
@@ -543,7 +540,7 @@ def run_c5_ddp(dev, rank, world, dist, steps, warmup):
             ddist.broadcast_parameters(optim.fp)
             T.seed_rank(topt, rank)                         # dropout masks / triplet negatives differ between the replicas
             ddp_ms = timed(T.GraphedTrainStep(m, optim, topt, defer_loss_float=True))
-            diff = replicas_max_abs_diff(optim.fp.flat, dist)
+            diff = replicas_max_abs_diff(optim.fp.flat, comm)
             # the same replayed step without the collective (the data-parallel branch switched off): what the all-reduce costs on top
             T.DDP_MIN_WORLD = world + 1
             local_ms = timed(T.GraphedTrainStep(m, optim, topt, defer_loss_float=True))
@@ -577,33 +574,25 @@ def main():
             raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N (one rank per GPU)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    dist = None
+    comm = None
     force_dist = os.environ.get("DLDKD_BENCH_FORCE_DIST") == "1"     # test hook: distributed code path with one rank
     if world > 1 or force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # RCCL kernels need CUs too, and the scorer parks a 512-register wave on every SIMD: give the collective's
-        # stream high priority so its workgroups are dispatched first whenever a scorer workgroup retires
-        try:
-            pg_opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-            dist.init_process_group("nccl", device_id=dev, pg_options=pg_opts)
-        except Exception:   # noqa: BLE001  (older/newer torch without this option)
-            dist.init_process_group("nccl", device_id=dev)
+        # one RCCL communicator over the ranks, driven through the C ABI (dldkd_amd.comm.RcclComm): every collective is one enqueue
+        # on the caller's stream - no torch.distributed process group, no watchdog thread polling events beside the graph captures
+        # of the training step.  The rendezvous id travels over the env:// TCP store torch.distributed.run set up.
+        from dldkd_amd import comm as dcomm
+        comm = dcomm.init_rccl_from_env(dev)
 
     from dldkd_amd import native, scoring
     native.lib()   # fail loudly before anything else if the HIP library is missing
     metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     out = None
 
-    if dist is not None:
+    if comm is not None:
         # ---- N ranks (or the one-rank test hook): the sharded step, self-verified, then the C4 workload the same way
-        r2 = run_sharded(C2, dev, rank, world, dist, a.steps, a.warmup)
-        r4 = run_sharded(C4, dev, rank, world, dist, max(min(a.steps, 20), 1), max(min(a.warmup, 3), 1)) if not a.no_extras else None
-        r5 = run_c5_ddp(dev, rank, world, dist, max(min(a.steps, 20), 2), max(min(a.warmup, 5), 3)) if not a.no_extras else None
+        r2 = run_sharded(C2, dev, rank, world, comm, a.steps, a.warmup)
+        r4 = run_sharded(C4, dev, rank, world, comm, max(min(a.steps, 20), 1), max(min(a.warmup, 3), 1)) if not a.no_extras else None
+        r5 = run_c5_ddp(dev, rank, world, comm, max(min(a.steps, 20), 2), max(min(a.warmup, 5), 3)) if not a.no_extras else None
         if rank == 0:
             achieved = r2["flops_per_step_all_ranks"] / (r2["ms_per_step"] * 1e-3) / 1e12
             out = {
@@ -639,7 +628,7 @@ def main():
                     "assembled_check": r4["assembled_check"], "recall_expected_n1": RECALL_C4_N1,
                     "recall_matches_n1": r4["recall_hip"] == RECALL_C4_N1},
                     "c5_ddp": r5}
-        dist.barrier()
+        comm.barrier()
     else:
         # ---- one GPU: the headline line with the kernel's roofline, the CPU baseline and the extras
         gs, mask, lens, qs, gt = synth_shard(dev, C2, 0, NV)
@@ -727,14 +716,9 @@ def main():
         except Exception:   # noqa: BLE001
             pass
         print(json.dumps(out), flush=True)
-    if world > 1 or os.environ.get("DLDKD_BENCH_FORCE_DIST") == "1":
-        # The line is out.  Leave without tearing the process group down: destroy_process_group() of this RCCL build aborts now
-        # and then (seen once per ~20 one-rank runs, always at teardown, never in a collective) and an abort here would turn a
-        # finished measurement into a failed run.  Every rank has passed the barrier above; nothing is in flight.
-        torch.cuda.synchronize()
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+    if comm is not None:
+        # every rank has passed the barrier above and drained its streams: free the communicator like any other resource
+        comm.destroy()
 
 
 if __name__ == "__main__":

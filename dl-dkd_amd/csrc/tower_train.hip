@@ -330,7 +330,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float v = xh * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
             const unsigned kb = e < 4 ? (k0 >> e) & 1u : (k1 >> (e - 4)) & 1u;
             xb[ks][e] = (short)f32_to_bf16_bits(kb ? v * p.drop.scale : 0.f);
-            xn[e] = (short)((f32_to_bf16_bits(xh) & 0xfffeu) | ((relu[ks] >> e) & 1u));
+            // bit 0 carries the ReLU mask: the value is rounded to nearest-even at bit 1 (15 value bits) in ONE step from the fp32
+            // number - not a bf16 with its last bit cleared, which truncates towards zero (a biased 1.5 x 2^-7; this is an unbiased
+            // 2^-7, and b1_kernel sums these rows into dgamma over every row of the batch)
+            const unsigned xu = __float_as_uint(xh);
+            xn[e] = (short)((((xu + 0xffffu + ((xu >> 17) & 1u)) >> 16) & 0xfffeu) | ((relu[ks] >> e) & 1u));
         }
         if (w.valid) {
             *reinterpret_cast<bf16x8*>(p.h1d + w.row * kD + 8 * h + 16 * ks) = xb[ks];
@@ -632,7 +636,7 @@ struct B1Args {
     const u16* dres;             // (M, 384) bf16
     const bf16x8* wqkvt;         // natural pack of [Wq; Wk; Wv]^T: [72][12][64]
     const u16* xh1;              // (M, 384) bf16 normalised rows of y0 + pos with bit 0 = [y0 > 0] (f1_kernel): the LayerNorm backward
-                                 // pass reads the value with that bit cleared (2^-8 relative, bf16 grade anyway) and the ReLU mask of the
+                                 // pass reads the value with that bit cleared (rounded to nearest at bit 1 by f1_kernel: 2^-7) and the ReLU mask of the
                                  // input projection from the bit - neither y0 nor the position rows are read again
     const float* stats;          // [2][M]: rstd = stats[M + row]
     const float* gamma;

@@ -1,6 +1,7 @@
-"""One-process-per-GPU pieces of the path (torch.distributed; backend "nccl" = RCCL over xGMI on MI355X,
-"gloo" in the CPU tests).  The reference is single-GPU; these are the two exchanges
-BASELINE.json's north_star adds.
+"""One-process-per-GPU pieces of the path.  The collectives go through a communicator (comm.py): on the GPU RCCL over xGMI driven
+directly through the C ABI (comm.RcclComm: every collective one enqueue on the caller's stream, no process-group watchdog), in the
+CPU tests a torch.distributed gloo group (comm.TorchGroupComm).  `comm=None` everywhere = comm.current().  The reference is
+single-GPU; these are the two exchanges BASELINE.json's north_star adds.
 
 Eval: the gallery shards by video (independent units).  Rank r keeps videos [r*S, (r+1)*S), S = ceil(Nv/N);
 every rank scores ALL queries against its shard; then either
@@ -11,7 +12,15 @@ every rank scores ALL queries against its shard; then either
 Training: local in-batch losses (model.py:353-387 defines negatives within one batch), one flat fp32 gradient
 buffer (the optimizer's own, optimization.FlatParams.grad) mean-all-reduced per step (sync_gradients)."""
 import torch
-import torch.distributed as dist
+
+from . import comm as _comm
+
+
+def _c(comm):
+    c = comm if comm is not None else _comm.current()
+    if c is None:
+        raise RuntimeError("no communicator: comm.init_rccl_from_env(device) (GPU) or an initialised torch.distributed group (CPU tests)")
+    return c
 
 
 def shard_range(n_videos, rank, world):
@@ -29,11 +38,12 @@ def _count_above_hip(scores, thr, n_valid):
     return counts
 
 
-def sharded_gt_ranks(local_scores, gt_video, n_videos, group=None, count_fn=None):
+def sharded_gt_ranks(local_scores, gt_video, n_videos, comm=None, count_fn=None):
     """Gather-free ranking.  local_scores (Nq, S) for this rank's shard; gt_video (Nq,) global index of each
     query's ground-truth video (-1: none).  Returns rank (Nq,) int64 = 1 + #videos scoring above the GT video, identical
     on every rank; n_videos + 1 for a query without ground truth or with a NaN ground-truth score (rank.hip NaN policy)."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    c = _c(comm)
+    rank, world = c.rank, c.world
     lo, hi, s = shard_range(n_videos, rank, world)
     nq = local_scores.shape[0]
     gt_video = gt_video.to(local_scores.device).long()
@@ -47,13 +57,13 @@ def sharded_gt_ranks(local_scores, gt_video, n_videos, group=None, count_fn=None
         bad = torch.isnan(g)
         thr[0, idx] = torch.where(bad, torch.full_like(g, float("-inf")), g)
         thr[1, idx] = bad.float()
-    dist.all_reduce(thr, op=dist.ReduceOp.MAX, group=group)
+    c.all_reduce(thr, "max")
     count_fn = count_fn or _count_above_hip
     if hi > lo:
         counts = count_fn(local_scores.contiguous(), thr[0].contiguous(), hi - lo).to(torch.int64)
     else:                                                  # empty shard (world > n_videos): nothing to count
         counts = torch.zeros(nq, dtype=torch.int64, device=local_scores.device)
-    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    c.all_reduce(counts, "sum")
     ranks = counts + 1
     worst = (thr[1] > 0) | (gt_video < 0)
     return torch.where(worst, torch.full_like(ranks, n_videos + 1), torch.clamp(ranks, max=n_videos + 1))
@@ -75,74 +85,87 @@ def local_gt_csr(t2v_gt, nq, lo, hi):
     return ptr, np.asarray(idx if idx else [0], np.int32), first, has
 
 
-def sharded_ranks_from_partials(local_thr_fn, local_count_fn, has_gt, bad, n_videos, group=None):
+def sharded_ranks_from_partials(local_thr_fn, local_count_fn, has_gt, bad, n_videos, comm=None):
     """Exact ranks of the ground-truth videos with the gallery sharded by video and NO score matrix anywhere: every rank computes
     thresholds over its own GT videos from its scorer's partial planes (local_thr_fn() -> (thr, nan_flag) fp32 (3, 2, Nq), -inf / 0
     where it holds none), all-reduce(MAX); counts its videos above them (local_count_fn(thr) -> int (3, 2, Nq)), all-reduce(SUM).
     has_gt (Nq,) bool and bad (Nq,) bool (NaN / Inf query vector) are the same on every rank.  Returns int64 (3, 2, Nq):
     [branch 0 / branch 1 / fused][best GT / first GT]; n_videos + 1 where there is no ground truth, the query is flagged, or the
     first GT video's score is NaN (rank.hip's NaN policy)."""
+    c = _c(comm)
     thr, flag = local_thr_fn()
     both = torch.stack([thr, flag])                         # one collective for both
-    dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
+    c.all_reduce(both, "max")
     thr, flag = both[0], both[1]
-    counts = local_count_fn(thr).to(torch.int64)
-    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    counts = local_count_fn(thr).to(torch.int64).contiguous()
+    c.all_reduce(counts, "sum")
     ranks = torch.clamp(counts + 1, max=n_videos + 1)
     worst = (flag > 0) | (~has_gt.to(ranks.device) | bad.to(ranks.device))[None, None, :]
     return torch.where(worst, torch.full_like(ranks, n_videos + 1), ranks)
 
 
-def all_reduce_flat(flat, group=None):
+def all_reduce_flat(flat, comm=None):
     """Mean all-reduce of a flat gradient buffer (BertAdam's FlatParams.grad: every parameter's gradient is a view of ONE
     fp32 buffer, 23.0 MB for the TVR model / 17.5 MB for ActivityNet and Charades): one collective per step."""
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat.div_(dist.get_world_size(group))
+    c = _c(comm)
+    c.all_reduce(flat, "sum")
+    flat.div_(c.world)
 
 
-def sync_gradients(fp, group=None, comm_stream=None):
+def sync_gradients(fp, comm=None, comm_stream=None, had=None):
     """The collective half of the data-parallel step (what DDP adds to method/train.py:141-151): gather whatever autograd left
     in p.grad into the flat buffer (parameters without a gradient contribute zeros), mean all-reduce it, and leave every
-    p.grad pointing at its slice.  `fp` is an optimization.FlatParams; pure torch, so it runs on CPU tensors with gloo.
+    p.grad pointing at its slice.  `fp` is an optimization.FlatParams; pure torch + the communicator, so it runs on CPU tensors
+    with gloo.  had: the "this parameter had a gradient" flags when the gradients are already in the flat buffer (a replayed
+    graph filled it: train.GraphedTrainStep) - nothing is gathered then.
 
-    comm_stream (GPU): issue the collective from that stream, fenced both ways against the current one.  Recent torch runs
-    a blocking collective ON the issuing stream and its watchdog thread keeps polling the collective's completion event; if
-    the issuing stream later starts a hipGraph capture (train.GraphedTrainStep captures on its own stream) the poll fails
-    with hipErrorCapturedEvent and the watchdog takes the process down - so collectives stay off streams that capture."""
-    had = fp.rebind_grads()
-    check_had_flags(fp, had, group)
+    The all-reduce is ONE enqueue on the current stream (comm.RcclComm), ordered like any launch: between two graph replays of
+    the step it needs no fence.  comm_stream: issue it from that stream instead, fenced both ways against the current one."""
+    if had is None:
+        had = fp.rebind_grads()
+    c = _c(comm)
+    check_had_flags(fp, had, c)
     if comm_stream is not None:
         cur = torch.cuda.current_stream(fp.grad.device)
         comm_stream.wait_stream(cur)
         with torch.cuda.stream(comm_stream):
-            all_reduce_flat(fp.grad, group)
+            all_reduce_flat(fp.grad, c)
         cur.wait_stream(comm_stream)
     else:
-        all_reduce_flat(fp.grad, group)
+        all_reduce_flat(fp.grad, c)
     # The "this parameter had no gradient" flags stay as they are: every rank builds the same autograd graph, so they agree
     # across ranks, and a parameter without a gradient on any rank must be SKIPPED by the optimizer (no weight decay, no moment
     # decay: optimization.py:294-295), exactly as on one GPU.
 
 
-def check_had_flags(fp, had, group=None):
-    """First data-parallel step of an optimizer: every rank must hold a gradient for the SAME parameters.  The optimizer skips a
-    parameter without one (no weight decay, no moment decay: optimization.py:294-295); if the sets differed between ranks one
-    replica would decay a parameter another skips and they would drift apart with no error.  One small all-gather,
-    once per optimizer (and again whenever this rank's set changes); never under a graph capture."""
-    key = tuple(bool(h) for h in had)
-    if getattr(fp, "_had_checked", None) == key:
+HAD_CHECK_EVERY = 256
+
+
+def check_had_flags(fp, had, comm=None):
+    """Every rank must hold a gradient for the SAME parameters: the optimizer skips a parameter without one (no weight decay, no
+    moment decay: optimization.py:294-295); if the sets differed between ranks one replica would decay a parameter another skips
+    and they would drift apart with no error.  One small SUM all-reduce of the 0 / 1 flags (each must come back 0 or
+    world) and one host read.
+
+    WHEN the check runs depends on nothing rank-local (a collective gated on this rank's own flag set pairs with
+    another rank's gradient all-reduce): it is counted per optimizer - this function is called exactly once per data-parallel
+    step on every rank - and runs on calls 0, 1 (the first eager and the first replayed step) and every HAD_CHECK_EVERY-th.
+    Never issued under a graph capture (the collectives of the step are enqueued between the graphs, not inside them)."""
+    n = getattr(fp, "_had_calls", 0)
+    fp._had_calls = n + 1
+    if not (n < 2 or n % HAD_CHECK_EVERY == 0):
         return
     if fp.grad.is_cuda and torch.cuda.is_current_stream_capturing():
-        return
-    mine = torch.tensor([1.0 if h else 0.0 for h in key], dtype=torch.float32, device=fp.grad.device)
-    lo, hi = mine.clone(), mine.clone()
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-    if not torch.equal(lo.cpu(), hi.cpu()):
-        bad = [i for i, (a, b) in enumerate(zip(lo.cpu().tolist(), hi.cpu().tolist())) if a != b]
+        raise RuntimeError("check_had_flags under a graph capture: the data-parallel collectives belong between the graphs")
+    c = _c(comm)
+    mine = torch.tensor([1.0 if h else 0.0 for h in had], dtype=torch.float32, device=fp.grad.device)
+    tot = mine.clone()
+    c.all_reduce(tot, "sum")
+    tot = tot.cpu().tolist()
+    bad = [i for i, t in enumerate(tot) if t != 0.0 and t != float(c.world)]
+    if bad:
         raise RuntimeError(f"data parallel: the ranks disagree on which parameters have a gradient (parameter indices {bad[:8]}...): "
                            "the replicas would diverge")
-    fp._had_checked = key
 
 
 class BucketedGradSync:
@@ -152,12 +175,12 @@ class BucketedGradSync:
     The buckets are the contiguous ranges FlatParams laid out (optimization.FlatParams.bucket_ranges); a sum over ranks is
     element-wise, so the result is bit-identical to the single-bucket all-reduce.
 
-    GPU: collectives go to `comm_stream`, ordered after the gradient copies by an event and joined back in finish(); they never
-    run on a stream that captures (sync_gradients says why).  CPU / gloo: asynchronous work handles, waited in finish()."""
+    GPU: collectives go to `comm_stream` (so that they run beside the next tower's backward kernels), ordered after the gradient
+    copies by an event and joined back in finish().  CPU / gloo: asynchronous work handles, waited in finish()."""
 
-    def __init__(self, fp, group=None, comm_stream=None):
-        self.fp, self.group, self.comm_stream = fp, group, comm_stream
-        self.world = dist.get_world_size(group)
+    def __init__(self, fp, comm=None, comm_stream=None):
+        self.fp, self.comm, self.comm_stream = fp, _c(comm), comm_stream
+        self.world = self.comm.world
         self.pending, self.issued = [], set()
 
     def _reduce(self, lo, hi):
@@ -168,10 +191,10 @@ class BucketedGradSync:
             cur = torch.cuda.current_stream(part.device)
             self.comm_stream.wait_stream(cur)
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+                self.comm.all_reduce(part, "sum")
                 part.div_(self.world)
         else:
-            self.pending.append((dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True), part))
+            self.pending.append((self.comm.all_reduce(part, "sum", async_op=True), part))
 
     def bucket_ready(self, b):
         """Every gradient of bucket b is final: gather them into the flat range (eager) and start its all-reduce."""
@@ -186,7 +209,7 @@ class BucketedGradSync:
 
     def finish(self):
         """Whatever has not been issued goes now; then the current stream waits for every collective."""
-        check_had_flags(self.fp, self.fp.rebind_grads(), self.group)
+        check_had_flags(self.fp, self.fp.rebind_grads(), self.comm)
         for b in range(len(self.fp.bucket_ranges)):
             self.issue(b)
         if self.comm_stream is not None:
@@ -197,9 +220,9 @@ class BucketedGradSync:
         self.pending, self.issued = [], set()
 
 
-def broadcast_parameters(fp, src=0, group=None):
+def broadcast_parameters(fp, src=0, comm=None):
     """All replicas start from rank `src`'s parameters: one broadcast of the flat parameter buffer."""
-    dist.broadcast(fp.flat, src=src, group=group)
+    _c(comm).broadcast(fp.flat, src=src)
 
 
 class ShardScorerBackend:
@@ -258,25 +281,29 @@ class HipShardBackend(ShardScorerBackend):
 
 class OverlappedShardScorer:
     """One rank of the sharded all-pairs scoring step (the loop of method/eval.py:188-212 with the gallery cut by video):
-    score all queries against this rank's shard in ONE launch whose query ranges complete in order, and, on a side stream,
-    for every range as it completes: finish its (nq_r, S) block and all-gather it asynchronously - the collective of range r
-    runs on RCCL's stream under the scoring of ranges r+1.. (xGMI is point-to-point: the 7 peer transfers of one all-gather
-    proceed in parallel).  Only the last range's gather is exposed.
+    score all queries against this rank's shard in ONE launch whose query ranges complete in order; on a side stream, for every
+    range as it completes: finish its (nq_r, S) block; on the collectives' stream, behind that block's event: all-gather it - the
+    collective of range r runs under the scoring of ranges r+1.. (xGMI is point-to-point: the 7 peer transfers of one all-gather
+    proceed in parallel).  Only the last range's gather is exposed.  Everything is enqueued up front; the host never waits.
 
     bounds: [(lo, hi)] query rows of every range; after step(): blocks[r] is (world * nq_r, S) rank-major;
     assemble() builds (Nq, n_videos)."""
 
-    def __init__(self, backend, bounds, shard, device, group=None, side_stream=None):
+    def __init__(self, backend, bounds, shard, device, comm=None, side_stream=None, comm_stream=None):
         bounds = list(bounds)
         if any(b[0] != a[1] for a, b in zip(bounds, bounds[1:])) or (bounds and bounds[0][0] != 0):
             raise ValueError(f"OverlappedShardScorer: ranges must tile the queries from 0 without gaps, got {bounds}")
-        self.backend, self.bounds, self.shard, self.group = backend, bounds, shard, group
-        self.world = dist.get_world_size(group)
+        self.backend, self.bounds, self.shard, self.comm = backend, bounds, shard, _c(comm)
+        self.world = self.comm.world
         self.local = [torch.empty(hi - lo, shard, dtype=torch.float32, device=device) for lo, hi in self.bounds]
         self.blocks = [torch.empty(self.world * (hi - lo), shard, dtype=torch.float32, device=device) for lo, hi in self.bounds]
         self.done = torch.zeros(max(len(self.bounds), 1), dtype=torch.int32, device=device)
         self.on_gpu = torch.device(device).type == "cuda"
         self.side = side_stream if (side_stream is not None or not self.on_gpu) else torch.cuda.Stream(device=device)
+        # RCCL's kernels need CUs too, and the scorer parks a 512-register wave on every SIMD: the collectives' stream has high
+        # priority, so its workgroups are dispatched first whenever a scorer workgroup retires
+        self.comm_stream = comm_stream if (comm_stream is not None or not self.on_gpu) else torch.cuda.Stream(device=device, priority=-1)
+        self.ready = [torch.cuda.Event() for _ in self.bounds] if self.on_gpu else []
 
     def step(self):
         if not self.on_gpu:                                   # CPU tests (gloo): same order of operations, no streams
@@ -286,7 +313,7 @@ class OverlappedShardScorer:
             for r, (lo, hi) in enumerate(self.bounds):
                 self.backend.wait_range(self.done, r)
                 self.backend.finish_range(r, lo, hi, self.local[r])
-                works.append(dist.all_gather_into_tensor(self.blocks[r], self.local[r], group=self.group, async_op=True))
+                works.append(self.comm.all_gather_into(self.blocks[r], self.local[r], async_op=True))
             for w in works:
                 w.wait()
             return
@@ -295,16 +322,17 @@ class OverlappedShardScorer:
         zeroed = torch.cuda.Event()
         zeroed.record(main)                                   # the side stream may look at the counters from here on...
         self.backend.launch(self.done)                        # ...while the scorer (main stream) is still running
-        works = []
         with torch.cuda.stream(self.side):
-            self.side.wait_event(zeroed)
+            self.side.wait_event(zeroed)                      # (also orders this step's blocks behind the last step's gathers)
             for r, (lo, hi) in enumerate(self.bounds):
                 self.backend.wait_range(self.done, r)
                 self.backend.finish_range(r, lo, hi, self.local[r])
-                works.append(dist.all_gather_into_tensor(self.blocks[r], self.local[r], group=self.group, async_op=True))
-            for w in works:
-                w.wait()                                      # side stream waits for RCCL's stream
-        main.wait_stream(self.side)
+                self.ready[r].record(self.side)
+        with torch.cuda.stream(self.comm_stream):
+            for r in range(len(self.bounds)):
+                self.comm_stream.wait_event(self.ready[r])
+                self.comm.all_gather_into(self.blocks[r], self.local[r])
+        main.wait_stream(self.comm_stream)                    # (which has waited for every block of the side stream)
 
     def assemble(self, n_videos):
         rows = []

@@ -498,10 +498,8 @@ def compute_query2ctx_info(model, eval_dataset, opt, ctx_info):
 
 
 def _dist_world():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
-    return 0, 1
+    from . import comm
+    return comm.info()
 
 
 def gallery_ids(dataset):
@@ -522,7 +520,7 @@ def gallery_ids(dataset):
 
 
 def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=False):
-    """eval_epoch with the gallery sharded by video over the ranks of the default process group (config C4).
+    """eval_epoch with the gallery sharded by video over the ranks of the current communicator (comm.current(); config C4).
 
     Rank r encodes and keeps videos [r*S, (r+1)*S) only (its features are the only ones it reads), every rank encodes all
     queries, scores them against its shard (the scorer's two partial planes, nothing else), and the ranks of all three score
@@ -533,9 +531,9 @@ def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=Fal
     on every rank."""
     from torch.utils.data import Subset
     from . import dist as ddist
-    import torch.distributed as tdist
+    from . import comm as _comm
     rank, world = _dist_world()
-    use_collectives = tdist.is_available() and tdist.is_initialized()
+    use_collectives = _comm.current() is not None
     model.eval()
     n_videos = len(val_video_dataset)
     lo, hi, _ = ddist.shard_range(n_videos, rank, world)
@@ -558,7 +556,7 @@ def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=Fal
     cnt_fn = lambda thr: scoring.shard_counts(ws, pq, pg, thr)                          # noqa: E731
     if use_collectives:
         ranks = ddist.sharded_ranks_from_partials(thr_fn, cnt_fn, torch.from_numpy(has), bad, n_videos)
-    else:                                                     # no process group: the one shard is the gallery
+    else:                                                     # no communicator: the one shard is the gallery
         thr, flag = thr_fn()
         r = torch.clamp(cnt_fn(thr).to(torch.int64) + 1, max=n_videos + 1)
         worst = (flag > 0) | (~torch.from_numpy(has).to(dev) | bad)[None, None, :]

@@ -1051,6 +1051,12 @@ class _BranchLoss(Function):
         if (g_trip is not None and g_nce is not None and _is_unit(g_trip) and _is_unit(g_nce)
                 and (dclip is None or (g_kl is not None and _is_unit(g_kl)))):
             return dC, dS, None, dclip, None, None, None, None, None, None, None, None      # scaling by exactly 1: nothing to launch
+        # The saved gradients are scaled IN PLACE and handed out as they are (no second copy of two (Nq, Nv) matrices per branch): a
+        # second backward pass through this node (retain_graph=True) would scale them twice.  Once only, loudly.
+        if getattr(ctx, "_scaled", False):
+            raise RuntimeError("_BranchLoss: second backward through a node whose saved gradients were scaled in place; rebuild the "
+                               "forward pass instead of retain_graph=True (or sum the terms with unit upstream gradients)")
+        ctx._scaled = True
         one = None
         def gs(g):                                             # an unused term has no upstream gradient: its gradients are zero
             nonlocal one

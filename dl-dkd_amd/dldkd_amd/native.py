@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdldkd_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -211,6 +211,19 @@ SIGNATURES = {
                                                 _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p]),
     "dldkd_gemm_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                          _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
+    # collectives (RCCL, driven directly; dldkd_amd.comm.RcclComm)
+    "dldkd_comm_rccl_version": (_c_int, []),
+    "dldkd_comm_unique_id": (_c_int, [_c_void_p]),
+    "dldkd_comm_init": (_c_int, [ctypes.POINTER(_c_void_p), _c_int, _c_int, _c_void_p]),
+    "dldkd_comm_info": (_c_int, [_c_void_p, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
+    "dldkd_comm_destroy": (_c_int, [_c_void_p]),
+    "dldkd_comm_abort": (_c_int, [_c_void_p]),
+    "dldkd_comm_async_error": (_c_int, [_c_void_p]),
+    "dldkd_comm_all_reduce": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_int, _c_void_p]),
+    "dldkd_comm_all_gather": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_void_p]),
+    "dldkd_comm_broadcast": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_int, _c_int, _c_void_p]),
+    "dldkd_comm_group_begin": (_c_int, []),
+    "dldkd_comm_group_end": (_c_int, []),
 }
 
 _lib = None

@@ -86,11 +86,10 @@ DDP_MIN_WORLD = 2      # tests set 1 to drive the all-reduce branch with a one-r
 
 
 def dist_info():
-    """(rank, world) of the default process group, (0, 1) without one."""
-    import torch.distributed as tdist
-    if tdist.is_available() and tdist.is_initialized():
-        return tdist.get_rank(), tdist.get_world_size()
-    return 0, 1
+    """(rank, world) of the current communicator (comm.current(): the installed RCCL communicator, or the default torch.distributed
+    group of the CPU tests), (0, 1) without one."""
+    from . import comm
+    return comm.info()
 
 
 def backward_in_phases(loss, phases, after_phase=None, between=None):
@@ -133,7 +132,8 @@ def train_step(model, batch, optimizer, opt, comm_stream=None):
     (optimization.FlatParams): nothing here is GPU-specific, the CPU tests drive it with a toy model over gloo.
     Data parallel with a model that exposes forward_phased and an optimizer laid out in gradient buckets: the backward pass
     runs tower by tower and each tower's all-reduce is issued as it completes (dist.BucketedGradSync), on comm_stream when
-    given (see dist.sync_gradients); otherwise one all-reduce of the whole flat buffer after the backward pass."""
+    given (so that it runs beside the next tower's backward kernels); otherwise one all-reduce of the whole flat buffer, enqueued
+    on the current stream behind the backward pass."""
     optimizer.zero_grad()
     ddp = dist_info()[1] >= DDP_MIN_WORLD
     fp = getattr(optimizer, "fp", None)
@@ -151,7 +151,7 @@ def train_step(model, batch, optimizer, opt, comm_stream=None):
         loss.backward()
         if ddp:
             from . import dist as ddist
-            ddist.sync_gradients(fp, comm_stream=comm_stream)
+            ddist.sync_gradients(fp)
     if getattr(opt, "grad_clip", -1) != -1:
         torch.nn.utils.clip_grad_norm_(model.parameters(), opt.grad_clip)
     optimizer.step()
@@ -193,8 +193,11 @@ class GraphedTrainStep:
     time; at most `max_graphs` graphs are kept (least recently used is dropped), an evicted key is never captured again and
     after `max_captures` captures every unseen key stays eager (variable caption counts - ActivityNet, Charades - would
     otherwise re-capture a 350-kernel graph far more often than they replay one).
-    Data parallel (world >= 2), default: one graph that ends after the backward pass, one all-reduce of the flat gradient buffer from
-    the comm stream, the optimizer update eagerly.  With the optimizer laid out in gradient buckets (opt.ddp_bucketed_overlap,
+    Data parallel (world >= 2), default: the same graphs as on one GPU, with ONE all-reduce of the flat gradient buffer enqueued on
+    the step's stream between the backward graphs and the optimizer graph (comm.RcclComm: a plain enqueue, no watchdog thread, so
+    it may sit between replays; the optimizer graph then computes the clip's norms from the reduced gradients).  Every form of
+    the step - eager, single graph, tower graphs - issues the same collectives in the same order, so ranks whose batch signatures
+    differ (one replays while another captures) still pair up.  With the optimizer laid out in gradient buckets (opt.ddp_bucketed_overlap,
     make_optimizer): the step is a chain of graphs, one per tower of the backward pass; each tower's all-reduce is issued from the
     comm stream as its segment has been launched and runs under the next segment; the optimizer update is the chain's last graph
     (_capture_segments)."""
@@ -227,7 +230,7 @@ class GraphedTrainStep:
         # still holds) would pull the default stream into a later capture on another stream through the engine's
         # cross-stream event, and hipStreamEndCapture then dies on the unjoined stream (seen as a segfault).
         self.stream = None
-        self.comm_stream = None      # gradient all-reduce: never on a stream that captures (dist.sync_gradients)
+        self.comm_stream = None      # the bucketed overlap's collectives (dist.BucketedGradSync); the single all-reduce needs none
         # the four towers on four streams (model._encode_towers): fork / join edges of the captured graph, so the chip runs
         # their under-filled kernels side by side (C3 bf16 step 5.9 -> 5.3 ms); opt.tower_streams = False keeps one stream
         if hasattr(model, "tower_streams"):
@@ -335,10 +338,14 @@ class GraphedTrainStep:
         """Capture `key`; with the self-check on, the batch is stepped eagerly first (the reference), the state is rewound, the graph
         is captured and replayed once from the same state, and loss + parameters are compared.  Returns the step's result."""
         if not self.self_check:
+            # Only the CAPTURE is guarded: it executes nothing, so the eager step that replaces it is this batch's first.  A failure
+            # inside the replay - graphs already launched, perhaps the optimizer's, and under data parallelism this rank's
+            # all-reduce already issued - must not be followed by a second step on the same batch (ADVICE r04): it propagates.
             try:
-                return self._replay(self._capture(batch, key), batch)
+                e = self._capture(batch, key)
             except Exception as ex:   # noqa: BLE001
                 return self._capture_failed(batch, key, ex, None)
+            return self._replay(e, batch)
         st0 = self._snapshot()
         ref_loss, ref_dict = self._eager(batch)
         self.eager_steps -= 1                              # (bookkeeping: this eager run is the check's reference, not a step of its own)
@@ -366,7 +373,7 @@ class GraphedTrainStep:
 
     def _degrade(self, key, why):
         """One notch down: parallel tower graphs -> single graph -> this key stays eager."""
-        if self.parallel_towers and not (dist_info()[1] >= DDP_MIN_WORLD):
+        if self.parallel_towers:
             self.parallel_towers = False
             self.seen[key] = 1                             # captured again (as a single graph) at its next sight
             what = "falling back to the single-graph stepper"
@@ -432,13 +439,13 @@ class GraphedTrainStep:
         try:
             opt_.zero_grad()
             e.graph = torch.cuda.CUDAGraph()
-            # thread_local: only THIS thread's unsafe calls fail while the capture is open.  In the default "global" mode every
-            # thread's do - and RCCL's watchdog thread polls its events with hipEventQuery all the time: it then dies on
-            # hipErrorStreamCaptureUnsupported and the process aborts at destroy_process_group (seen one run in two).
+            # thread_local: only THIS thread's unsafe calls fail while the capture is open (a loader thread may touch the runtime).
             # Kernels the autograd thread launches into the capturing stream are captured in either mode.
+            # Data parallel: the all-reduce is ONE enqueue (comm.RcclComm) between the backward graphs and the optimizer graph
+            # of whichever form the step takes; with gradient buckets the step is the chain of segments instead.
             if e.ddp and hasattr(m, "forward_phased") and len(opt_.fp.bucket_ranges) > 1:
                 self._capture_segments(e)
-            elif (not e.ddp and self.parallel_towers and hasattr(m, "forward_phased") and hasattr(m, "_tower_runner")
+            elif (self.parallel_towers and hasattr(m, "forward_phased") and hasattr(m, "_tower_runner")
                   and getattr(m, "tower_streams", False) and getattr(m, "double_branch", False)
                   and hasattr(opt_.fp, "gather_subset")):
                 self._capture_parallel(e)
@@ -604,7 +611,9 @@ class GraphedTrainStep:
             # tower's stream: FlatParams._gather) into the scratch zeroed here, at the head of the step; the optimizer graph is then
             # the update alone
             norm2 = None
-            if self.GATHER_WITH_NORMS and hasattr(opt_, "zero_norms") and opt_.param_groups[0].get("max_grad_norm", -1) > 0:
+            # (data parallel: the clip's norms are those of the all-reduced gradients - the optimizer graph computes them itself)
+            if (self.GATHER_WITH_NORMS and not e.ddp and hasattr(opt_, "zero_norms")
+                    and opt_.param_groups[0].get("max_grad_norm", -1) > 0):
                 opt_.zero_norms()
                 norm2 = opt_.norm2
             loss, parts, phases = m.forward_phased(e.static, staged=e)
@@ -689,6 +698,11 @@ class GraphedTrainStep:
                 main.wait_event(x)
         if par["tail"] is not None:
             par["tail"].replay()
+        if e.ddp:
+            # every tower's gradients are in the flat buffer (the waits above): the mean all-reduce is one enqueue on this stream
+            # between the backward graphs and the optimizer graph
+            from . import dist as ddist
+            ddist.sync_gradients(self.optimizer.fp, had=e.had)
         par["opt"].replay()
 
     def _replay(self, e, batch):
@@ -743,7 +757,7 @@ class GraphedTrainStep:
             e.graph.replay()
             if e.ddp:
                 from . import dist as ddist
-                ddist.sync_gradients(opt_.fp, comm_stream=self.comm_stream)
+                ddist.sync_gradients(opt_.fp)
                 opt_.enqueue(upload_lr=False)
         ops.bump_param_epoch()
         _end_zero_arena()

@@ -31,6 +31,7 @@ extern "C" {
 #define DLDKD_OK 0
 #define DLDKD_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
 #define DLDKD_ELAUNCH (-2)  /* HIP launch error */
+#define DLDKD_ECOMM (-3)    /* RCCL error (dldkd_comm_*), or librccl.so.1 not loadable */
 
 #define DLDKD_HIDDEN 384    /* config.py:70-71 hidden size the kernels are specialised for */
 #define DLDKD_MAX_CLIPS 128 /* config.py:60 max_ctx_l */
@@ -800,6 +801,52 @@ int dldkd_rows_to_bf16_stats(const float* src, const int32_t* lens, const long l
  * memory (hipHostMalloc / torch pin_memory), read over the bus on the compute queue - no copy-engine hand-off.  The caller keeps
  * pinned_src unchanged until the launch has executed (an event, as for hipMemcpyAsync). */
 int dldkd_upload_words(const int32_t* pinned_src, int32_t* dst, long n_words, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Collectives: the two exchanges of the one-process-per-GPU form of the path (nothing in the single-GPU reference; they stand
+ * where torch.nn.parallel would put them): the all-gather of the (Nq, Nv / world) score blocks of the gallery sharded by video
+ * (the loop of method/eval.py:188-212) and the all-reduce of the flat gradient buffer between loss.backward() and
+ * optimizer.step() (method/train.py:147-151).  RCCL over xGMI, driven directly (librccl.so.1 is resolved at the first call; the
+ * copy already mapped by the host process is used when there is one).
+ *   - a communicator is an explicit HOST object: created by dldkd_comm_init on the calling thread's current device (blocking:
+ *     RCCL's rendezvous; the 128-byte id comes from rank 0's dldkd_comm_unique_id and travels to the other ranks by whatever
+ *     the host has - dldkd_amd.comm uses the TCP store of torch.distributed's env:// rendezvous), destroyed by
+ *     dldkd_comm_destroy.  These three and dldkd_comm_abort are the only entry points of the library that do more than enqueue.
+ *   - every collective is ONE enqueue on `stream` and returns at once; completion is ordinary stream order.  No helper thread,
+ *     no event polling: the calls may be issued between hipGraph replays or inside a capture, as RCCL allows.  All ranks must issue
+ *     the same collectives in the same order; buffers are device pointers; in-place (send == recv, or recv + rank * send_count
+ *     for the gather) is allowed.
+ * ------------------------------------------------------------------------------------------- */
+#define DLDKD_COMM_ID_BYTES 128
+#define DLDKD_F32 0
+#define DLDKD_F64 1
+#define DLDKD_I32 2
+#define DLDKD_I64 3
+#define DLDKD_U8 4
+#define DLDKD_SUM 0
+#define DLDKD_MAX 1
+#define DLDKD_MIN 2
+/* RCCL's version code (e.g. 22606), or DLDKD_ECOMM when librccl.so.1 cannot be loaded. */
+int dldkd_comm_rccl_version(void);
+/* Rank 0: fill host_id_out (DLDKD_COMM_ID_BYTES bytes of host memory) with a fresh rendezvous id. */
+int dldkd_comm_unique_id(void* host_id_out);
+/* Every rank, with the same id: *host_comm_out = the communicator of `world` ranks on the current device. */
+int dldkd_comm_init(void** host_comm_out, int world, int rank, const void* host_id);
+int dldkd_comm_info(void* comm, int* host_world_out, int* host_rank_out);
+/* Destroy after the streams that carry its collectives have drained (the caller synchronises; this call does not). */
+int dldkd_comm_destroy(void* comm);
+int dldkd_comm_abort(void* comm);
+/* DLDKD_OK, or DLDKD_ECOMM with the text in dldkd_last_error() if a collective failed asynchronously (a peer died). */
+int dldkd_comm_async_error(void* comm);
+/* recv[i] = op over ranks of send[i], i < count (the gradient mean is SUM followed by the caller's 1 / world). */
+int dldkd_comm_all_reduce(void* comm, const void* send, void* recv, size_t count, int dtype, int op, void* stream);
+/* recv[r * send_count + i] = rank r's send[i]: the score blocks of one query range, rank-major. */
+int dldkd_comm_all_gather(void* comm, const void* send, void* recv, size_t send_count, int dtype, void* stream);
+/* buf on every rank = buf of rank `root` (the replicas' initial parameters, method/train.py:186-201 has one replica). */
+int dldkd_comm_broadcast(void* comm, void* buf, size_t count, int dtype, int root, void* stream);
+/* Several collectives as one RCCL group (one launch for a run of small ones). */
+int dldkd_comm_group_begin(void);
+int dldkd_comm_group_end(void);
 
 #ifdef __cplusplus
 }

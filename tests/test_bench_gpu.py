@@ -1,4 +1,6 @@
-"""bench.py's multi-rank path checks itself: run it through the one-rank RCCL hook and read the line."""
+"""bench.py's multi-rank path checks itself: run it through the one-rank RCCL hook and read the line.
+Collected LAST (conftest.pytest_collection_modifyitems): these tests run bench.py as a child process and must never stand between
+the driver's `pytest -x` and the parity tests."""
 import json
 import os
 import subprocess
@@ -14,12 +16,13 @@ def _line(env_extra, *args):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", **env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=1500,
                        cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
+    # (head AND tail of the child's stderr: the HIP / RCCL error string is at the head of an abort message, the stack at its tail)
+    assert r.returncode == 0, f"bench.py exit {r.returncode}\n--- stderr head\n{r.stderr[:3000]}\n--- stderr tail\n{r.stderr[-2000:]}"
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def test_bench_distributed_path_verifies_itself_on_one_rank():
-    """DLDKD_BENCH_FORCE_DIST=1: OverlappedShardScorer + RCCL with world size 1.  The gathered matrix equals a plain
+    """DLDKD_BENCH_FORCE_DIST=1: OverlappedShardScorer + the RCCL communicator of the C ABI with world size 1.  The gathered matrix equals a plain
     one-launch recompute of sampled videos bit for bit, its recalls are the one-GPU recalls (same gallery, same queries for
     every rank count), and the C4 workload goes through the same path."""
     import bench

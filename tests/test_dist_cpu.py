@@ -314,7 +314,8 @@ def _bench_setup_worker(rank, world, port, ret):
     cfg = _BENCH_CFG
     shard = (cfg["nv"] + world - 1) // world
     lo, hi = min(rank * shard, cfg["nv"]), min((rank + 1) * shard, cfg["nv"])
-    gs, mask, lens, qs, gt = bench.synth_shard("cpu", cfg, lo, hi, world, dist)
+    from dldkd_amd import comm as dcomm
+    gs, mask, lens, qs, gt = bench.synth_shard("cpu", cfg, lo, hi, world, dcomm.current())
     ret[rank] = dict(lo=lo, hi=hi, gs=[g.clone() for g in gs], lens=lens.clone(), qs=[q.clone() for q in qs], gt=gt.clone())
     dist.destroy_process_group()
 
@@ -410,3 +411,79 @@ def test_sharded_ranks_from_partials_two_ranks():
     mp.spawn(_ranks_worker, args=(world, port, ret), nprocs=world, join=True)
     assert (ret[0] == ret[1]).all()                                  # the same ranks on every rank
     assert (ret[0] == ret["want"]).all(), (ret[0][0], ret["want"][0])
+
+
+# ------------------------------------------------------------------------------------------------ rank-invariant had-flag check
+def _had_worker(rank, world, port, ret):
+    _setup(rank, world, port)
+    from dldkd_amd import dist as ddist
+    from dldkd_amd.optimization import FlatParams
+    torch.manual_seed(3)
+    model = _ToyModel()
+    fp = FlatParams(list(model.parameters()))
+    n = len(fp.params)
+    same = tuple(True for _ in range(n))
+    # (1) identical sets: calls 0 and 1 check, later ones do not - on BOTH ranks alike, whatever the rank-local history is
+    events = []
+    for step in range(5):
+        fp.grad.fill_(float(rank + 1))
+        ddist.sync_gradients(fp, had=same)
+        events.append(float(fp.grad[0]))
+    # (2) rank 1's set changes at a step where no check is due: nothing is issued by either rank (no unpaired collective: the
+    # gradient all-reduce that follows still pairs up and returns the mean)
+    mine = tuple(i != 0 or rank == 0 for i in range(n))
+    fp.grad.fill_(float(rank + 1))
+    ddist.sync_gradients(fp, had=mine)
+    events.append(float(fp.grad[0]))
+    # (3) at the next due call the divergence is caught on BOTH ranks, by a collective both take part in
+    fp._had_calls = ddist.HAD_CHECK_EVERY
+    try:
+        ddist.sync_gradients(fp, had=mine)
+        caught = False
+    except RuntimeError as ex:
+        caught = "disagree" in str(ex)
+    ret[rank] = dict(events=events, caught=caught, calls=fp._had_calls)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_had_flag_check_is_collective_on_every_rank():
+    """the check of the ranks' "had a gradient" sets must not be gated on rank-local state - a rank whose set
+    changed would issue collectives the others do not.  It runs on a call-count cadence that is the same on every rank; a
+    divergence is reported by RuntimeError on every rank at the next due call, never by a hang or a corrupted gradient buffer."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_had_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(2):
+        assert ret[r]["events"] == [1.5] * 6                       # mean of 1 and 2 at every step, including the diverged one
+        assert ret[r]["caught"] is True
+    assert ret[0]["calls"] == ret[1]["calls"]
+
+
+# ------------------------------------------------------------------------------------------------ RCCL rendezvous id over the env:// store
+def _store_worker(rank, world, port, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "dl-dkd_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from dldkd_amd import comm as dcomm
+    store, r, w = dcomm._env_store(rank, world, timeout_s=60)
+    if r == 0:
+        uid = dcomm.RcclComm.unique_id()                 # host-only call of librccl: works without a GPU
+        store.set("id", uid)
+    else:
+        uid = bytes(store.get("id"))
+    store.add("seen", 1)
+    while int(store.add("seen", 0)) < w:                 # rank 0 hosts the store: keep it alive until everyone has read
+        pass
+    ret[rank] = (r, w, uid)
+
+
+def test_rccl_unique_id_travels_over_the_env_store():
+    """comm.init_rccl_from_env's host half without a GPU: rank 0 draws the 128-byte id through the C ABI (dldkd_comm_unique_id) and
+    every rank reads the same bytes from the env:// TCP store."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_store_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0][:2] == (0, 2) and ret[1][:2] == (1, 2)
+    assert len(ret[0][2]) == 128 and ret[0][2] == ret[1][2] and any(ret[0][2])

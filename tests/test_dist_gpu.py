@@ -1,19 +1,14 @@
-"""GPU, one-rank RCCL group: the sharded scoring step as bench.py --gpus N runs it - ONE scorer launch with per-range
-arrival counters, a side stream parked on each counter (hipStreamWaitValue32), per-range finish + all_gather - must
-reproduce the plain one-launch matrix bit for bit, step after step (counters and buffers are reused)."""
-import os
-
+"""GPU, one-rank RCCL communicator: the sharded scoring step as bench.py --gpus N runs it - ONE scorer launch with per-range
+arrival counters, a side stream parked on each counter (hipStreamWaitValue32), per-range finish, per-range all_gather on the
+collectives' stream - must reproduce the plain one-launch matrix bit for bit, step after step (counters and buffers are reused)."""
 import pytest
-from conftest import in_child_process
 import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@in_child_process
-def test_overlapped_shard_scorer_one_rank_rccl():
-    import torch.distributed as dist
+def test_overlapped_shard_scorer_one_rank_rccl(rccl_comm):
     from dldkd_amd import dist as ddist
     from dldkd_amd import scoring
     nq, nv, L = 5000, 615, 128
@@ -24,8 +19,6 @@ def test_overlapped_shard_scorer_one_rank_rccl():
     qs = [torch.randn(nq, 384, generator=g, device=DEV) for _ in range(2)]
     pg = scoring.pack_gallery(gal, mask)
     ref = scoring.simpool_eval(scoring.pack_queries(qs), pg)[0]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29593", RANK="0", WORLD_SIZE="1")
-    dist.init_process_group("nccl", device_id=torch.device(DEV))
     try:
         backend = ddist.HipShardBackend(qs, pg, min_ranges=4)
         n = backend.n_ranges
@@ -44,4 +37,4 @@ def test_overlapped_shard_scorer_one_rank_rccl():
         torch.cuda.synchronize()
         assert torch.equal(ov.assemble(nv), scoring.simpool_eval(scoring.pack_queries(qs), pg)[0])
     finally:
-        pass                                     # (no teardown of the RCCL group: conftest.in_child_process)
+        torch.cuda.synchronize()

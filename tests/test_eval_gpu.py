@@ -4,7 +4,6 @@ import types
 
 import numpy as np
 import pytest
-from conftest import in_child_process
 import torch
 
 import dldkd_oracle as orc
@@ -89,25 +88,23 @@ def test_get_pred_from_raw_query():
     assert (s0.cpu() - ref0).abs().max() < 6e-3 and (s1.cpu() - ref1).abs().max() < 6e-3
 
 
-@in_child_process
 def test_eval_epoch_sharded_equals_unsharded():
-    """One-rank RCCL group: the sharded driver (gather-free ranking) returns the unsharded SumR."""
-    import os
-    import torch.distributed as dist
+    """One-rank RCCL communicator: the sharded driver (gather-free ranking) returns the unsharded SumR."""
+    from dldkd_amd import comm as dcomm
     from dldkd_amd import eval as ev
     m = _model(1024, 1024, synth.make_params(13, 1024, 1024))
     vids, txts = synth.make_eval_sets(8, nv=37, caps=2, dv=1024, dq=1024)
     opt = _opt()
     with torch.no_grad():
         ref = ev.eval_epoch(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), opt)
-        a = ev.eval_epoch_sharded(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), opt)   # no group
+        a = ev.eval_epoch_sharded(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), opt)   # no communicator
         assert a == pytest.approx(ref)
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device(DEV))
+        c = dcomm.install(dcomm.RcclComm(1, 0, dcomm.RcclComm.unique_id(), torch.device(DEV)))
         try:
             b = ev.eval_epoch_sharded(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), opt)
         finally:
-            pass                                     # (no teardown of the RCCL group: conftest.in_child_process)
+            dcomm.install(None)
+            c.destroy()
     assert b == pytest.approx(ref)
 
 
@@ -161,13 +158,10 @@ def test_streaming_context_and_query_super_batches_equal_per_batch_path():
             assert x.shape == y.shape and (x - y).abs().max().item() < 2e-6
 
 
-@in_child_process
-def test_eval_epoch_sharded_edge_cases(recwarn):
+def test_eval_epoch_sharded_edge_cases(recwarn, rccl_comm):
     """ids come from the dataset's `video_ids` attribute (the reference's VisDataSet4DLDKD has it, data_provider.py:270-275):
     no feature is read to build the ground truth; a caption whose video is missing from the gallery ranks nv + 1 like in the
     unsharded path; an empty gallery shard (more ranks than videos) scores nothing and still returns."""
-    import os
-    import torch.distributed as dist
     from dldkd_amd import eval as ev
     m = _model(1024, 1024, synth.make_params(13, 1024, 1024))
     vids, txts = synth.make_eval_sets(8, nv=21, caps=2, dv=1024, dq=1024)
@@ -186,8 +180,6 @@ def test_eval_epoch_sharded_edge_cases(recwarn):
     opt = _opt()
     with torch.no_grad():
         ref = ev.eval_epoch(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)), opt)
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29579", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device(DEV))
         try:
             gal = CountingGallery(list(vids))
             got = ev.eval_epoch_sharded(m, gal, synth.ListDataset(list(txts)), opt)
@@ -198,7 +190,7 @@ def test_eval_epoch_sharded_edge_cases(recwarn):
             fused, s0, s1, _ = ev.score_queries(m, synth.ListDataset(list(txts)), opt, ctx)
             assert fused.shape == (len(txts), 0) and ctx["_packed"].nv == 0
         finally:
-            pass                                     # (no teardown of the RCCL group: conftest.in_child_process)
+            torch.cuda.synchronize()
     assert got == pytest.approx(ref)
     assert not [w for w in recwarn.list if "video_ids" in str(w.message)]
 

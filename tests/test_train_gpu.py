@@ -786,3 +786,84 @@ def test_video_tower_skips_the_padding_in_parity_mode():
         assert torch.isfinite(ga[n]).all(), n
         scale = gb[n].abs().max().item()
         assert (ga[n] - gb[n]).abs().max().item() <= 2e-5 * max(scale, 1e-6) + 1e-8, (n, scale)
+
+
+@pytest.mark.parametrize("nq,Lq", [(640, 30), (257, 24), (1, 30), (1, 1), (5, 1), (7, 30), (642, 8), (3, 17)])
+def test_modular_pooling_backward_vs_oracle_fp64(nq, Lq):
+    """get_modularized_queries (method/model.py:245-258) backward: `modpool_bwd_kernel` (four queries per workgroup, the dw parts
+    added in LDS before the atomics) against the fp64 oracle's autograd - at the TVR batch's 640 queries, at query counts that are
+    not a multiple of 4, with one query, and at the word-count edges (1 word: the softmax is the constant 1 and dw = 0; 30 words =
+    max_desc_l).  Run twice: dh must be bit-identical (no atomics in it), dw - accumulated with fp32 atomics across workgroups -
+    equal up to the order of the sums."""
+    from dldkd_amd import functional as F_
+    gen = torch.Generator().manual_seed(1000 + 31 * nq + Lq)
+    h = torch.randn(nq, Lq, 384, generator=gen)
+    lens = torch.randint(1, Lq + 1, (nq,), generator=gen)
+    lens[0] = Lq
+    if nq > 2:
+        lens[1] = 1
+    mask = (torch.arange(Lq).unsqueeze(0) < lens.unsqueeze(1)).float()
+    w = torch.randn(1, 384, generator=gen) * 0.2
+    cot = torch.randn(nq, 384, generator=gen)
+    ho, wo = h.double().requires_grad_(True), w.double().requires_grad_(True)
+    out_o = orc.modular_pool(ho, mask.double(), wo)
+    (out_o * cot.double()).sum().backward()
+    res = []
+    for _ in range(2):
+        hg, wg = h.to(DEV).requires_grad_(True), w.reshape(-1).to(DEV).requires_grad_(True)
+        out = F_.modpool(hg, mask.to(DEV), wg)
+        assert (out.double().cpu() - out_o.detach().reshape(out.shape)).abs().max() < 2e-5
+        (out * cot.to(DEV)).sum().backward()
+        res.append((hg.grad.clone(), wg.grad.clone()))
+    dh, dw = res[0]
+    assert torch.equal(dh, res[1][0])
+    href, wref = ho.grad, wo.grad.reshape(-1)
+    assert (dh.double().cpu() - href).abs().max().item() <= 2e-5 * max(href.abs().max().item(), 1.0)
+    # gradients of masked words are exactly zero, as the reference's mask_logits (-1e10) leaves them
+    assert float((dh.cpu() * (1 - mask)[..., None]).abs().max()) == 0.0
+    scale = max(wref.abs().max().item(), 1e-6)
+    for got in (dw, res[1][1]):
+        assert (got.double().cpu() - wref).abs().max().item() <= 2e-4 * scale + 1e-6
+    assert (dw - res[1][1]).abs().max().item() <= 1e-5 * scale + 1e-7
+
+
+def test_fused_branch_losses_scale_by_upstream_gradients_once():
+    """functional._BranchLoss hands out gradients computed for an upstream gradient of 1 and scales them in the backward pass: with
+    NON-unit upstream gradients the result must be the weighted sum of the terms' own gradients, and a second backward pass through
+    the same node (retain_graph=True) - which would scale the saved tensors twice - raises."""
+    from dldkd_amd import functional as F_
+    rs = np.random.RandomState(5)
+    nv = 12
+    counts = sorted(rs.randint(1, 4, size=nv).tolist(), reverse=True)
+    labels = [i for i, c in enumerate(counts) for _ in range(c)]
+    nq, L = len(labels), 20
+    lens_np = rs.randint(1, L + 1, size=nv)
+    g = torch.Generator().manual_seed(42)
+    lab = _lab(labels)
+    lens = torch.from_numpy(lens_np).int().to(DEV)
+    cos = torch.tanh(torch.randn(nq, nv, generator=g)).to(DEV)
+    raw = (torch.randn(nq, nv, generator=g) * 3.0).to(DEV)
+    tch = (torch.randn(nq, nv, generator=g) * 3.0).to(DEV)
+    clip_p = (torch.randn(nq, L, generator=g) * 0.5).to(DEV)
+    clip_t = (torch.randn(nq, L, generator=g) * 0.5).to(DEV)
+    torch.manual_seed(3)
+    r_v2t, r_t2v = orc.draw_triplet_randoms(labels, nv, True, 20)
+    r_t2v = r_t2v.int().to(DEV)
+    r_v2t = None if r_v2t is None else r_v2t.int().to(DEV)
+
+    def run(weights, retain=False):
+        C, S, P = cos.clone().requires_grad_(True), raw.clone().requires_grad_(True), clip_p.clone().requires_grad_(True)
+        terms = F_.branch_losses(C, S, tch, P, clip_t, lab, lens, r_t2v, r_v2t, True, 0.1, True, 0.8, 0.8, 0.04, 0.1, False)
+        total = sum(w_ * t for w_, t in zip(weights, terms) if w_ is not None)
+        total.backward(retain_graph=retain)
+        return [x.grad.clone() if x.grad is not None else torch.zeros_like(x) for x in (C, S, P)], total, [float(t) for t in terms]
+
+    wts = (2.0, -3.0, 0.5)
+    got, total, vals = run(wts, retain=True)
+    parts = [run(tuple(1.0 if i == j else None for i in range(3)))[0] for j in range(3)]
+    for k in range(3):
+        ref = sum(w_ * parts[j][k] for j, w_ in enumerate(wts))
+        assert (got[k] - ref).abs().max().item() <= 1e-6 * max(ref.abs().max().item(), 1e-3), k
+    assert all(np.isfinite(v) for v in vals) and vals[0] > 0
+    with pytest.raises(RuntimeError, match="second backward"):
+        total.backward()

@@ -5,7 +5,6 @@ import types
 
 import numpy as np
 import pytest
-from conftest import in_child_process
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -130,23 +129,21 @@ def test_throughput_mode_training_learns_like_parity_mode(tmp_path):
     assert max(s_got[1:]) > s_got[0] + 20 and max(s_got[1:]) >= max(s_ref[1:]) - 25, (s_got, s_ref)
 
 
-@in_child_process
-def test_data_parallel_step_on_one_rank_rccl_group(tmp_path):
-    """The DDP branch of train_step (flat gradient bucket all-reduced over RCCL) with a one-rank group forced on:
+def test_data_parallel_step_on_one_rank_rccl_group(tmp_path, rccl_comm):
+    """The DDP branch of train_step (flat gradient bucket all-reduced over RCCL) with a one-rank communicator forced on:
     identical history to the plain run (mean over one rank is the identity)."""
-    import os
-    import torch.distributed as dist
     from dldkd_amd import train as T
-    ref = _fit("fp32", tmp_path)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", RANK="0", WORLD_SIZE="1")
-    dist.init_process_group("nccl", device_id=torch.device(DEV))
     old = T.DDP_MIN_WORLD
+    T.DDP_MIN_WORLD = 2
+    try:
+        ref = _fit("fp32", tmp_path)                      # the one-rank communicator is installed, the data-parallel branch is off
+    finally:
+        T.DDP_MIN_WORLD = old
     T.DDP_MIN_WORLD = 1
     try:
         got = _fit("fp32", tmp_path)
     finally:
         T.DDP_MIN_WORLD = old
-        pass                                     # (no teardown of the RCCL group: conftest.in_child_process)
     for a, b in zip(got[1:], ref[1:]):
         # not bitwise: split-K weight gradients and LayerNorm gamma/beta gradients accumulate with fp32 atomics, whose
         # order differs run to run; the difference stays at rounding level over the five epochs
@@ -263,15 +260,12 @@ def test_graphed_step_serves_variable_length_batches_from_a_few_graphs():
 
 
 @pytest.mark.parametrize("drop", [0.0, 0.2])
-@in_child_process
-def test_data_parallel_stepper_runs_the_step_as_a_chain_of_graph_segments(drop):
+def test_data_parallel_stepper_runs_the_step_as_a_chain_of_graph_segments(drop, rccl_comm):
     """Data parallel (one-rank RCCL group forced on, gradient buckets per tower): the stepper replays the step as a chain of
     graphs - one per tower of the backward pass, each tower's all-reduce issued from the comm stream behind its segment - plus
     the optimizer graph.  Against the plain single-graph stepper on the same seeds: same loss and parameters after every
     step (a mean over one rank is the identity), with dropout too; eager data-parallel steps (phased backward) agree as well."""
-    import os
     import synth
-    import torch.distributed as dist
     from dldkd_amd import train as T
     from dldkd_amd.model import DLDKD
     from dldkd_amd.optimization import BertAdam
@@ -304,10 +298,9 @@ def test_data_parallel_stepper_runs_the_step_as_a_chain_of_graph_segments(drop):
         dst_o.step_count = src_o.step_count
 
     mp_, op_ = make(False)
-    plain = T.GraphedTrainStep(mp_, op_, topt)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29595", RANK="0", WORLD_SIZE="1")
-    dist.init_process_group("nccl", device_id=torch.device(DEV))
     old = T.DDP_MIN_WORLD
+    T.DDP_MIN_WORLD = 2
+    plain = T.GraphedTrainStep(mp_, op_, topt)
     T.DDP_MIN_WORLD = 1
     try:
         md, od = make(True)
@@ -336,7 +329,6 @@ def test_data_parallel_stepper_runs_the_step_as_a_chain_of_graph_segments(drop):
         assert len(e.segments) == 4 and e.opt_graph is not None
     finally:
         T.DDP_MIN_WORLD = old
-        pass                                     # (no teardown of the RCCL group: conftest.in_child_process)
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
