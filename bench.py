@@ -332,18 +332,18 @@ def extras(dev):
         fold = ops.FoldedInProj([m.visual_input_proj, m.exp_visual_input_proj])
         def k4_ms():                                   # median of 10 single launches after 3 warm-ups (HIP events)
             for _ in range(3):
-                ops.in_proj_bf16(xk, fold)
+                ops.in_proj_h16(xk, fold)
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
             evs[0].record()
             for i in range(10):
-                ops.in_proj_bf16(xk, fold)
+                ops.in_proj_h16(xk, fold)
                 evs[i + 1].record()
             torch.cuda.synchronize()
             return sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(10))[5]
         ms = k4_ms()
         byts = 400000 * 3072 * 4 + 400000 * 768 * 4 + 768 * 3072 * 2
         out["k4_in_proj_roofline"] = {"bound": "hbm", "achieved": byts / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
-                                      "frac": byts / ms / 1e6 / 8000.0, "kernel": "in_proj_rows128_kernel (dldkd_in_proj_bf16_rows128)", "kernel_ms": ms,
+                                      "frac": byts / ms / 1e6 / 8000.0, "kernel": "in_proj_rows128_kernel (dldkd_in_proj_h16_rows128)", "kernel_ms": ms,
                                       "shape": "400000 rows x 3072 fp32 -> 2 x 384 fp32", "timing": "median of 10 launches after 3 warm-ups"}
         # K4b on the same rows in their resident form (bf16 + row statistics): 307 -> 560 flop per byte, the MFMA pipe is its bound
         tab = ops.ResidentRows(3072, dev, 400000)
@@ -364,7 +364,7 @@ def extras(dev):
         flops = 2.0 * 400000 * 3072 * 768
         bytes_b = 400000 * 3072 * 2 + 400000 * 8 + 400000 * 768 * 4 + 768 * 3072 * 2
         out["k4b_in_proj_roofline"] = {"bound": "mfma", "achieved": flops / msb / 1e9, "peak": 2500.0, "unit": "TFLOP/s",
-                                       "frac": flops / msb / 1e9 / 2500.0, "kernel": "in_proj_rows128b_kernel (dldkd_in_proj_bf16_rows128b)",
+                                       "frac": flops / msb / 1e9 / 2500.0, "kernel": "in_proj_rows128b_kernel (dldkd_in_proj_h16_rows128b)",
                                        "kernel_ms": msb, "shape": "400000 rows x 3072 bf16 (+ mean, rstd) -> 2 x 384 fp32",
                                        "algorithmic_GB": bytes_b / 1e9, "hbm_GBps": bytes_b / msb / 1e6,
                                        "same_rows_fp32_k4_ms": ms, "timing": "median of 10 launches after 3 warm-ups"}

@@ -23,6 +23,30 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __builtin_bit_cast(float, static_cast<unsigned int>(b) << 16);
 }
 
+// ---- h16: the 16-bit operand format of the EVAL-path towers (input projection K4 / K4b, fused tower K5, the resident feature
+// table and the h0 rows between K4b and K5) is IEEE fp16, not bf16.  Same MFMA rate (v_mfma_f32_32x32x16_f16), three more mantissa
+// bits: rounding an operand costs 2^-12 relative instead of 2^-9.  Measured on the trained TVR-dims model (tools/rk_stage_probe.py,
+// tools/emu_operand_format.py; profiles/r05/): with bf16 operands the K = 3072 input projection alone moved the fused scores by
+// 1.8e-4 (mean) and the whole throughput path by 2.4e-4 - 13 of 8,192 queries crossed the R@100 cut, a coin flip away from
+// north_star's +-0.1 gate; with fp16 operands the path sits at 7.7e-5, the bf16 SCORER's own rounding (K1 keeps bf16 operands:
+// BASELINE's named dtype, rows L2-normalised in fp32 first).  Range: every operand of these kernels is a LayerNorm output, a
+// weight, a probability or an L2-normalised feature (|x| <= ~20 measured, fp16 holds 65504; below 6e-5 precision tapers off
+// where the values no longer matter).  Training keeps bf16 (gradients need the exponent range).  The containers stay `short`
+// vectors (bf16x8): only the conversions and the MFMA opcode differ.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned short f32_to_h16_bits(float x) {       // round to nearest even (v_cvt_f16_f32 / v_cvt_pk_f16_f32)
+    return __builtin_bit_cast(unsigned short, static_cast<_Float16>(x));
+}
+__device__ __forceinline__ float h16_bits_to_f32(unsigned short b) { return static_cast<float>(__builtin_bit_cast(_Float16, b)); }
+// two fp32 -> one dword of two h16 (lo = a, hi = b)
+__device__ __forceinline__ unsigned h16_pack2(float a, float b) {
+    unsigned u;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u) : "v"(a), "v"(b));
+    return u;
+}
+#define DLDKD_H16_MFMA32 "v_mfma_f32_32x32x16_f16"
+#define DLDKD_H16_CVT_PK "v_cvt_pk_f16_f32"
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

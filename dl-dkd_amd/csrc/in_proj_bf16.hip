@@ -36,9 +36,9 @@ __global__ __launch_bounds__(256) void fold_ln_linear_kernel(const float* __rest
     float s = 0.f, t = 0.f;
     for (int k = lane; k < K; k += 64) {
         const float w = W[(size_t)n * K + k];
-        const unsigned short h = f32_to_bf16_bits(w * gamma[k]);
+        const unsigned short h = f32_to_h16_bits(w * gamma[k]);
         Wf[(size_t)n * K + k] = h;
-        s += bf16_bits_to_f32(h);
+        s += h16_bits_to_f32(h);
         t += w * beta[k];
     }
     s = wave_sum(s);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void in_proj_bf16_kernel(const InProjArgs p) {
                 const float v = rx[2 * g + (e >> 2)][e & 3];
                 sum += v;
                 sq += v * v;
-                h[e] = (short)f32_to_bf16_bits(v);
+                h[e] = (short)f32_to_h16_bits(v);
             }
             *reinterpret_cast<bf16x8*>(a + 8 * g) = h;
         }
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void in_proj_bf16_kernel(const InProjArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
@@ -208,10 +208,10 @@ __global__ __launch_bounds__(256) void fold_ln_linear_frag_kernel(const float* _
     float s = 0.f, t = 0.f;
     for (int k = lane; k < K; k += 64) {
         const float w = W[(size_t)n * K + k];
-        const unsigned short h = f32_to_bf16_bits(gamma ? w * gamma[k] : w);
+        const unsigned short h = f32_to_h16_bits(gamma ? w * gamma[k] : w);
         const int kt = k >> 5, kk = (k >> 4) & 1, half = (k >> 3) & 1, j = k & 7;
         Wfrag[((((size_t)kt * (fn / 32) + ct) * 2 + kk) * 64 + half * 32 + col) * 8 + j] = h;
-        s += bf16_bits_to_f32(h);
+        s += h16_bits_to_f32(h);
         if (beta) t += w * beta[k];
     }
     s = wave_sum(s);
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void rows_linear_bf16_kernel(const InProjAr
                 sum += v;
                 sq += v * v;
             }
-            h[e] = (short)f32_to_bf16_bits(v);
+            h[e] = (short)f32_to_h16_bits(v);
         }
         *reinterpret_cast<bf16x8*>(Al + buf * FBM * FPITCH + xrow * FPITCH + xq * 8) = h;
     };
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void rows_linear_bf16_kernel(const InProjAr
             for (int i = 0; i < RT; ++i) {   // one A fragment live at a time: 192 accumulators leave little room
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (32 * i + (lane & 31)) * FPITCH + kk * 16 + (lane >> 5) * 8);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
             }
         }
         if (kt + 1 < nk) xstore(cur ^ 1);
@@ -387,7 +387,7 @@ using namespace dldkd;
 
 extern "C" {
 
-int dldkd_fold_ln_linear_bf16(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+int dldkd_fold_ln_linear_h16(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
                               void* Wf, float* cs, float* bb, void* stream) {
     if (N < 1 || K < 1) { set_error("fold_ln_linear: bad sizes"); return DLDKD_EINVAL; }
     if (!W || !gamma || !beta || !Wf || !cs || !bb) { set_error("fold_ln_linear: null pointer"); return DLDKD_EINVAL; }
@@ -396,25 +396,25 @@ int dldkd_fold_ln_linear_bf16(const float* W, const float* bias, const float* ga
     return check_launch("fold_ln_linear");
 }
 
-int dldkd_in_proj_bf16(const float* x, const void* Wf, const float* cs, const float* bb, float* y0, float* y1, long M, int N,
+int dldkd_in_proj_h16(const float* x, const void* Wf, const float* cs, const float* bb, float* y0, float* y1, long M, int N,
                        int K, float eps, int relu, void* stream) {
     if (M < 0 || (N != kHidden && N != 2 * kHidden) || K < PBK || (K % PBK)) {
-        set_error("in_proj_bf16: need N = 384 or 768 and K a multiple of %d (got M=%ld N=%d K=%d)", PBK, M, N, K);
+        set_error("in_proj_h16: need N = 384 or 768 and K a multiple of %d (got M=%ld N=%d K=%d)", PBK, M, N, K);
         return DLDKD_EINVAL;
     }
     if (M == 0) return DLDKD_OK;
-    if (!x || !Wf || !cs || !bb || !y0 || (N == 2 * kHidden && !y1)) { set_error("in_proj_bf16: null pointer"); return DLDKD_EINVAL; }
+    if (!x || !Wf || !cs || !bb || !y0 || (N == 2 * kHidden && !y1)) { set_error("in_proj_h16: null pointer"); return DLDKD_EINVAL; }
     InProjArgs p{x, (const bf16x8*)Wf, cs, bb, {y0, y1}, M, N, K, eps, relu, kHidden, 0};
     const unsigned rows = (unsigned)((M + PBM - 1) / PBM);
     // 128-column tiles (6 for two branches).  Measured at M = 400k, K = 3072: BN 128 / BK 32 = 4.9 ms (1252 GB/s,
     // 384 TFLOP/s); BN 256 / BK 64 = 5.6 ms (one workgroup per CU at 255 VGPRs).
     constexpr int lds = (2 * PBM * PITCH + 2 * 128 * PITCH) * 2;
     DLDKD_LAUNCH(in_proj_bf16_kernel<128>, dim3(N / 128, rows), dim3(256), lds, (hipStream_t)stream, p);
-    return check_launch("in_proj_bf16");
+    return check_launch("in_proj_h16");
 }
 
 
-int dldkd_fold_ln_linear_bf16_frag(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+int dldkd_fold_ln_linear_h16_frag(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
                                    int n_offset, void* Wfrag, float* cs, float* bb, void* stream) {
     if (N < 1 || K < FBK || (K % FBK) || n_offset < 0 || n_offset + N > FN || (n_offset % 32)) {
         set_error("fold_ln_linear_frag: need K a multiple of %d and columns inside [0, %d)", FBK, FN);
@@ -441,7 +441,7 @@ int dldkd_pack_linear_bf16_frag(const float* W, const float* bias, int N, int K,
     return check_launch("pack_linear_frag");
 }
 
-int dldkd_linear_rows_bf16(const float* x, const void* Wfrag, const float* bb, void* y0, void* y1, int ldy, long M, int N, int K,
+int dldkd_linear_rows_h16(const float* x, const void* Wfrag, const float* bb, void* y0, void* y1, int ldy, long M, int N, int K,
                            int relu, int out_bf16, void* stream) {
     if (M < 0 || (N != 384 && N != 768) || K < FBK || (K % FBK) || ldy < 384 || (out_bf16 && (ldy & 7))) {
         set_error("linear_rows_bf16: need N = 384 or 768, K a multiple of %d, ldy >= 384 (M=%ld N=%d K=%d ldy=%d)", FBK, M, N, K, ldy);
@@ -467,7 +467,7 @@ int dldkd_linear_rows_bf16(const float* x, const void* Wfrag, const float* bb, v
     return check_launch("linear_rows_bf16");
 }
 
-int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1, long M,
+int dldkd_in_proj_h16_full(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1, long M,
                             int K, float eps, int relu, void* stream) {
     if (M < 0 || K < FBK || (K % FBK)) { set_error("in_proj_bf16_full: K must be a multiple of %d", FBK); return DLDKD_EINVAL; }
     if (M == 0) return DLDKD_OK;

@@ -1,6 +1,6 @@
 // K4, second generation: y = ReLU( LayerNorm(x) . W^T + b ) for the raw clip / word features, both branches (768 output
 // columns) in ONE pass over the fp32 rows.  Replaces LinearLayer.forward (reference method/model_components.py:305-312) on the
-// inference path, like rows_linear_bf16_kernel<1, true> (in_proj_bf16.hip), whose limits this kernel is built around
+// inference path, like rows_linear_bf16_kernel<1, true> (in_proj_h16.hip), whose limits this kernel is built around
 // (profiles/r01/ablation_k4_in_proj.md): 0.58 LDS fragment reads per MFMA and 8 waves in lock-step around a barrier with one
 // k-tile of loads in flight.  The kernel needs ~1.1 PFLOP/s to move 3.6 TB/s (307 flop per byte), i.e. the MFMA pipe busy
 // ~45 % of the time with ONE wave per SIMD - so every load has to be in flight long before it is needed, and nothing that is
@@ -64,13 +64,13 @@ struct Rows128Args {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// 8 fp32 -> one bf16 MFMA fragment: 4 v_cvt_pk_bf16_f32, pinned where they are written (between two MFMAs)
+// 8 fp32 -> one h16 (fp16: common.hpp) MFMA fragment: 4 v_cvt_pk_f16_f32, pinned where they are written (between two MFMAs)
 __device__ __forceinline__ void cvt8(u32x4& dst, const f32x4& lo, const f32x4& hi) {
     unsigned u0, u1, u2, u3;
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u0) : "v"(lo[0]), "v"(lo[1]));
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u1) : "v"(lo[2]), "v"(lo[3]));
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u2) : "v"(hi[0]), "v"(hi[1]));
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u3) : "v"(hi[2]), "v"(hi[3]));
+    asm volatile(DLDKD_H16_CVT_PK " %0, %1, %2" : "=v"(u0) : "v"(lo[0]), "v"(lo[1]));
+    asm volatile(DLDKD_H16_CVT_PK " %0, %1, %2" : "=v"(u1) : "v"(lo[2]), "v"(lo[3]));
+    asm volatile(DLDKD_H16_CVT_PK " %0, %1, %2" : "=v"(u2) : "v"(hi[0]), "v"(hi[1]));
+    asm volatile(DLDKD_H16_CVT_PK " %0, %1, %2" : "=v"(u3) : "v"(hi[2]), "v"(hi[3]));
     dst = u32x4{u0, u1, u2, u3};
 }
 
@@ -83,10 +83,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 __device__ __forceinline__ void mfma_agpr(f32x16& acc, const u32x4& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    asm volatile(DLDKD_H16_MFMA32 " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_vgpr(f32x16& acc, const u32x4& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    asm volatile(DLDKD_H16_MFMA32 " %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 // LDS-DMA, 16 B per lane: global address = scalar base + 32-bit lane offset + immediate (no 64-bit VALU add in the MFMA shadow),
 // LDS destination = wave-uniform lds_base (-> M0) + the SAME immediate + lane * 16.  hipcc treats M0 as reserved and re-materialises it before each
@@ -451,18 +451,18 @@ static int launch_rows128(const float* x, const void* Wfrag, const float* cs, co
     return check_launch("in_proj_bf16_rows128");
 }
 
-extern "C" int dldkd_in_proj_bf16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
+extern "C" int dldkd_in_proj_h16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                           long M, int K, float eps, int relu, void* stream) {
     return launch_rows128(x, Wfrag, cs, bb, y0, y1, M, K, eps, relu, nullptr, stream);
 }
 
-extern "C" int dldkd_in_proj_bf16_rows128_groups(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
+extern "C" int dldkd_in_proj_h16_rows128_groups(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                                  long M, int K, float eps, int relu, const int32_t* groups, long n_groups, void* stream) {
     if (!groups) { set_error("in_proj_bf16_rows128_groups: null group table"); return DLDKD_EINVAL; }
     return launch_rows128(x, Wfrag, cs, bb, y0, y1, M, K, eps, relu, nullptr, stream, groups, n_groups);
 }
 
-extern "C" int dldkd_in_proj_bf16_rows128_ok(int K) { return K >= 4 * RK && K % (2 * RK) == 0 && (long)127 * K * 4 + 128 <= 0xFFFFFFFFL; }
+extern "C" int dldkd_in_proj_h16_rows128_ok(int K) { return K >= 4 * RK && K % (2 * RK) == 0 && (long)127 * K * 4 + 128 <= 0xFFFFFFFFL; }
 
 // Diagnostics: the same kernel with clock stamps; stamps = 12 x u64 per workgroup (tools/k4_timeline.py).
 extern "C" int dldkd_debug_in_proj_rows128_timeline(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0,

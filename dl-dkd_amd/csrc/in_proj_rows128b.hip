@@ -1,6 +1,6 @@
 // K4b: the two-branch input projection y = ReLU( LayerNorm(x) . W^T + b ) (LinearLayer.forward, reference
 // method/model_components.py:305-312) on rows that are ALREADY stored the way the MFMA consumes them: bf16 features plus
-// the row's fp32 LayerNorm statistics, both written once by the ingest pass (dldkd_rows_to_bf16_stats, ingest.hip) when a
+// the row's fp32 LayerNorm statistics, both written once by the ingest pass (dldkd_rows_to_h16_stats, ingest.hip) when a
 // dataset's raw features become device-resident.  in_proj_rows128_kernel (K4) reads fp32 rows and spends its issue slots on
 // what this kernel no longer does: 16 fp32 fragment reads + 32 v_cvt_pk_bf16_f32 + the branch-free LayerNorm sums per k-step,
 // against 48 MFMAs (profiles/r02/ablation_k4_rows128.md: issue-bound at 1.38 GHz).  Here a k-step is 48 MFMAs + 8 A-fragment
@@ -33,11 +33,11 @@ struct Args {
     const unsigned short* x;   // (M, K) bf16
     const float* mean;         // (M)
     const float* rstd;         // (M)
-    const char* Wf;            // [k-step][24 column tiles][2][64][8] bf16 (dldkd_fold_ln_linear_bf16_frag)
+    const char* Wf;            // [k-step][24 column tiles][2][64][8] bf16 (dldkd_fold_ln_linear_h16_frag)
     const float* cs;           // [768] colsum of W'
     const float* bb;           // [768] W.beta + b
     float* y[2];               // columns [0, 384) -> y[0], [384, 768) -> y[1]; row stride 384
-    int y16;                   // y[] are bf16 rows (row stride 384 bf16) - what the fused tower reads (dldkd_tower_seq_bf16_h16)
+    int y16;                   // y[] are bf16 rows (row stride 384 bf16) - what the fused tower reads (dldkd_tower_seq_h16_rows16)
     long M;
     int K;
     int relu;
@@ -56,10 +56,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 __device__ __forceinline__ void mfma_agpr(f32x16& acc, const u32x4& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    asm volatile(DLDKD_H16_MFMA32 " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_vgpr(f32x16& acc, const u32x4& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    asm volatile(DLDKD_H16_MFMA32 " %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void glds_m0(uint32_t lds_base) { asm volatile("s_mov_b32 m0, %0" : : "s"(lds_base) : "memory"); }
 template <int OFF>                      // M0 set at least one instruction earlier by glds_m0
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128b_kernel(const Args p) 
                             if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
                             const float give = odd ? v0 : v1;                       // what the partner lane needs
                             const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
-                            const unsigned lo = f32_to_bf16_bits(odd ? got : v0), hi = f32_to_bf16_bits(odd ? v1 : got);
+                            const unsigned lo = f32_to_h16_bits(odd ? got : v0), hi = f32_to_h16_bits(odd ? v1 : got);
                             if (inside) gstore32<64 * j>(vo16, __builtin_bit_cast(float, lo | (hi << 16)), yg);
                         });
                     });
@@ -380,19 +380,19 @@ __global__ __launch_bounds__(256, 1) void in_proj_rows128b_kernel(const Args p) 
 
 using namespace dldkd;
 
-extern "C" int dldkd_in_proj_bf16_rows128b_ok(int K) { return K >= 8 * k4b::RK && K % (2 * k4b::RK) == 0 && (long)127 * K * 2 + 128 <= 0xFFFFFFFFL; }
+extern "C" int dldkd_in_proj_h16_rows128b_ok(int K) { return K >= 8 * k4b::RK && K % (2 * k4b::RK) == 0 && (long)127 * K * 2 + 128 <= 0xFFFFFFFFL; }
 
 static int rows128b_launch(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
                            const float* bb, void* y0, void* y1, int y16, long M, int K, int relu, const int32_t* groups,
                            long n_groups, void* stream);
 
-extern "C" int dldkd_in_proj_bf16_rows128b(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
+extern "C" int dldkd_in_proj_h16_rows128b(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
                                            const float* bb, float* y0, float* y1, long M, int K, int relu, const int32_t* groups,
                                            long n_groups, void* stream) {
     return rows128b_launch(x_bf16, mean, rstd, Wfrag, cs, bb, y0, y1, 0, M, K, relu, groups, n_groups, stream);
 }
 
-extern "C" int dldkd_in_proj_bf16_rows128b_out16(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
+extern "C" int dldkd_in_proj_h16_rows128b_out16(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
                                                  const float* bb, void* y0_bf16, void* y1_bf16, long M, int K, int relu,
                                                  const int32_t* groups, long n_groups, void* stream) {
     return rows128b_launch(x_bf16, mean, rstd, Wfrag, cs, bb, y0_bf16, y1_bf16, 1, M, K, relu, groups, n_groups, stream);
@@ -401,7 +401,7 @@ extern "C" int dldkd_in_proj_bf16_rows128b_out16(const void* x_bf16, const float
 static int rows128b_launch(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
                            const float* bb, void* y0, void* y1, int y16, long M, int K, int relu, const int32_t* groups,
                            long n_groups, void* stream) {
-    if (M < 0 || !dldkd_in_proj_bf16_rows128b_ok(K)) {
+    if (M < 0 || !dldkd_in_proj_h16_rows128b_ok(K)) {
         set_error("in_proj_bf16_rows128b: K must be a multiple of %d, at least %d (M=%ld K=%d)", 2 * k4b::RK, 8 * k4b::RK, M, K);
         return DLDKD_EINVAL;
     }

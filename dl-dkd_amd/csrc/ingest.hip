@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void gather_pad_rows_kernel(const float* __res
 // fp32 values (two passes: mean, then the centred second moment - torch's LayerNorm, method/model_components.py:297,308).
 // Valid rows of a padded (n_items, L, K) batch are APPENDED to a ragged table: item b's row l < lens[b] goes to table row
 // dst_row0[b] + l.  One wave per source row; the second pass re-reads the row from L1 / L2.
-__global__ __launch_bounds__(256) void rows_to_bf16_stats_kernel(const float* __restrict__ src, const int32_t* __restrict__ lens,
+__global__ __launch_bounds__(256) void rows_to_h16_stats_kernel(const float* __restrict__ src, const int32_t* __restrict__ lens,
                                                                  const long long* __restrict__ dst_row0, unsigned short* __restrict__ xb,
                                                                  float* __restrict__ mean, float* __restrict__ rstd, long n_rows, int L,
                                                                  int K, float eps) {
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void rows_to_bf16_stats_kernel(const float* __
         const float d0 = v[0] - mu, d1 = v[1] - mu, d2 = v[2] - mu, d3 = v[3] - mu;
         sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         uint2 pk;
-        pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-        pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        pk.x = (unsigned)f32_to_h16_bits(v[0]) | ((unsigned)f32_to_h16_bits(v[1]) << 16);     // h16 = fp16 (common.hpp)
+        pk.y = (unsigned)f32_to_h16_bits(v[2]) | ((unsigned)f32_to_h16_bits(v[3]) << 16);
         o[c] = pk;
     }
     const float var = wave_sum(sq) / (float)K;
@@ -113,16 +113,16 @@ __global__ __launch_bounds__(256) void rows_to_bf16_stats_kernel(const float* __
 
 using namespace dldkd;
 
-extern "C" int dldkd_rows_to_bf16_stats(const float* src, const int32_t* lens, const long long* dst_row0, int n_items, int L, int K,
+extern "C" int dldkd_rows_to_h16_stats(const float* src, const int32_t* lens, const long long* dst_row0, int n_items, int L, int K,
                                         float eps, void* x_bf16, float* mean, float* rstd, void* stream) {
-    if (n_items < 0 || L < 0 || K < 4 || (K & 3)) { set_error("rows_to_bf16_stats: bad sizes (K must be a multiple of 4)"); return DLDKD_EINVAL; }
+    if (n_items < 0 || L < 0 || K < 4 || (K & 3)) { set_error("rows_to_h16_stats: bad sizes (K must be a multiple of 4)"); return DLDKD_EINVAL; }
     const long n_rows = (long)n_items * L;
     if (n_rows == 0) return DLDKD_OK;
-    if (!src || !x_bf16 || !mean || !rstd) { set_error("rows_to_bf16_stats: null pointer"); return DLDKD_EINVAL; }
-    if (((uintptr_t)src & 15) || ((uintptr_t)x_bf16 & 7)) { set_error("rows_to_bf16_stats: unaligned buffer"); return DLDKD_EINVAL; }
-    DLDKD_LAUNCH(rows_to_bf16_stats_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, lens, dst_row0,
+    if (!src || !x_bf16 || !mean || !rstd) { set_error("rows_to_h16_stats: null pointer"); return DLDKD_EINVAL; }
+    if (((uintptr_t)src & 15) || ((uintptr_t)x_bf16 & 7)) { set_error("rows_to_h16_stats: unaligned buffer"); return DLDKD_EINVAL; }
+    DLDKD_LAUNCH(rows_to_h16_stats_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, lens, dst_row0,
                        (unsigned short*)x_bf16, mean, rstd, n_rows, L, K, eps);
-    return check_launch("rows_to_bf16_stats");
+    return check_launch("rows_to_h16_stats");
 }
 
 extern "C" int dldkd_gather_pad_rows_f32(const float* src, const long long* row_start, const int32_t* lens, const int32_t* items,

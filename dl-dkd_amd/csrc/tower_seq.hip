@@ -101,13 +101,13 @@ __device__ __forceinline__ float half_swap_sum(float m) {
 __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
     bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (short)f32_to_bf16_bits(v[j]);
+    for (int j = 0; j < 8; ++j) o[j] = (short)f32_to_h16_bits(v[j]);          // h16 = fp16 operands (common.hpp)
     return o;
 }
 
 struct TowerArgs {
     const float* h0[2];       // per branch: input-projection output, rows (., 384) fp32 ...
-    const unsigned short* h0b[2];   // ... or (H16 kernels) the same rows as bf16, written so by K4b (dldkd_in_proj_bf16_rows128b_out16)
+    const unsigned short* h0b[2];   // ... or (H16 kernels) the same rows as bf16, written so by K4b (dldkd_in_proj_h16_rows128b_out16)
     const char* blob[2];      // per branch: weight fragments in stream order, the parameter table, the position table in
                               // fragment order
     const int32_t* row0;      // [n_seq] first row of the sequence in h0 / out; null: seq * seq_rows
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
                 const unsigned w[4] = {(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};   // feature pairs in order
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float hv = __builtin_bit_cast(float, (e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16));
+                    const float hv = h16_bits_to_f32((unsigned short)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu)));
                     const float v = hv + pz[k2][e >> 2][e & 3];
                     s += v;
                     q += v * v;
@@ -512,14 +512,14 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         static_for<0, kNKS>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value, n = decltype(n0c)::value + ks;
             pre(std::integral_constant<int, n>{});
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[n % kFr], X[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[n % kFr]), __builtin_bit_cast(f16x8, X[ks]), acc, 0, 0, 0);
         });
     };
     auto nprod = [&](auto n0c, f32x16& acc, const bf16x8 (&X)[kNKS]) {
         static_for<0, kNKS>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value, n = decltype(n0c)::value + ks;
             pre(std::integral_constant<int, n>{});
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[ks], fr[n % kFr], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, X[ks]), __builtin_bit_cast(f16x8, fr[n % kFr]), acc, 0, 0, 0);
         });
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
                 for (int e = 0; e < 16; ++e) sa[kt][e] = (kt == ntiles - 1 && (e & 3) + 8 * (e >> 2) >= krem) ? -INFINITY : 0.f;
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
-                    sa[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kl[((first + kt) * 6 + i) * 64 + lane], Qf[i], sa[kt], 0, 0, 0);
+                    sa[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Kl[((first + kt) * 6 + i) * 64 + lane]), __builtin_bit_cast(f16x8, Qf[i]), sa[kt], 0, 0, 0);
             }
         });
         // (key tiles past the sequence - 4 - ntiles of them, wave-uniform - take no part: no -inf fill, no max / exp / sum over them:
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
                     const bf16x8 pf = pack8(v);
 #pragma unroll
                     for (int dt = 0; dt < 3; ++dt)
-                        oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Vl[((first + kt) * 6 + 2 * dt + s) * 64 + lane], pf, oa[dt], 0, 0, 0);
+                        oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Vl[((first + kt) * 6 + 2 * dt + s) * 64 + lane]), __builtin_bit_cast(f16x8, pf), oa[dt], 0, 0, 0);
                 }
             }
         });
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float v = a[8 * s + j] + bf16_bits_to_f32((unsigned short)X1[2 * ot + s][j]);
+                const float v = a[8 * s + j] + h16_bits_to_f32((unsigned short)X1[2 * ot + s][j]);
                 s1 += v;
                 s2 += v * v;
                 val[ot][8 * s + j] = v;
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(256) void tower_pack_kernel(const PackArgs a) {
         }
         const int f = 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
         if (TW_FOLD_LN2 && n >= kQKVFrags + kSqFrags) sc = a.g2[f];             // out mapping: LayerNorm 2's gamma folded in (its beta: the bias below)
-        a.frags[i] = f32_to_bf16_bits(W[(size_t)(rowbase + (lane & 31)) * kHidden + f] * sc);
+        a.frags[i] = f32_to_h16_bits(W[(size_t)(rowbase + (lane & 31)) * kHidden + f] * sc);
     }
     if (i < P_TOTAL) {
         const int tab = (int)i / kHidden, x = (int)i % kHidden;
@@ -949,7 +949,7 @@ size_t dldkd_tower_blob_bytes(int with_out_map) {
     return nfrag * 1024 + (size_t)(tw::P_TOTAL + tw::P_TAIL + 4 * tw::kPosTile) * 4;
 }
 
-int dldkd_tower_pack_bf16(const float* ln1_g, const float* ln1_b, const float* wq, const float* bq, const float* wk, const float* bk,
+int dldkd_tower_pack_h16(const float* ln1_g, const float* ln1_b, const float* wq, const float* bq, const float* wk, const float* bk,
                           const float* wv, const float* bv, const float* wd, const float* bd, const float* ln2_g, const float* ln2_b,
                           const float* wo, const float* bo, const float* mod_w, const float* pos, int max_pos, void* blob, void* stream) {
     if (!ln1_g || !ln1_b || !wq || !bq || !wk || !bk || !wv || !bv || !wd || !bd || !ln2_g || !ln2_b || !blob || !pos || (!wo != !bo) ||
@@ -970,7 +970,7 @@ static int tower_seq_launch(const void* const* h0, int h16, const void* const* b
                             int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
                             void* stream);
 
-int dldkd_tower_seq_bf16(const float* const* h0, const void* const* blob, const int32_t* row0,
+int dldkd_tower_seq_h16(const float* const* h0, const void* const* blob, const int32_t* row0,
                          const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                          int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
                          void* stream) {
@@ -978,7 +978,7 @@ int dldkd_tower_seq_bf16(const float* const* h0, const void* const* blob, const 
                             gallery, v0, Lp, lens_out, stream);
 }
 
-int dldkd_tower_seq_bf16_h16(const void* const* h0_bf16, const void* const* blob, const int32_t* row0,
+int dldkd_tower_seq_h16_rows16(const void* const* h0_bf16, const void* const* blob, const int32_t* row0,
                              const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                              void* const* gallery, int v0, int Lp, int32_t* lens_out, void* stream) {
     return tower_seq_launch(h0_bf16, 1, blob, row0, lens, items, n_items, n_seq, n_branches, 1, nullptr, 0, gallery, v0, Lp, lens_out,

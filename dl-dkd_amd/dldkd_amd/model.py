@@ -120,7 +120,7 @@ class DLDKD(nn.Module):
         if kind not in self._folded:
             layers = [getattr(self, pre + kind + "_input_proj") for pre in (("", "exp_") if self.double_branch else ("",))]
             self._folded[kind] = ops.FoldedInProj(layers)
-        return ops.in_proj_bf16(feat.float().contiguous(), self._folded[kind], groups=groups)
+        return ops.in_proj_h16(feat.float().contiguous(), self._folded[kind], groups=groups)
 
     def _use_fast(self, feat):
         if self.training or torch.is_grad_enabled():
@@ -188,7 +188,7 @@ class DLDKD(nn.Module):
         if lens_host is not None:
             tables = [ops.plan_tower_items(lens_host)]
             if (L % 32 == 0 and self.double_branch and ops.INPROJ_KERNEL == "rows128"
-                    and native.lib().dldkd_in_proj_bf16_rows128_ok(frame_video_feat.shape[-1])):
+                    and native.lib().dldkd_in_proj_h16_rows128_ok(frame_video_feat.shape[-1])):
                 # the input projection visits only the 32-row groups that hold valid clips (the tower never reads the others)
                 tables.append(ops.plan_row_groups(lens_host, L))
             tables = self._upload_tables(tables, frame_video_feat.device)
@@ -218,7 +218,7 @@ class DLDKD(nn.Module):
             self._folded["visual"] = ops.FoldedInProj([self.visual_input_proj, self.exp_visual_input_proj])
         packs = self._tower_packs("visual")
         for (va, n, r0, r1, lens_d, row0_d, items) in res.chunks:
-            y = ops.in_proj_resident(res.table, r0, r1, self._folded["visual"], out_bf16=ops.RESIDENT_H0_BF16)
+            y = ops.in_proj_resident(res.table, r0, r1, self._folded["visual"], out_h16=ops.RESIDENT_H0_H16)
             v0 = packer.reserve(n, int(res.lens_host[va:va + n].max(initial=0)))
             if items.shape[0]:
                 ops.tower_seq(y, packs, lens_d, seq_rows=0, row0=row0_d, items=items, out_mode=1, gallery=packer.blobs, v0=v0,

@@ -149,29 +149,29 @@ SIGNATURES = {
                                              _c_float, _c_void_p]),
     "dldkd_gather_sumsq_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_count_above_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
-    "dldkd_fold_ln_linear_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
+    "dldkd_fold_ln_linear_h16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
                                             _c_void_p, _c_void_p]),
-    "dldkd_in_proj_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int,
+    "dldkd_in_proj_h16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int,
                                      _c_float, _c_int, _c_void_p]),
     "dldkd_segment_mean_l2norm_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_float, _c_void_p]),
     "dldkd_upload_words": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p]),
-    "dldkd_rows_to_bf16_stats": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_void_p,
+    "dldkd_rows_to_h16_stats": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_void_p,
                                            _c_void_p, _c_void_p]),
-    "dldkd_in_proj_bf16_rows128b": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+    "dldkd_in_proj_h16_rows128b": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                               _c_long, _c_int, _c_int, _c_void_p, _c_long, _c_void_p]),
-    "dldkd_in_proj_bf16_rows128b_out16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+    "dldkd_in_proj_h16_rows128b_out16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                               _c_long, _c_int, _c_int, _c_void_p, _c_long, _c_void_p]),
-    "dldkd_in_proj_bf16_rows128b_ok": (_c_int, [_c_int]),
+    "dldkd_in_proj_h16_rows128b_ok": (_c_int, [_c_int]),
     "dldkd_gather_pad_rows_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p,
                                             _c_void_p]),
-    "dldkd_fold_ln_linear_bf16_frag": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
+    "dldkd_fold_ln_linear_h16_frag": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
                                                  _c_void_p, _c_void_p, _c_void_p]),
-    "dldkd_in_proj_bf16_full": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
+    "dldkd_in_proj_h16_full": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
                                           _c_float, _c_int, _c_void_p]),
-    "dldkd_in_proj_bf16_rows128": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
+    "dldkd_in_proj_h16_rows128": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
                                              _c_float, _c_int, _c_void_p]),
-    "dldkd_in_proj_bf16_rows128_ok": (_c_int, [_c_int]),
-    "dldkd_in_proj_bf16_rows128_groups": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
+    "dldkd_in_proj_h16_rows128_ok": (_c_int, [_c_int]),
+    "dldkd_in_proj_h16_rows128_groups": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int,
                                                     _c_float, _c_int, _c_void_p, _c_long, _c_void_p]),
     "dldkd_row_meanrstd_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_float, _c_void_p]),
     "dldkd_linear_lngrad": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p,
@@ -189,7 +189,7 @@ SIGNATURES = {
                                                        _c_int, _c_float, _c_int, _c_void_p, _c_void_p]),
     "dldkd_attention_fwd_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "dldkd_pack_linear_bf16_frag": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
-    "dldkd_linear_rows_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_int, _c_int,
+    "dldkd_linear_rows_h16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_int, _c_int,
                                          _c_int, _c_int, _c_void_p]),
     "dldkd_pack_gallery_chunk_bf16": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
                                                 _c_int, _c_void_p]),
@@ -202,10 +202,10 @@ SIGNATURES = {
                          _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p, _c_void_p]),
     "dldkd_order_by_len_desc": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_tower_blob_bytes": (_c_size_t, [_c_int]),
-    "dldkd_tower_pack_bf16": (_c_int, [_c_void_p] * 16 + [_c_int, _c_void_p, _c_void_p]),
-    "dldkd_tower_seq_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+    "dldkd_tower_pack_h16": (_c_int, [_c_void_p] * 16 + [_c_int, _c_void_p, _c_void_p]),
+    "dldkd_tower_seq_h16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                       _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
-    "dldkd_tower_seq_bf16_h16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+    "dldkd_tower_seq_h16_rows16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                           _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_debug_tower_seq_timeline": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                                 _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p]),

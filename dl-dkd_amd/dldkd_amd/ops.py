@@ -230,12 +230,12 @@ class FoldedInProj:
             for b, l in enumerate(self.layers):
                 lin = l.net[1]
                 if self.full_row:
-                    native.check(L.dldkd_fold_ln_linear_bf16_frag(
+                    native.check(L.dldkd_fold_ln_linear_h16_frag(
                         native.ptr(lin.weight.detach().contiguous()), native.ptr(lin.bias.detach()),
                         native.ptr(l.LayerNorm.weight.detach()), native.ptr(l.LayerNorm.bias.detach()), HIDDEN, K, b * HIDDEN,
                         native.ptr(self.Wf), native.ptr(self.cs), native.ptr(self.bb), native.stream()), "fold_ln_linear_frag")
                     continue
-                native.check(L.dldkd_fold_ln_linear_bf16(
+                native.check(L.dldkd_fold_ln_linear_h16(
                     native.ptr(lin.weight.detach().contiguous()), native.ptr(lin.bias.detach()),
                     native.ptr(l.LayerNorm.weight.detach()), native.ptr(l.LayerNorm.bias.detach()), HIDDEN, K,
                     ctypes.c_void_p(self.Wf.data_ptr() + b * HIDDEN * K * 2), ctypes.c_void_p(self.cs.data_ptr() + 4 * b * HIDDEN),
@@ -419,14 +419,14 @@ def linear_rows(x, packed, relu=False, out_bf16=False):
     for wf, bb, n_total in f.groups:
         y0 = ctypes.c_void_p(y.data_ptr() + esz * col)
         y1 = ctypes.c_void_p(y.data_ptr() + esz * (col + HIDDEN)) if n_total == 2 * HIDDEN else None
-        native.check(L.dldkd_linear_rows_bf16(native.ptr(x2), native.ptr(wf), native.ptr(bb), y0, y1, n_out, M, n_total, K, int(relu),
+        native.check(L.dldkd_linear_rows_h16(native.ptr(x2), native.ptr(wf), native.ptr(bb), y0, y1, n_out, M, n_total, K, int(relu),
                                               int(out_bf16), native.stream()), "linear_rows_bf16")
         col += n_total
     return y.view(*x.shape[:-1], n_out)
 
 
 def plan_row_groups(lens, L):
-    """Host side of in_proj_bf16(groups=...): the 32-row groups of a padded (n, L, K) batch that hold valid clips, as int32 first
+    """Host side of in_proj_h16(groups=...): the 32-row groups of a padded (n, L, K) batch that hold valid clips, as int32 first
     rows (video v, clips 32 t ..: v L + 32 t, t < ceil(len_v / 32)), padded to a multiple of 4 by repeating the last group."""
     import numpy as np
     lens = np.asarray(lens, dtype=np.int64)
@@ -443,7 +443,7 @@ def plan_row_groups(lens, L):
     return np.ascontiguousarray(g.astype(np.int32))
 
 
-def in_proj_bf16(x, folded, relu=True, groups=None):
+def in_proj_h16(x, folded, relu=True, groups=None):
     """x (..., K) fp32 -> list of per-branch (..., 384) fp32 outputs, one pass over x (K4).  groups (int32 GPU tensor from
     plan_row_groups, rows128 kernel only): only those 32-row groups are projected; the other output rows stay unwritten."""
     L = native.lib()
@@ -455,30 +455,34 @@ def in_proj_bf16(x, folded, relu=True, groups=None):
     M = x2.shape[0]
     ys = [torch.empty(M, HIDDEN, dtype=torch.float32, device=x.device) for _ in range(f.nb)]
     if groups is not None:
-        if not (f.full_row and INPROJ_KERNEL == "rows128" and L.dldkd_in_proj_bf16_rows128_ok(K)):
-            raise native.NativeError("in_proj_bf16: a row-group table needs the two-branch rows128 kernel")
+        if not (f.full_row and INPROJ_KERNEL == "rows128" and L.dldkd_in_proj_h16_rows128_ok(K)):
+            raise native.NativeError("in_proj_h16: a row-group table needs the two-branch rows128 kernel")
         if groups.dtype != torch.int32 or not groups.is_cuda:
-            raise native.NativeError("in_proj_bf16: groups must be an int32 GPU tensor")
-        native.check(L.dldkd_in_proj_bf16_rows128_groups(native.ptr(x2), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb),
+            raise native.NativeError("in_proj_h16: groups must be an int32 GPU tensor")
+        native.check(L.dldkd_in_proj_h16_rows128_groups(native.ptr(x2), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb),
                                                          native.ptr(ys[0]), native.ptr(ys[1]), M, K, LN_EPS, int(relu),
                                                          native.ptr(groups), groups.numel(), native.stream()), "in_proj_bf16_rows128_groups")
         return [y.view(*x.shape[:-1], HIDDEN) for y in ys]
     if f.full_row:
-        rows128 = INPROJ_KERNEL == "rows128" and L.dldkd_in_proj_bf16_rows128_ok(K)
-        fn = L.dldkd_in_proj_bf16_rows128 if rows128 else L.dldkd_in_proj_bf16_full
+        rows128 = INPROJ_KERNEL == "rows128" and L.dldkd_in_proj_h16_rows128_ok(K)
+        fn = L.dldkd_in_proj_h16_rows128 if rows128 else L.dldkd_in_proj_h16_full
         native.check(fn(native.ptr(x2), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb), native.ptr(ys[0]),
                         native.ptr(ys[1]), M, K, LN_EPS, int(relu), native.stream()), "in_proj_bf16_" + INPROJ_KERNEL)
         return [y.view(*x.shape[:-1], HIDDEN) for y in ys]
-    native.check(L.dldkd_in_proj_bf16(native.ptr(x2), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb), native.ptr(ys[0]),
+    native.check(L.dldkd_in_proj_h16(native.ptr(x2), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb), native.ptr(ys[0]),
                                       native.ptr(ys[1]) if f.nb == 2 else None, M, f.nb * HIDDEN, K, LN_EPS, int(relu),
-                                      native.stream()), "in_proj_bf16")
+                                      native.stream()), "in_proj_h16")
     return [y.view(*x.shape[:-1], HIDDEN) for y in ys]
 
 
-# ------------------------------------------------------------------------------------ K4b: projection of resident bf16 rows
+# ------------------------------------------------------------------------------------ K4b: projection of resident 16-bit rows
+# "h16" everywhere below = IEEE fp16, the operand format of the eval-path towers (csrc/common.hpp says why it is not bf16)
+H16 = torch.float16
+
+
 class ResidentRows:
-    """Raw feature rows in their device-resident form: bf16 (rows, K) + fp32 LayerNorm statistics per row (mean, rstd), ragged
-    (item i owns rows [start[i], start[i] + lens[i])).  Filled by appending padded fp32 batches (dldkd_rows_to_bf16_stats)."""
+    """Raw feature rows in their device-resident form: fp16 (rows, K) + fp32 LayerNorm statistics per row (mean, rstd), ragged
+    (item i owns rows [start[i], start[i] + lens[i])).  Filled by appending padded fp32 batches (dldkd_rows_to_h16_stats)."""
 
     def __init__(self, K, device, capacity_rows=0):
         self.K, self.device = int(K), torch.device(device)
@@ -488,7 +492,7 @@ class ResidentRows:
 
     def _alloc(self, cap):
         cap = -(-cap // 128) * 128 + 128                 # slack: whole 128-row tiles
-        xb = torch.empty(cap, self.K, dtype=torch.bfloat16, device=self.device)
+        xb = torch.empty(cap, self.K, dtype=H16, device=self.device)
         mean = torch.empty(cap, dtype=torch.float32, device=self.device)
         rstd = torch.empty(cap, dtype=torch.float32, device=self.device)
         if self.rows:
@@ -511,9 +515,9 @@ class ResidentRows:
         meta = torch.from_numpy(np.concatenate([start.astype(np.int64), lens_host])).to(self.device)   # (2 n) int64: one upload
         lens_d = meta[n:].to(torch.int32)
         x = _chk(feat.reshape(n * L, K), "ResidentRows.append")
-        native.check(native.lib().dldkd_rows_to_bf16_stats(native.ptr(x), native.ptr(lens_d), native.ptr(meta), n, L, K, LN_EPS,
+        native.check(native.lib().dldkd_rows_to_h16_stats(native.ptr(x), native.ptr(lens_d), native.ptr(meta), n, L, K, LN_EPS,
                                                            native.ptr(self.xb), native.ptr(self.mean), native.ptr(self.rstd),
-                                                           native.stream()), "rows_to_bf16_stats")
+                                                           native.stream()), "rows_to_h16_stats")
         self.lens.extend(int(v) for v in lens_host)
         self.rows += add
 
@@ -525,16 +529,16 @@ class ResidentRows:
 
 
 def in_proj_rows_ok(K):
-    return bool(native.lib().dldkd_in_proj_bf16_rows128b_ok(int(K)))
+    return bool(native.lib().dldkd_in_proj_h16_rows128b_ok(int(K)))
 
 
-# the resident gallery encode hands h0 from K4b to the fused tower as bf16 rows (DLDKD_H0_BF16=0: fp32 rows, for A/B runs)
-RESIDENT_H0_BF16 = os.environ.get("DLDKD_H0_BF16", "1") == "1"
+# the resident gallery encode hands h0 from K4b to the fused tower as fp16 rows (DLDKD_H0_H16=0: fp32 rows, for A/B runs)
+RESIDENT_H0_H16 = os.environ.get("DLDKD_H0_H16", "1") == "1"
 
 
-def in_proj_resident(table, row_lo, row_hi, folded, relu=True, out=None, out_bf16=False):
+def in_proj_resident(table, row_lo, row_hi, folded, relu=True, out=None, out_h16=False):
     """K4b: rows [row_lo, row_hi) of a ResidentRows table -> per-branch (row_hi - row_lo, 384) fp32 (both branches, one pass);
-    out_bf16: bf16 rows instead (what tower_seq's gallery mode reads with half the traffic)."""
+    out_h16: fp16 rows instead (what tower_seq's gallery mode reads with half the traffic)."""
     L = native.lib()
     f = folded.get()
     if not (f.full_row and f.nb == 2 and f.K == table.K and in_proj_rows_ok(table.K)):
@@ -542,13 +546,13 @@ def in_proj_resident(table, row_lo, row_hi, folded, relu=True, out=None, out_bf1
     M = int(row_hi - row_lo)
     if row_lo < 0 or row_hi > table.rows or M < 0:
         raise native.NativeError("in_proj_resident: row range outside the table")
-    dt = torch.bfloat16 if out_bf16 else torch.float32
+    dt = H16 if out_h16 else torch.float32
     ys = out if out is not None else [torch.empty(M, HIDDEN, dtype=dt, device=table.device) for _ in range(2)]
     if any(y.shape[0] < M or y.shape[1] != HIDDEN or y.dtype != dt or not y.is_contiguous() for y in ys):
         raise native.NativeError("in_proj_resident: out tensors must be contiguous %s (>= rows, 384)" % dt)
     if M == 0:
         return ys
-    fn = L.dldkd_in_proj_bf16_rows128b_out16 if out_bf16 else L.dldkd_in_proj_bf16_rows128b
+    fn = L.dldkd_in_proj_h16_rows128b_out16 if out_h16 else L.dldkd_in_proj_h16_rows128b
     native.check(fn(native.ptr(table.xb[row_lo:]), native.ptr(table.mean[row_lo:]), native.ptr(table.rstd[row_lo:]), native.ptr(f.Wf), native.ptr(f.cs), native.ptr(f.bb),
                     native.ptr(ys[0]), native.ptr(ys[1]), M, table.K, int(relu), None, 0, native.stream()), "in_proj_bf16_rows128b")
     return ys
@@ -584,7 +588,7 @@ class TowerPack:
             L = native.lib()
             self.blob = torch.empty(L.dldkd_tower_blob_bytes(int(self.out_linear is not None)), dtype=torch.uint8, device=ps[0].device)
             args = [None if t is None else native.ptr(_chk(t.detach().contiguous(), "tower_pack")) for t in ps]
-            native.check(L.dldkd_tower_pack_bf16(*args, int(ps[-1].shape[0]), native.ptr(self.blob), native.stream()), "tower_pack")
+            native.check(L.dldkd_tower_pack_h16(*args, int(ps[-1].shape[0]), native.ptr(self.blob), native.stream()), "tower_pack")
             self.key = key
         return self
 
@@ -656,11 +660,11 @@ def tower_seq(h0, packs, lens, seq_rows=0, row0=None, items=None, out_mode=0, ga
     fs = [p.get() for p in packs]
     if any((f.out_linear is None) != (out_mode == 2) for f in fs):
         raise native.NativeError("tower_seq: out_mode 2 takes query-tower packs, out_mode 0 / 1 video-tower packs")
-    h16 = h0[0].dtype == torch.bfloat16
+    h16 = h0[0].dtype == H16
     if h16:
-        if out_mode != 1 or row0 is None or any(x.dtype != torch.bfloat16 or not x.is_cuda or not x.is_contiguous() or x.shape[-1] != HIDDEN
+        if out_mode != 1 or row0 is None or any(x.dtype != H16 or not x.is_cuda or not x.is_contiguous() or x.shape[-1] != HIDDEN
                                                 for x in h0):
-            raise native.NativeError("tower_seq: bf16 h0 rows serve the gallery mode (out_mode 1) with a row0 table only")
+            raise native.NativeError("tower_seq: fp16 h0 rows serve the gallery mode (out_mode 1) with a row0 table only")
         hs = [x.reshape(-1, HIDDEN) for x in h0]
     else:
         hs = [_chk(x.reshape(-1, HIDDEN), "tower_seq.h0") for x in h0]
@@ -674,11 +678,11 @@ def tower_seq(h0, packs, lens, seq_rows=0, row0=None, items=None, out_mode=0, ga
     elif out_mode == 2:
         outs = [torch.empty(n_seq, HIDDEN, dtype=torch.float32, device=lens.device) for _ in hs]
     if h16:
-        native.check(L.dldkd_tower_seq_bf16_h16(native.ptr_array(hs), native.ptr_array([f.blob for f in fs]), native.ptr(row0),
+        native.check(L.dldkd_tower_seq_h16_rows16(native.ptr_array(hs), native.ptr_array([f.blob for f in fs]), native.ptr(row0),
                                                 native.ptr(lens), native.ptr(items), n_items, n_seq, nb, native.ptr_array(gallery),
                                                 int(v0), int(Lp), native.ptr(lens_out), native.stream()), "tower_seq_h16")
         return None
-    native.check(L.dldkd_tower_seq_bf16(native.ptr_array(hs), native.ptr_array([f.blob for f in fs]),
+    native.check(L.dldkd_tower_seq_h16(native.ptr_array(hs), native.ptr_array([f.blob for f in fs]),
                                         native.ptr(row0), native.ptr(lens), native.ptr(items), n_items, n_seq, nb,
                                         out_mode, native.ptr_array(outs) if outs is not None else None, int(seq_rows),
                                         native.ptr_array(gallery) if gallery is not None else None, int(v0), int(Lp),

@@ -219,55 +219,55 @@ int dldkd_modpool_fwd_f32(const float* h, const float* mask, const float* w, flo
 /* Fold LayerNorm(K) into the following Linear(K -> N): Wf[n,k] = bf16(gamma[k] * W[n,k]),
  * cs[n] = sum_k Wf[n,k], bb[n] = sum_k beta[k] * W[n,k] + bias[n]  (LinearLayer, model_components.py:294-312).
  * For two branches call it twice on the two halves of one (768, K) Wf buffer. */
-int dldkd_fold_ln_linear_bf16(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+int dldkd_fold_ln_linear_h16(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
                               void* Wf, float* cs, float* bb, void* stream);
 
 /* y_b[m, :] = act( LayerNorm(x[m, :]) . W_b^T + b_b ) for b < N/384 branches, from the folded weights:
  * rstd[m] * (bf16(x[m,:]) . Wf[n,:] - mean[m] * cs[n]) + bb[n];  x (M, K) fp32 is read ONCE for all branches,
  * mean / rstd are accumulated from the same tiles.  N = 384 (y1 unused) or 768; K a multiple of 32.
  * Replaces LinearLayer.forward (model_components.py:305-312) on the inference path. */
-int dldkd_in_proj_bf16(const float* x, const void* Wf, const float* cs, const float* bb, float* y0, float* y1, long M,
+int dldkd_in_proj_h16(const float* x, const void* Wf, const float* cs, const float* bb, float* y0, float* y1, long M,
                        int N, int K, float eps, int relu, void* stream);
 
 /* Full-row variant for two branches (N = 768): Wfrag holds the folded weights in MFMA B-fragment order
  * [k-tile of 32][32-column tile (24)][kk (2)][lane (64)][8 bf16]; fold each branch with n_offset = 0 / 384 into
  * the same Wfrag / cs / bb buffers.  One workgroup computes all 768 columns of its 128 rows, so x is converted to
- * bf16 and its LayerNorm sums are taken once.  Same result as dldkd_in_proj_bf16 with N = 768. */
-int dldkd_fold_ln_linear_bf16_frag(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+ * bf16 and its LayerNorm sums are taken once.  Same result as dldkd_in_proj_h16 with N = 768. */
+int dldkd_fold_ln_linear_h16_frag(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
                                    int n_offset, void* Wfrag, float* cs, float* bb, void* stream);
-int dldkd_in_proj_bf16_full(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
+int dldkd_in_proj_h16_full(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                             long M, int K, float eps, int relu, void* stream);
-/* Second-generation kernel for the same contract (same Wfrag / cs / bb from dldkd_fold_ln_linear_bf16_frag with n_total = 768;
+/* Second-generation kernel for the same contract (same Wfrag / cs / bb from dldkd_fold_ln_linear_h16_frag with n_total = 768;
  * same result up to fp32 summation order: the k-tiles are summed in a rotated order).  One 128-row x 768-column tile per
  * workgroup of 4 waves (128 rows x 192 columns each, 384 accumulator registers), x and W' streamed by LDS-DMA through rings that
  * fill all 160 KiB of LDS, hand-counted waits, no branch in the k-loop (in_proj_rows128.hip).  Needs K % 64 == 0, K >= 128:
- * dldkd_in_proj_bf16_rows128_ok(K) tells; otherwise use dldkd_in_proj_bf16_full.  Wfrag must be 16-byte aligned. */
-int dldkd_in_proj_bf16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
+ * dldkd_in_proj_h16_rows128_ok(K) tells; otherwise use dldkd_in_proj_h16_full.  Wfrag must be 16-byte aligned. */
+int dldkd_in_proj_h16_rows128(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                long M, int K, float eps, int relu, void* stream);
-int dldkd_in_proj_bf16_rows128_ok(int K);
+int dldkd_in_proj_h16_rows128_ok(int K);
 /* The same kernel over a ROW-GROUP TABLE: x and y0 / y1 are (M, K) / (M, 384) as above, but only the rows of the listed groups
  * are read and written.  groups[g] = first row of a group of 32 consecutive rows (g < n_groups, n_groups a multiple of 4: pad by
  * repeating a group; groups[g] + 32 <= M).  For a padded (n, L, K) batch with L a multiple of 32 the host lists the groups that
  * hold valid clips (video v, clips 32 t ..: row v L + 32 t for t < ceil(len_v / 32)): the rows of the padding are neither
  * projected nor written - 29 % fewer rows on a TVR-like length mix. */
-int dldkd_in_proj_bf16_rows128_groups(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
+int dldkd_in_proj_h16_rows128_groups(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                       long M, int K, float eps, int relu, const int32_t* groups, long n_groups, void* stream);
 /* K4b: the same projection on rows in their RESIDENT form - bf16 features (M, K) plus the rows' fp32 LayerNorm statistics
- * mean[M], rstd[M] - written once by dldkd_rows_to_bf16_stats when a dataset's raw features become device-resident (the
+ * mean[M], rstd[M] - written once by dldkd_rows_to_h16_stats when a dataset's raw features become device-resident (the
  * reference re-reads, re-pads and re-uploads the fp32 features of the validation videos in every epoch: method/eval.py:114-175
- * through method/data_provider.py:111-136).  Same arithmetic as dldkd_in_proj_bf16_rows128 (which rounds x to bf16 before the
+ * through method/data_provider.py:111-136).  Same arithmetic as dldkd_in_proj_h16_rows128 (which rounds x to bf16 before the
  * MFMA and takes the statistics from the fp32 values), same Wfrag / cs / bb, same row-group table (groups == NULL: all rows,
  * tile t = rows 128 t ..; the table rows index x, mean, rstd and y alike) - without the fp32 fragment reads, conversions and
  * LayerNorm sums in the k-loop and with half the bytes per row (in_proj_rows128b.hip).  Needs K % 64 == 0, K >= 256
- * (dldkd_in_proj_bf16_rows128b_ok); x_bf16 and Wfrag 16-byte aligned. */
-int dldkd_in_proj_bf16_rows128b(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
+ * (dldkd_in_proj_h16_rows128b_ok); x_bf16 and Wfrag 16-byte aligned. */
+int dldkd_in_proj_h16_rows128b(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
                                 const float* bb, float* y0, float* y1, long M, int K, int relu, const int32_t* groups, long n_groups,
                                 void* stream);
-int dldkd_in_proj_bf16_rows128b_ok(int K);
+int dldkd_in_proj_h16_rows128b_ok(int K);
 /* The same with BF16 output rows (round to nearest even, row stride 384 bf16): what the fused tower reads through
- * dldkd_tower_seq_bf16_h16 - half the bytes written here and read there (2 x 1.28 GB instead of 2 x 2.56 GB per branch pair at
+ * dldkd_tower_seq_h16_rows16 - half the bytes written here and read there (2 x 1.28 GB instead of 2 x 2.56 GB per branch pair at
  * TVR's 1.67 M clips), and the tower's prologue becomes one round of 16-byte loads straight into its operand registers. */
-int dldkd_in_proj_bf16_rows128b_out16(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
+int dldkd_in_proj_h16_rows128b_out16(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
                                       const float* bb, void* y0_bf16, void* y1_bf16, long M, int K, int relu, const int32_t* groups,
                                       long n_groups, void* stream);
 /* PARITY-grade two-branch input projection (in_proj_rows128x3.hip): y = ReLU(LayerNorm(x) W^T + b) with fp32-grade products
@@ -315,12 +315,12 @@ int dldkd_debug_in_proj_rows128_timeline(const float* x, const void* Wfrag, cons
  * towers in throughput mode (model_components.py:388-390 query/key/value, :442 dense; model.py:39 out_mapping_linear).
  * dldkd_pack_linear_bf16_frag writes rows [n_offset, n_offset + N) of a weight block of n_total (384 or 768) output
  * columns in MFMA fragment order (bf16) and its bias into bb[n_offset ..]; call it once per source matrix.
- * dldkd_linear_rows_bf16: x (M, K) fp32 contiguous; output columns [0, 384) go to y0 and [384, 768) to y1, both with
+ * dldkd_linear_rows_h16: x (M, K) fp32 contiguous; output columns [0, 384) go to y0 and [384, 768) to y1, both with
  * row stride ldy elements (so a (M, 1152) q|k|v buffer is filled by one N = 768 and one N = 384 launch).  out_bf16 != 0:
  * y0 / y1 are bf16 buffers (ldy a multiple of 8) - what dldkd_attention_fwd_bf16 consumes with qkv_is_bf16 != 0. */
 int dldkd_pack_linear_bf16_frag(const float* W, const float* bias, int N, int K, int n_offset, int n_total, void* Wfrag, float* bb,
                                 void* stream);
-int dldkd_linear_rows_bf16(const float* x, const void* Wfrag, const float* bb, void* y0, void* y1, int ldy, long M, int N, int K,
+int dldkd_linear_rows_h16(const float* x, const void* Wfrag, const float* bb, void* y0, void* y1, int ldy, long M, int N, int K,
                            int relu, int out_bf16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -730,13 +730,13 @@ int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv,
  *   y = h2 Wo^T + bo                                  out_mapping_linear                   method/model.py:219
  *   out_mode 1: row = bf16(y / max(|y|, 1e-12))       F.normalize in get_sim_scores        method/model.py:319
  *   out_mode 2 (query towers): modular pooling on top       get_modularized_queries      method/model.py:245-258
- * dldkd_tower_blob_bytes / dldkd_tower_pack_bf16: one branch's weights as bf16 MFMA fragments in the kernel's consumption
+ * dldkd_tower_blob_bytes / dldkd_tower_pack_h16: one branch's weights as bf16 MFMA fragments in the kernel's consumption
  * order (k permuted to the accumulator layout, q pre-scaled by log2(e) / sqrt(96)) followed by its bias / gamma / beta vectors;
  * all weight matrices (384, 384) row-major, vectors (384).  A video tower passes wo / bo (out_mapping_linear) and mod_w = NULL;
  * a query tower passes wo = bo = NULL and mod_w = modular_vector_mapping.weight (384).
  *   pos (max_pos, 384) = position_embeddings.weight goes into the blob too, re-arranged per 32-position tile (positions past
  *   max_pos read as zeros).
- * dldkd_tower_seq_bf16: h0 / blob / out_rows / gallery are HOST arrays of n_branches device pointers.
+ * dldkd_tower_seq_h16: h0 / blob / out_rows / gallery are HOST arrays of n_branches device pointers.
  *   h0[b] (rows, 384) fp32: the input projection's output; sequence s owns rows row0[s] .. row0[s] + lens[s] - 1
  *     (row0 == NULL: s * seq_rows); at most 128 rows per sequence.
  *   items (n_items, 4) int32 or NULL: the four 32-row slots of workgroup i: (s << 10) | (tile << 8) | lens[s], -1 = idle; the tiles of one
@@ -751,21 +751,21 @@ int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv,
  *   out_mode 2 (query-tower blobs): out_rows[b] (n_seq, 384) fp32 = the modular query vectors; 1 <= lens[s] <= 32 (a sequence
  *     with lens < 1 gives a zero vector). */
 size_t dldkd_tower_blob_bytes(int with_out_map);
-int dldkd_tower_pack_bf16(const float* ln1_g, const float* ln1_b, const float* wq, const float* bq, const float* wk, const float* bk,
+int dldkd_tower_pack_h16(const float* ln1_g, const float* ln1_b, const float* wq, const float* bq, const float* wk, const float* bk,
                           const float* wv, const float* bv, const float* wd, const float* bd, const float* ln2_g, const float* ln2_b,
                           const float* wo, const float* bo, const float* mod_w, const float* pos, int max_pos, void* blob, void* stream);
-int dldkd_tower_seq_bf16(const float* const* h0, const void* const* blob, const int32_t* row0,
+int dldkd_tower_seq_h16(const float* const* h0, const void* const* blob, const int32_t* row0,
                          const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                          int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
                          void* stream);
-/* out_mode 1 from BF16 h0 rows (dldkd_in_proj_bf16_rows128b_out16; ragged: row0 required): the prologue is one round of
+/* out_mode 1 from BF16 h0 rows (dldkd_in_proj_h16_rows128b_out16; ragged: row0 required): the prologue is one round of
  * 16-byte loads straight into the operand registers (no LDS staging); everything else as above. */
-int dldkd_tower_seq_bf16_h16(const void* const* h0_bf16, const void* const* blob, const int32_t* row0,
+int dldkd_tower_seq_h16_rows16(const void* const* h0_bf16, const void* const* blob, const int32_t* row0,
                              const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                              void* const* gallery, int v0, int Lp, int32_t* lens_out, void* stream);
 
 /* Diagnostics: the out_mode 1 kernel (two branches) with clock stamps at its phase boundaries; stamps = 24 x uint64 per workgroup
- * (h16: h0 holds bf16 rows, the dldkd_tower_seq_bf16_h16 kernel)
+ * (h16: h0 holds bf16 rows, the dldkd_tower_seq_h16_rows16 kernel)
  * (8 * ceil(n_items / 4) workgroups): [0] start, [1] prologue, [2 + 2 h] head h projected, [3 + 2 h] head h attended, [10] dense,
  * [11] LayerNorm, [12] out mapping, [13] rows stored, [16..21] inside the prologue (tools/tower_timeline.py). */
 int dldkd_debug_tower_seq_timeline(const float* const* h0, const void* const* blob, const int32_t* lens,
@@ -788,16 +788,16 @@ int dldkd_segment_mean_l2norm_f32(const float* frames, const int32_t* seg_start,
 int dldkd_gather_pad_rows_f32(const float* src, const long long* row_start, const int32_t* lens, const int32_t* items, int n_items,
                               int Lmax, int D, float* out, float* mask, void* stream);
 
-/* Raw feature rows -> their device-resident form (dldkd_in_proj_bf16_rows128b): bf16 (round to nearest even) + fp32 LayerNorm
+/* Raw feature rows -> their device-resident form (dldkd_in_proj_h16_rows128b): bf16 (round to nearest even) + fp32 LayerNorm
  * statistics of the fp32 values (mean, rstd = 1 / sqrt(biased variance + eps): nn.LayerNorm, method/model_components.py:297).
  * src (n_items, L, K) fp32, a padded batch as collate_frame_val builds it (method/data_provider.py:111-136); row l of item b goes
  * to table row dst_row0[b] + l when l < lens[b] (lens == NULL: every row; dst_row0 == NULL: row b L + l): the padding is dropped,
  * the table is ragged.  x_bf16 (rows, K) 8-byte aligned, mean / rstd (rows). */
-int dldkd_rows_to_bf16_stats(const float* src, const int32_t* lens, const long long* dst_row0, int n_items, int L, int K, float eps,
+int dldkd_rows_to_h16_stats(const float* src, const int32_t* lens, const long long* dst_row0, int n_items, int L, int K, float eps,
                              void* x_bf16, float* mean, float* rstd, void* stream);
 
-/* Upload of a small host-produced int32 table (the slot and row-group tables of dldkd_tower_seq_bf16 /
- * dldkd_in_proj_bf16_rows128_groups; nothing in the reference) by a kernel: pinned_src is page-locked, device-mapped host
+/* Upload of a small host-produced int32 table (the slot and row-group tables of dldkd_tower_seq_h16 /
+ * dldkd_in_proj_h16_rows128_groups; nothing in the reference) by a kernel: pinned_src is page-locked, device-mapped host
  * memory (hipHostMalloc / torch pin_memory), read over the bus on the compute queue - no copy-engine hand-off.  The caller keeps
  * pinned_src unchanged until the launch has executed (an event, as for hipMemcpyAsync). */
 int dldkd_upload_words(const int32_t* pinned_src, int32_t* dst, long n_words, void* stream);

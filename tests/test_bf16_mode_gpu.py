@@ -90,8 +90,14 @@ def test_forward_backward_bf16_vs_golden_g4(bf16_mode, golden_dir):
 
 @pytest.mark.parametrize("M,K,n_lin,relu", [(1, 384, 1, False), (130, 384, 3, False), (25600, 384, 3, False), (777, 384, 2, True),
                                             (1000, 768, 1, True), (129, 32, 3, False)])
+def _h(t):
+    """round to the eval-path towers' operand format (h16 = IEEE fp16, csrc/common.hpp)"""
+    return t.float().half().double()
+
+
 def test_linear_rows_full_row_kernel(bf16_mode, M, K, n_lin, relu):
-    """Full-row bf16 kernel (weights in MFMA fragment order) against fp64 products of the bf16-rounded operands."""
+    """Full-row kernel of the inference chain (weights in MFMA fragment order, fp16 operands like every eval-path tower kernel)
+    against fp64 products of the fp16-rounded operands."""
     from dldkd_amd import ops
     torch.manual_seed(M + K + n_lin)
     lins = [torch.nn.Linear(K, 384).to(DEV) for _ in range(n_lin)]
@@ -99,7 +105,7 @@ def test_linear_rows_full_row_kernel(bf16_mode, M, K, n_lin, relu):
     pk = ops.PackedLinear(lins)
     with torch.no_grad():
         y = ops.linear_rows(x, pk, relu=relu)
-        ref = torch.cat([_r(x.cpu()) @ _r(l.weight.detach().cpu()).t() + l.bias.detach().cpu().double() for l in lins], 1)
+        ref = torch.cat([_h(x.cpu()) @ _h(l.weight.detach().cpu()).t() + l.bias.detach().cpu().double() for l in lins], 1)
         if relu:
             ref = torch.relu(ref)
         assert y.shape == (M, 384 * n_lin)
@@ -107,7 +113,7 @@ def test_linear_rows_full_row_kernel(bf16_mode, M, K, n_lin, relu):
         # parameter update -> repack
         lins[0].weight.mul_(2.0)
         y2 = ops.linear_rows(x, pk, relu=relu)
-        ref2 = _r(x.cpu()) @ _r(lins[0].weight.detach().cpu()).t() + lins[0].bias.detach().cpu().double()
+        ref2 = _h(x.cpu()) @ _h(lins[0].weight.detach().cpu()).t() + lins[0].bias.detach().cpu().double()
         assert _rel(y2[:, :384], torch.relu(ref2) if relu else ref2) < 3e-6
 
 

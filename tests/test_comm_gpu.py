@@ -159,7 +159,13 @@ def test_data_parallel_replay_uses_the_tower_graphs_with_one_all_reduce(rccl_com
         calls = []
         real = rccl_comm.all_reduce
         rccl_comm.all_reduce = lambda t, op="sum", async_op=False: (calls.append((t.numel(), op)), real(t, op, async_op))[1]
+        from dldkd_amd import ops
         for it in range(8):
+            # both steppers start every step from the same state (the step's fp32 atomics make two runs drift apart at rounding
+            # level per step; the test is about one step's arithmetic, step after step)
+            od.fp.flat.copy_(op_.fp.flat); od.m.copy_(op_.m); od.v.copy_(op_.v)
+            od.step_count = op_.step_count
+            ops.bump_param_epoch()
             T.DDP_MIN_WORLD = 2
             torch.manual_seed(500 + it)
             lp, _ = plain(batches[it % 2])

@@ -22,14 +22,14 @@ flops = 2.0 * M * K * 768
 outs = {}
 for kern in os.environ.get("K4_KERNELS", "full,rows128").split(","):
     ops.INPROJ_KERNEL = kern
-    for _ in range(2): outs[kern] = ops.in_proj_bf16(x, f)
+    for _ in range(2): outs[kern] = ops.in_proj_h16(x, f)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
     ev[0].record()
     for i in range(10):
-        ops.in_proj_bf16(x, f); ev[i + 1].record()
+        ops.in_proj_h16(x, f); ev[i + 1].record()
     torch.cuda.synchronize()
     ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(10)); med = ts[5]
-    print(f"K4 in_proj_bf16[{kern}] M={M} K={K}: {med:.3f} ms  algorithmic {byts/med/1e6:.0f} GB/s ({byts/med/1e6/8000*100:.1f}% of 8 TB/s)  {flops/med/1e9:.0f} TFLOP/s", flush=True)
+    print(f"K4 in_proj_h16[{kern}] M={M} K={K}: {med:.3f} ms  algorithmic {byts/med/1e6:.0f} GB/s ({byts/med/1e6/8000*100:.1f}% of 8 TB/s)  {flops/med/1e9:.0f} TFLOP/s", flush=True)
 if len(outs) == 2:
     a, b = outs["full"], outs["rows128"]
     for i in range(2):

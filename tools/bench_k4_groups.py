@@ -22,12 +22,12 @@ variants = {"dense_1024_tiles": dict(x=x, groups=None), "dense_768_tiles": dict(
             "groups_first_768_videos": dict(x=x, groups=torch.from_numpy(ops.plan_row_groups(np.where(np.arange(n) < 768, 128, 0), L)).to(DEV))}
 times = {k: [] for k in variants}
 for k, v in variants.items():
-    ops.in_proj_bf16(v["x"], fold, groups=v["groups"])
+    ops.in_proj_h16(v["x"], fold, groups=v["groups"])
 torch.cuda.synchronize()
 for _ in range(15):
     for k, v in variants.items():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); ops.in_proj_bf16(v["x"], fold, groups=v["groups"]); e1.record(); e1.synchronize()
+        e0.record(); ops.in_proj_h16(v["x"], fold, groups=v["groups"]); e1.record(); e1.synchronize()
         times[k].append(e0.elapsed_time(e1))
 out = {k: {"ms_median": float(np.median(t)), "ms_min": float(min(t)), "tiles": int(v["groups"].numel() // 4 if v["groups"] is not None else v["x"].shape[0])} for (k, t), v in zip(times.items(), variants.values())}
 print(json.dumps(out))

@@ -22,7 +22,7 @@ for (n, L) in ((5, 32), (37, 128), (300, 96)) if mode == "all" else ():
     mu = rows.double().mean(1); var = rows.double().var(1, unbiased=False)
     print("stats err", (tab.mean[:tab.rows].double() - mu).abs().max().item(), (tab.rstd[:tab.rows].double() * (var + 1e-5).sqrt() - 1).abs().max().item())
     with torch.no_grad():
-        y_ref = ops.in_proj_bf16(rows.contiguous(), fold)
+        y_ref = ops.in_proj_h16(rows.contiguous(), fold)
         y = ops.in_proj_resident(tab, 0, tab.rows, fold)
         torch.cuda.synchronize()
         for b in range(2):
@@ -62,6 +62,6 @@ if mode == "pmc":
     sys.exit(0)
 with torch.no_grad():
     t_b = tm(lambda: ops.in_proj_resident(tab, 0, M, fold, out=outs))
-    t_a = tm(lambda: ops.in_proj_bf16(x2, fold))
+    t_a = tm(lambda: ops.in_proj_h16(x2, fold))
 fl = 2.0 * M * K * 768
 print(f"K4 {t_a:.3f} ms ({fl/t_a/1e9:.0f} TFLOP/s)  K4b {t_b:.3f} ms ({fl/t_b/1e9:.0f} TFLOP/s)")

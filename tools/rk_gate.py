@@ -66,7 +66,9 @@ def recalls(scores, gt):
     return [100.0 * float((r <= k).mean()) for k in (1, 5, 10, 100)], r
 
 
-def oracle_scores(m, d, threads=16):
+def oracle_scores(m, d, threads=16, chunk=50):
+    """chunk: queries per get_sim_scores call (the reference's eval_query_bsz = 50, eval.py:188-208; a larger chunk is the same
+    arithmetic - every call re-normalises the gallery and takes the same fp32 products - with fewer passes over the gallery)."""
     import dldkd_oracle as orc
     torch.set_num_threads(min(threads, os.cpu_count() or 1))
     p = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
@@ -77,7 +79,7 @@ def oracle_scores(m, d, threads=16):
             gi.append(a), ge.append(b)
         gi, ge = torch.cat(gi), torch.cat(ge)
         qi, qe = orc.encode_query(p, d["words"], d["qmask"])
-        inh, exp = orc.eval_scores(qi, qe, gi, ge, d["vmask"], chunk=50)
+        inh, exp = orc.eval_scores(qi, qe, gi, ge, d["vmask"], chunk=chunk)
     return orc.fuse_scores(inh, exp), inh, exp
 
 

@@ -58,8 +58,10 @@ def make_pairs(seed, nv, caps, L, len_lo, sigma, P, Pt, lq_lo=5, lq_hi=30, dev="
                 t_txt=3.0 * (base @ Pt)[:, None, :])
 
 
-def train_model(steps, sigma, P, Pt, dev="cuda:0", seed=0, bsz=128, caps=5, L=64, log=None):
-    """Parity-mode training on planted pairs: `steps` steps of 128 videos x 5 captions through train.GraphedTrainStep."""
+def train_model(steps, sigma, P, Pt, dev="cuda:0", seed=0, bsz=128, caps=5, L=64, log=None, precision="fp32", every=100):
+    """Training on planted pairs: `steps` steps of 128 videos x 5 captions through train.GraphedTrainStep.  precision "fp32" = parity
+    mode (fp32-grade GEMMs), "bf16" = the throughput training mode.  Same seed -> same initial weights, same batches and the same
+    triplet draws in either mode.  Returns (model in eval mode, [(step, loss)] every `every` steps)."""
     from dldkd_amd import ops
     from dldkd_amd import train as T
     from dldkd_amd.model import DLDKD
@@ -71,7 +73,7 @@ def train_model(steps, sigma, P, Pt, dev="cuda:0", seed=0, bsz=128, caps=5, L=64
     torch.manual_seed(seed)
     m = DLDKD(cfg, mopt).to(dev).train()
     topt = types.SimpleNamespace(grad_clip=-1, lr=3e-4, wd=0.01, lr_warmup_proportion=0.01, n_epoch=1)
-    ops.set_gemm_precision("fp32")
+    ops.set_gemm_precision(precision)
     optim = T.make_optimizer(m, topt, steps)
     stepper = T.GraphedTrainStep(m, optim, topt, defer_loss_float=True)
     losses = []
@@ -81,17 +83,18 @@ def train_model(steps, sigma, P, Pt, dev="cuda:0", seed=0, bsz=128, caps=5, L=64
         batch = {"student_videos": d["vid"], "student_videos_mask": d["vmask"], "teacher_videos": d["t_vid"], "student_text": d["words"],
                  "student_text_mask": d["qmask"], "teacher_text": d["t_txt"], "text_labels": labels}
         loss, parts = stepper(batch)
-        if it % 100 == 0 or it == steps - 1:
+        if it % every == 0 or it == steps - 1:
             losses.append((it, float(loss)))
-            if log:
+            if log and (it % 100 == 0 or it == steps - 1):
                 log(f"  train step {it}: loss {float(loss):.4f}  " + " ".join(f"{k} {float(v):.3f}" for k, v in parts.items() if k != "loss_overall"))
+    ops.set_gemm_precision("fp32")
     return m.eval(), losses
 
 
-def compare(m, d, modes=("parity", "fast", "resident"), dev="cuda:0"):
+def compare(m, d, modes=("parity", "fast", "resident"), dev="cuda:0", chunk=50):
     import rk_gate
     out = {}
-    ref, _, _ = rk_gate.oracle_scores(m, d, threads=32)
+    ref, _, _ = rk_gate.oracle_scores(m, d, threads=32, chunk=chunk)
     out["oracle"], r_ref = rk_gate.recalls(ref, d["gt"])
     for mode in modes:
         fused, _, _ = rk_gate.hip_scores(m, d, mode, dev)
@@ -104,7 +107,7 @@ def compare(m, d, modes=("parity", "fast", "resident"), dev="cuda:0"):
     return out
 
 
-def run(seeds=3, nv=4096, nq=8192, steps=400, sigma=6.0, L=64, log=print):
+def run(seeds=3, nv=4096, nq=8192, steps=400, sigma=6.0, L=64, log=print, chunk=50):
     P, Pt = maps()
     t0 = time.time()
     m, losses = train_model(steps, sigma, P, Pt, log=log)
@@ -115,7 +118,7 @@ def run(seeds=3, nv=4096, nq=8192, steps=400, sigma=6.0, L=64, log=print):
     for s in range(seeds):
         d = {k: v.cpu() for k, v in make_pairs(500 + s, nv, caps, L, 8, sigma, P, Pt, dev="cuda:0").items()}
         t1 = time.time()
-        r = compare(m, d)
+        r = compare(m, d, chunk=chunk)
         r["seed"], r["seconds"] = 500 + s, round(time.time() - t1, 1)
         res["seeds"].append(r)
         log(f"  eval seed {500 + s}: oracle {['%.3f' % x for x in r['oracle']]}  " + "  ".join(
