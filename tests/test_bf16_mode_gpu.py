@@ -88,13 +88,13 @@ def test_forward_backward_bf16_vs_golden_g4(bf16_mode, golden_dir):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("M,K,n_lin,relu", [(1, 384, 1, False), (130, 384, 3, False), (25600, 384, 3, False), (777, 384, 2, True),
-                                            (1000, 768, 1, True), (129, 32, 3, False)])
 def _h(t):
     """round to the eval-path towers' operand format (h16 = IEEE fp16, csrc/common.hpp)"""
     return t.float().half().double()
 
 
+@pytest.mark.parametrize("M,K,n_lin,relu", [(1, 384, 1, False), (130, 384, 3, False), (25600, 384, 3, False), (777, 384, 2, True),
+                                            (1000, 768, 1, True), (129, 32, 3, False)])
 def test_linear_rows_full_row_kernel(bf16_mode, M, K, n_lin, relu):
     """Full-row kernel of the inference chain (weights in MFMA fragment order, fp16 operands like every eval-path tower kernel)
     against fp64 products of the fp16-rounded operands."""
