@@ -1,3 +1,5 @@
+// NOTE (round 5): the 16-bit MFMA operands of this file are h16 = IEEE fp16, not bf16 (common.hpp says why; the text below and the
+// identifiers still say "bf16" where they mean "the 16-bit operand": bf16x8 is the 8 x 16-bit container, whatever the format).
 // K4 in_proj: y = ReLU( LayerNorm(x) . W^T + b ) for the raw clip / word features, bf16 MFMA.
 // Replaces LinearLayer.forward (reference method/model_components.py:305-312) on the inference path; it is
 // the only stage that touches the raw fp32 features (Dv = 3072 for TVR i3d: 1.57 MB per 128-clip video),
@@ -426,7 +428,7 @@ int dldkd_fold_ln_linear_h16_frag(const float* W, const float* bias, const float
     return check_launch("fold_ln_linear_frag");
 }
 
-int dldkd_pack_linear_bf16_frag(const float* W, const float* bias, int N, int K, int n_offset, int n_total, void* Wfrag, float* bb,
+int dldkd_pack_linear_h16_frag(const float* W, const float* bias, int N, int K, int n_offset, int n_total, void* Wfrag, float* bb,
                                 void* stream) {
     if (N < 1 || K < FBK || (K % FBK) || (n_total != 384 && n_total != 768) || n_offset < 0 || n_offset + N > n_total ||
         (n_offset % 32)) {

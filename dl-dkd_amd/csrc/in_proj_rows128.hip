@@ -1,3 +1,5 @@
+// NOTE (round 5): the 16-bit MFMA operands of this file are h16 = IEEE fp16, not bf16 (common.hpp says why; the text below and the
+// identifiers still say "bf16" where they mean "the 16-bit operand": bf16x8 is the 8 x 16-bit container, whatever the format).
 // K4, second generation: y = ReLU( LayerNorm(x) . W^T + b ) for the raw clip / word features, both branches (768 output
 // columns) in ONE pass over the fp32 rows.  Replaces LinearLayer.forward (reference method/model_components.py:305-312) on the
 // inference path, like rows_linear_bf16_kernel<1, true> (in_proj_h16.hip), whose limits this kernel is built around

@@ -1,3 +1,5 @@
+// NOTE (round 5): the 16-bit MFMA operands of this file are h16 = IEEE fp16, not bf16 (common.hpp says why; the text below and the
+// identifiers still say "bf16" where they mean "the 16-bit operand": bf16x8 is the 8 x 16-bit container, whatever the format).
 // K4b: the two-branch input projection y = ReLU( LayerNorm(x) . W^T + b ) (LinearLayer.forward, reference
 // method/model_components.py:305-312) on rows that are ALREADY stored the way the MFMA consumes them: bf16 features plus
 // the row's fp32 LayerNorm statistics, both written once by the ingest pass (dldkd_rows_to_h16_stats, ingest.hip) when a

@@ -1,3 +1,5 @@
+// NOTE (round 5): the 16-bit MFMA operands of this file are h16 = IEEE fp16, not bf16 (common.hpp says why; the text below and the
+// identifiers still say "bf16" where they mean "the 16-bit operand": bf16x8 is the 8 x 16-bit container, whatever the format).
 // K5: the whole clip / word tower AFTER the input projection as ONE kernel, one workgroup per (sequence, branch):
 //     h1 = LN(h0 + pos)                                   TrainablePositionalEncoding.forward, model_components.py:277-284
 //     q|k|v = h1 W^T + b ; P = softmax(q k^T / sqrt(96) + key mask) ; ctx = P v      BertSelfAttention.forward, :398-436

@@ -188,7 +188,7 @@ SIGNATURES = {
     "dldkd_debug_in_proj_rows128_timeline": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long,
                                                        _c_int, _c_float, _c_int, _c_void_p, _c_void_p]),
     "dldkd_attention_fwd_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
-    "dldkd_pack_linear_bf16_frag": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_pack_linear_h16_frag": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_linear_rows_h16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_int, _c_int,
                                          _c_int, _c_int, _c_void_p]),
     "dldkd_pack_gallery_chunk_bf16": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,

@@ -324,7 +324,7 @@ class PackedLinear:
                 wf = torch.empty(n_total * K * 2, dtype=torch.uint8, device=dev)
                 bb = torch.empty(n_total, dtype=torch.float32, device=dev)
                 for i, l in enumerate(g):
-                    native.check(L.dldkd_pack_linear_bf16_frag(native.ptr(l.weight.detach().contiguous()), native.ptr(l.bias.detach()),
+                    native.check(L.dldkd_pack_linear_h16_frag(native.ptr(l.weight.detach().contiguous()), native.ptr(l.bias.detach()),
                                                                HIDDEN, K, i * HIDDEN, n_total, native.ptr(wf), native.ptr(bb),
                                                                native.stream()), "pack_linear_frag")
                 self.groups.append((wf, bb, n_total))

@@ -213,26 +213,32 @@ int dldkd_modpool_fwd_f32(const float* h, const float* mask, const float* w, flo
                           int L, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * K4: bf16 input projection of the raw features (inference), the HBM-bound stage of the gallery encode.
+ * K4: 16-bit input projection of the raw features (inference), the HBM-bound stage of the gallery encode.
+ * "h16" in the names of this and the K5 section = the 16-bit operand format of the EVAL-path towers: IEEE fp16 (10 mantissa bits),
+ * fp32 accumulation - not bf16: same MFMA rate, and with bf16 operands the K = 3072 projection alone moved the fused scores by
+ * 1.8e-4, enough to put R@K a coin flip away from the reference's +-0.1 (dl-dkd_amd/csrc/common.hpp, profiles/r05/).  Every
+ * operand of these kernels is a LayerNorm output, a weight, a probability or an L2-normalised feature: far inside fp16's range.
+ * The SCORER (dldkd_simpool_eval_*) keeps bf16 operands, and so does training.  Buffers called Wf / Wfrag / blob / x_h16 / y_h16
+ * hold fp16 values.
  * ------------------------------------------------------------------------------------------- */
 
-/* Fold LayerNorm(K) into the following Linear(K -> N): Wf[n,k] = bf16(gamma[k] * W[n,k]),
+/* Fold LayerNorm(K) into the following Linear(K -> N): Wf[n,k] = h16(gamma[k] * W[n,k]),
  * cs[n] = sum_k Wf[n,k], bb[n] = sum_k beta[k] * W[n,k] + bias[n]  (LinearLayer, model_components.py:294-312).
  * For two branches call it twice on the two halves of one (768, K) Wf buffer. */
 int dldkd_fold_ln_linear_h16(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
                               void* Wf, float* cs, float* bb, void* stream);
 
 /* y_b[m, :] = act( LayerNorm(x[m, :]) . W_b^T + b_b ) for b < N/384 branches, from the folded weights:
- * rstd[m] * (bf16(x[m,:]) . Wf[n,:] - mean[m] * cs[n]) + bb[n];  x (M, K) fp32 is read ONCE for all branches,
+ * rstd[m] * (h16(x[m,:]) . Wf[n,:] - mean[m] * cs[n]) + bb[n];  x (M, K) fp32 is read ONCE for all branches,
  * mean / rstd are accumulated from the same tiles.  N = 384 (y1 unused) or 768; K a multiple of 32.
  * Replaces LinearLayer.forward (model_components.py:305-312) on the inference path. */
 int dldkd_in_proj_h16(const float* x, const void* Wf, const float* cs, const float* bb, float* y0, float* y1, long M,
                        int N, int K, float eps, int relu, void* stream);
 
 /* Full-row variant for two branches (N = 768): Wfrag holds the folded weights in MFMA B-fragment order
- * [k-tile of 32][32-column tile (24)][kk (2)][lane (64)][8 bf16]; fold each branch with n_offset = 0 / 384 into
+ * [k-tile of 32][32-column tile (24)][kk (2)][lane (64)][8 h16]; fold each branch with n_offset = 0 / 384 into
  * the same Wfrag / cs / bb buffers.  One workgroup computes all 768 columns of its 128 rows, so x is converted to
- * bf16 and its LayerNorm sums are taken once.  Same result as dldkd_in_proj_h16 with N = 768. */
+ * h16 and its LayerNorm sums are taken once.  Same result as dldkd_in_proj_h16 with N = 768. */
 int dldkd_fold_ln_linear_h16_frag(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
                                    int n_offset, void* Wfrag, float* cs, float* bb, void* stream);
 int dldkd_in_proj_h16_full(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
@@ -252,23 +258,23 @@ int dldkd_in_proj_h16_rows128_ok(int K);
  * projected nor written - 29 % fewer rows on a TVR-like length mix. */
 int dldkd_in_proj_h16_rows128_groups(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                       long M, int K, float eps, int relu, const int32_t* groups, long n_groups, void* stream);
-/* K4b: the same projection on rows in their RESIDENT form - bf16 features (M, K) plus the rows' fp32 LayerNorm statistics
+/* K4b: the same projection on rows in their RESIDENT form - h16 features (M, K) plus the rows' fp32 LayerNorm statistics
  * mean[M], rstd[M] - written once by dldkd_rows_to_h16_stats when a dataset's raw features become device-resident (the
  * reference re-reads, re-pads and re-uploads the fp32 features of the validation videos in every epoch: method/eval.py:114-175
- * through method/data_provider.py:111-136).  Same arithmetic as dldkd_in_proj_h16_rows128 (which rounds x to bf16 before the
+ * through method/data_provider.py:111-136).  Same arithmetic as dldkd_in_proj_h16_rows128 (which rounds x to h16 before the
  * MFMA and takes the statistics from the fp32 values), same Wfrag / cs / bb, same row-group table (groups == NULL: all rows,
  * tile t = rows 128 t ..; the table rows index x, mean, rstd and y alike) - without the fp32 fragment reads, conversions and
  * LayerNorm sums in the k-loop and with half the bytes per row (in_proj_rows128b.hip).  Needs K % 64 == 0, K >= 256
- * (dldkd_in_proj_h16_rows128b_ok); x_bf16 and Wfrag 16-byte aligned. */
-int dldkd_in_proj_h16_rows128b(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
+ * (dldkd_in_proj_h16_rows128b_ok); x_h16 and Wfrag 16-byte aligned. */
+int dldkd_in_proj_h16_rows128b(const void* x_h16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
                                 const float* bb, float* y0, float* y1, long M, int K, int relu, const int32_t* groups, long n_groups,
                                 void* stream);
 int dldkd_in_proj_h16_rows128b_ok(int K);
-/* The same with BF16 output rows (round to nearest even, row stride 384 bf16): what the fused tower reads through
+/* The same with h16 output rows (round to nearest even, row stride 384 h16): what the fused tower reads through
  * dldkd_tower_seq_h16_rows16 - half the bytes written here and read there (2 x 1.28 GB instead of 2 x 2.56 GB per branch pair at
  * TVR's 1.67 M clips), and the tower's prologue becomes one round of 16-byte loads straight into its operand registers. */
-int dldkd_in_proj_h16_rows128b_out16(const void* x_bf16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
-                                      const float* bb, void* y0_bf16, void* y1_bf16, long M, int K, int relu, const int32_t* groups,
+int dldkd_in_proj_h16_rows128b_out16(const void* x_h16, const float* mean, const float* rstd, const void* Wfrag, const float* cs,
+                                      const float* bb, void* y0_h16, void* y1_h16, long M, int K, int relu, const int32_t* groups,
                                       long n_groups, void* stream);
 /* PARITY-grade two-branch input projection (in_proj_rows128x3.hip): y = ReLU(LayerNorm(x) W^T + b) with fp32-grade products
  * (three bf16 planes per operand, six MFMAs per product: the scheme of dldkd_gemm_f32x3), both branches in one pass.
@@ -311,14 +317,14 @@ int dldkd_linear_f32x3_rows(const float* x, const float* mean, const float* rstd
 int dldkd_debug_in_proj_rows128_timeline(const float* x, const void* Wfrag, const float* cs, const float* bb, float* y0, float* y1,
                                          long M, int K, float eps, int relu, unsigned long long* stamps, void* stream);
 
-/* Plain y = act(x W^T + b) on the same full-row bf16 MFMA kernel (no LayerNorm fold) for the 384-wide linears of the
+/* Plain y = act(x W^T + b) on the same full-row 16-bit MFMA kernel (h16 operands, no LayerNorm fold) for the 384-wide linears of the
  * towers in throughput mode (model_components.py:388-390 query/key/value, :442 dense; model.py:39 out_mapping_linear).
- * dldkd_pack_linear_bf16_frag writes rows [n_offset, n_offset + N) of a weight block of n_total (384 or 768) output
- * columns in MFMA fragment order (bf16) and its bias into bb[n_offset ..]; call it once per source matrix.
+ * dldkd_pack_linear_h16_frag writes rows [n_offset, n_offset + N) of a weight block of n_total (384 or 768) output
+ * columns in MFMA fragment order (h16) and its bias into bb[n_offset ..]; call it once per source matrix.
  * dldkd_linear_rows_h16: x (M, K) fp32 contiguous; output columns [0, 384) go to y0 and [384, 768) to y1, both with
  * row stride ldy elements (so a (M, 1152) q|k|v buffer is filled by one N = 768 and one N = 384 launch).  out_bf16 != 0:
  * y0 / y1 are bf16 buffers (ldy a multiple of 8) - what dldkd_attention_fwd_bf16 consumes with qkv_is_bf16 != 0. */
-int dldkd_pack_linear_bf16_frag(const float* W, const float* bias, int N, int K, int n_offset, int n_total, void* Wfrag, float* bb,
+int dldkd_pack_linear_h16_frag(const float* W, const float* bias, int N, int K, int n_offset, int n_total, void* Wfrag, float* bb,
                                 void* stream);
 int dldkd_linear_rows_h16(const float* x, const void* Wfrag, const float* bb, void* y0, void* y1, int ldy, long M, int N, int K,
                            int relu, int out_bf16, void* stream);
@@ -723,14 +729,15 @@ int dldkd_bert_adam_update_f32(float* p, const float* g, float* m, float* v, con
 int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv, int ld, int32_t* counts, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * K5: the whole tower behind the input projection as ONE kernel per (32-row tile slot, branch), throughput mode (bf16 MFMA):
+ * K5: the whole tower behind the input projection as ONE kernel per (32-row tile slot, branch), throughput mode (MFMA on h16 =
+ * fp16 operands, see the K4 section; the gallery rows it writes for the scorer are bf16):
  *   h1 = LayerNorm(h0 + pos)                          TrainablePositionalEncoding.forward  method/model_components.py:277-284
  *   ctx = softmax(q k^T / sqrt(96) + key mask) v      BertSelfAttention.forward            method/model_components.py:398-436
  *   h2 = LayerNorm(ctx Wd^T + bd + h1)                BertSelfOutput / BertAttention       method/model_components.py:446-450,345-353
  *   y = h2 Wo^T + bo                                  out_mapping_linear                   method/model.py:219
  *   out_mode 1: row = bf16(y / max(|y|, 1e-12))       F.normalize in get_sim_scores        method/model.py:319
  *   out_mode 2 (query towers): modular pooling on top       get_modularized_queries      method/model.py:245-258
- * dldkd_tower_blob_bytes / dldkd_tower_pack_h16: one branch's weights as bf16 MFMA fragments in the kernel's consumption
+ * dldkd_tower_blob_bytes / dldkd_tower_pack_h16: one branch's weights as h16 MFMA fragments in the kernel's consumption
  * order (k permuted to the accumulator layout, q pre-scaled by log2(e) / sqrt(96)) followed by its bias / gamma / beta vectors;
  * all weight matrices (384, 384) row-major, vectors (384).  A video tower passes wo / bo (out_mapping_linear) and mod_w = NULL;
  * a query tower passes wo = bo = NULL and mod_w = modular_vector_mapping.weight (384).
@@ -758,14 +765,14 @@ int dldkd_tower_seq_h16(const float* const* h0, const void* const* blob, const i
                          const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                          int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
                          void* stream);
-/* out_mode 1 from BF16 h0 rows (dldkd_in_proj_h16_rows128b_out16; ragged: row0 required): the prologue is one round of
+/* out_mode 1 from h16 h0 rows (dldkd_in_proj_h16_rows128b_out16; ragged: row0 required): the prologue is one round of
  * 16-byte loads straight into the operand registers (no LDS staging); everything else as above. */
-int dldkd_tower_seq_h16_rows16(const void* const* h0_bf16, const void* const* blob, const int32_t* row0,
+int dldkd_tower_seq_h16_rows16(const void* const* h0_h16, const void* const* blob, const int32_t* row0,
                              const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                              void* const* gallery, int v0, int Lp, int32_t* lens_out, void* stream);
 
 /* Diagnostics: the out_mode 1 kernel (two branches) with clock stamps at its phase boundaries; stamps = 24 x uint64 per workgroup
- * (h16: h0 holds bf16 rows, the dldkd_tower_seq_h16_rows16 kernel)
+ * (h16 != 0: h0 holds h16 rows, the dldkd_tower_seq_h16_rows16 kernel)
  * (8 * ceil(n_items / 4) workgroups): [0] start, [1] prologue, [2 + 2 h] head h projected, [3 + 2 h] head h attended, [10] dense,
  * [11] LayerNorm, [12] out mapping, [13] rows stored, [16..21] inside the prologue (tools/tower_timeline.py). */
 int dldkd_debug_tower_seq_timeline(const float* const* h0, const void* const* blob, const int32_t* lens,
@@ -788,13 +795,13 @@ int dldkd_segment_mean_l2norm_f32(const float* frames, const int32_t* seg_start,
 int dldkd_gather_pad_rows_f32(const float* src, const long long* row_start, const int32_t* lens, const int32_t* items, int n_items,
                               int Lmax, int D, float* out, float* mask, void* stream);
 
-/* Raw feature rows -> their device-resident form (dldkd_in_proj_h16_rows128b): bf16 (round to nearest even) + fp32 LayerNorm
+/* Raw feature rows -> their device-resident form (dldkd_in_proj_h16_rows128b): h16 = fp16 (round to nearest even) + fp32 LayerNorm
  * statistics of the fp32 values (mean, rstd = 1 / sqrt(biased variance + eps): nn.LayerNorm, method/model_components.py:297).
  * src (n_items, L, K) fp32, a padded batch as collate_frame_val builds it (method/data_provider.py:111-136); row l of item b goes
  * to table row dst_row0[b] + l when l < lens[b] (lens == NULL: every row; dst_row0 == NULL: row b L + l): the padding is dropped,
- * the table is ragged.  x_bf16 (rows, K) 8-byte aligned, mean / rstd (rows). */
+ * the table is ragged.  x_h16 (rows, K) 8-byte aligned, mean / rstd (rows). */
 int dldkd_rows_to_h16_stats(const float* src, const int32_t* lens, const long long* dst_row0, int n_items, int L, int K, float eps,
-                             void* x_bf16, float* mean, float* rstd, void* stream);
+                             void* x_h16, float* mean, float* rstd, void* stream);
 
 /* Upload of a small host-produced int32 table (the slot and row-group tables of dldkd_tower_seq_h16 /
  * dldkd_in_proj_h16_rows128_groups; nothing in the reference) by a kernel: pinned_src is page-locked, device-mapped host
