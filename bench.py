@@ -306,7 +306,7 @@ def extras(dev):
         # round 3: throughput-mode gallery encode = K4 (row groups: padding skipped) + the fused tower kernel K5 straight into the
         # packed bf16 gallery, ragged lengths U{24..128}
         out["gallery_encode_videos_per_s_fused_k4_k5"] = out["eval_epoch_gpu_stages_fast"].get("gallery_videos_per_sec")
-        # round 3, second half: what eval_epoch runs now - the gallery's raw features resident as a ragged bf16 table with the
+        # round 3, second half: what eval_epoch runs now - the gallery's raw features resident as a ragged fp16 table with the
         # rows' LayerNorm statistics (filled once), K4b over the whole table + the fused tower kernel over all videos
         out["eval_epoch_gpu_stages_resident"] = stage_times(NV, NQ, "resident", str(dev))
         out["gallery_encode_videos_per_s_resident_k4b_k5"] = out["eval_epoch_gpu_stages_resident"].get("gallery_videos_per_sec")
@@ -345,7 +345,7 @@ def extras(dev):
         out["k4_in_proj_roofline"] = {"bound": "hbm", "achieved": byts / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
                                       "frac": byts / ms / 1e6 / 8000.0, "kernel": "in_proj_rows128_kernel (dldkd_in_proj_h16_rows128)", "kernel_ms": ms,
                                       "shape": "400000 rows x 3072 fp32 -> 2 x 384 fp32", "timing": "median of 10 launches after 3 warm-ups"}
-        # K4b on the same rows in their resident form (bf16 + row statistics): 307 -> 560 flop per byte, the MFMA pipe is its bound
+        # K4b on the same rows in their resident form (fp16 + row statistics): 307 -> 560 flop per byte, the MFMA pipe is its bound
         tab = ops.ResidentRows(3072, dev, 400000)
         for lo in range(0, 400000, 50000):
             tab.append(xk[lo:lo + 50000].view(50, 1000, 3072), [1000] * 50)
@@ -365,7 +365,7 @@ def extras(dev):
         bytes_b = 400000 * 3072 * 2 + 400000 * 8 + 400000 * 768 * 4 + 768 * 3072 * 2
         out["k4b_in_proj_roofline"] = {"bound": "mfma", "achieved": flops / msb / 1e9, "peak": 2500.0, "unit": "TFLOP/s",
                                        "frac": flops / msb / 1e9 / 2500.0, "kernel": "in_proj_rows128b_kernel (dldkd_in_proj_h16_rows128b)",
-                                       "kernel_ms": msb, "shape": "400000 rows x 3072 bf16 (+ mean, rstd) -> 2 x 384 fp32",
+                                       "kernel_ms": msb, "shape": "400000 rows x 3072 fp16 (+ mean, rstd) -> 2 x 384 fp32",
                                        "algorithmic_GB": bytes_b / 1e9, "hbm_GBps": bytes_b / msb / 1e6,
                                        "same_rows_fp32_k4_ms": ms, "timing": "median of 10 launches after 3 warm-ups"}
         del tab, outs_b
@@ -667,12 +667,13 @@ def main():
         # KiB units; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md section HBM) from the committed
         # profile of this same workload.  Not re-measured live (PMC needs the profiler).
         traffic, traffic_src = None, None
-        for rnd in ("r04", "r03", "r02"):
-            pmc = os.path.join(ROOT, "profiles", rnd, "pmc_simpool", "summary.json")
+        for pmc in [os.path.join(ROOT, "profiles", "r05", "pmc_simpool.json")] + [os.path.join(ROOT, "profiles", r_, "pmc_simpool", "summary.json")
+                                                                                  for r_ in ("r04", "r03", "r02")]:
+            rnd = os.path.relpath(pmc, os.path.join(ROOT, "profiles")).split(os.sep)[0]
             if os.path.exists(pmc):
                 d = json.load(open(pmc))
                 traffic = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
-                traffic_src = f"profiles/{rnd}/pmc_simpool/summary.json (rocprofv3 --pmc, separate passes; 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KiB units)"
+                traffic_src = f"{os.path.relpath(pmc, ROOT)} (rocprofv3 --pmc, separate passes; 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KiB units)"
                 break
         out = {
             "metric": metric, "value": NQ * NV * a.steps / dt, "unit": "pairs/s", "n_gpus": 1,

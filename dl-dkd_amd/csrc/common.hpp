@@ -34,18 +34,29 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
 // where the values no longer matter).  Training keeps bf16 (gradients need the exponent range).  The containers stay `short`
 // vectors (bf16x8): only the conversions and the MFMA opcode differ.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
+#ifndef DLDKD_H16_IS_BF16            // (make H16_BF16=1: the bf16 form of the same kernels, for same-box A/B runs only - tools/r05_ab_h16.sh)
 __device__ __forceinline__ unsigned short f32_to_h16_bits(float x) {       // round to nearest even (v_cvt_f16_f32 / v_cvt_pk_f16_f32)
     return __builtin_bit_cast(unsigned short, static_cast<_Float16>(x));
 }
 __device__ __forceinline__ float h16_bits_to_f32(unsigned short b) { return static_cast<float>(__builtin_bit_cast(_Float16, b)); }
-// two fp32 -> one dword of two h16 (lo = a, hi = b)
-__device__ __forceinline__ unsigned h16_pack2(float a, float b) {
-    unsigned u;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u) : "v"(a), "v"(b));
-    return u;
-}
 #define DLDKD_H16_MFMA32 "v_mfma_f32_32x32x16_f16"
 #define DLDKD_H16_CVT_PK "v_cvt_pk_f16_f32"
+template <class A, class B>
+__device__ __forceinline__ f32x16_ h16_mfma32(const A& a, const B& b, const f32x16_& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+#else
+typedef short s16x8_ __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned short f32_to_h16_bits(float x) { return __builtin_bit_cast(unsigned short, static_cast<__bf16>(x)); }
+__device__ __forceinline__ float h16_bits_to_f32(unsigned short b) { return __builtin_bit_cast(float, static_cast<unsigned int>(b) << 16); }
+#define DLDKD_H16_MFMA32 "v_mfma_f32_32x32x16_bf16"
+#define DLDKD_H16_CVT_PK "v_cvt_pk_bf16_f32"
+template <class A, class B>
+__device__ __forceinline__ f32x16_ h16_mfma32(const A& a, const B& b, const f32x16_& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8_, a), __builtin_bit_cast(s16x8_, b), c, 0, 0, 0);
+}
+#endif
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void in_proj_bf16_kernel(const InProjArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = h16_mfma32(a[i], b[j], acc[i][j]);
         }
         if (kt + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void rows_linear_bf16_kernel(const InProjAr
             for (int i = 0; i < RT; ++i) {   // one A fragment live at a time: 192 accumulators leave little room
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (32 * i + (lane & 31)) * FPITCH + kk * 16 + (lane >> 5) * 8);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 3; ++j) acc[i][j] = h16_mfma32(a, b[j], acc[i][j]);
             }
         }
         if (kt + 1 < nk) xstore(cur ^ 1);

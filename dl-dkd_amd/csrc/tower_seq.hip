@@ -514,14 +514,14 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         static_for<0, kNKS>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value, n = decltype(n0c)::value + ks;
             pre(std::integral_constant<int, n>{});
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[n % kFr]), __builtin_bit_cast(f16x8, X[ks]), acc, 0, 0, 0);
+            acc = h16_mfma32(fr[n % kFr], X[ks], acc);
         });
     };
     auto nprod = [&](auto n0c, f32x16& acc, const bf16x8 (&X)[kNKS]) {
         static_for<0, kNKS>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value, n = decltype(n0c)::value + ks;
             pre(std::integral_constant<int, n>{});
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, X[ks]), __builtin_bit_cast(f16x8, fr[n % kFr]), acc, 0, 0, 0);
+            acc = h16_mfma32(X[ks], fr[n % kFr], acc);
         });
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
                 for (int e = 0; e < 16; ++e) sa[kt][e] = (kt == ntiles - 1 && (e & 3) + 8 * (e >> 2) >= krem) ? -INFINITY : 0.f;
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
-                    sa[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Kl[((first + kt) * 6 + i) * 64 + lane]), __builtin_bit_cast(f16x8, Qf[i]), sa[kt], 0, 0, 0);
+                    sa[kt] = h16_mfma32(Kl[((first + kt) * 6 + i) * 64 + lane], Qf[i], sa[kt]);
             }
         });
         // (key tiles past the sequence - 4 - ntiles of them, wave-uniform - take no part: no -inf fill, no max / exp / sum over them:
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
                     const bf16x8 pf = pack8(v);
 #pragma unroll
                     for (int dt = 0; dt < 3; ++dt)
-                        oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Vl[((first + kt) * 6 + 2 * dt + s) * 64 + lane]), __builtin_bit_cast(f16x8, pf), oa[dt], 0, 0, 0);
+                        oa[dt] = h16_mfma32(Vl[((first + kt) * 6 + 2 * dt + s) * 64 + lane], pf, oa[dt]);
                 }
             }
         });

@@ -18,7 +18,7 @@ for (n, L) in ((5, 32), (37, 128), (300, 96)) if mode == "all" else ():
     tab.append(x[: n // 2], lens[: n // 2]); tab.append(x[n // 2:], lens[n // 2:])
     rows = torch.cat([x[i, :lens[i]] for i in range(n)], 0)
     assert tab.rows == rows.shape[0]
-    assert torch.equal(tab.xb[:tab.rows], rows.to(torch.bfloat16))
+    assert torch.equal(tab.xb[:tab.rows], rows.to(torch.float16))
     mu = rows.double().mean(1); var = rows.double().var(1, unbiased=False)
     print("stats err", (tab.mean[:tab.rows].double() - mu).abs().max().item(), (tab.rstd[:tab.rows].double() * (var + 1e-5).sqrt() - 1).abs().max().item())
     with torch.no_grad():
@@ -29,8 +29,8 @@ for (n, L) in ((5, 32), (37, 128), (300, 96)) if mode == "all" else ():
             d = (y[b] - y_ref[b]).abs().max().item()
             # fp64 reference with the kernel's roundings: bf16 x, bf16 W', fp32-ish stats
             l = layers[b]
-            Wp = (l.net[1].weight * l.LayerNorm.weight).to(torch.bfloat16).double()
-            xr = rows.to(torch.bfloat16).double()
+            Wp = (l.net[1].weight * l.LayerNorm.weight).to(torch.float16).double()
+            xr = rows.to(torch.float16).double()
             ref = (xr @ Wp.T - mu[:, None] * Wp.sum(1)[None]) / (var + 1e-5).sqrt()[:, None] + (l.net[1].weight.double() @ l.LayerNorm.bias.double() + l.net[1].bias.double())
             ref = ref.clamp_min(0)
             print(n, L, "branch", b, "max |K4b - K4|", d, "max |K4b - fp64|", (y[b].double() - ref).abs().max().item(), "scale", ref.abs().max().item())
