@@ -1,5 +1,6 @@
 // Stand-alone client of the C ABI (include/dldkd_hip.h): no Python, no torch.  What a C/C++ host (or a cgo/JNI/ctypes
-// stub) would do: allocate device buffers with the HIP runtime, pack, score, finish, copy back.
+// stub) would do: allocate device buffers with the HIP runtime, pack, score, finish, copy back; then a one-rank RCCL
+// communicator through the same ABI (dldkd_comm_*).
 // The check is a scalar loop in this file over the SAME bf16-rounded, L2-normalised operands (fp64 accumulation):
 //   fused[q][v] = 0.7 * max_{l < len_v} <q0, g0[v][l]> + 0.3 * max_l <q1, g1[v][l]>       (model.py:318-327, eval.py:254)
 // Build:  hipcc --offload-arch=gfx950 -I include tests/c/abi_client.cpp -L dl-dkd_amd/dldkd_amd -ldldkd_hip -o tests/c/abi_client
@@ -123,6 +124,34 @@ int main() {
     if (dldkd_simpool_eval_bf16(pq, pg, dlens, dorder, NQ, NV, DLDKD_MAX_CLIPS + 1, NB, 0, nullptr, ws, nullptr) == 0 ||
         std::strlen(dldkd_last_error()) == 0) { std::fprintf(stderr, "bad-size call was accepted\n"); return 5; }
     if (worst > 2e-5) { std::fprintf(stderr, "max |HIP - host| = %g\n", worst); return 6; }
+    // Collectives (one rank): the library finds RCCL by itself (no torch in this process: the system librccl.so.1), a communicator is
+    // an explicit object, every collective is one enqueue on the caller's stream.  One rank: sum / gather / broadcast are identities.
+    {
+        if (dldkd_comm_rccl_version() < 20000) { std::fprintf(stderr, "rccl version %d: %s\n", dldkd_comm_rccl_version(), dldkd_last_error()); return 7; }
+        unsigned char id[DLDKD_COMM_ID_BYTES];
+        void* comm = nullptr;
+        ABICHK(dldkd_comm_unique_id(id));
+        ABICHK(dldkd_comm_init(&comm, 1, 0, id));
+        int world = -1, rank = -1;
+        ABICHK(dldkd_comm_info(comm, &world, &rank));
+        if (world != 1 || rank != 0) { std::fprintf(stderr, "comm_info: %d of %d\n", rank, world); return 7; }
+        hipStream_t st;
+        HIPCHK(hipStreamCreate(&st));
+        float *dgather = nullptr;
+        HIPCHK(hipMalloc(&dgather, fused.size() * 4));
+        ABICHK(dldkd_comm_all_reduce(comm, dfused, dfused, fused.size(), DLDKD_F32, DLDKD_SUM, st));        // in place, like the gradient buffer
+        ABICHK(dldkd_comm_all_gather(comm, dfused, dgather, fused.size(), DLDKD_F32, st));                  // like a block of scores
+        ABICHK(dldkd_comm_broadcast(comm, dgather, fused.size(), DLDKD_F32, 0, st));
+        HIPCHK(hipStreamSynchronize(st));
+        ABICHK(dldkd_comm_async_error(comm));
+        std::vector<float> back(fused.size());
+        HIPCHK(hipMemcpy(back.data(), dgather, back.size() * 4, hipMemcpyDeviceToHost));
+        if (std::memcmp(back.data(), fused.data(), back.size() * 4) != 0) { std::fprintf(stderr, "one-rank collectives changed the data\n"); return 7; }
+        if (dldkd_comm_all_reduce(comm, dfused, dfused, 4, 99, DLDKD_SUM, st) != DLDKD_EINVAL) { std::fprintf(stderr, "bad dtype accepted\n"); return 7; }
+        ABICHK(dldkd_comm_destroy(comm));
+        HIPCHK(hipStreamDestroy(st));
+        HIPCHK(hipFree(dgather));
+    }
     std::printf("abi_client ok: %d x %d x <=%d clips, 2 branches, max |HIP - host scalar loop| = %.2e\n", NQ, NV, L, worst);
     return 0;
 }
