@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1700
 lens = torch.randint(1, 129, (n,), generator=g).tolist()
 ts, packs, _, lens_t = Tt._setup(seed=4, lens=lens)
 rows = int(sum(lens))
-h16 = [torch.relu(torch.randn(rows, H, generator=g)).bfloat16().to(DEV) for _ in range(2)]
+h16 = [torch.relu(torch.randn(rows, H, generator=g)).half().to(DEV) for _ in range(2)]
 row0 = torch.tensor([0] + np.cumsum(lens)[:-1].tolist(), dtype=torch.int32, device=DEV)
 items_np = ops.plan_tower_items(lens_t.numpy())
 items = torch.from_numpy(items_np).to(DEV)

@@ -30,7 +30,7 @@ def main(n=1024, dev="cuda:0", ragged=True, h16=False):
     n_wg = 8 * ((items.shape[0] + 3) // 4)
     stamps = torch.zeros(n_wg, 24, dtype=torch.int64, device=dev)
     L = native.lib()
-    hs = [(x.bfloat16() if h16 else x).view(-1, 384) for x in h0]
+    hs = [(x.half() if h16 else x).view(-1, 384) for x in h0]
     for _ in range(3):
         native.check(L.dldkd_debug_tower_seq_timeline(native.ptr_array(hs),
                                                       native.ptr_array([p.blob for p in packs]), native.ptr(lens), native.ptr(items),
