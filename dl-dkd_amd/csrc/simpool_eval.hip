@@ -29,6 +29,9 @@
 
 #include "common.hpp"
 
+#ifndef DLDKD_FIN_SWZ
+#define DLDKD_FIN_SWZ 1
+#endif
 namespace dldkd {
 
 constexpr int kQTile = 32;                     // queries per LDS tile (two 16-query sub-tiles)
@@ -811,7 +814,17 @@ __global__ __launch_bounds__(256) void simpool_finish64_kernel(const float* __re
                                                                float* __restrict__ s0, float* __restrict__ s1) {
     __shared__ float t0[64][65];
     __shared__ float t1[64][65];
+#if DLDKD_FIN_SWZ
+    // 1-D grid, XCD-aware (workgroup id % 8 = XCD): all video tiles of query tile qt run on XCD qt % 8, consecutively - an output row
+    // has 4 * nv bytes, so the 256-byte segments two neighbouring video tiles write share a 128-byte line at their seam; with the
+    // neighbours on one XCD, back to back, the two halves of such a line meet in ONE L2 instead of leaving two as partial lines
+    const int n_vt = (nv + 63) >> 6, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int qt = (slot / n_vt) * 8 + xcd, vt = slot % n_vt;
+    const int q0 = q_lo + qt * 64, v0 = vt * 64;
+    if (q0 >= q_hi) return;
+#else
     const int q0 = q_lo + blockIdx.x * 64, v0 = blockIdx.y * 64;
+#endif
     {
         const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 float4 along q x 16 video rows per pass
         const int q = q0 + 4 * tx;
@@ -1059,7 +1072,13 @@ int dldkd_simpool_finish_range(const void* workspace, const int32_t* inv_order, 
     if (q_hi == q_lo || nv == 0 || (!fused && !s0 && !s1)) return DLDKD_OK;
     if (!workspace || !inv_order) { set_error("simpool_finish: null pointer"); return DLDKD_EINVAL; }
     const int nq_pad = round_up(nq, kQTile);
-    DLDKD_LAUNCH(simpool_finish64_kernel, dim3((q_hi - q_lo + 63) / 64, (nv + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+#if DLDKD_FIN_SWZ
+    const unsigned n_qt = (unsigned)((q_hi - q_lo + 63) / 64), n_vt = (unsigned)((nv + 63) / 64);
+    const dim3 grid(8u * n_vt * ((n_qt + 7u) / 8u));
+#else
+    const dim3 grid((q_hi - q_lo + 63) / 64, (nv + 63) / 64);
+#endif
+    DLDKD_LAUNCH(simpool_finish64_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, inv_order, q_lo, q_hi, nq_pad, nv, n_branches, w0, w1, q_bad, fused, s0, s1);
     return check_launch("simpool_finish");
 }
