@@ -137,8 +137,9 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--sigma", type=float, default=6.0)
     ap.add_argument("--out", default="")
+    ap.add_argument("--chunk", type=int, default=512, help="queries per oracle get_sim_scores call (50 = the reference's eval_query_bsz; same arithmetic)")
     a = ap.parse_args()
-    res = run(a.seeds, a.nv, a.nq, a.steps, a.sigma)
+    res = run(a.seeds, a.nv, a.nq, a.steps, a.sigma, chunk=a.chunk)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         json.dump(res, open(a.out, "w"), indent=1)
