@@ -645,6 +645,14 @@ class GraphedTrainStep:
                     e.loss = F_.sum_scalars(*[e.parts[k] for k in keys]).detach()
                 e.par["tail_kept"], e.par["tail"] = e.par["tail"], None      # (kept alive: its pool holds the branch graphs' tensors)
             e.had = opt_.fp.rebind_grads()
+            # opt.ddp_allreduce_in_graph (off by default): the gradient all-reduce as a NODE of the optimizer graph - RCCL enqueues
+            # into the capturing stream like any launch (comm.RcclComm: tests/test_comm_gpu.py captures a gather) - instead of one
+            # enqueue between the graphs: one launch boundary fewer on the serial tail.  Off by default because a captured collective
+            # over more than one rank cannot be validated from a one-GPU environment.
+            e.par["ar_in_graph"] = bool(e.ddp and getattr(self.opt, "ddp_allreduce_in_graph", False))
+            if e.par["ar_in_graph"]:
+                from . import dist as ddist
+                ddist.all_reduce_flat(opt_.fp.grad)
             opt_.enqueue(upload_lr=False)
             close_graph()
             e.par["ev"] = {"fwd": [torch.cuda.Event() for _ in range(n)], "bwd": [torch.cuda.Event() for _ in range(n)],
@@ -700,9 +708,13 @@ class GraphedTrainStep:
             par["tail"].replay()
         if e.ddp:
             # every tower's gradients are in the flat buffer (the waits above): the mean all-reduce is one enqueue on this stream
-            # between the backward graphs and the optimizer graph
+            # between the backward graphs and the optimizer graph (or a node of that graph: opt.ddp_allreduce_in_graph - the flag
+            # check keeps its rank-invariant cadence either way)
             from . import dist as ddist
-            ddist.sync_gradients(self.optimizer.fp, had=e.had)
+            if par.get("ar_in_graph"):
+                ddist.check_had_flags(self.optimizer.fp, e.had)
+            else:
+                ddist.sync_gradients(self.optimizer.fp, had=e.had)
         par["opt"].replay()
 
     def _replay(self, e, batch):

@@ -119,7 +119,8 @@ def test_communicators_come_and_go():
     assert dcomm.current() is None and dcomm.info() == (0, 1)
 
 
-def test_data_parallel_replay_uses_the_tower_graphs_with_one_all_reduce(rccl_comm):
+@pytest.mark.parametrize("in_graph", [False, True])
+def test_data_parallel_replay_uses_the_tower_graphs_with_one_all_reduce(rccl_comm, in_graph):
     """The data-parallel step of the default layout (one gradient bucket): the same tower graphs as on one GPU, ONE all-reduce
     enqueued between the backward graphs and the optimizer graph, the optimizer graph computing the clip's norms from the reduced
     gradients.  Against the one-GPU stepper from the same state on the same seeds: same loss, same parameters (a mean over one rank
@@ -154,12 +155,13 @@ def test_data_parallel_replay_uses_the_tower_graphs_with_one_all_reduce(rccl_com
         T.DDP_MIN_WORLD = 1
         md, od = make()
         # (as under a real data-parallel run, world >= 2: no self-check - it would step the capture batch twice, with two all-reduces)
-        ddp = T.GraphedTrainStep(md, od, types.SimpleNamespace(grad_clip=-1, graph_self_check=False))
+        ddp = T.GraphedTrainStep(md, od, types.SimpleNamespace(grad_clip=-1, graph_self_check=False, ddp_allreduce_in_graph=in_graph))
         assert ddp.self_check is False and plain.self_check is True
         calls = []
         real = rccl_comm.all_reduce
         rccl_comm.all_reduce = lambda t, op="sum", async_op=False: (calls.append((t.numel(), op)), real(t, op, async_op))[1]
         from dldkd_amd import ops
+        replays_before = captures_before = 0
         for it in range(8):
             # both steppers start every step from the same state (the step's fp32 atomics make two runs drift apart at rounding
             # level per step; the test is about one step's arithmetic, step after step)
@@ -174,7 +176,13 @@ def test_data_parallel_replay_uses_the_tower_graphs_with_one_all_reduce(rccl_com
             n0 = len(calls)
             ld, _ = ddp(batches[it % 2])
             grads = [c_ for c_ in calls[n0:] if c_[0] == od.fp.grad.numel()]
-            assert len(grads) == 1 and grads[0][1] == "sum", (it, calls[n0:])      # exactly one gradient all-reduce per step
+            # exactly one gradient all-reduce per step: enqueued between the graphs, or (in_graph) captured once into the optimizer
+            # graph - the capture step sees the call, the replays run the node
+            replayed = ddp.replays > replays_before
+            replays_before = ddp.replays
+            expect = 0 if (in_graph and replayed and ddp.captures == captures_before) else 1
+            captures_before = ddp.captures
+            assert len(grads) == expect and all(g_[1] == "sum" for g_ in grads), (it, in_graph, calls[n0:])
             assert float(lp) == pytest.approx(float(ld), rel=1e-5), it
             tol = 2e-7 + 0.02 * od.get_lr()[0]
             assert (op_.fp.flat - od.fp.flat).abs().max().item() <= tol, it
@@ -182,5 +190,6 @@ def test_data_parallel_replay_uses_the_tower_graphs_with_one_all_reduce(rccl_com
         assert ddp.captures >= 1 and ddp.replays >= 5 and ddp.capture_failures == 0 and ddp.fallbacks == []
         e = next(iter(ddp.graphs.values()))
         assert e.ddp and getattr(e, "par", None), "the data-parallel step should replay the tower graphs"
+        assert e.par["ar_in_graph"] is in_graph
     finally:
         T.DDP_MIN_WORLD = old
