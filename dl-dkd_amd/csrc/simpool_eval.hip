@@ -32,6 +32,9 @@
 #ifndef DLDKD_FIN_SWZ
 #define DLDKD_FIN_SWZ 1
 #endif
+#ifndef K1_NT
+#define K1_NT 0      // A/B switch (tools/r05_ab_k1_nt.sh): 1 = non-temporal plane stores, 2 = non-temporal gallery loads, 3 = both
+#endif
 namespace dldkd {
 
 constexpr int kQTile = 32;                     // queries per LDS tile (two 16-query sub-tiles)
@@ -342,7 +345,7 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
                     // after the two swaps all four 16-lane groups hold the same maximum and prev_out is indexed by lane & 15:
                     // every lane stores (four identical writes per address) - no exec masking, no branch around the store
                     // (same-box A/B: 19.59 -> 19.38 ms)
-                    *prev_out = m;
+                    if constexpr (K1_NT & 1) __builtin_nontemporal_store(m, prev_out); else *prev_out = m;
                 }
                 // one 1-KiB LDS-DMA piece of tile t+2 per k-step of sub-tile 0 (6 per wave) instead of all six at the top
                 // of the tile, where the MFMA pipe waited for their issue (same-box A/B: 20.27-20.42 -> 20.03-20.06 ms).
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(256, 1) void simpool_eval16_kernel(const SimpoolEva
     for (int rt = 0; rt < 8; ++rt) {
         if (rt < nrt) {
 #pragma unroll
-            for (int ks = 0; ks < kKSteps16; ++ks) a[rt][ks] = gv[(size_t)rt * 16 * kRowBf16x8 + ks * 4];
+            for (int ks = 0; ks < kKSteps16; ++ks) a[rt][ks] = (K1_NT & 2) ? __builtin_nontemporal_load(gv + (size_t)rt * 16 * kRowBf16x8 + ks * 4) : gv[(size_t)rt * 16 * kRowBf16x8 + ks * 4];
         } else {
 #pragma unroll
             for (int ks = 0; ks < kKSteps16; ++ks) a[rt][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -622,7 +625,7 @@ __device__ __forceinline__ void score_stream16p(const bf16x8 (&a)[8][kKSteps16],
                 } else if constexpr (ks == 10) {
                     m = xor16_max(m);
                 } else {
-                    *prev_out = m;
+                    if constexpr (K1_NT & 1) __builtin_nontemporal_store(m, prev_out); else *prev_out = m;
                 }
                 // one 1-KiB LDS-DMA piece of tile t+2 per k-step of sub-tile 0 (6 per wave) instead of all six at the top
                 // of the tile, where the MFMA pipe waited for their issue (same-box A/B: 20.27-20.42 -> 20.03-20.06 ms).
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(256, 1) void simpool_eval16p_kernel(const SimpoolPa
             const int row = inA ? min(r, max(lenA - 1, 0)) : min(r - cA, lenB - 1);
             const bf16x8* gv = p.g[branch] + ((size_t)v * p.Lp + row) * kRowBf16x8 + (lane >> 4);
 #pragma unroll
-            for (int ks = 0; ks < kKSteps16; ++ks) a[rt][ks] = gv[ks * 4];
+            for (int ks = 0; ks < kKSteps16; ++ks) a[rt][ks] = (K1_NT & 2) ? __builtin_nontemporal_load(gv + ks * 4) : gv[ks * 4];
         } else {
 #pragma unroll
             for (int ks = 0; ks < kKSteps16; ++ks) a[rt][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
