@@ -32,6 +32,9 @@
 #ifndef DLDKD_FIN_SWZ
 #define DLDKD_FIN_SWZ 1
 #endif
+#ifndef K1_ROT
+#define K1_ROT 1     // query tiles visited in an order rotated by the chip-wide clock (see score_stream16): A/B switch, tools/r05_ab_k1_rot.sh
+#endif
 #ifndef K1_NT
 #define K1_NT 0      // A/B switch (tools/r05_ab_k1_nt.sh): 1 = non-temporal plane stores, 2 = non-temporal gallery loads, 3 = both
 #endif
@@ -249,12 +252,38 @@ __device__ __forceinline__ void lds_read_frag_off(bf16x8& dst, uint32_t lds_addr
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF) : "memory");
 }
 
+// Rotation of a workgroup's query-tile order (K1_ROT): workgroups are dispatched as CUs free up, i.e. at times spread over a
+// workgroup's whole life, and each streams its range's tiles from the first one - at any moment the 32 workgroups of an XCD are
+// spread over the whole 8.4-MB query blob, twice its 4-MiB L2: 6.8 GB of query tiles per launch came from beyond L2
+// (profiles/r04/pmc_simpool).  Starting at tile (clock / time per tile) mod T instead puts every workgroup of the chip on the same
+// tile at the same time, whenever it was dispatched.  s_memrealtime is the chip-wide constant 100-MHz counter; a tile of nrt row tiles
+// takes ~27 ticks per row tile (2.15 us at 8).  One lane reads the clock, the workgroup shares it through LDS.
+__device__ __forceinline__ int pick_rot(int T, int nrt_hint) {
+#if K1_ROT
+    __shared__ int s_rot;
+    if (threadIdx.x == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();     // (NOT s_memtime: that one counts core clocks, per XCD)
+        const unsigned per = (K1_ROT == 3 ? 23u : 27u) * (unsigned)(nrt_hint < 1 ? 1 : nrt_hint);
+        // ... minus a lag of 0..31 tiles by the workgroup's index within its XCD (blockIdx % 8 = XCD): with every workgroup of an
+        // XCD on the SAME tile at the same instant all 32 miss together and the L2 fetches the tile 32 times (measured: 31 GB per
+        // launch instead of 9); staggered, the first one misses and the others find the tile in L2 a few microseconds later
+        const unsigned lag = K1_ROT == 2 ? 0u : (blockIdx.x >> 3) & 31u;
+        s_rot = T > 1 ? (int)((now / per + (unsigned long long)T - lag % (unsigned)T) % (unsigned long long)T) : 0;
+    }
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(s_rot);
+#else
+    (void)T; (void)nrt_hint;
+    return 0;
+#endif
+}
+
 // ABL (diagnostic builds only, DLDKD_SIMPOOL_ABLATE): 1 = no max-pool / stores, 2 = no in-loop LDS-DMA staging,
 // 4 = no per-tile barrier, 8 = no B-fragment LDS reads (ring registers reused).  Results are wrong by design;
 // only the timing matters (cdna_hip_programming.md section 7, "Ablate").
 template <int NRT, int ABL = 0>
 __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], const SimpoolEvalArgs& p, int branch,
-                                               int vs, int t0, int T, char* smem) {
+                                               int vs, int t0, int T, char* smem, int rot = 0) {
     // this workgroup streams query tiles [t0, t0 + T) of the packed blob
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -270,14 +299,18 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
         }
     };
 
-    stage(0, 0);
-    if (T > 1) stage(1, 1);
+    // The range's tiles are visited in an order ROTATED by `rot` (the same for the four waves): iteration i works on tile tau(i).
+    // Every tile's scores are stored where they belong, so any rotation gives the same planes; the kernels pick rot from the
+    // chip-wide clock so that workgroups dispatched at different times stream the SAME query tiles at the same time (K1_ROT).
+    auto tau = [&](int i) { const int x = i + rot; return x >= T ? x - T : x; };
+    stage(tau(0), 0);
+    if (T > 1) stage(tau(1), 1);
 
     if constexpr (NRT == 0) {   // padding wave: staging + barriers only
         int slot2 = 2;
         for (int t = 0; t < T; ++t) {
             __syncthreads();
-            if (t + 2 < T) stage(t + 2, slot2);
+            if (t + 2 < T) stage(tau(t + 2), slot2);
             slot2 = slot2 == kRing - 1 ? 0 : slot2 + 1;
         }
     } else {
@@ -388,7 +421,7 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (t == 0 || !(ABL & 4)) __builtin_amdgcn_s_barrier();
             // staging of tile t+2 is spread over the k-steps of sub-tile 0; past the end it re-stages tile T-1 into a free slot
-            const int t2 = t + 2 < T ? t + 2 : T - 1;
+            const int t2 = tau(t + 2 < T ? t + 2 : T - 1);
             const char* st_src = qsrc + (size_t)t2 * kQTileBytes + (size_t)wave * 6 * 1024 + lane * 16;
             char* st_dst = smem + slot2 * kQTileBytes + wave * 6 * 1024;
             const int nslot = slot == kRing - 1 ? 0 : slot + 1;
@@ -404,8 +437,11 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
             }
             // t == 0: there is no previous sub-tile; its (garbage) result goes to queries 0..15, which the
             // next sub-tile's store - later in program order, same lanes, same addresses - overwrites.
-            subtile(std::integral_constant<int, 0>{}, accA, accB, cbase, nbase, outp + (t > 0 ? (size_t)t * kQTile - 16 : 0), st_src, st_dst);
-            subtile(std::integral_constant<int, 1>{}, accB, accA, cbase, nbase, outp + (size_t)t * kQTile, st_src, st_dst);
+            // (the previous sub-tile is the second half of tile tau(t - 1); at t == 0 the garbage goes where this tile's first half
+            // is stored next)
+            const size_t o_cur = (size_t)tau(t) * kQTile;
+            subtile(std::integral_constant<int, 0>{}, accA, accB, cbase, nbase, outp + (t > 0 ? (size_t)tau(t - 1) * kQTile + 16 : o_cur), st_src, st_dst);
+            subtile(std::integral_constant<int, 1>{}, accB, accA, cbase, nbase, outp + o_cur, st_src, st_dst);
             slot = nslot;
             slot2 = slot2 == kRing - 1 ? 0 : slot2 + 1;
         }
@@ -418,7 +454,7 @@ __device__ __forceinline__ void score_stream16(const bf16x8 (&a)[8][kKSteps16], 
             m = fmaxf(m, x);
         }
         m = xor32_max(xor16_max(m));
-        if (lane < 16) outp[(size_t)(T - 1) * kQTile + 16] = m;
+        if (lane < 16) outp[(size_t)tau(T - 1) * kQTile + 16] = m;
     }
 }
 
@@ -468,29 +504,30 @@ __global__ __launch_bounds__(256, 1) void simpool_eval16_kernel(const SimpoolEva
             else asm volatile("" : "+v"(a[rt][ks]));
         }
 
+    const int rot = pick_rot(T, nrt);                         // (every wave of the workgroup, padding waves included)
 #ifdef DLDKD_DIAG_ABLATE   // `make DIAG=1`: co-compiled variants perturb the shipped one's codegen (rule 19)
     if (p.ablate && nrt == 8) {   // diagnostic timing builds, full-length videos only
         switch (p.ablate) {
-            case 1: score_stream16<8, 1>(a, p, branch, vs, t0, T, smem); return;
-            case 2: score_stream16<8, 2>(a, p, branch, vs, t0, T, smem); return;
-            case 4: score_stream16<8, 4>(a, p, branch, vs, t0, T, smem); return;
-            case 8: score_stream16<8, 8>(a, p, branch, vs, t0, T, smem); return;
-            case 15: score_stream16<8, 15>(a, p, branch, vs, t0, T, smem); return;
+            case 1: score_stream16<8, 1>(a, p, branch, vs, t0, T, smem, rot); return;
+            case 2: score_stream16<8, 2>(a, p, branch, vs, t0, T, smem, rot); return;
+            case 4: score_stream16<8, 4>(a, p, branch, vs, t0, T, smem, rot); return;
+            case 8: score_stream16<8, 8>(a, p, branch, vs, t0, T, smem, rot); return;
+            case 15: score_stream16<8, 15>(a, p, branch, vs, t0, T, smem, rot); return;
             default: break;
         }
     }
 #endif
     switch (nrt) {
-        case 8: score_stream16<8>(a, p, branch, vs, t0, T, smem); break;
-        case 7: score_stream16<7>(a, p, branch, vs, t0, T, smem); break;
-        case 6: score_stream16<6>(a, p, branch, vs, t0, T, smem); break;
-        case 5: score_stream16<5>(a, p, branch, vs, t0, T, smem); break;
-        case 4: score_stream16<4>(a, p, branch, vs, t0, T, smem); break;
-        case 3: score_stream16<3>(a, p, branch, vs, t0, T, smem); break;
-        case 2: score_stream16<2>(a, p, branch, vs, t0, T, smem); break;
-        case 1: score_stream16<1>(a, p, branch, vs, t0, T, smem); break;
+        case 8: score_stream16<8>(a, p, branch, vs, t0, T, smem, rot); break;
+        case 7: score_stream16<7>(a, p, branch, vs, t0, T, smem, rot); break;
+        case 6: score_stream16<6>(a, p, branch, vs, t0, T, smem, rot); break;
+        case 5: score_stream16<5>(a, p, branch, vs, t0, T, smem, rot); break;
+        case 4: score_stream16<4>(a, p, branch, vs, t0, T, smem, rot); break;
+        case 3: score_stream16<3>(a, p, branch, vs, t0, T, smem, rot); break;
+        case 2: score_stream16<2>(a, p, branch, vs, t0, T, smem, rot); break;
+        case 1: score_stream16<1>(a, p, branch, vs, t0, T, smem, rot); break;
         default:
-            score_stream16<0>(a, p, branch, vs, t0, T, smem);
+            score_stream16<0>(a, p, branch, vs, t0, T, smem, rot);
             // a real video with no valid clip: the reference's masked maximum is exactly -1e10 (mask_logits, model.py:444)
             if (vs < p.nv) {
                 float* row = p.part + ((size_t)branch * p.nv + vs) * p.nq_pad + (size_t)t0 * kQTile;
@@ -527,7 +564,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // store with a per-lane row pointer writes both.  Instruction for instruction the one-video loop + 3 VALU.
 template <int KB>
 __device__ __forceinline__ void score_stream16p(const bf16x8 (&a)[8][kKSteps16], const SimpoolEvalArgs& p, int branch,
-                                                int posA, int posB, int cA, int t0, int T, char* smem) {
+                                                int posA, int posB, int cA, int t0, int T, char* smem, int rot = 0) {
     constexpr int ABL = 0;
     constexpr int NRT = 8;
     // this workgroup streams query tiles [t0, t0 + T) of the packed blob
@@ -545,14 +582,18 @@ __device__ __forceinline__ void score_stream16p(const bf16x8 (&a)[8][kKSteps16],
         }
     };
 
-    stage(0, 0);
-    if (T > 1) stage(1, 1);
+    // The range's tiles are visited in an order ROTATED by `rot` (the same for the four waves): iteration i works on tile tau(i).
+    // Every tile's scores are stored where they belong, so any rotation gives the same planes; the kernels pick rot from the
+    // chip-wide clock so that workgroups dispatched at different times stream the SAME query tiles at the same time (K1_ROT).
+    auto tau = [&](int i) { const int x = i + rot; return x >= T ? x - T : x; };
+    stage(tau(0), 0);
+    if (T > 1) stage(tau(1), 1);
 
     if constexpr (NRT == 0) {   // padding wave: staging + barriers only
         int slot2 = 2;
         for (int t = 0; t < T; ++t) {
             __syncthreads();
-            if (t + 2 < T) stage(t + 2, slot2);
+            if (t + 2 < T) stage(tau(t + 2), slot2);
             slot2 = slot2 == kRing - 1 ? 0 : slot2 + 1;
         }
     } else {
@@ -668,7 +709,7 @@ __device__ __forceinline__ void score_stream16p(const bf16x8 (&a)[8][kKSteps16],
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (t == 0 || !(ABL & 4)) __builtin_amdgcn_s_barrier();
             // staging of tile t+2 is spread over the k-steps of sub-tile 0; past the end it re-stages tile T-1 into a free slot
-            const int t2 = t + 2 < T ? t + 2 : T - 1;
+            const int t2 = tau(t + 2 < T ? t + 2 : T - 1);
             const char* st_src = qsrc + (size_t)t2 * kQTileBytes + (size_t)wave * 6 * 1024 + lane * 16;
             char* st_dst = smem + slot2 * kQTileBytes + wave * 6 * 1024;
             const int nslot = slot == kRing - 1 ? 0 : slot + 1;
@@ -684,8 +725,11 @@ __device__ __forceinline__ void score_stream16p(const bf16x8 (&a)[8][kKSteps16],
             }
             // t == 0: there is no previous sub-tile; its (garbage) result goes to queries 0..15, which the
             // next sub-tile's store - later in program order, same lanes, same addresses - overwrites.
-            subtile(std::integral_constant<int, 0>{}, accA, accB, cbase, nbase, outp + (t > 0 ? (size_t)t * kQTile - 16 : 0), st_src, st_dst);
-            subtile(std::integral_constant<int, 1>{}, accB, accA, cbase, nbase, outp + (size_t)t * kQTile, st_src, st_dst);
+            // (the previous sub-tile is the second half of tile tau(t - 1); at t == 0 the garbage goes where this tile's first half
+            // is stored next)
+            const size_t o_cur = (size_t)tau(t) * kQTile;
+            subtile(std::integral_constant<int, 0>{}, accA, accB, cbase, nbase, outp + (t > 0 ? (size_t)tau(t - 1) * kQTile + 16 : o_cur), st_src, st_dst);
+            subtile(std::integral_constant<int, 1>{}, accB, accA, cbase, nbase, outp + o_cur, st_src, st_dst);
             slot = nslot;
             slot2 = slot2 == kRing - 1 ? 0 : slot2 + 1;
         }
@@ -701,7 +745,7 @@ __device__ __forceinline__ void score_stream16p(const bf16x8 (&a)[8][kKSteps16],
             else { m = fmaxf(m, tm + route[0]); m2 = fmaxf(m2, tm + route[1]); }
         }
         m = xor16_max(halves_max2(m, m2));
-        if ((lane & 31) < 16) outp[(size_t)(T - 1) * kQTile + 16] = m;
+        if ((lane & 31) < 16) outp[(size_t)tau(T - 1) * kQTile + 16] = m;
     }
 }
 
@@ -767,27 +811,28 @@ __global__ __launch_bounds__(256, 1) void simpool_eval16p_kernel(const SimpoolPa
             if (rt * kKSteps16 + ks < 64) asm volatile("" : "+a"(a[rt][ks]));
             else asm volatile("" : "+v"(a[rt][ks]));
         }
+    const int rot = pick_rot(T, pair ? 8 : nrt);              // (every wave of the workgroup, padding waves included)
     switch (pair ? 8 + (cA >> 4) : nrt) {
-        case 15: score_stream16p<7>(a, p, branch, posA, posB, cA, t0, T, smem); break;
-        case 14: score_stream16p<6>(a, p, branch, posA, posB, cA, t0, T, smem); break;
-        case 13: score_stream16p<5>(a, p, branch, posA, posB, cA, t0, T, smem); break;
-        case 12: score_stream16p<4>(a, p, branch, posA, posB, cA, t0, T, smem); break;
-        case 11: score_stream16p<3>(a, p, branch, posA, posB, cA, t0, T, smem); break;
-        case 10: score_stream16p<2>(a, p, branch, posA, posB, cA, t0, T, smem); break;
-        case 9: score_stream16p<1>(a, p, branch, posA, posB, cA, t0, T, smem); break;
+        case 15: score_stream16p<7>(a, p, branch, posA, posB, cA, t0, T, smem, rot); break;
+        case 14: score_stream16p<6>(a, p, branch, posA, posB, cA, t0, T, smem, rot); break;
+        case 13: score_stream16p<5>(a, p, branch, posA, posB, cA, t0, T, smem, rot); break;
+        case 12: score_stream16p<4>(a, p, branch, posA, posB, cA, t0, T, smem, rot); break;
+        case 11: score_stream16p<3>(a, p, branch, posA, posB, cA, t0, T, smem, rot); break;
+        case 10: score_stream16p<2>(a, p, branch, posA, posB, cA, t0, T, smem, rot); break;
+        case 9: score_stream16p<1>(a, p, branch, posA, posB, cA, t0, T, smem, rot); break;
         case 8:
-            if (pair) score_stream16p<0>(a, p, branch, posA, posB, cA, t0, T, smem);
-            else score_stream16<8>(a, p, branch, posA, t0, T, smem);
+            if (pair) score_stream16p<0>(a, p, branch, posA, posB, cA, t0, T, smem, rot);
+            else score_stream16<8>(a, p, branch, posA, t0, T, smem, rot);
             break;
-        case 7: score_stream16<7>(a, p, branch, posA, t0, T, smem); break;
-        case 6: score_stream16<6>(a, p, branch, posA, t0, T, smem); break;
-        case 5: score_stream16<5>(a, p, branch, posA, t0, T, smem); break;
-        case 4: score_stream16<4>(a, p, branch, posA, t0, T, smem); break;
-        case 3: score_stream16<3>(a, p, branch, posA, t0, T, smem); break;
-        case 2: score_stream16<2>(a, p, branch, posA, t0, T, smem); break;
-        case 1: score_stream16<1>(a, p, branch, posA, t0, T, smem); break;
+        case 7: score_stream16<7>(a, p, branch, posA, t0, T, smem, rot); break;
+        case 6: score_stream16<6>(a, p, branch, posA, t0, T, smem, rot); break;
+        case 5: score_stream16<5>(a, p, branch, posA, t0, T, smem, rot); break;
+        case 4: score_stream16<4>(a, p, branch, posA, t0, T, smem, rot); break;
+        case 3: score_stream16<3>(a, p, branch, posA, t0, T, smem, rot); break;
+        case 2: score_stream16<2>(a, p, branch, posA, t0, T, smem, rot); break;
+        case 1: score_stream16<1>(a, p, branch, posA, t0, T, smem, rot); break;
         default:
-            score_stream16<0>(a, p, branch, 0, t0, T, smem);           // staging + barriers only
+            score_stream16<0>(a, p, branch, 0, t0, T, smem, rot);           // staging + barriers only
             // a real video with no valid clip (always a wave of its own): the reference's masked maximum is exactly -1e10
             if (w < pp.n_waves) {
                 float* row = p.part + ((size_t)branch * p.nv + posA) * p.nq_pad + (size_t)t0 * kQTile;
