@@ -462,8 +462,8 @@ __global__ __launch_bounds__(256, 1) void simpool_eval16_kernel(const SimpoolEva
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // block index = [query range][branch][group]: ranges are dispatched in order, and at any moment the resident
-    // workgroups stream (nearly) the same query tiles, which keeps them L2-hot
+    // block index = [query range][branch][group]: ranges are dispatched in order; inside a range the resident workgroups are
+    // kept on the same query tiles by the clock-rotated tile order (pick_rot), which keeps the tiles L2-hot
     const int range = blockIdx.x / p.n_wg0;
     const int b0 = blockIdx.x - range * p.n_wg0;
     const int branch = b0 / p.n_groups;
