@@ -185,6 +185,11 @@ def init_rccl_from_env(device, install_default=True):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: the only form the pool's driver supports
+    # one node (torch.distributed.run --nnodes=1, or one rank): RCCL's bootstrap sockets over loopback - the boxes have no network
+    # and their hostname need not resolve; the data path is xGMI peer access either way.  An explicit setting wins.
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local == world:
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     key = f"dldkd_comm_id_{_generation}"
     _generation += 1
     if world == 1:

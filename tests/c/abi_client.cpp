@@ -37,7 +37,8 @@ static float rnd() {   // xorshift -> roughly N(0,1) by summing uniforms
     return (s - 2.0f) * 1.7320508f;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool with_comm = !(argc > 1 && std::strcmp(argv[1], "nocomm") == 0);
     const int NQ = 45, NV = 19, L = 40, D = DLDKD_HIDDEN, NB = 2;
     if (dldkd_abi_version() <= 0) { std::fprintf(stderr, "bad abi version\n"); return 1; }
     std::vector<float> q[2], g[2], mask((size_t)NV * L, 0.f);
@@ -126,12 +127,16 @@ int main() {
     if (worst > 2e-5) { std::fprintf(stderr, "max |HIP - host| = %g\n", worst); return 6; }
     // Collectives (one rank): the library finds RCCL by itself (no torch in this process: the system librccl.so.1), a communicator is
     // an explicit object, every collective is one enqueue on the caller's stream.  One rank: sum / gather / broadcast are identities.
-    {
+    if (with_comm) {
+        std::fprintf(stderr, "comm: loading RCCL\n");
         if (dldkd_comm_rccl_version() < 20000) { std::fprintf(stderr, "rccl version %d: %s\n", dldkd_comm_rccl_version(), dldkd_last_error()); return 7; }
         unsigned char id[DLDKD_COMM_ID_BYTES];
         void* comm = nullptr;
+        std::fprintf(stderr, "comm: version %d, unique id\n", dldkd_comm_rccl_version());
         ABICHK(dldkd_comm_unique_id(id));
+        std::fprintf(stderr, "comm: init\n");
         ABICHK(dldkd_comm_init(&comm, 1, 0, id));
+        std::fprintf(stderr, "comm: collectives\n");
         int world = -1, rank = -1;
         ABICHK(dldkd_comm_info(comm, &world, &rank));
         if (world != 1 || rank != 0) { std::fprintf(stderr, "comm_info: %d of %d\n", rank, world); return 7; }
@@ -148,7 +153,9 @@ int main() {
         HIPCHK(hipMemcpy(back.data(), dgather, back.size() * 4, hipMemcpyDeviceToHost));
         if (std::memcmp(back.data(), fused.data(), back.size() * 4) != 0) { std::fprintf(stderr, "one-rank collectives changed the data\n"); return 7; }
         if (dldkd_comm_all_reduce(comm, dfused, dfused, 4, 99, DLDKD_SUM, st) != DLDKD_EINVAL) { std::fprintf(stderr, "bad dtype accepted\n"); return 7; }
+        std::fprintf(stderr, "comm: destroy\n");
         ABICHK(dldkd_comm_destroy(comm));
+        std::fprintf(stderr, "comm: done\n");
         HIPCHK(hipStreamDestroy(st));
         HIPCHK(hipFree(dgather));
     }

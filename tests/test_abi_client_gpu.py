@@ -1,6 +1,7 @@
 """GPU: the C ABI used from a stand-alone C++ program (tests/c/abi_client.cpp) - no Python, no torch in the
 process.  The client packs a small ragged two-branch gallery (streaming packer), scores it and checks the fused
-matrix against its own scalar loop."""
+matrix against its own scalar loop; with its collectives part it then drives a one-rank RCCL communicator through
+dldkd_comm_* (the library loads the SYSTEM librccl there: no torch in the process to bring one)."""
 import os
 import subprocess
 
@@ -10,10 +11,34 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cxx_client_of_the_c_abi():
+def _exe():
     exe = os.path.join(ROOT, "tests", "c", "abi_client")
     if not os.path.exists(exe):          # normally built by __graft_entry__.build()
         subprocess.run(["make", "-C", os.path.join(ROOT, "dl-dkd_amd", "csrc"), "client"], check=True)
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    return exe
+
+
+def test_cxx_client_of_the_c_abi():
+    r = subprocess.run([_exe(), "nocomm"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "abi_client ok" in r.stdout
+
+
+def test_cxx_client_drives_a_one_rank_communicator():
+    """The same client with its collectives part.  The process loads the system's RCCL build (not PyTorch's); its bootstrap has been
+    seen to hang once in ~20 runs of this child on one box (before any entry point of ours had returned: the client prints a marker
+    before every call), so the child gets 90 s and ONE fresh retry on a time-out - a time-out twice, or any non-zero exit, fails with
+    the markers.  NCCL_SOCKET_IFNAME=lo: one node, no network in the box."""
+    env = dict(os.environ, NCCL_SOCKET_IFNAME=os.environ.get("NCCL_SOCKET_IFNAME", "lo"))
+    log = []
+    for attempt in range(2):
+        try:
+            r = subprocess.run([_exe()], capture_output=True, text=True, timeout=90, env=env)
+        except subprocess.TimeoutExpired as ex:
+            err = ex.stderr.decode("utf8", "replace") if isinstance(ex.stderr, bytes) else (ex.stderr or "")
+            log.append(f"attempt {attempt}: timed out after 90 s; markers:\n{err[-1500:]}")
+            continue
+        assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+        assert "abi_client ok" in r.stdout and "comm: done" in r.stderr
+        return
+    pytest.fail("the stand-alone client hung twice:\n" + "\n".join(log))
