@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 
 def test_bf16_mode_training_lands_where_parity_mode_training_lands():
     import train_ab
-    res = train_ab.run(steps=300, seeds=2, nv=4096, nq=8192, runs=("parity", "bf16"), log=lambda *_: None)
+    res = train_ab.run(steps=300, seeds=1, nv=4096, nq=8192, runs=("parity", "bf16"), log=lambda *_: None)   # (one eval set: ~55 s of oracle)
     # the two loss curves (means over windows of 100 steps) within 2 % of each other (measured 0.03 %)
     assert res["loss_curve_max_rel_diff_bf16_vs_parity"] <= 0.02, res["loss_curve_max_rel_diff_bf16_vs_parity"]
     assert res["loss_window_means"]["bf16"][-1] < 0.9 * res["loss_window_means"]["bf16"][0]            # ... and it did train
