@@ -274,3 +274,38 @@ def test_visit_order_kernel_equals_stable_argsort(nv):
     want = torch.argsort(lens, descending=True, stable=True).to(torch.int32)
     assert torch.equal(order.cpu(), want)
     assert torch.equal(inv.cpu()[want.long()], torch.arange(nv, dtype=torch.int32))
+
+
+def test_planes_do_not_depend_on_when_the_scorer_runs():
+    """K1 visits a range's query tiles in an order rotated by the chip-wide clock (K1_ROT: workgroups dispatched at different times
+    stream the same tiles at the same time, which keeps them in L2).  Every tile's scores are stored where they belong, so launches
+    at different times - different rotations in every workgroup - must give bit-identical planes, with and without pair waves and
+    with a query split (the rotation stays inside each range)."""
+    import time
+    from dldkd_amd import scoring
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(77)
+    nq, nv, L = 3000, 700, 128
+    lens = torch.randint(1, L + 1, (nv,), generator=g)
+    mask = (torch.arange(L)[None, :] < lens[:, None]).float().to(dev)
+    gs = [torch.randn(nv, L, 384, generator=g).to(dev) for _ in range(2)]
+    pq = scoring.pack_queries([torch.randn(nq, 384, generator=g).to(dev) for _ in range(2)])
+    pg = scoring.pack_gallery(gs, mask)
+    n = 2 * nv * ((nq + 31) // 32 * 32)
+    was = scoring.PAIR_WAVES
+    try:
+        for pairs in (True, False):
+            scoring.PAIR_WAVES = pairs
+            for split in (0, 4):
+                ref = None
+                for rep in range(5):
+                    done = torch.zeros(8, dtype=torch.int32, device=dev) if split else None
+                    ws = torch.full((scoring.native.lib().dldkd_simpool_eval_workspace_bytes(nq, nv, 2),), 0x7f, dtype=torch.uint8, device=dev)
+                    got = scoring.simpool_partials(pq, pg, ws, q_split=split, done=done).view(torch.int32)[:n].clone()
+                    torch.cuda.synchronize()
+                    time.sleep(0.0007 * (rep + 1))                     # a different clock phase for the next launch
+                    if ref is None:
+                        ref = got
+                    assert torch.equal(got, ref), (pairs, split, rep)
+    finally:
+        scoring.PAIR_WAVES = was
