@@ -31,7 +31,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    if (keep != nullptr && state != nullptr) { seed = state[0]; off += state[1]; }
+    // dropout is on when a keep mask is asked for OR the threshold is non-zero (p > 0 without a mask buffer: the masks are
+    // Philox4x32-10 on the flat element index and whoever needs a bit later draws it again - gemm_bf16.hip, inproj_bwd_final_kernel)
+    const bool drop = keep != nullptr || thresh != 0u;
+    if (drop && state != nullptr) { seed = state[0]; off += state[1]; }
     const int nv = D >> 2;
     if (row_mask != nullptr || gin != nullptr) {
         // rows of the padding (row_mask[row] == 0: clips past a video's length in a padded batch) are not read: their output row
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-            if (keep != nullptr) {      // fused inverted dropout on the normalised row: the masks dldkd_dropout_fwd_f32 would draw
+            if (drop) {                 // fused inverted dropout on the normalised row: the masks dldkd_dropout_fwd_f32 would draw
                 const unsigned long long ctr = off + (unsigned long long)(row * nv + c);
                 unsigned rnd[4];
                 philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), rnd);
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 k.x = rnd[0] >= thresh; k.y = rnd[1] >= thresh; k.z = rnd[2] >= thresh; k.w = rnd[3] >= thresh;
                 o[0] = k.x ? o[0] * dscale : 0.f; o[1] = k.y ? o[1] * dscale : 0.f;
                 o[2] = k.z ? o[2] * dscale : 0.f; o[3] = k.w ? o[3] * dscale : 0.f;
-                reinterpret_cast<uchar4*>(keep + row * D)[c] = k;
+                if (keep != nullptr) reinterpret_cast<uchar4*>(keep + row * D)[c] = k;
             }
             if (out16 != nullptr) {
                 uint2 pk;
@@ -389,7 +392,7 @@ int dldkd_layernorm_dropout_bf16(const float* x, const float* gamma, const float
                                  long M, int D, float eps, float p_drop, unsigned long long seed, unsigned long long offset,
                                  const unsigned long long* state, const float* row_mask, unsigned char* group_flags, void* stream) {
     if (!out_bf16 || ((uintptr_t)out_bf16 & 7)) { set_error("layernorm_dropout_bf16: output missing or unaligned"); return DLDKD_EINVAL; }
-    if (p_drop > 0.f && (!keep || ((uintptr_t)keep & 3))) { set_error("layernorm_dropout_bf16: keep mask missing or unaligned"); return DLDKD_EINVAL; }
+    if (keep && ((uintptr_t)keep & 3)) { set_error("layernorm_dropout_bf16: keep mask unaligned"); return DLDKD_EINVAL; }     // (keep == NULL with p > 0: no mask written)
     if (group_flags && (!row_mask || (M & 31))) { set_error("layernorm_dropout_bf16: group flags need a row mask and M %% 32 == 0"); return DLDKD_EINVAL; }
     return launch_layernorm(x, nullptr, 0, gamma, beta, nullptr, M, D, eps, p_drop > 0.f ? keep : nullptr, p_drop, seed, offset, state, stream,
                             (unsigned short*)out_bf16, stats, row_mask, group_flags);

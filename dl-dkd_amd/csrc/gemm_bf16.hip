@@ -466,11 +466,19 @@ struct InprojFinalArgs {
     const float* rstd;           // (0 for rows of the padding)
     long M;
     int N;
+    // keep == null and thresh != 0: the dropout bits are drawn again - Philox4x32-10 on the flat element index exactly as
+    // layernorm_kernel drew them (counter = offset + (row K + col) / 4, lane of the counter = col % 4; seed / offset from `state`
+    // when given): the forward pass then writes no keep byte per element (50 MB per video tower at the TVR batch)
+    unsigned thresh;
+    unsigned long long seed, off;
+    const unsigned long long* state;
 };
 __global__ __launch_bounds__(256) void inproj_bwd_final_kernel(const InprojFinalArgs a) {
     __shared__ float wcol[kHidden];
     __shared__ float red[2][4];
     const int k = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long seed = a.seed, off = a.off;
+    if (a.state != nullptr) { seed = a.state[0]; off += a.state[1]; }
     bool small = false;
     if (k < a.K) {
         const float g = a.gamma[k], dbeta = a.keep_scale * a.db[k];
@@ -495,7 +503,15 @@ __global__ __launch_bounds__(256) void inproj_bwd_final_kernel(const InprojFinal
             for (long m = threadIdx.x; m < a.M; m += 256) {
                 const float rs = a.rstd[m];
                 if (rs == 0.f) continue;
-                const float kp = a.keep != nullptr ? (a.keep[(size_t)m * a.K + kc] ? a.keep_scale : 0.f) : a.keep_scale;
+                float kp = a.keep_scale;
+                if (a.keep != nullptr) {
+                    kp = a.keep[(size_t)m * a.K + kc] ? a.keep_scale : 0.f;
+                } else if (a.thresh != 0u) {
+                    const unsigned long long ctr = off + ((unsigned long long)m * (unsigned)(a.K >> 2) + (unsigned)(kc >> 2));
+                    unsigned rnd[4];
+                    philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), rnd);
+                    kp = rnd[kc & 3] >= a.thresh ? a.keep_scale : 0.f;
+                }
                 if (kp == 0.f) continue;
                 float dz = 0.f;
                 const float* dyr = a.dy + (size_t)m * a.N;
@@ -785,7 +801,8 @@ extern "C" size_t dldkd_inproj_bwd_workspace_bytes(int N, int K, long M) {
 }
 
 extern "C" int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const float* W, const float* gamma, const float* beta,
-                                     float keep_scale, const float* x, const unsigned char* keep, const float* mean, const float* rstd,
+                                     float keep_scale, const float* x, const unsigned char* keep, float p_drop, unsigned long long seed,
+                                     unsigned long long offset, const unsigned long long* state, const float* mean, const float* rstd,
                                      float* dW, float* dbias, float* dgamma, float* dbeta, long M, int N, int K, void* workspace,
                                      size_t workspace_bytes, const unsigned char* k_flags, void* stream) {
     if (M < 0 || M > 0x7fffffffL || N < 1 || N > kHidden || K < 2 || (K & 3) || (N & 1)) {
@@ -819,7 +836,10 @@ extern "C" int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const 
     DLDKD_LAUNCH(inproj_bwd_reduce_kernel, dim3((K + 255) / 256, (N + 15) / 16), dim3(256), 0, s, f);
     rc = check_launch("inproj_bwd (reduce)");
     if (rc != DLDKD_OK) return rc;
-    const InprojFinalArgs g{dgamma, dbeta, gamma, beta, keep_scale, K, dy, W, x, keep, mean, rstd, M, N};
+    if (!(p_drop >= 0.f && p_drop < 1.f)) { set_error("inproj_bwd: p_drop must be in [0, 1)"); return DLDKD_EINVAL; }
+    const double tq = (double)p_drop * 4294967296.0;                              // the threshold dldkd_layernorm_dropout_bf16 used
+    const unsigned thresh = tq >= 4294967295.0 ? 4294967295u : (unsigned)tq;
+    const InprojFinalArgs g{dgamma, dbeta, gamma, beta, keep_scale, K, dy, W, x, keep, mean, rstd, M, N, keep ? 0u : thresh, seed, offset, state};
     DLDKD_LAUNCH(inproj_bwd_final_kernel, dim3((K + 255) / 256), dim3(256), 0, s, g);
     return check_launch("inproj_bwd (final)");
 }

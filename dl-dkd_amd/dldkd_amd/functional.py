@@ -207,7 +207,13 @@ class _InProjTrain(Function):
             stats = torch.empty(2, M, dtype=torch.float32, device=x.device)
             seed, off, state = (0, 0, None)
             if p > 0.0:
-                keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
+                # the keep bytes (one per element: 50 MB per video tower at the TVR batch) are written only where the backward pass
+                # will read them - the two-GEMM fallback; the one-GEMM backward (IN_PROJ_BWD_DUAL) draws the few bits its
+                # small-gamma columns need again from the Philox slot saved below
+                dual = (IN_PROJ_BWD_DUAL and not IN_PROJ_KEEP_BYTES and gamma.requires_grad and beta.requires_grad and weight.requires_grad
+                        and N <= 384 and weight.is_contiguous())
+                if not dual:
+                    keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
                 seed, off, state = _philox_slot(x.device, x.numel())
             # rows of the padding (row_mask == 0) are never read and come out as zero rows; when the padded length is a multiple of
             # 32 the kernel also flags the 32-row groups that hold valid rows, and dW below skips the others
@@ -239,7 +245,13 @@ class _InProjTrain(Function):
             gflags = torch.empty(M // 32, dtype=torch.uint8, device=x.device)
             seed, off, state = (0, 0, None)
             if p > 0.0:
-                keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
+                # the keep bytes (one per element: 50 MB per video tower at the TVR batch) are written only where the backward pass
+                # will read them - the two-GEMM fallback; the one-GEMM backward (IN_PROJ_BWD_DUAL) draws the few bits its
+                # small-gamma columns need again from the Philox slot saved below
+                dual = (IN_PROJ_BWD_DUAL and not IN_PROJ_KEEP_BYTES and gamma.requires_grad and beta.requires_grad and weight.requires_grad
+                        and N <= 384 and weight.is_contiguous())
+                if not dual:
+                    keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
                 seed, off, state = _philox_slot(x.device, x.numel())
             native.check(_L().dldkd_layernorm_dropout_rows_f32(_p(x2), _p(gamma), _p(beta), _p(z), _p(keep), _p(stats), M, K, ops.LN_EPS,
                                                                float(p), seed, off, state, _p(_f32(row_mask).reshape(-1)), _p(gflags),
@@ -261,6 +273,8 @@ class _InProjTrain(Function):
         # [y > 0] - it reads y anyway - so the backward pass here neither keeps y nor runs relu_bwd over a clone of dy
         ctx.save_for_backward(x2, weight, z, y if (relu and not grad_premasked) else None, keep, stats, gflags, gamma, beta)
         ctx.relu, ctx.has_bias, ctx.keep_scale, ctx.prec = (relu and not grad_premasked), bias is not None, 1.0 / (1.0 - p), ops.gemm_precision()
+        # the dropout's Philox slot, for a backward pass that redraws bits instead of reading keep bytes (z16 path without `keep`)
+        ctx.drop_rng = (float(p), seed, off, state, _philox_step.dev if _philox_step is not None else None) if (z16 and p > 0.0) else (0.0, 0, 0, None, None)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -283,10 +297,16 @@ class _InProjTrain(Function):
             dgb = _zeros((2, K), x2.device)
             nbytes = _L().dldkd_inproj_bwd_workspace_bytes(N, K, M)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2.device)
+            p_, seed_, off_, state_, _alive = ctx.drop_rng
             native.check(_L().dldkd_inproj_bwd_bf16(_p(dy2), _p(z), _p(w), _p(gamma), _p(beta), ctx.keep_scale, _p(x2), _p(keep),
-                                                    _p(stats[0]), _p(stats[1]), _p(dw), _p(db), _p(dgb[0]), _p(dgb[1]), M, N, K, _p(ws),
-                                                    nbytes, _p(gflags), _s()), "inproj_bwd_bf16")
+                                                    p_, seed_, off_, state_, _p(stats[0]), _p(stats[1]), _p(dw), _p(db), _p(dgb[0]), _p(dgb[1]),
+                                                    M, N, K, _p(ws), nbytes, _p(gflags), _s()), "inproj_bwd_bf16")
             return None, dgb[0], dgb[1], dw, db, None, None, None, None
+        if keep is None and ctx.drop_rng[0] > 0.0:
+            # the forward pass wrote no keep bytes because every parameter of the layer wanted a gradient (the one-GEMM backward
+            # redraws the bits); a backward pass that asks for a subset lands here, where the two-GEMM path reads the bytes
+            raise RuntimeError("in_proj_train: this backward pass needs the dropout keep bytes the forward pass did not write "
+                               "(gradients requested for a subset of gamma / beta / weight): set functional.IN_PROJ_KEEP_BYTES = True")
         if ctx.needs_input_grad[3]:
             if z.dtype == torch.bfloat16:
                 dw = torch.empty(N, K, dtype=torch.float32, device=x2.device)
@@ -327,6 +347,7 @@ IN_PROJ_SKIP_PADDING = True           # ... and the rows of the padding (a row m
 IN_PROJ_TRAIN_BF16_ROWS = True        # throughput mode: the saved LayerNorm-dropout rows of the input projection are bf16
 IN_PROJ_TRAIN_FUSED = True
 IN_PROJ_BWD_DUAL = True               # throughput mode: dW and the LayerNorm parameter gradients from one two-accumulator GEMM
+IN_PROJ_KEEP_BYTES = False            # ... True: the forward pass still writes a keep byte per element (A/B and fallback)
 IN_PROJ_TRAIN_NT16 = True             # throughput mode: the forward GEMM of the input projection on the bf16 x bf16 LDS-DMA kernel
 
 

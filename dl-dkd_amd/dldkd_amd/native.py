@@ -92,7 +92,8 @@ SIGNATURES = {
     "dldkd_zero_scratch_f32": (_c_int, [_c_void_p, _c_int, _c_void_p]),
     "dldkd_set_zero_by_memset": (_c_int, [_c_int]),
     "dldkd_inproj_bwd_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_long]),
-    "dldkd_inproj_bwd_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p,
+    "dldkd_inproj_bwd_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_void_p, _c_void_p,
+                                       _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p,
                                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p,
                                        ctypes.c_size_t, _c_void_p, _c_void_p]),
     "dldkd_gemm_bf16_dw_bias": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_size_t,

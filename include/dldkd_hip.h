@@ -189,8 +189,9 @@ int dldkd_layernorm_dropout_rows_f32(const float* x, const float* gamma, const f
 /* The same LayerNorm (+ inverted dropout when p_drop > 0: same masks) writing the row as bf16 (round to nearest even) - the
  * operand form of the bf16 GEMMs that consume it (dldkd_gemm_bf16_mixed) - and, when stats != NULL, the row statistics
  * (mean -> stats[row], rstd -> stats[M + row]) the backward pass would otherwise recompute.  Training input projection in
- * throughput mode: LinearLayer.forward's LayerNorm -> Dropout (method/model_components.py:305-310).  keep may be NULL when
- * p_drop == 0; out_bf16 8-byte aligned.  row_mask (M floats, or NULL): rows with row_mask[row] == 0 - the clips past a video's
+ * throughput mode: LinearLayer.forward's LayerNorm -> Dropout (method/model_components.py:305-310).  keep may be NULL: the dropout
+ * is applied all the same and no mask is written (the bits are Philox4x32-10 on the flat element index; dldkd_inproj_bwd_bf16 draws
+ * the few it needs again from the same p_drop / seed / offset / state); out_bf16 8-byte aligned.  row_mask (M floats, or NULL): rows with row_mask[row] == 0 - the clips past a video's
  * length in a padded batch (collate_train's mask, method/data_provider.py:75-86) - are not read; their output row, keep bytes
  * and statistics are zeros (no loss term depends on them and their gradients are exactly zero).  group_flags (M / 32 bytes, or
  * NULL; needs row_mask, M % 32 == 0 and a padded length that is a multiple of 32): 1 when the 32-row group starts with a valid
@@ -373,14 +374,18 @@ int dldkd_gemm_bf16_dw_bias(int dw, const void* A, const void* B, float* C, int 
  *     H[n, k]   = sum_m dy[m, n] [z[m, k] != 0]
  *     dbeta[k]  = keep_scale sum_n W[n, k] H[n, k]            dgamma[k] = (sum_n W[n, k] dW[n, k] - beta[k] dbeta[k]) / gamma[k]
  * - the (M, K) product dy W of dldkd_linear_lngrad reassociated into the M-long contraction of the weight gradient.  Columns with
- * |gamma[k]| < 0.05 (z holds no trace of xhat there) are recomputed exactly from x / keep / mean / rstd (rstd = 0 marks padding rows).
+ * |gamma[k]| < 0.05 (z holds no trace of xhat there) are recomputed exactly from x / the dropout bits / mean / rstd (rstd = 0 marks
+ * padding rows).  The dropout bits: `keep` (M, K) bytes as dldkd_layernorm_dropout_bf16 wrote them, or keep == NULL and (p_drop, seed,
+ * offset, state) = the arguments that launch was given - the bits are then drawn again (Philox4x32-10 on the flat element index),
+ * and the forward pass need not write a keep byte per element.
  * dy (M, N) fp32, N <= 384; z (M, K) bf16; W (N, K); dW (N, K); dbias (N) zeroed by the caller or NULL; dgamma, dbeta (K) ZEROED by
  * the caller (used as accumulators); k_flags as in dldkd_gemm_bf16_mixed; workspace: dldkd_inproj_bwd_workspace_bytes.
  * (Three launches: the GEMM, the plane reduce + dot products, the finalisation.  Merging the last two behind an arrival ticket was
  * measured: the __threadfence of every workgroup made the finish 2-4 x slower than the two kernels.) */
 size_t dldkd_inproj_bwd_workspace_bytes(int N, int K, long M);
 int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const float* W, const float* gamma, const float* beta,
-                          float keep_scale, const float* x, const unsigned char* keep, const float* mean, const float* rstd,
+                          float keep_scale, const float* x, const unsigned char* keep, float p_drop, unsigned long long seed,
+                          unsigned long long offset, const unsigned long long* state, const float* mean, const float* rstd,
                           float* dW, float* dbias, float* dgamma, float* dbeta, long M, int N, int K, void* workspace,
                           size_t workspace_bytes, const unsigned char* k_flags, void* stream);
 /* The forward layout of dldkd_gemm_bf16 - C[M, N] = act(A[M, K] . B[N, K]^T + bias), both operands fp32 and k-minor (a Linear's
