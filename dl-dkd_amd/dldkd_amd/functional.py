@@ -245,13 +245,7 @@ class _InProjTrain(Function):
             gflags = torch.empty(M // 32, dtype=torch.uint8, device=x.device)
             seed, off, state = (0, 0, None)
             if p > 0.0:
-                # the keep bytes (one per element: 50 MB per video tower at the TVR batch) are written only where the backward pass
-                # will read them - the two-GEMM fallback; the one-GEMM backward (IN_PROJ_BWD_DUAL) draws the few bits its
-                # small-gamma columns need again from the Philox slot saved below
-                dual = (IN_PROJ_BWD_DUAL and not IN_PROJ_KEEP_BYTES and gamma.requires_grad and beta.requires_grad and weight.requires_grad
-                        and N <= 384 and weight.is_contiguous())
-                if not dual:
-                    keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
+                keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
                 seed, off, state = _philox_slot(x.device, x.numel())
             native.check(_L().dldkd_layernorm_dropout_rows_f32(_p(x2), _p(gamma), _p(beta), _p(z), _p(keep), _p(stats), M, K, ops.LN_EPS,
                                                                float(p), seed, off, state, _p(_f32(row_mask).reshape(-1)), _p(gflags),
