@@ -31,7 +31,7 @@ def _lab(labels):
 
 
 def _close(a, b, tol=1e-4):
-    a, b = float(a), float(b)
+    a, b = (float(v.reshape(-1)[0]) if isinstance(v, np.ndarray) else float(v) for v in (a, b))     # goldens are 0-d / 1-element arrays
     assert abs(a - b) <= tol * max(1.0, abs(b)), (a, b)
 
 
