@@ -409,6 +409,14 @@ int launch_linear_lngrad_x3(const float* dy, const float* W, long M, int N, int 
                             const unsigned char* row_flags = nullptr);
 int launch_simpool_pool_bf16(const float* g, const float* q, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream);
 int launch_splitk_reduce(const float* ws, float* out, int split, long n, hipStream_t s);
+// gemm_bf16_tn.hip: C = A^T B over bf16 rows (LDS-DMA tiles, transposed LDS reads) - the weight-gradient products of the training step
+bool gemm_bf16_tn_enabled();
+bool gemm_bf16_tn_ok(int M, int N, long R, int lda, int ldb);
+size_t gemm_bf16_tn_planes_bytes(int M, int N, long R, int dual);
+int launch_gemm_bf16_tn(const void* A, const void* B, float* C, int M, int N, long R, int lda, int ldb, int dual, void* planes,
+                        const unsigned char* rflags, float* a_colsum, hipStream_t stream);
+int launch_gemm_bf16_tn_group(const void* const* A, const int* lda, const int* acol, const void* const* B, int n_blocks, long R, float* dW,
+                              void* planes, const unsigned char* rflags, float* a_colsum, hipStream_t stream);
 // Every kernel launch of the library: drop whatever error another library left in the runtime's sticky per-thread slot
 // (torch's caching allocator probes the runtime while a hipGraph is being captured and leaves hipErrorInvalidValue behind),
 // so that check_launch() reports THIS launch only.

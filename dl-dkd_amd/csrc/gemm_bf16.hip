@@ -686,10 +686,21 @@ static int gemm_bf16_mixed_impl(int dw, const void* A, const void* B, const floa
                                 int ldb, int ldc, int relu, void* workspace, size_t workspace_bytes, const unsigned char* k_flags,
                                 float* a_colsum, void* stream);
 
-extern "C" size_t dldkd_tower_train_dw_workspace_bytes(int n_blocks, long rows) {
+extern "C" int dldkd_cast_bf16(const float* x, void* y, long n, void* stream);
+// planes of the register-staged kernel or of gemm_bf16_tn (whichever is larger), then room for the bf16 copy of ONE fp32 A block
+static size_t tower_dw_planes_bytes(int n_blocks, long rows) {
     int per = 0;
     const int split = gemm_bf16_split_plan(kHidden * n_blocks, kHidden, (int)rows, 1, 1, &per);
-    return split > 1 ? (size_t)split * kHidden * n_blocks * kHidden * sizeof(float) : 0;
+    size_t b = split > 1 ? (size_t)split * kHidden * n_blocks * kHidden * sizeof(float) : 0;
+    if (gemm_bf16_tn_enabled() && gemm_bf16_tn_ok(kHidden * n_blocks, kHidden, rows, kHidden, kHidden)) {
+        const size_t t = gemm_bf16_tn_planes_bytes(kHidden * n_blocks, kHidden, rows, 0);
+        b = t > b ? t : b;
+    }
+    return (b + 255) & ~(size_t)255;
+}
+extern "C" size_t dldkd_tower_train_dw_workspace_bytes(int n_blocks, long rows) {
+    if (n_blocks < 1 || rows < 1) return 0;
+    return tower_dw_planes_bytes(n_blocks, rows) + (size_t)rows * kHidden * sizeof(unsigned short);
 }
 
 // The split-K reduce of the towers' weight gradients and the column sums that make the position table's gradient (dpos[c] += sum over
@@ -749,15 +760,45 @@ static int tower_train_dw_impl(const void* const* host_A, const int* host_lda, c
     g.base.kflags = k_flags;
     g.base.a_colsum = dbias;
     int per = 0;
-    const int split = ((uintptr_t)dW & 15) ? 1 : gemm_bf16_split_plan(M, kHidden, (int)rows, 1, 1, &per);
-    const bool use_split = split > 1 && workspace && !((uintptr_t)workspace & 15) && workspace_bytes >= (size_t)split * M * kHidden * sizeof(float);
-    if (use_split) { g.base.split_k = split; g.base.k_tiles_per_split = per; g.base.C = (float*)workspace; }
-    constexpr size_t lds = sizeof(unsigned short) * 2 * 2 * HBM_ * HPITCH;
-    static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_bf16_dw_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
-    (void)attr_ok;
-    DLDKD_LAUNCH(gemm_bf16_dw_group_kernel, dim3(kHidden / HBN_, M / HBM_, use_split ? split : 1), dim3(256), lds, (hipStream_t)stream, g);
-    int rc = check_launch("tower_train_dw");
-    if (rc != DLDKD_OK) return rc;
+    int split = ((uintptr_t)dW & 15) ? 1 : gemm_bf16_split_plan(M, kHidden, (int)rows, 1, 1, &per);
+    bool use_split = split > 1 && workspace && !((uintptr_t)workspace & 15) && workspace_bytes >= (size_t)split * M * kHidden * sizeof(float);
+    int rc = DLDKD_OK;
+    // gemm_bf16_tn.hip (LDS-DMA tiles, transposed LDS reads) when every operand is 16-byte aligned bf16 - at most one fp32 A block (the
+    // loss's gradient under the out mapping) is cast into the workspace first
+    bool tn = gemm_bf16_tn_enabled() && gemm_bf16_tn_ok(M, kHidden, rows, kHidden, kHidden) && workspace && !((uintptr_t)workspace & 15) &&
+              !((uintptr_t)dW & 15) && workspace_bytes >= dldkd_tower_train_dw_workspace_bytes(n_blocks, rows);
+    int n32 = 0;
+    for (int b = 0; b < n_blocks && tn; ++b) {
+        n32 += host_a16[b] ? 0 : 1;
+        tn = !(host_lda[b] & 7) && !(host_acol[b] & 7) && !((uintptr_t)host_B[b] & 15) && !((uintptr_t)host_A[b] & 15) && n32 <= 1;
+    }
+    if (tn) {
+        const void* A16[5];
+        char* cast = (char*)workspace + tower_dw_planes_bytes(n_blocks, rows);
+        for (int b = 0; b < n_blocks; ++b) {
+            A16[b] = host_A[b];
+            if (!host_a16[b]) {
+                if (host_lda[b] != kHidden || host_acol[b] != 0) { tn = false; break; }
+                rc = dldkd_cast_bf16((const float*)host_A[b], cast, rows * kHidden, stream);
+                if (rc != DLDKD_OK) return rc;
+                A16[b] = cast;
+            }
+        }
+        if (tn) {
+            split = launch_gemm_bf16_tn_group(A16, host_lda, host_acol, host_B, n_blocks, rows, dW, workspace, k_flags, dbias, (hipStream_t)stream);
+            if (split < 0) return split;
+            use_split = split > 1;
+        }
+    }
+    if (!tn) {
+        if (use_split) { g.base.split_k = split; g.base.k_tiles_per_split = per; g.base.C = (float*)workspace; }
+        constexpr size_t lds = sizeof(unsigned short) * 2 * 2 * HBM_ * HPITCH;
+        static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_bf16_dw_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        (void)attr_ok;
+        DLDKD_LAUNCH(gemm_bf16_dw_group_kernel, dim3(kHidden / HBN_, M / HBM_, use_split ? split : 1), dim3(256), lds, (hipStream_t)stream, g);
+        rc = check_launch("tower_train_dw");
+        if (rc != DLDKD_OK) return rc;
+    }
     const bool pos = dx1 != nullptr && dpos != nullptr && n_seq > 0 && cols > 0;
     if (use_split && pos) {
         const long n4 = (long)M * kHidden / 4;
@@ -794,10 +835,20 @@ extern "C" int dldkd_tower_train_dw_pos(const void* const* host_A, const int* ho
 }
 
 
-extern "C" size_t dldkd_inproj_bwd_workspace_bytes(int N, int K, long M) {
+static size_t inproj_planes_bytes(int N, int K, long M) {
     int per = 0;
     const int split = gemm_bf16_split_plan(N, K, (int)M, 1, 1, &per);
-    return (size_t)(split > 1 ? split : 1) * 2 * N * K * sizeof(float);
+    size_t b = (size_t)(split > 1 ? split : 1) * 2 * N * K * sizeof(float);
+    if (gemm_bf16_tn_enabled() && gemm_bf16_tn_ok(N, K, M, N, K)) {
+        const size_t t = gemm_bf16_tn_planes_bytes(N, K, M, 1);
+        b = t > b ? t : b;
+    }
+    return (b + 255) & ~(size_t)255;
+}
+// the [split][dW | H] planes, then room for the bf16 copy of dY
+extern "C" size_t dldkd_inproj_bwd_workspace_bytes(int N, int K, long M) {
+    if (N < 1 || K < 1 || M < 1) return 0;
+    return inproj_planes_bytes(N, K, M) + (size_t)M * N * sizeof(unsigned short);
 }
 
 extern "C" int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const float* W, const float* gamma, const float* beta,
@@ -826,12 +877,22 @@ extern "C" int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const 
     int split = gemm_bf16_split_plan(N, K, (int)M, 1, 1, &per);
     if (split > 1) { p.split_k = split; p.k_tiles_per_split = per; } else split = 1;
     hipStream_t s = (hipStream_t)stream;
-    constexpr size_t lds = sizeof(unsigned short) * 3 * 2 * HBM_ * HPITCH;
-    static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_bf16_dw_dual_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
-    (void)attr_ok;
-    DLDKD_LAUNCH(gemm_bf16_dw_dual_kernel, dim3((K + HBN_ - 1) / HBN_, (N + HBM_ - 1) / HBM_, split), dim3(256), lds, s, p);
-    int rc = check_launch("inproj_bwd (dual dW)");
-    if (rc != DLDKD_OK) return rc;
+    int rc = DLDKD_OK;
+    if (gemm_bf16_tn_enabled() && gemm_bf16_tn_ok(N, K, M, N, K) && !((uintptr_t)z_bf16 & 15) && !((uintptr_t)dy & 15)) {
+        // gemm_bf16_tn.hip: dY cast to bf16 once (the register-staged kernel rounds the same values on their way to LDS)
+        char* dy16 = (char*)workspace + inproj_planes_bytes(N, K, M);
+        rc = dldkd_cast_bf16(dy, dy16, M * N, stream);
+        if (rc != DLDKD_OK) return rc;
+        split = launch_gemm_bf16_tn(dy16, z_bf16, nullptr, N, K, M, N, K, 1, workspace, k_flags, dbias, s);
+        if (split < 0) return split;
+    } else {
+        constexpr size_t lds = sizeof(unsigned short) * 3 * 2 * HBM_ * HPITCH;
+        static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_bf16_dw_dual_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        (void)attr_ok;
+        DLDKD_LAUNCH(gemm_bf16_dw_dual_kernel, dim3((K + HBN_ - 1) / HBN_, (N + HBM_ - 1) / HBM_, split), dim3(256), lds, s, p);
+        rc = check_launch("inproj_bwd (dual dW)");
+        if (rc != DLDKD_OK) return rc;
+    }
     const InprojFinishArgs f{(const float*)workspace, W, dW, dgamma, dbeta, split, N, K};
     DLDKD_LAUNCH(inproj_bwd_reduce_kernel, dim3((K + 255) / 256, (N + 15) / 16), dim3(256), 0, s, f);
     rc = check_launch("inproj_bwd (reduce)");

@@ -438,7 +438,10 @@ def test_input_projection_backward_as_one_two_accumulator_gemm(bf16_mode, nv, L,
         F_.IN_PROJ_BWD_DUAL = True
     (dg1, db1, dW1, dbb1, y1), (dg0, db0, dW0, dbb0, y0) = res[True], res[False]
     assert torch.equal(y1, y0)
-    assert torch.allclose(dW1, dW0, rtol=1e-4, atol=1e-5 * dW0.abs().max().item()) and torch.allclose(dbb1, dbb0, rtol=1e-4, atol=1e-5 * dbb0.abs().max().item())
+    assert torch.allclose(dW1, dW0, rtol=1e-4, atol=1e-5 * dW0.abs().max().item())
+    # the one-GEMM path takes the bias gradient from the bf16 copy of dy its GEMM reads (gemm_bf16_tn.hip: column sums of the A
+    # fragments), the two-GEMM path from the fp32 rows on their way to LDS: equal up to the bf16 rounding of 16,384 summands
+    assert ((dbb1 - dbb0).norm() / dbb0.norm()).item() <= 3e-3
     rel = lambda a, r: ((a - r).norm() / r.norm()).item()                                   # noqa: E731
     # the two paths round different things (two GEMMs: dy and W to bf16; one GEMM: dy and, for dgamma, the saved rows): a few 1e-3
     print(f"  one GEMM vs two: dgamma rel l2 {rel(dg1, dg0):.2e}, dbeta {rel(db1, db0):.2e}")
