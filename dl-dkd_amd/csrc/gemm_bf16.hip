@@ -703,36 +703,115 @@ extern "C" size_t dldkd_tower_train_dw_workspace_bytes(int n_blocks, long rows) 
     return tower_dw_planes_bytes(n_blocks, rows) + (size_t)rows * kHidden * sizeof(unsigned short);
 }
 
-// The split-K reduce of the towers' weight gradients and the column sums that make the position table's gradient (dpos[c] += sum over
-// the n_seq sequences of dx1[n, c], c < cols = L * 384) as ONE launch: workgroups [0, red_blocks) reduce, the others sum rows_per_block
-// sequences of 256 columns each (colsum_kernel's form; one atomic per column and workgroup).
-__global__ __launch_bounds__(256) void splitk_reduce_colsum_kernel(const float* __restrict__ ws, float* __restrict__ out, int split, long n4,
-                                                                   int red_blocks, const float* __restrict__ x, float* __restrict__ csum,
-                                                                   long n_seq, long cols, int rows_per_block, int col_blocks) {
-    if ((int)blockIdx.x < red_blocks) {
+// What is left of a tower's parameter gradients once the grouped weight-gradient GEMM has run, as ONE launch of three kinds of workgroups:
+//   [0, red_blocks)                 the split-K reduce of the GEMM's planes;
+//   the next col_blocks * row_blocks  the position table's gradient: dpos[c] += sum over the n_seq sequences of dx1[n, c], c < cols = L * 384
+//                                     (colsum_kernel's form; one atomic per column and workgroup);
+//   the next n_ln * ln_blocks        the two LayerNorms' parameter gradients: dgamma[c] += sum_r a[r, c] xh[r, c], dbeta[c] += sum_r a[r, c]
+//                                     over kLnRows rows per workgroup (a: the gradient of that LayerNorm's output as the row kernels left
+//                                     it - bf16, or the fp32 rows the loss handed in; xh: the saved normalised rows, bf16), 32-row groups
+//                                     of padding skipped by the row flags.  Thread = 8 columns of every fifth row: 16-byte loads, a row's
+//                                     48 threads cover its 768 bytes.
+#ifndef DLDKD_LN_ROWS
+#define DLDKD_LN_ROWS 64
+#endif
+constexpr int kLnRows = DLDKD_LN_ROWS;      // rows per workgroup of the LayerNorm sums (a multiple of 32)
+struct LnJob {
+    const void* a;
+    const unsigned short* xh;
+    float* dgamma;
+    float* dbeta;
+    int a16;                     // a is bf16 (else fp32)
+    int clear_bit0;              // xh carries a flag in bit 0 of every element (tower_train.hip f1_kernel): cleared before use
+};
+struct DwFinishArgs {
+    const float* ws; float* out; int split; long n4; int red_blocks;
+    const float* x; float* csum; long n_seq, cols; int rows_per_block, col_blocks, pos_blocks;
+    LnJob ln[2]; int n_ln, ln_blocks; long rows; const unsigned char* rflags;
+};
+__global__ __launch_bounds__(256) void dw_finish_kernel(const DwFinishArgs a) {
+    if ((int)blockIdx.x < a.red_blocks) {
         const long i = (long)blockIdx.x * 256 + threadIdx.x;
-        if (i >= n4) return;
-        const f32x4* w = reinterpret_cast<const f32x4*>(ws) + i;
-        f32x4 a = w[0];
+        if (i >= a.n4) return;
+        const f32x4* w = reinterpret_cast<const f32x4*>(a.ws) + i;
+        f32x4 acc = w[0];
 #pragma unroll 8
-        for (int z = 1; z < split; ++z) { const f32x4 b = w[(size_t)z * n4]; a += b; }
-        reinterpret_cast<f32x4*>(out)[i] = a;
+        for (int z = 1; z < a.split; ++z) { const f32x4 b = w[(size_t)z * a.n4]; acc += b; }
+        reinterpret_cast<f32x4*>(a.out)[i] = acc;
         return;
     }
-    const int b = (int)blockIdx.x - red_blocks, bx = b % col_blocks, by = b / col_blocks;
-    const long c = (long)bx * 256 + threadIdx.x;
-    if (c >= cols) return;
-    const long r0 = (long)by * rows_per_block, r1 = r0 + rows_per_block < n_seq ? r0 + rows_per_block : n_seq;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    long r = r0;
-    for (; r + 3 < r1; r += 4) {            // 4 independent loads in flight per lane
-        s0 += x[r * cols + c];
-        s1 += x[(r + 1) * cols + c];
-        s2 += x[(r + 2) * cols + c];
-        s3 += x[(r + 3) * cols + c];
+    int b = (int)blockIdx.x - a.red_blocks;
+    if (b < a.pos_blocks) {
+        const int bx = b % a.col_blocks, by = b / a.col_blocks;
+        const long c = (long)bx * 256 + threadIdx.x;
+        if (c >= a.cols) return;
+        const long r0 = (long)by * a.rows_per_block, r1 = r0 + a.rows_per_block < a.n_seq ? r0 + a.rows_per_block : a.n_seq;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        long r = r0;
+        for (; r + 3 < r1; r += 4) {            // 4 independent loads in flight per lane
+            s0 += a.x[r * a.cols + c];
+            s1 += a.x[(r + 1) * a.cols + c];
+            s2 += a.x[(r + 2) * a.cols + c];
+            s3 += a.x[(r + 3) * a.cols + c];
+        }
+        for (; r < r1; ++r) s0 += a.x[r * a.cols + c];
+        atomicAdd(a.csum + c, (s0 + s1) + (s2 + s3));
+        return;
     }
-    for (; r < r1; ++r) s0 += x[r * cols + c];
-    atomicAdd(csum + c, (s0 + s1) + (s2 + s3));
+    b -= a.pos_blocks;
+    const LnJob j = a.ln[b / a.ln_blocks];
+    const long row0 = (long)(b % a.ln_blocks) * kLnRows;
+    __shared__ float part[5][48][17];
+    const int tid = threadIdx.x, rsub = tid / 48, c8 = tid % 48;      // thread = 8 columns of every fifth row (240 of the 256 threads)
+    float sg[8], sb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sb[e] = 0.f; }
+    if (tid < 240) {
+        const unsigned xm = j.clear_bit0 ? 0xfffefffeu : 0xffffffffu;
+#pragma unroll 1
+        for (int g = 0; g < kLnRows / 32; ++g) {                          // the 32-row groups of this workgroup's rows
+            const long rg = row0 + 32 * g;
+            if (rg >= a.rows) break;
+            if (a.rflags != nullptr && a.rflags[rg >> 5] == 0) continue;
+            const long rend = rg + 32 < a.rows ? rg + 32 : a.rows;
+#pragma unroll 7
+            for (long r = rg + rsub; r < rend; r += 5) {
+                const uint4 xw = *reinterpret_cast<const uint4*>(j.xh + r * kHidden + 8 * c8);
+                const unsigned xu[4] = {xw.x & xm, xw.y & xm, xw.z & xm, xw.w & xm};
+                float v[8];
+                if (j.a16) {
+                    const uint4 aw = *reinterpret_cast<const uint4*>((const unsigned short*)j.a + r * kHidden + 8 * c8);
+                    const unsigned au[4] = {aw.x, aw.y, aw.z, aw.w};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) { v[2 * d] = __builtin_bit_cast(float, au[d] << 16); v[2 * d + 1] = __builtin_bit_cast(float, au[d] & 0xffff0000u); }
+                } else {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>((const float*)j.a + r * kHidden + 8 * c8);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>((const float*)j.a + r * kHidden + 8 * c8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    sg[2 * d] += v[2 * d] * __builtin_bit_cast(float, xu[d] << 16);
+                    sg[2 * d + 1] += v[2 * d + 1] * __builtin_bit_cast(float, xu[d] & 0xffff0000u);
+                    sb[2 * d] += v[2 * d]; sb[2 * d + 1] += v[2 * d + 1];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { part[rsub][c8][e] = sg[e]; part[rsub][c8][8 + e] = sb[e]; }
+    }
+    __syncthreads();
+    // one atomic per feature and workgroup, consecutive lanes on consecutive addresses: an atomic instruction is served per 128-byte
+    // line it touches (the first version - a thread adding its own 8 sums, 16 bytes apart - touched 8 lines per instruction and made
+    // this launch 40 us longer at the TVR batch)
+    for (int i = tid; i < 2 * kHidden; i += 256) {
+        const int which = i >= kHidden ? 1 : 0, col = i - which * kHidden;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) v += part[q][col >> 3][8 * which + (col & 7)];
+        atomicAdd((which ? j.dbeta : j.dgamma) + col, v);
+    }
 }
 
 extern "C" int dldkd_colsum_f32(const float* x, float* out, long M, long N, void* stream);
@@ -740,7 +819,7 @@ extern "C" int dldkd_colsum_f32(const float* x, float* out, long M, long N, void
 static int tower_train_dw_impl(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
                                const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
                                size_t workspace_bytes, const unsigned char* k_flags, const float* dx1, float* dpos, long n_seq, long cols,
-                               void* stream) {
+                               const LnJob* ln, int n_ln, void* stream) {
     if (n_blocks < 1 || n_blocks > 5 || rows < 0 || rows > 0x7fffffffL || !host_A || !host_lda || !host_acol || !host_a16 || !host_B || !dW) {
         set_error("tower_train_dw: bad arguments");
         return DLDKD_EINVAL;
@@ -800,29 +879,36 @@ static int tower_train_dw_impl(const void* const* host_A, const int* host_lda, c
         if (rc != DLDKD_OK) return rc;
     }
     const bool pos = dx1 != nullptr && dpos != nullptr && n_seq > 0 && cols > 0;
-    if (use_split && pos) {
-        const long n4 = (long)M * kHidden / 4;
-        const int red_blocks = (int)((n4 + 255) / 256);
+    DwFinishArgs f{};
+    if (use_split) {
+        f.ws = (const float*)workspace; f.out = dW; f.split = split; f.n4 = (long)M * kHidden / 4;
+        f.red_blocks = (int)((f.n4 + 255) / 256);
+    }
+    long blocks = f.red_blocks;
+    if (pos) {
         const int rpb = n_seq <= 256 ? 8 : 32;
         const long col_blocks = (cols + 255) / 256, row_blocks = (n_seq + rpb - 1) / rpb;
-        if (col_blocks * row_blocks + red_blocks < 0x7fffffffL) {
-            DLDKD_LAUNCH(splitk_reduce_colsum_kernel, dim3((unsigned)(red_blocks + col_blocks * row_blocks)), dim3(256), 0, (hipStream_t)stream,
-                         (const float*)workspace, dW, split, n4, red_blocks, dx1, dpos, n_seq, cols, rpb, (int)col_blocks);
-            return check_launch("tower_train_dw (reduce + position sums)");
-        }
+        if (col_blocks * row_blocks > 0x3fffffffL) { set_error("tower_train_dw: position table too large"); return DLDKD_EINVAL; }
+        f.x = dx1; f.csum = dpos; f.n_seq = n_seq; f.cols = cols; f.rows_per_block = rpb; f.col_blocks = (int)col_blocks;
+        f.pos_blocks = (int)(col_blocks * row_blocks);
+        blocks += f.pos_blocks;
     }
-    if (use_split) {
-        rc = launch_splitk_reduce((const float*)workspace, dW, split, (long)M * kHidden, (hipStream_t)stream);
-        if (rc != DLDKD_OK) return rc;
+    if (n_ln > 0) {
+        f.n_ln = n_ln; f.ln_blocks = (int)((rows + kLnRows - 1) / kLnRows); f.rows = rows; f.rflags = k_flags;
+        for (int i = 0; i < n_ln; ++i) f.ln[i] = ln[i];
+        blocks += (long)n_ln * f.ln_blocks;
     }
-    return pos ? dldkd_colsum_f32(dx1, dpos, n_seq, cols, stream) : DLDKD_OK;
+    if (blocks == 0) return DLDKD_OK;
+    if (blocks > 0x7fffffffL) { set_error("tower_train_dw: too many workgroups"); return DLDKD_EINVAL; }
+    DLDKD_LAUNCH(dw_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f);
+    return check_launch("tower_train_dw (reduce + position sums + LayerNorm sums)");
 }
 
 extern "C" int dldkd_tower_train_dw(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
                                     const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
                                     size_t workspace_bytes, const unsigned char* k_flags, void* stream) {
     return tower_train_dw_impl(host_A, host_lda, host_acol, host_a16, host_B, n_blocks, rows, dW, dbias, workspace, workspace_bytes, k_flags,
-                               nullptr, nullptr, 0, 0, stream);
+                               nullptr, nullptr, 0, 0, nullptr, 0, stream);
 }
 
 extern "C" int dldkd_tower_train_dw_pos(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
@@ -831,7 +917,25 @@ extern "C" int dldkd_tower_train_dw_pos(const void* const* host_A, const int* ho
                                         long cols, void* stream) {
     if (!dx1 || !dpos || n_seq < 0 || cols < 1) { set_error("tower_train_dw_pos: bad position-gradient arguments"); return DLDKD_EINVAL; }
     return tower_train_dw_impl(host_A, host_lda, host_acol, host_a16, host_B, n_blocks, rows, dW, dbias, workspace, workspace_bytes, k_flags,
-                               dx1, dpos, n_seq, cols, stream);
+                               dx1, dpos, n_seq, cols, nullptr, 0, stream);
+}
+
+extern "C" int dldkd_tower_train_dw_ln(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
+                                       const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
+                                       size_t workspace_bytes, const unsigned char* k_flags, const float* dx1, float* dpos, long n_seq,
+                                       long cols, const void* dz1_bf16, const void* xh1, const void* dh2, int dh2_is_bf16, const void* xh2,
+                                       float* ln_grads, void* stream) {
+    if ((dx1 != nullptr) != (dpos != nullptr) || (dx1 && (n_seq < 0 || cols < 1))) { set_error("tower_train_dw_ln: bad position-gradient arguments"); return DLDKD_EINVAL; }
+    if (!dz1_bf16 || !xh1 || !dh2 || !xh2 || !ln_grads || (((uintptr_t)dz1_bf16 | (uintptr_t)xh1 | (uintptr_t)xh2) & 7) ||
+        ((uintptr_t)dh2 & (dh2_is_bf16 ? 7 : 15)) || ((uintptr_t)ln_grads & 3)) {
+        set_error("tower_train_dw_ln: null or unaligned LayerNorm operands");
+        return DLDKD_EINVAL;
+    }
+    // ln_grads = [dgamma2 | dbeta2 | dgamma1 | dbeta1] (the order of the row kernels' accumulators)
+    const LnJob ln[2] = {{dh2, (const unsigned short*)xh2, ln_grads, ln_grads + kHidden, dh2_is_bf16 ? 1 : 0, 0},
+                         {dz1_bf16, (const unsigned short*)xh1, ln_grads + 2 * kHidden, ln_grads + 3 * kHidden, 1, 1}};
+    return tower_train_dw_impl(host_A, host_lda, host_acol, host_a16, host_B, n_blocks, rows, dW, dbias, workspace, workspace_bytes, k_flags,
+                               dx1, dpos, n_seq, cols, ln, 2, stream);
 }
 
 
@@ -855,7 +959,7 @@ extern "C" int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const 
                                      float keep_scale, const float* x, const unsigned char* keep, float p_drop, unsigned long long seed,
                                      unsigned long long offset, const unsigned long long* state, const float* mean, const float* rstd,
                                      float* dW, float* dbias, float* dgamma, float* dbeta, long M, int N, int K, void* workspace,
-                                     size_t workspace_bytes, const unsigned char* k_flags, void* stream) {
+                                     size_t workspace_bytes, const unsigned char* k_flags, const void* dy_bf16, void* stream) {
     if (M < 0 || M > 0x7fffffffL || N < 1 || N > kHidden || K < 2 || (K & 3) || (N & 1)) {
         set_error("inproj_bwd: bad sizes (M=%ld N=%d K=%d; N <= 384, K a multiple of 4)", M, N, K);
         return DLDKD_EINVAL;
@@ -880,9 +984,12 @@ extern "C" int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const 
     int rc = DLDKD_OK;
     if (gemm_bf16_tn_enabled() && gemm_bf16_tn_ok(N, K, M, N, K) && !((uintptr_t)z_bf16 & 15) && !((uintptr_t)dy & 15)) {
         // gemm_bf16_tn.hip: dY cast to bf16 once (the register-staged kernel rounds the same values on their way to LDS)
-        char* dy16 = (char*)workspace + inproj_planes_bytes(N, K, M);
-        rc = dldkd_cast_bf16(dy, dy16, M * N, stream);
-        if (rc != DLDKD_OK) return rc;
+        const void* dy16 = dy_bf16;
+        if (dy16 == nullptr || ((uintptr_t)dy16 & 15)) {
+            dy16 = (char*)workspace + inproj_planes_bytes(N, K, M);
+            rc = dldkd_cast_bf16(dy, (void*)dy16, M * N, stream);
+            if (rc != DLDKD_OK) return rc;
+        }
         split = launch_gemm_bf16_tn(dy16, z_bf16, nullptr, N, K, M, N, K, 1, workspace, k_flags, dbias, s);
         if (split < 0) return split;
     } else {

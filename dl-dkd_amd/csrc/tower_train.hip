@@ -498,8 +498,15 @@ struct B3Args {
     u16* dres;                   // (M, 384) bf16 gradient reaching h1d through the residual
     float* dgamma;               // [384] += (zeroed by the caller)
     float* dbeta;                // [384] +=
+    u16* dg16;                   // (M, 384) bf16 copy of dg for the out mapping's weight-gradient GEMM (wot != null), or null
+    u16* dh2_16;                 // SUMS = false, wot != null: (M, 384) bf16 gradient of the LayerNorm output h2 (wot == null: it is dg)
 };
 
+// SUMS: the LayerNorm parameter gradients (column sums over the batch rows of dh2 and dh2 (.) xh2) inside this kernel - DPP
+// reductions + one atomic per feature and wave: 24 of this kernel's 75 us at the TVR batch, 36 of b1_kernel's 116
+// (tools/r05_abl_tower2.sh).  false: the kernel leaves dh2 as bf16 rows and the column sums to the launch that reduces the
+// weight gradients' split-K planes (gemm_bf16.hip, dw_finish_kernel: plain coalesced row sweeps).
+template <bool SUMS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void b3_kernel(const B3Args p) {
     __shared__ __attribute__((aligned(16))) float vs[kD];          // gamma
     stage_vec(vs, p.gamma);
@@ -531,6 +538,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     xb[ks][e] = (short)f32_to_bf16_bits(w.valid ? ld[k][0][e] : 0.f);
                     xb[ks][4 + e] = (short)f32_to_bf16_bits(w.valid ? ld[k][1][e] : 0.f);
                 }
+                if (p.dg16 != nullptr && w.valid) *reinterpret_cast<bf16x8*>(p.dg16 + w.row * kD + 8 * h + 16 * ks) = xb[ks];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -553,6 +561,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float* gmp = vs + 4 * h;
     const size_t didx = (size_t)w.row * kD + 4 * h;
     Tile4 nx0 = load_tile16(xrow, 0), nx1 = load_tile16(xrow, 1);
+    u16* dh2r = p.dh2_16 + w.row * kD + 4 * h;
+    const bool put_dh2 = !SUMS && p.wot != nullptr;
 #pragma unroll
     for (int pr = 0; pr < kT / 2; ++pr) {
         f32x16 pg[2];
@@ -562,6 +572,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int t = 2 * pr + tt;
+            Tile4 odh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 gm = vec4(gmp, 32 * t + 8 * g);
@@ -570,18 +581,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float dy = acc[t][4 * g + e];
-                    pg[tt][4 * g + e] = dy * xh[e];
+                    if constexpr (SUMS) pg[tt][4 * g + e] = dy * xh[e];
                     m1 += dy * gm[e];
                     m2 += dy * gm[e] * xh[e];
                 }
+                if constexpr (!SUMS) odh.v[g] = pack4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
                 asm volatile("" : "+v"(m1), "+v"(m2));      // (pins the group's arithmetic here: see f3_kernel)
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (!SUMS) {
+                if (put_dh2) store_tile16(dh2r, t, odh, w.valid);
+            }
         }
-        colsum_tile(pg[0], p.dgamma + 64 * pr, lane);
-        colsum_tile(pg[1], p.dgamma + 64 * pr + 32, lane);
-        colsum_tile(acc[2 * pr], p.dbeta + 64 * pr, lane);
-        colsum_tile(acc[2 * pr + 1], p.dbeta + 64 * pr + 32, lane);
+        if constexpr (SUMS) {
+            colsum_tile(pg[0], p.dgamma + 64 * pr, lane);
+            colsum_tile(pg[1], p.dgamma + 64 * pr + 32, lane);
+            colsum_tile(acc[2 * pr], p.dbeta + 64 * pr, lane);
+            colsum_tile(acc[2 * pr + 1], p.dbeta + 64 * pr + 32, lane);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     m1 = hswap_sum(m1) * (1.f / kD);
@@ -648,9 +665,12 @@ struct B1Args {
     float* dx1;                  // (M, 384) fp32 gradient of y0 + pos (position-table gradient = its sum over sequences), or null
     float* dgamma;
     float* dbeta;
+    u16* dz16;                   // SUMS = false: (M, 384) bf16 gradient of the first LayerNorm's output (rows of skipped groups: not written)
+    u16* dy16;                   // (M, 384) bf16 copy of dy0 for the input projection's weight-gradient GEMM (rows of skipped groups: zeros,
+                                 // as in dy0), or null
 };
 
-template <bool DX1>
+template <bool DX1, bool SUMS>      // SUMS: see b3_kernel
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void b1_kernel(const B1Args p) {
     __shared__ __attribute__((aligned(16))) float vs[kD];          // gamma
     stage_vec(vs, p.gamma);
@@ -665,6 +685,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int i = 0; i < 48; ++i) {
                 *reinterpret_cast<f32x4*>(p.dy0 + w.row * kD + 192 * h + 4 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (DX1) *reinterpret_cast<f32x4*>(p.dx1 + w.row * kD + 192 * h + 4 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (p.dy16 != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 24; ++i) *reinterpret_cast<uint4*>(p.dy16 + w.row * kD + 192 * h + 8 * i) = uint4{0u, 0u, 0u, 0u};
             }
         }
         return;
@@ -691,6 +715,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     (void)dx1r;
     float m1 = 0.f, m2 = 0.f;
     Tile4 nx[2] = {load_tile16(xrow, 0), load_tile16(xrow, 1)}, nr[2] = {load_tile16(rrow, 0), load_tile16(rrow, 1)};
+    u16* dzr = p.dz16 + w.row * kD + 4 * h;
 #pragma unroll
     for (int pr = 0; pr < kT / 2; ++pr) {
         f32x16 pg[2];
@@ -703,6 +728,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int t = 2 * pr + tt;
+            Tile4 odz;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 gm = vec4(gmp, 32 * t + 8 * g);
@@ -715,28 +741,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     float dh = acc[t][4 * g + e] + res[e];
                     dh = (w.valid && ((kb >> e) & 1u)) ? dh * p.drop.scale : 0.f;
                     acc[t][4 * g + e] = dh;
-                    pg[tt][4 * g + e] = dh * xh[e];
+                    if constexpr (SUMS) pg[tt][4 * g + e] = dh * xh[e];
                     m1 += dh * gm[e];
                     m2 += dh * gm[e] * xh[e];
                 }
+                if constexpr (!SUMS) odz.v[g] = pack4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
                 asm volatile("" : "+v"(m1), "+v"(m2));      // (pins the group's arithmetic here: see f3_kernel)
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (!SUMS) store_tile16(dzr, t, odz, w.valid);
         }
-        colsum_tile(pg[0], p.dgamma + 64 * pr, lane);
-        colsum_tile(pg[1], p.dgamma + 64 * pr + 32, lane);
-        colsum_tile(acc[2 * pr], p.dbeta + 64 * pr, lane);
-        colsum_tile(acc[2 * pr + 1], p.dbeta + 64 * pr + 32, lane);
+        if constexpr (SUMS) {
+            colsum_tile(pg[0], p.dgamma + 64 * pr, lane);
+            colsum_tile(pg[1], p.dgamma + 64 * pr + 32, lane);
+            colsum_tile(acc[2 * pr], p.dbeta + 64 * pr, lane);
+            colsum_tile(acc[2 * pr + 1], p.dbeta + 64 * pr + 32, lane);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     m1 = hswap_sum(m1) * (1.f / kD);
     m2 = hswap_sum(m2) * (1.f / kD);
     Tile4 nxt = load_tile16(xrow, 0);
+    u16* dy16r = p.dy16 + w.row * kD + 4 * h;
 #pragma unroll
     for (int t = 0; t < kT; ++t) {
         const Tile4 cur = nxt;
         if (t + 1 < kT) nxt = load_tile16(xrow, t + 1);
         __builtin_amdgcn_sched_barrier(0);
+        Tile4 ody;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int fo = 32 * t + 8 * g;
@@ -751,11 +783,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 dx[e] = rstd * (acc[t][4 * g + e] * gm[e] - m1 - xh[e] * m2);
                 dy[e] = (!p.relu_mask || ((pos4 >> e) & 1u)) ? dx[e] : 0.f;
             }
+            ody.v[g] = pack4(dy[0], dy[1], dy[2], dy[3]);
             if (w.valid) {
                 *reinterpret_cast<f32x4*>(dy0r + fo) = dy;
                 if constexpr (DX1) *reinterpret_cast<f32x4*>(dx1r + fo) = dx;
             }
         }
+        if (p.dy16 != nullptr) store_tile16(dy16r, t, ody, w.valid);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -963,31 +997,50 @@ int dldkd_tower_train_f3(const void* ctx, const void* h1d, const void* wd_pack, 
 
 int dldkd_tower_train_b3(const float* dg, const void* wot_pack, const void* xh2, const float* rstd2, const float* gamma, float p_drop,
                          unsigned long long seed, unsigned long long offset, const unsigned long long* state, const void* wdt_pack,
-                         const unsigned char* flags, long M, void* ddo, void* dctx, void* dres, float* dgamma, float* dbeta, void* stream) {
+                         const unsigned char* flags, long M, void* ddo, void* dctx, void* dres, float* dgamma, float* dbeta, void* dg_bf16,
+                         void* dh2_bf16, void* stream) {
     if (M < 0 || tt::bad_p(p_drop)) { set_error("tower_train_b3: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0) return DLDKD_OK;
-    if (!dg || !xh2 || !rstd2 || !gamma || !wdt_pack || !ddo || !dctx || !dres || !dgamma || !dbeta) { set_error("tower_train_b3: null pointer"); return DLDKD_EINVAL; }
+    if (!dg || !xh2 || !rstd2 || !gamma || !wdt_pack || !ddo || !dctx || !dres) { set_error("tower_train_b3: null pointer"); return DLDKD_EINVAL; }
+    const bool sums = dgamma != nullptr;
+    if (sums ? !dbeta : (dbeta != nullptr || (wot_pack != nullptr && !dh2_bf16))) {
+        set_error("tower_train_b3: dgamma and dbeta together (column sums in the kernel), or neither and dh2_bf16 under an out mapping");
+        return DLDKD_EINVAL;
+    }
     if (((uintptr_t)dg | (uintptr_t)wot_pack | (uintptr_t)xh2 | (uintptr_t)gamma | (uintptr_t)wdt_pack | (uintptr_t)ddo | (uintptr_t)dctx |
-         (uintptr_t)dres) & 15) { set_error("tower_train_b3: 16-byte alignment"); return DLDKD_EINVAL; }
+         (uintptr_t)dres | (uintptr_t)dg_bf16 | (uintptr_t)dh2_bf16) & 15) { set_error("tower_train_b3: 16-byte alignment"); return DLDKD_EINVAL; }
     tt::B3Args a{dg, (const bf16x8*)wot_pack, (const tt::u16*)xh2, rstd2, gamma, tt::make_drop(p_drop, seed, offset, state), (const bf16x8*)wdt_pack,
-                 flags, M, (tt::u16*)ddo, (tt::u16*)dctx, (tt::u16*)dres, dgamma, dbeta};
-    DLDKD_LAUNCH(tt::b3_kernel, dim3(tt::grid_of(M)), dim3(256), 0, (hipStream_t)stream, a);
+                 flags, M, (tt::u16*)ddo, (tt::u16*)dctx, (tt::u16*)dres, dgamma, dbeta, (tt::u16*)dg_bf16, (tt::u16*)dh2_bf16};
+    if (sums) DLDKD_LAUNCH(tt::b3_kernel<true>, dim3(tt::grid_of(M)), dim3(256), 0, (hipStream_t)stream, a);
+    else DLDKD_LAUNCH(tt::b3_kernel<false>, dim3(tt::grid_of(M)), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("tower_train_b3");
 }
 
 int dldkd_tower_train_b1(const void* dqkv, const void* dres, const void* wqkvt_pack, const void* xh1, const float* stats,
                          const float* gamma, float p_drop, unsigned long long seed, unsigned long long offset,
                          const unsigned long long* state, const unsigned char* flags, long M, int relu_mask, float* dy0, float* dx1,
-                         float* dgamma, float* dbeta, void* stream) {
+                         float* dgamma, float* dbeta, void* dz_bf16, void* dy_bf16, void* stream) {
     if (M < 0 || tt::bad_p(p_drop)) { set_error("tower_train_b1: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0) return DLDKD_OK;
-    if (!dqkv || !dres || !wqkvt_pack || !xh1 || !stats || !gamma || !dy0 || !dgamma || !dbeta) { set_error("tower_train_b1: null pointer"); return DLDKD_EINVAL; }
+    if (!dqkv || !dres || !wqkvt_pack || !xh1 || !stats || !gamma || !dy0) { set_error("tower_train_b1: null pointer"); return DLDKD_EINVAL; }
+    const bool sums = dgamma != nullptr;
+    if (sums ? !dbeta : (dbeta != nullptr || !dz_bf16)) {
+        set_error("tower_train_b1: dgamma and dbeta together (column sums in the kernel), or neither and dz_bf16");
+        return DLDKD_EINVAL;
+    }
     if (((uintptr_t)dqkv | (uintptr_t)dres | (uintptr_t)wqkvt_pack | (uintptr_t)xh1 | (uintptr_t)gamma | (uintptr_t)dy0 |
-         (uintptr_t)dx1) & 15) { set_error("tower_train_b1: 16-byte alignment"); return DLDKD_EINVAL; }
+         (uintptr_t)dx1 | (uintptr_t)dz_bf16 | (uintptr_t)dy_bf16) & 15) { set_error("tower_train_b1: 16-byte alignment"); return DLDKD_EINVAL; }
     tt::B1Args a{(const tt::u16*)dqkv, (const tt::u16*)dres, (const bf16x8*)wqkvt_pack, (const tt::u16*)xh1, stats, gamma,
-                 tt::make_drop(p_drop, seed, offset, state), flags, M, relu_mask, dy0, dx1, dgamma, dbeta};
-    if (dx1 != nullptr) DLDKD_LAUNCH(tt::b1_kernel<true>, dim3(tt::grid_of(M)), dim3(256), 0, (hipStream_t)stream, a);
-    else DLDKD_LAUNCH(tt::b1_kernel<false>, dim3(tt::grid_of(M)), dim3(256), 0, (hipStream_t)stream, a);
+                 tt::make_drop(p_drop, seed, offset, state), flags, M, relu_mask, dy0, dx1, dgamma, dbeta, (tt::u16*)dz_bf16, (tt::u16*)dy_bf16};
+    const dim3 grid(tt::grid_of(M));
+    hipStream_t st = (hipStream_t)stream;
+    if (dx1 != nullptr) {
+        if (sums) DLDKD_LAUNCH((tt::b1_kernel<true, true>), grid, dim3(256), 0, st, a);
+        else DLDKD_LAUNCH((tt::b1_kernel<true, false>), grid, dim3(256), 0, st, a);
+    } else {
+        if (sums) DLDKD_LAUNCH((tt::b1_kernel<false, true>), grid, dim3(256), 0, st, a);
+        else DLDKD_LAUNCH((tt::b1_kernel<false, false>), grid, dim3(256), 0, st, a);
+    }
     return check_launch("tower_train_b1");
 }
 

@@ -292,9 +292,13 @@ class _InProjTrain(Function):
             nbytes = _L().dldkd_inproj_bwd_workspace_bytes(N, K, M)
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2.device)
             p_, seed_, off_, state_, _alive = ctx.drop_rng
+            # the bf16 copy of dy the fused tower's last backward kernel left beside the fp32 rows (else the library casts them)
+            dy16 = _DY16.pop(dy.data_ptr(), None) if (not ctx.relu and dy.dtype == torch.float32 and dy.is_contiguous()) else None
+            if dy16 is not None and dy16.numel() != dy2.numel():
+                dy16 = None
             native.check(_L().dldkd_inproj_bwd_bf16(_p(dy2), _p(z), _p(w), _p(gamma), _p(beta), ctx.keep_scale, _p(x2), _p(keep),
                                                     p_, seed_, off_, state_, _p(stats[0]), _p(stats[1]), _p(dw), _p(db), _p(dgb[0]), _p(dgb[1]),
-                                                    M, N, K, _p(ws), nbytes, _p(gflags), _s()), "inproj_bwd_bf16")
+                                                    M, N, K, _p(ws), nbytes, _p(gflags), _p(dy16), _s()), "inproj_bwd_bf16")
             return None, dgb[0], dgb[1], dw, db, None, None, None, None
         if keep is None and ctx.drop_rng[0] > 0.0:
             # the forward pass wrote no keep bytes because every parameter of the layer wanted a gradient (the one-GEMM backward
@@ -565,6 +569,11 @@ def _tt_pack(jobs, device, mask=None):
 # weights (matched by storage and parameter epoch) and fall back to their own launches otherwise.
 TOWER_PREPACK = os.environ.get("DLDKD_TOWER_PREPACK", "1") == "1"
 _PREPACKED = {}
+# _TowerTrain.backward -> _InProjTrain.backward: the bf16 copy of the gradient it returns (by the fp32 tensor's address; taken at once)
+_DY16 = {}
+# the LayerNorm parameter gradients of the fused towers: column sums inside the two backward row kernels (True: a third of their time)
+# or beside the split-K reduce of the weight gradients, from bf16 rows the kernels leave instead (False)
+TOWER_LN_SUMS_IN_KERNEL = os.environ.get("DLDKD_TOWER_LN_SUMS", "0") == "1"
 
 
 def _tt_jobs(wq, wk, wv, wd, wo):
@@ -653,20 +662,31 @@ class _TowerTrain(Function):
         L_ = _L()
         lnp = _zeros((4, HIDDEN), dev)                           # dgamma2, dbeta2, dgamma1, dbeta1 (atomics)
         ddo, dctx, dres, dqkv = _bf16((M, HIDDEN), dev), _bf16((M, HIDDEN), dev), _bf16((M, HIDDEN), dev), _bf16((M, 3 * HIDDEN), dev)
+        sums = TOWER_LN_SUMS_IN_KERNEL
+        # bf16 rows for the GEMMs / the finishing launch: dout under the out mapping (its weight gradient), the gradients of the two
+        # LayerNorms' outputs (their parameter gradients), dy0 (the input projection's weight gradient)
+        dg16 = _bf16((M, HIDDEN), dev) if video else None
+        dh2_16 = _bf16((M, HIDDEN), dev) if (video and not sums) else None
+        dz16 = None if sums else _bf16((M, HIDDEN), dev)
+        dy16 = _bf16((M, HIDDEN), dev)
         native.check(L_.dldkd_tower_train_b3(_p(dout), _p(pk_ot), _p(xh2), _p(rstd2), _p(g2), p_hid, sc[0], sc[1], sc[2], _p(pk_dt),
-                                             _p(flags), M, _p(ddo), _p(dctx), _p(dres), _p(lnp[0]), _p(lnp[1]), _s()), "tower_train_b3")
+                                             _p(flags), M, _p(ddo), _p(dctx), _p(dres), _p(lnp[0]) if sums else None,
+                                             _p(lnp[1]) if sums else None, _p(dg16), _p(dh2_16), _s()), "tower_train_b3")
         native.check(L_.dldkd_attention_train_bwd_bf16io(_p(qkv), _p(mask), _p(lens), _p(dctx), _p(dqkv), N, L, p_attn, sb[0], sb[1],
                                                          sb[2], _s()), "attention_train_bwd_bf16io")
         need_pos = ctx.needs_input_grad[1]
         dy0 = torch.empty(N, L, HIDDEN, dtype=torch.float32, device=dev)
         dx1 = torch.empty(N, L * HIDDEN, dtype=torch.float32, device=dev) if need_pos else None
         native.check(L_.dldkd_tower_train_b1(_p(dqkv), _p(dres), _p(pk_qkvt), _p(xh1), _p(stats), _p(g1), p_in, sa[0], sa[1],
-                                             sa[2], _p(flags), M, int(relu_mask), _p(dy0), _p(dx1), _p(lnp[2]), _p(lnp[3]), _s()),
-                     "tower_train_b1")
+                                             sa[2], _p(flags), M, int(relu_mask), _p(dy0), _p(dx1), _p(lnp[2]) if sums else None,
+                                             _p(lnp[3]) if sums else None, _p(dz16), _p(dy16), _s()), "tower_train_b1")
+        if len(_DY16) > 8:
+            _DY16.clear()
+        _DY16[dy0.data_ptr()] = dy16
 
         # weight + bias gradients: ONE split-K product over the saved bf16 rows, blocks [Wo |] Wd | Wq | Wk | Wv (gemm_bf16.hip)
         import ctypes
-        blocks = ([(dout, HIDDEN, 0, 0, h2)] if video else []) + [(ddo, HIDDEN, 0, 1, ctxl)] + [(dqkv, 3 * HIDDEN, c * HIDDEN, 1, h1d) for c in range(3)]
+        blocks = ([(dg16, HIDDEN, 0, 1, h2)] if video else []) + [(ddo, HIDDEN, 0, 1, ctxl)] + [(dqkv, 3 * HIDDEN, c * HIDDEN, 1, h1d) for c in range(3)]
         nb = len(blocks)
         dW = torch.empty(nb * HIDDEN, HIDDEN, dtype=torch.float32, device=dev)
         dB = _zeros((nb * HIDDEN,), dev)
@@ -679,6 +699,12 @@ class _TowerTrain(Function):
         dpos = None
         if need_pos:                                         # gradient of the whole table: rows >= L stay zero (arena); summed over the
             dpos = _zeros((pos.shape[0], HIDDEN), dev)       # sequences inside the launch that reduces the split-K planes
+        if not sums:                                         # ... which then sums the LayerNorm parameter gradients as well
+            dh2 = dh2_16 if video else dout
+            native.check(L_.dldkd_tower_train_dw_ln(hA, hl, hc, h16, hB, nb, M, _p(dW), _p(dB), _p(ws), ws_bytes, _p(flags), _p(dx1), _p(dpos),
+                                                    dx1.shape[0] if need_pos else 0, L * HIDDEN, _p(dz16), _p(xh1), _p(dh2), 1 if video else 0,
+                                                    _p(xh2), _p(lnp), _s()), "tower_train_dw_ln")
+        elif need_pos:
             native.check(L_.dldkd_tower_train_dw_pos(hA, hl, hc, h16, hB, nb, M, _p(dW), _p(dB), _p(ws), ws_bytes, _p(flags), _p(dx1), _p(dpos),
                                                      dx1.shape[0], L * HIDDEN, _s()), "tower_train_dw_pos")
         else:

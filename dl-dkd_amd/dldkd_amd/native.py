@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdldkd_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -75,15 +75,18 @@ SIGNATURES = {
                                        _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_tower_train_b3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, ctypes.c_uint64, ctypes.c_uint64,
                                        _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                                       _c_void_p]),
+                                       _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_tower_train_b1": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float,
                                        ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p,
-                                       _c_void_p, _c_void_p, _c_void_p]),
+                                       _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_tower_train_dw_workspace_bytes": (_c_size_t, [_c_int, _c_long]),
     "dldkd_tower_train_dw": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_void_p, _c_void_p, _c_void_p,
                                        _c_size_t, _c_void_p, _c_void_p]),
     "dldkd_tower_train_dw_pos": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_void_p, _c_void_p, _c_void_p,
                                            _c_size_t, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_long, _c_void_p]),
+    "dldkd_tower_train_dw_ln": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_long, _c_void_p, _c_void_p, _c_void_p,
+                                          _c_size_t, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_int,
+                                          _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_mask_lens_f32": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_colsum_bf16": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_branch_losses_f32": (_c_int, [_c_void_p] * 11 + [_c_int] * 7 + [_c_float] * 6 + [_c_void_p] * 6),
@@ -95,7 +98,7 @@ SIGNATURES = {
     "dldkd_inproj_bwd_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, _c_void_p, _c_void_p,
                                        _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p,
                                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p,
-                                       ctypes.c_size_t, _c_void_p, _c_void_p]),
+                                       ctypes.c_size_t, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_gemm_bf16_dw_bias": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_size_t,
                                           _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_gemm_bf16_mixed": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

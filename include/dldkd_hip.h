@@ -380,6 +380,9 @@ int dldkd_gemm_bf16_dw_bias(int dw, const void* A, const void* B, float* C, int 
  * and the forward pass need not write a keep byte per element.
  * dy (M, N) fp32, N <= 384; z (M, K) bf16; W (N, K); dW (N, K); dbias (N) zeroed by the caller or NULL; dgamma, dbeta (K) ZEROED by
  * the caller (used as accumulators); k_flags as in dldkd_gemm_bf16_mixed; workspace: dldkd_inproj_bwd_workspace_bytes.
+ * dy_bf16: dy rounded to bf16 (M, N) as dldkd_tower_train_b1 leaves it beside the fp32 rows, or NULL (the rows are then cast into the
+ * workspace first).  The GEMM (gemm_bf16_tn.hip: LDS-DMA row tiles read back transposed) contracts the bf16 rows; dbias is the column
+ * sum of those bf16 rows.
  * (Three launches: the GEMM, the plane reduce + dot products, the finalisation.  Merging the last two behind an arrival ticket was
  * measured: the __threadfence of every workgroup made the finish 2-4 x slower than the two kernels.) */
 size_t dldkd_inproj_bwd_workspace_bytes(int N, int K, long M);
@@ -387,7 +390,7 @@ int dldkd_inproj_bwd_bf16(const float* dy, const void* z_bf16, const float* W, c
                           float keep_scale, const float* x, const unsigned char* keep, float p_drop, unsigned long long seed,
                           unsigned long long offset, const unsigned long long* state, const float* mean, const float* rstd,
                           float* dW, float* dbias, float* dgamma, float* dbeta, long M, int N, int K, void* workspace,
-                          size_t workspace_bytes, const unsigned char* k_flags, void* stream);
+                          size_t workspace_bytes, const unsigned char* k_flags, const void* dy_bf16, void* stream);
 /* The forward layout of dldkd_gemm_bf16 - C[M, N] = act(A[M, K] . B[N, K]^T + bias), both operands fp32 and k-minor (a Linear's
  * forward pass; its input gradient once the weight is transposed) - with the operand tiles staged HBM -> LDS by LDS-DMA instead
  * of through registers (gemm_bf16_dma.hip): same products in the same order, bit-identical results, about half the time on
@@ -571,11 +574,18 @@ int dldkd_tower_train_f3(const void* ctx, const void* h1d, const void* wd_pack, 
                          float* h2_f32, float* g, void* stream);
 int dldkd_tower_train_b3(const float* dg, const void* wot_pack, const void* xh2, const float* rstd2, const float* gamma, float p_drop,
                          unsigned long long seed, unsigned long long offset, const unsigned long long* state, const void* wdt_pack,
-                         const unsigned char* flags, long M, void* ddo, void* dctx, void* dres, float* dgamma, float* dbeta, void* stream);
+                         const unsigned char* flags, long M, void* ddo, void* dctx, void* dres, float* dgamma, float* dbeta, void* dg_bf16,
+                         void* dh2_bf16, void* stream);
 int dldkd_tower_train_b1(const void* dqkv, const void* dres, const void* wqkvt_pack, const void* xh1, const float* stats,
                          const float* gamma, float p_drop, unsigned long long seed, unsigned long long offset,
                          const unsigned long long* state, const unsigned char* flags, long M, int relu_mask, float* dy0, float* dx1,
-                         float* dgamma, float* dbeta, void* stream);
+                         float* dgamma, float* dbeta, void* dz_bf16, void* dy_bf16, void* stream);
+/* The LayerNorm parameter gradients of the two backward kernels: with dgamma / dbeta (zeroed accumulators) the kernels sum them
+ * themselves (cross-lane reductions + atomics: a third of their time at the TVR batch); with dgamma = dbeta = NULL they leave the
+ * gradient of that LayerNorm's output as bf16 rows instead - dh2_bf16 (M, 384; b3 under an out mapping: without one it is dg itself)
+ * and dz_bf16 (M, 384; b1) - for dldkd_tower_train_dw_ln, which sums them beside the split-K reduce.  dg_bf16 (b3, out mapping only) and
+ * dy_bf16 (b1): optional bf16 copies of dg / dy0 (M, 384) for the weight-gradient GEMMs, which contract bf16 rows
+ * (dldkd_tower_train_dw block 0, dldkd_inproj_bwd_bf16).  Rows of skipped 32-row groups: zeros in dy_bf16 (as in dy0), not written in the other bf16 outputs. */
 /* The weight and bias gradients of one fused training tower as ONE split-K product: dW (384 n_blocks, 384) fp32, block b =
  * sum over the batch rows r of A_b[r, acol_b .. acol_b + 384)^T B_b[r, :] (A_b: the gradient of layer b's output, fp32 or bf16
  * (a16_b) rows of lda_b elements; B_b: the layer's saved bf16 input rows (rows, 384)), dbias (384 n_blocks; NULL: not wanted;
@@ -592,6 +602,16 @@ int dldkd_tower_train_dw_pos(const void* const* host_A, const int* host_lda, con
                              const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
                              size_t workspace_bytes, const unsigned char* k_flags, const float* dx1, float* dpos, long n_seq, long cols,
                              void* stream);
+/* dldkd_tower_train_dw_pos (dx1 / dpos may be NULL) plus the parameter gradients of the tower's two LayerNorms in the same finishing
+ * launch: ln_grads (4, 384) fp32, ZEROED by the caller = [dgamma2 | dbeta2 | dgamma1 | dbeta1] with dgamma[c] += sum_r a[r, c] xh[r, c],
+ * dbeta[c] += sum_r a[r, c] over the rows of flagged 32-row groups (k_flags) - LayerNorm 2: a = dh2 (dldkd_tower_train_b3's dh2_bf16, or
+ * the fp32 rows dg it was given when there is no out mapping: dh2_is_bf16 = 0), xh = xh2; LayerNorm 1: a = dz1_bf16
+ * (dldkd_tower_train_b1), xh = xh1 with its flag bit cleared.  All (rows, 384). */
+int dldkd_tower_train_dw_ln(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
+                            const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
+                            size_t workspace_bytes, const unsigned char* k_flags, const float* dx1, float* dpos, long n_seq, long cols,
+                            const void* dz1_bf16, const void* xh1, const void* dh2, int dh2_is_bf16, const void* xh2, float* ln_grads,
+                            void* stream);
 /* out[c] += sum over the rows r of x[r, c0 + c] (x (M, ld) bf16, c < N) whose 32-row group is flagged (flags NULL: all rows); out is
  * zeroed by the caller.  The bias gradients of the fused training towers (rows of skipped groups are not written: they must not be
  * read). */
