@@ -216,6 +216,9 @@ def extras(dev):
                     r["graph"]["stream_ms_median"]
                 # what train.train() runs: the loss stays on the device (one read-back per epoch), the host runs ahead of the GPU
                 out[f"{key}_train_step_ms_{prec}_deferred_loss"] = r["graph_no_loss_sync"]["stream_ms_median"]
+                # ... and the batch already sits in the stepper's input buffers (a data path that fills them itself: no staging copy)
+                if "graph_static_inputs" in r:
+                    out[f"{key}_train_step_ms_{prec}_deferred_loss_static_inputs"] = r["graph_static_inputs"]["stream_ms_median"]
         out["c3_train_step_config"] = "TVR: 128 videos / 640 queries, L<=128, label_style=soft, hard negatives, dropout 0.2, " \
                                       "zero_grad + forward + backward + fused BertAdam; fp32 = parity mode (fp32-grade GEMMs: three bf16 " \
                                       "planes per operand, losses within 1e-4 of the reference), bf16 = every GEMM on bf16 MFMA with fp32 " \
