@@ -354,6 +354,9 @@ static int launch_layernorm(const float* x, const float* add, int add_mod, const
     if (nv <= 2) DLDKD_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
     else if (nv <= 4) DLDKD_LAUNCH(layernorm_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
     else if (nv <= 8) DLDKD_LAUNCH(layernorm_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
+    // (3072-wide rows - the TVR video features - are 12 float4 per lane: the <16> instance holds 64 row registers, 142 VGPRs = 3 waves per
+    // SIMD; <12> 110 = 4 waves: 108 -> 94 us at 16,384 rows with dropout, tools/r05_ab_ln12.sh)
+    else if (nv <= 12) DLDKD_LAUNCH(layernorm_kernel<12>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
     else DLDKD_LAUNCH(layernorm_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
     return check_launch("layernorm");
 }
