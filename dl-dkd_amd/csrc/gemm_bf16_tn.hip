@@ -28,10 +28,8 @@ typedef unsigned short u16;
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BI = 128, BJ = 128, BR = 64, NST = 2;
-constexpr int TILE_B = BR * 256;                    // 16 KiB: 64 rows x 128 bf16
-constexpr int STAGE_B = 2 * TILE_B;                 // A then B
-constexpr int kMaxTiles = 128;                      // row tiles per workgroup (4 x 64 half-tile flags)
+constexpr int BI = 128, BJ = 128;
+constexpr int kMaxGroups = 256;                     // 32-row groups per workgroup (4 x 64 flag bits): 8,192 rows per k-slice
 
 struct Args {
     // (the names gemm_store_tile reads)
@@ -72,11 +70,15 @@ __device__ __forceinline__ bf16x8 nonzero_mask(const bf16x8& b) {
     return __builtin_bit_cast(bf16x8, u);
 }
 
-template <bool DUAL>
+template <bool DUAL, int NST, int BR>
 __device__ __forceinline__ void tn_body(Args p, const int bx, const int by, const int bz, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    constexpr int TILE_B = BR * 256;                    // one operand's row tile: BR rows x 128 bf16 (16 KiB at BR = 64)
+    constexpr int STAGE_B = 2 * TILE_B;                 // A then B
+    constexpr int G = BR / 32;                          // flag groups per tile
+    constexpr int PPW = BR / 16;                        // 1-KiB pieces (4 rows) per wave, operand and tile
     const int i0 = by * BI, j0 = bx * BJ;
     const int nt_all = (p.R + BR - 1) / BR;
     const int t0 = p.split > 1 ? bz * p.tiles_per_split : 0;
@@ -85,28 +87,29 @@ __device__ __forceinline__ void tn_body(Args p, const int bx, const int by, cons
     if (p.split > 1) p.C += (size_t)bz * p.M * p.ldc * (DUAL ? 2 : 1);
     const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
 
-    // half-tile flags of this workgroup's rows: bit (2 t + h) of km = half h of tile t is wanted (in range and not padding)
+    // group flags of this workgroup's rows: bit (G t + h) of km = 32-row group h of tile t is wanted (in range and not padding)
     unsigned long long km[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        const int hidx = 64 * w + lane;                                   // half index inside the workgroup's range
-        const long row = ((long)t0 * 2 + hidx) * 32;
-        bool on = hidx < 2 * nt && row < p.R;
-        if (on && p.rflags != nullptr) on = p.rflags[(long)t0 * 2 + hidx] != 0;
+        const int hidx = 64 * w + lane;                                   // group index inside the workgroup's range
+        const long row = ((long)t0 * G + hidx) * 32;
+        bool on = hidx < G * nt && row < p.R;
+        if (on && p.rflags != nullptr) on = p.rflags[(long)t0 * G + hidx] != 0;
         km[w] = __ballot(on);
     }
     auto half_on = [&](int t, int h) -> bool {
-        const int idx = 2 * t + h, w = idx >> 6;
+        const int idx = G * t + h, w = idx >> 6;
         const unsigned long long m = w == 0 ? km[0] : w == 1 ? km[1] : w == 2 ? km[2] : km[3];
         return ((m >> (idx & 63)) & 1ull) != 0;
     };
 
-    // DMA: wave w brings rows 16 w .. 16 w + 15 of a tile (pieces of 4 rows = 1 KiB); lane -> row 4 q + (lane >> 4) of them, LDS
+    // DMA: wave w brings rows 4 PPW w .. + 4 PPW - 1 of a tile (pieces of 4 rows = 1 KiB); lane -> row 4 q + (lane >> 4) of them, LDS
     // position lane & 15, which holds the row's chunk (lane & 15) ^ f(row)
-    uint32_t voa[4], vob[4];
+    constexpr int wgroup_shift = BR == 64 ? 1 : 2;      // the wave's rows lie in flag group wave >> shift of the tile
+    uint32_t voa[PPW], vob[PPW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = 16 * wave + 4 * q + (lane >> 4);
+    for (int q = 0; q < PPW; ++q) {
+        const int row = 4 * PPW * wave + 4 * q + (lane >> 4);
         const int ch = ((lane & 15) ^ swz(row)) << 4;
         voa[q] = (uint32_t)(row * p.lda * 2 + ch);
         vob[q] = (uint32_t)(row * p.ldb * 2 + ch);
@@ -115,14 +118,14 @@ __device__ __forceinline__ void tn_body(Args p, const int bx, const int by, cons
     const char* bbase = reinterpret_cast<const char*>(p.B + (size_t)t0 * BR * p.ldb + j0);
     const size_t astep = (size_t)BR * p.lda * 2, bstep = (size_t)BR * p.ldb * 2;
     auto issue = [&](int t, int stage) {
-        if (!half_on(t, wave >> 1)) return;
+        if (!half_on(t, wave >> wgroup_shift)) return;
         const char* as = abase + (size_t)t * astep;
         const char* bs = bbase + (size_t)t * bstep;
-        const uint32_t dst = smem_lds + stage * STAGE_B + (4 * wave) * 1024;
+        const uint32_t dst = smem_lds + stage * STAGE_B + (PPW * wave) * 1024;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) glds16_s(voa[q], as, dst + q * 1024);
+        for (int q = 0; q < PPW; ++q) glds16_s(voa[q], as, dst + q * 1024);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) glds16_s(vob[q], bs, dst + TILE_B + q * 1024);
+        for (int q = 0; q < PPW; ++q) glds16_s(vob[q], bs, dst + TILE_B + q * 1024);
     };
 
     // transposed fragment reads of one k-step (16 rows): 16-lane group g = lane >> 4 takes rows 8 (g >> 1) + 4 e .. + 3 (e = 0, 1: the
@@ -158,15 +161,31 @@ __device__ __forceinline__ void tn_body(Args p, const int bx, const int by, cons
     const bool want_cs = p.a_colsum != nullptr && bx == 0 && (wave & 1) == 0;
     float cs[2] = {0.f, 0.f};
 
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // NST stages: tiles t + 1 .. t + NST - 1 are in flight while tile t is multiplied.  One barrier per tile: behind it every wave's
+    // pieces of tile t have landed and every wave is done with tile t - 1, whose stage the DMA of tile t + NST - 1 then overwrites.
+    // The counted wait leaves this wave's pieces of the younger tiles outstanding (8 per tile it brings, none for a half of padding).
+#pragma unroll
+    for (int d = 0; d < NST - 1; ++d)
+        if (d < nt) issue(d, d);
     for (int t = 0; t < nt; ++t) {
-        const int st = t & 1;
-        if (t + 1 < nt) issue(t + 1, st ^ 1);
+        const int st = t % NST;
+        if constexpr (NST == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            // this wave's pieces of the tiles behind tile t stay in flight: 2 PPW per tile it brings
+            int younger = 0;
+#pragma unroll
+            for (int d = 1; d < NST - 1; ++d) younger += (t + d < nt && half_on(t + d, wave >> wgroup_shift)) ? 1 : 0;
+            static_assert(NST <= 4, "counted waits for at most two younger tiles");
+            if (younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * PPW) : "memory");
+        }
+        __syncthreads();
+        if (t + NST - 1 < nt) issue(t + NST - 1, (t + NST - 1) % NST);
         const char* S = smem + st * STAGE_B;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < BR / 16; ++kk) {
             if (!half_on(t, kk >> 1)) continue;
             bf16x8 a[2], b[2], bm[2];
 #pragma unroll
@@ -191,9 +210,8 @@ __device__ __forceinline__ void tn_body(Args p, const int bx, const int by, cons
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile has landed (this wave's pieces; the barrier covers the others)
-        __syncthreads();                                       // and everyone is done reading this one
     }
+    __syncthreads();                                           // (the epilogue stages its tiles through the operand region)
     if (want_cs) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) atomicAdd(p.a_colsum + i0 + wm + 32 * i + (lane & 31), cs[i]);      // (both lane halves: 8 rows each of every k-step)
@@ -205,11 +223,11 @@ __device__ __forceinline__ void tn_body(Args p, const int bx, const int by, cons
     }
 }
 
-template <bool DUAL>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const Args p) {
+template <bool DUAL, int NST, int BR>
+__global__ __launch_bounds__(256, NST * BR <= 128 ? 2 : 1) void gemm_bf16_tn_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Tile3 bid = xcd_tile_order();
-    tn_body<DUAL>(p, bid.x, bid.y, bid.z, smem);
+    tn_body<DUAL, NST, BR>(p, bid.x, bid.y, bid.z, smem);
 }
 
 // the weight gradients of one fused training tower as ONE launch: output rows are 384-row blocks, each with its own operands
@@ -219,7 +237,8 @@ struct GroupArgs {
     const u16* B[5];             // (R, 384)
     int lda[5], acol[5];
 };
-__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_group_kernel(const GroupArgs g) {
+template <int NST, int BR>
+__global__ __launch_bounds__(256, NST * BR <= 128 ? 2 : 1) void gemm_bf16_tn_group_kernel(const GroupArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Tile3 bid = xcd_tile_order();
     Args p = g.base;
@@ -228,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_group_kernel(const GroupA
     p.A = g.A[blk] + ((long)g.acol[blk] - (long)kHidden * blk);
     p.lda = g.lda[blk];
     p.B = g.B[blk];
-    tn_body<false>(p, bid.x, bid.y, bid.z, smem);
+    tn_body<false, NST, BR>(p, bid.x, bid.y, bid.z, smem);
 }
 
 }  // namespace gtn
@@ -236,17 +255,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_group_kernel(const GroupA
 // Row tiles per k-slice and the number of slices: ~384 workgroups (measured at the C3 step, tools/r05_ab_dw_tn_target.sh: 256 / 384 / 512 / 768
 // -> dual 69 / 56 / 62 / 64 us, grouped 53 / 42 / 50 / 46 us, more slices = more plane traffic for the reduce), at least 4 tiles (256 rows) per
 // slice, at most kMaxTiles
+// the operand ring: (stages, rows per tile) = (2, 64) - 64 KiB, two workgroups per CU, one tile in flight behind the one being
+// multiplied - or (4, 32): the same 64 KiB as four half-size tiles, two in flight (DLDKD_TN_RING=432; measured: see plan below)
+static int tn_ring() {
+    static const int n = [] { const char* e = getenv("DLDKD_TN_RING"); const int v = e ? atoi(e) : 0; return (v == 432 || v == 364 || v == 332) ? v : 264; }();
+    return n;
+}
+static int tn_rows() { return tn_ring() % 100; }
 int gemm_bf16_tn_plan(int M, int N, long R, int* tiles_per_split) {
+    const int BR = tn_rows();
     const int tiles = (M / gtn::BI) * (N / gtn::BJ);
-    const int nt = (int)((R + gtn::BR - 1) / gtn::BR);
+    const int nt = (int)((R + BR - 1) / BR);
     static const int target = [] { const char* e = getenv("DLDKD_TN_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 384; }();
     int split = (target + tiles - 1) / tiles;
     if (split > nt / 4) split = nt / 4;
     if (split < 1) split = 1;
     int per = (nt + split - 1) / split;
-    if (per > gtn::kMaxTiles) per = gtn::kMaxTiles;
+    if (per > gtn::kMaxGroups * 32 / BR) per = gtn::kMaxGroups * 32 / BR;
     *tiles_per_split = per;
     return (nt + per - 1) / per;
+}
+
+template <typename K, typename A>
+static void tn_launch(K kernel, dim3 grid, int lds, hipStream_t stream, const A& args) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    DLDKD_LAUNCH(kernel, grid, dim3(256), lds, stream, args);
 }
 
 bool gemm_bf16_tn_enabled() {
@@ -274,17 +307,12 @@ int launch_gemm_bf16_tn(const void* A, const void* B, float* C, int M, int N, lo
     const int split = gemm_bf16_tn_plan(M, N, R, &per);
     gtn::Args p{C, M, N, N, 1.0f, nullptr, 0, (const gtn::u16*)A, (const gtn::u16*)B, (int)R, lda, ldb, split, per, rflags, a_colsum};
     if (split > 1 || dual) p.C = (float*)planes;
-    constexpr int lds = gtn::NST * gtn::STAGE_B;
+    const int ring = tn_ring(), lds = (ring / 100) * 2 * (ring % 100) * 256;
     const dim3 grid(N / gtn::BJ, M / gtn::BI, split);
-    if (dual) {
-        static const bool ok = hipFuncSetAttribute((const void*)gtn::gemm_bf16_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
-        (void)ok;
-        DLDKD_LAUNCH(gtn::gemm_bf16_tn_kernel<true>, grid, dim3(256), lds, stream, p);
-    } else {
-        static const bool ok = hipFuncSetAttribute((const void*)gtn::gemm_bf16_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
-        (void)ok;
-        DLDKD_LAUNCH(gtn::gemm_bf16_tn_kernel<false>, grid, dim3(256), lds, stream, p);
-    }
+#define DLDKD_TN_CASE(R_, NST_, BR_) case R_: if (dual) tn_launch(gtn::gemm_bf16_tn_kernel<true, NST_, BR_>, grid, lds, stream, p); \
+                                              else tn_launch(gtn::gemm_bf16_tn_kernel<false, NST_, BR_>, grid, lds, stream, p); break;
+    switch (ring) { DLDKD_TN_CASE(432, 4, 32) DLDKD_TN_CASE(332, 3, 32) DLDKD_TN_CASE(364, 3, 64) default: DLDKD_TN_CASE(264, 2, 64) }
+#undef DLDKD_TN_CASE
     const int rc = check_launch("gemm_bf16_tn");
     return rc != DLDKD_OK ? rc : (split > 1 || dual ? split : 0);
 }
@@ -301,10 +329,14 @@ int launch_gemm_bf16_tn_group(const void* const* A, const int* lda, const int* a
     for (int b = 0; b < n_blocks; ++b) {
         g.A[b] = (const gtn::u16*)A[b]; g.B[b] = (const gtn::u16*)B[b]; g.lda[b] = lda[b]; g.acol[b] = acol[b];
     }
-    constexpr int lds = gtn::NST * gtn::STAGE_B;
-    static const bool ok = hipFuncSetAttribute((const void*)gtn::gemm_bf16_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
-    (void)ok;
-    DLDKD_LAUNCH(gtn::gemm_bf16_tn_group_kernel, dim3(kHidden / gtn::BJ, M / gtn::BI, split), dim3(256), lds, stream, g);
+    const int ring = tn_ring(), lds = (ring / 100) * 2 * (ring % 100) * 256;
+    const dim3 grid(kHidden / gtn::BJ, M / gtn::BI, split);
+    switch (ring) {
+        case 432: tn_launch(gtn::gemm_bf16_tn_group_kernel<4, 32>, grid, lds, stream, g); break;
+        case 332: tn_launch(gtn::gemm_bf16_tn_group_kernel<3, 32>, grid, lds, stream, g); break;
+        case 364: tn_launch(gtn::gemm_bf16_tn_group_kernel<3, 64>, grid, lds, stream, g); break;
+        default: tn_launch(gtn::gemm_bf16_tn_group_kernel<2, 64>, grid, lds, stream, g); break;
+    }
     const int rc = check_launch("gemm_bf16_tn (tower weight gradients)");
     return rc != DLDKD_OK ? rc : (split > 1 ? split : 0);
 }
