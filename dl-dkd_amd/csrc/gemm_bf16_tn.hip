@@ -278,7 +278,15 @@ int gemm_bf16_tn_plan(int M, int N, long R, int* tiles_per_split) {
 
 template <typename K, typename A>
 static void tn_launch(K kernel, dim3 grid, int lds, hipStream_t stream, const A& args) {
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    // the LDS limit of an instance is raised once per thread that launches it (instances share this function's type: a table, not a static)
+    thread_local const void* seen[8] = {};
+    bool known = false;
+    for (const void* k : seen) known |= k == (const void*)kernel;
+    if (!known) {
+        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        for (auto& k : seen)
+            if (k == nullptr) { k = (const void*)kernel; break; }
+    }
     DLDKD_LAUNCH(kernel, grid, dim3(256), lds, stream, args);
 }
 
