@@ -183,3 +183,38 @@ def test_gemm_bf16_nt16_vs_fp64(M, N, K, relu, flags):
         ref = ref.clamp_min(0)
     err = (y.cpu().double() - ref).abs().max().item()
     assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_backward_without_position_gradient_matches_the_one_with_it():
+    """pos.requires_grad = False takes the finishing launch without the position sums (dx1 / dpos NULL): every other gradient is
+    the one the full backward pass gives (bit for bit where no atomics are involved: the LayerNorm and bias sums end in fp32 atomics)."""
+    from dldkd_amd import functional as F_, ops
+    rs = np.random.RandomState(5)
+    N, L = 6, 64
+    lens = rs.randint(10, L + 1, size=N)
+    mask = torch.from_numpy((np.arange(L)[None] < lens[:, None]).astype(np.float32)).to(DEV)
+    y0 = torch.relu(torch.from_numpy(rs.standard_normal((N, L, H)).astype(np.float32))).to(DEV)
+    dout = torch.from_numpy(rs.standard_normal((N, L, H)).astype(np.float32)).to(DEV) * mask.unsqueeze(-1)
+    p64 = _params(rs, True)
+    res = {}
+    ops.set_gemm_precision("bf16")
+    try:
+        for need_pos in (True, False):
+            pd = {k: v.float().to(DEV).requires_grad_(need_pos or k != "pos") for k, v in p64.items()}
+            lin = lambda w, b: types.SimpleNamespace(weight=pd[w], bias=pd[b])             # noqa: E731
+            yd = y0.clone().requires_grad_(True)
+            out = F_.tower_train(yd, pd["pos"][:L], pd["g1"], pd["b1"], (lin("wq", "bq"), lin("wk", "bk"), lin("wv", "bv")), lin("wd", "bd"),
+                                 pd["g2"], pd["b2"], lin("wo", "bo"), mask, torch.from_numpy(lens.astype(np.int32)).to(DEV), None,
+                                 0.0, 0.0, 0.0, True, relu_mask=False)
+            out.backward(dout)
+            res[need_pos] = {k: pd[k].grad for k in ORDER if k != "pos"}
+            res[need_pos]["y0"] = yd.grad
+            assert (pd["pos"].grad is not None) == need_pos
+    finally:
+        ops.set_gemm_precision("fp32")
+    for k, g in res[True].items():
+        r = res[False][k]
+        if k in ("g1", "b1", "g2", "b2", "bq", "bk", "bv", "bd", "bo"):            # sums that end in fp32 atomics
+            assert torch.allclose(g, r, rtol=1e-4, atol=1e-5 * float(g.abs().max())), k
+        else:
+            assert torch.equal(g, r), k
