@@ -35,6 +35,9 @@ constexpr int kD = kHidden;               // 384
 constexpr int kT = 12;                    // 32-feature accumulator tiles of a row
 constexpr int kKS = 24;                   // 16-wide k-steps over 384
 constexpr int kMatFrags = kKS * kT;       // fragments (1 KiB) of one 384 x 384 operand
+#ifndef TT_WPB
+#define TT_WPB 4       // waves (32-row groups) per workgroup of the four row kernels: 4, 2 or 1 (make TT_WPB=n)
+#endif
 #ifndef TT_ABL
 #define TT_ABL 0       // diagnostic builds only (make TT_ABL=n): 1 no Philox, 2 no weight loads, 4 no LayerNorm-gradient column sums, 8 no MFMAs
 #endif
@@ -190,7 +193,7 @@ __device__ __forceinline__ Wave locate(long M, const unsigned char* flags) {
     w.lane = threadIdx.x & 63;
     w.r32 = w.lane & 31;
     w.h = w.lane >> 5;
-    const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long g = (long)blockIdx.x * TT_WPB + (threadIdx.x >> 6);
     const long row0 = g * 32;
     w.run = row0 < M && (flags == nullptr || flags[g] != 0);
     w.row = row0 + w.r32;
@@ -204,7 +207,7 @@ __device__ __forceinline__ Wave locate(long M, const unsigned char* flags) {
 // loaded as ONE batch of 48 loads per lane behind a scheduling barrier before the sweep starts: left to itself hipcc sinks every
 // load next to its use and waits for it there - 48 to 96 exposed L2 round trips per sweep, more than the products themselves.
 __device__ __forceinline__ void stage_vec(float* dst, const float* src) {
-    for (int i = threadIdx.x; i < kD; i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < kD; i += 64 * TT_WPB) dst[i] = src[i];
 }
 __device__ __forceinline__ f32x4 vec4(const float* lds_vec_plus_4h, int fo) { return *reinterpret_cast<const f32x4*>(lds_vec_plus_4h + fo); }
 
@@ -261,7 +264,7 @@ struct F1Args {
     u16* qkv;                    // (M, 1152) bf16
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void f1_kernel(const F1Args p) {
+__global__ __launch_bounds__(64 * TT_WPB) __attribute__((amdgpu_waves_per_eu(1, 1))) void f1_kernel(const F1Args p) {
     __shared__ __attribute__((aligned(16))) float vs[5][kD];      // gamma, beta, bq, bk, bv
     stage_vec(vs[0], p.gamma); stage_vec(vs[1], p.beta);
     stage_vec(vs[2], p.bias[0]); stage_vec(vs[3], p.bias[1]); stage_vec(vs[4], p.bias[2]);
@@ -380,7 +383,7 @@ struct F3Args {
 
 // VIDEO: h2 as bf16 + the out mapping; otherwise (query towers) h2 as fp32 rows for the modular pooling
 template <bool VIDEO>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void f3_kernel(const F3Args p) {
+__global__ __launch_bounds__(64 * TT_WPB) __attribute__((amdgpu_waves_per_eu(1, 1))) void f3_kernel(const F3Args p) {
     __shared__ __attribute__((aligned(16))) float vs[4][kD];      // bd, gamma, beta, bo
     stage_vec(vs[0], p.bd); stage_vec(vs[1], p.gamma); stage_vec(vs[2], p.beta);
     if constexpr (VIDEO) stage_vec(vs[3], p.bo);
@@ -507,7 +510,7 @@ struct B3Args {
 // (tools/r05_abl_tower2.sh).  false: the kernel leaves dh2 as bf16 rows and the column sums to the launch that reduces the
 // weight gradients' split-K planes (gemm_bf16.hip, dw_finish_kernel: plain coalesced row sweeps).
 template <bool SUMS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void b3_kernel(const B3Args p) {
+__global__ __launch_bounds__(64 * TT_WPB) __attribute__((amdgpu_waves_per_eu(1, 1))) void b3_kernel(const B3Args p) {
     __shared__ __attribute__((aligned(16))) float vs[kD];          // gamma
     stage_vec(vs, p.gamma);
     __syncthreads();
@@ -671,14 +674,14 @@ struct B1Args {
 };
 
 template <bool DX1, bool SUMS>      // SUMS: see b3_kernel
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void b1_kernel(const B1Args p) {
+__global__ __launch_bounds__(64 * TT_WPB) __attribute__((amdgpu_waves_per_eu(1, 1))) void b1_kernel(const B1Args p) {
     __shared__ __attribute__((aligned(16))) float vs[kD];          // gamma
     stage_vec(vs, p.gamma);
     __syncthreads();
     const Wave w = locate(p.M, nullptr);
     if (!w.run) return;
     const int h = w.h, lane = w.lane;
-    if (p.flags != nullptr && p.flags[(long)blockIdx.x * 4 + (threadIdx.x >> 6)] == 0) {
+    if (p.flags != nullptr && p.flags[(long)blockIdx.x * TT_WPB + (threadIdx.x >> 6)] == 0) {
         // a group of padding: its gradients are exact zeros (the weight-gradient GEMMs skip these rows, plain column sums read them)
         if (w.valid) {
 #pragma unroll
@@ -893,7 +896,7 @@ static Drop make_drop(float p, unsigned long long seed, unsigned long long off, 
 }
 
 static bool bad_p(float p) { return !(p >= 0.f && p < 1.f); }
-static unsigned grid_of(long M) { return (unsigned)((M + 127) / 128); }
+static unsigned grid_of(long M) { return (unsigned)((M + 32 * TT_WPB - 1) / (32 * TT_WPB)); }
 
 }  // namespace tt
 }  // namespace dldkd
@@ -970,7 +973,7 @@ int dldkd_tower_train_f1(const float* y0, const float* pos, int L, const float* 
          (uintptr_t)xh1 | (uintptr_t)qkv | (uintptr_t)wqkv_pack) & 15) { set_error("tower_train_f1: 16-byte alignment"); return DLDKD_EINVAL; }
     tt::F1Args a{y0, pos, L, gamma, beta, eps, tt::make_drop(p_drop, seed, offset, state), (const bf16x8*)wqkv_pack, {bq, bk, bv}, flags, M,
                  (tt::u16*)h1d, (tt::u16*)xh1, stats, (tt::u16*)qkv};
-    DLDKD_LAUNCH(tt::f1_kernel, dim3(tt::grid_of(M)), dim3(256), 0, (hipStream_t)stream, a);
+    DLDKD_LAUNCH(tt::f1_kernel, dim3(tt::grid_of(M)), dim3(64 * TT_WPB), 0, (hipStream_t)stream, a);
     return check_launch("tower_train_f1");
 }
 
@@ -987,10 +990,10 @@ int dldkd_tower_train_f3(const void* ctx, const void* h1d, const void* wd_pack, 
                  (const bf16x8*)wo_pack, bo, flags, M, (tt::u16*)xh2, rstd2, (tt::u16*)h2_bf16, h2_f32, g};
     if (wo_pack != nullptr) {
         if (!h2_bf16) { set_error("tower_train_f3: the out mapping needs the bf16 h2 buffer"); return DLDKD_EINVAL; }
-        DLDKD_LAUNCH(tt::f3_kernel<true>, dim3(tt::grid_of(M)), dim3(256), 0, (hipStream_t)stream, a);
+        DLDKD_LAUNCH(tt::f3_kernel<true>, dim3(tt::grid_of(M)), dim3(64 * TT_WPB), 0, (hipStream_t)stream, a);
     } else {
         if (!h2_f32) { set_error("tower_train_f3: without the out mapping h2 is written as fp32 rows"); return DLDKD_EINVAL; }
-        DLDKD_LAUNCH(tt::f3_kernel<false>, dim3(tt::grid_of(M)), dim3(256), 0, (hipStream_t)stream, a);
+        DLDKD_LAUNCH(tt::f3_kernel<false>, dim3(tt::grid_of(M)), dim3(64 * TT_WPB), 0, (hipStream_t)stream, a);
     }
     return check_launch("tower_train_f3");
 }
@@ -1011,8 +1014,8 @@ int dldkd_tower_train_b3(const float* dg, const void* wot_pack, const void* xh2,
          (uintptr_t)dres | (uintptr_t)dg_bf16 | (uintptr_t)dh2_bf16) & 15) { set_error("tower_train_b3: 16-byte alignment"); return DLDKD_EINVAL; }
     tt::B3Args a{dg, (const bf16x8*)wot_pack, (const tt::u16*)xh2, rstd2, gamma, tt::make_drop(p_drop, seed, offset, state), (const bf16x8*)wdt_pack,
                  flags, M, (tt::u16*)ddo, (tt::u16*)dctx, (tt::u16*)dres, dgamma, dbeta, (tt::u16*)dg_bf16, (tt::u16*)dh2_bf16};
-    if (sums) DLDKD_LAUNCH(tt::b3_kernel<true>, dim3(tt::grid_of(M)), dim3(256), 0, (hipStream_t)stream, a);
-    else DLDKD_LAUNCH(tt::b3_kernel<false>, dim3(tt::grid_of(M)), dim3(256), 0, (hipStream_t)stream, a);
+    if (sums) DLDKD_LAUNCH(tt::b3_kernel<true>, dim3(tt::grid_of(M)), dim3(64 * TT_WPB), 0, (hipStream_t)stream, a);
+    else DLDKD_LAUNCH(tt::b3_kernel<false>, dim3(tt::grid_of(M)), dim3(64 * TT_WPB), 0, (hipStream_t)stream, a);
     return check_launch("tower_train_b3");
 }
 
@@ -1035,11 +1038,11 @@ int dldkd_tower_train_b1(const void* dqkv, const void* dres, const void* wqkvt_p
     const dim3 grid(tt::grid_of(M));
     hipStream_t st = (hipStream_t)stream;
     if (dx1 != nullptr) {
-        if (sums) DLDKD_LAUNCH((tt::b1_kernel<true, true>), grid, dim3(256), 0, st, a);
-        else DLDKD_LAUNCH((tt::b1_kernel<true, false>), grid, dim3(256), 0, st, a);
+        if (sums) DLDKD_LAUNCH((tt::b1_kernel<true, true>), grid, dim3(64 * TT_WPB), 0, st, a);
+        else DLDKD_LAUNCH((tt::b1_kernel<true, false>), grid, dim3(64 * TT_WPB), 0, st, a);
     } else {
-        if (sums) DLDKD_LAUNCH((tt::b1_kernel<false, true>), grid, dim3(256), 0, st, a);
-        else DLDKD_LAUNCH((tt::b1_kernel<false, false>), grid, dim3(256), 0, st, a);
+        if (sums) DLDKD_LAUNCH((tt::b1_kernel<false, true>), grid, dim3(64 * TT_WPB), 0, st, a);
+        else DLDKD_LAUNCH((tt::b1_kernel<false, false>), grid, dim3(64 * TT_WPB), 0, st, a);
     }
     return check_launch("tower_train_b1");
 }
