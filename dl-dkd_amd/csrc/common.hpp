@@ -77,8 +77,11 @@ __device__ __forceinline__ float fuse2(float w0, float a, float w1, float b) { r
 // Philox4x32-10 (Salmon et al., SC'11): the counter-based generator of every dropout mask (train_f32.hip, attention_train.hip)
 __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
                                               unsigned (&out)[4]) {
+#ifndef DLDKD_PHILOX_ROUNDS
+#define DLDKD_PHILOX_ROUNDS 10     // (diagnostic builds: make PHILOX_ROUNDS=7 measures what the generator's last three rounds cost)
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < DLDKD_PHILOX_ROUNDS; ++r) {
         const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
         const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
         c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
