@@ -77,7 +77,10 @@ def test_grouped_weight_gradients_vs_fp64(rows, use_flags):
         a64 = a[:, col:col + H].bfloat16().double().cpu()[kd]                          # the kernel contracts bf16 rows
         ref, refb = a64.t() @ b.double().cpu()[kd], a64.sum(0)
         assert _rel(dW[i * H:(i + 1) * H], ref) <= 2e-6, (i, _rel(dW[i * H:(i + 1) * H], ref))
-        assert _rel(dB[i * H:(i + 1) * H], refb) <= 2e-6, (i, _rel(dB[i * H:(i + 1) * H], refb))
+        eb = _rel(dB[i * H:(i + 1) * H], refb)
+        if a.dtype == torch.float32:         # (the register-staged fallback, DLDKD_DW_TN=0, sums the fp32 rows before rounding them)
+            eb = min(eb, _rel(dB[i * H:(i + 1) * H], a[:, col:col + H].double().cpu()[kd].sum(0)))
+        assert eb <= 2e-6, (i, eb)
 
 
 @pytest.mark.parametrize("n_seq,L,video", [(128, 128, True), (150, 30, False), (5, 32, True), (3, 20, False)])
