@@ -122,3 +122,37 @@ def test_register_staged_fallback_for_shapes_off_the_grid():
     a, b = torch.randn(rows, H, generator=g, device=DEV).bfloat16(), torch.randn(rows, H, generator=g, device=DEV).bfloat16()
     dW, dB, _ = _dw(rows, [(a, 0, b)])
     assert _rel(dW, a.double().cpu().t() @ b.double().cpu()) <= 2e-6 and _rel(dB, a.double().cpu().sum(0)) <= 2e-6
+
+
+@pytest.mark.parametrize("M,K,p_drop", [(4096, 3072, 0.2), (1056, 768, 0.0), (640, 1024, 0.1)])
+def test_input_projection_backward_with_and_without_the_bf16_copy_of_dy(M, K, p_drop):
+    """dldkd_inproj_bwd_bf16's dy_bf16 argument (the rows dldkd_tower_train_b1 leaves beside dy0): the same planes as when the
+    library casts dy itself - bit for bit for dW, the LayerNorm sums and the bias up to their fp32 atomics - and dW against fp64."""
+    native, L_ = _lib()
+    p = native.ptr
+    N = H
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    rnd = lambda *s: torch.randn(*s, generator=g, device=DEV)                        # noqa: E731
+    x = rnd(M, K)
+    gamma, beta, W = 1 + 0.1 * rnd(K), 0.1 * rnd(K), 0.03 * rnd(N, K)
+    z = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    stats = torch.empty(2, M, device=DEV)
+    native.check(L_.dldkd_layernorm_dropout_bf16(p(x), p(gamma), p(beta), p(z), None, p(stats), M, K, 1e-5, p_drop, 11, 0, None, None, None,
+                                                 native.stream()), "ln")
+    dy = rnd(M, N)
+    dy16 = dy.bfloat16()
+    nbytes = L_.dldkd_inproj_bwd_workspace_bytes(N, K, M)
+    res = []
+    for given in (None, dy16):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        dW, db, dgb = torch.empty(N, K, device=DEV), torch.zeros(N, device=DEV), torch.zeros(2, K, device=DEV)
+        native.check(L_.dldkd_inproj_bwd_bf16(p(dy), p(z), p(W), p(gamma), p(beta), 1.0 / (1.0 - p_drop), p(x), None, p_drop, 11, 0, None,
+                                              p(stats[0]), p(stats[1]), p(dW), p(db), p(dgb[0]), p(dgb[1]), M, N, K, p(ws), nbytes, None,
+                                              p(given), native.stream()), "inproj_bwd")
+        torch.cuda.synchronize()
+        res.append((dW, db, dgb))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.allclose(res[0][2], res[1][2], rtol=1e-5, atol=1e-6 * float(res[0][2].abs().max()))
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-6 * float(res[0][1].abs().max()))
+    assert _rel(res[0][0], dy16.double().cpu().t() @ z.double().cpu()) <= 2e-6
+    assert _rel(res[0][1], dy16.double().cpu().sum(0)) <= 2e-6
