@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark: query x video pairs scored / s on the TVR full gallery (BASELINE.json).
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (any N: with N > 1 and no WORLD_SIZE in the environment it starts its
+                                                            own ranks - a fresh `python -m torch.distributed.run` child - and
+                                                            relays rank 0's JSON line and the child's exit code)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W     (the same ranks)
 
 A "step" = one pass of the scoring hot path over the whole synthetic TVR-shaped workload (config C2,
 SURVEY.md 8d): normalise + pack the 10,895 x 2 query vectors, score them against the resident bf16
@@ -432,7 +434,7 @@ def run_sharded(cfg, dev, rank, world, comm, steps, warmup):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
     def fence():
-        torch.cuda.synchronize()
+        comm.host_wait(what="bench step loop")      # deadline-bounded (comm.py): a dead peer must end the run, not hang it
         comm.barrier()
         torch.cuda.synchronize()
     for _ in range(warmup):
@@ -515,7 +517,7 @@ def run_c5_ddp(dev, rank, world, comm, steps, warmup):
            "n_gpus": world, "grad_bytes": None}
 
     def fence():
-        torch.cuda.synchronize()
+        comm.host_wait(what="bench step loop")      # deadline-bounded (comm.py): a dead peer must end the run, not hang it
         comm.barrier()
         torch.cuda.synchronize()
 
@@ -559,6 +561,83 @@ def run_c5_ddp(dev, rank, world, comm, steps, warmup):
     return res
 
 
+def launch_command(n, argv, port, python=None):
+    """The command `bench.py --gpus N` starts when nobody has started its ranks: one rank per GPU of this node under
+    torch.distributed.run (rendezvous on 127.0.0.1 - the boxes' hostname need not resolve), each rank = this script, same flags."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def relay_child(cmd, timeout_s=3600.0, env=None, out=None, err=None):
+    """Run `cmd` as a FRESH child process (never exec: this parent may not touch the GPU and must not be replaced), pass its stderr
+    through, keep its stdout back, and when it ends print the child's stdout with its last JSON line LAST - rank 0's result line
+    becomes this process's last stdout line whatever banners the ranks wrote around it.  Returns the child's exit code; a child
+    still running after timeout_s is killed with its whole process group (the ranks) and the code is 124."""
+    import signal
+    import subprocess
+    out, err = out or sys.stdout, err or sys.stderr
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None if err is sys.stderr else subprocess.PIPE, text=True, env=env,
+                         start_new_session=True)
+    try:
+        so, se = p.communicate(timeout=timeout_s if timeout_s and timeout_s > 0 else None)
+        rc = p.returncode
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            p.kill()
+        so, se = p.communicate()
+        rc = 124
+        print(f"bench.py: the launched ranks did not finish within {timeout_s:g} s: killed", file=err, flush=True)
+    if se:
+        err.write(se)
+    lines = (so or "").splitlines()
+    last_json = None
+    for i in range(len(lines) - 1, -1, -1):
+        t = lines[i].strip()
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                json.loads(t)
+            except ValueError:
+                continue
+            last_json = i
+            break
+    for i, ln in enumerate(lines):
+        if i != last_json:
+            print(ln, file=err)                     # whatever else the ranks printed: not part of the result
+    if last_json is not None:
+        print(lines[last_json], file=out, flush=True)
+    elif rc == 0:
+        print("bench.py: the launched ranks exited 0 without a JSON line", file=err, flush=True)
+        rc = 1
+    if rc < 0:                                      # died by a signal
+        rc = 128 - rc
+    return rc
+
+
+def self_launch(a, argv):
+    """`python bench.py --gpus N` (N > 1) with no WORLD_SIZE in the environment: count the GPUs WITHOUT initialising one
+    (torch.cuda.device_count()), refuse within seconds if there are fewer than N, else start the ranks and relay their result."""
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} needs {a.gpus} GPUs on this node, torch.cuda.device_count() = {have}: not starting "
+              "(nothing was launched; run with --gpus <= that, or on a node that has them)", file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("DLDKD_COMM_DEADLINE_S", "300")
+    cmd = launch_command(a.gpus, argv, free_port())
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    return relay_child(cmd, timeout_s=a.launch_timeout, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -566,15 +645,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0,
+                    help="N > 1 self-launch only: seconds before the launched ranks are killed (a hang must not outlive the lease)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # nobody started our ranks: do it ourselves, as a child process, BEFORE anything in this process touches a GPU
+        sys.exit(self_launch(a, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     sustained = mfma_sustained() if (world == 1 and rank == 0) else None    # child process, before this one touches the GPU
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N (one rank per GPU)")
+    if world != a.gpus and not (world == 1 and os.environ.get("DLDKD_BENCH_FORCE_DIST") == "1"):
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: start one rank per GPU (or leave WORLD_SIZE unset and "
+                         "let bench.py start them)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has LOCAL_RANK {local_rank} but this node has {torch.cuda.device_count()} GPUs")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     comm = None

@@ -161,6 +161,7 @@ def check_had_flags(fp, had, comm=None):
     mine = torch.tensor([1.0 if h else 0.0 for h in had], dtype=torch.float32, device=fp.grad.device)
     tot = mine.clone()
     c.all_reduce(tot, "sum")
+    c.host_wait(what="check_had_flags all-reduce")
     tot = tot.cpu().tolist()
     bad = [i for i, t in enumerate(tot) if t != 0.0 and t != float(c.world)]
     if bad:

@@ -49,3 +49,35 @@ def test_bench_plain_run_prints_the_same_recalls():
     import bench
     d = _line({}, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras")
     assert d["recall_hip"] == bench.RECALL_N1 and d["n_gpus"] == 1 and d["roofline"]["bound"] == "mfma"
+
+
+def test_bench_asking_for_more_gpus_than_the_box_has_exits_fast_with_the_reason():
+    """`python bench.py --gpus 2` (no WORLD_SIZE) used to print a usage message; now it starts its own ranks - and
+    on a box with fewer GPUs it must say so and exit non-zero within seconds, never hang a lease."""
+    import time
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(n, 2))], env=env, capture_output=True, text=True,
+                       timeout=120, cwd=ROOT)
+    assert r.returncode == 2 and time.monotonic() - t0 < 60.0
+    assert f"needs {max(n, 2)} GPUs" in r.stderr and r.stdout.strip() == ""
+
+
+def test_self_launched_ranks_relay_their_json_line():
+    """The launcher end to end on what this box has: bench.launch_command for ONE rank under torch.distributed.run (the agent's
+    rendezvous on 127.0.0.1, RANK / LOCAL_RANK / WORLD_SIZE from it) with the distributed code path forced, relayed by
+    bench.relay_child: the parent's stdout is exactly rank 0's JSON line."""
+    import io
+    import bench
+    env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}, DLDKD_BENCH_FORCE_DIST="1",
+               DLDKD_COMM_DEADLINE_S="120")
+    out, err = io.StringIO(), io.StringIO()
+    cmd = bench.launch_command(1, ["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-extras"], bench.free_port())
+    rc = bench.relay_child(cmd, timeout_s=1200, env=env, out=out, err=err)
+    assert rc == 0, err.getvalue()[-3000:]
+    lines = out.getvalue().strip().splitlines()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["recall_hip"] == bench.RECALL_N1 and d["assembled_max_abs_diff"] == 0.0

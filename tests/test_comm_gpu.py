@@ -193,3 +193,39 @@ def test_data_parallel_replay_uses_the_tower_graphs_with_one_all_reduce(rccl_com
         assert e.par["ar_in_graph"] is in_graph
     finally:
         T.DDP_MIN_WORLD = old
+
+
+def test_host_wait_is_deadline_bounded_and_aborts(rccl_comm):
+    """the blocking points of the multi-rank path poll an event + the communicator's error state against a
+    deadline instead of synchronising for ever.  A stream busy for ~4 s (a spin kernel: it ENDS by itself, so nothing here can
+    hang the box - ncclCommAbort frees device memory, which waits for the device) stands in for a collective whose peer is late:
+    host_wait raises CommTimeout at its 1-s deadline and leaves the communicator aborted; work that does finish returns at once;
+    watch() leaves markers without draining the stream."""
+    import time
+    from dldkd_amd import comm as dcomm
+    from dldkd_amd import native
+    c = rccl_comm
+    x = torch.ones(1 << 20, device=DEV)
+    c.all_reduce(x, "sum")
+    t0 = time.monotonic()
+    assert c.host_wait(what="a finished all-reduce") is True and time.monotonic() - t0 < 5.0
+    assert c.watch() and c.watch()                                   # second call checks the first marker: complete
+    # calibrate the spin kernel, then keep a side stream busy for ~4 s
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(20_000_000); e1.record(); torch.cuda.synchronize()
+    per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
+    busy = torch.cuda.Stream(device=DEV)
+    with torch.cuda.stream(busy):
+        for _ in range(8):
+            torch.cuda._sleep(int(per_ms * 500))                     # 8 x 0.5 s
+        y = x * 2
+    t0 = time.monotonic()
+    with pytest.raises(dcomm.CommTimeout) as ei:
+        c.host_wait(busy, what="a stream that is late", deadline_s=1.0)
+    dt = time.monotonic() - t0
+    assert 0.9 <= dt < 30.0 and "deadline 1 s" in str(ei.value) and "aborted" in str(ei.value)
+    assert not c._h                                                  # aborted: the handle is gone ...
+    with pytest.raises(native.NativeError):
+        c.all_reduce(x, "sum")                                       # ... and later collectives fail loudly instead of hanging
+    busy.synchronize()
+    assert float(y[0]) == 2.0

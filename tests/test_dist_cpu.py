@@ -413,6 +413,46 @@ def test_sharded_ranks_from_partials_two_ranks():
     assert (ret[0] == ret["want"]).all(), (ret[0][0], ret["want"][0])
 
 
+# ------------------------------------------------------------------------------------------------ a peer that stops stepping
+def _stall_worker(rank, world, port, ret):
+    import time
+    os.environ["DLDKD_COMM_DEADLINE_S"] = "2"
+    _setup(rank, world, port)
+    from dldkd_amd import comm as dcomm
+    from dldkd_amd import dist as ddist
+    from dldkd_amd import train as T
+    torch.manual_seed(100 + rank)
+    model = _ToyModel()
+    opt_ = _SGDOnFlat(model.parameters(), lr=0.1)
+    ddist.broadcast_parameters(opt_.fp)
+    x, y = _data()
+    cfg = types.SimpleNamespace(bsz=4, grad_clip=-1)
+    batch = {"x": x[4 * rank:4 * rank + 4], "y": y[4 * rank:4 * rank + 4]}
+    T.train_step(model, batch, opt_, cfg)                 # one healthy step on both ranks
+    if rank == 1:
+        time.sleep(8.0)                                   # alive, connected, but no longer stepping (a diverged / stuck peer)
+        ret[rank] = dict(raised=None, seconds=None)
+        return
+    t0 = time.monotonic()
+    try:
+        T.train_step(model, batch, opt_, cfg)
+        raised = None
+    except dcomm.CommTimeout as ex:
+        raised = str(ex)
+    ret[rank] = dict(raised=raised, seconds=time.monotonic() - t0)
+
+
+def test_a_rank_that_stops_stepping_makes_the_other_raise_within_the_deadline():
+    """with the process-group watchdog gone nothing bounded a wait on a dead or diverged peer.  Every blocking
+    point of the multi-rank path is deadline-bounded in the calling thread (comm.Comm.host_wait / the polled collectives of
+    TorchGroupComm): rank 1 stops stepping, rank 0's next train_step raises CommTimeout at DLDKD_COMM_DEADLINE_S = 2 s, not never."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_stall_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0]["raised"] is not None and "deadline" in ret[0]["raised"] and "rank 0 of 2" in ret[0]["raised"]
+    assert 1.5 <= ret[0]["seconds"] < 6.0
+
+
 # ------------------------------------------------------------------------------------------------ rank-invariant had-flag check
 def _had_worker(rank, world, port, ret):
     _setup(rank, world, port)
