@@ -59,6 +59,6 @@ size_t dldkd_gemm_workspace_bytes(int precision, int M, int N, int K, int a_kmaj
     }
     return split > 1 ? (size_t)split * M * N * sizeof(float) : 0;
 }
-int dldkd_abi_version(void) { return 6; }
+int dldkd_abi_version(void) { return 7; }
 const char* dldkd_last_error(void) { return dldkd::g_err; }
 }

@@ -125,6 +125,10 @@ struct TowerArgs {
     int32_t* lens_out;        // OUTMODE 1: lens of the whole gallery (or null)
     float* pooled[2];         // OUTMODE 2: (n_seq, 384) fp32 modular query vectors
     unsigned long long* stamps;   // diagnostics only (dldkd_debug_tower_seq_timeline): 24 words per workgroup, else null
+    int32_t* nonfinite;       // or null (OUTMODE 0 / 1): set to 1 when the second LayerNorm of a VALID row sees a mean that is not finite -
+                              // an fp16 operand overflowed somewhere upstream (h0 from K4 / K4b, q | k | v, the context).  OUTMODE 2
+                              // (query towers; that kernel has no register to spare) leaves it alone: a non-finite query vector is
+                              // flagged by dldkd_pack_queries_bf16 (bad_flags)
 };
 
 // OUTMAP: the stream ends with the 384 x 384 out_mapping_linear (video towers); OUTMODE 0: fp32 rows, 1: packed bf16 gallery,
@@ -732,8 +736,10 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
         }
         return;
     }
+    unsigned long long row_bad = 0ull;
     {
         const float mean = half_swap_sum(s1) * (1.f / kHidden);
+        row_bad = __builtin_amdgcn_ballot_w64(!(fabsf(mean) <= 3.0e38f) && r < len);      // fp16 overflow guard: stored behind the stream
         const float rstd = rsqrtf(fmaxf(half_swap_sum(s2) * (1.f / kHidden) - mean * mean, 0.f) + 1e-5f);
         const float nmr = -mean * rstd;
 #pragma unroll
@@ -776,6 +782,7 @@ __global__ __launch_bounds__(256, 1) void tower_seq_kernel(const TowerArgs p) {
     }
     asm volatile("; TW_STREAM_END" ::: "memory");
     stamp();                                                           // [12] out mapping done
+    if (row_bad != 0ull && p.nonfinite != nullptr && lane == 0) *p.nonfinite = 1;   // (TowerArgs.nonfinite; behind the counted stream)
     if constexpr (PERS) {
         if (has_next && !(TW_PERS_EXP & 2)) touch_rows(ent_nxt, row0_nxt);                   // the next item's h0 rows on their way to L2 under the row stores below
     }
@@ -970,27 +977,27 @@ int dldkd_tower_pack_h16(const float* ln1_g, const float* ln1_b, const float* wq
 static int tower_seq_launch(const void* const* h0, int h16, const void* const* blob, const int32_t* row0,
                             const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                             int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
-                            void* stream);
+                            int32_t* nonfinite_flag, void* stream);
 
 int dldkd_tower_seq_h16(const float* const* h0, const void* const* blob, const int32_t* row0,
                          const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                          int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
-                         void* stream) {
+                         int32_t* nonfinite_flag, void* stream) {
     return tower_seq_launch((const void* const*)h0, 0, blob, row0, lens, items, n_items, n_seq, n_branches, out_mode, out_rows, seq_rows,
-                            gallery, v0, Lp, lens_out, stream);
+                            gallery, v0, Lp, lens_out, nonfinite_flag, stream);
 }
 
 int dldkd_tower_seq_h16_rows16(const void* const* h0_bf16, const void* const* blob, const int32_t* row0,
                              const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
-                             void* const* gallery, int v0, int Lp, int32_t* lens_out, void* stream) {
+                             void* const* gallery, int v0, int Lp, int32_t* lens_out, int32_t* nonfinite_flag, void* stream) {
     return tower_seq_launch(h0_bf16, 1, blob, row0, lens, items, n_items, n_seq, n_branches, 1, nullptr, 0, gallery, v0, Lp, lens_out,
-                            stream);
+                            nonfinite_flag, stream);
 }
 
 static int tower_seq_launch(const void* const* h0, int h16, const void* const* blob, const int32_t* row0,
                             const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                             int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
-                            void* stream) {
+                            int32_t* nonfinite_flag, void* stream) {
     if (n_items < 0 || n_seq < 0 || (n_branches != 1 && n_branches != 2) || out_mode < 0 || out_mode > 2 || seq_rows < 0 ||
         seq_rows > 128 || (!row0 && seq_rows < 1) || (out_mode == 1 && (Lp < 32 || Lp > 128 || (Lp & 31) || v0 < 0)) ||
         (out_mode == 2 && !items && n_items != (n_seq + 3) / 4)) {
@@ -1014,7 +1021,7 @@ static int tower_seq_launch(const void* const* h0, int h16, const void* const* b
         }
     }
     p.row0 = row0; p.lens = lens; p.items = items; p.n_items = n_items; p.n_seq = n_seq; p.n_branches = n_branches;
-    p.seq_rows = seq_rows; p.v0 = v0; p.Lp = Lp; p.lens_out = lens_out;
+    p.seq_rows = seq_rows; p.v0 = v0; p.Lp = Lp; p.lens_out = lens_out; p.nonfinite = nonfinite_flag;
     dim3 grid(n_branches == 2 ? 8u * (unsigned)((n_items + 3) / 4) : (unsigned)n_items);
     if (h16 && !(TW_PERS_EXP & 4)) {
         // persistent workgroups, one per CU (a multiple of 8 so that a workgroup's branch = its XCD half stays put): workgroup w walks

@@ -8,6 +8,7 @@ is on the hot path.  Differences in HOW (not in what is returned):
     np.argsort per query + a pure-Python AP loop (eval.py:69-83,97-111).
 """
 import contextlib
+import os
 import logging
 import weakref
 
@@ -228,6 +229,21 @@ def _resident_context_info(model, eval_dataset, opt, loader, owner, kind):
             slot = None
     key = ("resident", kind)
     res = slot.get(key) if slot is not None else None
+    # opt.eval_resident_shard: the table persisted as ONE file (ingest.save_resident / load_resident: fp16 rows + statistics + ids,
+    # read back through a pinned ring at PCIe rate) - a fresh process starts from it instead of re-reading the fp32 features item
+    # by item through the loader (utils/basic_utils.py:9-68); written behind the first pass that built the whole table.
+    shard = getattr(opt, "eval_resident_shard", None) if kind == "video" else None
+    if res is None and shard and os.path.exists(shard):
+        from . import ingest
+        table, ids = ingest.load_resident(shard, dev)
+        if table.K != int(model.visual_input_proj.net[1].weight.shape[1]) or len(ids) != n or max(table.lens, default=0) > L:
+            raise native.NativeError(f"eval_resident_shard {shard}: {len(ids)} items of width {table.K} do not match the gallery "
+                                     f"({n} videos, width {int(model.visual_input_proj.net[1].weight.shape[1])}, max_ctx_l {L})")
+        res = ResidentGallery(table.K, dev)
+        res.table, res.metas, res.complete = table, ids, True
+        res.plan(dev)
+        if slot is not None:
+            slot[key] = res
     packer = scoring.GalleryPacker(n, L, 2, dev)
     if res is not None and res.complete and len(res.metas) == n and res.table.device == dev:
         torch.empty((), dtype=torch.int64).random_()        # the DataLoader iterator's base-seed draw (see _cached_batches)
@@ -263,6 +279,11 @@ def _resident_context_info(model, eval_dataset, opt, loader, owner, kind):
         if keep:
             res.metas, res.complete = metas, True
             slot[key] = res
+            if shard and not os.path.exists(shard):
+                from . import ingest
+                torch.cuda.synchronize(dev)
+                ingest.save_resident(shard, res.table, metas)
+                logger.info(f"resident gallery features saved to {shard} ({res.table.nbytes() / 1e9:.2f} GB)")
         if res.table.rows or not lens_parts:
             encode_table()
         lens_all = lens_parts[0] if len(lens_parts) == 1 else torch.cat(lens_parts)
@@ -537,6 +558,10 @@ def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=Fal
     model.eval()
     n_videos = len(val_video_dataset)
     lo, hi, _ = ddist.shard_range(n_videos, rank, world)
+    from . import ops
+    guard = eval_precision_mode(opt, test) == "throughput" and torch.device(getattr(opt, "device", "cuda")).type == "cuda"
+    if guard:
+        ops.nonfinite_flag(opt.device).zero_()
     with eval_precision(model, opt, test):
         # (the shard is a fresh Subset object every epoch: its cached features are filed under the gallery dataset itself)
         ctx = compute_context_info(model, Subset(val_video_dataset, range(lo, hi)), opt, keep_frame_feats=False,
@@ -561,6 +586,17 @@ def eval_epoch_sharded(model, val_video_dataset, val_text_dataset, opt, test=Fal
         r = torch.clamp(cnt_fn(thr).to(torch.int64) + 1, max=n_videos + 1)
         worst = (flag > 0) | (~torch.from_numpy(has).to(dev) | bad)[None, None, :]
         ranks = torch.where(worst, torch.full_like(r, n_videos + 1), r)
+    if guard and use_collectives:
+        _comm.current().all_reduce(ops.nonfinite_flag(opt.device), "max")       # every rank takes the same branch below
+    if ranks.is_cuda:
+        c = _comm.current()
+        if c is not None:
+            c.host_wait(what="eval_epoch_sharded: all-reduces of thresholds and counts")    # deadline-bounded (comm.py)
+    if guard and ops.take_nonfinite(opt.device):                                # fp16 overflow guard: see eval_epoch
+        if _fp16_overflow_policy(opt) == "raise":
+            raise RuntimeError(_OVERFLOW_TEXT)
+        logger.warning(_OVERFLOW_TEXT + ": repeating the sharded evaluation in parity mode")
+        return eval_epoch_sharded(model, val_video_dataset, val_text_dataset, _ParityOpt(opt), test)
     ranks = ranks.cpu().numpy()
     out = {}
     kinds = (("inher", 0), ("explore", 1), ("fused", 2)) if model.double_branch else (("inher", 0), ("fused", 0))
@@ -596,7 +632,7 @@ def eval_precision(model, opt, test=False):
     if mode == "parity":
         yield
         return
-    prev = (ops.gemm_precision(), model.fast_input_proj)
+    prev = (ops.precision_mode(), model.fast_input_proj)
     ops.set_gemm_precision("bf16")
     model.fast_input_proj = True
     try:
@@ -606,10 +642,57 @@ def eval_precision(model, opt, test=False):
         model.fast_input_proj = prev[1]
 
 
+def _fp16_overflow_policy(opt):
+    """opt.eval_overflow: "parity" (default) re-runs the evaluation in parity mode, "raise" raises RuntimeError."""
+    pol = getattr(opt, "eval_overflow", None) or "parity"
+    if pol not in ("parity", "raise"):
+        raise ValueError(f"eval_overflow must be 'parity' or 'raise', got {pol!r}")
+    return pol
+
+
+_OVERFLOW_TEXT = ("throughput-mode evaluation: an activation of this checkpoint overflowed the fp16 operands of the fused towers "
+                  "(|x| > 65,504: the towers' second LayerNorm met a non-finite row)")
+
+
+class _ParityOpt:
+    """`opt` with eval_precision forced to "parity" (attribute reads fall through to the caller's object)."""
+
+    def __init__(self, opt):
+        object.__setattr__(self, "_opt", opt)
+
+    def __getattr__(self, k):
+        if k == "eval_precision":
+            return "parity"
+        return getattr(object.__getattribute__(self, "_opt"), k)
+
+    def __setattr__(self, k, v):
+        setattr(object.__getattribute__(self, "_opt"), k, v)
+
+
 def eval_epoch(model, val_video_dataset, val_text_dataset, opt, test=False):
-    """SumR (R@1 + R@5 + R@10 + R@100) of the fused scores; logs the three rankings (eval.py:237-263)."""
-    with host_threads(), eval_precision(model, opt, test):
-        return _eval_epoch(model, val_video_dataset, val_text_dataset, opt, test)
+    """SumR (R@1 + R@5 + R@10 + R@100) of the fused scores; logs the three rankings (eval.py:237-263).
+
+    fp16 overflow guard (throughput mode): the fused towers raise a device flag when a valid row turns non-finite (an activation
+    beyond fp16's 65,504: ops.nonfinite_flag); it is read here, after the epoch's results (no extra synchronisation on the normal
+    path), and the evaluation is repeated in parity mode - or RuntimeError with opt.eval_overflow = "raise" - instead of ranking
+    NaN scores last in silence (the reference's fp32 path has no such cliff: model_components.py:305-312,398-436)."""
+    from . import ops
+    with host_threads():
+        mode = eval_precision_mode(opt, test)
+        dev = torch.device(getattr(opt, "device", "cuda"))
+        guard = mode == "throughput" and dev.type == "cuda"
+        if guard:
+            ops.nonfinite_flag(dev).zero_()
+        with eval_precision(model, opt, test):
+            res = _eval_epoch(model, val_video_dataset, val_text_dataset, opt, test)
+        if guard and ops.take_nonfinite(dev):
+            if _fp16_overflow_policy(opt) == "raise":
+                raise RuntimeError(_OVERFLOW_TEXT)
+            logger.warning(_OVERFLOW_TEXT + ": repeating the evaluation in parity mode")
+            popt = _ParityOpt(opt)
+            with eval_precision(model, popt, test):
+                res = _eval_epoch(model, val_video_dataset, val_text_dataset, popt, test)
+        return res
 
 
 def rank_queries(model, eval_dataset, opt, ctx_info, w=(0.7, 0.3)):

@@ -80,6 +80,7 @@ class _Linear(Function):
         return y
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         K, N = w.shape[1], w.shape[0]
@@ -119,6 +120,7 @@ class _LayerNorm(Function):
         return ops.layernorm(x, gamma, beta, add=add, add_mod=add_mod)
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, dy):
         x, gamma, add = ctx.saved_tensors
         D = x.shape[-1]
@@ -171,6 +173,7 @@ class _LayerNormDropout(Function):
         return out.view(x.shape)
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, dy):
         return _LayerNorm.backward(ctx, dy) + (None,)
 
@@ -272,6 +275,7 @@ class _InProjTrain(Function):
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, dy):
         x2, w, z, y, keep, stats, gflags, gamma, beta = ctx.saved_tensors
         N, K = w.shape
@@ -325,7 +329,7 @@ class _InProjTrain(Function):
             tiles = (M + 127) // 128
             ws = torch.empty(2 * tiles * K, dtype=torch.float32, device=x2.device)
             dgb = _zeros((2, K), x2.device)
-            native.check(_L().dldkd_linear_lngrad(ops._PREC_ID[ctx.prec], _p(dy2), _p(w), _p(x2), _p(keep), ctx.keep_scale, _p(stats[0]), _p(stats[1]),
+            native.check(_L().dldkd_linear_lngrad(ops._PREC_ID[ops.gemm_precision()], _p(dy2), _p(w), _p(x2), _p(keep), ctx.keep_scale, _p(stats[0]), _p(stats[1]),
                                                        _p(ws), ws.numel() * 4, _p(dgb[0]), _p(dgb[1]), M, N, K, _p(gflags), _s()), "linear_lngrad")
             dg, dbeta = dgb[0], dgb[1]
         return None, dg, dbeta, dw, db, None, None, None, None
@@ -429,6 +433,7 @@ class _Dropout(Function):
         return out
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, dy):
         (keep,) = ctx.saved_tensors
         dy = _f32(dy)
@@ -463,6 +468,7 @@ class _AttentionTrain(Function):
         return out
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, dout):
         qkv, P = ctx.saved_tensors
         p_drop, seed, off, state, _keep_alive = ctx.rng
@@ -490,6 +496,7 @@ class _AttentionTrainBf16(Function):
         return out
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, dout):
         qkv, mask = ctx.saved_tensors
         p_drop, seed, off, state, _keep_alive = ctx.rng
@@ -653,6 +660,7 @@ class _TowerTrain(Function):
         return out
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, dout):
         xh1, pos, g1, g2, mask, lens, flags, h1d, stats, qkv, ctxl, xh2, rstd2, h2, pk_ot, pk_dt, pk_qkvt = ctx.saved_tensors
         video, p_in, p_attn, p_hid, sa, sb, sc, relu_mask, _keep = ctx.cfg
@@ -738,6 +746,7 @@ class _ModPool(Function):
         return out
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, dout):
         h, mask, w, attn = ctx.saved_tensors
         dout = _f32(dout)
@@ -767,6 +776,7 @@ class _Normalize(Function):
         return y
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, dy):
         y, inv = ctx.saved_tensors
         D = y.shape[-1]
@@ -791,6 +801,7 @@ class _ClipScores(Function):
         return ops.linear(q, g.reshape(Nv * L, D)).view(q.shape[0], Nv, L)
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, dS):
         q, g = ctx.saved_tensors
         Nv, L, D = g.shape
@@ -821,6 +832,7 @@ class _ClipPool(Function):
         return pooled, Sm, arg
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, dpooled, dSm, _darg):
         arg, lens = ctx.saved_tensors
         Nq, Nv, L = ctx.shape
@@ -877,6 +889,7 @@ class _SimPoolTrain(Function):
         return pc, pr, ac, ar, clip
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, d_cos, d_raw, _dac, _dar, d_clip=None):
         q, g, rq, rg, lens, labels, ac, ar, pc, clip = ctx.saved_tensors
         Nq, D = q.shape
@@ -922,6 +935,7 @@ class _SumScalars(Function):
         return out
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, g):
         return (g,) * ctx.n
 
@@ -954,6 +968,7 @@ class _KLFrame(Function):
         return _sum(out)
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, g):
         Sp, St, labels, lens = ctx.saved_tensors
         Nq, Nv, L = Sp.shape if Sp.dim() == 3 else (Sp.shape[0], 0, Sp.shape[1])
@@ -980,6 +995,7 @@ class _NCE(Function):
         return _sum(terms)
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, g):
         S, T, labels, cq, cv = ctx.saved_tensors
         hardQ, hardV, beta, eps, t_is_s = ctx.cfg
@@ -1087,6 +1103,7 @@ class _BranchLoss(Function):
         return out[0], out[1], out[2]
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, g_trip, g_nce, g_kl):
         dC, dS, dclip = ctx.saved_tensors
         if (g_trip is not None and g_nce is not None and _is_unit(g_trip) and _is_unit(g_nce)
@@ -1145,6 +1162,7 @@ class _Triplet(Function):
         return _sum(terms)
 
     @staticmethod
+    @ops.in_backward
     def backward(ctx, g):
         C, labels, r_t2v, r_v2t = ctx.saved_tensors
         hard, margin = ctx.cfg

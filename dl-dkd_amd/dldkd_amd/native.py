@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdldkd_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -208,9 +208,9 @@ SIGNATURES = {
     "dldkd_tower_blob_bytes": (_c_size_t, [_c_int]),
     "dldkd_tower_pack_h16": (_c_int, [_c_void_p] * 16 + [_c_int, _c_void_p, _c_void_p]),
     "dldkd_tower_seq_h16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
-                                      _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
+                                      _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_tower_seq_h16_rows16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
-                                          _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
+                                          _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_debug_tower_seq_timeline": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                                 _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p]),
     "dldkd_gemm_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

@@ -145,6 +145,7 @@ def train_step(model, batch, optimizer, opt, comm_stream=None):
         backward_in_phases(loss, phases, after_phase=sync.bucket_ready)
         sync.finish()
         if "loss_overall" not in loss_dict:
+            ddist._c(None).host_wait(what="training step (bucketed all-reduce) before float(loss)")
             loss_dict = {"loss_overall": float(loss.detach()), **loss_dict}
     else:
         loss, loss_dict = model(batch)
@@ -156,6 +157,11 @@ def train_step(model, batch, optimizer, opt, comm_stream=None):
         torch.nn.utils.clip_grad_norm_(model.parameters(), opt.grad_clip)
     optimizer.step()
     _end_zero_arena()
+    if ddp:
+        # the eager step reads float(loss) inside the forward pass, i.e. behind the PREVIOUS step's all-reduce: wait for this
+        # step's collective here, against the deadline (comm.host_wait), so that the next blocking read cannot hang on a dead peer
+        from . import dist as ddist
+        ddist._c(None).host_wait(what="eager data-parallel training step")
     return loss, loss_dict
 
 
@@ -209,6 +215,8 @@ class GraphedTrainStep:
     GATHER_WITH_NORMS = True        # one GPU: a tower's gather also accumulates the clip's sums of squares (see _capture_parallel)
     UNIT_BRANCH_GRADS = True        # the branch graphs pass the constant 1 as the terms' upstream gradient (see branch_runner)
     TENSOR_KEYS = ("student_videos", "student_videos_mask", "teacher_videos", "student_text", "student_text_mask", "teacher_text")
+
+    WATCH_EVERY = 32       # deferred-loss data-parallel replays between two progress markers (comm.watch)
 
     def __init__(self, model, optimizer, opt, max_graphs=8, defer_loss_float=False, max_captures=24):
         self.model, self.optimizer, self.opt = model, optimizer, opt
@@ -775,6 +783,15 @@ class GraphedTrainStep:
         _end_zero_arena()
         self.replays += 1
         out = dict(e.parts)
+        if e.ddp:
+            # the host's blocking read of a data-parallel step is deadline-bounded (comm.host_wait: a dead peer parks the stream in
+            # the all-reduce for ever); a loop that never reads the loss back leaves a progress marker every WATCH_EVERY replays
+            from . import dist as ddist
+            c = ddist._c(None)
+            if not self.defer:
+                c.host_wait(self.stream, what="replayed data-parallel training step")
+            elif self.replays % self.WATCH_EVERY == 0:
+                c.watch(self.stream, what=f"replayed data-parallel training steps (marker every {self.WATCH_EVERY})")
         loss_overall = e.loss if self.defer else float(e.loss)
         return e.loss, {"loss_overall": loss_overall, **out}
 
@@ -852,6 +869,9 @@ def _train_epoch(model, train_loader, optimizer, opt, epoch_i, training=True, st
             break
     if acc is None:
         return {}
+    if acc.is_cuda and dist_info()[1] > 1:
+        from . import comm as _comm_mod
+        _comm_mod.current().host_wait(what="end of a data-parallel training epoch (loss sums read-back)")
     return {k: float(v) / max(n, 1) for k, v in zip(keys, acc.cpu().tolist())}
 
 

@@ -781,7 +781,12 @@ int dldkd_count_above_f32(const float* scores, const float* thr, int nq, int nv,
  *     rows past the length inside the last 16-row tile replicate the last clip, further rows zero); sequence s is video v0 + s;
  *     lens_out (whole gallery, or NULL) receives lens.  Lp a multiple of 32.
  *   out_mode 2 (query-tower blobs): out_rows[b] (n_seq, 384) fp32 = the modular query vectors; 1 <= lens[s] <= 32 (a sequence
- *     with lens < 1 gives a zero vector). */
+ *     with lens < 1 gives a zero vector).
+ *   nonfinite_flag (one device int32 the caller zeroed, or NULL; out_mode 0 / 1 - a non-finite query vector of out_mode 2 is
+ *     flagged by dldkd_pack_queries_bf16's bad_flags): set to 1 when the second LayerNorm of a VALID row meets a mean that is not finite.  The operands of this kernel and of K4 / K4b are IEEE fp16 (65,504 max): an activation of an
+ *     arbitrary checkpoint that overflows it (h0 = ReLU(W LN(x) + b), q | k | v, the context - none of them LayerNorm outputs)
+ *     turns into Inf, then NaN, and every such row passes through this LayerNorm; the host reads the flag with the epoch's results
+ *     and re-runs in parity mode (dldkd_amd.eval) instead of ranking NaN scores last in silence.  One compare per 32-row tile. */
 size_t dldkd_tower_blob_bytes(int with_out_map);
 int dldkd_tower_pack_h16(const float* ln1_g, const float* ln1_b, const float* wq, const float* bq, const float* wk, const float* bk,
                           const float* wv, const float* bv, const float* wd, const float* bd, const float* ln2_g, const float* ln2_b,
@@ -789,12 +794,12 @@ int dldkd_tower_pack_h16(const float* ln1_g, const float* ln1_b, const float* wq
 int dldkd_tower_seq_h16(const float* const* h0, const void* const* blob, const int32_t* row0,
                          const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
                          int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
-                         void* stream);
+                         int32_t* nonfinite_flag, void* stream);
 /* out_mode 1 from h16 h0 rows (dldkd_in_proj_h16_rows128b_out16; ragged: row0 required): the prologue is one round of
  * 16-byte loads straight into the operand registers (no LDS staging); everything else as above. */
 int dldkd_tower_seq_h16_rows16(const void* const* h0_h16, const void* const* blob, const int32_t* row0,
                              const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
-                             void* const* gallery, int v0, int Lp, int32_t* lens_out, void* stream);
+                             void* const* gallery, int v0, int Lp, int32_t* lens_out, int32_t* nonfinite_flag, void* stream);
 
 /* Diagnostics: the out_mode 1 kernel (two branches) with clock stamps at its phase boundaries; stamps = 24 x uint64 per workgroup
  * (h16 != 0: h0 holds h16 rows, the dldkd_tower_seq_h16_rows16 kernel)

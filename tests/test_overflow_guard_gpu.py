@@ -1,0 +1,92 @@
+"""fp16 overflow guard of the eval-path towers.  The throughput mode of eval_epoch runs K4 / K4b / K5 on IEEE fp16
+operands (65,504 max); h0 = ReLU(W LN(x) + b) and q | k | v are not LayerNorm outputs and are unbounded for an arbitrary checkpoint.
+A checkpoint whose input projection (or q | k | v) is scaled until the fp32 activations pass 7e4 stays finite in the fp32 oracle
+(the following LayerNorm / softmax is scale-free); the throughput mode must then either land on the oracle's R@K (it re-runs in
+parity mode) or raise - never rank NaN scores last in silence.  Reference: method/model_components.py:305-312,398-436."""
+import logging
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import dldkd_oracle as orc
+import synth
+from test_encoder_gpu import _model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _opt(**kw):
+    return types.SimpleNamespace(eval_context_bsz=25, eval_query_bsz=50, num_workers=0, pin_memory=False, device=torch.device(DEV),
+                                 double_branch=True, **kw)
+
+
+def _oracle_sumr(params, vids, txts):
+    """The oracle's eval_epoch from RAW features (fp32 CPU towers + scoring + ranking) on the same datasets."""
+    L = max(v[0].shape[0] for v in vids)
+    feat = torch.zeros(len(vids), L, vids[0][0].shape[1])
+    mask = torch.zeros(len(vids), L)
+    for i, (f, _, _) in enumerate(vids):
+        feat[i, :f.shape[0]], mask[i, :f.shape[0]] = f, 1.0
+    g_inh, g_exp = orc.encode_context(params, feat, mask)
+    Lq = max(t[0].shape[0] for t in txts)
+    qf = torch.zeros(len(txts), Lq, txts[0][0].shape[1])
+    qm = torch.zeros(len(txts), Lq)
+    for i, (f, _, _) in enumerate(txts):
+        qf[i, :f.shape[0]], qm[i, :f.shape[0]] = f, 1.0
+    q_inh, q_exp = orc.encode_query(params, qf, qm)
+    inh, exp = orc.eval_scores(q_inh, q_exp, g_inh, g_exp, mask)
+    assert torch.isfinite(inh).all() and torch.isfinite(exp).all()          # fp32 has no cliff here
+    met = orc.eval_metrics(inh.numpy(), exp.numpy(), [v[2] for v in vids], [t[2] for t in txts])
+    return met["sumr"], met["fused"][:4]
+
+
+def _scaled(params, which):
+    p = {k: v.clone() for k, v in params.items()}
+    if which == "input_proj":                       # h0 = ReLU(W LN(x) + b): |W LN(x)| ~ 1.1 per unit of scale
+        for pre in ("", "exp_"):
+            p[pre + "visual_input_proj.net.1.weight"] *= 2.0e5
+            p[pre + "visual_input_proj.net.1.bias"] *= 2.0e5
+    elif which == "qkv":                            # q = Wq h1 + bq with h1 a LayerNorm output: |q| ~ 2 per unit of scale.  The keys are
+        for pre in ("", "exp_"):                    # scaled DOWN by the same factor: q . k - the attention - is what it was, only q
+            p[pre + "visual_encoder.self.query.weight"] *= 3.0e5          # itself no longer fits fp16
+            p[pre + "visual_encoder.self.query.bias"] *= 3.0e5
+            p[pre + "visual_encoder.self.key.weight"] /= 3.0e5
+            p[pre + "visual_encoder.self.key.bias"] /= 3.0e5
+    return p
+
+
+@pytest.mark.parametrize("which", ["input_proj", "qkv"])
+def test_throughput_eval_of_an_overflowing_checkpoint_matches_the_oracle_or_raises(which, caplog):
+    from dldkd_amd import eval as ev, ops
+    params = _scaled(synth.make_params(51, 3072, 768), which)
+    vids, txts = synth.make_eval_sets(5, nv=64, caps=3, dv=3072, dq=768)
+    ref_sumr, ref_r = _oracle_sumr(params, vids, txts)
+    m = _model(3072, 768, params)
+    vd, td = synth.ListDataset(list(vids)), synth.ListDataset(list(txts))
+    with torch.no_grad():
+        # (1) default policy: the guard notices, eval_epoch repeats in parity mode and lands on the oracle (one of 192 queries = 0.52)
+        with caplog.at_level(logging.WARNING):
+            sumr = ev.eval_epoch(m, vd, td, _opt(eval_precision="throughput", eval_feature_cache=False))
+        assert any("overflowed the fp16 operands" in r.getMessage() for r in caplog.records), "the guard did not fire"
+        assert np.isfinite(sumr) and abs(sumr - ref_sumr) <= 1.6, (sumr, ref_sumr, ref_r)
+        # (2) eval_overflow="raise": a RuntimeError, and the caller's precision is restored
+        with pytest.raises(RuntimeError, match="overflowed the fp16 operands"):
+            ev.eval_epoch(m, vd, td, _opt(eval_precision="throughput", eval_overflow="raise", eval_feature_cache=False))
+        assert ops.precision_mode() == "fp32"
+        assert not ops.take_nonfinite(DEV)                                   # the flag was consumed
+
+
+def test_the_guard_stays_silent_on_an_ordinary_checkpoint(caplog):
+    from dldkd_amd import eval as ev, ops
+    params = synth.make_params(51, 3072, 768)
+    vids, txts = synth.make_eval_sets(5, nv=64, caps=3, dv=3072, dq=768)
+    ref_sumr, _ = _oracle_sumr(params, vids, txts)
+    m = _model(3072, 768, params)
+    with torch.no_grad(), caplog.at_level(logging.WARNING):
+        sumr = ev.eval_epoch(m, synth.ListDataset(list(vids)), synth.ListDataset(list(txts)),
+                             _opt(eval_precision="throughput", eval_overflow="raise"))
+    assert not any("overflowed" in r.getMessage() for r in caplog.records)
+    assert abs(sumr - ref_sumr) <= 1.6 and not ops.take_nonfinite(DEV)

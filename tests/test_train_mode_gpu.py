@@ -97,6 +97,10 @@ def _grad_stats(model, ref_grads):
     return out
 
 
+GRAD_TOL_BF16 = 0.25      # worst tensor's relative l2 error, throughput mode (measured 0.13)
+GRAD_TOL_MIXED = 0.25     # fp32-grade forward + bf16 backward
+
+
 def _assert_grads(stats, rel_tol, what, cos_min=None):
     worst = max(stats.items(), key=lambda kv: kv[1][0])
     print(f"  {what}: worst gradient rel l2 error {worst[1][0]:.3e} ({worst[0]}), median "
@@ -217,7 +221,7 @@ def _oracle_trajectory(name):
     return _ORACLE_CACHE[name]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "mixed"])
 @pytest.mark.parametrize("name", ["c3", "c5"])
 def test_train_step_at_full_size_train_mode_vs_oracle(monkeypatch, name, prec):
     """BASELINE configs[2] / configs[4] size, model.train(), dropout 0: the 7 losses AND all 74 gradients of the train-mode path
@@ -242,19 +246,26 @@ def test_train_step_at_full_size_train_mode_vs_oracle(monkeypatch, name, prec):
         ops.set_gemm_precision("fp32")
     L = batch["student_videos"].shape[1]
     skipped, groups = log.assert_skipped(batch["student_videos_mask"].sum(1).long().numpy(), L)
-    tol = 1e-4 if prec == "fp32" else 2e-2
+    # "mixed" (fp32-grade forward, bf16 backward): the LOSSES are the parity mode's - north_star's 1e-4 - the gradients bf16-grade
+    exact_fwd = prec in ("fp32", "mixed")
+    tol = 1e-4 if exact_fwd else 2e-2
+    worst_loss = 0.0
     for k in LOSS_KEYS + ("loss",):
         got = float(loss if k == "loss" else d[k])
-        assert abs(got - ref[k]) <= tol * max(abs(ref[k]), 1e-3 if prec == "fp32" else 0.1), (k, got, ref[k])
+        worst_loss = max(worst_loss, abs(got - ref[k]) / max(abs(ref[k]), 1e-3 if exact_fwd else 0.1))
+        assert abs(got - ref[k]) <= tol * max(abs(ref[k]), 1e-3 if exact_fwd else 0.1), (k, got, ref[k])
+    print(f"  {name} {prec}: worst loss error {worst_loss:.3e} (relative)")
     stats = _grad_stats(m, ref_grads)
     if prec == "fp32":
         _assert_grads(stats, 1e-3, f"{name} parity ({skipped}/{groups} groups skipped)")
+    elif prec == "mixed":
+        _assert_grads(stats, GRAD_TOL_MIXED, f"{name} mixed ({skipped}/{groups} groups skipped)", cos_min=0.97)
     else:
-        _assert_grads(stats, 0.25, f"{name} bf16 ({skipped}/{groups} groups skipped)", cos_min=0.97)
+        _assert_grads(stats, GRAD_TOL_BF16, f"{name} bf16 ({skipped}/{groups} groups skipped)", cos_min=0.97)
 
 
 # --------------------------------------------------------------------------- the replayed multi-graph step + fused BertAdam
-@pytest.mark.parametrize("name,prec", [("c5", "fp32"), ("c5", "bf16"), ("c3", "fp32"), ("c3", "bf16")])
+@pytest.mark.parametrize("name,prec", [("c5", "fp32"), ("c5", "bf16"), ("c3", "fp32"), ("c3", "bf16"), ("c5", "mixed"), ("c3", "mixed")])
 def test_replayed_multi_graph_step_and_bert_adam_vs_oracle(name, prec):
     """What train() runs: train.GraphedTrainStep with the towers as parallel graphs (one GPU) + the fused BertAdam update, three
     steps on one batch (step 0 eager, step 1 captured and replayed, step 2 replayed), model.train(), dropout 0.  Every step's 7
@@ -273,14 +284,16 @@ def test_replayed_multi_graph_step_and_bert_adam_vs_oracle(name, prec):
     try:
         optim = T.make_optimizer(m, topt, spe)
         stepper = T.GraphedTrainStep(m, optim, topt)
-        tol = 1e-4 if prec == "fp32" else 2e-2
-        for step in range(n_steps):
+        tol = 1e-4 if prec == "fp32" else 2e-2       # ("mixed": step 0's losses are parity-grade; later steps run on parameters
+        for step in range(n_steps):                   #  moved by bf16-grade gradients: gated like the throughput mode there)
             torch.manual_seed(SEED0 + step)
             loss, d = stepper(dbatch)
             for k in LOSS_KEYS + ("loss",):
                 got = float(loss if k == "loss" else d[k])
                 ref = ref_losses[step][k]
                 # the oracle's parameters drift from ours by the steps' rounding: the later steps get twice the tolerance
+                if prec == "mixed" and step == 0:
+                    assert abs(got - ref) <= 1e-4 * max(abs(ref), 1e-3), (step, k, got, ref)
                 assert abs(got - ref) <= (1 if step < 2 else 2) * tol * max(abs(ref), 1e-3 if prec == "fp32" else 0.1), (step, k, got, ref)
         torch.cuda.synchronize()
     finally:
