@@ -211,10 +211,11 @@ def extras(dev):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_train
         for cfgname, key in (("c3", "c3"), ("c5", "c5")):
-            for prec in ("fp32", "bf16"):
-                r = bench_train.run(cfgname, prec, 0.2 if cfgname == "c3" else 0.15, steps=30, warmup=10, dev=str(dev))
+            for prec in ("fp32", "bf16", "mixed"):
+                r = bench_train.run(cfgname, prec, 0.2 if cfgname == "c3" else 0.15, steps=30, warmup=10, dev=str(dev),
+                                    modes=("graph",) if prec == "mixed" else ("eager", "graph"))
                 out[f"{key}_train_step_{prec}"] = r
-                out[f"{key}_train_step_ms" + ("_bf16" if prec == "bf16" else "") if key == "c3" else f"c5_train_step_ms_{prec}"] = \
+                out[f"{key}_train_step_ms" + ("" if prec == "fp32" else f"_{prec}") if key == "c3" else f"c5_train_step_ms_{prec}"] = \
                     r["graph"]["stream_ms_median"]
                 # what train.train() runs: the loss stays on the device (one read-back per epoch), the host runs ahead of the GPU
                 out[f"{key}_train_step_ms_{prec}_deferred_loss"] = r["graph_no_loss_sync"]["stream_ms_median"]
@@ -224,7 +225,8 @@ def extras(dev):
         out["c3_train_step_config"] = "TVR: 128 videos / 640 queries, L<=128, label_style=soft, hard negatives, dropout 0.2, " \
                                       "zero_grad + forward + backward + fused BertAdam; fp32 = parity mode (fp32-grade GEMMs: three bf16 " \
                                       "planes per operand, losses within 1e-4 of the reference), bf16 = every GEMM on bf16 MFMA with fp32 " \
-                                      "accumulation (fp32 master weights / activations, losses 2e-2); *_ms = hipGraph-replayed step, median"
+                                      "accumulation (fp32 master weights / activations, losses 2e-2), mixed = fp32-grade forward on two bf16 planes per operand " \
+                                      "+ the fused bf16 backward (losses within 1e-6 of the reference's, gradients ~1e-2); *_ms = hipGraph-replayed step, median"
         out["c5_train_step_config"] = "Charades rank-local step: 128 videos / 257 queries, L<=64, Dv=Dq=1024, dropout 0.15 " \
                                       "(the gradient all-reduce of the 17.5 MB flat bucket is not part of a 1-GPU run)"
         torch.manual_seed(0)

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if (stats != nullptr && lane == 0) { stats[row] = 0.f; stats[M + row] = 0.f; }
             for (int c = lane; c < nv; c += 64) {
                 if (out16 != nullptr) reinterpret_cast<uint2*>(out16 + row * D)[c] = uint2{0u, 0u};
-                else reinterpret_cast<f32x4*>(out + row * D)[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (out != nullptr) reinterpret_cast<f32x4*>(out + row * D)[c] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (keep != nullptr) reinterpret_cast<uchar4*>(keep + row * D)[c] = uchar4{0, 0, 0, 0};
             }
             return;
@@ -110,8 +110,99 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 pk.x = (unsigned)f32_to_bf16_bits(o[0]) | ((unsigned)f32_to_bf16_bits(o[1]) << 16);
                 pk.y = (unsigned)f32_to_bf16_bits(o[2]) | ((unsigned)f32_to_bf16_bits(o[3]) << 16);
                 orow16[c] = pk;
-            } else {
-                orow[c] = o;
+            }
+            if (out != nullptr) orow[c] = o;           // (both: "mixed" training keeps fp32 rows for its forward GEMM and bf16 rows for the backward)
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// The LayerNorm (+ inverted dropout) of BOTH branches' input projections over the SAME raw rows in one pass (round 6): the two
+// video towers of the training step normalise the same (Nv, L, Dv) student features with their own gamma / beta and their own
+// dropout draws (method/model.py:229-243 -> LinearLayer.forward, model_components.py:305-310, once per branch).  Two launches of
+// layernorm_kernel on two streams read the 201-MB TVR batch twice, beside each other: 204 + 206 us against 87 alone
+// (profiles/r05/step_timeline_bf16_graph.txt).  Here a row is read once, its mean / rstd taken once, and written twice as bf16
+// rows; masks = what two dldkd_layernorm_dropout_bf16 calls at (seed, off0) and (seed, off1) draw, bit for bit.
+// ----------------------------------------------------------------------------------------------
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_dual_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gamma0,
+                                                                  const float* __restrict__ beta0, const float* __restrict__ gamma1,
+                                                                  const float* __restrict__ beta1, unsigned short* __restrict__ out0,
+                                                                  unsigned short* __restrict__ out1, float* __restrict__ stats, long M,
+                                                                  int D, float eps, unsigned thresh, float dscale, unsigned long long seed,
+                                                                  unsigned long long off0, unsigned long long off1,
+                                                                  const unsigned long long* __restrict__ state,
+                                                                  const float* __restrict__ row_mask, unsigned char* __restrict__ gflags) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bool drop = thresh != 0u;
+    if (drop && state != nullptr) { seed = state[0]; off0 += state[1]; off1 += state[1]; }
+    const int nv = D >> 2;
+    if (row_mask != nullptr) {
+        const bool valid = row_mask[row] > 0.f;
+        if (gflags != nullptr && (row & 31) == 0) {
+            const bool any = __ballot(lane < 32 && row_mask[row + (lane & 31)] > 0.f) != 0ull;
+            if (lane == 0) gflags[row >> 5] = any ? 1 : 0;
+        }
+        if (!valid) {
+            if (lane == 0) { stats[row] = 0.f; stats[M + row] = 0.f; }
+            for (int c = lane; c < nv; c += 64) {
+                reinterpret_cast<uint2*>(out0 + row * D)[c] = uint2{0u, 0u};
+                reinterpret_cast<uint2*>(out1 + row * D)[c] = uint2{0u, 0u};
+            }
+            return;
+        }
+    }
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            v[i] = xr[c];
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) { stats[row] = mean; stats[M + row] = rstd; }
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+        const f32x4* g4 = reinterpret_cast<const f32x4*>(br ? gamma1 : gamma0);
+        const f32x4* b4 = reinterpret_cast<const f32x4*>(br ? beta1 : beta0);
+        uint2* orow16 = reinterpret_cast<uint2*>((br ? out1 : out0) + row * D);
+        const unsigned long long off = br ? off1 : off0;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const f32x4 g = g4[c], b = b4[c];
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+                if (drop) {
+                    const unsigned long long ctr = off + (unsigned long long)(row * nv + c);
+                    unsigned rnd[4];
+                    philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), rnd);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rnd[e] >= thresh ? o[e] * dscale : 0.f;
+                }
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16_bits(o[0]) | ((unsigned)f32_to_bf16_bits(o[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16_bits(o[2]) | ((unsigned)f32_to_bf16_bits(o[3]) << 16);
+                orow16[c] = pk;
             }
         }
     }
@@ -399,6 +490,50 @@ int dldkd_layernorm_dropout_bf16(const float* x, const float* gamma, const float
     if (group_flags && (!row_mask || (M & 31))) { set_error("layernorm_dropout_bf16: group flags need a row mask and M %% 32 == 0"); return DLDKD_EINVAL; }
     return launch_layernorm(x, nullptr, 0, gamma, beta, nullptr, M, D, eps, p_drop > 0.f ? keep : nullptr, p_drop, seed, offset, state, stream,
                             (unsigned short*)out_bf16, stats, row_mask, group_flags);
+}
+
+int dldkd_layernorm_dropout_bf16_dual(const float* x, const float* gamma0, const float* beta0, const float* gamma1, const float* beta1,
+                                      void* out0_bf16, void* out1_bf16, float* stats, long M, int D, float eps, float p_drop,
+                                      unsigned long long seed, unsigned long long offset0, unsigned long long offset1,
+                                      const unsigned long long* state, const float* row_mask, unsigned char* group_flags, void* stream) {
+    if (M < 0 || D < 4 || (D & 3) || D > 4096 || !(p_drop >= 0.f && p_drop < 1.f)) {
+        set_error("layernorm_dropout_bf16_dual: bad sizes M=%ld D=%d (D must be a multiple of 4, <= 4096) or p=%f", M, D, (double)p_drop);
+        return DLDKD_EINVAL;
+    }
+    if (M == 0) return DLDKD_OK;
+    if (!x || !gamma0 || !beta0 || !gamma1 || !beta1 || !out0_bf16 || !out1_bf16 || !stats || (((uintptr_t)out0_bf16 | (uintptr_t)out1_bf16) & 7)) {
+        set_error("layernorm_dropout_bf16_dual: null pointer or unaligned output");
+        return DLDKD_EINVAL;
+    }
+    if (group_flags && (!row_mask || (M & 31))) { set_error("layernorm_dropout_bf16_dual: group flags need a row mask and M %% 32 == 0"); return DLDKD_EINVAL; }
+    const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int nv = (D / 4 + 63) / 64;
+    const double t = (double)p_drop * 4294967296.0;
+    const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    const float ds = 1.0f / (1.0f - p_drop);
+    unsigned short *o0 = (unsigned short*)out0_bf16, *o1 = (unsigned short*)out1_bf16;
+    if (nv <= 4) DLDKD_LAUNCH(layernorm_dual_bf16_kernel<4>, grid, block, 0, s, x, gamma0, beta0, gamma1, beta1, o0, o1, stats, M, D, eps, thresh, ds, seed, offset0, offset1, state, row_mask, group_flags);
+    else if (nv <= 8) DLDKD_LAUNCH(layernorm_dual_bf16_kernel<8>, grid, block, 0, s, x, gamma0, beta0, gamma1, beta1, o0, o1, stats, M, D, eps, thresh, ds, seed, offset0, offset1, state, row_mask, group_flags);
+    else if (nv <= 12) DLDKD_LAUNCH(layernorm_dual_bf16_kernel<12>, grid, block, 0, s, x, gamma0, beta0, gamma1, beta1, o0, o1, stats, M, D, eps, thresh, ds, seed, offset0, offset1, state, row_mask, group_flags);
+    else DLDKD_LAUNCH(layernorm_dual_bf16_kernel<16>, grid, block, 0, s, x, gamma0, beta0, gamma1, beta1, o0, o1, stats, M, D, eps, thresh, ds, seed, offset0, offset1, state, row_mask, group_flags);
+    return check_launch("layernorm_dropout_bf16_dual");
+}
+
+int dldkd_layernorm_ex_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out_f32,
+                           void* out_bf16, unsigned char* keep, float* stats, long M, int D, float eps, float p_drop,
+                           unsigned long long seed, unsigned long long offset, const unsigned long long* state, const float* row_mask,
+                           unsigned char* group_flags_out, const unsigned char* group_flags_in, void* stream) {
+    if ((!out_f32 && !out_bf16) || ((uintptr_t)out_bf16 & 7) || ((uintptr_t)keep & 3)) {
+        set_error("layernorm_ex: no output, or an unaligned bf16 output / keep mask");
+        return DLDKD_EINVAL;
+    }
+    if ((group_flags_out && (!row_mask || (M & 31))) || (group_flags_in && ((M & 31) || row_mask))) {
+        set_error("layernorm_ex: group flags out need a row mask, group flags in exclude one, both need M %% 32 == 0");
+        return DLDKD_EINVAL;
+    }
+    return launch_layernorm(x, add, add_mod, gamma, beta, out_f32, M, D, eps, p_drop > 0.f ? keep : nullptr, p_drop, seed, offset, state, stream,
+                            (unsigned short*)out_bf16, stats, row_mask, group_flags_out, group_flags_in);
 }
 
 int dldkd_attention_fwd_f32(const float* qkv, const float* mask, float* out, int N, int L, void* stream) {

@@ -102,7 +102,8 @@ struct TileX {
             for (int i = 0; i < XKPT; ++i) r[i] = src[(size_t)i * ld];
         }
     }
-    // registers -> three bf16 planes in LDS ([plane][row][k])
+    // registers -> three (NPL = 2: two) bf16 planes in LDS ([plane][row][k])
+    template <int NPL = 3>
     static __device__ __forceinline__ void store(unsigned short* __restrict__ S, int tid, const float (&r)[XNREG]) {
         if constexpr (!KMAJOR) {
 #pragma unroll
@@ -113,7 +114,7 @@ struct TileX {
                 unsigned short* dst = S + (tid / XKV + XRPP * j) * XPITCH + (tid % XKV) * 4;
                 *reinterpret_cast<uint2*>(dst) = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
                 *reinterpret_cast<uint2*>(dst + XPLANE) = uint2{(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
-                *reinterpret_cast<uint2*>(dst + 2 * XPLANE) = uint2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+                if constexpr (NPL == 3) *reinterpret_cast<uint2*>(dst + 2 * XPLANE) = uint2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
             }
         } else {
             unsigned short h[8], m[8], l[8];
@@ -126,15 +127,18 @@ struct TileX {
             };
             *reinterpret_cast<uint4*>(dst) = pk(h);
             *reinterpret_cast<uint4*>(dst + XPLANE) = pk(m);
-            *reinterpret_cast<uint4*>(dst + 2 * XPLANE) = pk(l);
+            if constexpr (NPL == 3) *reinterpret_cast<uint4*>(dst + 2 * XPLANE) = pk(l);
         }
     }
 };
 
 // EPI: 0 = store C, 1 = training simpool max-pool (PoolArgs), 2 = LayerNorm parameter gradients (LnGradArgs)
-template <bool A_KMAJOR, bool B_KMAJOR, int EPI, typename EArgs>
+// NPL = 2 ("fp32x2", the forward pass of the "mixed" training precision): two planes per operand, x ~= h + m (16 mantissa bits,
+// residual <= 2^-17 |x|), products a_h b_h + a_h b_m + a_m b_h (dropped: a_m b_m <= 2^-16 |ab|): three MFMAs instead of six, error
+// ~2^-16 per product against the three-plane scheme's 2^-24 - measured on the step's seven losses: tests/test_train_mode_gpu.py.
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, typename EArgs, int NPL = 3>
 __device__ __forceinline__ void gemm_f32x3_body(GemmXArgs p, const EArgs* pa) {
-    __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][3 * XPLANE];   // [stage][A|B][plane][row][k]: 72 KiB
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][3 * XPLANE];   // [stage][A|B][plane][row][k]: 72 KiB (the epilogues stage through all of it)
     const Tile3 bid = xcd_tile_order();              // column tiles of a row block (split-K: row tiles of a B slab) behind one L2: gemm_bf16.hip
     if (p.split_k > 1) {
         p.C += (size_t)bid.z * p.M * p.ldc;      // this split's partial plane in the workspace
@@ -211,7 +215,7 @@ __device__ __forceinline__ void gemm_f32x3_body(GemmXArgs p, const EArgs* pa) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl = 0; pl < NPL; ++pl) {
                     if (rt_ok[i]) a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * XPLANE + 32 * i * XPITCH);
                     b[i][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * XPLANE + 32 * i * XPITCH);
                 }
@@ -223,25 +227,27 @@ __device__ __forceinline__ void gemm_f32x3_body(GemmXArgs p, const EArgs* pa) {
             for (int j = 0; j < 2; ++j) {
                 if (!this_ok || !rt_ok[i]) continue;
                 f32x16 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                if constexpr (NPL == 3) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
                 acc[i][j] = c;
             }
         if (kt + 1 < nk && tile_ok(kt + 1)) {
-            TileX<A_KMAJOR>::store(lds[cur ^ 1][0], tid, ra[1 - S]);
-            TileX<B_KMAJOR>::store(lds[cur ^ 1][1], tid, rb[1 - S]);
+            TileX<A_KMAJOR>::template store<NPL>(lds[cur ^ 1][0], tid, ra[1 - S]);
+            TileX<B_KMAJOR>::template store<NPL>(lds[cur ^ 1][1], tid, rb[1 - S]);
         }
         __syncthreads();
     };
     if (tile_ok(0)) load_tiles(kt0 * XBK, S0{});
     if (nk > 1 && tile_ok(1)) load_tiles((kt0 + 1) * XBK, S1{});
     if (tile_ok(0)) {
-        TileX<A_KMAJOR>::store(lds[0][0], tid, ra[0]);
-        TileX<B_KMAJOR>::store(lds[0][1], tid, rb[0]);
+        TileX<A_KMAJOR>::template store<NPL>(lds[0][0], tid, ra[0]);
+        TileX<B_KMAJOR>::template store<NPL>(lds[0][1], tid, rb[0]);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
@@ -261,6 +267,13 @@ __global__ __launch_bounds__(256) void gemm_f32x3_kernel(GemmXArgs p) {
 // training simpool: one video per blockIdx.z, max-pool epilogue (common.hpp, gemm_pool_tile)
 __global__ __launch_bounds__(256) void gemm_f32x3_pool_kernel(GemmXArgs p, PoolArgs pa) {
     gemm_f32x3_body<false, false, 1, PoolArgs>(p, &pa);
+}
+// the two-plane ("fp32x2") forms: the forward layout and the pooled simpool product
+__global__ __launch_bounds__(256) void gemm_f32x2_kernel(GemmXArgs p) {
+    gemm_f32x3_body<false, false, 0, PoolArgs, 2>(p, nullptr);
+}
+__global__ __launch_bounds__(256) void gemm_f32x2_pool_kernel(GemmXArgs p, PoolArgs pa) {
+    gemm_f32x3_body<false, false, 1, PoolArgs, 2>(p, &pa);
 }
 // dz' = dY W (the dX layout) with the LayerNorm-parameter-gradient epilogue: the parity-mode twin of gemm_bf16_lngrad_kernel
 __global__ __launch_bounds__(256) void gemm_f32x3_lngrad_kernel(GemmXArgs p, LnGradArgs la) {
@@ -287,11 +300,12 @@ int launch_linear_lngrad_x3(const float* dy, const float* W, long M, int N, int 
     return check_launch("linear_lngrad (fp32x3)");
 }
 
-int launch_simpool_pool_x3(const float* g, const float* q, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream) {
+int launch_simpool_pool_x3(const float* g, const float* q, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream, int planes) {
     const bool al = !(D & 3) && !((uintptr_t)g & 15), bl = !(D & 3) && !((uintptr_t)q & 15);
     GemmXArgs p{g, q, nullptr, nullptr, L, nq, D, D, D, nq, 0, al, bl, 1, (long)L * D, 0, 0, 0, 0, 0, 1.0f, 1, 0};
-    DLDKD_LAUNCH(gemm_f32x3_pool_kernel, dim3((nq + XBN - 1) / XBN, 1, nv), dim3(256), 0, (hipStream_t)stream, p, pa);
-    return check_launch("simpool_train_fwd (fp32x3)");
+    if (planes == 2) DLDKD_LAUNCH(gemm_f32x2_pool_kernel, dim3((nq + XBN - 1) / XBN, 1, nv), dim3(256), 0, (hipStream_t)stream, p, pa);
+    else DLDKD_LAUNCH(gemm_f32x3_pool_kernel, dim3((nq + XBN - 1) / XBN, 1, nv), dim3(256), 0, (hipStream_t)stream, p, pa);
+    return check_launch("simpool_train_fwd (fp32x3 / fp32x2)");
 }
 
 }  // namespace dldkd
@@ -325,6 +339,18 @@ extern "C" int dldkd_gemm_f32x3_flags(const float* A, const float* B, const floa
                                       int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes,
                                       const unsigned char* flags, void* stream) {
     return gemm_f32x3_impl(A, B, bias, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, relu, workspace, workspace_bytes, flags, stream);
+}
+
+extern "C" int dldkd_gemm_f32x2(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                int relu, const unsigned char* row_flags, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || lda < 1 || ldb < 1 || ldc < N) { set_error("gemm_f32x2: bad sizes"); return DLDKD_EINVAL; }
+    if (M == 0 || N == 0) return DLDKD_OK;
+    if (!A || !B || !C) { set_error("gemm_f32x2: null pointer"); return DLDKD_EINVAL; }
+    const int a_vec = !(lda & 3) && !((uintptr_t)A & 15), b_vec = !(ldb & 3) && !((uintptr_t)B & 15);
+    GemmXArgs p{A, B, bias, C, M, N, K, lda, ldb, ldc, relu, a_vec, b_vec, 1, 0, 0, 0, 0, 0, 0, 1.0f, 1, 0};
+    if (row_flags != nullptr && M % XBM == 0 && !((uintptr_t)row_flags & 3)) p.mflags = row_flags;
+    DLDKD_LAUNCH(gemm_f32x2_kernel, dim3((N + XBN - 1) / XBN, (M + XBM - 1) / XBM, 1), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("gemm_f32x2");
 }
 
 static int gemm_f32x3_impl(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda,

@@ -359,6 +359,7 @@ int dldkd_simpool_train_fwd_f32(int precision, const float* q, const float* g, c
     PoolArgs pa{rg, rq, lens, labels, pooled_raw, pooled_cos, arg_raw, arg_cos, clip_pos, nv, L};
     if (precision == DLDKD_GEMM_BF16) return launch_simpool_pool_bf16(g, q, nv, L, nq, D, pa, stream);
     if (precision == DLDKD_GEMM_F32X3) return launch_simpool_pool_x3(g, q, nv, L, nq, D, pa, stream);
+    if (precision == DLDKD_GEMM_F32X2) return launch_simpool_pool_x3(g, q, nv, L, nq, D, pa, stream, 2);
     set_error("simpool_train_fwd: precision %d has no pooled kernel (DLDKD_GEMM_F32X3 or DLDKD_GEMM_BF16)", precision);
     return DLDKD_EINVAL;
 }

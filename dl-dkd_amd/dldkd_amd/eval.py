@@ -131,10 +131,12 @@ _FEATURE_CACHE = weakref.WeakKeyDictionary()          # dataset -> {kind: [devic
 
 def clear_feature_cache():
     _FEATURE_CACHE.clear()
+    _GT_CACHE.clear()
 
 
 def _cache_bytes():
-    return sum(k["bytes"] if isinstance(k, dict) else k.table.nbytes() for d in _FEATURE_CACHE.values() for k in d.values())
+    return sum(k["bytes"] if isinstance(k, dict) else k.table.nbytes() + sum(b.numel() for b in (getattr(k, "gallery_blobs", None) or []))
+               for d in _FEATURE_CACHE.values() for k in d.values())
 
 
 def _cached_batches(dataset, kind, n_items, opt, make_loader, to_device):
@@ -228,6 +230,7 @@ def _resident_context_info(model, eval_dataset, opt, loader, owner, kind):
         except TypeError:                                   # a dataset object that cannot be weakly referenced
             slot = None
     key = ("resident", kind)
+    lmax_host = None
     res = slot.get(key) if slot is not None else None
     # opt.eval_resident_shard: the table persisted as ONE file (ingest.save_resident / load_resident: fp16 rows + statistics + ids,
     # read back through a pinned ring at PCIe rate) - a fresh process starts from it instead of re-reading the fp32 features item
@@ -244,13 +247,25 @@ def _resident_context_info(model, eval_dataset, opt, loader, owner, kind):
         res.plan(dev)
         if slot is not None:
             slot[key] = res
-    packer = scoring.GalleryPacker(n, L, 2, dev)
     if res is not None and res.complete and len(res.metas) == n and res.table.device == dev:
+        # the packed gallery's buffers live with the resident table: zero-filled once, re-encoded in place every epoch (a dataset's
+        # lengths do not change, so the padding the scorers never load is never written again: 4.29 -> 2.56 GB per TVR gallery).
+        # A context dict of an earlier epoch of the SAME dataset therefore shows the newest encode.
+        blobs = getattr(res, "gallery_blobs", None)
+        try:
+            packer = scoring.GalleryPacker(n, L, 2, dev, blobs=blobs) if blobs is not None else None
+        except native.NativeError:
+            packer = None
+        if packer is None:
+            packer = scoring.GalleryPacker(n, L, 2, dev, zero_fill=True)
+            res.gallery_blobs = packer.blobs
         torch.empty((), dtype=torch.int64).random_()        # the DataLoader iterator's base-seed draw (see _cached_batches)
         with torch.no_grad():
             model.encode_resident_into(packer, res)
         metas, lens_all = list(res.metas), res.lens_dev
+        lmax_host = int(res.lens_host.max(initial=0))       # (known on the host: no read-back in front of the queries' encode)
     else:
+        packer = scoring.GalleryPacker(n, L, 2, dev)
         cap = float(getattr(opt, "eval_feature_cache_gb", 96.0)) * 1e9
         other = _cache_bytes()
         keep = slot is not None
@@ -287,8 +302,9 @@ def _resident_context_info(model, eval_dataset, opt, loader, owner, kind):
         if res.table.rows or not lens_parts:
             encode_table()
         lens_all = lens_parts[0] if len(lens_parts) == 1 else torch.cat(lens_parts)
-    lmax = int(lens_all.max().item()) if lens_all.numel() else 0
-    vmask = (torch.arange(lmax, device=dev).unsqueeze(0) < lens_all.unsqueeze(1)).float()
+    if lmax_host is None:
+        lmax_host = int(lens_all.max().item()) if lens_all.numel() else 0
+    vmask = (torch.arange(lmax_host, device=dev).unsqueeze(0) < lens_all.unsqueeze(1)).float()
     return dict(video_metas=metas, inher_frame_feat=None, explore_frame_feat=None, teacher_frame_feat=None,
                 video_mask=vmask, _packed=packer.finish())
 
@@ -630,6 +646,14 @@ def eval_precision(model, opt, test=False):
     if mode not in ("throughput", "parity"):
         raise ValueError(f"eval_precision must be 'throughput' or 'parity', got {mode!r}")
     if mode == "parity":
+        if ops.precision_mode() in ("mixed", "fp32x2"):      # training precisions whose forward is not the three-plane parity grade
+            prev_mode = ops.precision_mode()
+            ops.set_gemm_precision("fp32")
+            try:
+                yield
+            finally:
+                ops.set_gemm_precision(prev_mode)
+            return
         yield
         return
     prev = (ops.precision_mode(), model.fast_input_proj)
@@ -695,6 +719,23 @@ def eval_epoch(model, val_video_dataset, val_text_dataset, opt, test=False):
         return res
 
 
+_GT_CACHE = {}     # (videos, captions) -> (t2v_gt, ptr, idx): the validation sets do not change between epochs
+
+
+def _gt_cached(video_metas, query_metas, device):
+    """get_gt + gt_csr of one (gallery, caption set) pair, kept across epochs (13 + 7 ms of Python per epoch at TVR size -
+    a third of a cached eval_epoch's wall time, profiles/r06/eval_epoch_c2_cached_cprofile.txt); keyed by the ids themselves."""
+    key = (tuple(video_metas), tuple(query_metas), str(device))
+    hit = _GT_CACHE.get(key)
+    if hit is None:
+        _, t2v_gt = get_gt(video_metas, query_metas)
+        ptr, idx = gt_csr(t2v_gt, len(query_metas), device)
+        if len(_GT_CACHE) >= 4:
+            _GT_CACHE.pop(next(iter(_GT_CACHE)))
+        hit = _GT_CACHE[key] = (t2v_gt, ptr, idx)
+    return hit
+
+
 def rank_queries(model, eval_dataset, opt, ctx_info, w=(0.7, 0.3)):
     """What eval_epoch needs of compute_query2ctx_info + the three cal_perf calls, without the score matrices: encode the
     queries, score them against the resident gallery (scorer partial planes only), and rank the ground-truth videos straight
@@ -704,8 +745,7 @@ def rank_queries(model, eval_dataset, opt, ctx_info, w=(0.7, 0.3)):
     pg = ctx_info["_packed"]
     pq = scoring.pack_queries(qs)
     ws = scoring.simpool_partials(pq, pg)
-    _, t2v_gt = get_gt(ctx_info["video_metas"], metas)
-    ptr, idx = gt_csr(t2v_gt, len(metas), pg.lens.device)
+    _, ptr, idx = _gt_cached(ctx_info["video_metas"], metas, pg.lens.device)
     return scoring.rank_partials(ws, pq, pg, ptr, idx, w).cpu().numpy(), metas
 
 

@@ -189,6 +189,90 @@ def layernorm(x, gamma, beta, add=None, add_mod=0, p_drop=0.0, training=False):
     return ops.layernorm(x, gamma, beta, add=add, add_mod=add_mod)
 
 
+# ---- both video towers' input-projection LayerNorm in one pass (round 6).  The inheritance and the exploration tower normalise the
+# SAME student features (method/model.py:229-243): DLDKD.forward_tensors calls in_proj_ln_dual in front of the towers; the two
+# _InProjTrain.forward calls that follow find their rows here (matched by the raw rows' storage and the branch's gamma) and skip
+# their own LayerNorm launch - the 201-MB TVR batch is read once instead of twice.
+IN_PROJ_LN_DUAL = os.environ.get("DLDKD_LN_DUAL", "1") == "1"
+_PRE_LN = {}
+
+
+def in_proj_ln_dual_ok(x, layers, p, training):
+    """Throughput (bf16) training mode, two LinearLayers over one contiguous fp32 GPU tensor of raw features that needs no gradient,
+    the one-GEMM backward (no keep bytes), the bf16 x bf16 forward GEMM."""
+    if not (IN_PROJ_LN_DUAL and IN_PROJ_TRAIN_BF16_ROWS and IN_PROJ_TRAIN_FUSED and IN_PROJ_BWD_DUAL and IN_PROJ_TRAIN_NT16
+            and not IN_PROJ_KEEP_BYTES and IN_PROJ_SKIP_PADDING and len(layers) == 2 and training and torch.is_grad_enabled()):
+        return False
+    if not (ops.gemm_precision() == "bf16" and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+            and not x.requires_grad and x.shape[1] % 32 == 0):
+        return False
+    K = x.shape[-1]
+    M = x.shape[0] * x.shape[1]
+    for l in layers:
+        w = l.net[1].weight
+        N = w.shape[0]
+        if not (l.relu and l.layer_norm and w.requires_grad and l.LayerNorm.weight.requires_grad and l.LayerNorm.bias.requires_grad
+                and w.is_contiguous() and N <= 384 and N % 2 == 0 and K % 4 == 0 and K <= 4096 and M >= 1024
+                and _L().dldkd_gemm_bf16_nt16_ok(M, N, K, K, K)):
+            return False
+    return True
+
+
+_PRE_SLOT = {}
+
+
+def predraw_in_proj_slots(x, layers, p):
+    """The dropout slots of the two video towers' input projections, drawn up front, branch 0 first (DLDKD.forward_tensors, in
+    front of the towers, in EVERY precision mode and with or without the one-pass LayerNorm): the masks of a step do not depend on
+    which of those forms runs - the tests that compare two forms of the step with dropout on rely on it."""
+    _PRE_SLOT.clear()
+    if p > 0.0:
+        x2 = x.reshape(-1, x.shape[-1])
+        for l in layers:
+            _PRE_SLOT[(x2.data_ptr(), l.LayerNorm.weight.data_ptr())] = _philox_slot(x.device, x.numel())
+
+
+def _in_proj_slot(x2, gamma, n):
+    s = _PRE_SLOT.pop((x2.data_ptr(), gamma.data_ptr()), None)
+    return s if s is not None else _philox_slot(x2.device, n)
+
+
+def in_proj_ln_dual(x, row_mask, layers, p):
+    """One launch: z_b = dropout(LayerNorm(x; gamma_b, beta_b)) as bf16 rows for both layers, shared statistics and group flags.
+    The Philox slots are drawn here, branch 0 first."""
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    M, dev = x2.shape[0], x.device
+    z = [torch.empty(M, K, dtype=torch.bfloat16, device=dev) for _ in layers]
+    stats = torch.empty(2, M, dtype=torch.float32, device=dev)
+    gflags = torch.empty(M // 32, dtype=torch.uint8, device=dev)
+    rm = _f32(row_mask).reshape(-1)
+    g = [l.LayerNorm.weight for l in layers]
+    slots = [_in_proj_slot(x2, gi, x.numel()) if p > 0.0 else (0, 0, None) for gi in g]
+    b = [l.LayerNorm.bias for l in layers]
+    native.check(_L().dldkd_layernorm_dropout_bf16_dual(_p(x2), _p(g[0]), _p(b[0]), _p(g[1]), _p(b[1]), _p(z[0]), _p(z[1]), _p(stats), M, K,
+                                                        ops.LN_EPS, float(p), slots[0][0], slots[0][1], slots[1][1], slots[0][2], _p(rm),
+                                                        _p(gflags), _s()), "layernorm_dropout_bf16_dual")
+    _PRE_LN.clear()
+    for i in range(2):
+        _PRE_LN[(x2.data_ptr(), g[i].data_ptr())] = (z[i], stats, gflags, slots[i], float(p), M, K)
+
+
+def _take_pre_ln(x2, gamma, p, row_mask):
+    ent = _PRE_LN.pop((x2.data_ptr(), gamma.data_ptr()), None)
+    if ent is None:
+        return None
+    z, stats, gflags, slot, p0, M, K = ent
+    if p0 != float(p) or (M, K) != tuple(x2.shape) or row_mask is None:
+        return None
+    return z, stats, gflags, slot
+
+
+def drop_pre_ln():
+    _PRE_LN.clear()
+    _PRE_SLOT.clear()
+
+
 class _InProjTrain(Function):
     """LinearLayer on RAW features in training, throughput mode (model_components.py:294-312): LayerNorm -> Dropout -> Linear ->
     ReLU as one autograd node.  The features need no gradient, so the backward pass never forms the Linear's input gradient: the
@@ -205,7 +289,38 @@ class _InProjTrain(Function):
         # forward GEMM and dW read half the bytes (201 -> 100 MB per branch at the TVR batch), and the row statistics are kept
         # for the backward pass instead of being recomputed from x there
         z16 = IN_PROJ_TRAIN_BF16_ROWS and ops.gemm_precision() == "bf16" and K % 4 == 0 and N % 2 == 0
-        if z16:
+        pre = _take_pre_ln(x2, gamma, p, row_mask) if z16 else None
+        mixed16 = (ops.precision_mode() == "mixed" and IN_PROJ_BWD_DUAL and not IN_PROJ_KEEP_BYTES and K % 4 == 0 and N <= 384 and N % 2 == 0
+                   and weight.is_contiguous() and gamma.requires_grad and beta.requires_grad and weight.requires_grad)
+        if pre is not None:
+            # both branches' LayerNorm-dropout rows were written by ONE pass over the raw features (in_proj_ln_dual, called by the
+            # model in front of the towers): this branch's rows, the shared statistics and group flags, its Philox slot
+            z, stats, gflags, (seed, off, state) = pre
+            y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+            self_w16 = _take_prepacked("w16", weight.data_ptr())
+            if self_w16 is None:
+                self_w16 = torch.empty(N, K, dtype=torch.bfloat16, device=x.device)
+                native.check(_L().dldkd_cast_bf16(_p(weight), _p(self_w16), N * K, _s()), "cast_bf16")
+            native.check(_L().dldkd_gemm_bf16_nt16(_p(z), _p(self_w16), _p(bias), _p(y), M, N, K, K, K, N, int(relu), _p(gflags), _s()),
+                         "gemm_bf16_nt16")
+        elif mixed16:
+            # "mixed" precision: the forward product on the fp32-grade GEMM over fp32 LayerNorm-dropout rows (exact loss values); the
+            # SAME launch leaves the rows as bf16 too - all the backward pass reads (the one-GEMM bf16 backward below: dW and the
+            # LayerNorm parameter gradients; the fp32 rows die with this call)
+            zf = torch.empty_like(x2)
+            z = torch.empty(x2.shape, dtype=torch.bfloat16, device=x.device)
+            stats = torch.empty(2, M, dtype=torch.float32, device=x.device)
+            rm = None
+            if row_mask is not None and IN_PROJ_SKIP_PADDING and x.dim() == 3 and row_mask.numel() == M:
+                rm = _f32(row_mask).reshape(-1)
+                if x.shape[1] % 32 == 0:          # (query towers: 30 words - no 32-row groups; the rows of the padding are still skipped)
+                    gflags = torch.empty(M // 32, dtype=torch.uint8, device=x.device)
+            seed, off, state = _in_proj_slot(x2, gamma, x.numel()) if p > 0.0 else (0, 0, None)
+            native.check(_L().dldkd_layernorm_ex_f32(_p(x2), None, 0, _p(gamma), _p(beta), _p(zf), _p(z), None, _p(stats), M, K, ops.LN_EPS,
+                                                     float(p), seed, off, state, _p(rm), _p(gflags), None, _s()), "layernorm_ex")
+            y = ops.linear(zf, weight, bias, relu=relu, row_flags=gflags)
+            del zf
+        elif z16:
             z = torch.empty(x2.shape, dtype=torch.bfloat16, device=x.device)
             stats = torch.empty(2, M, dtype=torch.float32, device=x.device)
             seed, off, state = (0, 0, None)
@@ -217,7 +332,7 @@ class _InProjTrain(Function):
                         and N <= 384 and weight.is_contiguous())
                 if not dual:
                     keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
-                seed, off, state = _philox_slot(x.device, x.numel())
+                seed, off, state = _in_proj_slot(x2, gamma, x.numel())
             # rows of the padding (row_mask == 0) are never read and come out as zero rows; when the padded length is a multiple of
             # 32 the kernel also flags the 32-row groups that hold valid rows, and dW below skips the others
             rm = None
@@ -240,7 +355,7 @@ class _InProjTrain(Function):
                 native.check(_L().dldkd_gemm_bf16_mixed(0, _p(z), _p(weight), _p(bias), _p(y), M, N, K, K, K, N, int(relu), None, 0,
                                                         _p(gflags), _s()), "gemm_bf16_mixed")
         elif (row_mask is not None and IN_PROJ_SKIP_PADDING and x.dim() == 3 and row_mask.numel() == M and x.shape[1] % 32 == 0
-              and M % 128 == 0 and ops.gemm_precision() in ("fp32", "fp32x3")):
+              and M % 128 == 0 and ops.gemm_precision() in ("fp32", "fp32x3", "fp32x2")):
             # parity mode with the batch's mask: the same padding skip with fp32 rows (the three-plane GEMMs are compute-bound:
             # the 32-row groups that are not multiplied are time saved one for one)
             z = torch.empty_like(x2)
@@ -249,7 +364,7 @@ class _InProjTrain(Function):
             seed, off, state = (0, 0, None)
             if p > 0.0:
                 keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
-                seed, off, state = _philox_slot(x.device, x.numel())
+                seed, off, state = _in_proj_slot(x2, gamma, x.numel())
             native.check(_L().dldkd_layernorm_dropout_rows_f32(_p(x2), _p(gamma), _p(beta), _p(z), _p(keep), _p(stats), M, K, ops.LN_EPS,
                                                                float(p), seed, off, state, _p(_f32(row_mask).reshape(-1)), _p(gflags),
                                                                _s()), "layernorm_dropout_rows")
@@ -258,7 +373,7 @@ class _InProjTrain(Function):
             if p > 0.0:
                 z = torch.empty_like(x2)
                 keep = torch.empty(x2.shape, dtype=torch.uint8, device=x.device)
-                seed, off, state = _philox_slot(x.device, x.numel())
+                seed, off, state = _in_proj_slot(x2, gamma, x.numel())
                 native.check(_L().dldkd_layernorm_dropout_f32(_p(x2), None, 0, _p(gamma), _p(beta), _p(z), _p(keep), M, K,
                                                               ops.LN_EPS, float(p), seed, off, state, _s()), "layernorm_dropout")
             else:
@@ -271,7 +386,8 @@ class _InProjTrain(Function):
         ctx.save_for_backward(x2, weight, z, y if (relu and not grad_premasked) else None, keep, stats, gflags, gamma, beta)
         ctx.relu, ctx.has_bias, ctx.keep_scale, ctx.prec = (relu and not grad_premasked), bias is not None, 1.0 / (1.0 - p), ops.gemm_precision()
         # the dropout's Philox slot, for a backward pass that redraws bits instead of reading keep bytes (z16 path without `keep`)
-        ctx.drop_rng = (float(p), seed, off, state, _philox_step.dev if _philox_step is not None else None) if (z16 and p > 0.0) else (0.0, 0, 0, None, None)
+        ctx.drop_rng = ((float(p), seed, off, state, _philox_step.dev if _philox_step is not None else None)
+                        if ((z16 or mixed16) and p > 0.0) else (0.0, 0, 0, None, None))
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -329,7 +445,7 @@ class _InProjTrain(Function):
             tiles = (M + 127) // 128
             ws = torch.empty(2 * tiles * K, dtype=torch.float32, device=x2.device)
             dgb = _zeros((2, K), x2.device)
-            native.check(_L().dldkd_linear_lngrad(ops._PREC_ID[ops.gemm_precision()], _p(dy2), _p(w), _p(x2), _p(keep), ctx.keep_scale, _p(stats[0]), _p(stats[1]),
+            native.check(_L().dldkd_linear_lngrad(ops._PREC_ID[ops.gemm_precision()] if ops.gemm_precision() != "fp32x2" else 1, _p(dy2), _p(w), _p(x2), _p(keep), ctx.keep_scale, _p(stats[0]), _p(stats[1]),
                                                        _p(ws), ws.numel() * 4, _p(dgb[0]), _p(dgb[1]), M, N, K, _p(gflags), _s()), "linear_lngrad")
             dg, dbeta = dgb[0], dgb[1]
         return None, dg, dbeta, dw, db, None, None, None, None
@@ -356,7 +472,7 @@ IN_PROJ_TRAIN_NT16 = True             # throughput mode: the forward GEMM of the
 def in_proj_train_ok(x, weight):
     """Training, features without a gradient, a tiled-GEMM precision mode (bf16 or the three-plane fp32-grade one), row statistics
     kernel limits (D % 4 == 0, D <= 4096)."""
-    return (IN_PROJ_TRAIN_FUSED and ops.gemm_precision() in ("bf16", "fp32", "fp32x3") and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad
+    return (IN_PROJ_TRAIN_FUSED and ops.gemm_precision() in ("bf16", "fp32", "fp32x3", "fp32x2") and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad
             and x.shape[-1] % 4 == 0 and x.shape[-1] <= 4096 and weight.requires_grad)
 
 
@@ -525,8 +641,17 @@ def attention(qkv, mask, p_drop=0.0, training=False):
 TOWER_TRAIN_FUSED = True      # throughput mode, training: everything behind the input projection as 2 + 2 row kernels (tower_train.hip)
 
 
+TOWER_TRAIN_MIXED = os.environ.get("DLDKD_TOWER_MIXED", "1") == "1"   # "mixed" precision: fp32-grade forward chain + the fused bf16 backward
+
+
+def tower_train_mixed():
+    """A tower built NOW runs as _TowerTrainMixed: precision "mixed", outside a backward pass."""
+    return TOWER_TRAIN_MIXED and ops.precision_mode() == "mixed" and ops.gemm_precision() in ("fp32", "fp32x3", "fp32x2")
+
+
 def tower_train_ok(is_cuda, L):
-    return TOWER_TRAIN_FUSED and ops.gemm_precision() == "bf16" and is_cuda and torch.is_grad_enabled() and 1 <= L <= 128
+    return (TOWER_TRAIN_FUSED and (ops.gemm_precision() == "bf16" or tower_train_mixed()) and is_cuda and torch.is_grad_enabled()
+            and 1 <= L <= 128)
 
 
 def _bf16(shape, device):
@@ -727,14 +852,85 @@ class _TowerTrain(Function):
                 None, None, None, None, None, None, None)
 
 
+class _TowerTrainMixed(Function):
+    """_TowerTrain in "mixed" precision (ops.set_gemm_precision("mixed")): the FORWARD pass is the fp32-grade kernel chain of the
+    parity mode - LayerNorm + dropout, q | k | v as one three-plane GEMM, the exact fp32 attention, dense, dropout, residual
+    LayerNorm [, out mapping] (model_components.py:277-284, 398-450; model.py:219) - so the tower's output, hence every loss value, is
+    the parity mode's (north_star: 1e-4).  One launch (dldkd_tower_train_emit) then writes, from the fp32 intermediates, the bf16 rows
+    _TowerTrain's fused backward kernels read, and the BACKWARD pass IS _TowerTrain.backward: bf16 products on exact activations.
+    The dropout masks are the fused path's: same Philox slots, drawn in the same order, same element indexing."""
+
+    @staticmethod
+    def forward(ctx, y0, pos, g1, b1, wq, bq, wk, bk, wv, bv, wd, bd, g2, b2, wo, bo, mask, lens, flags, p_in, p_attn, p_hid,
+                relu_mask):
+        N, L, _ = y0.shape
+        M, dev = N * L, y0.device
+        video = wo is not None
+        if flags is None:
+            lens = None
+        packs = _take_prepacked("packs", tuple(w.data_ptr() for w in (wq, wk, wv, wd) + ((wo,) if video else ())))
+        if packs is None:
+            packs = _tt_pack(_tt_jobs(wq, wk, wv, wd, wo), dev)
+        if video:
+            _, _, _, pk_ot, pk_dt, pk_qkvt = packs
+        else:
+            (_, _, pk_dt, pk_qkvt), pk_ot = packs, None
+        slot = lambda p, n: _philox_slot(dev, n) if p > 0.0 else (0, 0, None)      # noqa: E731
+        sa, sb, sc = slot(p_in, M * HIDDEN), slot(p_attn, N * HEADS * L * L), slot(p_hid, M * HIDDEN)
+        L_ = _L()
+        f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)   # noqa: E731
+        y2 = y0.reshape(M, HIDDEN)
+        # (1) h1 = dropout(LayerNorm(y0 + pos)), statistics kept
+        h1, stats = f32(M, HIDDEN), f32(2, M)
+        native.check(L_.dldkd_layernorm_ex_f32(_p(y2), _p(pos), L, _p(g1), _p(b1), _p(h1), None, None, _p(stats), M, HIDDEN, ops.LN_EPS,
+                                               float(p_in), sa[0], sa[1], sa[2], None, None, _p(flags), _s()), "layernorm_ex")
+        # (2) q | k | v: one fp32-grade GEMM (padding groups not multiplied)
+        wqkv, bqkv = torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0)
+        qkv = ops.linear(h1, wqkv, bqkv, row_flags=flags)
+        # (3) the exact fp32 attention (probabilities written, not kept)
+        ctxf = f32(N, L, HIDDEN)
+        P = f32(N, HEADS, L, L)
+        native.check(L_.dldkd_attention_train_fwd_f32(_p(qkv), _p(mask), _p(P), _p(ctxf), N, L, float(p_attn), sb[0], sb[1], sb[2], _s()),
+                     "attention_train_fwd")
+        del P
+        # (4) dense -> dropout -> + h1 -> LayerNorm [-> out mapping]
+        d = ops.linear(ctxf.reshape(M, HIDDEN), wd, bd, row_flags=flags)
+        if p_hid > 0.0:
+            dd, keep = torch.empty_like(d), torch.empty(d.shape, dtype=torch.uint8, device=dev)
+            native.check(L_.dldkd_dropout_fwd_f32(_p(d), _p(dd), _p(keep), d.numel(), float(p_hid), sc[0], sc[1], sc[2], _s()), "dropout_fwd")
+            del keep
+        else:
+            dd = d
+        h2, stats2 = f32(M, HIDDEN), f32(2, M)
+        native.check(L_.dldkd_layernorm_ex_f32(_p(dd), _p(h1), 0, _p(g2), _p(b2), _p(h2), None, None, _p(stats2), M, HIDDEN, ops.LN_EPS, 0.0,
+                                               0, 0, None, None, None, _p(flags), _s()), "layernorm_ex")
+        out = ops.linear(h2, wo, bo, row_flags=flags).view(N, L, HIDDEN) if video else h2.view(N, L, HIDDEN)
+        # (5) what the fused bf16 backward reads
+        xh1, h1d, qkv16, ctxl, xh2 = (_bf16((M, HIDDEN), dev), _bf16((M, HIDDEN), dev), _bf16((M, 3 * HIDDEN), dev), _bf16((M, HIDDEN), dev),
+                                      _bf16((M, HIDDEN), dev))
+        rstd2 = f32(M)
+        h2_16 = _bf16((M, HIDDEN), dev) if video else None
+        native.check(L_.dldkd_tower_train_emit(_p(y2), _p(pos), L, _p(stats), _p(h1), _p(qkv), _p(ctxf), _p(dd), _p(stats2),
+                                               _p(h2) if video else None, _p(flags), M, _p(xh1), _p(h1d), _p(qkv16), _p(ctxl), _p(xh2), _p(rstd2),
+                                               _p(h2_16), _s()), "tower_train_emit")
+        ctx.save_for_backward(xh1, pos, g1, g2, mask, lens, flags, h1d, stats, qkv16, ctxl, xh2, rstd2, h2_16, pk_ot, pk_dt, pk_qkvt)
+        ctx.shape = (N, L)
+        keep_alive = _philox_step.dev if _philox_step is not None else None
+        ctx.cfg = (video, float(p_in), float(p_attn), float(p_hid), sa, sb, sc, bool(relu_mask), keep_alive)
+        return out
+
+    backward = _TowerTrain.backward
+
+
 def tower_train(y0, pos, g1, b1, qkv_layers, dense, g2, b2, out_linear, mask, lens, flags, p_in, p_attn, p_hid, training, relu_mask=True):
     """See _TowerTrain.  qkv_layers = (query, key, value) nn.Linear, dense / out_linear nn.Linear (out_linear None: query towers,
     the result is the LayerNorm output h2).  Dropout rates apply when `training`."""
     q, k, v = qkv_layers
     pz = (lambda p: float(p) if training else 0.0)               # noqa: E731
     wo, bo = (out_linear.weight, out_linear.bias) if out_linear is not None else (None, None)
-    return _TowerTrain.apply(_f32(y0), _f32(pos), g1, b1, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, dense.weight, dense.bias,
-                             g2, b2, wo, bo, _f32(mask), lens, flags, pz(p_in), pz(p_attn), pz(p_hid), bool(relu_mask))
+    fn = _TowerTrainMixed if tower_train_mixed() else _TowerTrain
+    return fn.apply(_f32(y0), _f32(pos), g1, b1, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, dense.weight, dense.bias,
+                    g2, b2, wo, bo, _f32(mask), lens, flags, pz(p_in), pz(p_attn), pz(p_hid), bool(relu_mask))
 
 
 # ------------------------------------------------------------------------------------------ modular pooling
@@ -905,7 +1101,7 @@ class _SimPoolTrain(Function):
 
 def simpool_train_ok():
     """The pooled GEMM exists for the parity ("fp32" = three bf16 planes) and the throughput ("bf16") precisions."""
-    return ops.gemm_precision() in ("fp32", "fp32x3", "bf16")
+    return ops.gemm_precision() in ("fp32", "fp32x3", "fp32x2", "bf16")
 
 
 def simpool_train(q, g, lens, labels, want_clip):

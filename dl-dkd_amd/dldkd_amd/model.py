@@ -53,6 +53,7 @@ class DLDKD(nn.Module):
         self.tower_streams = False         # training: the four towers on four streams (_encode_towers)
         self._side_streams = None
         self._tower_runner = None
+        self._pre_ln_hook = None
         self._branch_runner = None
         self.weight = 1
         self.kl_intra_weight = opt.kl_intra_weight
@@ -221,8 +222,10 @@ class DLDKD(nn.Module):
             y = ops.in_proj_resident(res.table, r0, r1, self._folded["visual"], out_h16=ops.RESIDENT_H0_H16)
             v0 = packer.reserve(n, int(res.lens_host[va:va + n].max(initial=0)))
             if items.shape[0]:
+                # (a packer whose buffers are zero beyond every video's last 16-row tile: those rows are not written again)
                 ops.tower_seq(y, packs, lens_d, seq_rows=0, row0=row0_d, items=items, out_mode=1, gallery=packer.blobs, v0=v0,
-                              Lp=packer.Lp, lens_out=packer.lens)
+                              Lp=packer.Lp, lens_out=packer.lens,
+                              skip_zero_rows=bool(getattr(packer, "zero_padded", False)) and ops.RESIDENT_H0_H16 and ops.SKIP_ZERO_ROWS)
 
     def encode_context(self, frame_video_feat, video_mask=None):
         out = []
@@ -421,7 +424,8 @@ class DLDKD(nn.Module):
         if F_.TOWER_PREPACK:
             # every weight operand of the tower - the projection's bf16 weight, the fragment packs - and the batch's sequence lengths
             # from ONE launch
-            lens = F_.tower_prepack(proj.net[1].weight if fused_proj else None, enc.self.query.weight, enc.self.key.weight,
+            # ("mixed" precision: the projection's forward GEMM takes the fp32 weight - no bf16 cast of it)
+            lens = F_.tower_prepack(proj.net[1].weight if (fused_proj and not F_.tower_train_mixed()) else None, enc.self.query.weight, enc.self.key.weight,
                                     enc.self.value.weight, enc.output.dense.weight, None if out_lin is None else out_lin.weight, mask=mask)
         if lens is None:
             lens = self._lens(mask, n, L, feat.device)
@@ -559,6 +563,26 @@ class DLDKD(nn.Module):
         labels = batch["text_labels"]
         mask = batch["student_videos_mask"].float()
         dev = mask.device
+        F_.drop_pre_ln()
+        dual = False
+        if self.training and self.double_branch and torch.is_grad_enabled() and mask.is_cuda:
+            # both video towers normalise the same raw features (model.py:229-243): their dropout slots are drawn here, up front
+            # (whatever form the step takes, the masks are the same), and in throughput mode ONE pass writes both branches'
+            # LayerNorm-dropout rows - on the first video tower's stream when the stepper captures (the hook), so that the main
+            # stream's chain (teacher scores, a query tower) is not held up by it
+            vid = batch["student_videos"]
+            layers = [self.visual_input_proj, self.exp_visual_input_proj]
+            p_in = float(layers[0].net[0].p)
+            if p_in == float(layers[1].net[0].p) and vid.dtype == torch.float32 and vid.is_contiguous():
+                F_.predraw_in_proj_slots(vid, layers, p_in)
+                dual = (mask.is_contiguous() and self._tower_fused_ok(vid, mask) and F_.in_proj_ln_dual_ok(vid, layers, p_in, True))
+        hook = self._pre_ln_hook
+        if hook is not None:
+            with hook(dual):
+                if dual:
+                    F_.in_proj_ln_dual(vid, mask, layers, p_in)
+        elif dual:
+            F_.in_proj_ln_dual(vid, mask, layers, p_in)
         if self.training and torch.is_grad_enabled() and mask.is_cuda:
             F_.begin_zero_arena(dev)          # one fill for the step's small zero-initialised gradient buffers
         else:
@@ -649,5 +673,6 @@ class DLDKD(nn.Module):
             kl = kl_intra
             loss = (F_.sum_scalars(inher_trip, inher_nce, kl, explore_trip, explore_nce) if self.double_branch and inher_trip.is_cuda
                     else inher_trip + inher_nce + kl + explore_trip + explore_nce)
+        F_.drop_pre_ln()
         return loss, {"inher_trip": inher_trip, "inher_nce": inher_nce, "explore_trip": explore_trip,
                       "explore_nce": explore_nce, "kl": kl, "kl_intra": kl_intra}

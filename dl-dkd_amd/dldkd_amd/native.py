@@ -60,6 +60,13 @@ SIGNATURES = {
                                                    _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_layernorm_dropout_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_float,
                                                _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_gemm_f32x2": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p,
+                                  _c_void_p]),
+    "dldkd_layernorm_ex_f32": (_c_int, [_c_void_p] * 9 + [_c_long, _c_int, _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p,
+                                         _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "dldkd_tower_train_emit": (_c_int, [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 8 + [_c_long] + [_c_void_p] * 8),
+    "dldkd_layernorm_dropout_bf16_dual": (_c_int, [_c_void_p] * 8 + [_c_long, _c_int, _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64,
+                                                    ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_attention_train_fwd_bf16io": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float, ctypes.c_uint64,
                                                    ctypes.c_uint64, _c_void_p, _c_void_p]),
     "dldkd_attention_train_bwd_bf16io": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float,
@@ -210,7 +217,7 @@ SIGNATURES = {
     "dldkd_tower_seq_h16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                       _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_tower_seq_h16_rows16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
-                                          _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+                                          _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p]),
     "dldkd_debug_tower_seq_timeline": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                                 _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p]),
     "dldkd_gemm_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

@@ -30,6 +30,9 @@ def param_epoch():
 
 _MIXED = False      # "mixed": parity-grade forward, bf16 backward
 _BWD_DEPTH = 0
+# the forward GEMMs of "mixed": "fp32x2" = two bf16 planes per operand, three MFMAs per product (gemm_f32x3.hip NPL = 2: ~2^-16 per
+# product; the seven losses stay inside 1e-4 with a wide margin, measured) or "fp32" = the parity mode's three planes
+MIXED_FORWARD = os.environ.get("DLDKD_MIXED_FORWARD", "fp32x2")
 
 
 def set_gemm_precision(precision):
@@ -43,10 +46,10 @@ def set_gemm_precision(precision):
     BACKWARD pass (autograd Functions of functional.py, which read the precision when they run) as "bf16": the gradients carry
     bf16-product noise like the throughput mode's, on the exact forward activations."""
     global _PRECISION, _MIXED
-    if precision not in ("fp32", "fp32_exact", "fp32x3", "bf16", "mixed"):
+    if precision not in ("fp32", "fp32_exact", "fp32x3", "fp32x2", "bf16", "mixed"):
         raise ValueError(precision)
     _MIXED = precision == "mixed"
-    _PRECISION = "fp32" if _MIXED else precision
+    _PRECISION = MIXED_FORWARD if _MIXED else precision
 
 
 def precision_mode():
@@ -73,7 +76,7 @@ class backward_scope:
         if self.on:
             _BWD_DEPTH -= 1
             if _BWD_DEPTH == 0 and _MIXED:
-                _PRECISION = "fp32"
+                _PRECISION = MIXED_FORWARD
         return False
 
 
@@ -108,7 +111,7 @@ def set_row_groups(flags, M):
 def row_groups(M):
     """The current tower's group flags when a tensor of M rows is one row per (item, position) of its padded batch."""
     rg = _ROW_GROUPS
-    return rg[0] if (rg is not None and rg[1] == int(M) and _PRECISION in ("bf16", "fp32", "fp32x3")) else None
+    return rg[0] if (rg is not None and rg[1] == int(M) and _PRECISION in ("bf16", "fp32", "fp32x3", "fp32x2")) else None
 
 
 GEMM_NT_DMA = True       # throughput mode: forward-layout GEMMs with >= 1024 rows on the LDS-DMA staged kernel
@@ -117,18 +120,19 @@ GEMM_NT_DMA = True       # throughput mode: forward-layout GEMMs with >= 1024 ro
 def _gemm_fn(L):
     if _PRECISION == "bf16":
         return L.dldkd_gemm_bf16
-    if _PRECISION in ("fp32", "fp32x3"):      # fp32-grade on the bf16 matrix cores (three-plane split), the default
-        return L.dldkd_gemm_f32x3
+    if _PRECISION in ("fp32", "fp32x3", "fp32x2"):   # fp32-grade on the bf16 matrix cores (three-plane split), the default; the two-plane
+        return L.dldkd_gemm_f32x3                     # form exists for the forward layout only (linear below): other layouts take three
     return L.dldkd_gemm_f32                     # "fp32_exact": the true fp32-input MFMA
 
 
-_PREC_ID = {"fp32_exact": 0, "fp32": 1, "fp32x3": 1, "bf16": 2}     # DLDKD_GEMM_F32 / _F32X3 / _BF16
+_PREC_ID = {"fp32_exact": 0, "fp32": 1, "fp32x3": 1, "bf16": 2, "fp32x2": 3}     # DLDKD_GEMM_F32 / _F32X3 / _BF16 / _F32X2
 
 
 def _gemm_workspace(L, M, N, K, a_kmajor, b_kmajor, device, precision=None):
     """Split-K scratch for one GEMM call, from torch's caching allocator (stream-ordered, so it is safe under graph capture
     and with several streams); None when the shape never splits.  The library itself never allocates."""
-    nbytes = L.dldkd_gemm_workspace_bytes(_PREC_ID[precision or _PRECISION], M, N, K, int(a_kmajor), int(b_kmajor))
+    pid = _PREC_ID[precision or _PRECISION]
+    nbytes = L.dldkd_gemm_workspace_bytes(1 if pid == 3 else pid, M, N, K, int(a_kmajor), int(b_kmajor))   # (fp32x2: other layouts run three planes)
     if nbytes == 0:
         return None, 0
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
@@ -155,6 +159,10 @@ def linear(x, weight, bias=None, relu=False, row_flags=None):
         # throughput mode, many rows: operand tiles by LDS-DMA (gemm_bf16_dma.hip; bit-identical to dldkd_gemm_bf16)
         native.check(L.dldkd_gemm_bf16_nt(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
                                           int(relu), native.ptr(row_flags), native.stream()), "gemm_bf16_nt")
+        return y.view(*x.shape[:-1], N)
+    if _PRECISION == "fp32x2":
+        native.check(L.dldkd_gemm_f32x2(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N, int(relu),
+                                        native.ptr(row_flags), native.stream()), "gemm_f32x2")
         return y.view(*x.shape[:-1], N)
     if row_flags is not None and _PRECISION in ("fp32", "fp32x3"):
         native.check(L.dldkd_gemm_f32x3_flags(native.ptr(x2), native.ptr(weight), native.ptr(bias), native.ptr(y), M, N, K, K, K, N,
@@ -187,7 +195,7 @@ def gemm(a, b, a_kmajor, b_kmajor, M, N, K, row_flags=None):
         return c
     fn = _gemm_fn(L)
     ws, ws_bytes = _gemm_workspace(L, M, N, K, a_kmajor, b_kmajor, a.device)
-    if row_flags is not None and _PRECISION in ("fp32", "fp32x3") and (not a_kmajor or b_kmajor):
+    if row_flags is not None and _PRECISION in ("fp32", "fp32x3", "fp32x2") and (not a_kmajor or b_kmajor):
         native.check(L.dldkd_gemm_f32x3_flags(native.ptr(a), native.ptr(b), None, native.ptr(c), M, N, K, a.shape[-1], b.shape[-1], N,
                                               int(a_kmajor), int(b_kmajor), 0, native.ptr(ws), ws_bytes, native.ptr(row_flags),
                                               native.stream()), "gemm_f32x3_flags")
@@ -582,6 +590,8 @@ def in_proj_rows_ok(K):
 
 # the resident gallery encode hands h0 from K4b to the fused tower as fp16 rows (DLDKD_H0_H16=0: fp32 rows, for A/B runs)
 RESIDENT_H0_H16 = os.environ.get("DLDKD_H0_H16", "1") == "1"
+# the resident gallery encode into a zero-filled (or reused) packed gallery leaves the rows the scorers never load unwritten
+SKIP_ZERO_ROWS = os.environ.get("DLDKD_SKIP_ZERO_ROWS", "1") == "1"
 
 
 def in_proj_resident(table, row_lo, row_hi, folded, relu=True, out=None, out_h16=False):
@@ -722,7 +732,8 @@ def take_nonfinite(device):
     return hit
 
 
-def tower_seq(h0, packs, lens, seq_rows=0, row0=None, items=None, out_mode=0, gallery=None, v0=0, Lp=0, lens_out=None):
+def tower_seq(h0, packs, lens, seq_rows=0, row0=None, items=None, out_mode=0, gallery=None, v0=0, Lp=0, lens_out=None,
+              skip_zero_rows=False):
     """h0: list (one per branch) of fp32 rows (..., 384) - the input projection's output; packs: list of TowerPack; lens int32
     GPU (n_seq).  items: int32 GPU (n_items, 4) from plan_tower_items or None (workgroup i = sequence i, rows i * seq_rows ..).
     out_mode 0 -> list of fp32 tensors shaped like h0; out_mode 1 -> writes videos v0 .. of the bf16 gallery blobs;
@@ -753,7 +764,7 @@ def tower_seq(h0, packs, lens, seq_rows=0, row0=None, items=None, out_mode=0, ga
         native.check(L.dldkd_tower_seq_h16_rows16(native.ptr_array(hs), native.ptr_array([f.blob for f in fs]), native.ptr(row0),
                                                 native.ptr(lens), native.ptr(items), n_items, n_seq, nb, native.ptr_array(gallery),
                                                 int(v0), int(Lp), native.ptr(lens_out), native.ptr(nonfinite_flag(lens.device)),
-                                                native.stream()), "tower_seq_h16")
+                                                int(bool(skip_zero_rows)), native.stream()), "tower_seq_h16")
         return None
     native.check(L.dldkd_tower_seq_h16(native.ptr_array(hs), native.ptr_array([f.blob for f in fs]),
                                         native.ptr(row0), native.ptr(lens), native.ptr(items), n_items, n_seq, nb,

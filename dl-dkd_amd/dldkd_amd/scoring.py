@@ -163,13 +163,23 @@ class GalleryPacker:
     gallery of the reference (eval.py:139-175, 2 x 4.3 GB at TVR scale) never exists.  add() packs videos
     [v0, v0 + n) of every branch; finish() computes the visiting order and returns the PackedGallery."""
 
-    def __init__(self, nv, L, n_branches, device, normalize=True):
+    def __init__(self, nv, L, n_branches, device, normalize=True, zero_fill=False, blobs=None):
+        """zero_fill: the blobs start as zeros (a producer may then leave the rows past a video's last 16-row tile unwritten:
+        zero_padded); blobs: buffers of an earlier packer of the SAME gallery (same videos, same lengths) that was zero-filled -
+        their padding is still zero, whatever was written into the valid rows."""
         if L > MAX_CLIPS:
             raise native.NativeError(f"at most {MAX_CLIPS} clips per video (config max_ctx_l); got {L}")
         L_ = native.lib()
         self.nv, self.L, self.normalize, self.filled = nv, L, normalize, 0
-        self.blobs = [torch.empty(L_.dldkd_packed_gallery_bytes(nv, L), dtype=torch.uint8, device=device)
-                      for _ in range(n_branches)]
+        nbytes = L_.dldkd_packed_gallery_bytes(nv, L)
+        if blobs is not None:
+            if len(blobs) != n_branches or any(b.numel() != nbytes or b.device != torch.device(device) for b in blobs):
+                raise native.NativeError("GalleryPacker: the buffers handed in do not fit this gallery")
+            self.blobs, self.zero_padded = list(blobs), True
+        else:
+            alloc = torch.zeros if zero_fill else torch.empty
+            self.blobs = [alloc(nbytes, dtype=torch.uint8, device=device) for _ in range(n_branches)]
+            self.zero_padded = bool(zero_fill)
         self.lens = torch.zeros(max(nv, 1), dtype=torch.int32, device=device)
 
     @property

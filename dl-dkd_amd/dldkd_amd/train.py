@@ -612,19 +612,44 @@ class GraphedTrainStep:
             e.par["tail"] = open_graph(self.stream, "main")  # the sum of the two branches' terms
             return res
 
-        m._tower_runner, m._branch_runner = runner, branch_runner
-        try:
+        import contextlib
+
+        @contextlib.contextmanager
+        def pre_ln_hook(dual):
+            # dual: the model is about to enqueue the ONE launch that writes both video towers' LayerNorm rows.  It becomes a graph of
+            # its own on the FIRST VIDEO TOWER's stream (and in that tower's pool: replayed there in front of the tower's forward
+            # graph); the other video tower's stream waits for it.  On the main stream it would sit in front of the teacher scores
+            # and a query tower - the chain the step's loss section waits for (measured: no gain there).
+            if dual:
+                if m._side_streams is None or m._side_streams[0].device != dev:
+                    m._side_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+                n_q = 2 if m.QUERY_TOWERS_FIRST else 0             # (double branch: towers [q, q, v, v] or [v, v, q, q])
+                e.par["pre0_tower"] = n_q
+                st = ([self.stream] + list(m._side_streams))[n_q]
+                e.par["pre0"] = open_graph(st, ("tower", n_q))
+                try:
+                    yield
+                finally:
+                    close_graph()
+            else:
+                yield
             e.par["pre"] = open_graph(self.stream, "main")
+            if e.par.get("zero_norms") is not None:
+                e.par["zero_norms"]()
+
+        m._tower_runner, m._branch_runner, m._pre_ln_hook = runner, branch_runner, pre_ln_hook
+        try:
+            # (the first main-stream graph is opened by pre_ln_hook, which the model enters first thing in forward_tensors)
             # the clip's per-tensor sums of squares are accumulated by the towers' gathers (one pass over a tower's gradients on that
             # tower's stream: FlatParams._gather) into the scratch zeroed here, at the head of the step; the optimizer graph is then
             # the update alone
-            norm2 = None
             # (data parallel: the clip's norms are those of the all-reduced gradients - the optimizer graph computes them itself)
-            if (self.GATHER_WITH_NORMS and not e.ddp and hasattr(opt_, "zero_norms")
-                    and opt_.param_groups[0].get("max_grad_norm", -1) > 0):
-                opt_.zero_norms()
-                norm2 = opt_.norm2
+            want_norms = (self.GATHER_WITH_NORMS and not e.ddp and hasattr(opt_, "zero_norms")
+                          and opt_.param_groups[0].get("max_grad_norm", -1) > 0)
+            e.par["zero_norms"] = opt_.zero_norms if want_norms else None       # (enqueued by pre_ln_hook at the head of "pre")
+            norm2 = opt_.norm2 if want_norms else None
             loss, parts, phases = m.forward_phased(e.static, staged=e)
+            e.par.pop("zero_norms", None)
             if any(t is None or id(t) not in stream_of for t, _ in phases) or "tail" not in e.par:
                 raise RuntimeError("parallel tower graphs: a backward phase is not one of the towers")
             e.loss, e.parts = loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in parts.items()}
@@ -666,11 +691,12 @@ class GraphedTrainStep:
             e.par["ev"] = {"fwd": [torch.cuda.Event() for _ in range(n)], "bwd": [torch.cuda.Event() for _ in range(n)],
                            "loss": [torch.cuda.Event() for _ in e.par["loss"]]}
             e.par["ev_pre"], e.par["ev_pre_done"], e.par["ev_in_video"] = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            e.par["ev_ln"] = torch.cuda.Event()
         except BaseException as ex:
             close_graph(type(ex), ex, ex.__traceback__)
             raise
         finally:
-            m._tower_runner = m._branch_runner = None
+            m._tower_runner = m._branch_runner = m._pre_ln_hook = None
 
     def _replay_parallel(self, e):
         par, main = e.par, self.stream
@@ -678,6 +704,15 @@ class GraphedTrainStep:
         # the towers read the staged batch only (the zero arena of the graph in front is for the backward passes, which wait for
         # a loss graph that runs behind it): the side streams start here, beside that graph's teacher scores
         par["ev_pre"].record(main)
+        pre0 = par.get("pre0")
+        if pre0 is not None:
+            # both video towers' input LayerNorm rows from ONE launch (functional.in_proj_ln_dual), on the first video tower's stream
+            # in front of that tower's forward graph; the other video tower waits for it
+            s0 = streams[par["pre0_tower"]]
+            s0.wait_event(par["ev_in_video"] if self.EARLY_VIDEO_START else par["ev_pre"])
+            with torch.cuda.stream(s0):
+                pre0.replay()
+                par["ev_ln"].record(s0)
         par["pre"].replay()
         par["ev_pre_done"].record(main)
         for i in par["order"]:
@@ -687,7 +722,11 @@ class GraphedTrainStep:
             # then the wrong way round for the short C5 towers - not kept)
             early = self.EARLY_VIDEO_START and par["video"][i] and streams[i] is not main
             if streams[i] is not main:
-                streams[i].wait_event(par["ev_in_video"] if early else par["ev_pre"])
+                if pre0 is not None and par["video"][i]:
+                    if i != par["pre0_tower"]:              # (the first video tower's graph follows pre0 on its own stream)
+                        streams[i].wait_event(par["ev_ln"])
+                else:
+                    streams[i].wait_event(par["ev_in_video"] if early else par["ev_pre"])
             with torch.cuda.stream(streams[i]):
                 par["fwd"][i].replay()
                 ev["fwd"][i].record(streams[i])

@@ -156,6 +156,7 @@ int dldkd_stream_wait_counter(void* stream, int32_t* counter, int32_t at_least);
 #define DLDKD_GEMM_F32 0    /* dldkd_gemm_f32   */
 #define DLDKD_GEMM_F32X3 1  /* dldkd_gemm_f32x3 */
 #define DLDKD_GEMM_BF16 2   /* dldkd_gemm_bf16  */
+#define DLDKD_GEMM_F32X2 3  /* dldkd_gemm_f32x2: forward layout and the pooled simpool product only */
 size_t dldkd_gemm_workspace_bytes(int precision, int M, int N, int K, int a_kmajor, int b_kmajor);
 int dldkd_gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda,
                    int ldb, int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes,
@@ -181,6 +182,15 @@ int dldkd_layernorm_dropout_f32(const float* x, const float* add, int add_mod, c
 int dldkd_layernorm_groups_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out,
                                unsigned char* keep, long M, int D, float eps, float p_drop, unsigned long long seed,
                                unsigned long long offset, const unsigned long long* state, const unsigned char* group_flags, void* stream);
+/* The general form of the LayerNorm launches in this section (LayerNorm(x [+ add]) [-> inverted dropout]): any of the outputs -
+ * fp32 rows, bf16 rows (both may be given: "mixed" training keeps fp32 rows for its forward GEMM and bf16 rows for the backward
+ * pass), keep bytes (NULL with p_drop > 0: the mask is applied, not written), statistics [2][M] - and either filter: row_mask (M
+ * floats; group_flags_out then receives the 32-row group flags) or group_flags_in (flags an earlier launch wrote).  Semantics of each
+ * as documented at dldkd_layernorm_dropout_f32 / _groups_f32 / _dropout_bf16. */
+int dldkd_layernorm_ex_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out_f32,
+                           void* out_bf16, unsigned char* keep, float* stats, long M, int D, float eps, float p_drop,
+                           unsigned long long seed, unsigned long long offset, const unsigned long long* state, const float* row_mask,
+                           unsigned char* group_flags_out, const unsigned char* group_flags_in, void* stream);
 /* The fp32-row twin of dldkd_layernorm_dropout_bf16 (parity mode): same row mask / group flags / statistics, fp32 output. */
 int dldkd_layernorm_dropout_rows_f32(const float* x, const float* gamma, const float* beta, float* out, unsigned char* keep, float* stats,
                                      long M, int D, float eps, float p_drop, unsigned long long seed, unsigned long long offset,
@@ -354,6 +364,15 @@ int dldkd_gemm_bf16(const float* A, const float* B, const float* bias, float* C,
  *   dw == 0           k_flags, if given, are per 32 ROWS of A16 / C (M % 128 == 0): the groups flagged 0 are not multiplied. */
 int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
                           int ldc, int relu, void* workspace, size_t workspace_bytes, const unsigned char* k_flags, void* stream);
+/* dldkd_layernorm_dropout_bf16 for BOTH branches' input projections over the same raw rows in one pass (the inheritance and the
+ * exploration video tower normalise the same student features: method/model.py:229-243, model_components.py:305-310): x is read
+ * once, mean / rstd taken once (stats: shared by the two backward passes), the row written twice - out0 = LN(x; gamma0, beta0)
+ * with the dropout bits of (seed, offset0), out1 likewise with (gamma1, beta1, offset1) - exactly what two calls of
+ * dldkd_layernorm_dropout_bf16 with keep == NULL write.  row_mask / group_flags as there. */
+int dldkd_layernorm_dropout_bf16_dual(const float* x, const float* gamma0, const float* beta0, const float* gamma1, const float* beta1,
+                                      void* out0_bf16, void* out1_bf16, float* stats, long M, int D, float eps, float p_drop,
+                                      unsigned long long seed, unsigned long long offset0, unsigned long long offset1,
+                                      const unsigned long long* state, const float* row_mask, unsigned char* group_flags, void* stream);
 /* dldkd_gemm_bf16_nt with BOTH operands bf16 in memory (A (M, K) = the rows dldkd_layernorm_dropout_bf16 writes, B (N, K) = the
  * weight cast by dldkd_cast_bf16): k-tiles of 64, no conversion on the way to the MFMA, half the dependent tile round trips.  The
  * forward GEMM of the training input projection (LinearLayer.forward, model_components.py:305-312).  K % 64 == 0, lda / ldb % 8 == 0,
@@ -408,6 +427,13 @@ int dldkd_gemm_bf16_nt_ok(int M, int N, int K, int lda, int ldb);
  * accuracy; the host mirror uses it for precision "fp32" and keeps the true fp32-input MFMA as "fp32_exact". */
 int dldkd_gemm_f32x3(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
                      int ldc, int a_kmajor, int b_kmajor, int relu, void* workspace, size_t workspace_bytes, void* stream);
+/* The two-plane form of dldkd_gemm_f32x3 for the FORWARD layout (C = act(A B^T + bias), A (M, K), B (N, K) row-major): every fp32
+ * operand split into two bf16 planes, three MFMAs per product instead of six, ~2^-16 relative error per product instead of 2^-24.
+ * The forward pass of the "mixed" training precision (ops.set_gemm_precision("mixed")): measured on the seven losses of the C3 / C5
+ * steps it stays inside north_star's 1e-4 with a wide margin (tests/test_train_mode_gpu.py), at two thirds of the three-plane time.
+ * row_flags as dldkd_gemm_f32x3_flags (forward layout). */
+int dldkd_gemm_f32x2(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                     int relu, const unsigned char* row_flags, void* stream);
 /* dldkd_gemm_f32x3 with a filter for the rows of the padding: flags = one byte per 32 rows of the ACTIVATION operand - A's rows
  * when A is k-minor (forward / dX; M % 128 == 0: groups flagged 0 are not multiplied, their C rows come out as act(bias)), the
  * contraction index when both operands are k-major (dW: the k-tiles of groups flagged 0 - zero rows of dy - are skipped). */
@@ -557,6 +583,16 @@ int dldkd_attention_train_bwd_bf16io(const void* qkv, const float* mask, const i
  *       relu_mask (the ReLU of LinearLayer, model_components.py:311), else dy0 = dx1.
  * Weight gradients are dldkd_gemm_bf16_mixed(dw = 3 / 1) over the saved bf16 rows, bias gradients dldkd_colsum_bf16 /
  * dldkd_colsum_f32. */
+/* "mixed" training precision (fp32-grade forward, bf16 backward): after a tower's forward pass on the fp32-grade kernels, ONE launch
+ * writes from its fp32 intermediates the bf16 rows the fused backward kernels above read (what f1 / f3 save in throughput mode):
+ * xh1 = ((y0 + pos) - mean1) rstd1 with bit 0 = [y0 > 0], h1d = bf16(h1), qkv16, ctx16, xh2 = ((dd + h1) - mean2) rstd2, rstd2,
+ * h2_16 (video towers; h2 = h2_16 = NULL otherwise).  y0, h1 (the position LayerNorm's output behind its dropout), ctx, dd (the
+ * dense layer's output behind its dropout), h2: (M, 384) fp32; qkv (M, 1152); stats1 / stats2 [2][M] = (mean, rstd) of the two
+ * LayerNorms (dldkd_layernorm_ex_f32); pos (>= L, 384); flags: the tower's 32-row group flags or NULL (rows of groups flagged 0
+ * are not written).  Reference: model_components.py:277-284, 398-450. */
+int dldkd_tower_train_emit(const float* y0, const float* pos, int L, const float* stats1, const float* h1, const float* qkv,
+                           const float* ctx, const float* dd, const float* stats2, const float* h2, const unsigned char* flags, long M,
+                           void* xh1, void* h1d, void* qkv16, void* ctx16, void* xh2, float* rstd2, void* h2_16, void* stream);
 size_t dldkd_tower_train_pack_bytes(int n_mats);
 int dldkd_tower_train_pack(const float* const* host_src, const int* host_nsrc, const int* host_mode, void* const* host_out, int njobs,
                            void* stream);
@@ -796,10 +832,13 @@ int dldkd_tower_seq_h16(const float* const* h0, const void* const* blob, const i
                          int out_mode, float* const* out_rows, int seq_rows, void* const* gallery, int v0, int Lp, int32_t* lens_out,
                          int32_t* nonfinite_flag, void* stream);
 /* out_mode 1 from h16 h0 rows (dldkd_in_proj_h16_rows128b_out16; ragged: row0 required): the prologue is one round of
- * 16-byte loads straight into the operand registers (no LDS staging); everything else as above. */
+ * 16-byte loads straight into the operand registers (no LDS staging); everything else as above.  skip_zero_rows != 0: the rows
+ * >= ceil(lens / 16) * 16 of a video - which the scorers never load - are not written: the caller's gallery buffer holds zeros there
+ * already (zero-filled once; a dataset's lengths do not change between epochs). */
 int dldkd_tower_seq_h16_rows16(const void* const* h0_h16, const void* const* blob, const int32_t* row0,
                              const int32_t* lens, const int32_t* items, int n_items, int n_seq, int n_branches,
-                             void* const* gallery, int v0, int Lp, int32_t* lens_out, int32_t* nonfinite_flag, void* stream);
+                             void* const* gallery, int v0, int Lp, int32_t* lens_out, int32_t* nonfinite_flag, int skip_zero_rows,
+                             void* stream);
 
 /* Diagnostics: the out_mode 1 kernel (two branches) with clock stamps at its phase boundaries; stamps = 24 x uint64 per workgroup
  * (h16 != 0: h0 holds h16 rows, the dldkd_tower_seq_h16_rows16 kernel)

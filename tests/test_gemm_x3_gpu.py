@@ -58,3 +58,31 @@ def test_x3_error_is_fp32_grade_not_bf16_grade(x3):
     yb = ops.linear(x.to(DEV), w.to(DEV)).cpu().double()
     e3, e1, eb = (y3 - ref).abs().max().item(), (y1 - ref).abs().max().item(), (yb - ref).abs().max().item()
     assert e3 < 4 * e1 + 1e-6 and e3 < eb / 200, (e3, e1, eb)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 4), (130, 70, 20), (257, 384, 3072), (1024, 1152, 384), (64, 384, 770)])
+def test_x2_forward_is_two_plane_grade(M, N, K):
+    """The two-plane form (ops "fp32x2", the forward GEMMs of the "mixed" training precision): ~2^-16 per product, i.e. between the
+    three-plane kernel (2e-6 at these shapes) and bf16 (4e-3); same bias / ReLU / row-flag semantics as the three-plane entry."""
+    from dldkd_amd import ops
+    old = ops.precision_mode()
+    ops.set_gemm_precision("fp32x2")
+    try:
+        g = torch.Generator().manual_seed(M + N + K)
+        x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+        ref = x.double() @ w.double().t() + b.double()
+        y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=True)
+        e2 = _rel(y, torch.relu(ref))
+        assert e2 < 4e-5, e2
+        if M % 128 == 0:                                       # row flags: groups flagged 0 are not multiplied (their rows: act(bias))
+            flags = torch.ones(M // 32, dtype=torch.uint8, device=DEV)
+            flags[1::4] = 0
+            yf = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=True, row_flags=flags)
+            keep = flags.bool().repeat_interleave(32).cpu()
+            assert torch.equal(yf.cpu()[keep], y.cpu()[keep])
+            assert torch.allclose(yf.cpu()[~keep], torch.relu(b).expand(int((~keep).sum()), N))
+        ops.set_gemm_precision("fp32x3")
+        e3 = _rel(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=True), torch.relu(ref))
+        assert e3 <= e2 or e2 < 1e-6
+    finally:
+        ops.set_gemm_precision(old)

@@ -255,6 +255,10 @@ def test_train_step_at_full_size_train_mode_vs_oracle(monkeypatch, name, prec):
         worst_loss = max(worst_loss, abs(got - ref[k]) / max(abs(ref[k]), 1e-3 if exact_fwd else 0.1))
         assert abs(got - ref[k]) <= tol * max(abs(ref[k]), 1e-3 if exact_fwd else 0.1), (k, got, ref[k])
     print(f"  {name} {prec}: worst loss error {worst_loss:.3e} (relative)")
+    if prec == "mixed":
+        # the forward GEMMs of "mixed" run two bf16 planes per operand (ops.MIXED_FORWARD = "fp32x2", ~2^-16 per product): the
+        # seven losses must sit well inside north_star's 1e-4 (<= 3e-5)
+        assert worst_loss <= 3e-5, worst_loss
     stats = _grad_stats(m, ref_grads)
     if prec == "fp32":
         _assert_grads(stats, 1e-3, f"{name} parity ({skipped}/{groups} groups skipped)")
@@ -323,3 +327,40 @@ def test_replayed_multi_graph_step_and_bert_adam_vs_oracle(name, prec):
         assert tot_err / tot_mov <= 1e-3 and frac_bad <= 1e-4 * n_el, (tot_err / tot_mov, frac_bad)
     else:
         assert tot_err / tot_mov <= 0.15, tot_err / tot_mov      # measured 0.07 - 0.08
+
+
+# ------------------------------------------------------------------------------------------------ "mixed" precision with dropout on
+def test_mixed_mode_with_dropout_draws_the_parity_modes_masks_and_agrees_with_it():
+    """ops.set_gemm_precision("mixed"): fp32-grade forward chain + the fused bf16 backward (functional._TowerTrainMixed).  With
+    dropout ON the oracle cannot be the yardstick (its masks are torch's), but the parity mode can: same seed -> the same Philox
+    slots in the same order -> the same masks in every layer (input projection, position LayerNorm, attention probabilities, hidden)
+    - so the seven losses agree to 1e-5 and the gradients to bf16-product grade.  A mask convention that differed anywhere (e.g. the
+    fp32 attention forward against the bf16 attention backward's recomputed bits) would show as a gradient error of order one."""
+    from dldkd_amd import ops
+    params, batch, hard, dv, dq, nv = _size_case("c5")
+    dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    res = {}
+    try:
+        for prec in ("fp32", "mixed"):
+            ops.set_gemm_precision(prec)
+            m = _train_model(dv, dq, params, hard, drop=0.15)
+            m.weight = 1.0
+            torch.manual_seed(SEED0)
+            loss, d = m(dbatch)
+            m.zero_grad()
+            loss.backward()
+            torch.cuda.synchronize()
+            res[prec] = ({k: float(d[k]) for k in LOSS_KEYS}, {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()})
+    finally:
+        ops.set_gemm_precision("fp32")
+    for k in LOSS_KEYS:
+        a, b = res["mixed"][0][k], res["fp32"][0][k]
+        assert abs(a - b) <= 1e-5 * max(abs(b), 1e-3), (k, a, b)
+    nmax = max(float(g.norm()) for g in res["fp32"][1].values())
+    worst = 0.0
+    for n, r in res["fp32"][1].items():
+        g = res["mixed"][1][n]
+        rel = float((g - r).norm()) / max(float(r.norm()), 1e-4 * nmax)
+        worst = max(worst, rel)
+        assert rel <= 0.03, (n, rel)
+    print(f"  mixed vs parity with dropout 0.15 (same masks): worst gradient rel l2 difference {worst:.3e}")

@@ -1,0 +1,137 @@
+"""Wall-clock of the metric's own top-level call - dldkd_amd.eval.eval_epoch(model, video_dataset, text_dataset, opt) - at BASELINE
+configs[1] size (C2: 21,793 videos x U{24..128} clips x 3072-d, 10,895 captions x U{5..30} words x 768-d) on in-memory datasets that
+obey the protocol of method/data_provider.py:307-309,344-354, host side included (DataLoader, collate, H2D, get_gt, cache replay):
+
+    first_epoch_from_host   the first call: every feature crosses PCIe once, the resident fp16 table is built
+    cached_epoch            a later call (opt.eval_feature_cache, the default): features device-resident
+    cProfile top-10 of a cached epoch -> profiles (python3 tools/bench_eval_epoch_c2.py --profile out.txt)
+    oracle_sample           the CPU oracle's eval (towers + scoring + ranking, fp32) on a stated sample: the CPU baseline beside it
+
+Items are views into a small pool of random base tensors (256 videos / 512 captions): the datasets cost 0.6 GB of host memory, not
+34 GB, and every item is still its own (len, D) tensor with its own length and id."""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("dl-dkd_amd", "tests/golden", "oracle"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+class PoolDataset(torch.utils.data.Dataset):
+    def __init__(self, pool, lens, ids):
+        self.pool, self.lens, self.ids = pool, lens, ids
+        self.video_ids = ids                                   # (eval.gallery_ids reads it without touching features)
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, i):
+        return self.pool[i % len(self.pool)][:self.lens[i]], i, self.ids[i]
+
+
+def make_sets(nv, nq, seed=2, dv=3072, dq=768, n_pool_v=256, n_pool_q=512):
+    g = torch.Generator().manual_seed(seed)
+    pv = torch.nn.functional.normalize(torch.randn(n_pool_v, 128, dv, generator=g), dim=-1)
+    pq = torch.nn.functional.normalize(torch.randn(n_pool_q, 30, dq, generator=g), dim=-1)
+    rs = np.random.RandomState(seed)
+    vlens, qlens = rs.randint(24, 129, size=nv), rs.randint(5, 31, size=nq)
+    vids = [f"vid{i:05d}" for i in range(nv)]
+    caps = [f"vid{j % nv:05d}#enc#{j // nv}" for j in range(nq)]
+    return PoolDataset(list(pv), vlens, vids), PoolDataset(list(pq), qlens, caps)
+
+
+def build_model(dev):
+    from dldkd_amd.model import DLDKD
+    cfg = types.SimpleNamespace(visual_input_size=3072, query_input_size=768, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=128, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4, initializer_range=0.02,
+                                margin=0.1, use_hard_negative=True, hard_pool_size=20, label_style="soft")
+    mopt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                 collection="tvr", alpha=0.8, belta=0.8)
+    torch.manual_seed(0)
+    return DLDKD(cfg, mopt).to(dev).eval()
+
+
+def oracle_sample(nv_s=256, nq_s=500, seed=2):
+    """The oracle's whole eval (fp32 CPU towers from raw features, scoring in 50-query chunks, ranking) on nv_s videos x nq_s captions."""
+    import dldkd_oracle as orc
+    import synth
+    vds, tds = make_sets(nv_s, nq_s, seed)
+    params = {k: v for k, v in build_model("cpu").state_dict().items()}
+    t0 = time.perf_counter()
+    L = int(max(vds.lens))
+    feat, mask = torch.zeros(nv_s, L, 3072), torch.zeros(nv_s, L)
+    for i in range(nv_s):
+        f = vds[i][0]
+        feat[i, :f.shape[0]], mask[i, :f.shape[0]] = f, 1.0
+    g_inh, g_exp = orc.encode_context(params, feat, mask)
+    Lq = int(max(tds.lens))
+    qf, qm = torch.zeros(nq_s, Lq, 768), torch.zeros(nq_s, Lq)
+    for i in range(nq_s):
+        f = tds[i][0]
+        qf[i, :f.shape[0]], qm[i, :f.shape[0]] = f, 1.0
+    q_inh, q_exp = orc.encode_query(params, qf, qm)
+    inh, exp = orc.eval_scores(q_inh, q_exp, g_inh, g_exp, mask)
+    met = orc.eval_metrics(inh.numpy(), exp.numpy(), vds.ids, tds.ids)
+    dt = time.perf_counter() - t0
+    return {"seconds": dt, "videos": nv_s, "captions": nq_s, "threads": torch.get_num_threads(), "sumr": met["sumr"],
+            "pairs_per_s_end_to_end": nv_s * nq_s / dt}
+
+
+def run(dev="cuda:0", nv=21793, nq=10895, profile_path=None, bsz=200, oracle=True):
+    from dldkd_amd import eval as ev
+    dev = torch.device(dev)
+    m = build_model(dev)
+    vds, tds = make_sets(nv, nq)
+    opt = types.SimpleNamespace(eval_context_bsz=bsz, eval_query_bsz=50, num_workers=0, pin_memory=False, device=dev,
+                                double_branch=True, eval_precision="throughput", eval_feature_cache=True)
+    out = {"videos": nv, "captions": nq, "eval_context_bsz": bsz, "eval_query_bsz": 50, "num_workers": 0, "mode": "throughput"}
+    ev.clear_feature_cache()
+    with torch.no_grad():
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        s0 = ev.eval_epoch(m, vds, tds, opt)
+        torch.cuda.synchronize(); out["first_epoch_from_host_s"] = time.perf_counter() - t0
+        ev.eval_epoch(m, vds, tds, opt)                                   # allocator pools settle
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            s1 = ev.eval_epoch(m, vds, tds, opt)
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        out["cached_epoch_s"] = sorted(ts)[len(ts) // 2]
+        out["cached_epoch_s_all"] = [round(t, 4) for t in ts]
+        out["sumr_first_vs_cached"] = [s0, s1]
+        if profile_path:
+            import cProfile
+            import io
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            ev.eval_epoch(m, vds, tds, opt)
+            torch.cuda.synchronize()
+            pr.disable()
+            buf = io.StringIO()
+            pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(30)
+            buf2 = io.StringIO()
+            pstats.Stats(pr, stream=buf2).sort_stats("tottime").print_stats(12)
+            with open(profile_path, "w") as f:
+                f.write(f"# cProfile of ONE cached eval_epoch at C2 ({nv} videos / {nq} captions), throughput mode\n")
+                f.write(buf.getvalue()); f.write("\n# by own time\n"); f.write(buf2.getvalue())
+    ev.clear_feature_cache()
+    if oracle:
+        out["oracle_sample"] = oracle_sample()
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nv", type=int, default=21793)
+    ap.add_argument("--nq", type=int, default=10895)
+    ap.add_argument("--profile", default=None)
+    ap.add_argument("--no-oracle", action="store_true")
+    a = ap.parse_args()
+    print(json.dumps(run(nv=a.nv, nq=a.nq, profile_path=a.profile, oracle=not a.no_oracle), indent=1))

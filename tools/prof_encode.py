@@ -56,11 +56,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "resident":
     res.complete = True
     res.plan(torch.device(DEV))
     with torch.no_grad():
+        # as eval._resident_context_info does for a cached table: the packed gallery's buffers are zero-filled once and re-encoded in
+        # place (DLDKD_SKIP_ZERO_ROWS=0: the kernel writes the padding rows every time)
+        first = scoring.GalleryPacker(NV, 128, 2, torch.device(DEV), zero_fill=True)
+        mk = lambda: scoring.GalleryPacker(NV, 128, 2, torch.device(DEV), blobs=first.blobs)      # noqa: E731
         for _ in range(2):
-            pk = scoring.GalleryPacker(NV, 128, 2, torch.device(DEV)); m.encode_resident_into(pk, res)
+            pk = mk(); m.encode_resident_into(pk, res)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(5):
-            pk = scoring.GalleryPacker(NV, 128, 2, torch.device(DEV)); m.encode_resident_into(pk, res)
+            pk = mk(); m.encode_resident_into(pk, res)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
     print(f"encode_resident_into {NV} videos ({res.table.rows} clips, {res.table.nbytes()/1e9:.1f} GB resident): {dt*1e3:.2f} ms = {NV/dt:.0f} videos/s")
     sys.exit(0)
