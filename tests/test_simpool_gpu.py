@@ -5,7 +5,7 @@ Two yardsticks per case:
     -> only fp32 accumulation order (and an occasional 1-ulp bf16 flip from the normalisation being
     summed in a different order on CPU and GPU) differs -> tolerance 1e-4.  Catches layout / mask / max bugs.
   * "reference": the oracle in fp32 on the original fp32 inputs (what the reference computes)
-    -> adds bf16 operand rounding -> tolerance 6e-3 absolute on cosine scores in [-1, 1].
+    -> adds bf16 operand rounding -> tolerance 1.5e-3 absolute on cosine scores in [-1, 1] (measured 4-5e-4; 6e-3 until round 5).
 """
 import numpy as np
 import pytest
@@ -18,7 +18,7 @@ import synth
 pytestmark = pytest.mark.gpu
 
 TOL_EXACT = 1e-4
-TOL_BF16 = 6e-3
+TOL_BF16 = 1.5e-3
 
 
 def _bf16_round(x):

@@ -7,7 +7,7 @@
 #   bash tools/ab.sh env  <VAR>    "<v0 v1 v0 v1>" <bench> [kernel-regex]     environment switch of the library / host package
 #                                                                              (DLDKD_LN_DUAL, DLDKD_TN_NST, DLDKD_TN_TARGET,
 #                                                                              DLDKD_TOWER_PREPACK, DLDKD_TOWER_LN_SUMS, DLDKD_H0_H16 ...)
-#   <bench>: simpool | finish | encode | tower | k4b | train-c3 | train-c5 | train-c3-mixed | "<any command>"
+#   <bench>: simpool | simpool-pmc | finish | encode | tower | k4b | train-c3 | train-c5 | train-c3-mixed | "<any command>"
 #   kernel-regex (train-* only): also print the rocprofv3 --kernel-trace --stats averages of the matching kernels (eager step)
 #
 # Replaces the 60 one-off tools/r04_*.sh / r05_*.sh scripts of rounds 4-5 (git history has them; tools/README.md maps each table
@@ -24,6 +24,13 @@ js() { python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d.get(
 run_bench() {
   case "$BENCH" in
     simpool)  python3 $R/tools/bench_simpool.py --iters 10 2>/dev/null | tail -2 ;;
+    simpool-pmc)   # kernel time + HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, one --pmc pass each: no trace domains beside counters)
+      python3 $R/tools/bench_simpool.py --iters 10 2>/dev/null | tail -2
+      ( cd /tmp && TMPDIR=/tmp rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -- python3 $R/tools/bench_simpool.py --iters 3 > $O/f.log 2>&1
+        TMPDIR=/tmp rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -- python3 $R/tools/bench_simpool.py --iters 3 > $O/w.log 2>&1 )
+      python3 $R/tools/pmc_summary.py simpool_eval16p_kernel 17.0 $O/s.json $O/f $O/w > /dev/null 2>&1
+      python3 -c "import json; d=json.load(open('$O/s.json'))['derived']; print({k: round(v,3) for k,v in d.items() if 'hbm' in k})"
+      rm -rf $O/f $O/w ;;
     finish)   python3 $R/tools/bench_finish.py 2>/dev/null | tail -2 ;;
     encode)   ENC_BATCH=1024 python3 $R/tools/prof_encode.py resident 2>/dev/null | tail -1 ;;
     tower)    python3 $R/tools/bench_tower.py 1024 2>/dev/null | tail -1 ;;

@@ -12,10 +12,10 @@ import bench_train as B  # noqa: E402
 import torch  # noqa: E402
 
 
-def main(config="c5", mode="sync", steps=30, warmup=10):
+def main(config="c5", mode="sync", steps=30, warmup=10, prec="bf16"):
     from dldkd_amd import ops
     from dldkd_amd import train as T
-    ops.set_gemm_precision("bf16")
+    ops.set_gemm_precision(prec)
     m, opt, batch = B.build(config, 0.2, "cuda:0")
     g = T.GraphedTrainStep(m, opt, types.SimpleNamespace(grad_clip=-1), defer_loss_float=(mode != "sync"))
     for _ in range(warmup):
@@ -40,12 +40,23 @@ def main(config="c5", mode="sync", steps=30, warmup=10):
         t0 = E()
         t0.record(main)
         par["ev_pre"].record(main)
+        pre0 = par.get("pre0")
+        if pre0 is not None:                                # (round 6: both video towers' input LayerNorm, on the first video tower's stream)
+            s0 = streams[par["pre0_tower"]]
+            s0.wait_event(par["ev_in_video"] if g.EARLY_VIDEO_START else par["ev_pre"])
+            with torch.cuda.stream(s0):
+                span("pre0_ln_dual", s0, pre0)
+                par["ev_ln"].record(s0)
         span("pre", main, par["pre"])
         par["ev_pre_done"].record(main)
         for i in par["order"]:
             early = g.EARLY_VIDEO_START and par["video"][i] and streams[i] is not main
             if streams[i] is not main:
-                streams[i].wait_event(par["ev_in_video"] if early else par["ev_pre"])
+                if pre0 is not None and par["video"][i]:
+                    if i != par["pre0_tower"]:
+                        streams[i].wait_event(par["ev_ln"])
+                else:
+                    streams[i].wait_event(par["ev_in_video"] if early else par["ev_pre"])
             with torch.cuda.stream(streams[i]):
                 span(f"fwd{i}{'v' if par['video'][i] else 'q'}", streams[i], par["fwd"][i])
                 ev["fwd"][i].record(streams[i])
@@ -86,4 +97,5 @@ def main(config="c5", mode="sync", steps=30, warmup=10):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "c5", sys.argv[2] if len(sys.argv) > 2 else "sync")
+    main(sys.argv[1] if len(sys.argv) > 1 else "c5", sys.argv[2] if len(sys.argv) > 2 else "sync",
+         prec=sys.argv[3] if len(sys.argv) > 3 else "bf16")
