@@ -316,6 +316,13 @@ def extras(dev):
         # round 3, second half: what eval_epoch runs now - the gallery's raw features resident as a ragged fp16 table with the
         # rows' LayerNorm statistics (filled once), K4b over the whole table + the fused tower kernel over all videos
         out["eval_epoch_gpu_stages_resident"] = stage_times(NV, NQ, "resident", str(dev))
+        # round 6: the wall-clock of the metric's own top-level call, host side included - dldkd_amd.eval.eval_epoch on in-memory
+        # datasets of C2 size (method/data_provider.py:307-309,344-354's protocol) - and the oracle's eval on a stated sample beside it
+        try:
+            import bench_eval_epoch_c2
+            out["eval_epoch_wall_s_c2"] = bench_eval_epoch_c2.run(str(dev), NV, NQ)
+        except Exception as ex:   # noqa: BLE001 - an extra never takes the headline line down
+            out["eval_epoch_wall_s_c2"] = {"error": repr(ex)[:300]}
         out["gallery_encode_videos_per_s_resident_k4b_k5"] = out["eval_epoch_gpu_stages_resident"].get("gallery_videos_per_sec")
         import types as _t
         cfg2 = cfg
@@ -657,7 +664,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    sustained = mfma_sustained() if (world == 1 and rank == 0) else None    # child process, before this one touches the GPU
+    # (child process, before this one touches the GPU; DLDKD_BENCH_NO_MFMA_PROBE=1: skipped - the PMC passes of
+    #  tools/collect_profiles_r06.sh profile THIS script's loop and want no second program under the profiler)
+    sustained = mfma_sustained() if (world == 1 and rank == 0 and os.environ.get("DLDKD_BENCH_NO_MFMA_PROBE") != "1") else None
     if world != a.gpus and not (world == 1 and os.environ.get("DLDKD_BENCH_FORCE_DIST") == "1"):
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: start one rank per GPU (or leave WORLD_SIZE unset and "
                          "let bench.py start them)")
@@ -758,13 +767,13 @@ def main():
         # KiB units; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md section HBM) from the committed
         # profile of this same workload.  Not re-measured live (PMC needs the profiler).
         traffic, traffic_src = None, None
-        for pmc in [os.path.join(ROOT, "profiles", "r05", "pmc_simpool.json")] + [os.path.join(ROOT, "profiles", r_, "pmc_simpool", "summary.json")
+        for pmc in [os.path.join(ROOT, "profiles", r_, "pmc_simpool.json") for r_ in ("r06", "r05")] + [os.path.join(ROOT, "profiles", r_, "pmc_simpool", "summary.json")
                                                                                   for r_ in ("r04", "r03", "r02")]:
             rnd = os.path.relpath(pmc, os.path.join(ROOT, "profiles")).split(os.sep)[0]
             if os.path.exists(pmc):
                 d = json.load(open(pmc))
                 traffic = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
-                traffic_src = f"{os.path.relpath(pmc, ROOT)} (rocprofv3 --pmc, separate passes; 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KiB units)"
+                traffic_src = f"{os.path.relpath(pmc, ROOT)} (rocprofv3 --pmc on `bench.py --no-extras --no-cpu-baseline` itself since round 6, separate passes; 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KiB units)"
                 break
         out = {
             "metric": metric, "value": NQ * NV * a.steps / dt, "unit": "pairs/s", "n_gpus": 1,

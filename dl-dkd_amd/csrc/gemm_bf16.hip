@@ -933,7 +933,7 @@ extern "C" int dldkd_tower_train_dw_ln(const void* const* host_A, const int* hos
     }
     // ln_grads = [dgamma2 | dbeta2 | dgamma1 | dbeta1] (the order of the row kernels' accumulators)
     const LnJob ln[2] = {{dh2, (const unsigned short*)xh2, ln_grads, ln_grads + kHidden, dh2_is_bf16 ? 1 : 0, 0},
-                         {dz1_bf16, (const unsigned short*)xh1, ln_grads + 2 * kHidden, ln_grads + 3 * kHidden, 1, 1}};
+                         {dz1_bf16, (const unsigned short*)xh1, ln_grads + 2 * kHidden, ln_grads + 3 * kHidden, 1, 0}};   // (xh1 carries no flag bit since round 6)
     return tower_train_dw_impl(host_A, host_lda, host_acol, host_a16, host_B, n_blocks, rows, dW, dbias, workspace, workspace_bytes, k_flags,
                                dx1, dpos, n_seq, cols, ln, 2, stream);
 }

@@ -259,9 +259,12 @@ struct F1Args {
     const unsigned char* flags;
     long M;
     u16* h1d;                    // (M, 384) bf16
-    u16* xh1;                    // (M, 384) bf16 normalised rows of y0 + pos; bit 0 of every element = [y0 > 0] (see b1_kernel)
+    u16* xh1;                    // (M, 384) bf16 normalised rows of y0 + pos (round to nearest even: all 16 bits are value bits)
     float* stats;                // [2][M] mean, rstd of y0 + pos
     u16* qkv;                    // (M, 1152) bf16
+    unsigned char* relu_bits;    // (M, 48) bytes: bit (c % 8) of byte c / 8 of a row = [y0[row, c] > 0] - the ReLU mask of the input
+                                 // projection for b1_kernel, in a plane of its own (round 6; until then bit 0 of every xh1 element, which
+                                 // cost the LayerNorm backward a mantissa bit: ADVICE r04)
 };
 
 __global__ __launch_bounds__(64 * TT_WPB) __attribute__((amdgpu_waves_per_eu(1, 1))) void f1_kernel(const F1Args p) {
@@ -333,15 +336,35 @@ __global__ __launch_bounds__(64 * TT_WPB) __attribute__((amdgpu_waves_per_eu(1, 
             const float v = xh * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
             const unsigned kb = e < 4 ? (k0 >> e) & 1u : (k1 >> (e - 4)) & 1u;
             xb[ks][e] = (short)f32_to_bf16_bits(kb ? v * p.drop.scale : 0.f);
-            // bit 0 carries the ReLU mask: the value is rounded to nearest-even at bit 1 (15 value bits) in ONE step from the fp32
-            // number - not a bf16 with its last bit cleared, which truncates towards zero (a biased 1.5 x 2^-7; this is an unbiased
-            // 2^-7, and b1_kernel sums these rows into dgamma over every row of the batch)
-            const unsigned xu = __float_as_uint(xh);
-            xn[e] = (short)((((xu + 0xffffu + ((xu >> 17) & 1u)) >> 16) & 0xfffeu) | ((relu[ks] >> e) & 1u));
+            xn[e] = (short)f32_to_bf16_bits(xh);
         }
         if (w.valid) {
             *reinterpret_cast<bf16x8*>(p.h1d + w.row * kD + 8 * h + 16 * ks) = xb[ks];
             *reinterpret_cast<bf16x8*>(p.xh1 + w.row * kD + 8 * h + 16 * ks) = xn;
+        }
+    }
+    {
+        // the ReLU mask as a bit plane: this lane's relu[ks] is byte 2 ks + h of its row (columns 16 ks + 8 h ..); one
+        // v_permlane32_swap pairs it with the other half-row lane's byte (r[0] is the h = 0 lane's value on BOTH lanes, r[1] the
+        // h = 1 lane's), and lane h stores ushorts 12 h .. 12 h + 11 of the row's 24: 24 contiguous bytes per lane
+        unsigned wd[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            unsigned lo[2], hi[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                auto a = __builtin_amdgcn_permlane32_swap(relu[12 * hh + 2 * j], relu[12 * hh + 2 * j], false, false);
+                auto b = __builtin_amdgcn_permlane32_swap(relu[12 * hh + 2 * j + 1], relu[12 * hh + 2 * j + 1], false, false);
+                lo[hh] = ((unsigned)a[0] & 0xffu) | (((unsigned)a[1] & 0xffu) << 8);
+                hi[hh] = ((unsigned)b[0] & 0xffu) | (((unsigned)b[1] & 0xffu) << 8);
+            }
+            wd[j] = h ? (lo[1] | (hi[1] << 16)) : (lo[0] | (hi[0] << 16));
+        }
+        if (w.valid && p.relu_bits != nullptr) {
+            unsigned char* rb = p.relu_bits + (size_t)w.row * 48 + 24 * h;
+            *reinterpret_cast<uint2*>(rb) = uint2{wd[0], wd[1]};
+            *reinterpret_cast<uint2*>(rb + 8) = uint2{wd[2], wd[3]};
+            *reinterpret_cast<uint2*>(rb + 16) = uint2{wd[4], wd[5]};
         }
     }
 #pragma unroll 1
@@ -655,9 +678,9 @@ struct B1Args {
     const u16* dqkv;             // (M, 1152) bf16
     const u16* dres;             // (M, 384) bf16
     const bf16x8* wqkvt;         // natural pack of [Wq; Wk; Wv]^T: [72][12][64]
-    const u16* xh1;              // (M, 384) bf16 normalised rows of y0 + pos with bit 0 = [y0 > 0] (f1_kernel): the LayerNorm backward
-                                 // pass reads the value with that bit cleared (rounded to nearest at bit 1 by f1_kernel: 2^-7) and the ReLU mask of the
-                                 // input projection from the bit - neither y0 nor the position rows are read again
+    const u16* xh1;              // (M, 384) bf16 normalised rows of y0 + pos (f1_kernel): all the LayerNorm backward pass needs of them
+    const unsigned char* relu_bits;   // (M, 48) bytes: the input projection's ReLU mask [y0 > 0], one bit per element (f1_kernel; needed
+                                 // when relu_mask) - neither y0 nor the position rows are read again
     const float* stats;          // [2][M]: rstd = stats[M + row]
     const float* gamma;
     Drop drop;
@@ -737,7 +760,7 @@ __global__ __launch_bounds__(64 * TT_WPB) __attribute__((amdgpu_waves_per_eu(1, 
                 const f32x4 gm = vec4(gmp, 32 * t + 8 * g);
                 float res[4], xh[4];
                 unpack4(cr[tt].v[g], res);
-                unpack4(uint2{cx[tt].v[g].x & 0xfffefffeu, cx[tt].v[g].y & 0xfffefffeu}, xh);
+                unpack4(cx[tt].v[g], xh);
                 const unsigned kb = keep4(p.drop, seed, off, didx + 32 * t + 8 * g);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -766,10 +789,17 @@ __global__ __launch_bounds__(64 * TT_WPB) __attribute__((amdgpu_waves_per_eu(1, 
     m2 = hswap_sum(m2) * (1.f / kD);
     Tile4 nxt = load_tile16(xrow, 0);
     u16* dy16r = p.dy16 + w.row * kD + 4 * h;
+    // the ReLU bits of this lane's columns 32 t + 8 g + 4 h ..+4: nibble h of byte 4 t + g of the row = one dword per tile t
+    const unsigned* rbits = reinterpret_cast<const unsigned*>(p.relu_bits + (size_t)w.rowc * 48);
+    unsigned nbits = p.relu_mask ? rbits[0] : 0xffffffffu;
 #pragma unroll
     for (int t = 0; t < kT; ++t) {
         const Tile4 cur = nxt;
-        if (t + 1 < kT) nxt = load_tile16(xrow, t + 1);
+        const unsigned cbits = nbits;
+        if (t + 1 < kT) {
+            nxt = load_tile16(xrow, t + 1);
+            if (p.relu_mask) nbits = rbits[t + 1];
+        }
         __builtin_amdgcn_sched_barrier(0);
         Tile4 ody;
 #pragma unroll
@@ -778,8 +808,8 @@ __global__ __launch_bounds__(64 * TT_WPB) __attribute__((amdgpu_waves_per_eu(1, 
             const f32x4 gm = vec4(gmp, fo);
             float xh[4];
             const uint2 xw = cur.v[g];
-            unpack4(uint2{xw.x & 0xfffefffeu, xw.y & 0xfffefffeu}, xh);
-            const unsigned pos4 = (xw.x & 1u) | ((xw.x >> 15) & 2u) | ((xw.y & 1u) << 2) | ((xw.y >> 13) & 8u);
+            unpack4(xw, xh);
+            const unsigned pos4 = (cbits >> (8 * g + 4 * h)) & 0xfu;
             f32x4 dx, dy;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -965,14 +995,15 @@ int dldkd_tower_train_prepare(const float* const* host_src, const int* host_nsrc
 int dldkd_tower_train_f1(const float* y0, const float* pos, int L, const float* gamma, const float* beta, float eps, float p_drop,
                          unsigned long long seed, unsigned long long offset, const unsigned long long* state, const void* wqkv_pack,
                          const float* bq, const float* bk, const float* bv, const unsigned char* flags, long M, void* h1d, void* xh1,
-                         float* stats, void* qkv, void* stream) {
+                         float* stats, void* qkv, void* relu_bits, void* stream) {
     if (M < 0 || L < 1 || tt::bad_p(p_drop)) { set_error("tower_train_f1: bad sizes"); return DLDKD_EINVAL; }
+    if ((uintptr_t)relu_bits & 7) { set_error("tower_train_f1: relu_bits must be 8-byte aligned"); return DLDKD_EINVAL; }
     if (M == 0) return DLDKD_OK;
     if (!y0 || !pos || !gamma || !beta || !wqkv_pack || !bq || !bk || !bv || !h1d || !xh1 || !stats || !qkv) { set_error("tower_train_f1: null pointer"); return DLDKD_EINVAL; }
     if (((uintptr_t)y0 | (uintptr_t)pos | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)bq | (uintptr_t)bk | (uintptr_t)bv | (uintptr_t)h1d |
          (uintptr_t)xh1 | (uintptr_t)qkv | (uintptr_t)wqkv_pack) & 15) { set_error("tower_train_f1: 16-byte alignment"); return DLDKD_EINVAL; }
     tt::F1Args a{y0, pos, L, gamma, beta, eps, tt::make_drop(p_drop, seed, offset, state), (const bf16x8*)wqkv_pack, {bq, bk, bv}, flags, M,
-                 (tt::u16*)h1d, (tt::u16*)xh1, stats, (tt::u16*)qkv};
+                 (tt::u16*)h1d, (tt::u16*)xh1, stats, (tt::u16*)qkv, (unsigned char*)relu_bits};
     DLDKD_LAUNCH(tt::f1_kernel, dim3(tt::grid_of(M)), dim3(64 * TT_WPB), 0, (hipStream_t)stream, a);
     return check_launch("tower_train_f1");
 }
@@ -1019,13 +1050,14 @@ int dldkd_tower_train_b3(const float* dg, const void* wot_pack, const void* xh2,
     return check_launch("tower_train_b3");
 }
 
-int dldkd_tower_train_b1(const void* dqkv, const void* dres, const void* wqkvt_pack, const void* xh1, const float* stats,
-                         const float* gamma, float p_drop, unsigned long long seed, unsigned long long offset,
+int dldkd_tower_train_b1(const void* dqkv, const void* dres, const void* wqkvt_pack, const void* xh1, const void* relu_bits,
+                         const float* stats, const float* gamma, float p_drop, unsigned long long seed, unsigned long long offset,
                          const unsigned long long* state, const unsigned char* flags, long M, int relu_mask, float* dy0, float* dx1,
                          float* dgamma, float* dbeta, void* dz_bf16, void* dy_bf16, void* stream) {
     if (M < 0 || tt::bad_p(p_drop)) { set_error("tower_train_b1: bad sizes"); return DLDKD_EINVAL; }
     if (M == 0) return DLDKD_OK;
     if (!dqkv || !dres || !wqkvt_pack || !xh1 || !stats || !gamma || !dy0) { set_error("tower_train_b1: null pointer"); return DLDKD_EINVAL; }
+    if (relu_mask && (!relu_bits || ((uintptr_t)relu_bits & 3))) { set_error("tower_train_b1: relu_mask needs the 4-byte aligned bit plane f1 wrote"); return DLDKD_EINVAL; }
     const bool sums = dgamma != nullptr;
     if (sums ? !dbeta : (dbeta != nullptr || !dz_bf16)) {
         set_error("tower_train_b1: dgamma and dbeta together (column sums in the kernel), or neither and dz_bf16");
@@ -1033,7 +1065,7 @@ int dldkd_tower_train_b1(const void* dqkv, const void* dres, const void* wqkvt_p
     }
     if (((uintptr_t)dqkv | (uintptr_t)dres | (uintptr_t)wqkvt_pack | (uintptr_t)xh1 | (uintptr_t)gamma | (uintptr_t)dy0 |
          (uintptr_t)dx1 | (uintptr_t)dz_bf16 | (uintptr_t)dy_bf16) & 15) { set_error("tower_train_b1: 16-byte alignment"); return DLDKD_EINVAL; }
-    tt::B1Args a{(const tt::u16*)dqkv, (const tt::u16*)dres, (const bf16x8*)wqkvt_pack, (const tt::u16*)xh1, stats, gamma,
+    tt::B1Args a{(const tt::u16*)dqkv, (const tt::u16*)dres, (const bf16x8*)wqkvt_pack, (const tt::u16*)xh1, (const unsigned char*)relu_bits, stats, gamma,
                  tt::make_drop(p_drop, seed, offset, state), flags, M, relu_mask, dy0, dx1, dgamma, dbeta, (tt::u16*)dz_bf16, (tt::u16*)dy_bf16};
     const dim3 grid(tt::grid_of(M));
     hipStream_t st = (hipStream_t)stream;

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256 * kModGroups) void modpool_bwd_kernel(const flo
 // "mixed" training mode (round 6): the tower's forward pass runs on the fp32-grade kernels (exact loss values); this kernel then
 // writes, from the fp32 intermediates, the bf16 rows the FUSED bf16 backward kernels (tower_train.hip: b3 / attention / b1 / the
 // grouped weight-gradient GEMM) read - the set tt::f1 / f3 save in throughput mode:
-//   xh1  = ((y0 + pos) - mean1) rstd1, bit 0 of every element = [y0 > 0]        (b1's LayerNorm backward + ReLU mask)
+//   xh1  = ((y0 + pos) - mean1) rstd1,   relu_bits = [y0 > 0] one bit per element   (b1's LayerNorm backward + ReLU mask)
 //   h1d  = bf16(h1)       qkv16 = bf16(qkv)       ctx16 = bf16(ctx)             (operands of the weight-gradient blocks / attention)
 //   xh2  = ((dd + h1) - mean2) rstd2,   rstd2,   h2_16 = bf16(h2) (video towers)
 // One thread per float4 column chunk of a row; rows of 32-row groups flagged 0 (padding) are skipped like the fused kernels skip them.
@@ -401,6 +401,7 @@ struct EmitArgs {
     const float *y0, *pos, *stats1, *h1, *qkv, *ctx, *dd, *stats2, *h2;
     const unsigned char* flags;
     unsigned short *xh1, *h1d, *qkv16, *ctx16, *xh2, *h2_16;
+    unsigned char* relu_bits;
     float* rstd2;
     long M;
     int L;
@@ -421,18 +422,18 @@ __global__ __launch_bounds__(256) void tower_train_emit_kernel(const EmitArgs p)
     const f32x4 y = reinterpret_cast<const f32x4*>(p.y0)[o];
     const f32x4 ps = reinterpret_cast<const f32x4*>(p.pos)[(size_t)(row % p.L) * 96 + c4];
     const float m1 = p.stats1[row], r1 = p.stats1[p.M + row];
-    uint2 x1;
-    {
-        unsigned short b[4];
+    f32x4 x1;
+    unsigned nib = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            // 15 value bits, rounded to nearest even at bit 1 in one step from fp32 (as tt::f1_kernel), bit 0 = [y0 > 0]
-            const unsigned xu = __builtin_bit_cast(unsigned, (y[e] + ps[e] - m1) * r1);
-            b[e] = (unsigned short)((((xu + 0xffffu + ((xu >> 17) & 1u)) >> 16) & 0xfffeu) | (y[e] > 0.f ? 1u : 0u));
-        }
-        x1 = uint2{(unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16)};
+    for (int e = 0; e < 4; ++e) {
+        x1[e] = (y[e] + ps[e] - m1) * r1;
+        nib |= (y[e] > 0.f ? 1u : 0u) << e;
     }
-    reinterpret_cast<uint2*>(p.xh1)[o] = x1;
+    reinterpret_cast<uint2*>(p.xh1)[o] = pack_bf16x4(x1);
+    // the ReLU mask [y0 > 0] as tt::f1_kernel leaves it: bit c % 8 of byte c / 8 of the row; threads of even c4 write the byte (their
+    // neighbour lane holds the other nibble: idx = 96 row + c4 has c4's parity, and a wave starts at an even idx)
+    const unsigned other = __shfl_down(nib, 1);
+    if (!(c4 & 1)) p.relu_bits[(size_t)row * 48 + (c4 >> 1)] = (unsigned char)(nib | (other << 4));
     const f32x4 h1 = reinterpret_cast<const f32x4*>(p.h1)[o];
     reinterpret_cast<uint2*>(p.h1d)[o] = pack_bf16x4(h1);
     reinterpret_cast<uint2*>(p.ctx16)[o] = pack_bf16x4(reinterpret_cast<const f32x4*>(p.ctx)[o]);
@@ -590,10 +591,10 @@ int dldkd_modpool_bwd_f32(const float* h, const float* mask, const float* w, con
 
 int dldkd_tower_train_emit(const float* y0, const float* pos, int L, const float* stats1, const float* h1, const float* qkv,
                            const float* ctx, const float* dd, const float* stats2, const float* h2, const unsigned char* flags, long M,
-                           void* xh1, void* h1d, void* qkv16, void* ctx16, void* xh2, float* rstd2, void* h2_16, void* stream) {
+                           void* xh1, void* relu_bits, void* h1d, void* qkv16, void* ctx16, void* xh2, float* rstd2, void* h2_16, void* stream) {
     if (M < 0 || L < 1 || (flags && (M & 31))) { set_error("tower_train_emit: bad sizes M=%ld L=%d", M, L); return DLDKD_EINVAL; }
     if (M == 0) return DLDKD_OK;
-    if (!y0 || !pos || !stats1 || !h1 || !qkv || !ctx || !dd || !stats2 || !xh1 || !h1d || !qkv16 || !ctx16 || !xh2 || !rstd2 ||
+    if (!y0 || !pos || !stats1 || !h1 || !qkv || !ctx || !dd || !stats2 || !xh1 || !relu_bits || !h1d || !qkv16 || !ctx16 || !xh2 || !rstd2 ||
         ((h2 == nullptr) != (h2_16 == nullptr))) {
         set_error("tower_train_emit: null pointer");
         return DLDKD_EINVAL;
@@ -604,7 +605,7 @@ int dldkd_tower_train_emit(const float* y0, const float* pos, int L, const float
         return DLDKD_EINVAL;
     }
     EmitArgs a{y0, pos, stats1, h1, qkv, ctx, dd, stats2, h2, flags, (unsigned short*)xh1, (unsigned short*)h1d, (unsigned short*)qkv16,
-               (unsigned short*)ctx16, (unsigned short*)xh2, (unsigned short*)h2_16, rstd2, M, L};
+               (unsigned short*)ctx16, (unsigned short*)xh2, (unsigned short*)h2_16, (unsigned char*)relu_bits, rstd2, M, L};
     LAUNCH1D(tower_train_emit_kernel, M * 96, 256, a);
     return check_launch("tower_train_emit");
 }

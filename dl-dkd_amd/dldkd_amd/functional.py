@@ -765,20 +765,21 @@ class _TowerTrain(Function):
         sa, sb, sc = slot(p_in, M * HIDDEN), slot(p_attn, N * HEADS * L * L), slot(p_hid, M * HIDDEN)
         h1d, qkv, ctxl, xh2 = _bf16((M, HIDDEN), dev), _bf16((M, 3 * HIDDEN), dev), _bf16((M, HIDDEN), dev), _bf16((M, HIDDEN), dev)
         xh1 = _bf16((M, HIDDEN), dev)
+        relu_bits = torch.empty(M * 48, dtype=torch.uint8, device=dev)       # [y0 > 0], one bit per element (tower_train.hip f1 / b1)
         stats = torch.empty(2, M, dtype=torch.float32, device=dev)
         rstd2 = torch.empty(M, dtype=torch.float32, device=dev)
         h2 = _bf16((M, HIDDEN), dev) if video else torch.empty(N, L, HIDDEN, dtype=torch.float32, device=dev)
         out = torch.empty(N, L, HIDDEN, dtype=torch.float32, device=dev) if video else h2
         L_ = _L()
         native.check(L_.dldkd_tower_train_f1(_p(y0), _p(pos), L, _p(g1), _p(b1), ops.LN_EPS, float(p_in), sa[0], sa[1], sa[2], _p(pk_qkv),
-                                             _p(bq), _p(bk), _p(bv), _p(flags), M, _p(h1d), _p(xh1), _p(stats), _p(qkv), _s()), "tower_train_f1")
+                                             _p(bq), _p(bk), _p(bv), _p(flags), M, _p(h1d), _p(xh1), _p(stats), _p(qkv), _p(relu_bits), _s()), "tower_train_f1")
         native.check(L_.dldkd_attention_train_fwd_bf16io(_p(qkv), _p(mask), _p(lens), _p(ctxl), N, L, float(p_attn), sb[0], sb[1], sb[2],
                                                          _s()), "attention_train_fwd_bf16io")
         native.check(L_.dldkd_tower_train_f3(_p(ctxl), _p(h1d), _p(pk_d), _p(bd), float(p_hid), sc[0], sc[1], sc[2], _p(g2), _p(b2),
                                              ops.LN_EPS, _p(pk_o), _p(bo), _p(flags), M, _p(xh2), _p(rstd2), _p(h2) if video else None,
                                              None if video else _p(h2), _p(out) if video else None, _s()), "tower_train_f3")
         ctx.save_for_backward(xh1, pos, g1, g2, mask, lens, flags, h1d, stats, qkv, ctxl, xh2, rstd2, h2 if video else None,
-                              pk_ot, pk_dt, pk_qkvt)
+                              pk_ot, pk_dt, pk_qkvt, relu_bits)
         ctx.shape = (N, L)
         keep = _philox_step.dev if _philox_step is not None else None
         ctx.cfg = (video, float(p_in), float(p_attn), float(p_hid), sa, sb, sc, bool(relu_mask), keep)
@@ -787,7 +788,7 @@ class _TowerTrain(Function):
     @staticmethod
     @ops.in_backward
     def backward(ctx, dout):
-        xh1, pos, g1, g2, mask, lens, flags, h1d, stats, qkv, ctxl, xh2, rstd2, h2, pk_ot, pk_dt, pk_qkvt = ctx.saved_tensors
+        xh1, pos, g1, g2, mask, lens, flags, h1d, stats, qkv, ctxl, xh2, rstd2, h2, pk_ot, pk_dt, pk_qkvt, relu_bits = ctx.saved_tensors
         video, p_in, p_attn, p_hid, sa, sb, sc, relu_mask, _keep = ctx.cfg
         N, L = ctx.shape
         M, dev = N * L, xh1.device
@@ -810,7 +811,7 @@ class _TowerTrain(Function):
         need_pos = ctx.needs_input_grad[1]
         dy0 = torch.empty(N, L, HIDDEN, dtype=torch.float32, device=dev)
         dx1 = torch.empty(N, L * HIDDEN, dtype=torch.float32, device=dev) if need_pos else None
-        native.check(L_.dldkd_tower_train_b1(_p(dqkv), _p(dres), _p(pk_qkvt), _p(xh1), _p(stats), _p(g1), p_in, sa[0], sa[1],
+        native.check(L_.dldkd_tower_train_b1(_p(dqkv), _p(dres), _p(pk_qkvt), _p(xh1), _p(relu_bits), _p(stats), _p(g1), p_in, sa[0], sa[1],
                                              sa[2], _p(flags), M, int(relu_mask), _p(dy0), _p(dx1), _p(lnp[2]) if sums else None,
                                              _p(lnp[3]) if sums else None, _p(dz16), _p(dy16), _s()), "tower_train_b1")
         if len(_DY16) > 8:
@@ -909,11 +910,12 @@ class _TowerTrainMixed(Function):
         xh1, h1d, qkv16, ctxl, xh2 = (_bf16((M, HIDDEN), dev), _bf16((M, HIDDEN), dev), _bf16((M, 3 * HIDDEN), dev), _bf16((M, HIDDEN), dev),
                                       _bf16((M, HIDDEN), dev))
         rstd2 = f32(M)
+        relu_bits = torch.empty(M * 48, dtype=torch.uint8, device=dev)
         h2_16 = _bf16((M, HIDDEN), dev) if video else None
         native.check(L_.dldkd_tower_train_emit(_p(y2), _p(pos), L, _p(stats), _p(h1), _p(qkv), _p(ctxf), _p(dd), _p(stats2),
-                                               _p(h2) if video else None, _p(flags), M, _p(xh1), _p(h1d), _p(qkv16), _p(ctxl), _p(xh2), _p(rstd2),
-                                               _p(h2_16), _s()), "tower_train_emit")
-        ctx.save_for_backward(xh1, pos, g1, g2, mask, lens, flags, h1d, stats, qkv16, ctxl, xh2, rstd2, h2_16, pk_ot, pk_dt, pk_qkvt)
+                                               _p(h2) if video else None, _p(flags), M, _p(xh1), _p(relu_bits), _p(h1d), _p(qkv16), _p(ctxl), _p(xh2),
+                                               _p(rstd2), _p(h2_16), _s()), "tower_train_emit")
+        ctx.save_for_backward(xh1, pos, g1, g2, mask, lens, flags, h1d, stats, qkv16, ctxl, xh2, rstd2, h2_16, pk_ot, pk_dt, pk_qkvt, relu_bits)
         ctx.shape = (N, L)
         keep_alive = _philox_step.dev if _philox_step is not None else None
         ctx.cfg = (video, float(p_in), float(p_attn), float(p_hid), sa, sb, sc, bool(relu_mask), keep_alive)

@@ -64,7 +64,7 @@ SIGNATURES = {
                                   _c_void_p]),
     "dldkd_layernorm_ex_f32": (_c_int, [_c_void_p] * 9 + [_c_long, _c_int, _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p,
                                          _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
-    "dldkd_tower_train_emit": (_c_int, [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 8 + [_c_long] + [_c_void_p] * 8),
+    "dldkd_tower_train_emit": (_c_int, [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 8 + [_c_long] + [_c_void_p] * 9),
     "dldkd_layernorm_dropout_bf16_dual": (_c_int, [_c_void_p] * 8 + [_c_long, _c_int, _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64,
                                                     ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_attention_train_fwd_bf16io": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float, ctypes.c_uint64,
@@ -76,14 +76,14 @@ SIGNATURES = {
     "dldkd_tower_train_prepare": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_tower_train_f1": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64,
                                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p,
-                                       _c_void_p, _c_void_p, _c_void_p]),
+                                       _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_tower_train_f3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p,
                                        _c_void_p, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p,
                                        _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_tower_train_b3": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float, ctypes.c_uint64, ctypes.c_uint64,
                                        _c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                        _c_void_p, _c_void_p, _c_void_p]),
-    "dldkd_tower_train_b1": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float,
+    "dldkd_tower_train_b1": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_float,
                                        ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p, _c_long, _c_int, _c_void_p, _c_void_p,
                                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_tower_train_dw_workspace_bytes": (_c_size_t, [_c_int, _c_long]),

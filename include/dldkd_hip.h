@@ -571,7 +571,9 @@ int dldkd_attention_train_bwd_bf16io(const void* qkv, const float* mask, const i
  * pointers); the call enqueues one kernel.
  *   f1: y0 (M, 384) fp32 (the input projection's output) + pos (L, 384) -> LayerNorm(gamma, beta) -> dropout -> h1d (M, 384) bf16,
  *       stats [2][M] (mean, rstd), qkv (M, 1152) bf16 = h1d Wqkv^T + (bq | bk | bv)          wqkv_pack: mode 0, three sources;
- *       xh1 (M, 384) bf16: the normalised rows with bit 0 of every element replaced by [y0 > 0] - all b1 needs of y0 and pos
+ *       xh1 (M, 384) bf16: the normalised rows; relu_bits (M, 48) bytes, 8-byte aligned: bit c % 8 of byte c / 8 of a row = [y0 > 0]
+ *       (the input projection's ReLU mask in a plane of its own since round 6 - it used to take bit 0 of every xh1 element) - together
+ *       all b1 needs of y0 and pos
  *   f3: ctx (M, 384) bf16 -> dense (wd_pack: mode 0) + bd -> dropout -> + h1d -> LayerNorm -> xh2 (normalised rows, bf16),
  *       rstd2 [M], and h2 = xh2 gamma + beta as bf16 (h2_bf16) followed by the out mapping g = h2 Wo^T + bo (fp32; wo_pack:
  *       mode 1) when wo_pack != NULL, as fp32 rows (h2_f32) otherwise (query towers: get_modularized_queries reads them)
@@ -580,19 +582,19 @@ int dldkd_attention_train_bwd_bf16io(const void* qkv, const float* mask, const i
  *       the residual (bf16), dctx = ddo Wd (bf16; wdt_pack: mode 3)
  *   b1: dqkv (M, 1152) bf16 -> dh1d = dqkv Wqkv + dres (wqkvt_pack: mode 2, three sources) -> dropout mask -> LayerNorm backward
  *       from xh1 and stats (dgamma, dbeta added) -> dx1 (M, 384) fp32 (gradient of y0 + pos; NULL: not written) and dy0 = dx1 (.) [y0 > 0] when
- *       relu_mask (the ReLU of LinearLayer, model_components.py:311), else dy0 = dx1.
+ *       relu_mask (the ReLU of LinearLayer, model_components.py:311; the mask = f1's relu_bits), else dy0 = dx1.
  * Weight gradients are dldkd_gemm_bf16_mixed(dw = 3 / 1) over the saved bf16 rows, bias gradients dldkd_colsum_bf16 /
  * dldkd_colsum_f32. */
 /* "mixed" training precision (fp32-grade forward, bf16 backward): after a tower's forward pass on the fp32-grade kernels, ONE launch
  * writes from its fp32 intermediates the bf16 rows the fused backward kernels above read (what f1 / f3 save in throughput mode):
- * xh1 = ((y0 + pos) - mean1) rstd1 with bit 0 = [y0 > 0], h1d = bf16(h1), qkv16, ctx16, xh2 = ((dd + h1) - mean2) rstd2, rstd2,
+ * xh1 = ((y0 + pos) - mean1) rstd1, relu_bits = [y0 > 0] (f1's bit plane), h1d = bf16(h1), qkv16, ctx16, xh2 = ((dd + h1) - mean2) rstd2, rstd2,
  * h2_16 (video towers; h2 = h2_16 = NULL otherwise).  y0, h1 (the position LayerNorm's output behind its dropout), ctx, dd (the
  * dense layer's output behind its dropout), h2: (M, 384) fp32; qkv (M, 1152); stats1 / stats2 [2][M] = (mean, rstd) of the two
  * LayerNorms (dldkd_layernorm_ex_f32); pos (>= L, 384); flags: the tower's 32-row group flags or NULL (rows of groups flagged 0
  * are not written).  Reference: model_components.py:277-284, 398-450. */
 int dldkd_tower_train_emit(const float* y0, const float* pos, int L, const float* stats1, const float* h1, const float* qkv,
                            const float* ctx, const float* dd, const float* stats2, const float* h2, const unsigned char* flags, long M,
-                           void* xh1, void* h1d, void* qkv16, void* ctx16, void* xh2, float* rstd2, void* h2_16, void* stream);
+                           void* xh1, void* relu_bits, void* h1d, void* qkv16, void* ctx16, void* xh2, float* rstd2, void* h2_16, void* stream);
 size_t dldkd_tower_train_pack_bytes(int n_mats);
 int dldkd_tower_train_pack(const float* const* host_src, const int* host_nsrc, const int* host_mode, void* const* host_out, int njobs,
                            void* stream);
@@ -603,7 +605,7 @@ int dldkd_tower_train_prepare(const float* const* host_src, const int* host_nsrc
 int dldkd_tower_train_f1(const float* y0, const float* pos, int L, const float* gamma, const float* beta, float eps, float p_drop,
                          unsigned long long seed, unsigned long long offset, const unsigned long long* state, const void* wqkv_pack,
                          const float* bq, const float* bk, const float* bv, const unsigned char* flags, long M, void* h1d, void* xh1,
-                         float* stats, void* qkv, void* stream);
+                         float* stats, void* qkv, void* relu_bits, void* stream);
 int dldkd_tower_train_f3(const void* ctx, const void* h1d, const void* wd_pack, const float* bd, float p_drop, unsigned long long seed,
                          unsigned long long offset, const unsigned long long* state, const float* gamma, const float* beta, float eps,
                          const void* wo_pack, const float* bo, const unsigned char* flags, long M, void* xh2, float* rstd2, void* h2_bf16,
@@ -612,7 +614,7 @@ int dldkd_tower_train_b3(const float* dg, const void* wot_pack, const void* xh2,
                          unsigned long long seed, unsigned long long offset, const unsigned long long* state, const void* wdt_pack,
                          const unsigned char* flags, long M, void* ddo, void* dctx, void* dres, float* dgamma, float* dbeta, void* dg_bf16,
                          void* dh2_bf16, void* stream);
-int dldkd_tower_train_b1(const void* dqkv, const void* dres, const void* wqkvt_pack, const void* xh1, const float* stats,
+int dldkd_tower_train_b1(const void* dqkv, const void* dres, const void* wqkvt_pack, const void* xh1, const void* relu_bits, const float* stats,
                          const float* gamma, float p_drop, unsigned long long seed, unsigned long long offset,
                          const unsigned long long* state, const unsigned char* flags, long M, int relu_mask, float* dy0, float* dx1,
                          float* dgamma, float* dbeta, void* dz_bf16, void* dy_bf16, void* stream);
@@ -642,7 +644,7 @@ int dldkd_tower_train_dw_pos(const void* const* host_A, const int* host_lda, con
  * launch: ln_grads (4, 384) fp32, ZEROED by the caller = [dgamma2 | dbeta2 | dgamma1 | dbeta1] with dgamma[c] += sum_r a[r, c] xh[r, c],
  * dbeta[c] += sum_r a[r, c] over the rows of flagged 32-row groups (k_flags) - LayerNorm 2: a = dh2 (dldkd_tower_train_b3's dh2_bf16, or
  * the fp32 rows dg it was given when there is no out mapping: dh2_is_bf16 = 0), xh = xh2; LayerNorm 1: a = dz1_bf16
- * (dldkd_tower_train_b1), xh = xh1 with its flag bit cleared.  All (rows, 384). */
+ * (dldkd_tower_train_b1), xh = xh1.  All (rows, 384). */
 int dldkd_tower_train_dw_ln(const void* const* host_A, const int* host_lda, const int* host_acol, const int* host_a16,
                             const void* const* host_B, int n_blocks, long rows, float* dW, float* dbias, void* workspace,
                             size_t workspace_bytes, const unsigned char* k_flags, const float* dx1, float* dpos, long n_seq, long cols,

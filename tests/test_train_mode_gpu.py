@@ -97,8 +97,12 @@ def _grad_stats(model, ref_grads):
     return out
 
 
-GRAD_TOL_BF16 = 0.25      # worst tensor's relative l2 error, throughput mode (measured 0.13)
-GRAD_TOL_MIXED = 0.25     # fp32-grade forward + bf16 backward
+# worst tensor's relative l2 gradient error against the oracle's autograd.  Throughput (bf16) mode: measured 0.127 (C3) / 0.164 (C5,
+# exp_query_encoder.self.value.bias), median 0.06 - 0.08; unchanged to three digits by round 6's move of the ReLU mask out of bit 0 of
+# the saved normalised rows (that bit was not what limits it - every operand of every product is rounded to 8 bits).
+# Mixed mode (fp32-grade forward, bf16 backward on exact activations): measured 8.4e-3 / 7.4e-3.
+GRAD_TOL_BF16 = 0.20
+GRAD_TOL_MIXED = 0.02
 
 
 def _assert_grads(stats, rel_tol, what, cos_min=None):
