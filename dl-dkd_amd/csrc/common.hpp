@@ -404,7 +404,8 @@ int gemm_f32x3_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor, int* 
 int gemm_bf16_split_plan(int M, int N, int K, int a_kmajor, int b_kmajor, int* k_tiles_per_split);
 // pooled batched GEMMs (gemm_f32x3.hip / gemm_bf16.hip): g (nv, L, D), q (nq, D) -> the PoolArgs outputs
 int launch_simpool_pool_x3(const float* g, const float* q, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream, int planes = 3);
-int launch_simpool_pool_bf16_dma(const void* g16, const void* q16, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream);
+int launch_simpool_pool_bf16_dma(const void* g16, const void* q16, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream,
+                                 long g_plane_stride = 0, long q_plane_stride = 0);
 // dz' = dy W with the LayerNorm-parameter-gradient epilogue (gemm_lngrad_tile), per precision mode
 int launch_linear_lngrad_bf16(const float* dy, const float* W, long M, int N, int K, const LnGradArgs& la, void* stream,
                               const unsigned char* row_flags = nullptr);

@@ -25,7 +25,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const unsigned long long* __restrict__ state,
                                                         unsigned short* __restrict__ out16, float* __restrict__ stats,
                                                         const float* __restrict__ row_mask, unsigned char* __restrict__ gflags,
-                                                        const unsigned char* __restrict__ gin) {
+                                                        const unsigned char* __restrict__ gin, unsigned short* __restrict__ planes) {
+    // planes != null: the row also as TWO bf16 planes [2][M][D] (h = bf16(o), m = bf16(o - h)): the operand form of the two-plane
+    // GEMM dldkd_gemm_bf16_nt16_planes ("mixed" training precision); plane 0 is the bf16 row the backward pass keeps
     // out16 != null: the row is written as bf16 (round to nearest even) instead of fp32 - the operand form of the bf16 GEMMs that
     // consume it (dldkd_gemm_bf16_mixed); stats != null: mean -> stats[row], rstd -> stats[M + row] (kept for the backward pass)
     const int lane = threadIdx.x & 63;
@@ -52,6 +54,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             for (int c = lane; c < nv; c += 64) {
                 if (out16 != nullptr) reinterpret_cast<uint2*>(out16 + row * D)[c] = uint2{0u, 0u};
                 if (out != nullptr) reinterpret_cast<f32x4*>(out + row * D)[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (planes != nullptr) {
+                    reinterpret_cast<uint2*>(planes + row * D)[c] = uint2{0u, 0u};
+                    reinterpret_cast<uint2*>(planes + (M + row) * D)[c] = uint2{0u, 0u};
+                }
                 if (keep != nullptr) reinterpret_cast<uchar4*>(keep + row * D)[c] = uchar4{0, 0, 0, 0};
             }
             return;
@@ -112,6 +118,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 orow16[c] = pk;
             }
             if (out != nullptr) orow[c] = o;           // (both: "mixed" training keeps fp32 rows for its forward GEMM and bf16 rows for the backward)
+            if (planes != nullptr) {
+                unsigned short hb[4], mb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hb[e] = f32_to_bf16_bits(o[e]);
+                    mb[e] = f32_to_bf16_bits(o[e] - bf16_bits_to_f32(hb[e]));
+                }
+                reinterpret_cast<uint2*>(planes + row * D)[c] = uint2{(unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[2] | ((unsigned)hb[3] << 16)};
+                reinterpret_cast<uint2*>(planes + (M + row) * D)[c] = uint2{(unsigned)mb[0] | ((unsigned)mb[1] << 16), (unsigned)mb[2] | ((unsigned)mb[3] << 16)};
+            }
         }
     }
 }
@@ -132,7 +148,10 @@ __global__ __launch_bounds__(256) void layernorm_dual_bf16_kernel(const float* _
                                                                   int D, float eps, unsigned thresh, float dscale, unsigned long long seed,
                                                                   unsigned long long off0, unsigned long long off1,
                                                                   const unsigned long long* __restrict__ state,
-                                                                  const float* __restrict__ row_mask, unsigned char* __restrict__ gflags) {
+                                                                  const float* __restrict__ row_mask, unsigned char* __restrict__ gflags,
+                                                                  int planes) {
+    // planes: out0 / out1 are [2][M][D] - the second bf16 plane m = bf16(o - bf16(o)) follows the first (the two-plane GEMM operands
+    // of the "mixed" training precision)
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -150,6 +169,10 @@ __global__ __launch_bounds__(256) void layernorm_dual_bf16_kernel(const float* _
             for (int c = lane; c < nv; c += 64) {
                 reinterpret_cast<uint2*>(out0 + row * D)[c] = uint2{0u, 0u};
                 reinterpret_cast<uint2*>(out1 + row * D)[c] = uint2{0u, 0u};
+                if (planes) {
+                    reinterpret_cast<uint2*>(out0 + (M + row) * D)[c] = uint2{0u, 0u};
+                    reinterpret_cast<uint2*>(out1 + (M + row) * D)[c] = uint2{0u, 0u};
+                }
             }
             return;
         }
@@ -199,10 +222,16 @@ __global__ __launch_bounds__(256) void layernorm_dual_bf16_kernel(const float* _
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = rnd[e] >= thresh ? o[e] * dscale : 0.f;
                 }
-                uint2 pk;
-                pk.x = (unsigned)f32_to_bf16_bits(o[0]) | ((unsigned)f32_to_bf16_bits(o[1]) << 16);
-                pk.y = (unsigned)f32_to_bf16_bits(o[2]) | ((unsigned)f32_to_bf16_bits(o[3]) << 16);
-                orow16[c] = pk;
+                unsigned short hb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hb[e] = f32_to_bf16_bits(o[e]);
+                orow16[c] = uint2{(unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[2] | ((unsigned)hb[3] << 16)};
+                if (planes) {
+                    unsigned short mb[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mb[e] = f32_to_bf16_bits(o[e] - bf16_bits_to_f32(hb[e]));
+                    orow16[(size_t)M * nv + c] = uint2{(unsigned)mb[0] | ((unsigned)mb[1] << 16), (unsigned)mb[2] | ((unsigned)mb[3] << 16)};
+                }
             }
         }
     }
@@ -429,26 +458,26 @@ static int launch_layernorm(const float* x, const float* add, int add_mod, const
                             long M, int D, float eps, unsigned char* keep, float p_drop, unsigned long long seed,
                             unsigned long long offset, const unsigned long long* state, void* stream,
                             unsigned short* out16 = nullptr, float* stats = nullptr, const float* row_mask = nullptr,
-                            unsigned char* gflags = nullptr, const unsigned char* gin = nullptr) {
+                            unsigned char* gflags = nullptr, const unsigned char* gin = nullptr, unsigned short* planes = nullptr) {
     if (M < 0 || D < 4 || (D & 3) || D > 4096 || add_mod < 0 || !(p_drop >= 0.f && p_drop < 1.f)) {
         set_error("layernorm: bad sizes M=%ld D=%d (D must be a multiple of 4, <= 4096) or p=%f", M, D, (double)p_drop);
         return DLDKD_EINVAL;
     }
     if (M == 0) return DLDKD_OK;
-    if (!x || !gamma || !beta || (!out && !out16)) { set_error("layernorm: null pointer"); return DLDKD_EINVAL; }
+    if (!x || !gamma || !beta || (!out && !out16 && !planes)) { set_error("layernorm: null pointer"); return DLDKD_EINVAL; }
     const dim3 grid((unsigned)((M + 3) / 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int nv = (D / 4 + 63) / 64;
     const double t = (double)p_drop * 4294967296.0;
     const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     const float ds = 1.0f / (1.0f - p_drop);
-    if (nv <= 2) DLDKD_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
-    else if (nv <= 4) DLDKD_LAUNCH(layernorm_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
-    else if (nv <= 8) DLDKD_LAUNCH(layernorm_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
+    if (nv <= 2) DLDKD_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin, planes);
+    else if (nv <= 4) DLDKD_LAUNCH(layernorm_kernel<4>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin, planes);
+    else if (nv <= 8) DLDKD_LAUNCH(layernorm_kernel<8>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin, planes);
     // (3072-wide rows - the TVR video features - are 12 float4 per lane: the <16> instance holds 64 row registers, 142 VGPRs = 3 waves per
     // SIMD; <12> 110 = 4 waves: 108 -> 94 us at 16,384 rows with dropout, tools/r05_ab_ln12.sh)
-    else if (nv <= 12) DLDKD_LAUNCH(layernorm_kernel<12>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
-    else DLDKD_LAUNCH(layernorm_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin);
+    else if (nv <= 12) DLDKD_LAUNCH(layernorm_kernel<12>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin, planes);
+    else DLDKD_LAUNCH(layernorm_kernel<16>, grid, block, 0, s, x, add, add_mod, gamma, beta, out, M, D, eps, keep, thresh, ds, seed, offset, state, out16, stats, row_mask, gflags, gin, planes);
     return check_launch("layernorm");
 }
 
@@ -495,7 +524,8 @@ int dldkd_layernorm_dropout_bf16(const float* x, const float* gamma, const float
 int dldkd_layernorm_dropout_bf16_dual(const float* x, const float* gamma0, const float* beta0, const float* gamma1, const float* beta1,
                                       void* out0_bf16, void* out1_bf16, float* stats, long M, int D, float eps, float p_drop,
                                       unsigned long long seed, unsigned long long offset0, unsigned long long offset1,
-                                      const unsigned long long* state, const float* row_mask, unsigned char* group_flags, void* stream) {
+                                      const unsigned long long* state, const float* row_mask, unsigned char* group_flags, int planes,
+                                      void* stream) {
     if (M < 0 || D < 4 || (D & 3) || D > 4096 || !(p_drop >= 0.f && p_drop < 1.f)) {
         set_error("layernorm_dropout_bf16_dual: bad sizes M=%ld D=%d (D must be a multiple of 4, <= 4096) or p=%f", M, D, (double)p_drop);
         return DLDKD_EINVAL;
@@ -513,18 +543,18 @@ int dldkd_layernorm_dropout_bf16_dual(const float* x, const float* gamma0, const
     const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     const float ds = 1.0f / (1.0f - p_drop);
     unsigned short *o0 = (unsigned short*)out0_bf16, *o1 = (unsigned short*)out1_bf16;
-    if (nv <= 4) DLDKD_LAUNCH(layernorm_dual_bf16_kernel<4>, grid, block, 0, s, x, gamma0, beta0, gamma1, beta1, o0, o1, stats, M, D, eps, thresh, ds, seed, offset0, offset1, state, row_mask, group_flags);
-    else if (nv <= 8) DLDKD_LAUNCH(layernorm_dual_bf16_kernel<8>, grid, block, 0, s, x, gamma0, beta0, gamma1, beta1, o0, o1, stats, M, D, eps, thresh, ds, seed, offset0, offset1, state, row_mask, group_flags);
-    else if (nv <= 12) DLDKD_LAUNCH(layernorm_dual_bf16_kernel<12>, grid, block, 0, s, x, gamma0, beta0, gamma1, beta1, o0, o1, stats, M, D, eps, thresh, ds, seed, offset0, offset1, state, row_mask, group_flags);
-    else DLDKD_LAUNCH(layernorm_dual_bf16_kernel<16>, grid, block, 0, s, x, gamma0, beta0, gamma1, beta1, o0, o1, stats, M, D, eps, thresh, ds, seed, offset0, offset1, state, row_mask, group_flags);
+    if (nv <= 4) DLDKD_LAUNCH(layernorm_dual_bf16_kernel<4>, grid, block, 0, s, x, gamma0, beta0, gamma1, beta1, o0, o1, stats, M, D, eps, thresh, ds, seed, offset0, offset1, state, row_mask, group_flags, planes ? 1 : 0);
+    else if (nv <= 8) DLDKD_LAUNCH(layernorm_dual_bf16_kernel<8>, grid, block, 0, s, x, gamma0, beta0, gamma1, beta1, o0, o1, stats, M, D, eps, thresh, ds, seed, offset0, offset1, state, row_mask, group_flags, planes ? 1 : 0);
+    else if (nv <= 12) DLDKD_LAUNCH(layernorm_dual_bf16_kernel<12>, grid, block, 0, s, x, gamma0, beta0, gamma1, beta1, o0, o1, stats, M, D, eps, thresh, ds, seed, offset0, offset1, state, row_mask, group_flags, planes ? 1 : 0);
+    else DLDKD_LAUNCH(layernorm_dual_bf16_kernel<16>, grid, block, 0, s, x, gamma0, beta0, gamma1, beta1, o0, o1, stats, M, D, eps, thresh, ds, seed, offset0, offset1, state, row_mask, group_flags, planes ? 1 : 0);
     return check_launch("layernorm_dropout_bf16_dual");
 }
 
 int dldkd_layernorm_ex_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out_f32,
-                           void* out_bf16, unsigned char* keep, float* stats, long M, int D, float eps, float p_drop,
+                           void* out_bf16, void* out_planes, unsigned char* keep, float* stats, long M, int D, float eps, float p_drop,
                            unsigned long long seed, unsigned long long offset, const unsigned long long* state, const float* row_mask,
                            unsigned char* group_flags_out, const unsigned char* group_flags_in, void* stream) {
-    if ((!out_f32 && !out_bf16) || ((uintptr_t)out_bf16 & 7) || ((uintptr_t)keep & 3)) {
+    if ((!out_f32 && !out_bf16 && !out_planes) || (((uintptr_t)out_bf16 | (uintptr_t)out_planes) & 7) || ((uintptr_t)keep & 3)) {
         set_error("layernorm_ex: no output, or an unaligned bf16 output / keep mask");
         return DLDKD_EINVAL;
     }
@@ -533,7 +563,7 @@ int dldkd_layernorm_ex_f32(const float* x, const float* add, int add_mod, const 
         return DLDKD_EINVAL;
     }
     return launch_layernorm(x, add, add_mod, gamma, beta, out_f32, M, D, eps, p_drop > 0.f ? keep : nullptr, p_drop, seed, offset, state, stream,
-                            (unsigned short*)out_bf16, stats, row_mask, group_flags_out, group_flags_in);
+                            (unsigned short*)out_bf16, stats, row_mask, group_flags_out, group_flags_in, (unsigned short*)out_planes);
 }
 
 int dldkd_attention_fwd_f32(const float* qkv, const float* mask, float* out, int N, int L, void* stream) {

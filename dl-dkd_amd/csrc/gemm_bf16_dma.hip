@@ -162,6 +162,13 @@ struct Args16 {
     int M, N, K, lda, ldb, ldc, relu;
     float alpha;
     const unsigned char* mflags;
+    // plane segments (round 6, the forward GEMMs of the "mixed" training precision): the contraction runs nseg times over K, segment s
+    // reading A from byte offset aoff[s] and B from boff[s] - with the operands stored as bf16 PLANES (x = h + m: dldkd_split2_bf16,
+    // dldkd_layernorm_ex_f32) the three segments (m, h), (h, m), (h, h) are the two-plane product of gemm_f32x3.hip (NPL = 2) at THIS
+    // kernel's rate: no split on the way to LDS, tiles by LDS-DMA.  nseg = 0 / 1: one pass, offsets ignored.  nseg = 3: am / bm = the
+    // byte offsets of the m planes (segment 0 reads A's m plane, segment 1 B's, segment 2 both h planes).
+    int nseg;
+    long am, bm;
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt16_kernel(const Args16 p) {
@@ -171,7 +178,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt16_kernel(const Args16 p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int m0 = bid.y * BM, n0 = bid.x * BN;
-    const int nk = p.K / BK16;
+    const int nk1 = p.K / BK16, nseg = p.nseg > 1 ? p.nseg : 1;
+    const int nk = nk1 * nseg;
     const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
     uint32_t voa[4], vob[4];
 #pragma unroll
@@ -192,9 +200,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt16_kernel(const Args16 p) 
     }
     const bool load_a = ((pm >> wave) & 1u) != 0;
     const bool rt_ok[2] = {((pm >> (wm / 32)) & 1u) != 0, ((pm >> (wm / 32 + 1)) & 1u) != 0};
-    auto issue = [&](int kt, int stage) {
-        const char* as = abase + (size_t)kt * (BK16 * 2);
-        const char* bs = bbase + (size_t)kt * (BK16 * 2);
+    int iseg = 0, ikk = 0;                                 // (segment, k-tile inside it) of the NEXT tile to be issued (tiles are issued in order)
+    auto issue = [&](int, int stage) {
+        const char* as = abase + ((p.nseg > 1 && iseg == 0) ? p.am : 0) + (size_t)ikk * (BK16 * 2);
+        const char* bs = bbase + ((p.nseg > 1 && iseg == 1) ? p.bm : 0) + (size_t)ikk * (BK16 * 2);
+        if (++ikk == nk1) { ikk = 0; ++iseg; }
         const uint32_t dst = smem_lds + stage * STAGE_B + (4 * wave) * 1024;
         if (load_a) {
 #pragma unroll
@@ -257,7 +267,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt16_pool_kernel(const Args1
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int v = blockIdx.z, n0 = blockIdx.x * BN;
-    const int nk = p.K / BK16;
+    const int nk1 = p.K / BK16, nseg = p.nseg > 1 ? p.nseg : 1;
+    const int nk = nk1 * nseg;
     const int len = min(pa.lens[v], p.M);
     const uint32_t smem_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
     uint32_t voa[4], vob[4];
@@ -275,9 +286,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt16_pool_kernel(const Args1
     const unsigned pm = __builtin_amdgcn_readfirstlane(tiles >= 4 ? 0xFu : ((1u << tiles) - 1u));
     const bool load_a = ((pm >> wave) & 1u) != 0;
     const bool rt_ok[2] = {((pm >> (wm / 32)) & 1u) != 0, ((pm >> (wm / 32 + 1)) & 1u) != 0};
-    auto issue = [&](int kt, int stage) {
-        const char* as = abase + (size_t)kt * (BK16 * 2);
-        const char* bs = bbase + (size_t)kt * (BK16 * 2);
+    int iseg = 0, ikk = 0;                                 // as in gemm_bf16_nt16_kernel
+    auto issue = [&](int, int stage) {
+        const char* as = abase + ((p.nseg > 1 && iseg == 0) ? p.am : 0) + (size_t)ikk * (BK16 * 2);
+        const char* bs = bbase + ((p.nseg > 1 && iseg == 1) ? p.bm : 0) + (size_t)ikk * (BK16 * 2);
+        if (++ikk == nk1) { ikk = 0; ++iseg; }
         const uint32_t dst = smem_lds + stage * STAGE_B + (4 * wave) * 1024;
         if (load_a) {
 #pragma unroll
@@ -368,7 +381,7 @@ extern "C" int dldkd_gemm_bf16_nt16(const void* A, const void* B, const float* b
         return DLDKD_EINVAL;
     }
     gdma::Args16 p{(const unsigned short*)A, (const unsigned short*)B, bias, C, M, N, K, lda, ldb, ldc, relu != 0, 1.0f,
-                   (M % gdma::BM == 0 && !((uintptr_t)row_flags & 3)) ? row_flags : nullptr};
+                   (M % gdma::BM == 0 && !((uintptr_t)row_flags & 3)) ? row_flags : nullptr, 1, 0, 0};
     constexpr int lds = gdma::NST * gdma::STAGE_B;
     static const bool ok = hipFuncSetAttribute((const void*)gdma::gemm_bf16_nt16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
     (void)ok;
@@ -377,14 +390,44 @@ extern "C" int dldkd_gemm_bf16_nt16(const void* A, const void* B, const float* b
     return check_launch("gemm_bf16_nt16");
 }
 
+// C = act(A B^T + bias) with both fp32 operands given as TWO bf16 planes each (x = h + m: h = bf16(x), m = bf16(x - h)): the
+// two-plane product a_h b_h + a_h b_m + a_m b_h of gemm_f32x3.hip (NPL = 2), smallest term first, as ONE pass of the LDS-DMA kernel
+// over three K-long segments.  A_planes = [2][M][lda], B_planes = [2][N][ldb] (plane strides in elements).
+extern "C" int dldkd_gemm_bf16_nt16_planes(const void* A_planes, const void* B_planes, const float* bias, float* C, int M, int N, int K, int lda,
+                                           int ldb, int ldc, int relu, const unsigned char* row_flags, long a_plane_stride, long b_plane_stride,
+                                           void* stream) {
+    if (M < 0 || N < 0 || K < 0 || lda < K || ldb < K || ldc < N || a_plane_stride < 0 || b_plane_stride < 0) { set_error("gemm_bf16_nt16_planes: bad sizes"); return DLDKD_EINVAL; }
+    if (M == 0 || N == 0) return DLDKD_OK;
+    if (!A_planes || !B_planes || !C) { set_error("gemm_bf16_nt16_planes: null pointer"); return DLDKD_EINVAL; }
+    if (!dldkd_gemm_bf16_nt16_ok(M, N, K, lda, ldb) || (((uintptr_t)A_planes | (uintptr_t)B_planes) & 15) || ((a_plane_stride | b_plane_stride) & 7)) {
+        set_error("gemm_bf16_nt16_planes: needs K %% 64 == 0, lda / ldb / plane strides %% 8 == 0 and 16-byte aligned operands (M=%d N=%d K=%d)", M, N, K);
+        return DLDKD_EINVAL;
+    }
+    gdma::Args16 p{(const unsigned short*)A_planes, (const unsigned short*)B_planes, bias, C, M, N, K, lda, ldb, ldc, relu != 0, 1.0f,
+                   (M % gdma::BM == 0 && !((uintptr_t)row_flags & 3)) ? row_flags : nullptr, 3,
+                   2 * a_plane_stride, 2 * b_plane_stride};                              // (m, h), (h, m), (h, h): byte offsets of the m planes
+    constexpr int lds = gdma::NST * gdma::STAGE_B;
+    static const bool ok = hipFuncSetAttribute((const void*)gdma::gemm_bf16_nt16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    (void)ok;
+    const dim3 grid((N + gdma::BN - 1) / gdma::BN, (M + gdma::BM - 1) / gdma::BM, 1);
+    DLDKD_LAUNCH(gdma::gemm_bf16_nt16_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    return check_launch("gemm_bf16_nt16_planes");
+}
+
 // g16 (nv, L, D) / q16 (nq, D) bf16 -> the PoolArgs outputs (simpool_train.hip: dldkd_simpool_train_fwd_bf16in)
 namespace dldkd {
-int launch_simpool_pool_bf16_dma(const void* g16, const void* q16, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream) {
+int launch_simpool_pool_bf16_dma(const void* g16, const void* q16, int nv, int L, int nq, int D, const PoolArgs& pa, void* stream,
+                                 long g_plane_stride, long q_plane_stride) {
     if (L < 1 || L > gdma::BM || !dldkd_gemm_bf16_nt16_ok(L, nq, D, D, D) || (((uintptr_t)g16 | (uintptr_t)q16) & 15)) {
         set_error("simpool_train_fwd_bf16in: needs L <= 128, D %% 64 == 0 and 16-byte aligned operands (L=%d nq=%d D=%d)", L, nq, D);
         return DLDKD_EINVAL;
     }
-    gdma::Args16 p{(const unsigned short*)g16, (const unsigned short*)q16, nullptr, nullptr, L, nq, D, D, D, nq, 0, 1.0f, nullptr};
+    gdma::Args16 p{(const unsigned short*)g16, (const unsigned short*)q16, nullptr, nullptr, L, nq, D, D, D, nq, 0, 1.0f, nullptr, 1, 0, 0};
+    if (g_plane_stride > 0 && q_plane_stride > 0) {       // two bf16 planes per operand: the two-plane product in three K-long segments
+        if ((g_plane_stride | q_plane_stride) & 7) { set_error("simpool_train_fwd_planes: plane strides must be multiples of 8 elements"); return DLDKD_EINVAL; }
+        p.nseg = 3;
+        p.am = 2 * g_plane_stride; p.bm = 2 * q_plane_stride;
+    }
     constexpr int lds = gdma::NST * gdma::STAGE_B;
     static const bool ok = hipFuncSetAttribute((const void*)gdma::gemm_bf16_nt16_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
     (void)ok;

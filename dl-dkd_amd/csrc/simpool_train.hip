@@ -19,8 +19,10 @@ namespace dldkd {
 
 // inv[r] = 1 / max(|x[r, :]|, 1e-12)   (F.normalize's clamp, model.py:318-319); one wave per row
 // y16 != null: the row is also written as bf16 (round to nearest even) - the operand form of the pooled GEMM with bf16 operands
+// y16: the row as bf16 beside its norm; mstride > 0 (elements): the second bf16 plane m = bf16(x - bf16(x)) too, at y16 + mstride
+// (the two-plane operands of dldkd_simpool_train_fwd_planes)
 __device__ __forceinline__ void row_invnorm_row(const float* __restrict__ x, float* __restrict__ inv, long r, int D, int lane,
-                                                unsigned short* __restrict__ y16 = nullptr) {
+                                                unsigned short* __restrict__ y16 = nullptr, long mstride = 0) {
     float ss = 0.f;
     const float* row = x + r * D;
     if (!(D & 3) && !((uintptr_t)x & 15)) {
@@ -32,12 +34,21 @@ __device__ __forceinline__ void row_invnorm_row(const float* __restrict__ x, flo
                 pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
                 pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
                 *reinterpret_cast<uint2*>(y16 + r * D + c) = pk;
+                if (mstride > 0) {
+                    unsigned short m[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] = f32_to_bf16_bits(v[e] - bf16_bits_to_f32(f32_to_bf16_bits(v[e])));
+                    *reinterpret_cast<uint2*>(y16 + mstride + r * D + c) = uint2{(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
+                }
             }
         }
     } else {
         for (int c = lane; c < D; c += 64) {
             ss += row[c] * row[c];
-            if (y16 != nullptr) y16[r * D + c] = f32_to_bf16_bits(row[c]);
+            if (y16 != nullptr) {
+                y16[r * D + c] = f32_to_bf16_bits(row[c]);
+                if (mstride > 0) y16[mstride + r * D + c] = f32_to_bf16_bits(row[c] - bf16_bits_to_f32(f32_to_bf16_bits(row[c])));
+            }
         }
     }
     ss = wave_sum(ss);
@@ -52,11 +63,12 @@ __global__ __launch_bounds__(256) void row_invnorm_kernel(const float* __restric
 // the two operands of one scored pair (queries, gallery clips) in one launch: workgroups [0, ceil(M0 / 4)) take x0's rows
 __global__ __launch_bounds__(256) void row_invnorm2_kernel(const float* __restrict__ x0, float* __restrict__ inv0, long M0,
                                                            const float* __restrict__ x1, float* __restrict__ inv1, long M1, int D,
-                                                           unsigned short* __restrict__ y0, unsigned short* __restrict__ y1) {
+                                                           unsigned short* __restrict__ y0, unsigned short* __restrict__ y1, int planes) {
     const long b0 = (M0 + 3) / 4;
     const bool first = (long)blockIdx.x < b0;
     const long r = ((long)blockIdx.x - (first ? 0 : b0)) * 4 + (threadIdx.x >> 6);
-    if (r < (first ? M0 : M1)) row_invnorm_row(first ? x0 : x1, first ? inv0 : inv1, r, D, threadIdx.x & 63, first ? y0 : y1);
+    if (r < (first ? M0 : M1))
+        row_invnorm_row(first ? x0 : x1, first ? inv0 : inv1, r, D, threadIdx.x & 63, first ? y0 : y1, planes ? (first ? M0 : M1) * D : 0);
 }
 
 struct SimpoolBwdArgs {
@@ -311,7 +323,7 @@ int dldkd_row_invnorm2_f32(const float* x0, float* inv0, long M0, const float* x
     if (M0 + M1 == 0) return DLDKD_OK;
     if ((M0 && (!x0 || !inv0)) || (M1 && (!x1 || !inv1))) { set_error("row_invnorm2: null pointer"); return DLDKD_EINVAL; }
     DLDKD_LAUNCH(row_invnorm2_kernel, dim3((unsigned)((M0 + 3) / 4 + (M1 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x0, inv0, M0, x1, inv1,
-                 M1, D, (unsigned short*)nullptr, (unsigned short*)nullptr);
+                 M1, D, (unsigned short*)nullptr, (unsigned short*)nullptr, 0);
     return check_launch("row_invnorm2");
 }
 
@@ -324,8 +336,21 @@ int dldkd_row_invnorm2_cast_f32(const float* x0, float* inv0, void* y0_bf16, lon
         return DLDKD_EINVAL;
     }
     DLDKD_LAUNCH(row_invnorm2_kernel, dim3((unsigned)((M0 + 3) / 4 + (M1 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x0, inv0, M0, x1, inv1,
-                 M1, D, (unsigned short*)y0_bf16, (unsigned short*)y1_bf16);
+                 M1, D, (unsigned short*)y0_bf16, (unsigned short*)y1_bf16, 0);
     return check_launch("row_invnorm2_cast");
+}
+
+int dldkd_row_invnorm2_planes_f32(const float* x0, float* inv0, void* y0_planes, long M0, const float* x1, float* inv1, void* y1_planes, long M1,
+                                  int D, void* stream) {
+    if (M0 < 0 || M1 < 0 || D < 1 || (D & 7)) { set_error("row_invnorm2_planes: bad sizes (D must be a multiple of 8)"); return DLDKD_EINVAL; }
+    if (M0 + M1 == 0) return DLDKD_OK;
+    if ((M0 && (!x0 || !inv0 || !y0_planes)) || (M1 && (!x1 || !inv1 || !y1_planes)) || (((uintptr_t)y0_planes | (uintptr_t)y1_planes) & 15)) {
+        set_error("row_invnorm2_planes: null or unaligned pointer");
+        return DLDKD_EINVAL;
+    }
+    DLDKD_LAUNCH(row_invnorm2_kernel, dim3((unsigned)((M0 + 3) / 4 + (M1 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x0, inv0, M0, x1, inv1,
+                 M1, D, (unsigned short*)y0_planes, (unsigned short*)y1_planes, 1);
+    return check_launch("row_invnorm2_planes");
 }
 
 int dldkd_simpool_train_fwd_bf16in(const void* q_bf16, const void* g_bf16, const float* rq, const float* rg, const int32_t* lens,
@@ -342,6 +367,24 @@ int dldkd_simpool_train_fwd_bf16in(const void* q_bf16, const void* g_bf16, const
     }
     PoolArgs pa{rg, rq, lens, labels, pooled_raw, pooled_cos, arg_raw, arg_cos, clip_pos, nv, L};
     return launch_simpool_pool_bf16_dma(g_bf16, q_bf16, nv, L, nq, D, pa, stream);
+}
+
+/* dldkd_simpool_train_fwd_bf16in with both operands as TWO bf16 planes (dldkd_row_invnorm2_planes_f32: [2][nq][D] / [2][nv L][D]):
+ * the two-plane fp32-grade product (three K-long segments of the LDS-DMA kernel) - the pooled scores of the "mixed" training precision. */
+int dldkd_simpool_train_fwd_planes(const void* q_planes, const void* g_planes, const float* rq, const float* rg, const int32_t* lens,
+                                   const int32_t* labels, int nq, int nv, int L, int D, float* pooled_cos, float* pooled_raw,
+                                   int32_t* arg_cos, int32_t* arg_raw, float* clip_pos, void* stream) {
+    if (nq < 0 || nv < 0 || L < 1 || L > DLDKD_MAX_CLIPS || D < 1 || nv > 65535) {
+        set_error("simpool_train_fwd_planes: bad sizes nq=%d nv=%d L=%d D=%d", nq, nv, L, D);
+        return DLDKD_EINVAL;
+    }
+    if (nq == 0 || nv == 0) return DLDKD_OK;
+    if (!q_planes || !g_planes || !rq || !rg || !lens || !labels || !pooled_cos || !pooled_raw || !arg_cos || !arg_raw) {
+        set_error("simpool_train_fwd_planes: null pointer");
+        return DLDKD_EINVAL;
+    }
+    PoolArgs pa{rg, rq, lens, labels, pooled_raw, pooled_cos, arg_raw, arg_cos, clip_pos, nv, L};
+    return launch_simpool_pool_bf16_dma(g_planes, q_planes, nv, L, nq, D, pa, stream, (long)nv * L * D, (long)nq * D);
 }
 
 int dldkd_simpool_train_fwd_f32(int precision, const float* q, const float* g, const float* rq, const float* rg,

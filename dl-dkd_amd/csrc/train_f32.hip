@@ -397,6 +397,36 @@ __global__ __launch_bounds__(256 * kModGroups) void modpool_bwd_kernel(const flo
 //   xh2  = ((dd + h1) - mean2) rstd2,   rstd2,   h2_16 = bf16(h2) (video towers)
 // One thread per float4 column chunk of a row; rows of 32-row groups flagged 0 (padding) are skipped like the fused kernels skip them.
 // ----------------------------------------------------------------------------------------------
+// x (fp32) -> two bf16 planes h = bf16(x), m = bf16(x - h) (x = h + m to 16 mantissa bits: the operands of dldkd_gemm_bf16_nt16_planes),
+// or a plain fp32 copy (kind 1: gathers scattered parameters - the three attention biases - into one vector) - up to 12 jobs in one launch
+struct SplitJobs {
+    const float* src[12];
+    void* dh[12];
+    unsigned short* dm[12];
+    long n4[12];               // float4 groups of the job
+    long first[13];            // first workgroup of job j (prefix sums, 256 groups per workgroup)
+    int kind[12];
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void split2_jobs_kernel(const SplitJobs p) {
+    int j = 0;
+#pragma unroll 1
+    while (j + 1 < p.njobs && (long)blockIdx.x >= p.first[j + 1]) ++j;
+    const long i = ((long)blockIdx.x - p.first[j]) * 256 + threadIdx.x;
+    if (i >= p.n4[j]) return;
+    const f32x4 v = reinterpret_cast<const f32x4*>(p.src[j])[i];
+    if (p.kind[j] == 1) { reinterpret_cast<f32x4*>(p.dh[j])[i] = v; return; }
+    unsigned short h[4], m[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = f32_to_bf16_bits(v[e]);
+        m[e] = f32_to_bf16_bits(v[e] - bf16_bits_to_f32(h[e]));
+    }
+    reinterpret_cast<uint2*>(p.dh[j])[i] = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+    reinterpret_cast<uint2*>(p.dm[j])[i] = uint2{(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
+}
+
 struct EmitArgs {
     const float *y0, *pos, *stats1, *h1, *qkv, *ctx, *dd, *stats2, *h2;
     const unsigned char* flags;
@@ -435,8 +465,8 @@ __global__ __launch_bounds__(256) void tower_train_emit_kernel(const EmitArgs p)
     const unsigned other = __shfl_down(nib, 1);
     if (!(c4 & 1)) p.relu_bits[(size_t)row * 48 + (c4 >> 1)] = (unsigned char)(nib | (other << 4));
     const f32x4 h1 = reinterpret_cast<const f32x4*>(p.h1)[o];
-    reinterpret_cast<uint2*>(p.h1d)[o] = pack_bf16x4(h1);
-    reinterpret_cast<uint2*>(p.ctx16)[o] = pack_bf16x4(reinterpret_cast<const f32x4*>(p.ctx)[o]);
+    if (p.h1d != nullptr) reinterpret_cast<uint2*>(p.h1d)[o] = pack_bf16x4(h1);            // (null: the caller holds them already - plane 0 of
+    if (p.ctx16 != nullptr) reinterpret_cast<uint2*>(p.ctx16)[o] = pack_bf16x4(reinterpret_cast<const f32x4*>(p.ctx)[o]);   //  the two-plane GEMM operands)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const size_t q = (size_t)row * 288 + 96 * j + c4;
@@ -589,13 +619,41 @@ int dldkd_modpool_bwd_f32(const float* h, const float* mask, const float* w, con
     return check_launch("modpool_bwd");
 }
 
+int dldkd_split2_bf16_jobs(const float* const* host_src, void* const* host_dst_h, void* const* host_dst_m, const long* host_n,
+                           const int* host_kind, int njobs, void* stream) {
+    if (njobs < 0 || njobs > 12 || (njobs && (!host_src || !host_dst_h || !host_dst_m || !host_n || !host_kind))) {
+        set_error("split2_bf16_jobs: 0 .. 12 jobs with their host tables");
+        return DLDKD_EINVAL;
+    }
+    if (njobs == 0) return DLDKD_OK;
+    SplitJobs a{};
+    a.njobs = njobs;
+    long blocks = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const int kind = host_kind[j];
+        if (host_n[j] < 0 || (host_n[j] & 3) || (kind != 0 && kind != 1) || (host_n[j] && (!host_src[j] || !host_dst_h[j] || (kind == 0 && !host_dst_m[j]))) ||
+            (((uintptr_t)host_src[j] | (kind == 1 ? (uintptr_t)host_dst_h[j] : 0)) & 15) || (kind == 0 && (((uintptr_t)host_dst_h[j] | (uintptr_t)host_dst_m[j]) & 7))) {
+            set_error("split2_bf16_jobs: job %d: n must be a multiple of 4, fp32 pointers 16-byte and plane pointers 8-byte aligned, kind 0 (split) or 1 (copy)", j);
+            return DLDKD_EINVAL;
+        }
+        a.src[j] = host_src[j]; a.dh[j] = host_dst_h[j]; a.dm[j] = (unsigned short*)host_dst_m[j]; a.n4[j] = host_n[j] / 4; a.kind[j] = kind;
+        a.first[j] = blocks;
+        blocks += (a.n4[j] + 255) / 256;
+    }
+    a.first[njobs] = blocks;
+    if (blocks == 0) return DLDKD_OK;
+    if (blocks > 0x7fffffffL) { set_error("split2_bf16_jobs: too many elements"); return DLDKD_EINVAL; }
+    DLDKD_LAUNCH(split2_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("split2_bf16_jobs");
+}
+
 int dldkd_tower_train_emit(const float* y0, const float* pos, int L, const float* stats1, const float* h1, const float* qkv,
                            const float* ctx, const float* dd, const float* stats2, const float* h2, const unsigned char* flags, long M,
                            void* xh1, void* relu_bits, void* h1d, void* qkv16, void* ctx16, void* xh2, float* rstd2, void* h2_16, void* stream) {
     if (M < 0 || L < 1 || (flags && (M & 31))) { set_error("tower_train_emit: bad sizes M=%ld L=%d", M, L); return DLDKD_EINVAL; }
     if (M == 0) return DLDKD_OK;
-    if (!y0 || !pos || !stats1 || !h1 || !qkv || !ctx || !dd || !stats2 || !xh1 || !relu_bits || !h1d || !qkv16 || !ctx16 || !xh2 || !rstd2 ||
-        ((h2 == nullptr) != (h2_16 == nullptr))) {
+    if (!y0 || !pos || !stats1 || !h1 || !qkv || !dd || !stats2 || !xh1 || !relu_bits || !qkv16 || !xh2 || !rstd2 || (ctx16 && !ctx) ||
+        (h2_16 && !h2)) {
         set_error("tower_train_emit: null pointer");
         return DLDKD_EINVAL;
     }

@@ -193,6 +193,63 @@ def layernorm(x, gamma, beta, add=None, add_mod=0, p_drop=0.0, training=False):
 # SAME student features (method/model.py:229-243): DLDKD.forward_tensors calls in_proj_ln_dual in front of the towers; the two
 # _InProjTrain.forward calls that follow find their rows here (matched by the raw rows' storage and the branch's gamma) and skip
 # their own LayerNorm launch - the 201-MB TVR batch is read once instead of twice.
+# ---- two-plane operands of the "mixed" precision's forward GEMMs (round 6): an fp32 tensor as [2][rows][K] bf16 (h = bf16(x), m =
+# bf16(x - h)); dldkd_gemm_bf16_nt16_planes contracts (m, h) + (h, m) + (h, h) in one pass of the LDS-DMA bf16 kernel - the numbers of
+# gemm_f32x2 (in-kernel split, 128 x 128 x 16 tiles) at 2.5x its rate.  DLDKD_MIXED_PLANES=0: the in-kernel-split kernel (A/B).
+MIXED_PLANES = os.environ.get("DLDKD_MIXED_PLANES", "1") == "1"
+
+
+def mixed_planes_ok(M, N, K):
+    return bool(MIXED_PLANES and ops.gemm_precision() == "fp32x2" and _L().dldkd_gemm_bf16_nt16_ok(int(M), int(N), int(K), int(K), int(K)))
+
+
+def split2_jobs(jobs, device):
+    """jobs = [(src fp32 contiguous, "split" | "copy")] -> their outputs from ONE launch: split -> bf16 (2,) + src.shape, copy -> a
+    fp32 tensor of src's shape; sources of one `group` tuple ((srcs...), "split") are concatenated along dim 0 first."""
+    import ctypes
+    outs, flat = [], []
+    for src, kind in jobs:
+        group = src if isinstance(src, (tuple, list)) else (src,)
+        rows = sum(t.shape[0] for t in group)
+        tail = tuple(group[0].shape[1:])
+        n_tot = rows
+        for d_ in tail:
+            n_tot *= int(d_)
+        if kind == "split":
+            out = torch.empty((2, rows) + tail, dtype=torch.bfloat16, device=device)
+        else:
+            out = torch.empty((rows,) + tail, dtype=torch.float32, device=device)
+        off = 0
+        for t in group:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() % 4:
+                raise native.NativeError("split2_jobs: sources must be contiguous fp32 with a multiple of 4 elements")
+            n = t.numel()
+            if kind == "split":
+                flat.append((t.data_ptr(), out.data_ptr() + 2 * off, out.data_ptr() + 2 * (n_tot + off), n, 0))
+            else:
+                flat.append((t.data_ptr(), out.data_ptr() + 4 * off, 0, n, 1))
+            off += n
+        outs.append(out)
+    nj = len(flat)
+    if nj > 12:
+        raise native.NativeError("split2_jobs: at most 12 jobs per launch")
+    src = (ctypes.c_void_p * nj)(*[f[0] for f in flat])
+    dh = (ctypes.c_void_p * nj)(*[f[1] for f in flat])
+    dm = (ctypes.c_void_p * nj)(*[f[2] for f in flat])
+    nn = (ctypes.c_long * nj)(*[f[3] for f in flat])
+    kk = (ctypes.c_int * nj)(*[f[4] for f in flat])
+    native.check(_L().dldkd_split2_bf16_jobs(src, dh, dm, nn, kk, nj, _s()), "split2_bf16_jobs")
+    return outs
+
+
+def gemm_planes(ap, bp, bias, M, N, K, relu=False, row_flags=None):
+    """y (M, N) fp32 = act(A B^T + bias) from the two-plane operands ap (2, M, K) and bp (2, N, K)."""
+    y = torch.empty(M, N, dtype=torch.float32, device=ap.device)
+    native.check(_L().dldkd_gemm_bf16_nt16_planes(_p(ap), _p(bp), _p(bias), _p(y), M, N, K, K, K, N, int(relu), _p(row_flags), M * K, N * K, _s()),
+                 "gemm_bf16_nt16_planes")
+    return y
+
+
 IN_PROJ_LN_DUAL = os.environ.get("DLDKD_LN_DUAL", "1") == "1"
 _PRE_LN = {}
 
@@ -203,7 +260,8 @@ def in_proj_ln_dual_ok(x, layers, p, training):
     if not (IN_PROJ_LN_DUAL and IN_PROJ_TRAIN_BF16_ROWS and IN_PROJ_TRAIN_FUSED and IN_PROJ_BWD_DUAL and IN_PROJ_TRAIN_NT16
             and not IN_PROJ_KEEP_BYTES and IN_PROJ_SKIP_PADDING and len(layers) == 2 and training and torch.is_grad_enabled()):
         return False
-    if not (ops.gemm_precision() == "bf16" and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+    mixed = ops.precision_mode() == "mixed" and ops.gemm_precision() == "fp32x2" and MIXED_PLANES     # (rows as two bf16 planes)
+    if not ((ops.gemm_precision() == "bf16" or mixed) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
             and not x.requires_grad and x.shape[1] % 32 == 0):
         return False
     K = x.shape[-1]
@@ -243,7 +301,8 @@ def in_proj_ln_dual(x, row_mask, layers, p):
     K = x.shape[-1]
     x2 = x.reshape(-1, K)
     M, dev = x2.shape[0], x.device
-    z = [torch.empty(M, K, dtype=torch.bfloat16, device=dev) for _ in layers]
+    planes = ops.gemm_precision() == "fp32x2"              # "mixed": [2][M][K] per branch, plane 0 = the bf16 rows
+    z = [torch.empty((2, M, K) if planes else (M, K), dtype=torch.bfloat16, device=dev) for _ in layers]
     stats = torch.empty(2, M, dtype=torch.float32, device=dev)
     gflags = torch.empty(M // 32, dtype=torch.uint8, device=dev)
     rm = _f32(row_mask).reshape(-1)
@@ -252,7 +311,7 @@ def in_proj_ln_dual(x, row_mask, layers, p):
     b = [l.LayerNorm.bias for l in layers]
     native.check(_L().dldkd_layernorm_dropout_bf16_dual(_p(x2), _p(g[0]), _p(b[0]), _p(g[1]), _p(b[1]), _p(z[0]), _p(z[1]), _p(stats), M, K,
                                                         ops.LN_EPS, float(p), slots[0][0], slots[0][1], slots[1][1], slots[0][2], _p(rm),
-                                                        _p(gflags), _s()), "layernorm_dropout_bf16_dual")
+                                                        _p(gflags), int(planes), _s()), "layernorm_dropout_bf16_dual")
     _PRE_LN.clear()
     for i in range(2):
         _PRE_LN[(x2.data_ptr(), g[i].data_ptr())] = (z[i], stats, gflags, slots[i], float(p), M, K)
@@ -307,19 +366,42 @@ class _InProjTrain(Function):
             # "mixed" precision: the forward product on the fp32-grade GEMM over fp32 LayerNorm-dropout rows (exact loss values); the
             # SAME launch leaves the rows as bf16 too - all the backward pass reads (the one-GEMM bf16 backward below: dW and the
             # LayerNorm parameter gradients; the fp32 rows die with this call)
-            zf = torch.empty_like(x2)
-            z = torch.empty(x2.shape, dtype=torch.bfloat16, device=x.device)
             stats = torch.empty(2, M, dtype=torch.float32, device=x.device)
             rm = None
             if row_mask is not None and IN_PROJ_SKIP_PADDING and x.dim() == 3 and row_mask.numel() == M:
                 rm = _f32(row_mask).reshape(-1)
                 if x.shape[1] % 32 == 0:          # (query towers: 30 words - no 32-row groups; the rows of the padding are still skipped)
                     gflags = torch.empty(M // 32, dtype=torch.uint8, device=x.device)
-            seed, off, state = _in_proj_slot(x2, gamma, x.numel()) if p > 0.0 else (0, 0, None)
-            native.check(_L().dldkd_layernorm_ex_f32(_p(x2), None, 0, _p(gamma), _p(beta), _p(zf), _p(z), None, _p(stats), M, K, ops.LN_EPS,
-                                                     float(p), seed, off, state, _p(rm), _p(gflags), None, _s()), "layernorm_ex")
-            y = ops.linear(zf, weight, bias, relu=relu, row_flags=gflags)
-            del zf
+            pre2 = _take_pre_ln(x2, gamma, p, row_mask) if mixed_planes_ok(M, N, K) else None
+            if pre2 is None or pre2[0].dim() != 3:
+                pre2 = None
+                seed, off, state = _in_proj_slot(x2, gamma, x.numel()) if p > 0.0 else (0, 0, None)
+            if pre2 is not None:
+                # both branches' planes came from ONE pass over the raw features (in_proj_ln_dual in front of the towers)
+                zp, stats, gflags, (seed, off, state) = pre2
+                wp = _take_prepacked("w_in_planes", weight.data_ptr())
+                if wp is None:
+                    (wp,) = split2_jobs([(weight, "split")], x.device)
+                y = gemm_planes(zp, wp, bias, M, N, K, relu=relu, row_flags=gflags)
+                z = zp[0]
+            elif mixed_planes_ok(M, N, K):
+                # the LayerNorm-dropout rows as TWO bf16 planes (same bytes as fp32 rows): the forward GEMM contracts them as they lie
+                # (LDS-DMA, no split on the way), and plane 0 IS the bf16 row the backward pass reads
+                zp = torch.empty(2, M, K, dtype=torch.bfloat16, device=x.device)
+                native.check(_L().dldkd_layernorm_ex_f32(_p(x2), None, 0, _p(gamma), _p(beta), None, None, _p(zp), None, _p(stats), M, K, ops.LN_EPS,
+                                                         float(p), seed, off, state, _p(rm), _p(gflags), None, _s()), "layernorm_ex")
+                wp = _take_prepacked("w_in_planes", weight.data_ptr())
+                if wp is None:
+                    (wp,) = split2_jobs([(weight, "split")], x.device)
+                y = gemm_planes(zp, wp, bias, M, N, K, relu=relu, row_flags=gflags)
+                z = zp[0]
+            else:
+                zf = torch.empty_like(x2)
+                z = torch.empty(x2.shape, dtype=torch.bfloat16, device=x.device)
+                native.check(_L().dldkd_layernorm_ex_f32(_p(x2), None, 0, _p(gamma), _p(beta), _p(zf), _p(z), None, None, _p(stats), M, K, ops.LN_EPS,
+                                                         float(p), seed, off, state, _p(rm), _p(gflags), None, _s()), "layernorm_ex")
+                y = ops.linear(zf, weight, bias, relu=relu, row_flags=gflags)
+                del zf
         elif z16:
             z = torch.empty(x2.shape, dtype=torch.bfloat16, device=x.device)
             stats = torch.empty(2, M, dtype=torch.float32, device=x.device)
@@ -712,10 +794,11 @@ def _tt_jobs(wq, wk, wv, wd, wo):
     return [([wq, wk, wv], 0), ([wd], 0)] + ([([wo], 1), ([wo], 2)] if wo is not None else []) + [([wd], 3), ([wq, wk, wv], 2)]
 
 
-def tower_prepack(w_in, wq, wk, wv, wd, wo, mask=None):
+def tower_prepack(w_in, wq, wk, wv, wd, wo, mask=None, mixed=None):
     """Prepares (bf16 cast of the input projection's weight w_in - None: not wanted, fragment packs of the tower's matrices) in one
     launch and leaves them for the two consumers; with the batch's mask ((n, L) fp32) the same launch counts the sequence lengths,
-    which are returned (int32; None without a usable mask)."""
+    which are returned (int32; None without a usable mask).  mixed = (w_in or None, bq, bk, bv): in "mixed" precision also the
+    two-plane forms of the forward weights (one more launch: split2_jobs)."""
     jobs = _tt_jobs(wq, wk, wv, wd, wo)
     cast = w_in is not None and w_in.is_contiguous() and w_in.dtype == torch.float32 and w_in.numel() % 8 == 0
     lens = None
@@ -729,6 +812,15 @@ def tower_prepack(w_in, wq, wk, wv, wd, wo, mask=None):
     if cast:
         _PREPACKED["w16"] = (w_in.data_ptr(), ep, outs.pop())
     _PREPACKED["packs"] = (tuple(w.data_ptr() for w in (wq, wk, wv, wd) + ((wo,) if wo is not None else ())), ep, outs)
+    if mixed is not None and tower_train_mixed() and MIXED_PLANES:
+        # "mixed" precision: the tower's forward weights as two bf16 planes each (+ the three attention biases gathered), ONE launch
+        w_in_m, bq, bk, bv = mixed
+        jobs = ([(w_in_m, "split")] if w_in_m is not None else []) + [((wq, wk, wv), "split"), ((bq, bk, bv), "copy"), (wd, "split")] + \
+               ([(wo, "split")] if wo is not None else [])
+        res = split2_jobs(jobs, wq.device)
+        if w_in_m is not None:
+            _PREPACKED["w_in_planes"] = (w_in_m.data_ptr(), ep, res.pop(0))
+        _PREPACKED["mixed_planes"] = (tuple(w.data_ptr() for w in (wq, wk, wv, wd) + ((wo,) if wo is not None else ())), ep, res)
     return lens
 
 
@@ -881,13 +973,25 @@ class _TowerTrainMixed(Function):
         L_ = _L()
         f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)   # noqa: E731
         y2 = y0.reshape(M, HIDDEN)
-        # (1) h1 = dropout(LayerNorm(y0 + pos)), statistics kept
+        planes = mixed_planes_ok(M, HIDDEN, HIDDEN)
+        bf = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)   # noqa: E731
+        wqkv_p = bqkv = wd_p = wo_p = None
+        if planes:
+            mp = _take_prepacked("mixed_planes", tuple(w.data_ptr() for w in (wq, wk, wv, wd) + ((wo,) if video else ())))
+            if mp is None:
+                mp = split2_jobs([((wq, wk, wv), "split"), ((bq, bk, bv), "copy"), (wd, "split")] + ([(wo, "split")] if video else []), dev)
+            wqkv_p, bqkv, wd_p = mp[0], mp[1], mp[2]
+            wo_p = mp[3] if video else None
+        # (1) h1 = dropout(LayerNorm(y0 + pos)), statistics kept [planes: also as the two-plane operand of q | k | v]
         h1, stats = f32(M, HIDDEN), f32(2, M)
-        native.check(L_.dldkd_layernorm_ex_f32(_p(y2), _p(pos), L, _p(g1), _p(b1), _p(h1), None, None, _p(stats), M, HIDDEN, ops.LN_EPS,
+        h1p = bf(2, M, HIDDEN) if planes else None
+        native.check(L_.dldkd_layernorm_ex_f32(_p(y2), _p(pos), L, _p(g1), _p(b1), _p(h1), None, _p(h1p), None, _p(stats), M, HIDDEN, ops.LN_EPS,
                                                float(p_in), sa[0], sa[1], sa[2], None, None, _p(flags), _s()), "layernorm_ex")
         # (2) q | k | v: one fp32-grade GEMM (padding groups not multiplied)
-        wqkv, bqkv = torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0)
-        qkv = ops.linear(h1, wqkv, bqkv, row_flags=flags)
+        if planes:
+            qkv = gemm_planes(h1p, wqkv_p, bqkv, M, 3 * HIDDEN, HIDDEN, row_flags=flags)
+        else:
+            qkv = ops.linear(h1, torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0), row_flags=flags)
         # (3) the exact fp32 attention (probabilities written, not kept)
         ctxf = f32(N, L, HIDDEN)
         P = f32(N, HEADS, L, L)
@@ -895,26 +999,38 @@ class _TowerTrainMixed(Function):
                      "attention_train_fwd")
         del P
         # (4) dense -> dropout -> + h1 -> LayerNorm [-> out mapping]
-        d = ops.linear(ctxf.reshape(M, HIDDEN), wd, bd, row_flags=flags)
+        ctxp = None
+        if planes:
+            (ctxp,) = split2_jobs([(ctxf.reshape(M, HIDDEN), "split")], dev)
+            d = gemm_planes(ctxp, wd_p, bd, M, HIDDEN, HIDDEN, row_flags=flags)
+        else:
+            d = ops.linear(ctxf.reshape(M, HIDDEN), wd, bd, row_flags=flags)
         if p_hid > 0.0:
             dd, keep = torch.empty_like(d), torch.empty(d.shape, dtype=torch.uint8, device=dev)
             native.check(L_.dldkd_dropout_fwd_f32(_p(d), _p(dd), _p(keep), d.numel(), float(p_hid), sc[0], sc[1], sc[2], _s()), "dropout_fwd")
             del keep
         else:
             dd = d
-        h2, stats2 = f32(M, HIDDEN), f32(2, M)
-        native.check(L_.dldkd_layernorm_ex_f32(_p(dd), _p(h1), 0, _p(g2), _p(b2), _p(h2), None, None, _p(stats2), M, HIDDEN, ops.LN_EPS, 0.0,
+        stats2 = f32(2, M)
+        h2 = None if (planes and video) else f32(M, HIDDEN)               # (video towers on planes: the out mapping reads the planes only)
+        h2p = bf(2, M, HIDDEN) if (planes and video) else None
+        native.check(L_.dldkd_layernorm_ex_f32(_p(dd), _p(h1), 0, _p(g2), _p(b2), _p(h2), None, _p(h2p), None, _p(stats2), M, HIDDEN, ops.LN_EPS, 0.0,
                                                0, 0, None, None, None, _p(flags), _s()), "layernorm_ex")
-        out = ops.linear(h2, wo, bo, row_flags=flags).view(N, L, HIDDEN) if video else h2.view(N, L, HIDDEN)
-        # (5) what the fused bf16 backward reads
-        xh1, h1d, qkv16, ctxl, xh2 = (_bf16((M, HIDDEN), dev), _bf16((M, HIDDEN), dev), _bf16((M, 3 * HIDDEN), dev), _bf16((M, HIDDEN), dev),
-                                      _bf16((M, HIDDEN), dev))
+        if video:
+            out = (gemm_planes(h2p, wo_p, bo, M, HIDDEN, HIDDEN, row_flags=flags) if planes else ops.linear(h2, wo, bo, row_flags=flags)).view(N, L, HIDDEN)
+        else:
+            out = h2.view(N, L, HIDDEN)
+        # (5) what the fused bf16 backward reads (on planes: h1d / ctx / h2 as bf16 are plane 0 of the GEMM operands - not written again)
+        xh1, qkv16, xh2 = _bf16((M, HIDDEN), dev), _bf16((M, 3 * HIDDEN), dev), _bf16((M, HIDDEN), dev)
+        h1d = h1p[0] if planes else _bf16((M, HIDDEN), dev)
+        ctxl = ctxp[0] if planes else _bf16((M, HIDDEN), dev)
         rstd2 = f32(M)
         relu_bits = torch.empty(M * 48, dtype=torch.uint8, device=dev)
-        h2_16 = _bf16((M, HIDDEN), dev) if video else None
-        native.check(L_.dldkd_tower_train_emit(_p(y2), _p(pos), L, _p(stats), _p(h1), _p(qkv), _p(ctxf), _p(dd), _p(stats2),
-                                               _p(h2) if video else None, _p(flags), M, _p(xh1), _p(relu_bits), _p(h1d), _p(qkv16), _p(ctxl), _p(xh2),
-                                               _p(rstd2), _p(h2_16), _s()), "tower_train_emit")
+        h2_16 = (h2p[0] if planes else _bf16((M, HIDDEN), dev)) if video else None
+        emit_h2 = video and not planes
+        native.check(L_.dldkd_tower_train_emit(_p(y2), _p(pos), L, _p(stats), _p(h1), _p(qkv), None if planes else _p(ctxf), _p(dd), _p(stats2),
+                                               _p(h2) if emit_h2 else None, _p(flags), M, _p(xh1), _p(relu_bits), None if planes else _p(h1d), _p(qkv16),
+                                               None if planes else _p(ctxl), _p(xh2), _p(rstd2), _p(h2_16) if emit_h2 else None, _s()), "tower_train_emit")
         ctx.save_for_backward(xh1, pos, g1, g2, mask, lens, flags, h1d, stats, qkv16, ctxl, xh2, rstd2, h2_16, pk_ot, pk_dt, pk_qkvt, relu_bits)
         ctx.shape = (N, L)
         keep_alive = _philox_step.dev if _philox_step is not None else None
@@ -1073,6 +1189,15 @@ class _SimPoolTrain(Function):
                          "row_invnorm2_cast")
             native.check(_L().dldkd_simpool_train_fwd_bf16in(_p(q16), _p(g16), _p(rq), _p(rg), _p(lens), _p(labels), Nq, Nv, L, D, _p(pc),
                                                              _p(pr), _p(ac), _p(ar), _p(clip), _s()), "simpool_train_fwd_bf16in")
+        elif MIXED_PLANES and ops.gemm_precision() == "fp32x2" and D % 64 == 0 and L <= 128:
+            # "mixed" precision: both operands as two bf16 planes (written by the norm pass, which reads every row anyway), the pooled
+            # product in three K-long segments of the LDS-DMA kernel: the numbers of the in-kernel-split two-plane kernel
+            qp = torch.empty(2, Nq, D, dtype=torch.bfloat16, device=dev)
+            gp = torch.empty(2, Nv * L, D, dtype=torch.bfloat16, device=dev)
+            native.check(_L().dldkd_row_invnorm2_planes_f32(_p(q), _p(rq), _p(qp), Nq, _p(g), _p(rg), _p(gp), Nv * L, D, _s()),
+                         "row_invnorm2_planes")
+            native.check(_L().dldkd_simpool_train_fwd_planes(_p(qp), _p(gp), _p(rq), _p(rg), _p(lens), _p(labels), Nq, Nv, L, D, _p(pc), _p(pr),
+                                                             _p(ac), _p(ar), _p(clip), _s()), "simpool_train_fwd_planes")
         else:
             native.check(_L().dldkd_row_invnorm2_f32(_p(q), _p(rq), Nq, _p(g), _p(rg), Nv * L, D, _s()), "row_invnorm2")
             native.check(_L().dldkd_simpool_train_fwd_f32(ops._PREC_ID[ops.gemm_precision()], _p(q), _p(g), _p(rq), _p(rg), _p(lens),

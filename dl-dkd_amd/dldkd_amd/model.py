@@ -426,7 +426,8 @@ class DLDKD(nn.Module):
             # from ONE launch
             # ("mixed" precision: the projection's forward GEMM takes the fp32 weight - no bf16 cast of it)
             lens = F_.tower_prepack(proj.net[1].weight if (fused_proj and not F_.tower_train_mixed()) else None, enc.self.query.weight, enc.self.key.weight,
-                                    enc.self.value.weight, enc.output.dense.weight, None if out_lin is None else out_lin.weight, mask=mask)
+                                    enc.self.value.weight, enc.output.dense.weight, None if out_lin is None else out_lin.weight, mask=mask,
+                                    mixed=(proj.net[1].weight if fused_proj else None, enc.self.query.bias, enc.self.key.bias, enc.self.value.bias))
         if lens is None:
             lens = self._lens(mask, n, L, feat.device)
         y0 = proj(feat, row_mask=mask, grad_premasked=True) if fused_proj else proj(feat)

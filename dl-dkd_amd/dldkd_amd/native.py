@@ -62,11 +62,16 @@ SIGNATURES = {
                                                _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_gemm_f32x2": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p,
                                   _c_void_p]),
-    "dldkd_layernorm_ex_f32": (_c_int, [_c_void_p] * 9 + [_c_long, _c_int, _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p,
+    "dldkd_split2_bf16_jobs": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p]),
+    "dldkd_gemm_bf16_nt16_planes": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                             _c_void_p, _c_long, _c_long, _c_void_p]),
+    "dldkd_row_invnorm2_planes_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
+    "dldkd_simpool_train_fwd_planes": (_c_int, [_c_void_p] * 6 + [_c_int, _c_int, _c_int, _c_int] + [_c_void_p] * 6),
+    "dldkd_layernorm_ex_f32": (_c_int, [_c_void_p] * 10 + [_c_long, _c_int, _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64, _c_void_p,
                                          _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_tower_train_emit": (_c_int, [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 8 + [_c_long] + [_c_void_p] * 9),
     "dldkd_layernorm_dropout_bf16_dual": (_c_int, [_c_void_p] * 8 + [_c_long, _c_int, _c_float, _c_float, ctypes.c_uint64, ctypes.c_uint64,
-                                                    ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+                                                    ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p]),
     "dldkd_attention_train_fwd_bf16io": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float, ctypes.c_uint64,
                                                    ctypes.c_uint64, _c_void_p, _c_void_p]),
     "dldkd_attention_train_bwd_bf16io": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float,

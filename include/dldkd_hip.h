@@ -183,12 +183,12 @@ int dldkd_layernorm_groups_f32(const float* x, const float* add, int add_mod, co
                                unsigned char* keep, long M, int D, float eps, float p_drop, unsigned long long seed,
                                unsigned long long offset, const unsigned long long* state, const unsigned char* group_flags, void* stream);
 /* The general form of the LayerNorm launches in this section (LayerNorm(x [+ add]) [-> inverted dropout]): any of the outputs -
- * fp32 rows, bf16 rows (both may be given: "mixed" training keeps fp32 rows for its forward GEMM and bf16 rows for the backward
- * pass), keep bytes (NULL with p_drop > 0: the mask is applied, not written), statistics [2][M] - and either filter: row_mask (M
+ * fp32 rows, bf16 rows, TWO bf16 planes [2][M][D] (h = bf16(y), m = bf16(y - h): the operands of dldkd_gemm_bf16_nt16_planes -
+ * "mixed" training feeds its forward GEMM from them and keeps plane 0 for the backward pass; any subset may be given), keep bytes (NULL with p_drop > 0: the mask is applied, not written), statistics [2][M] - and either filter: row_mask (M
  * floats; group_flags_out then receives the 32-row group flags) or group_flags_in (flags an earlier launch wrote).  Semantics of each
  * as documented at dldkd_layernorm_dropout_f32 / _groups_f32 / _dropout_bf16. */
 int dldkd_layernorm_ex_f32(const float* x, const float* add, int add_mod, const float* gamma, const float* beta, float* out_f32,
-                           void* out_bf16, unsigned char* keep, float* stats, long M, int D, float eps, float p_drop,
+                           void* out_bf16, void* out_planes, unsigned char* keep, float* stats, long M, int D, float eps, float p_drop,
                            unsigned long long seed, unsigned long long offset, const unsigned long long* state, const float* row_mask,
                            unsigned char* group_flags_out, const unsigned char* group_flags_in, void* stream);
 /* The fp32-row twin of dldkd_layernorm_dropout_bf16 (parity mode): same row mask / group flags / statistics, fp32 output. */
@@ -368,11 +368,13 @@ int dldkd_gemm_bf16_mixed(int dw, const void* A, const void* B, const float* bia
  * exploration video tower normalise the same student features: method/model.py:229-243, model_components.py:305-310): x is read
  * once, mean / rstd taken once (stats: shared by the two backward passes), the row written twice - out0 = LN(x; gamma0, beta0)
  * with the dropout bits of (seed, offset0), out1 likewise with (gamma1, beta1, offset1) - exactly what two calls of
- * dldkd_layernorm_dropout_bf16 with keep == NULL write.  row_mask / group_flags as there. */
+ * dldkd_layernorm_dropout_bf16 with keep == NULL write.  row_mask / group_flags as there.  planes != 0: out0 / out1 are [2][M][D], the
+ * second bf16 plane (m = bf16(y - bf16(y))) behind the first - the two-plane GEMM operands of the "mixed" training precision. */
 int dldkd_layernorm_dropout_bf16_dual(const float* x, const float* gamma0, const float* beta0, const float* gamma1, const float* beta1,
                                       void* out0_bf16, void* out1_bf16, float* stats, long M, int D, float eps, float p_drop,
                                       unsigned long long seed, unsigned long long offset0, unsigned long long offset1,
-                                      const unsigned long long* state, const float* row_mask, unsigned char* group_flags, void* stream);
+                                      const unsigned long long* state, const float* row_mask, unsigned char* group_flags, int planes,
+                                      void* stream);
 /* dldkd_gemm_bf16_nt with BOTH operands bf16 in memory (A (M, K) = the rows dldkd_layernorm_dropout_bf16 writes, B (N, K) = the
  * weight cast by dldkd_cast_bf16): k-tiles of 64, no conversion on the way to the MFMA, half the dependent tile round trips.  The
  * forward GEMM of the training input projection (LinearLayer.forward, model_components.py:305-312).  K % 64 == 0, lda / ldb % 8 == 0,
@@ -381,6 +383,17 @@ int dldkd_cast_bf16(const float* x, void* y, long n, void* stream);
 int dldkd_gemm_bf16_nt16_ok(int M, int N, int K, int lda, int ldb);
 int dldkd_gemm_bf16_nt16(const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                          int relu, const unsigned char* row_flags, void* stream);
+/* Two-plane operands of the "mixed" training precision's forward GEMMs.  dldkd_split2_bf16_jobs: up to 12 jobs in one launch, job j
+ * splitting host_n[j] fp32 values (a multiple of 4) into h = bf16(x) -> host_dst_h[j] and m = bf16(x - h) -> host_dst_m[j] (kind 0), or
+ * copying them as fp32 to host_dst_h[j] (kind 1: e.g. the three attention biases into one vector) - a tower's weights once per step.
+ * dldkd_gemm_bf16_nt16_planes: C = act(A B^T + bias) from A_planes [2][M][lda] and B_planes [2][N][ldb] (plane strides in elements,
+ * multiples of 8): a_h b_h + a_h b_m + a_m b_h, smallest term first, as ONE pass of dldkd_gemm_bf16_nt16's LDS-DMA kernel over three
+ * K-long segments - the two-plane product of dldkd_gemm_f32x2 without the split on the way to LDS (2.5x its rate at the tower shapes).
+ * Constraints of dldkd_gemm_bf16_nt16. */
+int dldkd_split2_bf16_jobs(const float* const* host_src, void* const* host_dst_h, void* const* host_dst_m, const long* host_n,
+                           const int* host_kind, int njobs, void* stream);
+int dldkd_gemm_bf16_nt16_planes(const void* A_planes, const void* B_planes, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
+                                int ldc, int relu, const unsigned char* row_flags, long a_plane_stride, long b_plane_stride, void* stream);
 /* dldkd_gemm_bf16_mixed(dw = 1 or 3) with the bias gradient on the side: a_colsum[m] += sum_k A[k, m] over the k-tiles that are not
  * skipped (fp32 atomics into a buffer zeroed by the caller) - in nn.Linear's backward pass A is dY, so this is the bias gradient, taken
  * from the A tiles on their way to LDS instead of by a second pass over dY (ldc = N, no bias / ReLU). */
@@ -591,7 +604,8 @@ int dldkd_attention_train_bwd_bf16io(const void* qkv, const float* mask, const i
  * h2_16 (video towers; h2 = h2_16 = NULL otherwise).  y0, h1 (the position LayerNorm's output behind its dropout), ctx, dd (the
  * dense layer's output behind its dropout), h2: (M, 384) fp32; qkv (M, 1152); stats1 / stats2 [2][M] = (mean, rstd) of the two
  * LayerNorms (dldkd_layernorm_ex_f32); pos (>= L, 384); flags: the tower's 32-row group flags or NULL (rows of groups flagged 0
- * are not written).  Reference: model_components.py:277-284, 398-450. */
+ * are not written); h1d / ctx16 / h2_16 may be NULL (the caller already holds those rows: plane 0 of its two-plane GEMM operands).
+ * Reference: model_components.py:277-284, 398-450. */
 int dldkd_tower_train_emit(const float* y0, const float* pos, int L, const float* stats1, const float* h1, const float* qkv,
                            const float* ctx, const float* dd, const float* stats2, const float* h2, const unsigned char* flags, long M,
                            void* xh1, void* relu_bits, void* h1d, void* qkv16, void* ctx16, void* xh2, float* rstd2, void* h2_16, void* stream);
@@ -678,6 +692,13 @@ int dldkd_row_invnorm2_f32(const float* x0, float* inv0, long M0, const float* x
 int dldkd_row_invnorm2_cast_f32(const float* x0, float* inv0, void* y0_bf16, long M0, const float* x1, float* inv1, void* y1_bf16, long M1,
                                 int D, void* stream);
 int dldkd_simpool_train_fwd_bf16in(const void* q_bf16, const void* g_bf16, const float* rq, const float* rg, const int32_t* lens,
+                                   const int32_t* labels, int nq, int nv, int L, int D, float* pooled_cos, float* pooled_raw,
+                                   int32_t* arg_cos, int32_t* arg_raw, float* clip_pos, void* stream);
+/* The same from TWO bf16 planes per operand (dldkd_row_invnorm2_planes_f32 writes them beside the norms: q_planes [2][nq][D], g_planes
+ * [2][nv L][D]): the two-plane fp32-grade product - the pooled scores of the "mixed" training precision.  D % 64 == 0. */
+int dldkd_row_invnorm2_planes_f32(const float* x0, float* inv0, void* y0_planes, long M0, const float* x1, float* inv1, void* y1_planes, long M1,
+                                  int D, void* stream);
+int dldkd_simpool_train_fwd_planes(const void* q_planes, const void* g_planes, const float* rq, const float* rg, const int32_t* lens,
                                    const int32_t* labels, int nq, int nv, int L, int D, float* pooled_cos, float* pooled_raw,
                                    int32_t* arg_cos, int32_t* arg_raw, float* clip_pos, void* stream);
 int dldkd_simpool_train_fwd_f32(int precision, const float* q, const float* g, const float* rq, const float* rg,

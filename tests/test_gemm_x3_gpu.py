@@ -86,3 +86,35 @@ def test_x2_forward_is_two_plane_grade(M, N, K):
         assert e3 <= e2 or e2 < 1e-6
     finally:
         ops.set_gemm_precision(old)
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 384, 3072), (1024, 1152, 384), (300, 384, 768), (128, 70, 64)])
+def test_two_plane_gemm_over_plane_segments_matches_the_in_kernel_split(M, N, K):
+    """dldkd_gemm_bf16_nt16_planes (the LDS-DMA bf16 kernel over three K-long segments of pre-split operands: functional.split2_jobs /
+    gemm_planes) computes the two-plane product of dldkd_gemm_f32x2: same error class against fp64 (4e-5), row flags honoured, and
+    dldkd_split2_bf16_jobs writes h = bf16(x), m = bf16(x - h) (x = h + m to 2^-16) and gathers fp32 vectors."""
+    from dldkd_amd import functional as F_, ops
+    old = ops.precision_mode()
+    ops.set_gemm_precision("fp32x2")
+    try:
+        g = torch.Generator().manual_seed(M + N + K)
+        x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+        b3 = [torch.randn(4, generator=g).to(DEV) for _ in range(3)]
+        xp, wp, bcat = F_.split2_jobs([(xd, "split"), (wd, "split"), (tuple(b3), "copy")], xd.device)
+        assert xp.shape == (2, M, K) and wp.shape == (2, N, K) and torch.equal(bcat, torch.cat(b3))
+        assert torch.equal(xp[0], xd.bfloat16()) and torch.equal(xp[1], (xd - xd.bfloat16().float()).bfloat16())
+        assert float((xp[0].float() + xp[1].float() - xd).abs().max()) <= 2.0 ** -15 * float(xd.abs().max())
+        ref = torch.relu(x.double() @ w.double().t() + b.double())
+        y = F_.gemm_planes(xp, wp, bd, M, N, K, relu=True)
+        assert _rel(y, ref) < 4e-5
+        y2 = ops.linear(xd, wd, bd, relu=True)                      # the in-kernel-split two-plane kernel
+        assert _rel(y, y2.double().cpu()) < 2e-6                    # same products, another summation order
+        if M % 128 == 0:
+            flags = torch.ones(M // 32, dtype=torch.uint8, device=DEV)
+            flags[2::4] = 0
+            yf = F_.gemm_planes(xp, wp, bd, M, N, K, relu=True, row_flags=flags)
+            keep = flags.bool().repeat_interleave(32).cpu()
+            assert torch.equal(yf.cpu()[keep], y.cpu()[keep])
+    finally:
+        ops.set_gemm_precision(old)

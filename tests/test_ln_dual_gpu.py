@@ -32,7 +32,7 @@ def test_dual_launch_writes_what_two_single_launches_write(nv, L, K, p):
     gfl = torch.empty(M // 32, dtype=torch.uint8, device=DEV)
     P = native.ptr
     native.check(lib.dldkd_layernorm_dropout_bf16_dual(P(x), P(gam[0]), P(bet[0]), P(gam[1]), P(bet[1]), P(z[0]), P(z[1]), P(stats), M, K,
-                                                      ops.LN_EPS, p, seed, offs[0], offs[1], None, P(mask), P(gfl), native.stream()), "dual")
+                                                      ops.LN_EPS, p, seed, offs[0], offs[1], None, P(mask), P(gfl), 0, native.stream()), "dual")
     for b in range(2):
         zr = torch.full((M, K), 9.0, dtype=torch.bfloat16, device=DEV)
         sr = torch.empty(2, M, device=DEV)
@@ -47,9 +47,18 @@ def test_dual_launch_writes_what_two_single_launches_write(nv, L, K, p):
     st = torch.tensor([seed, 1000], dtype=torch.int64, device=DEV)
     z2 = [torch.empty_like(z[0]) for _ in range(2)]
     native.check(lib.dldkd_layernorm_dropout_bf16_dual(P(x), P(gam[0]), P(bet[0]), P(gam[1]), P(bet[1]), P(z2[0]), P(z2[1]), P(stats), M, K,
-                                                      ops.LN_EPS, p, 0, offs[0] - 1000, offs[1] - 1000, P(st), P(mask), P(gfl),
+                                                      ops.LN_EPS, p, 0, offs[0] - 1000, offs[1] - 1000, P(st), P(mask), P(gfl), 0,
                                                       native.stream()), "dual_state")
     assert torch.equal(z2[0].view(torch.int16), z[0].view(torch.int16)) and torch.equal(z2[1].view(torch.int16), z[1].view(torch.int16))
+    # the two-plane form ("mixed" precision): [2][M][K] per branch = what dldkd_layernorm_ex_f32 writes as out_planes; plane 0 = the bf16 rows
+    zp = [torch.empty(2, M, K, dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    native.check(lib.dldkd_layernorm_dropout_bf16_dual(P(x), P(gam[0]), P(bet[0]), P(gam[1]), P(bet[1]), P(zp[0]), P(zp[1]), P(stats), M, K,
+                                                      ops.LN_EPS, p, seed, offs[0], offs[1], None, P(mask), P(gfl), 1, native.stream()), "dual_planes")
+    for b in range(2):
+        ref = torch.empty(2, M, K, dtype=torch.bfloat16, device=DEV)
+        native.check(lib.dldkd_layernorm_ex_f32(P(x), None, 0, P(gam[b]), P(bet[b]), None, None, P(ref), None, P(stats), M, K, ops.LN_EPS, p, seed,
+                                                offs[b], None, P(mask), P(gfl), None, native.stream()), "ln_ex_planes")
+        assert torch.equal(zp[b].view(torch.int16), ref.view(torch.int16)) and torch.equal(zp[b][0].view(torch.int16), z[b].view(torch.int16))
 
 
 def _model(drop):
