@@ -932,6 +932,22 @@ def train(model, train_dataset, val_video_dataset, val_text_dataset, opt):
     """Epoch loop with eval after each epoch, best-checkpoint saving and early stop (train.py:191-247)."""
     rank, world = dist_info()
     model.to(opt.device)
+    # opt.train_precision: "parity" / "fp32" (the default of the process), "mixed" (fp32-grade forward - the seven losses within 1e-6 of
+    # the reference's - and the throughput mode's bf16 backward: 2x the parity step rate) or "bf16" (throughput); None: whatever
+    # ops.set_gemm_precision was given.  Restored when train() returns.
+    from . import ops as _ops
+    tp = getattr(opt, "train_precision", None)
+    prev_precision = _ops.precision_mode()
+    if tp is not None:
+        _ops.set_gemm_precision({"parity": "fp32"}.get(tp, tp))
+        logger.info(f"training precision: {_ops.precision_mode()}")
+    try:
+        return _train(model, train_dataset, val_video_dataset, val_text_dataset, opt, rank, world)
+    finally:
+        _ops.set_gemm_precision(prev_precision)
+
+
+def _train(model, train_dataset, val_video_dataset, val_text_dataset, opt, rank, world):
     loader = make_train_loader(train_dataset, opt, rank, world)
     optimizer = make_optimizer(model, opt, len(loader))
     if world > 1:

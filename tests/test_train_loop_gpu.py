@@ -82,7 +82,7 @@ def test_train_loop_learns_and_checkpoints(tmp_path):
         assert eval_epoch(m2.to(DEV), L(ds.videos()), L(ds.texts()), opt) == pytest.approx(max(sumr))
 
 
-def _fit(precision, tmp_path, force_ddp=False):
+def _fit(precision, tmp_path, force_ddp=False, train_precision=None):
     from dldkd_amd.model import DLDKD
     from dldkd_amd import train as T, ops
     ds = TinySet()
@@ -95,7 +95,9 @@ def _fit(precision, tmp_path, force_ddp=False):
                                 hard_negative_start_epoch=0, hard_pool_size=5, distill_loss_decay="exp", exponential_k=0.95,
                                 selfDistil_sigmoid_k=800, alpha_decay="sigmoid", belta_decay="sigmoid", grad_clip=-1,
                                 eval_context_bsz=16, eval_query_bsz=50, eval_untrained=True,
-                                ckpt_filepath=str(tmp_path / f"model_{precision}.ckpt"))
+                                ckpt_filepath=str(tmp_path / f"model_{precision}_{train_precision}.ckpt"))
+    if train_precision is not None:
+        opt.train_precision = train_precision
     torch.manual_seed(0)
     m = DLDKD(cfg, opt)
     ops.set_gemm_precision(precision)
@@ -150,7 +152,23 @@ def test_data_parallel_step_on_one_rank_rccl_group(tmp_path, rccl_comm):
         assert a[1]["loss_overall"] == pytest.approx(b[1]["loss_overall"], rel=2e-3)
 
 
-@pytest.mark.parametrize("prec,drop", [("fp32", 0.0), ("fp32", 0.2), ("bf16", 0.2)])
+def test_train_takes_its_precision_from_opt_and_mixed_tracks_parity(tmp_path):
+    """opt.train_precision = "mixed" (fp32-grade forward, bf16 backward): train() sets and restores the precision itself, and the run
+    follows the parity run like the throughput run does (same data, seeds, schedule) - with loss values that ARE parity-grade."""
+    from dldkd_amd import ops
+    ref = _fit("fp32", tmp_path)
+    got = _fit("fp32", tmp_path, train_precision="mixed")
+    assert ops.precision_mode() == "fp32"                                   # restored
+    l_ref = [h[1]["loss_overall"] for h in ref[1:]]
+    l_got = [h[1]["loss_overall"] for h in got[1:]]
+    assert all(np.isfinite(l_got)) and l_got[-1] < l_got[0]
+    assert abs(l_got[0] - l_ref[0]) <= 2e-3 * abs(l_ref[0]) + 1e-3, (l_got, l_ref)     # first epoch: same parameters' worth of steps
+    assert abs(l_got[1] - l_ref[1]) <= 0.01 * abs(l_ref[1]) + 0.005, (l_got, l_ref)
+    s_ref, s_got = [h[2] for h in ref], [h[2] for h in got]
+    assert max(s_got[1:]) > s_got[0] + 20 and max(s_got[1:]) >= max(s_ref[1:]) - 25, (s_got, s_ref)
+
+
+@pytest.mark.parametrize("prec,drop", [("fp32", 0.0), ("fp32", 0.2), ("bf16", 0.2), ("mixed", 0.2)])
 def test_graphed_train_step_equals_eager(prec, drop):
     """train.GraphedTrainStep (zero_grad / forward / backward / fused BertAdam replayed from ONE hipGraph, method/train.py:141-151)
     against the eager step.  Two replicas; before EVERY step the graphed replica is given the eager replica's parameters,

@@ -32,7 +32,7 @@ def run(steps=1500, seeds=3, nv=4096, nq=8192, sigma=6.0, every=10, win=10, chun
     models, curves, secs = {}, {}, {}
     for name in runs:
         t0 = time.time()
-        m, losses = G.train_model(steps, sigma, P, Pt, seed=0, precision="bf16" if name == "bf16" else "fp32", every=every, log=None)
+        m, losses = G.train_model(steps, sigma, P, Pt, seed=0, precision={"bf16": "bf16", "mixed": "mixed"}.get(name, "fp32"), every=every, log=None)
         models[name], curves[name], secs[name] = m, losses, round(time.time() - t0, 2)
         log(f"trained {name}: {steps} steps in {secs[name]} s, loss {losses[0][1]:.3f} -> {losses[-1][1]:.3f}")
     res = {"task": "TVR dims (Dv 3072, Dq 768), planted pairs, 128 videos x 5 captions per step, dropout 0.1, hard negatives, soft labels",
@@ -66,8 +66,9 @@ if __name__ == "__main__":
     ap.add_argument("--nv", type=int, default=4096)
     ap.add_argument("--nq", type=int, default=8192)
     ap.add_argument("--out", default="")
+    ap.add_argument("--runs", default="parity,parity_b,bf16", help="comma-separated: parity first, then any of parity_b, bf16, mixed")
     a = ap.parse_args()
-    res = run(a.steps, a.seeds, a.nv, a.nq)
+    res = run(a.steps, a.seeds, a.nv, a.nq, runs=tuple(a.runs.split(",")))
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         json.dump(res, open(a.out, "w"), indent=1)
