@@ -154,7 +154,7 @@ __device__ __forceinline__ void attn_train_fwd_body(const AttnTrainArgs& p, floa
         f32x4 pv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { pv[e] = s[kt][4 * g + e] * inv; s[kt][4 * g + e] = pv[e] * k4[e]; }
-        if (q < L) {
+        if (q < L && p.P != nullptr) {            // (P == null: a forward whose backward recomputes the probabilities - "mixed" training)
             if (vec) { if (kb < L) *reinterpret_cast<f32x4*>(p.P + prow + kb) = pv; }
             else {
 #pragma unroll
@@ -427,7 +427,7 @@ int dldkd_attention_train_fwd_f32(const float* qkv, const float* mask, float* pr
     const int rc = attn_train_args(a, N, L, p_drop, seed, offset, state, "attention_train_fwd");
     if (rc != DLDKD_OK) return rc;
     if (N == 0) return DLDKD_OK;
-    if (!qkv || !probs || !out) { set_error("attention_train_fwd: null pointer"); return DLDKD_EINVAL; }
+    if (!qkv || !out) { set_error("attention_train_fwd: null pointer"); return DLDKD_EINVAL; }
     a.qkv = qkv; a.mask = mask; a.P = probs; a.out = out;
     const int LP = ((L + 31) / 32) * 32;
     const size_t lds = (size_t)(2 * LP * kPitch + LP * kDhT + LP) * sizeof(float);

@@ -992,12 +992,10 @@ class _TowerTrainMixed(Function):
             qkv = gemm_planes(h1p, wqkv_p, bqkv, M, 3 * HIDDEN, HIDDEN, row_flags=flags)
         else:
             qkv = ops.linear(h1, torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0), row_flags=flags)
-        # (3) the exact fp32 attention (probabilities written, not kept)
+        # (3) the exact fp32 attention (probabilities not written: the bf16 backward kernel recomputes them)
         ctxf = f32(N, L, HIDDEN)
-        P = f32(N, HEADS, L, L)
-        native.check(L_.dldkd_attention_train_fwd_f32(_p(qkv), _p(mask), _p(P), _p(ctxf), N, L, float(p_attn), sb[0], sb[1], sb[2], _s()),
+        native.check(L_.dldkd_attention_train_fwd_f32(_p(qkv), _p(mask), None, _p(ctxf), N, L, float(p_attn), sb[0], sb[1], sb[2], _s()),
                      "attention_train_fwd")
-        del P
         # (4) dense -> dropout -> + h1 -> LayerNorm [-> out mapping]
         ctxp = None
         if planes:

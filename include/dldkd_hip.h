@@ -540,7 +540,8 @@ int dldkd_triplet_f32(const float* C, const int32_t* labels, const int32_t* r_t2
  *        dropped probabilities (a saved tensor of a graph that is walked once).
  * Dropout: keep iff Philox4x32-10(seed, offset + idx / 4)[idx % 4] >= p * 2^32 on the flat index of probs - the masks
  * dldkd_dropout_fwd_f32 would draw for that tensor with the same (seed, offset); p_drop = 0 disables it.  state: NULL or
- * device {seed, base offset} as in dldkd_dropout_fwd_f32 (hipGraph-captured step). */
+ * device {seed, base offset} as in dldkd_dropout_fwd_f32 (hipGraph-captured step).  probs may be NULL in the forward call (not written: a caller whose backward pass
+ * recomputes them - the "mixed" training precision). */
 int dldkd_attention_train_fwd_f32(const float* qkv, const float* mask, float* probs, float* out, int N, int L, float p_drop,
                                   unsigned long long seed, unsigned long long offset, const unsigned long long* state,
                                   void* stream);

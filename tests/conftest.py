@@ -34,7 +34,7 @@ _GPU_ORDER = ["test_simpool_gpu", "test_encoder_gpu", "test_in_proj_gpu", "test_
               "test_tower_train_gpu", "test_train_gpu", "test_bf16_mode_gpu", "test_train_mode_gpu", "test_eval_gpu", "test_optim_gpu",
               "test_ingest_gpu", "test_fullsize_properties_gpu", "test_c4_properties_gpu", "test_rk_gate_gpu", "test_train_ab_gpu", "test_api_edges_gpu",
               "test_train_loop_gpu", "test_abi_contract_gpu"]
-_GPU_LAST = ["test_comm_gpu", "test_dist_gpu", "test_abi_client_gpu", "test_bench_gpu"]
+_GPU_LAST = ["test_overflow_guard_gpu", "test_comm_gpu", "test_dist_gpu", "test_abi_client_gpu", "test_bench_gpu"]
 
 
 def pytest_collection_modifyitems(session, config, items):

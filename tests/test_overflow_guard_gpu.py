@@ -90,3 +90,22 @@ def test_the_guard_stays_silent_on_an_ordinary_checkpoint(caplog):
                              _opt(eval_precision="throughput", eval_overflow="raise"))
     assert not any("overflowed" in r.getMessage() for r in caplog.records)
     assert abs(sumr - ref_sumr) <= 1.6 and not ops.take_nonfinite(DEV)
+
+
+def test_sharded_eval_takes_the_same_branch_on_every_rank(rccl_comm, caplog):
+    """eval_epoch_sharded: the flag is MAX-all-reduced (a one-rank RCCL group here) before anyone reads it, so every rank repeats the
+    evaluation in parity mode together; the result is the unsharded guarded evaluation's."""
+    from dldkd_amd import eval as ev, ops
+    params = _scaled(synth.make_params(51, 3072, 768), "input_proj")
+    vids, txts = synth.make_eval_sets(5, nv=64, caps=3, dv=3072, dq=768)
+    m = _model(3072, 768, params)
+    vd, td = synth.ListDataset(list(vids)), synth.ListDataset(list(txts))
+    with torch.no_grad():
+        plain = ev.eval_epoch(m, vd, td, _opt(eval_precision="throughput", eval_feature_cache=False))
+        with caplog.at_level(logging.WARNING):
+            sharded = ev.eval_epoch_sharded(m, vd, td, _opt(eval_precision="throughput", eval_feature_cache=False))
+        assert any("repeating the sharded evaluation in parity mode" in r.getMessage() for r in caplog.records)
+        assert sharded == pytest.approx(plain, abs=1e-6)
+        with pytest.raises(RuntimeError, match="overflowed the fp16 operands"):
+            ev.eval_epoch_sharded(m, vd, td, _opt(eval_precision="throughput", eval_overflow="raise", eval_feature_cache=False))
+    assert ops.precision_mode() == "fp32" and not ops.take_nonfinite(DEV)
