@@ -173,7 +173,9 @@ class GalleryPacker:
         self.nv, self.L, self.normalize, self.filled = nv, L, normalize, 0
         nbytes = L_.dldkd_packed_gallery_bytes(nv, L)
         if blobs is not None:
-            if len(blobs) != n_branches or any(b.numel() != nbytes or b.device != torch.device(device) for b in blobs):
+            want = torch.device(device)
+            same = lambda b: b.device.type == want.type and (want.index is None or b.device.index == want.index)   # noqa: E731
+            if len(blobs) != n_branches or any(b.numel() != nbytes or not same(b) for b in blobs):
                 raise native.NativeError("GalleryPacker: the buffers handed in do not fit this gallery")
             self.blobs, self.zero_padded = list(blobs), True
         else:
