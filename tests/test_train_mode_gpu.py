@@ -118,11 +118,12 @@ def _assert_grads(stats, rel_tol, what, cos_min=None):
 
 
 # ----------------------------------------------------------------------------------------------------------------- golden G4t
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "mixed"])
 @pytest.mark.parametrize("tag", [c[0] for c in synth.G4T_CASES])
 def test_train_mode_forward_backward_vs_golden_g4t(golden_dir, monkeypatch, tag, prec):
     """The REFERENCE's own train-mode step (model.train(), dropout 0): 7 losses within 1e-4 and all 74 gradients in parity mode,
-    2e-2 in throughput (bf16) mode; the padding-skip path must actually have skipped the all-padding row groups."""
+    2e-2 in throughput (bf16) mode, 1e-4 on the losses with bf16-backward gradients in mixed mode; the padding-skip path must
+    actually have skipped the all-padding row groups."""
     from dldkd_amd import ops
     g = np.load(f"{golden_dir}/g4t_forward_train.npz")
     batch, hard, nv, seed = synth.g4t_batch(tag)
@@ -141,18 +142,19 @@ def test_train_mode_forward_backward_vs_golden_g4t(golden_dir, monkeypatch, tag,
         ops.set_gemm_precision("fp32")
     skipped, groups = log.assert_skipped(lens, 64)
     print(f"  {tag} {prec}: {skipped} of {groups} 32-row groups skipped")
-    tol = 1e-4 if prec == "fp32" else 2e-2
+    exact_fwd = prec in ("fp32", "mixed")
+    tol = 1e-4 if exact_fwd else 2e-2
     for k in LOSS_KEYS + ("loss",):
         got = float(loss if k == "loss" else d[k])
         ref = float(g[f"{tag}_{k}"].reshape(()))
-        assert abs(got - ref) <= tol * max(abs(ref), 1e-3 if prec == "fp32" else 0.1), (k, got, ref)
+        assert abs(got - ref) <= tol * max(abs(ref), 1e-3 if exact_fwd else 0.1), (k, got, ref)
     names = [n for n, _ in m.named_parameters()]
     assert len(names) == 74
     gmax = max(float(np.abs(g[f"{tag}_grad/{n}/sample"]).max()) for n in names)
     nmax = max(float(g[f"{tag}_grad/{n}/norm"]) for n in names)
     # throughput mode: bf16 operand rounding through the stacked GEMMs; single sampled elements of a small tensor move by tens of
     # per cent of the tensor's largest element while its norm stays within a few per cent (measured 0.26 / 0.37 and 0.03)
-    gtol, ntol = (3e-3, 3e-3) if prec == "fp32" else (0.6, 0.15)
+    gtol, ntol = (3e-3, 3e-3) if prec == "fp32" else (0.1, 0.03) if prec == "mixed" else (0.6, 0.15)
     worst, worst_n = 0.0, 0.0
     for n, prm in m.named_parameters():
         gr = prm.grad.detach().reshape(-1).cpu()
