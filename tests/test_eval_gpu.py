@@ -386,3 +386,41 @@ def test_resident_gallery_features_match_the_padded_super_batches(monkeypatch):
         assert np.abs(ranks.astype(np.int64) - r_old.astype(np.int64)).max() <= 3
         assert np.abs(ranks.astype(np.int64) - r_old.astype(np.int64)).mean() < 0.5
     ev.clear_feature_cache()
+
+
+def test_reused_gallery_buffers_equal_a_fresh_encode():
+    """From the second epoch on, eval_epoch re-encodes the gallery IN PLACE into the buffers of the first cached epoch
+    (eval.ResidentGallery.gallery_blobs: zero-filled once; the fused tower kernel then skips the rows past a video's last 16-row
+    tile, ops.SKIP_ZERO_ROWS).  Bit for bit the packed gallery a fresh encode writes (every row, the padding included) - also
+    after the model's weights changed between the epochs (nothing of the older encode survives in the valid rows) - and the R@K
+    of the reference's per-batch path (method/eval.py:139-155) comes out the same."""
+    from dldkd_amd import eval as ev
+    vids, txts = synth.make_eval_sets(13, nv=90, caps=2, dv=3072, dq=768)
+    dv, dt = synth.ListDataset(list(vids)), synth.ListDataset(list(txts))
+    opt = _opt()
+    opt.eval_precision = "throughput"
+    models = [_model(3072, 768, synth.make_params(s, 3072, 768)) for s in (71, 72)]
+
+    def epoch(m):
+        with torch.no_grad(), ev.eval_precision(m, opt):
+            info = ev.compute_context_info(m, dv, opt, keep_frame_feats=False)
+            ranks, _ = ev.rank_queries(m, dt, opt, info)
+        return [b.clone() for b in info["_packed"].blobs], ranks, info["_packed"]
+
+    fresh = []
+    for m in models:                                        # first epochs: buffers the kernel writes whole, padding included
+        ev.clear_feature_cache()
+        fresh.append(epoch(m))
+    ev.clear_feature_cache()
+    epoch(models[0])                                        # builds the resident table
+    first = epoch(models[0])                                # cached: zero-filled buffers, padding rows skipped
+    res = next(iter(ev._FEATURE_CACHE[dv].values()))
+    kept = [b.data_ptr() for b in res.gallery_blobs]
+    again = epoch(models[0])                                # in place
+    other = epoch(models[1])                                # in place, other weights
+    assert [b.data_ptr() for b in other[2].blobs] == kept
+    for got, want in ((first, fresh[0]), (again, fresh[0]), (other, fresh[1])):
+        assert all(torch.equal(x, y) for x, y in zip(got[0], want[0]))
+        assert np.array_equal(got[1], want[1])
+    assert any(not torch.equal(x, y) for x, y in zip(fresh[0][0], fresh[1][0]))
+    ev.clear_feature_cache()
