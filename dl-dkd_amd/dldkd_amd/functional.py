@@ -3,6 +3,7 @@
 torch supplies tensors, the tape and the stream; every number is produced by libdldkd_hip.so.  Under
 torch.no_grad() the same entry points run the fused inference kernels (ops.attention etc.).
 """
+import contextlib
 import math
 import os
 
@@ -1400,12 +1401,81 @@ def _is_unit(g):
     return t is not None and g.data_ptr() == t.data_ptr() and g.numel() == 1
 
 
+class ScheduleWords:
+    """The scalars an epoch's schedule moves (train.epoch_schedules: alpha, belta, the KD weight; train.py:66-113) as DEVICE state a
+    captured step reads by address: the InfoNCE coefficient vectors cq (Nq) / cv (Nv) and, per loss weight w_kl, four words
+    {hardQ, hardV, bits(belta), bits(w_kl)} (dldkd_branch_losses_f32 `sched`).  train.GraphedTrainStep makes one per captured step,
+    installs it around the capture (`schedule_words`) and calls update() before every replay: a graph captured in epoch 0 serves
+    every epoch (by value the scalars were part of the graph's key: a capture per epoch, and none after max_captures).
+    update() enqueues a few fills on the current stream when - and only when - the values changed."""
+
+    def __init__(self, nq, nv, soft, device):
+        self.nq, self.nv, self.soft, self.device = int(nq), int(nv), bool(soft), torch.device(device)
+        self.cq = torch.zeros(self.nq, dtype=torch.float32, device=self.device)
+        self.cv = torch.zeros(self.nv, dtype=torch.float32, device=self.device)
+        self.words = {}                   # w_kl factor (host float, e.g. kl_intra_weight or 0.0) -> (4,) int32 device words
+        self.state = None
+        self.used = 0                     # branch_losses calls that took their scalars from here
+
+    def words_for(self, factor):
+        """The device words of a branch whose KL weight is `factor` x the epoch's KD weight (made while the step is captured)."""
+        f = float(factor)
+        if f not in self.words:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ScheduleWords: a branch's words must exist before the capture (prepare())")
+            self.words[f] = torch.zeros(4, dtype=torch.int32, device=self.device)
+            self.state = None
+        return self.words[f]
+
+    @staticmethod
+    def coefs(n_q, n_v, alpha, soft):
+        """(hardQ, hardV, (wq_hard, wq_soft), (wv_hard, wv_soft)) of clip_nce_soft / clip_nce (model_components.py:126-234)."""
+        if not soft:
+            return n_q, n_v, (0.0, 1.0 / n_q), (0.0, 1.0 / n_v)
+        hq, hv = math.floor(alpha * n_q), math.floor(alpha * n_v)
+        sq, sv = n_q - hq, n_v - hv
+        use_hard, use_soft = hq != 0 and hv != 0, sq != 0 and sv != 0
+        return (hq, hv, (alpha / hq if use_hard else 0.0, (1 - alpha) / sq if use_soft else 0.0),
+                (alpha / hv if use_hard else 0.0, (1 - alpha) / sv if use_soft else 0.0))
+
+    def update(self, alpha, beta, weight):
+        state = (float(alpha), float(beta), float(weight), tuple(self.words))
+        if state == self.state:
+            return False
+        hq, hv, (qh, qs), (vh, vs) = self.coefs(self.nq, self.nv, float(alpha), self.soft)
+        for c, h, wh, ws in ((self.cq, hq, qh, qs), (self.cv, hv, vh, vs)):
+            c.fill_(float(ws))
+            if self.soft and h > 0:
+                c[:h].fill_(float(wh))
+        b = float(beta) if self.soft else 0.0
+        for f, w in self.words.items():
+            w[0:1].fill_(int(hq)); w[1:2].fill_(int(hv))
+            w.view(torch.float32)[2:3].fill_(b)
+            w.view(torch.float32)[3:4].fill_(float(f * float(weight)))
+        self.state = state
+        return True
+
+
+_SCHED = None
+
+
+@contextlib.contextmanager
+def schedule_words(sw):
+    """branch_losses calls inside read the schedule's scalars from `sw` (device) instead of baking the host values in."""
+    global _SCHED
+    prev, _SCHED = _SCHED, sw
+    try:
+        yield sw
+    finally:
+        _SCHED = prev
+
+
 class _BranchLoss(Function):
     """The loss terms of one branch (model.py:137-155) from its pooled scores, values and gradients in one pass: the gradients are
     computed with the values (for an upstream gradient of 1) and scaled by the actual upstream gradients in the backward pass."""
 
     @staticmethod
-    def forward(ctx, C, S, T, clip_p, clip_t, labels, lens, r_t2v, r_v2t, cq, cv, cfg):
+    def forward(ctx, C, S, T, clip_p, clip_t, labels, lens, r_t2v, r_v2t, cq, cv, cfg, sched=None):
         hard, hardQ, hardV, fold_t, margin, beta, eps, temp, w_nce, w_kl = cfg
         nq, nv = C.shape
         dev = C.device
@@ -1418,7 +1488,7 @@ class _BranchLoss(Function):
         native.check(_L().dldkd_branch_losses_f32(_p(C), _p(S), _p(T), _p(clip_p), _p(clip_t), _p(labels), _p(lens), _p(r_t2v), _p(r_v2t),
                                                   _p(cq), _p(cv), nq, nv, Lc, int(hard), int(hardQ), int(hardV), int(fold_t), float(margin),
                                                   float(beta), float(eps), float(temp), float(w_nce), float(w_kl), _p(terms), _p(dC), _p(dS),
-                                                  _p(dclip), _p(out), _s()), "branch_losses")
+                                                  _p(dclip), _p(out), _p(sched), _s()), "branch_losses")
         ctx.save_for_backward(dC, dS, dclip)
         ctx.set_materialize_grads(False)       # a term nobody uses has no upstream gradient (None, handled in backward): no zero fill
         return out[0], out[1], out[2]
@@ -1429,7 +1499,7 @@ class _BranchLoss(Function):
         dC, dS, dclip = ctx.saved_tensors
         if (g_trip is not None and g_nce is not None and _is_unit(g_trip) and _is_unit(g_nce)
                 and (dclip is None or (g_kl is not None and _is_unit(g_kl)))):
-            return dC, dS, None, dclip, None, None, None, None, None, None, None, None      # scaling by exactly 1: nothing to launch
+            return dC, dS, None, dclip, None, None, None, None, None, None, None, None, None      # scaling by exactly 1: nothing to launch
         # The saved gradients are scaled IN PLACE and handed out as they are (no second copy of two (Nq, Nv) matrices per branch): a
         # second backward pass through this node (retain_graph=True) would scale them twice.  Once only, loudly.
         if getattr(ctx, "_scaled", False):
@@ -1446,14 +1516,27 @@ class _BranchLoss(Function):
             return one
         native.check(_L().dldkd_branch_losses_scale_f32(_p(dC), _p(dS), dC.numel(), _p(dclip), 0 if dclip is None else dclip.numel(),
                                                         _p(gs(g_trip)), _p(gs(g_nce)), _p(gs(g_kl)), _s()), "branch_losses_scale")
-        return dC, dS, None, dclip, None, None, None, None, None, None, None, None
+        return dC, dS, None, dclip, None, None, None, None, None, None, None, None, None
 
 
-def branch_losses(C, S, T, clip_p, clip_t, labels, lens, r_t2v, r_v2t, hard, margin, soft, alpha, beta, w_nce, w_kl, fold_t):
+def branch_losses(C, S, T, clip_p, clip_t, labels, lens, r_t2v, r_v2t, hard, margin, soft, alpha, beta, w_nce, w_kl, fold_t, kd_factor=None):
     """(triplet, w_nce * InfoNCE, w_kl * KL) of one branch.  soft: clip_nce_soft with soft-label scores T (fold_t: T is S itself,
-    exploration branch), else clip_nce.  clip_p None: no KL term (the third value is 0)."""
+    exploration branch), else clip_nce.  clip_p None: no KL term (the third value is 0).  kd_factor: w_kl = kd_factor x the epoch's KD
+    weight (what a ScheduleWords needs to follow the schedule; None: w_kl is a constant of the run)."""
     C, S = _f32(C), _f32(S)
     Nq, Nv = S.shape
+    sw = _SCHED
+    if sw is not None and kd_factor is not None and (sw.nq, sw.nv, sw.soft) == (Nq, Nv, bool(soft)) and S.is_cuda:
+        # the schedule's scalars as device state (ScheduleWords): this launch reads hardQ / hardV / belta / w_kl and the coefficient
+        # vectors by address; the by-value arguments are the current epoch's (what the words hold right now) and are ignored
+        hardQ, hardV, _, _ = sw.coefs(Nq, Nv, float(alpha), bool(soft))
+        eps, Tt = (1e-12, None if fold_t else _f32(T).detach()) if soft else (0.0, None)
+        if not soft:
+            fold_t, beta = False, 0.0
+        cfg = (bool(hard), hardQ, hardV, bool(fold_t), float(margin), float(beta), eps, 0.2, float(w_nce), float(w_kl))
+        sw.used += 1
+        return _BranchLoss.apply(C, S, Tt, None if clip_p is None else _f32(clip_p), None if clip_t is None else _f32(clip_t).detach(), labels,
+                                 lens, r_t2v, r_v2t, sw.cq, sw.cv, cfg, sw.words_for(kd_factor))
     if soft:
         hardQ, hardV = math.floor(alpha * Nq), math.floor(alpha * Nv)
         softQ, softV = Nq - hardQ, Nv - hardV

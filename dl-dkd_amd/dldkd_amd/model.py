@@ -637,7 +637,8 @@ class DLDKD(nn.Module):
             if fused_losses:
                 r_t2v, r_v2t = draws(0)
                 return F_.branch_losses(i_cos, i_raw, t_raw, i_clip, t_clip, lab, lens, r_t2v, r_v2t, hard_neg, _cfg_get(self.config, "margin"),
-                                        soft, self.alpha, self.belta, self.inher_nce_weight, self.kl_intra_weight * self.weight, False)
+                                        soft, self.alpha, self.belta, self.inher_nce_weight, self.kl_intra_weight * self.weight, False,
+                                        kd_factor=self.kl_intra_weight)
             inher_trip = trip(i_cos, 0)
             if soft:
                 inher_nce = self.inher_nce_weight * F_.nce_soft(lab, i_raw, t_raw, self.alpha, self.belta)
@@ -651,7 +652,7 @@ class DLDKD(nn.Module):
             if fused_losses:
                 r_t2v, r_v2t = draws(1)
                 return F_.branch_losses(e_cos, e_raw, None, None, None, lab, lens, r_t2v, r_v2t, hard_neg, _cfg_get(self.config, "margin"),
-                                        soft, self.alpha, self.belta, self.explore_nce_weight, 0.0, True)[:2]
+                                        soft, self.alpha, self.belta, self.explore_nce_weight, 0.0, True, kd_factor=0.0)[:2]
             explore_trip = trip(e_cos, 1)
             if soft:
                 explore_nce = self.explore_nce_weight * F_.nce_soft(lab, e_raw, e_raw, self.alpha, self.belta)

@@ -217,6 +217,10 @@ class GraphedTrainStep:
     TENSOR_KEYS = ("student_videos", "student_videos_mask", "teacher_videos", "student_text", "student_text_mask", "teacher_text")
 
     WATCH_EVERY = 32       # deferred-loss data-parallel replays between two progress markers (comm.watch)
+    # The scalars the epoch schedule moves (alpha, belta, the KD weight: train.py:66-113) as device words the captured loss launches
+    # read by address (functional.ScheduleWords), rewritten before the first replay of an epoch: ONE capture serves every epoch.
+    # False: the values are part of the graph's key (a capture per epoch, eager steps after max_captures epochs).
+    SCHEDULE_WORDS = True
 
     def __init__(self, model, optimizer, opt, max_graphs=8, defer_loss_float=False, max_captures=24):
         self.model, self.optimizer, self.opt = model, optimizer, opt
@@ -253,10 +257,17 @@ class GraphedTrainStep:
         cfg = m.config
         get = (lambda k: cfg.get(k)) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k, None))
         shapes = tuple((k, tuple(batch[k].shape), str(batch[k].dtype)) for k in self.TENSOR_KEYS)
-        return (shapes, len(batch["text_labels"]),
-                float(m.alpha), float(m.belta), float(m.weight), bool(get("use_hard_negative")), get("hard_pool_size"),
+        sched = (None, None, None) if self._schedule_on_device(batch) else (float(m.alpha), float(m.belta), float(m.weight))
+        return (shapes, len(batch["text_labels"]), *sched, bool(get("use_hard_negative")), get("hard_pool_size"),
                 m.label_style, bool(m.training), dist_info()[1] >= DDP_MIN_WORLD, getattr(self.opt, "grad_clip", -1),
                 len(self.optimizer.fp.bucket_ranges))
+
+    def _schedule_on_device(self, batch):
+        """Whether the step's losses run as the fused branch launches that can read the schedule from device words (model.py's
+        condition for F_.branch_losses)."""
+        from . import functional as F_
+        return (self.SCHEDULE_WORDS and F_.BRANCH_LOSS_FUSED and F_.simpool_train_ok() and batch["student_videos"].is_cuda
+                and hasattr(self.model, "kl_intra_weight"))
 
     def _bucketed(self, batch):
         """The batch with its word axis padded to a multiple of 8 (at most max_desc_l) and its clip axis to a multiple of 32 (at
@@ -440,10 +451,18 @@ class GraphedTrainStep:
         e.static["text_labels"] = labels                 # only len() of it is baked in; the values are staged per step
         e.nq, e.nv = nq, nv
         e.ddp = bool(key[9])
+        e.sched = None
+        if key[2] is None:
+            e.sched = F_.ScheduleWords(nq, nv, m.label_style == "soft", dev)
+            for f in (m.kl_intra_weight, 0.0):              # the two branches' KL factors (model.py:143-155)
+                e.sched.words_for(f)
+            e.sched.update(m.alpha, m.belta, m.weight)
         old_lr = opt_.t_lr
         opt_.t_lr = view("lr", len(opt_.fp.params)).view(torch.float32)      # the update kernel reads the staged rates
         e.t_lr = opt_.t_lr
         old = F_.set_philox_step(e.philox)
+        sched_ctx = F_.schedule_words(e.sched)
+        sched_ctx.__enter__()
         try:
             opt_.zero_grad()
             e.graph = torch.cuda.CUDAGraph()
@@ -471,7 +490,11 @@ class GraphedTrainStep:
             opt_.t_lr = old_lr
             raise
         finally:
+            sched_ctx.__exit__(None, None, None)
             F_.set_philox_step(old)
+        if e.sched is not None and not e.sched.used:
+            raise RuntimeError("GraphedTrainStep: the captured step did not read the schedule words (alpha / belta / KD weight would be "
+                               "frozen at this epoch's values): set GraphedTrainStep.SCHEDULE_WORDS = False")
         while len(self.graphs) >= self.max_graphs:
             old_key = next(iter(self.graphs))
             self.graphs.pop(old_key)
@@ -773,6 +796,8 @@ class GraphedTrainStep:
                 if batch[k].data_ptr() != e.static[k].data_ptr():
                     e.static[k].copy_(batch[k], non_blocking=True)
 
+        if e.sched is not None:
+            e.sched.update(m.alpha, m.belta, m.weight)    # a few fills, on the first replay of an epoch only
         # the video features first - the largest copy (201 MB at the TVR batch: 72 us) feeding the longest chains; the video towers
         # start behind it and the step's scalars (ev_in_video below) while the other inputs are still being copied
         stage(self.TENSOR_KEYS[:2])

@@ -867,3 +867,60 @@ def test_fused_branch_losses_scale_by_upstream_gradients_once():
     assert all(np.isfinite(v) for v in vals) and vals[0] > 0
     with pytest.raises(RuntimeError, match="second backward"):
         total.backward()
+
+
+@pytest.mark.parametrize("soft", [True, False])
+def test_branch_losses_read_the_epoch_schedule_from_device_words(soft):
+    """functional.ScheduleWords: alpha (-> hardQ / hardV and the coefficient vectors), belta and the KD weight of an epoch
+    (method/train.py:66-113) as device state the branch-loss launches read by address, so that a captured step follows the schedule
+    without a new capture.  For three schedule points - the values rewritten IN PLACE between the calls, the by-value arguments left
+    at the first epoch's - losses and gradients equal the by-value launch bit for bit; both branches' forms (teacher targets + KL,
+    folded targets without KL)."""
+    from dldkd_amd import functional as F_
+    rs = np.random.RandomState(9)
+    nv = 16
+    counts = sorted(rs.randint(1, 4, size=nv).tolist(), reverse=True)
+    labels = [i for i, c in enumerate(counts) for _ in range(c)]
+    nq, L = len(labels), 24
+    g = torch.Generator().manual_seed(43)
+    lab = _lab(labels)
+    lens = torch.from_numpy(rs.randint(1, L + 1, size=nv)).int().to(DEV)
+    cos = torch.tanh(torch.randn(nq, nv, generator=g)).to(DEV)
+    raw = (torch.randn(nq, nv, generator=g) * 3.0).to(DEV)
+    tch = (torch.randn(nq, nv, generator=g) * 3.0).to(DEV)
+    clip_p = (torch.randn(nq, L, generator=g) * 0.5).to(DEV)
+    clip_t = (torch.randn(nq, L, generator=g) * 0.5).to(DEV)
+    torch.manual_seed(4)
+    r_v2t, r_t2v = orc.draw_triplet_randoms(labels, nv, True, 20)
+    r_t2v = r_t2v.int().to(DEV)
+    r_v2t = None if r_v2t is None else r_v2t.int().to(DEV)
+    kl_factor = 0.1
+
+    def run(alpha, belta, weight, sw, first):
+        out = []
+        for inher in (True, False):
+            C, S, P = cos.clone().requires_grad_(True), raw.clone().requires_grad_(True), clip_p.clone().requires_grad_(True)
+            a, b, w = (first if sw is not None else (alpha, belta, weight))      # by-value arguments: stale under the words
+            with F_.schedule_words(sw):
+                if inher:
+                    terms = F_.branch_losses(C, S, tch, P, clip_t, lab, lens, r_t2v, r_v2t, True, 0.1, soft, a, b, 0.04, kl_factor * w, False,
+                                             kd_factor=kl_factor)
+                else:
+                    terms = F_.branch_losses(C, S, None, None, None, lab, lens, r_t2v, r_v2t, True, 0.1, soft, a, b, 0.04, 0.0, True,
+                                             kd_factor=0.0)[:2]
+            sum(terms).backward()
+            out.append([t.detach().clone() for t in terms] + [x.grad.clone() for x in (C, S, P) if x.grad is not None])
+        return out
+
+    sw = F_.ScheduleWords(nq, nv, soft, DEV)
+    for f in (kl_factor, 0.0):
+        sw.words_for(f)
+    points = [(0.8, 0.8, 1.0), (0.37, 0.61, 0.95 ** 7), (0.0, 0.5, 0.05)]
+    for i, (a, b, w) in enumerate(points):
+        assert sw.update(a, b, w) == True and sw.update(a, b, w) == False       # noqa: E712  (rewritten once per change)
+        got, ref = run(a, b, w, sw, points[0]), run(a, b, w, None, None)
+        for x, y in zip(got, ref):
+            assert len(x) == len(y) and all(torch.equal(p_, q_) for p_, q_ in zip(x, y)), i
+    assert sw.used == 2 * len(points)
+    if soft:       # the schedule does move the losses (the test would pass vacuously otherwise)
+        assert float(run(*points[0], None, None)[0][1]) != float(run(*points[1], None, None)[0][1])

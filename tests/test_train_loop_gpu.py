@@ -174,8 +174,9 @@ def test_graphed_train_step_equals_eager(prec, drop):
     against the eager step.  Two replicas; before EVERY step the graphed replica is given the eager replica's parameters,
     moments and step count, both get the same seeds, and after the step losses and parameters must agree to rounding -
     with dropout (device Philox state: every replay draws fresh masks, the ones the eager run draws), with the reference's
-    CPU randint draws for the triplet negatives (staged per step), across a per-epoch switch of the baked-in scalars (a new
-    graph), and with three different batches flowing through one captured graph.  (Whole trajectories are not compared:
+    CPU randint draws for the triplet negatives (staged per step), across a switch of the baked-in hard-negative mode (a new
+    graph) and a move of the epoch schedule's alpha / belta / KD weight (NO new graph: device words), and with three different
+    batches flowing through one captured graph.  (Whole trajectories are not compared:
     this tiny problem amplifies the run-to-run rounding of the fp32-atomic reductions by orders of magnitude in a few
     steps - two EAGER runs diverge the same way.)"""
     import synth
@@ -208,6 +209,9 @@ def test_graphed_train_step_equals_eager(prec, drop):
                 for m in (me, mg):
                     m.set_hard_negative(True, 5)          # per-epoch switch (train.py:62-64): a new graph key
                     m.alpha, m.weight = 0.6, 0.9
+            if it == 9:
+                for m in (me, mg):                        # an epoch's schedule (train.py:66-113): NO new graph - the captured loss
+                    m.alpha, m.belta, m.weight = 0.45, 0.7, 0.81     # launches read these from device words (ScheduleWords)
             og.fp.flat.copy_(oe.fp.flat); og.m.copy_(oe.m); og.v.copy_(oe.v); og.step_count = oe.step_count
             torch.manual_seed(100 + it)
             # the stepper pads the clip axis (20 -> 32) and the word axis to its buckets.  Without dropout that is exact, so
@@ -225,6 +229,41 @@ def test_graphed_train_step_equals_eager(prec, drop):
     finally:
         ops.set_gemm_precision("fp32")
     assert stepper.replays == 10 and stepper.captures == 2 and stepper.eager_steps == 2     # each key: 1 eager sight, then captured
+
+
+@pytest.mark.parametrize("words", [True, False])
+def test_one_captured_step_serves_every_epoch_of_the_schedule(words, monkeypatch):
+    """train_epoch moves alpha / belta / the KD weight every epoch (method/train.py:66-113).  With the schedule's scalars as device
+    words (GraphedTrainStep.SCHEDULE_WORDS, functional.ScheduleWords) the step captured in epoch 0 is replayed in every epoch; with
+    the scalars baked in (the fallback) every epoch costs an eager step + a capture - and a 100-epoch run would leave the graphs
+    after max_captures epochs."""
+    from dldkd_amd.model import DLDKD
+    from dldkd_amd import train as T
+    ds = TinySet()
+    cfg = types.SimpleNamespace(visual_input_size=256, query_input_size=128, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=128, max_desc_l=30, input_drop=0.1, drop=0.1, n_heads=4, initializer_range=0.02,
+                                margin=0.1, use_hard_negative=False, hard_pool_size=5, label_style="soft")
+    opt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                collection="tiny", alpha=0.8, belta=0.8, device=torch.device(DEV), bsz=8, pin_memory=False,
+                                num_workers=0, lr=1e-3, wd=0.01, lr_warmup_proportion=0.05, n_epoch=4, max_es_cnt=10,
+                                hard_negative_start_epoch=0, hard_pool_size=5, distill_loss_decay="exp", exponential_k=0.9,
+                                selfDistil_sigmoid_k=8, alpha_decay="sigmoid", belta_decay="sigmoid", grad_clip=-1)
+    monkeypatch.setattr(T.GraphedTrainStep, "SCHEDULE_WORDS", words)
+    torch.manual_seed(0)
+    m = DLDKD(cfg, opt).to(DEV)
+    loader = T.make_train_loader(ds, opt, 0, 1)
+    optim = T.make_optimizer(m, opt, len(loader))
+    stepper = T.GraphedTrainStep(m, optim, opt, defer_loss_float=True)
+    seen, losses = [], []
+    for ep in range(4):
+        losses.append(T.train_epoch(m, loader, optim, opt, ep, stepper=stepper)["loss_overall"])
+        seen.append((m.alpha, m.belta, m.weight))
+    assert len(set(seen)) == 4 and all(np.isfinite(losses))          # the schedule moved every epoch
+    n = 4 * len(loader)
+    if words:
+        assert (stepper.captures, stepper.eager_steps, stepper.replays) == (1, 1, n - 1)
+    else:
+        assert (stepper.captures, stepper.eager_steps, stepper.replays) == (4, 4, n - 4)
 
 
 def test_graphed_step_serves_variable_length_batches_from_a_few_graphs():
