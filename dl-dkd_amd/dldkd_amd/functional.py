@@ -314,17 +314,26 @@ def in_proj_ln_dual(x, row_mask, layers, p):
                                                         ops.LN_EPS, float(p), slots[0][0], slots[0][1], slots[1][1], slots[0][2], _p(rm),
                                                         _p(gflags), int(planes), _s()), "layernorm_dropout_bf16_dual")
     _PRE_LN.clear()
+    here = torch.cuda.current_stream(dev)
     for i in range(2):
-        _PRE_LN[(x2.data_ptr(), g[i].data_ptr())] = (z[i], stats, gflags, slots[i], float(p), M, K)
+        _PRE_LN[(x2.data_ptr(), g[i].data_ptr())] = (z[i], stats, gflags, slots[i], float(p), M, K, here)
 
 
 def _take_pre_ln(x2, gamma, p, row_mask):
     ent = _PRE_LN.pop((x2.data_ptr(), gamma.data_ptr()), None)
     if ent is None:
         return None
-    z, stats, gflags, slot, p0, M, K = ent
+    z, stats, gflags, slot, p0, M, K, made_on = ent
     if p0 != float(p) or (M, K) != tuple(x2.shape) or row_mask is None:
         return None
+    cur = torch.cuda.current_stream(z.device)
+    if cur != made_on:
+        # the rows were allocated on the stream of in_proj_ln_dual and are read - forward GEMM now, weight gradient in the backward pass -
+        # on THIS tower's stream: without this the allocator hands their memory to the producer's stream the moment the backward pass
+        # drops them, while this stream may not have run its reads yet (inside ONE captured graph with forked tower streams that
+        # order is real: the single-graph stepper's dW came out as NaN at the TVR batch)
+        for t in (z, stats, gflags):
+            t.record_stream(cur)
     return z, stats, gflags, slot
 
 

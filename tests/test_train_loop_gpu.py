@@ -247,7 +247,8 @@ def test_one_captured_step_serves_every_epoch_of_the_schedule(words, monkeypatch
                                 collection="tiny", alpha=0.8, belta=0.8, device=torch.device(DEV), bsz=8, pin_memory=False,
                                 num_workers=0, lr=1e-3, wd=0.01, lr_warmup_proportion=0.05, n_epoch=4, max_es_cnt=10,
                                 hard_negative_start_epoch=0, hard_pool_size=5, distill_loss_decay="exp", exponential_k=0.9,
-                                selfDistil_sigmoid_k=8, alpha_decay="sigmoid", belta_decay="sigmoid", grad_clip=-1)
+                                selfDistil_sigmoid_k=8, alpha_decay="sigmoid", belta_decay="sigmoid", grad_clip=-1,
+                                prefetch_batches=False)          # (one capture per signature: the count below is about the schedule)
     monkeypatch.setattr(T.GraphedTrainStep, "SCHEDULE_WORDS", words)
     torch.manual_seed(0)
     m = DLDKD(cfg, opt).to(DEV)
@@ -264,6 +265,100 @@ def test_one_captured_step_serves_every_epoch_of_the_schedule(words, monkeypatch
         assert (stepper.captures, stepper.eager_steps, stepper.replays) == (1, 1, n - 1)
     else:
         assert (stepper.captures, stepper.eager_steps, stepper.replays) == (4, 4, n - 4)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_double_buffered_inputs_give_the_same_steps(prec):
+    """GraphedTrainStep(batch, next_batch=...): the next step's inputs are copied into a SECOND set of static buffers (a second
+    capture of the same signature) on the staging stream while this step runs.  Against a stepper that stages every batch at the
+    head of its own step: same losses and parameters step by step (the plain stepper's state is copied over before every step, same
+    seeds: dropout masks and triplet draws are the same), with a batch of another signature in the stream (that step stages its
+    inputs itself) and a caller that breaks its promise once (the prefetched inputs are ignored, not used for the wrong batch)."""
+    import synth
+    from dldkd_amd import ops
+    from dldkd_amd import train as T
+    from dldkd_amd.model import DLDKD
+    from dldkd_amd.optimization import BertAdam
+    cfg = types.SimpleNamespace(visual_input_size=256, query_input_size=128, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=32, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4, initializer_range=0.02,
+                                margin=0.1, use_hard_negative=True, hard_pool_size=5, label_style="soft")
+    mopt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                 collection="tvr", alpha=0.8, belta=0.8)
+    topt = types.SimpleNamespace(grad_clip=-1, device=torch.device(DEV))
+    batches = [synth.make_train_batch(170 + i, nv=24, caps=2, L=20, len_lo=3, dv=256, dq=128) for i in range(4)]
+    batches.append(synth.make_train_batch(180, nv=16, caps=2, L=20, len_lo=3, dv=256, dq=128))      # another signature
+    batches = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
+    order = [0, 1, 2, 3, 0, 1, 2, 4, 3, 0, 1, 2, 3, 0, 1, 2]
+    lie_at = 10                                            # promised batches[order[11]], delivers batches[3]
+
+    def make():
+        torch.manual_seed(11)
+        m = DLDKD(types.SimpleNamespace(**vars(cfg)), mopt).to(DEV).train()
+        return m, BertAdam([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=2e-3, warmup=0.1, t_total=40)
+
+    ops.set_gemm_precision(prec)
+    try:
+        mp, op_ = make()
+        md, od = make()
+        plain, dbl = T.GraphedTrainStep(mp, op_, topt), T.GraphedTrainStep(md, od, topt)
+        tol = 1e-5 if prec == "fp32" else 1e-3
+        seq = list(order)
+        for it in range(len(seq)):
+            if it == lie_at + 1:
+                seq[it] = 3
+            b = batches[seq[it]]
+            nxt = batches[order[it + 1]] if it + 1 < len(order) else None
+            od.fp.flat.copy_(op_.fp.flat); od.m.copy_(op_.m); od.v.copy_(op_.v); od.step_count = op_.step_count
+            torch.manual_seed(300 + it)
+            lp, _ = plain(b)
+            torch.manual_seed(300 + it)
+            ld, _ = dbl(b, next_batch=nxt)
+            assert float(lp) == pytest.approx(float(ld), rel=tol), it
+            d = (op_.fp.flat - od.fp.flat).abs().max().item()
+            assert d <= (2e-7 if prec == "fp32" else 2e-5) + 0.02 * od.get_lr()[0], (it, d)
+    finally:
+        ops.set_gemm_precision("fp32")
+    # two captures of the main signature (its two buffer sets); the other signature and the broken promise staged their own inputs
+    assert dbl.double_buffer and dbl.captures == 2 and plain.captures == 1
+    assert dbl.prefetched >= len(order) - 9, dbl.prefetched
+    assert dbl.replays + dbl.eager_steps == len(order) + 0
+
+
+def test_train_epoch_prefetches_the_next_batch_and_follows_the_unprefetched_run():
+    """train_epoch drives a graphed stepper through GraphedTrainStep.iterate: batch i + 1 is fetched on the staging stream (the
+    device-resident set's gather kernels / a host loader's uploads) and copied into the other input buffer set while step i runs.
+    Same data, same seeds as a run with opt.prefetch_batches = False: the epoch means agree (first epochs: before run-to-run
+    rounding has been amplified), nearly every step found its inputs in place."""
+    from dldkd_amd.model import DLDKD
+    from dldkd_amd import train as T
+    ds = TinySet()
+    cfg = types.SimpleNamespace(visual_input_size=256, query_input_size=128, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=128, max_desc_l=30, input_drop=0.1, drop=0.1, n_heads=4, initializer_range=0.02,
+                                margin=0.1, use_hard_negative=False, hard_pool_size=5, label_style="soft")
+    res = {}
+    for resident in (False, True):
+        for ahead in (False, True):
+            opt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                        collection="tiny", alpha=0.8, belta=0.8, device=torch.device(DEV), bsz=8, pin_memory=False,
+                                        num_workers=0, lr=1e-3, wd=0.01, lr_warmup_proportion=0.05, n_epoch=4, max_es_cnt=10,
+                                        hard_negative_start_epoch=0, hard_pool_size=5, distill_loss_decay="exp", exponential_k=0.9,
+                                        selfDistil_sigmoid_k=8, alpha_decay="sigmoid", belta_decay="sigmoid", grad_clip=-1,
+                                        prefetch_batches=ahead, device_resident_train=resident)
+            torch.manual_seed(0)
+            m = DLDKD(cfg, opt).to(DEV)
+            loader = T.make_train_loader(ds, opt, 0, 1)
+            optim = T.make_optimizer(m, opt, len(loader))
+            stepper = T.GraphedTrainStep(m, optim, opt, defer_loss_float=True)
+            torch.manual_seed(5)
+            losses = [T.train_epoch(m, loader, optim, opt, ep, stepper=stepper)["loss_overall"] for ep in range(4)]
+            res[(resident, ahead)] = (losses, stepper)
+    for resident in (False, True):
+        (l0, s0), (l1, s1) = res[(resident, False)], res[(resident, True)]
+        assert s0.prefetched == 0 and not s0.double_buffer
+        # 12 steps: 2 first sights + 2 captures stage their own inputs; a step after an epoch's last batch has nothing ahead of it
+        assert s1.double_buffer and s1.captures == 2 and s1.prefetched >= 5, (s1.captures, s1.prefetched)
+        assert abs(l0[0] - l1[0]) <= 2e-3 * abs(l0[0]) + 1e-3 and abs(l0[1] - l1[1]) <= 0.01 * abs(l0[1]) + 0.005, (l0, l1)
+        assert all(np.isfinite(l1))
 
 
 def test_graphed_step_serves_variable_length_batches_from_a_few_graphs():
@@ -551,6 +646,71 @@ def test_parallel_tower_graphs_are_used_and_match_the_single_graph():
         one = min(spin(e.par["streams"][:1]) for _ in range(3))
         assert min(spin(e.par["streams"]) for _ in range(3)) < 1.6 * one
         assert len(staging.concurrent_streams(torch.device(DEV), 3)) == 3
+    finally:
+        ops.set_gemm_precision("fp32")
+
+
+@pytest.mark.parametrize("prec", ["bf16", "mixed"])
+def test_single_graph_stepper_at_c3_size_and_the_self_check(prec, monkeypatch):
+    """The TVR-size step through the single-graph form (opt.parallel_tower_graphs = False: the fallback of the tower graphs, fork /
+    join edges inside ONE capture) in the modes that run the one-pass input LayerNorm: the capture passes its self-check (round 6: the
+    rows that pass writes on the main stream are read on the towers' streams - without record_stream the single graph reused
+    their memory early and the input projections' dW came out as NaN) and steps like the tower-graph form.  The self-check
+    itself: gradients tensor by tensor against the eager step's (a sign flip of a rounding-noise gradient under BertAdam must not
+    fail it - it did at step 2 of bf16 runs); a replay whose gradient for ONE small tensor is wrong is rejected and the eager
+    step's result stands."""
+    import synth
+    from dldkd_amd import ops
+    from dldkd_amd import train as T
+    from dldkd_amd.model import DLDKD
+    from dldkd_amd.optimization import BertAdam
+    cfg = types.SimpleNamespace(visual_input_size=3072, query_input_size=768, inheritance_hidden=384, exploration_hidden=384,
+                                max_ctx_l=128, max_desc_l=30, input_drop=0.2, drop=0.2, n_heads=4, initializer_range=0.02,
+                                margin=0.1, use_hard_negative=True, hard_pool_size=20, label_style="soft")
+    mopt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                 collection="tvr", alpha=0.8, belta=0.8)
+    batch = synth.make_train_batch(3, nv=128, caps=5, L=128, len_lo=24, dv=3072, dq=768)
+    batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def make(par):
+        torch.manual_seed(0)
+        m = DLDKD(types.SimpleNamespace(**vars(cfg)), mopt).to(DEV).train()
+        o = BertAdam([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=3e-4, warmup=0.01, t_total=400)
+        return m, o, T.GraphedTrainStep(m, o, types.SimpleNamespace(grad_clip=-1, parallel_tower_graphs=par))
+
+    ops.set_gemm_precision(prec)
+    try:
+        res = {}
+        for par in (True, False):
+            m, o, g = make(par)
+            torch.manual_seed(7)
+            losses = [float(g(batch)[0]) for _ in range(4)]
+            assert g.captures == 1 and g.fallbacks == [] and g.replays == 3, (par, g.fallbacks)
+            assert g.last_check["finite"] and g.last_check["worst_grad_rel_l2"] < 1e-3 and g.last_check["d_loss"] < 1e-4, g.last_check
+            assert bool(torch.isfinite(o.fp.flat).all())
+            res[par] = (losses, o.fp.flat.clone())
+        assert res[True][0] == pytest.approx(res[False][0], rel=2e-3)
+        # a replay with ONE wrong gradient tensor (the position embedding's LayerNorm bias scaled by 1.5 behind the replay)
+        m, o, g = make(True)
+        idx = [n for n, _ in m.named_parameters()].index("visual_pos_embed.LayerNorm.bias")
+        orig = T.GraphedTrainStep._replay
+        state = {"armed": True}
+
+        def bad_replay(self, e, b, staged=False):
+            out = orig(self, e, b, staged)
+            if state["armed"]:
+                state["armed"] = False
+                self.optimizer.fp.views()[idx].mul_(1.5)
+            return out
+        monkeypatch.setattr(T.GraphedTrainStep, "_replay", bad_replay)
+        torch.manual_seed(7)
+        l0 = float(g(batch)[0])                           # first sight: eager
+        before = o.fp.flat.clone()
+        l1 = float(g(batch)[0])                           # capture + check: rejected
+        assert g.check_failures == 1 and g.captures == 0 and len(g.fallbacks) == 1 and "gradient" in g.fallbacks[0][0], g.fallbacks
+        assert 0.3 < g.last_check["worst_grad_rel_l2"] < 0.7 and np.isfinite(l1) and not torch.equal(before, o.fp.flat)
+        l2 = float(g(batch)[0])                           # the next notch (single graph) captures cleanly
+        assert g.captures == 1 and np.isfinite(l2) and l0 > 0
     finally:
         ops.set_gemm_precision("fp32")
 

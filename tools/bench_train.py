@@ -93,6 +93,26 @@ def run(config="c3", prec="bf16", drop=0.2, steps=30, warmup=10, dev="cuda:0", m
                         sb[k] = e.static[k]
                 torch.cuda.synchronize()
                 out["graph_static_inputs"] = timed(lambda: g2(sb), steps, warmup)
+            # double-buffered inputs: the caller hands over the NEXT batch with the current one (train_epoch does, through
+            # GraphedTrainStep.iterate); it is copied into the other buffer set while this step runs.  Two DIFFERENT batches take
+            # turns, every copy is real; float(loss) every step / deferred
+            m, opt, batch = build(config, drop, dev)
+            if tower_streams is not None:
+                m.tower_streams = tower_streams
+            other = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+            for k in ("student_videos", "teacher_videos", "student_text", "teacher_text"):
+                other[k] = other[k].flip(0) if k.endswith("videos") else other[k] * 0.5
+            pair = [batch, other]
+            for name, defer in (("graph_prefetch", False), ("graph_prefetch_no_loss_sync", True)):
+                gp = T.GraphedTrainStep(m, opt, topt, defer_loss_float=defer)
+                turn = [0]
+
+                def step():
+                    i = turn[0]
+                    turn[0] = 1 - i
+                    return gp(pair[i], next_batch=pair[1 - i])
+                out[name] = timed(step, steps, warmup)
+                out[name].update(replays=gp.replays, eager_steps=gp.eager_steps, captures=gp.captures, prefetched=gp.prefetched)
     finally:
         ops.set_gemm_precision("fp32")
     return out
