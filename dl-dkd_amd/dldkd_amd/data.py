@@ -4,6 +4,7 @@ Restates the two eval collates of the reference (method/data_provider.py:75-86,1
 readers (BigFile / HDF5) are out of scope - any Dataset yielding (feat (len, D) float32, index, id) works.
 """
 import contextlib
+import types
 
 import torch
 
@@ -146,28 +147,46 @@ class DeviceTrainSet:
     def __len__(self):
         return self.n_videos
 
-    def _gather(self, k, items_dev, items_host):
+    def _gather(self, k, items_dev, n, lmax, out=None, mask=None):
         from . import native
-        lmax = int(self.lens_host[k][items_host].max())
-        n, D = len(items_host), self.dim[k]
-        out = torch.empty(n, lmax, D, dtype=torch.float32, device=self.device)
-        mask = torch.empty(n, lmax, dtype=torch.float32, device=self.device)
+        D = self.dim[k]
+        if out is None:
+            out = torch.empty(n, lmax, D, dtype=torch.float32, device=self.device)
+        if mask is None:
+            mask = torch.empty(n, lmax, dtype=torch.float32, device=self.device)
+        if tuple(out.shape) != (n, lmax, D) or tuple(mask.shape) != (n, lmax) or not (out.is_contiguous() and mask.is_contiguous()):
+            raise ValueError(f"DeviceTrainSet: destination of {k} must be contiguous ({n}, {lmax}, {D}) + ({n}, {lmax})")
         native.check(native.lib().dldkd_gather_pad_rows_f32(native.ptr(self.src[k]), native.ptr(self.row_start[k]), native.ptr(self.lens_dev[k]),
                                                             native.ptr(items_dev), n, lmax, D, native.ptr(out), native.ptr(mask),
                                                             native.stream()), "gather_pad_rows")
         return out, mask
 
-    def batch(self, indices):
-        """The training batch of dataset items `indices` (in sampler order): collate_train's dict with device tensors."""
+    def plan(self, indices):
+        """Host half of a batch: the items in collate order, the captions, the labels and every table's longest sequence - all a
+        consumer needs to know the batch's shapes before a single row has moved (train.GraphedTrainStep.iterate picks the input
+        buffers of the captured step from them and has the rows gathered straight into those)."""
         import numpy as np
-        from .staging import PinnedRing
         idx = np.asarray(indices, dtype=np.int64)
         order = np.argsort(-self.n_caps_of[idx], kind="stable")        # most captions first, ties in sampler order (sorted() is stable)
         vids = idx[order]
         caps = np.concatenate([np.arange(self.caps_of[v][0], self.caps_of[v][0] + self.caps_of[v][1]) for v in vids])
         labels = [vi for vi, v in enumerate(vids) for _ in range(self.caps_of[v][1])]
+        items = {"student_videos": vids, "teacher_videos": vids, "student_text": caps, "teacher_text": caps}
+        lmax = {k: int(self.lens_host[k][items[k]].max()) for k in self.TABLES}
+        return types.SimpleNamespace(vids=vids, caps=caps, labels=labels, lmax=lmax, n={k: len(items[k]) for k in self.TABLES},
+                                     dim=dict(self.dim))
+
+    def gather(self, plan, out=None, pad=None):
+        """Device half: collate_train's dict for `plan`, gathered on the current stream.  pad: {table: padded length >= its longest
+        sequence} (zero rows, zero mask behind a sequence's end: what the stepper's bucketing would append); out: a dict of
+        destination tensors of exactly those shapes (the captured step's input buffers) - the rows then land where the step reads
+        them and the returned dict holds those tensors."""
+        from .staging import PinnedRing
+        import numpy as np
+        pad = pad or {}
+        L = {k: max(int(pad.get(k, 0)), plan.lmax[k]) for k in self.TABLES}
         # one upload for both index lists (pinned slot read by a kernel: staging.PinnedRing / dldkd_upload_words)
-        both = np.concatenate([vids, caps]).astype(np.int32)
+        both = np.concatenate([plan.vids, plan.caps]).astype(np.int32)
         if self._ring is None or self._ring.bufs[0].numel() < both.nbytes:
             self._ring = PinnedRing(max(both.nbytes, 1 << 16), self.device, slots=8)
         slot = self._ring.next()
@@ -175,13 +194,19 @@ class DeviceTrainSet:
         dev = torch.empty(both.nbytes, dtype=torch.uint8, device=self.device)
         self._ring.upload(dev, by_kernel=True)
         dev = dev.view(torch.int32)
-        v_dev, c_dev = dev[:len(vids)], dev[len(vids):]
-        sv, sm = self._gather("student_videos", v_dev, vids)
-        tv, _ = self._gather("teacher_videos", v_dev, vids)
-        st, stm = self._gather("student_text", c_dev, caps)
-        tt, _ = self._gather("teacher_text", c_dev, caps)
+        v_dev, c_dev = dev[:len(plan.vids)], dev[len(plan.vids):]
+        o = out or {}
+        nv, nq = len(plan.vids), len(plan.caps)
+        sv, sm = self._gather("student_videos", v_dev, nv, L["student_videos"], o.get("student_videos"), o.get("student_videos_mask"))
+        tv, _ = self._gather("teacher_videos", v_dev, nv, L["teacher_videos"], o.get("teacher_videos"))
+        st, stm = self._gather("student_text", c_dev, nq, L["student_text"], o.get("student_text"), o.get("student_text_mask"))
+        tt, _ = self._gather("teacher_text", c_dev, nq, L["teacher_text"], o.get("teacher_text"))
         return dict(student_videos=sv, teacher_videos=tv, student_videos_mask=sm, student_text=st, student_text_mask=stm,
-                    teacher_text=tt, text_labels=labels)
+                    teacher_text=tt, text_labels=plan.labels)
+
+    def batch(self, indices):
+        """The training batch of dataset items `indices` (in sampler order): collate_train's dict with device tensors."""
+        return self.gather(self.plan(indices))
 
 
 class DeviceTrainLoader:
@@ -201,3 +226,9 @@ class DeviceTrainLoader:
     def __iter__(self):
         for idx in self._index_loader:
             yield self.devset.batch(idx)
+
+    def plans(self):
+        """The epoch's batches as host-side plans (DeviceTrainSet.plan), in the order and with the random draws of __iter__; the
+        consumer gathers each with devset.gather(plan, out=..., pad=...)."""
+        for idx in self._index_loader:
+            yield self.devset.plan(idx)

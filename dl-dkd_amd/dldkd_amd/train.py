@@ -289,8 +289,7 @@ class GraphedTrainStep:
         cfg = self.model.config
         get = (lambda k, d: cfg.get(k, d)) if isinstance(cfg, dict) else (lambda k, d: getattr(cfg, k, d))
         lq, lv = batch["student_text"].shape[1], batch["student_videos"].shape[1]
-        lq_b = max(min(-(-lq // 8) * 8, int(get("max_desc_l", lq))), lq)
-        lv_b = max(min(-(-lv // 32) * 32, int(get("max_ctx_l", lv))), lv)
+        lq_b, lv_b = self._bucket_lens(lq, lv)
         if lq_b == lq and lv_b == lv:
             return batch
         out = dict(batch)
@@ -323,6 +322,16 @@ class GraphedTrainStep:
             return
         self.enable_double_buffer()
         st = self._streams(dev)
+        if hasattr(loader, "plans") and hasattr(getattr(loader, "devset", None), "gather"):
+            # a device-resident training set (data.DeviceTrainLoader): the batch's shapes are known from its host-side plan, so its
+            # rows are gathered STRAIGHT into the input buffers of the capture that will replay it (no staging copy at all), on the
+            # staging stream, when the generator is resumed - i.e. behind the launch of the step before it, beside its kernels
+            try:
+                for plan in loader.plans():
+                    yield self._materialize(loader.devset, plan, st)
+            finally:
+                self._fetched = None
+            return
         it = iter(loader)
 
         def fetch():
@@ -345,6 +354,35 @@ class GraphedTrainStep:
                 yield cur[0]
         finally:
             self._lookahead = self._fetched = None
+
+    def _bucket_lens(self, lq, lv):
+        cfg = self.model.config
+        get = (lambda k, d: cfg.get(k, d)) if isinstance(cfg, dict) else (lambda k, d: getattr(cfg, k, d))
+        return (max(min(-(-lq // 8) * 8, int(get("max_desc_l", lq))), lq), max(min(-(-lv // 32) * 32, int(get("max_ctx_l", lv))), lv))
+
+    def _materialize(self, devset, plan, st):
+        lq_b, lv_b = self._bucket_lens(plan.lmax["student_text"], max(plan.lmax["student_videos"], plan.lmax["teacher_videos"]))
+        pad = {"student_videos": lv_b, "teacher_videos": lv_b, "student_text": lq_b}
+        nv, nq, f32 = plan.n["student_videos"], plan.n["student_text"], str(torch.float32)
+        shape = {"student_videos": (nv, lv_b, plan.dim["student_videos"]), "student_videos_mask": (nv, lv_b),
+                 "teacher_videos": (nv, lv_b, plan.dim["teacher_videos"]), "student_text": (nq, lq_b, plan.dim["student_text"]),
+                 "student_text_mask": (nq, lq_b), "teacher_text": (nq, plan.lmax["teacher_text"], plan.dim["teacher_text"])}
+        key = (tuple((k, shape[k], f32) for k in self.TENSOR_KEYS), len(plan.labels)) + self._key_tail(True)
+        key = key + (self._turn.get(key, 0),)
+        e = self.graphs.get(key) if getattr(self.opt, "grad_clip", -1) == -1 else None
+        with torch.cuda.stream(st):
+            if e is not None:
+                st.wait_event(e.ev_done)                  # that capture's previous replay (two steps back) has read its inputs
+            batch = devset.gather(plan, out=None if e is None else e.static, pad=pad)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        sig = self._sig(batch)
+        if e is not None:
+            e.ev_staged.record(st)
+            e.staged_once = True
+            self._pending = (sig, key, e, batch)
+        self._fetched = (sig, ev)
+        return batch
 
     def _sig(self, batch):
         return tuple(batch[k].data_ptr() for k in self.TENSOR_KEYS) + (id(batch["text_labels"]),)

@@ -563,6 +563,30 @@ def test_device_resident_train_set_yields_the_collated_batches():
             assert a["text_labels"] == b["text_labels"]
             for k in ("student_videos", "teacher_videos", "student_videos_mask", "student_text", "student_text_mask", "teacher_text"):
                 assert a[k].is_cuda and torch.equal(a[k].cpu(), b[k]), k
+    # plan + gather into a caller's buffers with padding (what train.GraphedTrainStep.iterate does with a captured step's input
+    # buffers): the same rows, zero rows / zero mask behind them, written in place; the plans follow the loader's order and draws
+    import torch.nn.functional as TF
+    torch.manual_seed(100)
+    ref = list(DeviceTrainLoader(devset, 8, shuffle=True))
+    torch.manual_seed(100)
+    plans = list(DeviceTrainLoader(devset, 8, shuffle=True).plans())
+    assert len(plans) == len(ref)
+    for pl, b in zip(plans, ref):
+        lv, lq = pl.lmax["student_videos"] + 5, pl.lmax["student_text"] + 3
+        nv, nq = len(pl.vids), len(pl.caps)
+        out = {"student_videos": torch.full((nv, lv, 256), 7.0, device=DEV), "student_videos_mask": torch.full((nv, lv), 7.0, device=DEV),
+               "teacher_videos": torch.full((nv, lv, 512), 7.0, device=DEV), "student_text": torch.full((nq, lq, 128), 7.0, device=DEV),
+               "student_text_mask": torch.full((nq, lq), 7.0, device=DEV), "teacher_text": torch.full((nq, 1, 512), 7.0, device=DEV)}
+        got = devset.gather(pl, out=out, pad={"student_videos": lv, "teacher_videos": lv, "student_text": lq})
+        assert got["text_labels"] == b["text_labels"] and all(got[k] is out[k] for k in out)
+        assert torch.equal(got["student_videos"], TF.pad(b["student_videos"], (0, 0, 0, lv - b["student_videos"].shape[1])))
+        assert torch.equal(got["teacher_videos"], TF.pad(b["teacher_videos"], (0, 0, 0, lv - b["teacher_videos"].shape[1])))
+        assert torch.equal(got["student_videos_mask"], TF.pad(b["student_videos_mask"], (0, lv - b["student_videos_mask"].shape[1])))
+        assert torch.equal(got["student_text"], TF.pad(b["student_text"], (0, 0, 0, lq - b["student_text"].shape[1])))
+        assert torch.equal(got["student_text_mask"], TF.pad(b["student_text_mask"], (0, lq - b["student_text_mask"].shape[1])))
+        assert torch.equal(got["teacher_text"], b["teacher_text"])
+    with pytest.raises(ValueError, match="destination"):
+        devset.gather(plans[0], out={"student_videos": torch.empty(3, 3, 256, device=DEV)})
 
 
 def test_train_with_the_device_resident_set_follows_the_host_loader_run(tmp_path):

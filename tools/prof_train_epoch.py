@@ -1,5 +1,5 @@
 """Where the wall-clock of train.train_epoch goes with the device-resident data path (opt.device_resident_train) at TVR shapes:
-  python3 tools/prof_train_epoch.py [n_videos=4096] [precision=bf16] [--profile]
+  python3 tools/prof_train_epoch.py [n_videos=4096] [precision=bf16] [--profile] [--no-prefetch]
 Prints one JSON object: per-step wall inside an epoch (steady state: host enqueue time per step and the epoch's GPU-inclusive
 wall / steps), the per-epoch fixed cost (schedule switch, loss read-back), captures / replays / eager steps, and with --profile the
 cProfile top of one epoch.  (The step alone, inputs resident and the loss deferred: bench.py extras c3_train_step_ms_*_deferred_loss.)"""
@@ -10,7 +10,7 @@ for p in ("dl-dkd_amd", "tests/golden", "tools"):
 import torch
 
 
-def run(n_videos=4096, prec="bf16", profile=False, dev="cuda:0", epochs=3):
+def run(n_videos=4096, prec="bf16", profile=False, dev="cuda:0", epochs=3, prefetch=True):
     from bench_train_loader import SynthTrainSet
     from dldkd_amd import ops, train as T
     from dldkd_amd.model import DLDKD
@@ -22,9 +22,9 @@ def run(n_videos=4096, prec="bf16", profile=False, dev="cuda:0", epochs=3):
                                 num_workers=0, lr=3e-4, wd=0.01, lr_warmup_proportion=0.01, n_epoch=100,
                                 hard_negative_start_epoch=0, hard_pool_size=20, distill_loss_decay="exp", exponential_k=0.95,
                                 selfDistil_sigmoid_k=800, alpha_decay="sigmoid", belta_decay="sigmoid", grad_clip=-1,
-                                device_resident_train=True)
+                                device_resident_train=True, prefetch_batches=prefetch)
     ds = SynthTrainSet(n_videos)
-    out = {"n_videos": n_videos, "batch": 128, "precision": prec}
+    out = {"n_videos": n_videos, "batch": 128, "precision": prec, "prefetch_batches": prefetch}
     ops.set_gemm_precision(prec)
     try:
         torch.manual_seed(0)
@@ -79,7 +79,8 @@ def run(n_videos=4096, prec="bf16", profile=False, dev="cuda:0", epochs=3):
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    r = run(int(args[0]) if args else 4096, args[1] if len(args) > 1 else "bf16", "--profile" in sys.argv)
+    r = run(int(args[0]) if args else 4096, args[1] if len(args) > 1 else "bf16", "--profile" in sys.argv,
+            prefetch="--no-prefetch" not in sys.argv)
     prof = r.pop("cprofile", None)
     print(json.dumps(r))
     if prof:
