@@ -222,6 +222,21 @@ def extras(dev):
                 # ... and the batch already sits in the stepper's input buffers (a data path that fills them itself: no staging copy)
                 if "graph_static_inputs" in r:
                     out[f"{key}_train_step_ms_{prec}_deferred_loss_static_inputs"] = r["graph_static_inputs"]["stream_ms_median"]
+        # the training LOOP (train.train_epoch on a device-resident training set of TVR shapes: data path, per-epoch schedule,
+        # loss read-back included), wall-clock per step - what train.train() delivers, beside the bare step above
+        try:
+            import prof_train_epoch
+            from bench_train_loader import SynthTrainSet
+            ds_loop = SynthTrainSet(1024)
+            for prec in ("bf16", "mixed"):
+                r = prof_train_epoch.run(1024, prec, dev=str(dev), epochs=6, ds=ds_loop)
+                w = sorted(r["ms_per_step_wall"])
+                out[f"c3_train_loop_ms_per_step_{prec}"] = {"median_epoch": w[len(w) // 2], "epochs": r["ms_per_step_wall"], "steps_per_epoch": r["steps_per_epoch"],
+                                                            "captures": r["captures"], "eager_steps": r["eager_steps"], "replays": r["replays"],
+                                                            "prefetched": r["prefetched"], "fallbacks": r["fallbacks"]}
+            del ds_loop
+        except Exception as ex:   # noqa: BLE001 - an extra never takes the headline line down
+            out["c3_train_loop_ms_per_step"] = {"error": repr(ex)[:300]}
         out["c3_train_step_config"] = "TVR: 128 videos / 640 queries, L<=128, label_style=soft, hard negatives, dropout 0.2, " \
                                       "zero_grad + forward + backward + fused BertAdam; fp32 = parity mode (fp32-grade GEMMs: three bf16 " \
                                       "planes per operand, losses within 1e-4 of the reference), bf16 = every GEMM on bf16 MFMA with fp32 " \

@@ -10,7 +10,7 @@ for p in ("dl-dkd_amd", "tests/golden", "tools"):
 import torch
 
 
-def run(n_videos=4096, prec="bf16", profile=False, dev="cuda:0", epochs=3, prefetch=True):
+def run(n_videos=4096, prec="bf16", profile=False, dev="cuda:0", epochs=3, prefetch=True, ds=None):
     from bench_train_loader import SynthTrainSet
     from dldkd_amd import ops, train as T
     from dldkd_amd.model import DLDKD
@@ -23,7 +23,7 @@ def run(n_videos=4096, prec="bf16", profile=False, dev="cuda:0", epochs=3, prefe
                                 hard_negative_start_epoch=0, hard_pool_size=20, distill_loss_decay="exp", exponential_k=0.95,
                                 selfDistil_sigmoid_k=800, alpha_decay="sigmoid", belta_decay="sigmoid", grad_clip=-1,
                                 device_resident_train=True, prefetch_batches=prefetch)
-    ds = SynthTrainSet(n_videos)
+    ds = ds if ds is not None else SynthTrainSet(n_videos)
     out = {"n_videos": n_videos, "batch": 128, "precision": prec, "prefetch_batches": prefetch}
     ops.set_gemm_precision(prec)
     try:
