@@ -452,19 +452,25 @@ struct BranchArgs {
     float* dS;                   // (nq, nv) written
     float* dclip;                // (nq, L) zeroed by the caller
     float* out;                  // [3]: triplet, w_nce * InfoNCE, w_kl * KL
-    const int32_t* sched;        // null, or the per-epoch scalars read from the device: {hardQ, hardV, bits(beta), bits(w_kl)}
+    const int32_t* sched;        // null, or the per-step scalars read from the device: {hardQ, hardV, bits(beta), bits(w_kl), nq_valid}
+    int nq_valid;                // rows [nq_valid, nq) of C / S / T / clip_* belong to padding queries (<= 0: none)
 };
 
 // The scalars an epoch's schedule moves (alpha -> hardQ / hardV and the coefficient vectors, belta, the KD weight: train.py:66-113).
 // By value they are baked into a captured launch; behind `sched` a replayed graph follows the schedule without a new capture
 // (the coefficient vectors cq / cv are rewritten in place by the same caller).
-struct SchedWords { int hardQ, hardV; float beta, w_kl; };
+// nq_valid: a batch whose query axis was padded to a bucket (variable caption counts - Charades, ActivityNet - would otherwise give
+// every batch its own graph): the matrices are row-major with row stride nv, so the bodies simply run over the first nq_valid rows
+// (bounds, normalisers, the columns' softmax over queries); the padding rows' dS is written as zero, their terms are not summed.
+struct SchedWords { int hardQ, hardV; float beta, w_kl; int nqv; };
 __device__ __forceinline__ SchedWords sched_words(const BranchArgs& p) {
-    SchedWords w{p.hardQ, p.hardV, p.beta, p.w_kl};
+    SchedWords w{p.hardQ, p.hardV, p.beta, p.w_kl, p.nq_valid};
     if (p.sched != nullptr) {
         w.hardQ = p.sched[0]; w.hardV = p.sched[1];
         w.beta = __int_as_float(p.sched[2]); w.w_kl = __int_as_float(p.sched[3]);
+        w.nqv = p.sched[4];
     }
+    if (w.nqv <= 0 || w.nqv > p.nq) w.nqv = p.nq;
     return w;
 }
 
@@ -472,41 +478,50 @@ __global__ __launch_bounds__(256) void branch_loss_a_kernel(const BranchArgs p) 
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int nb_q = (p.nq + 3) / 4;
     int b = blockIdx.x;
-    if (b < nb_q) { trip_t2v_body(b, sm, p.C, p.labels, p.r_t2v, p.margin, 1.f / p.nq, p.nq, p.nv, p.terms, p.dC, 1.f); return; }
+    const SchedWords w = sched_words(p);
+    const int nqv = w.nqv;
+    if (b < nb_q) { trip_t2v_body(b, sm, p.C, p.labels, p.r_t2v, p.margin, 1.f / nqv, nqv, p.nv, p.terms, p.dC, 1.f); return; }
     b -= nb_q;
-    if (b < p.nv) { trip_v2t_body(b, sm, p.C, p.labels, p.r_v2t, p.hard, p.margin, 1.f / p.nv, p.nq, p.nv, p.terms + p.nq, p.dC, 1.f); return; }
+    if (b < p.nv) { trip_v2t_body(b, sm, p.C, p.labels, p.r_v2t, p.hard, p.margin, 1.f / p.nv, nqv, p.nv, p.terms + p.nq, p.dC, 1.f); return; }
     b -= p.nv;
     float* nterms = p.terms + p.nq + p.nv;
-    const SchedWords w = sched_words(p);
     if (b < nb_q) {
-        if (p.fold_t) nce_rows_body<true>(b, p.S, p.S, p.labels, p.cq, w.hardQ, w.beta, p.nq, p.nv, nterms, p.dS, nullptr, p.w_nce);
-        else nce_rows_body<false>(b, p.S, p.T, p.labels, p.cq, w.hardQ, w.beta, p.nq, p.nv, nterms, p.dS, nullptr, p.w_nce);
+        const int q = b * 4 + (threadIdx.x >> 6);
+        if (q >= nqv) {                                     // a padding query's row of dS: zero (simpool's backward reads every row)
+            if (q < p.nq) for (int v = threadIdx.x & 63; v < p.nv; v += 64) p.dS[(size_t)q * p.nv + v] = 0.f;
+            return;
+        }
+        if (p.fold_t) nce_rows_body<true>(b, p.S, p.S, p.labels, p.cq, w.hardQ, w.beta, nqv, p.nv, nterms, p.dS, nullptr, p.w_nce);
+        else nce_rows_body<false>(b, p.S, p.T, p.labels, p.cq, w.hardQ, w.beta, nqv, p.nv, nterms, p.dS, nullptr, p.w_nce);
         return;
     }
     b -= nb_q;
-    if (p.clip_p != nullptr) kl_frame_body(b, p.clip_p, p.clip_t, p.labels, p.lens, p.temp, p.nq, 0, p.L, p.terms + 2 * (p.nq + p.nv), p.dclip, w.w_kl);
+    if (p.clip_p != nullptr) kl_frame_body(b, p.clip_p, p.clip_t, p.labels, p.lens, p.temp, nqv, 0, p.L, p.terms + 2 * (p.nq + p.nv), p.dclip, w.w_kl);
 }
 
 template <bool REG>
 __global__ __launch_bounds__(256) void branch_loss_b_kernel(const BranchArgs p) {
     float* nterms = p.terms + p.nq + p.nv + p.nq;
     const SchedWords w = sched_words(p);
-    if (p.fold_t) nce_cols_body<REG, true>(blockIdx.x, p.S, p.S, p.labels, p.cv, w.hardV, w.beta, p.eps, p.nq, p.nv, nterms, p.dS, nullptr, p.w_nce);
-    else nce_cols_body<REG, false>(blockIdx.x, p.S, p.T, p.labels, p.cv, w.hardV, w.beta, p.eps, p.nq, p.nv, nterms, p.dS, nullptr, p.w_nce);
+    if (p.fold_t) nce_cols_body<REG, true>(blockIdx.x, p.S, p.S, p.labels, p.cv, w.hardV, w.beta, p.eps, w.nqv, p.nv, nterms, p.dS, nullptr, p.w_nce);
+    else nce_cols_body<REG, false>(blockIdx.x, p.S, p.T, p.labels, p.cv, w.hardV, w.beta, p.eps, w.nqv, p.nv, nterms, p.dS, nullptr, p.w_nce);
 }
 
-// block k sums segment k of the terms in a fixed order
+// block k sums segment k of the terms in a fixed order (a segment = [nq per-query terms | nv per-video terms]; the terms of padding
+// queries were never written and are skipped)
 __global__ __launch_bounds__(256) void branch_loss_c_kernel(const BranchArgs p) {
     __shared__ float red[4];
     const int k = blockIdx.x, n2 = p.nq + p.nv;
+    const SchedWords w = sched_words(p);
     const float* x = p.terms + (k == 0 ? 0 : k == 1 ? n2 : 2 * n2);
     const long n = k == 2 ? (p.clip_p != nullptr ? p.nq : 0) : n2;
     float s = 0.f;
-    for (long i = threadIdx.x; i < n; i += 256) s += x[i];
+    for (long i = threadIdx.x; i < n; i += 256)
+        if (i < w.nqv || i >= p.nq) s += x[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) p.out[k] = (red[0] + red[1] + red[2] + red[3]) * (k == 0 ? 1.f : k == 1 ? p.w_nce : sched_words(p).w_kl);
+    if (threadIdx.x == 0) p.out[k] = (red[0] + red[1] + red[2] + red[3]) * (k == 0 ? 1.f : k == 1 ? p.w_nce : w.w_kl);
 }
 
 // dC *= g[0], dS *= g[1], dclip *= g[2] (g: the upstream gradients of the three loss terms, device scalars)
@@ -590,7 +605,7 @@ int dldkd_branch_losses_f32(const float* C, const float* S, const float* T, cons
                             const int32_t* labels, const int32_t* lens, const int32_t* r_t2v, const int32_t* r_v2t, const float* cq,
                             const float* cv, int nq, int nv, int L, int hard, int hardQ, int hardV, int fold_t, float margin, float beta,
                             float eps, float temp, float w_nce, float w_kl, float* terms, float* dC, float* dS, float* dclip, float* out,
-                            const int32_t* sched, void* stream) {
+                            int nq_valid, const int32_t* sched, void* stream) {
     if (nq < 1 || nv < 1 || (clip_p && (L < 1 || L > 128)) || temp <= 0.f) { set_error("branch_losses: bad sizes"); return DLDKD_EINVAL; }
     if (!C || !S || !labels || !r_t2v || (!hard && !r_v2t) || !cq || !cv || !terms || !dC || !dS || !out || (clip_p && (!clip_t || !lens || !dclip))) {
         set_error("branch_losses: null pointer");
@@ -601,7 +616,7 @@ int dldkd_branch_losses_f32(const float* C, const float* S, const float* T, cons
         return DLDKD_EINVAL;
     }
     BranchArgs p{C, S, T, clip_p, clip_t, labels, lens, r_t2v, r_v2t, cq, cv, nq, nv, L, hard, hardQ, hardV, fold_t, margin, beta, eps,
-                 temp, w_nce, w_kl, terms, dC, dS, dclip, out, sched};
+                 temp, w_nce, w_kl, terms, dC, dS, dclip, out, sched, nq_valid};
     const int nb_q = (nq + 3) / 4;
     const size_t lds = sizeof(float) * (size_t)((nv * 4 > nq) ? nv * 4 : nq);
     hipStream_t s = (hipStream_t)stream;

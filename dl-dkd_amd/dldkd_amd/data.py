@@ -147,18 +147,26 @@ class DeviceTrainSet:
     def __len__(self):
         return self.n_videos
 
-    def _gather(self, k, items_dev, n, lmax, out=None, mask=None):
+    def _gather(self, k, items_dev, n, lmax, out=None, mask=None, rows=None):
+        """rows >= n: the destination holds `rows` sequences; those behind the n gathered ones become padding sequences - zero
+        features, ONE valid position (mask[:, 0] = 1: a tower never sees an empty sequence)."""
         from . import native
         D = self.dim[k]
+        rows = n if rows is None else int(rows)
         if out is None:
-            out = torch.empty(n, lmax, D, dtype=torch.float32, device=self.device)
+            out = torch.empty(rows, lmax, D, dtype=torch.float32, device=self.device)
         if mask is None:
-            mask = torch.empty(n, lmax, dtype=torch.float32, device=self.device)
-        if tuple(out.shape) != (n, lmax, D) or tuple(mask.shape) != (n, lmax) or not (out.is_contiguous() and mask.is_contiguous()):
-            raise ValueError(f"DeviceTrainSet: destination of {k} must be contiguous ({n}, {lmax}, {D}) + ({n}, {lmax})")
+            mask = torch.empty(rows, lmax, dtype=torch.float32, device=self.device)
+        if (rows < n or tuple(out.shape) != (rows, lmax, D) or tuple(mask.shape) != (rows, lmax)
+                or not (out.is_contiguous() and mask.is_contiguous())):
+            raise ValueError(f"DeviceTrainSet: destination of {k} must be contiguous ({rows}, {lmax}, {D}) + ({rows}, {lmax})")
         native.check(native.lib().dldkd_gather_pad_rows_f32(native.ptr(self.src[k]), native.ptr(self.row_start[k]), native.ptr(self.lens_dev[k]),
                                                             native.ptr(items_dev), n, lmax, D, native.ptr(out), native.ptr(mask),
                                                             native.stream()), "gather_pad_rows")
+        if rows > n:
+            out[n:].zero_()
+            mask[n:].zero_()
+            mask[n:, 0] = 1.0
         return out, mask
 
     def plan(self, indices):
@@ -176,11 +184,12 @@ class DeviceTrainSet:
         return types.SimpleNamespace(vids=vids, caps=caps, labels=labels, lmax=lmax, n={k: len(items[k]) for k in self.TABLES},
                                      dim=dict(self.dim))
 
-    def gather(self, plan, out=None, pad=None):
+    def gather(self, plan, out=None, pad=None, n_queries=None):
         """Device half: collate_train's dict for `plan`, gathered on the current stream.  pad: {table: padded length >= its longest
-        sequence} (zero rows, zero mask behind a sequence's end: what the stepper's bucketing would append); out: a dict of
-        destination tensors of exactly those shapes (the captured step's input buffers) - the rows then land where the step reads
-        them and the returned dict holds those tensors."""
+        sequence} (zero rows, zero mask behind a sequence's end: what the stepper's bucketing would append); n_queries >= the
+        plan's captions: the text tensors get that many rows, the extra ones as padding queries (train.GraphedTrainStep pads the
+        query axis to a bucket; text_labels stays the real list); out: a dict of destination tensors of exactly those shapes (the
+        captured step's input buffers) - the rows then land where the step reads them and the returned dict holds those tensors."""
         from .staging import PinnedRing
         import numpy as np
         pad = pad or {}
@@ -199,8 +208,8 @@ class DeviceTrainSet:
         nv, nq = len(plan.vids), len(plan.caps)
         sv, sm = self._gather("student_videos", v_dev, nv, L["student_videos"], o.get("student_videos"), o.get("student_videos_mask"))
         tv, _ = self._gather("teacher_videos", v_dev, nv, L["teacher_videos"], o.get("teacher_videos"))
-        st, stm = self._gather("student_text", c_dev, nq, L["student_text"], o.get("student_text"), o.get("student_text_mask"))
-        tt, _ = self._gather("teacher_text", c_dev, nq, L["teacher_text"], o.get("teacher_text"))
+        st, stm = self._gather("student_text", c_dev, nq, L["student_text"], o.get("student_text"), o.get("student_text_mask"), rows=n_queries)
+        tt, _ = self._gather("teacher_text", c_dev, nq, L["teacher_text"], o.get("teacher_text"), rows=n_queries)
         return dict(student_videos=sv, teacher_videos=tv, student_videos_mask=sm, student_text=st, student_text_mask=stm,
                     teacher_text=tt, text_labels=plan.labels)
 

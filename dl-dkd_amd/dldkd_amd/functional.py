@@ -1412,8 +1412,9 @@ def _is_unit(g):
 
 class ScheduleWords:
     """The scalars an epoch's schedule moves (train.epoch_schedules: alpha, belta, the KD weight; train.py:66-113) as DEVICE state a
-    captured step reads by address: the InfoNCE coefficient vectors cq (Nq) / cv (Nv) and, per loss weight w_kl, four words
-    {hardQ, hardV, bits(belta), bits(w_kl)} (dldkd_branch_losses_f32 `sched`).  train.GraphedTrainStep makes one per captured step,
+    captured step reads by address: the InfoNCE coefficient vectors cq (Nq) / cv (Nv) and, per loss weight w_kl, five words
+    {hardQ, hardV, bits(belta), bits(w_kl), nq_valid} (dldkd_branch_losses_f32 `sched`; nq_valid: the batch's real queries when the
+    query axis is padded to a bucket).  train.GraphedTrainStep makes one per captured step,
     installs it around the capture (`schedule_words`) and calls update() before every replay: a graph captured in epoch 0 serves
     every epoch (by value the scalars were part of the graph's key: a capture per epoch, and none after max_captures).
     update() enqueues a few fills on the current stream when - and only when - the values changed."""
@@ -1432,7 +1433,7 @@ class ScheduleWords:
         if f not in self.words:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("ScheduleWords: a branch's words must exist before the capture (prepare())")
-            self.words[f] = torch.zeros(4, dtype=torch.int32, device=self.device)
+            self.words[f] = torch.zeros(5, dtype=torch.int32, device=self.device)
             self.state = None
         return self.words[f]
 
@@ -1447,11 +1448,15 @@ class ScheduleWords:
         return (hq, hv, (alpha / hq if use_hard else 0.0, (1 - alpha) / sq if use_soft else 0.0),
                 (alpha / hv if use_hard else 0.0, (1 - alpha) / sv if use_soft else 0.0))
 
-    def update(self, alpha, beta, weight):
-        state = (float(alpha), float(beta), float(weight), tuple(self.words))
+    def update(self, alpha, beta, weight, nq_valid=None):
+        """nq_valid: the batch's number of real queries (<= nq: the query axis is padded to a bucket, dldkd_branch_losses_f32)."""
+        nqv = self.nq if nq_valid is None else int(nq_valid)
+        if not 0 < nqv <= self.nq:
+            raise ValueError(f"ScheduleWords: {nqv} valid queries of {self.nq}")
+        state = (float(alpha), float(beta), float(weight), nqv, tuple(self.words))
         if state == self.state:
             return False
-        hq, hv, (qh, qs), (vh, vs) = self.coefs(self.nq, self.nv, float(alpha), self.soft)
+        hq, hv, (qh, qs), (vh, vs) = self.coefs(nqv, self.nv, float(alpha), self.soft)
         for c, h, wh, ws in ((self.cq, hq, qh, qs), (self.cv, hv, vh, vs)):
             c.fill_(float(ws))
             if self.soft and h > 0:
@@ -1461,6 +1466,7 @@ class ScheduleWords:
             w[0:1].fill_(int(hq)); w[1:2].fill_(int(hv))
             w.view(torch.float32)[2:3].fill_(b)
             w.view(torch.float32)[3:4].fill_(float(f * float(weight)))
+            w[4:5].fill_(nqv)
         self.state = state
         return True
 
@@ -1484,7 +1490,7 @@ class _BranchLoss(Function):
     computed with the values (for an upstream gradient of 1) and scaled by the actual upstream gradients in the backward pass."""
 
     @staticmethod
-    def forward(ctx, C, S, T, clip_p, clip_t, labels, lens, r_t2v, r_v2t, cq, cv, cfg, sched=None):
+    def forward(ctx, C, S, T, clip_p, clip_t, labels, lens, r_t2v, r_v2t, cq, cv, cfg, sched=None, nq_valid=0):
         hard, hardQ, hardV, fold_t, margin, beta, eps, temp, w_nce, w_kl = cfg
         nq, nv = C.shape
         dev = C.device
@@ -1497,7 +1503,7 @@ class _BranchLoss(Function):
         native.check(_L().dldkd_branch_losses_f32(_p(C), _p(S), _p(T), _p(clip_p), _p(clip_t), _p(labels), _p(lens), _p(r_t2v), _p(r_v2t),
                                                   _p(cq), _p(cv), nq, nv, Lc, int(hard), int(hardQ), int(hardV), int(fold_t), float(margin),
                                                   float(beta), float(eps), float(temp), float(w_nce), float(w_kl), _p(terms), _p(dC), _p(dS),
-                                                  _p(dclip), _p(out), _p(sched), _s()), "branch_losses")
+                                                  _p(dclip), _p(out), int(nq_valid), _p(sched), _s()), "branch_losses")
         ctx.save_for_backward(dC, dS, dclip)
         ctx.set_materialize_grads(False)       # a term nobody uses has no upstream gradient (None, handled in backward): no zero fill
         return out[0], out[1], out[2]
@@ -1508,7 +1514,7 @@ class _BranchLoss(Function):
         dC, dS, dclip = ctx.saved_tensors
         if (g_trip is not None and g_nce is not None and _is_unit(g_trip) and _is_unit(g_nce)
                 and (dclip is None or (g_kl is not None and _is_unit(g_kl)))):
-            return dC, dS, None, dclip, None, None, None, None, None, None, None, None, None      # scaling by exactly 1: nothing to launch
+            return dC, dS, None, dclip, None, None, None, None, None, None, None, None, None, None      # scaling by exactly 1: nothing to launch
         # The saved gradients are scaled IN PLACE and handed out as they are (no second copy of two (Nq, Nv) matrices per branch): a
         # second backward pass through this node (retain_graph=True) would scale them twice.  Once only, loudly.
         if getattr(ctx, "_scaled", False):
@@ -1525,42 +1531,48 @@ class _BranchLoss(Function):
             return one
         native.check(_L().dldkd_branch_losses_scale_f32(_p(dC), _p(dS), dC.numel(), _p(dclip), 0 if dclip is None else dclip.numel(),
                                                         _p(gs(g_trip)), _p(gs(g_nce)), _p(gs(g_kl)), _s()), "branch_losses_scale")
-        return dC, dS, None, dclip, None, None, None, None, None, None, None, None, None
+        return dC, dS, None, dclip, None, None, None, None, None, None, None, None, None, None
 
 
-def branch_losses(C, S, T, clip_p, clip_t, labels, lens, r_t2v, r_v2t, hard, margin, soft, alpha, beta, w_nce, w_kl, fold_t, kd_factor=None):
+def branch_losses(C, S, T, clip_p, clip_t, labels, lens, r_t2v, r_v2t, hard, margin, soft, alpha, beta, w_nce, w_kl, fold_t, kd_factor=None,
+                  nq_valid=None):
     """(triplet, w_nce * InfoNCE, w_kl * KL) of one branch.  soft: clip_nce_soft with soft-label scores T (fold_t: T is S itself,
     exploration branch), else clip_nce.  clip_p None: no KL term (the third value is 0).  kd_factor: w_kl = kd_factor x the epoch's KD
-    weight (what a ScheduleWords needs to follow the schedule; None: w_kl is a constant of the run)."""
+    weight (what a ScheduleWords needs to follow the schedule; None: w_kl is a constant of the run).  nq_valid: rows [nq_valid, Nq) of
+    the score matrices belong to padding queries (None: none) - terms, normalisers and coefficients are those of nq_valid queries, the
+    padding rows get zero gradients."""
     C, S = _f32(C), _f32(S)
     Nq, Nv = S.shape
+    nqv = Nq if nq_valid is None else int(nq_valid)
+    if not 0 < nqv <= Nq:
+        raise native.NativeError(f"branch_losses: {nqv} valid queries of {Nq}")
     sw = _SCHED
     if sw is not None and kd_factor is not None and (sw.nq, sw.nv, sw.soft) == (Nq, Nv, bool(soft)) and S.is_cuda:
         # the schedule's scalars as device state (ScheduleWords): this launch reads hardQ / hardV / belta / w_kl and the coefficient
         # vectors by address; the by-value arguments are the current epoch's (what the words hold right now) and are ignored
-        hardQ, hardV, _, _ = sw.coefs(Nq, Nv, float(alpha), bool(soft))
+        hardQ, hardV, _, _ = sw.coefs(nqv, Nv, float(alpha), bool(soft))
         eps, Tt = (1e-12, None if fold_t else _f32(T).detach()) if soft else (0.0, None)
         if not soft:
             fold_t, beta = False, 0.0
         cfg = (bool(hard), hardQ, hardV, bool(fold_t), float(margin), float(beta), eps, 0.2, float(w_nce), float(w_kl))
         sw.used += 1
         return _BranchLoss.apply(C, S, Tt, None if clip_p is None else _f32(clip_p), None if clip_t is None else _f32(clip_t).detach(), labels,
-                                 lens, r_t2v, r_v2t, sw.cq, sw.cv, cfg, sw.words_for(kd_factor))
+                                 lens, r_t2v, r_v2t, sw.cq, sw.cv, cfg, sw.words_for(kd_factor), nqv)
     if soft:
-        hardQ, hardV = math.floor(alpha * Nq), math.floor(alpha * Nv)
-        softQ, softV = Nq - hardQ, Nv - hardV
+        hardQ, hardV = math.floor(alpha * nqv), math.floor(alpha * Nv)
+        softQ, softV = nqv - hardQ, Nv - hardV
         use_hard = hardQ != 0 and hardV != 0
         use_soft = softQ != 0 and softV != 0
         cq = _part_coefs(Nq, hardQ, alpha / hardQ if use_hard else 0.0, (1 - alpha) / softQ if use_soft else 0.0, S.device)
         cv = _part_coefs(Nv, hardV, alpha / hardV if use_hard else 0.0, (1 - alpha) / softV if use_soft else 0.0, S.device)
         eps, Tt = 1e-12, (None if fold_t else _f32(T).detach())
     else:
-        hardQ, hardV, eps, Tt, fold_t, beta = Nq, Nv, 0.0, None, False, 0.0
-        cq = _part_coefs(Nq, 0, 0.0, 1.0 / Nq, S.device)
+        hardQ, hardV, eps, Tt, fold_t, beta = nqv, Nv, 0.0, None, False, 0.0
+        cq = _part_coefs(Nq, 0, 0.0, 1.0 / nqv, S.device)
         cv = _part_coefs(Nv, 0, 0.0, 1.0 / Nv, S.device)
     cfg = (bool(hard), hardQ, hardV, bool(fold_t), float(margin), float(beta), eps, 0.2, float(w_nce), float(w_kl))
     return _BranchLoss.apply(C, S, Tt, None if clip_p is None else _f32(clip_p), None if clip_t is None else _f32(clip_t).detach(), labels, lens,
-                             r_t2v, r_v2t, cq, cv, cfg)
+                             r_t2v, r_v2t, cq, cv, cfg, None, nqv)
 
 
 class _Triplet(Function):

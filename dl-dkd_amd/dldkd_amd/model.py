@@ -588,11 +588,25 @@ class DLDKD(nn.Module):
             F_.begin_zero_arena(dev)          # one fill for the step's small zero-initialised gradient buffers
         else:
             F_.end_zero_arena()
-        lab = staged.labels_dev if staged is not None else torch.as_tensor(np.asarray(labels), dtype=torch.int32, device=dev)
+        # A query axis padded to a bucket (train.GraphedTrainStep, batches of variable caption counts: Charades / ActivityNet): the
+        # text tensors hold nq_rows >= len(labels) queries, the rows behind the real ones are padding (one valid zero word each).
+        # Towers and pooled scores run over all rows; the losses run over the first len(labels) (functional.branch_losses nq_valid).
+        nq_rows = int(batch["student_text"].shape[0])
+        nq_valid = None
+        if nq_rows != len(labels):
+            if nq_rows < len(labels) or not (mask.is_cuda and F_.BRANCH_LOSS_FUSED and F_.simpool_train_ok()):
+                raise ValueError(f"forward_tensors: {nq_rows} text rows for {len(labels)} labels (a padded query axis needs the fused loss path)")
+            nq_valid = len(labels)
+        if staged is not None:
+            lab = staged.labels_dev
+        else:
+            lab_np = np.zeros(nq_rows, dtype=np.int32)
+            lab_np[:len(labels)] = np.asarray(labels)
+            lab = torch.as_tensor(lab_np, dtype=torch.int32, device=dev)
         nv, L = mask.shape
         lens = self._lens(mask, nv, L, dev)
 
-        t_text = batch["teacher_text"].float().reshape(len(labels), -1)          # .squeeze() of model.py:114
+        t_text = batch["teacher_text"].float().reshape(nq_rows, -1)          # .squeeze() of model.py:114
         t_vid = batch["teacher_videos"].float()
 
         fused = F_.simpool_train_ok()
@@ -638,7 +652,7 @@ class DLDKD(nn.Module):
                 r_t2v, r_v2t = draws(0)
                 return F_.branch_losses(i_cos, i_raw, t_raw, i_clip, t_clip, lab, lens, r_t2v, r_v2t, hard_neg, _cfg_get(self.config, "margin"),
                                         soft, self.alpha, self.belta, self.inher_nce_weight, self.kl_intra_weight * self.weight, False,
-                                        kd_factor=self.kl_intra_weight)
+                                        kd_factor=self.kl_intra_weight, nq_valid=nq_valid)
             inher_trip = trip(i_cos, 0)
             if soft:
                 inher_nce = self.inher_nce_weight * F_.nce_soft(lab, i_raw, t_raw, self.alpha, self.belta)
@@ -652,7 +666,7 @@ class DLDKD(nn.Module):
             if fused_losses:
                 r_t2v, r_v2t = draws(1)
                 return F_.branch_losses(e_cos, e_raw, None, None, None, lab, lens, r_t2v, r_v2t, hard_neg, _cfg_get(self.config, "margin"),
-                                        soft, self.alpha, self.belta, self.explore_nce_weight, 0.0, True, kd_factor=0.0)[:2]
+                                        soft, self.alpha, self.belta, self.explore_nce_weight, 0.0, True, kd_factor=0.0, nq_valid=nq_valid)[:2]
             explore_trip = trip(e_cos, 1)
             if soft:
                 explore_nce = self.explore_nce_weight * F_.nce_soft(lab, e_raw, e_raw, self.alpha, self.belta)

@@ -101,7 +101,7 @@ SIGNATURES = {
                                           _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_mask_lens_f32": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
     "dldkd_colsum_bf16": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_long, _c_void_p, _c_void_p, _c_void_p]),
-    "dldkd_branch_losses_f32": (_c_int, [_c_void_p] * 11 + [_c_int] * 7 + [_c_float] * 6 + [_c_void_p] * 7),
+    "dldkd_branch_losses_f32": (_c_int, [_c_void_p] * 11 + [_c_int] * 7 + [_c_float] * 6 + [_c_void_p] * 5 + [_c_int, _c_void_p, _c_void_p]),
     "dldkd_branch_losses_scale_f32": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "dldkd_sum_scalars_f32": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
     "dldkd_zero_scratch_f32": (_c_int, [_c_void_p, _c_int, _c_void_p]),

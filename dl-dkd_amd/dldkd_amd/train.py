@@ -263,7 +263,7 @@ class GraphedTrainStep:
     # -- what is baked into a graph
     def _key(self, batch):
         shapes = tuple((k, tuple(batch[k].shape), str(batch[k].dtype)) for k in self.TENSOR_KEYS)
-        return (shapes, len(batch["text_labels"])) + self._key_tail(batch["student_videos"].is_cuda)
+        return (shapes, int(batch["student_text"].shape[0])) + self._key_tail(batch["student_videos"].is_cuda)
 
     def _key_tail(self, on_gpu):
         """The part of a graph's key that is not the batch's shapes: the model / run state baked into the captured launches."""
@@ -290,9 +290,20 @@ class GraphedTrainStep:
         get = (lambda k, d: cfg.get(k, d)) if isinstance(cfg, dict) else (lambda k, d: getattr(cfg, k, d))
         lq, lv = batch["student_text"].shape[1], batch["student_videos"].shape[1]
         lq_b, lv_b = self._bucket_lens(lq, lv)
-        if lq_b == lq and lv_b == lv:
+        nq = int(batch["student_text"].shape[0])
+        nq_b = self._bucket_queries(nq, batch["student_text"].is_cuda)
+        if lq_b == lq and lv_b == lv and nq_b == nq:
             return batch
         out = dict(batch)
+        if nq_b != nq:
+            # padding queries behind the real ones: zero features, one valid (zero) word, a zero teacher vector; text_labels keeps
+            # the real list - the model runs its losses over the first len(text_labels) rows (DLDKD.forward_tensors)
+            for k in ("student_text", "teacher_text"):
+                out[k] = TF.pad(batch[k], (0, 0, 0, 0, 0, nq_b - nq))
+            out["student_text_mask"] = TF.pad(batch["student_text_mask"], (0, 0, 0, nq_b - nq))
+            out["student_text_mask"][nq:, 0] = 1.0
+            batch = out
+            out = dict(batch)
         if lq_b != lq:
             out["student_text"] = TF.pad(batch["student_text"], (0, 0, 0, lq_b - lq))
             out["student_text_mask"] = TF.pad(batch["student_text_mask"], (0, lq_b - lq))
@@ -355,6 +366,14 @@ class GraphedTrainStep:
         finally:
             self._lookahead = self._fetched = None
 
+    QUERY_BUCKET = 32      # the query axis is padded to a multiple of this (0: never) where the fused losses can skip the padding rows
+
+    def _bucket_queries(self, nq, on_gpu):
+        """Batches of variable caption counts (data_provider.py:34-72: Charades ~2.3, ActivityNet ~3.7 captions per video) have a
+        different number of queries each; padded to a bucket, a handful of captures serve them all (instead of eager steps)."""
+        b = int(self.QUERY_BUCKET)
+        return -(-nq // b) * b if (b > 0 and self._schedule_on_device(on_gpu)) else nq
+
     def _bucket_lens(self, lq, lv):
         cfg = self.model.config
         get = (lambda k, d: cfg.get(k, d)) if isinstance(cfg, dict) else (lambda k, d: getattr(cfg, k, d))
@@ -363,17 +382,18 @@ class GraphedTrainStep:
     def _materialize(self, devset, plan, st):
         lq_b, lv_b = self._bucket_lens(plan.lmax["student_text"], max(plan.lmax["student_videos"], plan.lmax["teacher_videos"]))
         pad = {"student_videos": lv_b, "teacher_videos": lv_b, "student_text": lq_b}
-        nv, nq, f32 = plan.n["student_videos"], plan.n["student_text"], str(torch.float32)
+        nv, f32 = plan.n["student_videos"], str(torch.float32)
+        nq = self._bucket_queries(plan.n["student_text"], True)
         shape = {"student_videos": (nv, lv_b, plan.dim["student_videos"]), "student_videos_mask": (nv, lv_b),
                  "teacher_videos": (nv, lv_b, plan.dim["teacher_videos"]), "student_text": (nq, lq_b, plan.dim["student_text"]),
                  "student_text_mask": (nq, lq_b), "teacher_text": (nq, plan.lmax["teacher_text"], plan.dim["teacher_text"])}
-        key = (tuple((k, shape[k], f32) for k in self.TENSOR_KEYS), len(plan.labels)) + self._key_tail(True)
+        key = (tuple((k, shape[k], f32) for k in self.TENSOR_KEYS), nq) + self._key_tail(True)
         key = key + (self._turn.get(key, 0),)
         e = self.graphs.get(key) if getattr(self.opt, "grad_clip", -1) == -1 else None
         with torch.cuda.stream(st):
             if e is not None:
                 st.wait_event(e.ev_done)                  # that capture's previous replay (two steps back) has read its inputs
-            batch = devset.gather(plan, out=None if e is None else e.static, pad=pad)
+            batch = devset.gather(plan, out=None if e is None else e.static, pad=pad, n_queries=nq)
             ev = torch.cuda.Event()
             ev.record(st)
         sig = self._sig(batch)
@@ -617,7 +637,7 @@ class GraphedTrainStep:
         self.memset_defect = memset_node_defect(dev, log=logger.info, select=getattr(self.opt, "scratch_zeroing", "kernel") == "probe")
         e = _CapturedStep()
         labels = list(batch["text_labels"])
-        nq, nv = len(labels), batch["student_videos"].shape[0]
+        nq, nv = int(batch["student_text"].shape[0]), batch["student_videos"].shape[0]      # (nq: text rows, >= len(labels) when padded)
         e.hard = bool(key[5])
         e.n_calls = 2 if m.double_branch else 1
         self._layout(e, nq, nv, e.n_calls)
@@ -637,7 +657,9 @@ class GraphedTrainStep:
             e.sched = F_.ScheduleWords(nq, nv, m.label_style == "soft", dev)
             for f in (m.kl_intra_weight, 0.0):              # the two branches' KL factors (model.py:143-155)
                 e.sched.words_for(f)
-            e.sched.update(m.alpha, m.belta, m.weight)
+            e.sched.update(m.alpha, m.belta, m.weight, len(labels))
+        elif len(labels) != nq:
+            raise RuntimeError("GraphedTrainStep: a padded query axis without the schedule words")
         old_lr = opt_.t_lr
         opt_.t_lr = view("lr", len(opt_.fp.params)).view(torch.float32)      # the update kernel reads the staged rates
         e.t_lr = opt_.t_lr
@@ -981,8 +1003,11 @@ class GraphedTrainStep:
                 if batch[k].data_ptr() != e.static[k].data_ptr():
                     e.static[k].copy_(batch[k], non_blocking=True)
 
+        n_t = len(batch["text_labels"])                   # the batch's real queries (<= e.nq text rows)
         if e.sched is not None:
-            e.sched.update(m.alpha, m.belta, m.weight)    # a few fills, on the first replay of an epoch only
+            e.sched.update(m.alpha, m.belta, m.weight, n_t)      # a few fills, when the epoch's schedule or the query count moved
+        elif n_t != e.nq:
+            raise RuntimeError(f"GraphedTrainStep: {n_t} labels for a step captured with {e.nq} queries")
         # the video features first - the largest copy (201 MB at the TVR batch: 72 us) feeding the longest chains; the video towers
         # start behind it and the step's scalars (ev_in_video below) while the other inputs are still being copied
         stage(self.TENSOR_KEYS[:2])
@@ -996,13 +1021,17 @@ class GraphedTrainStep:
             e.ring.upload_range(e.dev_words.view(torch.uint8), 0, 16, last=False)
             par["ev_in_video"].record(self.stream)
         opt_.t_lr = e.t_lr
-        n_t = len(opt_.fp.params)
-        opt_.host_prepare(lr_out=slot[e.off["lr"]:e.off["lr"] + n_t].view(torch.float32))
+        n_par = len(opt_.fp.params)
+        opt_.host_prepare(lr_out=slot[e.off["lr"]:e.off["lr"] + n_par].view(torch.float32))
         labels_np = __import__("numpy").asarray(batch["text_labels"])      # THIS batch's caption -> video map
-        slot[e.off["labels"]:e.off["labels"] + e.nq] = torch.from_numpy(labels_np.astype("int32"))
+        slot[e.off["labels"]:e.off["labels"] + n_t] = torch.from_numpy(labels_np.astype("int32"))
+        if n_t < e.nq:                                    # padding queries: label 0, draw 1 (never read by the losses)
+            slot[e.off["labels"] + n_t:e.off["labels"] + e.nq] = 0
         for c in range(e.n_calls):                        # the reference's CPU draws, same order and arguments
             _, r_t2v, r_v2t = m._draw_triplet(labels_np, e.nv)
-            slot[e.off[("t2v", c)]:e.off[("t2v", c)] + e.nq] = r_t2v
+            slot[e.off[("t2v", c)]:e.off[("t2v", c)] + n_t] = r_t2v
+            if n_t < e.nq:
+                slot[e.off[("t2v", c)] + n_t:e.off[("t2v", c)] + e.nq] = 1
             if r_v2t is not None:
                 slot[e.off[("v2t", c)]:e.off[("v2t", c)] + e.nv] = r_v2t
         if par:

@@ -719,14 +719,19 @@ int dldkd_simpool_train_bwd_f32(const float* q, const float* g, const float* rq,
  * dldkd_nce_f32.  terms: scratch of 2 (nq + nv) + nq floats; dC (nq, nv) and dclip (nq, L) zeroed by the caller, dS (nq, nv) written;
  * out[3] = triplet, w_nce InfoNCE, w_kl KL.  Gradients are those of out[] for an upstream gradient of 1;
  * dldkd_branch_losses_scale_f32 multiplies them by the actual upstream gradients (device scalars) in place.
- * sched: NULL, or 4 device words {hardQ, hardV, bits of beta, bits of w_kl} that REPLACE the by-value arguments of those names when
- * the kernels run - the scalars an epoch's schedule moves (method/train.py:66-113: alpha -> hardQ / hardV and cq / cv, belta, the KD
- * weight).  A launch captured into a hipGraph then follows the schedule (the caller rewrites the words and cq / cv in place). */
+ * nq_valid: rows [nq_valid, nq) of C / S / T / clip_p / clip_t belong to PADDING queries (a batch whose query axis was padded to a
+ * bucket so that batches with different caption counts - method/data_provider.py:34-72, Charades / ActivityNet - share one captured
+ * graph): the terms, normalisers and the columns' softmax run over the first nq_valid queries only, the padding rows' dS is written
+ * as zero (dC / dclip stay as zeroed), labels / r_t2v need nq_valid valid entries; <= 0: nq.
+ * sched: NULL, or 5 device words {hardQ, hardV, bits of beta, bits of w_kl, nq_valid} that REPLACE the by-value arguments of those
+ * names when the kernels run - the scalars an epoch's schedule moves (method/train.py:66-113: alpha -> hardQ / hardV and cq / cv,
+ * belta, the KD weight) and the batch's query count.  A launch captured into a hipGraph then follows them (the caller rewrites the
+ * words and cq / cv in place). */
 int dldkd_branch_losses_f32(const float* C, const float* S, const float* T, const float* clip_p, const float* clip_t,
                             const int32_t* labels, const int32_t* lens, const int32_t* r_t2v, const int32_t* r_v2t, const float* cq,
                             const float* cv, int nq, int nv, int L, int hard, int hardQ, int hardV, int fold_t, float margin, float beta,
                             float eps, float temp, float w_nce, float w_kl, float* terms, float* dC, float* dS, float* dclip, float* out,
-                            const int32_t* sched, void* stream);
+                            int nq_valid, const int32_t* sched, void* stream);
 int dldkd_branch_losses_scale_f32(float* dC, float* dS, long n, float* dclip, long n_clip, const float* g_trip, const float* g_nce,
                                   const float* g_kl, void* stream);
 /* out[0] = sum of x[0..n) in a fixed order (single workgroup). */

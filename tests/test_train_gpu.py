@@ -924,3 +924,77 @@ def test_branch_losses_read_the_epoch_schedule_from_device_words(soft):
     assert sw.used == 2 * len(points)
     if soft:       # the schedule does move the losses (the test would pass vacuously otherwise)
         assert float(run(*points[0], None, None)[0][1]) != float(run(*points[1], None, None)[0][1])
+
+
+@pytest.mark.parametrize("soft,hard_neg", [(True, True), (True, False), (False, True)])
+def test_branch_losses_skip_padding_queries(soft, hard_neg):
+    """dldkd_branch_losses_f32 with nq_valid < nq (a query axis padded to a bucket, so that batches of different caption counts -
+    method/data_provider.py:34-72 - share a captured graph): with GARBAGE in the padding rows of every input the three terms and the
+    gradients of the real rows equal the launch on the unpadded matrices (to the last bits of a sum), and the padding rows' gradients are exactly zero;
+    by value and through the device words (functional.ScheduleWords), for both branches' forms."""
+    from dldkd_amd import functional as F_
+    rs = np.random.RandomState(19)
+    nv = 16
+    counts = sorted(rs.randint(1, 4, size=nv).tolist(), reverse=True)
+    labels = [i for i, c in enumerate(counts) for _ in range(c)]
+    nq, L = len(labels), 24
+    nq_b = -(-nq // 32) * 32
+    assert nq_b > nq
+    g = torch.Generator().manual_seed(47)
+    lens = torch.from_numpy(rs.randint(1, L + 1, size=nv)).int().to(DEV)
+
+    def padded(x, fill):
+        out = torch.full((nq_b,) + tuple(x.shape[1:]), fill, dtype=x.dtype, device=DEV)
+        out[:nq] = x
+        return out
+    cos = torch.tanh(torch.randn(nq, nv, generator=g)).to(DEV)
+    raw = (torch.randn(nq, nv, generator=g) * 3.0).to(DEV)
+    tch = (torch.randn(nq, nv, generator=g) * 3.0).to(DEV)
+    clip_p = (torch.randn(nq, L, generator=g) * 0.5).to(DEV)
+    clip_t = (torch.randn(nq, L, generator=g) * 0.5).to(DEV)
+    torch.manual_seed(6)
+    r_v2t, r_t2v = orc.draw_triplet_randoms(labels, nv, hard_neg, 20)
+    r_t2v = r_t2v.int().to(DEV)
+    r_v2t = None if r_v2t is None else r_v2t.int().to(DEV)
+    lab = _lab(labels)
+    lab_b = torch.zeros(nq_b, dtype=torch.int32, device=DEV)
+    lab_b[:nq] = lab
+    r_t2v_b = torch.ones(nq_b, dtype=torch.int32, device=DEV)
+    r_t2v_b[:nq] = r_t2v
+
+    def run(pad, sw):
+        out = []
+        for inher in (True, False):
+            ins = [cos, raw, tch, clip_p, clip_t]
+            if pad:      # garbage (huge scores, NaN clip rows) where the padding queries sit
+                ins = [padded(cos, 50.0), padded(raw, 1e4), padded(tch, -1e4), padded(clip_p, float("nan")), padded(clip_t, float("nan"))]
+            C, S, T, P, Pt = ins
+            C, S, P = C.clone().requires_grad_(True), S.clone().requires_grad_(True), P.clone().requires_grad_(True)
+            kw = dict(nq_valid=nq) if pad else {}
+            with F_.schedule_words(sw):
+                if inher:
+                    terms = F_.branch_losses(C, S, T, P, Pt, lab_b if pad else lab, lens, r_t2v_b if pad else r_t2v, r_v2t, hard_neg, 0.1, soft,
+                                             0.8, 0.7, 0.04, 0.1 * 0.9, False, kd_factor=0.1, **kw)
+                else:
+                    terms = F_.branch_losses(C, S, None, None, None, lab_b if pad else lab, lens, r_t2v_b if pad else r_t2v, r_v2t, hard_neg, 0.1,
+                                             soft, 0.8, 0.7, 0.04, 0.0, True, kd_factor=0.0, **kw)[:2]
+            sum(terms).backward()
+            out.append(([t.detach().clone() for t in terms], [x.grad.clone() for x in (C, S, P) if x.grad is not None]))
+        return out
+
+    ref = run(False, None)
+    sw = F_.ScheduleWords(nq_b, nv, soft, DEV)
+    for f in (0.1, 0.0):
+        sw.words_for(f)
+    sw.update(0.8, 0.7, 0.9, nq)
+    for got in (run(True, None), run(True, sw)):
+        for (t_got, g_got), (t_ref, g_ref) in zip(got, ref):
+            # (the sums run over the same terms at other positions of the scratch: the last bits of the three totals may differ)
+            assert all(float(a) == pytest.approx(float(b), rel=2e-6) for a, b in zip(t_got, t_ref)), (t_got, t_ref)
+            for a, b in zip(g_got, g_ref):
+                assert torch.allclose(a[:nq], b, rtol=1e-6, atol=1e-9) and float(a[nq:].abs().max()) == 0.0
+    assert sw.used == 2
+    # another count through the same words (the next batch of the bucket)
+    sw.update(0.8, 0.7, 0.9, nq - 3)
+    with pytest.raises(ValueError):
+        sw.update(0.8, 0.7, 0.9, nq_b + 1)

@@ -361,6 +361,83 @@ def test_train_epoch_prefetches_the_next_batch_and_follows_the_unprefetched_run(
         assert all(np.isfinite(l1))
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_variable_caption_counts_share_a_captured_step(prec):
+    """Charades / ActivityNet batches hold a different number of captions each (data_provider.py:34-72), i.e. a different query
+    count per batch: every batch its own graph signature, and GraphedTrainStep would never replay.  The stepper pads the QUERY axis
+    to a multiple of 32 (one-word zero queries behind the real ones); towers and pooled scores run over all rows, the fused losses
+    over the real ones (dldkd_branch_losses_f32 nq_valid, read from the step's device words).  (a) the model on a padded batch =
+    the model on the raw batch: losses and gradients (no dropout; both eager); (b) ten batches of seven different query counts in
+    one bucket: ONE capture, nine replays, each step equal to the eager step on the raw batch (state copied over before every
+    step, same seeds), with dropout on."""
+    import synth
+    from dldkd_amd import ops
+    from dldkd_amd import train as T
+    from dldkd_amd.model import DLDKD
+    from dldkd_amd.optimization import BertAdam
+    mopt = types.SimpleNamespace(double_branch=True, kl_intra_weight=0.1, inher_nce_weight=0.04, explore_nce_weight=0.04,
+                                 collection="charades", alpha=0.8, belta=0.8)
+    topt = types.SimpleNamespace(grad_clip=-1)
+
+    def cfg(drop):
+        return types.SimpleNamespace(visual_input_size=256, query_input_size=128, inheritance_hidden=384, exploration_hidden=384,
+                                     max_ctx_l=32, max_desc_l=30, input_drop=drop, drop=drop, n_heads=4, initializer_range=0.02,
+                                     margin=0.1, use_hard_negative=True, hard_pool_size=5, label_style="soft")
+
+    def batch(seed, counts):
+        b = synth.make_train_batch(seed, nv=len(counts), caps=sorted(counts, reverse=True), L=32, len_lo=3, dv=256, dq=128, lq_hi=24)
+        return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}
+
+    rs = np.random.RandomState(3)
+    ops.set_gemm_precision(prec)
+    try:
+        # (a)
+        torch.manual_seed(11)
+        m = DLDKD(cfg(0.0), mopt).to(DEV).train()
+        raw = batch(400, [3] * 6 + [2] * 10 + [1] * 8)              # 46 queries -> 64 rows
+        stepper = T.GraphedTrainStep(m, BertAdam([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=1e-3, warmup=0.1, t_total=40), topt)
+        pad = stepper._bucketed(raw)
+        assert pad["student_text"].shape[0] == 64 and len(pad["text_labels"]) == 46 and pad["teacher_text"].shape[0] == 64
+        assert float(pad["student_text_mask"][46:].sum()) == 18.0 and float(pad["student_text"][46:].abs().max()) == 0.0
+        res = []
+        for b in (raw, pad):
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(5)
+            loss, parts = m(b)
+            loss.backward()
+            res.append((float(loss), {k: float(v) for k, v in parts.items()}, [p.grad.clone() for p in m.parameters()]))
+        tol = 1e-5 if prec == "fp32" else 2e-3
+        assert res[0][0] == pytest.approx(res[1][0], rel=tol)
+        for k in res[0][1]:
+            assert res[0][1][k] == pytest.approx(res[1][1][k], rel=tol, abs=1e-7), k
+        for (n, _), a, b in zip(m.named_parameters(), res[0][2], res[1][2]):
+            assert (a - b).norm().item() <= (1e-4 if prec == "fp32" else 2e-2) * max(a.norm().item(), 1e-6) + 1e-7, n
+        # (b)
+        def make():
+            torch.manual_seed(12)
+            mm = DLDKD(cfg(0.2), mopt).to(DEV).train()
+            return mm, BertAdam([{"params": list(mm.parameters()), "weight_decay": 0.01}], lr=2e-3, warmup=0.1, t_total=40)
+        me, oe = make()
+        mg, og = make()
+        g = T.GraphedTrainStep(mg, og, topt)
+        counts = [[int(c) for c in rs.randint(1, 4, size=24)] for _ in range(10)]
+        nqs = [sum(c) for c in counts]
+        assert len(set(nqs)) >= 5 and len({-(-n // 32) * 32 for n in nqs}) == 1, nqs
+        for it, c in enumerate(counts):
+            b = batch(500 + it, c)
+            og.fp.flat.copy_(oe.fp.flat); og.m.copy_(oe.m); og.v.copy_(oe.v); og.step_count = oe.step_count
+            torch.manual_seed(700 + it)
+            le, _ = T.train_step(me, g._bucketed(b), oe, topt)      # (dropout masks are indexed by position in the padded tensors)
+            torch.manual_seed(700 + it)
+            lg, _ = g(b)
+            assert float(le) == pytest.approx(float(lg), rel=1e-5 if prec == "fp32" else 1e-3), it
+            d = (oe.fp.flat - og.fp.flat).abs().mean().item()
+            assert d <= 1e-7 + 0.02 * og.get_lr()[0], (it, d)
+        assert (g.captures, g.eager_steps, g.replays) == (1, 1, 9), (g.captures, g.eager_steps, g.replays)
+    finally:
+        ops.set_gemm_precision("fp32")
+
+
 def test_graphed_step_serves_variable_length_batches_from_a_few_graphs():
     """real loaders pad every batch to ITS longest caption / video, so raw shapes change from batch to
     batch.  The stepper buckets the word / clip axes (exact: no dropout here, every step is compared with the eager step on the
@@ -469,7 +546,8 @@ def test_data_parallel_stepper_runs_the_step_as_a_chain_of_graph_segments(drop, 
             torch.manual_seed(300 + it)
             ld, dd = ddp(batches[it % 3])
             torch.manual_seed(300 + it)
-            le, _ = T.train_step(me, batches[it % 3], oe, topt)
+            # (the stepper pads the 48 queries to its bucket of 64; the dropout masks are indexed by position in the padded tensors)
+            le, _ = T.train_step(me, plain._bucketed(batches[it % 3]), oe, topt)
             assert float(lp) == pytest.approx(float(ld), rel=1e-5), it
             assert float(lp) == pytest.approx(float(le), rel=1e-5), it
             tol = 2e-7 + 0.02 * od.get_lr()[0]
