@@ -235,6 +235,18 @@ def extras(dev):
                                                             "captures": r["captures"], "eager_steps": r["eager_steps"], "replays": r["replays"],
                                                             "prefetched": r["prefetched"], "fallbacks": r["fallbacks"]}
             del ds_loop
+            # ... and on a Charades-shaped set (C5's shapes; 1..6 captions per video: every batch has its own query count - the
+            # stepper pads the query axis to a bucket of 32 and the fused losses skip the padding rows, so a handful of captures serve
+            # every batch; unpadded, most steps of such a set ran eagerly or re-captured)
+            ds_loop = SynthTrainSet(2048, config="c5")
+            for prec in ("bf16", "mixed"):
+                r = prof_train_epoch.run(2048, prec, dev=str(dev), epochs=8, ds=ds_loop, config="c5")
+                w = sorted(r["ms_per_step_wall"])
+                out[f"c5_train_loop_ms_per_step_{prec}"] = {"median_epoch": w[len(w) // 2], "epochs": r["ms_per_step_wall"], "steps_per_epoch": r["steps_per_epoch"],
+                                                            "distinct_query_counts": len(r["queries_per_batch"] or []), "captures": r["captures"],
+                                                            "eager_steps": r["eager_steps"], "replays": r["replays"], "prefetched": r["prefetched"],
+                                                            "fallbacks": r["fallbacks"]}
+            del ds_loop
         except Exception as ex:   # noqa: BLE001 - an extra never takes the headline line down
             out["c3_train_loop_ms_per_step"] = {"error": repr(ex)[:300]}
         out["c3_train_step_config"] = "TVR: 128 videos / 640 queries, L<=128, label_style=soft, hard negatives, dropout 0.2, " \

@@ -366,7 +366,8 @@ class GraphedTrainStep:
         finally:
             self._lookahead = self._fetched = None
 
-    QUERY_BUCKET = 32      # the query axis is padded to a multiple of this (0: never) where the fused losses can skip the padding rows
+    # the query axis is padded to a multiple of this (0: never) where the fused losses can skip the padding rows
+    QUERY_BUCKET = int(os.environ.get("DLDKD_QUERY_BUCKET", "32"))
 
     def _bucket_queries(self, nq, on_gpu):
         """Batches of variable caption counts (data_provider.py:34-72: Charades ~2.3, ActivityNet ~3.7 captions per video) have a
