@@ -1089,18 +1089,55 @@ def make_train_loader(train_dataset, opt, rank=None, world=None):
         from torch.utils.data.distributed import DistributedSampler
         sampler = DistributedSampler(train_dataset, num_replicas=world, rank=rank, shuffle=True, seed=int(getattr(opt, "seed", 0) or 0),
                                      drop_last=False)
-    if getattr(opt, "device_resident_train", False) and torch.device(getattr(opt, "device", "cpu")).type == "cuda":
+    # opt.device_resident_train: True / False / "auto" (the default): on a GPU, when the dataset hands out the same item every time
+    # it is asked (the reference's Dataset4DLDKD does: features read and down-sampled deterministically, data_provider.py:34-72) and
+    # the whole set fits opt.train_feature_cache_gb (160; TVR: 27 GB)
+    mode = getattr(opt, "device_resident_train", "auto")
+    if mode in (True, "auto") and torch.device(getattr(opt, "device", "cpu")).type == "cuda" and len(train_dataset) > 0:
         # the training set read once into ragged tables on the device, batches gathered there (data.DeviceTrainSet): same
         # batches in the same order with the same random draws, no per-epoch DataLoader / pad / H2D
         from .data import DeviceTrainLoader, DeviceTrainSet
-        if sampler is not None:
-            sampler = DistributedSampler(range(len(train_dataset)), num_replicas=world, rank=rank, shuffle=True,
-                                         seed=int(getattr(opt, "seed", 0) or 0), drop_last=False)
-        devset = DeviceTrainSet(train_dataset, opt.device, num_workers=opt.num_workers,
-                                cap_gb=float(getattr(opt, "train_feature_cache_gb", 160.0)))
-        return DeviceTrainLoader(devset, opt.bsz, shuffle=True, sampler=sampler)
+        devset = None
+        if mode == "auto" and not _items_repeat(train_dataset):
+            logger.info("training set: items differ between two reads (augmentation?): the host DataLoader stays in charge")
+        else:
+            try:
+                devset = DeviceTrainSet(train_dataset, opt.device, num_workers=opt.num_workers,
+                                        cap_gb=float(getattr(opt, "train_feature_cache_gb", 160.0)))
+            except (MemoryError, ValueError, TypeError, IndexError) as ex:
+                if mode is True:
+                    raise
+                logger.info(f"training set not kept on the device ({type(ex).__name__}: {ex}): the host DataLoader stays in charge")
+        if devset is not None:
+            if sampler is not None:
+                sampler = DistributedSampler(range(len(train_dataset)), num_replicas=world, rank=rank, shuffle=True,
+                                             seed=int(getattr(opt, "seed", 0) or 0), drop_last=False)
+            logger.info(f"training set device-resident: {devset.n_videos} videos, {devset.n_caps} captions, "
+                        f"{sum(t.numel() for t in devset.src.values()) * 4 / 1e9:.2f} GB")
+            return DeviceTrainLoader(devset, opt.bsz, shuffle=True, sampler=sampler)
     return DataLoader(train_dataset, batch_size=opt.bsz, shuffle=sampler is None, sampler=sampler, pin_memory=opt.pin_memory,
                       num_workers=opt.num_workers, collate_fn=collate_train)
+
+
+def _items_repeat(dataset):
+    """Two reads of the first and the last item give the same tensors (a dataset without random augmentation); the global RNG is
+    left where it was."""
+    import numpy as np
+    rng = torch.get_rng_state()
+    np_state = np.random.get_state()
+    try:
+        for i in sorted({0, len(dataset) - 1}):
+            a, b = dataset[i], dataset[i]
+            for x, y in zip(a[:4], b[:4]):
+                xs, ys = (x, y) if isinstance(x, (list, tuple)) else ([x], [y])
+                if len(xs) != len(ys) or any(not np.array_equal(np.asarray(u), np.asarray(v)) for u, v in zip(xs, ys)):
+                    return False
+        return True
+    except Exception:   # noqa: BLE001 - a dataset this probe cannot read twice stays with the host loader
+        return False
+    finally:
+        torch.set_rng_state(rng)
+        np.random.set_state(np_state)
 
 
 def seed_rank(opt, rank):

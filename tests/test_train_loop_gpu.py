@@ -667,6 +667,35 @@ def test_device_resident_train_set_yields_the_collated_batches():
         devset.gather(plans[0], out={"student_videos": torch.empty(3, 3, 256, device=DEV)})
 
 
+def test_training_set_goes_device_resident_by_itself_when_its_items_repeat():
+    """make_train_loader, opt.device_resident_train unset ("auto"): a dataset that hands out the same item on every read (the
+    reference's Dataset4DLDKD) is kept on the device; one whose items change between reads (augmentation) or that does not fit the
+    cap stays with the host DataLoader; the probe leaves the global generators where they were; False / True are obeyed."""
+    from torch.utils.data import DataLoader
+    from dldkd_amd import train as T
+    from dldkd_amd.data import DeviceTrainLoader
+    ds = TinySet(n=16)
+
+    class Noisy(TinySet):
+        def __getitem__(self, i):
+            it = list(self.items[i])
+            it[0] = it[0] + 0.01 * torch.randn_like(it[0])
+            return tuple(it)
+
+    def opt(**kw):
+        return types.SimpleNamespace(device=torch.device(DEV), bsz=8, pin_memory=False, num_workers=0, **kw)
+    torch.manual_seed(3)
+    before = torch.get_rng_state()
+    assert isinstance(T.make_train_loader(ds, opt(), 0, 1), DeviceTrainLoader)
+    assert isinstance(T.make_train_loader(Noisy(n=16), opt(), 0, 1), DataLoader)
+    assert torch.equal(before, torch.get_rng_state())
+    assert isinstance(T.make_train_loader(ds, opt(device_resident_train=False), 0, 1), DataLoader)
+    assert isinstance(T.make_train_loader(ds, opt(train_feature_cache_gb=1e-6), 0, 1), DataLoader)
+    with pytest.raises(MemoryError):
+        T.make_train_loader(ds, opt(device_resident_train=True, train_feature_cache_gb=1e-6), 0, 1)
+    assert isinstance(T.make_train_loader(ds, types.SimpleNamespace(device="cpu", bsz=8, pin_memory=False, num_workers=0), 0, 1), DataLoader)
+
+
 def test_train_with_the_device_resident_set_follows_the_host_loader_run(tmp_path):
     """train() with opt.device_resident_train: the same history (losses, SumR) as with the DataLoader + collate + H2D path."""
     from dldkd_amd.model import DLDKD
