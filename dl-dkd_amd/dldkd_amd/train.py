@@ -236,6 +236,7 @@ class GraphedTrainStep:
         self.stage_stream = None
         self._turn, self._pending, self._lookahead, self._fetched = {}, None, None, None
         self.prefetched = 0                  # steps whose inputs were in place when the step began
+        self.vary_queries, self._nq_seen = False, set()      # see _bucket_queries
         # Self-check of every newly captured graph (opt.graph_self_check, default on): the capture step runs the batch TWICE from the
         # same optimizer / RNG state - eagerly and as the first replay - and keeps the graph only if loss and parameters agree.  The
         # multi-graph stepper leans on hipGraph behaviour that has changed between ROCm point releases (a MEMSET node that left stale
@@ -371,9 +372,16 @@ class GraphedTrainStep:
 
     def _bucket_queries(self, nq, on_gpu):
         """Batches of variable caption counts (data_provider.py:34-72: Charades ~2.3, ActivityNet ~3.7 captions per video) have a
-        different number of queries each; padded to a bucket, a handful of captures serve them all (instead of eager steps)."""
+        different number of queries each; padded to a bucket, a handful of captures serve them all (instead of eager steps).
+        Padding starts with the SECOND distinct query count this stepper sees (vary_queries, sticky): a run whose batches all hold
+        the same number of queries (TVR: 5 per video) never pays for padding rows (C5's 257-query bench batch: +7 % at 288 rows)."""
         b = int(self.QUERY_BUCKET)
-        return -(-nq // b) * b if (b > 0 and self._schedule_on_device(on_gpu)) else nq
+        if b <= 0 or not self._schedule_on_device(on_gpu):
+            return nq
+        if not self.vary_queries:
+            self._nq_seen.add(int(nq))
+            self.vary_queries = len(self._nq_seen) > 1
+        return -(-nq // b) * b if self.vary_queries else nq
 
     def _bucket_lens(self, lq, lv):
         cfg = self.model.config
