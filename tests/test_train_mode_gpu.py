@@ -274,6 +274,43 @@ def test_train_step_at_full_size_train_mode_vs_oracle(monkeypatch, name, prec):
         _assert_grads(stats, GRAD_TOL_BF16, f"{name} bf16 ({skipped}/{groups} groups skipped)", cos_min=0.97)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "mixed"])
+def test_padded_query_axis_at_c5_size_vs_oracle(prec):
+    """BASELINE configs[4] (one rank's Charades step: 257 queries) with the query axis padded to the stepper's bucket (288 rows: what
+    train.GraphedTrainStep feeds the model once a run's caption counts vary) against the ORACLE on the raw batch: the 7 losses within
+    north_star's 1e-4 and all 74 gradients at the mode's tolerance - the padding queries change nothing the reference computes."""
+    from dldkd_amd import ops
+    from dldkd_amd import train as T
+    from dldkd_amd.optimization import BertAdam
+    params, batch, hard, dv, dq, nv = _size_case("c5")
+    ref_losses, ref_grads, _ = _oracle_trajectory("c5")
+    ref = ref_losses[0]
+    m = _train_model(dv, dq, params, hard)
+    m.weight = 1.0
+    dbatch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    stepper = T.GraphedTrainStep(m, BertAdam([{"params": list(m.parameters()), "weight_decay": 0.01}], lr=1e-3, warmup=0.1, t_total=40),
+                                 types.SimpleNamespace(grad_clip=-1))
+    stepper.vary_queries = True
+    padded = stepper._bucketed(dbatch)
+    assert padded["student_text"].shape[0] == 288 and len(padded["text_labels"]) == 257
+    ops.set_gemm_precision(prec)
+    try:
+        torch.manual_seed(SEED0)
+        loss, d = m(padded)
+        m.zero_grad()
+        loss.backward()
+    finally:
+        ops.set_gemm_precision("fp32")
+    worst = 0.0
+    for k in LOSS_KEYS + ("loss",):
+        got = float(loss if k == "loss" else d[k])
+        worst = max(worst, abs(got - ref[k]) / max(abs(ref[k]), 1e-3))
+    print(f"  c5 padded {prec}: worst loss error {worst:.3e} (relative)")
+    assert worst <= (1e-4 if prec == "fp32" else 3e-5), worst
+    stats = _grad_stats(m, ref_grads)
+    _assert_grads(stats, 1e-3 if prec == "fp32" else GRAD_TOL_MIXED, f"c5 padded {prec}", cos_min=None if prec == "fp32" else 0.97)
+
+
 # --------------------------------------------------------------------------- the replayed multi-graph step + fused BertAdam
 @pytest.mark.parametrize("name,prec", [("c5", "fp32"), ("c5", "bf16"), ("c3", "fp32"), ("c3", "bf16"), ("c5", "mixed"), ("c3", "mixed")])
 def test_replayed_multi_graph_step_and_bert_adam_vs_oracle(name, prec):
