@@ -183,6 +183,7 @@ def _cached_batches(dataset, kind, n_items, opt, make_loader, to_device):
 # the k-loop, no per-batch tail) + the fused tower kernel over the whole gallery: two launches per chunk of RESIDENT_CHUNK_ROWS
 # clips, no DataLoader, no H2D, no host-side padding or concatenation of batches, tables planned once.
 RESIDENT_FEATURES = True          # throughput-mode eval_epoch keeps the gallery's raw features as ops.ResidentRows
+RESIDENT_RAGGED_INGEST = True       # first pass: items -> pinned staging ring -> table rows (no padded host batches)
 RESIDENT_STREAM_ROWS = 1 << 17      # clips staged per encode when the table is not kept (256 CUs x 4 tiles of 128 rows)
 RESIDENT_CHUNK_ROWS = 1 << 21       # clips per chunk: the projection's fp32 output of a chunk is 2 x 3.2 GB
 
@@ -208,6 +209,10 @@ class ResidentGallery:
             self.chunks.append((va, vb - va, int(start[va]), int(start[vb]), meta_d[:vb - va], meta_d[vb - va:], items))
             va = vb
         self.lens_dev = torch.from_numpy(lens.astype(np.int32)).to(device)
+
+
+def _items_as_they_are(items):
+    return items
 
 
 def _resident_context_info(model, eval_dataset, opt, loader, owner, kind):
@@ -279,18 +284,65 @@ def _resident_context_info(model, eval_dataset, opt, loader, owner, kind):
             lens_parts.append(res.lens_dev)
 
         with host_threads():
-            for batch in loader:
-                feat = batch[0].to(dev, non_blocking=True)
-                lens_h = (batch[1] > 0).sum(1).numpy()
-                if feat.shape[-1] != res.table.K or int(lens_h.max(initial=0)) > L:
-                    raise native.NativeError("eval: a gallery batch does not match the model's feature width / max_ctx_l")
-                res.table.append(feat.float(), lens_h)
-                metas.extend(batch[-1])
-                if keep and other + res.table.nbytes() > cap:
-                    keep = False
-                if not keep and res.table.rows >= RESIDENT_STREAM_ROWS:
-                    encode_table()
-                    res.table.clear()
+            if RESIDENT_RAGGED_INGEST:
+                # The items as the dataset hands them out (an identity collate in the same DataLoader: same order, same workers,
+                # same single draw from the global generator), each clip row copied ONCE into a pinned staging ring and uploaded
+                # from there into the table (ResidentRows.append_rows) - no padded host batch is ever built: building and
+                # freeing 315-MB pageable batches (pad_sequence, page faults, munmap) was 2/3 of the first pass from host memory
+                from torch.utils.data import DataLoader
+                from .data import _PinnedAppender
+                chunks, pending = [], []
+                fill = [0, 0]                               # rows handed to the table / rows of the items registered with it
+
+                def drain(final=False):
+                    """uploaded row chunks -> the table; the lengths of the items a chunk completes go with it"""
+                    for c in chunks:
+                        fill[0] += int(c.shape[0])
+                        k, tot = 0, fill[1]
+                        while k < len(pending) and tot + pending[k] <= fill[0]:
+                            tot += pending[k]
+                            k += 1
+                        res.table.append_rows(c, pending[:k])
+                        fill[1] = tot
+                        del pending[:k]
+                    chunks.clear()
+                    if final and pending:
+                        raise native.NativeError("eval: resident ingest lost rows")
+                app = _PinnedAppender(dev, chunks)
+                raw = DataLoader(loader.dataset, batch_size=loader.batch_size, shuffle=False, num_workers=loader.num_workers,
+                                 collate_fn=_items_as_they_are)
+                for items in raw:
+                    for feat, _idx, vid in items:
+                        feat = torch.as_tensor(feat)
+                        if feat.dim() != 2 or feat.shape[1] != res.table.K or feat.shape[0] > L:
+                            raise native.NativeError("eval: a gallery item does not match the model's feature width / max_ctx_l")
+                        app.add(feat)
+                        pending.append(int(feat.shape[0]))
+                        metas.append(vid)
+                    drain()
+                    if keep and other + res.table.nbytes() + app.rows * res.table.K * 4 > cap:
+                        keep = False
+                    if not keep and res.table.rows + app.rows >= RESIDENT_STREAM_ROWS:
+                        app.flush()                        # whole items only in the table before it is encoded and emptied
+                        drain()
+                        encode_table()
+                        res.table.clear()
+                        fill[0] = fill[1] = 0
+                app.flush(final=True)
+                drain(final=True)
+            else:
+                for batch in loader:
+                    feat = batch[0].to(dev, non_blocking=True)
+                    lens_h = (batch[1] > 0).sum(1).numpy()
+                    if feat.shape[-1] != res.table.K or int(lens_h.max(initial=0)) > L:
+                        raise native.NativeError("eval: a gallery batch does not match the model's feature width / max_ctx_l")
+                    res.table.append(feat.float(), lens_h)
+                    metas.extend(batch[-1])
+                    if keep and other + res.table.nbytes() > cap:
+                        keep = False
+                    if not keep and res.table.rows >= RESIDENT_STREAM_ROWS:
+                        encode_table()
+                        res.table.clear()
         if keep:
             res.metas, res.complete = metas, True
             slot[key] = res

@@ -577,6 +577,25 @@ class ResidentRows:
         self.lens.extend(int(v) for v in lens_host)
         self.rows += add
 
+    def append_rows(self, rows, item_lens=()):
+        """rows (R, K) fp32 GPU: R more rows join the table as they lie (ragged: no padding ever existed); item_lens: the lengths of
+        the items those rows COMPLETE, in order (an item's rows may arrive in two calls).  Same kernel as append (one "item" of R rows)."""
+        import numpy as np
+        R, K = rows.shape
+        if K != self.K:
+            raise native.NativeError("ResidentRows.append_rows: rows do not match the table")
+        if R:
+            if self.rows + R > self.cap - 128:
+                self._alloc(max(2 * self.cap, self.rows + R))
+            meta = torch.from_numpy(np.asarray([self.rows, R], dtype=np.int64)).to(self.device)
+            lens_d = meta[1:].to(torch.int32)
+            x = _chk(rows, "ResidentRows.append_rows")
+            native.check(native.lib().dldkd_rows_to_h16_stats(native.ptr(x), native.ptr(lens_d), native.ptr(meta), 1, R, K, LN_EPS,
+                                                               native.ptr(self.xb), native.ptr(self.mean), native.ptr(self.rstd),
+                                                               native.stream()), "rows_to_h16_stats")
+            self.rows += R
+        self.lens.extend(int(v) for v in item_lens)
+
     def clear(self):
         self.rows, self.lens = 0, []
 

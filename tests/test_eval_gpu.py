@@ -424,3 +424,52 @@ def test_reused_gallery_buffers_equal_a_fresh_encode():
         assert np.array_equal(got[1], want[1])
     assert any(not torch.equal(x, y) for x, y in zip(fresh[0][0], fresh[1][0]))
     ev.clear_feature_cache()
+
+
+def test_ragged_first_pass_ingest_builds_the_same_table(monkeypatch):
+    """The first pass over a gallery whose features start in host memory: items -> pinned staging ring -> table rows
+    (eval.RESIDENT_RAGGED_INGEST, ops.ResidentRows.append_rows: no padded host batch) against the padded-batch form (collate_frame_val
+    -> .to(device) -> ResidentRows.append): the same fp16 rows, statistics, lengths and ids bit for bit - with a staging ring smaller
+    than a video (rows of one item arrive in several uploads) and with the streaming form (table emptied every few clips)."""
+    from dldkd_amd import eval as ev, data
+    m = _model(3072, 768, synth.make_params(63, 3072, 768))
+    vids, _ = synth.make_eval_sets(17, nv=57, caps=1, dv=3072, dq=768)
+    dv = synth.ListDataset(list(vids))
+    opt = _opt()
+    opt.eval_precision = "throughput"
+    real = data._PinnedAppender
+
+    def build(ragged, ring_bytes=None):
+        ev.clear_feature_cache()
+        monkeypatch.setattr(ev, "RESIDENT_RAGGED_INGEST", ragged)
+        if ring_bytes:
+            monkeypatch.setattr(data, "_PinnedAppender", lambda dev, chunks: real(dev, chunks, ring_bytes=ring_bytes))
+        with torch.no_grad(), ev.eval_precision(m, opt):
+            info = ev.compute_context_info(m, dv, opt, keep_frame_feats=False)
+        monkeypatch.undo()
+        res = next(iter(ev._FEATURE_CACHE[dv].values()))
+        t = res.table
+        return (t.xb[:t.rows].clone(), t.mean[:t.rows].clone(), t.rstd[:t.rows].clone(), list(t.lens), list(res.metas),
+                [b.clone() for b in info["_packed"].blobs])
+
+    ref = build(False)
+    for ring in (None, 5 * 3072 * 4):                       # the default 64-MiB ring / a ring of five clip rows
+        got = build(True, ring)
+        assert got[3] == ref[3] and got[4] == ref[4] and sum(got[3]) == got[0].shape[0]
+        assert all(torch.equal(a, b) for a, b in zip(got[:3], ref[:3]))
+        assert all(torch.equal(a, b) for a, b in zip(got[5], ref[5]))
+    # streaming (no cache): the table is a staging buffer encoded and emptied every 150 clips, at the same loader-batch boundaries in
+    # both forms - the packed gallery comes out the same
+    off = types.SimpleNamespace(**vars(opt), eval_feature_cache=False)
+    streamed = []
+    for ragged in (False, True):
+        ev.clear_feature_cache()
+        monkeypatch.setattr(ev, "RESIDENT_RAGGED_INGEST", ragged)
+        monkeypatch.setattr(ev, "RESIDENT_STREAM_ROWS", 150)
+        with torch.no_grad(), ev.eval_precision(m, off):
+            info = ev.compute_context_info(m, dv, off, keep_frame_feats=False)
+        monkeypatch.undo()
+        streamed.append(([b.clone() for b in info["_packed"].blobs], info["_packed"].lens.clone(), list(info["video_metas"])))
+    assert all(torch.equal(a, b) for a, b in zip(streamed[0][0], streamed[1][0]))
+    assert torch.equal(streamed[0][1], streamed[1][1]) and streamed[0][2] == streamed[1][2] == ref[4]
+    ev.clear_feature_cache()
