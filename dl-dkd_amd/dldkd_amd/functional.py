@@ -1419,21 +1419,47 @@ class ScheduleWords:
     every epoch (by value the scalars were part of the graph's key: a capture per epoch, and none after max_captures).
     update() enqueues a few fills on the current stream when - and only when - the values changed."""
 
-    def __init__(self, nq, nv, soft, device):
+    def __init__(self, nq, nv, soft, device, store=None):
+        """store: an int32 device tensor of nq + nv + 10 words to live in - [cq | cv | 2 x 5 words] (train.GraphedTrainStep: a
+        range of the step's staged words, written on the host with write() and uploaded with them); None: own tensors, rewritten
+        on the device by update()."""
         self.nq, self.nv, self.soft, self.device = int(nq), int(nv), bool(soft), torch.device(device)
-        self.cq = torch.zeros(self.nq, dtype=torch.float32, device=self.device)
-        self.cv = torch.zeros(self.nv, dtype=torch.float32, device=self.device)
-        self.words = {}                   # w_kl factor (host float, e.g. kl_intra_weight or 0.0) -> (4,) int32 device words
+        self.store = store
+        if store is None:
+            self.cq = torch.zeros(self.nq, dtype=torch.float32, device=self.device)
+            self.cv = torch.zeros(self.nv, dtype=torch.float32, device=self.device)
+        else:
+            if store.dtype != torch.int32 or store.numel() != self.words_needed(nq, nv):
+                raise ValueError("ScheduleWords: store must be int32 of nq + nv + 10 words")
+            self.cq, self.cv = self.split(store, self.nq, self.nv)[:2]
+        self.words = {}                   # w_kl factor (host float, e.g. kl_intra_weight or 0.0) -> (5,) int32 device words
         self.state = None
         self.used = 0                     # branch_losses calls that took their scalars from here
+
+    MAX_FACTORS = 2
+
+    @classmethod
+    def words_needed(cls, nq, nv):
+        return int(nq) + int(nv) + 5 * cls.MAX_FACTORS
+
+    @classmethod
+    def split(cls, t, nq, nv):
+        """(cq, cv, [5-word slices]) views of an int32 tensor laid out like `store` (device words or their pinned host slot)."""
+        w = t[nq + nv:]
+        return t[:nq].view(torch.float32), t[nq:nq + nv].view(torch.float32), [w[5 * i:5 * i + 5] for i in range(cls.MAX_FACTORS)]
 
     def words_for(self, factor):
         """The device words of a branch whose KL weight is `factor` x the epoch's KD weight (made while the step is captured)."""
         f = float(factor)
         if f not in self.words:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("ScheduleWords: a branch's words must exist before the capture (prepare())")
-            self.words[f] = torch.zeros(5, dtype=torch.int32, device=self.device)
+            if self.store is not None:
+                if len(self.words) >= self.MAX_FACTORS:
+                    raise RuntimeError("ScheduleWords: more KL factors than word slots")
+                self.words[f] = self.split(self.store, self.nq, self.nv)[2][len(self.words)]
+            else:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("ScheduleWords: a branch's words must exist before the capture (prepare())")
+                self.words[f] = torch.zeros(5, dtype=torch.int32, device=self.device)
             self.state = None
         return self.words[f]
 
@@ -1456,19 +1482,30 @@ class ScheduleWords:
         state = (float(alpha), float(beta), float(weight), nqv, tuple(self.words))
         if state == self.state:
             return False
+        self._fill(self.cq, self.cv, [self.words[f] for f in self.words], alpha, beta, weight, nqv)
+        self.state = state
+        return True
+
+    def write(self, host_words, alpha, beta, weight, nq_valid=None):
+        """The same values into a HOST tensor laid out like `store` (the step's pinned staging slot): uploaded with the slot."""
+        nqv = self.nq if nq_valid is None else int(nq_valid)
+        if not 0 < nqv <= self.nq:
+            raise ValueError(f"ScheduleWords: {nqv} valid queries of {self.nq}")
+        cq, cv, w = self.split(host_words, self.nq, self.nv)
+        self._fill(cq, cv, w[:len(self.words)], alpha, beta, weight, nqv)
+
+    def _fill(self, cq, cv, words, alpha, beta, weight, nqv):
         hq, hv, (qh, qs), (vh, vs) = self.coefs(nqv, self.nv, float(alpha), self.soft)
-        for c, h, wh, ws in ((self.cq, hq, qh, qs), (self.cv, hv, vh, vs)):
+        for c, h, wh, ws in ((cq, hq, qh, qs), (cv, hv, vh, vs)):
             c.fill_(float(ws))
             if self.soft and h > 0:
                 c[:h].fill_(float(wh))
         b = float(beta) if self.soft else 0.0
-        for f, w in self.words.items():
+        for f, w in zip(self.words, words):
             w[0:1].fill_(int(hq)); w[1:2].fill_(int(hv))
             w.view(torch.float32)[2:3].fill_(b)
             w.view(torch.float32)[3:4].fill_(float(f * float(weight)))
             w[4:5].fill_(nqv)
-        self.state = state
-        return True
 
 
 _SCHED = None

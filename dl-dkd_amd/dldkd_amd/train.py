@@ -625,14 +625,18 @@ class GraphedTrainStep:
             return loss, d
         return self._eager(batch)
 
-    # -- staging layout (int32 words): [philox 4][lr n_t][labels nq][per triplet call: r_t2v nq, r_v2t nv]
-    def _layout(self, e, nq, nv, n_calls):
+    # -- staging layout (int32 words): [philox 4][lr n_t][labels nq][per triplet call: r_t2v nq, r_v2t nv][schedule words: cq nq, cv nv, 10]
+    def _layout(self, e, nq, nv, n_calls, sched=False):
+        from . import functional as F_
         n_t = len(self.optimizer.fp.params)
         e.off = {"philox": 0, "lr": 4, "labels": 4 + n_t}
         o = 4 + n_t + nq
         for c in range(n_calls):
             e.off[("t2v", c)], e.off[("v2t", c)] = o, o + nq
             o += nq + nv
+        if sched:
+            e.off["sched"] = o
+            o += F_.ScheduleWords.words_needed(nq, nv)
         e.words = o
 
     def _capture(self, batch, key):
@@ -649,7 +653,7 @@ class GraphedTrainStep:
         nq, nv = int(batch["student_text"].shape[0]), batch["student_videos"].shape[0]      # (nq: text rows, >= len(labels) when padded)
         e.hard = bool(key[5])
         e.n_calls = 2 if m.double_branch else 1
-        self._layout(e, nq, nv, e.n_calls)
+        self._layout(e, nq, nv, e.n_calls, sched=key[2] is None)
         e.ring = PinnedRing(4 * e.words, dev)
         e.dev_words = torch.zeros(e.words, dtype=torch.int32, device=dev)
         view = lambda name, n: e.dev_words[e.off[name]:e.off[name] + n]     # noqa: E731
@@ -663,10 +667,12 @@ class GraphedTrainStep:
         e.ev_done, e.ev_staged, e.staged_once = torch.cuda.Event(), torch.cuda.Event(), False
         e.sched = None
         if key[2] is None:
-            e.sched = F_.ScheduleWords(nq, nv, m.label_style == "soft", dev)
+            # the schedule's scalars live in the step's staged words: written on the host into the pinned slot, uploaded with it
+            n_s = F_.ScheduleWords.words_needed(nq, nv)
+            e.sched = F_.ScheduleWords(nq, nv, m.label_style == "soft", dev, store=e.dev_words[e.off["sched"]:e.off["sched"] + n_s])
             for f in (m.kl_intra_weight, 0.0):              # the two branches' KL factors (model.py:143-155)
                 e.sched.words_for(f)
-            e.sched.update(m.alpha, m.belta, m.weight, len(labels))
+            e.sched_in_slot = {}                            # ring slot -> the values it holds
         elif len(labels) != nq:
             raise RuntimeError("GraphedTrainStep: a padded query axis without the schedule words")
         old_lr = opt_.t_lr
@@ -1013,15 +1019,21 @@ class GraphedTrainStep:
                     e.static[k].copy_(batch[k], non_blocking=True)
 
         n_t = len(batch["text_labels"])                   # the batch's real queries (<= e.nq text rows)
-        if e.sched is not None:
-            e.sched.update(m.alpha, m.belta, m.weight, n_t)      # a few fills, when the epoch's schedule or the query count moved
-        elif n_t != e.nq:
+        if e.sched is None and n_t != e.nq:
             raise RuntimeError(f"GraphedTrainStep: {n_t} labels for a step captured with {e.nq} queries")
         # the video features first - the largest copy (201 MB at the TVR batch: 72 us) feeding the longest chains; the video towers
         # start behind it and the step's scalars (ev_in_video below) while the other inputs are still being copied
         stage(self.TENSOR_KEYS[:2])
         slot = e.ring.next()[:4 * e.words].view(torch.int32)
         e.philox.begin_step(slot[0:4].view(torch.int64))
+        if e.sched is not None:
+            # the epoch's alpha / belta / KD weight and the batch's query count -> this slot's schedule words (host writes; a slot
+            # that already holds these values - every step of an epoch on a fixed-count dataset - is left alone)
+            st = (float(m.alpha), float(m.belta), float(m.weight), n_t)
+            if e.sched_in_slot.get(e.ring.i) != st:
+                n_s = e.sched.words_needed(e.nq, e.nv)
+                e.sched.write(slot[e.off["sched"]:e.off["sched"] + n_s], *st)
+                e.sched_in_slot[e.ring.i] = st
         par = getattr(e, "par", None)
         if par:
             # ... and the dropout state (the slot's first 16 bytes) - all a tower's forward pass reads of the step's scalars - goes up
