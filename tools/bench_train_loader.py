@@ -14,18 +14,24 @@ import torch
 class SynthTrainSet(torch.utils.data.Dataset):
     """config "c3": TVR shapes (24..128 clips x 3072, 5 captions of 5..30 words x 768 per video); "c5": Charades shapes (8..64 clips x
     1024, 1..6 captions per video - mean 2.3, as Charades-STA's 12,408 / 5,338 - of 4..12 words x 1024): every batch of 128 videos
-    then has its own number of queries."""
+    then has its own number of queries; "anet": ActivityNet shapes (16..128 clips x 1024, 1..10 captions per video, mean 3.7)."""
 
     def __init__(self, n, seed=0, config="c3"):
         rs = np.random.RandomState(seed)
         self.items = []
-        dv, dq, l_lo, l_hi, w_lo, w_hi = (3072, 768, 24, 128, 5, 30) if config == "c3" else (1024, 1024, 8, 64, 4, 12)
+        dv, dq, l_lo, l_hi, w_lo, w_hi = {"c3": (3072, 768, 24, 128, 5, 30), "c5": (1024, 1024, 8, 64, 4, 12),
+                                          "anet": (1024, 1024, 16, 128, 5, 30)}[config]
         for i in range(n):
             L = int(rs.randint(l_lo, l_hi + 1))
             v = rs.standard_normal((L, dv)).astype(np.float32)
             v /= np.linalg.norm(v, axis=1, keepdims=True)
             tv = rs.standard_normal((L, 512)).astype(np.float32)
-            nc = 5 if config == "c3" else int(rs.choice([1, 2, 3, 4, 5, 6], p=[0.30, 0.35, 0.20, 0.08, 0.05, 0.02]))
+            if config == "c3":
+                nc = 5
+            elif config == "c5":
+                nc = int(rs.choice([1, 2, 3, 4, 5, 6], p=[0.30, 0.35, 0.20, 0.08, 0.05, 0.02]))
+            else:       # ActivityNet Captions: 37,421 / 10,009 = 3.7 per video, 1..10
+                nc = int(rs.choice(np.arange(1, 11), p=[0.05, 0.17, 0.27, 0.22, 0.13, 0.07, 0.04, 0.03, 0.01, 0.01]))
             caps = [rs.standard_normal((int(rs.randint(w_lo, w_hi + 1)), dq)).astype(np.float32) for _ in range(nc)]
             tcaps = [rs.standard_normal((1, 512)).astype(np.float32) for _ in range(nc)]
             self.items.append((v, caps, tv, tcaps, i, [f"v{i}#{c}" for c in range(nc)], f"v{i}"))

@@ -14,7 +14,7 @@ def run(n_videos=4096, prec="bf16", profile=False, dev="cuda:0", epochs=3, prefe
     from bench_train_loader import SynthTrainSet
     from dldkd_amd import ops, train as T
     from dldkd_amd.model import DLDKD
-    dv, dq, lmax, drop = (3072, 768, 128, 0.2) if config == "c3" else (1024, 1024, 64, 0.15)
+    dv, dq, lmax, drop = {"c3": (3072, 768, 128, 0.2), "c5": (1024, 1024, 64, 0.15), "anet": (1024, 1024, 128, 0.2)}[config]
     cfg = types.SimpleNamespace(visual_input_size=dv, query_input_size=dq, inheritance_hidden=384, exploration_hidden=384,
                                 max_ctx_l=lmax, max_desc_l=30, input_drop=drop, drop=drop, n_heads=4, initializer_range=0.02,
                                 margin=0.1, use_hard_negative=True, hard_pool_size=20, label_style="soft")
