@@ -84,6 +84,33 @@ def collate_train(data):
 # PCIe, after a host-side pad of 128 ragged videos), although the items never change.  Here every item is read ONCE into ragged
 # row tables on the device (TVR: 17,435 videos x <= 128 clips x 3072 fp32 = 27 GB of 288), and a batch is a gather from those
 # tables by a kernel: the tensors collate_train + .to(device) would have produced, bit for bit, in the same order.
+def _identity(x):
+    return x
+
+
+def _collate_train_tables(items):
+    """DeviceTrainSet's reading pass in a WORKER process: the batch as {table: (rows (sum len, D) fp32, [len, ...])} + the items'
+    caption counts - the concatenation runs in the worker, five tensors cross the process boundary."""
+    out, caps_n = {}, []
+    seqs = {k: [] for k in DeviceTrainSet.TABLES}
+    for it in items:
+        s_vid, caps, t_vid, t_caps = it[0], it[1], it[2], it[3]
+        if len(caps) != len(t_caps):
+            raise ValueError("DeviceTrainSet: an item's caption and teacher-caption lists differ in length")
+        seqs["student_videos"].append(s_vid)
+        seqs["teacher_videos"].append(t_vid)
+        seqs["student_text"].extend(caps)
+        seqs["teacher_text"].extend(t_caps)
+        caps_n.append(len(caps))
+    for k, v in seqs.items():
+        v = [torch.as_tensor(a, dtype=torch.float32) for a in v]
+        if any(a.dim() != 2 for a in v):
+            raise ValueError(f"DeviceTrainSet: {k} sequences must be (length, features)")
+        out[k] = (torch.cat(v, 0) if v else torch.zeros(0, 0), [int(a.shape[0]) for a in v])
+    out["caps"] = caps_n
+    return out
+
+
 class _PinnedAppender:
     """Rows of (length, D) float32 sequences appended into a ring of two pinned buffers; a full buffer is uploaded asynchronously
     into a device tensor of exactly its rows (appended to `chunks`) while the other one fills."""
@@ -148,7 +175,10 @@ class DeviceTrainSet:
         rows = {k: [] for k in self.TABLES}
         lens = {k: [] for k in self.TABLES}
         self.caps_of = []                       # per video: (first caption, number of captions)
-        loader = DataLoader(dataset, batch_size=64, shuffle=False, num_workers=num_workers, collate_fn=lambda x: x)
+        # (with workers: every table's rows concatenated BY the worker - a handful of tensors per batch through shared memory, not
+        # the ~800 an identity collate would pass)
+        loader = DataLoader(dataset, batch_size=64, shuffle=False, num_workers=num_workers,
+                            collate_fn=_collate_train_tables if num_workers else _identity)
         rng = torch.get_rng_state()             # the reading pass must not move the run's random stream (a DataLoader iterator
         try:                                    # draws its base seed from the global generator)
             chunks = list(self._read(loader, rows, lens, cap_gb))
@@ -164,6 +194,17 @@ class DeviceTrainSet:
         n_caps, nbytes = 0, 0
         app = {k: _PinnedAppender(self.device, rows[k]) for k in self.TABLES}
         for chunk in loader:                    # 64 items at a time
+            if isinstance(chunk, dict):             # a worker's batch: per table (rows, lens) + the items' caption counts
+                for k in self.TABLES:
+                    rows_k, lens_k = chunk[k]
+                    if lens_k:
+                        app[k].add(rows_k)
+                    lens[k].extend(lens_k)
+                    nbytes += rows_k.numel() * 4
+                for c in chunk["caps"]:
+                    self.caps_of.append((n_caps, c))
+                    n_caps += c
+                chunk = ()
             for item in chunk:
                 s_vid, caps, t_vid, t_caps = item[0], item[1], item[2], item[3]
                 for k, seqs in (("student_videos", [s_vid]), ("teacher_videos", [t_vid]), ("student_text", caps), ("teacher_text", t_caps)):

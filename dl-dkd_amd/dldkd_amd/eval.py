@@ -215,6 +215,13 @@ def _items_as_they_are(items):
     return items
 
 
+def _collate_ragged_rows(items):
+    """[(feat (len, D), idx, id)] -> (rows (sum len, D) fp32, lens, ids): the loader batch a WORKER process hands over as ONE tensor (an
+    identity collate would pass every item's tensor through shared memory: hundreds of descriptors per batch in flight)."""
+    feats = [torch.as_tensor(it[0], dtype=torch.float32) for it in items]
+    return (torch.cat(feats, 0) if feats else torch.zeros(0, 0)), [int(f.shape[0]) for f in feats], [it[2] for it in items]
+
+
 def _resident_context_info(model, eval_dataset, opt, loader, owner, kind):
     """compute_context_info(keep_frame_feats=False) through a resident feature table; None when the path does not apply (the
     caller then encodes padded fp32 super-batches as before).  With the feature cache on, the table of the first pass stays (up to
@@ -309,16 +316,26 @@ def _resident_context_info(model, eval_dataset, opt, loader, owner, kind):
                     if final and pending:
                         raise native.NativeError("eval: resident ingest lost rows")
                 app = _PinnedAppender(dev, chunks)
-                raw = DataLoader(loader.dataset, batch_size=loader.batch_size, shuffle=False, num_workers=loader.num_workers,
-                                 collate_fn=_items_as_they_are)
+                workers = int(loader.num_workers)
+                raw = DataLoader(loader.dataset, batch_size=loader.batch_size, shuffle=False, num_workers=workers,
+                                 collate_fn=_collate_ragged_rows if workers else _items_as_they_are)
                 for items in raw:
-                    for feat, _idx, vid in items:
-                        feat = torch.as_tensor(feat)
-                        if feat.dim() != 2 or feat.shape[1] != res.table.K or feat.shape[0] > L:
+                    if workers:                             # the batch's rows as one tensor, concatenated by the worker
+                        rows, lens_b, ids_b = items
+                        if lens_b and (rows.dim() != 2 or rows.shape[1] != res.table.K or max(lens_b) > L):
                             raise native.NativeError("eval: a gallery item does not match the model's feature width / max_ctx_l")
-                        app.add(feat)
-                        pending.append(int(feat.shape[0]))
-                        metas.append(vid)
+                        if lens_b:
+                            app.add(rows)
+                        pending.extend(lens_b)
+                        metas.extend(ids_b)
+                    else:
+                        for feat, _idx, vid in items:
+                            feat = torch.as_tensor(feat)
+                            if feat.dim() != 2 or feat.shape[1] != res.table.K or feat.shape[0] > L:
+                                raise native.NativeError("eval: a gallery item does not match the model's feature width / max_ctx_l")
+                            app.add(feat)
+                            pending.append(int(feat.shape[0]))
+                            metas.append(vid)
                     drain()
                     if keep and other + res.table.nbytes() + app.rows * res.table.K * 4 > cap:
                         keep = False

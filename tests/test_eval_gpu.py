@@ -453,11 +453,14 @@ def test_ragged_first_pass_ingest_builds_the_same_table(monkeypatch):
                 [b.clone() for b in info["_packed"].blobs])
 
     ref = build(False)
-    for ring in (None, 5 * 3072 * 4):                       # the default 64-MiB ring / a ring of five clip rows
+    for ring in (None, 5 * 3072 * 4, "workers"):            # the default 64-MiB ring / a ring of five clip rows / loader workers
+        if ring == "workers":                               # (a worker hands its batch over as ONE concatenated tensor)
+            opt.num_workers, ring = 2, None
         got = build(True, ring)
         assert got[3] == ref[3] and got[4] == ref[4] and sum(got[3]) == got[0].shape[0]
         assert all(torch.equal(a, b) for a, b in zip(got[:3], ref[:3]))
         assert all(torch.equal(a, b) for a, b in zip(got[5], ref[5]))
+    opt.num_workers = 0
     # streaming (no cache): the table is a staging buffer encoded and emptied every 150 clips, at the same loader-batch boundaries in
     # both forms - the packed gallery comes out the same
     off = types.SimpleNamespace(**vars(opt), eval_feature_cache=False)

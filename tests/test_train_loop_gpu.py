@@ -635,6 +635,10 @@ def test_device_resident_train_set_yields_the_collated_batches():
         ds.items[i] = tuple(it)
     devset = DeviceTrainSet(ds, DEV)
     assert len(devset) == 37 and devset.n_caps == sum(len(it[1]) for it in ds.items)
+    by_workers = DeviceTrainSet(ds, DEV, num_workers=2)        # (the reading pass with loader workers: tables concatenated in the worker)
+    assert by_workers.caps_of == devset.caps_of and all(torch.equal(by_workers.src[k], devset.src[k]) for k in devset.TABLES)
+    assert all(np.array_equal(by_workers.lens_host[k], devset.lens_host[k]) for k in devset.TABLES)
+    del by_workers
     for epoch in range(2):
         torch.manual_seed(100 + epoch)
         ref = list(DataLoader(ds, batch_size=8, shuffle=True, num_workers=0, collate_fn=collate_train))

@@ -47,6 +47,8 @@ def run(n_videos=4096, prec="bf16", profile=False, dev="cuda:0", epochs=3, prefe
             walls.append(time.perf_counter() - t0)
         steps = len(loader)
         out["queries_per_batch"] = sorted({len(p.labels) for p in loader.plans()}) if hasattr(loader, "plans") else None
+        out["max_memory_allocated_gb"] = torch.cuda.max_memory_allocated() / 1e9
+        out["memory_reserved_gb"] = torch.cuda.memory_reserved() / 1e9
         out.update(steps_per_epoch=steps, epoch_wall_s=walls, ms_per_step_wall=[w / steps * 1e3 for w in walls],
                    captures=stepper.captures, replays=stepper.replays, eager_steps=stepper.eager_steps,
                    prefetched=stepper.prefetched, fallbacks=[list(f) for f in stepper.fallbacks])
