@@ -16,9 +16,12 @@ class SynthTrainSet(torch.utils.data.Dataset):
     1024, 1..6 captions per video - mean 2.3, as Charades-STA's 12,408 / 5,338 - of 4..12 words x 1024): every batch of 128 videos
     then has its own number of queries; "anet": ActivityNet shapes (16..128 clips x 1024, 1..10 captions per video, mean 3.7)."""
 
-    def __init__(self, n, seed=0, config="c3"):
+    def __init__(self, n, seed=0, config="c3", pool=None):
+        """pool: generate that many distinct items and let item i be item i % pool with its own id (a 17,435-video TVR-sized set
+        costs 21 GB and a minute of random numbers otherwise; the device tables still hold every item's rows)."""
         rs = np.random.RandomState(seed)
         self.items = []
+        self.n, n = n, (min(n, pool) if pool else n)
         dv, dq, l_lo, l_hi, w_lo, w_hi = {"c3": (3072, 768, 24, 128, 5, 30), "c5": (1024, 1024, 8, 64, 4, 12),
                                           "anet": (1024, 1024, 16, 128, 5, 30)}[config]
         for i in range(n):
@@ -37,10 +40,11 @@ class SynthTrainSet(torch.utils.data.Dataset):
             self.items.append((v, caps, tv, tcaps, i, [f"v{i}#{c}" for c in range(nc)], f"v{i}"))
 
     def __len__(self):
-        return len(self.items)
+        return self.n
 
     def __getitem__(self, i):
-        return self.items[i]
+        it = self.items[i % len(self.items)]
+        return it if i < len(self.items) else it[:4] + (i, [f"v{i}#{c}" for c in range(len(it[1]))], f"v{i}")
 
 
 def run(n_videos=1024, workers=4, prec="bf16", dev="cuda:0"):

@@ -1,6 +1,6 @@
 """Wall-clock of train.train() itself - the reference's driver loop (method/train.py:191-247): epochs of train_epoch, an eval_epoch on
 the validation sets after every epoch, the best checkpoint - on in-memory TVR-shaped data:
-  python3 tools/prof_train_run.py [n_train=2048] [n_val=1089] [precision=bf16] [epochs=6] [--profile]
+  python3 tools/prof_train_run.py [n_train=2048] [n_val=1089] [precision=bf16] [epochs=6] [pool] [--profile]
 Prints the run's wall per epoch (training part / evaluation part, from the log's timestamps taken around the two calls), the
 one-time costs in front (device tables, captures), and with --profile the cProfile top of the whole run."""
 import cProfile, io, json, os, pstats, sys, time, types
@@ -32,7 +32,7 @@ def val_sets(n, seed=1, dv=3072, dq=768):
     return _L(vids), _L(txts)
 
 
-def run(n_train=2048, n_val=1089, prec="bf16", epochs=6, profile=False, dev="cuda:0"):
+def run(n_train=2048, n_val=1089, prec="bf16", epochs=6, profile=False, dev="cuda:0", pool=None):
     from bench_train_loader import SynthTrainSet
     from dldkd_amd import train as T
     from dldkd_amd import eval as E
@@ -47,7 +47,7 @@ def run(n_train=2048, n_val=1089, prec="bf16", epochs=6, profile=False, dev="cud
                                 selfDistil_sigmoid_k=800, alpha_decay="sigmoid", belta_decay="sigmoid", grad_clip=-1,
                                 eval_context_bsz=200, eval_query_bsz=50, train_precision=prec,
                                 ckpt_filepath="/tmp/prof_train_run.ckpt")
-    ds = SynthTrainSet(n_train)
+    ds = SynthTrainSet(n_train, pool=pool)
     vv, vt = val_sets(n_val)
     marks = []
     orig_te, orig_ee = T.train_epoch, T.eval_epoch
@@ -83,7 +83,8 @@ def run(n_train=2048, n_val=1089, prec="bf16", epochs=6, profile=False, dev="cud
     tr = [t for k, t in marks if k == "train"]
     ev = [t for k, t in marks if k == "eval"]
     out = {"n_train": n_train, "n_val_videos": n_val, "n_val_captions": 5 * n_val, "precision": prec, "epochs": len(tr), "steps_per_epoch": steps,
-           "total_s": total, "train_epoch_s": tr, "eval_epoch_s": ev, "train_ms_per_step": [t / steps * 1e3 for t in tr],
+           "total_s": total, "train_epoch_s": tr if len(tr) <= 12 else tr[:6] + ["..."] + tr[-6:], "eval_epoch_s": ev if len(ev) <= 12 else ev[:6] + ["..."] + ev[-6:],
+           "train_s_sum": sum(tr), "eval_s_sum": sum(ev), "train_ms_per_step_median": sorted(t / steps * 1e3 for t in tr)[len(tr) // 2],
            "outside_train_and_eval_s": total - sum(tr) - sum(ev), "sumr": [h[2] for h in hist]}
     if pr:
         s = io.StringIO()
@@ -95,7 +96,7 @@ def run(n_train=2048, n_val=1089, prec="bf16", epochs=6, profile=False, dev="cud
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     r = run(int(args[0]) if args else 2048, int(args[1]) if len(args) > 1 else 1089, args[2] if len(args) > 2 else "bf16",
-            int(args[3]) if len(args) > 3 else 6, "--profile" in sys.argv)
+            int(args[3]) if len(args) > 3 else 6, "--profile" in sys.argv, pool=int(args[4]) if len(args) > 4 else None)
     prof = r.pop("cprofile", None)
     print(json.dumps(r))
     if prof:
