@@ -410,7 +410,7 @@ class GraphedTrainStep:
             e.ev_staged.record(st)
             e.staged_once = True
             self._pending = (sig, key, e, batch)
-        self._fetched = (sig, ev)
+        self._fetched = (sig, ev, e)
         return batch
 
     def _sig(self, batch):
@@ -437,7 +437,8 @@ class GraphedTrainStep:
             self.enable_double_buffer()
             look = (next_batch, cur)
         fetched = getattr(self, "_fetched", None)
-        if fetched is not None and fetched[0] == self._sig(batch):
+        mine = fetched is not None and fetched[0] == self._sig(batch)
+        if mine:
             # a batch iterate() fetched on the staging stream: if this step reads its tensors itself (no prefetch: eager, capture,
             # first replays) it has to wait for them, and their memory must outlive this stream's use of it
             self.stream.wait_event(fetched[1])
@@ -445,6 +446,11 @@ class GraphedTrainStep:
                 batch[k].record_stream(self.stream)
         with torch.cuda.stream(self.stream):
             out = self._step(batch, look)
+            if mine and len(fetched) > 2 and fetched[2] is not None:
+                # the batch's tensors ARE the input buffers of a capture (gathered straight into them): whatever form this step took
+                # - that capture's replay, or an eager step reading them as plain tensors - the staging stream may refill them
+                # only behind it
+                fetched[2].ev_done.record(self.stream)
         cur.wait_stream(self.stream)
         return out
 
