@@ -191,14 +191,16 @@ class GraphedTrainStep:
       * dropout calls bake only their offset inside the step (functional.PhiloxStepState), so replays draw fresh masks and
         a captured run reproduces the eager run with the same torch.manual_seed;
       * float(loss) - the reference's one sync per step - happens after the replay (or never: defer_loss_float).
-    The graph key holds everything that is baked in: tensor shapes and the per-epoch scalars (alpha, belta, KD weight,
-    hard-negative mode) - not the labels: they are staged per step like the other host values.  Real loaders pad every batch to
-    ITS longest caption / video (data.collate_train, as the reference does), so raw shapes change from batch to batch; the
-    stepper therefore pads the word axis up to a multiple of 8 and the clip axis up to a multiple of 32 (the masks already make
-    padding exact), which leaves a handful of signatures.  A new key runs eagerly the first time and is captured the second
-    time; at most `max_graphs` graphs are kept (least recently used is dropped), an evicted key is never captured again and
-    after `max_captures` captures every unseen key stays eager (variable caption counts - ActivityNet, Charades - would
-    otherwise re-capture a 350-kernel graph far more often than they replay one).
+    The graph key holds everything that is baked in: tensor shapes and the hard-negative mode - not the labels, and (round 6) not
+    the epoch schedule's alpha / belta / KD weight: they are staged per step like the other host values (functional.ScheduleWords).
+    Real loaders pad every batch to ITS longest caption / video (data.collate_train, as the reference does), so raw shapes change
+    from batch to batch; the stepper therefore pads the word axis up to a multiple of 8, the clip axis up to a multiple of 32 (the
+    masks already make padding exact) and - once a second distinct query count has been seen: Charades / ActivityNet, whose videos
+    carry different numbers of captions - the QUERY axis up to a multiple of 32 (padding queries of one zero word; the fused losses
+    stop at the real count), which leaves a handful of signatures.  A new key runs eagerly the first time and is captured the
+    second time; at most `max_graphs` graphs are kept (least recently used is dropped), an evicted key is never captured again
+    and after `max_captures` captures every unseen key stays eager.  Under train_epoch a key is captured twice, each capture with
+    its own input buffers, and the next batch is staged into the idle set while the step runs (iterate, double_buffer).
     Data parallel (world >= 2), default: the same graphs as on one GPU, with ONE all-reduce of the flat gradient buffer enqueued on
     the step's stream between the backward graphs and the optimizer graph (comm.RcclComm: a plain enqueue, no watchdog thread, so
     it may sit between replays; the optimizer graph then computes the clip's norms from the reduced gradients).  Every form of
