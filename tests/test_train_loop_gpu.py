@@ -12,7 +12,7 @@ DEV = "cuda:0"
 
 
 class TinySet(torch.utils.data.Dataset):
-    def __init__(self, n=24, dv=256, dq=128, seed=0):
+    def __init__(self, n=24, dv=256, dq=128, seed=0, caps=lambda i: 2):
         g = torch.Generator().manual_seed(seed)
         proj = torch.randn(dv, dq, generator=g) / dv ** 0.5
         tproj_v = torch.randn(dv, 512, generator=g) / dv ** 0.5
@@ -20,14 +20,14 @@ class TinySet(torch.utils.data.Dataset):
         for i in range(n):
             L = int(torch.randint(4, 13, (1,), generator=g))
             v = torch.nn.functional.normalize(torch.randn(L, dv, generator=g), dim=-1)
-            caps, tcaps = [], []
-            for c in range(2):
+            caps_, tcaps = [], []
+            for c in range(caps(i)):
                 l = int(torch.randint(0, L, (1,), generator=g))
                 w = v[l] @ proj
                 words = torch.nn.functional.normalize(w.unsqueeze(0) + 0.3 * torch.randn(5 + c, dq, generator=g), dim=-1)
-                caps.append(words)
+                caps_.append(words)
                 tcaps.append((v[l] @ tproj_v).unsqueeze(0) * 3.0)
-            self.items.append((v, caps, v @ tproj_v * 3.0, tcaps, i, [f"v{i}#{c}" for c in range(2)], f"v{i}"))
+            self.items.append((v, caps_, v @ tproj_v * 3.0, tcaps, i, [f"v{i}#{c}" for c in range(len(caps_))], f"v{i}"))
 
     def __len__(self):
         return len(self.items)
@@ -82,10 +82,10 @@ def test_train_loop_learns_and_checkpoints(tmp_path):
         assert eval_epoch(m2.to(DEV), L(ds.videos()), L(ds.texts()), opt) == pytest.approx(max(sumr))
 
 
-def _fit(precision, tmp_path, force_ddp=False, train_precision=None):
+def _fit(precision, tmp_path, force_ddp=False, train_precision=None, ds=None):
     from dldkd_amd.model import DLDKD
     from dldkd_amd import train as T, ops
-    ds = TinySet()
+    ds = ds if ds is not None else TinySet()
     cfg = types.SimpleNamespace(visual_input_size=256, query_input_size=128, inheritance_hidden=384, exploration_hidden=384,
                                 max_ctx_l=128, max_desc_l=30, input_drop=0.1, drop=0.1, n_heads=4, initializer_range=0.02,
                                 margin=0.1, use_hard_negative=False, hard_pool_size=5, label_style="soft")
@@ -150,6 +150,27 @@ def test_data_parallel_step_on_one_rank_rccl_group(tmp_path, rccl_comm):
         # not bitwise: split-K weight gradients and LayerNorm gamma/beta gradients accumulate with fp32 atomics, whose
         # order differs run to run; the difference stays at rounding level over the five epochs
         assert a[1]["loss_overall"] == pytest.approx(b[1]["loss_overall"], rel=2e-3)
+
+
+def test_data_parallel_run_with_variable_caption_counts_on_one_rank(tmp_path, rccl_comm):
+    """train() on a set whose videos carry 1..3 captions (every batch its own query count: the stepper pads the query axis and the
+    losses read the real count from the step's staged words) with the data-parallel branch forced on over a one-rank RCCL group:
+    the history of the plain run - the all-reduce between the backward graphs and the optimizer graph changes nothing else."""
+    from dldkd_amd import train as T
+    ds = TinySet(caps=lambda i: 1 + (i * 7) % 3)
+    old = T.DDP_MIN_WORLD
+    hist = []
+    for world in (2, 1):
+        T.DDP_MIN_WORLD = world
+        try:
+            hist.append(_fit("fp32", tmp_path, ds=ds))
+        finally:
+            T.DDP_MIN_WORLD = old
+    ref, got = hist
+    assert len(ref) == len(got) == 6
+    for a, b in zip(got[1:3], ref[1:3]):                  # (first epochs: before run-to-run rounding has been amplified)
+        assert a[1]["loss_overall"] == pytest.approx(b[1]["loss_overall"], rel=5e-3)
+    assert all(np.isfinite(h[1]["loss_overall"]) for h in got[1:]) and got[-1][1]["loss_overall"] < got[1][1]["loss_overall"]
 
 
 def test_train_takes_its_precision_from_opt_and_mixed_tracks_parity(tmp_path):
